@@ -1,0 +1,224 @@
+/*
+ * srl_hip.h — C ABI of libsrlhip.so: the MI355X (gfx950) kernels behind the rollout -> GAE -> PPO
+ * hot path of openpsi-project/srl.
+ *
+ * The reference has no FFI: its hot path is Python calling torch ops.  Each entry point below
+ * therefore replaces a *sequence of torch ops* inside one reference function; the reference
+ * file:line it stands in for is cited per function (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes binding and the three-line plugin registration a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named host_*;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is enqueued
+ *     asynchronously on it, nothing synchronises the device;
+ *   - tensors are dense, row-major; sample leaves are time-major [T, B, ...] exactly as the
+ *     reference's SampleBatch stores them (api/trainer.py:14-82, base/buffer.py:120-121);
+ *   - flags (done / truncated / on_reset / masks) are uint8 as on the wire
+ *     (distributed/system/actor_worker.py:278-281) — they are NOT widened to float32 like the
+ *     reference's prefetcher does (api/trainer.py:217);
+ *   - return value: 0 on success, a negative errno-style code on failure (never throws);
+ *     srl_last_error() returns a thread-local message for the last failure;
+ *   - no global state, no allocation: callers own every buffer (workspaces are explicit).
+ */
+#ifndef SRL_HIP_H_
+#define SRL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRL_HIP_ABI_VERSION 1
+
+int srl_abi_version(void);
+const char* srl_last_error(void);
+/* Number of compute units / device name of the current device (host query helpers). */
+int srl_device_info(int* num_cus, int* lds_bytes_per_cu, char* name, int name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * GAE / V-trace reverse scan, fused with value masking, the return, and the advantage statistics.
+ * Replaces: MultiAgentPPO._compute_adv_and_value_target (legacy/algorithm/ppo/mappo.py:118-144)
+ *           -> gae_trace (legacy/algorithm/modules/gae.py:8-97), and the three reductions of
+ *           masked_normalization (legacy/algorithm/modules/utils.py:38-57).
+ *
+ *   v'[t]   = value[t] * (1 - done[t])                                    (mappo.py:124)
+ *   delta_t = reward[t] + gamma * v'[t+1] * (1 - on_reset[t+1]) - v'[t]   (gae.py:63)
+ *   m_t     = gamma * lambda * (1 - on_reset[t+1]) * (1 - truncated[t+1]) (gae.py:87)
+ *   V-trace (imp_ratio != NULL): delta_t *= min(rho, ratio_t); m_t *= min(c, ratio_t)  (gae.py:64,88)
+ *   adv[t]  = delta_t + m_t * adv[t+1], adv[T] = 0   — float64 arithmetic, float32 result (gae.py:46,97)
+ *   ret[t]  = adv[t] + v'[t]                          — float32 (mappo.py:143)
+ *   stats  += { sum mask, sum adv*mask, sum (adv*mask)^2 } in float64, mask[t] = 1 - on_reset[t+1]
+ *             (the loss mask of mappo.py:260-261 for burn_in = 0, bootstrap = 1)
+ *
+ * reward [>=T, B, Nc] (rows 0..T-1 read), value [T+1, B, Nc], done/truncated/on_reset [T+1, B, 1],
+ * imp_ratio [T, B, 1] or NULL; adv, ret [>=T, B, Nc] (rows 0..T-1 written; the caller provides the
+ * zero row T that mappo.py:254-256 pads).  stats: float64[3] or NULL; it is zeroed by this call
+ * and then accumulated with float64 atomics (order-dependent in the last bit of the float64 sums).
+ */
+int srl_gae_scan(void* stream, const float* reward, const float* value, const uint8_t* done,
+                 const uint8_t* truncated, const uint8_t* on_reset, const float* imp_ratio, int T, int B,
+                 int Nc, double gamma, double lambda, double rho, double c, float* adv, float* ret,
+                 double* stats);
+
+/* Masked statistics {n, sum x*mask, sum (x*mask)^2} in float64 (utils.py:38-57).
+ * mask: uint8[n] or NULL (no mask: n = count); mask_invert != 0 means mask = 1 - byte
+ * (so on_reset[t+1] can be passed directly).  stats is zeroed then accumulated. */
+int srl_masked_stats(void* stream, const float* x, const uint8_t* mask, int mask_invert, long n,
+                     double* stats);
+
+/* out = float32( (x*mask - mean) / (sqrt(var) + eps) ) with mean = s/n, var = q/n - mean^2
+ * (optionally * n/(n-1)) computed in float64 from stats = {n, s, q} (utils.py:62-67).  stats are
+ * the *global* (all-reduced) sums when data-parallel (utils.py:58-61). */
+int srl_masked_normalize(void* stream, const float* x, const uint8_t* mask, int mask_invert, long n,
+                         const double* stats, double eps, int unbiased, float* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * PPO loss, forward + backward in one pass over the batch.
+ * Replaces: MultiAgentPPO._compute_loss (mappo.py:146-217) + value-loss factories
+ *           (modules/utils.py:228-265) + the autograd backward through them (mappo.py:274).
+ */
+typedef struct srl_ppo_hparams {
+  float eps_clip;             /* mappo.py:72  default 0.2 */
+  float c_clip;               /* mappo.py:75  default 3   */
+  float value_eps_clip;       /* mappo.py:90  default eps_clip */
+  float value_loss_weight;    /* mappo.py:91  default 0.5 */
+  float entropy_bonus_weight; /* mappo.py:93  default 0.01 */
+  float huber_delta;          /* value_loss_config delta / beta */
+  float norm_eps;             /* utils.py:17  default 1e-5 */
+  int32_t dual_clip;          /* mappo.py:74  default 1 */
+  int32_t clip_value;         /* mappo.py:73  default 0 */
+  int32_t value_loss;         /* 0 mse, 1 huber, 2 smoothl1 (utils.py:232-247) */
+  int32_t mask_invert;        /* 1: mask byte is on_reset[t+1] (mask = 1 - byte); 0: byte is the mask */
+} srl_ppo_hparams;
+
+enum { SRL_LT_POLICY = 0, SRL_LT_VALUE = 1, SRL_LT_ENTROPY = 2, SRL_LT_CLIP = 3, SRL_LT_RATIO = 4,
+       SRL_LT_ADV = 5, SRL_LT_RET = 6, SRL_LT_MASK = 7, SRL_LT_COUNT = 8 };
+
+/* new_lp, old_lp, value, old_value, adv (raw, un-normalised), ret, entropy: float32[n]; mask uint8[n].
+ * norm_stats: float64[3] global {n, s, q} for the advantage normalisation.
+ * local_n: float64[1], this rank's sum(mask) — every masked mean divides by it (mappo.py:184,197,199).
+ * Outputs: d_new_lp, d_value, d_entropy float32[n] = d loss / d input;
+ *          loss_terms float64[SRL_LT_COUNT] (zeroed, then accumulated): masked SUMS of policy loss,
+ *          value loss, entropy, 1[s2<s1], ratio, adv, ret, and mask; the caller forms
+ *          loss = (P + w_v*V - w_H*E) / M. */
+int srl_ppo_loss_fwd_bwd(void* stream, const float* new_lp, const float* old_lp, const float* value,
+                         const float* old_value, const float* adv, const float* ret, const float* entropy,
+                         const uint8_t* mask, long n, const srl_ppo_hparams* hp, const double* norm_stats,
+                         const double* local_n, float* d_new_lp, float* d_value, float* d_entropy,
+                         double* loss_terms);
+
+/* ------------------------------------------------------------------------------------------------
+ * Categorical heads.  Replaces torch.distributions.Categorical log_prob / entropy / sample in
+ * ActorCriticPolicy.__get_log_prob_and_entropy (actor_critic_policy.py:311-324) and rollout
+ * (:484-497), including the -1e10 masking of unavailable actions (:135-136).
+ * logits [n, sum(head_dims)] (row stride ld_logits); action int32 [n, n_heads]; avail uint8
+ * [n, sum(head_dims)] or NULL.
+ */
+#define SRL_MAX_HEADS 8
+int srl_categorical_fwd(void* stream, const float* logits, int ld_logits, const int32_t* action,
+                        const uint8_t* avail, long n, int n_heads, const int32_t* host_head_dims,
+                        float* logp, float* entropy);
+/* d_logits [n, sum(head_dims)] (row stride ld_dlogits) = d_logp * dlogp/dlogits + d_entropy * dH/dlogits */
+int srl_categorical_bwd(void* stream, const float* logits, int ld_logits, const int32_t* action,
+                        const uint8_t* avail, long n, int n_heads, const int32_t* host_head_dims,
+                        const float* d_logp, const float* d_entropy, float* d_logits, int ld_dlogits);
+/* Rollout: action = argmax if is_eval[row] else inverse-CDF sample with Philox4x32-10
+ * (key = seed, counter = {row, head, offset}); logp [n] = sum over heads of log p(action).
+ * action_out int64 [n, n_heads] (dtype of actor_critic_policy.py:515). */
+int srl_categorical_sample(void* stream, const float* logits, int ld_logits, const uint8_t* avail,
+                           const uint8_t* is_eval, long n, int n_heads, const int32_t* host_head_dims,
+                           uint64_t seed, uint64_t offset, int64_t* action_out, float* logp);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense contraction on the FP32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA chains).
+ * Replaces nn.Linear / Conv2d-as-GEMM forward and both backward products of
+ * ActorCriticSeparate (actor_critic_policy.py:114-143; modules/utils.py:154-161; modules/cnn.py:93-135).
+ *
+ *   C[M,N] = epilogue( sum_k A(i,k) * B(k,j) )
+ *   A(i,k) = a_kmajor ? A[k*lda + i] : A[i*lda + k]
+ *   B(k,j) = b_kmajor ? B[k*ldb + j] : B[j*ldb + k]
+ *
+ *   forward   Y = act(X W^T + b):  A = X [M,K] (a_kmajor 0), B = W [N,K] (b_kmajor 0)
+ *   dgrad     dX = dZ W:           A = dZ [M,N'] (a_kmajor 0), B = W [N',K'] (b_kmajor 1)
+ *   wgrad     dW = dZ^T X:         A = dZ [rows,N'] (a_kmajor 1), B = X [rows,K'] (b_kmajor 1)
+ */
+typedef struct srl_gemm_desc {
+  int64_t M, N, K;
+  const float* A; int64_t lda; int32_t a_kmajor;
+  const float* B; int64_t ldb; int32_t b_kmajor;
+  float* C; int64_t ldc;
+  const float* bias;        /* [N] added per output column, or NULL */
+  int32_t act;              /* 0 none, 1 relu, 2 tanh — applied after bias */
+  const float* dact_src;    /* [M, ld_dact] forward output Y; C *= act'(Y) (relu: Y>0, tanh: 1-Y^2), or NULL */
+  int64_t ld_dact; int32_t dact;  /* activation kind for dact_src (1 relu, 2 tanh) */
+  int32_t accumulate;       /* 1: C += result (after split reduction) */
+  int32_t split_k;          /* >1: K is cut into split_k slices reduced through `workspace` */
+  float* workspace;         /* >= split_k * M * N floats when split_k > 1 */
+} srl_gemm_desc;
+int srl_gemm(void* stream, const srl_gemm_desc* d);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (eps 1e-5, elementwise affine) over the last dimension D of [rows, D].
+ * Replaces nn.LayerNorm in make_models_for_obs / mlp (policies/utils.py:47-49; modules/utils.py:159-160).
+ * mean / rstd: float32[rows] saved for the backward.
+ */
+int srl_layernorm_fwd(void* stream, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                      int64_t rows, int D, float* y, int64_t ldy, float* mean, float* rstd);
+/* dx = LN'(dy) (optionally * act'(dact_src) for the activation that FED the LayerNorm);
+ * dgamma/dbeta += column sums (float32 atomics). dx may be NULL (input leaf). */
+int srl_layernorm_bwd(void* stream, const float* dy, int64_t lddy, const float* x, int64_t ldx,
+                      const float* gamma, const float* mean, const float* rstd, int64_t rows, int D,
+                      float* dx, int64_t lddx, int dact, float* dgamma, float* dbeta);
+
+/* Whole-observation LayerNorm statistics for image observations [n, D] (D = C*H*W), uint8 or
+ * float32 (policies/utils.py:53: nn.LayerNorm(v) over the full (C,H,W) shape). */
+int srl_obs_ln_stats(void* stream, const void* obs, int is_u8, int64_t n, int D, float* mean, float* rstd);
+
+/* im2col for the FIRST convolution: reads NCHW observations (uint8 or float32), applies the
+ * whole-observation LayerNorm (mean/rstd per sample, affine gamma/beta [C,H,W]) on the fly and writes
+ * the patch matrix P [n*OH*OW, C*KH*KW] with k = (c, kh, kw) (the reference's Conv2d weight order). */
+int srl_im2col_obs_ln(void* stream, const void* obs, int is_u8, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, int64_t n, int C, int H, int W, int KH, int KW,
+                      int stride, float* P);
+/* im2col for later convolutions on NHWC float32 activations: P [n*OH*OW, KH*KW*C], k = (kh, kw, c). */
+int srl_im2col_nhwc(void* stream, const float* x, int64_t n, int H, int W, int C, int KH, int KW, int stride,
+                    float* P);
+/* Gather form of col2im: dX[n,h,w,c] = sum of the dP entries that patch (h,w,c) went to;
+ * optionally * act'(y) with y = forward activation of the same shape as dX (dact 1 relu, 2 tanh). */
+int srl_col2im_nhwc(void* stream, const float* dP, int64_t n, int H, int W, int C, int KH, int KW, int stride,
+                    const float* y, int dact, float* dX);
+/* Backward of srl_im2col_obs_ln w.r.t. the LayerNorm affine parameters:
+ * dgamma[c,h,w] += sum_n dXn * xhat, dbeta[c,h,w] += sum_n dXn, dXn = col2im(dP) (never materialised). */
+int srl_obs_ln_affine_bwd(void* stream, const float* dP, const void* obs, int is_u8, const float* mean,
+                          const float* rstd, int64_t n, int C, int H, int W, int KH, int KW, int stride,
+                          float* dgamma, float* dbeta);
+
+/* out[j] (+)= sum_i x[i*ld + j]  (bias gradients). */
+int srl_colsum(void* stream, const float* x, int64_t ld, int64_t rows, int cols, float* out, int accumulate);
+/* Strided 2-D copy dst[i*ldd + j] = src[i*lds + j] (observation concat / layout glue). */
+int srl_copy2d(void* stream, const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int cols);
+/* dst = float32(src uint8), n elements (flags that feed float arithmetic on the host-facing API). */
+int srl_u8_to_f32(void* stream, const uint8_t* src, float* dst, int64_t n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser on one flat parameter buffer.
+ * Replaces clip_grad_norm_ / get_grad_norm + torch.optim.Adam/AdamW.step
+ * (mappo.py:278-284, modules/utils.py:268-295).
+ */
+/* sumsq[0] = sum g^2 in float64 (zeroed first).  With data parallelism the caller all-reduces the
+ * gradients before this call (DDP semantics), so no further reduction is needed. */
+int srl_grad_sumsq(void* stream, const float* g, int64_t n, double* sumsq);
+/* Adam step with the clip coefficient min(1, max_norm / (sqrt(sumsq) + 1e-6)) applied to g on the
+ * fly (max_norm < 0: no clipping; sumsq may then be NULL).  grad_scale multiplies g first
+ * (1/world_size for the DDP mean).  step is the 1-based step count; weight_decay is decoupled
+ * (AdamW) when adamw != 0, L2 (added to g) otherwise.  grad_norm_out float32[1] or NULL. */
+int srl_adam_step(void* stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int adamw, int64_t step, float grad_scale,
+                  float max_norm, const double* sumsq, float* grad_norm_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRL_HIP_H_ */

@@ -1,0 +1,210 @@
+"""Oracle: the actor-critic network, PPO analysis and rollout on PyTorch-CPU float32.
+
+Functional restatement (explicit parameter dict keyed by the reference's ``state_dict`` names, so the
+reference's checkpoints and the golden fixtures load directly) of:
+
+* ``ActorCriticSeparate``          ``legacy/algorithm/ppo/actor_critic_policies/actor_critic_policy.py:28-143``
+* ``make_models_for_obs``          ``legacy/algorithm/ppo/actor_critic_policies/utils.py:33-63``
+* ``mlp``                          ``legacy/algorithm/modules/utils.py:154-161``
+* ``RecurrentBackbone``            ``legacy/algorithm/modules/recurrent_backbone.py:7-66``
+* ``Convolution`` (Conv2d, pad 0)  ``legacy/algorithm/modules/cnn.py:39-135``
+* ``AutoResetRNN`` (GRU)           ``legacy/algorithm/modules/autoreset_rnn.py:42-66``
+* ``_ppo_analyze`` / ``rollout``   ``actor_critic_policy.py:338-390`` / ``:458-528``
+
+TEST INFRASTRUCTURE ONLY (see package doc).  Parameter *initialisation* is not restated here: the
+oracle always runs on weights handed to it (from a fixture, or from the product's own initialiser).
+"""
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _act(name):
+    return {"relu": torch.relu, "tanh": torch.tanh}[name]
+
+
+class OracleActorCritic:
+    """Holds ``params`` (OrderedDict name -> leaf tensor, reference state_dict order) and evaluates the net."""
+
+    def __init__(self,
+                 obs_dim: Union[int, Dict[str, Union[int, Tuple[int, ...]]]],
+                 action_dim: Union[int, Sequence[int]],
+                 hidden_dim: int = 128,
+                 state_dim=None,
+                 value_dim: int = 1,
+                 chunk_len: int = 10,
+                 num_dense_layers: int = 2,
+                 rnn_type: str = "gru",
+                 cnn_layers: Optional[Dict[str, List[Tuple]]] = None,
+                 num_rnn_layers: int = 0,
+                 popart: bool = False,
+                 activation: str = "relu",
+                 layernorm: bool = True,
+                 shared_backbone: bool = False,
+                 continuous_action: bool = False,
+                 **_ignored):
+        assert not popart, "oracle: PopArt head not restated yet (a 'next' row of SURVEY.md 8f)"
+        assert not continuous_action, "oracle: continuous actions not restated yet"
+        self.obs_dim = {"obs": obs_dim} if isinstance(obs_dim, int) else dict(obs_dim)
+        if state_dim is not None and isinstance(state_dim, int):
+            state_dim = {"state": state_dim}
+        self.state_dim = state_dim or self.obs_dim
+        self.act_dims = [action_dim] if isinstance(action_dim, int) else list(action_dim)
+        self.hidden, self.value_dim, self.chunk_len = hidden_dim, value_dim, chunk_len
+        self.dense_layers, self.layernorm, self.activation = num_dense_layers, layernorm, activation
+        self.shared = shared_backbone
+        self.cnn_layers = cnn_layers or {}
+        self.num_rnn_layers, self.rnn_type = num_rnn_layers, rnn_type
+        assert rnn_type == "gru" or num_rnn_layers == 0, "oracle restates the GRU variant only"
+        self.params: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+    # ------------------------------------------------------------------ parameters
+    def load_state_dict(self, sd):
+        self.params = OrderedDict((k, torch.as_tensor(np.asarray(v)).clone().float().requires_grad_(True))
+                                  for k, v in sd.items())
+
+    def state_dict(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self.params.items())
+
+    def parameters(self):
+        return list(self.params.values())
+
+    def _p(self, name):
+        return self.params[name]
+
+    # ------------------------------------------------------------------ building blocks
+    def _embed(self, prefix, dims, obs):
+        """LayerNorm(obs) -> Linear/Conv stack -> ... per key, concatenated (policies/utils.py:44-62)."""
+        act = _act(self.activation)
+        outs = []
+        for k, shape in dims.items():
+            x = obs[k]
+            base = f"{prefix}.{k}"
+            nshape = (shape,) if isinstance(shape, int) else tuple(shape)
+            x = F.layer_norm(x, nshape, self._p(f"{base}.0.weight"), self._p(f"{base}.0.bias"), 1e-5)
+            if isinstance(shape, int):
+                x = act(F.linear(x, self._p(f"{base}.1.0.weight"), self._p(f"{base}.1.0.bias")))
+                x = F.layer_norm(x, (self.hidden,), self._p(f"{base}.1.2.weight"), self._p(f"{base}.1.2.bias"), 1e-5)
+            else:
+                assert len(shape) == 3, "oracle restates Conv2d encoders only"
+                T, B = x.shape[:2]
+                x = x.flatten(0, 1)  # cnn.py:131
+                cb = f"{base}.1._Convolution__model"
+                layers = self.cnn_layers[k]
+                for i, (_, _, stride, padding, _) in enumerate(layers):
+                    x = act(F.conv2d(x, self._p(f"{cb}.{2 * i}.weight"), self._p(f"{cb}.{2 * i}.bias"),
+                                     stride=stride, padding=padding))
+                x = x.flatten(1)
+                j = 0
+                fb = f"{cb}.{2 * len(layers) + 1}"
+                while f"{fb}.{3 * j}.weight" in self.params:  # cnn.py:86-91: halve until <= 8*hidden
+                    x = torch.relu(F.linear(x, self._p(f"{fb}.{3 * j}.weight"), self._p(f"{fb}.{3 * j}.bias")))
+                    x = F.layer_norm(x, (x.shape[-1],), self._p(f"{fb}.{3 * j + 2}.weight"),
+                                     self._p(f"{fb}.{3 * j + 2}.bias"), 1e-5)
+                    j += 1
+                x = x.reshape(T, B, -1)
+            outs.append(x)
+        return torch.cat(outs, dim=-1)
+
+    def _gru_step(self, prefix, layer, x, h):
+        p = lambda n: self._p(f"{prefix}.rnn._AutoResetRNN__net.{n}_l{layer}")
+        gi = F.linear(x, p("weight_ih"), p("bias_ih"))
+        gh = F.linear(h, p("weight_hh"), p("bias_hh"))
+        ir, iz, inn = gi.chunk(3, -1)
+        hr, hz, hn = gh.chunk(3, -1)
+        r = torch.sigmoid(ir + hr)
+        z = torch.sigmoid(iz + hz)
+        n = torch.tanh(inn + r * hn)
+        return (1 - z) * n + z * h
+
+    def _backbone(self, prefix, x, hx, on_reset):
+        """dense layers (+GRU with per-step reset of the hidden state) (recurrent_backbone.py:61-66)."""
+        act = _act(self.activation)
+        stride = 3 if self.layernorm else 2
+        for j in range(self.dense_layers):
+            x = act(F.linear(x, self._p(f"{prefix}.fc.{stride * j}.weight"), self._p(f"{prefix}.fc.{stride * j}.bias")))
+            if self.layernorm:
+                x = F.layer_norm(x, (self.hidden,), self._p(f"{prefix}.fc.{stride * j + 2}.weight"),
+                                 self._p(f"{prefix}.fc.{stride * j + 2}.bias"), 1e-5)
+        if self.num_rnn_layers == 0:
+            return x, hx
+        # AutoResetRNN: h is zeroed at every step whose on_reset flag is set (autoreset_rnn.py:46-60);
+        # stepping one row at a time is arithmetically the same as the reference's segment batching.
+        h = [hx[l] for l in range(self.num_rnn_layers)]
+        ys = []
+        for t in range(x.shape[0]):
+            inp = x[t]
+            for l in range(self.num_rnn_layers):
+                hl = h[l] if on_reset is None else h[l] * (1 - on_reset[t])
+                h[l] = self._gru_step(prefix, l, inp, hl)
+                inp = h[l]
+            ys.append(inp)
+        y = torch.stack(ys, 0)
+        y = F.layer_norm(y, (self.hidden,), self._p(f"{prefix}.rnn_norm.weight"), self._p(f"{prefix}.rnn_norm.bias"), 1e-5)
+        return y, torch.stack(h, 0)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, obs: Dict[str, torch.Tensor], policy_state=(None, None), on_reset=None):
+        """obs leaves [T, B, ...] float32 -> (logits [T,B,sum(A)], value [T,B,value_dim], new policy_state)."""
+        feat = self._embed("obs_modules_dict", self.obs_dim, obs)
+        a_feat, a_hx = self._backbone("actor_backbone", feat, policy_state[0], on_reset)
+        if self.shared:
+            c_feat, new_state = a_feat, (a_hx,)
+        else:
+            sfeat = self._embed("state_modules_dict", self.state_dim, obs)
+            c_feat, c_hx = self._backbone("critic_backbone", sfeat, policy_state[1], on_reset)
+            new_state = (a_hx, c_hx)
+        logits = F.linear(a_feat, self._p("actor_head.weight"), self._p("actor_head.bias"))
+        if "available_action" in obs:
+            logits = logits.masked_fill(obs["available_action"] == 0, -1e10)  # actor_critic_policy.py:135-136
+        value = F.linear(c_feat, self._p("critic_head.weight"), self._p("critic_head.bias"))
+        return logits, value, new_state
+
+    def _heads(self, logits):
+        out, start = [], 0
+        for d in self.act_dims:
+            out.append(torch.distributions.Categorical(logits=logits[..., start:start + d]))
+            start += d
+        return out
+
+    def analyze(self, obs, action, on_reset, policy_state=None):
+        """PPO analysis (actor_critic_policy.py:338-390): new log-probs, state values, entropy, each [T,B,1].
+
+        Without an RNN the chunking of the reference ([T,B] -> [C, B*T/C] and back) is a pure reshape
+        of independent rows, so it is skipped; with a GRU the chunks start from the stored per-row
+        ``policy_state`` exactly as the reference does.
+        """
+        if self.num_rnn_layers == 0:
+            logits, value, _ = self.forward(obs)
+        else:
+            T = on_reset.shape[0]
+            C = self.chunk_len
+            n = T // C
+            chunk = lambda x: torch.cat(torch.split(x, C, dim=0), dim=1)  # modules/utils.py:164-182
+            unchunk = lambda x: torch.cat(torch.split(x, x.shape[1] // n, dim=1), dim=0)
+            cobs = {k: chunk(v) for k, v in obs.items()}
+            state = tuple(chunk(s)[0].transpose(0, 1) for s in policy_state)  # :361-363
+            logits, value, _ = self.forward(cobs, state, chunk(on_reset))
+            logits, value = unchunk(logits), unchunk(value)
+        dists = self._heads(logits)
+        lp = torch.stack([d.log_prob(action[..., i]) for i, d in enumerate(dists)], -1).sum(-1, keepdim=True)
+        ent = torch.stack([d.entropy() for d in dists], -1).sum(-1, keepdim=True)
+        return lp, value, ent, logits
+
+    @torch.no_grad()
+    def rollout_eval(self, obs, policy_state=(None, None)):
+        """Deterministic (argmax) rollout (actor_critic_policy.py:480-497 with is_evaluation=1).
+
+        obs leaves [N, ...]; returns actions [N, heads] int64, log_probs [N,1], value [N,value_dim], logits.
+        """
+        obs = {k: v.unsqueeze(0) for k, v in obs.items()}
+        logits, value, new_state = self.forward(obs, policy_state)
+        logits, value = logits.squeeze(0), value.squeeze(0)
+        dists = self._heads(logits)
+        actions = torch.stack([d.probs.argmax(-1) for d in dists], -1)
+        lp = torch.stack([d.log_prob(actions[..., i]) for i, d in enumerate(dists)], -1).sum(-1, keepdim=True)
+        return actions, lp, value, logits, new_state

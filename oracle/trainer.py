@@ -1,0 +1,100 @@
+"""Oracle: one full ``MultiAgentPPO.step`` on PyTorch-CPU (restating reference ``legacy/algorithm/ppo/mappo.py``).
+
+Follows ``mappo.py:68-116`` (hyper-parameters and defaults), ``:118-144`` (advantage / value target),
+``:146-217`` (loss), ``:219-328`` (step driver: analysis, GAE, zero-padded adv/ret written back,
+``loss_mask = 1 - on_reset[1+burn_in : 1+Tb-boot]``, backward, global-L2 clip or measure, optimiser step,
+stats averaged over ``ppo_epochs``, ``policy.version`` += 1).  The reference's GPU prefetcher is a
+pass-through here: every leaf is converted to float32 like ``api/trainer.py:217``.
+
+This is also the CPU baseline timed by ``bench.py`` (``cpu_baseline.kind == "port"``).
+TEST INFRASTRUCTURE ONLY (see package doc).  Samples are flat ``{dotted.key: numpy array}`` dicts.
+"""
+from typing import Dict
+
+import numpy as np
+import torch
+
+from oracle import gae as ogae
+from oracle import ppo as oppo
+from oracle.net import OracleActorCritic
+
+
+class OracleMappo:
+
+    def __init__(self, net: OracleActorCritic, **kw):
+        self.net = net
+        g = kw.get
+        self.discount_rate = g("discount_rate", 0.99)
+        self.gae_lambda = g("gae_lambda", 0.97)
+        self.eps_clip = g("eps_clip", 0.2)
+        self.clip_value = g("clip_value", False)
+        self.dual_clip = g("dual_clip", True)
+        self.c_clip = g("c_clip", 3)
+        self.burn_in_steps = g("burn_in_steps", 0)
+        self.vtrace = g("vtrace", False)
+        self.value_eps_clip = g("value_eps_clip", self.eps_clip)
+        self.value_loss_weight = g("value_loss_weight", 0.5)
+        self.entropy_bonus_weight = g("entropy_bonus_weight", 0.01)
+        self.max_grad_norm = g("max_grad_norm")
+        self.bootstrap_steps = g("bootstrap_steps", 1)
+        self.ppo_epochs = g("ppo_epochs", 1)
+        self.value_loss = g("value_loss", "mse")
+        self.value_loss_config = g("value_loss_config", {})
+        assert g("optimizer", "adam") == "adam" and not g("popart", False) and not self.vtrace
+        self.optimizer = torch.optim.Adam(net.parameters(), **g("optimizer_config", {}))
+        self.version = -1
+        self.frames = 0
+
+    def step(self, sample: Dict[str, np.ndarray]):
+        f32 = lambda k: torch.from_numpy(np.asarray(sample[k])).float()
+        on_reset, done, truncated = f32("on_reset"), f32("done"), f32("truncated")
+        reward, old_value, old_lp = f32("reward"), f32("analyzed_result.value"), f32("analyzed_result.log_probs")
+        action = torch.from_numpy(np.asarray(sample["action.x"])).float()
+        obs = {k[4:]: f32(k) for k in sample if k.startswith("obs.")}
+        pstate = None
+        if self.net.num_rnn_layers:
+            names = ["policy_state.hx"] if self.net.shared else ["policy_state.actor_hx", "policy_state.critic_hx"]
+            pstate = [f32(n) for n in names]
+        Tb = on_reset.shape[0]
+        boot, burn = self.bootstrap_steps, self.burn_in_steps
+        assert burn == 0, "oracle: burn-in not restated"
+        keep = Tb - boot  # analysed rows (mappo.py:243-246, tail_len = bootstrap_steps without vtrace)
+
+        totals = {}
+        out = {}
+        for _ in range(self.ppo_epochs):
+            lp, value, ent, _ = self.net.analyze({k: v[:keep] for k, v in obs.items()}, action[:keep], on_reset[:keep],
+                                                 None if pstate is None else [s[:keep] for s in pstate])
+            adv, ret = ogae.adv_and_value_target(reward.numpy(), old_value.numpy(), truncated.numpy(), done.numpy(),
+                                                 on_reset.numpy(), self.discount_rate, self.gae_lambda)
+            pad = lambda x: np.concatenate([x, np.zeros_like(x[:1])], 0)  # mappo.py:254-256
+            adv_p, ret_p = pad(adv), pad(ret)
+            out["adv"], out["ret"] = adv_p, ret_p
+            lo, hi = burn, Tb - boot
+            mask = 1 - on_reset[1 + lo:1 + hi]  # mappo.py:260-261
+            loss, stats = oppo.ppo_loss(lp[lo:hi], old_lp[lo:hi], value[lo:hi], old_value[lo:hi],
+                                        torch.from_numpy(adv_p[lo:hi]), torch.from_numpy(ret_p[lo:hi]), ent[lo:hi],
+                                        mask, eps_clip=self.eps_clip, dual_clip=self.dual_clip, c_clip=self.c_clip,
+                                        value_loss=self.value_loss, value_loss_config=self.value_loss_config,
+                                        clip_value=self.clip_value, value_eps_clip=self.value_eps_clip,
+                                        value_loss_weight=self.value_loss_weight,
+                                        entropy_bonus_weight=self.entropy_bonus_weight)
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            params = self.net.parameters()
+            if self.max_grad_norm is not None:
+                gn = torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+            else:
+                gn = torch.sqrt(sum(p.grad.norm()**2 for p in params if p.grad is not None))
+            self.optimizer.step()
+            stats["grad_norm"] = float(gn)
+            stats["loss"] = float(loss.detach())
+            stats["done"] = done[lo:hi].mean().item()
+            stats["truncated"] = truncated[lo:hi].mean().item()
+            for k, v in stats.items():
+                totals[k] = totals.get(k, 0.0) + v
+        stats = {k: v / self.ppo_epochs for k, v in totals.items()}
+        self.version += 1
+        self.frames += int(np.prod(on_reset[burn:Tb - boot].shape))
+        stats["frames"] = self.frames
+        return stats, out

@@ -1,0 +1,298 @@
+"""Architecture description + parameter table + initialisation of the actor-critic network.
+
+The network family is the reference's ``ActorCriticSeparate`` (``actor_critic_policy.py:28-143``):
+per observation key ``LayerNorm -> (Linear | Conv2d stack + Flatten + Linear) -> ReLU -> LayerNorm``
+(``policies/utils.py:33-63``, ``modules/cnn.py:39-135``), concatenation, ``dense_layers x (Linear -> act
+[-> LayerNorm])`` (``modules/recurrent_backbone.py:40``, ``modules/utils.py:154-161``), and linear actor /
+critic heads.  Parameter *names and reference shapes* are exactly the reference's ``state_dict`` keys,
+so checkpoints interchange; the device copy may use a different *internal layout* per parameter
+(``ParamInfo.layout``), converted at the checkpoint boundary only:
+
+* ``conv_nhwc``:   Conv2d weight ``[Cout, Cin, KH, KW]`` stored ``[Cout, KH, KW, Cin]`` (activations are NHWC
+  between convolutions so that GEMM outputs need no transposition);
+* ``fc_from_chw``: first Linear after Flatten, ``[out, C*H*W]`` stored ``[out, H*W*C]`` for the same reason.
+
+Initialisation replays the reference's construction order call for call (default ``nn.Linear`` /
+``nn.Conv2d`` reset, then the orthogonal re-initialisations) on CPU tensors, so the same ``seed`` gives
+bit-identical initial weights (checked against the reference in ``tests/golden/gen_golden.py``).
+"""
+import dataclasses
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+ACTS = {"relu": 1, "tanh": 2}
+
+
+@dataclasses.dataclass
+class ParamInfo:
+    name: str
+    ref_shape: Tuple[int, ...]
+    offset: int = 0  # in floats, into the flat buffer
+    layout: str = "plain"  # plain | conv_nhwc | fc_from_chw
+    chw: Optional[Tuple[int, int, int]] = None  # for fc_from_chw
+
+    @property
+    def numel(self):
+        return int(math.prod(self.ref_shape))
+
+    def to_internal(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.detach().to(torch.float32).reshape(self.ref_shape)
+        if self.layout == "conv_nhwc":
+            t = t.permute(0, 2, 3, 1)
+        elif self.layout == "fc_from_chw":
+            c, h, w = self.chw
+            t = t.reshape(self.ref_shape[0], c, h, w).permute(0, 2, 3, 1)
+        return t.contiguous().reshape(-1)
+
+    def to_reference(self, flat: torch.Tensor) -> torch.Tensor:
+        if self.layout == "conv_nhwc":
+            co, ci, kh, kw = self.ref_shape
+            return flat.reshape(co, kh, kw, ci).permute(0, 3, 1, 2).contiguous()
+        if self.layout == "fc_from_chw":
+            c, h, w = self.chw
+            return flat.reshape(self.ref_shape[0], h, w, c).permute(0, 3, 1, 2).reshape(self.ref_shape).contiguous()
+        return flat.reshape(self.ref_shape).clone()
+
+
+# ---------------------------------------------------------------------------------------------------
+# layer descriptors (pure data; the device executor lives in hipnet.py)
+@dataclasses.dataclass
+class LayerNormSpec:
+    prefix: str  # parameter prefix: <prefix>.weight / <prefix>.bias
+    dim: int
+
+
+@dataclasses.dataclass
+class LinearSpec:
+    prefix: str
+    in_features: int
+    out_features: int
+    act: int  # 0 none | 1 relu | 2 tanh
+
+
+@dataclasses.dataclass
+class ConvSpec:
+    prefix: str
+    cin: int
+    cout: int
+    k: int
+    stride: int
+    in_hw: Tuple[int, int]
+    out_hw: Tuple[int, int]
+    act: int
+    first: bool  # reads the (layer-normed) NCHW observation directly
+
+
+@dataclasses.dataclass
+class ObsLayerNormSpec:
+    """LayerNorm over a whole image observation (C,H,W), fused into the first convolution's gather."""
+    prefix: str
+    shape: Tuple[int, int, int]
+
+
+@dataclasses.dataclass
+class EncoderSpec:
+    key: str
+    shape: Union[int, Tuple[int, ...]]
+    layers: list  # LayerNormSpec | LinearSpec | ObsLayerNormSpec | ConvSpec
+    out_dim: int
+
+
+@dataclasses.dataclass
+class NetSpec:
+    obs_encoders: List[EncoderSpec]
+    actor_backbone: list
+    state_encoders: Optional[List[EncoderSpec]]  # None when the backbone is shared
+    critic_backbone: Optional[list]
+    actor_head: LinearSpec
+    critic_head: LinearSpec
+    act_dims: List[int]
+    hidden_dim: int
+    value_dim: int
+    shared_backbone: bool
+    params: "OrderedDict[str, ParamInfo]"
+    total_params: int
+
+
+def _conv_out(size, k, s, p=0):
+    return (size + 2 * p - (k - 1) - 1) // s + 1
+
+
+class _Builder:
+    """Walks the reference's constructor in order, recording parameters (and initialising them)."""
+
+    def __init__(self, seed: Optional[int]):
+        self.params: "OrderedDict[str, ParamInfo]" = OrderedDict()
+        self.values: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self.init = seed is not None
+        if self.init:
+            torch.manual_seed(seed)
+
+    def _add(self, name, shape, value=None, layout="plain", chw=None):
+        self.params[name] = ParamInfo(name, tuple(shape), layout=layout, chw=chw)
+        if self.init:
+            self.values[name] = value
+
+    # default resets of nn.Linear / nn.Conv2d (torch/nn/modules/linear.py, conv.py)
+    def _default_wb(self, wshape):
+        if not self.init:
+            return None, None
+        w = torch.empty(wshape)
+        torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        fan_in = int(math.prod(wshape[1:]))
+        bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+        b = torch.empty(wshape[0])
+        torch.nn.init.uniform_(b, -bound, bound)
+        return w, b
+
+    def layernorm(self, prefix, shape):
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        self._add(f"{prefix}.weight", shape, torch.ones(shape) if self.init else None)
+        self._add(f"{prefix}.bias", shape, torch.zeros(shape) if self.init else None)
+
+    def linear(self, prefix, fin, fout, layout="plain", chw=None):
+        w, b = self._default_wb((fout, fin))
+        self._add(f"{prefix}.weight", (fout, fin), w, layout, chw)
+        self._add(f"{prefix}.bias", (fout,), b)
+
+    def conv(self, prefix, cin, cout, k, layout):
+        w, b = self._default_wb((cout, cin, k, k))
+        self._add(f"{prefix}.weight", (cout, cin, k, k), w, layout)
+        self._add(f"{prefix}.bias", (cout,), b)
+
+    def orthogonal(self, name, gain):
+        if self.init:
+            torch.nn.init.orthogonal_(self.values[name], gain=gain)
+
+    def zero(self, name):
+        if self.init:
+            self.values[name].zero_()
+
+
+def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, act_name: str, cnn_layers: Dict):
+    encs = []
+    for key, shape in dims.items():
+        base = f"{root}.{key}"
+        if isinstance(shape, int):
+            b.layernorm(f"{base}.0", shape)
+            b.linear(f"{base}.1.0", shape, hidden)
+            b.layernorm(f"{base}.1.2", hidden)
+            layers = [LayerNormSpec(f"{base}.0", shape), LinearSpec(f"{base}.1.0", shape, hidden, act),
+                      LayerNormSpec(f"{base}.1.2", hidden)]
+            encs.append(EncoderSpec(key, shape, layers, hidden))
+            continue
+        shape = tuple(shape)
+        if len(shape) != 3:
+            raise NotImplementedError(f"observation `{key}` of shape {shape}: only vectors and (C,H,W) images "
+                                      "are implemented on the HIP path (Conv1d/Conv3d encoders are not)")
+        b.layernorm(f"{base}.0", shape)
+        layers = [ObsLayerNormSpec(f"{base}.0", shape)]
+        cb = f"{base}.1._Convolution__model"
+        c, h, w = shape
+        cfg = cnn_layers.get(key)
+        if cfg is None:  # modules/cnn.py:96-98 default stack
+            cfg = [(c, 5, 1, 0, "zeros"), (c * 2, 3, 1, 0, "zeros"), (c, 3, 1, 0, "zeros")]
+        gain = torch.nn.init.calculate_gain(act_name)
+        for i, (cout, k, stride, padding, padding_mode) in enumerate(cfg):
+            if padding != 0:
+                raise NotImplementedError("convolutions with padding are not implemented on the HIP path")
+            oh, ow = _conv_out(h, k, stride), _conv_out(w, k, stride)
+            if oh <= 0 or ow <= 0:
+                raise ValueError(f"CNN Dimension error, got {(oh, ow)} after convolution")
+            name = f"{cb}.{2 * i}"
+            b.conv(name, c, cout, k, "plain" if i == 0 else "conv_nhwc")
+            b.orthogonal(f"{name}.weight", gain)  # modules/cnn.py:73-84 (use_orthogonal=True)
+            b.zero(f"{name}.bias")
+            layers.append(ConvSpec(name, c, cout, k, stride, (h, w), (oh, ow), act, first=(i == 0)))
+            c, h, w = cout, oh, ow
+        sizes = [c * h * w]
+        while sizes[-1] > hidden * 8:  # modules/cnn.py:86-91
+            sizes.append(sizes[-1] // 2)
+        sizes.append(hidden)
+        fb = f"{cb}.{2 * len(cfg) + 1}"
+        for j in range(len(sizes) - 1):
+            first_fc = j == 0
+            b.linear(f"{fb}.{3 * j}", sizes[j], sizes[j + 1], "fc_from_chw" if first_fc else "plain",
+                     (c, h, w) if first_fc else None)
+            b.layernorm(f"{fb}.{3 * j + 2}", sizes[j + 1])
+            layers.append(LinearSpec(f"{fb}.{3 * j}", sizes[j], sizes[j + 1], 1))  # utils.mlp default ReLU
+            layers.append(LayerNormSpec(f"{fb}.{3 * j + 2}", sizes[j + 1]))
+        encs.append(EncoderSpec(key, shape, layers, hidden))
+    return encs
+
+
+def _build_backbone(b: _Builder, root: str, in_dim: int, hidden: int, dense_layers: int, act: int, layernorm: bool):
+    layers = []
+    stride = 3 if layernorm else 2
+    names = []
+    d = in_dim
+    for j in range(dense_layers):
+        p = f"{root}.fc.{stride * j}"
+        b.linear(p, d, hidden)
+        names += [f"{p}.weight", f"{p}.bias"]
+        layers.append(LinearSpec(p, d, hidden, act))
+        if layernorm:
+            q = f"{root}.fc.{stride * j + 2}"
+            b.layernorm(q, hidden)
+            names += [f"{q}.weight", f"{q}.bias"]
+            layers.append(LayerNormSpec(q, hidden))
+        d = hidden
+    for n in names:  # recurrent_backbone.py:41-47: orthogonal on >=2-D weights, zero on every bias
+        if n.endswith("weight") and len(b.params[n].ref_shape) >= 2:
+            b.orthogonal(n, math.sqrt(2))
+        if n.endswith("bias"):
+            b.zero(n)
+    return layers
+
+
+def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim=1, num_dense_layers=2,
+                  cnn_layers=None, use_maxpool=None, num_rnn_layers=0, popart=False, activation="relu", layernorm=True,
+                  shared_backbone=False, continuous_action=False, auxiliary_head=False, seed: Optional[int] = None,
+                  **_unused):
+    """Returns ``(NetSpec, values)``; ``values`` is the name -> CPU tensor dict of initial weights (reference
+    layout) when ``seed`` is given, else ``None``."""
+    if num_rnn_layers:
+        raise NotImplementedError("recurrent backbones are a 'next' row (SURVEY.md 8f-2), not on the HIP path yet")
+    if popart:
+        raise NotImplementedError("PopArt value head is a 'next' row (SURVEY.md 8f-2), not on the HIP path yet")
+    if continuous_action or auxiliary_head:
+        raise NotImplementedError("continuous actions / auxiliary value head are not on the HIP path")
+    if use_maxpool and any(use_maxpool.values()):
+        raise NotImplementedError("max-pooling convolution encoders are not on the HIP path")
+    if activation not in ACTS:
+        raise NotImplementedError(f"Activation function {activation} not implemented.")
+    act = ACTS[activation]
+    obs_dims = {"obs": obs_dim} if isinstance(obs_dim, int) else dict(obs_dim)
+    if state_dim is not None and isinstance(state_dim, int):
+        state_dim = {"state": state_dim}
+    act_dims = [action_dim] if isinstance(action_dim, int) else list(action_dim)
+    cnn_layers = cnn_layers or {}
+
+    b = _Builder(seed)
+    obs_enc = _build_encoders(b, "obs_modules_dict", obs_dims, hidden_dim, act, activation, cnn_layers)
+    actor_bb = _build_backbone(b, "actor_backbone", hidden_dim * len(obs_dims), hidden_dim, num_dense_layers, act,
+                               layernorm)
+    state_enc = critic_bb = None
+    if not shared_backbone:
+        sdims = state_dim or obs_dims
+        state_enc = _build_encoders(b, "state_modules_dict", sdims, hidden_dim, act, activation, cnn_layers)
+        critic_bb = _build_backbone(b, "critic_backbone", hidden_dim * len(sdims), hidden_dim, num_dense_layers, act,
+                                    layernorm)
+    b.linear("actor_head", hidden_dim, sum(act_dims))
+    b.orthogonal("actor_head.weight", 0.01)  # actor_critic_policy.py:109-112
+    b.zero("actor_head.bias")
+    b.linear("critic_head", hidden_dim, value_dim)
+    b.orthogonal("critic_head.weight", 0.01)
+    b.zero("critic_head.bias")
+
+    off = 0
+    for info in b.params.values():
+        info.offset = off
+        off += (info.numel + 3) // 4 * 4  # 16-byte aligned starts (float4 staging in the GEMM)
+    spec = NetSpec(obs_enc, actor_bb, state_enc, critic_bb, LinearSpec("actor_head", hidden_dim, sum(act_dims), 0),
+                   LinearSpec("critic_head", hidden_dim, value_dim, 0), act_dims, hidden_dim, value_dim, shared_backbone,
+                   b.params, off)
+    return spec, (b.values if b.init else None)

@@ -1,0 +1,400 @@
+// Bandwidth-bound pieces of the actor/critic network: LayerNorm fwd/bwd, whole-observation LayerNorm
+// statistics, patch gathers (im2col) with the observation LayerNorm fused into the uint8 load path,
+// the gather form of col2im, column sums, strided copies.
+#include "srl_common.h"
+
+namespace {
+
+constexpr float kLnEps = 1e-5f;  // nn.LayerNorm default, used everywhere in the reference
+
+// ---- LayerNorm over the last dim: one wavefront per row ------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, long ldx, const float* gamma,
+                                                            const float* beta, long rows, int D, float* y, long ldy,
+                                                            float* mean_out, float* rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float s = 0.f;
+  for (int j = lane; j < D; j += 64) s += xr[j];
+  const float mean = wave_allsum(s) / (float)D;
+  float q = 0.f;
+  for (int j = lane; j < D; j += 64) {
+    const float d = xr[j] - mean;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_allsum(q) / (float)D + kLnEps);
+  float* yr = y + row * ldy;
+  for (int j = lane; j < D; j += 64) yr[j] = (xr[j] - mean) * rstd * gamma[j] + beta[j];
+  if (lane == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += sum dy*xhat; dbeta += sum dy.
+// Each workgroup walks `rows_per_block` rows with 4 wavefronts, keeps per-lane partial dgamma/dbeta in
+// registers (D <= 64*LN_MAXV) and flushes them once with float atomics.
+constexpr int LN_MAXV = 16;  // supports D <= 1024 in the register path
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, long lddy, const float* x, long ldx,
+                                                            const float* gamma, const float* mean, const float* rstd,
+                                                            long rows, int D, float* dx, long lddx, int dact,
+                                                            float* dgamma, float* dbeta, long rows_per_block) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float pg[LN_MAXV], pb[LN_MAXV];
+#pragma unroll
+  for (int v = 0; v < LN_MAXV; ++v) pg[v] = pb[v] = 0.f;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (long row = r0 + wid; row < r1; row += 4) {
+    const float* xr = x + row * ldx;
+    const float* dyr = dy + row * lddy;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < LN_MAXV; ++v) {
+      const int j = lane + v * 64;
+      if (j < D) {
+        const float xh = (xr[j] - mu) * rs, d = dyr[j];
+        const float g = d * gamma[j];
+        s1 += g;
+        s2 += g * xh;
+        pg[v] += d * xh;
+        pb[v] += d;
+      }
+    }
+    if (dx) {
+      const float m1 = wave_allsum(s1) / (float)D, m2 = wave_allsum(s2) / (float)D;
+      float* dxr = dx + row * lddx;
+#pragma unroll
+      for (int v = 0; v < LN_MAXV; ++v) {
+        const int j = lane + v * 64;
+        if (j < D) {
+          const float xv = xr[j];
+          const float xh = (xv - mu) * rs;
+          float o = rs * (dyr[j] * gamma[j] - m1 - xh * m2);
+          if (dact) o *= act_grad_from_output(xv, dact);  // x is the activation output that fed this LayerNorm
+          dxr[j] = o;
+        }
+      }
+    }
+  }
+  // combine the 4 wavefronts through LDS, then one atomic per column per workgroup
+  __shared__ float sg[4][64 * LN_MAXV / 4 + 1];  // processed in 4 passes of LN_MAXV/4 values to bound LDS
+  for (int pass = 0; pass < 4; ++pass) {
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < LN_MAXV / 4; ++v) sg[wid][v * 64 + lane] = which ? pb[pass * (LN_MAXV / 4) + v] : pg[pass * (LN_MAXV / 4) + v];
+      __syncthreads();
+      if (wid == 0) {
+#pragma unroll
+        for (int v = 0; v < LN_MAXV / 4; ++v) {
+          const int j = lane + (pass * (LN_MAXV / 4) + v) * 64;
+          if (j < D) {
+            const float t = sg[0][v * 64 + lane] + sg[1][v * 64 + lane] + sg[2][v * 64 + lane] + sg[3][v * 64 + lane];
+            atomicAdd((which ? dbeta : dgamma) + j, t);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- whole-observation LayerNorm statistics: one workgroup per sample ------------------------------------
+template <bool U8>
+__global__ __launch_bounds__(256) void obs_ln_stats_kernel(const void* obs, long n, int D, float* mean, float* rstd) {
+  __shared__ double red[8];
+  const long s = blockIdx.x;
+  double acc[2] = {0.0, 0.0};
+  if (U8) {
+    // exact integer sums: D*255 and D*255^2 stay far below 2^63
+    const uint8_t* p = static_cast<const uint8_t*>(obs) + s * D;
+    unsigned long long a = 0, b = 0;
+    for (int j = threadIdx.x; j < D; j += 256) {
+      const unsigned v = p[j];
+      a += v;
+      b += v * v;
+    }
+    acc[0] = (double)a;
+    acc[1] = (double)b;
+  } else {
+    const float* p = static_cast<const float*>(obs) + s * D;
+    for (int j = threadIdx.x; j < D; j += 256) {
+      const double v = p[j];
+      acc[0] += v;
+      acc[1] += v * v;
+    }
+  }
+  block_sum<2, 256>(acc, red);
+  if (threadIdx.x == 0) {
+    const double mu = acc[0] / D;
+    double var = acc[1] / D - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    mean[s] = (float)mu;
+    rstd[s] = (float)(1.0 / sqrt(var + (double)kLnEps));
+  }
+}
+
+// ---- im2col of the first convolution with the observation LayerNorm fused in ---------------------------------
+// P[(s*OH + oh)*OW + ow][(c*KH + kh)*KW + kw] = LN(obs)[s, c, oh*S + kh, ow*S + kw]
+template <bool U8>
+__global__ __launch_bounds__(256) void im2col_obs_ln_kernel(const void* obs, const float* mean, const float* rstd,
+                                                            const float* gamma, const float* beta, long n, int C, int H,
+                                                            int W, int KH, int KW, int S, int OH, int OW, float* P) {
+  const int Kp = C * KH * KW;
+  const long total = n * OH * OW * (long)Kp;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int k = (int)(e % Kp);
+    const long m = e / Kp;
+    const int ow = (int)(m % OW), oh = (int)((m / OW) % OH);
+    const long s = m / ((long)OW * OH);
+    const int kw = k % KW, kh = (k / KW) % KH, c = k / (KW * KH);
+    const int pos = (c * H + oh * S + kh) * W + ow * S + kw;
+    const long src = s * (long)C * H * W + pos;
+    const float x = U8 ? (float)static_cast<const uint8_t*>(obs)[src] : static_cast<const float*>(obs)[src];
+    P[e] = (x - mean[s]) * rstd[s] * gamma[pos] + beta[pos];
+  }
+}
+
+// P[(s*OH+oh)*OW+ow][(kh*KW + kw)*C + c] = x[s, oh*S+kh, ow*S+kw, c]   (NHWC, float4 along c)
+__global__ __launch_bounds__(256) void im2col_nhwc_kernel(const float* x, long n, int H, int W, int C, int KH, int KW,
+                                                          int S, int OH, int OW, float* P) {
+  const int C4 = C / 4;
+  const int Kq = KH * KW * C4;
+  const long total = n * OH * OW * (long)Kq;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int kq = (int)(e % Kq);
+    const long m = e / Kq;
+    const int ow = (int)(m % OW), oh = (int)((m / OW) % OH);
+    const long s = m / ((long)OW * OH);
+    const int c4 = kq % C4, kw = (kq / C4) % KW, kh = kq / (C4 * KW);
+    const float4 v = *reinterpret_cast<const float4*>(x + ((s * H + oh * S + kh) * W + ow * S + kw) * C + c4 * 4);
+    *reinterpret_cast<float4*>(P + e * 4) = v;
+  }
+}
+
+// dX[s,h,w,c] = sum_{kh,kw : (h-kh)%S==0, (w-kw)%S==0, in range} dP[(s,oh,ow)][(kh,kw,c)]  (* act'(y))
+__global__ __launch_bounds__(256) void col2im_nhwc_kernel(const float* dP, long n, int H, int W, int C, int KH, int KW,
+                                                          int S, int OH, int OW, const float* y, int dact, float* dX) {
+  const int C4 = C / 4;
+  const long total = n * H * W * (long)C4;
+  const long Kp = (long)KH * KW * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c4 = (int)(e % C4);
+    const long pix = e / C4;
+    const int w = (int)(pix % W), h = (int)((pix / W) % H);
+    const long s = pix / ((long)W * H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = h % S; kh < KH && kh <= h; kh += S) {
+      const int oh = (h - kh) / S;
+      if (oh >= OH) continue;
+      for (int kw = w % S; kw < KW && kw <= w; kw += S) {
+        const int ow = (w - kw) / S;
+        if (ow >= OW) continue;
+        const float4 v = *reinterpret_cast<const float4*>(dP + ((s * OH + oh) * OW + ow) * Kp + (kh * KW + kw) * C + c4 * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    if (y && dact) {
+      const float4 yv = *reinterpret_cast<const float4*>(y + e * 4);
+      acc.x *= act_grad_from_output(yv.x, dact);
+      acc.y *= act_grad_from_output(yv.y, dact);
+      acc.z *= act_grad_from_output(yv.z, dact);
+      acc.w *= act_grad_from_output(yv.w, dact);
+    }
+    *reinterpret_cast<float4*>(dX + e * 4) = acc;
+  }
+}
+
+// LayerNorm-affine gradients of the observation LayerNorm in front of the first convolution.
+// thread <-> observation position (c,h,w); grid.y splits the samples; float atomics at the end.
+template <bool U8>
+__global__ __launch_bounds__(256) void obs_ln_affine_bwd_kernel(const float* dP, const void* obs, const float* mean,
+                                                                const float* rstd, long n, int C, int H, int W, int KH,
+                                                                int KW, int S, int OH, int OW, float* dgamma,
+                                                                float* dbeta) {
+  const int D = C * H * W;
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= D) return;
+  const int w = pos % W, h = (pos / W) % H, c = pos / (W * H);
+  const long Kp = (long)C * KH * KW;
+  const long per = srl_ceil_div(n, gridDim.y);
+  const long s0 = (long)blockIdx.y * per, s1 = s0 + per < n ? s0 + per : n;
+  float ag = 0.f, ab = 0.f;
+  for (long s = s0; s < s1; ++s) {
+    float d = 0.f;
+    for (int kh = h % S; kh < KH && kh <= h; kh += S) {
+      const int oh = (h - kh) / S;
+      if (oh >= OH) continue;
+      for (int kw = w % S; kw < KW && kw <= w; kw += S) {
+        const int ow = (w - kw) / S;
+        if (ow >= OW) continue;
+        d += dP[((s * OH + oh) * OW + ow) * Kp + (c * KH + kh) * KW + kw];
+      }
+    }
+    const long src = s * (long)D + pos;
+    const float x = U8 ? (float)static_cast<const uint8_t*>(obs)[src] : static_cast<const float*>(obs)[src];
+    ag += d * ((x - mean[s]) * rstd[s]);
+    ab += d;
+  }
+  atomicAdd(dgamma + pos, ag);
+  atomicAdd(dbeta + pos, ab);
+}
+
+// out[j] (+)= sum_i x[i*ld + j]; 64 columns x 4 row-lanes per workgroup, grid.y splits rows.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, long ld, long rows, int cols, float* out) {
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const long per = srl_ceil_div(rows, gridDim.y);
+  const long r0 = (long)blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+  float s = 0.f;
+  if (col < cols)
+    for (long r = r0 + ry; r < r1; r += 4) s += x[r * ld + col];
+  part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < cols) atomicAdd(out + col, part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* src, long lds_, float* dst, long ldd, long rows,
+                                                     int cols) {
+  const long total = rows * cols;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256)
+    dst[(e / cols) * ldd + e % cols] = src[(e / cols) * lds_ + e % cols];
+}
+
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* src, float* dst, long n) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) dst[e] = (float)src[e];
+}
+
+unsigned stream_grid(long work_items) {
+  const long b = srl_ceil_div(work_items, 256);
+  return (unsigned)(b < 1 ? 1 : (b < 16384 ? b : 16384));
+}
+
+}  // namespace
+
+extern "C" int srl_layernorm_fwd(void* stream, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                 int64_t rows, int D, float* y, int64_t ldy, float* mean, float* rstd) {
+  SRL_CHECK_ARG(x && gamma && beta && y && mean && rstd && D >= 1 && rows >= 0, "null tensor");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)srl_ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                     x, ldx, gamma, beta, rows, D, y, ldy, mean, rstd);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_layernorm_bwd(void* stream, const float* dy, int64_t lddy, const float* x, int64_t ldx,
+                                 const float* gamma, const float* mean, const float* rstd, int64_t rows, int D,
+                                 float* dx, int64_t lddx, int dact, float* dgamma, float* dbeta) {
+  SRL_CHECK_ARG(dy && x && gamma && mean && rstd && dgamma && dbeta, "null tensor");
+  SRL_CHECK_ARG(D >= 1 && D <= 64 * LN_MAXV, "LayerNorm width must be in [1, 1024]");
+  if (rows == 0) return 0;
+  // ~4 workgroups per CU; each flushes D*2 atomics, so keep the row share large
+  long rpb = srl_ceil_div(rows, 1024);
+  if (rpb < 16) rpb = 16;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)srl_ceil_div(rows, rpb)), dim3(256), 0, (hipStream_t)stream,
+                     dy, lddy, x, ldx, gamma, mean, rstd, rows, D, dx, lddx, dact, dgamma, dbeta, rpb);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_obs_ln_stats(void* stream, const void* obs, int is_u8, int64_t n, int D, float* mean, float* rstd) {
+  SRL_CHECK_ARG(obs && mean && rstd && D >= 1, "null tensor");
+  if (n == 0) return 0;
+  if (is_u8) hipLaunchKernelGGL(obs_ln_stats_kernel<true>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, obs, n, D, mean, rstd);
+  else hipLaunchKernelGGL(obs_ln_stats_kernel<false>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, obs, n, D, mean, rstd);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+static int conv_out(int in, int k, int s) { return (in - k) / s + 1; }
+
+extern "C" int srl_im2col_obs_ln(void* stream, const void* obs, int is_u8, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, int64_t n, int C, int H, int W, int KH, int KW,
+                                 int stride, float* P) {
+  SRL_CHECK_ARG(obs && mean && rstd && gamma && beta && P, "null tensor");
+  SRL_CHECK_ARG(KH <= H && KW <= W && stride >= 1, "bad conv geometry");
+  if (n == 0) return 0;
+  const int OH = conv_out(H, KH, stride), OW = conv_out(W, KW, stride);
+  const long total = n * OH * OW * (long)C * KH * KW;
+  if (is_u8) hipLaunchKernelGGL(im2col_obs_ln_kernel<true>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, obs, mean, rstd, gamma, beta, n, C, H, W, KH, KW, stride, OH, OW, P);
+  else hipLaunchKernelGGL(im2col_obs_ln_kernel<false>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, obs, mean, rstd, gamma, beta, n, C, H, W, KH, KW, stride, OH, OW, P);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_im2col_nhwc(void* stream, const float* x, int64_t n, int H, int W, int C, int KH, int KW, int stride,
+                               float* P) {
+  SRL_CHECK_ARG(x && P, "null tensor");
+  SRL_CHECK_ARG(C % 4 == 0 && KH <= H && KW <= W && stride >= 1, "needs C % 4 == 0 and a valid geometry");
+  if (n == 0) return 0;
+  const int OH = conv_out(H, KH, stride), OW = conv_out(W, KW, stride);
+  const long total = n * OH * OW * (long)KH * KW * (C / 4);
+  hipLaunchKernelGGL(im2col_nhwc_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, n, H, W, C, KH,
+                     KW, stride, OH, OW, P);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_col2im_nhwc(void* stream, const float* dP, int64_t n, int H, int W, int C, int KH, int KW,
+                               int stride, const float* y, int dact, float* dX) {
+  SRL_CHECK_ARG(dP && dX, "null tensor");
+  SRL_CHECK_ARG(C % 4 == 0 && KH <= H && KW <= W && stride >= 1, "needs C % 4 == 0 and a valid geometry");
+  if (n == 0) return 0;
+  const int OH = conv_out(H, KH, stride), OW = conv_out(W, KW, stride);
+  const long total = n * H * W * (long)(C / 4);
+  hipLaunchKernelGGL(col2im_nhwc_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, dP, n, H, W, C, KH,
+                     KW, stride, OH, OW, y, dact, dX);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_obs_ln_affine_bwd(void* stream, const float* dP, const void* obs, int is_u8, const float* mean,
+                                     const float* rstd, int64_t n, int C, int H, int W, int KH, int KW, int stride,
+                                     float* dgamma, float* dbeta) {
+  SRL_CHECK_ARG(dP && obs && mean && rstd && dgamma && dbeta, "null tensor");
+  if (n == 0) return 0;
+  const int OH = conv_out(H, KH, stride), OW = conv_out(W, KW, stride);
+  const int D = C * H * W;
+  const unsigned gx = (unsigned)srl_ceil_div(D, 256);
+  long gy = srl_ceil_div(2048, gx);  // ~2048 workgroups in flight
+  if (gy > n) gy = n;
+  if (gy < 1) gy = 1;
+  if (is_u8) hipLaunchKernelGGL(obs_ln_affine_bwd_kernel<true>, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, dP, obs, mean, rstd, n, C, H, W, KH, KW, stride, OH, OW, dgamma, dbeta);
+  else hipLaunchKernelGGL(obs_ln_affine_bwd_kernel<false>, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, dP, obs, mean, rstd, n, C, H, W, KH, KW, stride, OH, OW, dgamma, dbeta);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_colsum(void* stream, const float* x, int64_t ld, int64_t rows, int cols, float* out, int accumulate) {
+  SRL_CHECK_ARG(x && out && cols >= 1, "null tensor");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) SRL_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
+  if (rows == 0) return 0;
+  const unsigned gx = (unsigned)srl_ceil_div(cols, 64);
+  long gy = srl_ceil_div(rows, 256);  // >= 256 rows per workgroup
+  if (gy > 2048) gy = 2048;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, st, x, ld, rows, cols, out);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_copy2d(void* stream, const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int cols) {
+  SRL_CHECK_ARG(src && dst && cols >= 1, "null tensor");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(stream_grid(rows * cols)), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd,
+                     rows, cols);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_u8_to_f32(void* stream, const uint8_t* src, float* dst, int64_t n) {
+  SRL_CHECK_ARG(src && dst, "null tensor");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,284 @@
+"""ctypes binding of ``libsrlhip.so`` (the C ABI declared in ``include/srl_hip.h``).
+
+PyTorch-ROCm is used for plumbing only: it owns device memory (``torch.empty(..., device="cuda")``) and
+the HIP stream; every kernel is launched through the C ABI with raw device pointers on torch's
+*current* stream.  There is no fallback: if the library is missing or a call fails, a ``HipError`` is
+raised (the product path never computes on the CPU).
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_long, c_uint64,
+                    c_void_p)
+from typing import Optional, Sequence
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsrlhip.so")
+_lib = None
+
+ABI_VERSION = 1
+
+# loss-term slots (srl_hip.h: SRL_LT_*)
+LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_COUNT = range(9)
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+VALUE_LOSS_KINDS = {"mse": 0, "huber": 1, "smoothl1": 2}
+MAX_HEADS = 8
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class PpoHparams(Structure):
+    _fields_ = [("eps_clip", c_float), ("c_clip", c_float), ("value_eps_clip", c_float),
+                ("value_loss_weight", c_float), ("entropy_bonus_weight", c_float), ("huber_delta", c_float),
+                ("norm_eps", c_float), ("dual_clip", c_int32), ("clip_value", c_int32), ("value_loss", c_int32),
+                ("mask_invert", c_int32)]
+
+
+class GemmDesc(Structure):
+    _fields_ = [("M", c_int64), ("N", c_int64), ("K", c_int64), ("A", c_void_p), ("lda", c_int64),
+                ("a_kmajor", c_int32), ("B", c_void_p), ("ldb", c_int64), ("b_kmajor", c_int32), ("C", c_void_p),
+                ("ldc", c_int64), ("bias", c_void_p), ("act", c_int32), ("dact_src", c_void_p), ("ld_dact", c_int64),
+                ("dact", c_int32), ("accumulate", c_int32), ("split_k", c_int32), ("workspace", c_void_p)]
+
+
+_SIGNATURES = {
+    "srl_abi_version": (c_int, []),
+    "srl_last_error": (c_char_p, []),
+    "srl_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "srl_gae_scan": (c_int, [c_void_p] + [c_void_p] * 6 + [c_int, c_int, c_int, c_double, c_double, c_double,
+                                                             c_double, c_void_p, c_void_p, c_void_p]),
+    "srl_masked_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
+    "srl_masked_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_double, c_int,
+                                      c_void_p]),
+    "srl_ppo_loss_fwd_bwd": (c_int, [c_void_p] + [c_void_p] * 8 + [c_long, POINTER(PpoHparams)] + [c_void_p] * 6),
+    "srl_categorical_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, POINTER(c_int32),
+                                     c_void_p, c_void_p]),
+    "srl_categorical_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, POINTER(c_int32),
+                                     c_void_p, c_void_p, c_void_p, c_int]),
+    "srl_categorical_sample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int,
+                                        POINTER(c_int32), c_uint64, c_uint64, c_void_p, c_void_p]),
+    "srl_gemm": (c_int, [c_void_p, POINTER(GemmDesc)]),
+    "srl_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
+                                   c_void_p, c_void_p]),
+    "srl_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                   c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "srl_obs_ln_stats": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p]),
+    "srl_im2col_obs_ln": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64] +
+                          [c_int] * 6 + [c_void_p]),
+    "srl_im2col_nhwc": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 6 + [c_void_p]),
+    "srl_col2im_nhwc": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 6 + [c_void_p, c_int, c_void_p]),
+    "srl_obs_ln_affine_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64] + [c_int] * 6 +
+                              [c_void_p, c_void_p]),
+    "srl_colsum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int]),
+    "srl_copy2d": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int]),
+    "srl_u8_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
+    "srl_grad_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "srl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
+                               c_float, c_float, c_int, c_int64, c_float, c_float, c_void_p, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes library; raises ``HipError`` if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise HipError(f"{_LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); "
+                           "there is no CPU fallback for the hot path")
+        handle = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header / library mismatch
+            fn.restype, fn.argtypes = res, args
+        if handle.srl_abi_version() != ABI_VERSION:
+            raise HipError(f"ABI mismatch: library {handle.srl_abi_version()} vs binding {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise HipError(f"{what} failed ({rc}): {lib().srl_last_error().decode(errors='replace')}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise HipError("no MI355X / ROCm device visible: the hot path has no CPU fallback")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=None, name="tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError(f"{name}: expected a device tensor, got {t.device}")
+    if dtype is not None and t.dtype != dtype:
+        raise HipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise HipError(f"{name}: expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def _i32_array(vals: Sequence[int]):
+    return (c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+# ------------------------------------------------------------------------------------------------
+def device_info():
+    n, l = c_int(0), c_int(0)
+    buf = ctypes.create_string_buffer(128)
+    _check(lib().srl_device_info(ctypes.byref(n), ctypes.byref(l), buf, 128), "srl_device_info")
+    return dict(num_cus=n.value, lds_bytes_per_cu=l.value, arch=buf.value.decode())
+
+
+def gae_scan(reward, value, done, truncated, on_reset, gamma, lmbda, adv, ret, stats=None, imp_ratio=None, rho=1.0,
+             c=1.0):
+    """reward [>=T,B,Nc] f32, value/done/truncated/on_reset [T+1,B,*]; writes adv/ret rows [0,T); stats f64[3]."""
+    Tp1, B = on_reset.shape[0], on_reset.shape[1]
+    T = Tp1 - 1
+    Nc = value.shape[2] if value.dim() > 2 else 1
+    assert value.shape[0] == Tp1 and reward.shape[0] >= T and adv.shape[0] >= T and ret.shape[0] >= T
+    _check(
+        lib().srl_gae_scan(_stream(), _ptr(reward, torch.float32, "reward"), _ptr(value, torch.float32, "value"),
+                           _ptr(done, torch.uint8, "done"), _ptr(truncated, torch.uint8, "truncated"),
+                           _ptr(on_reset, torch.uint8, "on_reset"), _ptr(imp_ratio, torch.float32, "imp_ratio"), T, B,
+                           Nc, float(gamma), float(lmbda), float(rho), float(c), _ptr(adv, torch.float32, "adv"),
+                           _ptr(ret, torch.float32, "ret"), _ptr(stats, torch.float64, "stats")), "srl_gae_scan")
+
+
+def masked_stats(x, mask, stats, mask_invert=False):
+    _check(
+        lib().srl_masked_stats(_stream(), _ptr(x, torch.float32, "x"), _ptr(mask, torch.uint8, "mask"),
+                               int(mask_invert), x.numel(), _ptr(stats, torch.float64, "stats")), "srl_masked_stats")
+
+
+def masked_normalize(x, mask, stats, out, mask_invert=False, eps=1e-5, unbiased=False):
+    _check(
+        lib().srl_masked_normalize(_stream(), _ptr(x, torch.float32, "x"), _ptr(mask, torch.uint8, "mask"),
+                                   int(mask_invert), x.numel(), _ptr(stats, torch.float64, "stats"), float(eps),
+                                   int(unbiased), _ptr(out, torch.float32, "out")), "srl_masked_normalize")
+
+
+def ppo_loss_fwd_bwd(new_lp, old_lp, value, old_value, adv, ret, entropy, mask, hp: PpoHparams, norm_stats, local_n,
+                     d_new_lp, d_value, d_entropy, loss_terms):
+    f = torch.float32
+    _check(
+        lib().srl_ppo_loss_fwd_bwd(_stream(), _ptr(new_lp, f, "new_lp"), _ptr(old_lp, f, "old_lp"),
+                                   _ptr(value, f, "value"), _ptr(old_value, f, "old_value"), _ptr(adv, f, "adv"),
+                                   _ptr(ret, f, "ret"), _ptr(entropy, f, "entropy"), _ptr(mask, torch.uint8, "mask"),
+                                   new_lp.numel(), ctypes.byref(hp), _ptr(norm_stats, torch.float64, "norm_stats"),
+                                   _ptr(local_n, torch.float64, "local_n"), _ptr(d_new_lp, f, "d_new_lp"),
+                                   _ptr(d_value, f, "d_value"), _ptr(d_entropy, f, "d_entropy"),
+                                   _ptr(loss_terms, torch.float64, "loss_terms")), "srl_ppo_loss_fwd_bwd")
+
+
+def categorical_fwd(logits, action, avail, head_dims, logp, entropy):
+    n = logits.shape[0]
+    _check(
+        lib().srl_categorical_fwd(_stream(), _ptr(logits, torch.float32, "logits"), logits.shape[1],
+                                  _ptr(action, torch.int32, "action"), _ptr(avail, torch.uint8, "avail"), n,
+                                  len(head_dims), _i32_array(head_dims), _ptr(logp, torch.float32, "logp"),
+                                  _ptr(entropy, torch.float32, "entropy")), "srl_categorical_fwd")
+
+
+def categorical_bwd(logits, action, avail, head_dims, d_logp, d_entropy, d_logits):
+    n = logits.shape[0]
+    _check(
+        lib().srl_categorical_bwd(_stream(), _ptr(logits, torch.float32, "logits"), logits.shape[1],
+                                  _ptr(action, torch.int32, "action"), _ptr(avail, torch.uint8, "avail"), n,
+                                  len(head_dims), _i32_array(head_dims), _ptr(d_logp, torch.float32, "d_logp"),
+                                  _ptr(d_entropy, torch.float32, "d_entropy"),
+                                  _ptr(d_logits, torch.float32, "d_logits"), d_logits.shape[1]), "srl_categorical_bwd")
+
+
+def categorical_sample(logits, avail, is_eval, head_dims, seed, offset, action_out, logp):
+    n = logits.shape[0]
+    _check(
+        lib().srl_categorical_sample(_stream(), _ptr(logits, torch.float32, "logits"), logits.shape[1],
+                                     _ptr(avail, torch.uint8, "avail"), _ptr(is_eval, torch.uint8, "is_eval"), n,
+                                     len(head_dims), _i32_array(head_dims), int(seed), int(offset),
+                                     _ptr(action_out, torch.int64, "action_out"), _ptr(logp, torch.float32, "logp")),
+        "srl_categorical_sample")
+
+
+def gemm(M, N, K, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, bias=None, act=ACT_NONE, dact_src=None, ld_dact=0,
+         dact=ACT_NONE, accumulate=False, split_k=1, workspace=None):
+    """Raw-pointer GEMM (``A``/``B``/``C``/... are ints from ``data_ptr()`` possibly with byte offsets)."""
+    d = GemmDesc(M, N, K, A, lda, int(a_kmajor), B, ldb, int(b_kmajor), C, ldc, bias, int(act), dact_src, ld_dact,
+                 int(dact), int(accumulate), int(split_k), workspace)
+    _check(lib().srl_gemm(_stream(), ctypes.byref(d)), "srl_gemm")
+
+
+def layernorm_fwd(x_ptr, ldx, gamma_ptr, beta_ptr, rows, D, y_ptr, ldy, mean_ptr, rstd_ptr):
+    _check(lib().srl_layernorm_fwd(_stream(), x_ptr, ldx, gamma_ptr, beta_ptr, rows, D, y_ptr, ldy, mean_ptr, rstd_ptr),
+           "srl_layernorm_fwd")
+
+
+def layernorm_bwd(dy_ptr, lddy, x_ptr, ldx, gamma_ptr, mean_ptr, rstd_ptr, rows, D, dx_ptr, lddx, dact, dgamma_ptr,
+                  dbeta_ptr):
+    _check(
+        lib().srl_layernorm_bwd(_stream(), dy_ptr, lddy, x_ptr, ldx, gamma_ptr, mean_ptr, rstd_ptr, rows, D, dx_ptr,
+                                lddx, int(dact), dgamma_ptr, dbeta_ptr), "srl_layernorm_bwd")
+
+
+def obs_ln_stats(obs_ptr, is_u8, n, D, mean_ptr, rstd_ptr):
+    _check(lib().srl_obs_ln_stats(_stream(), obs_ptr, int(is_u8), n, D, mean_ptr, rstd_ptr), "srl_obs_ln_stats")
+
+
+def im2col_obs_ln(obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, n, C, H, W, KH, KW, stride, P_ptr):
+    _check(
+        lib().srl_im2col_obs_ln(_stream(), obs_ptr, int(is_u8), mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, n, C, H, W, KH,
+                                KW, stride, P_ptr), "srl_im2col_obs_ln")
+
+
+def im2col_nhwc(x_ptr, n, H, W, C, KH, KW, stride, P_ptr):
+    _check(lib().srl_im2col_nhwc(_stream(), x_ptr, n, H, W, C, KH, KW, stride, P_ptr), "srl_im2col_nhwc")
+
+
+def col2im_nhwc(dP_ptr, n, H, W, C, KH, KW, stride, y_ptr, dact, dX_ptr):
+    _check(lib().srl_col2im_nhwc(_stream(), dP_ptr, n, H, W, C, KH, KW, stride, y_ptr, int(dact), dX_ptr),
+           "srl_col2im_nhwc")
+
+
+def obs_ln_affine_bwd(dP_ptr, obs_ptr, is_u8, mean_ptr, rstd_ptr, n, C, H, W, KH, KW, stride, dgamma_ptr, dbeta_ptr):
+    _check(
+        lib().srl_obs_ln_affine_bwd(_stream(), dP_ptr, obs_ptr, int(is_u8), mean_ptr, rstd_ptr, n, C, H, W, KH, KW,
+                                    stride, dgamma_ptr, dbeta_ptr), "srl_obs_ln_affine_bwd")
+
+
+def colsum(x_ptr, ld, rows, cols, out_ptr, accumulate=True):
+    _check(lib().srl_colsum(_stream(), x_ptr, ld, rows, cols, out_ptr, int(accumulate)), "srl_colsum")
+
+
+def copy2d(src_ptr, lds, dst_ptr, ldd, rows, cols):
+    _check(lib().srl_copy2d(_stream(), src_ptr, lds, dst_ptr, ldd, rows, cols), "srl_copy2d")
+
+
+def u8_to_f32(src, dst):
+    _check(lib().srl_u8_to_f32(_stream(), _ptr(src, torch.uint8, "src"), _ptr(dst, torch.float32, "dst"), src.numel()),
+           "srl_u8_to_f32")
+
+
+def grad_sumsq(g, sumsq):
+    _check(lib().srl_grad_sumsq(_stream(), _ptr(g, torch.float32, "g"), g.numel(), _ptr(sumsq, torch.float64, "sumsq")),
+           "srl_grad_sumsq")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, adamw, step, grad_scale=1.0, max_norm=-1.0, sumsq=None,
+              grad_norm_out=None):
+    f = torch.float32
+    _check(
+        lib().srl_adam_step(_stream(), _ptr(p, f, "p"), _ptr(g, f, "g"), _ptr(m, f, "m"), _ptr(v, f, "v"), p.numel(),
+                            float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(adamw),
+                            int(step), float(grad_scale), float(max_norm), _ptr(sumsq, torch.float64, "sumsq"),
+                            _ptr(grad_norm_out, f, "grad_norm_out")), "srl_adam_step")

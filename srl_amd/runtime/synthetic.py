@@ -1,0 +1,102 @@
+"""Synthetic ``[Tb, B]`` samples with the reference's data invariants.
+
+There is no ALE / SC2 on the GPU box, so benchmarks and parity tests run on synthetic rollouts
+that satisfy exactly the invariants the reference's ``gae_trace`` asserts in debug mode
+(``legacy/algorithm/modules/gae.py:69-77``):
+
+* ``truncated * done == 0``
+* ``on_reset[0] == 0`` and ``on_reset[t+1] == done[t] | truncated[t]``
+* ``reward[t] == 0`` where ``on_reset[t+1]`` (the final, reset-triggering step carries no reward)
+* ``value == 0`` where ``done``
+
+All leaves carry the wire dtypes the actor worker produces (flags ``uint8``, reward / value /
+log-prob ``float32``, action ``int32``, ``policy_version_steps`` ``int64``) and a trailing singleton
+dimension, time-major ``[Tb, B, ...]``.
+"""
+from typing import Dict, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+ObsSpec = Dict[str, Tuple[Tuple[int, ...], str]]  # name -> (shape, "f32" | "u8")
+
+
+def make_flags(rng: np.random.Generator, Tb: int, B: int, p_done: float, p_trunc: Optional[float] = None):
+    """done / truncated / on_reset ``[Tb, B, 1]`` uint8 obeying the invariants above."""
+    p_trunc = p_done / 4 if p_trunc is None else p_trunc
+    done = (rng.random((Tb, B, 1)) < p_done)
+    truncated = (rng.random((Tb, B, 1)) < p_trunc) & ~done
+    on_reset = np.zeros((Tb, B, 1), dtype=bool)
+    on_reset[1:] = done[:-1] | truncated[:-1]
+    # an observation cannot be both the first of an episode and terminal in these synthetic rollouts
+    # (keeps every episode at least two steps long, as real environments do)
+    done &= ~on_reset
+    truncated &= ~on_reset
+    on_reset[1:] = done[:-1] | truncated[:-1]
+    return done.astype(np.uint8), truncated.astype(np.uint8), on_reset.astype(np.uint8)
+
+
+def make_sample_arrays(seed: int,
+                       T: int,
+                       B: int,
+                       obs_spec: ObsSpec,
+                       action_dims: Union[int, Sequence[int]],
+                       p_done: float = 0.05,
+                       bootstrap_steps: int = 1,
+                       value_dim: int = 1,
+                       available_action: bool = False) -> Dict[str, np.ndarray]:
+    """Flat ``{dotted.key: array}`` dict of one synthetic sample; wrap with ``to_sample_batch``."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    Tb = T + bootstrap_steps
+    done, truncated, on_reset = make_flags(rng, Tb, B, p_done)
+    value = (rng.standard_normal((Tb, B, value_dim)) * (1 - done)).astype(np.float32)
+    reward = rng.standard_normal((Tb, B, value_dim)).astype(np.float32)
+    reward[:-1] *= (1 - on_reset[1:])
+    dims = [action_dims] if isinstance(action_dims, (int, np.integer)) else list(action_dims)
+    action = np.stack([rng.integers(0, d, size=(Tb, B)) for d in dims], axis=-1).astype(np.int32)
+    log_probs = (sum(np.log(1.0 / d) for d in dims) + 0.01 * rng.standard_normal((Tb, B, 1))).astype(np.float32)
+    out = {}
+    for name, (shape, kind) in obs_spec.items():
+        if kind == "u8":
+            out[f"obs.{name}"] = rng.integers(0, 256, size=(Tb, B, *shape), dtype=np.uint8)
+        else:
+            out[f"obs.{name}"] = rng.standard_normal((Tb, B, *shape)).astype(np.float32)
+    if available_action:
+        assert len(dims) == 1
+        avail = (rng.random((Tb, B, dims[0])) < 0.7)
+        avail[np.arange(Tb)[:, None], np.arange(B)[None, :], action[..., 0]] = True  # taken action is legal
+        out["obs.available_action"] = avail.astype(np.uint8)
+    out.update({
+        "on_reset": on_reset,
+        "done": done,
+        "truncated": truncated,
+        "action.x": action,
+        "reward": reward,
+        "analyzed_result.log_probs": log_probs,
+        "analyzed_result.value": value,
+        "policy_version_steps": np.zeros((Tb, B, 1), dtype=np.int64),
+        "info_mask": np.zeros((Tb, B, 1), dtype=np.uint8),
+    })
+    return out
+
+
+def to_sample_batch(arrays: Dict[str, np.ndarray]):
+    """Wrap the flat dict into this package's ``SampleBatch`` (field classes as the runtime uses)."""
+    from srl_amd.api.env_utils import DiscreteAction
+    from srl_amd.api.trainer import SampleBatch
+    from srl_amd.algorithm.ppo_types import PPORolloutAnalyzedResult
+    from srl_amd.namedarray import NamedArray
+    obs = NamedArray(**{k[4:]: v for k, v in arrays.items() if k.startswith("obs.")})
+    return SampleBatch(obs=obs,
+                       on_reset=arrays["on_reset"],
+                       done=arrays["done"],
+                       truncated=arrays["truncated"],
+                       action=DiscreteAction(arrays["action.x"]),
+                       reward=arrays["reward"],
+                       analyzed_result=PPORolloutAnalyzedResult(log_probs=arrays["analyzed_result.log_probs"],
+                                                                value=arrays["analyzed_result.value"]),
+                       policy_version_steps=arrays["policy_version_steps"],
+                       info_mask=arrays["info_mask"])
+
+
+CARTPOLE_OBS: ObsSpec = {"obs": ((4,), "f32")}
+ATARI_OBS: ObsSpec = {"obs": ((4, 84, 84), "u8")}

@@ -1,0 +1,401 @@
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference (read-only at
+/root/reference) in this build container.  The reference cannot travel to the GPU box, so the
+vectors are committed as small .npz files together with this script.
+
+Run (from the repo root):
+    CUDA_VISIBLE_DEVICES="" PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference:. python3 tests/golden/gen_golden.py
+
+Harness-side shims only: numpy>=2 alias, MagicMock for absent import-time deps, and a CPU
+pass-through in place of the CUDA prefetcher (api/trainer.py:199-228 needs a GPU to construct).
+While generating, the script also asserts that this repo's oracle/ and initialiser agree with the
+reference on the same inputs; fixtures are only written if they do.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+np.bool8 = np.bool_
+from unittest import mock
+
+for m in ["gym", "gym.spaces", "redis", "redis.backoff", "redis.retry", "wandb", "zmq", "blosc"]:
+    sys.modules[m] = mock.MagicMock()
+sys.modules.setdefault("mock", mock)
+import torch
+
+torch.set_num_threads(1)  # deterministic CPU reductions
+import api.config
+import api.policy
+import api.trainer
+from api.env_utils import DiscreteAction
+from base.namedarray import NamedArray, recursive_apply
+import base.namedarray as ref_namedarray
+
+
+class CPUPrefetcher:
+
+    def push(self, sample):
+        return sample, recursive_apply(sample, lambda x: torch.from_numpy(x).float())
+
+
+api.trainer.PyTorchGPUPrefetcher = CPUPrefetcher
+import legacy.algorithm.ppo.mappo as mappo
+
+mappo.PyTorchGPUPrefetcher = CPUPrefetcher
+import legacy.algorithm.modules as modules
+from legacy.algorithm.ppo.actor_critic_policies.actor_critic_policy import PPORolloutAnalyzedResult
+from legacy.algorithm.ppo.mappo import SampleAnalyzedResult
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import gae as ogae
+from oracle import ppo as oppo
+from oracle.net import OracleActorCritic
+from oracle.trainer import OracleMappo
+from srl_amd.algorithm.netspec import build_netspec
+from srl_amd.runtime import synthetic
+
+TORCH_VERSION = torch.__version__
+
+
+def save(name, **arrays):
+    arrays["torch_version"] = np.array(TORCH_VERSION)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+def state_sha(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v.detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def ref_sample(arrays):
+    """flat dict -> the reference's SampleBatch."""
+    obs = NamedArray(**{k[4:]: v for k, v in arrays.items() if k.startswith("obs.")})
+    return api.trainer.SampleBatch(obs=obs, on_reset=arrays["on_reset"], done=arrays["done"],
+                                   truncated=arrays["truncated"], action=DiscreteAction(arrays["action.x"]),
+                                   reward=arrays["reward"],
+                                   analyzed_result=PPORolloutAnalyzedResult(
+                                       log_probs=arrays["analyzed_result.log_probs"],
+                                       value=arrays["analyzed_result.value"]),
+                                   policy_version_steps=arrays["policy_version_steps"],
+                                   info_mask=arrays["info_mask"])
+
+
+# ------------------------------------------------------------------------------------------------ G1/G2
+def gen_gae():
+    out = {}
+    # the hand-computed case of legacy/tests/modules_test.py:119-138 (inputs restated; outputs from the reference)
+    on_reset = np.array([0, 0, 0, 1, 0, 0, 1, 0, 0], dtype=np.float32)
+    rew = np.array([1, 2, 0, 1, 3, 0, 1, 2, 3], dtype=np.float32)
+    value = np.array([2, 0, 1, 2, 2, 0, 1, 1, 1], dtype=np.float32)
+    truncated = np.array([0, 0, 1, 0, 0, 0, 0, 0, 0], dtype=np.float32)
+    done = np.array([0, 0, 0, 0, 0, 1, 0, 0, 0], dtype=np.float32)
+    t = torch.from_numpy
+    adv = modules.gae_trace(reward=t(rew)[:-1], value=t(value), truncated=t(truncated), done=t(done),
+                            on_reset=t(on_reset), gamma=0.1, lmbda=0.1).numpy()
+    out.update(hand_on_reset=on_reset, hand_reward=rew, hand_value=value, hand_truncated=truncated, hand_done=done,
+               hand_adv=adv)
+
+    cases = [("small", 32, 8, 1, 0.05, 21), ("mid", 128, 64, 1, 0.02, 22), ("nc3", 32, 8, 3, 0.1, 23),
+             ("dense_done", 16, 5, 1, 0.4, 24)]
+    names = []
+    for name, T, B, Nc, p, seed in cases:
+        arr = synthetic.make_sample_arrays(seed=seed, T=T, B=B, obs_spec={}, action_dims=2, p_done=p,
+                                           value_dim=Nc)
+        f = lambda k: torch.from_numpy(arr[k]).float()
+        # reference path: _compute_adv_and_value_target without popart (mappo.py:118-144)
+        v_masked = f("analyzed_result.value") * (1 - f("done"))
+        for tag, g, l in [("a", 0.99, 0.97), ("b", 0.9, 0.5)]:
+            adv = modules.gae_trace(f("reward")[:-1], v_masked, f("truncated"), f("done"), f("on_reset"), gamma=g,
+                                    lmbda=l)
+            ret = adv + v_masked[:-1]
+            o_adv, o_ret = ogae.adv_and_value_target(arr["reward"], arr["analyzed_result.value"], arr["truncated"],
+                                                     arr["done"], arr["on_reset"], g, l)
+            assert np.array_equal(o_adv, adv.numpy()) and np.array_equal(o_ret, ret.numpy()), name
+            out[f"{name}_{tag}_adv"], out[f"{name}_{tag}_ret"] = adv.numpy(), ret.numpy()
+        # v-trace variant (rho = c = 1) with a synthetic importance ratio
+        rng = np.random.default_rng(7)
+        ratio = np.exp(0.3 * rng.standard_normal((T, B, 1))).astype(np.float32)
+        ratio[arr["truncated"][:-1] == 1] = 1.0  # keeps the reference's debug assertion gae.py:77 valid under v-trace
+        adv_v = modules.gae_trace(f("reward")[:-1], v_masked, f("truncated"), f("done"), f("on_reset"), gamma=0.99,
+                                  lmbda=0.97, vtrace=True, imp_ratio=torch.from_numpy(ratio), rho=1.0, c=1.0)
+        o_adv_v = ogae.gae_trace(arr["reward"][:-1], v_masked.numpy(), arr["truncated"], arr["done"], arr["on_reset"],
+                                 0.99, 0.97, vtrace=True, imp_ratio=ratio)
+        assert np.array_equal(o_adv_v, adv_v.numpy())
+        out[f"{name}_ratio"], out[f"{name}_vtrace_adv"] = ratio, adv_v.numpy()
+        for k in ["reward", "analyzed_result.value", "done", "truncated", "on_reset"]:
+            out[f"{name}_{k.split('.')[-1]}"] = arr[k]
+        names.append(name)
+    out["cases"] = np.array(names)
+    save("gae.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------------ G3
+def gen_norm():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((33, 9, 1)).astype(np.float32) * 3 + 0.7
+    mask = (rng.random((33, 9, 1)) < 0.8).astype(np.float32)
+    out = dict(x=x, mask=mask)
+    for tag, m, unb in [("masked", mask, False), ("nomask", None, False), ("unbiased", mask, True)]:
+        y = modules.masked_normalization(torch.from_numpy(x), None if m is None else torch.from_numpy(m),
+                                         unbiased=unb).numpy()
+        o = oppo.masked_normalization(x, m, unbiased=unb)
+        assert np.array_equal(o, y), tag
+        out[f"{tag}_out"] = y
+        out[f"{tag}_stats"] = np.array(oppo.masked_stats(x, m), dtype=np.float64)
+    save("norm.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------------ G4
+def make_ref_trainer(policy_args, trainer_args):
+    return api.trainer.make(api.config.Trainer("mappo", args=trainer_args),
+                            api.config.Policy("actor-critic", args=policy_args))
+
+
+C1_POLICY = dict(obs_dim=4, action_dim=2, hidden_dim=64, num_dense_layers=2, num_rnn_layers=0, popart=False,
+                 layernorm=False, shared_backbone=False, chunk_len=8, seed=1)
+
+LOSS_COMBOS = [(vl, cv, dc) for vl in ("mse", "huber") for cv in (False, True) for dc in (False, True)]
+
+
+def gen_loss():
+    T, B = 24, 6
+    rng = np.random.default_rng(11)
+    shape = (T, B, 1)
+    new_lp = (np.log(0.5) + 0.3 * rng.standard_normal(shape)).astype(np.float32)
+    old_lp = (np.log(0.5) + 0.3 * rng.standard_normal(shape)).astype(np.float32)
+    value = rng.standard_normal(shape).astype(np.float32) * 2
+    old_value = (value + 0.5 * rng.standard_normal(shape)).astype(np.float32)
+    adv = rng.standard_normal(shape).astype(np.float32) * 4
+    ret = (old_value + adv + 15 * (rng.random(shape) < 0.1)).astype(np.float32)  # a few beyond huber delta
+    entropy = (0.6 + 0.05 * rng.standard_normal(shape)).astype(np.float32)
+    mask = (rng.random(shape) < 0.85).astype(np.float32)
+    out = dict(new_lp=new_lp, old_lp=old_lp, value=value, old_value=old_value, adv=adv, ret=ret, entropy=entropy,
+               mask=mask)
+    for vl, cv, dc in LOSS_COMBOS:
+        targs = dict(value_loss=vl, clip_value=cv, dual_clip=dc, popart=False,
+                     value_loss_config=dict(delta=10.0) if vl == "huber" else {})
+        trainer = make_ref_trainer(C1_POLICY, targs)
+        tl = lambda a, g=False: torch.from_numpy(a).clone().requires_grad_(g)
+        nlp, v, ent = tl(new_lp, True), tl(value, True), tl(entropy, True)
+        sample = NamedArray(on_reset=torch.zeros(shape), done=torch.zeros(shape), truncated=torch.zeros(shape),
+                            analyzed_result=NamedArray(adv=tl(adv), ret=tl(ret), value=tl(old_value)))
+        ar = SampleAnalyzedResult(old_action_log_probs=tl(old_lp), new_action_log_probs=nlp, state_values=v,
+                                  entropy=ent)
+        loss, res = trainer._compute_loss(sample, ar, tl(mask))
+        loss.backward()
+        tag = f"{vl}_{int(cv)}_{int(dc)}"
+        stats = dict(loss=loss.item(), policy_loss=res.policy_loss.item(), value_loss=res.value_loss.item(),
+                     entropy=res.entropy.item(), clip_ratio=res.clip_ratio.mean().item(),
+                     importance_weight=res.importance_weight.mean().item(), advantage=res.advantage.mean().item(),
+                     value_targets=res.value_targets.mean().item())
+        # oracle cross-check
+        o_nlp, o_v, o_ent = tl(new_lp, True), tl(value, True), tl(entropy, True)
+        o_loss, o_stats = oppo.ppo_loss(o_nlp, tl(old_lp), o_v, tl(old_value), tl(adv), tl(ret), o_ent, tl(mask),
+                                        dual_clip=dc, value_loss=vl, clip_value=cv,
+                                        value_loss_config=targs["value_loss_config"])
+        o_loss.backward()
+        assert abs(o_loss.item() - loss.item()) <= 1e-6 * max(1, abs(loss.item())), tag
+        for a, b_ in [(o_nlp.grad, nlp.grad), (o_v.grad, v.grad), (o_ent.grad, ent.grad)]:
+            assert torch.allclose(a, b_, rtol=1e-6, atol=1e-9), tag
+        for k, val in stats.items():
+            if k != "loss":
+                assert abs(o_stats[k] - val) <= 1e-6 * max(1, abs(val)), (tag, k)
+        out[f"{tag}_stats"] = np.array([stats[k] for k in sorted(stats)], dtype=np.float64)
+        out[f"{tag}_d_new_lp"], out[f"{tag}_d_value"], out[f"{tag}_d_entropy"] = (nlp.grad.numpy(), v.grad.numpy(),
+                                                                                   ent.grad.numpy())
+    out["stat_names"] = np.array(sorted(stats))
+    out["combos"] = np.array([f"{vl}_{int(cv)}_{int(dc)}" for vl, cv, dc in LOSS_COMBOS])
+    save("loss.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------------ G5/G6/G7
+def sd_to_np(sd):
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def check_init(policy_args, ref_sd):
+    """This repo's initialiser must reproduce the reference's initial weights bit for bit."""
+    args = {k: v for k, v in policy_args.items() if k != "chunk_len"}
+    spec, vals = build_netspec(**args)
+    assert list(vals.keys()) == list(ref_sd.keys()), "state_dict key order differs"
+    for k in vals:
+        assert torch.equal(vals[k], ref_sd[k]), f"init mismatch at {k}"
+    return spec
+
+
+def run_steps(tag, policy_args, trainer_args, sample_kw, n_steps, store_state="full", out=None):
+    out = {} if out is None else out
+    trainer = make_ref_trainer(policy_args, trainer_args)
+    net = trainer.policy.net
+    sd0 = sd_to_np(net.state_dict())
+    check_init(policy_args, net.state_dict())
+    out[f"{tag}_init_sha"] = np.array(state_sha(net.state_dict()))
+    oracle_net = OracleActorCritic(**policy_args)
+    oracle_net.load_state_dict(sd0)
+    oracle = OracleMappo(oracle_net, **trainer_args)
+    stat_keys = None
+    for step in range(n_steps):
+        arrays = synthetic.make_sample_arrays(seed=100 + step, **sample_kw)
+        sample = ref_sample({k: v.copy() for k, v in arrays.items()})
+        if step == 0:
+            # G6: analysis outputs on the initial weights
+            ts = recursive_apply(sample, lambda x: torch.from_numpy(x).float())
+            Tb = arrays["on_reset"].shape[0]
+            with torch.no_grad():
+                ar = trainer.policy.analyze(ts[:Tb - 1], target="ppo", burn_in_steps=0)
+                lp, v, ent, _ = oracle_net.analyze({k[4:]: torch.from_numpy(a[:Tb - 1]).float()
+                                                    for k, a in arrays.items() if k.startswith("obs.")},
+                                                   torch.from_numpy(arrays["action.x"][:Tb - 1]).float(),
+                                                   torch.from_numpy(arrays["on_reset"][:Tb - 1]).float())
+            assert torch.allclose(lp, ar.new_action_log_probs, rtol=1e-5, atol=1e-6)
+            assert torch.allclose(v, ar.state_values, rtol=1e-5, atol=1e-6)
+            assert torch.allclose(ent, ar.entropy, rtol=1e-5, atol=1e-6)
+            out[f"{tag}_analyze_new_lp"] = ar.new_action_log_probs.numpy()
+            out[f"{tag}_analyze_value"] = ar.state_values.numpy()
+            out[f"{tag}_analyze_entropy"] = ar.entropy.numpy()
+        res = trainer.step(sample)
+        o_stats, o_out = oracle.step(arrays)
+        stats = {k: float(v) for k, v in res.stats.items()}
+        for k in ("policy_loss", "value_loss", "entropy", "grad_norm", "clip_ratio", "importance_weight", "advantage",
+                  "value_targets", "done", "truncated"):
+            assert abs(o_stats[k] - stats[k]) <= 2e-5 * max(1.0, abs(stats[k])), (tag, step, k, o_stats[k], stats[k])
+        assert np.array_equal(o_out["adv"], sample.analyzed_result.adv)
+        assert np.array_equal(o_out["ret"], sample.analyzed_result.ret)
+        stat_keys = sorted(stats)
+        out[f"{tag}_step{step}_stats"] = np.array([stats[k] for k in stat_keys], dtype=np.float64)
+        if step == 0:
+            out[f"{tag}_step0_adv"], out[f"{tag}_step0_ret"] = sample.analyzed_result.adv, sample.analyzed_result.ret
+        sd = sd_to_np(net.state_dict())
+        osd = oracle_net.state_dict()
+        for k in sd:
+            assert np.allclose(osd[k].numpy(), sd[k], rtol=1e-4, atol=1e-6), (tag, step, k)
+        if step in (0, n_steps - 1):
+            for k, v in sd.items():
+                if store_state == "full" or v.size <= 4096:
+                    out[f"{tag}_step{step}_param:{k}"] = v
+                else:  # large tensors: a strided subsample (stride recorded in the key)
+                    out[f"{tag}_step{step}_param_s97:{k}"] = v.reshape(-1)[::97].copy()
+    out[f"{tag}_stat_names"] = np.array(stat_keys)
+    out[f"{tag}_version"] = np.array(trainer.policy.version)
+    if store_state == "full":
+        for k, v in sd0.items():
+            out[f"{tag}_init_param:{k}"] = v
+    return out
+
+
+def gen_steps():
+    c1_sample = dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05)
+    out = {}
+    # config #1 of BASELINE.json: CartPole shapes, separate 2x64 MLP, reference-default hyper-parameters, lr 3e-4
+    run_steps("c1", C1_POLICY, dict(popart=False, optimizer_config=dict(lr=3e-4)), c1_sample, 3, out=out)
+    # same shapes with the Atari preset of legacy/experiments/atari.py:952-973
+    atari_trainer = dict(discount_rate=0.99, gae_lambda=0.97, eps_clip=0.2, clip_value=True, dual_clip=False,
+                         value_loss='huber', value_loss_weight=1.0, value_loss_config=dict(delta=10.0),
+                         entropy_bonus_weight=0.01, optimizer='adam', optimizer_config=dict(lr=5e-4), popart=False,
+                         max_grad_norm=40.0, bootstrap_steps=1)
+    run_steps("c1atari", C1_POLICY, atari_trainer, c1_sample, 2, out=out)
+    # MLP variants: layernorm on, shared backbone, multi-discrete heads, two observation keys, tanh
+    ln_policy = dict(C1_POLICY, layernorm=True, seed=2)
+    run_steps("c1ln", ln_policy, dict(popart=False, optimizer_config=dict(lr=1e-3), max_grad_norm=0.5), c1_sample, 2,
+              out=out)
+    multi_policy = dict(obs_dim={"a": 5, "b": 3}, action_dim=[3, 4], hidden_dim=32, num_dense_layers=1,
+                        num_rnn_layers=0, popart=False, layernorm=True, shared_backbone=True, chunk_len=8, seed=3,
+                        activation="tanh")
+    multi_sample = dict(T=16, B=4, obs_spec={"a": ((5,), "f32"), "b": ((3,), "f32")}, action_dims=[3, 4], p_done=0.1)
+    run_steps("multi", multi_policy, dict(popart=False, ppo_epochs=2, optimizer_config=dict(lr=1e-3)), multi_sample, 2,
+              out=out)
+    save("steps_mlp.npz", **out)
+
+    # down-sized Atari: NatureCNN on (4,84,84) uint8 frames, shared backbone, Atari preset
+    cnn_policy = dict(obs_dim={"obs": (4, 84, 84)}, action_dim=6, hidden_dim=512, num_dense_layers=0, num_rnn_layers=0,
+                      popart=False, layernorm=False, shared_backbone=True, chunk_len=4, seed=5,
+                      cnn_layers=dict(obs=[(32, 8, 4, 0, 'zeros'), (64, 4, 2, 0, 'zeros'), (64, 3, 1, 0, 'zeros')]))
+    cnn_sample = dict(T=4, B=3, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.1)
+    out = run_steps("cnn", cnn_policy, atari_trainer, cnn_sample, 2, store_state="sampled")
+    save("steps_cnn.npz", **out)
+
+
+def gen_rollout():
+    out = {}
+    for tag, pargs, obs_spec in [("c1", C1_POLICY, synthetic.CARTPOLE_OBS)]:
+        policy = api.policy.make(api.config.Policy("actor-critic", args=pargs))
+        policy.eval_mode()
+        rng = np.random.default_rng(5)
+        N = 17
+        obs = {k: rng.standard_normal((N, *shape)).astype(np.float32) for k, (shape, _) in obs_spec.items()}
+        req = api.policy.RolloutRequest(obs=NamedArray(**obs), is_evaluation=np.ones((N, 1), dtype=np.uint8),
+                                        on_reset=np.zeros((N, 1), dtype=np.uint8))
+        res = policy.rollout(req)
+        out[f"{tag}_obs"] = obs["obs"]
+        out[f"{tag}_action"], out[f"{tag}_log_probs"], out[f"{tag}_value"] = (res.action.x,
+                                                                             res.analyzed_result.log_probs,
+                                                                             res.analyzed_result.value)
+        onet = OracleActorCritic(**pargs)
+        onet.load_state_dict(sd_to_np(policy.net.state_dict()))
+        a, lp, v, _, _ = onet.rollout_eval({k: torch.from_numpy(x) for k, x in obs.items()})
+        assert np.array_equal(a.numpy(), res.action.x) and np.allclose(lp.numpy(), res.analyzed_result.log_probs,
+                                                                       atol=1e-6)
+    save("rollout.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------------ G8/G9/G10
+def gen_host():
+    out = {}
+    # G8: TrajGAE on the two hand cases of legacy/tests/modules_test.py:140-178
+    for tag, rew, value, done, trunc in [("trunc", [1, 2, 0], [2, 0, 1], [0, 0, 0], [0, 0, 1]),
+                                         ("done", [1, 3, 0], [2, 2, 0], [0, 0, 1], [0, 0, 0])]:
+        memory = [
+            api.trainer.SampleBatch(obs=None, reward=np.array([r], dtype=np.float32),
+                                    analyzed_result=PPORolloutAnalyzedResult(value=np.array([v], dtype=np.float32),
+                                                                             log_probs=None),
+                                    done=np.array([d]), truncated=np.array([t]))
+            for r, v, d, t in zip(rew, value, done, trunc)
+        ]
+        proc = api.trainer.make_traj_postprocessor(api.config.TrajPostprocessor('gae', args=dict(gamma=0.1, lmbda=0.1)))
+        memory = proc.process(memory)
+        out[f"trajgae_{tag}_in"] = np.array([rew, value, done, trunc], dtype=np.float32)
+        out[f"trajgae_{tag}_adv"] = np.array([m.analyzed_result.adv.item() for m in memory[:-1]])
+        out[f"trajgae_{tag}_ret"] = np.array([m.analyzed_result.ret.item() for m in memory[:-1]])
+    # G10: wire formats
+    rng = np.random.default_rng(1)
+    na = NamedArray(a=rng.standard_normal((3, 2)).astype(np.float32),
+                    b=NamedArray(c=rng.integers(0, 255, (3, 4), dtype=np.uint8), d=None),
+                    e=np.arange(3, dtype=np.int64))
+    na.register_metadata(tag="golden")
+    for method in ("pickle_dict", "raw_bytes"):
+        chunks = ref_namedarray.dumps(na, method=method)
+        out[f"wire_{method}_n"] = np.array(len(chunks))
+        for i, ch in enumerate(chunks):
+            out[f"wire_{method}_{i}"] = np.frombuffer(ch, dtype=np.uint8)
+    out["wire_a"], out["wire_c"], out["wire_e"] = na.a, na.b.c, na.e
+    # G9: PriorityQueueBuffer stacking (base/buffer.py:109-130): batch_size [T,...] samples -> [T,B,...]
+    from base.buffer import PriorityQueueBuffer
+    buf = PriorityQueueBuffer(max_size=4, reuses=1, batch_size=3)
+    singles = []
+    for i in range(3):
+        arr = synthetic.make_sample_arrays(seed=40 + i, T=4, B=1, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2)
+        arr = {k: v[:, 0] for k, v in arr.items()}  # one agent's [Tb, ...] sample
+        singles.append(arr)
+        buf.put(ref_sample(arr))
+    batch = buf.get().sample
+    out["buffer_obs"] = batch.obs.obs
+    out["buffer_reward"] = batch.reward
+    out["buffer_action"] = batch.action.x
+    for i, arr in enumerate(singles):
+        out[f"buffer_in{i}_obs"], out[f"buffer_in{i}_reward"], out[f"buffer_in{i}_action"] = (arr["obs.obs"],
+                                                                                            arr["reward"],
+                                                                                            arr["action.x"])
+    save("host.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gae", "norm", "loss", "steps", "rollout", "host"]
+    for w in which:
+        globals()[f"gen_{w}"]()
