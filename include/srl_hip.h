@@ -94,7 +94,7 @@ typedef struct srl_ppo_hparams {
 } srl_ppo_hparams;
 
 enum { SRL_LT_POLICY = 0, SRL_LT_VALUE = 1, SRL_LT_ENTROPY = 2, SRL_LT_CLIP = 3, SRL_LT_RATIO = 4,
-       SRL_LT_ADV = 5, SRL_LT_RET = 6, SRL_LT_MASK = 7, SRL_LT_COUNT = 8 };
+       SRL_LT_ADV = 5, SRL_LT_RET = 6, SRL_LT_MASK = 7, SRL_LT_DONE = 8, SRL_LT_TRUNC = 9, SRL_LT_COUNT = 10 };
 
 /* new_lp, old_lp, value, old_value, adv (raw, un-normalised), ret, entropy: float32[n]; mask uint8[n].
  * norm_stats: float64[3] global {n, s, q} for the advantage normalisation.
@@ -102,12 +102,14 @@ enum { SRL_LT_POLICY = 0, SRL_LT_VALUE = 1, SRL_LT_ENTROPY = 2, SRL_LT_CLIP = 3,
  * Outputs: d_new_lp, d_value, d_entropy float32[n] = d loss / d input;
  *          loss_terms float64[SRL_LT_COUNT] (zeroed, then accumulated): masked SUMS of policy loss,
  *          value loss, entropy, 1[s2<s1], ratio, adv, ret, and mask; the caller forms
- *          loss = (P + w_v*V - w_H*E) / M. */
+ *          loss = (P + w_v*V - w_H*E) / M.  done / truncated (uint8[n], nullable) are only summed
+ *          (unmasked) into SRL_LT_DONE / SRL_LT_TRUNC for the `done` / `truncated` statistics
+ *          (mappo.py:40-41,293-296). */
 int srl_ppo_loss_fwd_bwd(void* stream, const float* new_lp, const float* old_lp, const float* value,
                          const float* old_value, const float* adv, const float* ret, const float* entropy,
                          const uint8_t* mask, long n, const srl_ppo_hparams* hp, const double* norm_stats,
-                         const double* local_n, float* d_new_lp, float* d_value, float* d_entropy,
-                         double* loss_terms);
+                         const double* local_n, const uint8_t* done, const uint8_t* truncated, float* d_new_lp,
+                         float* d_value, float* d_entropy, double* loss_terms);
 
 /* ------------------------------------------------------------------------------------------------
  * Categorical heads.  Replaces torch.distributions.Categorical log_prob / entropy / sample in

@@ -1,0 +1,208 @@
+"""Actor-critic policy on the HIP kernels, registered under the reference's names.
+
+Mirror of ``ActorCriticPolicy`` (reference ``legacy/algorithm/ppo/actor_critic_policies/actor_critic_policy.py``):
+same constructor keywords (``:146-166``), ``rollout`` contract (``:458-528``: numpy ``RolloutRequest`` in, numpy
+``RolloutResult`` out, ``action.x`` int64 ``[N, heads]``, ``log_probs`` / ``value`` ``[N, 1]``), ``analyze(target="ppo")``
+contract (``:338-390``), version / checkpoint semantics of ``SingleModelPytorchPolicy`` (``api/policy.py:205-288``:
+``{"steps", "state_dict"}`` with the reference's parameter names and shapes on the CPU).
+
+Differences by design: observations stay in their wire dtype on the device (uint8 frames are normalised
+inside the first convolution's gather instead of being widened to float32 first, ``:467-469``); sampling
+uses a counter-based Philox stream keyed by ``(seed, call counter)`` instead of the global torch RNG, so a
+rollout is reproducible regardless of how requests are batched.
+"""
+import functools
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from srl_amd import hip
+from srl_amd.algorithm import netspec as ns
+from srl_amd.algorithm.hipnet import HipNet
+from srl_amd.algorithm.ppo_types import PPORolloutAnalyzedResult, SampleAnalyzedResult
+from srl_amd.api import policy as policy_api
+from srl_amd.api.env_utils import DiscreteAction
+from srl_amd.namedarray import NamedArray, recursive_apply
+
+
+def to_device_leaf(x, device, kind: str) -> torch.Tensor:
+    """Host leaf -> contiguous device tensor in the dtype the kernels read.
+
+    kind: "flag" (uint8), "real" (float32), "index" (int32), "obs" (uint8 stays uint8, everything else float32).
+    Device tensors pass through (only the dtype is checked).
+    """
+    want = {"flag": torch.uint8, "real": torch.float32, "index": torch.int32}.get(kind)
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        a = np.asarray(x)
+        if a.dtype == np.bool_:
+            a = a.view(np.uint8)
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    if kind == "obs":
+        want = torch.uint8 if t.dtype == torch.uint8 else torch.float32
+    if t.dtype != want:
+        t = t.to(want)
+    return t.to(device, non_blocking=True).contiguous()
+
+
+class ActorCriticPolicy(policy_api.Policy):
+
+    def __init__(self,
+                 obs_dim: Union[int, Dict[str, Union[int, Tuple[int]]]],
+                 action_dim: Union[int, List[int]],
+                 hidden_dim: int = 128,
+                 state_dim=None,
+                 value_dim: int = 1,
+                 chunk_len: int = 10,
+                 num_dense_layers: int = 2,
+                 rnn_type: str = "gru",
+                 cnn_layers: Dict[str, Tuple] = None,
+                 use_maxpool: Dict[str, Tuple] = None,
+                 num_rnn_layers: int = 1,
+                 popart: bool = True,
+                 activation: str = "relu",
+                 layernorm: bool = True,
+                 shared_backbone: bool = False,
+                 continuous_action: bool = False,
+                 auxiliary_head: bool = False,
+                 seed=0,
+                 **kwargs):
+        super().__init__()
+        if auxiliary_head and shared_backbone:
+            raise AttributeError("Cannot use shared backbone when requiring auxiliary value head.")
+        self.spec, init = ns.build_netspec(obs_dim=obs_dim, action_dim=action_dim, hidden_dim=hidden_dim,
+                                           state_dim=state_dim, value_dim=value_dim, num_dense_layers=num_dense_layers,
+                                           cnn_layers=cnn_layers, use_maxpool=use_maxpool,
+                                           num_rnn_layers=num_rnn_layers, popart=popart, activation=activation,
+                                           layernorm=layernorm, shared_backbone=shared_backbone,
+                                           continuous_action=continuous_action, auxiliary_head=auxiliary_head,
+                                           seed=seed)
+        self._net = HipNet(self.spec, self.device)
+        self._net.load_reference_state(init)
+        self._version = -1
+        self._chunk_len = chunk_len
+        self._seed = int(seed)
+        self._rollout_calls = 0
+        self._distributed = False
+        self.denormalize_value_during_rollout = kwargs.get("denormalize_value_during_rollout", False)
+
+    # ------------------------------------------------------------------ bookkeeping (api/policy.py:205-288)
+    @property
+    def default_policy_state(self):
+        return None  # no recurrent state on the HIP path yet
+
+    @property
+    def version(self) -> int:
+        return self._version
+
+    @property
+    def net(self) -> HipNet:
+        return self._net
+
+    def inc_version(self):
+        self._version += 1
+
+    def parameters(self):
+        return [self._net.flat]
+
+    def train_mode(self):
+        pass
+
+    def eval_mode(self):
+        pass
+
+    def load_checkpoint(self, checkpoint):
+        self._version = checkpoint.get("steps", 0)
+        self._net.load_reference_state(checkpoint["state_dict"])
+
+    def get_checkpoint(self):
+        return {"steps": self._version, "state_dict": self._net.reference_state()}
+
+    def distributed(self):
+        """Data-parallel replica: adopt rank 0's parameters (what the DDP constructor does, api/policy.py:219-238)."""
+        if dist.is_initialized():
+            self.broadcast_parameters(src=0)
+            self._distributed = True
+
+    def broadcast_parameters(self, src: int = 0, group=None):
+        """One flat buffer, one broadcast (RCCL over xGMI on GPU ranks; also what inference replicas call to
+        receive fresh parameters from the trainer, replacing the reference's filesystem push/pull)."""
+        dist.broadcast(self._net.flat, src=src, group=group)
+        v = torch.tensor([self._version], dtype=torch.int64, device=self._net.flat.device)
+        dist.broadcast(v, src=src, group=group)
+        self._version = int(v.item())
+
+    # ------------------------------------------------------------------ inference
+    def rollout(self, requests: policy_api.RolloutRequest, **kwargs) -> policy_api.RolloutResult:
+        hip.require_gpu()
+        obs = {k: to_device_leaf(v, self.device, "obs") for k, v in requests.obs.items() if v is not None}
+        n = int(next(iter(obs.values())).shape[0])
+        avail = obs.pop("available_action", None)
+        if avail is not None and avail.dtype != torch.uint8:
+            avail = avail.to(torch.uint8)
+        is_eval = np.asarray(requests.is_evaluation).reshape(-1)
+        is_eval = to_device_leaf(np.broadcast_to(is_eval, (n,)) if is_eval.size == 1 else is_eval, self.device, "flag")
+        logits, value = self._net.forward(obs, n, keep_tape=False)
+        heads = self.spec.act_dims
+        action = torch.empty((n, len(heads)), dtype=torch.int64, device=self.device)
+        logp = torch.empty((n, 1), dtype=torch.float32, device=self.device)
+        hip.categorical_sample(logits, avail, is_eval, heads, self._seed, self._rollout_calls, action, logp)
+        self._rollout_calls += 1
+        return policy_api.RolloutResult(action=DiscreteAction(action.cpu().numpy()),
+                                        analyzed_result=PPORolloutAnalyzedResult(log_probs=logp.cpu().numpy(),
+                                                                                 value=value.cpu().numpy()),
+                                        policy_state=None)
+
+    # ------------------------------------------------------------------ training-side analysis
+    def analyze(self, sample, target="ppo", **kwargs):
+        if target != "ppo":
+            raise ValueError(f"Analyze method for algorithm {target} not implemented for {self.__class__.__name__}")
+        return self._ppo_analyze(sample, **kwargs)
+
+    def _ppo_analyze(self, sample, burn_in_steps=0, **kwargs):
+        """New log-probs, state values and entropy for every row of ``sample`` (leaves ``[T, B, ...]``).
+
+        Without a recurrent backbone the reference's chunking (``to_chunk`` / ``back_to_trajectory``,
+        ``modules/utils.py:164-195``) only permutes independent rows, so rows are evaluated in place.
+        The forward context is kept so that ``backward_ppo`` can follow.
+        """
+        if burn_in_steps:
+            raise NotImplementedError("burn-in only matters for recurrent policies, which are not on the HIP path")
+        T, B = sample.on_reset.shape[:2]
+        n = T * B
+        obs = {}
+        for k, v in sample.obs.items():
+            if v is None:
+                continue
+            t = to_device_leaf(v, self.device, "obs")
+            obs[k] = t.reshape(n, *t.shape[2:])
+        avail = obs.pop("available_action", None)
+        action = to_device_leaf(sample.action.x, self.device, "index").reshape(n, -1)
+        logits, value = self._net.forward(obs, n, keep_tape=True)
+        logp = self._net.ws.get("new_logp", n)[:n]
+        ent = self._net.ws.get("entropy", n)[:n]
+        hip.categorical_fwd(logits, action, avail, self.spec.act_dims, logp, ent)
+        self._analysis = (logits, action, avail, n)
+        old = sample.analyzed_result.log_probs
+        old = None if old is None else to_device_leaf(old, self.device, "real")
+        return SampleAnalyzedResult(old_action_log_probs=old, new_action_log_probs=logp.view(T, B, 1),
+                                    state_values=value.view(T, B, -1), entropy=ent.view(T, B, 1))
+
+    def backward_ppo(self, d_new_lp: torch.Tensor, d_value: torch.Tensor, d_entropy: torch.Tensor):
+        """Back-propagate d loss / d(new log-prob, value, entropy) of the last ``analyze`` into ``net.grad``."""
+        logits, action, avail, n = self._analysis
+        d_logits = self._net.ws.get("d_logits", logits.numel())[:logits.numel()].view_as(logits)
+        hip.categorical_bwd(logits, action, avail, self.spec.act_dims, d_new_lp.reshape(n), d_entropy.reshape(n),
+                            d_logits)
+        self._net.backward(d_logits, d_value.reshape(n, -1))
+        self._analysis = None
+
+
+policy_api.register("actor-critic", ActorCriticPolicy)
+policy_api.register("actor-critic-separate",
+                    functools.partial(ActorCriticPolicy, shared_backbone=False, auxiliary_head=False))
+policy_api.register("actor-critic-shared",
+                    functools.partial(ActorCriticPolicy, shared_backbone=True, auxiliary_head=False))

@@ -1,0 +1,339 @@
+"""Device executor of the actor-critic network: forward and hand-written backward on the HIP kernels.
+
+No autograd and no torch compute ops: PyTorch only allocates the buffers.  Every layer is one or two
+launches through the C ABI (``srl_amd.hip``):
+
+================  =========================================  ==========================================
+layer             forward                                    backward (accumulates parameter gradients)
+================  =========================================  ==========================================
+Linear (+act)     ``srl_gemm`` X W^T + b, act in epilogue    ``srl_gemm`` dZ^T X (split-K), ``srl_colsum``,
+                                                             ``srl_gemm`` dZ W with act'(X) in the epilogue
+LayerNorm         ``srl_layernorm_fwd``                      ``srl_layernorm_bwd`` (act' of the producer fused)
+first Conv2d      ``srl_obs_ln_stats`` + ``srl_im2col_obs_ln``  GEMMs + ``srl_obs_ln_affine_bwd``
+                  (uint8 -> LN -> patches) + ``srl_gemm``
+later Conv2d      ``srl_im2col_nhwc`` + ``srl_gemm``             GEMMs + ``srl_col2im_nhwc`` (act' fused)
+================  =========================================  ==========================================
+
+The gradient handed to a layer's ``backward`` is always w.r.t. its *pre-activation* output: whoever
+produces a gradient w.r.t. an activation output multiplies by act'(output) in its own epilogue, so the
+mask never costs a separate pass.  Activations between convolutions are NHWC, so a convolution's GEMM
+output ``[n*OH*OW, Cout]`` is the next layer's input without a transpose (parameter layouts are adapted
+once, at the checkpoint boundary: ``netspec.ParamInfo``).
+"""
+from collections import OrderedDict
+from typing import Dict, List, NamedTuple, Optional
+
+import torch
+
+from srl_amd import hip
+from srl_amd.algorithm import netspec as ns
+
+
+class Buf(NamedTuple):
+    ptr: int
+    ld: int
+    rows: int
+    cols: int
+
+
+class Workspace:
+    """Named device buffers that only ever grow (steady-state steps allocate nothing)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._bufs: Dict[str, torch.Tensor] = {}
+
+    def get(self, name: str, numel: int, dtype=torch.float32) -> torch.Tensor:
+        t = self._bufs.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.empty(max(int(numel), 1), dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self._bufs.values())
+
+
+def _split_for(rows: int, tiles: int) -> int:
+    """split-K factor for weight gradients: enough workgroups to fill 256 CUs, >= 2048 rows each."""
+    want = max(1, 512 // max(tiles, 1))
+    return int(max(1, min(want, rows // 2048)))
+
+
+class HipNet:
+
+    def __init__(self, spec: ns.NetSpec, device: str):
+        self.spec = spec
+        self.device = device
+        self.on_gpu = device != "cpu"
+        dev = device if self.on_gpu else "cpu"
+        self.flat = torch.zeros(spec.total_params, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.flat)
+        self.ws = Workspace(dev)
+        self._tape = None
+
+    # ------------------------------------------------------------------ parameters / checkpoints
+    def load_reference_state(self, state: Dict[str, torch.Tensor]):
+        missing = [k for k in self.spec.params if k not in state]
+        extra = [k for k in state if k not in self.spec.params]
+        if missing or extra:
+            raise KeyError(f"state_dict mismatch: missing {missing}, unexpected {extra}")
+        host = torch.zeros(self.spec.total_params, dtype=torch.float32)
+        for name, info in self.spec.params.items():
+            t = torch.as_tensor(state[name]).detach().cpu()
+            if tuple(t.shape) != info.ref_shape:
+                raise ValueError(f"{name}: shape {tuple(t.shape)} != {info.ref_shape}")
+            host[info.offset:info.offset + info.numel] = info.to_internal(t)
+        self.flat.copy_(host)
+
+    def reference_state(self) -> "OrderedDict[str, torch.Tensor]":
+        host = self.flat.detach().cpu()
+        return OrderedDict((name, info.to_reference(host[info.offset:info.offset + info.numel]))
+                           for name, info in self.spec.params.items())
+
+    def flat_to_reference(self, flat_host: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
+        """Split any flat buffer with the parameter layout (gradients, Adam moments) into named tensors."""
+        return OrderedDict((name, info.to_reference(flat_host[info.offset:info.offset + info.numel]))
+                           for name, info in self.spec.params.items())
+
+    def reference_to_flat(self, named: Dict[str, torch.Tensor]) -> torch.Tensor:
+        host = torch.zeros(self.spec.total_params, dtype=torch.float32)
+        for name, info in self.spec.params.items():
+            host[info.offset:info.offset + info.numel] = info.to_internal(torch.as_tensor(named[name]).cpu())
+        return host
+
+    def _p(self, name):
+        return self.flat.data_ptr() + 4 * self.spec.params[name].offset
+
+    def _g(self, name):
+        return self.grad.data_ptr() + 4 * self.spec.params[name].offset
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    # ------------------------------------------------------------------ layer kernels
+    def _buf(self, name, rows, cols) -> Buf:
+        t = self.ws.get(name, rows * cols)
+        return Buf(t.data_ptr(), cols, rows, cols)
+
+    def _linear_fwd(self, L: ns.LinearSpec, x: Buf, tag: str) -> Buf:
+        y = self._buf(f"{tag}{L.prefix}.y", x.rows, L.out_features)
+        hip.gemm(x.rows, L.out_features, L.in_features, x.ptr, x.ld, 0, self._p(f"{L.prefix}.weight"), L.in_features, 0,
+                 y.ptr, y.ld, bias=self._p(f"{L.prefix}.bias"), act=L.act)
+        return y
+
+    def _wgrad(self, out_f, in_f, rows, dz: Buf, x_ptr, x_ld, gw_ptr):
+        tiles = ((out_f + 127) // 128) * ((in_f + 127) // 128)
+        split = _split_for(rows, tiles)
+        wsp = self.ws.get("splitk", split * out_f * in_f).data_ptr() if split > 1 else None
+        hip.gemm(out_f, in_f, rows, dz.ptr, dz.ld, 1, x_ptr, x_ld, 1, gw_ptr, in_f, accumulate=True, split_k=split,
+                 workspace=wsp)
+
+    def _linear_bwd(self, L: ns.LinearSpec, x: Buf, dz: Buf, in_act: int, need_dx: bool, tag: str,
+                    dx_into: Optional[Buf] = None, dx_accumulate=False) -> Optional[Buf]:
+        self._wgrad(L.out_features, L.in_features, x.rows, dz, x.ptr, x.ld, self._g(f"{L.prefix}.weight"))
+        hip.colsum(dz.ptr, dz.ld, dz.rows, L.out_features, self._g(f"{L.prefix}.bias"), accumulate=True)
+        if not need_dx:
+            return None
+        dx = dx_into or self._buf(f"{tag}{L.prefix}.dx", x.rows, L.in_features)
+        hip.gemm(x.rows, L.in_features, L.out_features, dz.ptr, dz.ld, 0, self._p(f"{L.prefix}.weight"), L.in_features,
+                 1, dx.ptr, dx.ld, dact_src=x.ptr if in_act else None, ld_dact=x.ld, dact=in_act,
+                 accumulate=dx_accumulate)
+        return dx
+
+    def _ln_fwd(self, L: ns.LayerNormSpec, x: Buf, tag: str):
+        y = self._buf(f"{tag}{L.prefix}.y", x.rows, L.dim)
+        mean = self.ws.get(f"{tag}{L.prefix}.mean", x.rows)
+        rstd = self.ws.get(f"{tag}{L.prefix}.rstd", x.rows)
+        hip.layernorm_fwd(x.ptr, x.ld, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"), x.rows, L.dim, y.ptr,
+                          y.ld, mean.data_ptr(), rstd.data_ptr())
+        return y, (mean, rstd)
+
+    def _ln_bwd(self, L: ns.LayerNormSpec, x: Buf, saved, dy: Buf, in_act: int, need_dx: bool, tag: str):
+        mean, rstd = saved
+        dx = self._buf(f"{tag}{L.prefix}.dx", x.rows, L.dim) if need_dx else None
+        hip.layernorm_bwd(dy.ptr, dy.ld, x.ptr, x.ld, self._p(f"{L.prefix}.weight"), mean.data_ptr(), rstd.data_ptr(),
+                          x.rows, L.dim, dx.ptr if dx else None, dx.ld if dx else 0, in_act,
+                          self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"))
+        return dx
+
+    # ------------------------------------------------------------------ encoders
+    def _encoder_fwd(self, enc: ns.EncoderSpec, obs: torch.Tensor, n: int, tag: str, tape: list) -> Buf:
+        """obs: device tensor [n, *shape] (float32 vectors; uint8 or float32 images)."""
+        cur: Optional[Buf] = None
+        cur_act = 0
+        pending_obs_ln = None
+        for L in enc.layers:
+            if isinstance(L, ns.LayerNormSpec):
+                if cur is None:
+                    if obs.dtype != torch.float32:
+                        raise hip.HipError(f"vector observation `{enc.key}` must be float32, got {obs.dtype}")
+                    cur = Buf(obs.data_ptr(), L.dim, n, L.dim)
+                y, saved = self._ln_fwd(L, cur, tag)
+                tape.append(("ln", L, cur, saved, cur_act))
+                cur, cur_act = y, 0
+            elif isinstance(L, ns.LinearSpec):
+                if cur.cols != L.in_features:  # Flatten after the convolution stack: [n*OH*OW, C] -> [n, OH*OW*C]
+                    assert cur.rows * cur.cols == n * L.in_features and cur.ld == cur.cols
+                    cur = Buf(cur.ptr, L.in_features, n, L.in_features)
+                y = self._linear_fwd(L, cur, tag)
+                tape.append(("linear", L, cur, None, cur_act))
+                cur, cur_act = y, L.act
+            elif isinstance(L, ns.ObsLayerNormSpec):
+                pending_obs_ln = L
+            elif isinstance(L, ns.ConvSpec):
+                oh, ow = L.out_hw
+                m = n * oh * ow
+                kdim = L.cin * L.k * L.k
+                P = self._buf(f"{tag}{L.prefix}.P", m, kdim)
+                if L.first:
+                    c, h, w = pending_obs_ln.shape
+                    is_u8 = obs.dtype == torch.uint8
+                    if not is_u8 and obs.dtype != torch.float32:
+                        raise hip.HipError(f"image observation `{enc.key}` must be uint8 or float32, got {obs.dtype}")
+                    mean = self.ws.get(f"{tag}{pending_obs_ln.prefix}.mean", n)
+                    rstd = self.ws.get(f"{tag}{pending_obs_ln.prefix}.rstd", n)
+                    hip.obs_ln_stats(obs.data_ptr(), is_u8, n, c * h * w, mean.data_ptr(), rstd.data_ptr())
+                    hip.im2col_obs_ln(obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(),
+                                      self._p(f"{pending_obs_ln.prefix}.weight"), self._p(f"{pending_obs_ln.prefix}.bias"),
+                                      n, c, h, w, L.k, L.k, L.stride, P.ptr)
+                    saved = (obs, is_u8, mean, rstd, pending_obs_ln)
+                else:
+                    h, w = L.in_hw
+                    assert cur.ld == L.cin and cur.rows == n * h * w
+                    hip.im2col_nhwc(cur.ptr, n, h, w, L.cin, L.k, L.k, L.stride, P.ptr)
+                    saved = None
+                y = self._buf(f"{tag}{L.prefix}.y", m, L.cout)
+                hip.gemm(m, L.cout, kdim, P.ptr, kdim, 0, self._p(f"{L.prefix}.weight"), kdim, 0, y.ptr, y.ld,
+                         bias=self._p(f"{L.prefix}.bias"), act=L.act)
+                tape.append(("conv", L, cur, (P, saved, n), cur_act))
+                cur, cur_act = y, L.act
+            else:  # pragma: no cover
+                raise TypeError(L)
+        return cur
+
+    def _chain_bwd(self, records: list, dy: Buf, tag: str, need_input_grad=False) -> Optional[Buf]:
+        """Walk tape records of one sequential chain backwards; dy is w.r.t. the chain's (pre-activation) output."""
+        g = dy
+        for idx in range(len(records) - 1, -1, -1):
+            kind, L, x, saved, in_act = records[idx]
+            need_dx = idx > 0 or need_input_grad
+            if kind == "ln":
+                g = self._ln_bwd(L, x, saved, g, in_act, need_dx, tag)
+            elif kind == "linear":
+                g = self._linear_bwd(L, x, g, in_act, need_dx, tag)
+            elif kind == "conv":
+                P, first_saved, n = saved
+                kdim = L.cin * L.k * L.k
+                m = g.rows
+                self._wgrad(L.cout, kdim, m, g, P.ptr, kdim, self._g(f"{L.prefix}.weight"))
+                hip.colsum(g.ptr, g.ld, m, L.cout, self._g(f"{L.prefix}.bias"), accumulate=True)
+                # dP = dZ W, written over the patch matrix (its last reader was the weight gradient above)
+                hip.gemm(m, kdim, L.cout, g.ptr, g.ld, 0, self._p(f"{L.prefix}.weight"), kdim, 1, P.ptr, kdim)
+                if L.first:
+                    obs, is_u8, mean, rstd, lnspec = first_saved
+                    c, h, w = lnspec.shape
+                    hip.obs_ln_affine_bwd(P.ptr, obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), n, c, h, w, L.k,
+                                          L.k, L.stride, self._g(f"{lnspec.prefix}.weight"),
+                                          self._g(f"{lnspec.prefix}.bias"))
+                    g = None
+                else:
+                    h, w = L.in_hw
+                    dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.cin)
+                    hip.col2im_nhwc(P.ptr, n, h, w, L.cin, L.k, L.k, L.stride, x.ptr if in_act else None, in_act, dx.ptr)
+                    g = dx
+            if g is not None and idx > 0:
+                # a Flatten between this record's input and the previous record's output: reshape the gradient
+                prev_out_cols = self._out_cols(records[idx - 1])
+                if g.cols != prev_out_cols:
+                    assert g.ld == g.cols and (g.rows * g.cols) % prev_out_cols == 0
+                    g = Buf(g.ptr, prev_out_cols, g.rows * g.cols // prev_out_cols, prev_out_cols)
+        return g
+
+    @staticmethod
+    def _out_cols(record):
+        kind, L = record[0], record[1]
+        if kind == "ln":
+            return L.dim
+        if kind == "linear":
+            return L.out_features
+        return L.cout
+
+    def _trunk_fwd(self, tag, encoders, backbone, obs: Dict[str, torch.Tensor], n: int):
+        enc_tapes, outs = [], []
+        for enc in encoders:
+            tape = []
+            if enc.key not in obs:
+                raise KeyError(f"observation key `{enc.key}` missing from the sample (has {list(obs)})")
+            outs.append(self._encoder_fwd(enc, obs[enc.key], n, tag, tape))
+            enc_tapes.append(tape)
+        if len(outs) == 1:
+            feat = outs[0]
+        else:
+            width = sum(o.cols for o in outs)
+            feat = self._buf(f"{tag}concat", n, width)
+            col = 0
+            for o in outs:
+                hip.copy2d(o.ptr, o.ld, feat.ptr + 4 * col, width, n, o.cols)
+                col += o.cols
+        bb_tape = []
+        cur, cur_act = feat, 0
+        for L in backbone:
+            if isinstance(L, ns.LinearSpec):
+                y = self._linear_fwd(L, cur, tag)
+                bb_tape.append(("linear", L, cur, None, cur_act))
+                cur, cur_act = y, L.act
+            else:
+                y, saved = self._ln_fwd(L, cur, tag)
+                bb_tape.append(("ln", L, cur, saved, cur_act))
+                cur, cur_act = y, 0
+        return cur, cur_act, (enc_tapes, bb_tape, [o.cols for o in outs])
+
+    def _trunk_bwd(self, tag, trunk_tape, dfeat: Buf):
+        enc_tapes, bb_tape, widths = trunk_tape
+        g = self._chain_bwd(bb_tape, dfeat, tag, need_input_grad=True) if bb_tape else dfeat
+        col = 0
+        for tape, wdt in zip(enc_tapes, widths):
+            sub = Buf(g.ptr + 4 * col, g.ld, g.rows, wdt)
+            self._chain_bwd(tape, sub, tag, need_input_grad=False)
+            col += wdt
+
+    # ------------------------------------------------------------------ public: forward / backward
+    def forward(self, obs: Dict[str, torch.Tensor], n: int, keep_tape: bool = True):
+        """obs leaves [n, ...] on the device.  Returns (logits [n, sum(A)], value [n, value_dim]) tensors
+        (views of workspace buffers, valid until the next forward)."""
+        hip.require_gpu()
+        sp = self.spec
+        a_feat, a_act, a_tape = self._trunk_fwd("a:", sp.obs_encoders, sp.actor_backbone, obs, n)
+        if sp.shared_backbone:
+            c_feat, c_act, c_tape = a_feat, a_act, None
+        else:
+            c_feat, c_act, c_tape = self._trunk_fwd("c:", sp.state_encoders, sp.critic_backbone, obs, n)
+        atot = sum(sp.act_dims)
+        logits_t = self.ws.get("logits", n * atot)
+        value_t = self.ws.get("value", n * sp.value_dim)
+        hip.gemm(n, atot, sp.hidden_dim, a_feat.ptr, a_feat.ld, 0, self._p("actor_head.weight"), sp.hidden_dim, 0,
+                 logits_t.data_ptr(), atot, bias=self._p("actor_head.bias"))
+        hip.gemm(n, sp.value_dim, sp.hidden_dim, c_feat.ptr, c_feat.ld, 0, self._p("critic_head.weight"), sp.hidden_dim,
+                 0, value_t.data_ptr(), sp.value_dim, bias=self._p("critic_head.bias"))
+        self._tape = (n, a_feat, a_act, a_tape, c_feat, c_act, c_tape) if keep_tape else None
+        return logits_t[:n * atot].view(n, atot), value_t[:n * sp.value_dim].view(n, sp.value_dim)
+
+    def backward(self, d_logits: torch.Tensor, d_value: torch.Tensor):
+        """Accumulate d loss / d parameters into ``self.grad`` given d loss / d logits and d loss / d value."""
+        if self._tape is None:
+            raise hip.HipError("backward() without a preceding forward(keep_tape=True)")
+        sp = self.spec
+        n, a_feat, a_act, a_tape, c_feat, c_act, c_tape = self._tape
+        atot = sum(sp.act_dims)
+        dl = Buf(d_logits.data_ptr(), atot, n, atot)
+        dv = Buf(d_value.data_ptr(), sp.value_dim, n, sp.value_dim)
+        da = self._linear_bwd(sp.actor_head, a_feat, dl, a_act, True, "a:")
+        if sp.shared_backbone:
+            self._linear_bwd(sp.critic_head, c_feat, dv, c_act, True, "a:", dx_into=da, dx_accumulate=True)
+            self._trunk_bwd("a:", a_tape, da)
+        else:
+            dc = self._linear_bwd(sp.critic_head, c_feat, dv, c_act, True, "c:")
+            self._trunk_bwd("a:", a_tape, da)
+            self._trunk_bwd("c:", c_tape, dc)
+        self._tape = None

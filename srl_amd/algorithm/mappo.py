@@ -1,0 +1,295 @@
+"""``MultiAgentPPO`` on the HIP kernels, registered as trainer ``"mappo"`` (and ``"mappo-hip"``).
+
+Mirror of reference ``legacy/algorithm/ppo/mappo.py``: same keyword hyper-parameters and defaults
+(``:68-116``), same ``step(sample) -> TrainerStepResult`` contract including the in-place mutations of the
+sample (``truncated`` default ``:222-223``; ``analyzed_result.adv/ret`` reset / written back as numpy,
+``:224-225,254-257``), same statistics keys (``:36-47,293-324``), ``get_checkpoint`` / ``load_checkpoint``
+(``:58-66``) with a torch-Adam-compatible ``optimizer_state_dict``.
+
+What runs where (one process per GPU):
+
+1. the sample's leaves go to HBM in their wire dtypes (no float32 widening, no one-call pipeline delay);
+2. ``srl_gae_scan``: value masking + GAE scan + returns + local advantage statistics in one launch;
+3. data parallel: ONE all-reduce of the 3 float64 statistics (the reference issues three, ``utils.py:58-61``);
+4. per row-chunk: network forward, ``srl_categorical_fwd``, ``srl_ppo_loss_fwd_bwd`` (loss, its gradient and
+   the logging sums in one pass), ``srl_categorical_bwd``, network backward into one flat gradient buffer;
+5. data parallel: one all-reduce of the flat gradient (mean over ranks = DDP semantics, ``api/policy.py:219-238``);
+6. ``srl_grad_sumsq`` + ``srl_adam_step``: global-norm clip fused into the Adam update;
+7. a single device->host copy of the loss terms per epoch (the reference syncs ~11 times, ``:293-299``).
+
+Loss-normalisation semantics under data parallelism are the reference's: every rank divides its masked
+sums by its LOCAL mask count, gradients are then averaged over ranks, while the advantage normalisation
+uses GLOBAL statistics.
+"""
+import logging
+from collections import defaultdict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from srl_amd import hip
+from srl_amd.algorithm.actor_critic import ActorCriticPolicy, to_device_leaf
+from srl_amd.api.trainer import PytorchTrainer, TrainerStepResult, register
+from srl_amd.namedarray import recursive_apply
+
+logger = logging.getLogger("MAPPO")
+
+_STAT_TERMS = (("policy_loss", hip.LT_POLICY), ("value_loss", hip.LT_VALUE), ("entropy", hip.LT_ENTROPY),
+               ("clip_ratio", hip.LT_CLIP), ("importance_weight", hip.LT_RATIO), ("advantage", hip.LT_ADV),
+               ("value_targets", hip.LT_RET))
+
+
+class MultiAgentPPO(PytorchTrainer):
+
+    def __init__(self, policy: ActorCriticPolicy, **kwargs):
+        super().__init__(policy)
+        g = kwargs.get
+        self.discount_rate = g("discount_rate", 0.99)
+        self.gae_lambda = g("gae_lambda", 0.97)
+        self.eps_clip = g("eps_clip", 0.2)
+        self.clip_value = g("clip_value", False)
+        self.dual_clip = g("dual_clip", True)
+        self.c_clip = g("c_clip", 3)
+        self.burn_in_steps = g("burn_in_steps", 0)
+        self.vtrace = g("vtrace", False)
+        self.recompute_adv_on_reuse = g("recompute_adv_on_reuse", True)
+        self.recompute_adv_among_epochs = g("recompute_adv_among_epochs", False)
+        self.normalize_old_value = g("normalize_old_value", False)
+        if self.clip_value and self.normalize_old_value != getattr(policy, "denormalize_value_during_rollout", False):
+            raise ValueError(
+                "Trainer `normalize_old_value` and policy `denormalize_value_during_rollout` should be consistent!")
+        self.value_eps_clip = g("value_eps_clip", self.eps_clip)
+        self.value_loss_weight = g('value_loss_weight', 0.5)
+        self.entropy_bonus_weight = g('entropy_bonus_weight', 0.01)
+        self.entropy_decay_per_steps = g("entropy_decay_per_steps", None)
+        self.entropy_bonus_decay = g("entropy_bonus_decay", 0.99)
+        self.max_grad_norm = g('max_grad_norm')
+        self.popart = g('popart', False)
+        self.bootstrap_steps = g("bootstrap_steps", 1)
+        self.ppo_epochs = g("ppo_epochs", 1)
+        if self.popart:
+            raise NotImplementedError("PopArt is a 'next' row (SURVEY.md 8f-2), not on the HIP path yet")
+        if self.vtrace:
+            raise NotImplementedError("V-trace through the trainer is a 'next' row (SURVEY.md 8f-4); the scan kernel "
+                                      "itself supports it (srl_gae_scan imp_ratio)")
+        if self.burn_in_steps:
+            raise NotImplementedError("burn-in only matters for recurrent policies, not on the HIP path yet")
+
+        name = g('optimizer', 'adam')
+        if name not in ('adam', 'adamw'):
+            raise NotImplementedError(f"optimizer `{name}`: only adam / adamw are implemented on the HIP path")
+        cfg = dict(g('optimizer_config', {}))
+        self._adamw = name == 'adamw'
+        self._lr = cfg.pop("lr", 1e-3)
+        self._betas = tuple(cfg.pop("betas", (0.9, 0.999)))
+        self._eps = cfg.pop("eps", 1e-8)
+        self._weight_decay = cfg.pop("weight_decay", 1e-2 if self._adamw else 0.0)
+        if cfg:
+            raise NotImplementedError(f"unsupported optimizer_config entries: {sorted(cfg)}")
+        value_loss = g('value_loss', 'mse')
+        if value_loss not in hip.VALUE_LOSS_KINDS:
+            raise AssertionError(f"Value loss name {value_loss} does not match any implemented loss functions "
+                                 f"({list(hip.VALUE_LOSS_KINDS)})")
+        vcfg = g('value_loss_config', {})
+        self._hp = hip.PpoHparams(eps_clip=self.eps_clip, c_clip=float(self.c_clip), value_eps_clip=self.value_eps_clip,
+                                  value_loss_weight=self.value_loss_weight,
+                                  entropy_bonus_weight=self.entropy_bonus_weight,
+                                  huber_delta=float(vcfg.get("delta", vcfg.get("beta", 1.0))), norm_eps=1e-5,
+                                  dual_clip=int(bool(self.dual_clip)), clip_value=int(bool(self.clip_value)),
+                                  value_loss=hip.VALUE_LOSS_KINDS[value_loss], mask_invert=1)
+
+        net = policy.net
+        self._m = torch.zeros_like(net.flat)
+        self._v = torch.zeros_like(net.flat)
+        self._opt_steps = 0
+        self.frames = 0
+        # rows (env-steps) per forward/backward chunk: bounds the activation workspace, not the arithmetic
+        self.chunk_rows = int(g("chunk_rows", 16384))
+        self._world = 1
+
+    # ------------------------------------------------------------------ checkpoints (mappo.py:58-66)
+    def get_checkpoint(self):
+        ckpt = self.policy.get_checkpoint()
+        net = self.policy.net
+        names = list(net.spec.params)
+        m = net.flat_to_reference(self._m.detach().cpu())
+        v = net.flat_to_reference(self._v.detach().cpu())
+        state = {
+            i: dict(step=torch.tensor(float(self._opt_steps)), exp_avg=m[n], exp_avg_sq=v[n])
+            for i, n in enumerate(names)
+        } if self._opt_steps > 0 else {}
+        group = dict(lr=self._lr, betas=self._betas, eps=self._eps, weight_decay=self._weight_decay, amsgrad=False,
+                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     params=list(range(len(names))))
+        ckpt.update({"optimizer_state_dict": {"state": state, "param_groups": [group]}})
+        return ckpt
+
+    def load_checkpoint(self, checkpoint, **kwargs):
+        osd = checkpoint.get("optimizer_state_dict")
+        if osd is not None:
+            net = self.policy.net
+            names = list(net.spec.params)
+            st = osd["state"]
+            if st:
+                self._m.copy_(net.reference_to_flat({n: st[i]["exp_avg"] for i, n in enumerate(names)}))
+                self._v.copy_(net.reference_to_flat({n: st[i]["exp_avg_sq"] for i, n in enumerate(names)}))
+                self._opt_steps = int(float(st[0]["step"]))
+            else:
+                self._m.zero_()
+                self._v.zero_()
+                self._opt_steps = 0
+            grp = osd["param_groups"][0]
+            self._lr, self._betas, self._eps = grp["lr"], tuple(grp["betas"]), grp["eps"]
+            self._weight_decay = grp.get("weight_decay", self._weight_decay)
+        self.policy.load_checkpoint(checkpoint)
+
+    def distributed(self, rank=None, world_size=None, init_method=None, **kwargs):
+        super().distributed(rank=rank, world_size=world_size, init_method=init_method, **kwargs)
+        self._world = dist.get_world_size() if dist.is_initialized() else 1
+
+    # ------------------------------------------------------------------ the step (mappo.py:219-328)
+    def step(self, sample):
+        hip.require_gpu()
+        dev = self.policy.device
+        net = self.policy.net
+        if sample.truncated is None:
+            sample.truncated = (torch.zeros_like(sample.done) if isinstance(sample.done, torch.Tensor) else
+                                np.zeros_like(sample.done))  # mappo.py:222-223
+        if self.recompute_adv_on_reuse:
+            sample.analyzed_result.adv = sample.analyzed_result.ret = None  # :224-225
+
+        on_reset = to_device_leaf(sample.on_reset, dev, "flag")
+        done = to_device_leaf(sample.done, dev, "flag")
+        truncated = to_device_leaf(sample.truncated, dev, "flag")
+        reward = to_device_leaf(sample.reward, dev, "real")
+        old_value = to_device_leaf(sample.analyzed_result.value, dev, "real")
+        old_lp = to_device_leaf(sample.analyzed_result.log_probs, dev, "real")
+        action = to_device_leaf(sample.action.x, dev, "index")
+        obs = {k: to_device_leaf(v, dev, "obs") for k, v in sample.obs.items() if v is not None}
+        avail = obs.pop("available_action", None)
+
+        Tb, B = on_reset.shape[0], on_reset.shape[1]
+        boot, burn = self.bootstrap_steps, self.burn_in_steps
+        lo, hi = burn, Tb - boot  # valid rows (mappo.py:259)
+        n_valid = (hi - lo) * B
+        Nc = old_value.shape[2] if old_value.dim() > 2 else 1
+        if Nc != 1:
+            raise NotImplementedError("value_dim > 1 through the PPO loss is not on the HIP path (the scan supports it)")
+
+        f64 = dict(dtype=torch.float64, device=dev)
+        stats_local = torch.zeros(3, **f64)
+        adv_d = ret_d = None
+        have_adv = sample.analyzed_result.adv is not None
+        train_stats = defaultdict(float)
+
+        for _ in range(self.ppo_epochs):
+            # ---- advantages / value targets ------------------------------------------------------------------
+            if adv_d is None:
+                if have_adv:
+                    adv_d = to_device_leaf(sample.analyzed_result.adv, dev, "real")
+                    ret_d = to_device_leaf(sample.analyzed_result.ret, dev, "real")
+                    fused_stats = False
+                else:
+                    if boot == 0:
+                        raise ValueError("bootstrap_steps == 0 requires advantages computed before the trainer")
+                    adv_d = torch.zeros((Tb, B, Nc), dtype=torch.float32, device=dev)  # last row = the zero pad (:254-256)
+                    ret_d = torch.zeros((Tb, B, Nc), dtype=torch.float32, device=dev)
+                    fused_stats = boot == 1 and burn == 0
+                    hip.gae_scan(reward, old_value, done, truncated, on_reset, self.discount_rate, self.gae_lambda, adv_d,
+                                 ret_d, stats=stats_local if fused_stats else None)
+                mask_rows = on_reset[1 + lo:1 + hi]  # loss_mask = 1 - on_reset[1+burn : 1+Tb-boot]  (:260-261)
+                if not fused_stats:
+                    hip.masked_stats(adv_d[lo:hi], mask_rows, stats_local, mask_invert=True)
+                stats_global = stats_local.clone()
+                if self._world > 1:
+                    dist.all_reduce(stats_global)  # one 24-byte message instead of three
+                local_n = stats_local[0:1]
+
+            # ---- forward / loss / backward over row chunks -----------------------------------------------------------
+            net.zero_grad()
+            flat = lambda t: t[lo:hi].reshape(n_valid, *t.shape[2:])
+            f_obs = {k: flat(v) for k, v in obs.items()}
+            f_avail = None if avail is None else flat(avail)
+            f_action, f_oldlp, f_oldv = flat(action), flat(old_lp).reshape(-1), flat(old_value).reshape(-1)
+            f_adv, f_ret, f_mask = flat(adv_d).reshape(-1), flat(ret_d).reshape(-1), mask_rows.reshape(-1)
+            f_done, f_trunc = flat(done).reshape(-1), flat(truncated).reshape(-1)
+            nchunks = max(1, -(-n_valid // self.chunk_rows))
+            terms = torch.zeros((nchunks, hip.LT_COUNT), **f64)
+            for ci in range(nchunks):
+                r0, r1 = ci * self.chunk_rows, min(n_valid, (ci + 1) * self.chunk_rows)
+                n = r1 - r0
+                c_obs = {k: v[r0:r1] for k, v in f_obs.items()}
+                c_avail = None if f_avail is None else f_avail[r0:r1]
+                logits, value = net.forward(c_obs, n, keep_tape=True)
+                logp = net.ws.get("new_logp", n)[:n]
+                ent = net.ws.get("entropy", n)[:n]
+                hip.categorical_fwd(logits, f_action[r0:r1], c_avail, net.spec.act_dims, logp, ent)
+                d_lp = net.ws.get("d_logp", n)[:n]
+                d_v = net.ws.get("d_value", n)[:n]
+                d_ent = net.ws.get("d_entropy", n)[:n]
+                hip.ppo_loss_fwd_bwd(logp, f_oldlp[r0:r1], value.reshape(-1), f_oldv[r0:r1], f_adv[r0:r1], f_ret[r0:r1],
+                                     ent, f_mask[r0:r1], self._hp, stats_global, local_n, d_lp, d_v, d_ent, terms[ci],
+                                     done=f_done[r0:r1], truncated=f_trunc[r0:r1])
+                d_logits = net.ws.get("d_logits", logits.numel())[:logits.numel()].view_as(logits)
+                hip.categorical_bwd(logits, f_action[r0:r1], c_avail, net.spec.act_dims, d_lp, d_ent, d_logits)
+                net.backward(d_logits, d_v.view(n, 1))
+
+            # ---- gradient reduction, clip, Adam (mappo.py:272-284) ---------------------------------------------------
+            if self._world > 1:
+                dist.all_reduce(net.grad)
+            sumsq = torch.zeros(1, **f64)
+            gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+            hip.grad_sumsq(net.grad, sumsq)
+            self._opt_steps += 1
+            hip.adam_step(net.flat, net.grad, self._m, self._v, self._lr, self._betas[0], self._betas[1], self._eps,
+                          self._weight_decay, self._adamw, self._opt_steps, grad_scale=1.0 / self._world,
+                          max_norm=-1.0 if self.max_grad_norm is None else float(self.max_grad_norm), sumsq=sumsq,
+                          grad_norm_out=gnorm)
+
+            if self.recompute_adv_among_epochs:
+                adv_d = ret_d = None
+                have_adv = False
+
+            # ---- statistics: the only device->host synchronisation of the epoch ----------------------------------------
+            host = torch.cat([terms.sum(0), gnorm.double()]).cpu().numpy()
+            msum = max(host[hip.LT_MASK], 1e-30)
+            for key, slot in _STAT_TERMS:
+                train_stats[key] += host[slot] / msum
+            train_stats["done"] += host[hip.LT_DONE] / max(n_valid, 1)
+            train_stats["truncated"] += host[hip.LT_TRUNC] / max(n_valid, 1)
+            train_stats["grad_norm"] += host[hip.LT_COUNT]
+
+        for k in train_stats:
+            train_stats[k] /= self.ppo_epochs
+
+        # advantages / returns go back into the numpy sample so that a re-used buffer entry carries them (:254-257)
+        if adv_d is not None and not have_adv and not isinstance(sample.reward, torch.Tensor):
+            sample.analyzed_result.adv = adv_d.cpu().numpy()
+            sample.analyzed_result.ret = ret_d.cpu().numpy()
+        elif adv_d is not None and not have_adv:
+            sample.analyzed_result.adv, sample.analyzed_result.ret = adv_d, ret_d
+        if self.recompute_adv_among_epochs:
+            sample.analyzed_result.adv = sample.analyzed_result.ret = None
+
+        self.policy.inc_version()  # once per step, not per epoch (:305-307)
+        if self.entropy_decay_per_steps and self.policy.version % self.entropy_decay_per_steps == 0:
+            self.entropy_bonus_weight *= self.entropy_bonus_decay
+            self._hp.entropy_bonus_weight = self.entropy_bonus_weight
+
+        self.frames += n_valid
+        info = {}
+        if sample.info_mask is not None and sample.info is not None:
+            im = sample.info_mask[lo:hi]
+            im = im.cpu().numpy() if isinstance(im, torch.Tensor) else np.asarray(im)
+            elapsed = im.sum()
+            if elapsed > 0:
+                info = recursive_apply(sample.info[lo:hi] * im, lambda x: x.sum()) / elapsed
+                info = {k: float(v) for k, v in info.items()}
+        stats = dict(frames=int(self.frames), **{k: float(v) for k, v in train_stats.items()}, **info)
+        return TrainerStepResult(stats=stats, step=self.policy.version)
+
+
+register('mappo', MultiAgentPPO)
+register('mappo-hip', MultiAgentPPO)

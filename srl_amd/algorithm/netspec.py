@@ -271,6 +271,20 @@ def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim
     act_dims = [action_dim] if isinstance(action_dim, int) else list(action_dim)
     cnn_layers = cnn_layers or {}
 
+    # LAPACK's QR inside orthogonal_ rounds differently with different thread counts; pin it so that a seed
+    # always gives the same weights (and the same as the single-threaded reference run the fixtures record)
+    threads = torch.get_num_threads()
+    if seed is not None:
+        torch.set_num_threads(1)
+    try:
+        return _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation,
+                      layernorm, shared_backbone, seed)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation, layernorm,
+           shared_backbone, seed):
     b = _Builder(seed)
     obs_enc = _build_encoders(b, "obs_modules_dict", obs_dims, hidden_dim, act, activation, cnn_layers)
     actor_bb = _build_backbone(b, "actor_backbone", hidden_dim * len(obs_dims), hidden_dim, num_dense_layers, act,

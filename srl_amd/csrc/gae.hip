@@ -221,11 +221,11 @@ extern "C" int srl_gae_scan(void* stream, const float* reward, const float* valu
                             const uint8_t* truncated, const uint8_t* on_reset, const float* imp_ratio, int T, int B,
                             int Nc, double gamma, double lambda, double rho, double c, float* adv, float* ret,
                             double* stats) {
-  SRL_CHECK_ARG(reward && value && done && truncated && on_reset && adv && ret, "null tensor");
   SRL_CHECK_ARG(T >= 0 && B >= 0 && Nc >= 1, "T, B >= 0 and Nc >= 1 required");
   hipStream_t st = (hipStream_t)stream;
   if (stats) SRL_HIP_TRY(hipMemsetAsync(stats, 0, 3 * sizeof(double), st));
-  if (T == 0 || B == 0) return 0;
+  if (T == 0 || B == 0) return 0;  // empty batch: nothing to scan (tensors may be null)
+  SRL_CHECK_ARG(reward && value && done && truncated && on_reset && adv && ret, "null tensor");
   GaeParams p{reward, value, done, truncated, on_reset, imp_ratio, adv, ret, stats, T, B, Nc, 0,
               gamma,  lambda, rho,  c};
   const long ncols = (long)B * Nc;

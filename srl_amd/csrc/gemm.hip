@@ -16,6 +16,8 @@
 // MFMAs of tile t and written to LDS after them (register double buffering).
 #include "srl_common.h"
 
+static_assert(sizeof(srl_gemm_desc) == 144 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -32,6 +32,7 @@ struct LossArgs {
   srl_ppo_hparams hp;
   const double* norm_stats;
   const double* local_n;
+  const uint8_t *done, *truncated;
   float *d_new_lp, *d_value, *d_entropy;
   double* terms;
 };
@@ -105,6 +106,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs a) {
     acc[SRL_LT_ADV] += md * (double)adv;
     acc[SRL_LT_RET] += md * (double)tgt;
     acc[SRL_LT_MASK] += md;
+    if (a.done) acc[SRL_LT_DONE] += (double)a.done[i];
+    if (a.truncated) acc[SRL_LT_TRUNC] += (double)a.truncated[i];
   }
   block_sum<SRL_LT_COUNT, 256>(acc, red);
   if (threadIdx.x == 0) {
@@ -266,8 +269,8 @@ int make_heads(int n_heads, const int32_t* dims, Heads& h, int& atot) {
 extern "C" int srl_ppo_loss_fwd_bwd(void* stream, const float* new_lp, const float* old_lp, const float* value,
                                     const float* old_value, const float* adv, const float* ret, const float* entropy,
                                     const uint8_t* mask, long n, const srl_ppo_hparams* hp, const double* norm_stats,
-                                    const double* local_n, float* d_new_lp, float* d_value, float* d_entropy,
-                                    double* loss_terms) {
+                                    const double* local_n, const uint8_t* done, const uint8_t* truncated,
+                                    float* d_new_lp, float* d_value, float* d_entropy, double* loss_terms) {
   SRL_CHECK_ARG(new_lp && old_lp && value && adv && ret && entropy && mask && hp && norm_stats && local_n,
                 "null input");
   SRL_CHECK_ARG(d_new_lp && d_value && d_entropy && loss_terms, "null output");
@@ -277,7 +280,7 @@ extern "C" int srl_ppo_loss_fwd_bwd(void* stream, const float* new_lp, const flo
   SRL_HIP_TRY(hipMemsetAsync(loss_terms, 0, SRL_LT_COUNT * sizeof(double), st));
   if (n == 0) return 0;
   LossArgs a{new_lp, old_lp, value, old_value, adv, ret, entropy, mask, n, *hp, norm_stats, local_n,
-             d_new_lp, d_value, d_entropy, loss_terms};
+             done, truncated, d_new_lp, d_value, d_entropy, loss_terms};
   const unsigned grid = (unsigned)(srl_ceil_div(n, 256) < 2048 ? srl_ceil_div(n, 256) : 2048);
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(grid), dim3(256), 0, st, a);
   SRL_LAUNCH_CHECK();

@@ -19,7 +19,7 @@ _lib = None
 ABI_VERSION = 1
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
-LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_COUNT = range(9)
+LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 VALUE_LOSS_KINDS = {"mse": 0, "huber": 1, "smoothl1": 2}
 MAX_HEADS = 8
@@ -52,7 +52,7 @@ _SIGNATURES = {
     "srl_masked_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "srl_masked_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_double, c_int,
                                       c_void_p]),
-    "srl_ppo_loss_fwd_bwd": (c_int, [c_void_p] + [c_void_p] * 8 + [c_long, POINTER(PpoHparams)] + [c_void_p] * 6),
+    "srl_ppo_loss_fwd_bwd": (c_int, [c_void_p] + [c_void_p] * 8 + [c_long, POINTER(PpoHparams)] + [c_void_p] * 8),
     "srl_categorical_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, POINTER(c_int32),
                                      c_void_p, c_void_p]),
     "srl_categorical_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, POINTER(c_int32),
@@ -170,14 +170,15 @@ def masked_normalize(x, mask, stats, out, mask_invert=False, eps=1e-5, unbiased=
 
 
 def ppo_loss_fwd_bwd(new_lp, old_lp, value, old_value, adv, ret, entropy, mask, hp: PpoHparams, norm_stats, local_n,
-                     d_new_lp, d_value, d_entropy, loss_terms):
+                     d_new_lp, d_value, d_entropy, loss_terms, done=None, truncated=None):
     f = torch.float32
     _check(
         lib().srl_ppo_loss_fwd_bwd(_stream(), _ptr(new_lp, f, "new_lp"), _ptr(old_lp, f, "old_lp"),
                                    _ptr(value, f, "value"), _ptr(old_value, f, "old_value"), _ptr(adv, f, "adv"),
                                    _ptr(ret, f, "ret"), _ptr(entropy, f, "entropy"), _ptr(mask, torch.uint8, "mask"),
                                    new_lp.numel(), ctypes.byref(hp), _ptr(norm_stats, torch.float64, "norm_stats"),
-                                   _ptr(local_n, torch.float64, "local_n"), _ptr(d_new_lp, f, "d_new_lp"),
+                                   _ptr(local_n, torch.float64, "local_n"), _ptr(done, torch.uint8, "done"),
+                                   _ptr(truncated, torch.uint8, "truncated"), _ptr(d_new_lp, f, "d_new_lp"),
                                    _ptr(d_value, f, "d_value"), _ptr(d_entropy, f, "d_entropy"),
                                    _ptr(loss_terms, torch.float64, "loss_terms")), "srl_ppo_loss_fwd_bwd")
 

@@ -1,0 +1,459 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (ctypes binding ``srl_amd.hip``).
+
+Each kernel is compared with the CPU oracle (``oracle/``) on the same seeded inputs and with the golden
+vectors generated from the real reference (``tests/golden/*.npz``).  Tolerances: GAE returns and PPO loss
+1e-5 relative (the bar BASELINE.json states); network pieces are float32 MFMA chains checked at 1e-5
+relative to the scale of the output (float64-referenced where cheap).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gae as ogae
+from oracle import ppo as oppo
+from srl_amd import hip
+from srl_amd.runtime import synthetic
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def rel_close(a, b, rtol=1e-5, scale=None):
+    """|a-b| <= rtol * max(|b|, scale): the tolerance form of SURVEY.md section 7."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = float(np.abs(b).max()) if scale is None else scale
+    return bool((np.abs(a - b) <= rtol * np.maximum(np.abs(b), max(scale, 1e-30))).all())
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+def run_gae(arr, gamma, lmbda, ratio=None):
+    Tb, B = arr["on_reset"].shape[:2]
+    Nc = arr["value"].shape[2]
+    adv = torch.full((Tb, B, Nc), 7.0, device=DEV)
+    ret = torch.full((Tb, B, Nc), 7.0, device=DEV)
+    stats = torch.full((3,), -1.0, dtype=torch.float64, device=DEV)
+    hip.gae_scan(dev(arr["reward"]), dev(arr["value"]), dev(arr["done"]), dev(arr["truncated"]), dev(arr["on_reset"]),
+                 gamma, lmbda, adv, ret, stats=stats, imp_ratio=None if ratio is None else dev(ratio))
+    torch.cuda.synchronize()
+    return adv.cpu().numpy(), ret.cpu().numpy(), stats.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ GAE
+def test_gae_golden_cases(golden):
+    g = golden("gae.npz")
+    for name in g["cases"]:
+        arr = {k: g[f"{name}_{k}"] for k in ("reward", "value", "done", "truncated", "on_reset")}
+        for tag, gam, lam in (("a", 0.99, 0.97), ("b", 0.9, 0.5)):
+            adv, ret, stats = run_gae(arr, gam, lam)
+            ref_adv, ref_ret = g[f"{name}_{tag}_adv"], g[f"{name}_{tag}_ret"]
+            T = ref_adv.shape[0]
+            assert rel_close(adv[:T], ref_adv, 1e-5, scale=1.0), (name, tag)
+            assert rel_close(ret[:T], ref_ret, 1e-5, scale=1.0), (name, tag)
+            assert (adv[T:] == 7.0).all() and (ret[T:] == 7.0).all()  # the pad row is the caller's
+            mask = 1.0 - arr["on_reset"][1:].astype(np.float64)
+            n, s, q = oppo.masked_stats(np.broadcast_to(ref_adv, ref_adv.shape), np.broadcast_to(mask, ref_adv.shape))
+            assert stats[0] == n
+            assert abs(stats[1] - s) <= 1e-5 * max(1.0, q**0.5) and abs(stats[2] - q) <= 1e-6 * max(1, q)
+        adv, _, _ = run_gae(arr, 0.99, 0.97, ratio=g[f"{name}_ratio"])
+        assert rel_close(adv[:T], g[f"{name}_vtrace_adv"], 1e-5, scale=1.0), (name, "vtrace")
+
+
+def test_gae_hand_case(golden):
+    """The hand-computed vector of the reference's own test (legacy/tests/modules_test.py:119-138)."""
+    g = golden("gae.npz")
+    shp = lambda x: x.reshape(-1, 1, 1)
+    arr = dict(reward=shp(g["hand_reward"]), value=shp(g["hand_value"]), done=shp(g["hand_done"]).astype(np.uint8),
+               truncated=shp(g["hand_truncated"]).astype(np.uint8), on_reset=shp(g["hand_on_reset"]).astype(np.uint8))
+    adv, _, _ = run_gae(arr, 0.1, 0.1)
+    expect = np.array([2.1 * 0.01 - 1, 2.1, 0, -0.8 + 0.01, 1, 0, 0.111, 1.1])
+    keep = 1 - g["hand_on_reset"][1:]
+    np.testing.assert_array_almost_equal(adv[:8, 0, 0] * keep, expect * keep)
+    # note: the reference's value at done is NOT pre-masked in this test; the kernel masks value by done itself
+
+
+@pytest.mark.parametrize("T,B,Nc", [(1, 1, 1), (2, 3, 1), (128, 512, 1), (400, 37, 1), (130, 70, 2), (1000, 9, 1),
+                                    (16, 40000, 1)])
+def test_gae_shapes_vs_oracle(T, B, Nc):
+    arr = synthetic.make_sample_arrays(seed=T + B, T=T, B=B, obs_spec={}, action_dims=2, p_done=0.03, value_dim=Nc)
+    a = dict(reward=arr["reward"], value=arr["analyzed_result.value"], done=arr["done"], truncated=arr["truncated"],
+             on_reset=arr["on_reset"])
+    adv, ret, stats = run_gae(a, 0.99, 0.97)
+    o_adv, o_ret = ogae.adv_and_value_target(a["reward"], a["value"], a["truncated"], a["done"], a["on_reset"], 0.99,
+                                             0.97)
+    assert rel_close(adv[:T], o_adv, 1e-5, scale=1.0)
+    assert rel_close(ret[:T], o_ret, 1e-5, scale=1.0)
+    mask = np.broadcast_to(1.0 - a["on_reset"][1:].astype(np.float64), o_adv.shape)
+    n, s, q = oppo.masked_stats(o_adv, mask)
+    assert stats[0] == n and abs(stats[1] - s) <= 1e-6 * max(1.0, abs(s), q**0.5) and abs(stats[2] - q) <= 1e-6 * q + 1e-9
+
+
+def test_gae_empty():
+    z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=DEV)
+    stats = torch.ones(3, dtype=torch.float64, device=DEV)
+    hip.gae_scan(z(1, 0, 1), z(1, 0, 1), z(1, 0, 1, dt=torch.uint8), z(1, 0, 1, dt=torch.uint8),
+                 z(1, 0, 1, dt=torch.uint8), 0.99, 0.97, z(1, 0, 1), z(1, 0, 1), stats=stats)
+    assert (stats.cpu().numpy() == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ normalisation
+def test_masked_normalize_golden(golden):
+    g = golden("norm.npz")
+    x, mask = g["x"], g["mask"]
+    for tag, m, unb in (("masked", mask, False), ("nomask", None, False), ("unbiased", mask, True)):
+        stats = torch.zeros(3, dtype=torch.float64, device=DEV)
+        md = None if m is None else dev(m, torch.uint8)
+        hip.masked_stats(dev(x), md, stats)
+        assert np.allclose(stats.cpu().numpy(), g[f"{tag}_stats"], rtol=1e-12)
+        out = torch.empty(x.shape, device=DEV)
+        hip.masked_normalize(dev(x), md, stats, out, unbiased=unb)
+        assert rel_close(out.cpu().numpy(), g[f"{tag}_out"], 1e-5, scale=1.0), tag
+    # inverted-byte form (mask = 1 - on_reset)
+    stats = torch.zeros(3, dtype=torch.float64, device=DEV)
+    hip.masked_stats(dev(x), dev(1 - mask, torch.uint8), stats, mask_invert=True)
+    assert np.allclose(stats.cpu().numpy(), g["masked_stats"], rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ PPO loss
+def _hp(vl, cv, dc, **kw):
+    base = dict(eps_clip=0.2, c_clip=3.0, value_eps_clip=0.2, value_loss_weight=0.5, entropy_bonus_weight=0.01,
+                huber_delta=10.0 if vl == "huber" else 1.0, norm_eps=1e-5, dual_clip=int(dc), clip_value=int(cv),
+                value_loss=hip.VALUE_LOSS_KINDS[vl], mask_invert=0)
+    base.update(kw)
+    return hip.PpoHparams(**base)
+
+
+def run_loss(inp, hp):
+    n = inp["new_lp"].size
+    f = lambda k: dev(inp[k]).reshape(-1)
+    mask = dev(inp["mask"], torch.uint8).reshape(-1)
+    stats = torch.zeros(3, dtype=torch.float64, device=DEV)
+    hip.masked_stats(f("adv"), mask, stats)
+    outs = [torch.empty(n, device=DEV) for _ in range(3)]
+    terms = torch.empty(hip.LT_COUNT, dtype=torch.float64, device=DEV)
+    hip.ppo_loss_fwd_bwd(f("new_lp"), f("old_lp"), f("value"), f("old_value"), f("adv"), f("ret"), f("entropy"), mask, hp,
+                         stats, stats[0:1], *outs, terms)
+    t = terms.cpu().numpy()
+    m = t[hip.LT_MASK]
+    loss = (t[hip.LT_POLICY] + hp.value_loss_weight * t[hip.LT_VALUE] - hp.entropy_bonus_weight * t[hip.LT_ENTROPY]) / m
+    stats_out = dict(loss=loss, policy_loss=t[hip.LT_POLICY] / m, value_loss=t[hip.LT_VALUE] / m,
+                     entropy=t[hip.LT_ENTROPY] / m, clip_ratio=t[hip.LT_CLIP] / m, importance_weight=t[hip.LT_RATIO] / m,
+                     advantage=t[hip.LT_ADV] / m, value_targets=t[hip.LT_RET] / m)
+    return stats_out, [o.cpu().numpy().reshape(inp["new_lp"].shape) for o in outs]
+
+
+def test_ppo_loss_golden(golden):
+    g = golden("loss.npz")
+    inp = {k: g[k] for k in ("new_lp", "old_lp", "value", "old_value", "adv", "ret", "entropy", "mask")}
+    names = list(g["stat_names"])
+    for combo in g["combos"]:
+        vl, cv, dc = combo.split("_")
+        stats, grads = run_loss(inp, _hp(vl, cv == "1", dc == "1"))
+        ref = dict(zip(names, g[f"{combo}_stats"]))
+        for k, v in ref.items():
+            assert abs(stats[k] - v) <= 1e-5 * max(abs(v), 1e-3), (combo, k, stats[k], v)
+        for got, key in zip(grads, ("d_new_lp", "d_value", "d_entropy")):
+            assert rel_close(got, g[f"{combo}_{key}"], 1e-5), (combo, key)
+
+
+def test_ppo_loss_vs_oracle_large():
+    rng = np.random.default_rng(0)
+    shape = (128, 300, 1)
+    inp = dict(new_lp=-1 + 0.4 * rng.standard_normal(shape), old_lp=-1 + 0.4 * rng.standard_normal(shape),
+               value=rng.standard_normal(shape), old_value=rng.standard_normal(shape), adv=3 * rng.standard_normal(shape),
+               ret=2 * rng.standard_normal(shape), entropy=1 + 0.1 * rng.standard_normal(shape),
+               mask=(rng.random(shape) < 0.9))
+    inp = {k: v.astype(np.float32) for k, v in inp.items()}
+    for vl, cv, dc in (("mse", False, True), ("huber", True, False), ("smoothl1", True, True)):
+        stats, grads = run_loss(inp, _hp(vl, cv, dc))
+        t = lambda k, g=False: torch.from_numpy(inp[k]).clone().requires_grad_(g)
+        nlp, v, ent = t("new_lp", True), t("value", True), t("entropy", True)
+        loss, ostats = oppo.ppo_loss(nlp, t("old_lp"), v, t("old_value"), t("adv"), t("ret"), ent, t("mask"),
+                                     dual_clip=dc, value_loss=vl, clip_value=cv,
+                                     value_loss_config=dict(delta=10.0) if vl == "huber" else {})
+        loss.backward()
+        assert abs(stats["loss"] - loss.item()) <= 1e-5 * abs(loss.item())
+        for k, val in ostats.items():
+            assert abs(stats[k] - val) <= 1e-5 * max(abs(val), 1e-3), (vl, k)
+        for got, ref in zip(grads, (nlp.grad, v.grad, ent.grad)):
+            assert rel_close(got, ref.numpy(), 1e-5), vl
+
+
+# ------------------------------------------------------------------------------------------------ categorical
+def _cat_ref(logits, action, dims, avail=None):
+    lg = torch.from_numpy(logits).clone().requires_grad_(True)
+    x = lg if avail is None else lg.masked_fill(torch.from_numpy(avail) == 0, -1e10)
+    lp, ent, s = 0, 0, 0
+    for k, d in enumerate(dims):
+        dist = torch.distributions.Categorical(logits=x[:, s:s + d])
+        lp = lp + dist.log_prob(torch.from_numpy(action[:, k]).long())
+        ent = ent + dist.entropy()
+        s += d
+    return lg, lp, ent
+
+
+@pytest.mark.parametrize("dims,use_avail", [([2], False), ([6], False), ([3, 4], False), ([9], True), ([18], False)])
+def test_categorical_fwd_bwd(dims, use_avail):
+    rng = np.random.default_rng(1)
+    n, atot = 1000, sum(dims)
+    logits = (2 * rng.standard_normal((n, atot))).astype(np.float32)
+    action = np.stack([rng.integers(0, d, n) for d in dims], -1).astype(np.int32)
+    avail = None
+    if use_avail:
+        avail = (rng.random((n, atot)) < 0.6)
+        avail[np.arange(n), action[:, 0]] = True
+        avail = avail.astype(np.uint8)
+    lp = torch.empty(n, device=DEV)
+    ent = torch.empty(n, device=DEV)
+    av = None if avail is None else dev(avail)
+    hip.categorical_fwd(dev(logits), dev(action), av, dims, lp, ent)
+    lg, rlp, rent = _cat_ref(logits, action, dims, avail)
+    assert rel_close(lp.cpu().numpy(), rlp.detach().numpy(), 1e-5, scale=1.0)
+    assert rel_close(ent.cpu().numpy(), rent.detach().numpy(), 1e-5, scale=1.0)
+    glp = rng.standard_normal(n).astype(np.float32)
+    gent = rng.standard_normal(n).astype(np.float32)
+    (rlp * torch.from_numpy(glp) + rent * torch.from_numpy(gent)).sum().backward()
+    dl = torch.empty((n, atot), device=DEV)
+    hip.categorical_bwd(dev(logits), dev(action), av, dims, dev(glp), dev(gent), dl)
+    assert rel_close(dl.cpu().numpy(), lg.grad.numpy(), 2e-5, scale=1.0)
+
+
+def test_categorical_sample_distribution_and_eval():
+    dims = [5]
+    n = 200000
+    logits = np.tile(np.log(np.array([0.1, 0.2, 0.3, 0.25, 0.15], np.float32)), (n, 1))
+    is_eval = np.zeros(n, np.uint8)
+    is_eval[:100] = 1
+    act = torch.empty((n, 1), dtype=torch.int64, device=DEV)
+    lp = torch.empty((n, 1), device=DEV)
+    hip.categorical_sample(dev(logits), None, dev(is_eval), dims, 123, 0, act, lp)
+    a = act.cpu().numpy()[:, 0]
+    assert (a[:100] == 2).all()  # argmax rows
+    freq = np.bincount(a[100:], minlength=5) / (n - 100)
+    assert np.abs(freq - np.array([0.1, 0.2, 0.3, 0.25, 0.15])).max() < 5e-3
+    assert np.allclose(lp.cpu().numpy()[:, 0], logits[np.arange(n), a], atol=1e-5)
+    # same (seed, offset) -> same stream; different offset -> different stream
+    act2 = torch.empty_like(act)
+    hip.categorical_sample(dev(logits), None, dev(is_eval), dims, 123, 0, act2, lp)
+    assert torch.equal(act, act2)
+    hip.categorical_sample(dev(logits), None, dev(is_eval), dims, 123, 1, act2, lp)
+    assert not torch.equal(act, act2)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _gemm_ref(A, B, akm, bkm):
+    A64 = A.astype(np.float64).T if akm else A.astype(np.float64)
+    B64 = B.astype(np.float64) if bkm else B.astype(np.float64).T
+    return A64 @ B64
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 64, 64), (1000, 2, 64), (300, 64, 4), (513, 130, 77), (64, 512, 3136),
+                                   (4096, 32, 256), (130, 7, 512), (33, 300, 50)])
+@pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1)])
+def test_gemm_orientations(M, N, K, akm, bkm):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M) if akm else (M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N) if bkm else (N, K)).astype(np.float32)
+    C = torch.full((M, N), np.nan, device=DEV)
+    dA, dB = dev(A), dev(B)
+    hip.gemm(M, N, K, dA.data_ptr(), A.shape[1], akm, dB.data_ptr(), B.shape[1], bkm, C.data_ptr(), N)
+    ref = _gemm_ref(A, B, akm, bkm)
+    assert rel_close(C.cpu().numpy(), ref, 1e-5, scale=float(np.sqrt(K)))
+
+
+def test_gemm_epilogues_and_split():
+    rng = np.random.default_rng(5)
+    M, N, K = 700, 96, 200
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((N, K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dA, dW, db = dev(A), dev(W), dev(b)
+    for act, fn in ((1, lambda z: np.maximum(z, 0)), (2, np.tanh)):
+        C = torch.empty((M, N), device=DEV)
+        hip.gemm(M, N, K, dA.data_ptr(), K, 0, dW.data_ptr(), K, 0, C.data_ptr(), N, bias=db.data_ptr(), act=act)
+        ref = fn(A.astype(np.float64) @ W.astype(np.float64).T + b)
+        if act == 1:
+            assert rel_close(C.cpu().numpy(), ref, 1e-5, scale=float(np.sqrt(K)))
+        else:  # |tanh'| <= 1: the pre-activation error bound carries over as an absolute bound
+            assert np.abs(C.cpu().numpy() - ref).max() <= 1e-5 * np.sqrt(K)
+    # dgrad with the activation mask of the producer, accumulated on top of existing contents
+    Y = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    dZ = rng.standard_normal((M, N)).astype(np.float32)
+    base = rng.standard_normal((M, K)).astype(np.float32)
+    C = dev(base).clone()
+    dY, ddZ = dev(Y), dev(dZ)
+    hip.gemm(M, K, N, ddZ.data_ptr(), N, 0, dW.data_ptr(), K, 1, C.data_ptr(), K, dact_src=dY.data_ptr(), ld_dact=K,
+             dact=1, accumulate=True)
+    ref = base + (dZ.astype(np.float64) @ W.astype(np.float64)) * (Y > 0)
+    assert rel_close(C.cpu().numpy(), ref, 1e-5, scale=float(np.sqrt(N)))
+    # weight gradient with split-K through a workspace, accumulated
+    rows = 50000
+    dZ = rng.standard_normal((rows, 40)).astype(np.float32)
+    X = rng.standard_normal((rows, 72)).astype(np.float32)
+    g0 = rng.standard_normal((40, 72)).astype(np.float32)
+    G = dev(g0).clone()
+    ws = torch.empty(16 * 40 * 72, device=DEV)
+    ddZ, dX = dev(dZ), dev(X)
+    hip.gemm(40, 72, rows, ddZ.data_ptr(), 40, 1, dX.data_ptr(), 72, 1, G.data_ptr(), 72, accumulate=True, split_k=16,
+             workspace=ws.data_ptr())
+    ref = g0 + dZ.astype(np.float64).T @ X.astype(np.float64)
+    assert rel_close(G.cpu().numpy(), ref, 1e-5, scale=float(np.sqrt(rows)))
+
+
+def test_gemm_strided_views():
+    """Operands / outputs that are column slices of wider buffers (observation concat, head slices)."""
+    rng = np.random.default_rng(9)
+    M, N, K, LD = 200, 24, 40, 100
+    wide = rng.standard_normal((M, LD)).astype(np.float32)
+    W = rng.standard_normal((N, K)).astype(np.float32)
+    dwide, dW = dev(wide), dev(W)
+    out = torch.zeros((M, 64), device=DEV)
+    hip.gemm(M, N, K, dwide.data_ptr() + 4 * 12, LD, 0, dW.data_ptr(), K, 0, out.data_ptr() + 4 * 8, 64)
+    ref = wide[:, 12:12 + K].astype(np.float64) @ W.astype(np.float64).T
+    got = out.cpu().numpy()
+    assert rel_close(got[:, 8:8 + N], ref, 1e-5, scale=float(np.sqrt(K)))
+    assert (got[:, :8] == 0).all() and (got[:, 8 + N:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,D", [(1, 4), (1000, 4), (777, 64), (300, 512), (65, 100)])
+def test_layernorm_fwd_bwd(rows, D):
+    rng = np.random.default_rng(rows + D)
+    x = (rng.standard_normal((rows, D)) * 2 + 0.5).astype(np.float32)
+    x = np.maximum(x, 0)  # pretend it came out of a ReLU, to exercise the fused mask
+    gamma = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    dy = rng.standard_normal((rows, D)).astype(np.float32)
+    dx_, dg_, db_ = dev(x), dev(gamma), dev(beta)
+    y = torch.empty((rows, D), device=DEV)
+    mean = torch.empty(rows, device=DEV)
+    rstd = torch.empty(rows, device=DEV)
+    hip.layernorm_fwd(dx_.data_ptr(), D, dg_.data_ptr(), db_.data_ptr(), rows, D, y.data_ptr(), D, mean.data_ptr(),
+                      rstd.data_ptr())
+    tx = torch.from_numpy(x).double().requires_grad_(True)
+    tg = torch.from_numpy(gamma).double().requires_grad_(True)
+    tb = torch.from_numpy(beta).double().requires_grad_(True)
+    pre = tx.clone()
+    ty = torch.nn.functional.layer_norm(torch.relu(pre), (D,), tg, tb, 1e-5)
+    assert rel_close(y.cpu().numpy(), ty.detach().numpy(), 1e-5, scale=1.0)
+    ty.backward(torch.from_numpy(dy).double())
+    ddy = dev(dy)
+    dxo = torch.empty((rows, D), device=DEV)
+    dgo = torch.zeros(D, device=DEV)
+    dbo = torch.zeros(D, device=DEV)
+    hip.layernorm_bwd(ddy.data_ptr(), D, dx_.data_ptr(), D, dg_.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D,
+                      dxo.data_ptr(), D, 1, dgo.data_ptr(), dbo.data_ptr())
+    assert rel_close(dxo.cpu().numpy(), tx.grad.numpy(), 2e-5, scale=1.0)
+    assert rel_close(dgo.cpu().numpy(), tg.grad.numpy(), 2e-5, scale=float(np.sqrt(rows)))
+    assert rel_close(dbo.cpu().numpy(), tb.grad.numpy(), 2e-5, scale=float(np.sqrt(rows)))
+
+
+# ------------------------------------------------------------------------------------------------ convolution pieces
+def test_obs_ln_im2col_and_affine_bwd():
+    rng = np.random.default_rng(3)
+    n, C, H, W, k, s = 5, 4, 84, 84, 8, 4
+    obs = rng.integers(0, 256, (n, C, H, W), dtype=np.uint8)
+    gamma = (1 + 0.1 * rng.standard_normal((C, H, W))).astype(np.float32)
+    beta = (0.1 * rng.standard_normal((C, H, W))).astype(np.float32)
+    dobs, dg, db = dev(obs), dev(gamma), dev(beta)
+    mean = torch.empty(n, device=DEV)
+    rstd = torch.empty(n, device=DEV)
+    hip.obs_ln_stats(dobs.data_ptr(), True, n, C * H * W, mean.data_ptr(), rstd.data_ptr())
+    x64 = obs.astype(np.float64)
+    mu = x64.reshape(n, -1).mean(1)
+    var = x64.reshape(n, -1).var(1)
+    assert rel_close(mean.cpu().numpy(), mu, 1e-6) and rel_close(rstd.cpu().numpy(), 1 / np.sqrt(var + 1e-5), 1e-6)
+    OH = (H - k) // s + 1
+    P = torch.empty((n * OH * OH, C * k * k), device=DEV)
+    hip.im2col_obs_ln(dobs.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), db.data_ptr(), n, C, H, W, k,
+                      k, s, P.data_ptr())
+    xn = torch.nn.functional.layer_norm(torch.from_numpy(x64), (C, H, W), torch.from_numpy(gamma).double(),
+                                        torch.from_numpy(beta).double(), 1e-5)
+    ref = torch.nn.functional.unfold(xn, k, stride=s).transpose(1, 2).reshape(n * OH * OH, C * k * k)
+    assert rel_close(P.cpu().numpy(), ref.numpy(), 1e-5, scale=1.0)
+    # float32 observations take the same path
+    dobs_f = dev(obs.astype(np.float32))
+    hip.obs_ln_stats(dobs_f.data_ptr(), False, n, C * H * W, mean.data_ptr(), rstd.data_ptr())
+    assert rel_close(mean.cpu().numpy(), mu, 1e-6)
+    # affine gradients: d/dgamma, d/dbeta of sum(P * dP)
+    dP = rng.standard_normal((n * OH * OH, C * k * k)).astype(np.float32)
+    tg = torch.from_numpy(gamma).double().requires_grad_(True)
+    tb = torch.from_numpy(beta).double().requires_grad_(True)
+    xn2 = torch.nn.functional.layer_norm(torch.from_numpy(x64), (C, H, W), tg, tb, 1e-5)
+    p2 = torch.nn.functional.unfold(xn2, k, stride=s).transpose(1, 2).reshape(n * OH * OH, C * k * k)
+    (p2 * torch.from_numpy(dP).double()).sum().backward()
+    gg = torch.zeros((C, H, W), device=DEV)
+    gb = torch.zeros((C, H, W), device=DEV)
+    hip.obs_ln_stats(dobs.data_ptr(), True, n, C * H * W, mean.data_ptr(), rstd.data_ptr())
+    ddP = dev(dP)
+    hip.obs_ln_affine_bwd(ddP.data_ptr(), dobs.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), n, C, H, W, k, k, s,
+                          gg.data_ptr(), gb.data_ptr())
+    assert rel_close(gg.cpu().numpy(), tg.grad.numpy(), 2e-5, scale=1.0)
+    assert rel_close(gb.cpu().numpy(), tb.grad.numpy(), 2e-5, scale=1.0)
+
+
+@pytest.mark.parametrize("H,C,k,s", [(20, 32, 4, 2), (9, 64, 3, 1), (11, 8, 5, 3)])
+def test_im2col_col2im_nhwc(H, C, k, s):
+    rng = np.random.default_rng(H)
+    n = 6
+    x = rng.standard_normal((n, H, H, C)).astype(np.float32)
+    OH = (H - k) // s + 1
+    P = torch.empty((n * OH * OH, k * k * C), device=DEV)
+    dx_ = dev(x)
+    hip.im2col_nhwc(dx_.data_ptr(), n, H, H, C, k, k, s, P.data_ptr())
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).double().requires_grad_(True)  # NCHW for unfold
+    u = torch.nn.functional.unfold(xt, k, stride=s)  # [n, C*k*k, L] with (c,kh,kw) order
+    u = u.reshape(n, C, k, k, OH * OH).permute(0, 4, 2, 3, 1).reshape(n * OH * OH, k * k * C)  # -> (kh,kw,c)
+    assert np.array_equal(P.cpu().numpy(), u.detach().numpy().astype(np.float32))
+    dP = rng.standard_normal((n * OH * OH, k * k * C)).astype(np.float32)
+    (u * torch.from_numpy(dP).double()).sum().backward()
+    ymask = rng.standard_normal((n, H, H, C)).astype(np.float32)
+    dX = torch.empty((n, H, H, C), device=DEV)
+    ddP, dym = dev(dP), dev(ymask)  # keep the device copies alive across the asynchronous launch
+    hip.col2im_nhwc(ddP.data_ptr(), n, H, H, C, k, k, s, dym.data_ptr(), 1, dX.data_ptr())
+    torch.cuda.synchronize()
+    ref = xt.grad.permute(0, 2, 3, 1).numpy() * (ymask > 0)
+    assert rel_close(dX.cpu().numpy(), ref, 1e-5, scale=1.0)
+
+
+def test_colsum_copy2d():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((10000, 70)).astype(np.float32)
+    out = torch.ones(70, device=DEV)
+    dxx = dev(x)
+    hip.colsum(dxx.data_ptr(), 70, 10000, 70, out.data_ptr(), accumulate=True)
+    assert rel_close(out.cpu().numpy(), 1 + x.astype(np.float64).sum(0), 1e-5, scale=100.0)
+    dst = torch.zeros((100, 50), device=DEV)
+    src = dev(x[:100])
+    hip.copy2d(src.data_ptr(), 70, dst.data_ptr() + 4 * 5, 50, 100, 30)
+    assert np.array_equal(dst.cpu().numpy()[:, 5:35], x[:100, :30])
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+@pytest.mark.parametrize("max_norm", [None, 0.5, 1e9])
+def test_adam_matches_torch(max_norm):
+    rng = np.random.default_rng(4)
+    n = 100003
+    p0 = rng.standard_normal(n).astype(np.float32)
+    tp = torch.from_numpy(p0.copy()).requires_grad_(True)
+    opt = torch.optim.Adam([tp], lr=3e-4)
+    p, m, v = dev(p0).clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sumsq = torch.zeros(1, dtype=torch.float64, device=DEV)
+    gn = torch.zeros(1, device=DEV)
+    for step in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32) * 0.01
+        tp.grad = torch.from_numpy(g.copy())
+        ref_norm = torch.nn.utils.clip_grad_norm_([tp], max_norm if max_norm is not None else 1e30)
+        opt.step()
+        dg = dev(g)
+        hip.grad_sumsq(dg, sumsq)
+        hip.adam_step(p, dg, m, v, 3e-4, 0.9, 0.999, 1e-8, 0.0, False, step, max_norm=-1 if max_norm is None else max_norm,
+                      sumsq=sumsq, grad_norm_out=gn)
+        assert abs(gn.item() - ref_norm.item()) <= 1e-5 * ref_norm.item()
+        assert rel_close(p.cpu().numpy(), tp.detach().numpy(), 1e-6, scale=1.0), step

@@ -1,0 +1,189 @@
+"""GPU parity tests of the whole drop-in path: policy.analyze / rollout and trainer.step through the plugin API,
+against the golden vectors generated from the real reference and against the CPU oracle at larger sizes."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import srl_amd
+from oracle.net import OracleActorCritic
+from oracle.trainer import OracleMappo
+from srl_amd.api import config, policy as policy_api, trainer as trainer_api
+from srl_amd.namedarray import NamedArray
+from srl_amd.runtime import synthetic
+
+srl_amd.register_all()
+pytestmark = pytest.mark.gpu
+
+C1_POLICY = dict(obs_dim=4, action_dim=2, hidden_dim=64, num_dense_layers=2, num_rnn_layers=0, popart=False,
+                 layernorm=False, shared_backbone=False, chunk_len=8, seed=1)
+ATARI_TRAINER = dict(discount_rate=0.99, gae_lambda=0.97, eps_clip=0.2, clip_value=True, dual_clip=False,
+                     value_loss='huber', value_loss_weight=1.0, value_loss_config=dict(delta=10.0),
+                     entropy_bonus_weight=0.01, optimizer='adam', optimizer_config=dict(lr=5e-4), popart=False,
+                     max_grad_norm=40.0, bootstrap_steps=1)
+CNN_POLICY = dict(obs_dim={"obs": (4, 84, 84)}, action_dim=6, hidden_dim=512, num_dense_layers=0, num_rnn_layers=0,
+                  popart=False, layernorm=False, shared_backbone=True, chunk_len=4, seed=5,
+                  cnn_layers=dict(obs=[(32, 8, 4, 0, 'zeros'), (64, 4, 2, 0, 'zeros'), (64, 3, 1, 0, 'zeros')]))
+CASES = {
+    "c1": (C1_POLICY, dict(popart=False, optimizer_config=dict(lr=3e-4)),
+           dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05), 3, "steps_mlp.npz"),
+    "c1atari": (C1_POLICY, ATARI_TRAINER, dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05), 2,
+                "steps_mlp.npz"),
+    "c1ln": (dict(C1_POLICY, layernorm=True, seed=2),
+             dict(popart=False, optimizer_config=dict(lr=1e-3), max_grad_norm=0.5),
+             dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05), 2, "steps_mlp.npz"),
+    "multi": (dict(obs_dim={"a": 5, "b": 3}, action_dim=[3, 4], hidden_dim=32, num_dense_layers=1, num_rnn_layers=0,
+                   popart=False, layernorm=True, shared_backbone=True, chunk_len=8, seed=3, activation="tanh"),
+              dict(popart=False, ppo_epochs=2, optimizer_config=dict(lr=1e-3)),
+              dict(T=16, B=4, obs_spec={"a": ((5,), "f32"), "b": ((3,), "f32")}, action_dims=[3, 4], p_done=0.1), 2,
+              "steps_mlp.npz"),
+    "cnn": (CNN_POLICY, ATARI_TRAINER, dict(T=4, B=3, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.1), 2,
+            "steps_cnn.npz"),
+}
+
+
+def make_trainer(policy_args, trainer_args):
+    return trainer_api.make(config.Trainer("mappo", args=trainer_args), config.Policy("actor-critic", args=policy_args))
+
+
+def close(a, b, rtol, scale=1.0):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return bool((np.abs(a - b) <= rtol * np.maximum(np.abs(b), scale)).all())
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_step_matches_reference_golden(tag, golden):
+    pargs, targs, skw, n_steps, fname = CASES[tag]
+    g = golden(fname)
+    trainer = make_trainer(pargs, targs)
+    names = list(g[f"{tag}_stat_names"])
+    for step in range(n_steps):
+        arrays = synthetic.make_sample_arrays(seed=100 + step, **skw)
+        sample = synthetic.to_sample_batch(arrays)
+        if step == 0:
+            Tb = arrays["on_reset"].shape[0]
+            ar = trainer.policy.analyze(sample[:Tb - 1], target="ppo")
+            assert close(ar.new_action_log_probs.cpu().numpy(), g[f"{tag}_analyze_new_lp"], 1e-5), "analyze log-probs"
+            assert close(ar.state_values.cpu().numpy(), g[f"{tag}_analyze_value"], 1e-5), "analyze values"
+            assert close(ar.entropy.cpu().numpy(), g[f"{tag}_analyze_entropy"], 1e-5), "analyze entropy"
+        res = trainer.step(sample)
+        ref = dict(zip(names, g[f"{tag}_step{step}_stats"]))
+        for k in ("policy_loss", "value_loss", "entropy", "advantage", "value_targets", "importance_weight", "clip_ratio",
+                  "done", "truncated", "grad_norm", "frames"):
+            tol = 1e-5 if k in ("policy_loss", "value_loss", "entropy", "value_targets") else 1e-4
+            assert abs(res.stats[k] - ref[k]) <= tol * max(abs(ref[k]), 1e-2), (tag, step, k, res.stats[k], ref[k])
+        if step == 0:  # GAE returns written back into the sample: 1e-5 relative (BASELINE.json)
+            assert close(sample.analyzed_result.adv, g[f"{tag}_step0_adv"], 1e-5)
+            assert close(sample.analyzed_result.ret, g[f"{tag}_step0_ret"], 1e-5)
+        if step in (0, n_steps - 1):
+            sd = trainer.policy.get_checkpoint()["state_dict"]
+            for key in g.files:
+                pre_full, pre_s = f"{tag}_step{step}_param:", f"{tag}_step{step}_param_s97:"
+                if key.startswith(pre_full):
+                    got = sd[key[len(pre_full):]].numpy()
+                elif key.startswith(pre_s):
+                    got = sd[key[len(pre_s):]].numpy().reshape(-1)[::97]
+                else:
+                    continue
+                # parameters after Adam steps: each step moves a weight by ~lr, so compare at a few % of lr
+                assert np.abs(got - g[key]).max() <= 2e-5, (tag, step, key, np.abs(got - g[key]).max())
+    assert trainer.policy.version == int(g[f"{tag}_version"])
+    assert res.step == trainer.policy.version
+
+
+def test_init_matches_reference_init(golden):
+    """Same seed -> the reference's initial weights (bit-identical in the container that made the fixtures, where
+    gen_golden.py asserts torch.equal; LAPACK's QR may differ in the last bit on another CPU, hence allclose)."""
+    g = golden("steps_mlp.npz")
+    for tag in ("c1", "c1ln", "multi"):
+        pol = policy_api.make(config.Policy("actor-critic", args=CASES[tag][0]))
+        for k, v in pol.get_checkpoint()["state_dict"].items():
+            assert np.allclose(v.numpy(), g[f"{tag}_init_param:{k}"], rtol=1e-5, atol=1e-6), (tag, k)
+
+
+def test_rollout_eval_golden(golden):
+    g = golden("rollout.npz")
+    pol = policy_api.make(config.Policy("actor-critic", args=C1_POLICY))
+    N = g["c1_obs"].shape[0]
+    req = policy_api.RolloutRequest(obs=NamedArray(obs=g["c1_obs"]), is_evaluation=np.ones((N, 1), np.uint8),
+                                    on_reset=np.zeros((N, 1), np.uint8))
+    res = pol.rollout(req)
+    assert res.action.x.dtype == np.int64 and res.action.x.shape == (N, 1)
+    assert np.array_equal(res.action.x, g["c1_action"])
+    assert close(res.analyzed_result.log_probs, g["c1_log_probs"], 1e-5)
+    assert close(res.analyzed_result.value, g["c1_value"], 1e-5, scale=1e-2)
+    assert res.policy_state is None
+
+
+@pytest.mark.parametrize("T,B,chunk", [(128, 64, 16384), (64, 33, 1000)])
+def test_step_vs_oracle_larger(T, B, chunk):
+    """Bigger than the fixtures, incl. several row-chunks with a ragged tail: loss terms and GAE vs the CPU oracle."""
+    pargs = dict(C1_POLICY, layernorm=True, seed=7)
+    targs = dict(ATARI_TRAINER, chunk_rows=chunk)
+    trainer = make_trainer(pargs, targs)
+    onet = OracleActorCritic(**pargs)
+    onet.load_state_dict({k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()})
+    oracle = OracleMappo(onet, **{k: v for k, v in targs.items() if k != "chunk_rows"})
+    for step in range(2):
+        arrays = synthetic.make_sample_arrays(seed=step, T=T, B=B, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2,
+                                              p_done=0.02)
+        sample = synthetic.to_sample_batch(arrays)
+        res = trainer.step(sample)
+        ostats, oout = oracle.step(arrays)
+        assert close(sample.analyzed_result.ret, oout["ret"], 1e-5)
+        for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
+            assert abs(res.stats[k] - ostats[k]) <= 2e-5 * max(abs(ostats[k]), 1e-2), (step, k, res.stats[k], ostats[k])
+    sd = trainer.policy.get_checkpoint()["state_dict"]
+    osd = onet.state_dict()
+    for k in sd:
+        assert np.abs(sd[k].numpy() - osd[k].numpy()).max() <= 3e-5, k
+
+
+def test_cnn_step_vs_oracle_chunked():
+    """NatureCNN with more samples than one row-chunk, uint8 frames resident on the device."""
+    targs = dict(ATARI_TRAINER, chunk_rows=40)
+    trainer = make_trainer(CNN_POLICY, targs)
+    onet = OracleActorCritic(**CNN_POLICY)
+    onet.load_state_dict({k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()})
+    oracle = OracleMappo(onet, **ATARI_TRAINER)
+    arrays = synthetic.make_sample_arrays(seed=11, T=12, B=8, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.1)
+    sample = synthetic.to_sample_batch(arrays)
+    res = trainer.step(sample)
+    ostats, _ = oracle.step(arrays)
+    for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
+        assert abs(res.stats[k] - ostats[k]) <= 2e-5 * max(abs(ostats[k]), 1e-2), (k, res.stats[k], ostats[k])
+
+
+def test_checkpoint_roundtrip_and_reuse():
+    trainer = make_trainer(C1_POLICY, dict(popart=False, optimizer_config=dict(lr=1e-3), recompute_adv_on_reuse=False))
+    arrays = synthetic.make_sample_arrays(seed=1, T=16, B=4, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2)
+    sample = synthetic.to_sample_batch(arrays)
+    trainer.step(sample)
+    adv_first = sample.analyzed_result.adv.copy()
+    ckpt = copy.deepcopy(trainer.get_checkpoint())
+    assert set(ckpt) == {"steps", "state_dict", "optimizer_state_dict"} and ckpt["steps"] == 0
+    # torch's own Adam accepts the optimiser state (same structure as the reference's checkpoints)
+    params = [torch.nn.Parameter(v.clone()) for v in ckpt["state_dict"].values()]
+    torch.optim.Adam(params, lr=1e-3).load_state_dict(ckpt["optimizer_state_dict"])
+    r1 = trainer.step(sample)  # re-use: advantages in the sample are kept (recompute_adv_on_reuse=False)
+    assert np.array_equal(sample.analyzed_result.adv, adv_first)
+    other = make_trainer(dict(C1_POLICY, seed=99), dict(popart=False, optimizer_config=dict(lr=1e-3),
+                                                        recompute_adv_on_reuse=False))
+    other.load_checkpoint(ckpt)
+    assert other.policy.version == 0
+    r2 = other.step(sample)
+    for k in ("policy_loss", "value_loss", "grad_norm"):
+        assert abs(r1.stats[k] - r2.stats[k]) <= 1e-6 * max(abs(r1.stats[k]), 1e-3), k
+
+
+def test_device_resident_sample_matches_host_sample():
+    a = make_trainer(C1_POLICY, dict(popart=False))
+    b = make_trainer(C1_POLICY, dict(popart=False))
+    arrays = synthetic.make_sample_arrays(seed=2, T=16, B=4, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2)
+    host = synthetic.to_sample_batch(arrays)
+    devs = synthetic.to_sample_batch({k: torch.from_numpy(v).to("cuda:0") for k, v in arrays.items()})
+    ra, rb = a.step(host), b.step(devs)
+    for k in ("policy_loss", "value_loss", "grad_norm"):
+        assert ra.stats[k] == rb.stats[k]
+    assert isinstance(devs.analyzed_result.adv, torch.Tensor)

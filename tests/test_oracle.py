@@ -1,0 +1,130 @@
+"""The oracle is pinned here: against the hand-computed vectors of the reference's own tests and against the
+golden vectors generated from the real reference (tests/golden/gen_golden.py)."""
+import numpy as np
+import torch
+
+from oracle import gae as ogae
+from oracle import ppo as oppo
+from oracle.net import OracleActorCritic
+from oracle.trainer import OracleMappo
+from srl_amd.runtime import synthetic
+
+
+def test_gae_hand_vector_of_reference_test():
+    """legacy/tests/modules_test.py:119-138 (gamma = lambda = 0.1, done + truncated episodes)."""
+    on_reset = np.array([0, 0, 0, 1, 0, 0, 1, 0, 0], dtype=np.float32)
+    rew = np.array([1, 2, 0, 1, 3, 0, 1, 2, 3], dtype=np.float32)
+    value = np.array([2, 0, 1, 2, 2, 0, 1, 1, 1], dtype=np.float32)
+    truncated = np.array([0, 0, 1, 0, 0, 0, 0, 0, 0], dtype=np.float32)
+    done = np.array([0, 0, 0, 0, 0, 1, 0, 0, 0], dtype=np.float32)
+    adv = ogae.gae_trace(rew[:-1], value, truncated, done, on_reset, 0.1, 0.1)
+    expect = np.array([2.1 * 0.01 - 1, 2.1, 0, -0.8 + 0.01, 1, 0, 0.111, 1.1])
+    keep = 1 - on_reset[1:]
+    np.testing.assert_array_almost_equal(adv * keep, expect * keep)
+
+
+def test_gae_vs_tianshou_style_loop():
+    """legacy/tests/modules_test.py:91-117: random [101, 8, 1], done only, atol 1e-5."""
+    rng = np.random.default_rng(0)
+    value = rng.standard_normal((101, 8, 1))
+    rew = rng.standard_normal((100, 8, 1))
+    done = rng.integers(0, 2, (101, 8, 1)).astype(np.float64)
+    on_reset = np.concatenate([np.zeros_like(done[:1]), done[:-1]], axis=0)
+    rew = rew * (1 - on_reset[1:])
+    value = value * (1 - done)
+    delta = rew + value[1:] * 0.99 * (1 - done[:-1]) - value[:-1]
+    m = (1.0 - done[:-1]) * (0.99 * 0.97)
+    gae, ref = 0.0, np.zeros_like(rew)
+    for i in range(99, -1, -1):
+        gae = delta[i] + m[i] * gae
+        ref[i] = gae
+    adv = ogae.gae_trace(rew, value, np.zeros_like(done), done, on_reset, 0.99, 0.97)
+    assert np.abs(adv - ref).max() < 1e-5
+
+
+def test_traj_gae_hand_vectors(golden):
+    """legacy/tests/modules_test.py:140-178 + the reference's outputs."""
+    g = golden("host.npz")
+    for tag, expect in (("trunc", [2.1 * 0.01 - 1, 2.1]), ("done", [-0.8 + 0.01, 1])):
+        rew, value, done, trunc = g[f"trajgae_{tag}_in"]
+        adv, ret = ogae.traj_gae(list(rew[:-1]), list(value[:-1]), trunc[-1], value[-1], 0.1, 0.1)
+        np.testing.assert_allclose(adv, expect, rtol=1e-6)
+        np.testing.assert_allclose(adv, g[f"trajgae_{tag}_adv"], rtol=1e-6)
+        np.testing.assert_allclose(ret, g[f"trajgae_{tag}_ret"], rtol=1e-6)
+
+
+def test_gae_golden(golden):
+    g = golden("gae.npz")
+    for name in g["cases"]:
+        a = {k: g[f"{name}_{k}"] for k in ("reward", "value", "done", "truncated", "on_reset")}
+        for tag, gam, lam in (("a", 0.99, 0.97), ("b", 0.9, 0.5)):
+            adv, ret = ogae.adv_and_value_target(a["reward"], a["value"], a["truncated"], a["done"], a["on_reset"], gam,
+                                                 lam)
+            assert np.array_equal(adv, g[f"{name}_{tag}_adv"]) and np.array_equal(ret, g[f"{name}_{tag}_ret"])
+        v = (a["value"] * (1 - a["done"])).astype(np.float32)
+        adv = ogae.gae_trace(a["reward"][:-1], v, a["truncated"], a["done"], a["on_reset"], 0.99, 0.97, vtrace=True,
+                             imp_ratio=g[f"{name}_ratio"])
+        assert np.array_equal(adv, g[f"{name}_vtrace_adv"])
+
+
+def test_masked_normalization_golden_and_nanmean(golden):
+    g = golden("norm.npz")
+    x, mask = g["x"], g["mask"]
+    for tag, m, unb in (("masked", mask, False), ("nomask", None, False), ("unbiased", mask, True)):
+        assert np.array_equal(oppo.masked_normalization(x, m, unbiased=unb), g[f"{tag}_out"])
+    # legacy/tests/modules_test.py:36-46,267-271: vs nanmean / nanstd to 6 decimals on the unmasked entries
+    xc = x.astype(np.float64).copy()
+    xc[mask == 0] = np.nan
+    ref = (x - np.nanmean(xc)) / (np.nanstd(xc) + 1e-5)
+    np.testing.assert_almost_equal(oppo.masked_normalization(x, mask) * mask, ref * mask, decimal=6)
+    # all-reduced statistics override (data-parallel path)
+    n, s, q = oppo.masked_stats(x, mask)
+    half = x.shape[0] // 2
+    parts = [oppo.masked_stats(x[:half], mask[:half]), oppo.masked_stats(x[half:], mask[half:])]
+    tot = tuple(sum(p[i] for p in parts) for i in range(3))
+    assert np.allclose(tot, (n, s, q), rtol=1e-13)
+    assert np.array_equal(oppo.masked_normalization(x[:half], mask[:half], stats=(n, s, q)),
+                          oppo.masked_normalization(x, mask)[:half])
+
+
+def test_ppo_loss_golden(golden):
+    g = golden("loss.npz")
+    names = list(g["stat_names"])
+    t = lambda k, grad=False: torch.from_numpy(g[k]).clone().requires_grad_(grad)
+    for combo in g["combos"]:
+        vl, cv, dc = combo.split("_")
+        nlp, v, ent = t("new_lp", True), t("value", True), t("entropy", True)
+        loss, stats = oppo.ppo_loss(nlp, t("old_lp"), v, t("old_value"), t("adv"), t("ret"), ent, t("mask"),
+                                    dual_clip=dc == "1", value_loss=vl, clip_value=cv == "1",
+                                    value_loss_config=dict(delta=10.0) if vl == "huber" else {})
+        loss.backward()
+        stats["loss"] = loss.item()
+        ref = dict(zip(names, g[f"{combo}_stats"]))
+        for k, val in ref.items():
+            assert abs(stats[k] - val) <= 1e-6 * max(1, abs(val)), (combo, k)
+        assert torch.allclose(nlp.grad, torch.from_numpy(g[f"{combo}_d_new_lp"]), rtol=1e-6, atol=1e-9)
+        assert torch.allclose(v.grad, torch.from_numpy(g[f"{combo}_d_value"]), rtol=1e-6, atol=1e-9)
+        assert torch.allclose(ent.grad, torch.from_numpy(g[f"{combo}_d_entropy"]), rtol=1e-6, atol=1e-9)
+
+
+def test_full_step_golden_c1(golden):
+    """OracleMappo reproduces the reference trainer's statistics and post-step parameters (config #1 shapes)."""
+    g = golden("steps_mlp.npz")
+    pargs = dict(obs_dim=4, action_dim=2, hidden_dim=64, num_dense_layers=2, num_rnn_layers=0, popart=False,
+                 layernorm=False, shared_backbone=False, chunk_len=8)
+    net = OracleActorCritic(**pargs)
+    net.load_state_dict({k[len("c1_init_param:"):]: g[k] for k in g.files if k.startswith("c1_init_param:")})
+    tr = OracleMappo(net, popart=False, optimizer_config=dict(lr=3e-4))
+    names = list(g["c1_stat_names"])
+    for step in range(3):
+        arrays = synthetic.make_sample_arrays(seed=100 + step, T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2,
+                                              p_done=0.05)
+        stats, out = tr.step(arrays)
+        ref = dict(zip(names, g[f"c1_step{step}_stats"]))
+        for k in ("policy_loss", "value_loss", "entropy", "grad_norm", "clip_ratio"):
+            assert abs(stats[k] - ref[k]) <= 2e-5 * max(1.0, abs(ref[k])), (step, k)
+        if step == 0:
+            assert np.array_equal(out["ret"], g["c1_step0_ret"])
+    sd = net.state_dict()
+    for k in sd:
+        assert np.allclose(sd[k].numpy(), g[f"c1_step2_param:{k}"], rtol=1e-4, atol=1e-6), k
