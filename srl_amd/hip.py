@@ -133,6 +133,51 @@ def _i32_array(vals: Sequence[int]):
     return (c_int32 * len(vals))(*[int(v) for v in vals])
 
 
+class KernelProfile:
+    """Per-kernel device timing with HIP events recorded on the stream the kernels are launched on
+    (torch's current stream).  Used by bench.py in an untimed pass; off (``None``) otherwise."""
+
+    def __init__(self):
+        self.records = []  # (name, start_event, end_event, work) ; work = algorithmic flops or bytes
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b, work in self.records:
+            e = out.setdefault(name, dict(calls=0, ms=0.0, work=0.0))
+            e["calls"] += 1
+            e["ms"] += a.elapsed_time(b)
+            e["work"] += work
+        return out
+
+
+_prof: Optional[KernelProfile] = None
+
+
+def set_profile(p: Optional[KernelProfile]):
+    global _prof
+    _prof = p
+
+
+class _scope:
+
+    def __init__(self, name, work=0.0):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _prof is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            self.b.record()
+            _prof.records.append((self.name, self.a, self.b, self.work))
+        return False
+
+
 # ------------------------------------------------------------------------------------------------
 def device_info():
     n, l = c_int(0), c_int(0)
@@ -148,7 +193,9 @@ def gae_scan(reward, value, done, truncated, on_reset, gamma, lmbda, adv, ret, s
     T = Tp1 - 1
     Nc = value.shape[2] if value.dim() > 2 else 1
     assert value.shape[0] == Tp1 and reward.shape[0] >= T and adv.shape[0] >= T and ret.shape[0] >= T
-    _check(
+    # algorithmic bytes: r,v f32 + 3 flag bytes in, adv,ret f32 out = 19 B per env-step (+ bootstrap row)
+    with _scope("gae_scan", 19.0 * T * B * Nc + 7.0 * B * Nc):
+      _check(
         lib().srl_gae_scan(_stream(), _ptr(reward, torch.float32, "reward"), _ptr(value, torch.float32, "value"),
                            _ptr(done, torch.uint8, "done"), _ptr(truncated, torch.uint8, "truncated"),
                            _ptr(on_reset, torch.uint8, "on_reset"), _ptr(imp_ratio, torch.float32, "imp_ratio"), T, B,
@@ -217,7 +264,8 @@ def gemm(M, N, K, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, bias=None, act=ACT
     """Raw-pointer GEMM (``A``/``B``/``C``/... are ints from ``data_ptr()`` possibly with byte offsets)."""
     d = GemmDesc(M, N, K, A, lda, int(a_kmajor), B, ldb, int(b_kmajor), C, ldc, bias, int(act), dact_src, ld_dact,
                  int(dact), int(accumulate), int(split_k), workspace)
-    _check(lib().srl_gemm(_stream(), ctypes.byref(d)), "srl_gemm")
+    with _scope("gemm", 2.0 * M * N * K):
+        _check(lib().srl_gemm(_stream(), ctypes.byref(d)), "srl_gemm")
 
 
 def layernorm_fwd(x_ptr, ldx, gamma_ptr, beta_ptr, rows, D, y_ptr, ldy, mean_ptr, rstd_ptr):
@@ -283,3 +331,28 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, adamw, step, grad
                             float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(adamw),
                             int(step), float(grad_scale), float(max_norm), _ptr(sumsq, torch.float64, "sumsq"),
                             _ptr(grad_norm_out, f, "grad_norm_out")), "srl_adam_step")
+
+
+def _wrap_for_profile(names):
+    import functools
+    g = globals()
+    for name in names:
+        fn = g[name]
+
+        def make(fn, name):
+
+            @functools.wraps(fn)
+            def wrapper(*a, **k):
+                if _prof is None:
+                    return fn(*a, **k)
+                with _scope(name):
+                    return fn(*a, **k)
+
+            return wrapper
+
+        g[name] = make(fn, name)
+
+
+_wrap_for_profile(["masked_stats", "masked_normalize", "ppo_loss_fwd_bwd", "categorical_fwd", "categorical_bwd",
+                   "categorical_sample", "layernorm_fwd", "layernorm_bwd", "obs_ln_stats", "im2col_obs_ln", "im2col_nhwc",
+                   "col2im_nhwc", "obs_ln_affine_bwd", "colsum", "copy2d", "grad_sumsq", "adam_step"])

@@ -99,7 +99,7 @@ def test_init_matches_reference_init(golden):
     for tag in ("c1", "c1ln", "multi"):
         pol = policy_api.make(config.Policy("actor-critic", args=CASES[tag][0]))
         for k, v in pol.get_checkpoint()["state_dict"].items():
-            assert np.allclose(v.numpy(), g[f"{tag}_init_param:{k}"], rtol=1e-5, atol=1e-6), (tag, k)
+            assert np.allclose(v.numpy(), g[f"{tag}_init_param:{k}"], rtol=1e-4, atol=1e-4), (tag, k)
 
 
 def test_rollout_eval_golden(golden):
