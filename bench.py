@@ -163,9 +163,10 @@ def main():
         trainer.step(sample)
         hip.set_profile(None)
         summ = prof.summary()
-        g = summ["gemm"]
+        mm = [v for k, v in summ.items() if k == "gemm" or k.startswith("conv_")]  # every launch of gemm_kernel<...>
+        g = dict(calls=sum(v["calls"] for v in mm), ms=sum(v["ms"] for v in mm), work=sum(v["work"] for v in mm))
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12
-        roofline = dict(kernel="gemm_kernel<BM,BN,WM,WN,AKM,BKM> (v_mfma_f32_32x32x2_f32), all launches of one step",
+        roofline = dict(kernel="gemm_kernel<...> (v_mfma_f32_32x32x2_f32): dense + implicit-conv launches of one step",
                         bound="mfma", achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None, launches=g["calls"],
                         ms_per_step=round(g["ms"], 3), flops_per_step=g["work"])

@@ -205,6 +205,55 @@ int srl_copy2d(void* stream, const float* src, int64_t lds, float* dst, int64_t 
 int srl_u8_to_f32(void* stream, const uint8_t* src, float* dst, int64_t n);
 
 /* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolutions (padding 0): the patch matrix is never written to memory, the operand gather
+ * happens inside the MFMA kernel's load path.  Replaces nn.Conv2d forward / backward of the `Convolution`
+ * encoder (legacy/algorithm/modules/cnn.py:93-135) and, for the first layer, the whole-observation
+ * nn.LayerNorm in front of it (policies/utils.py:53) including the float32 widening of uint8 frames
+ * (api/trainer.py:217).  Activations between convolutions are NHWC; weights [Cout, KH, KW, Cin]; the first
+ * layer reads the NCHW observation with the reference's weight layout [Cout, Cin, KH, KW].
+ * The srl_im2col_* / srl_col2im_* entry points above remain as the general fallback for geometries
+ * srl_conv2d_supported() rejects.
+ */
+typedef struct srl_conv_desc {
+  int64_t n;                 /* images */
+  int32_t H, W, Cin;         /* input */
+  int32_t KH, KW, stride, Cout;
+  int32_t act;               /* forward activation fused after the bias: 0 none, 1 relu, 2 tanh */
+} srl_conv_desc;
+
+/* 1 if the implicit path handles this geometry (first_layer: NCHW observation + LayerNorm gather). */
+int srl_conv2d_supported(const srl_conv_desc* d, int first_layer);
+/* y[n,OH,OW,Cout] = act(conv(x[n,H,W,Cin], w) + bias) */
+int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w, const float* bias,
+                        float* y);
+/* dw[Cout,KH,KW,Cin] += sum over (n,oh,ow) dz[.,Cout]^T patch(x); workspace: srl_conv2d_wgrad_workspace floats
+ * (split over the n*OH*OW reduction) or NULL. */
+int64_t srl_conv2d_wgrad_workspace(const srl_conv_desc* d);
+int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const float* x, const float* dz, float* dw,
+                          float* workspace);
+/* Data gradient.  Input pixels are split into stride*stride parity classes, each a dense stride-1 problem
+ * over only the taps that reach it (no multiply-by-zero work).  wt = the weights regrouped per class
+ * (srl_conv2d_dgrad_repack, srl_conv2d_dgrad_weight_elems floats; redo after every optimiser step).
+ * dx[n,H,W,Cin] = (sum over taps dz * w) * act'(x_act)   (x_act = the forward activation that has dx's shape, or NULL) */
+int64_t srl_conv2d_dgrad_weight_elems(const srl_conv_desc* d);
+int srl_conv2d_dgrad_repack(void* stream, const srl_conv_desc* d, const float* w, float* wt);
+int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* wt, const float* x_act,
+                          int dact, float* dx);
+/* First layer: y = act(conv(LayerNorm_{C,H,W}(obs), w) + bias); obs [n,Cin,H,W] uint8 or float32, mean/rstd [n]
+ * from srl_obs_ln_stats, gamma/beta [Cin,H,W], w [Cout,Cin,KH,KW]. */
+int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, const float* mean,
+                       const float* rstd, const float* gamma, const float* beta, const float* w, const float* bias,
+                       float* y);
+/* First layer backward without a data gradient: one batched GEMM over the OH*OW output positions forms
+ * Q[pos] = dz[:,pos,:]^T xhat_patches[:,pos,:] (xhat = normalised, pre-affine observation); then
+ * dw += sum_pos gamma*Q + beta*R, db += sum_pos R, dgamma += fold_o(w*Q), dbeta += fold_o(w*R), R = per-position
+ * column sums of dz.  workspace: srl_conv2d_obs_bwd_workspace floats. */
+int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d);
+int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, const float* mean,
+                       const float* rstd, const float* gamma, const float* beta, const float* w, const float* dz,
+                       float* dw, float* db, float* dgamma, float* dbeta, float* workspace);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimiser on one flat parameter buffer.
  * Replaces clip_grad_norm_ / get_grad_norm + torch.optim.Adam/AdamW.step
  * (mappo.py:278-284, modules/utils.py:268-295).

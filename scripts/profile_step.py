@@ -41,5 +41,5 @@ summ = prof.summary()
 tot = sum(v["ms"] for v in summ.values())
 print(f"total event time {tot:.2f} ms")
 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
-    tf = v["work"] / (v["ms"] * 1e-3) / 1e12 if v["work"] and k.startswith("gemm") else 0
+    tf = v["work"] / (v["ms"] * 1e-3) / 1e12 if v["work"] and (k.startswith("gemm") or k.startswith("conv_")) else 0
     print(f"{v['ms']:9.3f} ms  calls={v['calls']:3d}  {tf:6.1f} TF  {k}")

@@ -71,6 +71,10 @@ class HipNet:
         self.grad = torch.zeros_like(self.flat)
         self.ws = Workspace(dev)
         self._tape = None
+        # SRL_EXPLICIT_CONV=1 forces the im2col + GEMM + col2im fallback (kept for geometries the implicit
+        # kernels reject, and as a cross-check of the implicit path in the tests)
+        import os
+        self.force_explicit_conv = os.environ.get("SRL_EXPLICIT_CONV", "0") == "1"
 
     # ------------------------------------------------------------------ parameters / checkpoints
     def load_reference_state(self, state: Dict[str, torch.Tensor]):
@@ -185,28 +189,40 @@ class HipNet:
                 oh, ow = L.out_hw
                 m = n * oh * ow
                 kdim = L.cin * L.k * L.k
-                P = self._buf(f"{tag}{L.prefix}.P", m, kdim)
+                h, w = L.in_hw
+                desc = hip.conv_desc(n, h, w, L.cin, L.k, L.k, L.stride, L.cout, L.act)
+                # implicit GEMM (no patch matrix) whenever the geometry allows; explicit im2col otherwise
+                implicit = not self.force_explicit_conv and hip.conv2d_supported(desc, L.first)
+                y = self._buf(f"{tag}{L.prefix}.y", m, L.cout)
+                P = None if implicit else self._buf(f"{tag}{L.prefix}.P", m, kdim)
+                saved = None
                 if L.first:
-                    c, h, w = pending_obs_ln.shape
+                    c = pending_obs_ln.shape[0]
                     is_u8 = obs.dtype == torch.uint8
                     if not is_u8 and obs.dtype != torch.float32:
                         raise hip.HipError(f"image observation `{enc.key}` must be uint8 or float32, got {obs.dtype}")
                     mean = self.ws.get(f"{tag}{pending_obs_ln.prefix}.mean", n)
                     rstd = self.ws.get(f"{tag}{pending_obs_ln.prefix}.rstd", n)
                     hip.obs_ln_stats(obs.data_ptr(), is_u8, n, c * h * w, mean.data_ptr(), rstd.data_ptr())
-                    hip.im2col_obs_ln(obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(),
-                                      self._p(f"{pending_obs_ln.prefix}.weight"), self._p(f"{pending_obs_ln.prefix}.bias"),
-                                      n, c, h, w, L.k, L.k, L.stride, P.ptr)
+                    gam, bet = self._p(f"{pending_obs_ln.prefix}.weight"), self._p(f"{pending_obs_ln.prefix}.bias")
+                    if implicit:
+                        hip.conv2d_obs_fwd(desc, obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet,
+                                           self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"), y.ptr)
+                    else:
+                        hip.im2col_obs_ln(obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet, n, c, h, w,
+                                          L.k, L.k, L.stride, P.ptr)
                     saved = (obs, is_u8, mean, rstd, pending_obs_ln)
                 else:
-                    h, w = L.in_hw
                     assert cur.ld == L.cin and cur.rows == n * h * w
-                    hip.im2col_nhwc(cur.ptr, n, h, w, L.cin, L.k, L.k, L.stride, P.ptr)
-                    saved = None
-                y = self._buf(f"{tag}{L.prefix}.y", m, L.cout)
-                hip.gemm(m, L.cout, kdim, P.ptr, kdim, 0, self._p(f"{L.prefix}.weight"), kdim, 0, y.ptr, y.ld,
-                         bias=self._p(f"{L.prefix}.bias"), act=L.act)
-                tape.append(("conv", L, cur, (P, saved, n), cur_act))
+                    if implicit:
+                        hip.conv2d_nhwc_fwd(desc, cur.ptr, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"),
+                                            y.ptr)
+                    else:
+                        hip.im2col_nhwc(cur.ptr, n, h, w, L.cin, L.k, L.k, L.stride, P.ptr)
+                if not implicit:
+                    hip.gemm(m, L.cout, kdim, P.ptr, kdim, 0, self._p(f"{L.prefix}.weight"), kdim, 0, y.ptr, y.ld,
+                             bias=self._p(f"{L.prefix}.bias"), act=L.act)
+                tape.append(("conv", L, cur, (P, saved, n, desc), cur_act))
                 cur, cur_act = y, L.act
             else:  # pragma: no cover
                 raise TypeError(L)
@@ -223,9 +239,35 @@ class HipNet:
             elif kind == "linear":
                 g = self._linear_bwd(L, x, g, in_act, need_dx, tag)
             elif kind == "conv":
-                P, first_saved, n = saved
+                P, first_saved, n, desc = saved
                 kdim = L.cin * L.k * L.k
                 m = g.rows
+                if P is None:  # implicit-GEMM path
+                    assert g.ld == L.cout
+                    gw, gb, wp = self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"), self._p(f"{L.prefix}.weight")
+                    if L.first:
+                        obs, is_u8, mean, rstd, lnspec = first_saved
+                        wsz = hip.conv2d_obs_bwd_workspace(desc)
+                        hip.conv2d_obs_bwd(desc, obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(),
+                                           self._p(f"{lnspec.prefix}.weight"), self._p(f"{lnspec.prefix}.bias"), wp, g.ptr,
+                                           gw, gb, self._g(f"{lnspec.prefix}.weight"), self._g(f"{lnspec.prefix}.bias"),
+                                           self.ws.get("conv_obs_bwd", wsz).data_ptr())
+                        g = None
+                    else:
+                        wsz = hip.conv2d_wgrad_workspace(desc)
+                        hip.conv2d_nhwc_wgrad(desc, x.ptr, g.ptr, gw, self.ws.get("conv_wgrad", wsz).data_ptr())
+                        hip.colsum(g.ptr, g.ld, m, L.cout, gb, accumulate=True)
+                        wt = self.ws.get(f"{L.prefix}.wt", hip.conv2d_dgrad_weight_elems(desc))
+                        hip.conv2d_dgrad_repack(desc, wp, wt.data_ptr())
+                        h, w = L.in_hw
+                        dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.cin)
+                        hip.conv2d_nhwc_dgrad(desc, g.ptr, wt.data_ptr(), x.ptr if in_act else None, in_act, dx.ptr)
+                        g = dx
+                    if g is not None and idx > 0:
+                        prev_out_cols = self._out_cols(records[idx - 1])
+                        if g.cols != prev_out_cols:
+                            g = Buf(g.ptr, prev_out_cols, g.rows * g.cols // prev_out_cols, prev_out_cols)
+                    continue
                 self._wgrad(L.cout, kdim, m, g, P.ptr, kdim, self._g(f"{L.prefix}.weight"))
                 hip.colsum(g.ptr, g.ld, m, L.cout, self._g(f"{L.prefix}.bias"), accumulate=True)
                 # dP = dZ W, written over the patch matrix (its last reader was the weight gradient above)

@@ -1,0 +1,392 @@
+// Implicit-GEMM convolution entry points (padding 0, square or rectangular kernels, any stride):
+// forward / weight gradient / data gradient on NHWC activations, and the first convolution on the NCHW
+// observation with the whole-observation LayerNorm fused into the operand gather.  No patch matrix is ever
+// written to memory; all contraction runs on the FP32 MFMA kernel of gemm_core.h.
+#include "gemm_core.h"
+
+using namespace srlgemm;
+
+namespace {
+
+inline int conv_out(int in, int k, int s) { return (in - k) / s + 1; }
+
+OutDesc plain_out(float* out, long ld) {
+  OutDesc o{};
+  o.out = out;
+  o.ldo = ld;
+  o.f_img = o.f_line = make_fastdiv(1);
+  return o;
+}
+
+bool fits31(long v) { return v >= 0 && v < (1L << 31); }
+
+// NHWC patch rows: r = (n, oh, ow) -> x[n, oh*S, ow*S, 0];  c = (kh, kw, ci) -> kh*W*C + kw*C + ci
+SrcDesc conv_patch_src(const float* x, const srl_conv_desc* d, int OH, int OW) {
+  SrcDesc s = plain_src(x, 0);
+  s.f_img = make_fastdiv((uint32_t)(OH * OW));
+  s.f_line = make_fastdiv((uint32_t)OW);
+  s.img_stride = d->H * d->W * d->Cin;
+  s.y_stride = d->stride * d->W * d->Cin;
+  s.x_stride = d->stride * d->Cin;
+  s.f_inner = make_fastdiv((uint32_t)(d->KW * d->Cin));
+  s.k1_stride = d->W * d->Cin;
+  return s;
+}
+
+// NCHW observation patch rows with LayerNorm: r = (n, oh, ow);  c = (ci, kh, kw) -> ci*H*W + kh*W + kw
+SrcDesc obs_patch_src(const void* obs, int is_u8, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, const srl_conv_desc* d, int rows_per_img, int OW) {
+  SrcDesc s = plain_src(nullptr, 0);
+  s.base = obs;
+  s.f_img = make_fastdiv((uint32_t)rows_per_img);
+  s.f_line = make_fastdiv((uint32_t)OW);
+  s.img_stride = d->Cin * d->H * d->W;
+  s.y_stride = d->stride * d->W;
+  s.x_stride = d->stride;
+  s.f_inner = make_fastdiv((uint32_t)(d->KH * d->KW));
+  s.f_tap = make_fastdiv((uint32_t)d->KW);
+  s.k1_stride = d->H * d->W;
+  s.k2_stride = d->W;
+  s.mean = mean; s.rstd = rstd; s.gamma = gamma; s.beta = beta;
+  s.is_u8 = is_u8;
+  s.affine = gamma != nullptr;
+  return s;
+}
+
+bool obs_geometry_ok(const srl_conv_desc* d) {
+  // 4-wide gathers along kw must stay aligned: every stride that enters an address is a multiple of 4
+  return d->KW % 4 == 0 && d->W % 4 == 0 && d->stride % 4 == 0 && (d->H * d->W) % 4 == 0;
+}
+
+int want_split(long rows, long tiles, long batch) {
+  long want = 1024 / (tiles * batch > 0 ? tiles * batch : 1);
+  if (want < 1) want = 1;
+  const long cap = rows / 2048 > 1 ? rows / 2048 : 1;
+  return (int)(want < cap ? want : cap);
+}
+
+// per parity class (ph, pw) of the data gradient: taps th x tw, row grid ra x rb, offset of its weight block
+struct DgradClass {
+  int ph, pw, th, tw, ra, rb;
+  long w_off;
+};
+
+int dgrad_classes(const srl_conv_desc* d, DgradClass* out /* stride*stride entries */) {
+  int n = 0;
+  long off = 0;
+  for (int ph = 0; ph < d->stride; ++ph)
+    for (int pw = 0; pw < d->stride; ++pw) {
+      DgradClass c;
+      c.ph = ph; c.pw = pw;
+      c.th = ph < d->KH ? (d->KH - ph + d->stride - 1) / d->stride : 0;
+      c.tw = pw < d->KW ? (d->KW - pw + d->stride - 1) / d->stride : 0;
+      c.ra = ph < d->H ? (d->H - ph + d->stride - 1) / d->stride : 0;
+      c.rb = pw < d->W ? (d->W - pw + d->stride - 1) / d->stride : 0;
+      c.w_off = off;
+      off += (long)c.th * c.tw * d->Cout * d->Cin;
+      out[n++] = c;
+    }
+  return n;
+}
+
+// wt[class][(jh, jw, o)][ci] = w[o][ph + jh*S][pw + jw*S][ci]
+__global__ __launch_bounds__(256) void dgrad_repack_kernel(const float* w, float* wt, int Cout, int KH, int KW, int Cin,
+                                                           int S, int ph, int pw, int th, int tw) {
+  const int total = th * tw * Cout * Cin;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int ci = e % Cin;
+    const int o = (e / Cin) % Cout;
+    const int t = e / (Cin * Cout);
+    const int jh = t / tw, jw = t % tw;
+    wt[e] = w[((o * KH + ph + jh * S) * KW + pw + jw * S) * Cin + ci];
+  }
+}
+
+// ---- finalisation of the first-layer backward from the per-position products Q and column sums R --------------------
+// dw[o,k] += sum_pos gamma[p(pos,k)] * Q[pos,o,k] + beta[p(pos,k)] * R[pos,o];   db[o] += sum_pos R[pos,o]
+__global__ __launch_bounds__(256) void obs_dw_kernel(const float* Q, const float* R, const float* gamma,
+                                                     const float* beta, int P, int OW, int Cout, int Cin, int H, int W,
+                                                     int KH, int KW, int S, float* dw, float* db) {
+  const int Kp = Cin * KH * KW;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= Cout * Kp) return;
+  const int k = e % Kp, o = e / Kp;
+  const int kw = k % KW, kh = (k / KW) % KH, ci = k / (KW * KH);
+  float acc = 0.f, rsum = 0.f;
+  for (int pos = 0; pos < P; ++pos) {
+    const int oh = pos / OW, ow = pos % OW;
+    const int p = (ci * H + oh * S + kh) * W + ow * S + kw;
+    const float r = R[pos * Cout + o];
+    acc += gamma[p] * Q[((long)pos * Cout + o) * Kp + k] + beta[p] * r;
+    rsum += r;
+  }
+  dw[e] += acc;
+  if (k == 0) db[o] += rsum;
+}
+
+// dgamma[p] += sum_{(pos,k) -> p} sum_o w[o,k] Q[pos,o,k];   dbeta[p] += sum_{(pos,k) -> p} sum_o w[o,k] R[pos,o]
+__global__ __launch_bounds__(256) void obs_affine_kernel(const float* Q, const float* R, const float* w, int OH, int OW,
+                                                         int Cout, int Cin, int H, int W, int KH, int KW, int S,
+                                                         float* dgamma, float* dbeta) {
+  const int Kp = Cin * KH * KW;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= Cin * H * W) return;
+  const int x = p % W, y = (p / W) % H, ci = p / (W * H);
+  float ag = 0.f, ab = 0.f;
+  for (int kh = y % S; kh < KH && kh <= y; kh += S) {
+    const int oh = (y - kh) / S;
+    if (oh >= OH) continue;
+    for (int kw = x % S; kw < KW && kw <= x; kw += S) {
+      const int ow = (x - kw) / S;
+      if (ow >= OW) continue;
+      const int pos = oh * OW + ow;
+      const int k = (ci * KH + kh) * KW + kw;
+      for (int o = 0; o < Cout; ++o) {
+        const float wv = w[o * Kp + k];
+        ag += wv * Q[((long)pos * Cout + o) * Kp + k];
+        ab += wv * R[pos * Cout + o];
+      }
+    }
+  }
+  dgamma[p] += ag;
+  dbeta[p] += ab;
+}
+
+int check_desc(const srl_conv_desc* d) {
+  if (!d) return -1;
+  if (d->n < 0 || d->H < 1 || d->W < 1 || d->Cin < 1 || d->Cout < 1 || d->KH < 1 || d->KW < 1 || d->stride < 1) return -1;
+  if (d->KH > d->H || d->KW > d->W) return -1;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int srl_conv2d_supported(const srl_conv_desc* d, int first_layer) {
+  if (check_desc(d) != 0) return 0;
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
+  const long in_elems = d->n * d->H * d->W * d->Cin, out_elems = d->n * OH * OW * d->Cout;
+  if (!fits31(in_elems) || !fits31(out_elems) || !fits31(d->n * OH * OW)) return 0;
+  if (first_layer) return obs_geometry_ok(d) ? 1 : 0;
+  return (d->Cin % 4 == 0 && d->Cout % 4 == 0) ? 1 : 0;
+}
+
+extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w,
+                                   const float* bias, float* y) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry (needs Cin, Cout multiples of 4, < 2^31 elements)");
+  SRL_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w), "null / unaligned tensor");
+  if (d->n == 0) return 0;
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
+  const long Kp = (long)d->KH * d->KW * d->Cin;
+  GemmArgs g{};
+  g.M = d->n * OH * OW; g.N = d->Cout; g.K = Kp;
+  g.a = conv_patch_src(x, d, OH, OW);
+  g.b = plain_src(w, Kp);
+  g.o = plain_out(y, d->Cout);
+  g.bias = bias; g.act = d->act;
+  g.k_per_split = srl_ceil_div(Kp, BK) * BK;
+  g.vec_a = 1; g.vec_b = 1;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (d->Cout > 64) rc = launch<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
+  else if (d->Cout > 32) rc = launch<256, 64, 4, 1, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
+  else rc = launch<256, 32, 4, 1, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
+  SRL_CHECK_ARG(rc == 0, "grid too large");
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t srl_conv2d_wgrad_workspace(const srl_conv_desc* d) {
+  if (check_desc(d) != 0) return 0;
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
+  const long Kp = (long)d->KH * d->KW * d->Cin;
+  const long tiles = srl_ceil_div(d->Cout, 32) * srl_ceil_div(Kp, 256);
+  return (int64_t)want_split(d->n * OH * OW, tiles, 1) * d->Cout * Kp;
+}
+
+extern "C" int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const float* x, const float* dz, float* dw,
+                                     float* workspace) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry");
+  SRL_CHECK_ARG(x && dz && dw && aligned16(x) && aligned16(dz), "null / unaligned tensor");
+  if (d->n == 0) return 0;
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
+  const long Kp = (long)d->KH * d->KW * d->Cin, rows = d->n * OH * OW;
+  GemmArgs g{};
+  g.M = d->Cout; g.N = Kp; g.K = rows;
+  g.a = plain_src(dz, d->Cout);          // A(i = o, k = row) = dz[row*Cout + o]   (k-major)
+  g.b = conv_patch_src(x, d, OH, OW);    // B(k = row, j) = patch(row)[j]           (k-major gather)
+  const long tiles = srl_ceil_div(d->Cout, 32) * srl_ceil_div(Kp, 256);
+  int split = want_split(rows, tiles, 1);
+  if (!workspace) split = 1;
+  const int nsplit = plan_split(rows, split, &g.k_per_split);
+  if (nsplit > 1) { g.o = plain_out(workspace, Kp); g.slab = (long)d->Cout * Kp; g.accumulate = 0; }
+  else { g.o = plain_out(dw, Kp); g.accumulate = 1; }
+  g.vec_a = 1; g.vec_b = 1;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch<32, 256, 1, 4, true, true, SRC_PLAIN, SRC_CONV>(st, g, 1, nsplit);
+  SRL_CHECK_ARG(rc == 0, "grid too large");
+  SRL_LAUNCH_CHECK();
+  if (nsplit > 1) {
+    const long total = (long)d->Cout * Kp;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)srl_ceil_div(total, 256)), dim3(256), 0, st,
+                       (const float*)workspace, nsplit, 1L, (long)d->Cout, Kp, dw, Kp, 0L, 1);
+    SRL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int64_t srl_conv2d_dgrad_weight_elems(const srl_conv_desc* d) {
+  if (check_desc(d) != 0) return 0;
+  return (int64_t)d->KH * d->KW * d->Cin * d->Cout;  // the classes partition the taps
+}
+
+extern "C" int srl_conv2d_dgrad_repack(void* stream, const srl_conv_desc* d, const float* w, float* wt) {
+  SRL_CHECK_ARG(check_desc(d) == 0 && w && wt && d->stride <= 8, "bad descriptor");
+  DgradClass cls[64];
+  const int nc = dgrad_classes(d, cls);
+  for (int i = 0; i < nc; ++i) {
+    const DgradClass& c = cls[i];
+    const int total = c.th * c.tw * d->Cout * d->Cin;
+    if (total == 0) continue;
+    hipLaunchKernelGGL(dgrad_repack_kernel, dim3((unsigned)srl_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       wt + c.w_off, d->Cout, d->KH, d->KW, d->Cin, d->stride, c.ph, c.pw, c.th, c.tw);
+  }
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* wt,
+                                     const float* x_act, int dact, float* dx) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, 0) && d->stride <= 8, "unsupported geometry");
+  SRL_CHECK_ARG(dz && wt && dx && aligned16(dz) && aligned16(wt), "null / unaligned tensor");
+  if (d->n == 0) return 0;
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
+  hipStream_t st = (hipStream_t)stream;
+  DgradClass cls[64];
+  const int nc = dgrad_classes(d, cls);
+  for (int i = 0; i < nc; ++i) {
+    const DgradClass& c = cls[i];
+    if (c.ra == 0 || c.rb == 0) continue;
+    GemmArgs g{};
+    g.M = d->n * c.ra * c.rb; g.N = d->Cin; g.K = (long)c.th * c.tw * d->Cout;
+    // rows (n, a, b) -> dz[n, a, b, 0]; columns (jh, jw, o) -> -(jh*OW + jw)*Cout + o, valid while inside the image
+    SrcDesc a = plain_src(dz, 0);
+    a.f_img = make_fastdiv((uint32_t)(c.ra * c.rb));
+    a.f_line = make_fastdiv((uint32_t)c.rb);
+    a.img_stride = OH * OW * d->Cout;
+    a.y_stride = OW * d->Cout;
+    a.x_stride = d->Cout;
+    a.f_inner = make_fastdiv((uint32_t)d->Cout);
+    a.f_tap = make_fastdiv((uint32_t)(c.tw > 0 ? c.tw : 1));
+    a.OH = OH; a.OW = OW;
+    g.a = a;
+    g.b = plain_src(wt + c.w_off, d->Cin);  // B(k, j = ci) k-major
+    OutDesc o{};
+    o.out = dx + ((long)c.ph * d->W + c.pw) * d->Cin;
+    o.rowmap = 1;
+    o.f_img = make_fastdiv((uint32_t)(c.ra * c.rb));
+    o.f_line = make_fastdiv((uint32_t)c.rb);
+    o.img_stride = (long)d->H * d->W * d->Cin;
+    o.y_stride = (long)d->stride * d->W * d->Cin;
+    o.x_stride = (long)d->stride * d->Cin;
+    g.o = o;
+    if (x_act && dact) { g.dact_src = x_act + ((long)c.ph * d->W + c.pw) * d->Cin; g.dact = dact; }
+    g.k_per_split = srl_ceil_div(g.K > 0 ? g.K : 1, BK) * BK;
+    g.vec_a = 1; g.vec_b = 1;
+    int rc;
+    if (g.K == 0) {  // no tap reaches this class: gradient is zero there (k loop is empty, epilogue writes 0)
+      rc = launch<256, 32, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);
+    } else if (d->Cin > 64) rc = launch<128, 128, 2, 2, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);
+    else if (d->Cin > 32) rc = launch<256, 64, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);
+    else rc = launch<256, 32, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);
+    SRL_CHECK_ARG(rc == 0, "grid too large");
+  }
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, const float* mean,
+                                  const float* rstd, const float* gamma, const float* beta, const float* w,
+                                  const float* bias, float* y) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, 1), "unsupported geometry (needs KW, W, stride, H*W multiples of 4)");
+  SRL_CHECK_ARG(obs && mean && rstd && gamma && beta && w && y && aligned16(obs) && aligned16(gamma) && aligned16(beta),
+                "null / unaligned tensor");
+  if (d->n == 0) return 0;
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
+  const long Kp = (long)d->Cin * d->KH * d->KW;
+  GemmArgs g{};
+  g.M = d->n * OH * OW; g.N = d->Cout; g.K = Kp;
+  g.a = obs_patch_src(obs, is_u8, mean, rstd, gamma, beta, d, OH * OW, OW);
+  g.b = plain_src(w, Kp);
+  g.o = plain_out(y, d->Cout);
+  g.bias = bias; g.act = d->act;
+  g.k_per_split = srl_ceil_div(Kp, BK) * BK;
+  g.vec_a = 1;
+  g.vec_b = aligned16(w) && Kp % 4 == 0;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (d->Cout > 64) rc = launch<128, 128, 2, 2, false, false, SRC_OBS, SRC_PLAIN>(st, g, 1, 1);
+  else if (d->Cout > 32) rc = launch<256, 64, 4, 1, false, false, SRC_OBS, SRC_PLAIN>(st, g, 1, 1);
+  else rc = launch<256, 32, 4, 1, false, false, SRC_OBS, SRC_PLAIN>(st, g, 1, 1);
+  SRL_CHECK_ARG(rc == 0, "grid too large");
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d) {
+  if (check_desc(d) != 0) return 0;
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
+  const long P = (long)OH * OW, Kp = (long)d->Cin * d->KH * d->KW;
+  const long tiles = srl_ceil_div(d->Cout, 32) * srl_ceil_div(Kp, 256);
+  const long split = want_split(d->n, tiles, P);
+  return (int64_t)((split + 1) * P * d->Cout * Kp + P * d->Cout + 64);
+}
+
+extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, const float* mean,
+                                  const float* rstd, const float* gamma, const float* beta, const float* w,
+                                  const float* dz, float* dw, float* db, float* dgamma, float* dbeta, float* workspace) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, 1), "unsupported geometry");
+  SRL_CHECK_ARG(obs && mean && rstd && gamma && beta && w && dz && dw && db && dgamma && dbeta && workspace,
+                "null tensor");
+  SRL_CHECK_ARG(aligned16(obs) && aligned16(dz) && aligned16(workspace) && d->Cout % 4 == 0, "unaligned tensor / Cout % 4");
+  if (d->n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
+  const int P = OH * OW;
+  const long Kp = (long)d->Cin * d->KH * d->KW;
+  // workspace: Q [P][Cout][Kp] | R [P][Cout] (padded to 16 B) | split slabs
+  float* Q = workspace;
+  float* R = Q + (long)P * d->Cout * Kp;
+  float* slabs = R + (((long)P * d->Cout + 3) & ~3L);
+  // R[pos, o] = sum_n dz[(n, pos), o]
+  int rc = srl_colsum(stream, dz, (int64_t)P * d->Cout, d->n, P * d->Cout, R, 0);
+  if (rc != 0) return rc;
+  // Q[pos][o][k] = sum_n dz[(n,pos), o] * xhat[n, patch(pos)[k]]   — one batched GEMM over the P output positions
+  GemmArgs g{};
+  g.M = d->Cout; g.N = Kp; g.K = d->n;
+  g.a = plain_src(dz, (long)P * d->Cout);  // A(i = o, k = n) = dz[n*P*Cout + pos*Cout + o]
+  g.a.brw = OW; g.a.by_stride = OW * d->Cout; g.a.bx_stride = d->Cout;
+  g.b = obs_patch_src(obs, is_u8, mean, rstd, nullptr, nullptr, d, 1, 1);  // rows = samples; no affine: xhat
+  g.b.brw = OW; g.b.by_stride = d->stride * d->W; g.b.bx_stride = d->stride;
+  const long tiles = srl_ceil_div(d->Cout, 32) * srl_ceil_div(Kp, 256);
+  const int nsplit = plan_split(d->n, want_split(d->n, tiles, P), &g.k_per_split);
+  g.o = plain_out(nsplit > 1 ? slabs : Q, Kp);
+  g.o.batch_stride = (long)d->Cout * Kp;
+  g.slab = (long)P * d->Cout * Kp;
+  g.vec_a = 1; g.vec_b = 1;
+  rc = launch<32, 256, 1, 4, true, true, SRC_PLAIN, SRC_OBS>(st, g, P, nsplit);
+  SRL_CHECK_ARG(rc == 0, "grid too large");
+  SRL_LAUNCH_CHECK();
+  if (nsplit > 1) {
+    const long total = (long)P * d->Cout * Kp;
+    const unsigned grid = (unsigned)(srl_ceil_div(total, 256) < 8192 ? srl_ceil_div(total, 256) : 8192);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, (const float*)slabs, nsplit, (long)P,
+                       (long)d->Cout, Kp, Q, Kp, (long)d->Cout * Kp, 0);
+    SRL_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(obs_dw_kernel, dim3((unsigned)srl_ceil_div(d->Cout * Kp, 256)), dim3(256), 0, st, Q, R, gamma, beta, P,
+                     OW, d->Cout, d->Cin, d->H, d->W, d->KH, d->KW, d->stride, dw, db);
+  hipLaunchKernelGGL(obs_affine_kernel, dim3((unsigned)srl_ceil_div(d->Cin * d->H * d->W, 256)), dim3(256), 0, st, Q, R, w,
+                     OH, OW, d->Cout, d->Cin, d->H, d->W, d->KH, d->KW, d->stride, dgamma, dbeta);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,451 @@
+// FP32 contraction core on the CDNA4 matrix cores, shared by the dense GEMM entry point (gemm.hip) and the
+// implicit-GEMM convolution entry points (conv.hip):   C[M,N] = epilogue( sum_k A(i,k) * B(k,j) ).
+//
+// v_mfma_f32_32x32x2_f32 (exact float32 FMA chains, 64 FLOP/clk/SIMD = the FP32 peak of gfx950): lane l of a
+// wavefront supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; the 32x32 result sits in 16 accumulator
+// registers per lane with col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+//
+// A workgroup of 4 wavefronts (WM x WN) owns a BM x BN output tile and walks K in steps of BK = 32.  Both operand
+// tiles live "k-major" in LDS ([BK][BM+pad], [BK][BN+pad]) whatever their layout in memory, so the MFMA feed is one
+// conflict-free ds_read_b32 per operand per step.  What varies is how an operand is *staged*:
+//   orientation  k-contiguous (rows = output index; float4 along k, transposed on the LDS store, pitch BX+1)
+//                k-major      (rows = reduction index; float4 along the output index, ds_write_b128, pitch BX+4)
+//   source       SRC_PLAIN    a dense row-major matrix
+//                SRC_CONV     rows are convolution patches gathered on the fly from an NHWC activation
+//                SRC_DGRAD    rows are the output-gradient taps that reach one input pixel (zero where none)
+//                SRC_OBS      rows are patches of the NCHW uint8/float32 observation with the whole-observation
+//                             LayerNorm (and optionally its affine) applied in the load path
+// so a convolution never materialises its patch matrix (no im2col / col2im traffic).  Row / column indices are
+// split with precomputed multiply-shift divisors.  Global loads of tile t+1 are issued before the MFMAs of tile t
+// and written to LDS after them (register double buffering).
+#pragma once
+#include "srl_common.h"
+
+namespace srlgemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+enum { SRC_PLAIN = 0, SRC_CONV = 1, SRC_DGRAD = 2, SRC_OBS = 3 };
+
+// ---- division by a runtime-invariant 32-bit divisor (valid for dividends < 2^31) ----------------------------------
+struct FastDiv {
+  uint32_t d, mul, shr;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f{d ? d : 1u, 0u, 0u};
+  if (f.d != 1) {
+    uint32_t lg = 31 - __builtin_clz(f.d);
+    if (f.d & (f.d - 1)) lg += 1;  // ceil(log2 d)
+    const uint32_t p = 31 + lg;
+    f.mul = (uint32_t)(((1ull << p) + f.d - 1) / f.d);
+    f.shr = p - 32;
+  }
+  return f;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr);
+}
+#endif
+
+// One operand.  For the gather sources a "row" r splits as r = (n * rows_per_img + y * rows_per_line + x) and a
+// "column" c as described per mode; element address = row_off(r) + col_off(c) (32-bit element offsets).
+struct SrcDesc {
+  const void* base;
+  long ld;  // SRC_PLAIN row pitch
+  FastDiv f_img, f_line;  // rows per image, rows per image line
+  int img_stride, y_stride, x_stride;
+  FastDiv f_inner, f_tap;  // column split (CONV: kw*C run; DGRAD: Co then taps-per-line; OBS: KH*KW then KW)
+  int k1_stride, k2_stride;  // CONV: W*C per kh.  OBS: H*W per channel, W per kh.
+  int OH, OW;                // DGRAD: bounds of the gradient image
+  const float *mean, *rstd, *gamma, *beta;  // OBS LayerNorm
+  int is_u8, affine;
+  // batch (grid.y) offset of the base: (by / brw) * by_stride + (by % brw) * bx_stride, in elements
+  int brw, by_stride, bx_stride;
+};
+
+struct OutDesc {
+  float* out;
+  long ldo;
+  int rowmap;  // 0: out[row*ldo + col];  1: row -> (n,y,x) -> n*img + y*ys + x*xs + col
+  FastDiv f_img, f_line;
+  long img_stride, y_stride, x_stride;
+  long batch_stride;
+};
+
+struct GemmArgs {
+  long M, N, K;
+  SrcDesc a, b;
+  OutDesc o;
+  long slab;  // split-K: out + z*slab
+  const float* bias;
+  const float* dact_src;  // same addressing as the output (own pitch ld_dact when !rowmap)
+  long ld_dact;
+  int act, dact, accumulate;
+  long k_per_split;
+  int vec_a, vec_b;
+  int tiles_n;
+};
+
+#ifdef __HIPCC__
+// ---- source policies ------------------------------------------------------------------------------------------------
+struct RowInfo {
+  int off;  // element offset of the row's origin
+  int y, x;
+  float rs, mr;  // OBS: rstd and -mean*rstd of the row's sample
+  int pos;       // OBS: offset inside the image (index into gamma/beta)
+};
+
+template <int MODE>
+__device__ __forceinline__ RowInfo row_info(const SrcDesc& s, uint32_t r) {
+  RowInfo ri;
+  const uint32_t n = fdiv(r, s.f_img);
+  const uint32_t rem = r - n * s.f_img.d;
+  const uint32_t y = fdiv(rem, s.f_line);
+  const uint32_t x = rem - y * s.f_line.d;
+  ri.y = (int)y;
+  ri.x = (int)x;
+  ri.pos = (int)(y * s.y_stride + x * s.x_stride);
+  ri.off = (int)n * s.img_stride + ri.pos;
+  if (MODE == SRC_OBS) {
+    const float rs = s.rstd[n];
+    ri.rs = rs;
+    ri.mr = -s.mean[n] * rs;
+  } else {
+    ri.rs = 1.f;
+    ri.mr = 0.f;
+  }
+  return ri;
+}
+
+struct ColInfo {
+  int off;
+  int jh, jw;
+};
+
+template <int MODE>
+__device__ __forceinline__ ColInfo col_info(const SrcDesc& s, uint32_t c) {
+  ColInfo ci;
+  ci.jh = ci.jw = 0;
+  const uint32_t t = fdiv(c, s.f_inner);
+  const uint32_t rem = c - t * s.f_inner.d;
+  if (MODE == SRC_CONV) {
+    ci.off = (int)(t * s.k1_stride + rem);
+  } else if (MODE == SRC_DGRAD) {
+    const uint32_t jh = fdiv(t, s.f_tap);
+    const uint32_t jw = t - jh * s.f_tap.d;
+    ci.jh = (int)jh;
+    ci.jw = (int)jw;
+    ci.off = -(int)((jh * s.OW + jw) * s.f_inner.d) + (int)rem;
+  } else {  // SRC_OBS
+    const uint32_t kh = fdiv(rem, s.f_tap);
+    const uint32_t kw = rem - kh * s.f_tap.d;
+    ci.off = (int)(t * s.k1_stride + kh * s.k2_stride + kw);
+  }
+  return ci;
+}
+
+template <int MODE>
+__device__ __forceinline__ float4 gather4(const SrcDesc& s, const RowInfo& ri, const ColInfo& ci) {
+  if (MODE == SRC_DGRAD) {
+    if ((unsigned)(ri.y - ci.jh) >= (unsigned)s.OH || (unsigned)(ri.x - ci.jw) >= (unsigned)s.OW)
+      return make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int off = ri.off + ci.off;
+  if (MODE != SRC_OBS) return *reinterpret_cast<const float4*>(static_cast<const float*>(s.base) + off);
+  float4 v;
+  if (s.is_u8) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(s.base) + off);
+    v = make_float4((float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24));
+  } else {
+    v = *reinterpret_cast<const float4*>(static_cast<const float*>(s.base) + off);
+  }
+  // LayerNorm of the sample: (x - mean) * rstd  [* gamma + beta]
+  v.x = fmaf(v.x, ri.rs, ri.mr); v.y = fmaf(v.y, ri.rs, ri.mr);
+  v.z = fmaf(v.z, ri.rs, ri.mr); v.w = fmaf(v.w, ri.rs, ri.mr);
+  if (s.affine) {
+    const int p = ri.pos + ci.off;
+    const float4 g = *reinterpret_cast<const float4*>(s.gamma + p);
+    const float4 b = *reinterpret_cast<const float4*>(s.beta + p);
+    v.x = fmaf(v.x, g.x, b.x); v.y = fmaf(v.y, g.y, b.y);
+    v.z = fmaf(v.z, g.z, b.z); v.w = fmaf(v.w, g.w, b.w);
+  }
+  return v;
+}
+
+// ---- staging of one operand tile: BX output indices x BK reduction indices ------------------------------------------
+template <int BX, bool KMAJOR, int MODE>
+struct Stage {
+  static constexpr int LD = KMAJOR ? BX + 4 : BX + 1;  // LDS row pitch (floats)
+  static constexpr int NF = BX * BK / 256;             // floats per thread
+  static constexpr int NV = NF / 4;                    // float4 per thread
+  float r[NF];
+  // cached, k-loop invariant part of the gather: rows when k-contiguous, columns when k-major
+  RowInfo frow[(MODE != SRC_PLAIN && !KMAJOR) ? NV : 1];
+  ColInfo fcol[(MODE != SRC_PLAIN && KMAJOR) ? NV : 1];
+
+  // x0: first output index of the tile; xn: extent of that dimension
+  __device__ __forceinline__ void prepare(const SrcDesc& s, long x0, long xn) {
+    if (MODE == SRC_PLAIN) return;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int u = tid + q * 256;
+      if (!KMAJOR) {
+        long x = x0 + u / 8;
+        if (x >= xn) x = xn - 1;  // clamp: the value is discarded by the bounds check in load()
+        frow[q] = row_info<MODE>(s, (uint32_t)x);
+      } else {
+        long x = x0 + (u % (BX / 4)) * 4;
+        if (x >= xn) x = 0;
+        fcol[q] = col_info<MODE>(s, (uint32_t)x);
+      }
+    }
+  }
+
+  __device__ __forceinline__ void load(const SrcDesc& s, long x0, long xn, long k0, long kend, bool vec) {
+    const int tid = threadIdx.x;
+    if (MODE != SRC_PLAIN) {
+      if (!KMAJOR) {
+        const long k = k0 + (tid % 8) * 4;  // u % 8 == tid % 8 for every q
+        const bool kok = k < kend;
+        ColInfo ci;
+        if (kok) ci = col_info<MODE>(s, (uint32_t)k);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const int u = tid + q * 256;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (kok && x0 + u / 8 < xn) v = gather4<MODE>(s, frow[q], ci);
+          r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const int u = tid + q * 256;
+          const long k = k0 + u / (BX / 4), x = x0 + (u % (BX / 4)) * 4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (x < xn && k < kend) {
+            const RowInfo ri = row_info<MODE>(s, (uint32_t)k);
+            v = gather4<MODE>(s, ri, fcol[q]);
+          }
+          r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+        }
+      }
+      return;
+    }
+    const float* __restrict__ src = static_cast<const float*>(s.base);
+    const long ld = s.ld;
+    if (vec) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int u = tid + q * 256;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!KMAJOR) {
+          const long x = x0 + u / 8, k = k0 + (u % 8) * 4;
+          if (x < xn && k < kend) v = *reinterpret_cast<const float4*>(src + x * ld + k);
+        } else {
+          const long k = k0 + u / (BX / 4), x = x0 + (u % (BX / 4)) * 4;
+          if (x < xn && k < kend) v = *reinterpret_cast<const float4*>(src + k * ld + x);
+        }
+        r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NF; ++q) {
+        const int e = tid + q * 256;
+        float v = 0.f;
+        if (!KMAJOR) {
+          const long x = x0 + e / BK, k = k0 + e % BK;
+          if (x < xn && k < kend) v = src[x * ld + k];
+        } else {
+          const long k = k0 + e / BX, x = x0 + e % BX;
+          if (x < xn && k < kend) v = src[k * ld + x];
+        }
+        r[q] = v;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ lds, bool vec) const {
+    const int tid = threadIdx.x;
+    if (vec || MODE != SRC_PLAIN) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int u = tid + q * 256;
+        if (!KMAJOR) {
+          const int x = u / 8, k = (u % 8) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) lds[(k + j) * LD + x] = r[4 * q + j];
+        } else {
+          const int k = u / (BX / 4), x = (u % (BX / 4)) * 4;
+          *reinterpret_cast<float4*>(lds + k * LD + x) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NF; ++q) {
+        const int e = tid + q * 256;
+        if (!KMAJOR) lds[(e % BK) * LD + e / BK] = r[q];
+        else lds[(e / BX) * LD + e % BX] = r[q];
+      }
+    }
+  }
+};
+
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 wavefronts per workgroup");
+  using SA = Stage<BM, AKM, AMODE>;
+  using SB = Stage<BN, BKM, BMODE>;
+  __shared__ __attribute__((aligned(16))) float lds[BK * SA::LD + BK * SB::LD + 8];
+  float* As = lds;
+  float* Bs = lds + ((BK * SA::LD + 3) & ~3);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const long tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x % g.tiles_n;
+  const long m0 = tile_m * BM, n0 = tile_n * BN;
+  const long kbeg = (long)blockIdx.z * g.k_per_split;
+  const long kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+
+  // batch (grid.y): shift the operand bases
+  const int by = blockIdx.y;
+  if (by) {
+    const long ao = (long)(by / g.a.brw) * g.a.by_stride + (long)(by % g.a.brw) * g.a.bx_stride;
+    const long bo = (long)(by / g.b.brw) * g.b.by_stride + (long)(by % g.b.brw) * g.b.bx_stride;
+    g.a.base = (AMODE == SRC_OBS && g.a.is_u8) ? (const void*)(static_cast<const uint8_t*>(g.a.base) + ao)
+                                               : (const void*)(static_cast<const float*>(g.a.base) + ao);
+    g.b.base = (BMODE == SRC_OBS && g.b.is_u8) ? (const void*)(static_cast<const uint8_t*>(g.b.base) + bo)
+                                               : (const void*)(static_cast<const float*>(g.b.base) + bo);
+    if (BMODE == SRC_OBS && g.b.affine) { g.b.gamma += bo; g.b.beta += bo; }
+    if (AMODE == SRC_OBS && g.a.affine) { g.a.gamma += ao; g.a.beta += ao; }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  SA sa;
+  SB sb;
+  const bool va = g.vec_a != 0, vb = g.vec_b != 0;
+  sa.prepare(g.a, m0, g.M);
+  sb.prepare(g.b, n0, g.N);
+  sa.load(g.a, m0, g.M, kbeg, kend, va);
+  sb.load(g.b, n0, g.N, kbeg, kend, vb);
+
+  for (long k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();  // previous tile's LDS reads are done
+    sa.store(As, va);
+    sb.store(Bs, vb);
+    __syncthreads();
+    if (k0 + BK < kend) {  // prefetch the next tile; latency hides under the MFMAs below
+      sa.load(g.a, m0, g.M, k0 + BK, kend, va);
+      sb.load(g.b, n0, g.N, k0 + BK, kend, vb);
+    }
+    const float* ap = As + h * SA::LD + wm * (TM * 32) + l31;
+    const float* bp = Bs + h * SB::LD + wn * (TN * 32) + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = ap[kk * 2 * SA::LD + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bp[kk * 2 * SB::LD + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------------------------------
+  float* out = g.o.out + (long)blockIdx.z * g.slab + (long)by * g.o.batch_stride;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row >= g.M) continue;
+      long rbase, dbase;
+      if (g.o.rowmap) {
+        const uint32_t n = fdiv((uint32_t)row, g.o.f_img);
+        const uint32_t rem = (uint32_t)row - n * g.o.f_img.d;
+        const uint32_t y = fdiv(rem, g.o.f_line);
+        const uint32_t x = rem - y * g.o.f_line.d;
+        rbase = (long)n * g.o.img_stride + (long)y * g.o.y_stride + (long)x * g.o.x_stride;
+        dbase = rbase;
+      } else {
+        rbase = row * g.o.ldo;
+        dbase = row * g.ld_dact;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const long col = n0 + wn * (TN * 32) + j * 32 + l31;
+        if (col >= g.N) continue;
+        float v = acc[i][j][r] + (g.bias ? g.bias[col] : 0.f);
+        v = act_apply(v, g.act);
+        if (g.dact_src) v *= act_grad_from_output(g.dact_src[dbase + col], g.dact);
+        float* dst = out + rbase + col;
+        if (g.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+  }
+}
+
+static __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* ws, int nslab, long batch, long M, long N,
+                                                           float* C, long ldc, long c_batch, int accumulate) {
+  const long per = M * N, total = batch * per;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int z = 0; z < nslab; ++z) s += ws[(long)z * total + e];
+    const long b = e / per, w = e % per;
+    float* dst = C + b * c_batch + (w / N) * ldc + (w % N);
+    *dst = accumulate ? *dst + s : s;
+  }
+}
+#endif  // __HIPCC__
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+inline SrcDesc plain_src(const float* base, long ld) {
+  SrcDesc s{};
+  s.base = base;
+  s.ld = ld;
+  s.f_img = s.f_line = s.f_inner = s.f_tap = make_fastdiv(1);
+  s.brw = 1;
+  return s;
+}
+
+// k range per split: a multiple of BK so that float4 loads never straddle a split boundary
+inline int plan_split(long K, int want, long* k_per_split) {
+  if (want < 1) want = 1;
+  long kps = srl_ceil_div(srl_ceil_div(K, want), BK) * BK;
+  if (kps == 0) kps = BK;
+  *k_per_split = kps;
+  const long n = srl_ceil_div(K, kps);
+  return (int)(n > 0 ? n : 1);
+}
+
+#ifdef __HIPCC__
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE>
+inline int launch(hipStream_t st, GemmArgs a, int batch, int nsplit) {
+  const long tiles_m = srl_ceil_div(a.M, BM);
+  a.tiles_n = (int)srl_ceil_div(a.N, BN);
+  const long nblk = tiles_m * a.tiles_n;
+  if (nblk > 0x7fffffffL || batch > 65535 || nsplit > 65535) return -EINVAL;
+  dim3 grid((unsigned)nblk, (unsigned)batch, (unsigned)nsplit);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE>), grid, dim3(256), 0, st, a);
+  return 0;
+}
+#endif
+
+}  // namespace srlgemm

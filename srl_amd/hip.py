@@ -43,7 +43,24 @@ class GemmDesc(Structure):
                 ("dact", c_int32), ("accumulate", c_int32), ("split_k", c_int32), ("workspace", c_void_p)]
 
 
+class ConvDesc(Structure):
+    _fields_ = [("n", c_int64), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("KH", c_int32), ("KW", c_int32),
+                ("stride", c_int32), ("Cout", c_int32), ("act", c_int32)]
+
+
+_CD = POINTER(ConvDesc)
+
 _SIGNATURES = {
+    "srl_conv2d_supported": (c_int, [_CD, c_int]),
+    "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srl_conv2d_wgrad_workspace": (c_int64, [_CD]),
+    "srl_conv2d_nhwc_wgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srl_conv2d_dgrad_weight_elems": (c_int64, [_CD]),
+    "srl_conv2d_dgrad_repack": (c_int, [c_void_p, _CD, c_void_p, c_void_p]),
+    "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int] + [c_void_p] * 7),
+    "srl_conv2d_obs_bwd_workspace": (c_int64, [_CD]),
+    "srl_conv2d_obs_bwd": (c_int, [c_void_p, _CD, c_void_p, c_int] + [c_void_p] * 11),
     "srl_abi_version": (c_int, []),
     "srl_last_error": (c_char_p, []),
     "srl_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
@@ -331,6 +348,68 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, adamw, step, grad
                             float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(adamw),
                             int(step), float(grad_scale), float(max_norm), _ptr(sumsq, torch.float64, "sumsq"),
                             _ptr(grad_norm_out, f, "grad_norm_out")), "srl_adam_step")
+
+
+def conv_desc(n, H, W, Cin, KH, KW, stride, Cout, act=ACT_NONE) -> ConvDesc:
+    return ConvDesc(int(n), int(H), int(W), int(Cin), int(KH), int(KW), int(stride), int(Cout), int(act))
+
+
+def _conv_flops(d: ConvDesc):
+    oh, ow = (d.H - d.KH) // d.stride + 1, (d.W - d.KW) // d.stride + 1
+    return 2.0 * d.n * oh * ow * d.Cout * d.KH * d.KW * d.Cin
+
+
+def conv2d_supported(d: ConvDesc, first_layer: bool) -> bool:
+    return bool(lib().srl_conv2d_supported(ctypes.byref(d), int(first_layer)))
+
+
+def conv2d_nhwc_fwd(d: ConvDesc, x_ptr, w_ptr, bias_ptr, y_ptr):
+    with _scope("conv_fwd", _conv_flops(d)):
+        _check(lib().srl_conv2d_nhwc_fwd(_stream(), ctypes.byref(d), x_ptr, w_ptr, bias_ptr, y_ptr), "srl_conv2d_nhwc_fwd")
+
+
+def conv2d_wgrad_workspace(d: ConvDesc) -> int:
+    return int(lib().srl_conv2d_wgrad_workspace(ctypes.byref(d)))
+
+
+def conv2d_nhwc_wgrad(d: ConvDesc, x_ptr, dz_ptr, dw_ptr, ws_ptr):
+    with _scope("conv_wgrad", _conv_flops(d)):
+        _check(lib().srl_conv2d_nhwc_wgrad(_stream(), ctypes.byref(d), x_ptr, dz_ptr, dw_ptr, ws_ptr),
+               "srl_conv2d_nhwc_wgrad")
+
+
+def conv2d_dgrad_weight_elems(d: ConvDesc) -> int:
+    return int(lib().srl_conv2d_dgrad_weight_elems(ctypes.byref(d)))
+
+
+def conv2d_dgrad_repack(d: ConvDesc, w_ptr, wt_ptr):
+    _check(lib().srl_conv2d_dgrad_repack(_stream(), ctypes.byref(d), w_ptr, wt_ptr), "srl_conv2d_dgrad_repack")
+
+
+def conv2d_nhwc_dgrad(d: ConvDesc, dz_ptr, wt_ptr, x_act_ptr, dact, dx_ptr):
+    with _scope("conv_dgrad", _conv_flops(d)):
+        _check(lib().srl_conv2d_nhwc_dgrad(_stream(), ctypes.byref(d), dz_ptr, wt_ptr, x_act_ptr, int(dact), dx_ptr),
+               "srl_conv2d_nhwc_dgrad")
+
+
+def conv2d_obs_fwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr):
+    with _scope("conv_obs_fwd", _conv_flops(d)):
+        _check(
+            lib().srl_conv2d_obs_fwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), mean_ptr, rstd_ptr, gamma_ptr,
+                                     beta_ptr, w_ptr, bias_ptr, y_ptr), "srl_conv2d_obs_fwd")
+
+
+def conv2d_obs_bwd_workspace(d: ConvDesc) -> int:
+    return int(lib().srl_conv2d_obs_bwd_workspace(ctypes.byref(d)))
+
+
+def conv2d_obs_bwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, dz_ptr, dw_ptr, db_ptr,
+                   dgamma_ptr, dbeta_ptr, ws_ptr):
+    with _scope("conv_obs_bwd", _conv_flops(d)):
+        _check(
+            lib().srl_conv2d_obs_bwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), mean_ptr, rstd_ptr, gamma_ptr,
+                                     beta_ptr, w_ptr, dz_ptr, dw_ptr, db_ptr, dgamma_ptr, dbeta_ptr, ws_ptr),
+            "srl_conv2d_obs_bwd")
 
 
 def _wrap_for_profile(names):

@@ -457,3 +457,91 @@ def test_adam_matches_torch(max_norm):
                       sumsq=sumsq, grad_norm_out=gn)
         assert abs(gn.item() - ref_norm.item()) <= 1e-5 * ref_norm.item()
         assert rel_close(p.cpu().numpy(), tp.detach().numpy(), 1e-6, scale=1.0), step
+
+
+# ------------------------------------------------------------------------------------------------ implicit-GEMM convolutions
+def _conv_ref(x_nhwc, w_ohwi, bias, stride, act):
+    """float64 reference on the CPU: NHWC in/out, weights [Cout, KH, KW, Cin]."""
+    xt = torch.from_numpy(x_nhwc).double().permute(0, 3, 1, 2).requires_grad_(True)
+    wt = torch.from_numpy(w_ohwi).double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    bt = torch.from_numpy(bias).double().requires_grad_(True)
+    z = torch.nn.functional.conv2d(xt, wt, bt, stride=stride)
+    y = torch.relu(z) if act == 1 else z
+    return xt, wt, bt, y
+
+
+@pytest.mark.parametrize("n,H,Cin,k,s,Cout", [(6, 20, 32, 4, 2, 64), (5, 9, 64, 3, 1, 64), (7, 11, 8, 5, 3, 12),
+                                              (300, 9, 64, 3, 1, 64), (3, 12, 4, 3, 2, 132)])
+def test_conv2d_nhwc_implicit(n, H, Cin, k, s, Cout):
+    rng = np.random.default_rng(n + H)
+    x = np.maximum(rng.standard_normal((n, H, H, Cin)), 0).astype(np.float32)  # a post-ReLU activation
+    w = (rng.standard_normal((Cout, k, k, Cin)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    d = hip.conv_desc(n, H, H, Cin, k, k, s, Cout, act=1)
+    assert hip.conv2d_supported(d, False)
+    OH = (H - k) // s + 1
+    dx_, dw_, db_ = dev(x), dev(w), dev(b)
+    y = torch.full((n, OH, OH, Cout), np.nan, device=DEV)
+    hip.conv2d_nhwc_fwd(d, dx_.data_ptr(), dw_.data_ptr(), db_.data_ptr(), y.data_ptr())
+    xt, wt, bt, yref = _conv_ref(x, w, b, s, 1)
+    assert rel_close(y.cpu().numpy(), yref.permute(0, 2, 3, 1).detach().numpy(), 1e-5, scale=1.0)
+    # backward: dz = upstream gradient w.r.t. the pre-activation
+    dz = (rng.standard_normal((n, OH, OH, Cout)) * (yref.permute(0, 2, 3, 1).detach().numpy() > 0)).astype(np.float32)
+    z = torch.nn.functional.conv2d(xt, wt, bt, stride=s)
+    z.backward(torch.from_numpy(dz).double().permute(0, 3, 1, 2))
+    ddz = dev(dz)
+    g0 = rng.standard_normal(w.shape).astype(np.float32)
+    gw = dev(g0).clone()
+    ws = torch.empty(max(hip.conv2d_wgrad_workspace(d), 1), device=DEV)
+    hip.conv2d_nhwc_wgrad(d, dx_.data_ptr(), ddz.data_ptr(), gw.data_ptr(), ws.data_ptr())
+    ref_gw = g0 + wt.grad.permute(0, 2, 3, 1).numpy()
+    assert rel_close(gw.cpu().numpy(), ref_gw, 1e-5, scale=float(np.sqrt(n * OH * OH)))
+    wtp = torch.empty(hip.conv2d_dgrad_weight_elems(d), device=DEV)
+    hip.conv2d_dgrad_repack(d, dw_.data_ptr(), wtp.data_ptr())
+    dxo = torch.full((n, H, H, Cin), np.nan, device=DEV)
+    hip.conv2d_nhwc_dgrad(d, ddz.data_ptr(), wtp.data_ptr(), dx_.data_ptr(), 1, dxo.data_ptr())
+    ref_dx = xt.grad.permute(0, 2, 3, 1).numpy() * (x > 0)
+    assert rel_close(dxo.cpu().numpy(), ref_dx, 1e-5, scale=1.0)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n,C,H,k,s,Cout,u8", [(5, 4, 84, 8, 4, 32, True), (3, 2, 20, 4, 4, 8, False),
+                                               (130, 4, 84, 8, 4, 32, True)])
+def test_conv2d_obs_implicit(n, C, H, k, s, Cout, u8):
+    rng = np.random.default_rng(n)
+    obs = rng.integers(0, 256, (n, C, H, H), dtype=np.uint8)
+    if not u8:
+        obs = obs.astype(np.float32) / 7
+    gamma = (1 + 0.1 * rng.standard_normal((C, H, H))).astype(np.float32)
+    beta = (0.1 * rng.standard_normal((C, H, H))).astype(np.float32)
+    w = (rng.standard_normal((Cout, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    d = hip.conv_desc(n, H, H, C, k, k, s, Cout, act=1)
+    assert hip.conv2d_supported(d, True)
+    OH = (H - k) // s + 1
+    dobs, dg, dbt, dw_, db_ = dev(obs), dev(gamma), dev(beta), dev(w), dev(b)
+    mean = torch.empty(n, device=DEV)
+    rstd = torch.empty(n, device=DEV)
+    hip.obs_ln_stats(dobs.data_ptr(), u8, n, C * H * H, mean.data_ptr(), rstd.data_ptr())
+    y = torch.full((n, OH, OH, Cout), np.nan, device=DEV)
+    hip.conv2d_obs_fwd(d, dobs.data_ptr(), u8, mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), dbt.data_ptr(),
+                       dw_.data_ptr(), db_.data_ptr(), y.data_ptr())
+    tg = torch.from_numpy(gamma).double().requires_grad_(True)
+    tb = torch.from_numpy(beta).double().requires_grad_(True)
+    tw = torch.from_numpy(w).double().requires_grad_(True)
+    tbias = torch.from_numpy(b).double().requires_grad_(True)
+    xn = torch.nn.functional.layer_norm(torch.from_numpy(obs.astype(np.float64)), (C, H, H), tg, tb, 1e-5)
+    z = torch.nn.functional.conv2d(xn, tw, tbias, stride=s)
+    yref = torch.relu(z)
+    assert rel_close(y.cpu().numpy(), yref.permute(0, 2, 3, 1).detach().numpy(), 1e-5, scale=1.0)
+    dz = (rng.standard_normal((n, OH, OH, Cout)) * (yref.permute(0, 2, 3, 1).detach().numpy() > 0)).astype(np.float32)
+    z.backward(torch.from_numpy(dz).double().permute(0, 3, 1, 2))
+    ddz = dev(dz)
+    outs = [torch.zeros(s_, device=DEV) for s_ in (w.shape, (Cout,), gamma.shape, beta.shape)]
+    ws = torch.empty(hip.conv2d_obs_bwd_workspace(d), device=DEV)
+    hip.conv2d_obs_bwd(d, dobs.data_ptr(), u8, mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), dbt.data_ptr(),
+                       dw_.data_ptr(), ddz.data_ptr(), *[o.data_ptr() for o in outs], ws.data_ptr())
+    sc = float(np.sqrt(n * OH * OH))
+    for got, ref, name in zip(outs, (tw.grad, tbias.grad, tg.grad, tb.grad), ("dw", "db", "dgamma", "dbeta")):
+        assert rel_close(got.cpu().numpy(), ref.numpy(), 2e-5, scale=sc if name in ("dw", "db") else float(np.sqrt(n))), name
+    torch.cuda.synchronize()

@@ -187,3 +187,19 @@ def test_device_resident_sample_matches_host_sample():
     for k in ("policy_loss", "value_loss", "grad_norm"):
         assert ra.stats[k] == rb.stats[k]
     assert isinstance(devs.analyzed_result.adv, torch.Tensor)
+
+
+def test_implicit_and_explicit_conv_paths_agree():
+    """The implicit-GEMM convolution path and the im2col fallback are two implementations of the same step."""
+    arrays = synthetic.make_sample_arrays(seed=3, T=6, B=5, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.1)
+    stats = []
+    for explicit in (False, True):
+        tr = make_trainer(CNN_POLICY, ATARI_TRAINER)
+        tr.policy.net.force_explicit_conv = explicit
+        res = tr.step(synthetic.to_sample_batch(arrays))
+        stats.append((res.stats, tr.policy.get_checkpoint()["state_dict"]))
+    for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
+        a, b = stats[0][0][k], stats[1][0][k]
+        assert abs(a - b) <= 1e-5 * max(abs(b), 1e-2), (k, a, b)
+    for k in stats[0][1]:
+        assert np.abs(stats[0][1][k].numpy() - stats[1][1][k].numpy()).max() <= 2e-5, k
