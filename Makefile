@@ -2,7 +2,7 @@
 HIPCC ?= hipcc
 ARCH  ?= gfx950
 CSRC  := $(wildcard srl_amd/csrc/*.hip)
-HDRS  := srl_amd/csrc/srl_common.h include/srl_hip.h
+HDRS  := $(wildcard srl_amd/csrc/*.h) include/srl_hip.h
 LIB   := srl_amd/csrc/libsrlhip.so
 
 all: $(LIB)

@@ -80,6 +80,7 @@ struct GemmArgs {
   OutDesc o;
   long slab;  // split-K: out + z*slab
   const float* bias;
+  long bias_batch;  // per-batch (grid.y) stride of the bias vector
   const float* dact_src;  // same addressing as the output (own pitch ld_dact when !rowmap)
   long ld_dact;
   int act, dact, accumulate;
@@ -93,7 +94,7 @@ struct GemmArgs {
 struct RowInfo {
   int off;  // element offset of the row's origin
   int y, x;
-  float rs, mr;  // OBS: rstd and -mean*rstd of the row's sample
+  float rs, mr;  // OBS: rstd and mean of the row's sample
   int pos;       // OBS: offset inside the image (index into gamma/beta)
 };
 
@@ -108,10 +109,9 @@ __device__ __forceinline__ RowInfo row_info(const SrcDesc& s, uint32_t r) {
   ri.x = (int)x;
   ri.pos = (int)(y * s.y_stride + x * s.x_stride);
   ri.off = (int)n * s.img_stride + ri.pos;
-  if (MODE == SRC_OBS) {
-    const float rs = s.rstd[n];
-    ri.rs = rs;
-    ri.mr = -s.mean[n] * rs;
+  if (MODE == SRC_OBS) {  // raw statistics: arithmetic on loaded values is deferred to the LDS-store phase
+    ri.rs = s.rstd[n];
+    ri.mr = s.mean[n];
   } else {
     ri.rs = 1.f;
     ri.mr = 0.f;
@@ -155,21 +155,27 @@ __device__ __forceinline__ float4 gather4(const SrcDesc& s, const RowInfo& ri, c
   const int off = ri.off + ci.off;
   if (MODE != SRC_OBS) return *reinterpret_cast<const float4*>(static_cast<const float*>(s.base) + off);
   float4 v;
-  if (s.is_u8) {
-    const uint32_t w = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(s.base) + off);
-    v = make_float4((float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24));
+  if (s.is_u8) {  // raw bytes travel as one dword; decoded in obs_finish()
+    v.x = __uint_as_float(*reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(s.base) + off));
+    v.y = v.z = v.w = 0.f;
   } else {
     v = *reinterpret_cast<const float4*>(static_cast<const float*>(s.base) + off);
   }
-  // LayerNorm of the sample: (x - mean) * rstd  [* gamma + beta]
-  v.x = fmaf(v.x, ri.rs, ri.mr); v.y = fmaf(v.y, ri.rs, ri.mr);
-  v.z = fmaf(v.z, ri.rs, ri.mr); v.w = fmaf(v.w, ri.rs, ri.mr);
-  if (s.affine) {
-    const int p = ri.pos + ci.off;
-    const float4 g = *reinterpret_cast<const float4*>(s.gamma + p);
-    const float4 b = *reinterpret_cast<const float4*>(s.beta + p);
-    v.x = fmaf(v.x, g.x, b.x); v.y = fmaf(v.y, g.y, b.y);
-    v.z = fmaf(v.z, g.z, b.z); v.w = fmaf(v.w, g.w, b.w);
+  return v;
+}
+
+// LayerNorm of the sample applied to one gathered quad: (x - mean) * rstd [* gamma + beta]
+__device__ __forceinline__ float4 obs_finish(const SrcDesc& s, float4 raw, float rs, float mean, const float4& g,
+                                             const float4& b, bool affine) {
+  float4 v = raw;
+  if (s.is_u8) {
+    const uint32_t w = __float_as_uint(raw.x);
+    v = make_float4((float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24));
+  }
+  const float mr = -mean * rs;
+  v.x = fmaf(v.x, rs, mr); v.y = fmaf(v.y, rs, mr); v.z = fmaf(v.z, rs, mr); v.w = fmaf(v.w, rs, mr);
+  if (affine) {
+    v.x = fmaf(v.x, g.x, b.x); v.y = fmaf(v.y, g.y, b.y); v.z = fmaf(v.z, g.z, b.z); v.w = fmaf(v.w, g.w, b.w);
   }
   return v;
 }
@@ -184,6 +190,10 @@ struct Stage {
   // cached, k-loop invariant part of the gather: rows when k-contiguous, columns when k-major
   RowInfo frow[(MODE != SRC_PLAIN && !KMAJOR) ? NV : 1];
   ColInfo fcol[(MODE != SRC_PLAIN && KMAJOR) ? NV : 1];
+  // SRC_OBS: the LayerNorm is applied when the tile is written to LDS (after the MFMAs of the previous tile), so
+  // that nothing between the global loads and the MFMA loop depends on loaded data
+  float d_rs[MODE == SRC_OBS ? NV : 1], d_mean[MODE == SRC_OBS ? NV : 1];
+  int d_gp[MODE == SRC_OBS ? NV : 1];  // gamma/beta offset of the quad, or -1 (out of bounds: the quad is zero)
 
   // x0: first output index of the tile; xn: extent of that dimension
   __device__ __forceinline__ void prepare(const SrcDesc& s, long x0, long xn) {
@@ -216,7 +226,12 @@ struct Stage {
         for (int q = 0; q < NV; ++q) {
           const int u = tid + q * 256;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (kok && x0 + u / 8 < xn) v = gather4<MODE>(s, frow[q], ci);
+          const bool ok = kok && x0 + u / 8 < xn;
+          if (ok) v = gather4<MODE>(s, frow[q], ci);
+          if (MODE == SRC_OBS) {
+            d_rs[q] = frow[q].rs; d_mean[q] = frow[q].mr;
+            d_gp[q] = ok ? frow[q].pos + ci.off : -1;
+          }
           r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
         }
       } else {
@@ -225,9 +240,11 @@ struct Stage {
           const int u = tid + q * 256;
           const long k = k0 + u / (BX / 4), x = x0 + (u % (BX / 4)) * 4;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (MODE == SRC_OBS) d_gp[q] = -1;
           if (x < xn && k < kend) {
             const RowInfo ri = row_info<MODE>(s, (uint32_t)k);
             v = gather4<MODE>(s, ri, fcol[q]);
+            if (MODE == SRC_OBS) { d_rs[q] = ri.rs; d_mean[q] = ri.mr; d_gp[q] = ri.pos + fcol[q].off; }
           }
           r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
         }
@@ -267,8 +284,28 @@ struct Stage {
     }
   }
 
-  __device__ __forceinline__ void store(float* __restrict__ lds, bool vec) const {
+  __device__ __forceinline__ void store(float* __restrict__ lds, bool vec, const SrcDesc& s) {
     const int tid = threadIdx.x;
+    if (MODE == SRC_OBS) {
+      float4 g[NV], b[NV];
+      const bool aff = s.affine != 0;
+      if (aff) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {  // all table loads first (L2-resident), then the arithmetic
+          const int gp = d_gp[q] < 0 ? 0 : d_gp[q];
+          g[q] = *reinterpret_cast<const float4*>(s.gamma + gp);
+          b[q] = *reinterpret_cast<const float4*>(s.beta + gp);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d_gp[q] >= 0)
+          v = obs_finish(s, make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]), d_rs[q], d_mean[q], g[q], b[q],
+                         aff);
+        r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+      }
+    }
     if (vec || MODE != SRC_PLAIN) {
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
@@ -342,8 +379,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   for (long k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();  // previous tile's LDS reads are done
-    sa.store(As, va);
-    sb.store(Bs, vb);
+    sa.store(As, va, g.a);
+    sb.store(Bs, vb, g.b);
     __syncthreads();
     if (k0 + BK < kend) {  // prefetch the next tile; latency hides under the MFMAs below
       sa.load(g.a, m0, g.M, k0 + BK, kend, va);
@@ -366,37 +403,68 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   }
 
-  // ---- epilogue -----------------------------------------------------------------------------------------------------
+  // ---- epilogue: per 32x32 accumulator block, all loads batched ahead of the arithmetic and the stores ----------------
   float* out = g.o.out + (long)blockIdx.z * g.slab + (long)by * g.o.batch_stride;
+  const float* bias = g.bias ? g.bias + (long)by * g.bias_batch : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    long rbase[16], dbase[16];
+    bool rok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const long row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row >= g.M) continue;
-      long rbase, dbase;
+      rok[r] = row < g.M;
+      const long rr = rok[r] ? row : 0;
       if (g.o.rowmap) {
-        const uint32_t n = fdiv((uint32_t)row, g.o.f_img);
-        const uint32_t rem = (uint32_t)row - n * g.o.f_img.d;
+        const uint32_t n = fdiv((uint32_t)rr, g.o.f_img);
+        const uint32_t rem = (uint32_t)rr - n * g.o.f_img.d;
         const uint32_t y = fdiv(rem, g.o.f_line);
         const uint32_t x = rem - y * g.o.f_line.d;
-        rbase = (long)n * g.o.img_stride + (long)y * g.o.y_stride + (long)x * g.o.x_stride;
-        dbase = rbase;
+        rbase[r] = (long)n * g.o.img_stride + (long)y * g.o.y_stride + (long)x * g.o.x_stride;
+        dbase[r] = rbase[r];
       } else {
-        rbase = row * g.o.ldo;
-        dbase = row * g.ld_dact;
+        rbase[r] = rr * g.o.ldo;
+        dbase[r] = rr * g.ld_dact;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const long col = n0 + wn * (TN * 32) + j * 32 + l31;
+      const bool cok = col < g.N;
+      const long cc = cok ? col : 0;
+      float v[16];
+      const float bv = bias ? bias[cc] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+      if (g.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (g.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
+      }
+      if (g.dact_src) {
+        float yv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yv[r] = (rok[r] && cok) ? g.dact_src[dbase[r] + cc] : 1.f;
+        if (g.dact == 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = yv[r] > 0.f ? v[r] : 0.f;
+        } else if (g.dact == 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] *= 1.f - yv[r] * yv[r];
+        }
+      }
+      if (g.accumulate) {
+        float ov[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ov[r] = (rok[r] && cok) ? out[rbase[r] + cc] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += ov[r];
       }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const long col = n0 + wn * (TN * 32) + j * 32 + l31;
-        if (col >= g.N) continue;
-        float v = acc[i][j][r] + (g.bias ? g.bias[col] : 0.f);
-        v = act_apply(v, g.act);
-        if (g.dact_src) v *= act_grad_from_output(g.dact_src[dbase + col], g.dact);
-        float* dst = out + rbase + col;
-        if (g.accumulate) v += *dst;
-        *dst = v;
-      }
+      for (int r = 0; r < 16; ++r)
+        if (rok[r] && cok) out[rbase[r] + cc] = v[r];
     }
   }
 }
