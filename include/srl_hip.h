@@ -221,7 +221,8 @@ typedef struct srl_conv_desc {
   int32_t act;               /* forward activation fused after the bias: 0 none, 1 relu, 2 tanh */
 } srl_conv_desc;
 
-/* 1 if the implicit path handles this geometry (first_layer: NCHW observation + LayerNorm gather). */
+/* 1 if the implicit path handles this geometry.  first_layer: 0 = NHWC activation layer, 1 = observation layer
+ * with a planar (NCHW) observation, 2 = observation layer with a channels-last (NHWC) observation. */
 int srl_conv2d_supported(const srl_conv_desc* d, int first_layer);
 /* y[n,OH,OW,Cout] = act(conv(x[n,H,W,Cin], w) + bias) */
 int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -239,19 +240,28 @@ int64_t srl_conv2d_dgrad_weight_elems(const srl_conv_desc* d);
 int srl_conv2d_dgrad_repack(void* stream, const srl_conv_desc* d, const float* w, float* wt);
 int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* wt, const float* x_act,
                           int dact, float* dx);
-/* First layer: y = act(conv(LayerNorm_{C,H,W}(obs), w) + bias); obs [n,Cin,H,W] uint8 or float32, mean/rstd [n]
- * from srl_obs_ln_stats, gamma/beta [Cin,H,W], w [Cout,Cin,KH,KW]. */
-int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, const float* mean,
-                       const float* rstd, const float* gamma, const float* beta, const float* w, const float* bias,
-                       float* y);
+/* First layer: y = act(conv(LayerNorm(obs), w) + bias) with the LayerNorm over the whole observation; obs uint8 or
+ * float32, mean/rstd [n] from srl_obs_ln_stats / srl_obs_space_to_depth.  channels_last = 0: obs [n,Cin,H,W],
+ * gamma/beta [Cin,H,W], w [Cout,Cin,KH,KW] (the reference's layouts); channels_last = 1: obs [n,H,W,Cin],
+ * gamma/beta [H,W,Cin], w [Cout,KH,KW,Cin] (what srl_obs_space_to_depth produces). */
+int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
+                       const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
+                       const float* bias, float* y);
+/* Space-to-depth of a planar observation for a strided first convolution (stride s | KH, KW, H, W):
+ * out[n, H/s, W/s, (c, ph, pw)] = obs[n, c, a*s + ph, b*s + pw], same element type, plus the whole-observation
+ * LayerNorm statistics in the same pass.  A KxK stride-s convolution on obs becomes a (K/s)x(K/s) stride-1
+ * convolution on the channels-last result with Cin' = C*s*s, whose patch rows are contiguous 128-byte runs instead
+ * of 8-byte ones (Atari: 8x8 stride 4 on 4x84x84 -> 2x2 stride 1 on 21x21x64). */
+int srl_obs_space_to_depth(void* stream, const void* obs, int is_u8, int64_t n, int C, int H, int W, int s, void* out,
+                           float* mean, float* rstd);
 /* First layer backward without a data gradient: one batched GEMM over the OH*OW output positions forms
  * Q[pos] = dz[:,pos,:]^T xhat_patches[:,pos,:] (xhat = normalised, pre-affine observation); then
  * dw += sum_pos gamma*Q + beta*R, db += sum_pos R, dgamma += fold_o(w*Q), dbeta += fold_o(w*R), R = per-position
  * column sums of dz.  workspace: srl_conv2d_obs_bwd_workspace floats. */
 int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d);
-int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, const float* mean,
-                       const float* rstd, const float* gamma, const float* beta, const float* w, const float* dz,
-                       float* dw, float* db, float* dgamma, float* dbeta, float* workspace);
+int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
+                       const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
+                       const float* dz, float* dw, float* db, float* dgamma, float* dbeta, float* workspace);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser on one flat parameter buffer.

@@ -193,6 +193,13 @@ class HipNet:
                 desc = hip.conv_desc(n, h, w, L.cin, L.k, L.k, L.stride, L.cout, L.act)
                 # implicit GEMM (no patch matrix) whenever the geometry allows; explicit im2col otherwise
                 implicit = not self.force_explicit_conv and hip.conv2d_supported(desc, L.first)
+                if L.first and L.s2d:  # strided first layer on the space-to-depth'd observation (channels-last)
+                    b = L.s2d
+                    desc = hip.conv_desc(n, h // b, w // b, L.cin * b * b, L.k // b, L.k // b, 1, L.cout, L.act)
+                    implicit = True
+                    if self.force_explicit_conv or not hip.conv2d_supported(desc, 2):
+                        raise hip.HipError("space-to-depth parameter layout needs the implicit convolution path "
+                                           "(build the policy with SRL_EXPLICIT_CONV=1 to use the fallback)")
                 y = self._buf(f"{tag}{L.prefix}.y", m, L.cout)
                 P = None if implicit else self._buf(f"{tag}{L.prefix}.P", m, kdim)
                 saved = None
@@ -203,15 +210,22 @@ class HipNet:
                         raise hip.HipError(f"image observation `{enc.key}` must be uint8 or float32, got {obs.dtype}")
                     mean = self.ws.get(f"{tag}{pending_obs_ln.prefix}.mean", n)
                     rstd = self.ws.get(f"{tag}{pending_obs_ln.prefix}.rstd", n)
-                    hip.obs_ln_stats(obs.data_ptr(), is_u8, n, c * h * w, mean.data_ptr(), rstd.data_ptr())
                     gam, bet = self._p(f"{pending_obs_ln.prefix}.weight"), self._p(f"{pending_obs_ln.prefix}.bias")
+                    src = obs
+                    if L.s2d:
+                        src = self.ws.get(f"{tag}{L.prefix}.s2d", n * c * h * w, dtype=obs.dtype)
+                        hip.obs_space_to_depth(obs.data_ptr(), is_u8, n, c, h, w, L.s2d, src.data_ptr(), mean.data_ptr(),
+                                               rstd.data_ptr())
+                    else:
+                        hip.obs_ln_stats(obs.data_ptr(), is_u8, n, c * h * w, mean.data_ptr(), rstd.data_ptr())
                     if implicit:
-                        hip.conv2d_obs_fwd(desc, obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet,
-                                           self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"), y.ptr)
+                        hip.conv2d_obs_fwd(desc, src.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet,
+                                           self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"), y.ptr,
+                                           channels_last=bool(L.s2d))
                     else:
                         hip.im2col_obs_ln(obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet, n, c, h, w,
                                           L.k, L.k, L.stride, P.ptr)
-                    saved = (obs, is_u8, mean, rstd, pending_obs_ln)
+                    saved = (src, is_u8, mean, rstd, pending_obs_ln, bool(L.s2d))
                 else:
                     assert cur.ld == L.cin and cur.rows == n * h * w
                     if implicit:
@@ -246,12 +260,12 @@ class HipNet:
                     assert g.ld == L.cout
                     gw, gb, wp = self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"), self._p(f"{L.prefix}.weight")
                     if L.first:
-                        obs, is_u8, mean, rstd, lnspec = first_saved
+                        obs, is_u8, mean, rstd, lnspec, chlast = first_saved
                         wsz = hip.conv2d_obs_bwd_workspace(desc)
                         hip.conv2d_obs_bwd(desc, obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(),
                                            self._p(f"{lnspec.prefix}.weight"), self._p(f"{lnspec.prefix}.bias"), wp, g.ptr,
                                            gw, gb, self._g(f"{lnspec.prefix}.weight"), self._g(f"{lnspec.prefix}.bias"),
-                                           self.ws.get("conv_obs_bwd", wsz).data_ptr())
+                                           self.ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=chlast)
                         g = None
                     else:
                         wsz = hip.conv2d_wgrad_workspace(desc)
@@ -273,7 +287,7 @@ class HipNet:
                 # dP = dZ W, written over the patch matrix (its last reader was the weight gradient above)
                 hip.gemm(m, kdim, L.cout, g.ptr, g.ld, 0, self._p(f"{L.prefix}.weight"), kdim, 1, P.ptr, kdim)
                 if L.first:
-                    obs, is_u8, mean, rstd, lnspec = first_saved
+                    obs, is_u8, mean, rstd, lnspec, _ = first_saved
                     c, h, w = lnspec.shape
                     hip.obs_ln_affine_bwd(P.ptr, obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), n, c, h, w, L.k,
                                           L.k, L.stride, self._g(f"{lnspec.prefix}.weight"),

@@ -31,8 +31,9 @@ class ParamInfo:
     name: str
     ref_shape: Tuple[int, ...]
     offset: int = 0  # in floats, into the flat buffer
-    layout: str = "plain"  # plain | conv_nhwc | fc_from_chw
+    layout: str = "plain"  # plain | conv_nhwc | fc_from_chw | conv_s2d | ln_s2d
     chw: Optional[Tuple[int, int, int]] = None  # for fc_from_chw
+    s2d: int = 0  # block size of the space-to-depth layouts
 
     @property
     def numel(self):
@@ -45,6 +46,14 @@ class ParamInfo:
         elif self.layout == "fc_from_chw":
             c, h, w = self.chw
             t = t.reshape(self.ref_shape[0], c, h, w).permute(0, 2, 3, 1)
+        elif self.layout == "conv_s2d":  # [Cout, Cin, KH, KW] -> [Cout, jh, jw, (ci, ph, pw)], kh = jh*s + ph
+            co, ci, kh, kw = self.ref_shape
+            b = self.s2d
+            t = t.reshape(co, ci, kh // b, b, kw // b, b).permute(0, 2, 4, 1, 3, 5)
+        elif self.layout == "ln_s2d":  # [C, H, W] -> [H/s, W/s, (c, ph, pw)]
+            c, h, w = self.ref_shape
+            b = self.s2d
+            t = t.reshape(c, h // b, b, w // b, b).permute(1, 3, 0, 2, 4)
         return t.contiguous().reshape(-1)
 
     def to_reference(self, flat: torch.Tensor) -> torch.Tensor:
@@ -54,6 +63,14 @@ class ParamInfo:
         if self.layout == "fc_from_chw":
             c, h, w = self.chw
             return flat.reshape(self.ref_shape[0], h, w, c).permute(0, 3, 1, 2).reshape(self.ref_shape).contiguous()
+        if self.layout == "conv_s2d":
+            co, ci, kh, kw = self.ref_shape
+            b = self.s2d
+            return flat.reshape(co, kh // b, kw // b, ci, b, b).permute(0, 3, 1, 4, 2, 5).reshape(self.ref_shape).contiguous()
+        if self.layout == "ln_s2d":
+            c, h, w = self.ref_shape
+            b = self.s2d
+            return flat.reshape(h // b, w // b, c, b, b).permute(2, 0, 3, 1, 4).reshape(self.ref_shape).contiguous()
         return flat.reshape(self.ref_shape).clone()
 
 
@@ -84,6 +101,7 @@ class ConvSpec:
     out_hw: Tuple[int, int]
     act: int
     first: bool  # reads the (layer-normed) NCHW observation directly
+    s2d: int = 0  # first layer only: the observation is space-to-depth'd by this factor (= stride) before the gather
 
 
 @dataclasses.dataclass
@@ -117,6 +135,11 @@ class NetSpec:
     total_params: int
 
 
+def _allow_s2d():
+    import os
+    return os.environ.get("SRL_EXPLICIT_CONV", "0") != "1"  # the im2col fallback works on the planar layouts
+
+
 def _conv_out(size, k, s, p=0):
     return (size + 2 * p - (k - 1) - 1) // s + 1
 
@@ -131,8 +154,8 @@ class _Builder:
         if self.init:
             torch.manual_seed(seed)
 
-    def _add(self, name, shape, value=None, layout="plain", chw=None):
-        self.params[name] = ParamInfo(name, tuple(shape), layout=layout, chw=chw)
+    def _add(self, name, shape, value=None, layout="plain", chw=None, s2d=0):
+        self.params[name] = ParamInfo(name, tuple(shape), layout=layout, chw=chw, s2d=s2d)
         if self.init:
             self.values[name] = value
 
@@ -148,19 +171,20 @@ class _Builder:
         torch.nn.init.uniform_(b, -bound, bound)
         return w, b
 
-    def layernorm(self, prefix, shape):
+    def layernorm(self, prefix, shape, s2d=0):
         shape = (shape,) if isinstance(shape, int) else tuple(shape)
-        self._add(f"{prefix}.weight", shape, torch.ones(shape) if self.init else None)
-        self._add(f"{prefix}.bias", shape, torch.zeros(shape) if self.init else None)
+        lay = "ln_s2d" if s2d else "plain"
+        self._add(f"{prefix}.weight", shape, torch.ones(shape) if self.init else None, lay, s2d=s2d)
+        self._add(f"{prefix}.bias", shape, torch.zeros(shape) if self.init else None, lay, s2d=s2d)
 
     def linear(self, prefix, fin, fout, layout="plain", chw=None):
         w, b = self._default_wb((fout, fin))
         self._add(f"{prefix}.weight", (fout, fin), w, layout, chw)
         self._add(f"{prefix}.bias", (fout,), b)
 
-    def conv(self, prefix, cin, cout, k, layout):
+    def conv(self, prefix, cin, cout, k, layout, s2d=0):
         w, b = self._default_wb((cout, cin, k, k))
-        self._add(f"{prefix}.weight", (cout, cin, k, k), w, layout)
+        self._add(f"{prefix}.weight", (cout, cin, k, k), w, layout, s2d=s2d)
         self._add(f"{prefix}.bias", (cout,), b)
 
     def orthogonal(self, name, gain):
@@ -188,13 +212,18 @@ def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, a
         if len(shape) != 3:
             raise NotImplementedError(f"observation `{key}` of shape {shape}: only vectors and (C,H,W) images "
                                       "are implemented on the HIP path (Conv1d/Conv3d encoders are not)")
-        b.layernorm(f"{base}.0", shape)
-        layers = [ObsLayerNormSpec(f"{base}.0", shape)]
         cb = f"{base}.1._Convolution__model"
         c, h, w = shape
         cfg = cnn_layers.get(key)
         if cfg is None:  # modules/cnn.py:96-98 default stack
             cfg = [(c, 5, 1, 0, "zeros"), (c * 2, 3, 1, 0, "zeros"), (c, 3, 1, 0, "zeros")]
+        # a strided first convolution whose stride divides kernel and image is run on the space-to-depth'd
+        # observation (contiguous patch rows); its weight and the LayerNorm tables then live in that layout
+        k0, s0 = cfg[0][1], cfg[0][2]
+        s2d = s0 if (_allow_s2d() and s0 > 1 and k0 % s0 == 0 and h % s0 == 0 and w % s0 == 0 and
+                     (c * s0 * s0) % 4 == 0) else 0
+        b.layernorm(f"{base}.0", shape, s2d=s2d)
+        layers = [ObsLayerNormSpec(f"{base}.0", shape)]
         gain = torch.nn.init.calculate_gain(act_name)
         for i, (cout, k, stride, padding, padding_mode) in enumerate(cfg):
             if padding != 0:
@@ -203,10 +232,11 @@ def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, a
             if oh <= 0 or ow <= 0:
                 raise ValueError(f"CNN Dimension error, got {(oh, ow)} after convolution")
             name = f"{cb}.{2 * i}"
-            b.conv(name, c, cout, k, "plain" if i == 0 else "conv_nhwc")
+            b.conv(name, c, cout, k, ("conv_s2d" if s2d else "plain") if i == 0 else "conv_nhwc", s2d=s2d if i == 0 else 0)
             b.orthogonal(f"{name}.weight", gain)  # modules/cnn.py:73-84 (use_orthogonal=True)
             b.zero(f"{name}.bias")
-            layers.append(ConvSpec(name, c, cout, k, stride, (h, w), (oh, ow), act, first=(i == 0)))
+            layers.append(ConvSpec(name, c, cout, k, stride, (h, w), (oh, ow), act, first=(i == 0),
+                                   s2d=s2d if i == 0 else 0))
             c, h, w = cout, oh, ow
         sizes = [c * h * w]
         while sizes[-1] > hidden * 8:  # modules/cnn.py:86-91

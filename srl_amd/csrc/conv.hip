@@ -33,30 +33,59 @@ SrcDesc conv_patch_src(const float* x, const srl_conv_desc* d, int OH, int OW) {
   return s;
 }
 
-// NCHW observation patch rows with LayerNorm: r = (n, oh, ow);  c = (ci, kh, kw) -> ci*H*W + kh*W + kw
+// Observation patch rows with LayerNorm: r = (n, oh, ow).
+//   planar (NCHW):        c = (ci, kh, kw) -> ci*H*W + kh*W + kw
+//   channels-last (NHWC): c = (kh, kw, ci) -> kh*W*C + kw*C + ci   (e.g. a space-to-depth'd frame stack)
 SrcDesc obs_patch_src(const void* obs, int is_u8, const float* mean, const float* rstd, const float* gamma,
-                      const float* beta, const srl_conv_desc* d, int rows_per_img, int OW) {
+                      const float* beta, const srl_conv_desc* d, int rows_per_img, int OW, int channels_last) {
   SrcDesc s = plain_src(nullptr, 0);
   s.base = obs;
   s.f_img = make_fastdiv((uint32_t)rows_per_img);
   s.f_line = make_fastdiv((uint32_t)OW);
   s.img_stride = d->Cin * d->H * d->W;
-  s.y_stride = d->stride * d->W;
-  s.x_stride = d->stride;
-  s.f_inner = make_fastdiv((uint32_t)(d->KH * d->KW));
-  s.f_tap = make_fastdiv((uint32_t)d->KW);
-  s.k1_stride = d->H * d->W;
-  s.k2_stride = d->W;
+  if (channels_last) {
+    s.y_stride = d->stride * d->W * d->Cin;
+    s.x_stride = d->stride * d->Cin;
+    s.f_inner = make_fastdiv((uint32_t)(d->KW * d->Cin));
+    s.f_tap = make_fastdiv((uint32_t)(d->KW * d->Cin));  // kh' = 0, kw' = offset inside the (kw, ci) run
+    s.k1_stride = d->W * d->Cin;
+    s.k2_stride = 0;
+  } else {
+    s.y_stride = d->stride * d->W;
+    s.x_stride = d->stride;
+    s.f_inner = make_fastdiv((uint32_t)(d->KH * d->KW));
+    s.f_tap = make_fastdiv((uint32_t)d->KW);
+    s.k1_stride = d->H * d->W;
+    s.k2_stride = d->W;
+  }
   s.mean = mean; s.rstd = rstd; s.gamma = gamma; s.beta = beta;
   s.is_u8 = is_u8;
   s.affine = gamma != nullptr;
   return s;
 }
 
-bool obs_geometry_ok(const srl_conv_desc* d) {
-  // 4-wide gathers along kw must stay aligned: every stride that enters an address is a multiple of 4
+bool obs_geometry_ok(const srl_conv_desc* d, int channels_last) {
+  // 4-wide gathers must stay aligned: every stride that enters an address is a multiple of 4
+  if (channels_last) return d->Cin % 4 == 0;
   return d->KW % 4 == 0 && d->W % 4 == 0 && d->stride % 4 == 0 && (d->H * d->W) % 4 == 0;
 }
+
+// (k, pos) -> index into the observation-shaped tables, for both layouts
+struct ObsIndex {
+  int Cin, H, W, KH, KW, S, OW, cl;
+  __host__ __device__ void split_k(int k, int& ci, int& kh, int& kw) const {
+    if (cl) { ci = k % Cin; kw = (k / Cin) % KW; kh = k / (Cin * KW); }
+    else { kw = k % KW; kh = (k / KW) % KH; ci = k / (KW * KH); }
+  }
+  __host__ __device__ int k_of(int ci, int kh, int kw) const {
+    return cl ? (kh * KW + kw) * Cin + ci : (ci * KH + kh) * KW + kw;
+  }
+  __host__ __device__ int p_of(int ci, int y, int x) const { return cl ? (y * W + x) * Cin + ci : (ci * H + y) * W + x; }
+  __host__ __device__ void split_p(int p, int& ci, int& y, int& x) const {
+    if (cl) { ci = p % Cin; x = (p / Cin) % W; y = p / (Cin * W); }
+    else { x = p % W; y = (p / W) % H; ci = p / (W * H); }
+  }
+};
 
 int want_split(long rows, long tiles, long batch) {
   long want = 1024 / (tiles * batch > 0 ? tiles * batch : 1);
@@ -105,17 +134,18 @@ __global__ __launch_bounds__(256) void dgrad_repack_kernel(const float* w, float
 // ---- finalisation of the first-layer backward from the per-position products Q and column sums R --------------------
 // dw[o,k] += sum_pos gamma[p(pos,k)] * Q[pos,o,k] + beta[p(pos,k)] * R[pos,o];   db[o] += sum_pos R[pos,o]
 __global__ __launch_bounds__(256) void obs_dw_kernel(const float* Q, const float* R, const float* gamma,
-                                                     const float* beta, int P, int OW, int Cout, int Cin, int H, int W,
-                                                     int KH, int KW, int S, float* dw, float* db) {
-  const int Kp = Cin * KH * KW;
+                                                     const float* beta, int P, int Cout, ObsIndex ix, float* dw,
+                                                     float* db) {
+  const int Kp = ix.Cin * ix.KH * ix.KW;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= Cout * Kp) return;
   const int k = e % Kp, o = e / Kp;
-  const int kw = k % KW, kh = (k / KW) % KH, ci = k / (KW * KH);
+  int ci, kh, kw;
+  ix.split_k(k, ci, kh, kw);
   float acc = 0.f, rsum = 0.f;
   for (int pos = 0; pos < P; ++pos) {
-    const int oh = pos / OW, ow = pos % OW;
-    const int p = (ci * H + oh * S + kh) * W + ow * S + kw;
+    const int oh = pos / ix.OW, ow = pos % ix.OW;
+    const int p = ix.p_of(ci, oh * ix.S + kh, ow * ix.S + kw);
     const float r = R[pos * Cout + o];
     acc += gamma[p] * Q[((long)pos * Cout + o) * Kp + k] + beta[p] * r;
     rsum += r;
@@ -125,22 +155,23 @@ __global__ __launch_bounds__(256) void obs_dw_kernel(const float* Q, const float
 }
 
 // dgamma[p] += sum_{(pos,k) -> p} sum_o w[o,k] Q[pos,o,k];   dbeta[p] += sum_{(pos,k) -> p} sum_o w[o,k] R[pos,o]
-__global__ __launch_bounds__(256) void obs_affine_kernel(const float* Q, const float* R, const float* w, int OH, int OW,
-                                                         int Cout, int Cin, int H, int W, int KH, int KW, int S,
-                                                         float* dgamma, float* dbeta) {
-  const int Kp = Cin * KH * KW;
+__global__ __launch_bounds__(256) void obs_affine_kernel(const float* Q, const float* R, const float* w, int OH, int Cout,
+                                                         ObsIndex ix, float* dgamma, float* dbeta) {
+  const int Kp = ix.Cin * ix.KH * ix.KW;
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= Cin * H * W) return;
-  const int x = p % W, y = (p / W) % H, ci = p / (W * H);
+  if (p >= ix.Cin * ix.H * ix.W) return;
+  int ci, y, x;
+  ix.split_p(p, ci, y, x);
+  const int S = ix.S;
   float ag = 0.f, ab = 0.f;
-  for (int kh = y % S; kh < KH && kh <= y; kh += S) {
+  for (int kh = y % S; kh < ix.KH && kh <= y; kh += S) {
     const int oh = (y - kh) / S;
     if (oh >= OH) continue;
-    for (int kw = x % S; kw < KW && kw <= x; kw += S) {
+    for (int kw = x % S; kw < ix.KW && kw <= x; kw += S) {
       const int ow = (x - kw) / S;
-      if (ow >= OW) continue;
-      const int pos = oh * OW + ow;
-      const int k = (ci * KH + kh) * KW + kw;
+      if (ow >= ix.OW) continue;
+      const int pos = oh * ix.OW + ow;
+      const int k = ix.k_of(ci, kh, kw);
       for (int o = 0; o < Cout; ++o) {
         const float wv = w[o * Kp + k];
         ag += wv * Q[((long)pos * Cout + o) * Kp + k];
@@ -166,7 +197,7 @@ extern "C" int srl_conv2d_supported(const srl_conv_desc* d, int first_layer) {
   const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
   const long in_elems = d->n * d->H * d->W * d->Cin, out_elems = d->n * OH * OW * d->Cout;
   if (!fits31(in_elems) || !fits31(out_elems) || !fits31(d->n * OH * OW)) return 0;
-  if (first_layer) return obs_geometry_ok(d) ? 1 : 0;
+  if (first_layer) return obs_geometry_ok(d, first_layer == 2) ? 1 : 0;
   return (d->Cin % 4 == 0 && d->Cout % 4 == 0) ? 1 : 0;
 }
 
@@ -304,10 +335,11 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
   return 0;
 }
 
-extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, const float* mean,
-                                  const float* rstd, const float* gamma, const float* beta, const float* w,
-                                  const float* bias, float* y) {
-  SRL_CHECK_ARG(srl_conv2d_supported(d, 1), "unsupported geometry (needs KW, W, stride, H*W multiples of 4)");
+extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
+                                  const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  const float* w, const float* bias, float* y) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1),
+                "unsupported geometry (planar: KW, W, stride, H*W multiples of 4; channels-last: Cin multiple of 4)");
   SRL_CHECK_ARG(obs && mean && rstd && gamma && beta && w && y && aligned16(obs) && aligned16(gamma) && aligned16(beta),
                 "null / unaligned tensor");
   if (d->n == 0) return 0;
@@ -315,7 +347,7 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
   const long Kp = (long)d->Cin * d->KH * d->KW;
   GemmArgs g{};
   g.M = d->n * OH * OW; g.N = d->Cout; g.K = Kp;
-  g.a = obs_patch_src(obs, is_u8, mean, rstd, gamma, beta, d, OH * OW, OW);
+  g.a = obs_patch_src(obs, is_u8, mean, rstd, gamma, beta, d, OH * OW, OW, channels_last);
   g.b = plain_src(w, Kp);
   g.o = plain_out(y, d->Cout);
   g.bias = bias; g.act = d->act;
@@ -341,10 +373,11 @@ extern "C" int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d) {
   return (int64_t)((split + 1) * P * d->Cout * Kp + P * d->Cout + 64);
 }
 
-extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, const float* mean,
-                                  const float* rstd, const float* gamma, const float* beta, const float* w,
-                                  const float* dz, float* dw, float* db, float* dgamma, float* dbeta, float* workspace) {
-  SRL_CHECK_ARG(srl_conv2d_supported(d, 1), "unsupported geometry");
+extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
+                                  const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  const float* w, const float* dz, float* dw, float* db, float* dgamma, float* dbeta,
+                                  float* workspace) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1), "unsupported geometry");
   SRL_CHECK_ARG(obs && mean && rstd && gamma && beta && w && dz && dw && db && dgamma && dbeta && workspace,
                 "null tensor");
   SRL_CHECK_ARG(aligned16(obs) && aligned16(dz) && aligned16(workspace) && d->Cout % 4 == 0, "unaligned tensor / Cout % 4");
@@ -365,8 +398,10 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
   g.M = d->Cout; g.N = Kp; g.K = d->n;
   g.a = plain_src(dz, (long)P * d->Cout);  // A(i = o, k = n) = dz[n*P*Cout + pos*Cout + o]
   g.a.brw = OW; g.a.by_stride = OW * d->Cout; g.a.bx_stride = d->Cout;
-  g.b = obs_patch_src(obs, is_u8, mean, rstd, nullptr, nullptr, d, 1, 1);  // rows = samples; no affine: xhat
-  g.b.brw = OW; g.b.by_stride = d->stride * d->W; g.b.bx_stride = d->stride;
+  g.b = obs_patch_src(obs, is_u8, mean, rstd, nullptr, nullptr, d, 1, 1, channels_last);  // rows = samples; xhat
+  g.b.brw = OW;
+  g.b.by_stride = channels_last ? d->stride * d->W * d->Cin : d->stride * d->W;
+  g.b.bx_stride = channels_last ? d->stride * d->Cin : d->stride;
   const long tiles = srl_ceil_div(d->Cout, 32) * srl_ceil_div(Kp, 256);
   const int nsplit = plan_split(d->n, want_split(d->n, tiles, P), &g.k_per_split);
   g.o = plain_out(nsplit > 1 ? slabs : Q, Kp);
@@ -383,10 +418,11 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
                        (long)d->Cout, Kp, Q, Kp, (long)d->Cout * Kp, 0);
     SRL_LAUNCH_CHECK();
   }
+  const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, channels_last ? 1 : 0};
   hipLaunchKernelGGL(obs_dw_kernel, dim3((unsigned)srl_ceil_div(d->Cout * Kp, 256)), dim3(256), 0, st, Q, R, gamma, beta, P,
-                     OW, d->Cout, d->Cin, d->H, d->W, d->KH, d->KW, d->stride, dw, db);
+                     d->Cout, ix, dw, db);
   hipLaunchKernelGGL(obs_affine_kernel, dim3((unsigned)srl_ceil_div(d->Cin * d->H * d->W, 256)), dim3(256), 0, st, Q, R, w,
-                     OH, OW, d->Cout, d->Cin, d->H, d->W, d->KH, d->KW, d->stride, dgamma, dbeta);
+                     OH, d->Cout, ix, dgamma, dbeta);
   SRL_LAUNCH_CHECK();
   return 0;
 }

@@ -180,107 +180,156 @@ __device__ __forceinline__ float4 obs_finish(const SrcDesc& s, float4 raw, float
   return v;
 }
 
+// ---- buffer loads: 32-bit per-lane byte offsets against a wave-uniform descriptor; an offset >= num_records makes
+// the hardware return zeros, which is how every out-of-bounds / padding element is produced (no branches)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kNumRecords = 0xFFFFFF00u;
+constexpr uint32_t kInvalidOff = 0xFFFFFF00u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)kNumRecords, 0x00020000);
+}
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, uint32_t voff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, uint32_t voff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
+}
+
 // ---- staging of one operand tile: BX output indices x BK reduction indices ------------------------------------------
+// Everything that does not change along k is computed once in prepare(): per-lane byte offsets (rows of the tile for a
+// k-contiguous operand, columns for a k-major one), validity, LayerNorm statistics.  Per k-tile a dense operand costs
+// no vector ALU work at all (the descriptor base advances on the scalar unit); a gathered one costs one column (or
+// row) decomposition per lane plus an add per quad.
 template <int BX, bool KMAJOR, int MODE>
 struct Stage {
   static constexpr int LD = KMAJOR ? BX + 4 : BX + 1;  // LDS row pitch (floats)
   static constexpr int NF = BX * BK / 256;             // floats per thread
   static constexpr int NV = NF / 4;                    // float4 per thread
+  static constexpr int KQ = BK / 4;                    // quads per k-contiguous row
+  static constexpr bool GATHER = MODE != SRC_PLAIN;
   float r[NF];
-  // cached, k-loop invariant part of the gather: rows when k-contiguous, columns when k-major
-  RowInfo frow[(MODE != SRC_PLAIN && !KMAJOR) ? NV : 1];
-  ColInfo fcol[(MODE != SRC_PLAIN && KMAJOR) ? NV : 1];
+  uint32_t voff[NV];                                 // k-invariant byte offset of quad q (kInvalidOff: always zero)
+  int yx[(MODE == SRC_DGRAD) ? NV : 1];              // DGRAD: (y << 16) | x of the row
+  int pos[(MODE == SRC_OBS && !KMAJOR) ? NV : 1];    // OBS: offset of the row inside its image
   // SRC_OBS: the LayerNorm is applied when the tile is written to LDS (after the MFMAs of the previous tile), so
   // that nothing between the global loads and the MFMA loop depends on loaded data
   float d_rs[MODE == SRC_OBS ? NV : 1], d_mean[MODE == SRC_OBS ? NV : 1];
   int d_gp[MODE == SRC_OBS ? NV : 1];  // gamma/beta offset of the quad, or -1 (out of bounds: the quad is zero)
+  const char* cur;                     // dense operands: base of the current k-tile (wave-uniform)
+  long step;                           // dense operands: bytes per k-tile
+  uint32_t esz;                        // element size of the source (1 for uint8 observations)
 
-  // x0: first output index of the tile; xn: extent of that dimension
-  __device__ __forceinline__ void prepare(const SrcDesc& s, long x0, long xn) {
-    if (MODE == SRC_PLAIN) return;
+  // x0: first output index of the tile; xn: extent of that dimension; kbeg: first k of this workgroup
+  __device__ __forceinline__ void prepare(const SrcDesc& s, long x0, long xn, long kbeg, bool vec) {
     const int tid = threadIdx.x;
+    esz = (MODE == SRC_OBS && s.is_u8) ? 1u : 4u;
+    if (!GATHER) {
+      if (!vec) return;  // scalar fallback addresses directly
+      const long ld = s.ld;
+      if (!KMAJOR) { cur = static_cast<const char*>(s.base) + (x0 * ld + kbeg) * 4; step = BK * 4; }
+      else { cur = static_cast<const char*>(s.base) + (kbeg * ld + x0) * 4; step = (long)BK * ld * 4; }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int u = tid + q * 256;
+        if (!KMAJOR) voff[q] = x0 + u / KQ < xn ? (uint32_t)(((u / KQ) * ld + (u % KQ) * 4) * 4) : kInvalidOff;
+        else voff[q] = x0 + (u % (BX / 4)) * 4 < xn ? (uint32_t)(((u / (BX / 4)) * ld + (u % (BX / 4)) * 4) * 4) : kInvalidOff;
+      }
+      return;
+    }
+    cur = static_cast<const char*>(s.base);
+    step = 0;
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const int u = tid + q * 256;
       if (!KMAJOR) {
-        long x = x0 + u / 8;
-        if (x >= xn) x = xn - 1;  // clamp: the value is discarded by the bounds check in load()
-        frow[q] = row_info<MODE>(s, (uint32_t)x);
+        const long x = x0 + u / KQ;
+        const RowInfo ri = row_info<MODE>(s, (uint32_t)(x < xn ? x : xn - 1));
+        voff[q] = x < xn ? (uint32_t)ri.off * esz : kInvalidOff;
+        if (MODE == SRC_DGRAD) yx[q] = (ri.y << 16) | ri.x;
+        if (MODE == SRC_OBS) { d_rs[q] = ri.rs; d_mean[q] = ri.mr; pos[q] = ri.pos; }
       } else {
-        long x = x0 + (u % (BX / 4)) * 4;
-        if (x >= xn) x = 0;
-        fcol[q] = col_info<MODE>(s, (uint32_t)x);
+        const long x = x0 + (u % (BX / 4)) * 4;
+        const ColInfo ci = col_info<MODE>(s, (uint32_t)(x < xn ? x : 0));
+        voff[q] = x < xn ? (uint32_t)ci.off * esz : kInvalidOff;
       }
     }
   }
 
+  // loads k-tile [k0, k0 + BK) clipped to kend; must be called for consecutive tiles (the dense base advances)
   __device__ __forceinline__ void load(const SrcDesc& s, long x0, long xn, long k0, long kend, bool vec) {
     const int tid = threadIdx.x;
-    if (MODE != SRC_PLAIN) {
+    if (GATHER) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(cur);
       if (!KMAJOR) {
-        const long k = k0 + (tid % 8) * 4;  // u % 8 == tid % 8 for every q
+        const long k = k0 + (tid % KQ) * 4;  // u % KQ == tid % KQ for every q
         const bool kok = k < kend;
-        ColInfo ci;
-        if (kok) ci = col_info<MODE>(s, (uint32_t)k);
+        const ColInfo ci = col_info<MODE>(s, (uint32_t)(kok ? k : 0));
+        const uint32_t cb = (uint32_t)ci.off * esz;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-          const int u = tid + q * 256;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          const bool ok = kok && x0 + u / 8 < xn;
-          if (ok) v = gather4<MODE>(s, frow[q], ci);
+          bool ok = kok && voff[q] != kInvalidOff;
+          if (MODE == SRC_DGRAD)
+            ok = ok && (unsigned)((yx[q] >> 16) - ci.jh) < (unsigned)s.OH && (unsigned)((yx[q] & 0xffff) - ci.jw) < (unsigned)s.OW;
+          const uint32_t o = ok ? voff[q] + cb : kInvalidOff;
           if (MODE == SRC_OBS) {
-            d_rs[q] = frow[q].rs; d_mean[q] = frow[q].mr;
-            d_gp[q] = ok ? frow[q].pos + ci.off : -1;
+            d_gp[q] = ok ? pos[q] + ci.off : -1;
+            if (s.is_u8) r[4 * q] = bload1(rs, o);
+            else { const float4 v = bload4(rs, o); r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w; }
+          } else {
+            const float4 v = bload4(rs, o);
+            r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
           }
-          r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
         }
       } else {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
           const int u = tid + q * 256;
-          const long k = k0 + u / (BX / 4), x = x0 + (u % (BX / 4)) * 4;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (MODE == SRC_OBS) d_gp[q] = -1;
-          if (x < xn && k < kend) {
-            const RowInfo ri = row_info<MODE>(s, (uint32_t)k);
-            v = gather4<MODE>(s, ri, fcol[q]);
-            if (MODE == SRC_OBS) { d_rs[q] = ri.rs; d_mean[q] = ri.mr; d_gp[q] = ri.pos + fcol[q].off; }
+          const long k = k0 + u / (BX / 4);
+          const bool ok = k < kend && voff[q] != kInvalidOff;
+          const RowInfo ri = row_info<MODE>(s, (uint32_t)(k < kend ? k : kend - 1));
+          const uint32_t o = ok ? voff[q] + (uint32_t)ri.off * esz : kInvalidOff;
+          if (MODE == SRC_OBS) {
+            d_rs[q] = ri.rs; d_mean[q] = ri.mr;
+            d_gp[q] = ok ? ri.pos + (int)(voff[q] / esz) : -1;
+            if (s.is_u8) r[4 * q] = bload1(rs, o);
+            else { const float4 v = bload4(rs, o); r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w; }
+          } else {
+            const float4 v = bload4(rs, o);
+            r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
           }
-          r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
         }
+      }
+      return;
+    }
+    if (vec) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(cur);
+      cur += step;
+      const long kleft = kend - k0;  // > 0
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int u = tid + q * 256;
+        const bool kok = !KMAJOR ? (tid % KQ) * 4 < kleft : u / (BX / 4) < kleft;
+        const float4 v = bload4(rs, kok ? voff[q] : kInvalidOff);
+        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
       }
       return;
     }
     const float* __restrict__ src = static_cast<const float*>(s.base);
     const long ld = s.ld;
-    if (vec) {
 #pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        const int u = tid + q * 256;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!KMAJOR) {
-          const long x = x0 + u / 8, k = k0 + (u % 8) * 4;
-          if (x < xn && k < kend) v = *reinterpret_cast<const float4*>(src + x * ld + k);
-        } else {
-          const long k = k0 + u / (BX / 4), x = x0 + (u % (BX / 4)) * 4;
-          if (x < xn && k < kend) v = *reinterpret_cast<const float4*>(src + k * ld + x);
-        }
-        r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    for (int q = 0; q < NF; ++q) {
+      const int e = tid + q * 256;
+      float v = 0.f;
+      if (!KMAJOR) {
+        const long x = x0 + e / BK, k = k0 + e % BK;
+        if (x < xn && k < kend) v = src[x * ld + k];
+      } else {
+        const long k = k0 + e / BX, x = x0 + e % BX;
+        if (x < xn && k < kend) v = src[k * ld + x];
       }
-    } else {
-#pragma unroll
-      for (int q = 0; q < NF; ++q) {
-        const int e = tid + q * 256;
-        float v = 0.f;
-        if (!KMAJOR) {
-          const long x = x0 + e / BK, k = k0 + e % BK;
-          if (x < xn && k < kend) v = src[x * ld + k];
-        } else {
-          const long k = k0 + e / BX, x = x0 + e % BX;
-          if (x < xn && k < kend) v = src[k * ld + x];
-        }
-        r[q] = v;
-      }
+      r[q] = v;
     }
   }
 
@@ -290,11 +339,12 @@ struct Stage {
       float4 g[NV], b[NV];
       const bool aff = s.affine != 0;
       if (aff) {
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(s.gamma), rb = make_rsrc(s.beta);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {  // all table loads first (L2-resident), then the arithmetic
-          const int gp = d_gp[q] < 0 ? 0 : d_gp[q];
-          g[q] = *reinterpret_cast<const float4*>(s.gamma + gp);
-          b[q] = *reinterpret_cast<const float4*>(s.beta + gp);
+          const uint32_t o = d_gp[q] < 0 ? kInvalidOff : (uint32_t)d_gp[q] * 4u;
+          g[q] = bload4(rg, o);
+          b[q] = bload4(rb, o);
         }
       }
 #pragma unroll
@@ -306,12 +356,12 @@ struct Stage {
         r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
       }
     }
-    if (vec || MODE != SRC_PLAIN) {
+    if (vec || GATHER) {
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int u = tid + q * 256;
         if (!KMAJOR) {
-          const int x = u / 8, k = (u % 8) * 4;
+          const int x = u / KQ, k = (u % KQ) * 4;
 #pragma unroll
           for (int j = 0; j < 4; ++j) lds[(k + j) * LD + x] = r[4 * q + j];
         } else {
@@ -372,8 +422,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   SA sa;
   SB sb;
   const bool va = g.vec_a != 0, vb = g.vec_b != 0;
-  sa.prepare(g.a, m0, g.M);
-  sb.prepare(g.b, n0, g.N);
+  sa.prepare(g.a, m0, g.M, kbeg, va);
+  sb.prepare(g.b, n0, g.N, kbeg, vb);
   sa.load(g.a, m0, g.M, kbeg, kend, va);
   sb.load(g.b, n0, g.N, kbeg, kend, vb);
 

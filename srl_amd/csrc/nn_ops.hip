@@ -398,3 +398,67 @@ extern "C" int srl_u8_to_f32(void* stream, const uint8_t* src, float* dst, int64
   SRL_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- space-to-depth of a planar observation + whole-observation LayerNorm statistics, one workgroup per sample -----
+namespace {
+template <bool U8>
+__global__ __launch_bounds__(256) void obs_s2d_kernel(const void* obs, long n, int C, int H, int W, int S, void* out,
+                                                      float* mean, float* rstd) {
+  __shared__ double red[8];
+  const long smp = blockIdx.x;
+  const int D = C * H * W, Wb = W / S, SS = S * S;
+  double acc[2] = {0.0, 0.0};
+  if (U8 && S == 4 && W % 4 == 0) {
+    // dword path: the 4 bytes (pw = 0..3) of one (c, h, b) stay together
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(obs) + smp * D);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(out) + smp * D);
+    unsigned long long a = 0, b = 0;
+    for (int e = threadIdx.x; e < D / 4; e += 256) {
+      const uint32_t w = src[e];
+      const int bq = e % Wb, h = (e / Wb) % H, c = e / (Wb * H);
+      dst[((h / 4 * Wb + bq) * C + c) * 4 + (h & 3)] = w;
+      const unsigned b0 = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u, b3 = w >> 24;
+      a += b0 + b1 + b2 + b3;
+      b += b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
+    }
+    acc[0] = (double)a;
+    acc[1] = (double)b;
+  } else {
+    for (int e = threadIdx.x; e < D; e += 256) {
+      const int x = e % W, y = (e / W) % H, c = e / (W * H);
+      const int o = (((y / S) * Wb + x / S) * C + c) * SS + (y % S) * S + x % S;
+      double v;
+      if (U8) {
+        const uint8_t t = static_cast<const uint8_t*>(obs)[smp * D + e];
+        static_cast<uint8_t*>(out)[smp * D + o] = t;
+        v = (double)t;
+      } else {
+        const float t = static_cast<const float*>(obs)[smp * D + e];
+        static_cast<float*>(out)[smp * D + o] = t;
+        v = (double)t;
+      }
+      acc[0] += v;
+      acc[1] += v * v;
+    }
+  }
+  block_sum<2, 256>(acc, red);
+  if (threadIdx.x == 0) {
+    const double mu = acc[0] / D;
+    double var = acc[1] / D - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    mean[smp] = (float)mu;
+    rstd[smp] = (float)(1.0 / sqrt(var + (double)kLnEps));
+  }
+}
+}  // namespace
+
+extern "C" int srl_obs_space_to_depth(void* stream, const void* obs, int is_u8, int64_t n, int C, int H, int W, int s,
+                                      void* out, float* mean, float* rstd) {
+  SRL_CHECK_ARG(obs && out && mean && rstd, "null tensor");
+  SRL_CHECK_ARG(s >= 1 && H % s == 0 && W % s == 0, "stride must divide H and W");
+  if (n == 0) return 0;
+  if (is_u8) hipLaunchKernelGGL(obs_s2d_kernel<true>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, obs, (long)n, C, H, W, s, out, mean, rstd);
+  else hipLaunchKernelGGL(obs_s2d_kernel<false>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, obs, (long)n, C, H, W, s, out, mean, rstd);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}

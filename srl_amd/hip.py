@@ -58,9 +58,11 @@ _SIGNATURES = {
     "srl_conv2d_dgrad_weight_elems": (c_int64, [_CD]),
     "srl_conv2d_dgrad_repack": (c_int, [c_void_p, _CD, c_void_p, c_void_p]),
     "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int] + [c_void_p] * 7),
+    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 7),
+    "srl_obs_space_to_depth": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                        c_void_p]),
     "srl_conv2d_obs_bwd_workspace": (c_int64, [_CD]),
-    "srl_conv2d_obs_bwd": (c_int, [c_void_p, _CD, c_void_p, c_int] + [c_void_p] * 11),
+    "srl_conv2d_obs_bwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 11),
     "srl_abi_version": (c_int, []),
     "srl_last_error": (c_char_p, []),
     "srl_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
@@ -359,7 +361,8 @@ def _conv_flops(d: ConvDesc):
     return 2.0 * d.n * oh * ow * d.Cout * d.KH * d.KW * d.Cin
 
 
-def conv2d_supported(d: ConvDesc, first_layer: bool) -> bool:
+def conv2d_supported(d: ConvDesc, first_layer) -> bool:
+    """first_layer: 0 / False = NHWC activation layer, 1 / True = planar observation, 2 = channels-last observation."""
     return bool(lib().srl_conv2d_supported(ctypes.byref(d), int(first_layer)))
 
 
@@ -392,11 +395,18 @@ def conv2d_nhwc_dgrad(d: ConvDesc, dz_ptr, wt_ptr, x_act_ptr, dact, dx_ptr):
                "srl_conv2d_nhwc_dgrad")
 
 
-def conv2d_obs_fwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr):
+def conv2d_obs_fwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr,
+                   channels_last=False):
     with _scope("conv_obs_fwd", _conv_flops(d)):
         _check(
-            lib().srl_conv2d_obs_fwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), mean_ptr, rstd_ptr, gamma_ptr,
-                                     beta_ptr, w_ptr, bias_ptr, y_ptr), "srl_conv2d_obs_fwd")
+            lib().srl_conv2d_obs_fwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), int(channels_last), mean_ptr,
+                                     rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr), "srl_conv2d_obs_fwd")
+
+
+def obs_space_to_depth(obs_ptr, is_u8, n, C, H, W, s, out_ptr, mean_ptr, rstd_ptr):
+    with _scope("obs_space_to_depth"):
+        _check(lib().srl_obs_space_to_depth(_stream(), obs_ptr, int(is_u8), n, C, H, W, s, out_ptr, mean_ptr, rstd_ptr),
+               "srl_obs_space_to_depth")
 
 
 def conv2d_obs_bwd_workspace(d: ConvDesc) -> int:
@@ -404,12 +414,12 @@ def conv2d_obs_bwd_workspace(d: ConvDesc) -> int:
 
 
 def conv2d_obs_bwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, dz_ptr, dw_ptr, db_ptr,
-                   dgamma_ptr, dbeta_ptr, ws_ptr):
+                   dgamma_ptr, dbeta_ptr, ws_ptr, channels_last=False):
     with _scope("conv_obs_bwd", _conv_flops(d)):
         _check(
-            lib().srl_conv2d_obs_bwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), mean_ptr, rstd_ptr, gamma_ptr,
-                                     beta_ptr, w_ptr, dz_ptr, dw_ptr, db_ptr, dgamma_ptr, dbeta_ptr, ws_ptr),
-            "srl_conv2d_obs_bwd")
+            lib().srl_conv2d_obs_bwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), int(channels_last), mean_ptr,
+                                     rstd_ptr, gamma_ptr, beta_ptr, w_ptr, dz_ptr, dw_ptr, db_ptr, dgamma_ptr, dbeta_ptr,
+                                     ws_ptr), "srl_conv2d_obs_bwd")
 
 
 def _wrap_for_profile(names):

@@ -545,3 +545,57 @@ def test_conv2d_obs_implicit(n, C, H, k, s, Cout, u8):
     for got, ref, name in zip(outs, (tw.grad, tbias.grad, tg.grad, tb.grad), ("dw", "db", "dgamma", "dbeta")):
         assert rel_close(got.cpu().numpy(), ref.numpy(), 2e-5, scale=sc if name in ("dw", "db") else float(np.sqrt(n))), name
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n,u8", [(5, True), (70, True), (3, False)])
+def test_conv2d_obs_space_to_depth_path(n, u8):
+    """Strided first layer on the space-to-depth'd observation == the planar convolution (Atari geometry)."""
+    from srl_amd.algorithm.netspec import ParamInfo
+    rng = np.random.default_rng(n)
+    C, H, k, s, Cout = 4, 84, 8, 4, 32
+    obs = rng.integers(0, 256, (n, C, H, H), dtype=np.uint8)
+    if not u8:
+        obs = obs.astype(np.float32) / 3
+    gamma = (1 + 0.1 * rng.standard_normal((C, H, H))).astype(np.float32)
+    beta = (0.1 * rng.standard_normal((C, H, H))).astype(np.float32)
+    w = (rng.standard_normal((Cout, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    pw = ParamInfo("w", w.shape, layout="conv_s2d", s2d=s)
+    pg = ParamInfo("g", gamma.shape, layout="ln_s2d", s2d=s)
+    t = torch.from_numpy
+    dobs = dev(obs)
+    dg, dbt = pg.to_internal(t(gamma)).to(DEV), pg.to_internal(t(beta)).to(DEV)
+    dw_, db_ = pw.to_internal(t(w)).to(DEV), dev(b)
+    s2d = torch.empty_like(dobs)
+    mean, rstd = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    hip.obs_space_to_depth(dobs.data_ptr(), u8, n, C, H, H, s, s2d.data_ptr(), mean.data_ptr(), rstd.data_ptr())
+    ref_s2d = obs.reshape(n, C, H // s, s, H // s, s).transpose(0, 2, 4, 1, 3, 5).reshape(n, -1)
+    assert np.array_equal(s2d.cpu().numpy().reshape(n, -1), ref_s2d)
+    x64 = obs.astype(np.float64).reshape(n, -1)
+    assert rel_close(mean.cpu().numpy(), x64.mean(1), 1e-6) and rel_close(rstd.cpu().numpy(), 1 / np.sqrt(x64.var(1) + 1e-5), 1e-6)
+    Hb, Cb, kb = H // s, C * s * s, k // s
+    d = hip.conv_desc(n, Hb, Hb, Cb, kb, kb, 1, Cout, act=1)
+    assert hip.conv2d_supported(d, 2)
+    OH = (H - k) // s + 1
+    y = torch.full((n, OH, OH, Cout), np.nan, device=DEV)
+    hip.conv2d_obs_fwd(d, s2d.data_ptr(), u8, mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), dbt.data_ptr(),
+                       dw_.data_ptr(), db_.data_ptr(), y.data_ptr(), channels_last=True)
+    tg, tb = t(gamma).double().requires_grad_(True), t(beta).double().requires_grad_(True)
+    tw, tbias = t(w).double().requires_grad_(True), t(b).double().requires_grad_(True)
+    xn = torch.nn.functional.layer_norm(t(obs.astype(np.float64)), (C, H, H), tg, tb, 1e-5)
+    z = torch.nn.functional.conv2d(xn, tw, tbias, stride=s)
+    yref = torch.relu(z)
+    assert rel_close(y.cpu().numpy(), yref.permute(0, 2, 3, 1).detach().numpy(), 1e-5, scale=1.0)
+    dz = (rng.standard_normal((n, OH, OH, Cout)) * (yref.permute(0, 2, 3, 1).detach().numpy() > 0)).astype(np.float32)
+    z.backward(t(dz).double().permute(0, 3, 1, 2))
+    ddz = dev(dz)
+    outs = [torch.zeros(w.size, device=DEV), torch.zeros(Cout, device=DEV), torch.zeros(gamma.size, device=DEV),
+            torch.zeros(beta.size, device=DEV)]
+    ws = torch.empty(hip.conv2d_obs_bwd_workspace(d), device=DEV)
+    hip.conv2d_obs_bwd(d, s2d.data_ptr(), u8, mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), dbt.data_ptr(),
+                       dw_.data_ptr(), ddz.data_ptr(), *[o.data_ptr() for o in outs], ws.data_ptr(), channels_last=True)
+    got = [pw.to_reference(outs[0].cpu()), outs[1].cpu(), pg.to_reference(outs[2].cpu()), pg.to_reference(outs[3].cpu())]
+    sc = float(np.sqrt(n * OH * OH))
+    for g_, ref, name in zip(got, (tw.grad, tbias.grad, tg.grad, tb.grad), ("dw", "db", "dgamma", "dbeta")):
+        assert rel_close(g_.numpy(), ref.numpy(), 2e-5, scale=sc if name in ("dw", "db") else float(np.sqrt(n))), name
+    torch.cuda.synchronize()

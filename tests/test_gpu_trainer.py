@@ -193,9 +193,14 @@ def test_implicit_and_explicit_conv_paths_agree():
     """The implicit-GEMM convolution path and the im2col fallback are two implementations of the same step."""
     arrays = synthetic.make_sample_arrays(seed=3, T=6, B=5, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.1)
     stats = []
+    import os
     for explicit in (False, True):
-        tr = make_trainer(CNN_POLICY, ATARI_TRAINER)
-        tr.policy.net.force_explicit_conv = explicit
+        os.environ["SRL_EXPLICIT_CONV"] = "1" if explicit else "0"
+        try:
+            tr = make_trainer(CNN_POLICY, ATARI_TRAINER)
+        finally:
+            os.environ.pop("SRL_EXPLICIT_CONV")
+        assert tr.policy.net.force_explicit_conv == explicit
         res = tr.step(synthetic.to_sample_batch(arrays))
         stats.append((res.stats, tr.policy.get_checkpoint()["state_dict"]))
     for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
