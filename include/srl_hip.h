@@ -244,9 +244,13 @@ int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz,
  * float32, mean/rstd [n] from srl_obs_ln_stats / srl_obs_space_to_depth.  channels_last = 0: obs [n,Cin,H,W],
  * gamma/beta [Cin,H,W], w [Cout,Cin,KH,KW] (the reference's layouts); channels_last = 1: obs [n,H,W,Cin],
  * gamma/beta [H,W,Cin], w [Cout,KH,KW,Cin] (what srl_obs_space_to_depth produces). */
+int64_t srl_conv2d_obs_fwd_workspace(const srl_conv_desc* d);
+/* workspace (srl_conv2d_obs_fwd_workspace floats, or NULL): with it the layer runs position-batched, one GEMM per
+ * output position over the samples with the LayerNorm affine folded into per-position weights (w*gamma) and biases
+ * (bias + w.beta), so that the operand gather needs no table lookups; without it the affine is applied in the gather. */
 int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
-                       const float* bias, float* y);
+                       const float* bias, float* y, float* workspace);
 /* Space-to-depth of a planar observation for a strided first convolution (stride s | KH, KW, H, W):
  * out[n, H/s, W/s, (c, ph, pw)] = obs[n, c, a*s + ph, b*s + pw], same element type, plus the whole-observation
  * LayerNorm statistics in the same pass.  A KxK stride-s convolution on obs becomes a (K/s)x(K/s) stride-1

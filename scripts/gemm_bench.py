@@ -72,7 +72,24 @@ def conv_cases(n=16384):
     fl = 2.0 * n * 400 * 32 * 256
     ms = timeit(lambda: hip.conv2d_obs_fwd(d, obs.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), g.data_ptr(),
                                            bt.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr()))
-    print(f"conv1 obs fwd: {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF", flush=True)
+    print(f"conv1 obs fwd (planar, direct): {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF", flush=True)
+    # space-to-depth'd, channels-last variants
+    d2 = hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, act=1)
+    s2d = torch.empty_like(obs)
+    ms = timeit(lambda: hip.obs_space_to_depth(obs.data_ptr(), True, n, 4, 84, 84, 4, s2d.data_ptr(), mean.data_ptr(),
+                                               rstd.data_ptr()))
+    print(f"obs space-to-depth + stats: {ms:8.3f} ms", flush=True)
+    fws = torch.empty(hip.conv2d_obs_fwd_workspace(d2), device=DEV)
+    for tag, wsp in (("direct", None), ("position-batched", fws.data_ptr())):
+        ms = timeit(lambda: hip.conv2d_obs_fwd(d2, s2d.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), g.data_ptr(),
+                                               bt.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), channels_last=True,
+                                               ws_ptr=wsp))
+        print(f"conv1 s2d fwd ({tag}): {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF", flush=True)
+    ws2 = torch.empty(hip.conv2d_obs_bwd_workspace(d2), device=DEV)
+    ms = timeit(lambda: hip.conv2d_obs_bwd(d2, s2d.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), g.data_ptr(),
+                                           bt.data_ptr(), w.data_ptr(), dz.data_ptr(), *[o.data_ptr() for o in outs],
+                                           ws2.data_ptr(), channels_last=True))
+    print(f"conv1 s2d bwd: {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF", flush=True)
     ms = timeit(lambda: hip.conv2d_obs_bwd(d, obs.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), g.data_ptr(),
                                            bt.data_ptr(), w.data_ptr(), dz.data_ptr(), *[o.data_ptr() for o in outs],
                                            ws.data_ptr()))

@@ -88,7 +88,8 @@ struct ObsIndex {
 };
 
 int want_split(long rows, long tiles, long batch) {
-  long want = 1024 / (tiles * batch > 0 ? tiles * batch : 1);
+  // a batched problem (one GEMM per output position) wants ~4096 workgroups, a single weight gradient ~1024
+  long want = (batch > 1 ? 4096 : 1024) / (tiles * batch > 0 ? tiles * batch : 1);
   if (want < 1) want = 1;
   const long cap = rows / 2048 > 1 ? rows / 2048 : 1;
   return (int)(want < cap ? want : cap);
@@ -181,6 +182,30 @@ __global__ __launch_bounds__(256) void obs_affine_kernel(const float* Q, const f
   }
   dgamma[p] += ag;
   dbeta[p] += ab;
+}
+
+// ---- position-batched first layer: fold the LayerNorm affine into per-position weights ---------------------------------
+// wg[pos][o][k] = w[o][k] * gamma[p(pos,k)];   b2[pos][o] = bias[o] + sum_k w[o][k] * beta[p(pos,k)]
+__global__ __launch_bounds__(256) void obs_fold_affine_kernel(const float* w, const float* bias, const float* gamma,
+                                                              const float* beta, int P, int Cout, ObsIndex ix, float* wg,
+                                                              float* b2) {
+  __shared__ float red[4];
+  const int Kp = ix.Cin * ix.KH * ix.KW;
+  const int pos = blockIdx.x / Cout, o = blockIdx.x % Cout;
+  const int oh = pos / ix.OW, ow = pos % ix.OW;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < Kp; k += 256) {
+    int ci, kh, kw;
+    ix.split_k(k, ci, kh, kw);
+    const int p = ix.p_of(ci, oh * ix.S + kh, ow * ix.S + kw);
+    const float wv = w[o * Kp + k];
+    wg[((long)pos * Cout + o) * Kp + k] = wv * gamma[p];
+    acc += wv * beta[p];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) b2[pos * Cout + o] = (bias ? bias[o] : 0.f) + red[0] + red[1] + red[2] + red[3];
 }
 
 int check_desc(const srl_conv_desc* d) {
@@ -335,9 +360,15 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
   return 0;
 }
 
+extern "C" int64_t srl_conv2d_obs_fwd_workspace(const srl_conv_desc* d) {
+  if (check_desc(d) != 0) return 0;
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
+  return (int64_t)OH * OW * d->Cout * ((long)d->Cin * d->KH * d->KW + 1) + 64;
+}
+
 extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                  const float* w, const float* bias, float* y) {
+                                  const float* w, const float* bias, float* y, float* workspace) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1),
                 "unsupported geometry (planar: KW, W, stride, H*W multiples of 4; channels-last: Cin multiple of 4)");
   SRL_CHECK_ARG(obs && mean && rstd && gamma && beta && w && y && aligned16(obs) && aligned16(gamma) && aligned16(beta),
@@ -345,20 +376,47 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
   if (d->n == 0) return 0;
   const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
   const long Kp = (long)d->Cin * d->KH * d->KW;
+  hipStream_t st = (hipStream_t)stream;
   GemmArgs g{};
-  g.M = d->n * OH * OW; g.N = d->Cout; g.K = Kp;
-  g.a = obs_patch_src(obs, is_u8, mean, rstd, gamma, beta, d, OH * OW, OW, channels_last);
-  g.b = plain_src(w, Kp);
-  g.o = plain_out(y, d->Cout);
-  g.bias = bias; g.act = d->act;
+  g.K = Kp;
+  g.act = d->act;
   g.k_per_split = srl_ceil_div(Kp, BK) * BK;
   g.vec_a = 1;
-  g.vec_b = aligned16(w) && Kp % 4 == 0;
-  hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (d->Cout > 64) rc = launch<128, 128, 2, 2, false, false, SRC_OBS, SRC_PLAIN>(st, g, 1, 1);
-  else if (d->Cout > 32) rc = launch<256, 64, 4, 1, false, false, SRC_OBS, SRC_PLAIN>(st, g, 1, 1);
-  else rc = launch<256, 32, 4, 1, false, false, SRC_OBS, SRC_PLAIN>(st, g, 1, 1);
+  if (workspace && aligned16(workspace) && Kp % 4 == 0 && d->n >= 64) {
+    // Position-batched form: one GEMM per output position over the samples, with the LayerNorm affine folded into
+    // per-position weights (w * gamma) and biases (bias + w . beta): the gather then needs no table lookups.
+    const int P = OH * OW;
+    float* wg = workspace;
+    float* b2 = wg + (long)P * d->Cout * Kp;
+    const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, channels_last ? 1 : 0};
+    hipLaunchKernelGGL(obs_fold_affine_kernel, dim3((unsigned)(P * d->Cout)), dim3(256), 0, st, w, bias, gamma, beta, P,
+                       d->Cout, ix, wg, b2);
+    g.M = d->n; g.N = d->Cout;
+    g.a = obs_patch_src(obs, is_u8, mean, rstd, nullptr, nullptr, d, 1, 1, channels_last);  // rows = samples
+    g.a.brw = OW;
+    g.a.by_stride = channels_last ? d->stride * d->W * d->Cin : d->stride * d->W;
+    g.a.bx_stride = channels_last ? d->stride * d->Cin : d->stride;
+    g.b = plain_src(wg, Kp);
+    g.b.brw = 1; g.b.by_stride = (int)(d->Cout * Kp); g.b.bx_stride = 0;
+    g.o = plain_out(y, (long)P * d->Cout);
+    g.o.batch_stride = d->Cout;
+    g.bias = b2; g.bias_batch = d->Cout;
+    g.vec_b = 1;
+    if (d->Cout > 64) rc = launch<128, 128, 2, 2, false, false, SRC_OBSN, SRC_PLAIN>(st, g, P, 1);
+    else if (d->Cout > 32) rc = launch<256, 64, 4, 1, false, false, SRC_OBSN, SRC_PLAIN>(st, g, P, 1);
+    else rc = launch<256, 32, 4, 1, false, false, SRC_OBSN, SRC_PLAIN>(st, g, P, 1);
+  } else {
+    g.M = d->n * OH * OW; g.N = d->Cout;
+    g.a = obs_patch_src(obs, is_u8, mean, rstd, gamma, beta, d, OH * OW, OW, channels_last);
+    g.b = plain_src(w, Kp);
+    g.o = plain_out(y, d->Cout);
+    g.bias = bias;
+    g.vec_b = aligned16(w) && Kp % 4 == 0;
+    if (d->Cout > 64) rc = launch<128, 128, 2, 2, false, false, SRC_OBS, SRC_PLAIN>(st, g, 1, 1);
+    else if (d->Cout > 32) rc = launch<256, 64, 4, 1, false, false, SRC_OBS, SRC_PLAIN>(st, g, 1, 1);
+    else rc = launch<256, 32, 4, 1, false, false, SRC_OBS, SRC_PLAIN>(st, g, 1, 1);
+  }
   SRL_CHECK_ARG(rc == 0, "grid too large");
   SRL_LAUNCH_CHECK();
   return 0;
@@ -408,7 +466,7 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
   g.o.batch_stride = (long)d->Cout * Kp;
   g.slab = (long)P * d->Cout * Kp;
   g.vec_a = 1; g.vec_b = 1;
-  rc = launch<32, 256, 1, 4, true, true, SRC_PLAIN, SRC_OBS>(st, g, P, nsplit);
+  rc = launch<32, 256, 1, 4, true, true, SRC_PLAIN, SRC_OBSN>(st, g, P, nsplit);
   SRL_CHECK_ARG(rc == 0, "grid too large");
   SRL_LAUNCH_CHECK();
   if (nsplit > 1) {

@@ -26,7 +26,8 @@ namespace srlgemm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
-enum { SRC_PLAIN = 0, SRC_CONV = 1, SRC_DGRAD = 2, SRC_OBS = 3 };
+enum { SRC_PLAIN = 0, SRC_CONV = 1, SRC_DGRAD = 2, SRC_OBS = 3, SRC_OBSN = 4 };  // OBSN: OBS without the affine
+constexpr bool is_obs(int m) { return m == SRC_OBS || m == SRC_OBSN; }
 
 // ---- division by a runtime-invariant 32-bit divisor (valid for dividends < 2^31) ----------------------------------
 struct FastDiv {
@@ -87,6 +88,7 @@ struct GemmArgs {
   long k_per_split;
   int vec_a, vec_b;
   int tiles_n;
+  int nbatch;
 };
 
 #ifdef __HIPCC__
@@ -109,7 +111,7 @@ __device__ __forceinline__ RowInfo row_info(const SrcDesc& s, uint32_t r) {
   ri.x = (int)x;
   ri.pos = (int)(y * s.y_stride + x * s.x_stride);
   ri.off = (int)n * s.img_stride + ri.pos;
-  if (MODE == SRC_OBS) {  // raw statistics: arithmetic on loaded values is deferred to the LDS-store phase
+  if (is_obs(MODE)) {  // raw statistics: arithmetic on loaded values is deferred to the LDS-store phase
     ri.rs = s.rstd[n];
     ri.mr = s.mean[n];
   } else {
@@ -153,7 +155,7 @@ __device__ __forceinline__ float4 gather4(const SrcDesc& s, const RowInfo& ri, c
       return make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const int off = ri.off + ci.off;
-  if (MODE != SRC_OBS) return *reinterpret_cast<const float4*>(static_cast<const float*>(s.base) + off);
+  if (!is_obs(MODE)) return *reinterpret_cast<const float4*>(static_cast<const float*>(s.base) + off);
   float4 v;
   if (s.is_u8) {  // raw bytes travel as one dword; decoded in obs_finish()
     v.x = __uint_as_float(*reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(s.base) + off));
@@ -212,11 +214,12 @@ struct Stage {
   float r[NF];
   uint32_t voff[NV];                                 // k-invariant byte offset of quad q (kInvalidOff: always zero)
   int yx[(MODE == SRC_DGRAD) ? NV : 1];              // DGRAD: (y << 16) | x of the row
-  int pos[(MODE == SRC_OBS && !KMAJOR) ? NV : 1];    // OBS: offset of the row inside its image
+  int pos[(MODE == SRC_OBS && !KMAJOR) ? NV : 1];       // OBS: offset of the row inside its image
   // SRC_OBS: the LayerNorm is applied when the tile is written to LDS (after the MFMAs of the previous tile), so
   // that nothing between the global loads and the MFMA loop depends on loaded data
-  float d_rs[MODE == SRC_OBS ? NV : 1], d_mean[MODE == SRC_OBS ? NV : 1];
-  int d_gp[MODE == SRC_OBS ? NV : 1];  // gamma/beta offset of the quad, or -1 (out of bounds: the quad is zero)
+  float d_rs[is_obs(MODE) ? NV : 1], d_mean[is_obs(MODE) ? NV : 1];
+  int d_gp[MODE == SRC_OBS ? NV : 1];
+  uint32_t vmask;  // OBSN, k-contiguous: bit q = quad q of the current tile is in bounds  // gamma/beta offset of the quad, or -1 (out of bounds: the quad is zero)
   const char* cur;                     // dense operands: base of the current k-tile (wave-uniform)
   long step;                           // dense operands: bytes per k-tile
   uint32_t esz;                        // element size of the source (1 for uint8 observations)
@@ -224,7 +227,7 @@ struct Stage {
   // x0: first output index of the tile; xn: extent of that dimension; kbeg: first k of this workgroup
   __device__ __forceinline__ void prepare(const SrcDesc& s, long x0, long xn, long kbeg, bool vec) {
     const int tid = threadIdx.x;
-    esz = (MODE == SRC_OBS && s.is_u8) ? 1u : 4u;
+    esz = (is_obs(MODE) && s.is_u8) ? 1u : 4u;
     if (!GATHER) {
       if (!vec) return;  // scalar fallback addresses directly
       const long ld = s.ld;
@@ -248,7 +251,8 @@ struct Stage {
         const RowInfo ri = row_info<MODE>(s, (uint32_t)(x < xn ? x : xn - 1));
         voff[q] = x < xn ? (uint32_t)ri.off * esz : kInvalidOff;
         if (MODE == SRC_DGRAD) yx[q] = (ri.y << 16) | ri.x;
-        if (MODE == SRC_OBS) { d_rs[q] = ri.rs; d_mean[q] = ri.mr; pos[q] = ri.pos; }
+        if (is_obs(MODE)) { d_rs[q] = ri.rs; d_mean[q] = ri.mr; }
+        if (MODE == SRC_OBS) pos[q] = ri.pos;
       } else {
         const long x = x0 + (u % (BX / 4)) * 4;
         const ColInfo ci = col_info<MODE>(s, (uint32_t)(x < xn ? x : 0));
@@ -273,8 +277,9 @@ struct Stage {
           if (MODE == SRC_DGRAD)
             ok = ok && (unsigned)((yx[q] >> 16) - ci.jh) < (unsigned)s.OH && (unsigned)((yx[q] & 0xffff) - ci.jw) < (unsigned)s.OW;
           const uint32_t o = ok ? voff[q] + cb : kInvalidOff;
-          if (MODE == SRC_OBS) {
-            d_gp[q] = ok ? pos[q] + ci.off : -1;
+          if (is_obs(MODE)) {
+            if (MODE == SRC_OBS) d_gp[q] = ok ? pos[q] + ci.off : -1;
+            if (MODE == SRC_OBSN) vmask = (q == 0 ? 0u : vmask) | ((ok ? 1u : 0u) << q);
             if (s.is_u8) r[4 * q] = bload1(rs, o);
             else { const float4 v = bload4(rs, o); r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w; }
           } else {
@@ -283,16 +288,19 @@ struct Stage {
           }
         }
       } else {
+        // with 64 quads per k-row (BX == 256) a wavefront stages exactly one row per q: the row index, its
+        // decomposition and its LayerNorm statistics are wave-uniform and live on the scalar unit
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
           const int u = tid + q * 256;
-          const long k = k0 + u / (BX / 4);
+          const long k = k0 + (BX == 256 ? wave + 4 * q : u / (BX / 4));
           const bool ok = k < kend && voff[q] != kInvalidOff;
           const RowInfo ri = row_info<MODE>(s, (uint32_t)(k < kend ? k : kend - 1));
           const uint32_t o = ok ? voff[q] + (uint32_t)ri.off * esz : kInvalidOff;
-          if (MODE == SRC_OBS) {
-            d_rs[q] = ri.rs; d_mean[q] = ri.mr;
-            d_gp[q] = ok ? ri.pos + (int)(voff[q] / esz) : -1;
+          if (is_obs(MODE)) {
+            d_rs[q] = ok ? ri.rs : 0.f; d_mean[q] = ok ? ri.mr : 0.f;
+            if (MODE == SRC_OBS) d_gp[q] = !ok ? -1 : ri.pos + (int)(voff[q] / esz);
             if (s.is_u8) r[4 * q] = bload1(rs, o);
             else { const float4 v = bload4(rs, o); r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w; }
           } else {
@@ -337,22 +345,29 @@ struct Stage {
     const int tid = threadIdx.x;
     if (MODE == SRC_OBS) {
       float4 g[NV], b[NV];
-      const bool aff = s.affine != 0;
-      if (aff) {
-        const __amdgpu_buffer_rsrc_t rg = make_rsrc(s.gamma), rb = make_rsrc(s.beta);
+      const __amdgpu_buffer_rsrc_t rg = make_rsrc(s.gamma), rb = make_rsrc(s.beta);
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {  // all table loads first (L2-resident), then the arithmetic
-          const uint32_t o = d_gp[q] < 0 ? kInvalidOff : (uint32_t)d_gp[q] * 4u;
-          g[q] = bload4(rg, o);
-          b[q] = bload4(rb, o);
-        }
+      for (int q = 0; q < NV; ++q) {  // all table loads first (L2-resident), then the arithmetic
+        const uint32_t o = d_gp[q] < 0 ? kInvalidOff : (uint32_t)d_gp[q] * 4u;
+        g[q] = bload4(rg, o);
+        b[q] = bload4(rb, o);
       }
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (d_gp[q] >= 0)
           v = obs_finish(s, make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]), d_rs[q], d_mean[q], g[q], b[q],
-                         aff);
+                         true);
+        r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+      }
+    } else if (MODE == SRC_OBSN) {
+      // no tables: padding quads (loaded as zeros) must stay zero, so their statistics were zeroed in load()
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = obs_finish(s, make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]), d_rs[q], d_mean[q], z, z,
+                              false);
+        if (!KMAJOR && !((vmask >> q) & 1u)) v = z;
         r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
       }
     }
@@ -393,19 +408,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, h = lane >> 5;
-  const long tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x % g.tiles_n;
+  // grid.x carries (tile, batch) with the batch index fastest when nbatch > 1 (workgroups that run together then
+  // share the same rows of the gathered tensor through L2); grid.y is unused in that case
+  const unsigned bx = g.nbatch > 1 ? blockIdx.x / g.nbatch : blockIdx.x;
+  const long tile_m = bx / g.tiles_n, tile_n = bx % g.tiles_n;
   const long m0 = tile_m * BM, n0 = tile_n * BN;
   const long kbeg = (long)blockIdx.z * g.k_per_split;
   const long kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
 
   // batch (grid.y): shift the operand bases
-  const int by = blockIdx.y;
+  const int by = g.nbatch > 1 ? (int)(blockIdx.x % g.nbatch) : 0;
   if (by) {
     const long ao = (long)(by / g.a.brw) * g.a.by_stride + (long)(by % g.a.brw) * g.a.bx_stride;
     const long bo = (long)(by / g.b.brw) * g.b.by_stride + (long)(by % g.b.brw) * g.b.bx_stride;
-    g.a.base = (AMODE == SRC_OBS && g.a.is_u8) ? (const void*)(static_cast<const uint8_t*>(g.a.base) + ao)
+    g.a.base = (is_obs(AMODE) && g.a.is_u8) ? (const void*)(static_cast<const uint8_t*>(g.a.base) + ao)
                                                : (const void*)(static_cast<const float*>(g.a.base) + ao);
-    g.b.base = (BMODE == SRC_OBS && g.b.is_u8) ? (const void*)(static_cast<const uint8_t*>(g.b.base) + bo)
+    g.b.base = (is_obs(BMODE) && g.b.is_u8) ? (const void*)(static_cast<const uint8_t*>(g.b.base) + bo)
                                                : (const void*)(static_cast<const float*>(g.b.base) + bo);
     if (BMODE == SRC_OBS && g.b.affine) { g.b.gamma += bo; g.b.beta += bo; }
     if (AMODE == SRC_OBS && g.a.affine) { g.a.gamma += ao; g.a.beta += ao; }
@@ -558,9 +576,10 @@ template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMO
 inline int launch(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   const long tiles_m = srl_ceil_div(a.M, BM);
   a.tiles_n = (int)srl_ceil_div(a.N, BN);
-  const long nblk = tiles_m * a.tiles_n;
-  if (nblk > 0x7fffffffL || batch > 65535 || nsplit > 65535) return -EINVAL;
-  dim3 grid((unsigned)nblk, (unsigned)batch, (unsigned)nsplit);
+  a.nbatch = batch > 1 ? batch : 1;
+  const long nblk = tiles_m * a.tiles_n * a.nbatch;
+  if (nblk > 0x7fffffffL || nsplit > 65535) return -EINVAL;
+  dim3 grid((unsigned)nblk, 1, (unsigned)nsplit);
   hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE>), grid, dim3(256), 0, st, a);
   return 0;
 }

@@ -58,7 +58,8 @@ _SIGNATURES = {
     "srl_conv2d_dgrad_weight_elems": (c_int64, [_CD]),
     "srl_conv2d_dgrad_repack": (c_int, [c_void_p, _CD, c_void_p, c_void_p]),
     "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 7),
+    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 8),
+    "srl_conv2d_obs_fwd_workspace": (c_int64, [_CD]),
     "srl_obs_space_to_depth": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                         c_void_p]),
     "srl_conv2d_obs_bwd_workspace": (c_int64, [_CD]),
@@ -395,12 +396,16 @@ def conv2d_nhwc_dgrad(d: ConvDesc, dz_ptr, wt_ptr, x_act_ptr, dact, dx_ptr):
                "srl_conv2d_nhwc_dgrad")
 
 
+def conv2d_obs_fwd_workspace(d: ConvDesc) -> int:
+    return int(lib().srl_conv2d_obs_fwd_workspace(ctypes.byref(d)))
+
+
 def conv2d_obs_fwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr,
-                   channels_last=False):
+                   channels_last=False, ws_ptr=None):
     with _scope("conv_obs_fwd", _conv_flops(d)):
         _check(
             lib().srl_conv2d_obs_fwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), int(channels_last), mean_ptr,
-                                     rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr), "srl_conv2d_obs_fwd")
+                                     rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr, ws_ptr), "srl_conv2d_obs_fwd")
 
 
 def obs_space_to_depth(obs_ptr, is_u8, n, C, H, W, s, out_ptr, mean_ptr, rstd_ptr):

@@ -586,6 +586,12 @@ def test_conv2d_obs_space_to_depth_path(n, u8):
     z = torch.nn.functional.conv2d(xn, tw, tbias, stride=s)
     yref = torch.relu(z)
     assert rel_close(y.cpu().numpy(), yref.permute(0, 2, 3, 1).detach().numpy(), 1e-5, scale=1.0)
+    # position-batched form (affine folded into per-position weights); needs >= 64 samples to be selected
+    fws = torch.empty(hip.conv2d_obs_fwd_workspace(d), device=DEV)
+    y2 = torch.full((n, OH, OH, Cout), np.nan, device=DEV)
+    hip.conv2d_obs_fwd(d, s2d.data_ptr(), u8, mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), dbt.data_ptr(),
+                       dw_.data_ptr(), db_.data_ptr(), y2.data_ptr(), channels_last=True, ws_ptr=fws.data_ptr())
+    assert rel_close(y2.cpu().numpy(), yref.permute(0, 2, 3, 1).detach().numpy(), 1e-5, scale=1.0)
     dz = (rng.standard_normal((n, OH, OH, Cout)) * (yref.permute(0, 2, 3, 1).detach().numpy() > 0)).astype(np.float32)
     z.backward(t(dz).double().permute(0, 3, 1, 2))
     ddz = dev(dz)
