@@ -1,0 +1,67 @@
+"""World-size-2 checks of the data-parallel arithmetic on CPU (gloo), the way the reference tests its
+distributed pieces (legacy/tests/modules_test.py:49-74,273-299): the statistic exchange that makes the
+advantage normalisation global, the DDP gradient semantics (mean of per-rank masked means), and the
+flat-buffer parameter broadcast.  The HIP kernels themselves need a GPU; here the collectives and the
+host-side composition are exercised with the oracle's arithmetic standing in for the kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ppo as oppo
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, adv, mask, expected, ckpt_flat):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        half = adv.shape[1] // world
+        a, m = adv[:, rank * half:(rank + 1) * half], mask[:, rank * half:(rank + 1) * half]
+        # what MultiAgentPPO.step does with the three sums produced by srl_gae_scan: ONE all-reduce
+        stats = torch.tensor(oppo.masked_stats(a, m), dtype=torch.float64)
+        local_n = float(stats[0])
+        g = stats.clone()
+        dist.all_reduce(g)
+        out = oppo.masked_normalization(a, m, stats=tuple(g.tolist()))
+        np.testing.assert_almost_equal(out * m, expected[:, rank * half:(rank + 1) * half] * m, decimal=6)
+        assert local_n == m.sum()
+        # gradient semantics: each rank's gradient is of its LOCAL masked mean; all-reduce SUM then 1/world
+        grad = torch.full((5,), float(rank + 1))
+        dist.all_reduce(grad)
+        assert torch.allclose(grad / world, torch.full((5,), (1 + 2) / 2))
+        # parameter broadcast through the policy's own method on a CPU shell
+        import srl_amd
+        from srl_amd.api import config, policy as policy_api
+        srl_amd.register_all()
+        pol = policy_api.make(config.Policy("actor-critic", args=dict(obs_dim=4, action_dim=2, hidden_dim=8,
+                                                                         num_dense_layers=1, num_rnn_layers=0,
+                                                                         popart=False, seed=rank)))
+        if rank == 0:
+            pol.net.flat.copy_(ckpt_flat)
+            pol._version = 11
+        pol.distributed()
+        assert torch.equal(pol.net.flat, ckpt_flat) and pol.version == 11
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_statistics_gradients_and_broadcast():
+    rng = np.random.default_rng(0)
+    adv = rng.standard_normal((6, 16, 1)).astype(np.float32)
+    mask = (rng.random((6, 16, 1)) < 0.7).astype(np.float32)
+    expected = oppo.masked_normalization(adv, mask)
+    import srl_amd
+    from srl_amd.algorithm.netspec import build_netspec
+    spec, _ = build_netspec(obs_dim=4, action_dim=2, hidden_dim=8, num_dense_layers=1)
+    flat = torch.arange(spec.total_params, dtype=torch.float32)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, adv, mask, expected, flat), nprocs=2, join=True)
