@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--chunk-rows", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -126,19 +127,20 @@ def main():
     from srl_amd.api import config, trainer as trainer_api
     srl_amd.register_all()
 
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world,
                                 device_id=torch.device(device))
     trainer = trainer_api.make(config.Trainer("mappo", args=dict(TRAINER, chunk_rows=args.chunk_rows)),
                                config.Policy("actor-critic", args=POLICY))
-    if world > 1:
+    if use_dist:
         trainer.distributed(rank=rank, world_size=world, init_method="env://")
 
     T, B = args.rollout_len, args.envs_per_gpu
     sample = device_sample(1000 + rank, T, B, device)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -150,7 +152,7 @@ def main():
         res = trainer.step(sample)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -192,7 +194,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T, threads=min(os.cpu_count() or 1, 32))
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

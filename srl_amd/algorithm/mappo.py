@@ -108,6 +108,7 @@ class MultiAgentPPO(PytorchTrainer):
         # rows (env-steps) per forward/backward chunk: bounds the activation workspace, not the arithmetic
         self.chunk_rows = int(g("chunk_rows", 16384))
         self._world = 1
+        self._dist = False
 
     # ------------------------------------------------------------------ checkpoints (mappo.py:58-66)
     def get_checkpoint(self):
@@ -148,6 +149,7 @@ class MultiAgentPPO(PytorchTrainer):
     def distributed(self, rank=None, world_size=None, init_method=None, **kwargs):
         super().distributed(rank=rank, world_size=world_size, init_method=init_method, **kwargs)
         self._world = dist.get_world_size() if dist.is_initialized() else 1
+        self._dist = dist.is_initialized()  # collectives run whenever a group exists (also with one rank)
 
     # ------------------------------------------------------------------ the step (mappo.py:219-328)
     def step(self, sample):
@@ -203,7 +205,7 @@ class MultiAgentPPO(PytorchTrainer):
                 if not fused_stats:
                     hip.masked_stats(adv_d[lo:hi], mask_rows, stats_local, mask_invert=True)
                 stats_global = stats_local.clone()
-                if self._world > 1:
+                if self._dist:
                     dist.all_reduce(stats_global)  # one 24-byte message instead of three
                 local_n = stats_local[0:1]
 
@@ -237,7 +239,7 @@ class MultiAgentPPO(PytorchTrainer):
                 net.backward(d_logits, d_v.view(n, 1))
 
             # ---- gradient reduction, clip, Adam (mappo.py:272-284) ---------------------------------------------------
-            if self._world > 1:
+            if self._dist:
                 dist.all_reduce(net.grad)
             sumsq = torch.zeros(1, **f64)
             gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
