@@ -57,7 +57,7 @@ class Workspace:
 def _split_for(rows: int, tiles: int) -> int:
     """split-K factor for weight gradients: enough workgroups to fill 256 CUs, >= 2048 rows each."""
     want = max(1, 512 // max(tiles, 1))
-    return int(max(1, min(want, rows // 2048)))
+    return int(max(1, min(want, rows // 512)))
 
 
 class HipNet:

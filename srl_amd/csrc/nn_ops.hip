@@ -409,17 +409,24 @@ __global__ __launch_bounds__(256) void obs_s2d_kernel(const void* obs, long n, i
   const int D = C * H * W, Wb = W / S, SS = S * S;
   double acc[2] = {0.0, 0.0};
   if (U8 && S == 4 && W % 4 == 0) {
-    // dword path: the 4 bytes (pw = 0..3) of one (c, h, b) stay together
+    // dword path: the 4 bytes (pw = 0..3) of one (c, h, b) stay together.  The sample is staged in LDS so that both
+    // the read and the re-tiled write are fully coalesced.
+    extern __shared__ __attribute__((aligned(16))) uint32_t stage[];
     const uint32_t* src = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(obs) + smp * D);
     uint32_t* dst = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(out) + smp * D);
     unsigned long long a = 0, b = 0;
     for (int e = threadIdx.x; e < D / 4; e += 256) {
       const uint32_t w = src[e];
-      const int bq = e % Wb, h = (e / Wb) % H, c = e / (Wb * H);
-      dst[((h / 4 * Wb + bq) * C + c) * 4 + (h & 3)] = w;
+      stage[e] = w;
       const unsigned b0 = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u, b3 = w >> 24;
       a += b0 + b1 + b2 + b3;
       b += b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < D / 4; o += 256) {  // o = ((a*Wb + bq)*C + c)*4 + ph
+      const int ph = o & 3, c = (o >> 2) % C, blk = (o >> 2) / C;
+      const int bq = blk % Wb, ab = blk / Wb;
+      dst[o] = stage[(c * H + ab * 4 + ph) * Wb + bq];
     }
     acc[0] = (double)a;
     acc[1] = (double)b;
@@ -457,7 +464,9 @@ extern "C" int srl_obs_space_to_depth(void* stream, const void* obs, int is_u8, 
   SRL_CHECK_ARG(obs && out && mean && rstd, "null tensor");
   SRL_CHECK_ARG(s >= 1 && H % s == 0 && W % s == 0, "stride must divide H and W");
   if (n == 0) return 0;
-  if (is_u8) hipLaunchKernelGGL(obs_s2d_kernel<true>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, obs, (long)n, C, H, W, s, out, mean, rstd);
+  const size_t lds = (is_u8 && s == 4 && W % 4 == 0 && (size_t)C * H * W <= 60 * 1024) ? (size_t)C * H * W : 0;
+  SRL_CHECK_ARG(!(is_u8 && s == 4 && W % 4 == 0) || lds, "observation too large for the LDS-staged re-tiling");
+  if (is_u8) hipLaunchKernelGGL(obs_s2d_kernel<true>, dim3((unsigned)n), dim3(256), lds, (hipStream_t)stream, obs, (long)n, C, H, W, s, out, mean, rstd);
   else hipLaunchKernelGGL(obs_s2d_kernel<false>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, obs, (long)n, C, H, W, s, out, mean, rstd);
   SRL_LAUNCH_CHECK();
   return 0;
