@@ -12,6 +12,9 @@
 //   3. every lane replays its chunk from the carry-in, emitting adv, ret and the masked sums
 // Time is processed in tiles of TT rows from the end, the carry crossing tiles through LDS, so T is
 // unbounded.  All arithmetic that the reference does in float64 (gae.py:46-48) is float64 here.
+// Two kernels share that scheme: gae_scan_reg_kernel (one value channel, B % 4 == 0 -- the trainer's
+// layout; register-resident quads of columns, 16-byte loads, log-step scan over chunk maps) and
+// gae_scan_kernel (any Nc / alignment; LDS-staged tile).
 #include "srl_common.h"
 
 namespace {
@@ -179,6 +182,194 @@ int launch_gae(hipStream_t st, GaeParams p, bool vtrace) {
   return 0;
 }
 
+// ---- register-resident variant (Nc == 1, B % 4 == 0, 16-byte aligned leaves) ------------------------
+// The common layout: one value channel, so flags and floats share the column index.  Each lane owns
+// a quad of adjacent columns x L consecutive time rows and reads them straight into registers with
+// 16-byte (floats) / 4-byte (flags) loads: a time row of the workgroup's tile is one contiguous
+// CQ*16-byte segment.  Nothing but the per-chunk affine maps goes through LDS, and the carry-in of
+// every chunk comes from a log-step suffix scan over those maps (SEG = 256/CQ chunks per column).
+template <int CQ, int L, bool VTRACE>
+__global__ __launch_bounds__(256) void gae_scan_reg_kernel(GaeParams p) {
+  constexpr int COLS = CQ * 4;
+  constexpr int SEG = 256 / CQ;
+  constexpr int TT = SEG * L;
+  __shared__ __attribute__((aligned(16))) double sM[SEG * COLS];
+  __shared__ __attribute__((aligned(16))) double sD[SEG * COLS];
+  __shared__ double red[12];
+
+  const int tid = threadIdx.x;
+  const int cq = tid % CQ;
+  const int seg = tid / CQ;
+  const long B = p.B;
+  const long col = (long)blockIdx.x * COLS + 4 * cq;
+  const bool col_ok = col < B;
+  const double gl = p.gamma * p.lambda;
+  const int lbase = seg * COLS + 4 * cq;
+
+  double carry[4] = {0.0, 0.0, 0.0, 0.0};  // adv[T] = 0 (gae.py:80)
+  double acc[3] = {0.0, 0.0, 0.0};
+
+  for (int t1 = p.T; t1 > 0; t1 -= TT) {
+    const int t0 = t1 - TT > 0 ? t1 - TT : 0;
+    const int len = t1 - t0;
+    const int a = seg * L;
+
+    float v[L + 1][4], rw[L][4], q[L][4];
+    uint32_t orw[L + 1], trw[L + 1];
+#pragma unroll
+    for (int i = 0; i <= L; ++i) {
+      float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint32_t dn = 0;
+      orw[i] = 0;
+      trw[i] = 0;
+      if (col_ok && a + i <= len) {
+        const long o = (long)(t0 + a + i) * B + col;
+        vv = *reinterpret_cast<const float4*>(p.value + o);
+        dn = *reinterpret_cast<const uint32_t*>(p.done + o);
+        trw[i] = *reinterpret_cast<const uint32_t*>(p.truncated + o);
+        orw[i] = *reinterpret_cast<const uint32_t*>(p.on_reset + o);
+      }
+      v[i][0] = (dn & 0xffu) ? 0.f : vv.x;  // value * (1 - done), mappo.py:124
+      v[i][1] = (dn & 0xff00u) ? 0.f : vv.y;
+      v[i][2] = (dn & 0xff0000u) ? 0.f : vv.z;
+      v[i][3] = (dn & 0xff000000u) ? 0.f : vv.w;
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 qq = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (col_ok && a + i < len) {
+        const long o = (long)(t0 + a + i) * B + col;
+        rr = *reinterpret_cast<const float4*>(p.reward + o);
+        if (VTRACE) qq = *reinterpret_cast<const float4*>(p.ratio + o);
+      }
+      rw[i][0] = rr.x, rw[i][1] = rr.y, rw[i][2] = rr.z, rw[i][3] = rr.w;
+      q[i][0] = qq.x, q[i][1] = qq.y, q[i][2] = qq.z, q[i][3] = qq.w;
+    }
+
+    auto step = [&](int i, int c, double& delta, double& m) {
+      const double nr = 1.0 - (double)((orw[i + 1] >> (8 * c)) & 0xffu);
+      const double nt = 1.0 - (double)((trw[i + 1] >> (8 * c)) & 0xffu);
+      delta = (double)rw[i][c] + p.gamma * (double)v[i + 1][c] * nr - (double)v[i][c];  // gae.py:63
+      m = gl * nr * nt;                                                                 // gae.py:87
+      if (VTRACE) {
+        delta *= fmin((double)q[i][c], p.rho);  // gae.py:65
+        m *= fmin((double)q[i][c], p.c);        // gae.py:89
+      }
+      if (a + i >= len) delta = 0.0, m = 1.0;  // rows past the (partial) tile: identity map
+    };
+
+    // ---- pass 1: fold my chunk into (M, D) per column --------------------------------------------
+    double M[4], D[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      M[c] = 1.0, D[c] = 0.0;
+#pragma unroll
+      for (int i = L - 1; i >= 0; --i) {
+        double delta, m;
+        step(i, c, delta, m);
+        D[c] = delta + m * D[c];
+        M[c] = m * M[c];
+      }
+    }
+    // ---- pass 2: inclusive suffix scan of the chunk maps over seg (log steps, in place) ----------
+    __syncthreads();  // previous tile's readers are done
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sM[lbase + c] = M[c], sD[lbase + c] = D[c];
+    __syncthreads();
+#pragma unroll
+    for (int off = 1; off < SEG; off <<= 1) {
+      double M2[4], D2[4];
+      const bool has = seg + off < SEG;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        M2[c] = has ? sM[lbase + off * COLS + c] : 1.0;
+        D2[c] = has ? sD[lbase + off * COLS + c] : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        D[c] = D[c] + M[c] * D2[c];
+        M[c] = M[c] * M2[c];
+        sM[lbase + c] = M[c], sD[lbase + c] = D[c];
+      }
+      __syncthreads();
+    }
+    // carry-in of my chunk: the composite of every later chunk applied to the tile carry
+    double g[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool has = seg + 1 < SEG;
+      const double Mn = has ? sM[lbase + COLS + c] : 1.0;
+      const double Dn = has ? sD[lbase + COLS + c] : 0.0;
+      g[c] = Dn + Mn * carry[c];
+      carry[c] = sD[4 * cq + c] + sM[4 * cq + c] * carry[c];  // whole tile applied: next tile's carry
+    }
+    // ---- pass 3: replay -------------------------------------------------------------------------
+    float ao[L][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int i = L - 1; i >= 0; --i) {
+        double delta, m;
+        step(i, c, delta, m);
+        g[c] = delta + m * g[c];
+        const float advf = (float)g[c];  // gae.py:97
+        ao[i][c] = advf;
+        if (col_ok && a + i < len) {
+          const double mask = 1.0 - (double)((orw[i + 1] >> (8 * c)) & 0xffu);  // mappo.py:260
+          const double x = (double)advf * mask;                                  // utils.py:52
+          acc[0] += mask;
+          acc[1] += x;
+          acc[2] += x * x;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      if (col_ok && a + i < len) {
+        const long o = (long)(t0 + a + i) * B + col;
+        *reinterpret_cast<float4*>(p.adv + o) = make_float4(ao[i][0], ao[i][1], ao[i][2], ao[i][3]);
+        // mappo.py:143 (float32 add)
+        *reinterpret_cast<float4*>(p.ret + o) =
+            make_float4(ao[i][0] + v[i][0], ao[i][1] + v[i][1], ao[i][2] + v[i][2], ao[i][3] + v[i][3]);
+      }
+    }
+  }
+
+  if (p.stats != nullptr) {
+    __syncthreads();
+    block_sum<3, 256>(acc, red);
+    if (tid == 0) {
+      atomicAdd(&p.stats[0], acc[0]);
+      atomicAdd(&p.stats[1], acc[1]);
+      atomicAdd(&p.stats[2], acc[2]);
+    }
+  }
+}
+
+template <int CQ, int L>
+int launch_gae_reg(hipStream_t st, const GaeParams& p, bool vtrace) {
+  dim3 grid((unsigned)srl_ceil_div((long)p.B, (long)CQ * 4));
+  if (vtrace)
+    hipLaunchKernelGGL((gae_scan_reg_kernel<CQ, L, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((gae_scan_reg_kernel<CQ, L, false>), grid, dim3(256), 0, st, p);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int CQ>
+int launch_gae_reg_l(hipStream_t st, const GaeParams& p, bool vtrace, int lmax = 4) {
+  constexpr int SEG = 256 / CQ;
+  const int need = (p.T + SEG - 1) / SEG;  // rows per lane if one time tile covered all of T
+  if (need <= 1 || lmax == 1) return launch_gae_reg<CQ, 1>(st, p, vtrace);
+  if (need <= 2 || lmax == 2) return launch_gae_reg<CQ, 2>(st, p, vtrace);
+  return launch_gae_reg<CQ, 4>(st, p, vtrace);  // longer T: several time tiles, carry in registers
+}
+
+inline bool aligned_to(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) & (a - 1)) == 0; }
+
 // ---- masked statistics / normalisation -------------------------------------------------------------
 __global__ __launch_bounds__(256) void masked_stats_kernel(const float* x, const uint8_t* mask, int invert, long n,
                                                            double* stats) {
@@ -229,6 +420,31 @@ extern "C" int srl_gae_scan(void* stream, const float* reward, const float* valu
   GaeParams p{reward, value, done, truncated, on_reset, imp_ratio, adv, ret, stats, T, B, Nc, 0,
               gamma,  lambda, rho,  c};
   const long ncols = (long)B * Nc;
+  const bool quads = Nc == 1 && B % 4 == 0 && aligned_to(reward, 16) && aligned_to(value, 16) &&
+                     aligned_to(adv, 16) && aligned_to(ret, 16) && aligned_to(done, 4) &&
+                     aligned_to(truncated, 4) && aligned_to(on_reset, 4) && (!imp_ratio || aligned_to(imp_ratio, 16));
+  if (quads) {
+    const bool vt = imp_ratio != nullptr;
+    static const char* tune = getenv("SRL_GAE_TILE");  // "<cq><l>" tuning knob for scripts/gae_sweep.py
+    if (tune && tune[0] && tune[1]) {
+      const int lmax = tune[1] - '0';
+      if (tune[0] == '4') return launch_gae_reg_l<4>(st, p, vt, lmax);
+      if (tune[0] == '8') return launch_gae_reg_l<8>(st, p, vt, lmax);
+      if (tune[0] == '3') return launch_gae_reg_l<32>(st, p, vt, lmax);
+      if (tune[0] == '6') return launch_gae_reg_l<64>(st, p, vt, lmax);
+      if (tune[0] == 'a') return launch_gae_reg_l<128>(st, p, vt, lmax);
+      if (tune[0] == 'b') return launch_gae_reg_l<256>(st, p, vt, lmax);
+      return launch_gae_reg_l<16>(st, p, vt, lmax);
+    }
+    // Row width per workgroup grows with the batch (measured on MI355X, scripts/gae_sweep.py): wide
+    // rows stream best (1 KiB = 8 whole cache lines per wave load) but need B/256 >> 256 workgroups.
+    if (ncols < 2048) return launch_gae_reg_l<4>(st, p, vt);
+    if (ncols < 16384) return launch_gae_reg_l<8>(st, p, vt);
+    if (ncols < 98304) return launch_gae_reg_l<32>(st, p, vt);
+    if (ncols < 393216) return launch_gae_reg_l<64>(st, p, vt);
+    if (ncols < 786432) return launch_gae_reg_l<128>(st, p, vt, 2);
+    return launch_gae_reg_l<256>(st, p, vt, 2);  // one lane per column quad, pure streaming over T
+  }
   // narrow tiles while the grid would not cover the chip; wide (256-byte rows) once it does
   if (ncols >= 64L * 512) return launch_gae<64>(st, p, imp_ratio != nullptr);
   return launch_gae<16>(st, p, imp_ratio != nullptr);

@@ -79,14 +79,23 @@ def test_gae_hand_case(golden):
 
 
 @pytest.mark.parametrize("T,B,Nc", [(1, 1, 1), (2, 3, 1), (128, 512, 1), (400, 37, 1), (130, 70, 2), (1000, 9, 1),
-                                    (16, 40000, 1)])
+                                    (16, 40000, 1), (1000, 12, 1), (300, 33000, 1), (77, 36864, 1), (5, 8, 1),
+                                    (64, 4, 1), (257, 256, 1), (40, 131072, 1), (6, 400000, 1)])
 def test_gae_shapes_vs_oracle(T, B, Nc):
+    # B % 4 == 0 with one value channel takes the register-resident kernel (64- or 128-byte rows,
+    # 1/2/4 time rows per lane, several time tiles when T is long); everything else the LDS-tile one
     arr = synthetic.make_sample_arrays(seed=T + B, T=T, B=B, obs_spec={}, action_dims=2, p_done=0.03, value_dim=Nc)
     a = dict(reward=arr["reward"], value=arr["analyzed_result.value"], done=arr["done"], truncated=arr["truncated"],
              on_reset=arr["on_reset"])
     adv, ret, stats = run_gae(a, 0.99, 0.97)
     o_adv, o_ret = ogae.adv_and_value_target(a["reward"], a["value"], a["truncated"], a["done"], a["on_reset"], 0.99,
                                              0.97)
+    if Nc == 1:  # V-trace through the same tiling
+        ratio = np.random.RandomState(T).uniform(0.3, 1.8, size=(T, B, 1)).astype(np.float32)
+        vadv, _, _ = run_gae(a, 0.99, 0.97, ratio=ratio)
+        o_vadv, _ = ogae.adv_and_value_target(a["reward"], a["value"], a["truncated"], a["done"], a["on_reset"], 0.99,
+                                              0.97, vtrace=True, imp_ratio=ratio)
+        assert rel_close(vadv[:T], o_vadv, 1e-5, scale=1.0)
     assert rel_close(adv[:T], o_adv, 1e-5, scale=1.0)
     assert rel_close(ret[:T], o_ret, 1e-5, scale=1.0)
     mask = np.broadcast_to(1.0 - a["on_reset"][1:].astype(np.float64), o_adv.shape)
