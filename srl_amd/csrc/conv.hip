@@ -417,7 +417,8 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
     g.b = plain_src(w, Kp);
     g.o = plain_out(y, d->Cout);
     g.bias = bias;
-    g.vec_b = aligned16(w) && Kp % 4 == 0;
+    g.vec_b = 1;
+    SRL_CHECK_ARG(Kp % 4 == 0, "Cin*KH*KW must be a multiple of 4");
     if (d->Cout > 64) rc = launch<128, 128, 2, 2, false, false, SRC_OBS, SRC_PLAIN>(st, g, 1, 1);
     else if (d->Cout > 32) rc = launch<256, 64, 4, 1, false, false, SRC_OBS, SRC_PLAIN>(st, g, 1, 1);
     else rc = launch<256, 32, 4, 1, false, false, SRC_OBS, SRC_PLAIN>(st, g, 1, 1);

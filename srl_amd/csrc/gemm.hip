@@ -7,12 +7,19 @@ using namespace srlgemm;
 
 namespace {
 
+template <int BM, int BN, int WM, int WN, bool GEN>
+int launch_or(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
+  if (!akm && !bkm) return launch<BM, BN, WM, WN, false, false, SRC_PLAIN, SRC_PLAIN, GEN>(st, g, 1, split);
+  if (!akm && bkm) return launch<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN, GEN>(st, g, 1, split);
+  if (akm && bkm) return launch<BM, BN, WM, WN, true, true, SRC_PLAIN, SRC_PLAIN, GEN>(st, g, 1, split);
+  return launch<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN, GEN>(st, g, 1, split);
+}
+
+// both operands float4-loadable (aligned, leading dimensions multiples of 4): the lean instantiation
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
-  if (!akm && !bkm) return launch<BM, BN, WM, WN, false, false, SRC_PLAIN, SRC_PLAIN>(st, g, 1, split);
-  if (!akm && bkm) return launch<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN>(st, g, 1, split);
-  if (akm && bkm) return launch<BM, BN, WM, WN, true, true, SRC_PLAIN, SRC_PLAIN>(st, g, 1, split);
-  return launch<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN>(st, g, 1, split);
+  if (g.vec_a && g.vec_b) return launch_or<BM, BN, WM, WN, false>(st, g, akm, bkm, split);
+  return launch_or<BM, BN, WM, WN, true>(st, g, akm, bkm, split);
 }
 
 }  // namespace

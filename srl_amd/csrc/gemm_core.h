@@ -395,8 +395,20 @@ struct Stage {
   }
 };
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+// GEN: the dense operands may need the element-wise (unaligned / ragged leading dimension) staging path.  The
+// float4-only instantiation (GEN = false) carries no per-element pointers and needs far fewer registers.
+// Wavefronts per SIMD the register allocator is asked to fit (second __launch_bounds__ argument on AMD): three
+// workgroups per CU for the 64-accumulator tiles, four for the 32-accumulator ones; fewer where the gather state
+// of the observation modes (or the element-wise staging of GEN) would otherwise spill.
+constexpr int min_waves(int bm, int bn, int amode, int bmode, bool gen) {
+  const bool big = bm * bn >= 16384;
+  if (gen || amode == SRC_OBS || bmode == SRC_OBS) return 1;
+  if (amode == SRC_OBSN || bmode == SRC_OBSN) return big ? 2 : 3;
+  return big ? 3 : 4;
+}
+
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN>
+__global__ __launch_bounds__(256, min_waves(BM, BN, AMODE, BMODE, GEN)) void gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 wavefronts per workgroup");
   using SA = Stage<BM, AKM, AMODE>;
@@ -439,7 +451,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   SA sa;
   SB sb;
-  const bool va = g.vec_a != 0, vb = g.vec_b != 0;
+  const bool va = GEN ? g.vec_a != 0 : true, vb = GEN ? g.vec_b != 0 : true;
   sa.prepare(g.a, m0, g.M, kbeg, va);
   sb.prepare(g.b, n0, g.N, kbeg, vb);
   sa.load(g.a, m0, g.M, kbeg, kend, va);
@@ -474,32 +486,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // ---- epilogue: per 32x32 accumulator block, all loads batched ahead of the arithmetic and the stores ----------------
   float* out = g.o.out + (long)blockIdx.z * g.slab + (long)by * g.o.batch_stride;
   const float* bias = g.bias ? g.bias + (long)by * g.bias_batch : nullptr;
+  // Row addressing stays 32-bit: a 64-bit base per 32-row block plus element offsets (dense output), or offsets
+  // from the tensor base through the (image, line, pixel) map (callers keep mapped outputs below 2^32 elements).
+  const uint32_t ldo = (uint32_t)g.o.ldo, ldd = (uint32_t)g.ld_dact;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    long rbase[16], dbase[16];
-    bool rok[16];
+    const long row0 = m0 + wm * (TM * 32) + i * 32 + 4 * h;  // accumulator register r holds row0 + (r&3) + 8*(r>>2)
+    float* ob = out;
+    const float* db = g.dact_src;
+    uint32_t ro[16];
+    uint32_t okm = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const long row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      rok[r] = row < g.M;
-      const long rr = rok[r] ? row : 0;
+      const int cr = (r & 3) + 8 * (r >> 2);
+      const bool ok = row0 + cr < g.M;
+      okm |= (ok ? 1u : 0u) << r;
       if (g.o.rowmap) {
-        const uint32_t n = fdiv((uint32_t)rr, g.o.f_img);
-        const uint32_t rem = (uint32_t)rr - n * g.o.f_img.d;
+        const uint32_t rr = ok ? (uint32_t)(row0 + cr) : 0u;
+        const uint32_t n = fdiv(rr, g.o.f_img);
+        const uint32_t rem = rr - n * g.o.f_img.d;
         const uint32_t y = fdiv(rem, g.o.f_line);
         const uint32_t x = rem - y * g.o.f_line.d;
-        rbase[r] = (long)n * g.o.img_stride + (long)y * g.o.y_stride + (long)x * g.o.x_stride;
-        dbase[r] = rbase[r];
+        ro[r] = n * (uint32_t)g.o.img_stride + y * (uint32_t)g.o.y_stride + x * (uint32_t)g.o.x_stride;
       } else {
-        rbase[r] = rr * g.o.ldo;
-        dbase[r] = rr * g.ld_dact;
+        ro[r] = (uint32_t)cr * ldo;
       }
+    }
+    if (!g.o.rowmap) {
+      ob += row0 * g.o.ldo;
+      if (db) db += row0 * g.ld_dact;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const long col = n0 + wn * (TN * 32) + j * 32 + l31;
       const bool cok = col < g.N;
-      const long cc = cok ? col : 0;
+      const uint32_t cc = cok ? (uint32_t)col : 0u;
+      const uint32_t okj = cok ? okm : 0u;
       float v[16];
       const float bv = bias ? bias[cc] : 0.f;
 #pragma unroll
@@ -511,10 +533,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
       }
-      if (g.dact_src) {
+      if (db) {
         float yv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) yv[r] = (rok[r] && cok) ? g.dact_src[dbase[r] + cc] : 1.f;
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t o = g.o.rowmap ? ro[r] : (uint32_t)((r & 3) + 8 * (r >> 2)) * ldd;
+          yv[r] = ((okj >> r) & 1u) ? db[o + cc] : 1.f;
+        }
         if (g.dact == 1) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = yv[r] > 0.f ? v[r] : 0.f;
@@ -526,13 +551,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       if (g.accumulate) {
         float ov[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ov[r] = (rok[r] && cok) ? out[rbase[r] + cc] : 0.f;
+        for (int r = 0; r < 16; ++r) ov[r] = ((okj >> r) & 1u) ? ob[ro[r] + cc] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] += ov[r];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if (rok[r] && cok) out[rbase[r] + cc] = v[r];
+        if ((okj >> r) & 1u) ob[ro[r] + cc] = v[r];
     }
   }
 }
@@ -572,15 +597,16 @@ inline int plan_split(long K, int want, long* k_per_split) {
 }
 
 #ifdef __HIPCC__
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN = false>
 inline int launch(hipStream_t st, GemmArgs a, int batch, int nsplit) {
+  if (!GEN && !(a.vec_a && a.vec_b)) return -EINVAL;  // float4-only instantiation
   const long tiles_m = srl_ceil_div(a.M, BM);
   a.tiles_n = (int)srl_ceil_div(a.N, BN);
   a.nbatch = batch > 1 ? batch : 1;
   const long nblk = tiles_m * a.tiles_n * a.nbatch;
   if (nblk > 0x7fffffffL || nsplit > 65535) return -EINVAL;
   dim3 grid((unsigned)nblk, 1, (unsigned)nsplit);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, GEN>), grid, dim3(256), 0, st, a);
   return 0;
 }
 #endif
