@@ -5,27 +5,33 @@
 // wavefront supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; the 32x32 result sits in 16 accumulator
 // registers per lane with col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 //
-// A workgroup of 4 wavefronts (WM x WN) owns a BM x BN output tile and walks K in steps of BK = 32.  Both operand
-// tiles live "k-major" in LDS ([BK][BM+pad], [BK][BN+pad]) whatever their layout in memory, so the MFMA feed is one
+// A workgroup of 4 wavefronts (WM x WN) owns a BM x BN output tile and walks K in steps of BK = 16.  Both operand
+// tiles live "k-major" in LDS ([BK][BM+4], [BK][BN+4]) whatever their layout in memory, so the MFMA feed is one
 // conflict-free ds_read_b32 per operand per step.  What varies is how an operand is *staged*:
-//   orientation  k-contiguous (rows = output index; float4 along k, transposed on the LDS store, pitch BX+1)
-//                k-major      (rows = reduction index; float4 along the output index, ds_write_b128, pitch BX+4)
+//   orientation  k-contiguous (rows = output index; float4 along k, transposed on the LDS store)
+//                k-major      (rows = reduction index; float4 along the output index, ds_write_b128)
 //   source       SRC_PLAIN    a dense row-major matrix
 //                SRC_CONV     rows are convolution patches gathered on the fly from an NHWC activation
 //                SRC_DGRAD    rows are the output-gradient taps that reach one input pixel (zero where none)
 //                SRC_OBS      rows are patches of the NCHW uint8/float32 observation with the whole-observation
 //                             LayerNorm (and optionally its affine) applied in the load path
 // so a convolution never materialises its patch matrix (no im2col / col2im traffic).  Row / column indices are
-// split with precomputed multiply-shift divisors.  Global loads of tile t+1 are issued before the MFMAs of tile t
-// and written to LDS after them (register double buffering).
+// split with precomputed multiply-shift divisors.
+//
+// Pipeline (measured with scripts/mfma_peak.hip: a wavefront that leaves the MFMA stream to stage a tile idles
+// the matrix pipe, and co-resident workgroups run in phase, so they do not fill the gap for each other): LDS holds
+// two tiles; inside k-step t every wavefront issues half of its MFMAs, writes tile t+1 (already in registers) to
+// the other LDS buffer, issues the global loads of tile t+2, issues the other half of its MFMAs, and meets the
+// single barrier of the step.  No wavefront ever waits on "write LDS -> barrier -> read LDS" with nothing to do.
 #pragma once
 #include "srl_common.h"
+#include <type_traits>
 
 namespace srlgemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
+constexpr int BK = 16;
 enum { SRC_PLAIN = 0, SRC_CONV = 1, SRC_DGRAD = 2, SRC_OBS = 3, SRC_OBSN = 4 };  // OBSN: OBS without the affine
 constexpr bool is_obs(int m) { return m == SRC_OBS || m == SRC_OBSN; }
 
@@ -206,9 +212,13 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, uint32_t voff
 // row) decomposition per lane plus an add per quad.
 template <int BX, bool KMAJOR, int MODE>
 struct Stage {
-  static constexpr int LD = KMAJOR ? BX + 4 : BX + 1;  // LDS row pitch (floats)
-  static constexpr int NF = BX * BK / 256;             // floats per thread
-  static constexpr int NV = NF / 4;                    // float4 per thread
+  // LDS row pitch (floats): with 4 k-quads per row the transposed store of a wavefront hits banks x + 16*kq
+  // (2 lanes per bank, the minimum for 64 lanes), and ds_write_b128 rows stay 16-byte aligned
+  static constexpr int LD = BX + 4;
+  static constexpr int QUADS = BX * BK / 4;            // float4 per tile
+  static constexpr int NV = (QUADS + 255) / 256;       // float4 per thread
+  static constexpr int NF = NV * 4;                    // floats per thread
+  static constexpr bool PARTIAL = QUADS < NV * 256;    // narrow tiles: only threads with u < QUADS stage
   static constexpr int KQ = BK / 4;                    // quads per k-contiguous row
   static constexpr bool GATHER = MODE != SRC_PLAIN;
   float r[NF];
@@ -238,6 +248,7 @@ struct Stage {
         const int u = tid + q * 256;
         if (!KMAJOR) voff[q] = x0 + u / KQ < xn ? (uint32_t)(((u / KQ) * ld + (u % KQ) * 4) * 4) : kInvalidOff;
         else voff[q] = x0 + (u % (BX / 4)) * 4 < xn ? (uint32_t)(((u / (BX / 4)) * ld + (u % (BX / 4)) * 4) * 4) : kInvalidOff;
+        if (PARTIAL && u >= QUADS) voff[q] = kInvalidOff;
       }
       return;
     }
@@ -258,6 +269,7 @@ struct Stage {
         const ColInfo ci = col_info<MODE>(s, (uint32_t)(x < xn ? x : 0));
         voff[q] = x < xn ? (uint32_t)ci.off * esz : kInvalidOff;
       }
+      if (PARTIAL && u >= QUADS) voff[q] = kInvalidOff;
     }
   }
 
@@ -330,7 +342,8 @@ struct Stage {
     for (int q = 0; q < NF; ++q) {
       const int e = tid + q * 256;
       float v = 0.f;
-      if (!KMAJOR) {
+      if (PARTIAL && e >= BX * BK) {
+      } else if (!KMAJOR) {
         const long x = x0 + e / BK, k = k0 + e % BK;
         if (x < xn && k < kend) v = src[x * ld + k];
       } else {
@@ -375,6 +388,7 @@ struct Stage {
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int u = tid + q * 256;
+        if (PARTIAL && u >= QUADS) continue;
         if (!KMAJOR) {
           const int x = u / KQ, k = (u % KQ) * 4;
 #pragma unroll
@@ -388,6 +402,7 @@ struct Stage {
 #pragma unroll
       for (int q = 0; q < NF; ++q) {
         const int e = tid + q * 256;
+        if (PARTIAL && e >= BX * BK) continue;
         if (!KMAJOR) lds[(e % BK) * LD + e / BK] = r[q];
         else lds[(e / BX) * LD + e % BX] = r[q];
       }
@@ -413,9 +428,8 @@ __global__ __launch_bounds__(256, min_waves(BM, BN, AMODE, BMODE, GEN)) void gem
   static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 wavefronts per workgroup");
   using SA = Stage<BM, AKM, AMODE>;
   using SB = Stage<BN, BKM, BMODE>;
-  __shared__ __attribute__((aligned(16))) float lds[BK * SA::LD + BK * SB::LD + 8];
-  float* As = lds;
-  float* Bs = lds + ((BK * SA::LD + 3) & ~3);
+  constexpr int A_FLOATS = BK * SA::LD, TILE_FLOATS = BK * (SA::LD + SB::LD);  // multiples of 4: 16-byte aligned
+  __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
@@ -454,33 +468,59 @@ __global__ __launch_bounds__(256, min_waves(BM, BN, AMODE, BMODE, GEN)) void gem
   const bool va = GEN ? g.vec_a != 0 : true, vb = GEN ? g.vec_b != 0 : true;
   sa.prepare(g.a, m0, g.M, kbeg, va);
   sb.prepare(g.b, n0, g.N, kbeg, vb);
+  // prologue: tile 0 into LDS buffer 0, tile 1 into registers
   sa.load(g.a, m0, g.M, kbeg, kend, va);
   sb.load(g.b, n0, g.N, kbeg, kend, vb);
+  sa.store(lds, va, g.a);
+  sb.store(lds + A_FLOATS, vb, g.b);
+  __syncthreads();
+  if (kbeg + BK < kend) {
+    sa.load(g.a, m0, g.M, kbeg + BK, kend, va);
+    sb.load(g.b, n0, g.N, kbeg + BK, kend, vb);
+  }
 
-  for (long k0 = kbeg; k0 < kend; k0 += BK) {
-    __syncthreads();  // previous tile's LDS reads are done
-    sa.store(As, va, g.a);
-    sb.store(Bs, vb, g.b);
-    __syncthreads();
-    if (k0 + BK < kend) {  // prefetch the next tile; latency hides under the MFMAs below
-      sa.load(g.a, m0, g.M, k0 + BK, kend, va);
-      sb.load(g.b, n0, g.N, k0 + BK, kend, vb);
-    }
-    const float* ap = As + h * SA::LD + wm * (TM * 32) + l31;
-    const float* bp = Bs + h * SB::LD + wn * (TN * 32) + l31;
+  // one k-step on LDS buffer `cur` (compile-time): MFMAs, with the staging of the following tiles in the middle
+  auto kstep = [&](auto cur_c, long k0) {
+    constexpr int cur = decltype(cur_c)::value;
+    const float* ap = lds + cur * TILE_FLOATS + h * SA::LD + wm * (TM * 32) + l31;
+    const float* bp = lds + cur * TILE_FLOATS + A_FLOATS + h * SB::LD + wn * (TN * 32) + l31;
+    float* nxt = lds + (cur ^ 1) * TILE_FLOATS;
+    // operand registers are double-buffered: the LDS reads of step kk + 1 are in flight under the MFMAs of kk
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[TM], b[TN];
+      if (kk + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = ap[kk * 2 * SA::LD + i * 32];
+        for (int i = 0; i < TM; ++i) a[(kk + 1) & 1][i] = ap[(kk + 1) * 2 * SA::LD + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bp[kk * 2 * SB::LD + j * 32];
+        for (int j = 0; j < TN; ++j) b[(kk + 1) & 1][j] = bp[(kk + 1) * 2 * SB::LD + j * 32];
+      }
+      if (kk == BK / 4) {
+        if (k0 + BK < kend) {  // tile t+1: registers -> the other LDS buffer (its readers left at the last barrier)
+          sa.store(nxt, va, g.a);
+          sb.store(nxt + A_FLOATS, vb, g.b);
+        }
+        if (k0 + 2 * BK < kend) {  // tile t+2: global -> registers
+          sa.load(g.a, m0, g.M, k0 + 2 * BK, kend, va);
+          sb.load(g.b, n0, g.N, k0 + 2 * BK, kend, vb);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the order: prefetch / staging above, then this step's MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
     }
+    __syncthreads();  // tile t+1 is visible; everyone is done reading tile t
+  };
+  for (long k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+    kstep(std::integral_constant<int, 0>{}, k0);
+    if (k0 + BK < kend) kstep(std::integral_constant<int, 1>{}, k0 + BK);
   }
 
   // ---- epilogue: per 32x32 accumulator block, all loads batched ahead of the arithmetic and the stores ----------------
