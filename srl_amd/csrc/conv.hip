@@ -324,7 +324,15 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
   hipStream_t st = (hipStream_t)stream;
   DgradClass cls[64];
   const int nc = dgrad_classes(d, cls);
-  for (int i = 0; i < nc; ++i) {
+  // When every parity class has the same tap and row grids (stride divides the kernel and the image), the
+  // classes differ only in their weight block and in where their rows land: they run as the batch index of one
+  // launch (fastest-varying, so the workgroups that share rows of dz run together and hit L2).
+  bool uniform = nc > 1;
+  for (int i = 1; i < nc; ++i)
+    uniform = uniform && cls[i].th == cls[0].th && cls[i].tw == cls[0].tw && cls[i].ra == cls[0].ra &&
+              cls[i].rb == cls[0].rb;
+  uniform = uniform && cls[0].th * cls[0].tw > 0 && cls[0].ra > 0 && cls[0].rb > 0;
+  for (int i = 0; i < (uniform ? 1 : nc); ++i) {
     const DgradClass& c = cls[i];
     if (c.ra == 0 || c.rb == 0) continue;
     GemmArgs g{};
@@ -351,14 +359,20 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
     o.x_stride = (long)d->stride * d->Cin;
     g.o = o;
     if (x_act && dact) { g.dact_src = x_act + ((long)c.ph * d->W + c.pw) * d->Cin; g.dact = dact; }
+    int batch = 1;
+    if (uniform) {  // class (ph, pw) = batch index ph * stride + pw
+      batch = nc;
+      g.b.brw = 1; g.b.by_stride = (int)(g.K * d->Cin); g.b.bx_stride = 0;
+      g.o.brw = d->stride; g.o.batch_stride = (long)d->W * d->Cin; g.o.bx_stride = d->Cin;
+    }
     g.k_per_split = srl_ceil_div(g.K > 0 ? g.K : 1, BK) * BK;
     g.vec_a = 1; g.vec_b = 1;
     int rc;
     if (g.K == 0) {  // no tap reaches this class: gradient is zero there (k loop is empty, epilogue writes 0)
       rc = launch<256, 32, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);
-    } else if (d->Cin > 64) rc = launch<128, 128, 2, 2, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);
-    else if (d->Cin > 32) rc = launch<256, 64, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);
-    else rc = launch<256, 32, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);
+    } else if (d->Cin > 64) rc = launch<128, 128, 2, 2, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
+    else if (d->Cin > 32) rc = launch<256, 64, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
+    else rc = launch<256, 32, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
     SRL_CHECK_ARG(rc == 0, "grid too large");
   }
   SRL_LAUNCH_CHECK();

@@ -78,7 +78,9 @@ struct OutDesc {
   int rowmap;  // 0: out[row*ldo + col];  1: row -> (n,y,x) -> n*img + y*ys + x*xs + col
   FastDiv f_img, f_line;
   long img_stride, y_stride, x_stride;
-  long batch_stride;
+  long batch_stride;  // batch b: out += (b / brw) * batch_stride + (b % brw) * bx_stride  (brw 0: b * batch_stride)
+  int brw;
+  long bx_stride;
 };
 
 struct GemmArgs {
@@ -524,7 +526,10 @@ __global__ __launch_bounds__(256, min_waves(BM, BN, AMODE, BMODE, GEN)) void gem
   }
 
   // ---- epilogue: per 32x32 accumulator block, all loads batched ahead of the arithmetic and the stores ----------------
-  float* out = g.o.out + (long)blockIdx.z * g.slab + (long)by * g.o.batch_stride;
+  const long obatch = g.o.brw ? (long)(by / g.o.brw) * g.o.batch_stride + (long)(by % g.o.brw) * g.o.bx_stride
+                              : (long)by * g.o.batch_stride;
+  float* out = g.o.out + (long)blockIdx.z * g.slab + obatch;
+  if (g.o.rowmap && g.dact_src) g.dact_src += obatch;  // the activation shares the output's map
   const float* bias = g.bias ? g.bias + (long)by * g.bias_batch : nullptr;
   // Row addressing stays 32-bit: a 64-bit base per 32-row block plus element offsets (dense output), or offsets
   // from the tensor base through the (image, line, pixel) map (callers keep mapped outputs below 2^32 elements).
