@@ -34,6 +34,14 @@ __global__ __launch_bounds__(256, 4) void probe(float* out, const float* src, in
         *reinterpret_cast<float4*>(lds + (q >> 2) * 32 * 132 + (u / 32) * 132 + (u % 32) * 4) = r[q];
       }
     }
+    if (LEVEL == 7) {  // the same tile written as transposed scalars (k-contiguous operand): 32 ds_write_b32
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int u = tid + (q & 3) * 256, x = u / 8, k = (u % 8) * 4;
+        float* d = lds + (q >> 2) * 32 * 132 + k * 132 + x;
+        d[0] = r[q].x, d[132] = r[q].y, d[264] = r[q].z, d[396] = r[q].w;
+      }
+    }
     if (LEVEL >= 1) __syncthreads();
     if (LEVEL == 4) {
 #pragma unroll
@@ -96,5 +104,6 @@ int main() {
   run<4>(out, src, e0, e1);
   run<5>(out, src, e0, e1);
   run<6>(out, src, e0, e1);
+  run<7>(out, src, e0, e1);
   return 0;
 }
