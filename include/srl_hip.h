@@ -75,6 +75,32 @@ int srl_masked_normalize(void* stream, const float* x, const uint8_t* mask, int 
                          const double* stats, double eps, int unbiased, float* out);
 
 /* ------------------------------------------------------------------------------------------------
+ * PopArt value head: running statistics of the value targets and the two element-wise maps.
+ * Replaces: RunningMeanStd.update / mean_std / normalize / denormalize (modules/utils.py:104-156) and
+ *           PopArtValueHead.update (popart.py:42-51).
+ * rms: float64[2*vd + 1] = {mean[vd], mean_sq[vd], debiasing_term}, the reference's three nn.Parameters.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Per value column c: stats[3c..3c+2] = {sum mask, sum x*mask, sum (x*mask)^2} in float64
+ * (utils.py:113-120).  x float32[n, vd]; mask uint8[n] or NULL; mask_invert as in srl_masked_stats.
+ * Data-parallel callers all-reduce stats (one message instead of utils.py:121-124's three). */
+int srl_masked_stats_cols(void* stream, const float* x, const uint8_t* mask, int mask_invert, long n,
+                          int vd, double* stats);
+
+/* rms <- beta * rms + (1 - beta) * {s/n, q/n, 1} (utils.py:125-130).  rescale != 0 additionally rewrites
+ * the head so that its de-normalised output is unchanged: w[r,:] *= old_std/new_std,
+ * b = (old_std*b + old_mean - new_mean)/new_std (popart.py:49-51; the reference only does this after
+ * burn_in_updates, infinite by default).  w float32[vd, in_features], b float32[vd]. */
+int srl_popart_update(void* stream, const double* stats, double beta, double eps, int vd, double* rms,
+                      float* w, float* b, int in_features, int rescale);
+
+/* normalize != 0: out = float32(clip((x - mean)/std, -5, 5)) (utils.py:143-148); else out =
+ * float32(x*std + mean) (:150-155); mean = rms_mean/max(debias, eps), std = sqrt(max(E[x^2] - mean^2,
+ * 1e-2)) in float64 (:137-142).  x, out float32[n, vd]. */
+int srl_popart_map(void* stream, const float* x, long n, int vd, const double* rms, double eps,
+                   int normalize, float* out);
+
+/* ------------------------------------------------------------------------------------------------
  * PPO loss, forward + backward in one pass over the batch.
  * Replaces: MultiAgentPPO._compute_loss (mappo.py:146-217) + value-loss factories
  *           (modules/utils.py:228-265) + the autograd backward through them (mappo.py:274).

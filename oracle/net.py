@@ -47,7 +47,7 @@ class OracleActorCritic:
                  shared_backbone: bool = False,
                  continuous_action: bool = False,
                  **_ignored):
-        assert not popart, "oracle: PopArt head not restated yet (a 'next' row of SURVEY.md 8f)"
+        self.popart = popart
         assert not continuous_action, "oracle: continuous actions not restated yet"
         self.obs_dim = {"obs": obs_dim} if isinstance(obs_dim, int) else dict(obs_dim)
         if state_dim is not None and isinstance(state_dim, int):
@@ -64,8 +64,11 @@ class OracleActorCritic:
 
     # ------------------------------------------------------------------ parameters
     def load_state_dict(self, sd):
-        self.params = OrderedDict((k, torch.as_tensor(np.asarray(v)).clone().float().requires_grad_(True))
-                                  for k, v in sd.items())
+        # the running statistics of the PopArt head are float64 nn.Parameters without gradient (modules/utils.py:80-82)
+        self.params = OrderedDict()
+        for k, v in sd.items():
+            t = torch.as_tensor(np.asarray(v)).clone()
+            self.params[k] = t.double() if "_RunningMeanStd__" in k else t.float().requires_grad_(True)
 
     def state_dict(self):
         return OrderedDict((k, v.detach().clone()) for k, v in self.params.items())
@@ -161,8 +164,44 @@ class OracleActorCritic:
         logits = F.linear(a_feat, self._p("actor_head.weight"), self._p("actor_head.bias"))
         if "available_action" in obs:
             logits = logits.masked_fill(obs["available_action"] == 0, -1e10)  # actor_critic_policy.py:135-136
-        value = F.linear(c_feat, self._p("critic_head.weight"), self._p("critic_head.bias"))
+        head = "critic_head._PopArtValueHead__" if self.popart else "critic_head."  # popart.py:21-22,39-40
+        value = F.linear(c_feat, self._p(head + "weight"), self._p(head + "bias"))
         return logits, value, new_state
+
+    # ------------------------------------------------------------------ PopArt (popart.py:8-59, modules/utils.py:70-151)
+    POPART_BETA, POPART_EPS = 0.99999, 1e-5  # PopArtValueHead defaults; burn_in_updates = inf: never rescales
+
+    def _rms(self, n):
+        return self.params[f"critic_head._PopArtValueHead__rms._RunningMeanStd__{n}"]
+
+    @torch.no_grad()
+    def popart_mean_std(self):
+        deb = self._rms("debiasing_term").clamp(min=self.POPART_EPS)
+        mean = self._rms("mean") / deb
+        var = (self._rms("mean_sq") / deb - mean**2).clamp(min=1e-2)
+        return mean, var.sqrt()
+
+    @torch.no_grad()
+    def normalize_value(self, x):
+        mean, std = self.popart_mean_std()
+        return ((x.double() - mean) / std).clip(-5, 5).float()
+
+    @torch.no_grad()
+    def denormalize_value(self, x):
+        mean, std = self.popart_mean_std()
+        return (x.double() * std + mean).float()
+
+    @torch.no_grad()
+    def update_popart(self, x, mask):
+        x, mask = x.double(), mask.double()
+        x = x * mask
+        factor = mask.sum()
+        dims = tuple(range(x.dim() - 1))
+        bm, bsq = x.sum(dims) / factor, x.square().sum(dims) / factor
+        b = self.POPART_BETA
+        self._rms("mean")[:] = b * self._rms("mean") + bm * (1.0 - b)
+        self._rms("mean_sq")[:] = b * self._rms("mean_sq") + bsq * (1.0 - b)
+        self._rms("debiasing_term")[:] = b * self._rms("debiasing_term") + 1.0 - b
 
     def _heads(self, logits):
         out, start = [], 0

@@ -40,8 +40,10 @@ class OracleMappo:
         self.ppo_epochs = g("ppo_epochs", 1)
         self.value_loss = g("value_loss", "mse")
         self.value_loss_config = g("value_loss_config", {})
-        assert g("optimizer", "adam") == "adam" and not g("popart", False) and not self.vtrace
-        self.optimizer = torch.optim.Adam(net.parameters(), **g("optimizer_config", {}))
+        assert g("optimizer", "adam") == "adam"
+        self.popart = g("popart", False)
+        assert not g("normalize_old_value", False), "oracle: normalize_old_value not restated"
+        self.optimizer = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], **g("optimizer_config", {}))
         self.version = -1
         self.frames = 0
 
@@ -65,15 +67,26 @@ class OracleMappo:
         for _ in range(self.ppo_epochs):
             lp, value, ent, _ = self.net.analyze({k: v[:keep] for k, v in obs.items()}, action[:keep], on_reset[:keep],
                                                  None if pstate is None else [s[:keep] for s in pstate])
-            adv, ret = ogae.adv_and_value_target(reward.numpy(), old_value.numpy(), truncated.numpy(), done.numpy(),
-                                                 on_reset.numpy(), self.discount_rate, self.gae_lambda)
-            pad = lambda x: np.concatenate([x, np.zeros_like(x[:1])], 0)  # mappo.py:254-256
-            adv_p, ret_p = pad(adv), pad(ret)
-            out["adv"], out["ret"] = adv_p, ret_p
+            if "adv" not in out:  # computed in the first epoch only (mappo.py:247-257; matters with PopArt, whose
+                # statistics move between epochs)
+                trace_value = self.net.denormalize_value(old_value) if self.popart else old_value  # :120-124
+                kw = {}
+                if self.vtrace:  # :130-133 (bootstrap_steps == 1: the analysed rows are the rewarding rows)
+                    assert boot == 1, "oracle: V-trace restated for bootstrap_steps == 1 only"
+                    kw = dict(vtrace=True, imp_ratio=(lp - old_lp[:keep]).exp().detach().numpy())
+                adv, ret = ogae.adv_and_value_target(reward.numpy(), trace_value.numpy(), truncated.numpy(), done.numpy(),
+                                                     on_reset.numpy(), self.discount_rate, self.gae_lambda, **kw)
+                pad = lambda x: np.concatenate([x, np.zeros_like(x[:1])], 0)  # mappo.py:254-256
+                adv_p, ret_p = pad(adv), pad(ret)
+                out["adv"], out["ret"] = adv_p, ret_p
             lo, hi = burn, Tb - boot
             mask = 1 - on_reset[1 + lo:1 + hi]  # mappo.py:260-261
+            target = torch.from_numpy(ret_p[lo:hi])
+            if self.popart:  # mappo.py:263-264 then :173-176
+                self.net.update_popart(target, mask)
+                denorm_target, target = target, self.net.normalize_value(target)
             loss, stats = oppo.ppo_loss(lp[lo:hi], old_lp[lo:hi], value[lo:hi], old_value[lo:hi],
-                                        torch.from_numpy(adv_p[lo:hi]), torch.from_numpy(ret_p[lo:hi]), ent[lo:hi],
+                                        torch.from_numpy(adv_p[lo:hi]), target, ent[lo:hi],
                                         mask, eps_clip=self.eps_clip, dual_clip=self.dual_clip, c_clip=self.c_clip,
                                         value_loss=self.value_loss, value_loss_config=self.value_loss_config,
                                         clip_value=self.clip_value, value_eps_clip=self.value_eps_clip,
@@ -81,7 +94,9 @@ class OracleMappo:
                                         entropy_bonus_weight=self.entropy_bonus_weight)
             self.optimizer.zero_grad(set_to_none=True)
             loss.backward()
-            params = self.net.parameters()
+            if self.popart:
+                stats["denorm_value"] = torch.masked_select(denorm_target, mask.bool()).mean().item()
+            params = [p for p in self.net.parameters() if p.requires_grad]
             if self.max_grad_norm is not None:
                 gn = torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
             else:

@@ -87,6 +87,7 @@ class ActorCriticPolicy(policy_api.Policy):
         self._seed = int(seed)
         self._rollout_calls = 0
         self._distributed = False
+        self._popart_updates, self._popart_burn_in = 0, float("inf")  # PopArtValueHead defaults (popart.py:16,28-29)
         self.denormalize_value_during_rollout = kwargs.get("denormalize_value_during_rollout", False)
 
     # ------------------------------------------------------------------ bookkeeping (api/policy.py:205-288)
@@ -104,6 +105,45 @@ class ActorCriticPolicy(policy_api.Policy):
 
     def inc_version(self):
         self._version += 1
+
+    # ------------------------------------------------------------------ PopArt (actor_critic_policy.py:261-274)
+    @property
+    def popart_head(self):
+        if not self.spec.popart:
+            raise ValueError("Set popart=True in policy config to activate popart value head.")
+        return self._net.popart_state  # float64 [mean(vd), mean_sq(vd), debiasing_term]
+
+    def _popart_map(self, x, normalize):
+        rms = self.popart_head
+        xd = to_device_leaf(x, self.device, "real")
+        out = torch.empty_like(xd)
+        hip.popart_map(xd, rms, self.spec.value_dim, out, normalize, ns.POPART_EPS)
+        return out
+
+    def normalize_value(self, x):
+        return self._popart_map(x, True)
+
+    def denormalize_value(self, x):
+        return self._popart_map(x, False)
+
+    def update_popart(self, x, mask):
+        """x float32 [..., value_dim], mask uint8/float [..., 1] (1 = counted), as PopArtValueHead.update."""
+        vd = self.spec.value_dim
+        xd = to_device_leaf(x, self.device, "real").reshape(-1, vd)
+        md = None if mask is None else (to_device_leaf(mask, self.device, "real") != 0).to(torch.uint8).reshape(-1)
+        stats = torch.zeros((vd, 3), dtype=torch.float64, device=xd.device)
+        hip.masked_stats_cols(xd, md, stats, vd)
+        if dist.is_initialized() and self._distributed:
+            dist.all_reduce(stats)
+        self.update_popart_from_stats(stats)
+
+    def update_popart_from_stats(self, stats):
+        """stats float64 [value_dim, 3] = (sum mask, sum x*mask, sum (x*mask)^2), already all-reduced."""
+        self._popart_updates += 1
+        rescale = self._popart_updates > self._popart_burn_in  # popart.py:49 (burn_in_updates = inf: never)
+        net, head = self._net, self.spec.critic_head
+        hip.popart_update(stats, net.popart_state, self.spec.value_dim, ns.POPART_BETA, ns.POPART_EPS,
+                          net._p(f"{head.prefix}.weight"), net._p(f"{head.prefix}.bias"), head.in_features, rescale)
 
     def parameters(self):
         return [self._net.flat]

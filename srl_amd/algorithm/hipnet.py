@@ -69,6 +69,8 @@ class HipNet:
         dev = device if self.on_gpu else "cpu"
         self.flat = torch.zeros(spec.total_params, dtype=torch.float32, device=dev)
         self.grad = torch.zeros_like(self.flat)
+        # PopArt running statistics (float64: mean[vd], mean_sq[vd], debiasing_term[1]); empty without PopArt
+        self.popart_state = torch.zeros(2 * spec.value_dim + 1 if spec.popart else 0, dtype=torch.float64, device=dev)
         self.ws = Workspace(dev)
         self._tape = None
         # SRL_EXPLICIT_CONV=1 forces the im2col + GEMM + col2im fallback (kept for geometries the implicit
@@ -77,33 +79,46 @@ class HipNet:
         self.force_explicit_conv = os.environ.get("SRL_EXPLICIT_CONV", "0") == "1"
 
     # ------------------------------------------------------------------ parameters / checkpoints
+    def ref_names(self):
+        """The reference's state_dict keys of the float32 parameters, in order."""
+        return [info.key for info in self.spec.params.values()]
+
     def load_reference_state(self, state: Dict[str, torch.Tensor]):
-        missing = [k for k in self.spec.params if k not in state]
-        extra = [k for k in state if k not in self.spec.params]
+        want = self.ref_names() + (list(ns.POPART_KEYS) if self.spec.popart else [])
+        missing = [k for k in want if k not in state]
+        extra = [k for k in state if k not in want]
         if missing or extra:
             raise KeyError(f"state_dict mismatch: missing {missing}, unexpected {extra}")
         host = torch.zeros(self.spec.total_params, dtype=torch.float32)
-        for name, info in self.spec.params.items():
-            t = torch.as_tensor(state[name]).detach().cpu()
+        for info in self.spec.params.values():
+            t = torch.as_tensor(state[info.key]).detach().cpu()
             if tuple(t.shape) != info.ref_shape:
-                raise ValueError(f"{name}: shape {tuple(t.shape)} != {info.ref_shape}")
+                raise ValueError(f"{info.key}: shape {tuple(t.shape)} != {info.ref_shape}")
             host[info.offset:info.offset + info.numel] = info.to_internal(t)
         self.flat.copy_(host)
+        if self.spec.popart:  # [mean(vd), mean_sq(vd), debiasing_term(1)] float64
+            rms = torch.cat([torch.as_tensor(state[k]).detach().cpu().double().reshape(-1) for k in ns.POPART_KEYS])
+            self.popart_state.copy_(rms)
 
     def reference_state(self) -> "OrderedDict[str, torch.Tensor]":
         host = self.flat.detach().cpu()
-        return OrderedDict((name, info.to_reference(host[info.offset:info.offset + info.numel]))
-                           for name, info in self.spec.params.items())
+        out = OrderedDict((info.key, info.to_reference(host[info.offset:info.offset + info.numel]))
+                          for info in self.spec.params.values())
+        if self.spec.popart:
+            rms, vd = self.popart_state.detach().cpu(), self.spec.value_dim
+            out[ns.POPART_KEYS[0]], out[ns.POPART_KEYS[1]] = rms[:vd].clone(), rms[vd:2 * vd].clone()
+            out[ns.POPART_KEYS[2]] = rms[2 * vd:].clone()
+        return out
 
     def flat_to_reference(self, flat_host: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
         """Split any flat buffer with the parameter layout (gradients, Adam moments) into named tensors."""
-        return OrderedDict((name, info.to_reference(flat_host[info.offset:info.offset + info.numel]))
-                           for name, info in self.spec.params.items())
+        return OrderedDict((info.key, info.to_reference(flat_host[info.offset:info.offset + info.numel]))
+                           for info in self.spec.params.values())
 
     def reference_to_flat(self, named: Dict[str, torch.Tensor]) -> torch.Tensor:
         host = torch.zeros(self.spec.total_params, dtype=torch.float32)
-        for name, info in self.spec.params.items():
-            host[info.offset:info.offset + info.numel] = info.to_internal(torch.as_tensor(named[name]).cpu())
+        for info in self.spec.params.values():
+            host[info.offset:info.offset + info.numel] = info.to_internal(torch.as_tensor(named[info.key]).cpu())
         return host
 
     def _p(self, name):

@@ -30,6 +30,7 @@ import torch
 import torch.distributed as dist
 
 from srl_amd import hip
+from srl_amd.algorithm import netspec as ns
 from srl_amd.algorithm.actor_critic import ActorCriticPolicy, to_device_leaf
 from srl_amd.api.trainer import PytorchTrainer, TrainerStepResult, register
 from srl_amd.namedarray import recursive_apply
@@ -69,11 +70,10 @@ class MultiAgentPPO(PytorchTrainer):
         self.popart = g('popart', False)
         self.bootstrap_steps = g("bootstrap_steps", 1)
         self.ppo_epochs = g("ppo_epochs", 1)
-        if self.popart:
-            raise NotImplementedError("PopArt is a 'next' row (SURVEY.md 8f-2), not on the HIP path yet")
-        if self.vtrace:
-            raise NotImplementedError("V-trace through the trainer is a 'next' row (SURVEY.md 8f-4); the scan kernel "
-                                      "itself supports it (srl_gae_scan imp_ratio)")
+        if self.popart and not policy.net.spec.popart:
+            raise ValueError("Set popart=True in policy config to activate popart value head.")  # actor_critic_policy.py:264
+        if self.vtrace and self.bootstrap_steps != 1:
+            raise NotImplementedError("V-trace with bootstrap_steps != 1 is not on the HIP path")
         if self.burn_in_steps:
             raise NotImplementedError("burn-in only matters for recurrent policies, not on the HIP path yet")
 
@@ -114,7 +114,7 @@ class MultiAgentPPO(PytorchTrainer):
     def get_checkpoint(self):
         ckpt = self.policy.get_checkpoint()
         net = self.policy.net
-        names = list(net.spec.params)
+        names = net.ref_names()
         m = net.flat_to_reference(self._m.detach().cpu())
         v = net.flat_to_reference(self._v.detach().cpu())
         state = {
@@ -123,7 +123,8 @@ class MultiAgentPPO(PytorchTrainer):
         } if self._opt_steps > 0 else {}
         group = dict(lr=self._lr, betas=self._betas, eps=self._eps, weight_decay=self._weight_decay, amsgrad=False,
                      maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
-                     params=list(range(len(names))))
+                     # the PopArt statistics are gradient-less nn.Parameters of the reference: listed, stateless
+                     params=list(range(len(names) + (3 if net.spec.popart else 0))))
         ckpt.update({"optimizer_state_dict": {"state": state, "param_groups": [group]}})
         return ckpt
 
@@ -131,7 +132,7 @@ class MultiAgentPPO(PytorchTrainer):
         osd = checkpoint.get("optimizer_state_dict")
         if osd is not None:
             net = self.policy.net
-            names = list(net.spec.params)
+            names = net.ref_names()
             st = osd["state"]
             if st:
                 self._m.copy_(net.reference_to_flat({n: st[i]["exp_avg"] for i, n in enumerate(names)}))
@@ -150,6 +151,23 @@ class MultiAgentPPO(PytorchTrainer):
         super().distributed(rank=rank, world_size=world_size, init_method=init_method, **kwargs)
         self._world = dist.get_world_size() if dist.is_initialized() else 1
         self._dist = dist.is_initialized()  # collectives run whenever a group exists (also with one rank)
+
+    def _importance_ratio(self, net, obs, avail, action, old_lp, rows, B):
+        """exp(new_lp - old_lp) on rows [0, rows) of the sample, forward only, row-chunked; [rows, B, 1] float32."""
+        n_all = rows * B
+        flat = lambda t: t[:rows].reshape(n_all, *t.shape[2:])
+        f_obs = {k: flat(v) for k, v in obs.items()}
+        f_avail = None if avail is None else flat(avail)
+        f_action = flat(action)
+        new_lp = torch.empty(n_all, dtype=torch.float32, device=old_lp.device)
+        for r0 in range(0, n_all, self.chunk_rows):
+            r1 = min(n_all, r0 + self.chunk_rows)
+            n = r1 - r0
+            logits, _ = net.forward({k: v[r0:r1] for k, v in f_obs.items()}, n, keep_tape=False)
+            ent = net.ws.get("entropy", n)[:n]
+            hip.categorical_fwd(logits, f_action[r0:r1], None if f_avail is None else f_avail[r0:r1], net.spec.act_dims,
+                                new_lp[r0:r1], ent)
+        return torch.exp(new_lp - flat(old_lp).reshape(-1)).reshape(rows, B, 1)
 
     # ------------------------------------------------------------------ the step (mappo.py:219-328)
     def step(self, sample):
@@ -199,8 +217,13 @@ class MultiAgentPPO(PytorchTrainer):
                     adv_d = torch.zeros((Tb, B, Nc), dtype=torch.float32, device=dev)  # last row = the zero pad (:254-256)
                     ret_d = torch.zeros((Tb, B, Nc), dtype=torch.float32, device=dev)
                     fused_stats = boot == 1 and burn == 0
-                    hip.gae_scan(reward, old_value, done, truncated, on_reset, self.discount_rate, self.gae_lambda, adv_d,
-                                 ret_d, stats=stats_local if fused_stats else None)
+                    # PopArt: the stored values are normalised; the trace runs on de-normalised ones (mappo.py:120-124)
+                    trace_value = self.policy.denormalize_value(old_value) if self.popart else old_value
+                    ratio = None
+                    if self.vtrace:  # importance ratio of the CURRENT parameters on every rewarding step (:130-133)
+                        ratio = self._importance_ratio(net, obs, avail, action, old_lp, Tb - 1, B)
+                    hip.gae_scan(reward, trace_value, done, truncated, on_reset, self.discount_rate, self.gae_lambda,
+                                 adv_d, ret_d, stats=stats_local if fused_stats else None, imp_ratio=ratio)
                 mask_rows = on_reset[1 + lo:1 + hi]  # loss_mask = 1 - on_reset[1+burn : 1+Tb-boot]  (:260-261)
                 if not fused_stats:
                     hip.masked_stats(adv_d[lo:hi], mask_rows, stats_local, mask_invert=True)
@@ -209,13 +232,26 @@ class MultiAgentPPO(PytorchTrainer):
                     dist.all_reduce(stats_global)  # one 24-byte message instead of three
                 local_n = stats_local[0:1]
 
+            flat = lambda t: t[lo:hi].reshape(n_valid, *t.shape[2:])
+            # ---- PopArt: statistics of the value targets, then the loss sees normalised targets (:263-264, :173-176) ----
+            loss_ret, pstats_local = ret_d, None
+            if self.popart:
+                pstats_local = torch.zeros((Nc, 3), **f64)
+                hip.masked_stats_cols(flat(ret_d), on_reset[1 + lo:1 + hi], pstats_local, Nc, mask_invert=True)
+                pstats = pstats_local.clone()
+                if self._dist:
+                    dist.all_reduce(pstats)  # one message instead of utils.py:121-124's three
+                self.policy.update_popart_from_stats(pstats)
+                loss_ret = torch.empty_like(ret_d)
+                hip.popart_map(ret_d, net.popart_state, Nc, loss_ret, True, ns.POPART_EPS)
+            loss_oldv = self.policy.normalize_value(old_value) if self.normalize_old_value else old_value  # :151-152
+
             # ---- forward / loss / backward over row chunks -----------------------------------------------------------
             net.zero_grad()
-            flat = lambda t: t[lo:hi].reshape(n_valid, *t.shape[2:])
             f_obs = {k: flat(v) for k, v in obs.items()}
             f_avail = None if avail is None else flat(avail)
-            f_action, f_oldlp, f_oldv = flat(action), flat(old_lp).reshape(-1), flat(old_value).reshape(-1)
-            f_adv, f_ret, f_mask = flat(adv_d).reshape(-1), flat(ret_d).reshape(-1), mask_rows.reshape(-1)
+            f_action, f_oldlp, f_oldv = flat(action), flat(old_lp).reshape(-1), flat(loss_oldv).reshape(-1)
+            f_adv, f_ret, f_mask = flat(adv_d).reshape(-1), flat(loss_ret).reshape(-1), mask_rows.reshape(-1)
             f_done, f_trunc = flat(done).reshape(-1), flat(truncated).reshape(-1)
             nchunks = max(1, -(-n_valid // self.chunk_rows))
             terms = torch.zeros((nchunks, hip.LT_COUNT), **f64)
@@ -255,8 +291,11 @@ class MultiAgentPPO(PytorchTrainer):
                 have_adv = False
 
             # ---- statistics: the only device->host synchronisation of the epoch ----------------------------------------
-            host = torch.cat([terms.sum(0), gnorm.double()]).cpu().numpy()
+            extra = [] if pstats_local is None else [pstats_local[0, :2]]
+            host = torch.cat([terms.sum(0), gnorm.double()] + extra).cpu().numpy()
             msum = max(host[hip.LT_MASK], 1e-30)
+            if pstats_local is not None:  # PPOStepResult.denorm_value: masked mean of the de-normalised targets (:215)
+                train_stats["denorm_value"] += host[hip.LT_COUNT + 2] / max(host[hip.LT_COUNT + 1], 1e-30)
             for key, slot in _STAT_TERMS:
                 train_stats[key] += host[slot] / msum
             train_stats["done"] += host[hip.LT_DONE] / max(n_valid, 1)

@@ -34,6 +34,11 @@ class ParamInfo:
     layout: str = "plain"  # plain | conv_nhwc | fc_from_chw | conv_s2d | ln_s2d
     chw: Optional[Tuple[int, int, int]] = None  # for fc_from_chw
     s2d: int = 0  # block size of the space-to-depth layouts
+    ref_name: str = ""  # the reference's state_dict key when it differs from ``name`` (PopArt head)
+
+    @property
+    def key(self):
+        return self.ref_name or self.name
 
     @property
     def numel(self):
@@ -133,6 +138,15 @@ class NetSpec:
     shared_backbone: bool
     params: "OrderedDict[str, ParamInfo]"
     total_params: int
+    popart: bool = False  # critic head is a PopArtValueHead: float64 running statistics ride along (POPART_KEYS)
+
+
+# state_dict keys of the PopArt head (popart.py:21-22,30-31; modules/utils.py:80-82), in the reference's order
+POPART_W = "critic_head._PopArtValueHead__weight"
+POPART_B = "critic_head._PopArtValueHead__bias"
+_RMS = "critic_head._PopArtValueHead__rms._RunningMeanStd__"
+POPART_KEYS = (_RMS + "mean", _RMS + "mean_sq", _RMS + "debiasing_term")
+POPART_BETA, POPART_EPS = 0.99999, 1e-5  # PopArtValueHead defaults (the policy never overrides them)
 
 
 def _allow_s2d():
@@ -154,10 +168,10 @@ class _Builder:
         if self.init:
             torch.manual_seed(seed)
 
-    def _add(self, name, shape, value=None, layout="plain", chw=None, s2d=0):
-        self.params[name] = ParamInfo(name, tuple(shape), layout=layout, chw=chw, s2d=s2d)
+    def _add(self, name, shape, value=None, layout="plain", chw=None, s2d=0, ref_name=""):
+        self.params[name] = ParamInfo(name, tuple(shape), layout=layout, chw=chw, s2d=s2d, ref_name=ref_name)
         if self.init:
-            self.values[name] = value
+            self.values[ref_name or name] = value
 
     # default resets of nn.Linear / nn.Conv2d (torch/nn/modules/linear.py, conv.py)
     def _default_wb(self, wshape):
@@ -177,10 +191,10 @@ class _Builder:
         self._add(f"{prefix}.weight", shape, torch.ones(shape) if self.init else None, lay, s2d=s2d)
         self._add(f"{prefix}.bias", shape, torch.zeros(shape) if self.init else None, lay, s2d=s2d)
 
-    def linear(self, prefix, fin, fout, layout="plain", chw=None):
+    def linear(self, prefix, fin, fout, layout="plain", chw=None, ref_names=("", "")):
         w, b = self._default_wb((fout, fin))
-        self._add(f"{prefix}.weight", (fout, fin), w, layout, chw)
-        self._add(f"{prefix}.bias", (fout,), b)
+        self._add(f"{prefix}.weight", (fout, fin), w, layout, chw, ref_name=ref_names[0])
+        self._add(f"{prefix}.bias", (fout,), b, ref_name=ref_names[1])
 
     def conv(self, prefix, cin, cout, k, layout, s2d=0):
         w, b = self._default_wb((cout, cin, k, k))
@@ -189,11 +203,11 @@ class _Builder:
 
     def orthogonal(self, name, gain):
         if self.init:
-            torch.nn.init.orthogonal_(self.values[name], gain=gain)
+            torch.nn.init.orthogonal_(self.values[self.params[name].key], gain=gain)
 
     def zero(self, name):
         if self.init:
-            self.values[name].zero_()
+            self.values[self.params[name].key].zero_()
 
 
 def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, act_name: str, cnn_layers: Dict):
@@ -286,8 +300,6 @@ def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim
     layout) when ``seed`` is given, else ``None``."""
     if num_rnn_layers:
         raise NotImplementedError("recurrent backbones are a 'next' row (SURVEY.md 8f-2), not on the HIP path yet")
-    if popart:
-        raise NotImplementedError("PopArt value head is a 'next' row (SURVEY.md 8f-2), not on the HIP path yet")
     if continuous_action or auxiliary_head:
         raise NotImplementedError("continuous actions / auxiliary value head are not on the HIP path")
     if use_maxpool and any(use_maxpool.values()):
@@ -308,13 +320,13 @@ def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim
         torch.set_num_threads(1)
     try:
         return _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation,
-                      layernorm, shared_backbone, seed)
+                      layernorm, shared_backbone, seed, popart)
     finally:
         torch.set_num_threads(threads)
 
 
 def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation, layernorm,
-           shared_backbone, seed):
+           shared_backbone, seed, popart=False):
     b = _Builder(seed)
     obs_enc = _build_encoders(b, "obs_modules_dict", obs_dims, hidden_dim, act, activation, cnn_layers)
     actor_bb = _build_backbone(b, "actor_backbone", hidden_dim * len(obs_dims), hidden_dim, num_dense_layers, act,
@@ -328,9 +340,18 @@ def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num
     b.linear("actor_head", hidden_dim, sum(act_dims))
     b.orthogonal("actor_head.weight", 0.01)  # actor_critic_policy.py:109-112
     b.zero("actor_head.bias")
-    b.linear("critic_head", hidden_dim, value_dim)
-    b.orthogonal("critic_head.weight", 0.01)
-    b.zero("critic_head.bias")
+    if popart:
+        # PopArtValueHead (popart.py:19-26): the nn.Linear default reset, no orthogonal re-initialisation; the same
+        # linear map on the device, only its state_dict keys and the float64 running statistics differ
+        b.linear("critic_head", hidden_dim, value_dim, ref_names=(POPART_W, POPART_B))
+        if b.init:
+            b.values[POPART_KEYS[0]] = torch.zeros(value_dim, dtype=torch.float64)
+            b.values[POPART_KEYS[1]] = torch.zeros(value_dim, dtype=torch.float64)
+            b.values[POPART_KEYS[2]] = torch.zeros(1, dtype=torch.float64)
+    else:
+        b.linear("critic_head", hidden_dim, value_dim)
+        b.orthogonal("critic_head.weight", 0.01)
+        b.zero("critic_head.bias")
 
     off = 0
     for info in b.params.values():
@@ -338,5 +359,5 @@ def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num
         off += (info.numel + 3) // 4 * 4  # 16-byte aligned starts (float4 staging in the GEMM)
     spec = NetSpec(obs_enc, actor_bb, state_enc, critic_bb, LinearSpec("actor_head", hidden_dim, sum(act_dims), 0),
                    LinearSpec("critic_head", hidden_dim, value_dim, 0), act_dims, hidden_dim, value_dim, shared_backbone,
-                   b.params, off)
+                   b.params, off, popart)
     return spec, (b.values if b.init else None)

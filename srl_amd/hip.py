@@ -72,6 +72,10 @@ _SIGNATURES = {
     "srl_masked_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "srl_masked_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_double, c_int,
                                       c_void_p]),
+    "srl_masked_stats_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
+    "srl_popart_update": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_int]),
+    "srl_popart_map": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_double, c_int, c_void_p]),
     "srl_ppo_loss_fwd_bwd": (c_int, [c_void_p] + [c_void_p] * 8 + [c_long, POINTER(PpoHparams)] + [c_void_p] * 8),
     "srl_categorical_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, POINTER(c_int32),
                                      c_void_p, c_void_p]),
@@ -234,6 +238,28 @@ def masked_normalize(x, mask, stats, out, mask_invert=False, eps=1e-5, unbiased=
         lib().srl_masked_normalize(_stream(), _ptr(x, torch.float32, "x"), _ptr(mask, torch.uint8, "mask"),
                                    int(mask_invert), x.numel(), _ptr(stats, torch.float64, "stats"), float(eps),
                                    int(unbiased), _ptr(out, torch.float32, "out")), "srl_masked_normalize")
+
+
+def masked_stats_cols(x, mask, stats, vd, mask_invert=False):
+    """x float32 [n, vd] -> stats float64 [vd, 3] = per column {sum mask, sum x*mask, sum (x*mask)^2}."""
+    _check(
+        lib().srl_masked_stats_cols(_stream(), _ptr(x, torch.float32, "x"), _ptr(mask, torch.uint8, "mask"),
+                                    int(mask_invert), x.numel() // vd, int(vd), _ptr(stats, torch.float64, "stats")),
+        "srl_masked_stats_cols")
+
+
+def popart_update(stats, rms, vd, beta, eps, w_ptr=None, b_ptr=None, in_features=0, rescale=False):
+    _check(
+        lib().srl_popart_update(_stream(), _ptr(stats, torch.float64, "stats"), float(beta), float(eps), int(vd),
+                                _ptr(rms, torch.float64, "rms"), w_ptr, b_ptr, int(in_features), int(rescale)),
+        "srl_popart_update")
+
+
+def popart_map(x, rms, vd, out, normalize, eps):
+    _check(
+        lib().srl_popart_map(_stream(), _ptr(x, torch.float32, "x"), x.numel() // vd, int(vd),
+                             _ptr(rms, torch.float64, "rms"), float(eps), int(normalize), _ptr(out, torch.float32, "out")),
+        "srl_popart_map")
 
 
 def ppo_loss_fwd_bwd(new_lp, old_lp, value, old_value, adv, ret, entropy, mask, hp: PpoHparams, norm_stats, local_n,

@@ -43,11 +43,12 @@ def make_sample_arrays(seed: int,
                        p_done: float = 0.05,
                        bootstrap_steps: int = 1,
                        value_dim: int = 1,
-                       available_action: bool = False) -> Dict[str, np.ndarray]:
+                       available_action: bool = False,
+                       p_trunc: Optional[float] = None) -> Dict[str, np.ndarray]:
     """Flat ``{dotted.key: array}`` dict of one synthetic sample; wrap with ``to_sample_batch``."""
     rng = np.random.Generator(np.random.PCG64(seed))
     Tb = T + bootstrap_steps
-    done, truncated, on_reset = make_flags(rng, Tb, B, p_done)
+    done, truncated, on_reset = make_flags(rng, Tb, B, p_done, p_trunc)
     value = (rng.standard_normal((Tb, B, value_dim)) * (1 - done)).astype(np.float32)
     reward = rng.standard_normal((Tb, B, value_dim)).astype(np.float32)
     reward[:-1] *= (1 - on_reset[1:])

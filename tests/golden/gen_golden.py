@@ -154,8 +154,14 @@ def gen_norm():
 
 # ------------------------------------------------------------------------------------------------ G4
 def make_ref_trainer(policy_args, trainer_args):
-    return api.trainer.make(api.config.Trainer("mappo", args=trainer_args),
-                            api.config.Policy("actor-critic", args=policy_args))
+    trainer = api.trainer.make(api.config.Trainer("mappo", args=trainer_args),
+                               api.config.Policy("actor-critic", args=policy_args))
+    if policy_args.get("popart"):
+        # harness shim: `popart_head` reads `self.net.module` (actor_critic_policy.py:265), which only exists once
+        # DistributedDataParallel wraps the net; single-process, give the bare net a plain `module` attribute
+        # (object.__setattr__: not registered as a sub-module, so state_dict / parameters are unchanged)
+        object.__setattr__(trainer.policy.net, "module", trainer.policy.net)
+    return trainer
 
 
 C1_POLICY = dict(obs_dim=4, action_dim=2, hidden_dim=64, num_dense_layers=2, num_rnn_layers=0, popart=False,
@@ -266,8 +272,12 @@ def run_steps(tag, policy_args, trainer_args, sample_kw, n_steps, store_state="f
         for k in ("policy_loss", "value_loss", "entropy", "grad_norm", "clip_ratio", "importance_weight", "advantage",
                   "value_targets", "done", "truncated"):
             assert abs(o_stats[k] - stats[k]) <= 2e-5 * max(1.0, abs(stats[k])), (tag, step, k, o_stats[k], stats[k])
-        assert np.array_equal(o_out["adv"], sample.analyzed_result.adv)
-        assert np.array_equal(o_out["ret"], sample.analyzed_result.ret)
+        if trainer_args.get("vtrace"):  # the ratio comes out of the network: equal to float32 rounding, not bitwise
+            assert np.allclose(o_out["adv"], sample.analyzed_result.adv, rtol=1e-5, atol=1e-6)
+            assert np.allclose(o_out["ret"], sample.analyzed_result.ret, rtol=1e-5, atol=1e-6)
+        else:
+            assert np.array_equal(o_out["adv"], sample.analyzed_result.adv)
+            assert np.array_equal(o_out["ret"], sample.analyzed_result.ret)
         stat_keys = sorted(stats)
         out[f"{tag}_step{step}_stats"] = np.array([stats[k] for k in stat_keys], dtype=np.float64)
         if step == 0:
@@ -320,6 +330,27 @@ def gen_steps():
     cnn_sample = dict(T=4, B=3, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.1)
     out = run_steps("cnn", cnn_policy, atari_trainer, cnn_sample, 2, store_state="sampled")
     save("steps_cnn.npz", **out)
+
+
+def gen_popart():
+    """PopArt value head (the reference policy's default) and V-trace through the trainer: full steps."""
+    c1_sample = dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05)
+    out = {}
+    pa_policy = dict(C1_POLICY, popart=True, seed=7)
+    run_steps("pa", pa_policy, dict(popart=True, optimizer_config=dict(lr=3e-4)), c1_sample, 3, out=out)
+    # shared backbone + layernorm, Atari-style loss (huber, clipped value), two epochs
+    pa2_policy = dict(C1_POLICY, popart=True, layernorm=True, shared_backbone=True, seed=8)
+    run_steps("pa2", pa2_policy, dict(popart=True, clip_value=True, dual_clip=False, value_loss='huber',
+                                     value_loss_config=dict(delta=10.0), value_loss_weight=1.0, ppo_epochs=2,
+                                     optimizer_config=dict(lr=5e-4), max_grad_norm=40.0), c1_sample, 2, out=out)
+    # V-trace (no PopArt), and both together.  No truncated steps in these samples: one of the reference's debug
+    # assertions (gae.py:72, stripped by the launcher's `python -O`) does not hold for truncations under V-trace.
+    vt_sample = dict(c1_sample, p_trunc=0.0)
+    run_steps("vt", dict(C1_POLICY, seed=9), dict(popart=False, vtrace=True, optimizer_config=dict(lr=3e-4)), vt_sample, 2,
+              out=out)
+    run_steps("vtpa", dict(C1_POLICY, popart=True, seed=10), dict(popart=True, vtrace=True, max_grad_norm=10.0,
+                                                                 optimizer_config=dict(lr=1e-3)), vt_sample, 2, out=out)
+    save("steps_popart.npz", **out)
 
 
 def gen_rollout():

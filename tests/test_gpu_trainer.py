@@ -40,6 +40,20 @@ CASES = {
               "steps_mlp.npz"),
     "cnn": (CNN_POLICY, ATARI_TRAINER, dict(T=4, B=3, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.1), 2,
             "steps_cnn.npz"),
+    # PopArt value head (the reference policy's default) and V-trace through the trainer (gen_golden.py gen_popart)
+    "pa": (dict(C1_POLICY, popart=True, seed=7), dict(popart=True, optimizer_config=dict(lr=3e-4)),
+           dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05), 3, "steps_popart.npz"),
+    "pa2": (dict(C1_POLICY, popart=True, layernorm=True, shared_backbone=True, seed=8),
+            dict(popart=True, clip_value=True, dual_clip=False, value_loss='huber', value_loss_config=dict(delta=10.0),
+                 value_loss_weight=1.0, ppo_epochs=2, optimizer_config=dict(lr=5e-4), max_grad_norm=40.0),
+            dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05), 2, "steps_popart.npz"),
+    "vt": (dict(C1_POLICY, seed=9), dict(popart=False, vtrace=True, optimizer_config=dict(lr=3e-4)),
+           dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05, p_trunc=0.0), 2,
+           "steps_popart.npz"),
+    "vtpa": (dict(C1_POLICY, popart=True, seed=10),
+             dict(popart=True, vtrace=True, max_grad_norm=10.0, optimizer_config=dict(lr=1e-3)),
+             dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05, p_trunc=0.0), 2,
+             "steps_popart.npz"),
 }
 
 
@@ -73,6 +87,8 @@ def test_step_matches_reference_golden(tag, golden):
                   "done", "truncated", "grad_norm", "frames"):
             tol = 1e-5 if k in ("policy_loss", "value_loss", "entropy", "value_targets") else 1e-4
             assert abs(res.stats[k] - ref[k]) <= tol * max(abs(ref[k]), 1e-2), (tag, step, k, res.stats[k], ref[k])
+        if "denorm_value" in ref:  # PopArt: masked mean of the de-normalised value targets
+            assert abs(res.stats["denorm_value"] - ref["denorm_value"]) <= 1e-5 * max(abs(ref["denorm_value"]), 1e-2)
         if step == 0:  # GAE returns written back into the sample: 1e-5 relative (BASELINE.json)
             assert close(sample.analyzed_result.adv, g[f"{tag}_step0_adv"], 1e-5)
             assert close(sample.analyzed_result.ret, g[f"{tag}_step0_ret"], 1e-5)
@@ -88,6 +104,8 @@ def test_step_matches_reference_golden(tag, golden):
                     continue
                 # parameters after Adam steps: each step moves a weight by ~lr, so compare at a few % of lr
                 assert np.abs(got - g[key]).max() <= 2e-5, (tag, step, key, np.abs(got - g[key]).max())
+                if "_RunningMeanStd__" in key:  # float64 PopArt statistics: EMA of float64 masked sums
+                    assert got.dtype == np.float64 and np.allclose(got, g[key], rtol=1e-6, atol=1e-13), (tag, step, key)
     assert trainer.policy.version == int(g[f"{tag}_version"])
     assert res.step == trainer.policy.version
 

@@ -59,9 +59,24 @@ def test_product_path_fails_loudly_without_gpu():
 
 def test_unsupported_configs_raise():
     base = dict(obs_dim=4, action_dim=2, num_rnn_layers=0, popart=False)
-    for bad in (dict(num_rnn_layers=1), dict(popart=True), dict(continuous_action=True), dict(obs_dim={"o": (3, 10)})):
+    for bad in (dict(num_rnn_layers=1), dict(continuous_action=True), dict(obs_dim={"o": (3, 10)})):
         with pytest.raises((NotImplementedError, AttributeError)):
             policy_api.make(config.Policy("actor-critic", args={**base, **bad}))
+
+
+def test_popart_param_table_and_init(golden):
+    """PopArt head: the reference's state_dict keys (name-mangled parameters + float64 running statistics), the
+    nn.Linear default reset instead of the orthogonal one, same seed -> same initial weights."""
+    g = golden("steps_popart.npz")
+    c1 = dict(obs_dim=4, action_dim=2, hidden_dim=64, num_dense_layers=2, num_rnn_layers=0, popart=True, layernorm=False,
+              shared_backbone=False, seed=7)
+    spec, vals = ns.build_netspec(**c1)
+    assert spec.popart and list(vals)[-5:] == [ns.POPART_W, ns.POPART_B, *ns.POPART_KEYS]
+    ref_keys = [k[len("pa_init_param:"):] for k in g.files if k.startswith("pa_init_param:")]
+    assert sorted(ref_keys) == sorted(vals)
+    for k, v in vals.items():
+        assert v.dtype == (torch.float64 if "_RunningMeanStd__" in k else torch.float32)
+        assert np.allclose(v.numpy(), g[f"pa_init_param:{k}"], rtol=1e-4, atol=1e-4), k
 
 
 def test_param_table_layout_roundtrip_and_init_sha(golden):

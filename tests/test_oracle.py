@@ -1,6 +1,7 @@
 """The oracle is pinned here: against the hand-computed vectors of the reference's own tests and against the
 golden vectors generated from the real reference (tests/golden/gen_golden.py)."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import gae as ogae
@@ -128,3 +129,38 @@ def test_full_step_golden_c1(golden):
     sd = net.state_dict()
     for k in sd:
         assert np.allclose(sd[k].numpy(), g[f"c1_step2_param:{k}"], rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize("tag,pargs,targs,n_steps,p_trunc", [
+    ("pa", dict(popart=True), dict(popart=True, optimizer_config=dict(lr=3e-4)), 3, None),
+    ("pa2", dict(popart=True, layernorm=True, shared_backbone=True),
+     dict(popart=True, clip_value=True, dual_clip=False, value_loss='huber', value_loss_config=dict(delta=10.0),
+          value_loss_weight=1.0, ppo_epochs=2, optimizer_config=dict(lr=5e-4), max_grad_norm=40.0), 2, None),
+    ("vt", dict(), dict(popart=False, vtrace=True, optimizer_config=dict(lr=3e-4)), 2, 0.0),
+    ("vtpa", dict(popart=True), dict(popart=True, vtrace=True, max_grad_norm=10.0, optimizer_config=dict(lr=1e-3)), 2, 0.0),
+])
+def test_full_step_golden_popart_vtrace(golden, tag, pargs, targs, n_steps, p_trunc):
+    """PopArt head (float64 running statistics, normalised targets) and V-trace: OracleMappo reproduces the
+    reference trainer's statistics, value targets and post-step state (fixtures: gen_golden.py gen_popart)."""
+    g = golden("steps_popart.npz")
+    base = dict(obs_dim=4, action_dim=2, hidden_dim=64, num_dense_layers=2, num_rnn_layers=0, popart=False,
+                layernorm=False, shared_backbone=False, chunk_len=8)
+    net = OracleActorCritic(**dict(base, **pargs))
+    pre = f"{tag}_init_param:"
+    net.load_state_dict({k[len(pre):]: g[k] for k in g.files if k.startswith(pre)})
+    tr = OracleMappo(net, **targs)
+    names = list(g[f"{tag}_stat_names"])
+    for step in range(n_steps):
+        arrays = synthetic.make_sample_arrays(seed=100 + step, T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2,
+                                              p_done=0.05, p_trunc=p_trunc)
+        stats, out = tr.step(arrays)
+        ref = dict(zip(names, g[f"{tag}_step{step}_stats"]))
+        keys = ["policy_loss", "value_loss", "entropy", "grad_norm", "clip_ratio", "value_targets"]
+        keys += ["denorm_value"] if targs["popart"] else []
+        for k in keys:
+            assert abs(stats[k] - ref[k]) <= 2e-5 * max(1.0, abs(ref[k])), (tag, step, k)
+        if step == 0:
+            assert np.allclose(out["ret"], g[f"{tag}_step0_ret"], rtol=1e-5, atol=1e-6)
+    sd = net.state_dict()
+    for k in sd:
+        assert np.allclose(sd[k].numpy(), g[f"{tag}_step{n_steps - 1}_param:{k}"], rtol=1e-4, atol=1e-6), k
