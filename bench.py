@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank")
+    ap.add_argument("--from-host", action="store_true",
+                    help="also time the step fed from the pinned ingest ring (H2D of every leaf inside the timed region, "
+                         "overlapped with the previous update); reported as `pcie_inclusive`, never as `value`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -200,6 +203,36 @@ def main():
                                            us_per_launch=round(big["ms"] * 1e3, 1), algorithmic_bytes=big["work"]))
         breakdown = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
 
+    pcie = None
+    if args.from_host and world == 1:
+        from srl_amd.namedarray import recursive_apply
+        from srl_amd.runtime.ingest import SampleRing
+        host = recursive_apply(sample, lambda x: x.cpu().numpy())
+        ring = SampleRing(host[:, 0], batch_size=B, slots=2, device=device)
+        for _ in range(2):
+            ring.put_batch(host)
+        del host
+
+        def fed_step():
+            b = ring.get_device()
+            r = trainer.step(b)
+            slot = b.metadata["ring_slot"]
+            ring.release(slot)
+            ring.recycle(slot)
+            return r
+
+        for _ in range(args.warmup):
+            fed_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fed_step()
+        sync()
+        el = time.perf_counter() - t0
+        pcie = dict(value=T * B * args.steps / el, unit="env-steps/s", ms_per_step=1e3 * el / args.steps,
+                    host_bytes_per_step=ring.nbytes() // 2,
+                    note="sample in the pinned ingest ring; async H2D of every leaf on a side stream, double-buffered")
+
     if rank == 0:
         steps_total = T * B * world * args.steps
         line = dict(metric="env-steps/sec through GAE+PPO update", value=steps_total / elapsed, unit="env-steps/s",
@@ -210,6 +243,8 @@ def main():
                                 envs_per_gpu=B, rollout_len=T, global_envs=B * world, parallelism=f"dp{world}",
                                 chunk_rows=args.chunk_rows, policy_loss=res.stats.get("policy_loss")),
                     roofline=roofline, roofline_gae=roofline_gae, kernel_ms_per_step=breakdown)
+        if pcie is not None:
+            line["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T, threads=min(os.cpu_count() or 1, 32))
         print(json.dumps(line), flush=True)

@@ -366,6 +366,23 @@ def _from_quadruples(chunks):
     return from_flattened(entries)
 
 
+def is_raw_bytes(chunks: List[bytes]) -> bool:
+    return len(chunks) > 0 and bytes(chunks[0]) == _TAG_RAW_BYTES
+
+
+def iter_raw_leaves(chunks: List[bytes]):
+    """(dotted key, zero-copy ndarray | None) for every leaf of a ``raw_bytes`` message, without building the tree
+    (the ingest ring writes each leaf straight into its pinned block)."""
+    body = chunks[1:-1]
+    for i in range(0, len(body) - 3, 4):
+        key, dtype, shape, buf = body[i:i + 4]
+        if dtype == b'':
+            yield key.decode('ascii'), None
+        else:
+            arr = np.frombuffer(buf, dtype=np.dtype(dtype.decode('ascii')))
+            yield key.decode('ascii'), arr.reshape(*ast.literal_eval(shape.decode('ascii')))
+
+
 def dumps(obj: NamedArray, method: str = "pickle_dict") -> List[bytes]:
     """Encode to the reference's list-of-bytes wire format: [tag, payload..., pickled metadata]."""
     if method == "pickle_dict":
