@@ -226,3 +226,33 @@ def test_implicit_and_explicit_conv_paths_agree():
         assert abs(a - b) <= 1e-5 * max(abs(b), 1e-2), (k, a, b)
     for k in stats[0][1]:
         assert np.abs(stats[0][1][k].numpy() - stats[1][1][k].numpy()).max() <= 2e-5, k
+
+
+def test_batcher_device_staging_matches_host_concatenation():
+    """The batcher's device block (no host np.concatenate of the observations) feeds rollout the same rows."""
+    from srl_amd.namedarray import NamedArray
+    from srl_amd.runtime.batcher import InferenceBatcher
+    pol = policy_api.make(config.Policy("actor-critic", args=dict(C1_POLICY, seed=11)))
+    rng = np.random.default_rng(3)
+
+    def req(ids):
+        n = len(ids)
+        return policy_api.RolloutRequest(obs=NamedArray(obs=rng.standard_normal((n, 4)).astype(np.float32)),
+                                         is_evaluation=np.ones((n, 1), np.uint8), on_reset=np.zeros((n, 1), np.uint8),
+                                         client_id=np.array(ids, np.int32).reshape(n, 1),
+                                         request_id=np.arange(n).reshape(n, 1), received_time=np.zeros((n, 1), np.int64),
+                                         buffer_index=np.zeros((n, 1), np.int32))
+
+    reqs = [req([0, 1, 2]), req([3]), req([4, 5, 6, 7, 8])]
+    outs = []
+    for staged in (True, False):
+        b = InferenceBatcher(pol, batch_size=7, stage_on_device=staged)
+        for r in reqs:
+            b.post(r)
+        res = b.poll()
+        assert [o.action.x.shape[0] for o in res] == [7, 2]
+        outs.append(res)
+    for a, c in zip(*outs):
+        assert np.array_equal(a.client_id, c.client_id) and np.array_equal(a.action.x, c.action.x)
+        assert np.array_equal(a.analyzed_result.value, c.analyzed_result.value)
+        assert np.array_equal(a.analyzed_result.log_probs, c.analyzed_result.log_probs)
