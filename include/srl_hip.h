@@ -101,6 +101,31 @@ int srl_popart_map(void* stream, const float* x, long n, int vd, const double* r
                    int normalize, float* out);
 
 /* ------------------------------------------------------------------------------------------------
+ * Recurrent backbone: GRU cell between the GEMMs, one time step per launch.
+ * Replaces: AutoResetRNN.forward around torch.nn.GRU (modules/autoreset_rnn.py:42-66,
+ *           recurrent_backbone.py:61-66) and its autograd backward; chunking of modules/utils.py:164-182.
+ * Per-step blocks: gates [N, 3H] in torch order r|z|n, states [N, H]; N = env columns of the chunked batch.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* out = h * (1 - reset) row-wise (reset uint8[N] or NULL: copy); autoreset_rnn.py:59. */
+int srl_gru_mask_state(void* stream, const float* h, const uint8_t* reset, long N, int H, float* out);
+
+/* gi = W_ih x + b_ih, gh = W_hh h_in + b_hh (both from srl_gemm) -> y = h(t); gi is overwritten with the gates
+ * (r, z, n) and gh keeps its n part, both for srl_gru_cell_bwd; hin_next (optional) = y * (1 - reset_next). */
+int srl_gru_cell_fwd(void* stream, float* gi, float* gh, const float* hin, const uint8_t* reset_next,
+                     long N, int H, float* y, float* hin_next);
+
+/* dh = dy (or 0) + carry * (1 - reset_next) (carry = d loss / d h_in(t+1), or NULL at the last step).
+ * gates <- d gi, gh <- d gh (in place), dh_direct = dh * z; the caller adds d gh . W_hh with srl_gemm
+ * (accumulate) to obtain d loss / d h_in(t), the next call's carry. */
+int srl_gru_cell_bwd(void* stream, const float* dy, const float* carry, const uint8_t* reset_next,
+                     float* gates, float* gh, const float* hin, long N, int H, float* dh_direct);
+
+/* Rows of D floats between time-major [T*B] and chunk-major order: dst[(c, k*B + b)] = src[((k*C + c), b)]
+ * (modules/utils.py:164-182 `to_chunk`: torch.cat(torch.split(x, C, dim=0), dim=1)); inverse != 0 undoes it. */
+int srl_chunk_rows(void* stream, const float* src, float* dst, int T, int B, int C, int D, int inverse);
+
+/* ------------------------------------------------------------------------------------------------
  * PPO loss, forward + backward in one pass over the batch.
  * Replaces: MultiAgentPPO._compute_loss (mappo.py:146-217) + value-loss factories
  *           (modules/utils.py:228-265) + the autograd backward through them (mappo.py:274).

@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 from srl_amd import hip
 from srl_amd.algorithm import netspec as ns
-from srl_amd.algorithm.hipnet import HipNet
+from srl_amd.algorithm.hipnet import HipNet, RnnCtx
 from srl_amd.algorithm.ppo_types import PPORolloutAnalyzedResult, SampleAnalyzedResult
 from srl_amd.api import policy as policy_api
 from srl_amd.api.env_utils import DiscreteAction
@@ -76,7 +76,8 @@ class ActorCriticPolicy(policy_api.Policy):
         self.spec, init = ns.build_netspec(obs_dim=obs_dim, action_dim=action_dim, hidden_dim=hidden_dim,
                                            state_dim=state_dim, value_dim=value_dim, num_dense_layers=num_dense_layers,
                                            cnn_layers=cnn_layers, use_maxpool=use_maxpool,
-                                           num_rnn_layers=num_rnn_layers, popart=popart, activation=activation,
+                                           num_rnn_layers=num_rnn_layers, rnn_type=rnn_type, popart=popart,
+                                           activation=activation,
                                            layernorm=layernorm, shared_backbone=shared_backbone,
                                            continuous_action=continuous_action, auxiliary_head=auxiliary_head,
                                            seed=seed)
@@ -93,7 +94,36 @@ class ActorCriticPolicy(policy_api.Policy):
     # ------------------------------------------------------------------ bookkeeping (api/policy.py:205-288)
     @property
     def default_policy_state(self):
-        return None  # no recurrent state on the HIP path yet
+        """Zeros [layers, H] per backbone, batch dimension stripped (actor_critic_policy.py:229-237)."""
+        L, H = self.spec.num_rnn_layers, self.spec.hidden_dim
+        if not L:
+            return None
+        z = lambda: np.zeros((L, H), dtype=np.float32)
+        return NamedArray(hx=z()) if self.spec.shared_backbone else NamedArray(actor_hx=z(), critic_hx=z())
+
+    def _state_keys(self):
+        return (("hx", "a:"),) if self.spec.shared_backbone else (("actor_hx", "a:"), ("critic_hx", "c:"))
+
+    def _rnn_ctx(self, policy_state, T, B, on_reset) -> Optional[RnnCtx]:
+        """Chunking of [T, B] rows for the recurrent layers (actor_critic_policy.py:349-363): ``T // chunk_len``
+        chunks, each starting from the state stored at its first row; ``on_reset`` [T, B, 1] device uint8 or None."""
+        L, H = self.spec.num_rnn_layers, self.spec.hidden_dim
+        if not L:
+            return None
+        if policy_state is None:
+            raise ValueError("recurrent policy: the sample / request carries no policy_state")
+        K = max(T // self._chunk_len, 1)
+        C = T // K
+        if K * C != T:
+            raise ValueError(f"{T} rows do not split into {K} chunks of equal length (chunk_len={self._chunk_len})")
+        h0 = {}
+        for key, tag in self._state_keys():
+            s = to_device_leaf(policy_state[key], self.device, "real")  # [T, B, L, H]
+            h0[tag] = s.reshape(T, B, L, H)[0::C].reshape(K * B, L, H).permute(1, 0, 2).contiguous()
+        reset = None
+        if on_reset is not None:
+            reset = on_reset.reshape(K, C, B).permute(1, 0, 2).contiguous()  # chunk-major [C, K*B]
+        return RnnCtx(T, B, C, h0, reset)
 
     @property
     def version(self) -> int:
@@ -185,7 +215,13 @@ class ActorCriticPolicy(policy_api.Policy):
             avail = avail.to(torch.uint8)
         is_eval = np.asarray(requests.is_evaluation).reshape(-1)
         is_eval = to_device_leaf(np.broadcast_to(is_eval, (n,)) if is_eval.size == 1 else is_eval, self.device, "flag")
-        logits, value = self._net.forward(obs, n, keep_tape=False)
+        rnn = None
+        if self.spec.num_rnn_layers:  # requests carry [n, layers, H]; the state is used as given (:473-481)
+            ps = requests.policy_state
+            if ps is None:
+                raise ValueError("recurrent policy: the request carries no policy_state")
+            rnn = self._rnn_ctx(NamedArray(**{k: np.asarray(ps[k])[None] for k, _ in self._state_keys()}), 1, n, None)
+        logits, value = self._net.forward(obs, n, keep_tape=False, rnn=rnn)
         heads = self.spec.act_dims
         action = torch.empty((n, len(heads)), dtype=torch.int64, device=self.device)
         logp = torch.empty((n, 1), dtype=torch.float32, device=self.device)
@@ -194,7 +230,13 @@ class ActorCriticPolicy(policy_api.Policy):
         return policy_api.RolloutResult(action=DiscreteAction(action.cpu().numpy()),
                                         analyzed_result=PPORolloutAnalyzedResult(log_probs=logp.cpu().numpy(),
                                                                                  value=value.cpu().numpy()),
-                                        policy_state=None)
+                                        policy_state=self._packed_last_state())
+
+    def _packed_last_state(self):
+        """New hidden states as the actors store them: numpy [n, layers, H] per backbone (:505-508)."""
+        if not self.spec.num_rnn_layers:
+            return None
+        return NamedArray(**{k: self._net.last_state[tag].permute(1, 0, 2).cpu().numpy() for k, tag in self._state_keys()})
 
     # ------------------------------------------------------------------ training-side analysis
     def analyze(self, sample, target="ppo", **kwargs):
@@ -210,7 +252,7 @@ class ActorCriticPolicy(policy_api.Policy):
         The forward context is kept so that ``backward_ppo`` can follow.
         """
         if burn_in_steps:
-            raise NotImplementedError("burn-in only matters for recurrent policies, which are not on the HIP path")
+            raise NotImplementedError("burn-in steps are not on the HIP path")
         T, B = sample.on_reset.shape[:2]
         n = T * B
         obs = {}
@@ -221,7 +263,10 @@ class ActorCriticPolicy(policy_api.Policy):
             obs[k] = t.reshape(n, *t.shape[2:])
         avail = obs.pop("available_action", None)
         action = to_device_leaf(sample.action.x, self.device, "index").reshape(n, -1)
-        logits, value = self._net.forward(obs, n, keep_tape=True)
+        rnn = None
+        if self.spec.num_rnn_layers:
+            rnn = self._rnn_ctx(sample.policy_state, T, B, to_device_leaf(sample.on_reset, self.device, "flag"))
+        logits, value = self._net.forward(obs, n, keep_tape=True, rnn=rnn)
         logp = self._net.ws.get("new_logp", n)[:n]
         ent = self._net.ws.get("entropy", n)[:n]
         hip.categorical_fwd(logits, action, avail, self.spec.act_dims, logp, ent)

@@ -36,6 +36,18 @@ class Buf(NamedTuple):
     cols: int
 
 
+class RnnCtx(NamedTuple):
+    """How the n = T*B time-major rows of a forward pass are laid out for the recurrent layers: chunks of C time
+    steps (T % C == 0), N = (T/C)*B environment columns per step; h0[tag] float32 [layers, N, H] initial states
+    ("a:" actor / shared backbone, "c:" critic backbone); reset uint8 [C, N] chunk-major on_reset flags, or None
+    (rollout: the state is used as given, actor_critic_policy.py:476-481)."""
+    T: int
+    B: int
+    C: int
+    h0: dict
+    reset: Optional[torch.Tensor]
+
+
 class Workspace:
     """Named device buffers that only ever grow (steady-state steps allocate nothing)."""
 
@@ -73,6 +85,8 @@ class HipNet:
         self.popart_state = torch.zeros(2 * spec.value_dim + 1 if spec.popart else 0, dtype=torch.float64, device=dev)
         self.ws = Workspace(dev)
         self._tape = None
+        self._rnn: Optional[RnnCtx] = None
+        self.last_state: Dict[str, torch.Tensor] = {}
         # SRL_EXPLICIT_CONV=1 forces the im2col + GEMM + col2im fallback (kept for geometries the implicit
         # kernels reject, and as a cross-check of the implicit path in the tests)
         import os
@@ -176,6 +190,97 @@ class HipNet:
                           self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"))
         return dx
 
+    # ------------------------------------------------------------------ recurrent layers (GRU + auto reset)
+    def _gru_fwd(self, G: ns.GruSpec, x: Buf, tag: str):
+        """x: time-major [T*B, H].  Returns (y time-major [T*B, H], saved, last states [layers, N, H])."""
+        ctx = self._rnn
+        if ctx is None:
+            raise hip.HipError("recurrent backbone: forward() needs the `rnn` context (chunking, states, on_reset)")
+        T, B, C, H = ctx.T, ctx.B, ctx.C, G.hidden
+        n, K = T * B, T // C
+        N = K * B
+        assert x.rows == n and x.cols == H and x.ld == H and T % C == 0
+        if K > 1:
+            xc = self._buf(f"{tag}{G.prefix}.xc", n, H)
+            hip.chunk_rows(x.ptr, xc.ptr, T, B, C, H)
+        else:
+            xc = x
+        h0 = ctx.h0[tag]
+        assert tuple(h0.shape) == (G.layers, N, H) and h0.dtype == torch.float32 and h0.is_contiguous()
+        rs = ctx.reset
+        rptr = (lambda c: rs.data_ptr() + c * N) if rs is not None else (lambda c: None)
+        last = self.ws.get(f"{tag}{G.prefix}.last", G.layers * N * H)[:G.layers * N * H].view(G.layers, N, H)
+        inp, saved = xc, []
+        for l in range(G.layers):
+            w_ih, w_hh = self._p(f"{G.prefix}.weight_ih_l{l}"), self._p(f"{G.prefix}.weight_hh_l{l}")
+            b_ih, b_hh = self._p(f"{G.prefix}.bias_ih_l{l}"), self._p(f"{G.prefix}.bias_hh_l{l}")
+            gi = self._buf(f"{tag}{G.prefix}.gi{l}", n, 3 * H)
+            gh = self._buf(f"{tag}{G.prefix}.gh{l}", n, 3 * H)
+            hin = self._buf(f"{tag}{G.prefix}.hin{l}", n, H)
+            y = self._buf(f"{tag}{G.prefix}.y{l}", n, H)
+            hip.gemm(n, 3 * H, H, inp.ptr, inp.ld, 0, w_ih, H, 0, gi.ptr, 3 * H, bias=b_ih)  # every step at once
+            hip.gru_mask_state(h0[l].data_ptr(), rptr(0), N, H, hin.ptr)
+            for c in range(C):
+                o3, o1 = 4 * c * N * 3 * H, 4 * c * N * H
+                hip.gemm(N, 3 * H, H, hin.ptr + o1, H, 0, w_hh, H, 0, gh.ptr + o3, 3 * H, bias=b_hh)
+                nxt = c + 1 < C
+                hip.gru_cell_fwd(gi.ptr + o3, gh.ptr + o3, hin.ptr + o1, rptr(c + 1) if nxt else None, N, H, y.ptr + o1,
+                                 hin.ptr + 4 * (c + 1) * N * H if nxt else None)
+            hip.copy2d(y.ptr + 4 * (C - 1) * N * H, H, last[l].data_ptr(), H, N, H)
+            saved.append((inp, gi, gh, hin))
+            inp = y
+        if K > 1:
+            ytm = self._buf(f"{tag}{G.prefix}.ytm", n, H)
+            hip.chunk_rows(inp.ptr, ytm.ptr, T, B, C, H, inverse=True)
+        else:
+            ytm = inp
+        return ytm, (saved, ctx), last
+
+    def _gru_bwd(self, G: ns.GruSpec, saved_all, dy: Buf, in_act: int, need_dx: bool, tag: str) -> Optional[Buf]:
+        saved, ctx = saved_all
+        T, B, C, H = ctx.T, ctx.B, ctx.C, G.hidden
+        n, K = T * B, T // C
+        N = K * B
+        rs = ctx.reset
+        rptr = (lambda c: rs.data_ptr() + c * N) if rs is not None else (lambda c: None)
+        if K > 1:
+            dyc = self._buf(f"{tag}{G.prefix}.dyc", n, H)
+            assert dy.ld == H
+            hip.chunk_rows(dy.ptr, dyc.ptr, T, B, C, H)
+        else:
+            dyc = dy
+        dout = dyc
+        for l in range(G.layers - 1, -1, -1):
+            inp, gi, gh, hin = saved[l]
+            w_ih, w_hh = self._p(f"{G.prefix}.weight_ih_l{l}"), self._p(f"{G.prefix}.weight_hh_l{l}")
+            dh = [self._buf(f"{tag}{G.prefix}.dh{i}", N, H) for i in range(2)]
+            carry = None
+            for c in range(C - 1, -1, -1):
+                o3, o1 = 4 * c * N * 3 * H, 4 * c * N * H
+                cur = dh[c & 1]
+                hip.gru_cell_bwd(dout.ptr + 4 * c * N * dout.ld, carry, rptr(c + 1) if c + 1 < C else None, gi.ptr + o3,
+                                 gh.ptr + o3, hin.ptr + o1, N, H, cur.ptr)
+                # d h_in(c) = dh*z + d gh . W_hh: the carry of step c-1 (masked there by on_reset[c])
+                hip.gemm(N, H, 3 * H, gh.ptr + o3, 3 * H, 0, w_hh, H, 1, cur.ptr, H, accumulate=True)
+                carry = cur.ptr
+            # parameter gradients over all steps at once (gi / gh now hold d gi / d gh)
+            self._wgrad(3 * H, H, n, gh, hin.ptr, H, self._g(f"{G.prefix}.weight_hh_l{l}"))
+            hip.colsum(gh.ptr, 3 * H, n, 3 * H, self._g(f"{G.prefix}.bias_hh_l{l}"), accumulate=True)
+            self._wgrad(3 * H, H, n, gi, inp.ptr, inp.ld, self._g(f"{G.prefix}.weight_ih_l{l}"))
+            hip.colsum(gi.ptr, 3 * H, n, 3 * H, self._g(f"{G.prefix}.bias_ih_l{l}"), accumulate=True)
+            if l == 0 and not need_dx:
+                return None
+            dx = self._buf(f"{tag}{G.prefix}.dx{l}", n, H)
+            act = in_act if l == 0 else 0  # layer 0 reads the (activated) output of the dense stack
+            hip.gemm(n, H, 3 * H, gi.ptr, 3 * H, 0, w_ih, H, 1, dx.ptr, H, dact_src=inp.ptr if act else None, ld_dact=inp.ld,
+                     dact=act)
+            dout = dx
+        if K > 1:
+            dxt = self._buf(f"{tag}{G.prefix}.dxt", n, H)
+            hip.chunk_rows(dout.ptr, dxt.ptr, T, B, C, H, inverse=True)
+            return dxt
+        return dout
+
     # ------------------------------------------------------------------ encoders
     def _encoder_fwd(self, enc: ns.EncoderSpec, obs: torch.Tensor, n: int, tag: str, tape: list) -> Buf:
         """obs: device tensor [n, *shape] (float32 vectors; uint8 or float32 images)."""
@@ -268,6 +373,8 @@ class HipNet:
                 g = self._ln_bwd(L, x, saved, g, in_act, need_dx, tag)
             elif kind == "linear":
                 g = self._linear_bwd(L, x, g, in_act, need_dx, tag)
+            elif kind == "gru":
+                g = self._gru_bwd(L, saved, g, in_act, need_dx, tag)
             elif kind == "conv":
                 P, first_saved, n, desc = saved
                 kdim = L.cin * L.k * L.k
@@ -329,6 +436,8 @@ class HipNet:
             return L.dim
         if kind == "linear":
             return L.out_features
+        if kind == "gru":
+            return L.hidden
         return L.cout
 
     def _trunk_fwd(self, tag, encoders, backbone, obs: Dict[str, torch.Tensor], n: int):
@@ -355,6 +464,11 @@ class HipNet:
                 y = self._linear_fwd(L, cur, tag)
                 bb_tape.append(("linear", L, cur, None, cur_act))
                 cur, cur_act = y, L.act
+            elif isinstance(L, ns.GruSpec):
+                y, saved, last = self._gru_fwd(L, cur, tag)
+                bb_tape.append(("gru", L, cur, saved, cur_act))
+                self.last_state[tag] = last
+                cur, cur_act = y, 0
             else:
                 y, saved = self._ln_fwd(L, cur, tag)
                 bb_tape.append(("ln", L, cur, saved, cur_act))
@@ -371,11 +485,16 @@ class HipNet:
             col += wdt
 
     # ------------------------------------------------------------------ public: forward / backward
-    def forward(self, obs: Dict[str, torch.Tensor], n: int, keep_tape: bool = True):
+    def forward(self, obs: Dict[str, torch.Tensor], n: int, keep_tape: bool = True, rnn: Optional[RnnCtx] = None):
         """obs leaves [n, ...] on the device.  Returns (logits [n, sum(A)], value [n, value_dim]) tensors
-        (views of workspace buffers, valid until the next forward)."""
+        (views of workspace buffers, valid until the next forward).  Recurrent nets: ``rnn`` describes the time
+        structure of the rows; the final hidden states are left in ``self.last_state`` ("a:" / "c:")."""
         hip.require_gpu()
         sp = self.spec
+        self._rnn = rnn
+        self.last_state = {}
+        if sp.num_rnn_layers and (rnn is None or rnn.T * rnn.B != n):
+            raise hip.HipError("recurrent backbone: `rnn` context missing or inconsistent with the row count")
         a_feat, a_act, a_tape = self._trunk_fwd("a:", sp.obs_encoders, sp.actor_backbone, obs, n)
         if sp.shared_backbone:
             c_feat, c_act, c_tape = a_feat, a_act, None

@@ -75,7 +75,7 @@ class MultiAgentPPO(PytorchTrainer):
         if self.vtrace and self.bootstrap_steps != 1:
             raise NotImplementedError("V-trace with bootstrap_steps != 1 is not on the HIP path")
         if self.burn_in_steps:
-            raise NotImplementedError("burn-in only matters for recurrent policies, not on the HIP path yet")
+            raise NotImplementedError("burn-in steps are not on the HIP path")
 
         name = g('optimizer', 'adam')
         if name not in ('adam', 'adamw'):
@@ -163,6 +163,8 @@ class MultiAgentPPO(PytorchTrainer):
         for r0 in range(0, n_all, self.chunk_rows):
             r1 = min(n_all, r0 + self.chunk_rows)
             n = r1 - r0
+            if net.spec.num_rnn_layers:
+                raise NotImplementedError("V-trace with a recurrent policy is not on the HIP path")
             logits, _ = net.forward({k: v[r0:r1] for k, v in f_obs.items()}, n, keep_tape=False)
             ent = net.ws.get("entropy", n)[:n]
             hip.categorical_fwd(logits, f_action[r0:r1], None if f_avail is None else f_avail[r0:r1], net.spec.act_dims,
@@ -253,14 +255,19 @@ class MultiAgentPPO(PytorchTrainer):
             f_action, f_oldlp, f_oldv = flat(action), flat(old_lp).reshape(-1), flat(loss_oldv).reshape(-1)
             f_adv, f_ret, f_mask = flat(adv_d).reshape(-1), flat(loss_ret).reshape(-1), mask_rows.reshape(-1)
             f_done, f_trunc = flat(done).reshape(-1), flat(truncated).reshape(-1)
-            nchunks = max(1, -(-n_valid // self.chunk_rows))
+            # recurrent nets walk the time axis: all valid rows go through in one piece
+            rnn = None
+            if net.spec.num_rnn_layers:
+                rnn = self.policy._rnn_ctx(sample.policy_state[lo:hi], hi - lo, B, on_reset[lo:hi])
+            chunk_rows = n_valid if rnn is not None else self.chunk_rows
+            nchunks = max(1, -(-n_valid // chunk_rows))
             terms = torch.zeros((nchunks, hip.LT_COUNT), **f64)
             for ci in range(nchunks):
-                r0, r1 = ci * self.chunk_rows, min(n_valid, (ci + 1) * self.chunk_rows)
+                r0, r1 = ci * chunk_rows, min(n_valid, (ci + 1) * chunk_rows)
                 n = r1 - r0
                 c_obs = {k: v[r0:r1] for k, v in f_obs.items()}
                 c_avail = None if f_avail is None else f_avail[r0:r1]
-                logits, value = net.forward(c_obs, n, keep_tape=True)
+                logits, value = net.forward(c_obs, n, keep_tape=True, rnn=rnn)
                 logp = net.ws.get("new_logp", n)[:n]
                 ent = net.ws.get("entropy", n)[:n]
                 hip.categorical_fwd(logits, f_action[r0:r1], c_avail, net.spec.act_dims, logp, ent)

@@ -96,6 +96,16 @@ class LinearSpec:
 
 
 @dataclasses.dataclass
+class GruSpec:
+    """AutoResetRNN(GRU) of a RecurrentBackbone (recurrent_backbone.py:50-58, autoreset_rnn.py:42-66): parameters
+    ``<prefix>.weight_ih_l{l} [3H, H]``, ``weight_hh_l{l} [3H, H]``, ``bias_ih_l{l}``, ``bias_hh_l{l} [3H]`` (gate order
+    r, z, n as in torch.nn.GRU); the hidden state is zeroed at every step whose on_reset flag is set."""
+    prefix: str  # "<backbone>.rnn._AutoResetRNN__net"
+    hidden: int
+    layers: int
+
+
+@dataclasses.dataclass
 class ConvSpec:
     prefix: str
     cin: int
@@ -139,6 +149,7 @@ class NetSpec:
     params: "OrderedDict[str, ParamInfo]"
     total_params: int
     popart: bool = False  # critic head is a PopArtValueHead: float64 running statistics ride along (POPART_KEYS)
+    num_rnn_layers: int = 0  # GRU layers at the end of each backbone (GruSpec + the rnn_norm LayerNormSpec)
 
 
 # state_dict keys of the PopArt head (popart.py:21-22,30-31; modules/utils.py:80-82), in the reference's order
@@ -200,6 +211,13 @@ class _Builder:
         w, b = self._default_wb((cout, cin, k, k))
         self._add(f"{prefix}.weight", (cout, cin, k, k), w, layout, s2d=s2d)
         self._add(f"{prefix}.bias", (cout,), b)
+
+    def uniform(self, name, shape, bound):
+        v = None
+        if self.init:
+            v = torch.empty(shape)
+            torch.nn.init.uniform_(v, -bound, bound)
+        self._add(name, shape, v)
 
     def orthogonal(self, name, gain):
         if self.init:
@@ -268,7 +286,8 @@ def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, a
     return encs
 
 
-def _build_backbone(b: _Builder, root: str, in_dim: int, hidden: int, dense_layers: int, act: int, layernorm: bool):
+def _build_backbone(b: _Builder, root: str, in_dim: int, hidden: int, dense_layers: int, act: int, layernorm: bool,
+                    num_rnn_layers: int = 0):
     layers = []
     stride = 3 if layernorm else 2
     names = []
@@ -289,17 +308,35 @@ def _build_backbone(b: _Builder, root: str, in_dim: int, hidden: int, dense_laye
             b.orthogonal(n, math.sqrt(2))
         if n.endswith("bias"):
             b.zero(n)
+    if num_rnn_layers:
+        # nn.GRU.reset_parameters: every tensor uniform(+-1/sqrt(H)) in _flat_weights order, then
+        # recurrent_backbone.py:54-58: orthogonal (gain 1) on the matrices, zeros on the biases
+        rp = f"{root}.rnn._AutoResetRNN__net"
+        bound = 1.0 / math.sqrt(hidden)
+        for l in range(num_rnn_layers):
+            b.uniform(f"{rp}.weight_ih_l{l}", (3 * hidden, hidden), bound)
+            b.uniform(f"{rp}.weight_hh_l{l}", (3 * hidden, hidden), bound)
+            b.uniform(f"{rp}.bias_ih_l{l}", (3 * hidden,), bound)
+            b.uniform(f"{rp}.bias_hh_l{l}", (3 * hidden,), bound)
+        b.layernorm(f"{root}.rnn_norm", hidden)
+        for l in range(num_rnn_layers):
+            b.orthogonal(f"{rp}.weight_ih_l{l}", 1.0)
+            b.orthogonal(f"{rp}.weight_hh_l{l}", 1.0)
+            b.zero(f"{rp}.bias_ih_l{l}")
+            b.zero(f"{rp}.bias_hh_l{l}")
+        layers.append(GruSpec(rp, hidden, num_rnn_layers))
+        layers.append(LayerNormSpec(f"{root}.rnn_norm", hidden))
     return layers
 
 
 def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim=1, num_dense_layers=2,
                   cnn_layers=None, use_maxpool=None, num_rnn_layers=0, popart=False, activation="relu", layernorm=True,
                   shared_backbone=False, continuous_action=False, auxiliary_head=False, seed: Optional[int] = None,
-                  **_unused):
+                  rnn_type="gru", **_unused):
     """Returns ``(NetSpec, values)``; ``values`` is the name -> CPU tensor dict of initial weights (reference
     layout) when ``seed`` is given, else ``None``."""
-    if num_rnn_layers:
-        raise NotImplementedError("recurrent backbones are a 'next' row (SURVEY.md 8f-2), not on the HIP path yet")
+    if num_rnn_layers and rnn_type != "gru":
+        raise NotImplementedError(f"rnn_type `{rnn_type}`: only the GRU variant of AutoResetRNN is on the HIP path")
     if continuous_action or auxiliary_head:
         raise NotImplementedError("continuous actions / auxiliary value head are not on the HIP path")
     if use_maxpool and any(use_maxpool.values()):
@@ -320,23 +357,23 @@ def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim
         torch.set_num_threads(1)
     try:
         return _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation,
-                      layernorm, shared_backbone, seed, popart)
+                      layernorm, shared_backbone, seed, popart, num_rnn_layers)
     finally:
         torch.set_num_threads(threads)
 
 
 def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation, layernorm,
-           shared_backbone, seed, popart=False):
+           shared_backbone, seed, popart=False, num_rnn_layers=0):
     b = _Builder(seed)
     obs_enc = _build_encoders(b, "obs_modules_dict", obs_dims, hidden_dim, act, activation, cnn_layers)
     actor_bb = _build_backbone(b, "actor_backbone", hidden_dim * len(obs_dims), hidden_dim, num_dense_layers, act,
-                               layernorm)
+                               layernorm, num_rnn_layers)
     state_enc = critic_bb = None
     if not shared_backbone:
         sdims = state_dim or obs_dims
         state_enc = _build_encoders(b, "state_modules_dict", sdims, hidden_dim, act, activation, cnn_layers)
         critic_bb = _build_backbone(b, "critic_backbone", hidden_dim * len(sdims), hidden_dim, num_dense_layers, act,
-                                    layernorm)
+                                    layernorm, num_rnn_layers)
     b.linear("actor_head", hidden_dim, sum(act_dims))
     b.orthogonal("actor_head.weight", 0.01)  # actor_critic_policy.py:109-112
     b.zero("actor_head.bias")
@@ -359,5 +396,5 @@ def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num
         off += (info.numel + 3) // 4 * 4  # 16-byte aligned starts (float4 staging in the GEMM)
     spec = NetSpec(obs_enc, actor_bb, state_enc, critic_bb, LinearSpec("actor_head", hidden_dim, sum(act_dims), 0),
                    LinearSpec("critic_head", hidden_dim, value_dim, 0), act_dims, hidden_dim, value_dim, shared_backbone,
-                   b.params, off, popart)
+                   b.params, off, popart, num_rnn_layers)
     return spec, (b.values if b.init else None)

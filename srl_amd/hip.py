@@ -76,6 +76,11 @@ _SIGNATURES = {
     "srl_popart_update": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                   c_int]),
     "srl_popart_map": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_double, c_int, c_void_p]),
+    "srl_gru_mask_state": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "srl_gru_cell_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
+    "srl_gru_cell_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
+                                 c_void_p]),
+    "srl_chunk_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "srl_ppo_loss_fwd_bwd": (c_int, [c_void_p] + [c_void_p] * 8 + [c_long, POINTER(PpoHparams)] + [c_void_p] * 8),
     "srl_categorical_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, POINTER(c_int32),
                                      c_void_p, c_void_p]),
@@ -238,6 +243,24 @@ def masked_normalize(x, mask, stats, out, mask_invert=False, eps=1e-5, unbiased=
         lib().srl_masked_normalize(_stream(), _ptr(x, torch.float32, "x"), _ptr(mask, torch.uint8, "mask"),
                                    int(mask_invert), x.numel(), _ptr(stats, torch.float64, "stats"), float(eps),
                                    int(unbiased), _ptr(out, torch.float32, "out")), "srl_masked_normalize")
+
+
+def gru_mask_state(h_ptr, reset_ptr, N, H, out_ptr):
+    _check(lib().srl_gru_mask_state(_stream(), h_ptr, reset_ptr, int(N), int(H), out_ptr), "srl_gru_mask_state")
+
+
+def gru_cell_fwd(gi_ptr, gh_ptr, hin_ptr, reset_next_ptr, N, H, y_ptr, hin_next_ptr):
+    _check(lib().srl_gru_cell_fwd(_stream(), gi_ptr, gh_ptr, hin_ptr, reset_next_ptr, int(N), int(H), y_ptr, hin_next_ptr),
+           "srl_gru_cell_fwd")
+
+
+def gru_cell_bwd(dy_ptr, carry_ptr, reset_next_ptr, gates_ptr, gh_ptr, hin_ptr, N, H, dh_direct_ptr):
+    _check(lib().srl_gru_cell_bwd(_stream(), dy_ptr, carry_ptr, reset_next_ptr, gates_ptr, gh_ptr, hin_ptr, int(N), int(H),
+                                  dh_direct_ptr), "srl_gru_cell_bwd")
+
+
+def chunk_rows(src_ptr, dst_ptr, T, B, C, D, inverse=False):
+    _check(lib().srl_chunk_rows(_stream(), src_ptr, dst_ptr, int(T), int(B), int(C), int(D), int(inverse)), "srl_chunk_rows")
 
 
 def masked_stats_cols(x, mask, stats, vd, mask_invert=False):

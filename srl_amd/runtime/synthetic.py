@@ -44,8 +44,12 @@ def make_sample_arrays(seed: int,
                        bootstrap_steps: int = 1,
                        value_dim: int = 1,
                        available_action: bool = False,
-                       p_trunc: Optional[float] = None) -> Dict[str, np.ndarray]:
-    """Flat ``{dotted.key: array}`` dict of one synthetic sample; wrap with ``to_sample_batch``."""
+                       p_trunc: Optional[float] = None,
+                       policy_state: Optional[Dict[str, Tuple[int, int]]] = None) -> Dict[str, np.ndarray]:
+    """Flat ``{dotted.key: array}`` dict of one synthetic sample; wrap with ``to_sample_batch``.
+
+    ``policy_state``: ``{"hx": (layers, hidden)}`` (or ``actor_hx`` / ``critic_hx``) adds stored recurrent states
+    ``[Tb, B, layers, hidden]`` (drawn from their own stream, so the other leaves do not depend on it)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     Tb = T + bootstrap_steps
     done, truncated, on_reset = make_flags(rng, Tb, B, p_done, p_trunc)
@@ -77,6 +81,10 @@ def make_sample_arrays(seed: int,
         "policy_version_steps": np.zeros((Tb, B, 1), dtype=np.int64),
         "info_mask": np.zeros((Tb, B, 1), dtype=np.uint8),
     })
+    if policy_state:
+        srng = np.random.Generator(np.random.PCG64(seed + 7919))
+        for name, (layers, hidden) in policy_state.items():
+            out[f"policy_state.{name}"] = (0.5 * srng.standard_normal((Tb, B, layers, hidden))).astype(np.float32)
     return out
 
 
@@ -87,7 +95,9 @@ def to_sample_batch(arrays: Dict[str, np.ndarray]):
     from srl_amd.algorithm.ppo_types import PPORolloutAnalyzedResult
     from srl_amd.namedarray import NamedArray
     obs = NamedArray(**{k[4:]: v for k, v in arrays.items() if k.startswith("obs.")})
+    ps = {k[len("policy_state."):]: v for k, v in arrays.items() if k.startswith("policy_state.")}
     return SampleBatch(obs=obs,
+                       policy_state=NamedArray(**ps) if ps else None,
                        on_reset=arrays["on_reset"],
                        done=arrays["done"],
                        truncated=arrays["truncated"],

@@ -77,7 +77,9 @@ def state_sha(sd):
 def ref_sample(arrays):
     """flat dict -> the reference's SampleBatch."""
     obs = NamedArray(**{k[4:]: v for k, v in arrays.items() if k.startswith("obs.")})
-    return api.trainer.SampleBatch(obs=obs, on_reset=arrays["on_reset"], done=arrays["done"],
+    ps = {k[len("policy_state."):]: v for k, v in arrays.items() if k.startswith("policy_state.")}
+    return api.trainer.SampleBatch(obs=obs, policy_state=NamedArray(**ps) if ps else None,
+                                   on_reset=arrays["on_reset"], done=arrays["done"],
                                    truncated=arrays["truncated"], action=DiscreteAction(arrays["action.x"]),
                                    reward=arrays["reward"],
                                    analyzed_result=PPORolloutAnalyzedResult(
@@ -256,10 +258,13 @@ def run_steps(tag, policy_args, trainer_args, sample_kw, n_steps, store_state="f
             Tb = arrays["on_reset"].shape[0]
             with torch.no_grad():
                 ar = trainer.policy.analyze(ts[:Tb - 1], target="ppo", burn_in_steps=0)
+                pnames = ["policy_state.hx"] if "policy_state.hx" in arrays else \
+                    [n for n in ("policy_state.actor_hx", "policy_state.critic_hx") if n in arrays]
                 lp, v, ent, _ = oracle_net.analyze({k[4:]: torch.from_numpy(a[:Tb - 1]).float()
                                                     for k, a in arrays.items() if k.startswith("obs.")},
                                                    torch.from_numpy(arrays["action.x"][:Tb - 1]).float(),
-                                                   torch.from_numpy(arrays["on_reset"][:Tb - 1]).float())
+                                                   torch.from_numpy(arrays["on_reset"][:Tb - 1]).float(),
+                                                   [torch.from_numpy(arrays[n][:Tb - 1]) for n in pnames] or None)
             assert torch.allclose(lp, ar.new_action_log_probs, rtol=1e-5, atol=1e-6)
             assert torch.allclose(v, ar.state_values, rtol=1e-5, atol=1e-6)
             assert torch.allclose(ent, ar.entropy, rtol=1e-5, atol=1e-6)
@@ -351,6 +356,40 @@ def gen_popart():
     run_steps("vtpa", dict(C1_POLICY, popart=True, seed=10), dict(popart=True, vtrace=True, max_grad_norm=10.0,
                                                                  optimizer_config=dict(lr=1e-3)), vt_sample, 2, out=out)
     save("steps_popart.npz", **out)
+
+
+def gen_rnn():
+    """Recurrent backbones (GRU + auto reset, chunked analysis from stored states): full steps and a stateful rollout."""
+    out = {}
+    sh_policy = dict(obs_dim=4, action_dim=2, hidden_dim=32, num_dense_layers=1, num_rnn_layers=1, popart=False,
+                     layernorm=True, shared_backbone=True, chunk_len=8, seed=21)
+    sh_sample = dict(T=32, B=6, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.08, policy_state={"hx": (1, 32)})
+    run_steps("gru", sh_policy, dict(popart=False, optimizer_config=dict(lr=1e-3), max_grad_norm=10.0), sh_sample, 3,
+              out=out)
+    # separate backbones, two GRU layers, no LayerNorm in the dense stack (ReLU output feeds the GRU), PopArt head,
+    # the chunk is the whole trajectory
+    sep_policy = dict(obs_dim=4, action_dim=[3, 2], hidden_dim=16, num_dense_layers=2, num_rnn_layers=2, popart=True,
+                      layernorm=False, shared_backbone=False, chunk_len=16, seed=22)
+    sep_sample = dict(T=16, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2], p_done=0.1,
+                      policy_state={"actor_hx": (2, 16), "critic_hx": (2, 16)})
+    run_steps("gru2", sep_policy, dict(popart=True, ppo_epochs=2, optimizer_config=dict(lr=5e-4)), sep_sample, 2, out=out)
+    # stateful deterministic rollout
+    policy = api.policy.make(api.config.Policy("actor-critic", args=sh_policy))
+    policy.eval_mode()
+    rng = np.random.default_rng(6)
+    N = 9
+    obs = rng.standard_normal((N, 4)).astype(np.float32)
+    hx = (0.5 * rng.standard_normal((N, 1, 32))).astype(np.float32)
+    req = api.policy.RolloutRequest(obs=NamedArray(obs=obs), policy_state=NamedArray(hx=hx),
+                                    is_evaluation=np.ones((N, 1), dtype=np.uint8), on_reset=np.zeros((N, 1), dtype=np.uint8))
+    res = policy.rollout(req)
+    out["roll_obs"], out["roll_hx"] = obs, hx
+    out["roll_action"], out["roll_log_probs"], out["roll_value"] = (res.action.x, res.analyzed_result.log_probs,
+                                                                    res.analyzed_result.value)
+    out["roll_new_hx"] = res.policy_state.hx
+    for k, v in sd_to_np(policy.net.state_dict()).items():
+        out[f"roll_param:{k}"] = v
+    save("steps_rnn.npz", **out)
 
 
 def gen_rollout():

@@ -54,6 +54,17 @@ CASES = {
              dict(popart=True, vtrace=True, max_grad_norm=10.0, optimizer_config=dict(lr=1e-3)),
              dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05, p_trunc=0.0), 2,
              "steps_popart.npz"),
+    # recurrent backbones: GRU + auto reset, chunked analysis from the stored states (gen_golden.py gen_rnn)
+    "gru": (dict(obs_dim=4, action_dim=2, hidden_dim=32, num_dense_layers=1, num_rnn_layers=1, popart=False,
+                 layernorm=True, shared_backbone=True, chunk_len=8, seed=21),
+            dict(popart=False, optimizer_config=dict(lr=1e-3), max_grad_norm=10.0),
+            dict(T=32, B=6, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.08, policy_state={"hx": (1, 32)}),
+            3, "steps_rnn.npz"),
+    "gru2": (dict(obs_dim=4, action_dim=[3, 2], hidden_dim=16, num_dense_layers=2, num_rnn_layers=2, popart=True,
+                  layernorm=False, shared_backbone=False, chunk_len=16, seed=22),
+             dict(popart=True, ppo_epochs=2, optimizer_config=dict(lr=5e-4)),
+             dict(T=16, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2], p_done=0.1,
+                  policy_state={"actor_hx": (2, 16), "critic_hx": (2, 16)}), 2, "steps_rnn.npz"),
 }
 
 
@@ -256,3 +267,20 @@ def test_batcher_device_staging_matches_host_concatenation():
         assert np.array_equal(a.client_id, c.client_id) and np.array_equal(a.action.x, c.action.x)
         assert np.array_equal(a.analyzed_result.value, c.analyzed_result.value)
         assert np.array_equal(a.analyzed_result.log_probs, c.analyzed_result.log_probs)
+
+
+def test_recurrent_rollout_golden(golden):
+    """Stateful rollout: [n, layers, H] states in, new states out, against the reference (deterministic actions)."""
+    g = golden("steps_rnn.npz")
+    pol = policy_api.make(config.Policy("actor-critic", args=CASES["gru"][0]))
+    pol.load_checkpoint({"steps": 0, "state_dict": {k[len("roll_param:"):]: torch.from_numpy(g[k]) for k in g.files
+                                                    if k.startswith("roll_param:")}})
+    assert pol.default_policy_state.hx.shape == (1, 32)
+    n = g["roll_obs"].shape[0]
+    req = policy_api.RolloutRequest(obs=NamedArray(obs=g["roll_obs"]), policy_state=NamedArray(hx=g["roll_hx"]),
+                                    is_evaluation=np.ones((n, 1), np.uint8), on_reset=np.zeros((n, 1), np.uint8))
+    res = pol.rollout(req)
+    assert np.array_equal(res.action.x, g["roll_action"])
+    assert close(res.analyzed_result.log_probs, g["roll_log_probs"], 1e-5)
+    assert close(res.analyzed_result.value, g["roll_value"], 1e-5)
+    assert res.policy_state.hx.shape == (n, 1, 32) and close(res.policy_state.hx, g["roll_new_hx"], 1e-5)

@@ -164,3 +164,24 @@ def test_full_step_golden_popart_vtrace(golden, tag, pargs, targs, n_steps, p_tr
     sd = net.state_dict()
     for k in sd:
         assert np.allclose(sd[k].numpy(), g[f"{tag}_step{n_steps - 1}_param:{k}"], rtol=1e-4, atol=1e-6), k
+
+
+def test_full_step_golden_recurrent(golden):
+    """GRU backbone with auto reset and chunked analysis: OracleMappo against the reference (gen_golden.py gen_rnn)."""
+    g = golden("steps_rnn.npz")
+    pargs = dict(obs_dim=4, action_dim=2, hidden_dim=32, num_dense_layers=1, num_rnn_layers=1, popart=False,
+                 layernorm=True, shared_backbone=True, chunk_len=8)
+    net = OracleActorCritic(**pargs)
+    net.load_state_dict({k[len("gru_init_param:"):]: g[k] for k in g.files if k.startswith("gru_init_param:")})
+    tr = OracleMappo(net, popart=False, optimizer_config=dict(lr=1e-3), max_grad_norm=10.0)
+    names = list(g["gru_stat_names"])
+    for step in range(3):
+        arrays = synthetic.make_sample_arrays(seed=100 + step, T=32, B=6, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2,
+                                              p_done=0.08, policy_state={"hx": (1, 32)})
+        stats, _ = tr.step(arrays)
+        ref = dict(zip(names, g[f"gru_step{step}_stats"]))
+        for k in ("policy_loss", "value_loss", "entropy", "grad_norm", "clip_ratio"):
+            assert abs(stats[k] - ref[k]) <= 2e-5 * max(1.0, abs(ref[k])), (step, k)
+    sd = net.state_dict()
+    for k in sd:
+        assert np.allclose(sd[k].numpy(), g[f"gru_step2_param:{k}"], rtol=1e-4, atol=1e-6), k
