@@ -214,9 +214,13 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, uint32_t voff
 // row) decomposition per lane plus an add per quad.
 template <int BX, bool KMAJOR, int MODE>
 struct Stage {
-  // LDS row pitch (floats): with 4 k-quads per row the transposed store of a wavefront hits banks x + 16*kq
-  // (2 lanes per bank, the minimum for 64 lanes), and ds_write_b128 rows stay 16-byte aligned
+  // LDS tile: a k-major operand is stored [BK][BX + 4] (ds_write_b128 along the output index); a k-contiguous one
+  // is stored as it comes, [BX][BK + 4] (ds_write_b128 along k: no transposing scalar stores, which cost 14 % of the
+  // MFMA rate in scripts/mfma_peak.hip).  The +4 keeps rows 16-byte aligned and spreads 8 consecutive rows over
+  // all eight 16-byte bank groups (pitch 20 floats = 5 groups, odd).
   static constexpr int LD = BX + 4;
+  static constexpr int PK = BK + 4;
+  static constexpr int TILE = KMAJOR ? BK * LD : BX * PK;
   static constexpr int QUADS = BX * BK / 4;            // float4 per tile
   static constexpr int NV = (QUADS + 255) / 256;       // float4 per thread
   static constexpr int NF = NV * 4;                    // floats per thread
@@ -393,8 +397,7 @@ struct Stage {
         if (PARTIAL && u >= QUADS) continue;
         if (!KMAJOR) {
           const int x = u / KQ, k = (u % KQ) * 4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) lds[(k + j) * LD + x] = r[4 * q + j];
+          *reinterpret_cast<float4*>(lds + x * PK + k) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
         } else {
           const int k = u / (BX / 4), x = (u % (BX / 4)) * 4;
           *reinterpret_cast<float4*>(lds + k * LD + x) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
@@ -405,7 +408,7 @@ struct Stage {
       for (int q = 0; q < NF; ++q) {
         const int e = tid + q * 256;
         if (PARTIAL && e >= BX * BK) continue;
-        if (!KMAJOR) lds[(e % BK) * LD + e / BK] = r[q];
+        if (!KMAJOR) lds[(e / BK) * PK + e % BK] = r[q];
         else lds[(e / BX) * LD + e % BX] = r[q];
       }
     }
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(256, min_waves(BM, BN, AMODE, BMODE, GEN)) void gem
   static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 wavefronts per workgroup");
   using SA = Stage<BM, AKM, AMODE>;
   using SB = Stage<BN, BKM, BMODE>;
-  constexpr int A_FLOATS = BK * SA::LD, TILE_FLOATS = BK * (SA::LD + SB::LD);  // multiples of 4: 16-byte aligned
+  constexpr int A_FLOATS = SA::TILE, TILE_FLOATS = SA::TILE + SB::TILE;  // multiples of 4: 16-byte aligned
   __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -438,14 +441,22 @@ __global__ __launch_bounds__(256, min_waves(BM, BN, AMODE, BMODE, GEN)) void gem
   const int l31 = lane & 31, h = lane >> 5;
   // grid.x carries (tile, batch) with the batch index fastest when nbatch > 1 (workgroups that run together then
   // share the same rows of the gathered tensor through L2); grid.y is unused in that case
-  const unsigned bx = g.nbatch > 1 ? blockIdx.x / g.nbatch : blockIdx.x;
+  // Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  Renumber them so that every
+  // XCD owns one contiguous run of logical ids: neighbours in (tile, batch) order -- which read the same rows of the
+  // gathered tensor or the same operand panel -- then share an L2 instead of each fetching their own copy.
+  unsigned lid;
+  {
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    lid = xcd * q + (xcd < r ? xcd : r) + slot;
+  }
+  const unsigned bx = g.nbatch > 1 ? lid / g.nbatch : lid;
   const long tile_m = bx / g.tiles_n, tile_n = bx % g.tiles_n;
   const long m0 = tile_m * BM, n0 = tile_n * BN;
   const long kbeg = (long)blockIdx.z * g.k_per_split;
   const long kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
 
   // batch (grid.y): shift the operand bases
-  const int by = g.nbatch > 1 ? (int)(blockIdx.x % g.nbatch) : 0;
+  const int by = g.nbatch > 1 ? (int)(lid % g.nbatch) : 0;
   if (by) {
     const long ao = (long)(by / g.a.brw) * g.a.by_stride + (long)(by % g.a.brw) * g.a.bx_stride;
     const long bo = (long)(by / g.b.brw) * g.b.by_stride + (long)(by % g.b.brw) * g.b.bx_stride;
@@ -484,22 +495,50 @@ __global__ __launch_bounds__(256, min_waves(BM, BN, AMODE, BMODE, GEN)) void gem
   // one k-step on LDS buffer `cur` (compile-time): MFMAs, with the staging of the following tiles in the middle
   auto kstep = [&](auto cur_c, long k0) {
     constexpr int cur = decltype(cur_c)::value;
-    const float* ap = lds + cur * TILE_FLOATS + h * SA::LD + wm * (TM * 32) + l31;
-    const float* bp = lds + cur * TILE_FLOATS + A_FLOATS + h * SB::LD + wn * (TN * 32) + l31;
+    // MFMA step kk consumes k = 8*h + kk of the tile (h = lane >> 5): any pairing of the 16 k values works as long
+    // as both operands use the same one, and this one lets a k-contiguous operand fetch its 8 values with two
+    // ds_read_b128.  A k-major operand reads row 8*h + kk, one step ahead of its MFMAs.
+    const float* ap = lds + cur * TILE_FLOATS +
+                      (AKM ? 8 * h * SA::LD + wm * (TM * 32) + l31 : (wm * (TM * 32) + l31) * SA::PK + 8 * h);
+    const float* bp = lds + cur * TILE_FLOATS + A_FLOATS +
+                      (BKM ? 8 * h * SB::LD + wn * (TN * 32) + l31 : (wn * (TN * 32) + l31) * SB::PK + 8 * h);
     float* nxt = lds + (cur ^ 1) * TILE_FLOATS;
-    // operand registers are double-buffered: the LDS reads of step kk + 1 are in flight under the MFMAs of kk
-    float a[2][TM], b[2][TN];
+    float a[AKM ? 2 : 8][TM], b[BKM ? 2 : 8][TN];
+    if (AKM) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32];
+      for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32];
+    } else {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32];
+      for (int i = 0; i < TM; ++i) {
+        const float4 lo = *reinterpret_cast<const float4*>(ap + i * 32 * SA::PK);
+        const float4 hi = *reinterpret_cast<const float4*>(ap + i * 32 * SA::PK + 4);
+        a[0][i] = lo.x, a[1][i] = lo.y, a[2][i] = lo.z, a[3][i] = lo.w;
+        a[4][i] = hi.x, a[5][i] = hi.y, a[6][i] = hi.z, a[7][i] = hi.w;
+      }
+    }
+    if (BKM) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32];
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float4 lo = *reinterpret_cast<const float4*>(bp + j * 32 * SB::PK);
+        const float4 hi = *reinterpret_cast<const float4*>(bp + j * 32 * SB::PK + 4);
+        b[0][j] = lo.x, b[1][j] = lo.y, b[2][j] = lo.z, b[3][j] = lo.w;
+        b[4][j] = hi.x, b[5][j] = hi.y, b[6][j] = hi.z, b[7][j] = hi.w;
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       if (kk + 1 < BK / 2) {
+        if (AKM) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[(kk + 1) & 1][i] = ap[(kk + 1) * 2 * SA::LD + i * 32];
+          for (int i = 0; i < TM; ++i) a[(kk + 1) & 1][i] = ap[(kk + 1) * SA::LD + i * 32];
+        }
+        if (BKM) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[(kk + 1) & 1][j] = bp[(kk + 1) * 2 * SB::LD + j * 32];
+          for (int j = 0; j < TN; ++j) b[(kk + 1) & 1][j] = bp[(kk + 1) * SB::LD + j * 32];
+        }
       }
       if (kk == BK / 4) {
         if (k0 + BK < kend) {  // tile t+1: registers -> the other LDS buffer (its readers left at the last barrier)
@@ -516,7 +555,7 @@ __global__ __launch_bounds__(256, min_waves(BM, BN, AMODE, BMODE, GEN)) void gem
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[AKM ? (kk & 1) : kk][i], b[BKM ? (kk & 1) : kk][j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();  // tile t+1 is visible; everyone is done reading tile t
   };
