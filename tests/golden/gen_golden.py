@@ -392,6 +392,37 @@ def gen_rnn():
     save("steps_rnn.npz", **out)
 
 
+def gen_paramdb():
+    """Cross-check of the filesystem parameter store with the reference's client on the same directory: each reads
+    what the other wrote; the resulting listing is the fixture."""
+    import tempfile
+    sys.modules.setdefault("pymongo", mock.MagicMock())
+    sys.modules.setdefault("pymongo.errors", mock.MagicMock())
+    import distributed.system.parameter_db as ref_db
+    import base.names
+    from srl_amd.runtime.parameter_db import FilesystemParameterDB
+    with tempfile.TemporaryDirectory() as root:
+        ref_db.PytorchFilesystemParameterDB.ROOT = root
+        ref = ref_db.PytorchFilesystemParameterDB("exp", "trial", user_namespace="ns")
+        ours = FilesystemParameterDB("exp", "trial", root=root, user_namespace="ns")
+        ck = lambda steps: {"steps": steps, "state_dict": {"w": torch.full((3,), float(steps))}}
+        ours.push("pol", ck(5), version="5")
+        ref.push("pol", ck(12), version="12", tags="best")
+        ours.push("pol", ck(20), version="20", tags=["eval"])
+        ref.tag("pol", "5", "first")
+        for v in (30, 40, 50):
+            ours.push("pol", ck(v), version=str(v))
+        assert ref.get("pol")["steps"] == 50 and ours.get("pol", "best")["steps"] == 12
+        assert ref.get("pol", "eval")["state_dict"]["w"][0] == 20 and ours.version_of("pol", "first") == 5
+        assert ref.list_versions("pol") == ours.list_versions("pol") and sorted(ref.list_tags("pol")) == sorted(
+            ours.list_tags("pol"))
+        ours.gc("pol", max_untagged_version_count=1)
+        ref2 = sorted(ref.list_versions("pol"))
+        assert ref2 == sorted(ours.list_versions("pol"))
+        save("paramdb.npz", versions_after_gc=np.array(ref.list_versions("pol")),
+             tags=np.array(sorted(f"{t}={v}" for t, v in ref.list_tags("pol"))), names=np.array(ref.list_names()))
+
+
 def gen_rollout():
     out = {}
     for tag, pargs, obs_spec in [("c1", C1_POLICY, synthetic.CARTPOLE_OBS)]:
