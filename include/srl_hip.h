@@ -121,6 +121,18 @@ int srl_gru_cell_fwd(void* stream, float* gi, float* gh, const float* hin, const
 int srl_gru_cell_bwd(void* stream, const float* dy, const float* carry, const uint8_t* reset_next,
                      float* gates, float* gh, const float* hin, long N, int H, float* dh_direct);
 
+/* LSTM cell (torch.nn.LSTM, gates i|f|g|o): pre [N, 4H] = W_ih x + b_ih + W_hh h_in + b_hh (two srl_gemm calls
+ * accumulating into one block); cin = c(t-1) after the auto reset.  y = h(t), cnew = c(t); pre is overwritten with
+ * the activated gates; hin_next / cin_next (optional, both or neither) = h(t), c(t) * (1 - reset_next). */
+int srl_lstm_cell_fwd(void* stream, float* pre, const float* cin, const uint8_t* reset_next, long N, int H,
+                      float* y, float* cnew, float* hin_next, float* cin_next);
+
+/* carry_h / carry_c = d loss / d (h_in, c_in)(t+1) (both or neither), cut where reset_next.  gates <- d pre (in
+ * place; d gi = d gh for an LSTM), dc_in = d loss / d c_in(t); d loss / d h_in(t) = d pre . W_hh via srl_gemm. */
+int srl_lstm_cell_bwd(void* stream, const float* dy, const float* carry_h, const float* carry_c,
+                      const uint8_t* reset_next, float* gates, const float* cin, const float* cnew, long N,
+                      int H, float* dc_in);
+
 /* Rows of D floats between time-major [T*B] and chunk-major order: dst[(c, k*B + b)] = src[((k*C + c), b)]
  * (modules/utils.py:164-182 `to_chunk`: torch.cat(torch.split(x, C, dim=0), dim=1)); inverse != 0 undoes it. */
 int srl_chunk_rows(void* stream, const float* src, float* dst, int T, int B, int C, int D, int inverse);

@@ -59,7 +59,7 @@ class OracleActorCritic:
         self.shared = shared_backbone
         self.cnn_layers = cnn_layers or {}
         self.num_rnn_layers, self.rnn_type = num_rnn_layers, rnn_type
-        assert rnn_type == "gru" or num_rnn_layers == 0, "oracle restates the GRU variant only"
+        assert rnn_type in ("gru", "lstm") or num_rnn_layers == 0, "oracle restates the GRU and LSTM variants"
         self.params: "OrderedDict[str, torch.Tensor]" = OrderedDict()
 
     # ------------------------------------------------------------------ parameters
@@ -124,6 +124,17 @@ class OracleActorCritic:
         n = torch.tanh(inn + r * hn)
         return (1 - z) * n + z * h
 
+    def _lstm_step(self, prefix, layer, x, hc):
+        """torch.nn.LSTM cell; the AutoResetRNN state is cat(h, c) on the last axis (autoreset_rnn.py:31-39)."""
+        p = lambda n: self._p(f"{prefix}.rnn._AutoResetRNN__net.{n}_l{layer}")
+        H = self.hidden
+        h, c = hc[..., :H], hc[..., H:]
+        pre = F.linear(x, p("weight_ih"), p("bias_ih")) + F.linear(h, p("weight_hh"), p("bias_hh"))
+        i, f, g, o = pre.chunk(4, -1)
+        c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h2 = torch.sigmoid(o) * torch.tanh(c2)
+        return torch.cat([h2, c2], -1)
+
     def _backbone(self, prefix, x, hx, on_reset):
         """dense layers (+GRU with per-step reset of the hidden state) (recurrent_backbone.py:61-66)."""
         act = _act(self.activation)
@@ -143,8 +154,12 @@ class OracleActorCritic:
             inp = x[t]
             for l in range(self.num_rnn_layers):
                 hl = h[l] if on_reset is None else h[l] * (1 - on_reset[t])
-                h[l] = self._gru_step(prefix, l, inp, hl)
-                inp = h[l]
+                if self.rnn_type == "lstm":
+                    h[l] = self._lstm_step(prefix, l, inp, hl)
+                    inp = h[l][..., :self.hidden]
+                else:
+                    h[l] = self._gru_step(prefix, l, inp, hl)
+                    inp = h[l]
             ys.append(inp)
         y = torch.stack(ys, 0)
         y = F.layer_norm(y, (self.hidden,), self._p(f"{prefix}.rnn_norm.weight"), self._p(f"{prefix}.rnn_norm.bias"), 1e-5)

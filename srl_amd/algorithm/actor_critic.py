@@ -95,7 +95,7 @@ class ActorCriticPolicy(policy_api.Policy):
     @property
     def default_policy_state(self):
         """Zeros [layers, H] per backbone, batch dimension stripped (actor_critic_policy.py:229-237)."""
-        L, H = self.spec.num_rnn_layers, self.spec.hidden_dim
+        L, H = self.spec.num_rnn_layers, self.spec.rnn_state_width  # LSTM: cat(h, c) (:223-225)
         if not L:
             return None
         z = lambda: np.zeros((L, H), dtype=np.float32)
@@ -107,7 +107,7 @@ class ActorCriticPolicy(policy_api.Policy):
     def _rnn_ctx(self, policy_state, T, B, on_reset) -> Optional[RnnCtx]:
         """Chunking of [T, B] rows for the recurrent layers (actor_critic_policy.py:349-363): ``T // chunk_len``
         chunks, each starting from the state stored at its first row; ``on_reset`` [T, B, 1] device uint8 or None."""
-        L, H = self.spec.num_rnn_layers, self.spec.hidden_dim
+        L, H = self.spec.num_rnn_layers, self.spec.rnn_state_width
         if not L:
             return None
         if policy_state is None:

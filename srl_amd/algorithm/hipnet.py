@@ -206,12 +206,38 @@ class HipNet:
         else:
             xc = x
         h0 = ctx.h0[tag]
-        assert tuple(h0.shape) == (G.layers, N, H) and h0.dtype == torch.float32 and h0.is_contiguous()
+        SW = G.state_width
+        assert tuple(h0.shape) == (G.layers, N, SW) and h0.dtype == torch.float32 and h0.is_contiguous()
         rs = ctx.reset
         rptr = (lambda c: rs.data_ptr() + c * N) if rs is not None else (lambda c: None)
-        last = self.ws.get(f"{tag}{G.prefix}.last", G.layers * N * H)[:G.layers * N * H].view(G.layers, N, H)
+        last = self.ws.get(f"{tag}{G.prefix}.last", G.layers * N * SW)[:G.layers * N * SW].view(G.layers, N, SW)
         inp, saved = xc, []
-        for l in range(G.layers):
+        for l in range(G.layers if G.kind == "lstm" else 0):
+            w_ih, w_hh = self._p(f"{G.prefix}.weight_ih_l{l}"), self._p(f"{G.prefix}.weight_hh_l{l}")
+            b_ih, b_hh = self._p(f"{G.prefix}.bias_ih_l{l}"), self._p(f"{G.prefix}.bias_hh_l{l}")
+            pre = self._buf(f"{tag}{G.prefix}.gi{l}", n, 4 * H)
+            hin = self._buf(f"{tag}{G.prefix}.hin{l}", n, H)
+            cin = self._buf(f"{tag}{G.prefix}.cin{l}", n, H)
+            cnew = self._buf(f"{tag}{G.prefix}.cnew{l}", n, H)
+            y = self._buf(f"{tag}{G.prefix}.y{l}", n, H)
+            hip.gemm(n, 4 * H, H, inp.ptr, inp.ld, 0, w_ih, H, 0, pre.ptr, 4 * H, bias=b_ih)  # every step at once
+            # the stored state is cat(h, c) per row (autoreset_rnn.py:31-39); both halves are reset together
+            hip.copy2d(h0[l].data_ptr(), SW, y.ptr, H, N, H)
+            hip.gru_mask_state(y.ptr, rptr(0), N, H, hin.ptr)
+            hip.copy2d(h0[l].data_ptr() + 4 * H, SW, y.ptr, H, N, H)
+            hip.gru_mask_state(y.ptr, rptr(0), N, H, cin.ptr)
+            for c in range(C):
+                o4, o1 = 4 * c * N * 4 * H, 4 * c * N * H
+                hip.gemm(N, 4 * H, H, hin.ptr + o1, H, 0, w_hh, H, 0, pre.ptr + o4, 4 * H, bias=b_hh, accumulate=True)
+                nxt = c + 1 < C
+                o1n = 4 * (c + 1) * N * H
+                hip.lstm_cell_fwd(pre.ptr + o4, cin.ptr + o1, rptr(c + 1) if nxt else None, N, H, y.ptr + o1, cnew.ptr + o1,
+                                  hin.ptr + o1n if nxt else None, cin.ptr + o1n if nxt else None)
+            hip.copy2d(y.ptr + 4 * (C - 1) * N * H, H, last[l].data_ptr(), SW, N, H)
+            hip.copy2d(cnew.ptr + 4 * (C - 1) * N * H, H, last[l].data_ptr() + 4 * H, SW, N, H)
+            saved.append((inp, pre, hin, cin, cnew))
+            inp = y
+        for l in range(G.layers if G.kind == "gru" else 0):
             w_ih, w_hh = self._p(f"{G.prefix}.weight_ih_l{l}"), self._p(f"{G.prefix}.weight_hh_l{l}")
             b_ih, b_hh = self._p(f"{G.prefix}.bias_ih_l{l}"), self._p(f"{G.prefix}.bias_hh_l{l}")
             gi = self._buf(f"{tag}{G.prefix}.gi{l}", n, 3 * H)
@@ -250,7 +276,30 @@ class HipNet:
         else:
             dyc = dy
         dout = dyc
-        for l in range(G.layers - 1, -1, -1):
+        for l in range(G.layers - 1 if G.kind == "lstm" else -1, -1, -1):
+            inp, pre, hin, cin, cnew = saved[l]
+            w_ih, w_hh = self._p(f"{G.prefix}.weight_ih_l{l}"), self._p(f"{G.prefix}.weight_hh_l{l}")
+            dh = [self._buf(f"{tag}{G.prefix}.dh{i}", N, H) for i in range(2)]
+            dc = [self._buf(f"{tag}{G.prefix}.dc{i}", N, H) for i in range(2)]
+            ch = cc = None
+            for c in range(C - 1, -1, -1):
+                o4, o1 = 4 * c * N * 4 * H, 4 * c * N * H
+                hip.lstm_cell_bwd(dout.ptr + 4 * c * N * dout.ld, ch, cc, rptr(c + 1) if c + 1 < C else None, pre.ptr + o4,
+                                  cin.ptr + o1, cnew.ptr + o1, N, H, dc[c & 1].ptr)
+                hip.gemm(N, H, 4 * H, pre.ptr + o4, 4 * H, 0, w_hh, H, 1, dh[c & 1].ptr, H)  # d h_in(c) = d pre . W_hh
+                ch, cc = dh[c & 1].ptr, dc[c & 1].ptr
+            self._wgrad(4 * H, H, n, pre, hin.ptr, H, self._g(f"{G.prefix}.weight_hh_l{l}"))
+            hip.colsum(pre.ptr, 4 * H, n, 4 * H, self._g(f"{G.prefix}.bias_hh_l{l}"), accumulate=True)
+            self._wgrad(4 * H, H, n, pre, inp.ptr, inp.ld, self._g(f"{G.prefix}.weight_ih_l{l}"))
+            hip.colsum(pre.ptr, 4 * H, n, 4 * H, self._g(f"{G.prefix}.bias_ih_l{l}"), accumulate=True)
+            if l == 0 and not need_dx:
+                return None
+            dx = self._buf(f"{tag}{G.prefix}.dx{l}", n, H)
+            act = in_act if l == 0 else 0
+            hip.gemm(n, H, 4 * H, pre.ptr, 4 * H, 0, w_ih, H, 1, dx.ptr, H, dact_src=inp.ptr if act else None,
+                     ld_dact=inp.ld, dact=act)
+            dout = dx
+        for l in range(G.layers - 1 if G.kind == "gru" else -1, -1, -1):
             inp, gi, gh, hin = saved[l]
             w_ih, w_hh = self._p(f"{G.prefix}.weight_ih_l{l}"), self._p(f"{G.prefix}.weight_hh_l{l}")
             dh = [self._buf(f"{tag}{G.prefix}.dh{i}", N, H) for i in range(2)]

@@ -103,6 +103,15 @@ class GruSpec:
     prefix: str  # "<backbone>.rnn._AutoResetRNN__net"
     hidden: int
     layers: int
+    kind: str = "gru"  # "lstm": gates i|f|g|o ([4H, H] weights); the stored state is cat(h, c) (autoreset_rnn.py:31-39)
+
+    @property
+    def gates(self):
+        return 4 if self.kind == "lstm" else 3
+
+    @property
+    def state_width(self):
+        return 2 * self.hidden if self.kind == "lstm" else self.hidden
 
 
 @dataclasses.dataclass
@@ -149,7 +158,8 @@ class NetSpec:
     params: "OrderedDict[str, ParamInfo]"
     total_params: int
     popart: bool = False  # critic head is a PopArtValueHead: float64 running statistics ride along (POPART_KEYS)
-    num_rnn_layers: int = 0  # GRU layers at the end of each backbone (GruSpec + the rnn_norm LayerNormSpec)
+    num_rnn_layers: int = 0  # GRU / LSTM layers at the end of each backbone (GruSpec + the rnn_norm LayerNormSpec)
+    rnn_state_width: int = 0  # per-layer width of the stored policy state (H, or 2H for LSTM: cat(h, c))
 
 
 # state_dict keys of the PopArt head (popart.py:21-22,30-31; modules/utils.py:80-82), in the reference's order
@@ -287,7 +297,7 @@ def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, a
 
 
 def _build_backbone(b: _Builder, root: str, in_dim: int, hidden: int, dense_layers: int, act: int, layernorm: bool,
-                    num_rnn_layers: int = 0):
+                    num_rnn_layers: int = 0, rnn_type: str = "gru"):
     layers = []
     stride = 3 if layernorm else 2
     names = []
@@ -313,18 +323,19 @@ def _build_backbone(b: _Builder, root: str, in_dim: int, hidden: int, dense_laye
         # recurrent_backbone.py:54-58: orthogonal (gain 1) on the matrices, zeros on the biases
         rp = f"{root}.rnn._AutoResetRNN__net"
         bound = 1.0 / math.sqrt(hidden)
+        ng = 4 if rnn_type == "lstm" else 3
         for l in range(num_rnn_layers):
-            b.uniform(f"{rp}.weight_ih_l{l}", (3 * hidden, hidden), bound)
-            b.uniform(f"{rp}.weight_hh_l{l}", (3 * hidden, hidden), bound)
-            b.uniform(f"{rp}.bias_ih_l{l}", (3 * hidden,), bound)
-            b.uniform(f"{rp}.bias_hh_l{l}", (3 * hidden,), bound)
+            b.uniform(f"{rp}.weight_ih_l{l}", (ng * hidden, hidden), bound)
+            b.uniform(f"{rp}.weight_hh_l{l}", (ng * hidden, hidden), bound)
+            b.uniform(f"{rp}.bias_ih_l{l}", (ng * hidden,), bound)
+            b.uniform(f"{rp}.bias_hh_l{l}", (ng * hidden,), bound)
         b.layernorm(f"{root}.rnn_norm", hidden)
         for l in range(num_rnn_layers):
             b.orthogonal(f"{rp}.weight_ih_l{l}", 1.0)
             b.orthogonal(f"{rp}.weight_hh_l{l}", 1.0)
             b.zero(f"{rp}.bias_ih_l{l}")
             b.zero(f"{rp}.bias_hh_l{l}")
-        layers.append(GruSpec(rp, hidden, num_rnn_layers))
+        layers.append(GruSpec(rp, hidden, num_rnn_layers, rnn_type))
         layers.append(LayerNormSpec(f"{root}.rnn_norm", hidden))
     return layers
 
@@ -335,8 +346,8 @@ def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim
                   rnn_type="gru", **_unused):
     """Returns ``(NetSpec, values)``; ``values`` is the name -> CPU tensor dict of initial weights (reference
     layout) when ``seed`` is given, else ``None``."""
-    if num_rnn_layers and rnn_type != "gru":
-        raise NotImplementedError(f"rnn_type `{rnn_type}`: only the GRU variant of AutoResetRNN is on the HIP path")
+    if num_rnn_layers and rnn_type not in ("gru", "lstm"):
+        raise NotImplementedError(f"rnn_type `{rnn_type}`: only the GRU and LSTM cells of AutoResetRNN are on the HIP path")
     if continuous_action or auxiliary_head:
         raise NotImplementedError("continuous actions / auxiliary value head are not on the HIP path")
     if use_maxpool and any(use_maxpool.values()):
@@ -357,23 +368,23 @@ def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim
         torch.set_num_threads(1)
     try:
         return _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation,
-                      layernorm, shared_backbone, seed, popart, num_rnn_layers)
+                      layernorm, shared_backbone, seed, popart, num_rnn_layers, rnn_type)
     finally:
         torch.set_num_threads(threads)
 
 
 def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation, layernorm,
-           shared_backbone, seed, popart=False, num_rnn_layers=0):
+           shared_backbone, seed, popart=False, num_rnn_layers=0, rnn_type="gru"):
     b = _Builder(seed)
     obs_enc = _build_encoders(b, "obs_modules_dict", obs_dims, hidden_dim, act, activation, cnn_layers)
     actor_bb = _build_backbone(b, "actor_backbone", hidden_dim * len(obs_dims), hidden_dim, num_dense_layers, act,
-                               layernorm, num_rnn_layers)
+                               layernorm, num_rnn_layers, rnn_type)
     state_enc = critic_bb = None
     if not shared_backbone:
         sdims = state_dim or obs_dims
         state_enc = _build_encoders(b, "state_modules_dict", sdims, hidden_dim, act, activation, cnn_layers)
         critic_bb = _build_backbone(b, "critic_backbone", hidden_dim * len(sdims), hidden_dim, num_dense_layers, act,
-                                    layernorm, num_rnn_layers)
+                                    layernorm, num_rnn_layers, rnn_type)
     b.linear("actor_head", hidden_dim, sum(act_dims))
     b.orthogonal("actor_head.weight", 0.01)  # actor_critic_policy.py:109-112
     b.zero("actor_head.bias")
@@ -396,5 +407,6 @@ def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num
         off += (info.numel + 3) // 4 * 4  # 16-byte aligned starts (float4 staging in the GEMM)
     spec = NetSpec(obs_enc, actor_bb, state_enc, critic_bb, LinearSpec("actor_head", hidden_dim, sum(act_dims), 0),
                    LinearSpec("critic_head", hidden_dim, value_dim, 0), act_dims, hidden_dim, value_dim, shared_backbone,
-                   b.params, off, popart, num_rnn_layers)
+                   b.params, off, popart, num_rnn_layers,
+                   (2 * hidden_dim if rnn_type == "lstm" else hidden_dim) if num_rnn_layers else 0)
     return spec, (b.values if b.init else None)

@@ -60,6 +60,51 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* dy, cons
   }
 }
 
+// LSTM (torch.nn.LSTM gate order i|f|g|o).  pre = W_ih x + b_ih + W_hh h_in + b_hh (both GEMMs accumulate into one
+// block).  c' = s(f)*c_in + s(i)*tanh(g), h = s(o)*tanh(c').  pre is overwritten with the activated gates.
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float* pre, const float* cin, const uint8_t* reset_next,
+                                                            long N, int H, float* y, float* cnew, float* hin_next,
+                                                            float* cin_next) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N * H; i += (long)gridDim.x * 256) {
+    const long row = i / H;
+    const int j = (int)(i - row * H);
+    float* p = pre + row * 4 * H;
+    const float gi = sigmoidf_(p[j]), gf = sigmoidf_(p[H + j]), gg = tanhf(p[2 * H + j]), go = sigmoidf_(p[3 * H + j]);
+    const float c2 = gf * cin[i] + gi * gg;
+    const float h = go * tanhf(c2);
+    p[j] = gi, p[H + j] = gf, p[2 * H + j] = gg, p[3 * H + j] = go;
+    y[i] = h;
+    cnew[i] = c2;
+    if (hin_next) {
+      const bool rs = reset_next && reset_next[row];
+      hin_next[i] = rs ? 0.f : h;
+      cin_next[i] = rs ? 0.f : c2;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* dy, const float* carry_h, const float* carry_c,
+                                                            const uint8_t* reset_next, float* gates, const float* cin,
+                                                            const float* cnew, long N, int H, float* dc_in) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N * H; i += (long)gridDim.x * 256) {
+    const long row = i / H;
+    const int j = (int)(i - row * H);
+    float* g = gates + row * 4 * H;
+    const bool cut = reset_next && reset_next[row];
+    float dh = dy ? dy[i] : 0.f;
+    float dc = 0.f;
+    if (carry_h && !cut) { dh += carry_h[i]; dc = carry_c[i]; }
+    const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
+    const float tc = tanhf(cnew[i]);
+    dc += dh * go * (1.0f - tc * tc);
+    g[j] = dc * gg * gi * (1.0f - gi);
+    g[H + j] = dc * cin[i] * gf * (1.0f - gf);
+    g[2 * H + j] = dc * gi * (1.0f - gg * gg);
+    g[3 * H + j] = dh * tc * go * (1.0f - go);
+    dc_in[i] = dc * gf;
+  }
+}
+
 // dst row (c, k*B + b) <- src row ((k*C + c)*B + b)   (inverse: the other way round); rows of D floats
 __global__ __launch_bounds__(256) void chunk_rows_kernel(const float* src, float* dst, int T, int B, int C, int D,
                                                          int inverse) {
@@ -107,6 +152,29 @@ extern "C" int srl_gru_cell_bwd(void* stream, const float* dy, const float* carr
   SRL_CHECK_ARG(gates && gh && hin && dh_direct, "null tensor");
   hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(grid_for(N * H)), dim3(256), 0, (hipStream_t)stream, dy, carry,
                      reset_next, gates, gh, hin, N, H, dh_direct);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_lstm_cell_fwd(void* stream, float* pre, const float* cin, const uint8_t* reset_next, long N, int H,
+                                 float* y, float* cnew, float* hin_next, float* cin_next) {
+  SRL_CHECK_ARG(N >= 0 && H >= 1, "bad extents");
+  if (N == 0) return 0;
+  SRL_CHECK_ARG(pre && cin && y && cnew && (!hin_next == !cin_next), "null tensor");
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_for(N * H)), dim3(256), 0, (hipStream_t)stream, pre, cin, reset_next,
+                     N, H, y, cnew, hin_next, cin_next);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_lstm_cell_bwd(void* stream, const float* dy, const float* carry_h, const float* carry_c,
+                                 const uint8_t* reset_next, float* gates, const float* cin, const float* cnew, long N,
+                                 int H, float* dc_in) {
+  SRL_CHECK_ARG(N >= 0 && H >= 1, "bad extents");
+  if (N == 0) return 0;
+  SRL_CHECK_ARG(gates && cin && cnew && dc_in && (!carry_h == !carry_c), "null tensor");
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for(N * H)), dim3(256), 0, (hipStream_t)stream, dy, carry_h, carry_c,
+                     reset_next, gates, cin, cnew, N, H, dc_in);
   SRL_LAUNCH_CHECK();
   return 0;
 }

@@ -80,6 +80,10 @@ _SIGNATURES = {
     "srl_gru_cell_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "srl_gru_cell_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
                                  c_void_p]),
+    "srl_lstm_cell_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
+    "srl_lstm_cell_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long,
+                                  c_int, c_void_p]),
     "srl_chunk_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "srl_ppo_loss_fwd_bwd": (c_int, [c_void_p] + [c_void_p] * 8 + [c_long, POINTER(PpoHparams)] + [c_void_p] * 8),
     "srl_categorical_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, POINTER(c_int32),
@@ -257,6 +261,16 @@ def gru_cell_fwd(gi_ptr, gh_ptr, hin_ptr, reset_next_ptr, N, H, y_ptr, hin_next_
 def gru_cell_bwd(dy_ptr, carry_ptr, reset_next_ptr, gates_ptr, gh_ptr, hin_ptr, N, H, dh_direct_ptr):
     _check(lib().srl_gru_cell_bwd(_stream(), dy_ptr, carry_ptr, reset_next_ptr, gates_ptr, gh_ptr, hin_ptr, int(N), int(H),
                                   dh_direct_ptr), "srl_gru_cell_bwd")
+
+
+def lstm_cell_fwd(pre_ptr, cin_ptr, reset_next_ptr, N, H, y_ptr, cnew_ptr, hin_next_ptr, cin_next_ptr):
+    _check(lib().srl_lstm_cell_fwd(_stream(), pre_ptr, cin_ptr, reset_next_ptr, int(N), int(H), y_ptr, cnew_ptr, hin_next_ptr,
+                                   cin_next_ptr), "srl_lstm_cell_fwd")
+
+
+def lstm_cell_bwd(dy_ptr, carry_h_ptr, carry_c_ptr, reset_next_ptr, gates_ptr, cin_ptr, cnew_ptr, N, H, dc_in_ptr):
+    _check(lib().srl_lstm_cell_bwd(_stream(), dy_ptr, carry_h_ptr, carry_c_ptr, reset_next_ptr, gates_ptr, cin_ptr, cnew_ptr,
+                                   int(N), int(H), dc_in_ptr), "srl_lstm_cell_bwd")
 
 
 def chunk_rows(src_ptr, dst_ptr, T, B, C, D, inverse=False):

@@ -373,6 +373,11 @@ def gen_rnn():
     sep_sample = dict(T=16, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2], p_done=0.1,
                       policy_state={"actor_hx": (2, 16), "critic_hx": (2, 16)})
     run_steps("gru2", sep_policy, dict(popart=True, ppo_epochs=2, optimizer_config=dict(lr=5e-4)), sep_sample, 2, out=out)
+    # LSTM cell: the stored state is cat(h, c); shared backbone, two layers, chunks of 4
+    lstm_policy = dict(obs_dim=4, action_dim=2, hidden_dim=16, num_dense_layers=1, num_rnn_layers=2, rnn_type="lstm",
+                       popart=False, layernorm=True, shared_backbone=True, chunk_len=4, seed=23)
+    lstm_sample = dict(T=16, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.1, policy_state={"hx": (2, 32)})
+    run_steps("lstm", lstm_policy, dict(popart=False, optimizer_config=dict(lr=1e-3)), lstm_sample, 2, out=out)
     # stateful deterministic rollout
     policy = api.policy.make(api.config.Policy("actor-critic", args=sh_policy))
     policy.eval_mode()

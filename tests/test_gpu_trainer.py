@@ -65,6 +65,11 @@ CASES = {
              dict(popart=True, ppo_epochs=2, optimizer_config=dict(lr=5e-4)),
              dict(T=16, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2], p_done=0.1,
                   policy_state={"actor_hx": (2, 16), "critic_hx": (2, 16)}), 2, "steps_rnn.npz"),
+    "lstm": (dict(obs_dim=4, action_dim=2, hidden_dim=16, num_dense_layers=1, num_rnn_layers=2, rnn_type="lstm",
+                  popart=False, layernorm=True, shared_backbone=True, chunk_len=4, seed=23),
+             dict(popart=False, optimizer_config=dict(lr=1e-3)),
+             dict(T=16, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.1, policy_state={"hx": (2, 32)}),
+             2, "steps_rnn.npz"),
 }
 
 
