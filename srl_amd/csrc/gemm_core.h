@@ -212,7 +212,7 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, uint32_t voff
 // k-contiguous operand, columns for a k-major one), validity, LayerNorm statistics.  Per k-tile a dense operand costs
 // no vector ALU work at all (the descriptor base advances on the scalar unit); a gathered one costs one column (or
 // row) decomposition per lane plus an add per quad.
-template <int BX, bool KMAJOR, int MODE>
+template <int BX, bool KMAJOR, int MODE, int NT = 256>
 struct Stage {
   // LDS tile: a k-major operand is stored [BK][BX + 4] (ds_write_b128 along the output index); a k-contiguous one
   // is stored as it comes, [BX][BK + 4] (ds_write_b128 along k: no transposing scalar stores, which cost 14 % of the
@@ -222,9 +222,9 @@ struct Stage {
   static constexpr int PK = BK + 4;
   static constexpr int TILE = KMAJOR ? BK * LD : BX * PK;
   static constexpr int QUADS = BX * BK / 4;            // float4 per tile
-  static constexpr int NV = (QUADS + 255) / 256;       // float4 per thread
+  static constexpr int NV = (QUADS + NT - 1) / NT;       // float4 per thread
   static constexpr int NF = NV * 4;                    // floats per thread
-  static constexpr bool PARTIAL = QUADS < NV * 256;    // narrow tiles: only threads with u < QUADS stage
+  static constexpr bool PARTIAL = QUADS < NV * NT;    // narrow tiles: only threads with u < QUADS stage
   static constexpr int KQ = BK / 4;                    // quads per k-contiguous row
   static constexpr bool GATHER = MODE != SRC_PLAIN;
   float r[NF];
@@ -251,7 +251,7 @@ struct Stage {
       else { cur = static_cast<const char*>(s.base) + (kbeg * ld + x0) * 4; step = (long)BK * ld * 4; }
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
-        const int u = tid + q * 256;
+        const int u = tid + q * NT;
         if (!KMAJOR) voff[q] = x0 + u / KQ < xn ? (uint32_t)(((u / KQ) * ld + (u % KQ) * 4) * 4) : kInvalidOff;
         else voff[q] = x0 + (u % (BX / 4)) * 4 < xn ? (uint32_t)(((u / (BX / 4)) * ld + (u % (BX / 4)) * 4) * 4) : kInvalidOff;
         if (PARTIAL && u >= QUADS) voff[q] = kInvalidOff;
@@ -262,7 +262,7 @@ struct Stage {
     step = 0;
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
-      const int u = tid + q * 256;
+      const int u = tid + q * NT;
       if (!KMAJOR) {
         const long x = x0 + u / KQ;
         const RowInfo ri = row_info<MODE>(s, (uint32_t)(x < xn ? x : xn - 1));
@@ -311,8 +311,8 @@ struct Stage {
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-          const int u = tid + q * 256;
-          const long k = k0 + (BX == 256 ? wave + 4 * q : u / (BX / 4));
+          const int u = tid + q * NT;
+          const long k = k0 + (BX == 256 ? wave + (NT / 64) * q : u / (BX / 4));
           const bool ok = k < kend && voff[q] != kInvalidOff;
           const RowInfo ri = row_info<MODE>(s, (uint32_t)(k < kend ? k : kend - 1));
           const uint32_t o = ok ? voff[q] + (uint32_t)ri.off * esz : kInvalidOff;
@@ -335,7 +335,7 @@ struct Stage {
       const long kleft = kend - k0;  // > 0
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
-        const int u = tid + q * 256;
+        const int u = tid + q * NT;
         const bool kok = !KMAJOR ? (tid % KQ) * 4 < kleft : u / (BX / 4) < kleft;
         const float4 v = bload4(rs, kok ? voff[q] : kInvalidOff);
         r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
@@ -346,7 +346,7 @@ struct Stage {
     const long ld = s.ld;
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
-      const int e = tid + q * 256;
+      const int e = tid + q * NT;
       float v = 0.f;
       if (PARTIAL && e >= BX * BK) {
       } else if (!KMAJOR) {
@@ -393,7 +393,7 @@ struct Stage {
     if (vec || GATHER) {
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
-        const int u = tid + q * 256;
+        const int u = tid + q * NT;
         if (PARTIAL && u >= QUADS) continue;
         if (!KMAJOR) {
           const int x = u / KQ, k = (u % KQ) * 4;
@@ -406,7 +406,7 @@ struct Stage {
     } else {
 #pragma unroll
       for (int q = 0; q < NF; ++q) {
-        const int e = tid + q * 256;
+        const int e = tid + q * NT;
         if (PARTIAL && e >= BX * BK) continue;
         if (!KMAJOR) lds[(e / BK) * PK + e % BK] = r[q];
         else lds[(e / BX) * LD + e % BX] = r[q];
@@ -420,7 +420,8 @@ struct Stage {
 // Wavefronts per SIMD the register allocator is asked to fit (second __launch_bounds__ argument on AMD): three
 // workgroups per CU for the 64-accumulator tiles, four for the 32-accumulator ones; fewer where the gather state
 // of the observation modes (or the element-wise staging of GEN) would otherwise spill.
-constexpr int min_waves(int bm, int bn, int amode, int bmode, bool gen) {
+constexpr int min_waves(int bm, int bn, int amode, int bmode, bool gen, int nwaves = 4) {
+  if (nwaves == 8) return 2;  // one 8-wavefront workgroup per CU (LDS-bound): 2 wavefronts per SIMD
   const bool big = bm * bn >= 16384;
   if (gen || amode == SRC_OBS || bmode == SRC_OBS) return 1;
   if (amode == SRC_OBSN || bmode == SRC_OBSN) return big ? 2 : 3;
@@ -428,11 +429,12 @@ constexpr int min_waves(int bm, int bn, int amode, int bmode, bool gen) {
 }
 
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN>
-__global__ __launch_bounds__(256, min_waves(BM, BN, AMODE, BMODE, GEN)) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, WM * WN)) void gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 wavefronts per workgroup");
-  using SA = Stage<BM, AKM, AMODE>;
-  using SB = Stage<BN, BKM, BMODE>;
+  static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1, "4 or 8 wavefronts per workgroup");
+  constexpr int NT = WM * WN * 64;
+  using SA = Stage<BM, AKM, AMODE, NT>;
+  using SB = Stage<BN, BKM, BMODE, NT>;
   constexpr int A_FLOATS = SA::TILE, TILE_FLOATS = SA::TILE + SB::TILE;  // multiples of 4: 16-byte aligned
   __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
 
@@ -690,7 +692,7 @@ inline int launch(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   const long nblk = tiles_m * a.tiles_n * a.nbatch;
   if (nblk > 0x7fffffffL || nsplit > 65535) return -EINVAL;
   dim3 grid((unsigned)nblk, 1, (unsigned)nsplit);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, GEN>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, GEN>), grid, dim3(WM * WN * 64), 0, st, a);
   return 0;
 }
 #endif
