@@ -341,10 +341,14 @@ int srl_grad_sumsq(void* stream, const float* g, int64_t n, double* sumsq);
 /* Adam step with the clip coefficient min(1, max_norm / (sqrt(sumsq) + 1e-6)) applied to g on the
  * fly (max_norm < 0: no clipping; sumsq may then be NULL).  grad_scale multiplies g first
  * (1/world_size for the DDP mean).  step is the 1-based step count; weight_decay is decoupled
- * (AdamW) when adamw != 0, L2 (added to g) otherwise.  grad_norm_out float32[1] or NULL. */
+ * (AdamW) when adamw != 0, L2 (added to g) otherwise.  grad_norm_out float32[1] or NULL.
+ * step_scalars: NULL, or device float32[2] = {lr / (1 - beta1^step), sqrt(1 - beta2^step)} read by the kernel
+ * instead of deriving them from `step` -- the launch then carries no per-step scalar and can sit in a captured
+ * hipGraph that is replayed every step (the caller refreshes the two floats before each replay). */
 int srl_adam_step(void* stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int adamw, int64_t step, float grad_scale,
-                  float max_norm, const double* sumsq, float* grad_norm_out);
+                  float max_norm, const double* sumsq, float* grad_norm_out,
+                  const float* step_scalars);
 
 #ifdef __cplusplus
 }

@@ -167,10 +167,11 @@ class ActorCriticPolicy(policy_api.Policy):
             dist.all_reduce(stats)
         self.update_popart_from_stats(stats)
 
-    def update_popart_from_stats(self, stats):
+    def update_popart_from_stats(self, stats, count=True):
         """stats float64 [value_dim, 3] = (sum mask, sum x*mask, sum (x*mask)^2), already all-reduced."""
-        self._popart_updates += 1
-        rescale = self._popart_updates > self._popart_burn_in  # popart.py:49 (burn_in_updates = inf: never)
+        if count:
+            self._popart_updates += 1
+        rescale = self._popart_updates + (0 if count else 1) > self._popart_burn_in  # popart.py:49 (inf: never)
         net, head = self._net, self.spec.critic_head
         hip.popart_update(stats, net.popart_state, self.spec.value_dim, ns.POPART_BETA, ns.POPART_EPS,
                           net._p(f"{head.prefix}.weight"), net._p(f"{head.prefix}.bias"), head.in_features, rescale)

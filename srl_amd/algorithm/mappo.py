@@ -109,6 +109,10 @@ class MultiAgentPPO(PytorchTrainer):
         self.chunk_rows = int(g("chunk_rows", 16384))
         self._world = 1
         self._dist = False
+        # capture the device part of a step into a hipGraph per sample signature and replay it (launch-bound small
+        # configurations; needs device-resident or equal-shaped samples; not with a process group)
+        self.use_graph = bool(g("use_graph", False))
+        self._graphs = {}
 
     # ------------------------------------------------------------------ checkpoints (mappo.py:58-66)
     def get_checkpoint(self):
@@ -182,40 +186,150 @@ class MultiAgentPPO(PytorchTrainer):
         if self.recompute_adv_on_reuse:
             sample.analyzed_result.adv = sample.analyzed_result.ret = None  # :224-225
 
-        on_reset = to_device_leaf(sample.on_reset, dev, "flag")
-        done = to_device_leaf(sample.done, dev, "flag")
-        truncated = to_device_leaf(sample.truncated, dev, "flag")
-        reward = to_device_leaf(sample.reward, dev, "real")
-        old_value = to_device_leaf(sample.analyzed_result.value, dev, "real")
-        old_lp = to_device_leaf(sample.analyzed_result.log_probs, dev, "real")
-        action = to_device_leaf(sample.action.x, dev, "index")
-        obs = {k: to_device_leaf(v, dev, "obs") for k, v in sample.obs.items() if v is not None}
-        avail = obs.pop("available_action", None)
+        # ---- the sample's leaves on the device, in their wire dtypes ---------------------------------------------------
+        L = dict(on_reset=to_device_leaf(sample.on_reset, dev, "flag"), done=to_device_leaf(sample.done, dev, "flag"),
+                 truncated=to_device_leaf(sample.truncated, dev, "flag"), reward=to_device_leaf(sample.reward, dev, "real"),
+                 old_value=to_device_leaf(sample.analyzed_result.value, dev, "real"),
+                 old_lp=to_device_leaf(sample.analyzed_result.log_probs, dev, "real"),
+                 action=to_device_leaf(sample.action.x, dev, "index"))
+        for k, v in sample.obs.items():
+            if v is not None:
+                L[f"obs.{k}"] = to_device_leaf(v, dev, "obs")
+        have_adv = sample.analyzed_result.adv is not None
+        if have_adv:
+            L["adv"] = to_device_leaf(sample.analyzed_result.adv, dev, "real")
+            L["ret"] = to_device_leaf(sample.analyzed_result.ret, dev, "real")
+        if net.spec.num_rnn_layers:
+            if sample.policy_state is None:
+                raise ValueError("recurrent policy: the sample carries no policy_state")
+            for k, v in sample.policy_state.items():
+                L[f"policy_state.{k}"] = to_device_leaf(v, dev, "real")
 
-        Tb, B = on_reset.shape[0], on_reset.shape[1]
+        Tb, B = L["on_reset"].shape[0], L["on_reset"].shape[1]
         boot, burn = self.bootstrap_steps, self.burn_in_steps
         lo, hi = burn, Tb - boot  # valid rows (mappo.py:259)
         n_valid = (hi - lo) * B
-        Nc = old_value.shape[2] if old_value.dim() > 2 else 1
+        Nc = L["old_value"].shape[2] if L["old_value"].dim() > 2 else 1
         if Nc != 1:
             raise NotImplementedError("value_dim > 1 through the PPO loss is not on the HIP path (the scan supports it)")
+        if not have_adv and boot == 0:
+            raise ValueError("bootstrap_steps == 0 requires advantages computed before the trainer")
 
+        # ---- the device part: everything between "leaves in HBM" and "terms ready"; no host synchronisation inside, so
+        # it can be captured once into a hipGraph and replayed (use_graph) -----------------------------------------
+        scal = self._step_scalars(self.ppo_epochs) if self.use_graph and not self._dist else None
+        if scal is not None:
+            out = self._replay(L, have_adv, scal)
+        else:
+            out = self._device_part(L, have_adv, None)
+        self._opt_steps += self.ppo_epochs
+        if self.popart:
+            self.policy._popart_updates += self.ppo_epochs
+
+        # ---- statistics: the only device->host synchronisation of the step (the reference syncs ~11 times per epoch) ------
+        host = out["terms"].cpu().numpy()  # [epochs, LT_COUNT + 1 (+ 2 with PopArt)]
+        train_stats = defaultdict(float)
+        for row in host:
+            msum = max(row[hip.LT_MASK], 1e-30)
+            if self.popart:  # PPOStepResult.denorm_value: masked mean of the de-normalised targets (:215)
+                train_stats["denorm_value"] += row[hip.LT_COUNT + 2] / max(row[hip.LT_COUNT + 1], 1e-30)
+            for key, slot in _STAT_TERMS:
+                train_stats[key] += row[slot] / msum
+            train_stats["done"] += row[hip.LT_DONE] / max(n_valid, 1)
+            train_stats["truncated"] += row[hip.LT_TRUNC] / max(n_valid, 1)
+            train_stats["grad_norm"] += row[hip.LT_COUNT]
+        for k in train_stats:
+            train_stats[k] /= self.ppo_epochs
+
+        # advantages / returns go back into the numpy sample so that a re-used buffer entry carries them (:254-257)
+        adv_d, ret_d = out["adv"], out["ret"]
+        if not have_adv and not isinstance(sample.reward, torch.Tensor):
+            sample.analyzed_result.adv = adv_d.cpu().numpy()
+            sample.analyzed_result.ret = ret_d.cpu().numpy()
+        elif not have_adv:
+            sample.analyzed_result.adv, sample.analyzed_result.ret = adv_d.clone(), ret_d.clone()
+        if self.recompute_adv_among_epochs:
+            sample.analyzed_result.adv = sample.analyzed_result.ret = None
+
+        self.policy.inc_version()  # once per step, not per epoch (:305-307)
+        if self.entropy_decay_per_steps and self.policy.version % self.entropy_decay_per_steps == 0:
+            self.entropy_bonus_weight *= self.entropy_bonus_decay
+            self._hp.entropy_bonus_weight = self.entropy_bonus_weight
+            self._graphs.clear()  # the coefficient is baked into captured launches
+
+        self.frames += n_valid
+        info = {}
+        if sample.info_mask is not None and sample.info is not None:
+            im = sample.info_mask[lo:hi]
+            im = im.cpu().numpy() if isinstance(im, torch.Tensor) else np.asarray(im)
+            elapsed = im.sum()
+            if elapsed > 0:
+                info = recursive_apply(sample.info[lo:hi] * im, lambda x: x.sum()) / elapsed
+                info = {k: float(v) for k, v in info.items()}
+        stats = dict(frames=int(self.frames), **{k: float(v) for k, v in train_stats.items()}, **info)
+        return TrainerStepResult(stats=stats, step=self.policy.version)
+
+    # ------------------------------------------------------------------ hipGraph capture of the device part
+    def _step_scalars(self, epochs):
+        """Adam bias corrections of the next `epochs` optimiser steps, float32 [epochs, 2] (what srl_adam_step derives
+        from its `step` argument, precomputed so that the captured launch carries no per-step scalar)."""
+        rows = []
+        for e in range(1, epochs + 1):
+            t = self._opt_steps + e
+            rows.append([self._lr / (1.0 - self._betas[0]**t), (1.0 - self._betas[1]**t)**0.5])
+        return torch.tensor(rows, dtype=torch.float32)
+
+    def _replay(self, L, have_adv, scal):
+        key = (have_adv,) + tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(L.items()))
+        if key not in self._graphs:
+            # first sight of this signature: run it eagerly (loads every kernel, sizes the workspaces), capture next time
+            self._graphs[key] = None
+            return self._device_part(L, have_adv, None)
+        ent = self._graphs[key]
+        if ent is None:
+            static = {k: v.clone() for k, v in L.items()}
+            dscal = scal.to(self.policy.device)
+            side = torch.cuda.Stream(device=self.policy.device)
+            side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                out = self._device_part(static, have_adv, dscal)
+            ent = (graph, static, dscal, out)
+            self._graphs[key] = ent
+        graph, static, dscal, out = ent
+        for k, v in L.items():
+            static[k].copy_(v, non_blocking=True)
+        dscal.copy_(scal, non_blocking=True)
+        graph.replay()
+        return out
+
+    def _device_part(self, L, have_adv, dscal):
+        """GAE / statistics / (PopArt) / epochs x (forward, loss, backward, [all-reduce], clip + Adam).  Returns device
+        tensors only: per-epoch loss terms, and the padded advantages / value targets."""
+        dev = self.policy.device
+        net = self.policy.net
+        on_reset, done, truncated, reward = L["on_reset"], L["done"], L["truncated"], L["reward"]
+        old_value, old_lp, action = L["old_value"], L["old_lp"], L["action"]
+        obs = {k[4:]: v for k, v in L.items() if k.startswith("obs.")}
+        avail = obs.pop("available_action", None)
+        pstate = {k[len("policy_state."):]: v for k, v in L.items() if k.startswith("policy_state.")}
+        Tb, B = on_reset.shape[0], on_reset.shape[1]
+        boot, burn = self.bootstrap_steps, self.burn_in_steps
+        lo, hi = burn, Tb - boot
+        n_valid = (hi - lo) * B
+        Nc = 1
         f64 = dict(dtype=torch.float64, device=dev)
         stats_local = torch.zeros(3, **f64)
         adv_d = ret_d = None
-        have_adv = sample.analyzed_result.adv is not None
-        train_stats = defaultdict(float)
+        epoch_terms = []
 
-        for _ in range(self.ppo_epochs):
+        for epoch in range(self.ppo_epochs):
             # ---- advantages / value targets ------------------------------------------------------------------
             if adv_d is None:
                 if have_adv:
-                    adv_d = to_device_leaf(sample.analyzed_result.adv, dev, "real")
-                    ret_d = to_device_leaf(sample.analyzed_result.ret, dev, "real")
+                    adv_d, ret_d = L["adv"], L["ret"]
                     fused_stats = False
                 else:
-                    if boot == 0:
-                        raise ValueError("bootstrap_steps == 0 requires advantages computed before the trainer")
                     adv_d = torch.zeros((Tb, B, Nc), dtype=torch.float32, device=dev)  # last row = the zero pad (:254-256)
                     ret_d = torch.zeros((Tb, B, Nc), dtype=torch.float32, device=dev)
                     fused_stats = boot == 1 and burn == 0
@@ -243,7 +357,7 @@ class MultiAgentPPO(PytorchTrainer):
                 pstats = pstats_local.clone()
                 if self._dist:
                     dist.all_reduce(pstats)  # one message instead of utils.py:121-124's three
-                self.policy.update_popart_from_stats(pstats)
+                self.policy.update_popart_from_stats(pstats, count=False)
                 loss_ret = torch.empty_like(ret_d)
                 hip.popart_map(ret_d, net.popart_state, Nc, loss_ret, True, ns.POPART_EPS)
             loss_oldv = self.policy.normalize_value(old_value) if self.normalize_old_value else old_value  # :151-152
@@ -258,7 +372,9 @@ class MultiAgentPPO(PytorchTrainer):
             # recurrent nets walk the time axis: all valid rows go through in one piece
             rnn = None
             if net.spec.num_rnn_layers:
-                rnn = self.policy._rnn_ctx(sample.policy_state[lo:hi], hi - lo, B, on_reset[lo:hi])
+                from srl_amd.namedarray import NamedArray
+                rnn = self.policy._rnn_ctx(NamedArray(**{k: v[lo:hi] for k, v in pstate.items()}), hi - lo, B,
+                                           on_reset[lo:hi])
             chunk_rows = n_valid if rnn is not None else self.chunk_rows
             nchunks = max(1, -(-n_valid // chunk_rows))
             terms = torch.zeros((nchunks, hip.LT_COUNT), **f64)
@@ -287,56 +403,18 @@ class MultiAgentPPO(PytorchTrainer):
             sumsq = torch.zeros(1, **f64)
             gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
             hip.grad_sumsq(net.grad, sumsq)
-            self._opt_steps += 1
             hip.adam_step(net.flat, net.grad, self._m, self._v, self._lr, self._betas[0], self._betas[1], self._eps,
-                          self._weight_decay, self._adamw, self._opt_steps, grad_scale=1.0 / self._world,
+                          self._weight_decay, self._adamw, self._opt_steps + epoch + 1, grad_scale=1.0 / self._world,
                           max_norm=-1.0 if self.max_grad_norm is None else float(self.max_grad_norm), sumsq=sumsq,
-                          grad_norm_out=gnorm)
+                          grad_norm_out=gnorm, step_scalars=None if dscal is None else dscal[epoch])
 
-            if self.recompute_adv_among_epochs:
+            if self.recompute_adv_among_epochs and epoch + 1 < self.ppo_epochs:
                 adv_d = ret_d = None
                 have_adv = False
 
-            # ---- statistics: the only device->host synchronisation of the epoch ----------------------------------------
             extra = [] if pstats_local is None else [pstats_local[0, :2]]
-            host = torch.cat([terms.sum(0), gnorm.double()] + extra).cpu().numpy()
-            msum = max(host[hip.LT_MASK], 1e-30)
-            if pstats_local is not None:  # PPOStepResult.denorm_value: masked mean of the de-normalised targets (:215)
-                train_stats["denorm_value"] += host[hip.LT_COUNT + 2] / max(host[hip.LT_COUNT + 1], 1e-30)
-            for key, slot in _STAT_TERMS:
-                train_stats[key] += host[slot] / msum
-            train_stats["done"] += host[hip.LT_DONE] / max(n_valid, 1)
-            train_stats["truncated"] += host[hip.LT_TRUNC] / max(n_valid, 1)
-            train_stats["grad_norm"] += host[hip.LT_COUNT]
-
-        for k in train_stats:
-            train_stats[k] /= self.ppo_epochs
-
-        # advantages / returns go back into the numpy sample so that a re-used buffer entry carries them (:254-257)
-        if adv_d is not None and not have_adv and not isinstance(sample.reward, torch.Tensor):
-            sample.analyzed_result.adv = adv_d.cpu().numpy()
-            sample.analyzed_result.ret = ret_d.cpu().numpy()
-        elif adv_d is not None and not have_adv:
-            sample.analyzed_result.adv, sample.analyzed_result.ret = adv_d, ret_d
-        if self.recompute_adv_among_epochs:
-            sample.analyzed_result.adv = sample.analyzed_result.ret = None
-
-        self.policy.inc_version()  # once per step, not per epoch (:305-307)
-        if self.entropy_decay_per_steps and self.policy.version % self.entropy_decay_per_steps == 0:
-            self.entropy_bonus_weight *= self.entropy_bonus_decay
-            self._hp.entropy_bonus_weight = self.entropy_bonus_weight
-
-        self.frames += n_valid
-        info = {}
-        if sample.info_mask is not None and sample.info is not None:
-            im = sample.info_mask[lo:hi]
-            im = im.cpu().numpy() if isinstance(im, torch.Tensor) else np.asarray(im)
-            elapsed = im.sum()
-            if elapsed > 0:
-                info = recursive_apply(sample.info[lo:hi] * im, lambda x: x.sum()) / elapsed
-                info = {k: float(v) for k, v in info.items()}
-        stats = dict(frames=int(self.frames), **{k: float(v) for k, v in train_stats.items()}, **info)
-        return TrainerStepResult(stats=stats, step=self.policy.version)
+            epoch_terms.append(torch.cat([terms.sum(0), gnorm.double()] + extra))
+        return dict(terms=torch.stack(epoch_terms), adv=adv_d, ret=ret_d)
 
 
 register('mappo', MultiAgentPPO)

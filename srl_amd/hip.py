@@ -109,7 +109,7 @@ _SIGNATURES = {
     "srl_u8_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "srl_grad_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
-                               c_float, c_float, c_int, c_int64, c_float, c_float, c_void_p, c_void_p]),
+                               c_float, c_float, c_int, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -407,13 +407,14 @@ def grad_sumsq(g, sumsq):
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, adamw, step, grad_scale=1.0, max_norm=-1.0, sumsq=None,
-              grad_norm_out=None):
+              grad_norm_out=None, step_scalars=None):
     f = torch.float32
     _check(
         lib().srl_adam_step(_stream(), _ptr(p, f, "p"), _ptr(g, f, "g"), _ptr(m, f, "m"), _ptr(v, f, "v"), p.numel(),
                             float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(adamw),
                             int(step), float(grad_scale), float(max_norm), _ptr(sumsq, torch.float64, "sumsq"),
-                            _ptr(grad_norm_out, f, "grad_norm_out")), "srl_adam_step")
+                            _ptr(grad_norm_out, f, "grad_norm_out"), _ptr(step_scalars, f, "step_scalars")),
+        "srl_adam_step")
 
 
 def conv_desc(n, H, W, Cin, KH, KW, stride, Cout, act=ACT_NONE) -> ConvDesc:
