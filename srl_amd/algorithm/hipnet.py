@@ -87,6 +87,9 @@ class HipNet:
         self._tape = None
         self._rnn: Optional[RnnCtx] = None
         self.last_state: Dict[str, torch.Tensor] = {}
+        # data parallel: called with the prefixes of the parameters whose gradient has just become final during
+        # backward(), so that the trainer can start reducing finished buckets while the rest is still computed
+        self.grad_ready_hook = None
         # SRL_EXPLICIT_CONV=1 forces the im2col + GEMM + col2im fallback (kept for geometries the implicit
         # kernels reject, and as a cross-check of the implicit path in the tests)
         import os
@@ -453,6 +456,7 @@ class HipNet:
                         prev_out_cols = self._out_cols(records[idx - 1])
                         if g.cols != prev_out_cols:
                             g = Buf(g.ptr, prev_out_cols, g.rows * g.cols // prev_out_cols, prev_out_cols)
+                    self._notify_ready(kind, L, saved)
                     continue
                 self._wgrad(L.cout, kdim, m, g, P.ptr, kdim, self._g(f"{L.prefix}.weight"))
                 hip.colsum(g.ptr, g.ld, m, L.cout, self._g(f"{L.prefix}.bias"), accumulate=True)
@@ -470,6 +474,7 @@ class HipNet:
                     dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.cin)
                     hip.col2im_nhwc(P.ptr, n, h, w, L.cin, L.k, L.k, L.stride, x.ptr if in_act else None, in_act, dx.ptr)
                     g = dx
+            self._notify_ready(kind, L, saved)
             if g is not None and idx > 0:
                 # a Flatten between this record's input and the previous record's output: reshape the gradient
                 prev_out_cols = self._out_cols(records[idx - 1])
@@ -477,6 +482,14 @@ class HipNet:
                     assert g.ld == g.cols and (g.rows * g.cols) % prev_out_cols == 0
                     g = Buf(g.ptr, prev_out_cols, g.rows * g.cols // prev_out_cols, prev_out_cols)
         return g
+
+    def _notify_ready(self, kind, L, saved):
+        if self.grad_ready_hook is None:
+            return
+        done = [L.prefix]
+        if kind == "conv" and L.first and saved[1] is not None:
+            done.append(saved[1][4].prefix)  # the observation LayerNorm fused into the first convolution
+        self.grad_ready_hook(done)
 
     @staticmethod
     def _out_cols(record):
@@ -569,11 +582,17 @@ class HipNet:
         dl = Buf(d_logits.data_ptr(), atot, n, atot)
         dv = Buf(d_value.data_ptr(), sp.value_dim, n, sp.value_dim)
         da = self._linear_bwd(sp.actor_head, a_feat, dl, a_act, True, "a:")
+        if self.grad_ready_hook is not None and sp.shared_backbone:
+            self.grad_ready_hook([sp.actor_head.prefix])
         if sp.shared_backbone:
             self._linear_bwd(sp.critic_head, c_feat, dv, c_act, True, "a:", dx_into=da, dx_accumulate=True)
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook([sp.critic_head.prefix])
             self._trunk_bwd("a:", a_tape, da)
         else:
             dc = self._linear_bwd(sp.critic_head, c_feat, dv, c_act, True, "c:")
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook([sp.actor_head.prefix, sp.critic_head.prefix])
             self._trunk_bwd("a:", a_tape, da)
             self._trunk_bwd("c:", c_tape, dc)
         self._tape = None

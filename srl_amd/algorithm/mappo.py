@@ -42,6 +42,57 @@ _STAT_TERMS = (("policy_loss", hip.LT_POLICY), ("value_loss", hip.LT_VALUE), ("e
                ("value_targets", hip.LT_RET))
 
 
+class _BucketReducer:
+    """Gradient all-reduce overlapped with the backward pass (what DDP's bucketing does for the reference,
+    api/policy.py:219-238): the flat gradient is cut into contiguous buckets in parameter order; as soon as every
+    parameter of a bucket has its final gradient the bucket's all-reduce is launched asynchronously (RCCL runs it on
+    its own stream while the compute stream continues with the earlier layers); `finish` launches what is left and
+    makes the compute stream wait.  Sum over ranks; the mean is folded into the Adam kernel."""
+
+    def __init__(self, net, bucket_bytes):
+        self.net = net
+        self.buckets = []  # [lo, hi, set of pending parameter prefixes]
+        lo, pending, size = None, set(), 0
+        for name, info in net.spec.params.items():
+            prefix = name.rsplit(".", 1)[0]
+            if ".rnn._AutoResetRNN__net" in name:
+                prefix = name[:name.index("._AutoResetRNN__net") + len("._AutoResetRNN__net")]
+            if lo is not None and size + 4 * info.numel > bucket_bytes:  # a big tensor starts its own bucket
+                self.buckets.append([lo, info.offset, pending])
+                lo, pending, size = None, set(), 0
+            if lo is None:
+                lo = info.offset
+            pending.add(prefix)
+            size += 4 * info.numel
+            hi = info.offset + (info.numel + 3) // 4 * 4
+            if size >= bucket_bytes:
+                self.buckets.append([lo, hi, pending])
+                lo, pending, size = None, set(), 0
+        if lo is not None:
+            self.buckets.append([lo, net.spec.total_params, pending])
+        self.launched = [False] * len(self.buckets)
+        self.works = []
+
+    def _launch(self, i):
+        lo, hi, _ = self.buckets[i]
+        self.works.append(dist.all_reduce(self.net.grad[lo:hi], async_op=True))
+        self.launched[i] = True
+
+    def ready(self, prefixes):
+        for i, b in enumerate(self.buckets):
+            if not self.launched[i] and b[2]:
+                b[2].difference_update(prefixes)
+                if not b[2]:
+                    self._launch(i)
+
+    def finish(self):
+        for i in range(len(self.buckets)):
+            if not self.launched[i]:
+                self._launch(i)
+        for w in self.works:
+            w.wait()
+
+
 class MultiAgentPPO(PytorchTrainer):
 
     def __init__(self, policy: ActorCriticPolicy, **kwargs):
@@ -111,6 +162,7 @@ class MultiAgentPPO(PytorchTrainer):
         self._dist = False
         # capture the device part of a step into a hipGraph per sample signature and replay it (launch-bound small
         # configurations; needs device-resident or equal-shaped samples; not with a process group)
+        self.grad_bucket_bytes = int(g("grad_bucket_bytes", 1 << 20))
         self.use_graph = bool(g("use_graph", False))
         self._graphs = {}
 
@@ -378,9 +430,12 @@ class MultiAgentPPO(PytorchTrainer):
             chunk_rows = n_valid if rnn is not None else self.chunk_rows
             nchunks = max(1, -(-n_valid // chunk_rows))
             terms = torch.zeros((nchunks, hip.LT_COUNT), **f64)
+            reducer = _BucketReducer(net, self.grad_bucket_bytes) if self._dist else None
             for ci in range(nchunks):
                 r0, r1 = ci * chunk_rows, min(n_valid, (ci + 1) * chunk_rows)
                 n = r1 - r0
+                if reducer is not None and ci == nchunks - 1:
+                    net.grad_ready_hook = reducer.ready  # gradients become final in the last chunk's backward
                 c_obs = {k: v[r0:r1] for k, v in f_obs.items()}
                 c_avail = None if f_avail is None else f_avail[r0:r1]
                 logits, value = net.forward(c_obs, n, keep_tape=True, rnn=rnn)
@@ -398,8 +453,9 @@ class MultiAgentPPO(PytorchTrainer):
                 net.backward(d_logits, d_v.view(n, 1))
 
             # ---- gradient reduction, clip, Adam (mappo.py:272-284) ---------------------------------------------------
-            if self._dist:
-                dist.all_reduce(net.grad)
+            if reducer is not None:  # the buckets not yet launched, then wait for all of them
+                net.grad_ready_hook = None
+                reducer.finish()
             sumsq = torch.zeros(1, **f64)
             gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
             hip.grad_sumsq(net.grad, sumsq)

@@ -65,3 +65,36 @@ def test_two_rank_statistics_gradients_and_broadcast():
     flat = torch.arange(spec.total_params, dtype=torch.float32)
     port = _free_port()
     mp.spawn(_worker, args=(2, port, adv, mask, expected, flat), nprocs=2, join=True)
+
+
+def test_bucket_reducer_cuts_and_readiness():
+    """Host logic of the overlapped gradient all-reduce: buckets tile the flat buffer in parameter order, a big tensor
+    gets its own bucket, and a bucket fires exactly when the last of its parameters reports a final gradient."""
+    from srl_amd.algorithm import netspec as ns
+    from srl_amd.algorithm.mappo import _BucketReducer
+    cnn = dict(obs_dim={"obs": (4, 84, 84)}, action_dim=6, hidden_dim=512, num_dense_layers=0, num_rnn_layers=0,
+               popart=False, layernorm=False, shared_backbone=True,
+               cnn_layers=dict(obs=[(32, 8, 4, 0, 'zeros'), (64, 4, 2, 0, 'zeros'), (64, 3, 1, 0, 'zeros')]))
+    spec, _ = ns.build_netspec(**cnn)
+
+    class Net:
+        pass
+
+    net = Net()
+    net.spec, net.grad = spec, torch.zeros(spec.total_params)
+    r = _BucketReducer(net, 1 << 20)
+    assert r.buckets[0][0] == 0 and r.buckets[-1][1] == spec.total_params
+    assert all(r.buckets[i][1] == r.buckets[i + 1][0] for i in range(len(r.buckets) - 1))
+    fc = spec.params["obs_modules_dict.obs.1._Convolution__model.7.0.weight"]
+    assert [b[0] for b in r.buckets].count(fc.offset) == 1  # the 6.4 MB tensor starts a bucket of its own
+    fired = []
+    r._launch = lambda i: (fired.append(i), r.launched.__setitem__(i, True))
+    cm = "obs_modules_dict.obs.1._Convolution__model"
+    r.ready(["actor_head"]); r.ready(["critic_head"]); r.ready([f"{cm}.7.2"])
+    assert fired == []  # the tail bucket also holds the FC bias
+    r.ready([f"{cm}.7.0"])
+    assert fired == [2, 1]  # FC bias completes the tail bucket, FC weight its own: both go while the convs still run
+    r.ready([f"{cm}.4"]); r.ready([f"{cm}.2"])
+    assert fired == [2, 1]
+    r.ready([f"{cm}.0", "obs_modules_dict.obs.0"])
+    assert fired == [2, 1, 0]
