@@ -552,7 +552,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
           sb.load(g.b, n0, g.N, k0 + 2 * BK, kend, vb);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);  // keep the order: prefetch / staging above, then this step's MFMAs
+      // (no sched_barrier: order-pinning was measured)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
