@@ -225,25 +225,35 @@ class OracleActorCritic:
             start += d
         return out
 
-    def analyze(self, obs, action, on_reset, policy_state=None):
+    def analyze(self, obs, action, on_reset, policy_state=None, burn_in_steps=0):
         """PPO analysis (actor_critic_policy.py:338-390): new log-probs, state values, entropy, each [T,B,1].
 
         Without an RNN the chunking of the reference ([T,B] -> [C, B*T/C] and back) is a pure reshape
         of independent rows, so it is skipped; with a GRU the chunks start from the stored per-row
         ``policy_state`` exactly as the reference does.
         """
+        burn = burn_in_steps
         if self.num_rnn_layers == 0:
-            logits, value, _ = self.forward(obs)
+            logits, value, _ = self.forward({k: v[burn:] for k, v in obs.items()})
         else:
-            T = on_reset.shape[0]
+            T = on_reset.shape[0] - burn
             C = self.chunk_len
             n = T // C
-            chunk = lambda x: torch.cat(torch.split(x, C, dim=0), dim=1)  # modules/utils.py:164-182
+            chunk = lambda x: torch.cat(torch.split(x, T // n, dim=0), dim=1)  # modules/utils.py:164-182
             unchunk = lambda x: torch.cat(torch.split(x, x.shape[1] // n, dim=1), dim=0)
-            cobs = {k: chunk(v) for k, v in obs.items()}
-            state = tuple(chunk(s)[0].transpose(0, 1) for s in policy_state)  # :361-363
-            logits, value, _ = self.forward(cobs, state, chunk(on_reset))
+            cobs = {k: chunk(v[burn:]) for k, v in obs.items()}
+            if burn == 0:
+                state = tuple(chunk(s)[0].transpose(0, 1) for s in policy_state)  # :361-363
+            else:
+                # :365-378: the `burn` rows before every chunk are replayed without gradient from the state stored
+                # at their first row; what comes out is the chunk's initial state
+                win = lambda x: torch.cat([x[i * C:i * C + burn] for i in range(n)], dim=1)
+                with torch.no_grad():
+                    _, _, state = self.forward({k: win(v) for k, v in obs.items()},
+                                               tuple(win(s)[0].transpose(0, 1) for s in policy_state), win(on_reset))
+            logits, value, _ = self.forward(cobs, state, chunk(on_reset[burn:]))
             logits, value = unchunk(logits), unchunk(value)
+        action = action[burn:]
         dists = self._heads(logits)
         lp = torch.stack([d.log_prob(action[..., i]) for i, d in enumerate(dists)], -1).sum(-1, keepdim=True)
         ent = torch.stack([d.entropy() for d in dists], -1).sum(-1, keepdim=True)

@@ -59,14 +59,16 @@ class OracleMappo:
             pstate = [f32(n) for n in names]
         Tb = on_reset.shape[0]
         boot, burn = self.bootstrap_steps, self.burn_in_steps
-        assert burn == 0, "oracle: burn-in not restated"
         keep = Tb - boot  # analysed rows (mappo.py:243-246, tail_len = bootstrap_steps without vtrace)
 
         totals = {}
         out = {}
         for _ in range(self.ppo_epochs):
             lp, value, ent, _ = self.net.analyze({k: v[:keep] for k, v in obs.items()}, action[:keep], on_reset[:keep],
-                                                 None if pstate is None else [s[:keep] for s in pstate])
+                                                 None if pstate is None else [s[:keep] for s in pstate], burn)
+            if burn:  # the analysis covers rows [burn, keep): pad in front so that row indices stay the sample's
+                padf = lambda x: torch.cat([torch.zeros((burn,) + tuple(x.shape[1:]), dtype=x.dtype), x], 0)
+                lp, value, ent = padf(lp), padf(value), padf(ent)
             if "adv" not in out:  # computed in the first epoch only (mappo.py:247-257; matters with PopArt, whose
                 # statistics move between epochs)
                 trace_value = self.net.denormalize_value(old_value) if self.popart else old_value  # :120-124

@@ -104,22 +104,23 @@ class ActorCriticPolicy(policy_api.Policy):
     def _state_keys(self):
         return (("hx", "a:"),) if self.spec.shared_backbone else (("actor_hx", "a:"), ("critic_hx", "c:"))
 
-    def _rnn_ctx(self, policy_state, T, B, on_reset) -> Optional[RnnCtx]:
+    def _rnn_ctx(self, policy_state, T, B, on_reset, chunk: Optional[int] = None, h0=None) -> Optional[RnnCtx]:
         """Chunking of [T, B] rows for the recurrent layers (actor_critic_policy.py:349-363): ``T // chunk_len``
         chunks, each starting from the state stored at its first row; ``on_reset`` [T, B, 1] device uint8 or None."""
         L, H = self.spec.num_rnn_layers, self.spec.rnn_state_width
         if not L:
             return None
-        if policy_state is None:
+        if policy_state is None and h0 is None:
             raise ValueError("recurrent policy: the sample / request carries no policy_state")
-        K = max(T // self._chunk_len, 1)
+        K = max(T // (chunk or self._chunk_len), 1)
         C = T // K
         if K * C != T:
             raise ValueError(f"{T} rows do not split into {K} chunks of equal length (chunk_len={self._chunk_len})")
-        h0 = {}
-        for key, tag in self._state_keys():
-            s = to_device_leaf(policy_state[key], self.device, "real")  # [T, B, L, H]
-            h0[tag] = s.reshape(T, B, L, H)[0::C].reshape(K * B, L, H).permute(1, 0, 2).contiguous()
+        if h0 is None:
+            h0 = {}
+            for key, tag in self._state_keys():
+                s = to_device_leaf(policy_state[key], self.device, "real")  # [T, B, L, H]
+                h0[tag] = s.reshape(T, B, L, H)[0::C].reshape(K * B, L, H).permute(1, 0, 2).contiguous()
         reset = None
         if on_reset is not None:
             reset = on_reset.reshape(K, C, B).permute(1, 0, 2).contiguous()  # chunk-major [C, K*B]
@@ -233,6 +234,27 @@ class ActorCriticPolicy(policy_api.Policy):
                                                                                  value=value.cpu().numpy()),
                                         policy_state=self._packed_last_state())
 
+    def _rnn_ctx_with_burn_in(self, obs, avail_unused, policy_state, on_reset, burn, T, B) -> Optional[RnnCtx]:
+        """Recurrent context for rows [burn, burn + T) of leaves that start `burn` rows earlier: the `burn` rows before
+        every chunk are replayed without gradient from the state stored at their first row, and what comes out is
+        the chunk's initial state (actor_critic_policy.py:365-378).  obs / policy_state / on_reset: device leaves
+        [burn + T (+ more), B, ...]."""
+        if not self.spec.num_rnn_layers:
+            return None
+        if not burn:
+            ps = NamedArray(**{k: v[:T] for k, v in policy_state.items()})
+            return self._rnn_ctx(ps, T, B, on_reset[:T])
+        Cl = self._chunk_len
+        K = max(T // Cl, 1)
+        win = lambda x: torch.cat([x[i * Cl:i * Cl + burn] for i in range(K)], dim=0)  # [K*burn, B, ...] time-major
+        n = K * burn * B
+        w_obs = {k: win(v).reshape(n, *v.shape[2:]) for k, v in obs.items() if k != "available_action"}
+        w_ps = NamedArray(**{k: win(v) for k, v in policy_state.items()})
+        ctx = self._rnn_ctx(w_ps, K * burn, B, win(on_reset), chunk=burn)
+        self._net.forward(w_obs, n, keep_tape=False, rnn=ctx)
+        h0 = {tag: self._net.last_state[tag].clone() for _, tag in self._state_keys()}
+        return self._rnn_ctx(None, T, B, on_reset[burn:burn + T], h0=h0)
+
     def _packed_last_state(self):
         """New hidden states as the actors store them: numpy [n, layers, H] per backbone (:505-508)."""
         if not self.spec.num_rnn_layers:
@@ -252,28 +274,33 @@ class ActorCriticPolicy(policy_api.Policy):
         ``modules/utils.py:164-195``) only permutes independent rows, so rows are evaluated in place.
         The forward context is kept so that ``backward_ppo`` can follow.
         """
-        if burn_in_steps:
-            raise NotImplementedError("burn-in steps are not on the HIP path")
-        T, B = sample.on_reset.shape[:2]
+        burn = int(burn_in_steps)
+        Tall, B = sample.on_reset.shape[:2]
+        T = Tall - burn  # analysed rows: [burn, Tall) (:346-349)
         n = T * B
-        obs = {}
+        obs, full_obs = {}, {}
         for k, v in sample.obs.items():
             if v is None:
                 continue
             t = to_device_leaf(v, self.device, "obs")
-            obs[k] = t.reshape(n, *t.shape[2:])
+            full_obs[k] = t
+            obs[k] = t[burn:].reshape(n, *t.shape[2:])
         avail = obs.pop("available_action", None)
-        action = to_device_leaf(sample.action.x, self.device, "index").reshape(n, -1)
+        action = to_device_leaf(sample.action.x, self.device, "index")[burn:].reshape(n, -1)
         rnn = None
         if self.spec.num_rnn_layers:
-            rnn = self._rnn_ctx(sample.policy_state, T, B, to_device_leaf(sample.on_reset, self.device, "flag"))
+            if sample.policy_state is None:
+                raise ValueError("recurrent policy: the sample carries no policy_state")
+            ps = {k: to_device_leaf(v, self.device, "real") for k, v in sample.policy_state.items()}
+            rnn = self._rnn_ctx_with_burn_in(full_obs, None, ps, to_device_leaf(sample.on_reset, self.device, "flag"), burn,
+                                             T, B)
         logits, value = self._net.forward(obs, n, keep_tape=True, rnn=rnn)
         logp = self._net.ws.get("new_logp", n)[:n]
         ent = self._net.ws.get("entropy", n)[:n]
         hip.categorical_fwd(logits, action, avail, self.spec.act_dims, logp, ent)
         self._analysis = (logits, action, avail, n)
         old = sample.analyzed_result.log_probs
-        old = None if old is None else to_device_leaf(old, self.device, "real")
+        old = None if old is None else to_device_leaf(old, self.device, "real")[burn:]
         return SampleAnalyzedResult(old_action_log_probs=old, new_action_log_probs=logp.view(T, B, 1),
                                     state_values=value.view(T, B, -1), entropy=ent.view(T, B, 1))
 

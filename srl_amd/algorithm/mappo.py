@@ -125,8 +125,8 @@ class MultiAgentPPO(PytorchTrainer):
             raise ValueError("Set popart=True in policy config to activate popart value head.")  # actor_critic_policy.py:264
         if self.vtrace and self.bootstrap_steps != 1:
             raise NotImplementedError("V-trace with bootstrap_steps != 1 is not on the HIP path")
-        if self.burn_in_steps:
-            raise NotImplementedError("burn-in steps are not on the HIP path")
+        if self.burn_in_steps and self.vtrace:
+            raise NotImplementedError("burn-in together with V-trace is not on the HIP path")
 
         name = g('optimizer', 'adam')
         if name not in ('adam', 'adamw'):
@@ -423,10 +423,8 @@ class MultiAgentPPO(PytorchTrainer):
             f_done, f_trunc = flat(done).reshape(-1), flat(truncated).reshape(-1)
             # recurrent nets walk the time axis: all valid rows go through in one piece
             rnn = None
-            if net.spec.num_rnn_layers:
-                from srl_amd.namedarray import NamedArray
-                rnn = self.policy._rnn_ctx(NamedArray(**{k: v[lo:hi] for k, v in pstate.items()}), hi - lo, B,
-                                           on_reset[lo:hi])
+            if net.spec.num_rnn_layers:  # chunk states from the sample, or from a no-grad replay of the burn-in rows
+                rnn = self.policy._rnn_ctx_with_burn_in(obs, None, pstate, on_reset, burn, hi - lo, B)
             chunk_rows = n_valid if rnn is not None else self.chunk_rows
             nchunks = max(1, -(-n_valid // chunk_rows))
             terms = torch.zeros((nchunks, hip.LT_COUNT), **f64)

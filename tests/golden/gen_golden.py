@@ -238,7 +238,7 @@ def check_init(policy_args, ref_sd):
     return spec
 
 
-def run_steps(tag, policy_args, trainer_args, sample_kw, n_steps, store_state="full", out=None):
+def run_steps(tag, policy_args, trainer_args, sample_kw, n_steps, store_state="full", out=None, analyze_check=True):
     out = {} if out is None else out
     trainer = make_ref_trainer(policy_args, trainer_args)
     net = trainer.policy.net
@@ -252,7 +252,7 @@ def run_steps(tag, policy_args, trainer_args, sample_kw, n_steps, store_state="f
     for step in range(n_steps):
         arrays = synthetic.make_sample_arrays(seed=100 + step, **sample_kw)
         sample = ref_sample({k: v.copy() for k, v in arrays.items()})
-        if step == 0:
+        if step == 0 and analyze_check:
             # G6: analysis outputs on the initial weights
             ts = recursive_apply(sample, lambda x: torch.from_numpy(x).float())
             Tb = arrays["on_reset"].shape[0]
@@ -378,6 +378,14 @@ def gen_rnn():
                        popart=False, layernorm=True, shared_backbone=True, chunk_len=4, seed=23)
     lstm_sample = dict(T=16, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.1, policy_state={"hx": (2, 32)})
     run_steps("lstm", lstm_policy, dict(popart=False, optimizer_config=dict(lr=1e-3)), lstm_sample, 2, out=out)
+    # burn-in: the 2 rows before every chunk are replayed without gradient to produce the chunk's initial state
+    # (18 stored rows + bootstrap: 2 burn-in + 16 = 4 chunks of 4)
+    bi_policy = dict(obs_dim=4, action_dim=2, hidden_dim=16, num_dense_layers=1, num_rnn_layers=1, popart=False,
+                     layernorm=True, shared_backbone=False, chunk_len=4, seed=24)
+    bi_sample = dict(T=18, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.1,
+                     policy_state={"actor_hx": (1, 16), "critic_hx": (1, 16)})
+    run_steps("burn", bi_policy, dict(popart=False, burn_in_steps=2, optimizer_config=dict(lr=1e-3)), bi_sample, 2, out=out,
+              analyze_check=False)
     # stateful deterministic rollout
     policy = api.policy.make(api.config.Policy("actor-critic", args=sh_policy))
     policy.eval_mode()
