@@ -101,6 +101,27 @@ int srl_popart_map(void* stream, const float* x, long n, int vd, const double* r
                    int normalize, float* out);
 
 /* ------------------------------------------------------------------------------------------------
+ * Continuous actions: diagonal Gaussian head, torch.distributions.Normal(mean, std) summed over the action
+ * dimensions.  Replaces actor_critic_policy.py:128-133 (std), :318-321 (log_prob / entropy and their autograd
+ * backward), :499-506 (rollout).  mean float32[n, A] with row pitch ld_mean; log_std float32[A] shared by all
+ * rows (ld_log_std = 0: `fixed`, `separate_learnable`) or float32[n, A] with pitch ld_log_std
+ * (`shared_learnable`: output of a second head); action float32[n, A] contiguous.
+ * ---------------------------------------------------------------------------------------------- */
+int srl_gaussian_fwd(void* stream, const float* mean, int ld_mean, const float* log_std, int ld_log_std,
+                     const float* action, long n, int A, float* logp, float* entropy);
+
+/* d_mean, d_log_std float32[n, A] (per row; the caller column-sums d_log_std for the shared vector). */
+int srl_gaussian_bwd(void* stream, const float* mean, int ld_mean, const float* log_std, int ld_log_std,
+                     const float* action, long n, int A, const float* d_logp, const float* d_entropy,
+                     float* d_mean, float* d_log_std);
+
+/* action = mean where is_eval (or sampled: Box-Muller on Philox4x32-10 counters (row, dim, offset) keyed by seed),
+ * logp = its log-probability. */
+int srl_gaussian_sample(void* stream, const float* mean, int ld_mean, const float* log_std, int ld_log_std,
+                        const uint8_t* is_eval, long n, int A, uint64_t seed, uint64_t offset, float* action,
+                        float* logp);
+
+/* ------------------------------------------------------------------------------------------------
  * Recurrent backbone: GRU cell between the GEMMs, one time step per launch.
  * Replaces: AutoResetRNN.forward around torch.nn.GRU (modules/autoreset_rnn.py:42-66,
  *           recurrent_backbone.py:61-66) and its autograd backward; chunking of modules/utils.py:164-182.

@@ -48,7 +48,8 @@ class OracleActorCritic:
                  continuous_action: bool = False,
                  **_ignored):
         self.popart = popart
-        assert not continuous_action, "oracle: continuous actions not restated yet"
+        self.continuous = continuous_action
+        self.std_type = _ignored.get("std_type", "fixed")
         self.obs_dim = {"obs": obs_dim} if isinstance(obs_dim, int) else dict(obs_dim)
         if state_dim is not None and isinstance(state_dim, int):
             state_dim = {"state": state_dim}
@@ -68,7 +69,11 @@ class OracleActorCritic:
         self.params = OrderedDict()
         for k, v in sd.items():
             t = torch.as_tensor(np.asarray(v)).clone()
-            self.params[k] = t.double() if "_RunningMeanStd__" in k else t.float().requires_grad_(True)
+            if "_RunningMeanStd__" in k:
+                self.params[k] = t.double()
+            else:
+                fixed = k == "log_std" and self.continuous and self.std_type == "fixed"  # :88-89 requires_grad=False
+                self.params[k] = t.float().requires_grad_(not fixed)
 
     def state_dict(self):
         return OrderedDict((k, v.detach().clone()) for k, v in self.params.items())
@@ -177,7 +182,12 @@ class OracleActorCritic:
             c_feat, c_hx = self._backbone("critic_backbone", sfeat, policy_state[1], on_reset)
             new_state = (a_hx, c_hx)
         logits = F.linear(a_feat, self._p("actor_head.weight"), self._p("actor_head.bias"))
-        if "available_action" in obs:
+        if self.continuous:  # actor_critic_policy.py:128-133: (mean, std); std from a vector or from a second head
+            if self.std_type == "shared_learnable":
+                self._std = F.linear(a_feat, self._p("log_std.weight"), self._p("log_std.bias")).exp()
+            else:
+                self._std = self._p("log_std").exp() * torch.ones_like(logits)
+        elif "available_action" in obs:
             logits = logits.masked_fill(obs["available_action"] == 0, -1e10)  # actor_critic_policy.py:135-136
         head = "critic_head._PopArtValueHead__" if self.popart else "critic_head."  # popart.py:21-22,39-40
         value = F.linear(c_feat, self._p(head + "weight"), self._p(head + "bias"))
@@ -254,6 +264,10 @@ class OracleActorCritic:
             logits, value, _ = self.forward(cobs, state, chunk(on_reset[burn:]))
             logits, value = unchunk(logits), unchunk(value)
         action = action[burn:]
+        if self.continuous:  # :318-321
+            std = unchunk(self._std) if (self.num_rnn_layers and self._std.shape != logits.shape) else self._std
+            dist = torch.distributions.Normal(logits, std)
+            return dist.log_prob(action).sum(-1, keepdim=True), value, dist.entropy().sum(-1, keepdim=True), logits
         dists = self._heads(logits)
         lp = torch.stack([d.log_prob(action[..., i]) for i, d in enumerate(dists)], -1).sum(-1, keepdim=True)
         ent = torch.stack([d.entropy() for d in dists], -1).sum(-1, keepdim=True)
@@ -268,6 +282,9 @@ class OracleActorCritic:
         obs = {k: v.unsqueeze(0) for k, v in obs.items()}
         logits, value, new_state = self.forward(obs, policy_state)
         logits, value = logits.squeeze(0), value.squeeze(0)
+        if self.continuous:  # :499-506 with is_evaluation = 1: the action is the mean
+            dist = torch.distributions.Normal(logits, self._std.squeeze(0))
+            return logits, dist.log_prob(logits).sum(-1, keepdim=True), value, logits, new_state
         dists = self._heads(logits)
         actions = torch.stack([d.probs.argmax(-1) for d in dists], -1)
         lp = torch.stack([d.log_prob(actions[..., i]) for i, d in enumerate(dists)], -1).sum(-1, keepdim=True)

@@ -80,6 +80,8 @@ class ActorCriticPolicy(policy_api.Policy):
                                            activation=activation,
                                            layernorm=layernorm, shared_backbone=shared_backbone,
                                            continuous_action=continuous_action, auxiliary_head=auxiliary_head,
+                                           std_type=kwargs.get("std_type", "fixed"),
+                                           init_log_std=kwargs.get("init_log_std", -0.5),
                                            seed=seed)
         self._net = HipNet(self.spec, self.device)
         self._net.load_reference_state(init)
@@ -225,9 +227,14 @@ class ActorCriticPolicy(policy_api.Policy):
             rnn = self._rnn_ctx(NamedArray(**{k: np.asarray(ps[k])[None] for k, _ in self._state_keys()}), 1, n, None)
         logits, value = self._net.forward(obs, n, keep_tape=False, rnn=rnn)
         heads = self.spec.act_dims
-        action = torch.empty((n, len(heads)), dtype=torch.int64, device=self.device)
         logp = torch.empty((n, 1), dtype=torch.float32, device=self.device)
-        hip.categorical_sample(logits, avail, is_eval, heads, self._seed, self._rollout_calls, action, logp)
+        if self.spec.std_type:  # Normal(mean, std): the mean when evaluating, a sample otherwise (:499-506)
+            action = torch.empty((n, sum(heads)), dtype=torch.float32, device=self.device)
+            ptr, ld = self._log_std()
+            hip.gaussian_sample(logits, ptr, ld, is_eval, self._seed, self._rollout_calls, action, logp)
+        else:
+            action = torch.empty((n, len(heads)), dtype=torch.int64, device=self.device)
+            hip.categorical_sample(logits, avail, is_eval, heads, self._seed, self._rollout_calls, action, logp)
         self._rollout_calls += 1
         return policy_api.RolloutResult(action=DiscreteAction(action.cpu().numpy()),
                                         analyzed_result=PPORolloutAnalyzedResult(log_probs=logp.cpu().numpy(),
@@ -254,6 +261,39 @@ class ActorCriticPolicy(policy_api.Policy):
         self._net.forward(w_obs, n, keep_tape=False, rnn=ctx)
         h0 = {tag: self._net.last_state[tag].clone() for _, tag in self._state_keys()}
         return self._rnn_ctx(None, T, B, on_reset[burn:burn + T], h0=h0)
+
+    # ------------------------------------------------------------------ action distribution on top of the actor head
+    def action_kind(self) -> str:
+        return "real" if self.spec.std_type else "index"  # continuous actions are float32 [.., A]
+
+    def _log_std(self):
+        """(pointer, row pitch) of log sigma: the shared vector (pitch 0) or the second head's rows."""
+        if self.spec.std_type == "shared_learnable":
+            return self._net.log_std_rows.data_ptr(), self._net.log_std_rows.stride(0)
+        return self._net._p("log_std"), 0
+
+    def dist_fwd(self, logits, action, avail, logp, ent):
+        """log-probability of `action` and entropy under the current head outputs (:311-324)."""
+        if self.spec.std_type:
+            ptr, ld = self._log_std()
+            hip.gaussian_fwd(logits, ptr, ld, action, logp, ent)
+        else:
+            hip.categorical_fwd(logits, action, avail, self.spec.act_dims, logp, ent)
+
+    def dist_bwd(self, logits, action, avail, d_lp, d_ent, d_logits):
+        """d loss / d head outputs; returns what ``HipNet.backward`` needs besides d_logits (d log sigma rows or None)."""
+        if not self.spec.std_type:
+            hip.categorical_bwd(logits, action, avail, self.spec.act_dims, d_lp, d_ent, d_logits)
+            return None
+        n, A = logits.shape
+        ptr, ld = self._log_std()
+        d_ls = self._net.ws.get("d_log_std_rows", n * A)[:n * A].view(n, A)
+        hip.gaussian_bwd(logits, ptr, ld, action, d_lp, d_ent, d_logits, d_ls)
+        if self.spec.std_type == "shared_learnable":
+            return d_ls
+        if self.spec.std_type == "separate_learnable":  # `fixed`: requires_grad=False in the reference, no gradient
+            hip.colsum(d_ls.data_ptr(), A, n, A, self._net._g("log_std"), accumulate=True)
+        return None
 
     def _packed_last_state(self):
         """New hidden states as the actors store them: numpy [n, layers, H] per backbone (:505-508)."""
@@ -286,7 +326,7 @@ class ActorCriticPolicy(policy_api.Policy):
             full_obs[k] = t
             obs[k] = t[burn:].reshape(n, *t.shape[2:])
         avail = obs.pop("available_action", None)
-        action = to_device_leaf(sample.action.x, self.device, "index")[burn:].reshape(n, -1)
+        action = to_device_leaf(sample.action.x, self.device, self.action_kind())[burn:].reshape(n, -1)
         rnn = None
         if self.spec.num_rnn_layers:
             if sample.policy_state is None:
@@ -297,7 +337,7 @@ class ActorCriticPolicy(policy_api.Policy):
         logits, value = self._net.forward(obs, n, keep_tape=True, rnn=rnn)
         logp = self._net.ws.get("new_logp", n)[:n]
         ent = self._net.ws.get("entropy", n)[:n]
-        hip.categorical_fwd(logits, action, avail, self.spec.act_dims, logp, ent)
+        self.dist_fwd(logits, action, avail, logp, ent)
         self._analysis = (logits, action, avail, n)
         old = sample.analyzed_result.log_probs
         old = None if old is None else to_device_leaf(old, self.device, "real")[burn:]
@@ -308,14 +348,17 @@ class ActorCriticPolicy(policy_api.Policy):
         """Back-propagate d loss / d(new log-prob, value, entropy) of the last ``analyze`` into ``net.grad``."""
         logits, action, avail, n = self._analysis
         d_logits = self._net.ws.get("d_logits", logits.numel())[:logits.numel()].view_as(logits)
-        hip.categorical_bwd(logits, action, avail, self.spec.act_dims, d_new_lp.reshape(n), d_entropy.reshape(n),
-                            d_logits)
-        self._net.backward(d_logits, d_value.reshape(n, -1))
+        d_ls = self.dist_bwd(logits, action, avail, d_new_lp.reshape(n), d_entropy.reshape(n), d_logits)
+        self._net.backward(d_logits, d_value.reshape(n, -1), d_ls)
         self._analysis = None
 
 
 policy_api.register("actor-critic", ActorCriticPolicy)
 policy_api.register("actor-critic-separate",
                     functools.partial(ActorCriticPolicy, shared_backbone=False, auxiliary_head=False))
+policy_api.register("gym_mujoco", functools.partial(ActorCriticPolicy, continuous_action=True))  # :538
+policy_api.register("actor-critic-separate-continuous-action",
+                    functools.partial(ActorCriticPolicy, shared_backbone=False, auxiliary_head=False,
+                                      continuous_action=True))  # :539-540
 policy_api.register("actor-critic-shared",
                     functools.partial(ActorCriticPolicy, shared_backbone=True, auxiliary_head=False))

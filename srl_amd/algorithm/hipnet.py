@@ -569,11 +569,18 @@ class HipNet:
                  logits_t.data_ptr(), atot, bias=self._p("actor_head.bias"))
         hip.gemm(n, sp.value_dim, sp.hidden_dim, c_feat.ptr, c_feat.ld, 0, self._p("critic_head.weight"), sp.hidden_dim,
                  0, value_t.data_ptr(), sp.value_dim, bias=self._p("critic_head.bias"))
+        self.log_std_rows = None
+        if sp.std_type == "shared_learnable":  # log sigma from a second head on the actor features (:93, :131-132)
+            ls_t = self.ws.get("log_std_rows", n * atot)
+            hip.gemm(n, atot, sp.hidden_dim, a_feat.ptr, a_feat.ld, 0, self._p("log_std.weight"), sp.hidden_dim, 0,
+                     ls_t.data_ptr(), atot, bias=self._p("log_std.bias"))
+            self.log_std_rows = ls_t[:n * atot].view(n, atot)
         self._tape = (n, a_feat, a_act, a_tape, c_feat, c_act, c_tape) if keep_tape else None
         return logits_t[:n * atot].view(n, atot), value_t[:n * sp.value_dim].view(n, sp.value_dim)
 
-    def backward(self, d_logits: torch.Tensor, d_value: torch.Tensor):
-        """Accumulate d loss / d parameters into ``self.grad`` given d loss / d logits and d loss / d value."""
+    def backward(self, d_logits: torch.Tensor, d_value: torch.Tensor, d_log_std_rows: Optional[torch.Tensor] = None):
+        """Accumulate d loss / d parameters into ``self.grad`` given d loss / d logits and d loss / d value (and, with a
+        `shared_learnable` Gaussian head, d loss / d log sigma per row)."""
         if self._tape is None:
             raise hip.HipError("backward() without a preceding forward(keep_tape=True)")
         sp = self.spec
@@ -582,6 +589,12 @@ class HipNet:
         dl = Buf(d_logits.data_ptr(), atot, n, atot)
         dv = Buf(d_value.data_ptr(), sp.value_dim, n, sp.value_dim)
         da = self._linear_bwd(sp.actor_head, a_feat, dl, a_act, True, "a:")
+        if sp.std_type == "shared_learnable":
+            dls = Buf(d_log_std_rows.data_ptr(), atot, n, atot)
+            self._linear_bwd(ns.LinearSpec("log_std", sp.hidden_dim, atot, 0), a_feat, dls, a_act, True, "a:", dx_into=da,
+                             dx_accumulate=True)
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(["log_std"])
         if self.grad_ready_hook is not None and sp.shared_backbone:
             self.grad_ready_hook([sp.actor_head.prefix])
         if sp.shared_backbone:

@@ -223,8 +223,7 @@ class MultiAgentPPO(PytorchTrainer):
                 raise NotImplementedError("V-trace with a recurrent policy is not on the HIP path")
             logits, _ = net.forward({k: v[r0:r1] for k, v in f_obs.items()}, n, keep_tape=False)
             ent = net.ws.get("entropy", n)[:n]
-            hip.categorical_fwd(logits, f_action[r0:r1], None if f_avail is None else f_avail[r0:r1], net.spec.act_dims,
-                                new_lp[r0:r1], ent)
+            self.policy.dist_fwd(logits, f_action[r0:r1], None if f_avail is None else f_avail[r0:r1], new_lp[r0:r1], ent)
         return torch.exp(new_lp - flat(old_lp).reshape(-1)).reshape(rows, B, 1)
 
     # ------------------------------------------------------------------ the step (mappo.py:219-328)
@@ -243,7 +242,7 @@ class MultiAgentPPO(PytorchTrainer):
                  truncated=to_device_leaf(sample.truncated, dev, "flag"), reward=to_device_leaf(sample.reward, dev, "real"),
                  old_value=to_device_leaf(sample.analyzed_result.value, dev, "real"),
                  old_lp=to_device_leaf(sample.analyzed_result.log_probs, dev, "real"),
-                 action=to_device_leaf(sample.action.x, dev, "index"))
+                 action=to_device_leaf(sample.action.x, dev, self.policy.action_kind()))
         for k, v in sample.obs.items():
             if v is not None:
                 L[f"obs.{k}"] = to_device_leaf(v, dev, "obs")
@@ -439,7 +438,7 @@ class MultiAgentPPO(PytorchTrainer):
                 logits, value = net.forward(c_obs, n, keep_tape=True, rnn=rnn)
                 logp = net.ws.get("new_logp", n)[:n]
                 ent = net.ws.get("entropy", n)[:n]
-                hip.categorical_fwd(logits, f_action[r0:r1], c_avail, net.spec.act_dims, logp, ent)
+                self.policy.dist_fwd(logits, f_action[r0:r1], c_avail, logp, ent)
                 d_lp = net.ws.get("d_logp", n)[:n]
                 d_v = net.ws.get("d_value", n)[:n]
                 d_ent = net.ws.get("d_entropy", n)[:n]
@@ -447,8 +446,8 @@ class MultiAgentPPO(PytorchTrainer):
                                      ent, f_mask[r0:r1], self._hp, stats_global, local_n, d_lp, d_v, d_ent, terms[ci],
                                      done=f_done[r0:r1], truncated=f_trunc[r0:r1])
                 d_logits = net.ws.get("d_logits", logits.numel())[:logits.numel()].view_as(logits)
-                hip.categorical_bwd(logits, f_action[r0:r1], c_avail, net.spec.act_dims, d_lp, d_ent, d_logits)
-                net.backward(d_logits, d_v.view(n, 1))
+                d_ls = self.policy.dist_bwd(logits, f_action[r0:r1], c_avail, d_lp, d_ent, d_logits)
+                net.backward(d_logits, d_v.view(n, 1), d_ls)
 
             # ---- gradient reduction, clip, Adam (mappo.py:272-284) ---------------------------------------------------
             if reducer is not None:  # the buckets not yet launched, then wait for all of them

@@ -159,6 +159,7 @@ class NetSpec:
     total_params: int
     popart: bool = False  # critic head is a PopArtValueHead: float64 running statistics ride along (POPART_KEYS)
     num_rnn_layers: int = 0  # GRU / LSTM layers at the end of each backbone (GruSpec + the rnn_norm LayerNormSpec)
+    std_type: Optional[str] = None  # continuous actions: "fixed" | "separate_learnable" | "shared_learnable" (log_std)
     rnn_state_width: int = 0  # per-layer width of the stored policy state (H, or 2H for LSTM: cat(h, c))
 
 
@@ -348,8 +349,11 @@ def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim
     layout) when ``seed`` is given, else ``None``."""
     if num_rnn_layers and rnn_type not in ("gru", "lstm"):
         raise NotImplementedError(f"rnn_type `{rnn_type}`: only the GRU and LSTM cells of AutoResetRNN are on the HIP path")
-    if continuous_action or auxiliary_head:
-        raise NotImplementedError("continuous actions / auxiliary value head are not on the HIP path")
+    if auxiliary_head:
+        raise NotImplementedError("the auxiliary value head (PPG) is not on the HIP path")
+    std_type = _unused.get("std_type", "fixed")
+    if continuous_action and std_type not in ("fixed", "separate_learnable", "shared_learnable"):
+        raise NotImplementedError(f"Standard deviation type {std_type} not implemented.")
     if use_maxpool and any(use_maxpool.values()):
         raise NotImplementedError("max-pooling convolution encoders are not on the HIP path")
     if activation not in ACTS:
@@ -368,14 +372,19 @@ def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim
         torch.set_num_threads(1)
     try:
         return _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation,
-                      layernorm, shared_backbone, seed, popart, num_rnn_layers, rnn_type)
+                      layernorm, shared_backbone, seed, popart, num_rnn_layers, rnn_type,
+                      (std_type, float(_unused.get("init_log_std", -0.5))) if continuous_action else None)
     finally:
         torch.set_num_threads(threads)
 
 
 def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation, layernorm,
-           shared_backbone, seed, popart=False, num_rnn_layers=0, rnn_type="gru"):
+           shared_backbone, seed, popart=False, num_rnn_layers=0, rnn_type="gru", continuous=None):
     b = _Builder(seed)
+    if continuous is not None and continuous[0] != "shared_learnable":
+        # one vector of log standard deviations; a direct nn.Parameter of the net, so it leads the state_dict.
+        # `fixed` is excluded from the optimiser in the reference (requires_grad=False): its gradient stays zero here
+        b._add("log_std", (sum(act_dims),), continuous[1] * torch.ones(sum(act_dims)) if b.init else None)
     obs_enc = _build_encoders(b, "obs_modules_dict", obs_dims, hidden_dim, act, activation, cnn_layers)
     actor_bb = _build_backbone(b, "actor_backbone", hidden_dim * len(obs_dims), hidden_dim, num_dense_layers, act,
                                layernorm, num_rnn_layers, rnn_type)
@@ -388,6 +397,14 @@ def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num
     b.linear("actor_head", hidden_dim, sum(act_dims))
     b.orthogonal("actor_head.weight", 0.01)  # actor_critic_policy.py:109-112
     b.zero("actor_head.bias")
+    std_type = None
+    if continuous is not None:  # Normal(mean, std): actor_critic_policy.py:85-96
+        std_type, init_log_std = continuous
+        if std_type == "shared_learnable":
+            b.linear("log_std", hidden_dim, sum(act_dims))
+            b.orthogonal("log_std.weight", 0.01)
+            b.zero("log_std.bias")
+        # (the vector forms were registered first: a module's own parameters precede its sub-modules' in state_dict)
     if popart:
         # PopArtValueHead (popart.py:19-26): the nn.Linear default reset, no orthogonal re-initialisation; the same
         # linear map on the device, only its state_dict keys and the float64 running statistics differ
@@ -408,5 +425,5 @@ def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num
     spec = NetSpec(obs_enc, actor_bb, state_enc, critic_bb, LinearSpec("actor_head", hidden_dim, sum(act_dims), 0),
                    LinearSpec("critic_head", hidden_dim, value_dim, 0), act_dims, hidden_dim, value_dim, shared_backbone,
                    b.params, off, popart, num_rnn_layers,
-                   (2 * hidden_dim if rnn_type == "lstm" else hidden_dim) if num_rnn_layers else 0)
+                   std_type, (2 * hidden_dim if rnn_type == "lstm" else hidden_dim) if num_rnn_layers else 0)
     return spec, (b.values if b.init else None)

@@ -76,6 +76,11 @@ _SIGNATURES = {
     "srl_popart_update": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                   c_int]),
     "srl_popart_map": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_double, c_int, c_void_p]),
+    "srl_gaussian_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_void_p]),
+    "srl_gaussian_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "srl_gaussian_sample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_uint64,
+                                    c_uint64, c_void_p, c_void_p]),
     "srl_gru_mask_state": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "srl_gru_cell_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "srl_gru_cell_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
@@ -247,6 +252,29 @@ def masked_normalize(x, mask, stats, out, mask_invert=False, eps=1e-5, unbiased=
         lib().srl_masked_normalize(_stream(), _ptr(x, torch.float32, "x"), _ptr(mask, torch.uint8, "mask"),
                                    int(mask_invert), x.numel(), _ptr(stats, torch.float64, "stats"), float(eps),
                                    int(unbiased), _ptr(out, torch.float32, "out")), "srl_masked_normalize")
+
+
+def gaussian_fwd(mean, log_std_ptr, ld_ls, action, logp, ent):
+    n, A = mean.shape
+    _check(lib().srl_gaussian_fwd(_stream(), _ptr(mean, torch.float32, "mean"), mean.stride(0), log_std_ptr, int(ld_ls),
+                                  _ptr(action, torch.float32, "action"), n, A, _ptr(logp, torch.float32, "logp"),
+                                  _ptr(ent, torch.float32, "ent")), "srl_gaussian_fwd")
+
+
+def gaussian_bwd(mean, log_std_ptr, ld_ls, action, d_logp, d_ent, d_mean, d_log_std):
+    n, A = mean.shape
+    f = torch.float32
+    _check(lib().srl_gaussian_bwd(_stream(), _ptr(mean, f, "mean"), mean.stride(0), log_std_ptr, int(ld_ls),
+                                  _ptr(action, f, "action"), n, A, _ptr(d_logp, f, "d_logp"), _ptr(d_ent, f, "d_ent"),
+                                  _ptr(d_mean, f, "d_mean"), _ptr(d_log_std, f, "d_log_std")), "srl_gaussian_bwd")
+
+
+def gaussian_sample(mean, log_std_ptr, ld_ls, is_eval, seed, offset, action, logp):
+    n, A = mean.shape
+    _check(lib().srl_gaussian_sample(_stream(), _ptr(mean, torch.float32, "mean"), mean.stride(0), log_std_ptr, int(ld_ls),
+                                     _ptr(is_eval, torch.uint8, "is_eval"), n, A, int(seed) & (2**64 - 1),
+                                     int(offset) & (2**64 - 1), _ptr(action, torch.float32, "action"),
+                                     _ptr(logp, torch.float32, "logp")), "srl_gaussian_sample")
 
 
 def gru_mask_state(h_ptr, reset_ptr, N, H, out_ptr):

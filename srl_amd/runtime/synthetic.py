@@ -45,7 +45,8 @@ def make_sample_arrays(seed: int,
                        value_dim: int = 1,
                        available_action: bool = False,
                        p_trunc: Optional[float] = None,
-                       policy_state: Optional[Dict[str, Tuple[int, int]]] = None) -> Dict[str, np.ndarray]:
+                       policy_state: Optional[Dict[str, Tuple[int, int]]] = None,
+                       continuous_action: bool = False) -> Dict[str, np.ndarray]:
     """Flat ``{dotted.key: array}`` dict of one synthetic sample; wrap with ``to_sample_batch``.
 
     ``policy_state``: ``{"hx": (layers, hidden)}`` (or ``actor_hx`` / ``critic_hx``) adds stored recurrent states
@@ -81,6 +82,12 @@ def make_sample_arrays(seed: int,
         "policy_version_steps": np.zeros((Tb, B, 1), dtype=np.int64),
         "info_mask": np.zeros((Tb, B, 1), dtype=np.uint8),
     })
+    if continuous_action:  # float32 actions [Tb, B, A] and log-probs of a unit Gaussian around them
+        crng = np.random.Generator(np.random.PCG64(seed + 104729))
+        a = crng.standard_normal((Tb, B, int(sum(dims)))).astype(np.float32)
+        out["action.x"] = a
+        out["analyzed_result.log_probs"] = (-0.5 * a.shape[-1] * np.log(2 * np.pi) - 0.5 * (a**2).sum(-1, keepdims=True) +
+                                            0.01 * crng.standard_normal((Tb, B, 1))).astype(np.float32)
     if policy_state:
         srng = np.random.Generator(np.random.PCG64(seed + 7919))
         for name, (layers, hidden) in policy_state.items():

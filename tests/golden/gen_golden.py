@@ -405,6 +405,33 @@ def gen_rnn():
     save("steps_rnn.npz", **out)
 
 
+def gen_continuous():
+    """Continuous actions (Normal(mean, std), the `gym_mujoco` policy): the three std parametrisations, full steps and a
+    deterministic rollout."""
+    out = {}
+    base = dict(obs_dim=7, action_dim=3, hidden_dim=32, num_dense_layers=2, num_rnn_layers=0, popart=False,
+                layernorm=True, shared_backbone=False, chunk_len=8, continuous_action=True)
+    smp = dict(T=16, B=6, obs_spec={"obs": ((7,), "f32")}, action_dims=3, p_done=0.1, continuous_action=True)
+    tr = dict(popart=False, optimizer_config=dict(lr=1e-3), max_grad_norm=5.0)
+    run_steps("cfix", dict(base, std_type="fixed", init_log_std=-0.3, seed=31), tr, smp, 2, out=out)
+    run_steps("csep", dict(base, std_type="separate_learnable", seed=32), dict(tr, ppo_epochs=2), smp, 2, out=out)
+    run_steps("cshr", dict(base, std_type="shared_learnable", shared_backbone=True, seed=33), tr, smp, 2, out=out)
+    policy = api.policy.make(api.config.Policy("actor-critic", args=dict(base, std_type="separate_learnable", seed=32)))
+    policy.eval_mode()
+    rng = np.random.default_rng(8)
+    N = 7
+    obs = rng.standard_normal((N, 7)).astype(np.float32)
+    req = api.policy.RolloutRequest(obs=NamedArray(obs=obs), is_evaluation=np.ones((N, 1), dtype=np.uint8),
+                                    on_reset=np.zeros((N, 1), dtype=np.uint8))
+    res = policy.rollout(req)
+    out["roll_obs"] = obs
+    out["roll_action"], out["roll_log_probs"], out["roll_value"] = (res.action.x, res.analyzed_result.log_probs,
+                                                                    res.analyzed_result.value)
+    for k, v in sd_to_np(policy.net.state_dict()).items():
+        out[f"roll_param:{k}"] = v
+    save("steps_continuous.npz", **out)
+
+
 def gen_paramdb():
     """Cross-check of the filesystem parameter store with the reference's client on the same directory: each reads
     what the other wrote; the resulting listing is the fixture."""

@@ -77,6 +77,18 @@ CASES = {
              dict(T=18, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.1,
                   policy_state={"actor_hx": (1, 16), "critic_hx": (1, 16)}), 2, "steps_rnn.npz"),
 }
+# continuous actions: Normal(mean, std) with the three parametrisations of log sigma (gen_golden.py gen_continuous)
+_CBASE = dict(obs_dim=7, action_dim=3, hidden_dim=32, num_dense_layers=2, num_rnn_layers=0, popart=False, layernorm=True,
+              shared_backbone=False, chunk_len=8, continuous_action=True)
+_CSMP = dict(T=16, B=6, obs_spec={"obs": ((7,), "f32")}, action_dims=3, p_done=0.1, continuous_action=True)
+_CTR = dict(popart=False, optimizer_config=dict(lr=1e-3), max_grad_norm=5.0)
+CASES.update({
+    "cfix": (dict(_CBASE, std_type="fixed", init_log_std=-0.3, seed=31), _CTR, _CSMP, 2, "steps_continuous.npz"),
+    "csep": (dict(_CBASE, std_type="separate_learnable", seed=32), dict(_CTR, ppo_epochs=2), _CSMP, 2,
+             "steps_continuous.npz"),
+    "cshr": (dict(_CBASE, std_type="shared_learnable", shared_backbone=True, seed=33), _CTR, _CSMP, 2,
+             "steps_continuous.npz"),
+})
 
 
 def make_trainer(policy_args, trainer_args):
@@ -295,3 +307,29 @@ def test_recurrent_rollout_golden(golden):
     assert close(res.analyzed_result.log_probs, g["roll_log_probs"], 1e-5)
     assert close(res.analyzed_result.value, g["roll_value"], 1e-5)
     assert res.policy_state.hx.shape == (n, 1, 32) and close(res.policy_state.hx, g["roll_new_hx"], 1e-5)
+
+
+def test_continuous_rollout_golden(golden):
+    """Gaussian head: evaluation rollout returns the mean and its log-probability; sampling is checked statistically."""
+    g = golden("steps_continuous.npz")
+    pol = policy_api.make(config.Policy("gym_mujoco", args=dict(_CBASE, std_type="separate_learnable", seed=32)))
+    pol.load_checkpoint({"steps": 0, "state_dict": {k[len("roll_param:"):]: torch.from_numpy(g[k]) for k in g.files
+                                                    if k.startswith("roll_param:")}})
+    n = g["roll_obs"].shape[0]
+    req = policy_api.RolloutRequest(obs=NamedArray(obs=g["roll_obs"]), is_evaluation=np.ones((n, 1), np.uint8),
+                                    on_reset=np.zeros((n, 1), np.uint8))
+    res = pol.rollout(req)
+    assert res.action.x.dtype == np.float32 and close(res.action.x, g["roll_action"], 1e-5)
+    assert close(res.analyzed_result.log_probs, g["roll_log_probs"], 1e-5)
+    assert close(res.analyzed_result.value, g["roll_value"], 1e-5)
+    # stochastic: (x - mean) / std is standard normal; the reported log-prob is that of the returned action
+    m = 4096
+    obs = np.repeat(g["roll_obs"][:1], m, 0)
+    req = policy_api.RolloutRequest(obs=NamedArray(obs=obs), is_evaluation=np.zeros((m, 1), np.uint8),
+                                    on_reset=np.zeros((m, 1), np.uint8))
+    s = pol.rollout(req)
+    std = np.exp(g["roll_param:log_std"])
+    z = (s.action.x - g["roll_action"][:1]) / std
+    assert abs(z.mean()) < 0.05 and abs(z.std() - 1.0) < 0.05
+    lp = (-0.5 * z**2 - np.log(std) - 0.5 * np.log(2 * np.pi)).sum(-1, keepdims=True)
+    assert close(s.analyzed_result.log_probs, lp, 1e-4)

@@ -59,7 +59,8 @@ def test_product_path_fails_loudly_without_gpu():
 
 def test_unsupported_configs_raise():
     base = dict(obs_dim=4, action_dim=2, num_rnn_layers=0, popart=False)
-    for bad in (dict(num_rnn_layers=1, rnn_type="gtrxl"), dict(continuous_action=True), dict(obs_dim={"o": (3, 10)})):
+    for bad in (dict(num_rnn_layers=1, rnn_type="gtrxl"), dict(continuous_action=True, std_type="state_dependent"),
+                dict(auxiliary_head=True), dict(obs_dim={"o": (3, 10)})):
         with pytest.raises((NotImplementedError, AttributeError)):
             policy_api.make(config.Policy("actor-critic", args={**base, **bad}))
 
