@@ -32,6 +32,122 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, long
   }
 }
 
+// Narrow LayerNorms (D <= 128, the hidden sizes of the MLP / recurrent policies): LPR = 4..32 lanes own one row
+// (one float4 each), so a wavefront normalises 64/LPR rows at once and its reductions are LPR-wide butterflies
+// instead of a 64-wide one per 256-byte row.  Needs D % 4 == 0, pitches % 4 == 0 and 16-byte aligned bases.
+template <int LPR>
+__device__ __forceinline__ float sub_allsum(float v) {
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_fwd_small_kernel(const float* x, long ldx, const float* gamma,
+                                                                  const float* beta, long rows, int D, float* y,
+                                                                  long ldy, float* mean_out, float* rstd_out) {
+  constexpr int RW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sl = lane % LPR;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW + lane / LPR;
+  const bool ok = row < rows && sl * 4 < D;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) v = *reinterpret_cast<const float4*>(x + row * ldx + sl * 4);
+  const float mean = sub_allsum<LPR>(v.x + v.y + v.z + v.w) / (float)D;
+  const float4 d = ok ? make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float rstd = rsqrtf(sub_allsum<LPR>(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) / (float)D + kLnEps);
+  if (!ok) return;
+  const float4 g = *reinterpret_cast<const float4*>(gamma + sl * 4), b = *reinterpret_cast<const float4*>(beta + sl * 4);
+  *reinterpret_cast<float4*>(y + row * ldy + sl * 4) =
+      make_float4(d.x * rstd * g.x + b.x, d.y * rstd * g.y + b.y, d.z * rstd * g.z + b.z, d.w * rstd * g.w + b.w);
+  if (sl == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const float* dy, long lddy, const float* x, long ldx,
+                                                                  const float* gamma, const float* mean,
+                                                                  const float* rstd, long rows, int D, float* dx,
+                                                                  long lddx, int dact, float* dgamma, float* dbeta,
+                                                                  long rows_per_block) {
+  constexpr int RW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sl = lane % LPR, sub = lane / LPR;
+  const bool col_ok = sl * 4 < D;
+  float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col_ok) gm = *reinterpret_cast<const float4*>(gamma + sl * 4);
+  float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (long base = r0 + (long)wid * RW; base < r1; base += 4 * RW) {
+    const long row = base + sub;
+    const bool ok = row < r1 && col_ok;
+    float xv[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
+    float mu = 0.f, rs = 0.f;
+    if (ok) {
+      const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + sl * 4);
+      const float4 c = *reinterpret_cast<const float4*>(dy + row * lddy + sl * 4);
+      xv[0] = a.x, xv[1] = a.y, xv[2] = a.z, xv[3] = a.w;
+      dv[0] = c.x, dv[1] = c.y, dv[2] = c.z, dv[3] = c.w;
+      mu = mean[row], rs = rstd[row];
+    }
+    const float gv[4] = {gm.x, gm.y, gm.z, gm.w};
+    float s1 = 0.f, s2 = 0.f, xh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xh[e] = ok ? (xv[e] - mu) * rs : 0.f;
+      const float g = dv[e] * gv[e];
+      s1 += g;
+      s2 += g * xh[e];
+      pg[e] += dv[e] * xh[e];
+      pb[e] += dv[e];
+    }
+    if (dx) {
+      const float m1 = sub_allsum<LPR>(s1) / (float)D, m2 = sub_allsum<LPR>(s2) / (float)D;
+      if (ok) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = rs * (dv[e] * gv[e] - m1 - xh[e] * m2);
+          if (dact) o[e] *= act_grad_from_output(xv[e], dact);  // x is the activation output that fed this LayerNorm
+        }
+        *reinterpret_cast<float4*>(dx + row * lddx + sl * 4) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+  // fold the 64/LPR row groups of the wavefront, then the 4 wavefronts through LDS, then one atomic per column
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int m = LPR; m < 64; m <<= 1) {
+      pg[e] += __shfl_xor(pg[e], m, 64);
+      pb[e] += __shfl_xor(pb[e], m, 64);
+    }
+  }
+  __shared__ float sg[4][LPR * 8];
+  if (lane < LPR) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sg[wid][lane * 8 + e] = pg[e];
+      sg[wid][lane * 8 + 4 + e] = pb[e];
+    }
+  }
+  __syncthreads();
+  if (wid == 0 && lane < LPR && col_ok) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(dgamma + sl * 4 + e, sg[0][lane * 8 + e] + sg[1][lane * 8 + e] + sg[2][lane * 8 + e] + sg[3][lane * 8 + e]);
+      atomicAdd(dbeta + sl * 4 + e,
+                sg[0][lane * 8 + 4 + e] + sg[1][lane * 8 + 4 + e] + sg[2][lane * 8 + 4 + e] + sg[3][lane * 8 + 4 + e]);
+    }
+  }
+}
+
+inline bool ln_small_ok(const void* a, const void* b, const void* c, long lda, long ldb, int D) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return D <= 128 && D % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && al(a) && al(b) && al(c);
+}
+
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += sum dy*xhat; dbeta += sum dy.
 // Each workgroup walks `rows_per_block` rows with 4 wavefronts, keeps per-lane partial dgamma/dbeta in
 // registers (D <= 64*LN_MAXV) and flushes them once with float atomics.
@@ -279,6 +395,19 @@ extern "C" int srl_layernorm_fwd(void* stream, const float* x, int64_t ldx, cons
                                  int64_t rows, int D, float* y, int64_t ldy, float* mean, float* rstd) {
   SRL_CHECK_ARG(x && gamma && beta && y && mean && rstd && D >= 1 && rows >= 0, "null tensor");
   if (rows == 0) return 0;
+  if (ln_small_ok(x, y, gamma, ldx, ldy, D) && (reinterpret_cast<uintptr_t>(beta) & 15) == 0) {
+    hipStream_t st = (hipStream_t)stream;
+#define SRL_LN_FWD(LPR)                                                                                               \
+  hipLaunchKernelGGL(layernorm_fwd_small_kernel<LPR>, dim3((unsigned)srl_ceil_div(rows, 4L * (64 / LPR))), dim3(256), 0, \
+                     st, x, ldx, gamma, beta, rows, D, y, ldy, mean, rstd)
+    if (D <= 16) SRL_LN_FWD(4);
+    else if (D <= 32) SRL_LN_FWD(8);
+    else if (D <= 64) SRL_LN_FWD(16);
+    else SRL_LN_FWD(32);
+#undef SRL_LN_FWD
+    SRL_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)srl_ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
                      x, ldx, gamma, beta, rows, D, y, ldy, mean, rstd);
   SRL_LAUNCH_CHECK();
@@ -294,6 +423,20 @@ extern "C" int srl_layernorm_bwd(void* stream, const float* dy, int64_t lddy, co
   // ~4 workgroups per CU; each flushes D*2 atomics, so keep the row share large
   long rpb = srl_ceil_div(rows, 1024);
   if (rpb < 16) rpb = 16;
+  if (ln_small_ok(x, dy, gamma, ldx, lddy, D) && (!dx || ((reinterpret_cast<uintptr_t>(dx) & 15) == 0 && lddx % 4 == 0))) {
+    hipStream_t st = (hipStream_t)stream;
+    if (rpb < 64) rpb = 64;
+#define SRL_LN_BWD(LPR)                                                                                              \
+  hipLaunchKernelGGL(layernorm_bwd_small_kernel<LPR>, dim3((unsigned)srl_ceil_div(rows, rpb)), dim3(256), 0, st, dy, lddy, \
+                     x, ldx, gamma, mean, rstd, rows, D, dx, lddx, dact, dgamma, dbeta, rpb)
+    if (D <= 16) SRL_LN_BWD(4);
+    else if (D <= 32) SRL_LN_BWD(8);
+    else if (D <= 64) SRL_LN_BWD(16);
+    else SRL_LN_BWD(32);
+#undef SRL_LN_BWD
+    SRL_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)srl_ceil_div(rows, rpb)), dim3(256), 0, (hipStream_t)stream,
                      dy, lddy, x, ldx, gamma, mean, rstd, rows, D, dx, lddx, dact, dgamma, dbeta, rpb);
   SRL_LAUNCH_CHECK();
