@@ -119,17 +119,27 @@ int dgrad_classes(const srl_conv_desc* d, DgradClass* out /* stride*stride entri
   return n;
 }
 
-// wt[class][(jh, jw, o)][ci] = w[o][ph + jh*S][pw + jw*S][ci]
+// wt[(jh, jw, o) * ld + ci] = w[o][ph + jh*S][pw + jw*S][ci]: one class's block; ld = Cin when the classes are stored
+// one after the other, ncls * Cin when they sit side by side along N (wt then points at the class's first column)
 __global__ __launch_bounds__(256) void dgrad_repack_kernel(const float* w, float* wt, int Cout, int KH, int KW, int Cin,
-                                                           int S, int ph, int pw, int th, int tw) {
+                                                           int S, int ph, int pw, int th, int tw, int ld) {
   const int total = th * tw * Cout * Cin;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
     const int ci = e % Cin;
     const int o = (e / Cin) % Cout;
     const int t = e / (Cin * Cout);
     const int jh = t / tw, jw = t % tw;
-    wt[e] = w[((o * KH + ph + jh * S) * KW + pw + jw * S) * Cin + ci];
+    wt[(long)(e / Cin) * ld + ci] = w[((o * KH + ph + jh * S) * KW + pw + jw * S) * Cin + ci];
   }
+}
+
+// every parity class has the same tap and row grids (stride divides the kernel and the image): the classes then share
+// the A operand (the taps of dz that reach a pixel do not depend on the class) and are packed along N
+bool dgrad_uniform(const DgradClass* cls, int nc) {
+  bool u = nc > 1 && cls[0].th * cls[0].tw > 0 && cls[0].ra > 0 && cls[0].rb > 0;
+  for (int i = 1; i < nc; ++i)
+    u = u && cls[i].th == cls[0].th && cls[i].tw == cls[0].tw && cls[i].ra == cls[0].ra && cls[i].rb == cls[0].rb;
+  return u;
 }
 
 // ---- finalisation of the first-layer backward from the per-position products Q and column sums R --------------------
@@ -304,12 +314,14 @@ extern "C" int srl_conv2d_dgrad_repack(void* stream, const srl_conv_desc* d, con
   SRL_CHECK_ARG(check_desc(d) == 0 && w && wt && d->stride <= 8, "bad descriptor");
   DgradClass cls[64];
   const int nc = dgrad_classes(d, cls);
+  const bool packed = dgrad_uniform(cls, nc) && (nc * d->Cin) % 4 == 0;
   for (int i = 0; i < nc; ++i) {
     const DgradClass& c = cls[i];
     const int total = c.th * c.tw * d->Cout * d->Cin;
     if (total == 0) continue;
     hipLaunchKernelGGL(dgrad_repack_kernel, dim3((unsigned)srl_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       wt + c.w_off, d->Cout, d->KH, d->KW, d->Cin, d->stride, c.ph, c.pw, c.th, c.tw);
+                       packed ? wt + (long)i * d->Cin : wt + c.w_off, d->Cout, d->KH, d->KW, d->Cin, d->stride, c.ph, c.pw,
+                       c.th, c.tw, packed ? nc * d->Cin : d->Cin);
   }
   SRL_LAUNCH_CHECK();
   return 0;
@@ -324,14 +336,12 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
   hipStream_t st = (hipStream_t)stream;
   DgradClass cls[64];
   const int nc = dgrad_classes(d, cls);
-  // When every parity class has the same tap and row grids (stride divides the kernel and the image), the
-  // classes differ only in their weight block and in where their rows land: they run as the batch index of one
-  // launch (fastest-varying, so the workgroups that share rows of dz run together and hit L2).
-  bool uniform = nc > 1;
-  for (int i = 1; i < nc; ++i)
-    uniform = uniform && cls[i].th == cls[0].th && cls[i].tw == cls[0].tw && cls[i].ra == cls[0].ra &&
-              cls[i].rb == cls[0].rb;
-  uniform = uniform && cls[0].th * cls[0].tw > 0 && cls[0].ra > 0 && cls[0].rb > 0;
+  // When every parity class has the same tap and row grids (stride divides the kernel and the image), the classes
+  // differ only in their weight block and in where their rows land.  They share the A operand (the taps of dz that
+  // reach a pixel do not depend on its class), so they are packed side by side along N: ONE GEMM with
+  // N = classes * Cin whose column groups land on the classes' pixels -- A is staged once for all of them and the
+  // tile is 128 wide instead of 32.
+  const bool uniform = dgrad_uniform(cls, nc) && (nc * d->Cin) % 4 == 0;
   for (int i = 0; i < (uniform ? 1 : nc); ++i) {
     const DgradClass& c = cls[i];
     if (c.ra == 0 || c.rb == 0) continue;
@@ -359,19 +369,21 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
     o.x_stride = (long)d->stride * d->Cin;
     g.o = o;
     if (x_act && dact) { g.dact_src = x_act + ((long)c.ph * d->W + c.pw) * d->Cin; g.dact = dact; }
-    int batch = 1;
-    if (uniform) {  // class (ph, pw) = batch index ph * stride + pw
-      batch = nc;
-      g.b.brw = 1; g.b.by_stride = (int)(g.K * d->Cin); g.b.bx_stride = 0;
-      g.o.brw = d->stride; g.o.batch_stride = (long)d->W * d->Cin; g.o.bx_stride = d->Cin;
+    const int batch = 1;
+    if (uniform) {  // column group (ph, pw) = ph * stride + pw, Cin columns each
+      g.N = (long)nc * d->Cin;
+      g.b = plain_src(wt, nc * d->Cin);
+      g.o.cg_width = d->Cin; g.o.cg_brw = d->stride; g.o.f_cg = make_fastdiv((uint32_t)d->Cin);
+      g.o.cg_ystride = (long)d->W * d->Cin; g.o.cg_xstride = d->Cin;
     }
+    const long ncols = g.N;
     g.k_per_split = srl_ceil_div(g.K > 0 ? g.K : 1, BK) * BK;
     g.vec_a = 1; g.vec_b = 1;
     int rc;
     if (g.K == 0) {  // no tap reaches this class: gradient is zero there (k loop is empty, epilogue writes 0)
       rc = launch<256, 32, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);
-    } else if (d->Cin > 64) rc = launch<128, 128, 2, 2, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
-    else if (d->Cin > 32) rc = launch<256, 64, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
+    } else if (ncols > 64) rc = launch<128, 128, 2, 2, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
+    else if (ncols > 32) rc = launch<256, 64, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
     else rc = launch<256, 32, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
     SRL_CHECK_ARG(rc == 0, "grid too large");
   }

@@ -81,6 +81,12 @@ struct OutDesc {
   long batch_stride;  // batch b: out += (b / brw) * batch_stride + (b % brw) * bx_stride  (brw 0: b * batch_stride)
   int brw;
   long bx_stride;
+  // column groups (cg_width > 0): column c = (group, ci), ci = c % cg_width; the group's columns land at
+  // + (group / cg_brw) * cg_ystride + (group % cg_brw) * cg_xstride + ci  (parity classes of a strided data gradient
+  // packed along N: they share the A operand and differ only in where their rows land)
+  int cg_width, cg_brw;
+  FastDiv f_cg;
+  long cg_ystride, cg_xstride;
 };
 
 struct GemmArgs {
@@ -606,10 +612,15 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     for (int j = 0; j < TN; ++j) {
       const long col = n0 + wn * (TN * 32) + j * 32 + l31;
       const bool cok = col < g.N;
-      const uint32_t cc = cok ? (uint32_t)col : 0u;
+      const uint32_t cb = cok ? (uint32_t)col : 0u;  // bias index
+      uint32_t cc = cb;                               // offset of the column inside an output row
+      if (g.o.cg_width) {
+        const uint32_t grp = fdiv(cb, g.o.f_cg);
+        cc = (uint32_t)((grp / g.o.cg_brw) * g.o.cg_ystride + (grp % g.o.cg_brw) * g.o.cg_xstride) + (cb - grp * g.o.cg_width);
+      }
       const uint32_t okj = cok ? okm : 0u;
       float v[16];
-      const float bv = bias ? bias[cc] : 0.f;
+      const float bv = bias ? bias[cb] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
       if (g.act == 1) {
