@@ -218,20 +218,20 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, uint32_t voff
 // k-contiguous operand, columns for a k-major one), validity, LayerNorm statistics.  Per k-tile a dense operand costs
 // no vector ALU work at all (the descriptor base advances on the scalar unit); a gathered one costs one column (or
 // row) decomposition per lane plus an add per quad.
-template <int BX, bool KMAJOR, int MODE, int NT = 256>
+template <int BX, bool KMAJOR, int MODE, int NT = 256, int KB = BK>
 struct Stage {
-  // LDS tile: a k-major operand is stored [BK][BX + 4] (ds_write_b128 along the output index); a k-contiguous one
-  // is stored as it comes, [BX][BK + 4] (ds_write_b128 along k: no transposing scalar stores, which cost 14 % of the
+  // LDS tile: a k-major operand is stored [KB][BX + 4] (ds_write_b128 along the output index); a k-contiguous one
+  // is stored as it comes, [BX][KB + 4] (ds_write_b128 along k: no transposing scalar stores, which cost 14 % of the
   // MFMA rate in scripts/mfma_peak.hip).  The +4 keeps rows 16-byte aligned and spreads 8 consecutive rows over
   // all eight 16-byte bank groups (pitch 20 floats = 5 groups, odd).
   static constexpr int LD = BX + 4;
-  static constexpr int PK = BK + 4;
-  static constexpr int TILE = KMAJOR ? BK * LD : BX * PK;
-  static constexpr int QUADS = BX * BK / 4;            // float4 per tile
+  static constexpr int PK = KB + 4;
+  static constexpr int TILE = KMAJOR ? KB * LD : BX * PK;
+  static constexpr int QUADS = BX * KB / 4;            // float4 per tile
   static constexpr int NV = (QUADS + NT - 1) / NT;       // float4 per thread
   static constexpr int NF = NV * 4;                    // floats per thread
   static constexpr bool PARTIAL = QUADS < NV * NT;    // narrow tiles: only threads with u < QUADS stage
-  static constexpr int KQ = BK / 4;                    // quads per k-contiguous row
+  static constexpr int KQ = KB / 4;                    // quads per k-contiguous row
   static constexpr bool GATHER = MODE != SRC_PLAIN;
   float r[NF];
   uint32_t voff[NV];                                 // k-invariant byte offset of quad q (kInvalidOff: always zero)
@@ -253,8 +253,8 @@ struct Stage {
     if (!GATHER) {
       if (!vec) return;  // scalar fallback addresses directly
       const long ld = s.ld;
-      if (!KMAJOR) { cur = static_cast<const char*>(s.base) + (x0 * ld + kbeg) * 4; step = BK * 4; }
-      else { cur = static_cast<const char*>(s.base) + (kbeg * ld + x0) * 4; step = (long)BK * ld * 4; }
+      if (!KMAJOR) { cur = static_cast<const char*>(s.base) + (x0 * ld + kbeg) * 4; step = KB * 4; }
+      else { cur = static_cast<const char*>(s.base) + (kbeg * ld + x0) * 4; step = (long)KB * ld * 4; }
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int u = tid + q * NT;
@@ -285,7 +285,7 @@ struct Stage {
     }
   }
 
-  // loads k-tile [k0, k0 + BK) clipped to kend; must be called for consecutive tiles (the dense base advances)
+  // loads k-tile [k0, k0 + KB) clipped to kend; must be called for consecutive tiles (the dense base advances)
   __device__ __forceinline__ void load(const SrcDesc& s, long x0, long xn, long k0, long kend, bool vec) {
     const int tid = threadIdx.x;
     if (GATHER) {
@@ -354,9 +354,9 @@ struct Stage {
     for (int q = 0; q < NF; ++q) {
       const int e = tid + q * NT;
       float v = 0.f;
-      if (PARTIAL && e >= BX * BK) {
+      if (PARTIAL && e >= BX * KB) {
       } else if (!KMAJOR) {
-        const long x = x0 + e / BK, k = k0 + e % BK;
+        const long x = x0 + e / KB, k = k0 + e % KB;
         if (x < xn && k < kend) v = src[x * ld + k];
       } else {
         const long k = k0 + e / BX, x = x0 + e % BX;
@@ -413,8 +413,8 @@ struct Stage {
 #pragma unroll
       for (int q = 0; q < NF; ++q) {
         const int e = tid + q * NT;
-        if (PARTIAL && e >= BX * BK) continue;
-        if (!KMAJOR) lds[(e / BK) * PK + e % BK] = r[q];
+        if (PARTIAL && e >= BX * KB) continue;
+        if (!KMAJOR) lds[(e / KB) * PK + e % KB] = r[q];
         else lds[(e / BX) * LD + e % BX] = r[q];
       }
     }
@@ -434,13 +434,13 @@ constexpr int min_waves(int bm, int bn, int amode, int bmode, bool gen, int nwav
   return big ? 3 : 4;
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN, int KB>
 __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, WM * WN)) void gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1, "4 or 8 wavefronts per workgroup");
   constexpr int NT = WM * WN * 64;
-  using SA = Stage<BM, AKM, AMODE, NT>;
-  using SB = Stage<BN, BKM, BMODE, NT>;
+  using SA = Stage<BM, AKM, AMODE, NT, KB>;
+  using SB = Stage<BN, BKM, BMODE, NT, KB>;
   constexpr int A_FLOATS = SA::TILE, TILE_FLOATS = SA::TILE + SB::TILE;  // multiples of 4: 16-byte aligned
   __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
 
@@ -495,33 +495,34 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
   sa.store(lds, va, g.a);
   sb.store(lds + A_FLOATS, vb, g.b);
   __syncthreads();
-  if (kbeg + BK < kend) {
-    sa.load(g.a, m0, g.M, kbeg + BK, kend, va);
-    sb.load(g.b, n0, g.N, kbeg + BK, kend, vb);
+  if (kbeg + KB < kend) {
+    sa.load(g.a, m0, g.M, kbeg + KB, kend, va);
+    sb.load(g.b, n0, g.N, kbeg + KB, kend, vb);
   }
 
   // one k-step on LDS buffer `cur` (compile-time): MFMAs, with the staging of the following tiles in the middle
   auto kstep = [&](auto cur_c, long k0) {
     constexpr int cur = decltype(cur_c)::value;
-    // MFMA step kk consumes k = 8*h + kk of the tile (h = lane >> 5): any pairing of the 16 k values works as long
+    // MFMA step kk consumes k = (KB/2)*h + kk of the tile (h = lane >> 5): any pairing of the KB k values works as long
     // as both operands use the same one, and this one lets a k-contiguous operand fetch its 8 values with two
     // ds_read_b128.  A k-major operand reads row 8*h + kk, one step ahead of its MFMAs.
     const float* ap = lds + cur * TILE_FLOATS +
-                      (AKM ? 8 * h * SA::LD + wm * (TM * 32) + l31 : (wm * (TM * 32) + l31) * SA::PK + 8 * h);
+                      (AKM ? (KB / 2) * h * SA::LD + wm * (TM * 32) + l31 : (wm * (TM * 32) + l31) * SA::PK + (KB / 2) * h);
     const float* bp = lds + cur * TILE_FLOATS + A_FLOATS +
-                      (BKM ? 8 * h * SB::LD + wn * (TN * 32) + l31 : (wn * (TN * 32) + l31) * SB::PK + 8 * h);
+                      (BKM ? (KB / 2) * h * SB::LD + wn * (TN * 32) + l31 : (wn * (TN * 32) + l31) * SB::PK + (KB / 2) * h);
     float* nxt = lds + (cur ^ 1) * TILE_FLOATS;
-    float a[AKM ? 2 : 8][TM], b[BKM ? 2 : 8][TN];
+    float a[AKM ? 2 : KB / 2][TM], b[BKM ? 2 : KB / 2][TN];
     if (AKM) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32];
     } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const float4 lo = *reinterpret_cast<const float4*>(ap + i * 32 * SA::PK);
-        const float4 hi = *reinterpret_cast<const float4*>(ap + i * 32 * SA::PK + 4);
-        a[0][i] = lo.x, a[1][i] = lo.y, a[2][i] = lo.z, a[3][i] = lo.w;
-        a[4][i] = hi.x, a[5][i] = hi.y, a[6][i] = hi.z, a[7][i] = hi.w;
+#pragma unroll
+        for (int c4 = 0; c4 < KB / 8; ++c4) {
+          const float4 q = *reinterpret_cast<const float4*>(ap + i * 32 * SA::PK + 4 * c4);
+          a[4 * c4][i] = q.x, a[4 * c4 + 1][i] = q.y, a[4 * c4 + 2][i] = q.z, a[4 * c4 + 3][i] = q.w;
+        }
       }
     }
     if (BKM) {
@@ -530,15 +531,16 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     } else {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const float4 lo = *reinterpret_cast<const float4*>(bp + j * 32 * SB::PK);
-        const float4 hi = *reinterpret_cast<const float4*>(bp + j * 32 * SB::PK + 4);
-        b[0][j] = lo.x, b[1][j] = lo.y, b[2][j] = lo.z, b[3][j] = lo.w;
-        b[4][j] = hi.x, b[5][j] = hi.y, b[6][j] = hi.z, b[7][j] = hi.w;
+#pragma unroll
+        for (int c4 = 0; c4 < KB / 8; ++c4) {
+          const float4 q = *reinterpret_cast<const float4*>(bp + j * 32 * SB::PK + 4 * c4);
+          b[4 * c4][j] = q.x, b[4 * c4 + 1][j] = q.y, b[4 * c4 + 2][j] = q.z, b[4 * c4 + 3][j] = q.w;
+        }
       }
     }
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      if (kk + 1 < BK / 2) {
+    for (int kk = 0; kk < KB / 2; ++kk) {
+      if (kk + 1 < KB / 2) {
         if (AKM) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) a[(kk + 1) & 1][i] = ap[(kk + 1) * SA::LD + i * 32];
@@ -548,14 +550,14 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
           for (int j = 0; j < TN; ++j) b[(kk + 1) & 1][j] = bp[(kk + 1) * SB::LD + j * 32];
         }
       }
-      if (kk == BK / 4) {
-        if (k0 + BK < kend) {  // tile t+1: registers -> the other LDS buffer (its readers left at the last barrier)
+      if (kk == KB / 4) {
+        if (k0 + KB < kend) {  // tile t+1: registers -> the other LDS buffer (its readers left at the last barrier)
           sa.store(nxt, va, g.a);
           sb.store(nxt + A_FLOATS, vb, g.b);
         }
-        if (k0 + 2 * BK < kend) {  // tile t+2: global -> registers
-          sa.load(g.a, m0, g.M, k0 + 2 * BK, kend, va);
-          sb.load(g.b, n0, g.N, k0 + 2 * BK, kend, vb);
+        if (k0 + 2 * KB < kend) {  // tile t+2: global -> registers
+          sa.load(g.a, m0, g.M, k0 + 2 * KB, kend, va);
+          sb.load(g.b, n0, g.N, k0 + 2 * KB, kend, vb);
         }
       }
       // (no sched_barrier: order-pinning was measured)
@@ -567,9 +569,9 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     }
     __syncthreads();  // tile t+1 is visible; everyone is done reading tile t
   };
-  for (long k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+  for (long k0 = kbeg; k0 < kend; k0 += 2 * KB) {
     kstep(std::integral_constant<int, 0>{}, k0);
-    if (k0 + BK < kend) kstep(std::integral_constant<int, 1>{}, k0 + BK);
+    if (k0 + KB < kend) kstep(std::integral_constant<int, 1>{}, k0 + KB);
   }
 
   // ---- epilogue: per 32x32 accumulator block, all loads batched ahead of the arithmetic and the stores ----------------
@@ -686,15 +688,15 @@ inline SrcDesc plain_src(const float* base, long ld) {
 // k range per split: a multiple of BK so that float4 loads never straddle a split boundary
 inline int plan_split(long K, int want, long* k_per_split) {
   if (want < 1) want = 1;
-  long kps = srl_ceil_div(srl_ceil_div(K, want), BK) * BK;
-  if (kps == 0) kps = BK;
+  long kps = srl_ceil_div(srl_ceil_div(K, want), 2 * BK) * 2 * BK;  // multiple of every k-step depth in use
+  if (kps == 0) kps = 2 * BK;
   *k_per_split = kps;
   const long n = srl_ceil_div(K, kps);
   return (int)(n > 0 ? n : 1);
 }
 
 #ifdef __HIPCC__
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN = false>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN = false, int KB = BK>
 inline int launch(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   if (!GEN && !(a.vec_a && a.vec_b)) return -EINVAL;  // float4-only instantiation
   const long tiles_m = srl_ceil_div(a.M, BM);
@@ -703,7 +705,7 @@ inline int launch(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   const long nblk = tiles_m * a.tiles_n * a.nbatch;
   if (nblk > 0x7fffffffL || nsplit > 65535) return -EINVAL;
   dim3 grid((unsigned)nblk, 1, (unsigned)nsplit);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, GEN>), grid, dim3(WM * WN * 64), 0, st, a);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, GEN, KB>), grid, dim3(WM * WN * 64), 0, st, a);
   return 0;
 }
 #endif
