@@ -118,8 +118,11 @@ class OracleActorCritic:
             outs.append(x)
         return torch.cat(outs, dim=-1)
 
+    def _rnn_key(self, prefix, n, layer):
+        return f"{prefix}.rnn._AutoResetRNN__net.{n}_l{layer}"
+
     def _gru_step(self, prefix, layer, x, h):
-        p = lambda n: self._p(f"{prefix}.rnn._AutoResetRNN__net.{n}_l{layer}")
+        p = lambda n: self._p(self._rnn_key(prefix, n, layer))
         gi = F.linear(x, p("weight_ih"), p("bias_ih"))
         gh = F.linear(h, p("weight_hh"), p("bias_hh"))
         ir, iz, inn = gi.chunk(3, -1)
@@ -131,7 +134,7 @@ class OracleActorCritic:
 
     def _lstm_step(self, prefix, layer, x, hc):
         """torch.nn.LSTM cell; the AutoResetRNN state is cat(h, c) on the last axis (autoreset_rnn.py:31-39)."""
-        p = lambda n: self._p(f"{prefix}.rnn._AutoResetRNN__net.{n}_l{layer}")
+        p = lambda n: self._p(self._rnn_key(prefix, n, layer))
         H = self.hidden
         h, c = hc[..., :H], hc[..., H:]
         pre = F.linear(x, p("weight_ih"), p("bias_ih")) + F.linear(h, p("weight_hh"), p("bias_hh"))
@@ -151,6 +154,11 @@ class OracleActorCritic:
                                  self._p(f"{prefix}.fc.{stride * j + 2}.bias"), 1e-5)
         if self.num_rnn_layers == 0:
             return x, hx
+        y, h = self._recur(prefix, x, hx, on_reset)
+        y = F.layer_norm(y, (self.hidden,), self._p(f"{prefix}.rnn_norm.weight"), self._p(f"{prefix}.rnn_norm.bias"), 1e-5)
+        return y, h
+
+    def _recur(self, prefix, x, hx, on_reset):
         # AutoResetRNN: h is zeroed at every step whose on_reset flag is set (autoreset_rnn.py:46-60);
         # stepping one row at a time is arithmetically the same as the reference's segment batching.
         h = [hx[l] for l in range(self.num_rnn_layers)]
@@ -166,9 +174,7 @@ class OracleActorCritic:
                     h[l] = self._gru_step(prefix, l, inp, hl)
                     inp = h[l]
             ys.append(inp)
-        y = torch.stack(ys, 0)
-        y = F.layer_norm(y, (self.hidden,), self._p(f"{prefix}.rnn_norm.weight"), self._p(f"{prefix}.rnn_norm.bias"), 1e-5)
-        return y, torch.stack(h, 0)
+        return torch.stack(ys, 0), torch.stack(h, 0)
 
     # ------------------------------------------------------------------ forward
     def forward(self, obs: Dict[str, torch.Tensor], policy_state=(None, None), on_reset=None):
@@ -196,8 +202,10 @@ class OracleActorCritic:
     # ------------------------------------------------------------------ PopArt (popart.py:8-59, modules/utils.py:70-151)
     POPART_BETA, POPART_EPS = 0.99999, 1e-5  # PopArtValueHead defaults; burn_in_updates = inf: never rescales
 
+    VALUE_HEAD = "critic_head"
+
     def _rms(self, n):
-        return self.params[f"critic_head._PopArtValueHead__rms._RunningMeanStd__{n}"]
+        return self.params[f"{self.VALUE_HEAD}._PopArtValueHead__rms._RunningMeanStd__{n}"]
 
     @torch.no_grad()
     def popart_mean_std(self):
@@ -289,3 +297,61 @@ class OracleActorCritic:
         actions = torch.stack([d.probs.argmax(-1) for d in dists], -1)
         lp = torch.stack([d.log_prob(actions[..., i]) for i, d in enumerate(dists)], -1).sum(-1, keepdim=True)
         return actions, lp, value, logits, new_state
+
+
+class OracleSMACNet(OracleActorCritic):
+    """``SMACNet`` with flat observations (game_policies/smac_rnn.py:88-167) and ``SMACPolicy.analyze`` (:239-327).
+
+    Leaves of a shared environment are ``[T, B, agents, ...]``; agents are merged into the batch axis (:253-266) and the
+    outputs split again (:313-320).  The recurrent cell is the LSTM ``AutoResetRNN`` defaults to (autoreset_rnn.py:9):
+    stored states are ``cat(h, c)``."""
+    VALUE_HEAD = "value_head"
+
+    def __init__(self, obs_dim, state_dim, act_dim, hidden_dim, chunk_len, num_rnn_layers=1, agent_shared=True, **_ignored):
+        super().__init__(obs_dim={"local_obs": obs_dim}, action_dim=act_dim, hidden_dim=hidden_dim,
+                         state_dim={"state": state_dim}, chunk_len=chunk_len, num_rnn_layers=num_rnn_layers,
+                         rnn_type="lstm", popart=True, shared_backbone=False)
+        self.agent_shared = agent_shared
+
+    def _rnn_key(self, prefix, n, layer):
+        return f"{prefix}._AutoResetRNN__net.{n}_l{layer}"
+
+    def _base(self, root, x):
+        p = self._p
+        x = F.layer_norm(x, (x.shape[-1],), p(f"{root}.0.weight"), p(f"{root}.0.bias"), 1e-5)
+        for j in (0, 3):  # mlp([d, H, H], ReLU, layernorm=True): Linear, ReLU, LayerNorm twice (modules/utils.py:154-161)
+            x = torch.relu(F.linear(x, p(f"{root}.1.{j}.weight"), p(f"{root}.1.{j}.bias")))
+            x = F.layer_norm(x, (self.hidden,), p(f"{root}.1.{j + 2}.weight"), p(f"{root}.1.{j + 2}.bias"), 1e-5)
+        return x
+
+    def forward(self, obs, policy_state=(None, None), on_reset=None):
+        a, c = self._base("actor_base", obs["local_obs"]), self._base("critic_base", obs["state"])
+        a_hx = c_hx = None
+        if self.num_rnn_layers:
+            a, a_hx = self._recur("actor_rnn", a, policy_state[0], on_reset)
+            c, c_hx = self._recur("critic_rnn", c, policy_state[1], on_reset)
+            a = F.layer_norm(a, (self.hidden,), self._p("actor_rnn_norm.weight"), self._p("actor_rnn_norm.bias"), 1e-5)
+            c = F.layer_norm(c, (self.hidden,), self._p("critic_rnn_norm.weight"), self._p("critic_rnn_norm.bias"), 1e-5)
+        logits = F.linear(a, self._p("policy_head.weight"), self._p("policy_head.bias"))
+        logits = logits.masked_fill(obs["available_action"] == 0, -1e10)  # :165
+        value = F.linear(c, self._p("value_head._PopArtValueHead__weight"), self._p("value_head._PopArtValueHead__bias"))
+        return logits, value, (a_hx, c_hx)
+
+    def analyze(self, obs, action, on_reset, policy_state=None, burn_in_steps=0):
+        assert burn_in_steps == 0, "oracle: SMAC burn-in not restated"
+        bs = on_reset.shape[1]
+        merge = (lambda x: x.reshape(x.shape[0], x.shape[1] * x.shape[2], *x.shape[3:])) if self.agent_shared else (lambda x: x)
+        split = (lambda x: x.reshape(x.shape[0], bs, x.shape[1] // bs, *x.shape[2:])) if self.agent_shared else (lambda x: x)
+        T = on_reset.shape[0]
+        n = T // self.chunk_len
+        chunk = lambda x: torch.cat(torch.split(merge(x), T // n, dim=0), dim=1)
+        unchunk = lambda x: torch.cat(torch.split(x, x.shape[1] // n, dim=1), dim=0)
+        cobs = {k: chunk(v) for k, v in obs.items()}
+        state = tuple(chunk(s)[0].transpose(0, 1) for s in policy_state)
+        logits, value, _ = self.forward(cobs, state, chunk(on_reset))
+        dist = torch.distributions.Categorical(logits=logits)
+        lp = dist.log_prob(chunk(action).squeeze(-1)).unsqueeze(-1)
+        if self.agent_shared:  # :309-311
+            lp = lp.masked_fill(cobs["is_alive"] == 0, float("-inf"))
+        ent = dist.entropy().unsqueeze(-1)
+        return split(unchunk(lp)), split(unchunk(value)), split(unchunk(ent)), split(unchunk(logits))

@@ -83,6 +83,12 @@ class ActorCriticPolicy(policy_api.Policy):
                                            std_type=kwargs.get("std_type", "fixed"),
                                            init_log_std=kwargs.get("init_log_std", -0.5),
                                            seed=seed)
+        self._setup(init, chunk_len, seed, kwargs.get("denormalize_value_during_rollout", False))
+
+    masks_dead_agents = False  # SMACPolicy: log-probabilities of dead agents' steps are -inf (smac_rnn.py:309-311)
+
+    def _setup(self, init, chunk_len, seed, denormalize_value_during_rollout=False):
+        """Device network from ``self.spec`` + the bookkeeping every policy of this family shares."""
         self._net = HipNet(self.spec, self.device)
         self._net.load_reference_state(init)
         self._version = -1
@@ -91,7 +97,8 @@ class ActorCriticPolicy(policy_api.Policy):
         self._rollout_calls = 0
         self._distributed = False
         self._popart_updates, self._popart_burn_in = 0, float("inf")  # PopArtValueHead defaults (popart.py:16,28-29)
-        self.denormalize_value_during_rollout = kwargs.get("denormalize_value_during_rollout", False)
+        self._popart_beta = ns.POPART_BETA
+        self.denormalize_value_during_rollout = denormalize_value_during_rollout
 
     # ------------------------------------------------------------------ bookkeeping (api/policy.py:205-288)
     @property
@@ -176,7 +183,7 @@ class ActorCriticPolicy(policy_api.Policy):
             self._popart_updates += 1
         rescale = self._popart_updates + (0 if count else 1) > self._popart_burn_in  # popart.py:49 (inf: never)
         net, head = self._net, self.spec.critic_head
-        hip.popart_update(stats, net.popart_state, self.spec.value_dim, ns.POPART_BETA, ns.POPART_EPS,
+        hip.popart_update(stats, net.popart_state, self.spec.value_dim, self._popart_beta, ns.POPART_EPS,
                           net._p(f"{head.prefix}.weight"), net._p(f"{head.prefix}.bias"), head.in_features, rescale)
 
     def parameters(self):
@@ -214,17 +221,29 @@ class ActorCriticPolicy(policy_api.Policy):
         hip.require_gpu()
         obs = {k: to_device_leaf(v, self.device, "obs") for k, v in requests.obs.items() if v is not None}
         n = int(next(iter(obs.values())).shape[0])
-        avail = obs.pop("available_action", None)
-        if avail is not None and avail.dtype != torch.uint8:
-            avail = avail.to(torch.uint8)
-        is_eval = np.asarray(requests.is_evaluation).reshape(-1)
-        is_eval = to_device_leaf(np.broadcast_to(is_eval, (n,)) if is_eval.size == 1 else is_eval, self.device, "flag")
-        rnn = None
+        state = None
         if self.spec.num_rnn_layers:  # requests carry [n, layers, H]; the state is used as given (:473-481)
             ps = requests.policy_state
             if ps is None:
                 raise ValueError("recurrent policy: the request carries no policy_state")
-            rnn = self._rnn_ctx(NamedArray(**{k: np.asarray(ps[k])[None] for k, _ in self._state_keys()}), 1, n, None)
+            state = {k: np.asarray(ps[k]) for k, _ in self._state_keys()}
+        action, logp, value = self._rollout_rows(obs, n, requests.is_evaluation, state)
+        return policy_api.RolloutResult(action=DiscreteAction(action.cpu().numpy()),
+                                        analyzed_result=PPORolloutAnalyzedResult(log_probs=logp.cpu().numpy(),
+                                                                                 value=value.cpu().numpy()),
+                                        policy_state=self._packed_last_state())
+
+    def _rollout_rows(self, obs, n, is_evaluation, state):
+        """One inference pass over ``n`` independent rows: device ``(action, log_prob [n,1], value [n,vd])``; the new
+        recurrent states are left in ``net.last_state``.  ``state``: ``{key: [n, layers, W]}`` host or device, or None."""
+        avail = obs.pop("available_action", None)
+        if avail is not None and avail.dtype != torch.uint8:
+            avail = avail.to(torch.uint8)
+        is_eval = np.asarray(is_evaluation).reshape(-1)
+        is_eval = to_device_leaf(np.broadcast_to(is_eval, (n,)) if is_eval.size == 1 else is_eval, self.device, "flag")
+        rnn = None
+        if self.spec.num_rnn_layers:
+            rnn = self._rnn_ctx(NamedArray(**{k: v[None] for k, v in state.items()}), 1, n, None)
         logits, value = self._net.forward(obs, n, keep_tape=False, rnn=rnn)
         heads = self.spec.act_dims
         logp = torch.empty((n, 1), dtype=torch.float32, device=self.device)
@@ -236,10 +255,7 @@ class ActorCriticPolicy(policy_api.Policy):
             action = torch.empty((n, len(heads)), dtype=torch.int64, device=self.device)
             hip.categorical_sample(logits, avail, is_eval, heads, self._seed, self._rollout_calls, action, logp)
         self._rollout_calls += 1
-        return policy_api.RolloutResult(action=DiscreteAction(action.cpu().numpy()),
-                                        analyzed_result=PPORolloutAnalyzedResult(log_probs=logp.cpu().numpy(),
-                                                                                 value=value.cpu().numpy()),
-                                        policy_state=self._packed_last_state())
+        return action, logp, value
 
     def _rnn_ctx_with_burn_in(self, obs, avail_unused, policy_state, on_reset, burn, T, B) -> Optional[RnnCtx]:
         """Recurrent context for rows [burn, burn + T) of leaves that start `burn` rows earlier: the `burn` rows before
@@ -315,34 +331,47 @@ class ActorCriticPolicy(policy_api.Policy):
         The forward context is kept so that ``backward_ppo`` can follow.
         """
         burn = int(burn_in_steps)
-        Tall, B = sample.on_reset.shape[:2]
+        # [T, B, agents, ...] leaves of a shared multi-agent environment: agents are merged into the batch axis for the
+        # network and split again on the way out (smac_rnn.py:253-266, :313-320); a free view on contiguous leaves
+        agents = sample.on_reset.shape[2] if len(sample.on_reset.shape) == 4 else 0
+        mg = (lambda t: t.reshape(t.shape[0], t.shape[1] * t.shape[2], *t.shape[3:])) if agents else (lambda t: t)
+        Tall, B = sample.on_reset.shape[0], sample.on_reset.shape[1] * max(agents, 1)
         T = Tall - burn  # analysed rows: [burn, Tall) (:346-349)
         n = T * B
         obs, full_obs = {}, {}
         for k, v in sample.obs.items():
             if v is None:
                 continue
-            t = to_device_leaf(v, self.device, "obs")
+            t = mg(to_device_leaf(v, self.device, "obs"))
             full_obs[k] = t
             obs[k] = t[burn:].reshape(n, *t.shape[2:])
         avail = obs.pop("available_action", None)
-        action = to_device_leaf(sample.action.x, self.device, self.action_kind())[burn:].reshape(n, -1)
+        alive = obs.pop("is_alive", None)
+        action = mg(to_device_leaf(sample.action.x, self.device, self.action_kind()))[burn:].reshape(n, -1)
         rnn = None
         if self.spec.num_rnn_layers:
             if sample.policy_state is None:
                 raise ValueError("recurrent policy: the sample carries no policy_state")
-            ps = {k: to_device_leaf(v, self.device, "real") for k, v in sample.policy_state.items()}
-            rnn = self._rnn_ctx_with_burn_in(full_obs, None, ps, to_device_leaf(sample.on_reset, self.device, "flag"), burn,
-                                             T, B)
+            ps = {k: mg(to_device_leaf(v, self.device, "real")) for k, v in sample.policy_state.items()}
+            rnn = self._rnn_ctx_with_burn_in(full_obs, None, ps, mg(to_device_leaf(sample.on_reset, self.device, "flag")),
+                                             burn, T, B)
         logits, value = self._net.forward(obs, n, keep_tape=True, rnn=rnn)
         logp = self._net.ws.get("new_logp", n)[:n]
         ent = self._net.ws.get("entropy", n)[:n]
         self.dist_fwd(logits, action, avail, logp, ent)
+        self.mask_dead(logp, alive)
         self._analysis = (logits, action, avail, n)
         old = sample.analyzed_result.log_probs
         old = None if old is None else to_device_leaf(old, self.device, "real")[burn:]
-        return SampleAnalyzedResult(old_action_log_probs=old, new_action_log_probs=logp.view(T, B, 1),
-                                    state_values=value.view(T, B, -1), entropy=ent.view(T, B, 1))
+        shape = (T, B // agents, agents) if agents else (T, B)
+        return SampleAnalyzedResult(old_action_log_probs=old, new_action_log_probs=logp.view(*shape, 1),
+                                    state_values=value.view(*shape, -1), entropy=ent.view(*shape, 1))
+
+    def mask_dead(self, logp, alive):
+        """Policies of shared multi-agent environments: no policy gradient through a dead agent's steps -- its new
+        log-probability becomes -inf, the ratio 0 (smac_rnn.py:309-311).  ``alive``: rows of ``obs.is_alive`` or None."""
+        if self.masks_dead_agents and alive is not None:
+            logp.masked_fill_(alive.reshape(-1) == 0, float("-inf"))
 
     def backward_ppo(self, d_new_lp: torch.Tensor, d_value: torch.Tensor, d_entropy: torch.Tensor):
         """Back-propagate d loss / d(new log-prob, value, entropy) of the last ``analyze`` into ``net.grad``."""

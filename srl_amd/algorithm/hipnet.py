@@ -101,7 +101,7 @@ class HipNet:
         return [info.key for info in self.spec.params.values()]
 
     def load_reference_state(self, state: Dict[str, torch.Tensor]):
-        want = self.ref_names() + (list(ns.POPART_KEYS) if self.spec.popart else [])
+        want = self.ref_names() + (list(self.spec.popart_keys) if self.spec.popart else [])
         missing = [k for k in want if k not in state]
         extra = [k for k in state if k not in want]
         if missing or extra:
@@ -114,7 +114,7 @@ class HipNet:
             host[info.offset:info.offset + info.numel] = info.to_internal(t)
         self.flat.copy_(host)
         if self.spec.popart:  # [mean(vd), mean_sq(vd), debiasing_term(1)] float64
-            rms = torch.cat([torch.as_tensor(state[k]).detach().cpu().double().reshape(-1) for k in ns.POPART_KEYS])
+            rms = torch.cat([torch.as_tensor(state[k]).detach().cpu().double().reshape(-1) for k in self.spec.popart_keys])
             self.popart_state.copy_(rms)
 
     def reference_state(self) -> "OrderedDict[str, torch.Tensor]":
@@ -123,8 +123,8 @@ class HipNet:
                           for info in self.spec.params.values())
         if self.spec.popart:
             rms, vd = self.popart_state.detach().cpu(), self.spec.value_dim
-            out[ns.POPART_KEYS[0]], out[ns.POPART_KEYS[1]] = rms[:vd].clone(), rms[vd:2 * vd].clone()
-            out[ns.POPART_KEYS[2]] = rms[2 * vd:].clone()
+            out[self.spec.popart_keys[0]], out[self.spec.popart_keys[1]] = rms[:vd].clone(), rms[vd:2 * vd].clone()
+            out[self.spec.popart_keys[2]] = rms[2 * vd:].clone()
         return out
 
     def flat_to_reference(self, flat_host: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
@@ -565,10 +565,10 @@ class HipNet:
         atot = sum(sp.act_dims)
         logits_t = self.ws.get("logits", n * atot)
         value_t = self.ws.get("value", n * sp.value_dim)
-        hip.gemm(n, atot, sp.hidden_dim, a_feat.ptr, a_feat.ld, 0, self._p("actor_head.weight"), sp.hidden_dim, 0,
-                 logits_t.data_ptr(), atot, bias=self._p("actor_head.bias"))
-        hip.gemm(n, sp.value_dim, sp.hidden_dim, c_feat.ptr, c_feat.ld, 0, self._p("critic_head.weight"), sp.hidden_dim,
-                 0, value_t.data_ptr(), sp.value_dim, bias=self._p("critic_head.bias"))
+        hip.gemm(n, atot, sp.hidden_dim, a_feat.ptr, a_feat.ld, 0, self._p(f"{sp.actor_head.prefix}.weight"), sp.hidden_dim, 0,
+                 logits_t.data_ptr(), atot, bias=self._p(f"{sp.actor_head.prefix}.bias"))
+        hip.gemm(n, sp.value_dim, sp.hidden_dim, c_feat.ptr, c_feat.ld, 0, self._p(f"{sp.critic_head.prefix}.weight"), sp.hidden_dim,
+                 0, value_t.data_ptr(), sp.value_dim, bias=self._p(f"{sp.critic_head.prefix}.bias"))
         self.log_std_rows = None
         if sp.std_type == "shared_learnable":  # log sigma from a second head on the actor features (:93, :131-132)
             ls_t = self.ws.get("log_std_rows", n * atot)

@@ -208,7 +208,7 @@ class MultiAgentPPO(PytorchTrainer):
         self._world = dist.get_world_size() if dist.is_initialized() else 1
         self._dist = dist.is_initialized()  # collectives run whenever a group exists (also with one rank)
 
-    def _importance_ratio(self, net, obs, avail, action, old_lp, rows, B):
+    def _importance_ratio(self, net, obs, avail, action, old_lp, rows, B, alive=None):
         """exp(new_lp - old_lp) on rows [0, rows) of the sample, forward only, row-chunked; [rows, B, 1] float32."""
         n_all = rows * B
         flat = lambda t: t[:rows].reshape(n_all, *t.shape[2:])
@@ -224,6 +224,7 @@ class MultiAgentPPO(PytorchTrainer):
             logits, _ = net.forward({k: v[r0:r1] for k, v in f_obs.items()}, n, keep_tape=False)
             ent = net.ws.get("entropy", n)[:n]
             self.policy.dist_fwd(logits, f_action[r0:r1], None if f_avail is None else f_avail[r0:r1], new_lp[r0:r1], ent)
+            self.policy.mask_dead(new_lp[r0:r1], None if alive is None else flat(alive).reshape(-1)[r0:r1])
         return torch.exp(new_lp - flat(old_lp).reshape(-1)).reshape(rows, B, 1)
 
     # ------------------------------------------------------------------ the step (mappo.py:219-328)
@@ -256,6 +257,11 @@ class MultiAgentPPO(PytorchTrainer):
             for k, v in sample.policy_state.items():
                 L[f"policy_state.{k}"] = to_device_leaf(v, dev, "real")
 
+        # shared multi-agent samples carry [Tb, B, agents, ...] leaves: every operation of the step is per (env, agent)
+        # column, so the agents are folded into the batch axis (a view) and unfolded where results go back to the sample
+        agents = L["on_reset"].shape[2] if L["on_reset"].dim() == 4 else 0
+        if agents:
+            L = {k: v.reshape(v.shape[0], v.shape[1] * v.shape[2], *v.shape[3:]) for k, v in L.items()}
         Tb, B = L["on_reset"].shape[0], L["on_reset"].shape[1]
         boot, burn = self.bootstrap_steps, self.burn_in_steps
         lo, hi = burn, Tb - boot  # valid rows (mappo.py:259)
@@ -294,6 +300,8 @@ class MultiAgentPPO(PytorchTrainer):
 
         # advantages / returns go back into the numpy sample so that a re-used buffer entry carries them (:254-257)
         adv_d, ret_d = out["adv"], out["ret"]
+        if agents:
+            adv_d, ret_d = (t.reshape(Tb, B // agents, agents, *t.shape[2:]) for t in (adv_d, ret_d))
         if not have_adv and not isinstance(sample.reward, torch.Tensor):
             sample.analyzed_result.adv = adv_d.cpu().numpy()
             sample.analyzed_result.ret = ret_d.cpu().numpy()
@@ -363,6 +371,7 @@ class MultiAgentPPO(PytorchTrainer):
         old_value, old_lp, action = L["old_value"], L["old_lp"], L["action"]
         obs = {k[4:]: v for k, v in L.items() if k.startswith("obs.")}
         avail = obs.pop("available_action", None)
+        alive = obs.pop("is_alive", None) if self.policy.masks_dead_agents else None
         pstate = {k[len("policy_state."):]: v for k, v in L.items() if k.startswith("policy_state.")}
         Tb, B = on_reset.shape[0], on_reset.shape[1]
         boot, burn = self.bootstrap_steps, self.burn_in_steps
@@ -388,7 +397,7 @@ class MultiAgentPPO(PytorchTrainer):
                     trace_value = self.policy.denormalize_value(old_value) if self.popart else old_value
                     ratio = None
                     if self.vtrace:  # importance ratio of the CURRENT parameters on every rewarding step (:130-133)
-                        ratio = self._importance_ratio(net, obs, avail, action, old_lp, Tb - 1, B)
+                        ratio = self._importance_ratio(net, obs, avail, action, old_lp, Tb - 1, B, alive)
                     hip.gae_scan(reward, trace_value, done, truncated, on_reset, self.discount_rate, self.gae_lambda,
                                  adv_d, ret_d, stats=stats_local if fused_stats else None, imp_ratio=ratio)
                 mask_rows = on_reset[1 + lo:1 + hi]  # loss_mask = 1 - on_reset[1+burn : 1+Tb-boot]  (:260-261)
@@ -417,6 +426,7 @@ class MultiAgentPPO(PytorchTrainer):
             net.zero_grad()
             f_obs = {k: flat(v) for k, v in obs.items()}
             f_avail = None if avail is None else flat(avail)
+            f_alive = None if alive is None else flat(alive).reshape(-1)
             f_action, f_oldlp, f_oldv = flat(action), flat(old_lp).reshape(-1), flat(loss_oldv).reshape(-1)
             f_adv, f_ret, f_mask = flat(adv_d).reshape(-1), flat(loss_ret).reshape(-1), mask_rows.reshape(-1)
             f_done, f_trunc = flat(done).reshape(-1), flat(truncated).reshape(-1)
@@ -439,6 +449,7 @@ class MultiAgentPPO(PytorchTrainer):
                 logp = net.ws.get("new_logp", n)[:n]
                 ent = net.ws.get("entropy", n)[:n]
                 self.policy.dist_fwd(logits, f_action[r0:r1], c_avail, logp, ent)
+                self.policy.mask_dead(logp, None if f_alive is None else f_alive[r0:r1])
                 d_lp = net.ws.get("d_logp", n)[:n]
                 d_v = net.ws.get("d_value", n)[:n]
                 d_ent = net.ws.get("d_entropy", n)[:n]

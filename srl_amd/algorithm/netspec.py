@@ -161,6 +161,11 @@ class NetSpec:
     num_rnn_layers: int = 0  # GRU / LSTM layers at the end of each backbone (GruSpec + the rnn_norm LayerNormSpec)
     std_type: Optional[str] = None  # continuous actions: "fixed" | "separate_learnable" | "shared_learnable" (log_std)
     rnn_state_width: int = 0  # per-layer width of the stored policy state (H, or 2H for LSTM: cat(h, c))
+    popart_keys: Tuple[str, str, str] = ()  # state_dict keys of the float64 running statistics (set in __post_init__)
+
+    def __post_init__(self):
+        if not self.popart_keys:
+            self.popart_keys = POPART_KEYS
 
 
 # state_dict keys of the PopArt head (popart.py:21-22,30-31; modules/utils.py:80-82), in the reference's order
@@ -426,4 +431,85 @@ def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num
                    LinearSpec("critic_head", hidden_dim, value_dim, 0), act_dims, hidden_dim, value_dim, shared_backbone,
                    b.params, off, popart, num_rnn_layers,
                    std_type, (2 * hidden_dim if rnn_type == "lstm" else hidden_dim) if num_rnn_layers else 0)
+    return spec, (b.values if b.init else None)
+
+
+def popart_keys_of(head: str):
+    rms = f"{head}._PopArtValueHead__rms._RunningMeanStd__"
+    return (rms + "mean", rms + "mean_sq", rms + "debiasing_term")
+
+
+def build_smac_netspec(obs_dim: int, state_dim: int, act_dim: int, hidden_dim: int, num_rnn_layers: int = 1,
+                       act_init_gain: float = 0.01, seed: Optional[int] = None):
+    """``SMACNet`` with flat (not agent-specific) observations (``game_policies/smac_rnn.py:88-167``): actor on
+    ``local_obs``, critic on ``state``, each ``LayerNorm -> mlp([d, H, H], ReLU, layernorm=True)`` -> ``AutoResetRNN``
+    -> ``LayerNorm``; heads ``policy_head`` and the PopArt ``value_head``.  The recurrent cell is an **LSTM**:
+    ``AutoResetRNN``'s default ``rnn_type`` (``autoreset_rnn.py:9``) is what ``SMACNet`` gets (``:125-126``), so the
+    stored state is ``cat(h, c)``, ``2 * hidden_dim`` wide.  Parameters are registered in the reference's
+    ``state_dict`` order and initialised by replaying its constructor (``:137-160``)."""
+    H = hidden_dim
+    threads = torch.get_num_threads()
+    if seed is not None:
+        torch.set_num_threads(1)
+    try:
+        b = _Builder(seed)
+
+        def base(root, din):
+            b.layernorm(f"{root}.0", din)
+            b.linear(f"{root}.1.0", din, H)
+            b.layernorm(f"{root}.1.2", H)
+            b.linear(f"{root}.1.3", H, H)
+            b.layernorm(f"{root}.1.5", H)
+            return [LayerNormSpec(f"{root}.0", din), LinearSpec(f"{root}.1.0", din, H, 1), LayerNormSpec(f"{root}.1.2", H),
+                    LinearSpec(f"{root}.1.3", H, H, 1), LayerNormSpec(f"{root}.1.5", H)]
+
+        def rnn(root):
+            bound = 1.0 / math.sqrt(H)
+            for l in range(num_rnn_layers):
+                b.uniform(f"{root}.weight_ih_l{l}", (4 * H, H), bound)
+                b.uniform(f"{root}.weight_hh_l{l}", (4 * H, H), bound)
+                b.uniform(f"{root}.bias_ih_l{l}", (4 * H,), bound)
+                b.uniform(f"{root}.bias_hh_l{l}", (4 * H,), bound)
+
+        a_layers = base("actor_base", obs_dim)
+        c_layers = base("critic_base", state_dim)
+        a_bb = c_bb = []
+        if num_rnn_layers:
+            ar, cr = "actor_rnn._AutoResetRNN__net", "critic_rnn._AutoResetRNN__net"
+            rnn(ar)
+            rnn(cr)
+            b.layernorm("actor_rnn_norm", H)
+            b.layernorm("critic_rnn_norm", H)
+            a_bb = [GruSpec(ar, H, num_rnn_layers, "lstm"), LayerNormSpec("actor_rnn_norm", H)]
+            c_bb = [GruSpec(cr, H, num_rnn_layers, "lstm"), LayerNormSpec("critic_rnn_norm", H)]
+        b.linear("policy_head", H, act_dim)
+        b.linear("value_head", H, 1, ref_names=("value_head._PopArtValueHead__weight", "value_head._PopArtValueHead__bias"))
+        pkeys = popart_keys_of("value_head")
+        if b.init:
+            b.values[pkeys[0]] = torch.zeros(1, dtype=torch.float64)
+            b.values[pkeys[1]] = torch.zeros(1, dtype=torch.float64)
+            b.values[pkeys[2]] = torch.zeros(1, dtype=torch.float64)
+        # re-initialisation in the reference's order (:137-160)
+        for root in ("actor_base", "critic_base"):
+            for lin in (f"{root}.1.0", f"{root}.1.3"):
+                b.orthogonal(f"{lin}.weight", math.sqrt(2))
+                b.zero(f"{lin}.bias")
+        if num_rnn_layers:
+            for root in (ar, cr):
+                for l in range(num_rnn_layers):
+                    b.orthogonal(f"{root}.weight_ih_l{l}", 1.0)
+                    b.orthogonal(f"{root}.weight_hh_l{l}", 1.0)
+                    b.zero(f"{root}.bias_ih_l{l}")
+                    b.zero(f"{root}.bias_hh_l{l}")
+        b.orthogonal("policy_head.weight", act_init_gain)
+        b.zero("policy_head.bias")
+    finally:
+        torch.set_num_threads(threads)
+    off = 0
+    for info in b.params.values():
+        info.offset = off
+        off += (info.numel + 3) // 4 * 4
+    spec = NetSpec([EncoderSpec("local_obs", obs_dim, a_layers, H)], a_bb, [EncoderSpec("state", state_dim, c_layers, H)], c_bb,
+                   LinearSpec("policy_head", H, act_dim, 0), LinearSpec("value_head", H, 1, 0), [act_dim], H, 1, False,
+                   b.params, off, True, num_rnn_layers, None, 2 * H if num_rnn_layers else 0, pkeys)
     return spec, (b.values if b.init else None)

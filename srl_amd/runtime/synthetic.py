@@ -46,14 +46,15 @@ def make_sample_arrays(seed: int,
                        available_action: bool = False,
                        p_trunc: Optional[float] = None,
                        policy_state: Optional[Dict[str, Tuple[int, int]]] = None,
-                       continuous_action: bool = False) -> Dict[str, np.ndarray]:
+                       continuous_action: bool = False,
+                       flags=None) -> Dict[str, np.ndarray]:
     """Flat ``{dotted.key: array}`` dict of one synthetic sample; wrap with ``to_sample_batch``.
 
     ``policy_state``: ``{"hx": (layers, hidden)}`` (or ``actor_hx`` / ``critic_hx``) adds stored recurrent states
     ``[Tb, B, layers, hidden]`` (drawn from their own stream, so the other leaves do not depend on it)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     Tb = T + bootstrap_steps
-    done, truncated, on_reset = make_flags(rng, Tb, B, p_done, p_trunc)
+    done, truncated, on_reset = make_flags(rng, Tb, B, p_done, p_trunc) if flags is None else flags
     value = (rng.standard_normal((Tb, B, value_dim)) * (1 - done)).astype(np.float32)
     reward = rng.standard_normal((Tb, B, value_dim)).astype(np.float32)
     reward[:-1] *= (1 - on_reset[1:])
@@ -93,6 +94,23 @@ def make_sample_arrays(seed: int,
         for name, (layers, hidden) in policy_state.items():
             out[f"policy_state.{name}"] = (0.5 * srng.standard_normal((Tb, B, layers, hidden))).astype(np.float32)
     return out
+
+
+def make_multiagent_arrays(seed: int, T: int, B: int, agents: int, obs_spec: ObsSpec, action_dim: int, p_done: float = 0.05,
+                           p_dead: float = 0.15, policy_state: Optional[Dict[str, Tuple[int, int]]] = None,
+                           bootstrap_steps: int = 1) -> Dict[str, np.ndarray]:
+    """One sample of a *shared* multi-agent environment: every leaf ``[Tb, B, agents, ...]`` (smac_env.py:229-241).
+    Episode flags are per environment and identical for its agents (``dones[:] = dones.all()``); observations,
+    actions, rewards and values are per agent; ``obs.is_alive`` marks dead agents, ``obs.available_action`` masks
+    actions (the taken one is always legal)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 15485863))
+    Tb = T + bootstrap_steps
+    env_flags = make_flags(rng, Tb, B, p_done)
+    flags = tuple(np.repeat(f, agents, axis=1) for f in env_flags)
+    flat = make_sample_arrays(seed, T, B * agents, obs_spec, action_dim, p_done, bootstrap_steps, available_action=True,
+                              policy_state=policy_state, flags=flags)
+    flat["obs.is_alive"] = (rng.random((Tb, B * agents, 1)) >= p_dead).astype(np.uint8)
+    return {k: v.reshape(Tb, B, agents, *v.shape[2:]) for k, v in flat.items()}
 
 
 def to_sample_batch(arrays: Dict[str, np.ndarray]):
