@@ -79,3 +79,43 @@ def test_step_full_size_chunking_and_repeatability():
         assert torch.allclose(p0[k], p1[k], rtol=0, atol=2e-5), ("chunking", k)
         assert torch.allclose(p0[k], p2[k], rtol=0, atol=1e-6), ("repeat", k)
     assert s0["frames"] == T * B and np.isfinite(list(s0.values())).all()
+
+
+def test_smac_config_full_size_step_vs_oracle():
+    """BASELINE.json configs[3] at full size (1024 shared 3m environments x 3 agents x 100 steps, `smac_rnn`): the GAE
+    returns of all 307 200 agent-steps against the numpy oracle (1e-5), the folded-agent step equal to the same data
+    presented as 3072 independent columns, and the CPU oracle's full step (LSTM unrolled on the CPU, seconds at this
+    size) on the loss terms."""
+    from oracle.net import OracleSMACNet
+    from oracle.trainer import OracleMappo
+    Ts, Bs, A, H = 100, 1024, 3, 64
+    pol = dict(map_name="3m", hidden_dim=H, chunk_len=10, seed=1, shared=True)
+    tr_args = dict(popart=True, clip_value=True, dual_clip=False, value_loss="huber", value_loss_config=dict(delta=10.0),
+                   max_grad_norm=10.0, optimizer_config=dict(lr=5e-4, eps=1e-5))
+    arrays = synthetic.make_multiagent_arrays(seed=4, T=Ts, B=Bs, agents=A,
+                                              obs_spec={"local_obs": ((30,), "f32"), "state": ((48,), "f32")}, action_dim=9,
+                                              p_done=1 / 60, policy_state={"actor_hx": (1, 2 * H), "critic_hx": (1, 2 * H)})
+    shared = trainer_api.make(config.Trainer("mappo", args=tr_args), config.Policy("smac_rnn", args=pol))
+    onet = OracleSMACNet(30, 48, 9, H, 10)
+    onet.load_state_dict({k: v.numpy() for k, v in shared.policy.get_checkpoint()["state_dict"].items()})
+    oracle = OracleMappo(onet, **tr_args)
+    sample = synthetic.to_sample_batch({k: v.copy() for k, v in arrays.items()})
+    res = shared.step(sample)
+    ostats, oout = oracle.step(arrays)
+    assert sample.analyzed_result.ret.shape == (Ts + 1, Bs, A, 1)
+    err = np.abs(sample.analyzed_result.ret - oout["ret"]) / np.maximum(np.abs(oout["ret"]), 1.0)
+    assert err.max() <= 1e-5, err.max()
+    assert res.stats["frames"] == Ts * Bs * A
+    for k in ("policy_loss", "value_loss", "entropy", "grad_norm", "importance_weight", "denorm_value"):
+        assert abs(res.stats[k] - ostats[k]) <= 2e-5 * max(abs(ostats[k]), 1e-2), (k, res.stats[k], ostats[k])
+    # the same rows as 3072 independent columns through the non-shared policy (is_alive is not part of that observation,
+    # so compare without it on both sides)
+    flat = {k: v.reshape(v.shape[0], Bs * A, *v.shape[3:]) for k, v in arrays.items() if k != "obs.is_alive"}
+    folded = {k: v for k, v in arrays.items() if k != "obs.is_alive"}
+    t1 = trainer_api.make(config.Trainer("mappo", args=tr_args), config.Policy("smac_rnn", args=dict(pol, shared=False)))
+    t2 = trainer_api.make(config.Trainer("mappo", args=tr_args), config.Policy("smac_rnn", args=pol))
+    r1, r2 = t1.step(synthetic.to_sample_batch(flat)), t2.step(synthetic.to_sample_batch(folded))
+    for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
+        assert abs(r1.stats[k] - r2.stats[k]) <= 1e-6 * max(1.0, abs(r2.stats[k])), k
+    d = (t1.policy.net.flat - t2.policy.net.flat).abs()  # split-K partial sums land in launch order: not bitwise
+    assert float(d.max()) <= 5e-4 and float((d > 1e-6).float().mean()) < 1e-3
