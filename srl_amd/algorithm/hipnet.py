@@ -94,6 +94,18 @@ class HipNet:
         # kernels reject, and as a cross-check of the implicit path in the tests)
         import os
         self.force_explicit_conv = os.environ.get("SRL_EXPLICIT_CONV", "0") == "1"
+        # rows one encoder pass may take: the gather kernels address an activation tensor with 32-bit byte offsets, so
+        # the widest per-row activation bounds the rows per launch (2 GiB per tensor, half the hardware range)
+        per_row = 1
+        for enc in list(spec.obs_encoders) + list(spec.state_encoders or []):
+            for L in enc.layers:
+                if isinstance(L, ns.ConvSpec):
+                    per_row = max(per_row, L.out_hw[0] * L.out_hw[1] * L.cout, L.in_hw[0] * L.in_hw[1] * L.cin)
+                    if self.force_explicit_conv:
+                        per_row = max(per_row, L.out_hw[0] * L.out_hw[1] * L.cin * L.k * L.k)
+                elif isinstance(L, ns.LinearSpec):
+                    per_row = max(per_row, L.in_features, L.out_features)
+        self.encoder_rows = max(1, (1 << 31) // (4 * per_row))
 
     # ------------------------------------------------------------------ parameters / checkpoints
     def ref_names(self):
@@ -503,21 +515,34 @@ class HipNet:
         return L.cout
 
     def _trunk_fwd(self, tag, encoders, backbone, obs: Dict[str, torch.Tensor], n: int):
-        enc_tapes, outs = [], []
         for enc in encoders:
-            tape = []
             if enc.key not in obs:
                 raise KeyError(f"observation key `{enc.key}` missing from the sample (has {list(obs)})")
-            outs.append(self._encoder_fwd(enc, obs[enc.key], n, tag, tape))
-            enc_tapes.append(tape)
-        if len(outs) == 1:
-            feat = outs[0]
-        else:
-            width = sum(o.cols for o in outs)
-            feat = self._buf(f"{tag}concat", n, width)
+        # the encoders see independent rows: more rows than one launch may address (recurrent nets hand over every
+        # row of the sample at once) go through in pieces, each piece with its own tape; the features of all pieces
+        # are gathered into one [n, width] block for the backbone, which walks the time axis
+        step = self.encoder_rows
+        pieces = [(r0, min(n, r0 + step)) for r0 in range(0, n, step)]
+        widths = [enc.out_dim for enc in encoders]
+        width = sum(widths)
+        enc_tapes = []
+        feat = None
+        for pi, (r0, r1) in enumerate(pieces):
+            ptag = tag if len(pieces) == 1 else f"{tag}piece{pi}:"
+            tapes, outs = [], []
+            for enc in encoders:
+                tape = []
+                outs.append(self._encoder_fwd(enc, obs[enc.key][r0:r1], r1 - r0, ptag, tape))
+                tapes.append(tape)
+            enc_tapes.append(tapes)
+            if len(pieces) == 1 and len(outs) == 1:
+                feat = outs[0]
+                break
+            if feat is None:
+                feat = self._buf(f"{tag}concat", n, width)
             col = 0
             for o in outs:
-                hip.copy2d(o.ptr, o.ld, feat.ptr + 4 * col, width, n, o.cols)
+                hip.copy2d(o.ptr, o.ld, feat.ptr + 4 * (r0 * width + col), width, r1 - r0, o.cols)
                 col += o.cols
         bb_tape = []
         cur, cur_act = feat, 0
@@ -535,16 +560,21 @@ class HipNet:
                 y, saved = self._ln_fwd(L, cur, tag)
                 bb_tape.append(("ln", L, cur, saved, cur_act))
                 cur, cur_act = y, 0
-        return cur, cur_act, (enc_tapes, bb_tape, [o.cols for o in outs])
+        return cur, cur_act, (enc_tapes, bb_tape, widths, pieces)
 
     def _trunk_bwd(self, tag, trunk_tape, dfeat: Buf):
-        enc_tapes, bb_tape, widths = trunk_tape
+        enc_tapes, bb_tape, widths, pieces = trunk_tape
         g = self._chain_bwd(bb_tape, dfeat, tag, need_input_grad=True) if bb_tape else dfeat
-        col = 0
-        for tape, wdt in zip(enc_tapes, widths):
-            sub = Buf(g.ptr + 4 * col, g.ld, g.rows, wdt)
-            self._chain_bwd(tape, sub, tag, need_input_grad=False)
-            col += wdt
+        hook = self.grad_ready_hook
+        for pi, (r0, r1) in enumerate(pieces):
+            # encoder gradients accumulate over the pieces: they are final (and may be reduced) after the last one
+            self.grad_ready_hook = hook if pi == len(pieces) - 1 else None
+            col = 0
+            for tape, wdt in zip(enc_tapes[pi], widths):
+                sub = Buf(g.ptr + 4 * (r0 * g.ld + col), g.ld, r1 - r0, wdt)
+                self._chain_bwd(tape, sub, tag, need_input_grad=False)
+                col += wdt
+        self.grad_ready_hook = hook
 
     # ------------------------------------------------------------------ public: forward / backward
     def forward(self, obs: Dict[str, torch.Tensor], n: int, keep_tape: bool = True, rnn: Optional[RnnCtx] = None):

@@ -268,7 +268,7 @@ def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, a
         # a strided first convolution whose stride divides kernel and image is run on the space-to-depth'd
         # observation (contiguous patch rows); its weight and the LayerNorm tables then live in that layout
         k0, s0 = cfg[0][1], cfg[0][2]
-        s2d = s0 if (_allow_s2d() and s0 > 1 and k0 % s0 == 0 and h % s0 == 0 and w % s0 == 0 and
+        s2d = s0 if (_allow_s2d() and s0 >= 1 and k0 % s0 == 0 and h % s0 == 0 and w % s0 == 0 and
                      (c * s0 * s0) % 4 == 0) else 0
         b.layernorm(f"{base}.0", shape, s2d=s2d)
         layers = [ObsLayerNormSpec(f"{base}.0", shape)]

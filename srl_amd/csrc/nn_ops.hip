@@ -217,6 +217,58 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, lon
   }
 }
 
+// Wide rows (D > 1024: the halving Linear towers behind the default convolution stack, modules/cnn.py:86-91): one
+// workgroup per row for dx, and a separate column pass for dgamma / dbeta in which a thread owns one column and walks a
+// slab of rows (coalesced across the workgroup), one atomic per column per slab.
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_dx_kernel(const float* dy, long lddy, const float* x, long ldx,
+                                                                    const float* gamma, const float* mean,
+                                                                    const float* rstd, int D, float* dx, long lddx,
+                                                                    int dact) {
+  __shared__ float red[2][4];
+  const long row = blockIdx.x;
+  const float* xr = x + row * ldx;
+  const float* dyr = dy + row * lddy;
+  const float mu = mean[row], rs = rstd[row];
+  float s1 = 0.f, s2 = 0.f;
+  for (int j = threadIdx.x; j < D; j += 256) {
+    const float g = dyr[j] * gamma[j];
+    s1 += g;
+    s2 += g * (xr[j] - mu) * rs;
+  }
+  s1 = wave_allsum(s1);
+  s2 = wave_allsum(s2);
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s1, red[1][threadIdx.x >> 6] = s2;
+  __syncthreads();
+  const float m1 = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)D;
+  const float m2 = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)D;
+  float* dxr = dx + row * lddx;
+  for (int j = threadIdx.x; j < D; j += 256) {
+    const float xv = xr[j];
+    const float xh = (xv - mu) * rs;
+    float o = rs * (dyr[j] * gamma[j] - m1 - xh * m2);
+    if (dact) o *= act_grad_from_output(xv, dact);
+    dxr[j] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_param_kernel(const float* dy, long lddy, const float* x, long ldx,
+                                                                       const float* mean, const float* rstd, long rows,
+                                                                       int D, float* dgamma, float* dbeta,
+                                                                       long rows_per_block) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  if (j >= D) return;
+  float pg = 0.f, pb = 0.f;
+  for (long row = r0; row < r1; ++row) {
+    const float d = dy[row * lddy + j];
+    pg += d * (x[row * ldx + j] - mean[row]) * rstd[row];
+    pb += d;
+  }
+  atomicAdd(dgamma + j, pg);
+  atomicAdd(dbeta + j, pb);
+}
+
 // ---- whole-observation LayerNorm statistics: one workgroup per sample ------------------------------------
 template <bool U8>
 __global__ __launch_bounds__(256) void obs_ln_stats_kernel(const void* obs, long n, int D, float* mean, float* rstd) {
@@ -418,8 +470,22 @@ extern "C" int srl_layernorm_bwd(void* stream, const float* dy, int64_t lddy, co
                                  const float* gamma, const float* mean, const float* rstd, int64_t rows, int D,
                                  float* dx, int64_t lddx, int dact, float* dgamma, float* dbeta) {
   SRL_CHECK_ARG(dy && x && gamma && mean && rstd && dgamma && dbeta, "null tensor");
-  SRL_CHECK_ARG(D >= 1 && D <= 64 * LN_MAXV, "LayerNorm width must be in [1, 1024]");
+  SRL_CHECK_ARG(D >= 1, "LayerNorm width must be positive");
   if (rows == 0) return 0;
+  if (D > 64 * LN_MAXV) {
+    hipStream_t st = (hipStream_t)stream;
+    if (dx)
+      hipLaunchKernelGGL(layernorm_bwd_wide_dx_kernel, dim3((unsigned)rows), dim3(256), 0, st, dy, lddy, x, ldx, gamma, mean,
+                         rstd, D, dx, lddx, dact);
+    const long col_blocks = srl_ceil_div((long)D, 256L);
+    long slabs = srl_ceil_div(2048L, col_blocks);  // ~2048 workgroups in all
+    if (slabs > rows) slabs = rows;
+    const long rpb_w = srl_ceil_div(rows, slabs);
+    hipLaunchKernelGGL(layernorm_bwd_wide_param_kernel, dim3((unsigned)col_blocks, (unsigned)srl_ceil_div(rows, rpb_w)),
+                       dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd, rows, D, dgamma, dbeta, rpb_w);
+    SRL_LAUNCH_CHECK();
+    return 0;
+  }
   // ~4 workgroups per CU; each flushes D*2 atomics, so keep the row share large
   long rpb = srl_ceil_div(rows, 1024);
   if (rpb < 16) rpb = 16;

@@ -137,3 +137,44 @@ def test_football_smm_preset_downsized_vs_oracle():
         # amplified to a fraction of lr; everywhere else the two agree to ~1e-8
         d = np.abs(sd[k].numpy() - osd[k].numpy())
         assert d.max() <= 5e-4 and np.mean(d > 1e-6) < 1e-3, (k, d.max(), np.mean(d > 1e-6))
+
+
+@pytest.mark.parametrize("kind", ["vector", "frames"])
+def test_encoder_pieces_do_not_change_the_step(kind):
+    """Recurrent nets hand every row of the sample to the network at once; the (row-independent) encoders then run
+    in pieces bounded by 32-bit addressing of their activations.  Forcing tiny pieces must give the same update."""
+    if kind == "vector":
+        name, pargs = "smac_rnn", POLICY
+        arrays = synthetic.make_multiagent_arrays(seed=9, **SAMPLE)
+    else:
+        name, pargs = "football-smm-separate", dict(obs_dim={"obs": (4, 24, 20)}, hidden_dim=32, seed=3, chunk_len=4,
+                                                     rnn_type="lstm")
+        arrays = synthetic.make_sample_arrays(seed=5, T=8, B=6, obs_spec={"obs": ((4, 24, 20), "u8")}, action_dims=19,
+                                              p_done=0.1, policy_state={"actor_hx": (1, 64), "critic_hx": (1, 64)})
+    targs = dict(popart=True, optimizer_config=dict(lr=5e-4), max_grad_norm=10.0)
+    whole = trainer_api.make(config.Trainer("mappo", args=targs), config.Policy(name, args=pargs))
+    pieces = trainer_api.make(config.Trainer("mappo", args=targs), config.Policy(name, args=pargs))
+    pieces.policy.net.encoder_rows = 13
+    r1 = whole.step(synthetic.to_sample_batch({k: v.copy() for k, v in arrays.items()}))
+    r2 = pieces.step(synthetic.to_sample_batch({k: v.copy() for k, v in arrays.items()}))
+    for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
+        assert abs(r1.stats[k] - r2.stats[k]) <= 1e-6 * max(1.0, abs(r1.stats[k])), (k, r1.stats[k], r2.stats[k])
+    d = (whole.policy.net.flat - pieces.policy.net.flat).abs()
+    assert float(d.max()) <= 5e-4 and float((d > 1e-6).float().mean()) < 1e-3
+    # and through rollout (forward only)
+    n = 40
+    rng = np.random.default_rng(0)
+    if kind == "vector":
+        obs = NamedArray(local_obs=rng.standard_normal((n, A, 30)).astype(np.float32),
+                         state=rng.standard_normal((n, A, 48)).astype(np.float32),
+                         available_action=np.ones((n, A, 9), np.uint8))
+        req = policy_api.RolloutRequest(obs=obs, policy_state=None, is_evaluation=np.ones((n, 1), np.uint8),
+                                        on_reset=np.ones((n, A, 1), np.uint8))
+    else:
+        obs = NamedArray(obs=rng.integers(0, 256, (n, 4, 24, 20), dtype=np.uint8))
+        z = np.zeros((n, 1, 64), np.float32)
+        req = policy_api.RolloutRequest(obs=obs, policy_state=NamedArray(actor_hx=z, critic_hx=z),
+                                        is_evaluation=np.ones((n, 1), np.uint8), on_reset=np.zeros((n, 1), np.uint8))
+    pieces.policy.load_checkpoint(whole.policy.get_checkpoint())
+    a, b = whole.policy.rollout(req), pieces.policy.rollout(req)
+    assert np.array_equal(a.action.x, b.action.x) and close(a.analyzed_result.value, b.analyzed_result.value, 1e-6)
