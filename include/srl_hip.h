@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 1
+#define SRL_HIP_ABI_VERSION 2
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -242,6 +242,10 @@ typedef struct srl_gemm_desc {
   int32_t accumulate;       /* 1: C += result (after split reduction) */
   int32_t split_k;          /* >1: K is cut into split_k slices reduced through `workspace` */
   float* workspace;         /* >= split_k * M * N floats when split_k > 1 */
+  float* a_colsum;          /* [M] += sum_k A(i, k), or NULL.  Needs a_kmajor and float4-stageable operands (16-byte
+                             * aligned bases, pitches and contiguous extents multiples of 4): a weight-gradient
+                             * product dZ^T X then also delivers the bias gradient sum_rows dZ (mappo.py:276's
+                             * backward computes both), without a second pass over dZ. */
 } srl_gemm_desc;
 int srl_gemm(void* stream, const srl_gemm_desc* d);
 
@@ -312,10 +316,11 @@ int srl_conv2d_supported(const srl_conv_desc* d, int first_layer);
 int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w, const float* bias,
                         float* y);
 /* dw[Cout,KH,KW,Cin] += sum over (n,oh,ow) dz[.,Cout]^T patch(x); workspace: srl_conv2d_wgrad_workspace floats
- * (split over the n*OH*OW reduction) or NULL. */
+ * (split over the n*OH*OW reduction) or NULL.  dbias (optional): [Cout] += sum over (n,oh,ow) dz, the bias
+ * gradient, from the same pass over dz. */
 int64_t srl_conv2d_wgrad_workspace(const srl_conv_desc* d);
 int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const float* x, const float* dz, float* dw,
-                          float* workspace);
+                          float* workspace, float* dbias);
 /* Data gradient.  Input pixels are split into stride*stride parity classes, each a dense stride-1 problem
  * over only the taps that reach it (no multiply-by-zero work).  wt = the weights regrouped per class
  * (srl_conv2d_dgrad_repack, srl_conv2d_dgrad_weight_elems floats; redo after every optimiser step).

@@ -170,17 +170,21 @@ class HipNet:
                  y.ptr, y.ld, bias=self._p(f"{L.prefix}.bias"), act=L.act)
         return y
 
-    def _wgrad(self, out_f, in_f, rows, dz: Buf, x_ptr, x_ld, gw_ptr):
+    def _wgrad(self, out_f, in_f, rows, dz: Buf, x_ptr, x_ld, gw_ptr, gb_ptr=None):
+        """gw += dz^T x; gb += column sums of dz -- from the same kernel when the operands allow it."""
         tiles = ((out_f + 127) // 128) * ((in_f + 127) // 128)
         split = _split_for(rows, tiles)
         wsp = self.ws.get("splitk", split * out_f * in_f).data_ptr() if split > 1 else None
+        fused = gb_ptr is not None and hip.gemm_colsum_ok(out_f, in_f, rows, dz.ptr, dz.ld, x_ptr, x_ld, 1)
         hip.gemm(out_f, in_f, rows, dz.ptr, dz.ld, 1, x_ptr, x_ld, 1, gw_ptr, in_f, accumulate=True, split_k=split,
-                 workspace=wsp)
+                 workspace=wsp, a_colsum=gb_ptr if fused else None)
+        if gb_ptr is not None and not fused:
+            hip.colsum(dz.ptr, dz.ld, rows, out_f, gb_ptr, accumulate=True)
 
     def _linear_bwd(self, L: ns.LinearSpec, x: Buf, dz: Buf, in_act: int, need_dx: bool, tag: str,
                     dx_into: Optional[Buf] = None, dx_accumulate=False) -> Optional[Buf]:
-        self._wgrad(L.out_features, L.in_features, x.rows, dz, x.ptr, x.ld, self._g(f"{L.prefix}.weight"))
-        hip.colsum(dz.ptr, dz.ld, dz.rows, L.out_features, self._g(f"{L.prefix}.bias"), accumulate=True)
+        self._wgrad(L.out_features, L.in_features, x.rows, dz, x.ptr, x.ld, self._g(f"{L.prefix}.weight"),
+                    self._g(f"{L.prefix}.bias"))
         if not need_dx:
             return None
         dx = dx_into or self._buf(f"{tag}{L.prefix}.dx", x.rows, L.in_features)
@@ -456,8 +460,7 @@ class HipNet:
                         g = None
                     else:
                         wsz = hip.conv2d_wgrad_workspace(desc)
-                        hip.conv2d_nhwc_wgrad(desc, x.ptr, g.ptr, gw, self.ws.get("conv_wgrad", wsz).data_ptr())
-                        hip.colsum(g.ptr, g.ld, m, L.cout, gb, accumulate=True)
+                        hip.conv2d_nhwc_wgrad(desc, x.ptr, g.ptr, gw, self.ws.get("conv_wgrad", wsz).data_ptr(), gb)
                         wt = self.ws.get(f"{L.prefix}.wt", hip.conv2d_dgrad_weight_elems(desc))
                         hip.conv2d_dgrad_repack(desc, wp, wt.data_ptr())
                         h, w = L.in_hw

@@ -271,7 +271,7 @@ extern "C" int64_t srl_conv2d_wgrad_workspace(const srl_conv_desc* d) {
 }
 
 extern "C" int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const float* x, const float* dz, float* dw,
-                                     float* workspace) {
+                                     float* workspace, float* dbias) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry");
   SRL_CHECK_ARG(x && dz && dw && aligned16(x) && aligned16(dz), "null / unaligned tensor");
   if (d->n == 0) return 0;
@@ -291,6 +291,7 @@ extern "C" int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const
   if (nsplit > 1) { g.o = plain_out(workspace, Kp); g.slab = (long)d->Cout * Kp; g.accumulate = 0; }
   else { g.o = plain_out(dw, Kp); g.accumulate = 1; }
   g.vec_a = 1; g.vec_b = 1;
+  g.a_colsum = dbias;
   hipStream_t st = (hipStream_t)stream;
   int rc = bm == 64 ? launch<64, 256, 1, 4, true, true, SRC_PLAIN, SRC_CONV>(st, g, 1, nsplit)
                     : launch<32, 256, 1, 4, true, true, SRC_PLAIN, SRC_CONV>(st, g, 1, nsplit);

@@ -1,7 +1,7 @@
 // Dense FP32-MFMA GEMM entry point (srl_gemm).  The kernel itself lives in gemm_core.h.
 #include "gemm_core.h"
 
-static_assert(sizeof(srl_gemm_desc) == 144 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
+static_assert(sizeof(srl_gemm_desc) == 152 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
 
 using namespace srlgemm;
 
@@ -52,6 +52,11 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   const long a_contig = d->a_kmajor ? d->M : d->K, b_contig = d->b_kmajor ? d->N : d->K;
   g.vec_a = aligned16(d->A) && d->lda % 4 == 0 && a_contig % 4 == 0;
   g.vec_b = aligned16(d->B) && d->ldb % 4 == 0 && b_contig % 4 == 0;
+  if (d->a_colsum) {
+    SRL_CHECK_ARG(d->a_kmajor && g.vec_a && g.vec_b,
+                  "a_colsum needs a k-major A and float4-stageable operands (16-byte aligned, pitches % 4 == 0)");
+    g.a_colsum = d->a_colsum;
+  }
 
   int rc;
   // long reductions over big outputs: 8-wavefront workgroups on 256x128 tiles (measured +6 % at K = 3136; on the

@@ -103,6 +103,7 @@ struct GemmArgs {
   int vec_a, vec_b;
   int tiles_n;
   int nbatch;
+  float* a_colsum;  // [M] += sum_k A(i, k) (k-major dense A only): the bias gradient of a weight-gradient product
 };
 
 #ifdef __HIPCC__
@@ -489,9 +490,25 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
   const bool va = GEN ? g.vec_a != 0 : true, vb = GEN ? g.vec_b != 0 : true;
   sa.prepare(g.a, m0, g.M, kbeg, va);
   sb.prepare(g.b, n0, g.N, kbeg, vb);
+  // Column sums of a dense k-major A, for free: a thread stages the same four output indices of every k-tile
+  // (NT is a multiple of BM/4), so it keeps four running sums of what it writes to LDS; the workgroups of the first
+  // column of tiles combine theirs at the end.  (A weight-gradient product dZ^T X thereby also yields the bias
+  // gradient sum_rows dZ, which used to be a separate pass over dZ.)
+  constexpr bool CSUM = AKM && AMODE == SRC_PLAIN && !GEN;
+  const bool do_cs = CSUM && g.a_colsum != nullptr && n0 == 0;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  auto cs_acc = [&]() {
+    if (CSUM && do_cs) {
+#pragma unroll
+      for (int q = 0; q < SA::NV; ++q) {
+        cs[0] += sa.r[4 * q]; cs[1] += sa.r[4 * q + 1]; cs[2] += sa.r[4 * q + 2]; cs[3] += sa.r[4 * q + 3];
+      }
+    }
+  };
   // prologue: tile 0 into LDS buffer 0, tile 1 into registers
   sa.load(g.a, m0, g.M, kbeg, kend, va);
   sb.load(g.b, n0, g.N, kbeg, kend, vb);
+  cs_acc();
   sa.store(lds, va, g.a);
   sb.store(lds + A_FLOATS, vb, g.b);
   __syncthreads();
@@ -552,6 +569,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
       }
       if (kk == KB / 4) {
         if (k0 + KB < kend) {  // tile t+1: registers -> the other LDS buffer (its readers left at the last barrier)
+          cs_acc();
           sa.store(nxt, va, g.a);
           sb.store(nxt + A_FLOATS, vb, g.b);
         }
@@ -572,6 +590,21 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
   for (long k0 = kbeg; k0 < kend; k0 += 2 * KB) {
     kstep(std::integral_constant<int, 0>{}, k0);
     if (k0 + KB < kend) kstep(std::integral_constant<int, 1>{}, k0 + KB);
+  }
+  if (CSUM && do_cs) {  // workgroup-uniform; the tiles in LDS are dead after the loop's last barrier
+    constexpr int G = BM / 4;  // threads that share a k-row of the A tile; thread t owns columns 4 * (t % G) ..+3
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lds[tid * 4 + c] = cs[c];
+    __syncthreads();
+    if (tid < G) {
+      float t4[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NT / G; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t4[c] += lds[(tid + j * G) * 4 + c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (m0 + tid * 4 + c < g.M) atomicAdd(g.a_colsum + m0 + tid * 4 + c, t4[c]);
+    }
   }
 
   // ---- epilogue: per 32x32 accumulator block, all loads batched ahead of the arithmetic and the stores ----------------

@@ -16,7 +16,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsrlhip.so")
 _lib = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -40,7 +40,8 @@ class GemmDesc(Structure):
     _fields_ = [("M", c_int64), ("N", c_int64), ("K", c_int64), ("A", c_void_p), ("lda", c_int64),
                 ("a_kmajor", c_int32), ("B", c_void_p), ("ldb", c_int64), ("b_kmajor", c_int32), ("C", c_void_p),
                 ("ldc", c_int64), ("bias", c_void_p), ("act", c_int32), ("dact_src", c_void_p), ("ld_dact", c_int64),
-                ("dact", c_int32), ("accumulate", c_int32), ("split_k", c_int32), ("workspace", c_void_p)]
+                ("dact", c_int32), ("accumulate", c_int32), ("split_k", c_int32), ("workspace", c_void_p),
+                ("a_colsum", c_void_p)]
 
 
 class ConvDesc(Structure):
@@ -54,7 +55,7 @@ _SIGNATURES = {
     "srl_conv2d_supported": (c_int, [_CD, c_int]),
     "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_conv2d_wgrad_workspace": (c_int64, [_CD]),
-    "srl_conv2d_nhwc_wgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srl_conv2d_nhwc_wgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_conv2d_dgrad_weight_elems": (c_int64, [_CD]),
     "srl_conv2d_dgrad_repack": (c_int, [c_void_p, _CD, c_void_p, c_void_p]),
     "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
@@ -371,12 +372,19 @@ def categorical_sample(logits, avail, is_eval, head_dims, seed, offset, action_o
 
 
 def gemm(M, N, K, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, bias=None, act=ACT_NONE, dact_src=None, ld_dact=0,
-         dact=ACT_NONE, accumulate=False, split_k=1, workspace=None):
-    """Raw-pointer GEMM (``A``/``B``/``C``/... are ints from ``data_ptr()`` possibly with byte offsets)."""
+         dact=ACT_NONE, accumulate=False, split_k=1, workspace=None, a_colsum=None):
+    """Raw-pointer GEMM (``A``/``B``/``C``/... are ints from ``data_ptr()`` possibly with byte offsets).
+    ``a_colsum``: [M] += sum_k A(i, k) as a by-product (k-major, float4-stageable A; see ``gemm_colsum_ok``)."""
     d = GemmDesc(M, N, K, A, lda, int(a_kmajor), B, ldb, int(b_kmajor), C, ldc, bias, int(act), dact_src, ld_dact,
-                 int(dact), int(accumulate), int(split_k), workspace)
+                 int(dact), int(accumulate), int(split_k), workspace, a_colsum)
     with _scope("gemm", 2.0 * M * N * K):
         _check(lib().srl_gemm(_stream(), ctypes.byref(d)), "srl_gemm")
+
+
+def gemm_colsum_ok(M, N, K, A, lda, B, ldb, b_kmajor) -> bool:
+    """Whether ``gemm(..., a_kmajor=1, a_colsum=...)`` is accepted: both operands float4-stageable (srl_hip.h)."""
+    b_contig = N if b_kmajor else K
+    return A % 16 == 0 and B % 16 == 0 and lda % 4 == 0 and ldb % 4 == 0 and M % 4 == 0 and b_contig % 4 == 0
 
 
 def layernorm_fwd(x_ptr, ldx, gamma_ptr, beta_ptr, rows, D, y_ptr, ldy, mean_ptr, rstd_ptr):
@@ -468,9 +476,10 @@ def conv2d_wgrad_workspace(d: ConvDesc) -> int:
     return int(lib().srl_conv2d_wgrad_workspace(ctypes.byref(d)))
 
 
-def conv2d_nhwc_wgrad(d: ConvDesc, x_ptr, dz_ptr, dw_ptr, ws_ptr):
+def conv2d_nhwc_wgrad(d: ConvDesc, x_ptr, dz_ptr, dw_ptr, ws_ptr, dbias_ptr=None):
+    """``dbias_ptr``: [Cout] += column sums of dz (the bias gradient), produced by the same kernel."""
     with _scope("conv_wgrad", _conv_flops(d)):
-        _check(lib().srl_conv2d_nhwc_wgrad(_stream(), ctypes.byref(d), x_ptr, dz_ptr, dw_ptr, ws_ptr),
+        _check(lib().srl_conv2d_nhwc_wgrad(_stream(), ctypes.byref(d), x_ptr, dz_ptr, dw_ptr, ws_ptr, dbias_ptr),
                "srl_conv2d_nhwc_wgrad")
 
 

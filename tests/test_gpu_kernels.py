@@ -433,6 +433,29 @@ def test_im2col_col2im_nhwc(H, C, k, s):
     assert rel_close(dX.cpu().numpy(), ref, 1e-5, scale=1.0)
 
 
+@pytest.mark.parametrize("M,N,K,split", [(64, 512, 5000, 1), (512, 3136, 16384, 4), (8, 512, 777, 1), (132, 68, 1001, 3),
+                                         (32, 36, 40000, 8), (4, 4, 3, 1)])
+def test_gemm_a_colsum(M, N, K, split):
+    """Weight-gradient shape C[M,N] += A^T B with A [K,M], B [K,N] both k-major; a_colsum[M] += sum_k A[k, :]."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    c0 = rng.standard_normal((M, N)).astype(np.float32)
+    s0 = rng.standard_normal(M).astype(np.float32)
+    dA, dB, dC, dS = dev(A), dev(B), dev(c0).clone(), dev(s0).clone()
+    ws = torch.empty(max(split * M * N, 1), device=DEV)
+    assert hip.gemm_colsum_ok(M, N, K, dA.data_ptr(), M, dB.data_ptr(), N, 1)
+    hip.gemm(M, N, K, dA.data_ptr(), M, 1, dB.data_ptr(), N, 1, dC.data_ptr(), N, accumulate=True, split_k=split,
+             workspace=ws.data_ptr(), a_colsum=dS.data_ptr())
+    assert rel_close(dC.cpu().numpy(), c0 + A.astype(np.float64).T @ B.astype(np.float64), 1e-5, scale=float(np.sqrt(K)))
+    assert rel_close(dS.cpu().numpy(), s0 + A.astype(np.float64).sum(0), 1e-5, scale=float(np.sqrt(K)))
+    # operands the float4 path cannot stage are refused loudly (the caller then runs srl_colsum)
+    assert not hip.gemm_colsum_ok(M + 1, N, K, dA.data_ptr(), M + 1, dB.data_ptr(), N, 1)
+    with pytest.raises(hip.HipError):
+        hip.gemm(M, N, K, dA.data_ptr() + 4, M, 1, dB.data_ptr(), N, 1, dC.data_ptr(), N, accumulate=True,
+                 a_colsum=dS.data_ptr())
+
+
 def test_colsum_copy2d():
     rng = np.random.default_rng(2)
     x = rng.standard_normal((10000, 70)).astype(np.float32)
@@ -504,9 +527,12 @@ def test_conv2d_nhwc_implicit(n, H, Cin, k, s, Cout):
     g0 = rng.standard_normal(w.shape).astype(np.float32)
     gw = dev(g0).clone()
     ws = torch.empty(max(hip.conv2d_wgrad_workspace(d), 1), device=DEV)
-    hip.conv2d_nhwc_wgrad(d, dx_.data_ptr(), ddz.data_ptr(), gw.data_ptr(), ws.data_ptr())
+    gb0 = rng.standard_normal(Cout).astype(np.float32)
+    gb = dev(gb0).clone()  # the bias gradient comes out of the same kernel (column sums of dz), accumulating
+    hip.conv2d_nhwc_wgrad(d, dx_.data_ptr(), ddz.data_ptr(), gw.data_ptr(), ws.data_ptr(), gb.data_ptr())
     ref_gw = g0 + wt.grad.permute(0, 2, 3, 1).numpy()
     assert rel_close(gw.cpu().numpy(), ref_gw, 1e-5, scale=float(np.sqrt(n * OH * OH)))
+    assert rel_close(gb.cpu().numpy(), gb0 + bt.grad.numpy(), 1e-5, scale=float(np.sqrt(n * OH * OH)))
     wtp = torch.empty(hip.conv2d_dgrad_weight_elems(d), device=DEV)
     hip.conv2d_dgrad_repack(d, dw_.data_ptr(), wtp.data_ptr())
     dxo = torch.full((n, H, H, Cin), np.nan, device=DEV)
