@@ -7,7 +7,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // LEVEL 0: MFMA only; 1: + two barriers per 64 MFMAs; 2: + operand reads from LDS; 3: + LDS tile writes;
 // 4: + 8 x 16-byte global loads per lane per k-step; 5: the global loads spread over the MFMA loop (one per two
-// kk steps) instead of issued in a burst; 6: the LDS writes spread too (into a second buffer)
+// kk steps) instead of issued in a burst; 6: the LDS writes spread too (into a second buffer); 7: the tile written
+// as transposed scalars; 8: the same 8 x 16 bytes per lane moved global -> LDS directly (buffer_load ... lds, no
+// VGPR round trip and no ds_write), spread like level 6; 9: the same in one burst after the barrier
 template <int LEVEL>
 __global__ __launch_bounds__(256, 4) void probe(float* out, const float* src, int iters) {
   __shared__ float lds[4 * 32 * 132];
@@ -19,8 +21,10 @@ __global__ __launch_bounds__(256, 4) void probe(float* out, const float* src, in
   float4 r[8];
   for (int q = 0; q < 8; ++q) r[q] = make_float4(a0, a1, b0, b1);
   const float4* gp = reinterpret_cast<const float4*>(src) + (size_t)blockIdx.x * 2048 + tid;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float4*>(reinterpret_cast<const float4*>(src) + (size_t)blockIdx.x * 2048), 0, 2048 * 16, 0x00020000);
   if (LEVEL >= 2) {
-    for (int e = tid; e < 2 * 32 * 132; e += 256) lds[e] = e * 1e-4f;
+    for (int e = tid; e < 4 * 32 * 132; e += 256) lds[e] = e * 1e-4f;
     __syncthreads();
   }
   const float* ap = lds + h * 132 + (wid >> 1) * 64 + l31;
@@ -43,6 +47,12 @@ __global__ __launch_bounds__(256, 4) void probe(float* out, const float* src, in
       }
     }
     if (LEVEL >= 1) __syncthreads();
+    if (LEVEL == 9) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + 2 * 32 * 132 + (q * 4 + wid) * 256), 16,
+                                             (int)(((size_t)((it * 8 + q) & 7) * 256 + tid) * 16), 0, 0, 0);
+    }
     if (LEVEL == 4) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) r[q] = gp[(size_t)((it * 8 + q) & 7) * 256];
@@ -53,12 +63,17 @@ __global__ __launch_bounds__(256, 4) void probe(float* out, const float* src, in
         a0 = ap[kk * 2 * 132], a1 = ap[kk * 2 * 132 + 32];
         b0 = bp[kk * 2 * 132], b1 = bp[kk * 2 * 132 + 32];
       }
-      if (LEVEL >= 5 && (kk & 1) == 0) r[kk >> 1] = gp[(size_t)((it * 8 + (kk >> 1)) & 7) * 256];
+      if (LEVEL == 8 && (kk & 1) == 0) {
+        const int q = kk >> 1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + 2 * 32 * 132 + (q * 4 + wid) * 256), 16,
+                                             (int)(((size_t)((it * 8 + q) & 7) * 256 + tid) * 16), 0, 0, 0);
+      }
+      if (LEVEL >= 5 && LEVEL < 8 && (kk & 1) == 0) r[kk >> 1] = gp[(size_t)((it * 8 + (kk >> 1)) & 7) * 256];
       if (LEVEL >= 6 && (kk & 1) == 1) {
         const int q = kk >> 1, u = tid + (q & 3) * 256;
         *reinterpret_cast<float4*>(lds + (2 + (q >> 2)) * 32 * 132 + (u / 32) * 132 + (u % 32) * 4) = r[(q + 4) & 7];
       }
-      if (LEVEL >= 5) __builtin_amdgcn_sched_barrier(0);
+      if (LEVEL >= 5 && LEVEL < 9) __builtin_amdgcn_sched_barrier(0);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[2], 0, 0, 0);
@@ -105,5 +120,7 @@ int main() {
   run<5>(out, src, e0, e1);
   run<6>(out, src, e0, e1);
   run<7>(out, src, e0, e1);
+  run<8>(out, src, e0, e1);
+  run<9>(out, src, e0, e1);
   return 0;
 }

@@ -380,6 +380,17 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
     const long ncols = g.N;
     g.k_per_split = srl_ceil_div(g.K > 0 ? g.K : 1, BK) * BK;
     g.vec_a = 1; g.vec_b = 1;
+    // Position-grouped rows: a tile = one pixel position of BM images, so the taps that leave the gradient image are
+    // known per tile and their k-steps are skipped (at the borders of a 9x9 image under a 3x3 kernel that is 40 % of
+    // the multiply-adds).  Needs whole taps per k-step, a step mask that fits 64 bits, and enough images to fill tiles.
+    const int bm = ncols > 64 ? 128 : 256, shift = ncols > 64 ? 7 : 8;
+    if (g.K > 0 && d->Cout % BK == 0 && g.K / BK <= 64 && d->n >= 4L * bm) {
+      const long groups = srl_ceil_div(d->n, (long)bm);
+      g.M = groups * c.ra * c.rb * bm;
+      g.a.grp_shift = g.o.grp_shift = shift;
+      g.a.n_img = g.o.n_img = (int)d->n;
+      SRL_CHECK_ARG(fits31(g.M), "unsupported geometry (too many rows)");
+    }
     int rc;
     if (g.K == 0) {  // no tap reaches this class: gradient is zero there (k loop is empty, epilogue writes 0)
       rc = launch<256, 32, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);

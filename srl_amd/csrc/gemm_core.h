@@ -70,6 +70,11 @@ struct SrcDesc {
   int is_u8, affine;
   // batch (grid.y) offset of the base: (by / brw) * by_stride + (by % brw) * bx_stride, in elements
   int brw, by_stride, bx_stride;
+  // DGRAD, position-grouped rows (grp_shift > 0): row r = ((g * P + pos) << grp_shift) + nl stands for pixel pos of
+  // image n = (g << grp_shift) + nl (valid while n < n_img), P = f_img.d positions per image.  A tile of 1 << grp_shift
+  // rows then holds ONE pixel position of that many images, so the taps that fall outside the gradient image are the
+  // same for all its rows and their k-steps are skipped instead of multiplied by zeros.
+  int grp_shift, n_img;
 };
 
 struct OutDesc {
@@ -87,6 +92,7 @@ struct OutDesc {
   int cg_width, cg_brw;
   FastDiv f_cg;
   long cg_ystride, cg_xstride;
+  int grp_shift, n_img;  // rowmap with position-grouped rows (see SrcDesc)
 };
 
 struct GemmArgs {
@@ -113,13 +119,23 @@ struct RowInfo {
   int y, x;
   float rs, mr;  // OBS: rstd and mean of the row's sample
   int pos;       // OBS: offset inside the image (index into gamma/beta)
+  bool ok;       // DGRAD with grouped rows: the row's image exists
 };
 
 template <int MODE>
 __device__ __forceinline__ RowInfo row_info(const SrcDesc& s, uint32_t r) {
   RowInfo ri;
-  const uint32_t n = fdiv(r, s.f_img);
-  const uint32_t rem = r - n * s.f_img.d;
+  uint32_t n = fdiv(r, s.f_img);
+  uint32_t rem = r - n * s.f_img.d;
+  ri.ok = true;
+  if (MODE == SRC_DGRAD && s.grp_shift) {
+    const uint32_t tile = r >> s.grp_shift, nl = r & ((1u << s.grp_shift) - 1u);
+    const uint32_t g = fdiv(tile, s.f_img);
+    rem = tile - g * s.f_img.d;
+    n = (g << s.grp_shift) + nl;
+    ri.ok = n < (uint32_t)s.n_img;
+    if (!ri.ok) n = 0;
+  }
   const uint32_t y = fdiv(rem, s.f_line);
   const uint32_t x = rem - y * s.f_line.d;
   ri.y = (int)y;
@@ -243,14 +259,16 @@ struct Stage {
   float d_rs[is_obs(MODE) ? NV : 1], d_mean[is_obs(MODE) ? NV : 1];
   int d_gp[MODE == SRC_OBS ? NV : 1];
   uint32_t vmask;  // OBSN, k-contiguous: bit q = quad q of the current tile is in bounds  // gamma/beta offset of the quad, or -1 (out of bounds: the quad is zero)
-  const char* cur;                     // dense operands: base of the current k-tile (wave-uniform)
+  const char* cur;                     // dense operands: base of the first k-tile (wave-uniform)
   long step;                           // dense operands: bytes per k-tile
+  long kb0;                            // dense operands: k of that first tile
   uint32_t esz;                        // element size of the source (1 for uint8 observations)
 
   // x0: first output index of the tile; xn: extent of that dimension; kbeg: first k of this workgroup
   __device__ __forceinline__ void prepare(const SrcDesc& s, long x0, long xn, long kbeg, bool vec) {
     const int tid = threadIdx.x;
     esz = (is_obs(MODE) && s.is_u8) ? 1u : 4u;
+    kb0 = kbeg;
     if (!GATHER) {
       if (!vec) return;  // scalar fallback addresses directly
       const long ld = s.ld;
@@ -273,7 +291,7 @@ struct Stage {
       if (!KMAJOR) {
         const long x = x0 + u / KQ;
         const RowInfo ri = row_info<MODE>(s, (uint32_t)(x < xn ? x : xn - 1));
-        voff[q] = x < xn ? (uint32_t)ri.off * esz : kInvalidOff;
+        voff[q] = (x < xn && ri.ok) ? (uint32_t)ri.off * esz : kInvalidOff;
         if (MODE == SRC_DGRAD) yx[q] = (ri.y << 16) | ri.x;
         if (is_obs(MODE)) { d_rs[q] = ri.rs; d_mean[q] = ri.mr; }
         if (MODE == SRC_OBS) pos[q] = ri.pos;
@@ -286,7 +304,7 @@ struct Stage {
     }
   }
 
-  // loads k-tile [k0, k0 + KB) clipped to kend; must be called for consecutive tiles (the dense base advances)
+  // loads k-tile [k0, k0 + KB) clipped to kend; k0 - kbeg is a multiple of KB (tiles may be skipped)
   __device__ __forceinline__ void load(const SrcDesc& s, long x0, long xn, long k0, long kend, bool vec) {
     const int tid = threadIdx.x;
     if (GATHER) {
@@ -337,8 +355,7 @@ struct Stage {
       return;
     }
     if (vec) {
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(cur);
-      cur += step;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(cur + ((k0 - kb0) / KB) * step);
       const long kleft = kend - k0;  // > 0
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
@@ -505,20 +522,50 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
       }
     }
   };
-  // prologue: tile 0 into LDS buffer 0, tile 1 into registers
-  sa.load(g.a, m0, g.M, kbeg, kend, va);
-  sb.load(g.b, n0, g.N, kbeg, kend, vb);
+  // k-steps.  Normally kbeg, kbeg + KB, ... < kend.  A data-gradient tile of position-grouped rows (SrcDesc::grp_shift)
+  // only visits the k-steps whose tap reaches the gradient image from the tile's pixel: bit t of kmask = step
+  // kbeg + t * KB is to be done (everything here is workgroup-uniform and lives on the scalar unit).
+  constexpr bool SKIP = AMODE == SRC_DGRAD;
+  uint64_t kmask = 0;
+  bool use_mask = false;
+  if (SKIP && g.a.grp_shift) {
+    const uint32_t tpos = (uint32_t)tile_m - fdiv((uint32_t)tile_m, g.a.f_img) * g.a.f_img.d;
+    const int py = (int)fdiv(tpos, g.a.f_line), px = (int)tpos - py * (int)g.a.f_line.d;
+    const int nsteps = (int)((kend - kbeg + KB - 1) / KB);  // <= 64 (host)
+    for (int t = 0; t < nsteps; ++t) {
+      const ColInfo ci = col_info<SRC_DGRAD>(g.a, (uint32_t)(kbeg + (long)t * KB));
+      if ((unsigned)(py - ci.jh) < (unsigned)g.a.OH && (unsigned)(px - ci.jw) < (unsigned)g.a.OW) kmask |= 1ull << t;
+    }
+    use_mask = true;
+  }
+  auto nextk = [&](long k) -> long {  // the k-step after k, or -1
+    if (SKIP && use_mask) {
+      if (!kmask) return -1;
+      const int t = __builtin_ctzll(kmask);
+      kmask &= kmask - 1;
+      return kbeg + (long)t * KB;
+    }
+    return k + KB < kend ? k + KB : -1;
+  };
+  long kcur = (SKIP && use_mask) ? nextk(0) : kbeg;
+  long kend_l = kend;
+  if (kcur < 0) { kcur = kbeg; kend_l = kbeg; }  // no tap reaches this pixel: one step on an all-zero tile
+  long knext = nextk(kcur);
+  // prologue: the first tile into LDS buffer 0, the second into registers
+  sa.load(g.a, m0, g.M, kcur, kend_l, va);
+  sb.load(g.b, n0, g.N, kcur, kend_l, vb);
   cs_acc();
   sa.store(lds, va, g.a);
   sb.store(lds + A_FLOATS, vb, g.b);
   __syncthreads();
-  if (kbeg + KB < kend) {
-    sa.load(g.a, m0, g.M, kbeg + KB, kend, va);
-    sb.load(g.b, n0, g.N, kbeg + KB, kend, vb);
+  if (knext >= 0) {
+    sa.load(g.a, m0, g.M, knext, kend, va);
+    sb.load(g.b, n0, g.N, knext, kend, vb);
   }
 
   // one k-step on LDS buffer `cur` (compile-time): MFMAs, with the staging of the following tiles in the middle
-  auto kstep = [&](auto cur_c, long k0) {
+  // k1 / k2: the k of the next two steps (-1: none)
+  auto kstep = [&](auto cur_c, long k1, long k2) {
     constexpr int cur = decltype(cur_c)::value;
     // MFMA step kk consumes k = (KB/2)*h + kk of the tile (h = lane >> 5): any pairing of the KB k values works as long
     // as both operands use the same one, and this one lets a k-contiguous operand fetch its 8 values with two
@@ -568,14 +615,14 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
         }
       }
       if (kk == KB / 4) {
-        if (k0 + KB < kend) {  // tile t+1: registers -> the other LDS buffer (its readers left at the last barrier)
+        if (k1 >= 0) {  // tile t+1: registers -> the other LDS buffer (its readers left at the last barrier)
           cs_acc();
           sa.store(nxt, va, g.a);
           sb.store(nxt + A_FLOATS, vb, g.b);
         }
-        if (k0 + 2 * KB < kend) {  // tile t+2: global -> registers
-          sa.load(g.a, m0, g.M, k0 + 2 * KB, kend, va);
-          sb.load(g.b, n0, g.N, k0 + 2 * KB, kend, vb);
+        if (k2 >= 0) {  // tile t+2: global -> registers
+          sa.load(g.a, m0, g.M, k2, kend, va);
+          sb.load(g.b, n0, g.N, k2, kend, vb);
         }
       }
       // (no sched_barrier: order-pinning was measured)
@@ -587,9 +634,15 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     }
     __syncthreads();  // tile t+1 is visible; everyone is done reading tile t
   };
-  for (long k0 = kbeg; k0 < kend; k0 += 2 * KB) {
-    kstep(std::integral_constant<int, 0>{}, k0);
-    if (k0 + KB < kend) kstep(std::integral_constant<int, 1>{}, k0 + KB);
+  for (;;) {
+    long k2 = knext >= 0 ? nextk(knext) : -1;
+    kstep(std::integral_constant<int, 0>{}, knext, k2);
+    if (knext < 0) break;
+    knext = k2;
+    k2 = knext >= 0 ? nextk(knext) : -1;
+    kstep(std::integral_constant<int, 1>{}, knext, k2);
+    if (knext < 0) break;
+    knext = k2;
   }
   if (CSUM && do_cs) {  // workgroup-uniform; the tiles in LDS are dead after the loop's last barrier
     constexpr int G = BM / 4;  // threads that share a k-row of the A tile; thread t owns columns 4 * (t % G) ..+3
@@ -630,8 +683,15 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
       okm |= (ok ? 1u : 0u) << r;
       if (g.o.rowmap) {
         const uint32_t rr = ok ? (uint32_t)(row0 + cr) : 0u;
-        const uint32_t n = fdiv(rr, g.o.f_img);
-        const uint32_t rem = rr - n * g.o.f_img.d;
+        uint32_t n = fdiv(rr, g.o.f_img);
+        uint32_t rem = rr - n * g.o.f_img.d;
+        if (g.o.grp_shift) {  // position-grouped rows (see SrcDesc::grp_shift)
+          const uint32_t tile = rr >> g.o.grp_shift, nl = rr & ((1u << g.o.grp_shift) - 1u);
+          const uint32_t gq = fdiv(tile, g.o.f_img);
+          rem = tile - gq * g.o.f_img.d;
+          n = (gq << g.o.grp_shift) + nl;
+          if (n >= (uint32_t)g.o.n_img) { n = 0; okm &= ~(1u << r); }
+        }
         const uint32_t y = fdiv(rem, g.o.f_line);
         const uint32_t x = rem - y * g.o.f_line.d;
         ro[r] = n * (uint32_t)g.o.img_stride + y * (uint32_t)g.o.y_stride + x * (uint32_t)g.o.x_stride;

@@ -505,7 +505,11 @@ def _conv_ref(x_nhwc, w_ohwi, bias, stride, act):
 
 
 @pytest.mark.parametrize("n,H,Cin,k,s,Cout", [(6, 20, 32, 4, 2, 64), (5, 9, 64, 3, 1, 64), (7, 11, 8, 5, 3, 12),
-                                              (300, 9, 64, 3, 1, 64), (3, 12, 4, 3, 2, 132)])
+                                              (300, 9, 64, 3, 1, 64), (3, 12, 4, 3, 2, 132),
+                                              # enough images for the data gradient's position-grouped tiles (border
+                                              # taps skipped), image counts that do not fill the last group
+                                              (1100, 9, 64, 3, 1, 64), (600, 20, 32, 4, 2, 64), (1030, 7, 8, 3, 1, 16),
+                                              (1024, 6, 16, 5, 1, 32)])
 def test_conv2d_nhwc_implicit(n, H, Cin, k, s, Cout):
     rng = np.random.default_rng(n + H)
     x = np.maximum(rng.standard_normal((n, H, H, Cin)), 0).astype(np.float32)  # a post-ReLU activation
