@@ -1,5 +1,6 @@
 // Dense FP32-MFMA GEMM entry point (srl_gemm).  The kernel itself lives in gemm_core.h.
 #include "gemm_core.h"
+#include "skinny.h"
 
 static_assert(sizeof(srl_gemm_desc) == 152 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
 
@@ -33,6 +34,10 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   SRL_CHECK_ARG(split == 1 || (!d->bias && !d->act && !d->dact_src), "split_k supports only the accumulate epilogue");
   if (d->M == 0 || d->N == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (srlskinny::try_skinny(st, d)) {  // one extent <= 16: bandwidth kernels instead of padded MFMA tiles
+    SRL_LAUNCH_CHECK();
+    return 0;
+  }
 
   GemmArgs g{};
   g.M = d->M; g.N = d->N; g.K = d->K;

@@ -384,6 +384,8 @@ def gemm(M, N, K, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, bias=None, act=ACT
 def gemm_colsum_ok(M, N, K, A, lda, B, ldb, b_kmajor) -> bool:
     """Whether ``gemm(..., a_kmajor=1, a_colsum=...)`` is accepted: both operands float4-stageable (srl_hip.h)."""
     b_contig = N if b_kmajor else K
+    if M <= 16 and K >= 256 and b_kmajor and N % 4 == 0 and ldb % 4 == 0 and B % 16 == 0:
+        return True  # the narrow-head kernel (csrc/skinny.h) sums A's columns whatever M's alignment
     return A % 16 == 0 and B % 16 == 0 and lda % 4 == 0 and ldb % 4 == 0 and M % 4 == 0 and b_contig % 4 == 0
 
 

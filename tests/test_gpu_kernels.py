@@ -315,6 +315,45 @@ def test_gemm_epilogues_and_split():
     assert rel_close(G.cpu().numpy(), ref, 1e-5, scale=float(np.sqrt(rows)))
 
 
+@pytest.mark.parametrize("rows,H,A", [(16384, 512, 6), (16384, 512, 1), (3000, 64, 9), (777, 128, 16), (100, 32, 3),
+                                      (5000, 516, 7)])
+def test_gemm_narrow_heads(rows, H, A):
+    """The three products of a Linear(H, A <= 16) head (forward, weight + bias gradient, data gradient) take the
+    bandwidth kernels of csrc/skinny.h; same contract as the MFMA path."""
+    rng = np.random.default_rng(rows + H + A)
+    X = np.maximum(rng.standard_normal((rows, H)), 0).astype(np.float32)
+    W = (rng.standard_normal((A, H)) / np.sqrt(H)).astype(np.float32)
+    b = rng.standard_normal(A).astype(np.float32)
+    dZ = rng.standard_normal((rows, A)).astype(np.float32)
+    dX_, dW_, db_, ddZ = dev(X), dev(W), dev(b), dev(dZ)
+    # forward: Y = X W^T + b, then accumulated a second time without bias (the LSTM-style accumulate contract)
+    Y = torch.full((rows, A), np.nan, device=DEV)
+    hip.gemm(rows, A, H, dX_.data_ptr(), H, 0, dW_.data_ptr(), H, 0, Y.data_ptr(), A, bias=db_.data_ptr())
+    ref = X.astype(np.float64) @ W.astype(np.float64).T + b
+    assert rel_close(Y.cpu().numpy(), ref, 1e-5, scale=float(np.sqrt(H)))
+    hip.gemm(rows, A, H, dX_.data_ptr(), H, 0, dW_.data_ptr(), H, 0, Y.data_ptr(), A, accumulate=True)
+    assert rel_close(Y.cpu().numpy(), 2 * ref - b, 1e-5, scale=float(np.sqrt(H)))
+    # weight gradient (+ bias gradient from the same pass), accumulating
+    g0, s0 = rng.standard_normal((A, H)).astype(np.float32), rng.standard_normal(A).astype(np.float32)
+    G, S = dev(g0).clone(), dev(s0).clone()
+    ws = torch.empty(8 * A * H, device=DEV)
+    assert hip.gemm_colsum_ok(A, H, rows, ddZ.data_ptr(), A, dX_.data_ptr(), H, 1) == (rows >= 256 or A % 4 == 0)
+    cs = S.data_ptr() if hip.gemm_colsum_ok(A, H, rows, ddZ.data_ptr(), A, dX_.data_ptr(), H, 1) else None
+    hip.gemm(A, H, rows, ddZ.data_ptr(), A, 1, dX_.data_ptr(), H, 1, G.data_ptr(), H, accumulate=True, split_k=8,
+             workspace=ws.data_ptr(), a_colsum=cs)
+    assert rel_close(G.cpu().numpy(), g0 + dZ.astype(np.float64).T @ X.astype(np.float64), 1e-5, scale=float(np.sqrt(rows)))
+    if cs is not None:
+        assert rel_close(S.cpu().numpy(), s0 + dZ.astype(np.float64).sum(0), 1e-5, scale=float(np.sqrt(rows)))
+    # data gradient with the producer's ReLU mask, plain and accumulated
+    D = torch.full((rows, H), np.nan, device=DEV)
+    hip.gemm(rows, H, A, ddZ.data_ptr(), A, 0, dW_.data_ptr(), H, 1, D.data_ptr(), H, dact_src=dX_.data_ptr(), ld_dact=H,
+             dact=1)
+    refd = (dZ.astype(np.float64) @ W.astype(np.float64)) * (X > 0)
+    assert rel_close(D.cpu().numpy(), refd, 1e-5, scale=1.0)
+    hip.gemm(rows, H, A, ddZ.data_ptr(), A, 0, dW_.data_ptr(), H, 1, D.data_ptr(), H, accumulate=True)
+    assert rel_close(D.cpu().numpy(), refd + dZ.astype(np.float64) @ W.astype(np.float64), 1e-5, scale=1.0)
+
+
 def test_gemm_strided_views():
     """Operands / outputs that are column slices of wider buffers (observation concat, head slices)."""
     rng = np.random.default_rng(9)
@@ -450,6 +489,8 @@ def test_gemm_a_colsum(M, N, K, split):
     assert rel_close(dC.cpu().numpy(), c0 + A.astype(np.float64).T @ B.astype(np.float64), 1e-5, scale=float(np.sqrt(K)))
     assert rel_close(dS.cpu().numpy(), s0 + A.astype(np.float64).sum(0), 1e-5, scale=float(np.sqrt(K)))
     # operands the float4 path cannot stage are refused loudly (the caller then runs srl_colsum)
+    if M <= 16:  # narrow products take the bandwidth kernels, which have no alignment demands on A
+        return
     assert not hip.gemm_colsum_ok(M + 1, N, K, dA.data_ptr(), M + 1, dB.data_ptr(), N, 1)
     with pytest.raises(hip.HipError):
         hip.gemm(M, N, K, dA.data_ptr() + 4, M, 1, dB.data_ptr(), N, 1, dC.data_ptr(), N, accumulate=True,
