@@ -298,9 +298,7 @@ extern "C" int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const
   SRL_CHECK_ARG(rc == 0, "grid too large");
   SRL_LAUNCH_CHECK();
   if (nsplit > 1) {
-    const long total = (long)d->Cout * Kp;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)srl_ceil_div(total, 256)), dim3(256), 0, st,
-                       (const float*)workspace, nsplit, 1L, (long)d->Cout, Kp, dw, Kp, 0L, 1);
+    reduce_slabs(st, workspace, nsplit, 1L, (long)d->Cout, Kp, dw, Kp, 0L, 1);
     SRL_LAUNCH_CHECK();
   }
   return 0;
@@ -492,9 +490,9 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
   float* Q = workspace;
   float* R = Q + (long)P * d->Cout * Kp;
   float* slabs = R + (((long)P * d->Cout + 3) & ~3L);
-  // R[pos, o] = sum_n dz[(n, pos), o]
-  int rc = srl_colsum(stream, dz, (int64_t)P * d->Cout, d->n, P * d->Cout, R, 0);
-  if (rc != 0) return rc;
+  // R[pos, o] = sum_n dz[(n, pos), o]: column sums of the A tiles the batched product below stages anyway
+  if (hipMemsetAsync(R, 0, sizeof(float) * P * d->Cout, st) != hipSuccess) return -EIO;
+  int rc;
   // Q[pos][o][k] = sum_n dz[(n,pos), o] * xhat[n, patch(pos)[k]]   — one batched GEMM over the P output positions
   GemmArgs g{};
   g.M = d->Cout; g.N = Kp; g.K = d->n;
@@ -510,14 +508,12 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
   g.o.batch_stride = (long)d->Cout * Kp;
   g.slab = (long)P * d->Cout * Kp;
   g.vec_a = 1; g.vec_b = 1;
+  g.a_colsum = R; g.a_colsum_batch = d->Cout;
   rc = launch<32, 256, 1, 4, true, true, SRC_PLAIN, SRC_OBSN>(st, g, P, nsplit);
   SRL_CHECK_ARG(rc == 0, "grid too large");
   SRL_LAUNCH_CHECK();
   if (nsplit > 1) {
-    const long total = (long)P * d->Cout * Kp;
-    const unsigned grid = (unsigned)(srl_ceil_div(total, 256) < 8192 ? srl_ceil_div(total, 256) : 8192);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, (const float*)slabs, nsplit, (long)P,
-                       (long)d->Cout, Kp, Q, Kp, (long)d->Cout * Kp, 0);
+    reduce_slabs(st, slabs, nsplit, (long)P, (long)d->Cout, Kp, Q, Kp, (long)d->Cout * Kp, 0);
     SRL_LAUNCH_CHECK();
   }
   const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, channels_last ? 1 : 0};

@@ -75,10 +75,7 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   SRL_CHECK_ARG(rc == 0, "grid too large");
   SRL_LAUNCH_CHECK();
   if (nsplit > 1) {
-    const long total = d->M * d->N;
-    const unsigned grid = (unsigned)(srl_ceil_div(total, 256) < 4096 ? srl_ceil_div(total, 256) : 4096);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, (const float*)d->workspace, nsplit, 1L, d->M,
-                       d->N, d->C, d->ldc, 0L, d->accumulate);
+    reduce_slabs(st, d->workspace, nsplit, 1L, d->M, d->N, d->C, d->ldc, 0L, d->accumulate);
     SRL_LAUNCH_CHECK();
   }
   return 0;

@@ -110,6 +110,7 @@ struct GemmArgs {
   int tiles_n;
   int nbatch;
   float* a_colsum;  // [M] += sum_k A(i, k) (k-major dense A only): the bias gradient of a weight-gradient product
+  long a_colsum_batch;  // per-batch (grid.y) stride of a_colsum
 };
 
 #ifdef __HIPCC__
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
         for (int c = 0; c < 4; ++c) t4[c] += lds[(tid + j * G) * 4 + c];
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if (m0 + tid * 4 + c < g.M) atomicAdd(g.a_colsum + m0 + tid * 4 + c, t4[c]);
+        if (m0 + tid * 4 + c < g.M) atomicAdd(g.a_colsum + (long)by * g.a_colsum_batch + m0 + tid * 4 + c, t4[c]);
     }
   }
 
@@ -764,6 +765,83 @@ static __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* w
     float* dst = C + b * c_batch + (w / N) * ldc + (w % N);
     *dst = accumulate ? *dst + s : s;
   }
+}
+// The common case: the output is one dense block (ldc == N, batches back to back), so slab element e lands at C[e] and
+// the reduction is a pure stream -- no index arithmetic (the general kernel spends its time in 64-bit divisions).
+static __global__ __launch_bounds__(256) void reduce_slabs_dense_kernel(const float4* ws, int nslab, long total4, float4* C,
+                                                                 int accumulate) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long)gridDim.x * 256) {
+    float4 s = ws[e];
+    for (int z = 1; z < nslab; ++z) {
+      const float4 v = ws[(long)z * total4 + e];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (accumulate) {
+      const float4 o = C[e];
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    C[e] = s;
+  }
+}
+
+// Few outputs under many slabs (a convolution's weight gradient: 64 x 512 outputs, ~100 slabs): one thread per output
+// would walk its slabs as a serial chain of dependent-latency loads on a handful of workgroups.  ZL threads share an
+// output, each taking every ZL-th slab with several loads in flight, and combine through LDS.
+template <int ZL>
+static __global__ __launch_bounds__(256) void reduce_slabs_dense_z_kernel(const float4* ws, int nslab, long total4, float4* C,
+                                                                   int accumulate) {
+  constexpr int EL = 256 / ZL;
+  __shared__ float4 red[256];
+  const int ex = threadIdx.x % EL, zy = threadIdx.x / EL;
+  const long e = (long)blockIdx.x * EL + ex;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < total4) {
+#pragma unroll 4
+    for (int z = zy; z < nslab; z += ZL) {
+      const float4 v = ws[(long)z * total4 + e];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (zy == 0 && e < total4) {
+    for (int g2 = 1; g2 < ZL; ++g2) {
+      const float4 v = red[g2 * EL + ex];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (accumulate) {
+      const float4 o = C[e];
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    C[e] = s;
+  }
+}
+
+// sum of the split-K slabs into C[batch][M][N] (pitch ldc, batch stride c_batch)
+inline void reduce_slabs(hipStream_t st, const float* ws, int nslab, long batch, long M, long N, float* C, long ldc,
+                         long c_batch, int accumulate) {
+  const long total = batch * M * N;
+  const bool dense = ldc == N && (batch == 1 || c_batch == M * N) && total % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+  if (dense) {
+    const long total4 = total / 4;
+    if (nslab >= 16 && total4 <= 256 * 1024) {
+      hipLaunchKernelGGL(reduce_slabs_dense_z_kernel<16>, dim3((unsigned)srl_ceil_div(total4, 16)), dim3(256), 0, st,
+                         reinterpret_cast<const float4*>(ws), nslab, total4, reinterpret_cast<float4*>(C), accumulate);
+      return;
+    }
+    if (nslab >= 4 && total4 <= 1024 * 1024) {
+      hipLaunchKernelGGL(reduce_slabs_dense_z_kernel<4>, dim3((unsigned)srl_ceil_div(total4, 64)), dim3(256), 0, st,
+                         reinterpret_cast<const float4*>(ws), nslab, total4, reinterpret_cast<float4*>(C), accumulate);
+      return;
+    }
+    const unsigned grid = (unsigned)(srl_ceil_div(total4, 256) < 4096 ? srl_ceil_div(total4, 256) : 4096);
+    hipLaunchKernelGGL(reduce_slabs_dense_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float4*>(ws), nslab,
+                       total4, reinterpret_cast<float4*>(C), accumulate);
+    return;
+  }
+  const unsigned grid = (unsigned)(srl_ceil_div(total, 256) < 8192 ? srl_ceil_div(total, 256) : 8192);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, ws, nslab, batch, M, N, C, ldc, c_batch, accumulate);
 }
 #endif  // __HIPCC__
 
