@@ -144,25 +144,39 @@ bool dgrad_uniform(const DgradClass* cls, int nc) {
 
 // ---- finalisation of the first-layer backward from the per-position products Q and column sums R --------------------
 // dw[o,k] += sum_pos gamma[p(pos,k)] * Q[pos,o,k] + beta[p(pos,k)] * R[pos,o];   db[o] += sum_pos R[pos,o]
+// 32 outputs x 8 position-lanes per workgroup: one thread per output would walk the P positions as a serial chain of
+// loads on 32 workgroups
+constexpr int kDwEL = 32, kDwZL = 8;
 __global__ __launch_bounds__(256) void obs_dw_kernel(const float* Q, const float* R, const float* gamma,
                                                      const float* beta, int P, int Cout, ObsIndex ix, float* dw,
                                                      float* db) {
+  __shared__ float red_a[256], red_r[256];
   const int Kp = ix.Cin * ix.KH * ix.KW;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= Cout * Kp) return;
-  const int k = e % Kp, o = e / Kp;
+  const int ex = threadIdx.x % kDwEL, pz = threadIdx.x / kDwEL;
+  const int e = blockIdx.x * kDwEL + ex;
+  const bool live = e < Cout * Kp;
+  const int k = live ? e % Kp : 0, o = live ? e / Kp : 0;
   int ci, kh, kw;
   ix.split_k(k, ci, kh, kw);
   float acc = 0.f, rsum = 0.f;
-  for (int pos = 0; pos < P; ++pos) {
-    const int oh = pos / ix.OW, ow = pos % ix.OW;
-    const int p = ix.p_of(ci, oh * ix.S + kh, ow * ix.S + kw);
-    const float r = R[pos * Cout + o];
-    acc += gamma[p] * Q[((long)pos * Cout + o) * Kp + k] + beta[p] * r;
-    rsum += r;
+  if (live) {
+#pragma unroll 4
+    for (int pos = pz; pos < P; pos += kDwZL) {
+      const int oh = pos / ix.OW, ow = pos % ix.OW;
+      const int p = ix.p_of(ci, oh * ix.S + kh, ow * ix.S + kw);
+      const float r = R[pos * Cout + o];
+      acc += gamma[p] * Q[((long)pos * Cout + o) * Kp + k] + beta[p] * r;
+      rsum += r;
+    }
   }
-  dw[e] += acc;
-  if (k == 0) db[o] += rsum;
+  red_a[threadIdx.x] = acc;
+  red_r[threadIdx.x] = rsum;
+  __syncthreads();
+  if (pz == 0 && live) {
+    for (int z = 1; z < kDwZL; ++z) acc += red_a[z * kDwEL + ex], rsum += red_r[z * kDwEL + ex];
+    dw[e] += acc;
+    if (k == 0) db[o] += rsum;
+  }
 }
 
 // dgamma[p] += sum_{(pos,k) -> p} sum_o w[o,k] Q[pos,o,k];   dbeta[p] += sum_{(pos,k) -> p} sum_o w[o,k] R[pos,o]
@@ -517,7 +531,7 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
     SRL_LAUNCH_CHECK();
   }
   const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, channels_last ? 1 : 0};
-  hipLaunchKernelGGL(obs_dw_kernel, dim3((unsigned)srl_ceil_div(d->Cout * Kp, 256)), dim3(256), 0, st, Q, R, gamma, beta, P,
+  hipLaunchKernelGGL(obs_dw_kernel, dim3((unsigned)srl_ceil_div(d->Cout * Kp, kDwEL)), dim3(256), 0, st, Q, R, gamma, beta, P,
                      d->Cout, ix, dw, db);
   hipLaunchKernelGGL(obs_affine_kernel, dim3((unsigned)srl_ceil_div(d->Cin * d->H * d->W, 256)), dim3(256), 0, st, Q, R, w,
                      OH, d->Cout, ix, dgamma, dbeta);

@@ -617,25 +617,36 @@ __global__ __launch_bounds__(256) void obs_s2d_kernel(const void* obs, long n, i
   const long smp = blockIdx.x;
   const int D = C * H * W, Wb = W / S, SS = S * S;
   double acc[2] = {0.0, 0.0};
-  if (U8 && S == 4 && W % 4 == 0) {
+  if (U8 && S == 4 && W % 4 == 0 && H % 4 == 0) {
     // dword path: the 4 bytes (pw = 0..3) of one (c, h, b) stay together.  The sample is staged in LDS so that both
     // the read and the re-tiled write are fully coalesced.
     extern __shared__ __attribute__((aligned(16))) uint32_t stage[];
     const uint32_t* src = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(obs) + smp * D);
     uint32_t* dst = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(out) + smp * D);
-    unsigned long long a = 0, b = 0;
-    for (int e = threadIdx.x; e < D / 4; e += 256) {
-      const uint32_t w = src[e];
-      stage[e] = w;
+    // 32-bit partial sums are exact: even the whole sample's sum of squares fits (D * 255^2 < 2^32 for D <= 66051,
+    // and this path is taken for D <= 61440, the LDS staging limit)
+    uint32_t a = 0, b = 0;
+    auto tally = [&](uint32_t w) {
       const unsigned b0 = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u, b3 = w >> 24;
       a += b0 + b1 + b2 + b3;
       b += b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
+    };
+    // H and W are multiples of 4 here, so D is a multiple of 16 and every sample starts 16-byte aligned
+    const uint4* src4 = reinterpret_cast<const uint4*>(src);
+    uint4* st4 = reinterpret_cast<uint4*>(stage);
+    for (int e = threadIdx.x; e < D / 16; e += 256) {
+      const uint4 q = src4[e];
+      st4[e] = q;
+      tally(q.x); tally(q.y); tally(q.z); tally(q.w);
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < D / 4; o += 256) {  // o = ((a*Wb + bq)*C + c)*4 + ph
-      const int ph = o & 3, c = (o >> 2) % C, blk = (o >> 2) / C;
+    // one thread writes the 16 bytes of a (block, channel): ph = 0..3 are rows ab*4 + ph of the source plane
+    uint4* dst4 = reinterpret_cast<uint4*>(dst);
+    for (int o4 = threadIdx.x; o4 < D / 16; o4 += 256) {  // o4 = (ab*Wb + bq)*C + c
+      const int c = o4 % C, blk = o4 / C;
       const int bq = blk % Wb, ab = blk / Wb;
-      dst[o] = stage[(c * H + ab * 4 + ph) * Wb + bq];
+      const uint32_t* sp = stage + (c * H + ab * 4) * Wb + bq;
+      dst4[o4] = make_uint4(sp[0], sp[Wb], sp[2 * Wb], sp[3 * Wb]);
     }
     acc[0] = (double)a;
     acc[1] = (double)b;
