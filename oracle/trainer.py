@@ -115,3 +115,75 @@ class OracleMappo:
         self.frames += int(np.prod(on_reset[burn:Tb - boot].shape))
         stats["frames"] = self.frames
         return stats, out
+
+    def step_dp(self, samples):
+        """One DATA-PARALLEL step of ``len(samples)`` ranks, emulated on the CPU: what the reference does when every
+        trainer rank holds its own columns of the batch.  Gradients are the mean over ranks of each rank's gradient
+        (DistributedDataParallel, ``api/policy.py:219-238``), each rank's loss terms being masked means over its LOCAL
+        steps (``mappo.py:184-199``); the advantage statistics (``modules/utils.py:58-61``) and the PopArt statistics
+        (``:121-124``) are sums over all ranks.  Returns (list of per-rank stats, list of per-rank padded adv/ret)."""
+        assert not self.vtrace and not self.burn_in_steps and not self.net.num_rnn_layers, "oracle DP: feed-forward PPO only"
+        W = len(samples)
+        f32 = lambda smp, k: torch.from_numpy(np.asarray(smp[k])).float()
+        boot = self.bootstrap_steps
+        ranks = []
+        for smp in samples:
+            r = dict(on_reset=f32(smp, "on_reset"), done=f32(smp, "done"), truncated=f32(smp, "truncated"),
+                     reward=f32(smp, "reward"), old_value=f32(smp, "analyzed_result.value"),
+                     old_lp=f32(smp, "analyzed_result.log_probs"),
+                     action=torch.from_numpy(np.asarray(smp["action.x"])).float(),
+                     obs={k[4:]: f32(smp, k) for k in smp if k.startswith("obs.")})
+            Tb = r["on_reset"].shape[0]
+            r["keep"] = Tb - boot
+            r["mask"] = 1 - r["on_reset"][1:1 + r["keep"]]
+            ranks.append(r)
+        totals = [dict() for _ in range(W)]
+        for _ in range(self.ppo_epochs):
+            for r in ranks:
+                k = r["keep"]
+                r["lp"], r["value"], r["ent"], _ = self.net.analyze({n: v[:k] for n, v in r["obs"].items()}, r["action"][:k],
+                                                                    r["on_reset"][:k], None, 0)
+                if "adv" not in r:
+                    tv = self.net.denormalize_value(r["old_value"]) if self.popart else r["old_value"]
+                    adv, ret = ogae.adv_and_value_target(r["reward"].numpy(), tv.numpy(), r["truncated"].numpy(),
+                                                         r["done"].numpy(), r["on_reset"].numpy(), self.discount_rate,
+                                                         self.gae_lambda)
+                    pad = lambda x: np.concatenate([x, np.zeros_like(x[:1])], 0)
+                    r["adv"], r["ret"] = pad(adv), pad(ret)
+            # the three sums of the advantage normalisation, over all ranks
+            parts = [oppo.masked_stats(r["adv"][:r["keep"]], r["mask"].numpy()) for r in ranks]
+            gstats = tuple(sum(p[i] for p in parts) for i in range(3))
+            targets = [torch.from_numpy(r["ret"][:r["keep"]]) for r in ranks]
+            if self.popart:  # one update from the statistics of every rank's targets
+                self.net.update_popart(torch.cat(targets, 1), torch.cat([r["mask"] for r in ranks], 1))
+                denorm = targets
+                targets = [self.net.normalize_value(t) for t in targets]
+            self.optimizer.zero_grad(set_to_none=True)
+            total = 0.0
+            per_rank = []
+            for r, tgt in zip(ranks, targets):
+                k = r["keep"]
+                loss, st = oppo.ppo_loss(r["lp"], r["old_lp"][:k], r["value"], r["old_value"][:k],
+                                         torch.from_numpy(r["adv"][:k]), tgt, r["ent"], r["mask"], eps_clip=self.eps_clip,
+                                         dual_clip=self.dual_clip, c_clip=self.c_clip, value_loss=self.value_loss,
+                                         value_loss_config=self.value_loss_config, clip_value=self.clip_value,
+                                         value_eps_clip=self.value_eps_clip, value_loss_weight=self.value_loss_weight,
+                                         entropy_bonus_weight=self.entropy_bonus_weight, norm_stats=gstats)
+                total = total + loss / W
+                per_rank.append(st)
+            total.backward()
+            params = [p for p in self.net.parameters() if p.requires_grad]
+            if self.max_grad_norm is not None:
+                gn = torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+            else:
+                gn = torch.sqrt(sum(p.grad.norm()**2 for p in params if p.grad is not None))
+            self.optimizer.step()
+            for i, st in enumerate(per_rank):
+                st["grad_norm"] = float(gn)
+                if self.popart:
+                    st["denorm_value"] = torch.masked_select(denorm[i], ranks[i]["mask"].bool()).mean().item()
+                for kk, v in st.items():
+                    totals[i][kk] = totals[i].get(kk, 0.0) + v
+        self.version += 1
+        stats = [{k: v / self.ppo_epochs for k, v in t.items()} for t in totals]
+        return stats, [dict(adv=r["adv"], ret=r["ret"]) for r in ranks]

@@ -1,0 +1,80 @@
+"""The data-parallel trainer path on device memory: two processes share the one GPU of the test box, each with its own
+columns of the batch, joined by a gloo process group (RCCL needs one device per rank; the collectives the trainer issues
+are the same calls either way: the advantage / PopArt statistics all-reduces, the bucketed gradient all-reduce
+overlapped with backward, the parameter broadcast).  Checked against the CPU oracle's emulation of the reference's
+DistributedDataParallel semantics (``OracleMappo.step_dp``)."""
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+POLICY = dict(obs_dim=4, action_dim=3, hidden_dim=64, num_dense_layers=2, num_rnn_layers=0, popart=True, layernorm=True,
+              shared_backbone=False, chunk_len=8)
+TRAINER = dict(popart=True, ppo_epochs=2, clip_value=True, dual_clip=False, value_loss="huber",
+               value_loss_config=dict(delta=10.0), optimizer_config=dict(lr=1e-3), max_grad_norm=5.0,
+               grad_bucket_bytes=8192, chunk_rows=100)
+T, B, STEPS = 24, 12, 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_arrays(step, rank, world):
+    from srl_amd.runtime import synthetic
+    full = synthetic.make_sample_arrays(seed=50 + step, T=T, B=B, obs_spec=synthetic.CARTPOLE_OBS, action_dims=3, p_done=0.1)
+    half = B // world
+    return {k: np.ascontiguousarray(v[:, rank * half:(rank + 1) * half]) for k, v in full.items()}
+
+
+def _worker(rank, world, port, out):
+    import srl_amd
+    from srl_amd.api import config, trainer as trainer_api
+    from srl_amd.runtime import synthetic
+    srl_amd.register_all()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        # different seeds: joining the group must adopt rank 0's parameters (what the DDP constructor does)
+        trainer = trainer_api.make(config.Trainer("mappo", args=TRAINER), config.Policy("actor-critic", args=dict(POLICY, seed=7 + rank)))
+        trainer.distributed(rank=rank, world_size=world, init_method=None)
+        init = {k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()}
+        stats = []
+        for step in range(STEPS):
+            res = trainer.step(synthetic.to_sample_batch(_rank_arrays(step, rank, world)))
+            stats.append(res.stats)
+        final = {k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()}
+        out[rank] = dict(init=init, final=final, stats=stats)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_trainer_matches_ddp_semantics():
+    from oracle.net import OracleActorCritic
+    from oracle.trainer import OracleMappo
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = {r: out[r] for r in range(world)}
+    for k in res[0]["init"]:  # both ranks start from rank 0's parameters and stay identical
+        assert np.array_equal(res[0]["init"][k], res[1]["init"][k]), k
+        assert np.array_equal(res[0]["final"][k], res[1]["final"][k]), k
+    onet = OracleActorCritic(**POLICY)
+    onet.load_state_dict(res[0]["init"])
+    oracle = OracleMappo(onet, **{k: v for k, v in TRAINER.items() if k not in ("grad_bucket_bytes", "chunk_rows")})
+    for step in range(STEPS):
+        ostats, _ = oracle.step_dp([_rank_arrays(step, r, world) for r in range(world)])
+        for r in range(world):
+            got = res[r]["stats"][step]
+            for k in ("policy_loss", "value_loss", "entropy", "grad_norm", "importance_weight", "clip_ratio", "denorm_value"):
+                assert abs(got[k] - ostats[r][k]) <= 2e-5 * max(abs(ostats[r][k]), 1e-2), (step, r, k, got[k], ostats[r][k])
+    osd = onet.state_dict()
+    for k, v in res[0]["final"].items():
+        assert np.abs(v - osd[k].numpy()).max() <= 3e-5, (k, np.abs(v - osd[k].numpy()).max())

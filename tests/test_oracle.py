@@ -185,3 +185,31 @@ def test_full_step_golden_recurrent(golden):
     sd = net.state_dict()
     for k in sd:
         assert np.allclose(sd[k].numpy(), g[f"gru_step2_param:{k}"], rtol=1e-4, atol=1e-6), k
+
+
+def test_oracle_data_parallel_emulation_reduces_to_single_rank():
+    """OracleMappo.step_dp (the reference's DDP semantics on the CPU) with ONE rank is the plain step; with two ranks
+    whose columns are copies of each other the gradient mean and the summed statistics change nothing either."""
+    pargs = dict(obs_dim=4, action_dim=3, hidden_dim=16, num_dense_layers=1, num_rnn_layers=0, popart=True, layernorm=True,
+                 shared_backbone=False, chunk_len=8)
+    targs = dict(popart=True, ppo_epochs=2, clip_value=True, dual_clip=False, value_loss="huber",
+                 value_loss_config=dict(delta=10.0), optimizer_config=dict(lr=1e-3), max_grad_norm=5.0)
+    from srl_amd.algorithm.netspec import build_netspec
+    _, init = build_netspec(**{k: v for k, v in pargs.items() if k != "chunk_len"}, seed=3)
+    arrays = synthetic.make_sample_arrays(seed=9, T=16, B=6, obs_spec=synthetic.CARTPOLE_OBS, action_dims=3, p_done=0.1)
+    nets, trainers = [], []
+    for _ in range(3):
+        net = OracleActorCritic(**pargs)
+        net.load_state_dict({k: v.numpy() for k, v in init.items()})
+        nets.append(net)
+        trainers.append(OracleMappo(net, **targs))
+    s_plain, _ = trainers[0].step(arrays)
+    s_one, _ = trainers[1].step_dp([arrays])
+    s_two, _ = trainers[2].step_dp([arrays, {k: v.copy() for k, v in arrays.items()}])
+    for k in ("policy_loss", "value_loss", "entropy", "grad_norm", "denorm_value"):
+        assert abs(s_plain[k] - s_one[0][k]) <= 1e-6 * max(1.0, abs(s_plain[k])), k
+        assert abs(s_plain[k] - s_two[1][k]) <= 1e-5 * max(1.0, abs(s_plain[k])), k
+    for k, v in nets[0].state_dict().items():
+        assert np.allclose(v.numpy(), nets[1].state_dict()[k].numpy(), rtol=1e-6, atol=1e-7), k
+        if "_RunningMeanStd__" not in k:  # doubled data moves the PopArt EMA identically (means), so everything matches
+            assert np.allclose(v.numpy(), nets[2].state_dict()[k].numpy(), rtol=1e-4, atol=1e-6), k
