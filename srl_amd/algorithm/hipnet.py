@@ -307,10 +307,11 @@ class HipNet:
                                   cin.ptr + o1, cnew.ptr + o1, N, H, dc[c & 1].ptr)
                 hip.gemm(N, H, 4 * H, pre.ptr + o4, 4 * H, 0, w_hh, H, 1, dh[c & 1].ptr, H)  # d h_in(c) = d pre . W_hh
                 ch, cc = dh[c & 1].ptr, dc[c & 1].ptr
-            self._wgrad(4 * H, H, n, pre, hin.ptr, H, self._g(f"{G.prefix}.weight_hh_l{l}"))
-            hip.colsum(pre.ptr, 4 * H, n, 4 * H, self._g(f"{G.prefix}.bias_hh_l{l}"), accumulate=True)
-            self._wgrad(4 * H, H, n, pre, inp.ptr, inp.ld, self._g(f"{G.prefix}.weight_ih_l{l}"))
-            hip.colsum(pre.ptr, 4 * H, n, 4 * H, self._g(f"{G.prefix}.bias_ih_l{l}"), accumulate=True)
+            # bias gradients (column sums of d pre) come out of the weight-gradient kernels
+            self._wgrad(4 * H, H, n, pre, hin.ptr, H, self._g(f"{G.prefix}.weight_hh_l{l}"),
+                        self._g(f"{G.prefix}.bias_hh_l{l}"))
+            self._wgrad(4 * H, H, n, pre, inp.ptr, inp.ld, self._g(f"{G.prefix}.weight_ih_l{l}"),
+                        self._g(f"{G.prefix}.bias_ih_l{l}"))
             if l == 0 and not need_dx:
                 return None
             dx = self._buf(f"{tag}{G.prefix}.dx{l}", n, H)
@@ -332,10 +333,10 @@ class HipNet:
                 hip.gemm(N, H, 3 * H, gh.ptr + o3, 3 * H, 0, w_hh, H, 1, cur.ptr, H, accumulate=True)
                 carry = cur.ptr
             # parameter gradients over all steps at once (gi / gh now hold d gi / d gh)
-            self._wgrad(3 * H, H, n, gh, hin.ptr, H, self._g(f"{G.prefix}.weight_hh_l{l}"))
-            hip.colsum(gh.ptr, 3 * H, n, 3 * H, self._g(f"{G.prefix}.bias_hh_l{l}"), accumulate=True)
-            self._wgrad(3 * H, H, n, gi, inp.ptr, inp.ld, self._g(f"{G.prefix}.weight_ih_l{l}"))
-            hip.colsum(gi.ptr, 3 * H, n, 3 * H, self._g(f"{G.prefix}.bias_ih_l{l}"), accumulate=True)
+            self._wgrad(3 * H, H, n, gh, hin.ptr, H, self._g(f"{G.prefix}.weight_hh_l{l}"),
+                        self._g(f"{G.prefix}.bias_hh_l{l}"))
+            self._wgrad(3 * H, H, n, gi, inp.ptr, inp.ld, self._g(f"{G.prefix}.weight_ih_l{l}"),
+                        self._g(f"{G.prefix}.bias_ih_l{l}"))
             if l == 0 and not need_dx:
                 return None
             dx = self._buf(f"{tag}{G.prefix}.dx{l}", n, H)

@@ -66,12 +66,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_small_kernel(const float* x
 }
 
 template <int LPR>
-__global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const float* dy, long lddy, const float* x, long ldx,
+__global__ __launch_bounds__(1024) void layernorm_bwd_small_kernel(const float* dy, long lddy, const float* x, long ldx,
                                                                   const float* gamma, const float* mean,
                                                                   const float* rstd, long rows, int D, float* dx,
                                                                   long lddx, int dact, float* dgamma, float* dbeta,
                                                                   long rows_per_block) {
   constexpr int RW = 64 / LPR;
+  const int nwv = blockDim.x >> 6;  // 4 or 16 wavefronts: every workgroup ends with 2 D atomics on the same addresses as
+                                    // all the others, so big inputs use few, fat workgroups
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sl = lane % LPR, sub = lane / LPR;
   const bool col_ok = sl * 4 < D;
   float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const float* d
   float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-  for (long base = r0 + (long)wid * RW; base < r1; base += 4 * RW) {
+  for (long base = r0 + (long)wid * RW; base < r1; base += (long)nwv * RW) {
     const long row = base + sub;
     const bool ok = row < r1 && col_ok;
     float xv[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const float* d
       pb[e] += __shfl_xor(pb[e], m, 64);
     }
   }
-  __shared__ float sg[4][LPR * 8];
+  __shared__ float sg[16][LPR * 8];
   if (lane < LPR) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -136,9 +138,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const float* d
   if (wid == 0 && lane < LPR && col_ok) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      atomicAdd(dgamma + sl * 4 + e, sg[0][lane * 8 + e] + sg[1][lane * 8 + e] + sg[2][lane * 8 + e] + sg[3][lane * 8 + e]);
-      atomicAdd(dbeta + sl * 4 + e,
-                sg[0][lane * 8 + 4 + e] + sg[1][lane * 8 + 4 + e] + sg[2][lane * 8 + 4 + e] + sg[3][lane * 8 + 4 + e]);
+      float tg = 0.f, tb = 0.f;
+      for (int w = 0; w < nwv; ++w) tg += sg[w][lane * 8 + e], tb += sg[w][lane * 8 + 4 + e];
+      atomicAdd(dgamma + sl * 4 + e, tg);
+      atomicAdd(dbeta + sl * 4 + e, tb);
     }
   }
 }
@@ -492,8 +495,14 @@ extern "C" int srl_layernorm_bwd(void* stream, const float* dy, int64_t lddy, co
   if (ln_small_ok(x, dy, gamma, ldx, lddy, D) && (!dx || ((reinterpret_cast<uintptr_t>(dx) & 15) == 0 && lddx % 4 == 0))) {
     hipStream_t st = (hipStream_t)stream;
     if (rpb < 64) rpb = 64;
+    int threads = 256;
+    if (rows >= 65536) {  // 16-wavefront workgroups, at most 256 of them
+      threads = 1024;
+      rpb = srl_ceil_div(rows, 256);
+      if (rpb < 256) rpb = 256;
+    }
 #define SRL_LN_BWD(LPR)                                                                                              \
-  hipLaunchKernelGGL(layernorm_bwd_small_kernel<LPR>, dim3((unsigned)srl_ceil_div(rows, rpb)), dim3(256), 0, st, dy, lddy, \
+  hipLaunchKernelGGL(layernorm_bwd_small_kernel<LPR>, dim3((unsigned)srl_ceil_div(rows, rpb)), dim3(threads), 0, st, dy, lddy, \
                      x, ldx, gamma, mean, rstd, rows, D, dx, lddx, dact, dgamma, dbeta, rpb)
     if (D <= 16) SRL_LN_BWD(4);
     else if (D <= 32) SRL_LN_BWD(8);
