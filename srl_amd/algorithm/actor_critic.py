@@ -40,7 +40,10 @@ def to_device_leaf(x, device, kind: str) -> torch.Tensor:
         a = np.asarray(x)
         if a.dtype == np.bool_:
             a = a.view(np.uint8)
-        t = torch.from_numpy(np.ascontiguousarray(a))
+        a = np.ascontiguousarray(a)
+        if not a.flags.writeable:  # broadcast views: torch wants to own writable memory
+            a = a.copy()
+        t = torch.from_numpy(a)
     if kind == "obs":
         want = torch.uint8 if t.dtype == torch.uint8 else torch.float32
     if t.dtype != want:

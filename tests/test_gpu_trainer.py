@@ -333,3 +333,31 @@ def test_continuous_rollout_golden(golden):
     assert abs(z.mean()) < 0.05 and abs(z.std() - 1.0) < 0.05
     lp = (-0.5 * z**2 - np.log(std) - 0.5 * np.log(2 * np.pi)).sum(-1, keepdims=True)
     assert close(s.analyzed_result.log_probs, lp, 1e-4)
+
+
+@pytest.mark.parametrize("T,B", [(2, 1), (5, 7), (1, 3), (33, 2)])
+def test_ragged_and_tiny_batches_vs_oracle(T, B):
+    """Shapes that hit none of the vectorised fast paths (B not a multiple of 4, a single column, a single rewarding
+    row): the generic scan / loss / GEMM paths against the CPU oracle."""
+    pargs = dict(C1_POLICY, layernorm=True, popart=True, seed=4)
+    targs = dict(popart=True, optimizer_config=dict(lr=1e-3), max_grad_norm=1.0)
+    trainer = make_trainer(pargs, targs)
+    onet = OracleActorCritic(**pargs)
+    onet.load_state_dict({k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()})
+    oracle = OracleMappo(onet, **targs)
+    arrays = synthetic.make_sample_arrays(seed=T * 10 + B, T=T, B=B, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2,
+                                          p_done=0.2)
+    arrays["on_reset"][1:] = 0  # keep every step in the loss mask: with so few steps an all-masked batch (0/0 in the
+    arrays["done"][:] = 0       # reference too) would otherwise be likely
+    arrays["truncated"][:] = 0
+    sample = synthetic.to_sample_batch(arrays)
+    res = trainer.step(sample)
+    ostats, oout = oracle.step(arrays)
+    assert close(sample.analyzed_result.ret, oout["ret"], 1e-5) and close(sample.analyzed_result.adv, oout["adv"], 1e-5)
+    for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
+        assert abs(res.stats[k] - ostats[k]) <= 2e-5 * max(abs(ostats[k]), 1e-2), (k, res.stats[k], ostats[k])
+    # a single rollout request, and an empty one
+    pol = trainer.policy
+    one = pol.rollout(policy_api.RolloutRequest(obs=NamedArray(obs=np.zeros((1, 4), np.float32)),
+                                                is_evaluation=np.ones((1, 1), np.uint8), on_reset=np.zeros((1, 1), np.uint8)))
+    assert one.action.x.shape == (1, 1) and np.isfinite(one.analyzed_result.value).all()
