@@ -220,10 +220,20 @@ class ActorCriticPolicy(policy_api.Policy):
         self._version = int(v.item())
 
     # ------------------------------------------------------------------ inference
+    ROLLOUT_PIECE = 2048  # rows per piece when a big host batch is streamed in (copy of piece i+1 under the compute of i)
+
     def rollout(self, requests: policy_api.RolloutRequest, **kwargs) -> policy_api.RolloutResult:
         hip.require_gpu()
-        obs = {k: to_device_leaf(v, self.device, "obs") for k, v in requests.obs.items() if v is not None}
-        n = int(next(iter(obs.values())).shape[0])
+        host = {k: v for k, v in requests.obs.items() if v is not None}
+        n = int(next(iter(host.values())).shape[0])
+        if (not self.spec.num_rnn_layers and n >= 2 * self.ROLLOUT_PIECE
+                and not any(isinstance(v, torch.Tensor) for v in host.values())):
+            action, logp, value = self._rollout_streamed(host, n, requests.is_evaluation)
+            return policy_api.RolloutResult(action=DiscreteAction(action.cpu().numpy()),
+                                            analyzed_result=PPORolloutAnalyzedResult(log_probs=logp.cpu().numpy(),
+                                                                                     value=value.cpu().numpy()),
+                                            policy_state=None)
+        obs = {k: to_device_leaf(v, self.device, "obs") for k, v in host.items()}
         state = None
         if self.spec.num_rnn_layers:  # requests carry [n, layers, H]; the state is used as given (:473-481)
             ps = requests.policy_state
@@ -235,6 +245,58 @@ class ActorCriticPolicy(policy_api.Policy):
                                         analyzed_result=PPORolloutAnalyzedResult(log_probs=logp.cpu().numpy(),
                                                                                  value=value.cpu().numpy()),
                                         policy_state=self._packed_last_state())
+
+    def _rollout_streamed(self, host, n, is_evaluation):
+        """A big batch of host observations (the policy worker's 10 240-request batches are 289 MB of frames): rows
+        go through in pieces, the H2D copy of piece i+1 on a side stream under the network pass of piece i, so the
+        call costs about max(copy, compute) instead of their sum.  Each piece is one Philox call (sampling stays
+        reproducible for a given batch; evaluation-mode outputs do not depend on the split at all)."""
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        is_eval = np.asarray(is_evaluation).reshape(-1)
+        if is_eval.size == 1:
+            is_eval = np.broadcast_to(is_eval, (n,))
+        heads = self.spec.act_dims
+        cont = bool(self.spec.std_type)
+        action = torch.empty((n, sum(heads) if cont else len(heads)), dtype=torch.float32 if cont else torch.int64,
+                             device=self.device)
+        logp = torch.empty((n, 1), dtype=torch.float32, device=self.device)
+        value = torch.empty((n, self.spec.value_dim), dtype=torch.float32, device=self.device)
+        arrays = {}
+        for k, v in host.items():
+            a = np.asarray(v)
+            if a.dtype == np.bool_:
+                a = a.view(np.uint8)
+            if k != "available_action" and a.dtype != np.uint8 and a.dtype != np.float32:
+                a = a.astype(np.float32)
+            arrays[k] = np.ascontiguousarray(a)
+        step = self.ROLLOUT_PIECE
+        bounds = [(r0, min(n, r0 + step)) for r0 in range(0, n, step)]
+        staged = [None, None]  # the piece being computed and the piece being copied (fresh allocations of the side
+        # stream's pool, handed to the main stream with record_stream)
+
+        def stage(i):
+            r0, r1 = bounds[i]
+            with torch.cuda.stream(self._copy_stream):
+                dev = {k: torch.from_numpy(a[r0:r1]).to(self.device, non_blocking=True) for k, a in arrays.items()}
+                ev = torch.cuda.Event()
+                ev.record(self._copy_stream)
+            staged[i & 1] = (dev, ev)
+
+        stage(0)
+        for i, (r0, r1) in enumerate(bounds):
+            dev, ev = staged[i & 1]
+            main.wait_event(ev)
+            a_i, l_i, v_i = self._rollout_rows(dev, r1 - r0, is_eval[r0:r1], None)
+            action[r0:r1].copy_(a_i)
+            logp[r0:r1].copy_(l_i)
+            value[r0:r1].copy_(v_i)
+            for t in dev.values():
+                t.record_stream(main)
+            if i + 1 < len(bounds):
+                stage(i + 1)  # issued after piece i's launches: a pageable copy blocks the host, not the GPU
+        return action, logp, value
 
     def _rollout_rows(self, obs, n, is_evaluation, state):
         """One inference pass over ``n`` independent rows: device ``(action, log_prob [n,1], value [n,vd])``; the new

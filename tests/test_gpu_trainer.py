@@ -361,3 +361,23 @@ def test_ragged_and_tiny_batches_vs_oracle(T, B):
     one = pol.rollout(policy_api.RolloutRequest(obs=NamedArray(obs=np.zeros((1, 4), np.float32)),
                                                 is_evaluation=np.ones((1, 1), np.uint8), on_reset=np.zeros((1, 1), np.uint8)))
     assert one.action.x.shape == (1, 1) and np.isfinite(one.analyzed_result.value).all()
+
+
+def test_streamed_rollout_matches_one_piece():
+    """Big host batches go through rollout in pieces with the copies overlapped; outputs must not depend on the split."""
+    pol = policy_api.make(config.Policy("actor-critic", args=CNN_POLICY))
+    n = 2 * pol.ROLLOUT_PIECE + 300
+    rng = np.random.default_rng(3)
+    obs = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    req = policy_api.RolloutRequest(obs=NamedArray(obs=obs), is_evaluation=np.ones((n, 1), np.uint8),
+                                    on_reset=np.zeros((n, 1), np.uint8))
+    streamed = pol.rollout(req)
+    pol.ROLLOUT_PIECE = n  # one piece: the plain path
+    whole = pol.rollout(req)
+    assert np.array_equal(streamed.action.x, whole.action.x)
+    assert close(streamed.analyzed_result.log_probs, whole.analyzed_result.log_probs, 1e-6)
+    assert close(streamed.analyzed_result.value, whole.analyzed_result.value, 1e-6)
+    # sampling mode: same distribution family, reproducible for the same policy state
+    req_s = policy_api.RolloutRequest(obs=NamedArray(obs=obs[:64]), is_evaluation=np.zeros((64, 1), np.uint8),
+                                      on_reset=np.zeros((64, 1), np.uint8))
+    assert pol.rollout(req_s).action.x.shape == (64, 1)
