@@ -460,6 +460,7 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
     g.vec_b = 1;
     if (d->Cout > 64) rc = launch<128, 128, 2, 2, false, false, SRC_OBSN, SRC_PLAIN>(st, g, P, 1);
     else if (d->Cout > 32) rc = launch<256, 64, 4, 1, false, false, SRC_OBSN, SRC_PLAIN>(st, g, P, 1);
+    else if (is_u8) rc = launch<256, 32, 4, 1, false, false, SRC_OBSN, SRC_PLAIN, false, 2 * BK, true>(st, g, P, 1);  // bytes in LDS
     else rc = launch<256, 32, 4, 1, false, false, SRC_OBSN, SRC_PLAIN>(st, g, P, 1);
   } else {
     g.M = d->n * OH * OW; g.N = d->Cout;
@@ -523,7 +524,8 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
   g.slab = (long)P * d->Cout * Kp;
   g.vec_a = 1; g.vec_b = 1;
   g.a_colsum = R; g.a_colsum_batch = d->Cout;
-  rc = launch<32, 256, 1, 4, true, true, SRC_PLAIN, SRC_OBSN>(st, g, P, nsplit);
+  rc = is_u8 ? launch<32, 256, 1, 4, true, true, SRC_PLAIN, SRC_OBSN, false, 2 * BK, true>(st, g, P, nsplit)  // bytes in LDS
+             : launch<32, 256, 1, 4, true, true, SRC_PLAIN, SRC_OBSN>(st, g, P, nsplit);
   SRL_CHECK_ARG(rc == 0, "grid too large");
   SRL_LAUNCH_CHECK();
   if (nsplit > 1) {

@@ -236,15 +236,23 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, uint32_t voff
 // k-contiguous operand, columns for a k-major one), validity, LayerNorm statistics.  Per k-tile a dense operand costs
 // no vector ALU work at all (the descriptor base advances on the scalar unit); a gathered one costs one column (or
 // row) decomposition per lane plus an add per quad.
-template <int BX, bool KMAJOR, int MODE, int NT = 256, int KB = BK>
+// U8 (SRC_OBSN over uint8 frames only): the tile stays BYTES in LDS -- [BX][KB + 8] for a k-contiguous operand,
+// [KB][BX + 16] (+ the KB rows' LayerNorm statistics) for a k-major one -- and is widened and normalised after the
+// fragment read, in registers.  Every element of these operands is consumed by exactly one wavefront, so the arithmetic
+// is the same as normalising at the store, but the LDS traffic of the operand drops fourfold: with 32-wide tiles the
+// float staging of the frames alone took ~2/3 of the LDS bandwidth of a CU.
+template <int BX, bool KMAJOR, int MODE, int NT = 256, int KB = BK, bool U8 = false>
 struct Stage {
+  static constexpr int PK8 = KB + 8;   // U8, k-contiguous: row pitch in bytes (8-byte aligned fragment reads)
+  static constexpr int LD8 = BX + 16;  // U8, k-major: row pitch in bytes
+  static constexpr int ST8 = KMAJOR ? KB * LD8 / 4 : BX * PK8 / 4;  // U8: floats of tile bytes (k-major: + 2 KB stats)
   // LDS tile: a k-major operand is stored [KB][BX + 4] (ds_write_b128 along the output index); a k-contiguous one
   // is stored as it comes, [BX][KB + 4] (ds_write_b128 along k: no transposing scalar stores, which cost 14 % of the
   // MFMA rate in scripts/mfma_peak.hip).  The +4 keeps rows 16-byte aligned and spreads 8 consecutive rows over
   // all eight 16-byte bank groups (pitch 20 floats = 5 groups, odd).
   static constexpr int LD = BX + 4;
   static constexpr int PK = KB + 4;
-  static constexpr int TILE = KMAJOR ? KB * LD : BX * PK;
+  static constexpr int TILE = U8 ? (KMAJOR ? ST8 + 2 * KB : ST8) : (KMAJOR ? KB * LD : BX * PK);
   static constexpr int QUADS = BX * KB / 4;            // float4 per tile
   static constexpr int NV = (QUADS + NT - 1) / NT;       // float4 per thread
   static constexpr int NF = NV * 4;                    // floats per thread
@@ -404,6 +412,27 @@ struct Stage {
                          true);
         r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
       }
+    } else if (MODE == SRC_OBSN && U8) {
+      // raw bytes: dword r[4q] goes to LDS as it is.  k-major: the thread that stages the first quad of a k-row also
+      // leaves that row's (rstd, -mean * rstd) behind the tile (both zero for padding rows, whose bytes are zero too)
+      uint32_t* l32 = reinterpret_cast<uint32_t*>(lds);
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int u = tid + q * NT;
+        if (PARTIAL && u >= QUADS) continue;
+        if (!KMAJOR) {
+          const int x = u / KQ, k = (u % KQ) * 4;
+          l32[(x * PK8 + k) >> 2] = __float_as_uint(r[4 * q]);
+        } else {
+          const int k = u / (BX / 4), x = (u % (BX / 4)) * 4;
+          l32[(k * LD8 + x) >> 2] = __float_as_uint(r[4 * q]);
+          if (x == 0) {
+            lds[ST8 + 2 * k] = d_rs[q];
+            lds[ST8 + 2 * k + 1] = -d_mean[q] * d_rs[q];
+          }
+        }
+      }
+      return;
     } else if (MODE == SRC_OBSN) {
       // no tables: padding quads (loaded as zeros) must stay zero, so their statistics were zeroed in load()
 #pragma unroll
@@ -453,13 +482,16 @@ constexpr int min_waves(int bm, int bn, int amode, int bmode, bool gen, int nwav
   return big ? 3 : 4;
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN, int KB>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN, int KB, bool OBS8>
 __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, WM * WN)) void gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1, "4 or 8 wavefronts per workgroup");
   constexpr int NT = WM * WN * 64;
-  using SA = Stage<BM, AKM, AMODE, NT, KB>;
-  using SB = Stage<BN, BKM, BMODE, NT, KB>;
+  constexpr bool A8 = OBS8 && AMODE == SRC_OBSN && !AKM;  // uint8 frames as the k-contiguous A (first-layer forward)
+  constexpr bool B8 = OBS8 && BMODE == SRC_OBSN && BKM;   // ... as the k-major B (first-layer weight gradient)
+  static_assert(!OBS8 || A8 || B8, "OBS8 without a byte-staged operand");
+  using SA = Stage<BM, AKM, AMODE, NT, KB, A8>;
+  using SB = Stage<BN, BKM, BMODE, NT, KB, B8>;
   constexpr int A_FLOATS = SA::TILE, TILE_FLOATS = SA::TILE + SB::TILE;  // multiples of 4: 16-byte aligned
   __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
 
@@ -508,6 +540,17 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
   const bool va = GEN ? g.vec_a != 0 : true, vb = GEN ? g.vec_b != 0 : true;
   sa.prepare(g.a, m0, g.M, kbeg, va);
   sb.prepare(g.b, n0, g.N, kbeg, vb);
+  // A8: (rstd, -mean * rstd) of the rows whose fragments this lane feeds to the MFMAs -- fixed for the whole tile
+  float a8_rs[A8 ? TM : 1], a8_mr[A8 ? TM : 1];
+  if (A8) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long row = m0 + wm * (TM * 32) + i * 32 + l31;
+      const RowInfo ri = row_info<SRC_OBSN>(g.a, (uint32_t)(row < g.M ? row : g.M - 1));
+      a8_rs[i] = ri.rs;
+      a8_mr[i] = -ri.mr * ri.rs;
+    }
+  }
   // Column sums of a dense k-major A, for free: a thread stages the same four output indices of every k-tile
   // (NT is a multiple of BM/4), so it keeps four running sums of what it writes to LDS; the workgroups of the first
   // column of tiles combine theirs at the end.  (A weight-gradient product dZ^T X thereby also yields the bias
@@ -577,9 +620,40 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
                       (BKM ? (KB / 2) * h * SB::LD + wn * (TN * 32) + l31 : (wn * (TN * 32) + l31) * SB::PK + (KB / 2) * h);
     float* nxt = lds + (cur ^ 1) * TILE_FLOATS;
     float a[AKM ? 2 : KB / 2][TM], b[BKM ? 2 : KB / 2][TN];
+    // byte-staged operands (see Stage): widen + normalise here, after the fragment read
+    const uint8_t* ap8 = reinterpret_cast<const uint8_t*>(lds + cur * TILE_FLOATS) + (wm * (TM * 32) + l31) * SA::PK8 +
+                         (KB / 2) * h;
+    const uint8_t* bp8 = reinterpret_cast<const uint8_t*>(lds + cur * TILE_FLOATS + A_FLOATS) + (KB / 2) * h * SB::LD8 +
+                         wn * (TN * 32) + l31;
+    // (rstd, -mean rstd) of this half-wave's KB/2 k-rows: fetched once per k-step (KB/4 ds_read_b128)
+    float bst[B8 ? KB : 1];
+    if (B8) {
+      const float4* sp = reinterpret_cast<const float4*>(lds + cur * TILE_FLOATS + A_FLOATS + SB::ST8 + KB * h);
+#pragma unroll
+      for (int c4 = 0; c4 < KB / 4; ++c4) {
+        const float4 q = sp[c4];
+        bst[4 * c4] = q.x, bst[4 * c4 + 1] = q.y, bst[4 * c4 + 2] = q.z, bst[4 * c4 + 3] = q.w;
+      }
+    }
+    auto read_b8 = [&](int kk, int j) {
+      const float raw = (float)bp8[kk * SB::LD8 + j * 32];
+      return fmaf(raw, bst[2 * kk], bst[2 * kk + 1]);
+    };
     if (AKM) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32];
+    } else if (A8) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int c8 = 0; c8 < KB / 16; ++c8) {
+          const uint2 w = *reinterpret_cast<const uint2*>(ap8 + i * 32 * SA::PK8 + 8 * c8);
+          const uint32_t ww[2] = {w.x, w.y};
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            a[8 * c8 + e][i] = fmaf((float)((ww[e >> 2] >> (8 * (e & 3))) & 255u), a8_rs[i], a8_mr[i]);
+        }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -590,7 +664,10 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
         }
       }
     }
-    if (BKM) {
+    if (B8) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = read_b8(0, j);
+    } else if (BKM) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32];
     } else {
@@ -610,7 +687,10 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
 #pragma unroll
           for (int i = 0; i < TM; ++i) a[(kk + 1) & 1][i] = ap[(kk + 1) * SA::LD + i * 32];
         }
-        if (BKM) {
+        if (B8) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[(kk + 1) & 1][j] = read_b8(kk + 1, j);
+        } else if (BKM) {
 #pragma unroll
           for (int j = 0; j < TN; ++j) b[(kk + 1) & 1][j] = bp[(kk + 1) * SB::LD + j * 32];
         }
@@ -867,7 +947,8 @@ inline int plan_split(long K, int want, long* k_per_split) {
 }
 
 #ifdef __HIPCC__
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN = false, int KB = BK>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN = false, int KB = BK,
+          bool OBS8 = false>
 inline int launch(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   if (!GEN && !(a.vec_a && a.vec_b)) return -EINVAL;  // float4-only instantiation
   const long tiles_m = srl_ceil_div(a.M, BM);
@@ -876,7 +957,7 @@ inline int launch(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   const long nblk = tiles_m * a.tiles_n * a.nbatch;
   if (nblk > 0x7fffffffL || nsplit > 65535) return -EINVAL;
   dim3 grid((unsigned)nblk, 1, (unsigned)nsplit);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, GEN, KB>), grid, dim3(WM * WN * 64), 0, st, a);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, GEN, KB, OBS8>), grid, dim3(WM * WN * 64), 0, st, a);
   return 0;
 }
 #endif
