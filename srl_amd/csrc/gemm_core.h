@@ -243,15 +243,25 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, uint32_t voff
 // float staging of the frames alone took ~2/3 of the LDS bandwidth of a CU.
 template <int BX, bool KMAJOR, int MODE, int NT = 256, int KB = BK, bool U8 = false>
 struct Stage {
-  static constexpr int PK8 = KB + 8;   // U8, k-contiguous: row pitch in bytes (8-byte aligned fragment reads)
+  static constexpr int PK8 = KB;       // U8, k-contiguous: row pitch in bytes; 16-byte chunks XOR-swizzled like the float
+                                       // tiles (swz8): dword writes and b64 / b128 fragment reads without bank conflicts
+  static constexpr int CPR8 = KB / 16 > 0 ? KB / 16 : 1, RPL8 = 256 / KB;
+  __device__ static __forceinline__ int swz8(int x, int c) { return c ^ ((x / RPL8) % CPR8); }
   static constexpr int LD8 = BX + 16;  // U8, k-major: row pitch in bytes
   static constexpr int ST8 = KMAJOR ? KB * LD8 / 4 : BX * PK8 / 4;  // U8: floats of tile bytes (k-major: + 2 KB stats)
   // LDS tile: a k-major operand is stored [KB][BX + 4] (ds_write_b128 along the output index); a k-contiguous one
-  // is stored as it comes, [BX][KB + 4] (ds_write_b128 along k: no transposing scalar stores, which cost 14 % of the
-  // MFMA rate in scripts/mfma_peak.hip).  The +4 keeps rows 16-byte aligned and spreads 8 consecutive rows over
-  // all eight 16-byte bank groups (pitch 20 floats = 5 groups, odd).
+  // is stored as it comes, row by row (ds_write_b128 along k: no transposing scalar stores, which cost 14 % of the
+  // MFMA rate in scripts/mfma_peak.hip), in the swizzled layout described below.
   static constexpr int LD = BX + 4;
-  static constexpr int PK = KB + 4;
+  // k-contiguous tile: [BX][KB] floats, NO padding; the 16-byte chunk c of row x sits at chunk position
+  // c ^ ((x / RPL) % CPR) (CPR chunks per row, RPL rows per 256-byte bank line).  A 16-lane pass of ds_write_b128 covers
+  // RPL whole rows = every bank once whatever the permutation; a 16-lane pass of ds_read_b128 reads the same chunk c
+  // of 16 consecutive rows, and the rows that share a bank line get distinct positions from the XOR: neither side
+  // conflicts (the padded layout [BX][KB + 4] had clean reads and two-way write conflicts: SQ_LDS_BANK_CONFLICT was
+  // 17-36 % of the LDS-active cycles of the k-contiguous kernels, zero in the k-major ones).
+  static constexpr int PK = KB;
+  static constexpr int CPR = KB / 4, RPL = 16 / CPR > 0 ? 16 / CPR : 1;
+  __device__ static __forceinline__ int swz(int x, int c) { return c ^ ((x / RPL) % CPR); }
   static constexpr int TILE = U8 ? (KMAJOR ? ST8 + 2 * KB : ST8) : (KMAJOR ? KB * LD : BX * PK);
   static constexpr int QUADS = BX * KB / 4;            // float4 per tile
   static constexpr int NV = (QUADS + NT - 1) / NT;       // float4 per thread
@@ -422,7 +432,7 @@ struct Stage {
         if (PARTIAL && u >= QUADS) continue;
         if (!KMAJOR) {
           const int x = u / KQ, k = (u % KQ) * 4;
-          l32[(x * PK8 + k) >> 2] = __float_as_uint(r[4 * q]);
+          l32[(x * PK8 + 16 * swz8(x, k >> 4) + (k & 15)) >> 2] = __float_as_uint(r[4 * q]);
         } else {
           const int k = u / (BX / 4), x = (u % (BX / 4)) * 4;
           l32[(k * LD8 + x) >> 2] = __float_as_uint(r[4 * q]);
@@ -451,7 +461,8 @@ struct Stage {
         if (PARTIAL && u >= QUADS) continue;
         if (!KMAJOR) {
           const int x = u / KQ, k = (u % KQ) * 4;
-          *reinterpret_cast<float4*>(lds + x * PK + k) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+          *reinterpret_cast<float4*>(lds + x * PK + 4 * swz(x, k >> 2)) =
+              make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
         } else {
           const int k = u / (BX / 4), x = (u % (BX / 4)) * 4;
           *reinterpret_cast<float4*>(lds + k * LD + x) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
@@ -462,7 +473,7 @@ struct Stage {
       for (int q = 0; q < NF; ++q) {
         const int e = tid + q * NT;
         if (PARTIAL && e >= BX * KB) continue;
-        if (!KMAJOR) lds[(e / KB) * PK + e % KB] = r[q];
+        if (!KMAJOR) lds[(e / KB) * PK + 4 * swz(e / KB, (e % KB) >> 2) + (e & 3)] = r[q];
         else lds[(e / BX) * LD + e % BX] = r[q];
       }
     }
@@ -615,14 +626,13 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     // as both operands use the same one, and this one lets a k-contiguous operand fetch its 8 values with two
     // ds_read_b128.  A k-major operand reads row 8*h + kk, one step ahead of its MFMAs.
     const float* ap = lds + cur * TILE_FLOATS +
-                      (AKM ? (KB / 2) * h * SA::LD + wm * (TM * 32) + l31 : (wm * (TM * 32) + l31) * SA::PK + (KB / 2) * h);
+                      (AKM ? (KB / 2) * h * SA::LD + wm * (TM * 32) + l31 : (wm * (TM * 32) + l31) * SA::PK);
     const float* bp = lds + cur * TILE_FLOATS + A_FLOATS +
-                      (BKM ? (KB / 2) * h * SB::LD + wn * (TN * 32) + l31 : (wn * (TN * 32) + l31) * SB::PK + (KB / 2) * h);
+                      (BKM ? (KB / 2) * h * SB::LD + wn * (TN * 32) + l31 : (wn * (TN * 32) + l31) * SB::PK);
     float* nxt = lds + (cur ^ 1) * TILE_FLOATS;
     float a[AKM ? 2 : KB / 2][TM], b[BKM ? 2 : KB / 2][TN];
     // byte-staged operands (see Stage): widen + normalise here, after the fragment read
-    const uint8_t* ap8 = reinterpret_cast<const uint8_t*>(lds + cur * TILE_FLOATS) + (wm * (TM * 32) + l31) * SA::PK8 +
-                         (KB / 2) * h;
+    const uint8_t* ap8 = reinterpret_cast<const uint8_t*>(lds + cur * TILE_FLOATS) + (wm * (TM * 32) + l31) * SA::PK8;
     const uint8_t* bp8 = reinterpret_cast<const uint8_t*>(lds + cur * TILE_FLOATS + A_FLOATS) + (KB / 2) * h * SB::LD8 +
                          wn * (TN * 32) + l31;
     // (rstd, -mean rstd) of this half-wave's KB/2 k-rows: fetched once per k-step (KB/4 ds_read_b128)
@@ -645,9 +655,13 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     } else if (A8) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
+        // the lane's KB/2 bytes: k = (KB/2) h + 0 .. KB/2 - 1, i.e. 8-byte pieces p = (KB/16) h + c8 of the row
+        const int row = wm * (TM * 32) + i * 32 + l31;
 #pragma unroll
         for (int c8 = 0; c8 < KB / 16; ++c8) {
-          const uint2 w = *reinterpret_cast<const uint2*>(ap8 + i * 32 * SA::PK8 + 8 * c8);
+          const int piece = (KB / 16) * h + c8;  // 8-byte piece index within the row
+          const uint2 w = *reinterpret_cast<const uint2*>(ap8 + i * 32 * SA::PK8 + 16 * SA::swz8(row, piece >> 1) +
+                                                          8 * (piece & 1));
           const uint32_t ww[2] = {w.x, w.y};
 #pragma unroll
           for (int e = 0; e < 8; ++e)
@@ -659,7 +673,8 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int c4 = 0; c4 < KB / 8; ++c4) {
-          const float4 q = *reinterpret_cast<const float4*>(ap + i * 32 * SA::PK + 4 * c4);
+          const float4 q = *reinterpret_cast<const float4*>(
+              ap + i * 32 * SA::PK + 4 * SA::swz(wm * (TM * 32) + i * 32 + l31, (KB / 8) * h + c4));
           a[4 * c4][i] = q.x, a[4 * c4 + 1][i] = q.y, a[4 * c4 + 2][i] = q.z, a[4 * c4 + 3][i] = q.w;
         }
       }
@@ -675,7 +690,8 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
       for (int j = 0; j < TN; ++j) {
 #pragma unroll
         for (int c4 = 0; c4 < KB / 8; ++c4) {
-          const float4 q = *reinterpret_cast<const float4*>(bp + j * 32 * SB::PK + 4 * c4);
+          const float4 q = *reinterpret_cast<const float4*>(
+              bp + j * 32 * SB::PK + 4 * SB::swz(wn * (TN * 32) + j * 32 + l31, (KB / 8) * h + c4));
           b[4 * c4][j] = q.x, b[4 * c4 + 1][j] = q.y, b[4 * c4 + 2][j] = q.z, b[4 * c4 + 3][j] = q.w;
         }
       }
