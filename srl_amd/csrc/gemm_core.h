@@ -247,8 +247,10 @@ struct Stage {
                                        // tiles (swz8): dword writes and b64 / b128 fragment reads without bank conflicts
   static constexpr int CPR8 = KB / 16 > 0 ? KB / 16 : 1, RPL8 = 256 / KB;
   __device__ static __forceinline__ int swz8(int x, int c) { return c ^ ((x / RPL8) % CPR8); }
-  static constexpr int LD8 = BX + 16;  // U8, k-major: row pitch in bytes
-  static constexpr int ST8 = KMAJOR ? KB * LD8 / 4 : BX * PK8 / 4;  // U8: floats of tile bytes (k-major: + 2 KB stats)
+  // U8, k-major (BX == 256): dwords D[KB / 4][BX], D[g][col] = the bytes of rows 4g .. 4g+3 of column col.  A thread
+  // stages four consecutive k-rows of its four columns, transposes the 4 x 4 bytes in registers and writes ONE
+  // ds_write_b128; a lane reads its column's KB / 8 dwords per k-step with ds_read_b32 over consecutive columns.
+  static constexpr int ST8 = KMAJOR ? KB * BX / 4 : BX * PK8 / 4;  // U8: floats of tile bytes (k-major: + 2 KB stats)
   // LDS tile: a k-major operand is stored [KB][BX + 4] (ds_write_b128 along the output index); a k-contiguous one
   // is stored as it comes, row by row (ds_write_b128 along k: no transposing scalar stores, which cost 14 % of the
   // MFMA rate in scripts/mfma_peak.hip), in the swizzled layout described below.
@@ -277,6 +279,8 @@ struct Stage {
   // that nothing between the global loads and the MFMA loop depends on loaded data
   float d_rs[is_obs(MODE) ? NV : 1], d_mean[is_obs(MODE) ? NV : 1];
   int d_gp[MODE == SRC_OBS ? NV : 1];
+  float st_rs, st_mr;  // U8, k-major: lane q < NV holds (rstd, mean) of the wavefront's q-th k-row (one vector load each,
+                       // in flight like the tile itself; as scalar loads they stalled the wavefront row after row)
   uint32_t vmask;  // OBSN, k-contiguous: bit q = quad q of the current tile is in bounds  // gamma/beta offset of the quad, or -1 (out of bounds: the quad is zero)
   const char* cur;                     // dense operands: base of the first k-tile (wave-uniform)
   long step;                           // dense operands: bytes per k-tile
@@ -356,12 +360,13 @@ struct Stage {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
           const int u = tid + q * NT;
-          const long k = k0 + (BX == 256 ? wave + (NT / 64) * q : u / (BX / 4));
+          // U8: a wavefront takes NV consecutive k-rows (it transposes 4 x 4 bytes at the store); else rows wave + 4q
+          const long k = k0 + (U8 ? NV * wave + q : BX == 256 ? wave + (NT / 64) * q : u / (BX / 4));
           const bool ok = k < kend && voff[q] != kInvalidOff;
           const RowInfo ri = row_info<MODE>(s, (uint32_t)(k < kend ? k : kend - 1));
           const uint32_t o = ok ? voff[q] + (uint32_t)ri.off * esz : kInvalidOff;
           if (is_obs(MODE)) {
-            d_rs[q] = ok ? ri.rs : 0.f; d_mean[q] = ok ? ri.mr : 0.f;
+            if (!U8) { d_rs[q] = ok ? ri.rs : 0.f; d_mean[q] = ok ? ri.mr : 0.f; }
             if (MODE == SRC_OBS) d_gp[q] = !ok ? -1 : ri.pos + (int)(voff[q] / esz);
             if (s.is_u8) r[4 * q] = bload1(rs, o);
             else { const float4 v = bload4(rs, o); r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w; }
@@ -369,6 +374,14 @@ struct Stage {
             const float4 v = bload4(rs, o);
             r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
           }
+        }
+        if (U8) {  // statistics of this wavefront's NV k-rows: lane q fetches row q's
+          const int lq = tid & 63;
+          const long k = k0 + NV * wave + (lq < NV ? lq : 0);
+          const bool okk = lq < NV && k < kend;
+          const uint32_t n = fdiv((uint32_t)(okk ? k : 0), s.f_img);
+          st_rs = okk ? s.rstd[n] : 0.f;
+          st_mr = okk ? s.mean[n] : 0.f;
         }
       }
       return;
@@ -426,21 +439,39 @@ struct Stage {
       // raw bytes: dword r[4q] goes to LDS as it is.  k-major: the thread that stages the first quad of a k-row also
       // leaves that row's (rstd, -mean * rstd) behind the tile (both zero for padding rows, whose bytes are zero too)
       uint32_t* l32 = reinterpret_cast<uint32_t*>(lds);
+      if (KMAJOR) {
+        static_assert(!KMAJOR || !U8 || (BX == 256 && NT == 256 && NV % 4 == 0), "byte k-major staging: 256 columns, 4 wavefronts");
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int g4 = 0; g4 < NV / 4; ++g4) {
+          // rows 4g .. 4g+3 (g = (NV/4) wave + g4) x columns 4 lane .. 4 lane + 3: transpose the 4 x 4 bytes
+          const uint32_t r0 = __float_as_uint(r[16 * g4]), r1 = __float_as_uint(r[16 * g4 + 4]);
+          const uint32_t r2 = __float_as_uint(r[16 * g4 + 8]), r3 = __float_as_uint(r[16 * g4 + 12]);
+          const uint32_t t0 = __builtin_amdgcn_perm(r1, r0, 0x05010400u);  // r0.b0 r1.b0 r0.b1 r1.b1
+          const uint32_t t1 = __builtin_amdgcn_perm(r1, r0, 0x07030602u);  // r0.b2 r1.b2 r0.b3 r1.b3
+          const uint32_t t2 = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
+          const uint32_t t3 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+          uint4 c;
+          c.x = __builtin_amdgcn_perm(t2, t0, 0x05040100u);  // column 0: r0.b0 r1.b0 r2.b0 r3.b0
+          c.y = __builtin_amdgcn_perm(t2, t0, 0x07060302u);  // column 1
+          c.z = __builtin_amdgcn_perm(t3, t1, 0x05040100u);  // column 2
+          c.w = __builtin_amdgcn_perm(t3, t1, 0x07060302u);  // column 3
+          const int g = (NV / 4) * wave + g4;
+          *reinterpret_cast<uint4*>(l32 + g * BX + 4 * lane) = c;
+        }
+        if (lane < NV) {  // (rstd, -mean rstd) of this wavefront's k-rows, behind the tile (zeros for padding rows)
+          const int k = NV * wave + lane;
+          lds[ST8 + 2 * k] = st_rs;
+          lds[ST8 + 2 * k + 1] = -st_mr * st_rs;
+        }
+        return;
+      }
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int u = tid + q * NT;
         if (PARTIAL && u >= QUADS) continue;
-        if (!KMAJOR) {
-          const int x = u / KQ, k = (u % KQ) * 4;
-          l32[(x * PK8 + 16 * swz8(x, k >> 4) + (k & 15)) >> 2] = __float_as_uint(r[4 * q]);
-        } else {
-          const int k = u / (BX / 4), x = (u % (BX / 4)) * 4;
-          l32[(k * LD8 + x) >> 2] = __float_as_uint(r[4 * q]);
-          if (x == 0) {
-            lds[ST8 + 2 * k] = d_rs[q];
-            lds[ST8 + 2 * k + 1] = -d_mean[q] * d_rs[q];
-          }
-        }
+        const int x = u / KQ, k = (u % KQ) * 4;
+        l32[(x * PK8 + 16 * swz8(x, k >> 4) + (k & 15)) >> 2] = __float_as_uint(r[4 * q]);
       }
       return;
     } else if (MODE == SRC_OBSN) {
@@ -633,8 +664,16 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     float a[AKM ? 2 : KB / 2][TM], b[BKM ? 2 : KB / 2][TN];
     // byte-staged operands (see Stage): widen + normalise here, after the fragment read
     const uint8_t* ap8 = reinterpret_cast<const uint8_t*>(lds + cur * TILE_FLOATS) + (wm * (TM * 32) + l31) * SA::PK8;
-    const uint8_t* bp8 = reinterpret_cast<const uint8_t*>(lds + cur * TILE_FLOATS + A_FLOATS) + (KB / 2) * h * SB::LD8 +
-                         wn * (TN * 32) + l31;
+    // B8: the lane's columns' dwords for this half-wave's k-rows (KB / 8 per column; byte e of dword g = row 4g + e)
+    uint32_t bw[B8 ? TN : 1][B8 ? KB / 8 : 1];
+    if (B8) {
+      const uint32_t* dp = reinterpret_cast<const uint32_t*>(lds + cur * TILE_FLOATS + A_FLOATS) + (KB / 8) * h * BN +
+                           wn * (TN * 32) + l31;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g2 = 0; g2 < KB / 8; ++g2) bw[j][g2] = dp[g2 * BN + j * 32];
+    }
     // (rstd, -mean rstd) of this half-wave's KB/2 k-rows: fetched once per k-step (KB/4 ds_read_b128)
     float bst[B8 ? KB : 1];
     if (B8) {
@@ -646,7 +685,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
       }
     }
     auto read_b8 = [&](int kk, int j) {
-      const float raw = (float)bp8[kk * SB::LD8 + j * 32];
+      const float raw = (float)((bw[j][kk >> 2] >> (8 * (kk & 3))) & 255u);
       return fmaf(raw, bst[2 * kk], bst[2 * kk + 1]);
     };
     if (AKM) {
