@@ -327,6 +327,58 @@ struct Stage {
     }
   }
 
+  // ---- U8, k-major: two register sets (SET = parity of the tile), so that a tile's loads are issued TWO k-steps before
+  // its LDS store.  Every k-step of this operand touches KB samples it has never seen (rows = samples), i.e. cold
+  // lines with full memory latency: with one k-step of lead the wavefronts stalled on them (skipping these loads
+  // altogether took the first-layer weight gradient from 81 to 107 TFLOP/s); a set costs NV + 2 registers.
+  uint32_t w8[(U8 && KMAJOR) ? 2 : 1][(U8 && KMAJOR) ? NV : 1];
+  float s8_rs[2], s8_mr[2];
+  template <int SET>
+  __device__ __forceinline__ void load8(const SrcDesc& s, long k0, long kend) {
+    const int tid = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(cur);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const long k = k0 + NV * wave + q;  // NV consecutive k-rows per wavefront (transposed 4 x 4 at the store)
+      const bool ok = k < kend && voff[q] != kInvalidOff;
+      const RowInfo ri = row_info<SRC_CONV>(s, (uint32_t)(k < kend ? k : kend - 1));  // address only (no statistics)
+      w8[SET][q] = __float_as_uint(bload1(rs, ok ? voff[q] + (uint32_t)ri.off : kInvalidOff));
+    }
+    const int lq = tid & 63;  // statistics of the wavefront's NV rows: lane q fetches row q's
+    const long k = k0 + NV * wave + (lq < NV ? lq : 0);
+    const bool okk = lq < NV && k < kend;
+    const uint32_t n = fdiv((uint32_t)(okk ? k : 0), s.f_img);
+    s8_rs[SET] = okk ? s.rstd[n] : 0.f;
+    s8_mr[SET] = okk ? s.mean[n] : 0.f;
+  }
+  template <int SET>
+  __device__ __forceinline__ void store8(float* __restrict__ lds) {
+    static_assert(!(U8 && KMAJOR) || (BX == 256 && NT == 256 && NV % 4 == 0), "byte k-major staging: 256 columns, 4 wavefronts");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint32_t* l32 = reinterpret_cast<uint32_t*>(lds);
+#pragma unroll
+    for (int g4 = 0; g4 < NV / 4; ++g4) {
+      // rows 4g .. 4g+3 (g = (NV/4) wave + g4) x columns 4 lane .. 4 lane + 3: transpose the 4 x 4 bytes
+      const uint32_t r0 = w8[SET][4 * g4], r1 = w8[SET][4 * g4 + 1], r2 = w8[SET][4 * g4 + 2], r3 = w8[SET][4 * g4 + 3];
+      const uint32_t t0 = __builtin_amdgcn_perm(r1, r0, 0x05010400u);  // r0.b0 r1.b0 r0.b1 r1.b1
+      const uint32_t t1 = __builtin_amdgcn_perm(r1, r0, 0x07030602u);  // r0.b2 r1.b2 r0.b3 r1.b3
+      const uint32_t t2 = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
+      const uint32_t t3 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+      uint4 c;
+      c.x = __builtin_amdgcn_perm(t2, t0, 0x05040100u);  // column 0: r0.b0 r1.b0 r2.b0 r3.b0
+      c.y = __builtin_amdgcn_perm(t2, t0, 0x07060302u);  // column 1
+      c.z = __builtin_amdgcn_perm(t3, t1, 0x05040100u);  // column 2
+      c.w = __builtin_amdgcn_perm(t3, t1, 0x07060302u);  // column 3
+      *reinterpret_cast<uint4*>(l32 + ((NV / 4) * wave + g4) * BX + 4 * lane) = c;
+    }
+    if (lane < NV) {  // (rstd, -mean rstd) of this wavefront's k-rows, behind the tile (zeros for padding rows)
+      const int k = NV * wave + lane;
+      lds[ST8 + 2 * k] = s8_rs[SET];
+      lds[ST8 + 2 * k + 1] = -s8_mr[SET] * s8_rs[SET];
+    }
+  }
+
   // loads k-tile [k0, k0 + KB) clipped to kend; k0 - kbeg is a multiple of KB (tiles may be skipped)
   __device__ __forceinline__ void load(const SrcDesc& s, long x0, long xn, long k0, long kend, bool vec) {
     const int tid = threadIdx.x;
@@ -637,21 +689,26 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
   long kend_l = kend;
   if (kcur < 0) { kcur = kbeg; kend_l = kbeg; }  // no tap reaches this pixel: one step on an all-zero tile
   long knext = nextk(kcur);
+  long knext2 = B8 && knext >= 0 ? nextk(knext) : -1;  // B8 stages two tiles ahead (Stage::load8)
   // prologue: the first tile into LDS buffer 0, the second into registers
   sa.load(g.a, m0, g.M, kcur, kend_l, va);
-  sb.load(g.b, n0, g.N, kcur, kend_l, vb);
+  if (B8) sb.template load8<0>(g.b, kcur, kend_l);
+  else sb.load(g.b, n0, g.N, kcur, kend_l, vb);
   cs_acc();
   sa.store(lds, va, g.a);
-  sb.store(lds + A_FLOATS, vb, g.b);
+  if (B8) sb.template store8<0>(lds + A_FLOATS);
+  else sb.store(lds + A_FLOATS, vb, g.b);
   __syncthreads();
   if (knext >= 0) {
     sa.load(g.a, m0, g.M, knext, kend, va);
-    sb.load(g.b, n0, g.N, knext, kend, vb);
+    if (B8) sb.template load8<1>(g.b, knext, kend);
+    else sb.load(g.b, n0, g.N, knext, kend, vb);
   }
+  if (B8 && knext2 >= 0) sb.template load8<0>(g.b, knext2, kend);
 
   // one k-step on LDS buffer `cur` (compile-time): MFMAs, with the staging of the following tiles in the middle
-  // k1 / k2: the k of the next two steps (-1: none)
-  auto kstep = [&](auto cur_c, long k1, long k2) {
+  // k1 / k2 / k3: the k of the next steps (-1: none); tile t+1 sits in registers (B8: t+1 and t+2, sets by tile parity)
+  auto kstep = [&](auto cur_c, long k1, long k2, long k3) {
     constexpr int cur = decltype(cur_c)::value;
     // MFMA step kk consumes k = (KB/2)*h + kk of the tile (h = lane >> 5): any pairing of the KB k values works as long
     // as both operands use the same one, and this one lets a k-contiguous operand fetch its 8 values with two
@@ -754,12 +811,14 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
         if (k1 >= 0) {  // tile t+1: registers -> the other LDS buffer (its readers left at the last barrier)
           cs_acc();
           sa.store(nxt, va, g.a);
-          sb.store(nxt + A_FLOATS, vb, g.b);
+          if (B8) sb.template store8<cur ^ 1>(nxt + A_FLOATS);
+          else sb.store(nxt + A_FLOATS, vb, g.b);
         }
         if (k2 >= 0) {  // tile t+2: global -> registers
           sa.load(g.a, m0, g.M, k2, kend, va);
-          sb.load(g.b, n0, g.N, k2, kend, vb);
+          if (!B8) sb.load(g.b, n0, g.N, k2, kend, vb);
         }
+        if (B8 && k3 >= 0) sb.template load8<cur ^ 1>(g.b, k3, kend);  // tile t+3 into the set tile t+1 just left
       }
       // (no sched_barrier: order-pinning was measured)
 #pragma unroll
@@ -770,15 +829,19 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     }
     __syncthreads();  // tile t+1 is visible; everyone is done reading tile t
   };
-  for (;;) {
-    long k2 = knext >= 0 ? nextk(knext) : -1;
-    kstep(std::integral_constant<int, 0>{}, knext, k2);
+  for (;;) {  // k1 = knext; B8 keeps k2 = knext2 as well (its loads were issued a step earlier)
+    long k2 = B8 ? knext2 : (knext >= 0 ? nextk(knext) : -1);
+    long k3 = B8 && k2 >= 0 ? nextk(k2) : -1;
+    kstep(std::integral_constant<int, 0>{}, knext, k2, k3);
     if (knext < 0) break;
     knext = k2;
-    k2 = knext >= 0 ? nextk(knext) : -1;
-    kstep(std::integral_constant<int, 1>{}, knext, k2);
+    knext2 = k3;
+    k2 = B8 ? knext2 : (knext >= 0 ? nextk(knext) : -1);
+    k3 = B8 && k2 >= 0 ? nextk(k2) : -1;
+    kstep(std::integral_constant<int, 1>{}, knext, k2, k3);
     if (knext < 0) break;
     knext = k2;
+    knext2 = k3;
   }
   if (CSUM && do_cs) {  // workgroup-uniform; the tiles in LDS are dead after the loop's last barrier
     constexpr int G = BM / 4;  // threads that share a k-row of the A tile; thread t owns columns 4 * (t % G) ..+3
