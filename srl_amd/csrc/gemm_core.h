@@ -272,6 +272,12 @@ struct Stage {
   static constexpr int KQ = KB / 4;                    // quads per k-contiguous row
   static constexpr bool GATHER = MODE != SRC_PLAIN;
   float r[NF];
+  // A second register set lets an operand be staged TWO tiles ahead (load<SET> / store<SET>, SET = tile parity), as the
+  // byte tiles below are.  Measured for the k-major patch gathers of the weight gradients (GATHER && KMAJOR && MODE ==
+  // SRC_CONV; skipping their loads altogether gains 15 %): 16 more registers, same occupancy, and the step's weight
+  // gradients got SLOWER, 6.03 -> 6.22 ms, A/B on one box -- so no float operand uses it.
+  static constexpr bool TWO = false;
+  float r2[TWO ? NF : 1];
   uint32_t voff[NV];                                 // k-invariant byte offset of quad q (kInvalidOff: always zero)
   int yx[(MODE == SRC_DGRAD) ? NV : 1];              // DGRAD: (y << 16) | x of the row
   int pos[(MODE == SRC_OBS && !KMAJOR) ? NV : 1];       // OBS: offset of the row inside its image
@@ -380,8 +386,10 @@ struct Stage {
   }
 
   // loads k-tile [k0, k0 + KB) clipped to kend; k0 - kbeg is a multiple of KB (tiles may be skipped)
+  template <int SET = 0>
   __device__ __forceinline__ void load(const SrcDesc& s, long x0, long xn, long k0, long kend, bool vec) {
     const int tid = threadIdx.x;
+    float* rr = (TWO && SET) ? r2 : r;
     if (GATHER) {
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(cur);
       if (!KMAJOR) {
@@ -398,11 +406,11 @@ struct Stage {
           if (is_obs(MODE)) {
             if (MODE == SRC_OBS) d_gp[q] = ok ? pos[q] + ci.off : -1;
             if (MODE == SRC_OBSN) vmask = (q == 0 ? 0u : vmask) | ((ok ? 1u : 0u) << q);
-            if (s.is_u8) r[4 * q] = bload1(rs, o);
-            else { const float4 v = bload4(rs, o); r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w; }
+            if (s.is_u8) rr[4 * q] = bload1(rs, o);
+            else { const float4 v = bload4(rs, o); rr[4 * q] = v.x; rr[4 * q + 1] = v.y; rr[4 * q + 2] = v.z; rr[4 * q + 3] = v.w; }
           } else {
             const float4 v = bload4(rs, o);
-            r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+            rr[4 * q] = v.x; rr[4 * q + 1] = v.y; rr[4 * q + 2] = v.z; rr[4 * q + 3] = v.w;
           }
         }
       } else {
@@ -420,11 +428,11 @@ struct Stage {
           if (is_obs(MODE)) {
             if (!U8) { d_rs[q] = ok ? ri.rs : 0.f; d_mean[q] = ok ? ri.mr : 0.f; }
             if (MODE == SRC_OBS) d_gp[q] = !ok ? -1 : ri.pos + (int)(voff[q] / esz);
-            if (s.is_u8) r[4 * q] = bload1(rs, o);
-            else { const float4 v = bload4(rs, o); r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w; }
+            if (s.is_u8) rr[4 * q] = bload1(rs, o);
+            else { const float4 v = bload4(rs, o); rr[4 * q] = v.x; rr[4 * q + 1] = v.y; rr[4 * q + 2] = v.z; rr[4 * q + 3] = v.w; }
           } else {
             const float4 v = bload4(rs, o);
-            r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+            rr[4 * q] = v.x; rr[4 * q + 1] = v.y; rr[4 * q + 2] = v.z; rr[4 * q + 3] = v.w;
           }
         }
         if (U8) {  // statistics of this wavefront's NV k-rows: lane q fetches row q's
@@ -446,7 +454,7 @@ struct Stage {
         const int u = tid + q * NT;
         const bool kok = !KMAJOR ? (tid % KQ) * 4 < kleft : u / (BX / 4) < kleft;
         const float4 v = bload4(rs, kok ? voff[q] : kInvalidOff);
-        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+        rr[4 * q] = v.x; rr[4 * q + 1] = v.y; rr[4 * q + 2] = v.z; rr[4 * q + 3] = v.w;
       }
       return;
     }
@@ -464,12 +472,14 @@ struct Stage {
         const long k = k0 + e / BX, x = x0 + e % BX;
         if (x < xn && k < kend) v = src[k * ld + x];
       }
-      r[q] = v;
+      rr[q] = v;
     }
   }
 
+  template <int SET = 0>
   __device__ __forceinline__ void store(float* __restrict__ lds, bool vec, const SrcDesc& s) {
     const int tid = threadIdx.x;
+    float* rr = (TWO && SET) ? r2 : r;
     if (MODE == SRC_OBS) {
       float4 g[NV], b[NV];
       const __amdgpu_buffer_rsrc_t rg = make_rsrc(s.gamma), rb = make_rsrc(s.beta);
@@ -483,12 +493,12 @@ struct Stage {
       for (int q = 0; q < NV; ++q) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (d_gp[q] >= 0)
-          v = obs_finish(s, make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]), d_rs[q], d_mean[q], g[q], b[q],
+          v = obs_finish(s, make_float4(rr[4 * q], rr[4 * q + 1], rr[4 * q + 2], rr[4 * q + 3]), d_rs[q], d_mean[q], g[q], b[q],
                          true);
-        r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+        rr[4 * q + 0] = v.x; rr[4 * q + 1] = v.y; rr[4 * q + 2] = v.z; rr[4 * q + 3] = v.w;
       }
     } else if (MODE == SRC_OBSN && U8) {
-      // raw bytes: dword r[4q] goes to LDS as it is.  k-major: the thread that stages the first quad of a k-row also
+      // raw bytes: dword rr[4q] goes to LDS as it is.  k-major: the thread that stages the first quad of a k-row also
       // leaves that row's (rstd, -mean * rstd) behind the tile (both zero for padding rows, whose bytes are zero too)
       uint32_t* l32 = reinterpret_cast<uint32_t*>(lds);
       if (KMAJOR) {
@@ -497,8 +507,8 @@ struct Stage {
 #pragma unroll
         for (int g4 = 0; g4 < NV / 4; ++g4) {
           // rows 4g .. 4g+3 (g = (NV/4) wave + g4) x columns 4 lane .. 4 lane + 3: transpose the 4 x 4 bytes
-          const uint32_t r0 = __float_as_uint(r[16 * g4]), r1 = __float_as_uint(r[16 * g4 + 4]);
-          const uint32_t r2 = __float_as_uint(r[16 * g4 + 8]), r3 = __float_as_uint(r[16 * g4 + 12]);
+          const uint32_t r0 = __float_as_uint(rr[16 * g4]), r1 = __float_as_uint(rr[16 * g4 + 4]);
+          const uint32_t r2 = __float_as_uint(rr[16 * g4 + 8]), r3 = __float_as_uint(rr[16 * g4 + 12]);
           const uint32_t t0 = __builtin_amdgcn_perm(r1, r0, 0x05010400u);  // r0.b0 r1.b0 r0.b1 r1.b1
           const uint32_t t1 = __builtin_amdgcn_perm(r1, r0, 0x07030602u);  // r0.b2 r1.b2 r0.b3 r1.b3
           const uint32_t t2 = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
@@ -523,7 +533,7 @@ struct Stage {
         const int u = tid + q * NT;
         if (PARTIAL && u >= QUADS) continue;
         const int x = u / KQ, k = (u % KQ) * 4;
-        l32[(x * PK8 + 16 * swz8(x, k >> 4) + (k & 15)) >> 2] = __float_as_uint(r[4 * q]);
+        l32[(x * PK8 + 16 * swz8(x, k >> 4) + (k & 15)) >> 2] = __float_as_uint(rr[4 * q]);
       }
       return;
     } else if (MODE == SRC_OBSN) {
@@ -531,10 +541,10 @@ struct Stage {
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 v = obs_finish(s, make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]), d_rs[q], d_mean[q], z, z,
+        float4 v = obs_finish(s, make_float4(rr[4 * q], rr[4 * q + 1], rr[4 * q + 2], rr[4 * q + 3]), d_rs[q], d_mean[q], z, z,
                               false);
         if (!KMAJOR && !((vmask >> q) & 1u)) v = z;
-        r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+        rr[4 * q + 0] = v.x; rr[4 * q + 1] = v.y; rr[4 * q + 2] = v.z; rr[4 * q + 3] = v.w;
       }
     }
     if (vec || GATHER) {
@@ -545,10 +555,10 @@ struct Stage {
         if (!KMAJOR) {
           const int x = u / KQ, k = (u % KQ) * 4;
           *reinterpret_cast<float4*>(lds + x * PK + 4 * swz(x, k >> 2)) =
-              make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+              make_float4(rr[4 * q], rr[4 * q + 1], rr[4 * q + 2], rr[4 * q + 3]);
         } else {
           const int k = u / (BX / 4), x = (u % (BX / 4)) * 4;
-          *reinterpret_cast<float4*>(lds + k * LD + x) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+          *reinterpret_cast<float4*>(lds + k * LD + x) = make_float4(rr[4 * q], rr[4 * q + 1], rr[4 * q + 2], rr[4 * q + 3]);
         }
       }
     } else {
@@ -556,8 +566,8 @@ struct Stage {
       for (int q = 0; q < NF; ++q) {
         const int e = tid + q * NT;
         if (PARTIAL && e >= BX * KB) continue;
-        if (!KMAJOR) lds[(e / KB) * PK + 4 * swz(e / KB, (e % KB) >> 2) + (e & 3)] = r[q];
-        else lds[(e / BX) * LD + e % BX] = r[q];
+        if (!KMAJOR) lds[(e / KB) * PK + 4 * swz(e / KB, (e % KB) >> 2) + (e & 3)] = rr[q];
+        else lds[(e / BX) * LD + e % BX] = rr[q];
       }
     }
   }
@@ -689,22 +699,37 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
   long kend_l = kend;
   if (kcur < 0) { kcur = kbeg; kend_l = kbeg; }  // no tap reaches this pixel: one step on an all-zero tile
   long knext = nextk(kcur);
-  long knext2 = B8 && knext >= 0 ? nextk(knext) : -1;  // B8 stages two tiles ahead (Stage::load8)
-  // prologue: the first tile into LDS buffer 0, the second into registers
+  // B2: the B operand is staged TWO tiles ahead, in two register sets chosen by tile parity -- the k-major gathers
+  // whose every k-step touches rows it has never seen (frames of new samples, patches of new pixels): cold lines with
+  // full memory latency, on which the wavefronts stalled with one k-step of lead (skipping those loads altogether
+  // gains 24 % in the first-layer weight gradient and 15 % in the others)
+  constexpr bool B2 = B8 || SB::TWO;
+  auto loadB = [&](auto set_c, long k, long kendx) {
+    constexpr int S = decltype(set_c)::value;
+    if constexpr (B8) sb.template load8<S>(g.b, k, kendx);
+    else sb.template load<S>(g.b, n0, g.N, k, kendx, vb);
+  };
+  auto storeB = [&](auto set_c, float* dst) {
+    constexpr int S = decltype(set_c)::value;
+    if constexpr (B8) sb.template store8<S>(dst);
+    else sb.template store<S>(dst, vb, g.b);
+  };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  long knext2 = B2 && knext >= 0 ? nextk(knext) : -1;
+  // prologue: the first tile into LDS buffer 0, the second (B2: and third) into registers
   sa.load(g.a, m0, g.M, kcur, kend_l, va);
-  if (B8) sb.template load8<0>(g.b, kcur, kend_l);
-  else sb.load(g.b, n0, g.N, kcur, kend_l, vb);
+  loadB(Set0{}, kcur, kend_l);
   cs_acc();
   sa.store(lds, va, g.a);
-  if (B8) sb.template store8<0>(lds + A_FLOATS);
-  else sb.store(lds + A_FLOATS, vb, g.b);
+  storeB(Set0{}, lds + A_FLOATS);
   __syncthreads();
   if (knext >= 0) {
     sa.load(g.a, m0, g.M, knext, kend, va);
-    if (B8) sb.template load8<1>(g.b, knext, kend);
-    else sb.load(g.b, n0, g.N, knext, kend, vb);
+    if (B2) loadB(Set1{}, knext, kend);
+    else loadB(Set0{}, knext, kend);
   }
-  if (B8 && knext2 >= 0) sb.template load8<0>(g.b, knext2, kend);
+  if (B2 && knext2 >= 0) loadB(Set0{}, knext2, kend);
 
   // one k-step on LDS buffer `cur` (compile-time): MFMAs, with the staging of the following tiles in the middle
   // k1 / k2 / k3: the k of the next steps (-1: none); tile t+1 sits in registers (B8: t+1 and t+2, sets by tile parity)
@@ -811,14 +836,13 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
         if (k1 >= 0) {  // tile t+1: registers -> the other LDS buffer (its readers left at the last barrier)
           cs_acc();
           sa.store(nxt, va, g.a);
-          if (B8) sb.template store8<cur ^ 1>(nxt + A_FLOATS);
-          else sb.store(nxt + A_FLOATS, vb, g.b);
+          storeB(std::integral_constant<int, B2 ? (cur ^ 1) : 0>{}, nxt + A_FLOATS);
         }
         if (k2 >= 0) {  // tile t+2: global -> registers
           sa.load(g.a, m0, g.M, k2, kend, va);
-          if (!B8) sb.load(g.b, n0, g.N, k2, kend, vb);
+          if (!B2) loadB(Set0{}, k2, kend);
         }
-        if (B8 && k3 >= 0) sb.template load8<cur ^ 1>(g.b, k3, kend);  // tile t+3 into the set tile t+1 just left
+        if (B2 && k3 >= 0) loadB(std::integral_constant<int, cur ^ 1>{}, k3, kend);  // tile t+3 into the set t+1 left
       }
       // (no sched_barrier: order-pinning was measured)
 #pragma unroll
@@ -829,15 +853,15 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     }
     __syncthreads();  // tile t+1 is visible; everyone is done reading tile t
   };
-  for (;;) {  // k1 = knext; B8 keeps k2 = knext2 as well (its loads were issued a step earlier)
-    long k2 = B8 ? knext2 : (knext >= 0 ? nextk(knext) : -1);
-    long k3 = B8 && k2 >= 0 ? nextk(k2) : -1;
+  for (;;) {  // k1 = knext; B2 keeps k2 = knext2 as well (its loads were issued a step earlier)
+    long k2 = B2 ? knext2 : (knext >= 0 ? nextk(knext) : -1);
+    long k3 = B2 && k2 >= 0 ? nextk(k2) : -1;
     kstep(std::integral_constant<int, 0>{}, knext, k2, k3);
     if (knext < 0) break;
     knext = k2;
     knext2 = k3;
-    k2 = B8 ? knext2 : (knext >= 0 ? nextk(knext) : -1);
-    k3 = B8 && k2 >= 0 ? nextk(k2) : -1;
+    k2 = B2 ? knext2 : (knext >= 0 ? nextk(knext) : -1);
+    k3 = B2 && k2 >= 0 ? nextk(k2) : -1;
     kstep(std::integral_constant<int, 1>{}, knext, k2, k3);
     if (knext < 0) break;
     knext = k2;
