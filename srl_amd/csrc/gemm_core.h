@@ -241,7 +241,7 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, uint32_t voff
 // fragment read, in registers.  Every element of these operands is consumed by exactly one wavefront, so the arithmetic
 // is the same as normalising at the store, but the LDS traffic of the operand drops fourfold: with 32-wide tiles the
 // float staging of the frames alone took ~2/3 of the LDS bandwidth of a CU.
-template <int BX, bool KMAJOR, int MODE, int NT = 256, int KB = BK, bool U8 = false>
+template <int BX, bool KMAJOR, int MODE, int NT = 256, int KB = BK, bool U8 = false, bool TWO_ = false>
 struct Stage {
   static constexpr int PK8 = KB;       // U8, k-contiguous: row pitch in bytes; 16-byte chunks XOR-swizzled like the float
                                        // tiles (swz8): dword writes and b64 / b128 fragment reads without bank conflicts
@@ -276,7 +276,7 @@ struct Stage {
   // byte tiles below are.  Measured for the k-major patch gathers of the weight gradients (GATHER && KMAJOR && MODE ==
   // SRC_CONV; skipping their loads altogether gains 15 %): 16 more registers, same occupancy, and the step's weight
   // gradients got SLOWER, 6.03 -> 6.22 ms, A/B on one box -- so no float operand uses it.
-  static constexpr bool TWO = false;
+  static constexpr bool TWO = TWO_;
   float r2[TWO ? NF : 1];
   uint32_t voff[NV];                                 // k-invariant byte offset of quad q (kInvalidOff: always zero)
   int yx[(MODE == SRC_DGRAD) ? NV : 1];              // DGRAD: (y << 16) | x of the row
@@ -594,7 +594,10 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
   constexpr bool A8 = OBS8 && AMODE == SRC_OBSN && !AKM;  // uint8 frames as the k-contiguous A (first-layer forward)
   constexpr bool B8 = OBS8 && BMODE == SRC_OBSN && BKM;   // ... as the k-major B (first-layer weight gradient)
   static_assert(!OBS8 || A8 || B8, "OBS8 without a byte-staged operand");
-  using SA = Stage<BM, AKM, AMODE, NT, KB, A8>;
+  // two-deep staging of A (Stage TWO_): measured on the forward convolutions' patch rows (AMODE == SRC_CONV && !AKM),
+  // 5.19 -> 5.27 ms per step -- off, like the k-major patch gathers; only the byte tiles of the frames profit
+  constexpr bool A2 = false;
+  using SA = Stage<BM, AKM, AMODE, NT, KB, A8, A2>;
   using SB = Stage<BN, BKM, BMODE, NT, KB, B8>;
   constexpr int A_FLOATS = SA::TILE, TILE_FLOATS = SA::TILE + SB::TILE;  // multiples of 4: 16-byte aligned
   __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
@@ -716,20 +719,24 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
   };
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, 1>;
-  long knext2 = B2 && knext >= 0 ? nextk(knext) : -1;
-  // prologue: the first tile into LDS buffer 0, the second (B2: and third) into registers
-  sa.load(g.a, m0, g.M, kcur, kend_l, va);
+  auto loadA = [&](auto set_c, long k, long kendx) { sa.template load<decltype(set_c)::value>(g.a, m0, g.M, k, kendx, va); };
+  auto storeA = [&](auto set_c, float* dst) { sa.template store<decltype(set_c)::value>(dst, va, g.a); };
+  long knext2 = (B2 || A2) && knext >= 0 ? nextk(knext) : -1;
+  // prologue: the first tile into LDS buffer 0, the second (two-deep operands: and third) into registers
+  loadA(Set0{}, kcur, kend_l);
   loadB(Set0{}, kcur, kend_l);
   cs_acc();
-  sa.store(lds, va, g.a);
+  storeA(Set0{}, lds);
   storeB(Set0{}, lds + A_FLOATS);
   __syncthreads();
   if (knext >= 0) {
-    sa.load(g.a, m0, g.M, knext, kend, va);
+    if (A2) loadA(Set1{}, knext, kend);
+    else loadA(Set0{}, knext, kend);
     if (B2) loadB(Set1{}, knext, kend);
     else loadB(Set0{}, knext, kend);
   }
   if (B2 && knext2 >= 0) loadB(Set0{}, knext2, kend);
+  if (A2 && knext2 >= 0) loadA(Set0{}, knext2, kend);
 
   // one k-step on LDS buffer `cur` (compile-time): MFMAs, with the staging of the following tiles in the middle
   // k1 / k2 / k3: the k of the next steps (-1: none); tile t+1 sits in registers (B8: t+1 and t+2, sets by tile parity)
@@ -835,14 +842,15 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
       if (kk == KB / 4) {
         if (k1 >= 0) {  // tile t+1: registers -> the other LDS buffer (its readers left at the last barrier)
           cs_acc();
-          sa.store(nxt, va, g.a);
+          storeA(std::integral_constant<int, A2 ? (cur ^ 1) : 0>{}, nxt);
           storeB(std::integral_constant<int, B2 ? (cur ^ 1) : 0>{}, nxt + A_FLOATS);
         }
         if (k2 >= 0) {  // tile t+2: global -> registers
-          sa.load(g.a, m0, g.M, k2, kend, va);
+          if (!A2) loadA(Set0{}, k2, kend);
           if (!B2) loadB(Set0{}, k2, kend);
         }
         if (B2 && k3 >= 0) loadB(std::integral_constant<int, cur ^ 1>{}, k3, kend);  // tile t+3 into the set t+1 left
+        if (A2 && k3 >= 0) loadA(std::integral_constant<int, cur ^ 1>{}, k3, kend);
       }
       // (no sched_barrier: order-pinning was measured)
 #pragma unroll
@@ -854,14 +862,14 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     __syncthreads();  // tile t+1 is visible; everyone is done reading tile t
   };
   for (;;) {  // k1 = knext; B2 keeps k2 = knext2 as well (its loads were issued a step earlier)
-    long k2 = B2 ? knext2 : (knext >= 0 ? nextk(knext) : -1);
-    long k3 = B2 && k2 >= 0 ? nextk(k2) : -1;
+    long k2 = (B2 || A2) ? knext2 : (knext >= 0 ? nextk(knext) : -1);
+    long k3 = (B2 || A2) && k2 >= 0 ? nextk(k2) : -1;
     kstep(std::integral_constant<int, 0>{}, knext, k2, k3);
     if (knext < 0) break;
     knext = k2;
     knext2 = k3;
-    k2 = B2 ? knext2 : (knext >= 0 ? nextk(knext) : -1);
-    k3 = B2 && k2 >= 0 ? nextk(k2) : -1;
+    k2 = (B2 || A2) ? knext2 : (knext >= 0 ? nextk(knext) : -1);
+    k3 = (B2 || A2) && k2 >= 0 ? nextk(k2) : -1;
     kstep(std::integral_constant<int, 1>{}, knext, k2, k3);
     if (knext < 0) break;
     knext = k2;
