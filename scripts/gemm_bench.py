@@ -55,7 +55,8 @@ def conv_cases(n=16384):
         fl = 2.0 * n * OH * OH * Cout * k * k * Cin
         for name, fn in (("fwd", lambda: hip.conv2d_nhwc_fwd(d, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr())),
                          ("wgrad", lambda: hip.conv2d_nhwc_wgrad(d, x.data_ptr(), dz.data_ptr(), gw.data_ptr(), ws.data_ptr())),
-                         ("dgrad", lambda: hip.conv2d_nhwc_dgrad(d, dz.data_ptr(), wt.data_ptr(), x.data_ptr(), 1, dx.data_ptr()))):
+                         ("dgrad", lambda: hip.conv2d_nhwc_dgrad(d, dz.data_ptr(), wt.data_ptr(), x.data_ptr(), 1, dx.data_ptr())),
+                         ("dgrad, no activation mask", lambda: hip.conv2d_nhwc_dgrad(d, dz.data_ptr(), wt.data_ptr(), None, 0, dx.data_ptr()))):
             ms = timeit(fn)
             print(f"conv H={H} Cin={Cin} k={k} s={s} Cout={Cout} {name:6s}: {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF", flush=True)
     # first layer
