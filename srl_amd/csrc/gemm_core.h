@@ -5,11 +5,15 @@
 // wavefront supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; the 32x32 result sits in 16 accumulator
 // registers per lane with col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 //
-// A workgroup of 4 wavefronts (WM x WN) owns a BM x BN output tile and walks K in steps of BK = 16.  Both operand
-// tiles live "k-major" in LDS ([BK][BM+4], [BK][BN+4]) whatever their layout in memory, so the MFMA feed is one
-// conflict-free ds_read_b32 per operand per step.  What varies is how an operand is *staged*:
-//   orientation  k-contiguous (rows = output index; float4 along k, transposed on the LDS store)
-//                k-major      (rows = reduction index; float4 along the output index, ds_write_b128)
+// A workgroup of 4 (or 8) wavefronts (WM x WN) owns a BM x BN output tile and walks K in steps of KB (16; 32 for the
+// byte-staged first-layer kernels).  An operand's *orientation* decides how it is staged and fed:
+//   k-major      (rows = reduction index): LDS [KB][BX + 4], float4 along the output index (ds_write_b128), one
+//                ds_read_b32 per MFMA step;
+//   k-contiguous (rows = output index): LDS [BX][KB] unpadded, 16-byte chunks XOR-swizzled by the row (ds_write_b128
+//                along k as the data comes -- no transposing scalar stores), each lane fetches its KB/2 k-values with
+//                ds_read_b128; MFMA step kk consumes k = (KB/2) * (lane >> 5) + kk, a pairing both operands share.
+//   uint8 frames (SRC_OBSN, flag OBS8) stay bytes in LDS and are widened + normalised after the fragment read.
+// What else varies is the operand's *source*:
 //   source       SRC_PLAIN    a dense row-major matrix
 //                SRC_CONV     rows are convolution patches gathered on the fly from an NHWC activation
 //                SRC_DGRAD    rows are the output-gradient taps that reach one input pixel (zero where none)
@@ -20,9 +24,10 @@
 //
 // Pipeline (measured with scripts/mfma_peak.hip: a wavefront that leaves the MFMA stream to stage a tile idles
 // the matrix pipe, and co-resident workgroups run in phase, so they do not fill the gap for each other): LDS holds
-// two tiles; inside k-step t every wavefront issues half of its MFMAs, writes tile t+1 (already in registers) to
-// the other LDS buffer, issues the global loads of tile t+2, issues the other half of its MFMAs, and meets the
-// single barrier of the step.  No wavefront ever waits on "write LDS -> barrier -> read LDS" with nothing to do.
+// two tiles; inside k-step t every wavefront issues a quarter of its MFMAs, writes tile t+1 (already in registers) to
+// the other LDS buffer, issues the global loads of tile t+2 (t+3 for operands staged two deep), issues the rest of its
+// MFMAs, and meets the single barrier of the step.  No wavefront ever waits on "write LDS -> barrier -> read LDS" with
+// nothing to do.  A data-gradient tile of position-grouped rows skips the k-steps of taps that leave the image.
 #pragma once
 #include "srl_common.h"
 #include <type_traits>
