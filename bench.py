@@ -155,8 +155,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # SRL_BENCH_BACKEND=gloo lets the ranks share one GPU: only for tests/test_gpu_dist.py, which drives this script with
+    # two ranks on a one-GPU box to check the multi-rank control flow (RCCL needs a device per rank)
+    backend = os.environ.get("SRL_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
 
     import srl_amd
     from srl_amd import hip
@@ -165,8 +169,8 @@ def main():
 
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world,
-                                device_id=torch.device(device))
+        kw = dict(device_id=torch.device(device)) if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world, **kw)
     trainer = trainer_api.make(config.Trainer("mappo", args=dict(TRAINER, chunk_rows=args.chunk_rows)),
                                config.Policy("actor-critic", args=POLICY))
     if use_dist:
@@ -195,11 +199,15 @@ def main():
 
     # ---- untimed extra step with per-kernel HIP events (same stream as the launches) -----------------------
     roofline = roofline_gae = breakdown = None
-    if rank == 0 and not args.no_profile:
-        prof = hip.KernelProfile()
-        hip.set_profile(prof)
+    if not args.no_profile:
+        # EVERY rank takes this step (its collectives need all of them); only rank 0 wraps its launches in events
+        prof = hip.KernelProfile() if rank == 0 else None
+        if prof is not None:
+            hip.set_profile(prof)
         trainer.step(sample)
-        hip.set_profile(None)
+        if prof is not None:
+            hip.set_profile(None)
+    if rank == 0 and not args.no_profile:
         summ = prof.summary()
         mm = [v for k, v in summ.items() if k == "gemm" or k.startswith("conv_")]  # every launch of gemm_kernel<...>
         g = dict(calls=sum(v["calls"] for v in mm), ms=sum(v["ms"] for v in mm), work=sum(v["work"] for v in mm))

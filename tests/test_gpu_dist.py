@@ -78,3 +78,26 @@ def test_two_rank_trainer_matches_ddp_semantics():
     osd = onet.state_dict()
     for k, v in res[0]["final"].items():
         assert np.abs(v - osd[k].numpy()).max() <= 3e-5, (k, np.abs(v - osd[k].numpy()).max())
+
+
+def test_bench_script_with_two_ranks():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), except that
+    the two ranks share this box's GPU over gloo: every rank must reach the same collectives in the same order (warm-up,
+    timed steps, the untimed profiled step, the final barrier) and rank 0 must print one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SRL_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--envs-per-gpu", "16", "--rollout-len", "8"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2
+    assert line["config"]["global_envs"] == 32 and line["value"] > 0
+    assert line["roofline"]["bound"] == "mfma" and "cpu_baseline" not in line  # the CPU baseline is N = 1 only
