@@ -101,3 +101,20 @@ def test_bench_script_with_two_ranks():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2
     assert line["config"]["global_envs"] == 32 and line["value"] > 0
     assert line["roofline"]["bound"] == "mfma" and "cpu_baseline" not in line  # the CPU baseline is N = 1 only
+
+
+def test_bench_script_one_rank_over_rccl():
+    """The same script with a real RCCL process group (one rank: all this box can offer): communicator creation, the
+    float64 statistics all-reduces, the asynchronous bucket all-reduces on gradient slices, the barriers."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--envs-per-gpu", "16", "--rollout-len", "8", "--force-dist", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1
