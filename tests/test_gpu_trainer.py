@@ -381,3 +381,28 @@ def test_streamed_rollout_matches_one_piece():
     req_s = policy_api.RolloutRequest(obs=NamedArray(obs=obs[:64]), is_evaluation=np.zeros((64, 1), np.uint8),
                                       on_reset=np.zeros((64, 1), np.uint8))
     assert pol.rollout(req_s).action.x.shape == (64, 1)
+
+
+def test_float32_frames_and_mixed_observation_keys_vs_oracle():
+    """Image observations delivered as float32 (the non-byte staging of the first layer), next to a vector key and an
+    action mask, separate backbones: one trainer step against the CPU oracle."""
+    pargs = dict(obs_dim={"img": (4, 20, 20), "vec": 6}, action_dim=5, hidden_dim=32, num_dense_layers=1, num_rnn_layers=0,
+                 popart=False, layernorm=True, shared_backbone=False, chunk_len=4, seed=12,
+                 cnn_layers=dict(img=[(8, 4, 4, 0, 'zeros'), (16, 3, 1, 0, 'zeros')]))
+    targs = dict(popart=False, optimizer_config=dict(lr=1e-3), max_grad_norm=5.0, chunk_rows=50)
+    trainer = make_trainer(pargs, targs)
+    onet = OracleActorCritic(**pargs)
+    onet.load_state_dict({k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()})
+    oracle = OracleMappo(onet, **{k: v for k, v in targs.items() if k != "chunk_rows"})
+    arrays = synthetic.make_sample_arrays(seed=21, T=10, B=9, obs_spec={"img": ((4, 20, 20), "f32"), "vec": ((6,), "f32")},
+                                          action_dims=5, p_done=0.1, available_action=True)
+    sample = synthetic.to_sample_batch(arrays)
+    res = trainer.step(sample)
+    ostats, oout = oracle.step(arrays)
+    assert close(sample.analyzed_result.ret, oout["ret"], 1e-5)
+    for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
+        assert abs(res.stats[k] - ostats[k]) <= 2e-5 * max(abs(ostats[k]), 1e-2), (k, res.stats[k], ostats[k])
+    sd, osd = trainer.policy.get_checkpoint()["state_dict"], onet.state_dict()
+    for k in sd:
+        d = np.abs(sd[k].numpy() - osd[k].numpy())
+        assert d.max() <= 1e-3 and np.mean(d > 1e-6) < 2e-3, (k, d.max())
