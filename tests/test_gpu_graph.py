@@ -24,6 +24,14 @@ CASES = {
                  layernorm=True, shared_backbone=True, chunk_len=8, seed=3),
             dict(popart=False, optimizer_config=dict(lr=1e-3)),
             dict(T=32, B=6, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.08, policy_state={"hx": (1, 32)})),
+    # convolution encoder on uint8 frames: the first-layer kernels (byte staging, per-position sums zeroed by a
+    # memset node inside the capture) and the grouped data gradient under replay
+    "cnn": (dict(obs_dim={"obs": (4, 84, 84)}, action_dim=6, hidden_dim=64, num_dense_layers=0, num_rnn_layers=0,
+                 popart=False, layernorm=False, shared_backbone=True, seed=5,
+                 cnn_layers=dict(obs=[(32, 8, 4, 0, 'zeros'), (64, 4, 2, 0, 'zeros'), (64, 3, 1, 0, 'zeros')])),
+            dict(popart=False, optimizer_config=dict(lr=5e-4), max_grad_norm=40.0, clip_value=True, value_loss="huber",
+                 value_loss_config=dict(delta=10.0)),
+            dict(T=4, B=3, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.1)),
 }
 
 
