@@ -1,21 +1,33 @@
-#!/usr/bin/env python3
 """Benchmark of the hot path: env-steps/s through the GAE + PPO update (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+    python3 bench.py --gpus N --steps K --warmup W
+    python3 -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], per GPU): Atari-shaped rollouts, 512 envs x 128 steps (+1 bootstrap row),
-uint8 (4,84,84) frames, NatureCNN-512 shared actor-critic, PPO with the reference's Atari preset
-(legacy/experiments/atari.py:952-973).  Weak scaling: N GPUs = N x 512 envs (8 GPUs = configs[2], 4096 envs),
-data parallel with one RCCL all-reduce of the advantage statistics and one of the flat gradient per step.
-A "step" is one full ``trainer.step``: GAE scan + statistics, forward, fused loss fwd/bwd, backward, gradient
-all-reduce, clip + Adam.  The sample is synthetic (no ALE on the box) and RESIDENT IN HBM before the timed
-region; weights are randomly initialised.  value = T * B_global * K / t, t = max over ranks of the K-step wall time.
+Workload = the configuration the metric is quoted on (BASELINE.json configs[2]): Atari-shaped rollouts, **4096 envs x
+128 steps** (+1 bootstrap row) per update, uint8 (4,84,84) frames, NatureCNN-512 shared actor-critic, PPO with the
+reference's Atari preset (legacy/experiments/atari.py:952-973).  STRONG scaling: the global batch is fixed, N GPUs
+take 4096 / N env columns each, data parallel with one RCCL all-reduce of the advantage
+statistics and a bucketed all-reduce of the flat gradient per step.  A "step" is one full ``trainer.step``: GAE scan
++ statistics, forward, fused loss fwd/bwd, backward, gradient all-reduce, clip + Adam.  Synthetic data (no ALE on the
+box), random-init weights.
 
-Extra objects on the JSON line: ``roofline`` (the dominant kernel family: the FP32-MFMA GEMM, timed live with
-HIP events on the launch stream in an extra untimed step), ``roofline_gae`` (the GAE scan against HBM),
-``cpu_baseline`` (the oracle's CPU restatement of the same step on a bounded sample, rank 0, N=1 only).
+``value`` = T * B_global * K / t with the sample RESIDENT IN HBM when the timed region starts (the task's bench
+contract), t = max over ranks of the K-step wall time between barrier + synchronize.  The same update fed from PINNED
+HOST memory -- every leaf's H2D copy inside the timed region, double-buffered on a side stream (SURVEY.md 8d's
+``t_update``; reference api/trainer.py:211-228) -- is measured in the same run and reported as ``from_pinned_host``.
+
+Extra objects on the JSON line: ``roofline`` (dominant kernel family: the matrix-core contractions, timed live with
+HIP events on the launch stream in an extra untimed step), ``roofline_gae`` (the GAE scan against HBM at this batch,
+with t / t_launch_floor, and saturated), ``cpu_baseline`` (the oracle's CPU restatement of the same step on a
+bounded sample, rank 0, N = 1 only).
+
+Profiling recipe (counters in their own passes; the interpreter directly after ``--``):
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-from-host
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
+    python3 scripts/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --steps-in-run 2 --envs 4096 --rollout-len 128 \
+        --chunk-rows 16384 > profiles/r02_hbm_traffic_vN.csv     (writes the matching .json with the configuration)
 """
 import argparse
 import json
@@ -31,7 +43,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0  # HBM3E spec
+GLOBAL_ENVS = 4096  # BASELINE.json metric: "4096 envs x 128 steps"
 
 POLICY = dict(obs_dim={"obs": (4, 84, 84)}, action_dim=6, hidden_dim=512, num_dense_layers=0, num_rnn_layers=0,
               popart=False, layernorm=False, shared_backbone=True, seed=1,
@@ -50,6 +64,24 @@ def device_sample(seed, T, B, device):
     dev = {k: torch.from_numpy(v).to(device) for k, v in arrays.items()}
     dev["obs.obs"] = torch.randint(0, 256, (T + 1, B, 4, 84, 84), dtype=torch.uint8, device=device, generator=gen)
     return synthetic.to_sample_batch(dev)
+
+
+def launch_floor_us(device, reps=400):
+    """Back-to-back launches of an (almost) empty kernel through the same C ABI and stream: the per-launch floor the
+    microsecond kernels are compared with (report t / t_launch_floor)."""
+    from srl_amd import hip
+    x = torch.zeros(4, dtype=torch.float32, device=device)
+    y = torch.zeros(4, dtype=torch.float32, device=device)
+    for _ in range(20):
+        hip.copy2d(x.data_ptr(), 4, y.data_ptr(), 4, 1, 4)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        hip.copy2d(x.data_ptr(), 4, y.data_ptr(), 4, 1, 4)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
 
 
 def gae_microbench(sample, targs, device, reps=200, big_B=None):
@@ -87,51 +119,93 @@ def gae_microbench(sample, targs, device, reps=200, big_B=None):
     return dict(ms=a.elapsed_time(b) / reps, work=19.0 * T * B + 7.0 * B)
 
 
-def cpu_baseline(T, threads):
-    """The oracle's restatement of the same trainer step (torch-CPU, op for op with the reference) on a bounded
-    sample of the same workload."""
+def physical_cores():
+    """Physical cores this process may run on: distinct (package, core) pairs of the CPUs in its affinity mask."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    cores = set()
+    for cpu in allowed:
+        base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+        try:
+            with open(base + "physical_package_id") as f:
+                pkg = f.read().strip()
+            with open(base + "core_id") as f:
+                core = f.read().strip()
+            cores.add((pkg, core))
+        except OSError:
+            cores.add(("?", str(cpu)))
+    return max(1, len(cores)), len(allowed)
+
+
+def _cpu_steps(T, B, threads, budget_s, max_steps):
     from oracle.net import OracleActorCritic
     from oracle.trainer import OracleMappo
     from srl_amd.algorithm.netspec import build_netspec
     from srl_amd.runtime import synthetic
     torch.set_num_threads(threads)
-    B = 8
     _, init = build_netspec(**POLICY)
     net = OracleActorCritic(**POLICY)
     net.load_state_dict({k: v.numpy() for k, v in init.items()})
     tr = OracleMappo(net, **TRAINER)
     arrays = synthetic.make_sample_arrays(seed=0, T=T, B=B, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=1.0 / 800)
-    tr.step(arrays)  # warm-up
-    times = []
-    t_all = time.perf_counter()
-    while len(times) < 2 or (time.perf_counter() - t_all < 10.0 and len(times) < 8):
+    tr.step(arrays)  # warm-up (allocator, thread pool)
+    times, t_all = [], time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_all < budget_s and len(times) < max_steps):
         t0 = time.perf_counter()
         tr.step(arrays)
         times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return dict(value=T * B / med, unit="env-steps/s", cores=threads, kind="port",
-                sample=f"{T}x{B} env-steps of the same Atari-shaped workload, {len(times)} timed steps, "
-                       f"median {med:.3f} s/step")
+    return times
 
 
-def recorded_traffic(kernel_substr):
-    """HBM bytes per step of the kernels whose name contains `kernel_substr`, from the PMC passes committed under
-    profiles/ (FETCH_SIZE and WRITE_SIZE collected in separate `rocprofv3 --pmc` runs of this same script with
-    --steps 1 --warmup 1, FETCH_SIZE x2 per the MI355X guide's gfx950 correction: scripts/hbm_traffic.py).  Counters
-    cannot be read from inside the process, so the line carries the recorded figure and names its source."""
+def cpu_baseline(T):
+    """The oracle's restatement of the same trainer step (torch-CPU, op for op with the reference: float32-widened
+    frames, float64 GAE loop, autograd loss, torch.optim.Adam) on a bounded sample of the same workload, on all
+    physical cores and on one thread.  The per-update cost of this path is linear in the env columns B (every op is
+    per row), so env-steps/s at the reduced B carries over to B = 4096 (whose float32 frames alone, 60 GB, would not
+    fit the sample budget)."""
+    cores, logical = physical_cores()
+    B_all, B_one = 64, 8
+    t_all = _cpu_steps(T, B_all, cores, budget_s=14.0, max_steps=6)
+    t_one = _cpu_steps(T, B_one, 1, budget_s=8.0, max_steps=3)
+    torch.set_num_threads(cores)
+    med, mn = float(np.median(t_all)), float(min(t_all))
+    med1, mn1 = float(np.median(t_one)), float(min(t_one))
+    return dict(value=T * B_all / med, unit="env-steps/s", cores=cores, kind="port", best=T * B_all / mn,
+                logical_cpus=logical,
+                one_thread=dict(value=T * B_one / med1, best=T * B_one / mn1, cores=1,
+                                sample=f"{T}x{B_one} env-steps, {len(t_one)} timed steps, median {med1:.3f} s, min {mn1:.3f} s"),
+                sample=f"{T}x{B_all} env-steps (B reduced from {GLOBAL_ENVS}: the path is row-independent, cost linear "
+                       f"in B) of the same Atari-shaped workload and seeds, {len(t_all)} timed steps on {cores} threads "
+                       f"(= physical cores of the affinity mask; {logical} logical), median {med:.3f} s, min {mn:.3f} s")
+
+
+def recorded_traffic(kernel_substr, envs, T, chunk_rows):
+    """HBM bytes per step of the kernels whose name contains `kernel_substr`, from the newest PMC passes committed
+    under profiles/ (FETCH_SIZE and WRITE_SIZE in separate `rocprofv3 --pmc` runs of this script, FETCH_SIZE x2 per
+    the MI355X guide's gfx950 correction: scripts/hbm_traffic.py, which records the run's configuration next to the
+    table).  Counters cannot be read from inside the process, so the line carries the recorded figure and names its
+    source -- and only when that recording was made at THIS run's configuration; otherwise traffic is null."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_hbm_traffic_v*.csv")),
-                   key=lambda f: int(f.rsplit("_v", 1)[1].split(".")[0]))
-    if not files:
-        return dict(traffic=None)
-    total, steps_in_run = 0.0, 2  # warm-up step + timed step
-    for r in csv.DictReader(open(files[-1])):
-        if kernel_substr in r["kernel"]:
-            per_launch = float(r["FETCH_bytes_per_launch_corrected_x2"]) + float(r["WRITE_bytes_per_launch"])
-            total += per_launch * float(r["dispatches"]) / steps_in_run
-    return dict(traffic=round(total), traffic_unit="HBM bytes per step (fetch + write) over the same launches",
-                traffic_source=os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__))))
+    here = os.path.dirname(os.path.abspath(__file__))
+    metas = sorted(glob.glob(os.path.join(here, "profiles", "r*_hbm_traffic_v*.json")),
+                   key=lambda f: (int(os.path.basename(f)[1:3]), int(f.rsplit("_v", 1)[1].split(".")[0])))
+    for mf in reversed(metas):
+        with open(mf) as f:
+            meta = json.load(f)
+        if (meta.get("envs"), meta.get("rollout_len"), meta.get("chunk_rows")) != (envs, T, chunk_rows):
+            continue
+        total = 0.0
+        with open(mf[:-5] + ".csv") as f:
+            for r in csv.DictReader(f):
+                if kernel_substr in r["kernel"]:
+                    per_launch = float(r["FETCH_bytes_per_launch_corrected_x2"]) + float(r["WRITE_bytes_per_launch"])
+                    total += per_launch * float(r["dispatches"]) / meta["steps_in_run"]
+        return dict(traffic=round(total), traffic_unit="HBM bytes per step (fetch + write) over the same launches",
+                    traffic_source=os.path.relpath(mf[:-5] + ".csv", here), traffic_commit=meta.get("commit"))
+    return dict(traffic=None, traffic_note="no PMC recording under profiles/ at this configuration")
 
 
 def main():
@@ -139,21 +213,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--envs-per-gpu", type=int, default=512)
+    ap.add_argument("--global-envs", type=int, default=GLOBAL_ENVS, help="B_global, fixed as N grows (strong scaling)")
     ap.add_argument("--rollout-len", type=int, default=128)
     ap.add_argument("--chunk-rows", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-from-host", action="store_true", help="skip the pinned-host-fed pass (`from_pinned_host`)")
+    ap.add_argument("--from-host-steps", type=int, default=6)
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank")
-    ap.add_argument("--from-host", action="store_true",
-                    help="also time the step fed from the pinned ingest ring (H2D of every leaf inside the timed region, "
-                         "overlapped with the previous update); reported as `pcie_inclusive`, never as `value`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert args.global_envs % world == 0, "the global batch must split evenly over the ranks"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
     # SRL_BENCH_BACKEND=gloo lets the ranks share one GPU: only for tests/test_gpu_dist.py, which drives this script with
     # two ranks on a one-GPU box to check the multi-rank control flow (RCCL needs a device per rank)
@@ -168,15 +242,21 @@ def main():
     srl_amd.register_all()
 
     use_dist = world > 1 or args.force_dist
+    ranks_seen = 1
     if use_dist:
         kw = dict(device_id=torch.device(device)) if backend == "nccl" else {}
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world, **kw)
+        assert dist.get_world_size() == args.gpus, f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}"
+        seen = torch.ones(1, dtype=torch.float32, device=device)
+        dist.all_reduce(seen)  # every rank contributes 1 through the collective backend itself
+        ranks_seen = int(round(float(seen.item())))
+        assert ranks_seen == args.gpus, f"collective saw {ranks_seen} ranks, --gpus {args.gpus}"
     trainer = trainer_api.make(config.Trainer("mappo", args=dict(TRAINER, chunk_rows=args.chunk_rows)),
                                config.Policy("actor-critic", args=POLICY))
     if use_dist:
         trainer.distributed(rank=rank, world_size=world, init_method="env://")
 
-    T, B = args.rollout_len, args.envs_per_gpu
+    T, B = args.rollout_len, args.global_envs // world
     sample = device_sample(1000 + rank, T, B, device)
 
     def sync():
@@ -184,18 +264,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.step(sample)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = trainer.step(sample)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(fn, warmup, steps):
+        for _ in range(warmup):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        sync()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, r
+
+    elapsed, res = timed(lambda: trainer.step(sample), args.warmup, args.steps)
 
     # ---- untimed extra step with per-kernel HIP events (same stream as the launches) -----------------------
     roofline = roofline_gae = breakdown = None
@@ -209,72 +293,95 @@ def main():
             hip.set_profile(None)
     if rank == 0 and not args.no_profile:
         summ = prof.summary()
-        mm = [v for k, v in summ.items() if k == "gemm" or k.startswith("conv_")]  # every launch of gemm_kernel<...>
+        mm = [v for k, v in summ.items() if k == "gemm" or k.startswith("conv_")]  # every matrix-core launch group
         g = dict(calls=sum(v["calls"] for v in mm), ms=sum(v["ms"] for v in mm), work=sum(v["work"] for v in mm))
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12
-        roofline = dict(kernel="gemm_kernel<...> (v_mfma_f32_32x32x2_f32): dense + implicit-conv launches of one step",
+        roofline = dict(kernel="gemm_kernel<...> family (dense + implicit-conv launches of one step; f32 results)",
                         bound="mfma", achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), launches=g["calls"],
-                        ms_per_step=round(g["ms"], 3), flops_per_step=g["work"], **recorded_traffic("gemm_kernel"))
-        # the scan is a ~microsecond kernel: time it as 200 back-to-back launches between two events on the launch
+                        ms_per_step=round(g["ms"], 3), flops_per_step=g["work"],
+                        flops_per_env_step=g["work"] / (T * B),
+                        **recorded_traffic("gemm_kernel", B, T, args.chunk_rows))
+        # the scan is a ~microsecond kernel: time it as back-to-back launches between two events on the launch
         # stream so that host enqueue latency does not sit inside the interval
+        floor = launch_floor_us(device)
         s = gae_microbench(sample, TRAINER, device)
         gbs = s["work"] / (s["ms"] * 1e-3) / 1e9
         big = gae_microbench(sample, TRAINER, device, reps=30, big_B=1 << 20)
         big_gbs = big["work"] / (big["ms"] * 1e-3) / 1e9
         roofline_gae = dict(kernel="gae_scan_reg_kernel", bound="hbm", achieved=round(gbs, 2), peak=PEAK_HBM_GBS,
-                            unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 5), traffic=None,
+                            unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 5), traffic=None, envs=B, rollout_len=T,
                             us_per_launch=round(s["ms"] * 1e3, 2), algorithmic_bytes=s["work"],
-                            note="this step's own [T, 512] leaves: launch-latency bound, see 'saturated'",
+                            launch_floor_us=round(floor, 2), t_over_launch_floor=round(s["ms"] * 1e3 / floor, 2),
+                            note=f"this step's own [T, {B}] leaves: {s['work'] / 1e6:.1f} MB, launch-latency bound "
+                                 "(t / t_launch_floor), see 'saturated' for the HBM-bound size",
                             saturated=dict(envs=1 << 20, rollout_len=T, achieved=round(big_gbs, 1),
                                            frac=round(big_gbs / PEAK_HBM_GBS, 4),
                                            us_per_launch=round(big["ms"] * 1e3, 1), algorithmic_bytes=big["work"]))
         breakdown = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
 
+    # ---- the same update fed from pinned host memory: every leaf's H2D inside the timed region ------------------------
     pcie = None
-    if args.from_host and world == 1:
+    if not args.no_from_host:
         from srl_amd.namedarray import recursive_apply
         from srl_amd.runtime.ingest import SampleRing
-        host = recursive_apply(sample, lambda x: x.cpu().numpy())
-        ring = SampleRing(host[:, 0], batch_size=B, slots=2, device=device)
+        template = recursive_apply(sample[:, 0], lambda x: x.cpu().numpy())
+        ring = SampleRing(template, batch_size=B, slots=2, device=device)
         for _ in range(2):
-            ring.put_batch(host)
-        del host
+            ring.put_batch(sample)  # device leaves -> the slot's pinned blocks (D2H, untimed)
+        del sample
+        torch.cuda.empty_cache()
 
         def fed_step():
-            b = ring.get_device()
+            b = ring.get_device()  # waits (stream-side) on this batch's copies, starts the next batch's
             r = trainer.step(b)
             slot = b.metadata["ring_slot"]
             ring.release(slot)
             ring.recycle(slot)
             return r
 
-        for _ in range(args.warmup):
-            fed_step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fed_step()
-        sync()
-        el = time.perf_counter() - t0
-        pcie = dict(value=T * B * args.steps / el, unit="env-steps/s", ms_per_step=1e3 * el / args.steps,
-                    host_bytes_per_step=ring.nbytes() // 2,
-                    note="sample in the pinned ingest ring; async H2D of every leaf on a side stream, double-buffered")
+        el, _ = timed(fed_step, 2, args.from_host_steps)
+        host_bytes = ring.nbytes() // 2
+        ms = 1e3 * el / args.from_host_steps
+        h2d_ms = None
+        if rank == 0:  # the copy alone, same ring, nothing else running
+            b = ring.get_device()
+            slot = b.metadata["ring_slot"]
+            ring.release(slot)
+            ring.recycle(slot)
+            torch.cuda.synchronize()
+            b2 = None
+            t0 = time.perf_counter()
+            b2 = ring.get_device()
+            torch.cuda.synchronize()
+            h2d_ms = 1e3 * (time.perf_counter() - t0)
+            ring.release(b2.metadata["ring_slot"])
+        pcie = dict(value=T * B * world * args.from_host_steps / el, unit="env-steps/s", ms_per_step=ms,
+                    steps=args.from_host_steps, host_bytes_per_step_per_gpu=host_bytes, h2d_alone_ms=h2d_ms,
+                    h2d_alone_GBps=None if not h2d_ms else round(host_bytes / h2d_ms / 1e6, 1),
+                    note="SURVEY 8d t_update: sample in the pinned ingest ring ([Tb,B] namedarray layout, wire dtypes); "
+                         "async H2D of every leaf on a side stream inside the timed region, double-buffered so that the "
+                         "copy of update k+1 runs under the compute of update k")
 
     if rank == 0:
         steps_total = T * B * world * args.steps
-        line = dict(metric="env-steps/sec through GAE+PPO update", value=steps_total / elapsed, unit="env-steps/s",
-                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
-                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                    config=dict(workload=f"Atari-shaped PPO+GAE, {B} envs x {T} steps per GPU (BASELINE configs[1]; "
-                                         f"x{world} GPUs data-parallel), NatureCNN-512, uint8 (4,84,84) frames",
+        ms_step = 1e3 * elapsed / args.steps
+        line = dict(metric=f"env-steps/sec through GAE+PPO update, {B * world} envs x {T} steps", value=steps_total / elapsed,
+                    unit="env-steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_step,
+                    higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
+                    value_basis="sample resident in HBM when the timed region starts; see from_pinned_host for H2D inside",
+                    config=dict(workload=f"BASELINE configs[2]: Atari-shaped PPO+GAE, {B * world} envs x {T} steps per update "
+                                         f"(global batch fixed; {B} env columns per GPU x {world} GPUs data-parallel), "
+                                         "NatureCNN-512, uint8 (4,84,84) frames, Atari PPO preset",
                                 envs_per_gpu=B, rollout_len=T, global_envs=B * world, parallelism=f"dp{world}",
-                                chunk_rows=args.chunk_rows, policy_loss=res.stats.get("policy_loss")),
+                                chunk_rows=args.chunk_rows, collective_ranks=ranks_seen,
+                                policy_loss=res.stats.get("policy_loss")),
                     roofline=roofline, roofline_gae=roofline_gae, kernel_ms_per_step=breakdown)
         if pcie is not None:
-            line["pcie_inclusive"] = pcie
+            pcie["bound"] = ("pcie" if pcie["h2d_alone_ms"] and pcie["h2d_alone_ms"] > ms_step else "mfma")
+            line["from_pinned_host"] = pcie
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(T, threads=min(os.cpu_count() or 1, 32))
+            line["cpu_baseline"] = cpu_baseline(T)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 2
+#define SRL_HIP_ABI_VERSION 3
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -54,13 +54,23 @@ int srl_device_info(int* num_cus, int* lds_bytes_per_cu, char* name, int name_le
  *
  * reward [>=T, B, Nc] (rows 0..T-1 read), value [T+1, B, Nc], done/truncated/on_reset [T+1, B, 1],
  * imp_ratio [T, B, 1] or NULL; adv, ret [>=T, B, Nc] (rows 0..T-1 written; the caller provides the
- * zero row T that mappo.py:254-256 pads).  stats: float64[3] or NULL; it is zeroed by this call
- * and then accumulated with float64 atomics (order-dependent in the last bit of the float64 sums).
+ * zero row T that mappo.py:254-256 pads).
+ * gamma_t / lambda_t: per-step discount / lambda tensors [T, B, 1] float32 (widened to float64 like
+ * gae.py:51-60) or NULL, in which case the scalar `gamma` / `lambda` (a double, like the reference's
+ * python float) is used.
+ * stats: float64[3] or NULL.  With workspace == NULL it is zeroed by this call (one memset launch)
+ * and accumulated with float64 atomics (order-dependent in the last bit).  With a workspace of
+ * srl_gae_scan_workspace_bytes(B, Nc) bytes -- zeroed ONCE by the caller, then owned by this entry
+ * point; one workspace per stream that may run it concurrently -- the workgroups leave partial sums
+ * there and the last one to finish adds them in a fixed order and overwrites stats: no extra launch,
+ * bitwise reproducible sums.
  */
 int srl_gae_scan(void* stream, const float* reward, const float* value, const uint8_t* done,
-                 const uint8_t* truncated, const uint8_t* on_reset, const float* imp_ratio, int T, int B,
-                 int Nc, double gamma, double lambda, double rho, double c, float* adv, float* ret,
-                 double* stats);
+                 const uint8_t* truncated, const uint8_t* on_reset, const float* imp_ratio,
+                 const float* gamma_t, const float* lambda_t, int T, int B, int Nc, double gamma,
+                 double lambda, double rho, double c, float* adv, float* ret, double* stats,
+                 void* workspace);
+long srl_gae_scan_workspace_bytes(int B, int Nc);
 
 /* Masked statistics {n, sum x*mask, sum (x*mask)^2} in float64 (utils.py:38-57).
  * mask: uint8[n] or NULL (no mask: n = count); mask_invert != 0 means mask = 1 - byte
@@ -375,6 +385,36 @@ int srl_adam_step(void* stream, float* p, const float* g, float* m, float* v, in
                   float beta2, float eps, float weight_decay, int adamw, int64_t step, float grad_scale,
                   float max_norm, const double* sumsq, float* grad_norm_out,
                   const float* step_scalars);
+
+/* ------------------------------------------------------------------------------------------------
+ * Collectives (RCCL over xGMI), one process per GPU.  `comm` is an ncclComm_t behind void*; every
+ * call is enqueued on `stream` and returns at once (stream-ordered like the kernels above).  librccl
+ * is resolved with dlopen at first use (-ENOSYS if absent).
+ *
+ * Bootstrap: one rank calls srl_comm_unique_id and hands the SRL_COMM_ID_BYTES bytes to the others by
+ * any side channel (the Python mirror broadcasts them through the process group the reference already
+ * forms in `trainer.distributed`, api/trainer.py:113-128); every rank then calls srl_comm_init with its
+ * rank, on the device it owns.
+ *
+ * srl_allreduce_stats_f64x3: in-place SUM of `count` float64 values.  Replaces the three all_reduce
+ *   calls of masked_normalization (legacy/algorithm/modules/utils.py:58-61; count = 3: n, sum, sumsq)
+ *   and of RunningMeanStd.update (utils.py:121-124; count = 3 * value_dim) with one message each.
+ * srl_allreduce_grads: in-place SUM of n float32 gradients (a bucket of the flat gradient buffer).
+ *   Replaces DistributedDataParallel's bucketed all-reduce (api/policy.py:219-238); the mean over
+ *   ranks is the grad_scale of srl_adam_step.
+ * srl_broadcast_params: `nbytes` bytes from rank `root` to all (the flat float32 parameter buffer,
+ *   PopArt float64 statistics, the int64 version).  Replaces the DDP constructor's parameter
+ *   broadcast (same lines) and the parameter-server push / pull between trainer and policy workers
+ *   (distributed/system/parameter_db.py:250-324) for replicas on the node.
+ */
+#define SRL_COMM_ID_BYTES 128
+int srl_comm_unique_id(void* id_out);
+int srl_comm_init(void** comm_out, const void* id, int rank, int world);
+int srl_comm_world(void* comm, int* world_out);
+int srl_comm_destroy(void* comm);
+int srl_allreduce_stats_f64x3(void* stream, void* comm, double* stats, int count);
+int srl_allreduce_grads(void* stream, void* comm, float* grad, int64_t n);
+int srl_broadcast_params(void* stream, void* comm, void* buf, int64_t nbytes, int root);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """BASELINE configs[4] at its per-GPU size (Google Football 11v11: 2048 envs x 200 steps over 8 GPUs = 256 envs per
 GPU): the `football-smm-separate` preset with an LSTM (CNN + LSTM policy on stacked (4, 96, 72) uint8 super-mini-map
 frames, separate actor / critic backbones, PopArt), synthetic data.  676 M parameters (the preset's default

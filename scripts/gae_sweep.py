@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """GAE scan kernel: time per launch and achieved algorithmic GB/s over a sweep of batch sizes (T = 128)."""
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Micro-benchmark of srl_gemm / implicit conv entry points (TFLOP/s per shape and orientation)."""
 import os
 import sys

@@ -1,13 +1,32 @@
-#!/usr/bin/env python3
 """HBM bytes per launch per kernel from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, separate runs).
 
-FETCH_SIZE / WRITE_SIZE count kilobytes; on gfx950 FETCH_SIZE is reported per 32-byte... the MI355X guide's
-correction is x2 on FETCH_SIZE (WRITE_SIZE as is).  usage: hbm_traffic.py <fetch_dir> <write_dir> > out.csv
+FETCH_SIZE / WRITE_SIZE count kilobytes; the MI355X guide's gfx950 correction is x2 on FETCH_SIZE (WRITE_SIZE as is).
+
+    python3 scripts/hbm_traffic.py <fetch_dir> <write_dir> --steps-in-run 2 --envs 4096 --rollout-len 128 \
+        --chunk-rows 16384 --out profiles/r02_hbm_traffic_v1.csv
+
+writes the table and, next to it, ``<out>.json`` with the configuration of the profiled run (bench.py only quotes a
+recording made at its own configuration).  The passes themselves (interpreter directly after ``--``):
+
+    rocprofv3 --pmc FETCH_SIZE -d <fetch_dir> -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
+    rocprofv3 --pmc WRITE_SIZE -d <write_dir> -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
 """
+import argparse
 import csv
 import glob
-import sys
+import json
+import subprocess
 from collections import defaultdict
+
+ap = argparse.ArgumentParser()
+ap.add_argument("fetch_dir")
+ap.add_argument("write_dir")
+ap.add_argument("--steps-in-run", type=int, default=2, help="trainer steps the profiled command ran (warm-up + timed)")
+ap.add_argument("--envs", type=int, default=4096)
+ap.add_argument("--rollout-len", type=int, default=128)
+ap.add_argument("--chunk-rows", type=int, default=16384)
+ap.add_argument("--out", required=True)
+args = ap.parse_args()
 
 
 def collect(d, counter):
@@ -19,12 +38,22 @@ def collect(d, counter):
     return acc
 
 
-fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-w = csv.writer(sys.stdout)
-w.writerow(["kernel", "dispatches", "FETCH_SIZE_KB_per_launch_raw", "FETCH_bytes_per_launch_corrected_x2",
-            "WRITE_SIZE_KB_per_launch", "WRITE_bytes_per_launch"])
-for k, v in sorted(fetch.items(), key=lambda kv: -sum(kv[1])):
-    f = sum(v) / len(v)
-    wr = write.get(k, [0.0])
-    wv = sum(wr) / len(wr)
-    w.writerow([k, len(v), round(f), round(f * 1024 * 2), round(wv), round(wv * 1024)])
+fetch, write = collect(args.fetch_dir, "FETCH_SIZE"), collect(args.write_dir, "WRITE_SIZE")
+with open(args.out, "w", newline="") as fh:
+    w = csv.writer(fh)
+    w.writerow(["kernel", "dispatches", "FETCH_SIZE_KB_per_launch_raw", "FETCH_bytes_per_launch_corrected_x2",
+                "WRITE_SIZE_KB_per_launch", "WRITE_bytes_per_launch"])
+    for k, v in sorted(fetch.items(), key=lambda kv: -sum(kv[1])):
+        f = sum(v) / len(v)
+        wr = write.get(k, [0.0])
+        wv = sum(wr) / len(wr)
+        w.writerow([k, len(v), round(f), round(f * 1024 * 2), round(wv), round(wv * 1024)])
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except OSError:
+    commit = None
+meta = dict(envs=args.envs, rollout_len=args.rollout_len, chunk_rows=args.chunk_rows, steps_in_run=args.steps_in_run,
+            commit=commit, command="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 "
+                                   "--no-cpu-baseline --no-from-host --no-profile")
+with open(args.out[:-4] + ".json", "w") as fh:
+    json.dump(meta, fh, indent=1)

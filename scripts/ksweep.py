@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Time of a tall plain GEMM (M rows, N in {32, 64}) against K: the intercept is the per-tile fixed cost (prologue +
 epilogue), the slope the steady-state k-loop."""
 import os

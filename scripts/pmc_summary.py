@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc counter_collection.csv files per kernel name (mean per dispatch)."""
 import csv
 import glob

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """BASELINE configs[3] (SMAC 3m MAPPO): 1024 shared environments x 3 agents, T = 100, the `smac_rnn` policy (separate
 LSTM-64 actor / critic over 30- / 48-dim vectors, 9 masked actions, dead-agent masking, PopArt) on
 [Tb, B, agents, ...] samples.  Synthetic data; prints agent-steps/s through the GAE+PPO update and the per-kernel

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Secondary metric of SURVEY.md 8(d): rollout-inference requests/s (a10 `ActorCriticPolicy.rollout`, a11 batcher).
 
 One request = one observation (Atari: 4x84x84 uint8) in, (action, log-prob, value) out, host numpy on both sides

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """BASELINE configs[0] shapes (CartPole: 8 envs x 32 steps, separate 2x64 MLP): one trainer step is ~70 tiny
 launches -- this measures how launch-bound it is (ms per step, launches per step, summed kernel time)."""
 import os

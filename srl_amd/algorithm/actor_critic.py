@@ -215,6 +215,9 @@ class ActorCriticPolicy(policy_api.Policy):
         """One flat buffer, one broadcast (RCCL over xGMI on GPU ranks; also what inference replicas call to
         receive fresh parameters from the trainer, replacing the reference's filesystem push/pull)."""
         dist.broadcast(self._net.flat, src=src, group=group)
+        if self.spec.popart:  # the float64 running statistics are (gradient-less) parameters of the reference's module
+            # and travel with them in the DDP constructor's broadcast (api/policy.py:219-238, popart.py:8-59)
+            dist.broadcast(self._net.popart_state, src=src, group=group)
         v = torch.tensor([self._version], dtype=torch.int64, device=self._net.flat.device)
         dist.broadcast(v, src=src, group=group)
         self._version = int(v.item())
@@ -268,7 +271,9 @@ class ActorCriticPolicy(policy_api.Policy):
             a = np.asarray(v)
             if a.dtype == np.bool_:
                 a = a.view(np.uint8)
-            if k != "available_action" and a.dtype != np.uint8 and a.dtype != np.float32:
+            if k == "available_action" and a.dtype != np.uint8:
+                a = a.astype(np.uint8)  # converted on the host: no side-stream temporary inside _rollout_rows
+            elif k != "available_action" and a.dtype != np.uint8 and a.dtype != np.float32:
                 a = a.astype(np.float32)
             arrays[k] = np.ascontiguousarray(a)
         step = self.ROLLOUT_PIECE
@@ -301,6 +306,8 @@ class ActorCriticPolicy(policy_api.Policy):
     def _rollout_rows(self, obs, n, is_evaluation, state):
         """One inference pass over ``n`` independent rows: device ``(action, log_prob [n,1], value [n,vd])``; the new
         recurrent states are left in ``net.last_state``.  ``state``: ``{key: [n, layers, W]}`` host or device, or None."""
+        obs = dict(obs)  # the caller keeps its dict whole: a streamed piece must still own EVERY staged tensor (the mask
+        # included) when it hands them to the main stream with record_stream
         avail = obs.pop("available_action", None)
         if avail is not None and avail.dtype != torch.uint8:
             avail = avail.to(torch.uint8)

@@ -49,9 +49,10 @@ class _BucketReducer:
     its own stream while the compute stream continues with the earlier layers); `finish` launches what is left and
     makes the compute stream wait.  Sum over ranks; the mean is folded into the Adam kernel."""
 
-    def __init__(self, net, bucket_bytes):
+    def __init__(self, net, bucket_bytes, comm=None):
         self.net = net
-        self.buckets = []  # [lo, hi, set of pending parameter prefixes]
+        self.comm = comm  # srl_amd.comm.NativeComm (RCCL through the C ABI on a side stream) or None (torch.distributed)
+        self.buckets = []  # [lo, hi, frozenset of the parameter prefixes inside]
         lo, pending, size = None, set(), 0
         for name, info in net.spec.params.items():
             prefix = name.rsplit(".", 1)[0]
@@ -70,25 +71,37 @@ class _BucketReducer:
                 lo, pending, size = None, set(), 0
         if lo is not None:
             self.buckets.append([lo, net.spec.total_params, pending])
+        self.buckets = [(lo, hi, frozenset(p)) for lo, hi, p in self.buckets]
+        self.begin()
+
+    def begin(self):
+        """Start of an epoch's backward pass: nothing launched, every parameter pending.  (The bucket layout is
+        built once per trainer; only this per-epoch state is reset.)"""
+        self.pending = [set(b[2]) for b in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.works = []
 
     def _launch(self, i):
         lo, hi, _ = self.buckets[i]
-        self.works.append(dist.all_reduce(self.net.grad[lo:hi], async_op=True))
+        if self.comm is not None:
+            self.comm.all_reduce_f32_async(self.net.grad[lo:hi])
+        else:
+            self.works.append(dist.all_reduce(self.net.grad[lo:hi], async_op=True))
         self.launched[i] = True
 
     def ready(self, prefixes):
-        for i, b in enumerate(self.buckets):
-            if not self.launched[i] and b[2]:
-                b[2].difference_update(prefixes)
-                if not b[2]:
+        for i, pend in enumerate(self.pending):
+            if not self.launched[i] and pend:
+                pend.difference_update(prefixes)
+                if not pend:
                     self._launch(i)
 
     def finish(self):
         for i in range(len(self.buckets)):
             if not self.launched[i]:
                 self._launch(i)
+        if self.comm is not None:
+            self.comm.join()  # the compute stream waits for the side stream's collectives
         for w in self.works:
             w.wait()
 
@@ -165,6 +178,9 @@ class MultiAgentPPO(PytorchTrainer):
         self.grad_bucket_bytes = int(g("grad_bucket_bytes", 1 << 20))
         self.use_graph = bool(g("use_graph", False))
         self._graphs = {}
+        self._comm = None
+        self._reducer = None
+        self._gae_ws = {}
 
     # ------------------------------------------------------------------ checkpoints (mappo.py:58-66)
     def get_checkpoint(self):
@@ -207,6 +223,11 @@ class MultiAgentPPO(PytorchTrainer):
         super().distributed(rank=rank, world_size=world_size, init_method=init_method, **kwargs)
         self._world = dist.get_world_size() if dist.is_initialized() else 1
         self._dist = dist.is_initialized()  # collectives run whenever a group exists (also with one rank)
+        self._comm = None
+        if self._dist and self.policy.device != "cpu" and dist.get_backend() == "nccl":
+            from srl_amd import comm
+            self._comm = comm.NativeComm.from_process_group(self.policy.device)  # None: torch.distributed collectives
+        self._reducer = _BucketReducer(self.policy.net, self.grad_bucket_bytes, self._comm) if self._dist else None
 
     def _importance_ratio(self, net, obs, avail, action, old_lp, rows, B, alive=None):
         """exp(new_lp - old_lp) on rows [0, rows) of the sample, forward only, row-chunked; [rows, B, 1] float32."""
@@ -379,7 +400,10 @@ class MultiAgentPPO(PytorchTrainer):
         n_valid = (hi - lo) * B
         Nc = 1
         f64 = dict(dtype=torch.float64, device=dev)
-        stats_local = torch.zeros(3, **f64)
+        # step-persistent device state lives in the net's workspace: nothing below allocates in steady state
+        stats_local = net.ws.get("mappo.stats_local", 3, torch.float64)[:3]
+        stats_global = net.ws.get("mappo.stats_global", 3, torch.float64)[:3]
+        stats_work = None  # pending all-reduce of stats_global (joined right before its first reader)
         adv_d = ret_d = None
         epoch_terms = []
 
@@ -390,22 +414,34 @@ class MultiAgentPPO(PytorchTrainer):
                     adv_d, ret_d = L["adv"], L["ret"]
                     fused_stats = False
                 else:
-                    adv_d = torch.zeros((Tb, B, Nc), dtype=torch.float32, device=dev)  # last row = the zero pad (:254-256)
-                    ret_d = torch.zeros((Tb, B, Nc), dtype=torch.float32, device=dev)
+                    adv_d = net.ws.get("mappo.adv", Tb * B * Nc)[:Tb * B * Nc].view(Tb, B, Nc)
+                    ret_d = net.ws.get("mappo.ret", Tb * B * Nc)[:Tb * B * Nc].view(Tb, B, Nc)
+                    adv_d[Tb - 1:].zero_()  # the scan writes rows [0, Tb-1); the last row is the zero pad (:254-256)
+                    ret_d[Tb - 1:].zero_()
                     fused_stats = boot == 1 and burn == 0
+                    gws = self._gae_ws.get((B, Nc))
+                    if gws is None:  # zeroed once; afterwards the scan's own last workgroup resets it
+                        gws = self._gae_ws[(B, Nc)] = hip.gae_scan_workspace(B, Nc, dev)
                     # PopArt: the stored values are normalised; the trace runs on de-normalised ones (mappo.py:120-124)
                     trace_value = self.policy.denormalize_value(old_value) if self.popart else old_value
                     ratio = None
                     if self.vtrace:  # importance ratio of the CURRENT parameters on every rewarding step (:130-133)
                         ratio = self._importance_ratio(net, obs, avail, action, old_lp, Tb - 1, B, alive)
                     hip.gae_scan(reward, trace_value, done, truncated, on_reset, self.discount_rate, self.gae_lambda,
-                                 adv_d, ret_d, stats=stats_local if fused_stats else None, imp_ratio=ratio)
+                                 adv_d, ret_d, stats=stats_local if fused_stats else None, imp_ratio=ratio,
+                                 workspace=gws if fused_stats else None)
                 mask_rows = on_reset[1 + lo:1 + hi]  # loss_mask = 1 - on_reset[1+burn : 1+Tb-boot]  (:260-261)
                 if not fused_stats:
                     hip.masked_stats(adv_d[lo:hi], mask_rows, stats_local, mask_invert=True)
-                stats_global = stats_local.clone()
+                stats_global.copy_(stats_local)
                 if self._dist:
-                    dist.all_reduce(stats_global)  # one 24-byte message instead of three
+                    # one 24-byte message instead of three (utils.py:58-61), issued asynchronously: it crosses the
+                    # links while the first chunk's forward pass runs and is joined before the first loss kernel
+                    if self._comm is not None:
+                        self._comm.all_reduce_f64_async(stats_global)
+                        stats_work = self._comm
+                    else:
+                        stats_work = dist.all_reduce(stats_global, async_op=True)
                 local_n = stats_local[0:1]
 
             flat = lambda t: t[lo:hi].reshape(n_valid, *t.shape[2:])
@@ -436,8 +472,12 @@ class MultiAgentPPO(PytorchTrainer):
                 rnn = self.policy._rnn_ctx_with_burn_in(obs, None, pstate, on_reset, burn, hi - lo, B)
             chunk_rows = n_valid if rnn is not None else self.chunk_rows
             nchunks = max(1, -(-n_valid // chunk_rows))
-            terms = torch.zeros((nchunks, hip.LT_COUNT), **f64)
-            reducer = _BucketReducer(net, self.grad_bucket_bytes) if self._dist else None
+            terms = net.ws.get("mappo.terms", nchunks * hip.LT_COUNT, torch.float64)[:nchunks * hip.LT_COUNT]
+            terms = terms.view(nchunks, hip.LT_COUNT)
+            terms.zero_()
+            reducer = self._reducer if self._dist else None
+            if reducer is not None:
+                reducer.begin()
             for ci in range(nchunks):
                 r0, r1 = ci * chunk_rows, min(n_valid, (ci + 1) * chunk_rows)
                 n = r1 - r0
@@ -453,6 +493,9 @@ class MultiAgentPPO(PytorchTrainer):
                 d_lp = net.ws.get("d_logp", n)[:n]
                 d_v = net.ws.get("d_value", n)[:n]
                 d_ent = net.ws.get("d_entropy", n)[:n]
+                if stats_work is not None:  # the global advantage statistics: first needed here
+                    stats_work.join() if stats_work is self._comm else stats_work.wait()
+                    stats_work = None
                 hip.ppo_loss_fwd_bwd(logp, f_oldlp[r0:r1], value.reshape(-1), f_oldv[r0:r1], f_adv[r0:r1], f_ret[r0:r1],
                                      ent, f_mask[r0:r1], self._hp, stats_global, local_n, d_lp, d_v, d_ent, terms[ci],
                                      done=f_done[r0:r1], truncated=f_trunc[r0:r1])
@@ -464,8 +507,8 @@ class MultiAgentPPO(PytorchTrainer):
             if reducer is not None:  # the buckets not yet launched, then wait for all of them
                 net.grad_ready_hook = None
                 reducer.finish()
-            sumsq = torch.zeros(1, **f64)
-            gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+            sumsq = net.ws.get("mappo.sumsq", 1, torch.float64)[:1]  # zeroed by srl_grad_sumsq
+            gnorm = net.ws.get("mappo.gnorm", self.ppo_epochs)[epoch:epoch + 1]
             hip.grad_sumsq(net.grad, sumsq)
             hip.adam_step(net.flat, net.grad, self._m, self._v, self._lr, self._betas[0], self._betas[1], self._eps,
                           self._weight_decay, self._adamw, self._opt_steps + epoch + 1, grad_scale=1.0 / self._world,

@@ -26,18 +26,70 @@ struct GaeParams {
   const uint8_t* truncated;
   const uint8_t* on_reset;
   const float* ratio;
+  const float* gamma_t;   // per-step discount [T, B, 1] or null (gae.py:51-55)
+  const float* lambda_t;  // per-step lambda [T, B, 1] or null (gae.py:56-60)
   float* adv;
   float* ret;
   double* stats;
   int T, B, Nc, TT;
   double gamma, lambda, rho, c;
+  void* ws;  // null: stats zeroed by a memset and accumulated with atomics; else see stats_finish()
 };
+
+// ---- the three advantage sums without a zeroing launch and without float64 atomics ---------------------------------
+// workspace = { uint32 ticket, pad, double partial[grid][3] }.  Every workgroup stores its partial sums, releases
+// them (agent scope) and takes a ticket; the workgroup that draws the last ticket acquires, adds the partials up in
+// workgroup order -- so the result does not depend on which workgroup finished when: bitwise reproducible -- writes
+// stats[0..2] and puts the ticket back to zero for the next launch.  The caller zeroes the workspace once.
+struct StatsWs {
+  unsigned int ticket;
+  unsigned int pad;
+  double partial[1];
+};
+
+__device__ __forceinline__ void stats_finish(const GaeParams& p, double (&acc)[3], double* red) {
+  if (p.stats == nullptr) return;
+  __syncthreads();
+  block_sum<3, 256>(acc, red);
+  if (p.ws == nullptr) {
+    if (threadIdx.x == 0) {
+      atomicAdd(&p.stats[0], acc[0]);
+      atomicAdd(&p.stats[1], acc[1]);
+      atomicAdd(&p.stats[2], acc[2]);
+    }
+    return;
+  }
+  StatsWs* ws = static_cast<StatsWs*>(p.ws);
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    double* mine = ws->partial + 3 * (size_t)blockIdx.x;
+    mine[0] = acc[0], mine[1] = acc[1], mine[2] = acc[2];
+    __threadfence();  // release: the partials are visible device-wide before the ticket is
+    const unsigned int t = atomicAdd(&ws->ticket, 1u);
+    is_last = t == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();  // acquire
+  double tot[3] = {0.0, 0.0, 0.0};
+  for (unsigned int b = threadIdx.x; b < gridDim.x; b += 256) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      tot[i] += __hip_atomic_load(ws->partial + 3 * (size_t)b + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();  // `red` was read by thread 0 above
+  block_sum<3, 256>(tot, red);
+  if (threadIdx.x == 0) {
+    p.stats[0] = tot[0], p.stats[1] = tot[1], p.stats[2] = tot[2];
+    __hip_atomic_store(&ws->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 // LDS carve (dynamic, 16-byte aligned pieces):
 //   double segM[SEG*COLS], segD[SEG*COLS], carry[COLS], red[4*3]
 //   float  r[TT*COLS], v[(TT+1)*COLS], (ratio[TT*COLS])
 //   uint8  tr[(TT+1)*COLS], orr[(TT+1)*COLS]
-template <int COLS, bool VTRACE>
+template <int COLS, bool VTRACE, bool GLT>
 __global__ __launch_bounds__(256) void gae_scan_kernel(GaeParams p) {
   constexpr int SEG = 256 / COLS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -48,7 +100,9 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(GaeParams p) {
   float* s_r = reinterpret_cast<float*>(red + 12);
   float* s_v = s_r + p.TT * COLS;
   float* s_q = s_v + (p.TT + 1) * COLS;  // ratio (only when VTRACE)
-  uint8_t* s_tr = reinterpret_cast<uint8_t*>(s_q + (VTRACE ? p.TT * COLS : 0));
+  float* s_g = s_q + (VTRACE ? p.TT * COLS : 0);  // per-step gamma, lambda (only when GLT)
+  float* s_l = s_g + (GLT ? p.TT * COLS : 0);
+  uint8_t* s_tr = reinterpret_cast<uint8_t*>(s_l + (GLT ? p.TT * COLS : 0));
   uint8_t* s_or = s_tr + (p.TT + 1) * COLS;
 
   const int tid = threadIdx.x;
@@ -86,6 +140,10 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(GaeParams p) {
       if (r < len) {
         s_r[r * COLS + lc] = col_ok ? p.reward[t * ncols + col] : 0.f;
         if (VTRACE) s_q[r * COLS + lc] = col_ok ? p.ratio[t * p.B + fcol] : 1.f;
+        if (GLT) {
+          s_g[r * COLS + lc] = col_ok && p.gamma_t ? p.gamma_t[t * p.B + fcol] : (float)p.gamma;
+          s_l[r * COLS + lc] = col_ok && p.lambda_t ? p.lambda_t[t * p.B + fcol] : (float)p.lambda;
+        }
       }
     }
     __syncthreads();
@@ -99,8 +157,11 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(GaeParams p) {
       const double v1 = (double)s_v[(r + 1) * COLS + lc];
       const double nr = 1.0 - (double)s_or[(r + 1) * COLS + lc];
       const double nt = 1.0 - (double)s_tr[(r + 1) * COLS + lc];
-      delta = (double)s_r[r * COLS + lc] + p.gamma * v1 * nr - v0;  // gae.py:63
-      m = gl * nr * nt;                                             // gae.py:87
+      // per-step tensors are float32 widened to float64 (gae.py:54,59); a scalar stays the caller's double
+      const double gam = GLT && p.gamma_t ? (double)s_g[r * COLS + lc] : p.gamma;
+      const double lam = GLT && p.lambda_t ? (double)s_l[r * COLS + lc] : p.lambda;
+      delta = (double)s_r[r * COLS + lc] + gam * v1 * nr - v0;  // gae.py:63
+      m = (GLT ? gam * lam : gl) * nr * nt;                      // gae.py:87
       if (VTRACE) {
         const double q = (double)s_q[r * COLS + lc];
         delta *= fmin(q, p.rho);  // gae.py:65
@@ -144,40 +205,38 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(GaeParams p) {
     if (seg == 0) carry[lc] = g_tile_out;
   }
 
-  if (p.stats != nullptr) {
-    __syncthreads();
-    block_sum<3, 256>(acc, red);
-    if (tid == 0) {
-      atomicAdd(&p.stats[0], acc[0]);
-      atomicAdd(&p.stats[1], acc[1]);
-      atomicAdd(&p.stats[2], acc[2]);
-    }
-  }
+  stats_finish(p, acc, red);
 }
 
 template <int COLS>
-size_t gae_lds_bytes(int TT, bool vtrace) {
+size_t gae_lds_bytes(int TT, bool vtrace, bool glt) {
   constexpr int SEG = 256 / COLS;
   size_t b = sizeof(double) * (2 * SEG * COLS + COLS + 12);
-  b += sizeof(float) * ((size_t)TT * COLS + (size_t)(TT + 1) * COLS + (vtrace ? (size_t)TT * COLS : 0));
+  b += sizeof(float) * ((size_t)TT * COLS + (size_t)(TT + 1) * COLS + (vtrace ? (size_t)TT * COLS : 0) +
+                        (glt ? 2 * (size_t)TT * COLS : 0));
   b += 2 * (size_t)(TT + 1) * COLS;
   return (b + 15) & ~size_t(15);
 }
 
 template <int COLS>
 int launch_gae(hipStream_t st, GaeParams p, bool vtrace) {
+  const bool glt = p.gamma_t != nullptr || p.lambda_t != nullptr;
   // largest time tile that keeps the LDS tile under ~60 KiB (>= 2 workgroups per CU)
   const size_t budget = 60 * 1024;
   int TT = p.T;
-  while (TT > 8 && gae_lds_bytes<COLS>(TT, vtrace) > budget) TT = (TT + 1) / 2;
+  while (TT > 8 && gae_lds_bytes<COLS>(TT, vtrace, glt) > budget) TT = (TT + 1) / 2;
   p.TT = TT;
-  const size_t lds = gae_lds_bytes<COLS>(TT, vtrace);
+  const size_t lds = gae_lds_bytes<COLS>(TT, vtrace, glt);
   const long ncols = (long)p.B * p.Nc;
   dim3 grid((unsigned)srl_ceil_div(ncols, COLS));
-  if (vtrace)
-    hipLaunchKernelGGL((gae_scan_kernel<COLS, true>), grid, dim3(256), lds, st, p);
+  if (vtrace && glt)
+    hipLaunchKernelGGL((gae_scan_kernel<COLS, true, true>), grid, dim3(256), lds, st, p);
+  else if (vtrace)
+    hipLaunchKernelGGL((gae_scan_kernel<COLS, true, false>), grid, dim3(256), lds, st, p);
+  else if (glt)
+    hipLaunchKernelGGL((gae_scan_kernel<COLS, false, true>), grid, dim3(256), lds, st, p);
   else
-    hipLaunchKernelGGL((gae_scan_kernel<COLS, false>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gae_scan_kernel<COLS, false, false>), grid, dim3(256), lds, st, p);
   SRL_LAUNCH_CHECK();
   return 0;
 }
@@ -337,15 +396,7 @@ __global__ __launch_bounds__(256) void gae_scan_reg_kernel(GaeParams p) {
     }
   }
 
-  if (p.stats != nullptr) {
-    __syncthreads();
-    block_sum<3, 256>(acc, red);
-    if (tid == 0) {
-      atomicAdd(&p.stats[0], acc[0]);
-      atomicAdd(&p.stats[1], acc[1]);
-      atomicAdd(&p.stats[2], acc[2]);
-    }
-  }
+  stats_finish(p, acc, red);
 }
 
 template <int CQ, int L>
@@ -408,19 +459,29 @@ __global__ __launch_bounds__(256) void masked_normalize_kernel(const float* x, c
 
 }  // namespace
 
+// widest grid any of the tilings above launches: one workgroup per 16 columns
+static long gae_max_grid(long B, long Nc) { return srl_ceil_div(B * Nc, 16); }
+
+extern "C" long srl_gae_scan_workspace_bytes(int B, int Nc) {
+  if (B < 0 || Nc < 1) return -EINVAL;
+  return (long)(16 + 24 * gae_max_grid(B, Nc));
+}
+
 extern "C" int srl_gae_scan(void* stream, const float* reward, const float* value, const uint8_t* done,
-                            const uint8_t* truncated, const uint8_t* on_reset, const float* imp_ratio, int T, int B,
-                            int Nc, double gamma, double lambda, double rho, double c, float* adv, float* ret,
-                            double* stats) {
+                            const uint8_t* truncated, const uint8_t* on_reset, const float* imp_ratio,
+                            const float* gamma_t, const float* lambda_t, int T, int B, int Nc, double gamma,
+                            double lambda, double rho, double c, float* adv, float* ret, double* stats,
+                            void* workspace) {
   SRL_CHECK_ARG(T >= 0 && B >= 0 && Nc >= 1, "T, B >= 0 and Nc >= 1 required");
   hipStream_t st = (hipStream_t)stream;
-  if (stats) SRL_HIP_TRY(hipMemsetAsync(stats, 0, 3 * sizeof(double), st));
+  SRL_CHECK_ARG(!workspace || aligned_to(workspace, 8), "workspace must be 8-byte aligned");
+  if (stats && (!workspace || T == 0 || B == 0)) SRL_HIP_TRY(hipMemsetAsync(stats, 0, 3 * sizeof(double), st));
   if (T == 0 || B == 0) return 0;  // empty batch: nothing to scan (tensors may be null)
   SRL_CHECK_ARG(reward && value && done && truncated && on_reset && adv && ret, "null tensor");
-  GaeParams p{reward, value, done, truncated, on_reset, imp_ratio, adv, ret, stats, T, B, Nc, 0,
-              gamma,  lambda, rho,  c};
+  GaeParams p{reward, value, done, truncated, on_reset, imp_ratio, gamma_t, lambda_t, adv, ret, stats, T, B, Nc, 0,
+              gamma,  lambda, rho,  c, stats ? workspace : nullptr};
   const long ncols = (long)B * Nc;
-  const bool quads = Nc == 1 && B % 4 == 0 && aligned_to(reward, 16) && aligned_to(value, 16) &&
+  const bool quads = Nc == 1 && B % 4 == 0 && !gamma_t && !lambda_t && aligned_to(reward, 16) && aligned_to(value, 16) &&
                      aligned_to(adv, 16) && aligned_to(ret, 16) && aligned_to(done, 4) &&
                      aligned_to(truncated, 4) && aligned_to(on_reset, 4) && (!imp_ratio || aligned_to(imp_ratio, 16));
   if (quads) {

@@ -16,7 +16,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsrlhip.so")
 _lib = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -68,8 +68,9 @@ _SIGNATURES = {
     "srl_abi_version": (c_int, []),
     "srl_last_error": (c_char_p, []),
     "srl_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
-    "srl_gae_scan": (c_int, [c_void_p] + [c_void_p] * 6 + [c_int, c_int, c_int, c_double, c_double, c_double,
-                                                             c_double, c_void_p, c_void_p, c_void_p]),
+    "srl_gae_scan": (c_int, [c_void_p] + [c_void_p] * 8 + [c_int, c_int, c_int, c_double, c_double, c_double,
+                                                             c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srl_gae_scan_workspace_bytes": (c_long, [c_int, c_int]),
     "srl_masked_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "srl_masked_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_double, c_int,
                                       c_void_p]),
@@ -116,6 +117,13 @@ _SIGNATURES = {
     "srl_grad_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                c_float, c_float, c_int, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "srl_comm_unique_id": (c_int, [c_void_p]),
+    "srl_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
+    "srl_comm_world": (c_int, [c_void_p, POINTER(c_int)]),
+    "srl_comm_destroy": (c_int, [c_void_p]),
+    "srl_allreduce_stats_f64x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    "srl_allreduce_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
+    "srl_broadcast_params": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -225,21 +233,43 @@ def device_info():
     return dict(num_cus=n.value, lds_bytes_per_cu=l.value, arch=buf.value.decode())
 
 
+def gae_scan_workspace(B, Nc, device) -> torch.Tensor:
+    """Zeroed workspace for ``gae_scan(..., workspace=)``: statistics without a memset launch or float64 atomics."""
+    n = int(lib().srl_gae_scan_workspace_bytes(int(B), int(Nc)))
+    if n < 0:
+        raise HipError("srl_gae_scan_workspace_bytes: invalid argument")
+    return torch.zeros((n + 7) // 8, dtype=torch.int64, device=device)
+
+
 def gae_scan(reward, value, done, truncated, on_reset, gamma, lmbda, adv, ret, stats=None, imp_ratio=None, rho=1.0,
-             c=1.0):
-    """reward [>=T,B,Nc] f32, value/done/truncated/on_reset [T+1,B,*]; writes adv/ret rows [0,T); stats f64[3]."""
+             c=1.0, workspace=None):
+    """reward [>=T,B,Nc] f32, value/done/truncated/on_reset [T+1,B,*]; writes adv/ret rows [0,T); stats f64[3].
+    ``gamma`` / ``lmbda``: python floats or float32 device tensors [T, B, 1] (reference gae.py:51-60)."""
     Tp1, B = on_reset.shape[0], on_reset.shape[1]
     T = Tp1 - 1
     Nc = value.shape[2] if value.dim() > 2 else 1
     assert value.shape[0] == Tp1 and reward.shape[0] >= T and adv.shape[0] >= T and ret.shape[0] >= T
+    gamma_t = lambda_t = None
+    if isinstance(gamma, torch.Tensor):
+        if tuple(gamma.shape) != (T, B, 1):
+            raise HipError(f"gamma tensor: expected shape {(T, B, 1)}, got {tuple(gamma.shape)}")  # gae.py:53
+        gamma_t, gamma = gamma, 0.0
+    if isinstance(lmbda, torch.Tensor):
+        if tuple(lmbda.shape) != (T, B, 1):
+            raise HipError(f"lmbda tensor: expected shape {(T, B, 1)}, got {tuple(lmbda.shape)}")  # gae.py:58
+        lambda_t, lmbda = lmbda, 0.0
+    if workspace is not None and workspace.numel() * workspace.element_size() < lib().srl_gae_scan_workspace_bytes(B, Nc):
+        raise HipError("gae_scan: workspace too small for this batch")
     # algorithmic bytes (SURVEY.md 8d): r,v f32 + 3 flag bytes in, adv,ret f32 out = 19 B per env-step (+ bootstrap row)
     with _scope("gae_scan", 19.0 * T * B * Nc + 7.0 * B * Nc):
       _check(
         lib().srl_gae_scan(_stream(), _ptr(reward, torch.float32, "reward"), _ptr(value, torch.float32, "value"),
                            _ptr(done, torch.uint8, "done"), _ptr(truncated, torch.uint8, "truncated"),
-                           _ptr(on_reset, torch.uint8, "on_reset"), _ptr(imp_ratio, torch.float32, "imp_ratio"), T, B,
+                           _ptr(on_reset, torch.uint8, "on_reset"), _ptr(imp_ratio, torch.float32, "imp_ratio"),
+                           _ptr(gamma_t, torch.float32, "gamma"), _ptr(lambda_t, torch.float32, "lmbda"), T, B,
                            Nc, float(gamma), float(lmbda), float(rho), float(c), _ptr(adv, torch.float32, "adv"),
-                           _ptr(ret, torch.float32, "ret"), _ptr(stats, torch.float64, "stats")), "srl_gae_scan")
+                           _ptr(ret, torch.float32, "ret"), _ptr(stats, torch.float64, "stats"),
+                           _ptr(workspace, None, "workspace")), "srl_gae_scan")
 
 
 def masked_stats(x, mask, stats, mask_invert=False):

@@ -68,6 +68,9 @@ class SampleRing:
         self._full = deque()
         self._filling: Optional[int] = None
         self._count = 0
+        # columns whose write has FINISHED, per slot: a slot is published only when all of them have (a slot whose
+        # last column was merely claimed may still have other threads writing theirs)
+        self._written = [0] * self.slots
 
     # ------------------------------------------------------------------ introspection
     def block_specs(self) -> Dict[str, Tuple[Tuple[int, ...], str]]:
@@ -82,9 +85,24 @@ class SampleRing:
             return len(self._full)
 
     # ------------------------------------------------------------------ producer side
-    def _claim(self) -> Tuple[int, int]:
-        """(slot, column) for the next trajectory; raises when every slot is full and unreleased."""
+    def _commit(self, slot: int, columns: int = 1) -> Optional[int]:
+        """Called after a column's write has finished; the writer of the last column to finish publishes the slot."""
         with self._lock:
+            self._written[slot] += columns
+            if self._written[slot] == self.batch_size:
+                self._written[slot] = 0
+                self._full.append(slot)
+                if slot == self._filling:
+                    self._filling = None
+                return slot
+        return None
+
+    def _claim(self) -> Tuple[int, int]:
+        """(slot, column) for the next trajectory; raises when every slot is full and unreleased.  Once every column
+        of the slot being filled is claimed the next claim opens a new slot, whether or not the writers are done."""
+        with self._lock:
+            if self._filling is not None and self._count == self.batch_size:
+                self._filling = None
             if self._filling is None:
                 if not self._free:
                     raise BufferError("sample ring is full: release a slot (trainer is behind the actors)")
@@ -93,14 +111,6 @@ class SampleRing:
             slot, col = self._filling, self._count
             self._count += 1
             return slot, col
-
-    def _commit(self, slot: int) -> Optional[int]:
-        with self._lock:
-            if slot == self._filling and self._count == self.batch_size:
-                self._full.append(slot)
-                self._filling = None
-                return slot
-        return None
 
     def put_column(self, traj) -> Optional[int]:
         """Write one trajectory (leaves ``[Tb, ...]``) into the next column; returns the slot id when that
@@ -119,18 +129,14 @@ class SampleRing:
         ``np.frombuffer`` (no copy) and written straight into its column."""
         if not na.is_raw_bytes(chunks):
             return self.put_column(na.loads(chunks))
+        leaves = [(k, arr) for k, arr in na.iter_raw_leaves(chunks) if arr is not None]  # zero-copy views
+        keys = {k for k, _ in leaves}
+        if keys != set(self._np[0]):  # before a column is claimed: a bad message must not leave a hole in the slot
+            raise KeyError(f"wire trajectory keys differ from the ring's: {sorted(keys ^ set(self._np[0]))}")
         slot, col = self._claim()
         blk = self._np[slot]
-        seen = 0
-        for k, arr in na.iter_raw_leaves(chunks):
-            if arr is None:
-                continue
-            if k not in blk:
-                raise KeyError(f"wire leaf `{k}` is not in the ring")
+        for k, arr in leaves:
             blk[k][:, col] = arr
-            seen += 1
-        if seen != len(blk):
-            raise KeyError("wire trajectory lacks some of the ring's leaves")
         return self._commit(slot)
 
     def put_batch(self, batch) -> int:
@@ -139,16 +145,21 @@ class SampleRing:
         if set(leaves) != set(self._np[0]):
             raise KeyError(f"batch keys differ from the ring's: {sorted(set(leaves) ^ set(self._np[0]))}")
         with self._lock:
-            if self._filling is not None and self._count:
+            if self._filling is not None and 0 < self._count < self.batch_size:
                 raise BufferError("a slot is being filled column by column")
+            if self._filling is not None and self._count == self.batch_size:
+                self._filling = None
             if self._filling is None:
                 if not self._free:
                     raise BufferError("sample ring is full: release a slot (trainer is behind the actors)")
                 self._filling = self._free.popleft()
             slot, self._count = self._filling, self.batch_size
         for k, dst in self._np[slot].items():
-            dst[...] = leaves[k]
-        return self._commit(slot)
+            if isinstance(leaves[k], torch.Tensor):  # device-resident batch: D2H straight into the pinned block
+                self._host[slot][k].copy_(leaves[k])
+            else:
+                dst[...] = leaves[k]
+        return self._commit(slot, self.batch_size)
 
     def recycle(self, slot: int):
         """Benchmarks: make a released slot complete again with the data it still holds (no host pass)."""

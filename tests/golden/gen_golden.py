@@ -138,6 +138,41 @@ def gen_gae():
     save("gae.npz", **out)
 
 
+def gen_gae_tensor():
+    """G1, tensor-valued discount / lambda ([T, B, 1] float32 tensors, gae.py:51-60): both tensors, only gamma, only
+    lambda (the other a python float), with and without V-trace, one and three value channels."""
+    out, names = {}, []
+    for name, T, B, Nc, p, seed in [("tsmall", 32, 8, 1, 0.05, 31), ("tmid", 129, 36, 1, 0.03, 32), ("tnc3", 24, 8, 3, 0.1, 33)]:
+        arr = synthetic.make_sample_arrays(seed=seed, T=T, B=B, obs_spec={}, action_dims=2, p_done=p, value_dim=Nc)
+        f = lambda k: torch.from_numpy(arr[k]).float()
+        v_masked = f("analyzed_result.value") * (1 - f("done"))
+        rng = np.random.default_rng(seed)
+        gam = rng.uniform(0.9, 1.0, size=(T, B, 1)).astype(np.float32)
+        lam = rng.uniform(0.5, 1.0, size=(T, B, 1)).astype(np.float32)
+        ratio = np.exp(0.3 * rng.standard_normal((T, B, 1))).astype(np.float32)
+        ratio[arr["truncated"][:-1] == 1] = 1.0
+        for tag, g, l in [("gl", gam, lam), ("g", gam, 0.95), ("l", 0.99, lam)]:
+            tg = torch.from_numpy(g) if isinstance(g, np.ndarray) else g
+            tl = torch.from_numpy(l) if isinstance(l, np.ndarray) else l
+            adv = modules.gae_trace(f("reward")[:-1], v_masked, f("truncated"), f("done"), f("on_reset"), gamma=tg, lmbda=tl)
+            o_adv = ogae.gae_trace(arr["reward"][:-1], v_masked.numpy(), arr["truncated"], arr["done"], arr["on_reset"], g, l)
+            assert np.array_equal(o_adv, adv.numpy()), (name, tag)
+            out[f"{name}_{tag}_adv"] = adv.numpy()
+        adv_v = modules.gae_trace(f("reward")[:-1], v_masked, f("truncated"), f("done"), f("on_reset"),
+                                  gamma=torch.from_numpy(gam), lmbda=torch.from_numpy(lam), vtrace=True,
+                                  imp_ratio=torch.from_numpy(ratio), rho=1.0, c=1.0)
+        o_adv_v = ogae.gae_trace(arr["reward"][:-1], v_masked.numpy(), arr["truncated"], arr["done"], arr["on_reset"], gam, lam,
+                                 vtrace=True, imp_ratio=ratio)
+        assert np.array_equal(o_adv_v, adv_v.numpy()), name
+        out[f"{name}_vtrace_adv"] = adv_v.numpy()
+        out[f"{name}_gamma"], out[f"{name}_lambda"], out[f"{name}_ratio"] = gam, lam, ratio
+        for k in ["reward", "analyzed_result.value", "done", "truncated", "on_reset"]:
+            out[f"{name}_{k.split('.')[-1]}"] = arr[k]
+        names.append(name)
+    out["cases"] = np.array(names)
+    save("gae_tensor.npz", **out)
+
+
 # ------------------------------------------------------------------------------------------------ G3
 def gen_norm():
     rng = np.random.default_rng(3)

@@ -27,14 +27,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_arrays(step, rank, world):
+def _rank_arrays(step, rank, world, unequal=False):
     from srl_amd.runtime import synthetic
+    if unequal:  # rank 1's environments reset ~15x as often: the ranks' loss masks hold very different counts
+        return synthetic.make_sample_arrays(seed=90 + 10 * step + rank, T=T, B=B // world, obs_spec=synthetic.CARTPOLE_OBS,
+                                            action_dims=3, p_done=0.02 if rank == 0 else 0.3)
     full = synthetic.make_sample_arrays(seed=50 + step, T=T, B=B, obs_spec=synthetic.CARTPOLE_OBS, action_dims=3, p_done=0.1)
     half = B // world
     return {k: np.ascontiguousarray(v[:, rank * half:(rank + 1) * half]) for k, v in full.items()}
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, unequal=False):
     import srl_amd
     from srl_amd.api import config, trainer as trainer_api
     from srl_amd.runtime import synthetic
@@ -47,7 +50,7 @@ def _worker(rank, world, port, out):
         init = {k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()}
         stats = []
         for step in range(STEPS):
-            res = trainer.step(synthetic.to_sample_batch(_rank_arrays(step, rank, world)))
+            res = trainer.step(synthetic.to_sample_batch(_rank_arrays(step, rank, world, unequal)))
             stats.append(res.stats)
         final = {k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()}
         out[rank] = dict(init=init, final=final, stats=stats)
@@ -55,13 +58,20 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_rank_trainer_matches_ddp_semantics():
+@pytest.mark.parametrize("unequal", [False, True], ids=["split-batch", "unequal-mask-counts"])
+def test_two_rank_trainer_matches_ddp_semantics(unequal):
+    """`unequal`: the ranks' masks hold very different counts.  Reference semantics (mappo.py:184,197,199 under DDP): each
+    rank divides its masked sums by its LOCAL count, the gradients are then averaged over ranks with equal weight, while the
+    advantage normalisation uses the GLOBAL statistics -- not a global masked mean of the loss."""
     from oracle.net import OracleActorCritic
     from oracle.trainer import OracleMappo
     world = 2
+    if unequal:
+        counts = [int((1 - _rank_arrays(0, r, world, True)["on_reset"][1:]).sum()) for r in range(world)]
+        assert counts[0] > 1.15 * counts[1], counts
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), out, unequal), nprocs=world, join=True)
         res = {r: out[r] for r in range(world)}
     for k in res[0]["init"]:  # both ranks start from rank 0's parameters and stay identical
         assert np.array_equal(res[0]["init"][k], res[1]["init"][k]), k
@@ -70,7 +80,7 @@ def test_two_rank_trainer_matches_ddp_semantics():
     onet.load_state_dict(res[0]["init"])
     oracle = OracleMappo(onet, **{k: v for k, v in TRAINER.items() if k not in ("grad_bucket_bytes", "chunk_rows")})
     for step in range(STEPS):
-        ostats, _ = oracle.step_dp([_rank_arrays(step, r, world) for r in range(world)])
+        ostats, _ = oracle.step_dp([_rank_arrays(step, r, world, unequal) for r in range(world)])
         for r in range(world):
             got = res[r]["stats"][step]
             for k in ("policy_loss", "value_loss", "entropy", "grad_norm", "importance_weight", "clip_ratio", "denorm_value"):
@@ -92,14 +102,15 @@ def test_bench_script_with_two_ranks():
     env = dict(os.environ, SRL_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--envs-per-gpu", "16", "--rollout-len", "8"]
+           "--global-envs", "32", "--rollout-len", "8", "--from-host-steps", "2"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2
-    assert line["config"]["global_envs"] == 32 and line["value"] > 0
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2
+    assert line["config"]["global_envs"] == 32 and line["config"]["envs_per_gpu"] == 16 and line["value"] > 0
+    assert line["config"]["collective_ranks"] == 2 and line["from_pinned_host"]["value"] > 0
     assert line["roofline"]["bound"] == "mfma" and "cpu_baseline" not in line  # the CPU baseline is N = 1 only
 
 
@@ -113,8 +124,46 @@ def test_bench_script_one_rank_over_rccl():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--envs-per-gpu", "16", "--rollout-len", "8", "--force-dist", "--no-cpu-baseline"]
+           "--global-envs", "16", "--rollout-len", "8", "--force-dist", "--no-cpu-baseline", "--from-host-steps", "2"]
     out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1
+    assert json.loads(lines[0])["config"]["collective_ranks"] == 1
+
+
+def _native_comm_worker(rank, world, port, out):
+    """One rank over RCCL (all a one-GPU box can offer): the C-ABI collectives on their side stream."""
+    import srl_amd
+    from srl_amd import comm
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            device_id=torch.device("cuda:0"))
+    try:
+        c = comm.NativeComm.from_process_group("cuda:0")
+        assert c is not None and c.world == world
+        stats = torch.tensor([3.0, 1.5, 2.25], dtype=torch.float64, device="cuda:0")
+        grads = torch.arange(100000, dtype=torch.float32, device="cuda:0")
+        flat = torch.full((777,), 2.5, dtype=torch.float32, device="cuda:0")
+        c.all_reduce_f64_async(stats)
+        c.all_reduce_f32_async(grads[:50000])
+        c.all_reduce_f32_async(grads[50000:])
+        c.broadcast_async(flat, root=0)
+        c.join()
+        torch.cuda.synchronize()
+        out[rank] = (stats.tolist(), float(grads.sum()), float(flat.sum()))
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_rccl_wrappers_one_rank():
+    """srl_comm_* / srl_allreduce_stats_f64x3 / srl_allreduce_grads / srl_broadcast_params through a real RCCL communicator
+    bootstrapped from the process group (world size 1 leaves the data unchanged)."""
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_native_comm_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+        stats, gsum, fsum = out[0]
+    assert stats == [3.0, 1.5, 2.25]
+    assert gsum == float(np.arange(100000, dtype=np.float32).astype(np.float64).sum()) or abs(gsum - 4999950000.0) < 1e4
+    assert fsum == 777 * 2.5

@@ -1,5 +1,7 @@
-"""BASELINE.json configs[1] at FULL size (512 envs x 128 steps, uint8 (4,84,84) frames, NatureCNN-512): the oracle
-cannot run this in seconds, so parity is checked through size-independent properties of the path."""
+"""BASELINE.json configs at FULL size -- [1] 512 envs x 128 steps and [2] 4096 envs x 128 steps (uint8 (4,84,84) frames,
+NatureCNN-512), [3] SMAC 3m 1024 x 3 agents x 100 steps, [4] football 256 envs (per GPU) x 200 steps CNN + LSTM: the
+oracle's network cannot run these in seconds, so parity is checked through size-independent properties of the path
+(chunking invariance, repeatability, linearity) plus the numpy oracle where it is cheap (GAE returns, statistics)."""
 import numpy as np
 import pytest
 import torch
@@ -21,12 +23,29 @@ TRAINER = dict(discount_rate=0.99, gae_lambda=0.97, eps_clip=0.2, clip_value=Tru
 T, B = 128, 512
 
 
-def device_sample(seed):
-    arr = synthetic.make_sample_arrays(seed=seed, T=T, B=B, obs_spec={}, action_dims=6, p_done=1.0 / 800)
+def device_sample(seed, b=B, frame=(4, 84, 84), t=T, actions=6, p_done=1.0 / 800, **kw):
+    arr = synthetic.make_sample_arrays(seed=seed, T=t, B=b, obs_spec={}, action_dims=actions, p_done=p_done, **kw)
     dev = {k: torch.from_numpy(v).cuda() for k, v in arr.items()}
     gen = torch.Generator(device="cuda").manual_seed(seed)
-    dev["obs.obs"] = torch.randint(0, 256, (T + 1, B, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=gen)
-    return dev
+    dev["obs.obs"] = torch.randint(0, 256, (t + 1, b, *frame), dtype=torch.uint8, device="cuda", generator=gen)
+    return dev, arr
+
+
+def check_gae_vs_oracle(sample, arr, gamma=0.99, lmbda=0.97, popart_net=None):
+    """The advantages / value targets the step wrote back into the sample against the numpy oracle (1e-5 relative)."""
+    from oracle import gae as ogae
+    value = arr["analyzed_result.value"]
+    if popart_net is not None:  # PopArt: the trace runs on de-normalised values (mappo.py:120-124; popart.py:53-59)
+        rms = popart_net.popart_state.cpu().numpy()
+        debias = max(rms[2], 1e-5)
+        mean, var = rms[0] / debias, max(rms[1] / debias - (rms[0] / debias)**2, 1e-2)
+        value = (value.astype(np.float64) * np.sqrt(var) + mean).astype(np.float32)
+    o_adv, o_ret = ogae.adv_and_value_target(arr["reward"], value, arr["truncated"], arr["done"], arr["on_reset"], gamma, lmbda)
+    adv, ret = sample.analyzed_result.adv.cpu().numpy(), sample.analyzed_result.ret.cpu().numpy()
+    Tn = o_adv.shape[0]
+    assert (np.abs(adv[:Tn] - o_adv) <= 1e-5 * np.maximum(np.abs(o_adv), 1.0)).all()
+    assert (np.abs(ret[:Tn] - o_ret) <= 1e-5 * np.maximum(np.abs(o_ret), 1.0)).all()
+    assert (adv[Tn:] == 0).all() and (ret[Tn:] == 0).all()  # the zero pad row (mappo.py:254-256)
 
 
 def make(chunk_rows):
@@ -63,7 +82,7 @@ def test_gae_scan_full_size_properties():
 def test_step_full_size_chunking_and_repeatability():
     """The row-chunking of the forward/backward (activation workspace) must not change the update; the same step on
     the same weights must repeat; returned advantages obey the masked statistics reported in the stats."""
-    sample = device_sample(7)
+    sample, _ = device_sample(7)
     results = []
     for chunk in (16384, 8192, 16384):
         tr = make(chunk)
@@ -79,6 +98,95 @@ def test_step_full_size_chunking_and_repeatability():
         assert torch.allclose(p0[k], p1[k], rtol=0, atol=2e-5), ("chunking", k)
         assert torch.allclose(p0[k], p2[k], rtol=0, atol=1e-6), ("repeat", k)
     assert s0["frames"] == T * B and np.isfinite(list(s0.values())).all()
+
+
+def test_config2_step_4096_envs():
+    """BASELINE.json configs[2], the configuration the metric is quoted on: ONE GPU takes all 4096 env columns x 128 steps
+    (14.9 GB of uint8 frames, 32 row-chunks).  GAE returns against the numpy oracle, row-chunking invariance (16384 vs
+    32768 rows per chunk), repeatability, and the statistics the step reports."""
+    b = 4096
+    sample, arr = device_sample(11, b=b)
+    results = []
+    for chunk in (16384, 32768, 16384):
+        tr = make(chunk)
+        smp = synthetic.to_sample_batch(dict(sample))
+        res = tr.step(smp)
+        results.append((res.stats, tr.policy.get_checkpoint()["state_dict"]))
+        if chunk == 16384 and len(results) == 1:
+            check_gae_vs_oracle(smp, arr)
+        del tr
+    (s0, p0), (s1, p1), (s2, p2) = results
+    for k in s0:
+        tol = 1e-5 if k in ("policy_loss", "value_loss", "entropy") else 1e-4
+        assert abs(s0[k] - s1[k]) <= tol * max(abs(s0[k]), 1e-3), ("chunking", k, s0[k], s1[k])
+        assert abs(s0[k] - s2[k]) <= 1e-6 * max(abs(s0[k]), 1e-3), ("repeat", k, s0[k], s2[k])
+    for k in p0:
+        assert torch.allclose(p0[k], p1[k], rtol=0, atol=2e-5), ("chunking", k)
+        assert torch.allclose(p0[k], p2[k], rtol=0, atol=1e-6), ("repeat", k)
+    assert s0["frames"] == T * b and np.isfinite(list(s0.values())).all()
+    mask = 1.0 - arr["on_reset"][1:].astype(np.float64)
+    assert abs(s0["done"] - float(arr["done"][:T].mean())) < 1e-9 and abs(s0["truncated"] - float(arr["truncated"][:T].mean())) < 1e-9
+    assert mask.sum() > 0.99 * T * b
+    del sample
+    torch.cuda.empty_cache()
+
+
+def test_config4_football_per_gpu_size():
+    """BASELINE.json configs[4] at its per-GPU size: 256 of the 2048 football environments x 200 steps, the
+    `football-smm-separate` preset with an LSTM ((4, 96, 72) uint8 frames -> convolution stack -> the halving Linear
+    tower -> LSTM-128, separate actor / critic, PopArt; 676 M parameters).  GAE returns against the numpy oracle (on the
+    values de-normalised with the initial PopArt statistics, restated in numpy), invariance of the update to how
+    the encoder rows are cut into pieces, repeatability.  The orthogonal initialisation (a QR of a 22528 x 11264 matrix,
+    minutes on one core) is replaced by a scaled normal draw: random-init weights of the same architecture."""
+    import math
+    Tf, Bf, H = 200, 256, 128
+    orig = torch.nn.init.orthogonal_
+
+    def cheap(t, gain=1.0):
+        with torch.no_grad():
+            return t.normal_(0.0, gain / math.sqrt(t.shape[1] if t.dim() > 1 else t.numel()))
+
+    torch.nn.init.orthogonal_ = cheap
+    try:
+        tr = trainer_api.make(config.Trainer("mappo", args=dict(popart=True, clip_value=True, value_loss="huber",
+                                                                value_loss_config=dict(delta=10.0), max_grad_norm=10.0,
+                                                                optimizer_config=dict(lr=5e-4, eps=1e-5))),
+                              config.Policy("football-smm-separate", args=dict(rnn_type="lstm", seed=1)))
+    finally:
+        torch.nn.init.orthogonal_ = orig
+    net = tr.policy.net
+    assert net.spec.total_params > 600e6
+    sample, arr = device_sample(5, b=Bf, frame=(4, 96, 72), t=Tf, actions=19, p_done=1 / 400,
+                                policy_state={"actor_hx": (1, 2 * H), "critic_hx": (1, 2 * H)})
+    flat0, pop0 = net.flat.clone(), net.popart_state.clone()
+
+    def one_step(rows):
+        net.flat.copy_(flat0)
+        net.popart_state.copy_(pop0)
+        tr._m.zero_(), tr._v.zero_()
+        tr._opt_steps = 0
+        tr.policy._popart_updates = 0
+        net.encoder_rows = rows
+        smp = synthetic.to_sample_batch(dict(sample))
+        res = tr.step(smp)
+        return res.stats, net.flat.clone(), smp
+
+    rows = net.encoder_rows
+    pop_init = type("P", (), {"popart_state": pop0})
+    s0, p0, smp = one_step(rows)
+    check_gae_vs_oracle(smp, arr, popart_net=pop_init)
+    s1, p1, _ = one_step(rows // 2 + 17)  # more, unevenly cut encoder pieces
+    s2, p2, _ = one_step(rows)
+    for k in ("policy_loss", "value_loss", "entropy", "grad_norm", "importance_weight", "denorm_value"):
+        assert abs(s0[k] - s1[k]) <= 1e-4 * max(abs(s0[k]), 1e-3), ("pieces", k, s0[k], s1[k])
+        assert abs(s0[k] - s2[k]) <= 1e-6 * max(abs(s0[k]), 1e-3), ("repeat", k, s0[k], s2[k])
+    assert s0["frames"] - 0 == Tf * Bf * 1 or s0["frames"] % (Tf * Bf) == 0
+    d1, d2 = (p0 - p1).abs(), (p0 - p2).abs()
+    assert float(d1.max()) <= 5e-4 and float((d1 > 2e-5).float().mean()) < 1e-3, float(d1.max())
+    assert float(d2.max()) <= 1e-6
+    assert np.isfinite(list(s0.values())).all() and float((p0 - flat0).abs().max()) > 0  # the step moved the weights
+    del tr, net, sample
+    torch.cuda.empty_cache()
 
 
 def test_smac_config_full_size_step_vs_oracle():

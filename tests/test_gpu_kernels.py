@@ -103,6 +103,49 @@ def test_gae_shapes_vs_oracle(T, B, Nc):
     assert stats[0] == n and abs(stats[1] - s) <= 1e-6 * max(1.0, abs(s), q**0.5) and abs(stats[2] - q) <= 1e-6 * q + 1e-9
 
 
+def test_gae_tensor_gamma_lambda_golden(golden):
+    """gamma / lmbda as [T, B, 1] float32 tensors (reference gae.py:51-60) against the reference's own outputs."""
+    g = golden("gae_tensor.npz")
+    for name in g["cases"]:
+        arr = {k: g[f"{name}_{k}"] for k in ("reward", "value", "done", "truncated", "on_reset")}
+        gam, lam = dev(g[f"{name}_gamma"]), dev(g[f"{name}_lambda"])
+        for tag, gg, ll in (("gl", gam, lam), ("g", gam, 0.95), ("l", 0.99, lam)):
+            adv, ret, _ = run_gae(arr, gg, ll)
+            ref = g[f"{name}_{tag}_adv"]
+            T = ref.shape[0]
+            assert rel_close(adv[:T], ref, 1e-5, scale=1.0), (name, tag)
+            vm = (arr["value"] * (1 - arr["done"])).astype(np.float32)
+            assert rel_close(ret[:T], ref + vm[:T], 1e-5, scale=1.0), (name, tag)
+        adv, _, _ = run_gae(arr, gam, lam, ratio=g[f"{name}_ratio"])
+        assert rel_close(adv[:T], g[f"{name}_vtrace_adv"], 1e-5, scale=1.0), (name, "vtrace")
+    with pytest.raises(hip.HipError):  # a tensor of the wrong shape is refused like the reference's assert (gae.py:53)
+        run_gae(arr, gam[:-1], 0.9)
+
+
+@pytest.mark.parametrize("T,B", [(128, 4096), (128, 512), (33, 12), (64, 100000), (7, 10)])
+def test_gae_stats_workspace_is_reproducible_and_self_resetting(T, B):
+    """With a workspace the three sums need no zeroing launch: partial sums per workgroup, added in workgroup order by the
+    last workgroup to finish.  Same sums as the atomic path (to float64 rounding), bitwise equal from launch to launch, and
+    the workspace is ready for the next launch without the caller touching it."""
+    arr = synthetic.make_sample_arrays(seed=3 * T + B, T=T, B=B, obs_spec={}, action_dims=2, p_done=0.03)
+    a = [dev(arr[k]) for k in ("reward", "analyzed_result.value", "done", "truncated", "on_reset")]
+    adv, ret = torch.zeros((T + 1, B, 1), device=DEV), torch.zeros((T + 1, B, 1), device=DEV)
+    ws = hip.gae_scan_workspace(B, 1, DEV)
+    ref = torch.zeros(3, dtype=torch.float64, device=DEV)
+    hip.gae_scan(*a, 0.99, 0.97, adv, ret, stats=ref)
+    adv_ref = adv.clone()
+    outs = []
+    for _ in range(4):
+        st = torch.full((3,), 123.0, dtype=torch.float64, device=DEV)  # overwritten, not accumulated
+        hip.gae_scan(*a, 0.99, 0.97, adv, ret, stats=st, workspace=ws)
+        outs.append(st.cpu().numpy())
+    assert torch.equal(adv, adv_ref)
+    r = ref.cpu().numpy()
+    assert outs[0][0] == r[0] and np.allclose(outs[0], r, rtol=1e-12, atol=1e-9)
+    assert all(np.array_equal(o, outs[0]) for o in outs[1:])
+    assert int(ws.view(torch.int32)[0].item()) == 0  # the ticket is back at zero
+
+
 def test_gae_empty():
     z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=DEV)
     stats = torch.ones(3, dtype=torch.float64, device=DEV)

@@ -383,6 +383,30 @@ def test_streamed_rollout_matches_one_piece():
     assert pol.rollout(req_s).action.x.shape == (64, 1)
 
 
+def test_streamed_rollout_with_action_mask_matches_one_piece():
+    """The availability mask of a streamed piece is staged on the side stream like the frames: a piece must sample
+    with ITS OWN mask (every action legal under it) and give the one-piece result."""
+    pol = policy_api.make(config.Policy("actor-critic", args=dict(CNN_POLICY, seed=8)))
+    pol.ROLLOUT_PIECE = 256
+    n = 6 * pol.ROLLOUT_PIECE + 77
+    rng = np.random.default_rng(11)
+    obs = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    A = CNN_POLICY["action_dim"]
+    avail = np.zeros((n, A), dtype=np.uint8)
+    avail[np.arange(n), rng.integers(0, A, size=n)] = 1  # exactly one legal action per row, different between pieces
+    for mode in (1, 0):  # evaluation (argmax) and sampling: with one legal action both are fully determined
+        req = policy_api.RolloutRequest(obs=NamedArray(obs=obs, available_action=avail),
+                                        is_evaluation=np.full((n, 1), mode, np.uint8), on_reset=np.zeros((n, 1), np.uint8))
+        for _ in range(3):
+            out = pol.rollout(req)
+            assert np.array_equal(out.action.x[:, 0], avail.argmax(1)), "a piece used another piece's mask"
+            assert np.abs(out.analyzed_result.log_probs).max() < 1e-4  # log-prob of the only legal action ~ 0
+    pol.ROLLOUT_PIECE = n
+    whole = pol.rollout(req)
+    assert np.array_equal(whole.action.x, out.action.x)
+    assert close(whole.analyzed_result.value, out.analyzed_result.value, 1e-6)
+
+
 def test_float32_frames_and_mixed_observation_keys_vs_oracle():
     """Image observations delivered as float32 (the non-byte staging of the first layer), next to a vector key and an
     action mask, separate backbones: one trainer step against the CPU oracle."""

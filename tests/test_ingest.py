@@ -73,6 +73,63 @@ def test_uint8_frames_stay_uint8():
     assert ring.nbytes() >= 3 * 3 * 4 * 84 * 84
 
 
+def test_slot_is_published_only_after_every_column_is_written():
+    """A slot whose last column has been CLAIMED may still have slower writers: it must not reach the consumer until
+    every column's write has finished (threads release the GIL inside the strided numpy copies)."""
+    import threading
+    import time
+    B = 8
+    trajs = [traj(50 + s, T=4, obs_spec=synthetic.ATARI_OBS) for s in range(B)]
+    ring = SampleRing(trajs[0], batch_size=B, slots=2)
+    slow_started, let_go = threading.Event(), threading.Event()
+
+    class SlowLeaf:  # the first column's frames take their time to arrive
+
+        def __init__(self, arr):
+            self.arr, self.shape, self.dtype = arr, arr.shape, arr.dtype
+
+        def __array__(self, *a, **k):
+            slow_started.set()
+            let_go.wait(5.0)
+            return self.arr
+
+    slow = trajs[0]
+    slow_obs = slow.obs.obs
+    slow.obs = na.NamedArray(obs=SlowLeaf(slow_obs))
+    th = threading.Thread(target=ring.put_column, args=(slow,))
+    th.start()
+    assert slow_started.wait(5.0)
+    others = [threading.Thread(target=ring.put_column, args=(t,)) for t in trajs[1:]]
+    for o in others:
+        o.start()
+    for o in others:
+        o.join()
+    time.sleep(0.05)
+    assert ring.ready() == 0  # all columns claimed, the last claimed one written -- but column 0 is not finished
+    with pytest.raises(LookupError):
+        ring.get()
+    let_go.set()
+    th.join()
+    assert ring.ready() == 1
+    b = ring.get()
+    assert np.array_equal(b.obs.obs[:, 0], slow_obs)
+    cols = {tuple(b.reward[:, c, 0]) for c in range(B)}
+    assert cols == {tuple(t.reward[:, 0]) for t in trajs}  # every trajectory landed in exactly one column
+
+
+def test_bad_wire_message_leaves_no_hole():
+    trajs = [traj(70 + s) for s in range(2)]
+    ring = SampleRing(trajs[0], batch_size=2, slots=1)
+    bad = traj(99)
+    bad.obs = na.NamedArray(other=bad.obs.obs)
+    with pytest.raises(KeyError):
+        ring.put_wire(na.dumps(bad, "raw_bytes"))
+    assert ring.put_wire(na.dumps(trajs[0], "raw_bytes")) is None
+    assert ring.put_wire(na.dumps(trajs[1], "raw_bytes")) == 0  # the failed message claimed no column
+    b = ring.get()
+    assert np.array_equal(b.reward, np.stack([trajs[0].reward, trajs[1].reward], 1))
+
+
 @pytest.mark.gpu
 def test_ring_to_device_feeds_the_trainer():
     import srl_amd

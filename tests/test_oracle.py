@@ -54,6 +54,20 @@ def test_traj_gae_hand_vectors(golden):
         np.testing.assert_allclose(ret, g[f"trajgae_{tag}_ret"], rtol=1e-6)
 
 
+def test_gae_tensor_gamma_lambda_golden(golden):
+    """Per-step discount / lambda tensors (reference gae.py:51-60), bit-equal to the reference's own outputs."""
+    g = golden("gae_tensor.npz")
+    for name in g["cases"]:
+        a = {k: g[f"{name}_{k}"] for k in ("reward", "value", "done", "truncated", "on_reset", "gamma", "lambda", "ratio")}
+        vm = (a["value"] * (1 - a["done"])).astype(np.float32)
+        for tag, gam, lam in (("gl", a["gamma"], a["lambda"]), ("g", a["gamma"], 0.95), ("l", 0.99, a["lambda"])):
+            adv = ogae.gae_trace(a["reward"][:-1], vm, a["truncated"], a["done"], a["on_reset"], gam, lam)
+            assert np.array_equal(adv, g[f"{name}_{tag}_adv"]), (name, tag)
+        adv = ogae.gae_trace(a["reward"][:-1], vm, a["truncated"], a["done"], a["on_reset"], a["gamma"], a["lambda"],
+                             vtrace=True, imp_ratio=a["ratio"])
+        assert np.array_equal(adv, g[f"{name}_vtrace_adv"]), name
+
+
 def test_gae_golden(golden):
     g = golden("gae.npz")
     for name in g["cases"]:
