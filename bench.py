@@ -23,9 +23,9 @@ with t / t_launch_floor, and saturated), ``cpu_baseline`` (the oracle's CPU rest
 bounded sample, rank 0, N = 1 only).
 
 Profiling recipe (counters in their own passes; the interpreter directly after ``--``):
-    rocprofv3 --kernel-trace --stats -d gpurun_out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-from-host
-    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
-    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-from-host
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
     python3 scripts/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --steps-in-run 2 --envs 4096 --rollout-len 128 \
         --chunk-rows 16384 > profiles/r02_hbm_traffic_vN.csv     (writes the matching .json with the configuration)
 """

@@ -8,8 +8,8 @@ FETCH_SIZE / WRITE_SIZE count kilobytes; the MI355X guide's gfx950 correction is
 writes the table and, next to it, ``<out>.json`` with the configuration of the profiled run (bench.py only quotes a
 recording made at its own configuration).  The passes themselves (interpreter directly after ``--``):
 
-    rocprofv3 --pmc FETCH_SIZE -d <fetch_dir> -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
-    rocprofv3 --pmc WRITE_SIZE -d <write_dir> -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d <fetch_dir> -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d <write_dir> -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
 """
 import argparse
 import csv
