@@ -106,13 +106,14 @@ def gae_microbench(sample, targs, device, reps=200, big_B=None):
     ret = torch.zeros((Tb, B, 1), device=device)
     stats = torch.zeros(3, dtype=torch.float64, device=device)
     args = (*leaves, targs["discount_rate"], targs["gae_lambda"], adv, ret)
+    ws = hip.gae_scan_workspace(B, 1, device)  # as the trainer calls it: statistics without a zeroing launch
     for _ in range(10):
-        hip.gae_scan(*args, stats=stats)
+        hip.gae_scan(*args, stats=stats, workspace=ws)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     a.record()
     for _ in range(reps):
-        hip.gae_scan(*args, stats=stats)
+        hip.gae_scan(*args, stats=stats, workspace=ws)
     b.record()
     torch.cuda.synchronize()
     T = Tb - 1
