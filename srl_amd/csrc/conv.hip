@@ -1,8 +1,12 @@
 // Implicit-GEMM convolution entry points (padding 0, square or rectangular kernels, any stride):
 // forward / weight gradient / data gradient on NHWC activations, and the first convolution on the NCHW
 // observation with the whole-observation LayerNorm fused into the operand gather.  No patch matrix is ever
-// written to memory; all contraction runs on the FP32 MFMA kernel of gemm_core.h.
+// written to memory; the contraction runs on the FP32 MFMA kernel of gemm_core.h, except the first layer on uint8
+// channels-last frames, which runs exactly on the bf16 matrix cores (obs_bf16.h).
+#include <stdlib.h>
+
 #include "gemm_core.h"
+#include "obs_bf16.h"
 
 using namespace srlgemm;
 
@@ -147,7 +151,9 @@ bool dgrad_uniform(const DgradClass* cls, int nc) {
 // 32 outputs x 8 position-lanes per workgroup: one thread per output would walk the P positions as a serial chain of
 // loads on 32 workgroups
 constexpr int kDwEL = 32, kDwZL = 8;
-__global__ __launch_bounds__(256) void obs_dw_kernel(const float* Q, const float* R, const float* gamma,
+// C[pos,o] (zeros on the float32 path): the mean correction the bf16 path leaves outside its contraction (obs_bf16.h),
+// Q_true = Q - C
+__global__ __launch_bounds__(256) void obs_dw_kernel(const float* Q, const float* R, const float* C, const float* gamma,
                                                      const float* beta, int P, int Cout, ObsIndex ix, float* dw,
                                                      float* db) {
   __shared__ float red_a[256], red_r[256];
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256) void obs_dw_kernel(const float* Q, const float
       const int oh = pos / ix.OW, ow = pos % ix.OW;
       const int p = ix.p_of(ci, oh * ix.S + kh, ow * ix.S + kw);
       const float r = R[pos * Cout + o];
-      acc += gamma[p] * Q[((long)pos * Cout + o) * Kp + k] + beta[p] * r;
+      acc += gamma[p] * (Q[((long)pos * Cout + o) * Kp + k] - C[pos * Cout + o]) + beta[p] * r;
       rsum += r;
     }
   }
@@ -180,8 +186,8 @@ __global__ __launch_bounds__(256) void obs_dw_kernel(const float* Q, const float
 }
 
 // dgamma[p] += sum_{(pos,k) -> p} sum_o w[o,k] Q[pos,o,k];   dbeta[p] += sum_{(pos,k) -> p} sum_o w[o,k] R[pos,o]
-__global__ __launch_bounds__(256) void obs_affine_kernel(const float* Q, const float* R, const float* w, int OH, int Cout,
-                                                         ObsIndex ix, float* dgamma, float* dbeta) {
+__global__ __launch_bounds__(256) void obs_affine_kernel(const float* Q, const float* R, const float* C, const float* w, int OH,
+                                                         int Cout, ObsIndex ix, float* dgamma, float* dbeta) {
   const int Kp = ix.Cin * ix.KH * ix.KW;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= ix.Cin * ix.H * ix.W) return;
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256) void obs_affine_kernel(const float* Q, const f
       const int k = ix.k_of(ci, kh, kw);
       for (int o = 0; o < Cout; ++o) {
         const float wv = w[o * Kp + k];
-        ag += wv * Q[((long)pos * Cout + o) * Kp + k];
+        ag += wv * (Q[((long)pos * Cout + o) * Kp + k] - C[pos * Cout + o]);
         ab += wv * R[pos * Cout + o];
       }
     }
@@ -230,6 +236,38 @@ __global__ __launch_bounds__(256) void obs_fold_affine_kernel(const float* w, co
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) b2[pos * Cout + o] = (bias ? bias[o] : 0.f) + red[0] + red[1] + red[2] + red[3];
+}
+
+// uint8 channels-last first layer on the bf16 matrix cores (obs_bf16.h): geometry it is written for
+bool obs_bf16_ok(const srl_conv_desc* d, int is_u8, int channels_last, const void* obs) {
+  const char* env = getenv("SRL_OBS_BF16");  // "0": force the float32 kernels (A/B timing, cross-check in the tests)
+  const bool off = env && env[0] == '0';
+  if (off || !is_u8 || !channels_last || d->Cout != srlobs::kCout) return false;
+  const long run = (long)d->KW * d->Cin, Kp = run * d->KH;
+  if (Kp != 256 || run < 16 || (run & (run - 1)) != 0) return false;
+  const long img = (long)d->H * d->W * d->Cin;
+  return img % 16 == 0 && ((long)d->stride * d->Cin) % 16 == 0 && aligned16(obs) && d->n >= 32;
+}
+
+srlobs::ObsGeom obs_geom(const srl_conv_desc* d, const void* obs, const float* mean, const float* rstd, int OW) {
+  srlobs::ObsGeom g{};
+  g.frames = static_cast<const uint8_t*>(obs);
+  g.img_stride = (long)d->H * d->W * d->Cin;
+  g.W = d->W; g.Cin = d->Cin; g.OW = OW; g.stride = d->stride;
+  const int run = d->KW * d->Cin;
+  g.run_shift = 31 - __builtin_clz((unsigned)run);
+  g.run_stride = d->W * d->Cin;
+  g.mean = mean; g.rstd = rstd; g.n = d->n;
+  return g;
+}
+
+// sample ranges per output position: enough workgroups for a few rounds over the chip, >= 512 samples each
+int obs_bf16_split(long n, int P, int per_cu) {
+  const long slots = 256L * per_cu;
+  long want = (4 * slots + P - 1) / P;
+  const long cap = n / 512 > 1 ? n / 512 : 1;
+  if (want > cap) want = cap;
+  return (int)(want < 1 ? 1 : want);
 }
 
 int check_desc(const srl_conv_desc* d) {
@@ -418,7 +456,8 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
 extern "C" int64_t srl_conv2d_obs_fwd_workspace(const srl_conv_desc* d) {
   if (check_desc(d) != 0) return 0;
   const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
-  return (int64_t)OH * OW * d->Cout * ((long)d->Cin * d->KH * d->KW + 1) + 64;
+  // float32 path: wg [P][Cout][Kp] + b2 [P][Cout]; bf16 path: three bf16 planes (1.5 x wg) + S + b2
+  return (int64_t)OH * OW * d->Cout * (2 * (long)d->Cin * d->KH * d->KW + 2) + 64;
 }
 
 extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
@@ -438,6 +477,24 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
   g.k_per_split = srl_ceil_div(Kp, BK) * BK;
   g.vec_a = 1;
   int rc;
+  if (workspace && aligned16(workspace) && obs_bf16_ok(d, is_u8, channels_last, obs)) {
+    // bytes x (three exact bf16 planes of the folded weights) on the bf16 matrix cores: obs_bf16.h
+    const int P = OH * OW;
+    uint16_t* wq = reinterpret_cast<uint16_t*>(workspace);
+    float* S = workspace + ((long)P * 3 * d->Cout * Kp) / 2;
+    float* b2 = S + (long)P * d->Cout;
+    const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, 1};
+    hipLaunchKernelGGL(srlobs::obs_fold_split_kernel<ObsIndex>, dim3((unsigned)(P * d->Cout)), dim3(256), 0, st, w, bias, gamma,
+                       beta, P, (int)Kp, ix, wq, S, b2);
+    srlobs::FwdArgs a{};
+    a.g = obs_geom(d, obs, mean, rstd, OW);
+    a.wq = reinterpret_cast<const uint4*>(wq);
+    a.S = S; a.b2 = b2; a.y = y; a.P = P; a.act = d->act;
+    a.nsplit = obs_bf16_split(d->n, P, 3);
+    hipLaunchKernelGGL(srlobs::obs_fwd_bf16_kernel<256>, dim3((unsigned)(P * a.nsplit)), dim3(256), 0, st, a);
+    SRL_LAUNCH_CHECK();
+    return 0;
+  }
   if (workspace && aligned16(workspace) && Kp % 4 == 0 && d->n >= 64) {
     // Position-batched form: one GEMM per output position over the samples, with the LayerNorm affine folded into
     // per-position weights (w * gamma) and biases (bias + w . beta): the gather then needs no table lookups.
@@ -484,8 +541,10 @@ extern "C" int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d) {
   const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
   const long P = (long)OH * OW, Kp = (long)d->Cin * d->KH * d->KW;
   const long tiles = srl_ceil_div(d->Cout, 32) * srl_ceil_div(Kp, 256);
-  const long split = want_split(d->n, tiles, P);
-  return (int64_t)((split + 1) * P * d->Cout * Kp + P * d->Cout + 64);
+  long split = want_split(d->n, tiles, P);
+  const long split16 = obs_bf16_split(d->n, (int)P, 3);
+  if (split16 > split) split = split16;
+  return (int64_t)((split + 1) * P * d->Cout * Kp + 2 * P * d->Cout + 64);
 }
 
 extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
@@ -504,9 +563,31 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
   // workspace: Q [P][Cout][Kp] | R [P][Cout] (padded to 16 B) | split slabs
   float* Q = workspace;
   float* R = Q + (long)P * d->Cout * Kp;
-  float* slabs = R + (((long)P * d->Cout + 3) & ~3L);
+  float* C = R + (long)P * d->Cout;  // bf16 path: mean correction of Q (zero otherwise)
+  float* slabs = C + (((long)P * d->Cout + 3) & ~3L);
   // R[pos, o] = sum_n dz[(n, pos), o]: column sums of the A tiles the batched product below stages anyway
-  if (hipMemsetAsync(R, 0, sizeof(float) * P * d->Cout, st) != hipSuccess) return -EIO;
+  if (hipMemsetAsync(R, 0, sizeof(float) * 2 * P * d->Cout, st) != hipSuccess) return -EIO;
+  const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, channels_last ? 1 : 0};
+  if (obs_bf16_ok(d, is_u8, channels_last, obs) && (P * d->Cout) % 4 == 0) {
+    srlobs::BwdArgs a{};
+    a.g = obs_geom(d, obs, mean, rstd, OW);
+    a.dz = dz; a.R = R; a.C = C; a.P = P;
+    a.nsplit = obs_bf16_split(d->n, P, 3);
+    a.Q = a.nsplit > 1 ? slabs : Q;
+    a.slab = (long)P * d->Cout * Kp;
+    hipLaunchKernelGGL(srlobs::obs_bwd_bf16_kernel<256>, dim3((unsigned)(P * a.nsplit)), dim3(256), 0, st, a);
+    SRL_LAUNCH_CHECK();
+    if (a.nsplit > 1) {
+      reduce_slabs(st, slabs, a.nsplit, (long)P, (long)d->Cout, Kp, Q, Kp, (long)d->Cout * Kp, 0);
+      SRL_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(obs_dw_kernel, dim3((unsigned)srl_ceil_div(d->Cout * Kp, kDwEL)), dim3(256), 0, st, Q, R, C, gamma, beta,
+                       P, d->Cout, ix, dw, db);
+    hipLaunchKernelGGL(obs_affine_kernel, dim3((unsigned)srl_ceil_div(d->Cin * d->H * d->W, 256)), dim3(256), 0, st, Q, R, C, w,
+                       OH, d->Cout, ix, dgamma, dbeta);
+    SRL_LAUNCH_CHECK();
+    return 0;
+  }
   int rc;
   // Q[pos][o][k] = sum_n dz[(n,pos), o] * xhat[n, patch(pos)[k]]   — one batched GEMM over the P output positions
   GemmArgs g{};
@@ -532,10 +613,9 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
     reduce_slabs(st, slabs, nsplit, (long)P, (long)d->Cout, Kp, Q, Kp, (long)d->Cout * Kp, 0);
     SRL_LAUNCH_CHECK();
   }
-  const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, channels_last ? 1 : 0};
-  hipLaunchKernelGGL(obs_dw_kernel, dim3((unsigned)srl_ceil_div(d->Cout * Kp, kDwEL)), dim3(256), 0, st, Q, R, gamma, beta, P,
+  hipLaunchKernelGGL(obs_dw_kernel, dim3((unsigned)srl_ceil_div(d->Cout * Kp, kDwEL)), dim3(256), 0, st, Q, R, C, gamma, beta, P,
                      d->Cout, ix, dw, db);
-  hipLaunchKernelGGL(obs_affine_kernel, dim3((unsigned)srl_ceil_div(d->Cin * d->H * d->W, 256)), dim3(256), 0, st, Q, R, w,
+  hipLaunchKernelGGL(obs_affine_kernel, dim3((unsigned)srl_ceil_div(d->Cin * d->H * d->W, 256)), dim3(256), 0, st, Q, R, C, w,
                      OH, d->Cout, ix, dgamma, dbeta);
   SRL_LAUNCH_CHECK();
   return 0;

@@ -1,0 +1,389 @@
+// First convolution on uint8 frames through the BF16 matrix cores, exactly.
+//
+// The float32 MFMA of gfx950 runs at the vector rate (157 TFLOP/s); the bf16 MFMA at 16x that.  For the first layer the
+// 16x is available WITHOUT giving up float32 results, because one operand is bytes:
+//   * a uint8 value 0..255 is exactly representable in bf16 (8 significand bits);
+//   * a float32 value splits exactly into three bf16 pieces, v = v0 + v1 + v2 (truncation splits: v0 = top 8
+//     significand bits, v1 = the next 8, v2 = the last 8; every subtraction below is exact in float32);
+//   * a product (bf16 piece) x (byte) has at most 16 significand bits: exact in the MFMA's float32 accumulate.
+// So  sum_k x_k * v_k  =  sum over the three planes of a bf16 MFMA, with NO dropped term: the only roundings are the
+// float32 accumulations (3 per 16 k-values instead of 16 for the float32 FMA chain).  3 bf16 MFMAs (32 cycles each)
+// replace 8 float32 MFMAs (64 cycles each) per 32x32x16 block: 5.3x fewer matrix-pipe cycles.
+//
+// The whole-observation LayerNorm (x - mean_n) * rstd_n is taken out of the contraction, which then sees raw bytes:
+//   forward   y[n,pos,o] = act( rstd_n * ( sum_k x[n,pos,k] wg[pos,o,k]  -  mean_n * S[pos,o] ) + b2[pos,o] )
+//             wg = w * gamma (LayerNorm affine folded per output position), S = sum_k wg, b2 = bias + w . beta
+//   backward  Q[pos,o,k] = sum_n dz'[n,pos,o] x[n,pos,k]  -  C[pos,o],   dz' = dz * rstd_n,  C = sum_n dz' mean_n
+//             (Q is what conv.hip's finalisation kernels turn into dW, dgamma, dbeta; R = sum_n dz as before)
+// Layout requirements (srl_conv2d_obs_* fall back to the float32 kernels otherwise): uint8 channels-last frames (the
+// space-to-depth'd stack), Cout == 32, patch length Kp == 256 bytes made of runs (KW * Cin bytes) that are a power of
+// two >= 16 bytes, 16-byte aligned samples.
+#pragma once
+#include "gemm_core.h"
+
+namespace srlobs {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kCout = 32;
+
+struct ObsGeom {
+  const uint8_t* frames;   // [n][H][W][Cin] uint8
+  long img_stride;         // bytes per sample
+  int W, Cin, OW, stride;  // position (oy, ox) starts at ((oy * W + ox) * stride) * Cin
+  int run_shift;           // log2(KW * Cin): bytes of one contiguous run of the patch
+  int run_stride;          // W * Cin: bytes between the runs (kernel rows)
+  const float* mean;
+  const float* rstd;
+  long n;
+};
+
+#ifdef __HIPCC__
+// exact three-way truncation split of a float32 into bf16 pieces (returned as the high halves of float32 words)
+__device__ __forceinline__ void split3(float v, uint32_t& b0, uint32_t& b1, uint32_t& b2) {
+  b0 = __float_as_uint(v) & 0xffff0000u;
+  const float r1 = v - __uint_as_float(b0);
+  b1 = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(b1);
+  b2 = __float_as_uint(r2) & 0xffff0000u;  // r2 has at most 8 significant bits: nothing is cut here
+}
+// [lo.hi16, hi.hi16]: two bf16 in one dword from the high halves of two float32 words
+__device__ __forceinline__ uint32_t pack_hi(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+// 8 bytes (two dwords) -> 8 bf16, element j = byte j
+__device__ __forceinline__ bf16x8 bytes_to_bf16x8(uint32_t d0, uint32_t d1) {
+  union { uint32_t u[4]; bf16x8 v; } r;
+#define SRL_B2F(d, i) __float_as_uint((float)(((d) >> (8 * (i))) & 255u))
+  r.u[0] = pack_hi(SRL_B2F(d0, 0), SRL_B2F(d0, 1));
+  r.u[1] = pack_hi(SRL_B2F(d0, 2), SRL_B2F(d0, 3));
+  r.u[2] = pack_hi(SRL_B2F(d1, 0), SRL_B2F(d1, 1));
+  r.u[3] = pack_hi(SRL_B2F(d1, 2), SRL_B2F(d1, 3));
+#undef SRL_B2F
+  return r.v;
+}
+
+// byte offset of patch byte b (a multiple of 16) from the patch origin
+__device__ __forceinline__ int patch_off(const ObsGeom& g, int b) {
+  return (b >> g.run_shift) * g.run_stride + (b & ((1 << g.run_shift) - 1));
+}
+
+// Workgroup ids are dealt round-robin to the 8 XCDs: renumber so that every XCD owns one contiguous run of logical ids
+__device__ __forceinline__ unsigned xcd_contiguous_id() {
+  const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  return xcd * q + (xcd < r ? xcd : r) + slot;
+}
+
+// ---- fold + split: wq[pos][plane][kb][lane][8] bf16 (MFMA A-operand fragments, rows = output channels) -----------------
+// MFMA k-block kb = 2c + e of a lane with half h covers patch bytes 32c + 16h + 8e + (0..7): a lane's 16-byte load of
+// the patch feeds two consecutive k-blocks.  Any pairing of k-values works as long as both operands use the same one.
+template <class Index>
+__global__ __launch_bounds__(256) void obs_fold_split_kernel(const float* w, const float* bias, const float* gamma,
+                                                             const float* beta, int P, int Kp, Index ix, uint16_t* wq,
+                                                             float* S, float* b2) {
+  __shared__ double red[8];
+  const int pos = blockIdx.x / kCout, o = blockIdx.x % kCout;
+  const int oh = pos / ix.OW, ow = pos % ix.OW;
+  const int nkb = Kp / 16;
+  double acc[2] = {0.0, 0.0};  // sum_k w gamma, sum_k w beta
+  for (int k = threadIdx.x; k < Kp; k += 256) {
+    int ci, kh, kw;
+    ix.split_k(k, ci, kh, kw);
+    const int p = ix.p_of(ci, oh * ix.S + kh, ow * ix.S + kw);
+    const float wv = w[o * Kp + k];
+    const float wg = wv * gamma[p];  // the float32 product the float32 path folds as well
+    acc[0] += (double)wg;
+    acc[1] += (double)wv * (double)beta[p];
+    uint32_t b[3];
+    split3(wg, b[0], b[1], b[2]);
+    const int c = k >> 5, h = (k >> 4) & 1, e = (k >> 3) & 1, j = k & 7;
+    const int kb = 2 * c + e, lane = o + 32 * h;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) wq[((((long)pos * 3 + pl) * nkb + kb) * 64 + lane) * 8 + j] = (uint16_t)(b[pl] >> 16);
+  }
+  block_sum<2, 256>(acc, red);
+  if (threadIdx.x == 0) {
+    S[pos * kCout + o] = (float)acc[0];
+    b2[pos * kCout + o] = (float)((bias ? (double)bias[o] : 0.0) + acc[1]);
+  }
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------------------
+struct FwdArgs {
+  ObsGeom g;
+  const uint4* wq;  // [P][3][KP/16][64] fragments
+  const float* S;   // [P][32]
+  const float* b2;  // [P][32]
+  float* y;         // [n][P][32]
+  int P, nsplit, act;
+};
+
+// One workgroup = one output position x one range of samples.  The position's folded weights (3 planes, 48 KB) sit in
+// LDS in fragment order; every wavefront walks its own 32-sample tiles: 16-byte loads of the raw patch bytes straight
+// into registers (no staging: a tile's bytes are used by this wavefront only), bytes -> bf16 in registers, 3 MFMAs per
+// 16 k-values (A = weights from LDS, rows = output channels; B = the samples' bytes), LayerNorm + bias + activation on
+// the accumulators, float4 stores.  The next tile's loads are issued before the current tile's arithmetic.
+template <int KP>
+__global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
+  constexpr int NKB = KP / 16, NC = KP / 32;
+  __shared__ uint4 Wl[3 * NKB * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const unsigned lid = xcd_contiguous_id();
+  const int split = lid / a.P, pos = lid % a.P;  // positions fastest: neighbours on an XCD read the same samples
+  {
+    const uint4* src = a.wq + (long)pos * 3 * NKB * 64;
+#pragma unroll
+    for (int i = 0; i < 3 * NKB * 64 / 256; ++i) Wl[tid + 256 * i] = src[tid + 256 * i];
+  }
+  float Sr[16], Br[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = 8 * (r >> 2) + (r & 3) + 4 * h;
+    Sr[r] = a.S[pos * kCout + o];
+    Br[r] = a.b2[pos * kCout + o];
+  }
+  __syncthreads();
+  const long ntiles = (a.g.n + 31) / 32;
+  const long t0 = ntiles * split / a.nsplit, t1 = ntiles * (split + 1) / a.nsplit;
+  const int oy = pos / a.g.OW, ox = pos % a.g.OW;
+  const long posoff = ((long)(oy * a.g.W + ox) * a.g.stride) * a.g.Cin;
+  int poff[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) poff[c] = patch_off(a.g, 32 * c + 16 * h);
+  const long ldy = (long)a.P * kCout;
+
+  uint4 raw[2][NC];
+  float rs[2], mr[2];
+  auto issue = [&](int set, long tile) {
+    long n = tile * 32 + l31;
+    if (n >= a.g.n) n = a.g.n - 1;  // clamped: the loads stay in bounds, the stores of such rows are masked
+    const uint8_t* rowp = a.g.frames + n * a.g.img_stride + posoff;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) raw[set][c] = *reinterpret_cast<const uint4*>(rowp + poff[c]);
+    const float r = a.g.rstd[n];
+    rs[set] = r;
+    mr[set] = -a.g.mean[n] * r;
+  };
+  auto compute = [&](int set, long tile) {
+    // the weight fragments are re-read from LDS for every tile: keeping them in registers (192 of them) would leave
+    // one wavefront per SIMD, and this kernel lives on loads in flight.  The barrier keeps the compiler from hoisting.
+    asm volatile("" ::: "memory");
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const uint4 q = raw[set][c];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bf16x8 xf = e == 0 ? bytes_to_bf16x8(q.x, q.y) : bytes_to_bf16x8(q.z, q.w);
+        const int kb = 2 * c + e;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          union { uint4 u; bf16x8 v; } wf;
+          wf.u = Wl[(pl * NKB + kb) * 64 + lane];
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.v, xf, acc, 0, 0, 0);
+        }
+      }
+    }
+    // D[o][n]: this lane holds sample n = tile * 32 + l31, output channels 8g + 4h + (0..3) in registers 4g .. 4g+3
+    const long n = tile * 32 + l31;
+    if (n < a.g.n) {
+      float* yp = a.y + n * ldy + (long)pos * kCout + 4 * h;
+      const float r_s = rs[set], m_r = mr[set];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = fmaf(r_s, acc[4 * g4 + i], fmaf(m_r, Sr[4 * g4 + i], Br[4 * g4 + i]));
+          if (a.act == 1) v[i] = fmaxf(v[i], 0.f);
+          else if (a.act == 2) v[i] = tanhf(v[i]);
+        }
+        *reinterpret_cast<float4*>(yp + 8 * g4) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  };
+  long t = t0 + wave;
+  if (t < t1) issue(0, t);
+  for (; t < t1; t += 8) {
+    const long tn = t + 4;
+    if (tn < t1) issue(1, tn);
+    compute(0, t);
+    if (tn >= t1) break;
+    if (tn + 4 < t1) issue(0, tn + 4);
+    compute(1, tn);
+  }
+}
+
+// ---- backward: Q[pos][o][k] (+ split-K slabs), R[pos][o] += sum dz, C[pos][o] += sum dz' mean -----------------------------
+struct BwdArgs {
+  ObsGeom g;
+  const float* dz;  // [n][P][32]
+  float* Q;         // [nsplit][P][32][KP] (slabs) or [P][32][KP]
+  long slab;
+  float* R;         // [P][32], atomically accumulated
+  float* C;         // [P][32], atomically accumulated
+  int P, nsplit;
+};
+
+// One workgroup = one output position x one range of samples; K-steps of 32 samples.  Both operands are contiguous
+// along the OUTPUT index in memory (dz rows of 32 channels, patch rows of KP bytes) while the MFMA wants 8 consecutive
+// k (= samples) per lane: the tiles go to LDS as they come -- [sample][channel] bf16 (three planes of dz') and
+// [sample][patch byte] bf16 -- and the fragments are fetched with ds_read_b64_tr_b16, the transposing LDS read of
+// gfx950 (4 rows x 16 columns per 16 lanes, delivered column-major): no register transposes, no scalar LDS stores.
+// Wavefront w owns patch columns 64 w .. 64 w + 63 (two 32 x 32 accumulator tiles); all wavefronts share the dz' tile.
+template <int KP>
+__global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
+  constexpr int KS = 32;                       // samples per K-step
+  constexpr int A_BYTES = KS * kCout * 2;      // one plane of dz': [32 samples][32 channels] bf16, 64-byte rows
+  constexpr int B_BYTES = KS * KP * 2;         // [32 samples][KP] bf16, KP * 2-byte rows, 16-byte chunks XOR-swizzled
+  constexpr int BUF = 3 * A_BYTES + B_BYTES;
+  constexpr int NBQ = KP / 128;                // 16-byte chunks of patch bytes per thread and K-step (8 threads per sample)
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const unsigned lid = xcd_contiguous_id();
+  const int split = lid / a.P, pos = lid % a.P;
+  const long nsteps_all = (a.g.n + KS - 1) / KS;
+  const long s0 = nsteps_all * split / a.nsplit, s1 = nsteps_all * (split + 1) / a.nsplit;
+  const int oy = pos / a.g.OW, ox = pos % a.g.OW;
+  const long posoff = ((long)(oy * a.g.W + ox) * a.g.stride) * a.g.Cin;
+  const long ldz = (long)a.P * kCout;
+
+  // staging roles: thread -> sample row sr = tid / 8 of the K-step, 4 channels o4 of dz, NBQ 16-byte patch chunks
+  const int sr = tid >> 3, sub = tid & 7;
+  int boff[NBQ];
+#pragma unroll
+  for (int i = 0; i < NBQ; ++i) boff[i] = patch_off(a.g, 16 * (sub + 8 * i));
+  float4 dzr;
+  uint4 xb[NBQ];
+  float s_rs = 0.f, s_mean = 0.f;
+  float rsum[4] = {0.f, 0.f, 0.f, 0.f}, csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  auto gload = [&](long step) {
+    const long n = step * KS + sr;
+    const bool ok = n < a.g.n;
+    const long nn = ok ? n : a.g.n - 1;
+    dzr = ok ? *reinterpret_cast<const float4*>(a.dz + nn * ldz + (long)pos * kCout + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint8_t* rowp = a.g.frames + nn * a.g.img_stride + posoff;
+#pragma unroll
+    for (int i = 0; i < NBQ; ++i) xb[i] = *reinterpret_cast<const uint4*>(rowp + boff[i]);
+    s_rs = ok ? a.g.rstd[nn] : 0.f;  // rows past the end contribute zeros (dz' = 0)
+    s_mean = a.g.mean[nn];
+  };
+  auto lstore = [&](uint8_t* buf) {
+    const float d[4] = {dzr.x, dzr.y, dzr.z, dzr.w};
+    uint32_t pl[3][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float ds = d[i] * s_rs;
+      rsum[i] += d[i];
+      csum[i] = fmaf(ds, s_mean, csum[i]);
+      split3(ds, pl[0][i], pl[1][i], pl[2][i]);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      *reinterpret_cast<uint2*>(buf + p * A_BYTES + sr * (kCout * 2) + sub * 8) =
+          make_uint2(pack_hi(pl[p][0], pl[p][1]), pack_hi(pl[p][2], pl[p][3]));
+    uint8_t* bb = buf + 3 * A_BYTES + sr * (KP * 2);
+#pragma unroll
+    for (int i = 0; i < NBQ; ++i) {
+      // patch bytes 16 j .. 16 j + 15 (j = sub + 8 i) -> bf16 columns: 32 bytes = chunks 2 j, 2 j + 1 of the row
+      const int j = sub + 8 * i;
+      union { bf16x8 v; uint4 u; } lo, hi;
+      lo.v = bytes_to_bf16x8(xb[i].x, xb[i].y);
+      hi.v = bytes_to_bf16x8(xb[i].z, xb[i].w);
+      const int sw = (sr & 3) << 2;  // rows 4 apart in time share banks otherwise: see the transposed reads below
+      *reinterpret_cast<uint4*>(bb + 16 * ((2 * j) ^ sw)) = lo.u;
+      *reinterpret_cast<uint4*>(bb + 16 * ((2 * j + 1) ^ sw)) = hi.u;
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // transposed-read addresses.  ds_read_b64_tr_b16: in each group of 16 lanes, lane 4 q + p supplies the address of
+  // row q, columns 4 p .. 4 p + 3 of a 4 x 16 block; lane i of the group receives column i (4 rows).  For the
+  // 32 x 32 x 16 operand a lane with half h needs k-rows 8 h .. 8 h + 7 of its column: two reads (rows +0..3, +4..7).
+  const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int col0 = 16 * (grp & 1) + 4 * p;  // first of the 4 columns this lane addresses, within a 32-column tile
+  auto a_addr = [&](const uint8_t* buf, int plane, int kb, int r) {
+    const int row = 16 * kb + 8 * h + 4 * r + q;
+    return buf + plane * A_BYTES + row * (kCout * 2) + col0 * 2;
+  };
+  auto b_addr = [&](const uint8_t* buf, int jt, int kb, int r) {
+    const int row = 16 * kb + 8 * h + 4 * r + q;
+    const int colb = (64 * wave + 32 * jt + col0) * 2;  // byte offset of the column inside the row
+    const int ch = colb >> 4;
+    return buf + 3 * A_BYTES + row * (KP * 2) + 16 * (ch ^ ((row & 3) << 2)) + (colb & 15);
+  };
+  auto trread = [&](const uint8_t* p0, const uint8_t* p1) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+    return u.v;
+  };
+
+  if (s0 < s1) {
+    gload(s0);
+    lstore(lds);
+    if (s0 + 1 < s1) gload(s0 + 1);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (long s = s0; s < s1; ++s) {
+    const uint8_t* buf = lds + cur * BUF;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 bf[2];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) bf[jt] = trread(b_addr(buf, jt, kb, 0), b_addr(buf, jt, kb, 1));
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const bf16x8 af = trread(a_addr(buf, pl, kb, 0), a_addr(buf, pl, kb, 1));
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[jt], acc[jt], 0, 0, 0);
+      }
+      if (kb == 0 && s + 1 < s1) {  // tile s+1: registers -> the other buffer (its readers left at the last barrier)
+        lstore(lds + (cur ^ 1) * BUF);
+        if (s + 2 < s1) gload(s + 2);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // column sums of dz (R) and the mean correction (C): the 32 threads that staged the same 4 channels combine in LDS
+  {
+    float* red = reinterpret_cast<float*>(lds);  // the tiles are dead after the loop's last barrier
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[tid * 8 + i] = rsum[i];
+      red[tid * 8 + 4 + i] = csum[i];
+    }
+    __syncthreads();
+    if (tid < 64) {  // tid = (which << 5) | channel
+      const int ch = tid & 31, which = tid >> 5;
+      float t = 0.f;
+      for (int r = 0; r < 32; ++r) t += red[(r * 8 + (ch >> 2)) * 8 + which * 4 + (ch & 3)];
+      atomicAdd((which ? a.C : a.R) + pos * kCout + ch, t);
+    }
+  }
+  // D[o][k]: registers 4g .. 4g+3 hold channels 8g + 4h + (0..3) of patch column 64 wave + 32 jt + l31
+  float* qo = a.Q + (long)split * a.slab + (long)pos * kCout * KP;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = 8 * (r >> 2) + (r & 3) + 4 * h;
+      qo[(long)o * KP + 64 * wave + 32 * jt + l31] = acc[jt][r];
+    }
+}
+#endif  // __HIPCC__
+
+}  // namespace srlobs

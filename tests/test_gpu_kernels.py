@@ -672,13 +672,30 @@ def test_conv2d_obs_implicit(n, C, H, k, s, Cout, u8):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("n,u8", [(5, True), (70, True), (3, False)])
-def test_conv2d_obs_space_to_depth_path(n, u8):
-    """Strided first layer on the space-to-depth'd observation == the planar convolution (Atari geometry)."""
+def _frames(rng, n, C, H, kind):
+    """uint8 frame stacks: uniform noise, or Atari-like (a flat background with a few objects: small variance around a
+    large mean -- what stresses the bf16 path's mean correction, obs_bf16.h), or nearly black."""
+    if kind == "noise":
+        return rng.integers(0, 256, (n, C, H, H), dtype=np.uint8)
+    bg = 87 if kind == "pong" else 0
+    obs = np.full((n, C, H, H), bg, dtype=np.uint8)
+    for i in range(n):
+        for _ in range(6):
+            y, x, hh, ww = rng.integers(0, H - 8), rng.integers(0, H - 8), rng.integers(1, 8), rng.integers(1, 8)
+            obs[i, :, y:y + hh, x:x + ww] = rng.integers(100, 256)
+    return obs
+
+
+@pytest.mark.parametrize("n,u8,kind", [(5, True, "noise"), (70, True, "noise"), (3, False, "noise"), (200, True, "pong"),
+                                       (1100, True, "noise"), (96, True, "black")])
+def test_conv2d_obs_space_to_depth_path(n, u8, kind):
+    """Strided first layer on the space-to-depth'd observation == the planar convolution (Atari geometry).  uint8 frames
+    with n >= 32 take the bf16 matrix-core kernels (obs_bf16.h: bytes x three exact bf16 planes); the others the float32
+    MFMA kernels.  Both against float64 torch."""
     from srl_amd.algorithm.netspec import ParamInfo
     rng = np.random.default_rng(n)
     C, H, k, s, Cout = 4, 84, 8, 4, 32
-    obs = rng.integers(0, 256, (n, C, H, H), dtype=np.uint8)
+    obs = _frames(rng, n, C, H, kind)
     if not u8:
         obs = obs.astype(np.float32) / 3
     gamma = (1 + 0.1 * rng.standard_normal((C, H, H))).astype(np.float32)
@@ -730,3 +747,21 @@ def test_conv2d_obs_space_to_depth_path(n, u8):
     for g_, ref, name in zip(got, (tw.grad, tbias.grad, tg.grad, tb.grad), ("dw", "db", "dgamma", "dbeta")):
         assert rel_close(g_.numpy(), ref.numpy(), 2e-5, scale=sc if name in ("dw", "db") else float(np.sqrt(n))), name
     torch.cuda.synchronize()
+    if u8 and n >= 32:  # the two first-layer implementations against each other: same bytes, same weights
+        import os
+        os.environ["SRL_OBS_BF16"] = "0"
+        try:
+            y3 = torch.full((n, OH, OH, Cout), np.nan, device=DEV)
+            hip.conv2d_obs_fwd(d, s2d.data_ptr(), u8, mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), dbt.data_ptr(),
+                               dw_.data_ptr(), db_.data_ptr(), y3.data_ptr(), channels_last=True, ws_ptr=fws.data_ptr())
+            outs3 = [torch.zeros_like(o) for o in outs]
+            hip.conv2d_obs_bwd(d, s2d.data_ptr(), u8, mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), dbt.data_ptr(),
+                               dw_.data_ptr(), ddz.data_ptr(), *[o.data_ptr() for o in outs3], ws.data_ptr(), channels_last=True)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["SRL_OBS_BF16"]
+        ref64 = yref.permute(0, 2, 3, 1).detach().numpy()
+        e_bf16, e_f32 = np.abs(y2.cpu().numpy() - ref64).max(), np.abs(y3.cpu().numpy() - ref64).max()
+        assert e_bf16 <= max(4 * e_f32, 2e-6), (e_bf16, e_f32)  # no worse than the float32 MFMA chain, up to noise
+        for a_, b_, name in zip(outs, outs3, ("dw", "db", "dgamma", "dbeta")):
+            assert rel_close(a_.cpu().numpy(), b_.cpu().numpy(), 2e-5, scale=sc if name in ("dw", "db") else float(np.sqrt(n))), name
