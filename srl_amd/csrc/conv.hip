@@ -491,7 +491,7 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
     a.wq = reinterpret_cast<const uint4*>(wq);
     a.S = S; a.b2 = b2; a.y = y; a.P = P; a.act = d->act;
     a.nsplit = obs_bf16_split(d->n, P, 3);
-    hipLaunchKernelGGL(srlobs::obs_fwd_bf16_kernel<256>, dim3((unsigned)(P * a.nsplit)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(srlobs::obs_fwd_bf16_kernel<256>, dim3(srlobs::xcd_position_grid(P, a.nsplit)), dim3(256), 0, st, a);
     SRL_LAUNCH_CHECK();
     return 0;
   }
@@ -575,7 +575,7 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
     a.nsplit = obs_bf16_split(d->n, P, 3);
     a.Q = a.nsplit > 1 ? slabs : Q;
     a.slab = (long)P * d->Cout * Kp;
-    hipLaunchKernelGGL(srlobs::obs_bwd_bf16_kernel<256>, dim3((unsigned)(P * a.nsplit)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(srlobs::obs_bwd_bf16_kernel<256>, dim3(srlobs::xcd_position_grid(P, a.nsplit)), dim3(256), 0, st, a);
     SRL_LAUNCH_CHECK();
     if (a.nsplit > 1) {
       reduce_slabs(st, slabs, a.nsplit, (long)P, (long)d->Cout, Kp, Q, Kp, (long)d->Cout * Kp, 0);

@@ -10,10 +10,13 @@
 // float32 accumulations (3 per 16 k-values instead of 16 for the float32 FMA chain).  3 bf16 MFMAs (32 cycles each)
 // replace 8 float32 MFMAs (64 cycles each) per 32x32x16 block: 5.3x fewer matrix-pipe cycles.
 //
-// The whole-observation LayerNorm (x - mean_n) * rstd_n is taken out of the contraction, which then sees raw bytes:
-//   forward   y[n,pos,o] = act( rstd_n * ( sum_k x[n,pos,k] wg[pos,o,k]  -  mean_n * S[pos,o] ) + b2[pos,o] )
+// The whole-observation LayerNorm (x - mean_n) * rstd_n is taken out of the contraction, which sees the bytes minus an
+// INTEGER centre c_n = round(mean_n): x - c_n is an integer of magnitude <= 255, still exact in bf16, and what is left
+// outside, (mean_n - c_n) in [-0.5, 0.5], is too small to cancel against anything (with raw bytes a flat Atari
+// background -- large mean, small variance -- cost several digits: sum x w and mean * sum w nearly cancel):
+//   forward   y[n,pos,o] = act( rstd_n * ( sum_k (x[n,pos,k] - c_n) wg[pos,o,k]  -  (mean_n - c_n) S[pos,o] ) + b2[pos,o] )
 //             wg = w * gamma (LayerNorm affine folded per output position), S = sum_k wg, b2 = bias + w . beta
-//   backward  Q[pos,o,k] = sum_n dz'[n,pos,o] x[n,pos,k]  -  C[pos,o],   dz' = dz * rstd_n,  C = sum_n dz' mean_n
+//   backward  Q[pos,o,k] = sum_n dz'[n,pos,o] (x[n,pos,k] - c_n)  -  C[pos,o],  dz' = dz rstd_n,  C = sum_n dz' (mean_n - c_n)
 //             (Q is what conv.hip's finalisation kernels turn into dW, dgamma, dbeta; R = sum_n dz as before)
 // Layout requirements (srl_conv2d_obs_* fall back to the float32 kernels otherwise): uint8 channels-last frames (the
 // space-to-depth'd stack), Cout == 32, patch length Kp == 256 bytes made of runs (KW * Cin bytes) that are a power of
@@ -52,10 +55,10 @@ __device__ __forceinline__ void split3(float v, uint32_t& b0, uint32_t& b1, uint
 // [lo.hi16, hi.hi16]: two bf16 in one dword from the high halves of two float32 words
 __device__ __forceinline__ uint32_t pack_hi(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
-// 8 bytes (two dwords) -> 8 bf16, element j = byte j
-__device__ __forceinline__ bf16x8 bytes_to_bf16x8(uint32_t d0, uint32_t d1) {
+// 8 bytes (two dwords) -> 8 bf16, element j = byte j minus the (integer-valued) centre c
+__device__ __forceinline__ bf16x8 bytes_to_bf16x8(uint32_t d0, uint32_t d1, float c) {
   union { uint32_t u[4]; bf16x8 v; } r;
-#define SRL_B2F(d, i) __float_as_uint((float)(((d) >> (8 * (i))) & 255u))
+#define SRL_B2F(d, i) __float_as_uint((float)(((d) >> (8 * (i))) & 255u) - c)
   r.u[0] = pack_hi(SRL_B2F(d0, 0), SRL_B2F(d0, 1));
   r.u[1] = pack_hi(SRL_B2F(d0, 2), SRL_B2F(d0, 3));
   r.u[2] = pack_hi(SRL_B2F(d1, 0), SRL_B2F(d1, 1));
@@ -69,11 +72,20 @@ __device__ __forceinline__ int patch_off(const ObsGeom& g, int b) {
   return (b >> g.run_shift) * g.run_stride + (b & ((1 << g.run_shift) - 1));
 }
 
-// Workgroup ids are dealt round-robin to the 8 XCDs: renumber so that every XCD owns one contiguous run of logical ids
-__device__ __forceinline__ unsigned xcd_contiguous_id() {
-  const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  return xcd * q + (xcd < r ? xcd : r) + slot;
+// (position, sample range) of a workgroup.  Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its
+// own 4 MiB L2.  Every XCD gets its own group of ceil(P / 8) consecutive output positions -- neighbouring positions
+// read the same frame rows, so the group's workgroups share them through that L2 -- and ALL XCDs walk the sample
+// ranges in the same order, so that the frames in flight chip-wide are one or two ranges (tens of MB: they stay in the
+// 256 MB Infinity Cache for the other XCDs' overlapping rows) instead of a different range per XCD.
+// grid = 8 * ceil(P / 8) * nsplit; returns false for the padding ids of a last, shorter group.
+__device__ __forceinline__ bool xcd_position_split(int P, int& pos, int& split) {
+  const int per = (P + 7) >> 3;
+  const int xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  pos = xcd * per + slot % per;
+  split = slot / per;
+  return pos < P && slot % per < per;
 }
+inline unsigned xcd_position_grid(int P, int nsplit) { return 8u * (unsigned)((P + 7) / 8) * (unsigned)nsplit; }
 
 // ---- fold + split: wq[pos][plane][kb][lane][8] bf16 (MFMA A-operand fragments, rows = output channels) -----------------
 // MFMA k-block kb = 2c + e of a lane with half h covers patch bytes 32c + 16h + 8e + (0..7): a lane's 16-byte load of
@@ -129,8 +141,8 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
   constexpr int NKB = KP / 16, NC = KP / 32;
   __shared__ uint4 Wl[3 * NKB * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const unsigned lid = xcd_contiguous_id();
-  const int split = lid / a.P, pos = lid % a.P;  // positions fastest: neighbours on an XCD read the same samples
+  int pos, split;
+  if (!xcd_position_split(a.P, pos, split)) return;
   {
     const uint4* src = a.wq + (long)pos * 3 * NKB * 64;
 #pragma unroll
@@ -154,16 +166,18 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
   const long ldy = (long)a.P * kCout;
 
   uint4 raw[2][NC];
-  float rs[2], mr[2];
+  float rs[2], mr[2], cen[2];
   auto issue = [&](int set, long tile) {
     long n = tile * 32 + l31;
     if (n >= a.g.n) n = a.g.n - 1;  // clamped: the loads stay in bounds, the stores of such rows are masked
     const uint8_t* rowp = a.g.frames + n * a.g.img_stride + posoff;
 #pragma unroll
     for (int c = 0; c < NC; ++c) raw[set][c] = *reinterpret_cast<const uint4*>(rowp + poff[c]);
-    const float r = a.g.rstd[n];
+    const float r = a.g.rstd[n], m = a.g.mean[n];
+    const float c = rintf(m);  // integer centre in [0, 255]
     rs[set] = r;
-    mr[set] = -a.g.mean[n] * r;
+    cen[set] = c;
+    mr[set] = -(m - c) * r;
   };
   auto compute = [&](int set, long tile) {
     // the weight fragments are re-read from LDS for every tile: keeping them in registers (192 of them) would leave
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
       const uint4 q = raw[set][c];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const bf16x8 xf = e == 0 ? bytes_to_bf16x8(q.x, q.y) : bytes_to_bf16x8(q.z, q.w);
+        const bf16x8 xf = e == 0 ? bytes_to_bf16x8(q.x, q.y, cen[set]) : bytes_to_bf16x8(q.z, q.w, cen[set]);
         const int kb = 2 * c + e;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
@@ -243,8 +257,8 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
   constexpr int NBQ = KP / 128;                // 16-byte chunks of patch bytes per thread and K-step (8 threads per sample)
   __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const unsigned lid = xcd_contiguous_id();
-  const int split = lid / a.P, pos = lid % a.P;
+  int pos, split;
+  if (!xcd_position_split(a.P, pos, split)) return;
   const long nsteps_all = (a.g.n + KS - 1) / KS;
   const long s0 = nsteps_all * split / a.nsplit, s1 = nsteps_all * (split + 1) / a.nsplit;
   const int oy = pos / a.g.OW, ox = pos % a.g.OW;
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
   for (int i = 0; i < NBQ; ++i) boff[i] = patch_off(a.g, 16 * (sub + 8 * i));
   float4 dzr;
   uint4 xb[NBQ];
-  float s_rs = 0.f, s_mean = 0.f;
+  float s_rs = 0.f, s_mean = 0.f, s_cen = 0.f;
   float rsum[4] = {0.f, 0.f, 0.f, 0.f}, csum[4] = {0.f, 0.f, 0.f, 0.f};
 
   auto gload = [&](long step) {
@@ -271,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
     for (int i = 0; i < NBQ; ++i) xb[i] = *reinterpret_cast<const uint4*>(rowp + boff[i]);
     s_rs = ok ? a.g.rstd[nn] : 0.f;  // rows past the end contribute zeros (dz' = 0)
     s_mean = a.g.mean[nn];
+    s_cen = rintf(s_mean);  // integer centre in [0, 255]
   };
   auto lstore = [&](uint8_t* buf) {
     const float d[4] = {dzr.x, dzr.y, dzr.z, dzr.w};
@@ -279,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
     for (int i = 0; i < 4; ++i) {
       const float ds = d[i] * s_rs;
       rsum[i] += d[i];
-      csum[i] = fmaf(ds, s_mean, csum[i]);
+      csum[i] = fmaf(ds, s_mean - s_cen, csum[i]);
       split3(ds, pl[0][i], pl[1][i], pl[2][i]);
     }
 #pragma unroll
@@ -292,8 +307,8 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
       // patch bytes 16 j .. 16 j + 15 (j = sub + 8 i) -> bf16 columns: 32 bytes = chunks 2 j, 2 j + 1 of the row
       const int j = sub + 8 * i;
       union { bf16x8 v; uint4 u; } lo, hi;
-      lo.v = bytes_to_bf16x8(xb[i].x, xb[i].y);
-      hi.v = bytes_to_bf16x8(xb[i].z, xb[i].w);
+      lo.v = bytes_to_bf16x8(xb[i].x, xb[i].y, s_cen);
+      hi.v = bytes_to_bf16x8(xb[i].z, xb[i].w, s_cen);
       const int sw = (sr & 3) << 2;  // rows 4 apart in time share banks otherwise: see the transposed reads below
       *reinterpret_cast<uint4*>(bb + 16 * ((2 * j) ^ sw)) = lo.u;
       *reinterpret_cast<uint4*>(bb + 16 * ((2 * j + 1) ^ sw)) = hi.u;
