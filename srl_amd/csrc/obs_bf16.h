@@ -140,6 +140,7 @@ template <int KP>
 __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
   constexpr int NKB = KP / 16, NC = KP / 32;
   __shared__ uint4 Wl[3 * NKB * 64];
+  __shared__ __attribute__((aligned(16))) float SBl[2 * kCout];  // S[pos][0..31], b2[pos][0..31]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   int pos, split;
   if (!xcd_position_split(a.P, pos, split)) return;
@@ -147,13 +148,8 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
     const uint4* src = a.wq + (long)pos * 3 * NKB * 64;
 #pragma unroll
     for (int i = 0; i < 3 * NKB * 64 / 256; ++i) Wl[tid + 256 * i] = src[tid + 256 * i];
-  }
-  float Sr[16], Br[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int o = 8 * (r >> 2) + (r & 3) + 4 * h;
-    Sr[r] = a.S[pos * kCout + o];
-    Br[r] = a.b2[pos * kCout + o];
+    if (tid < kCout) SBl[tid] = a.S[pos * kCout + tid];
+    else if (tid < 2 * kCout) SBl[tid] = a.b2[pos * kCout + tid - kCout];
   }
   __syncthreads();
   const long ntiles = (a.g.n + 31) / 32;
@@ -179,27 +175,36 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
     cen[set] = c;
     mr[set] = -(m - c) * r;
   };
+  // weight fragments of one 32-byte chunk of the patch (2 k-blocks x 3 planes), double-buffered in registers: the LDS
+  // reads of chunk c + 1 are issued before the MFMAs of chunk c (left to itself the compiler reads one fragment,
+  // waits, multiplies, and pays the LDS latency 48 times a tile).  The fragments are re-read for every tile: holding
+  // all 48 would cost 192 registers, i.e. leave one wavefront per SIMD, and this kernel lives on loads in flight.
+  uint4 wfr[2][6];
+  auto wload = [&](int set, int c) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) wfr[set][3 * e + pl] = Wl[(pl * NKB + 2 * c + e) * 64 + lane];
+  };
   auto compute = [&](int set, long tile) {
-    // the weight fragments are re-read from LDS for every tile: keeping them in registers (192 of them) would leave
-    // one wavefront per SIMD, and this kernel lives on loads in flight.  The barrier keeps the compiler from hoisting.
-    asm volatile("" ::: "memory");
+    asm volatile("" ::: "memory");  // keeps the compiler from hoisting the (tile-invariant) fragment reads out of the loop
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    wload(0, 0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
+      if (c + 1 < NC) wload((c + 1) & 1, c + 1);
       const uint4 q = raw[set][c];
+      const bf16x8 x0 = bytes_to_bf16x8(q.x, q.y, cen[set]), x1 = bytes_to_bf16x8(q.z, q.w, cen[set]);
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const bf16x8 xf = e == 0 ? bytes_to_bf16x8(q.x, q.y, cen[set]) : bytes_to_bf16x8(q.z, q.w, cen[set]);
-        const int kb = 2 * c + e;
+      for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
           union { uint4 u; bf16x8 v; } wf;
-          wf.u = Wl[(pl * NKB + kb) * 64 + lane];
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.v, xf, acc, 0, 0, 0);
+          wf.u = wfr[c & 1][3 * e + pl];
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.v, e ? x1 : x0, acc, 0, 0, 0);
         }
-      }
     }
     // D[o][n]: this lane holds sample n = tile * 32 + l31, output channels 8g + 4h + (0..3) in registers 4g .. 4g+3
     const long n = tile * 32 + l31;
@@ -208,10 +213,13 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
       const float r_s = rs[set], m_r = mr[set];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 s4 = *reinterpret_cast<const float4*>(SBl + 8 * g4 + 4 * h);
+        const float4 b4 = *reinterpret_cast<const float4*>(SBl + kCout + 8 * g4 + 4 * h);
+        const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          v[i] = fmaf(r_s, acc[4 * g4 + i], fmaf(m_r, Sr[4 * g4 + i], Br[4 * g4 + i]));
+          v[i] = fmaf(r_s, acc[4 * g4 + i], fmaf(m_r, sv[i], bv[i]));
           if (a.act == 1) v[i] = fmaxf(v[i], 0.f);
           else if (a.act == 2) v[i] = tanhf(v[i]);
         }
@@ -270,31 +278,33 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
   int boff[NBQ];
 #pragma unroll
   for (int i = 0; i < NBQ; ++i) boff[i] = patch_off(a.g, 16 * (sub + 8 * i));
-  float4 dzr;
-  uint4 xb[NBQ];
-  float s_rs = 0.f, s_mean = 0.f, s_cen = 0.f;
+  // two register sets: the global loads of a K-step are issued TWO steps before its tile is written to LDS (one step
+  // of lead left the wavefronts parked on s_waitcnt: half of their cycles by the counters)
+  float4 dzr[2];
+  uint4 xb[2][NBQ];
+  float s_rs[2] = {0.f, 0.f}, s_mean[2] = {0.f, 0.f}, s_cen[2] = {0.f, 0.f};
   float rsum[4] = {0.f, 0.f, 0.f, 0.f}, csum[4] = {0.f, 0.f, 0.f, 0.f};
 
-  auto gload = [&](long step) {
+  auto gload = [&](int set, long step) {
     const long n = step * KS + sr;
     const bool ok = n < a.g.n;
     const long nn = ok ? n : a.g.n - 1;
-    dzr = ok ? *reinterpret_cast<const float4*>(a.dz + nn * ldz + (long)pos * kCout + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+    dzr[set] = ok ? *reinterpret_cast<const float4*>(a.dz + nn * ldz + (long)pos * kCout + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
     const uint8_t* rowp = a.g.frames + nn * a.g.img_stride + posoff;
 #pragma unroll
-    for (int i = 0; i < NBQ; ++i) xb[i] = *reinterpret_cast<const uint4*>(rowp + boff[i]);
-    s_rs = ok ? a.g.rstd[nn] : 0.f;  // rows past the end contribute zeros (dz' = 0)
-    s_mean = a.g.mean[nn];
-    s_cen = rintf(s_mean);  // integer centre in [0, 255]
+    for (int i = 0; i < NBQ; ++i) xb[set][i] = *reinterpret_cast<const uint4*>(rowp + boff[i]);
+    s_rs[set] = ok ? a.g.rstd[nn] : 0.f;  // rows past the end contribute zeros (dz' = 0)
+    s_mean[set] = a.g.mean[nn];
   };
-  auto lstore = [&](uint8_t* buf) {
-    const float d[4] = {dzr.x, dzr.y, dzr.z, dzr.w};
+  auto lstore = [&](int set, uint8_t* buf) {
+    const float d[4] = {dzr[set].x, dzr[set].y, dzr[set].z, dzr[set].w};
+    const float cen = rintf(s_mean[set]);  // integer centre in [0, 255]
     uint32_t pl[3][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float ds = d[i] * s_rs;
+      const float ds = d[i] * s_rs[set];
       rsum[i] += d[i];
-      csum[i] = fmaf(ds, s_mean - s_cen, csum[i]);
+      csum[i] = fmaf(ds, s_mean[set] - cen, csum[i]);
       split3(ds, pl[0][i], pl[1][i], pl[2][i]);
     }
 #pragma unroll
@@ -307,8 +317,8 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
       // patch bytes 16 j .. 16 j + 15 (j = sub + 8 i) -> bf16 columns: 32 bytes = chunks 2 j, 2 j + 1 of the row
       const int j = sub + 8 * i;
       union { bf16x8 v; uint4 u; } lo, hi;
-      lo.v = bytes_to_bf16x8(xb[i].x, xb[i].y, s_cen);
-      hi.v = bytes_to_bf16x8(xb[i].z, xb[i].w, s_cen);
+      lo.v = bytes_to_bf16x8(xb[set][i].x, xb[set][i].y, cen);
+      hi.v = bytes_to_bf16x8(xb[set][i].z, xb[set][i].w, cen);
       const int sw = (sr & 3) << 2;  // rows 4 apart in time share banks otherwise: see the transposed reads below
       *reinterpret_cast<uint4*>(bb + 16 * ((2 * j) ^ sw)) = lo.u;
       *reinterpret_cast<uint4*>(bb + 16 * ((2 * j + 1) ^ sw)) = hi.u;
@@ -344,15 +354,10 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
     return u.v;
   };
 
-  if (s0 < s1) {
-    gload(s0);
-    lstore(lds);
-    if (s0 + 1 < s1) gload(s0 + 1);
-  }
-  __syncthreads();
-  int cur = 0;
-  for (long s = s0; s < s1; ++s) {
-    const uint8_t* buf = lds + cur * BUF;
+  // one K-step on LDS buffer CUR (= parity of s - s0): MFMAs, with the staging of the following tiles in the middle
+  auto kstep = [&](auto cur_c, long s) {
+    constexpr int CUR = decltype(cur_c)::value;
+    const uint8_t* buf = lds + CUR * BUF;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       bf16x8 bf[2];
@@ -364,13 +369,23 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[jt], acc[jt], 0, 0, 0);
       }
-      if (kb == 0 && s + 1 < s1) {  // tile s+1: registers -> the other buffer (its readers left at the last barrier)
-        lstore(lds + (cur ^ 1) * BUF);
-        if (s + 2 < s1) gload(s + 2);
+      if (kb == 0 && s + 1 < s1) {  // tile s+1: registers (set CUR^1) -> the other buffer (its readers left at the last barrier)
+        lstore(CUR ^ 1, lds + (CUR ^ 1) * BUF);
+        if (s + 3 < s1) gload(CUR ^ 1, s + 3);  // ... and that register set takes the loads of tile s+3
       }
     }
     __syncthreads();
-    cur ^= 1;
+  };
+  if (s0 < s1) {
+    gload(0, s0);
+    lstore(0, lds);
+    if (s0 + 1 < s1) gload(1, s0 + 1);
+    if (s0 + 2 < s1) gload(0, s0 + 2);
+  }
+  __syncthreads();
+  for (long s = s0; s < s1; s += 2) {
+    kstep(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < s1) kstep(std::integral_constant<int, 1>{}, s + 1);
   }
 
   // column sums of dz (R) and the mean correction (C): the 32 threads that staged the same 4 channels combine in LDS
