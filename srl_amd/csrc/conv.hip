@@ -491,7 +491,15 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
     a.wq = reinterpret_cast<const uint4*>(wq);
     a.S = S; a.b2 = b2; a.y = y; a.P = P; a.act = d->act;
     a.nsplit = obs_bf16_split(d->n, P, 3);
-    hipLaunchKernelGGL(srlobs::obs_fwd_bf16_kernel<256>, dim3(srlobs::xcd_position_grid(P, a.nsplit)), dim3(256), 0, st, a);
+    const char* dbg = getenv("SRL_OBS_DBG");  // timing experiments (wrong results): see obs_bf16.h
+    const dim3 grid(srlobs::xcd_position_grid(P, a.nsplit));
+    switch (dbg ? atoi(dbg) : 0) {
+      case 3: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 3>), grid, dim3(256), 0, st, a); break;
+      case 4: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 4>), grid, dim3(256), 0, st, a); break;
+      case 8: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 8>), grid, dim3(256), 0, st, a); break;
+      case 12: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 12>), grid, dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 0>), grid, dim3(256), 0, st, a);
+    }
     SRL_LAUNCH_CHECK();
     return 0;
   }

@@ -87,7 +87,7 @@ __device__ __forceinline__ bool xcd_position_split(int P, int& pos, int& split) 
 }
 inline unsigned xcd_position_grid(int P, int nsplit) { return 8u * (unsigned)((P + 7) / 8) * (unsigned)nsplit; }
 
-// ---- fold + split: wq[pos][plane][kb][lane][8] bf16 (MFMA A-operand fragments, rows = output channels) -----------------
+// ---- fold + split: wq[pos][plane][kb][lane][8] bf16 (MFMA B-operand fragments, columns = output channels) -------------
 // MFMA k-block kb = 2c + e of a lane with half h covers patch bytes 32c + 16h + 8e + (0..7): a lane's 16-byte load of
 // the patch feeds two consecutive k-blocks.  Any pairing of k-values works as long as both operands use the same one.
 template <class Index>
@@ -134,13 +134,16 @@ struct FwdArgs {
 // One workgroup = one output position x one range of samples.  The position's folded weights (3 planes, 48 KB) sit in
 // LDS in fragment order; every wavefront walks its own 32-sample tiles: 16-byte loads of the raw patch bytes straight
 // into registers (no staging: a tile's bytes are used by this wavefront only), bytes -> bf16 in registers, 3 MFMAs per
-// 16 k-values (A = weights from LDS, rows = output channels; B = the samples' bytes), LayerNorm + bias + activation on
-// the accumulators, float4 stores.  The next tile's loads are issued before the current tile's arithmetic.
-template <int KP>
+// 16 k-values (A = the samples' bytes, rows = samples; B = weights from LDS, columns = output channels), LayerNorm +
+// bias + activation on the accumulators, whole-line stores.  The next tile's loads are issued before the current
+// tile's arithmetic.
+// DBG (timing experiments only, wrong results; SRL_OBS_DBG): 1 = bytes reinterpreted instead of converted, 2 = no MFMAs,
+// 4 = no stores, 8 = the patch loads of every tile go to the first tile's rows (cache-hot)
+template <int KP, int DBG = 0>
 __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
   constexpr int NKB = KP / 16, NC = KP / 32;
   __shared__ uint4 Wl[3 * NKB * 64];
-  __shared__ __attribute__((aligned(16))) float SBl[2 * kCout];  // S[pos][0..31], b2[pos][0..31]
+  __shared__ __attribute__((aligned(16))) float rowl[4][2][2][32];  // [wave][register set][rstd | -(mean - c) rstd][row of the tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   int pos, split;
   if (!xcd_position_split(a.P, pos, split)) return;
@@ -148,9 +151,8 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
     const uint4* src = a.wq + (long)pos * 3 * NKB * 64;
 #pragma unroll
     for (int i = 0; i < 3 * NKB * 64 / 256; ++i) Wl[tid + 256 * i] = src[tid + 256 * i];
-    if (tid < kCout) SBl[tid] = a.S[pos * kCout + tid];
-    else if (tid < 2 * kCout) SBl[tid] = a.b2[pos * kCout + tid - kCout];
   }
+  const float S_o = a.S[pos * kCout + l31], b2_o = a.b2[pos * kCout + l31];  // this lane's output channel is l31
   __syncthreads();
   const long ntiles = (a.g.n + 31) / 32;
   const long t0 = ntiles * split / a.nsplit, t1 = ntiles * (split + 1) / a.nsplit;
@@ -161,81 +163,104 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
   for (int c = 0; c < NC; ++c) poff[c] = patch_off(a.g, 32 * c + 16 * h);
   const long ldy = (long)a.P * kCout;
 
-  uint4 raw[2][NC];
-  float rs[2], mr[2], cen[2];
-  auto issue = [&](int set, long tile) {
+  // The patch bytes of a tile sit in ONE register set: as soon as a 32-byte chunk has been converted its registers take
+  // the same chunk of the wavefront's NEXT tile, so the loads run a whole tile ahead at half the registers of two sets
+  // (which, with the fragment registers, would leave two wavefronts per SIMD instead of three).
+  uint4 raw[NC];
+  auto rowptr = [&](long tile) {
     long n = tile * 32 + l31;
     if (n >= a.g.n) n = a.g.n - 1;  // clamped: the loads stay in bounds, the stores of such rows are masked
-    const uint8_t* rowp = a.g.frames + n * a.g.img_stride + posoff;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) raw[set][c] = *reinterpret_cast<const uint4*>(rowp + poff[c]);
+    return a.g.frames + ((DBG & 8) ? (long)l31 : n) * a.g.img_stride + posoff;
+  };
+  // (rstd, -(mean - c) rstd) of the accumulator ROWS go through LDS for the wavefront's own later reads (a wavefront's
+  // LDS instructions execute in order; no other wavefront touches this slice); returns the integer centre c in [0, 255]
+  auto rowstats = [&](int set, long tile) {
+    long n = tile * 32 + l31;
+    if (n >= a.g.n) n = a.g.n - 1;
     const float r = a.g.rstd[n], m = a.g.mean[n];
-    const float c = rintf(m);  // integer centre in [0, 255]
-    rs[set] = r;
-    cen[set] = c;
-    mr[set] = -(m - c) * r;
+    const float c = rintf(m);
+    if (h == 0) {
+      rowl[wave][set][0][l31] = r;
+      rowl[wave][set][1][l31] = -(m - c) * r;
+    }
+    return c;
   };
-  // weight fragments of one 32-byte chunk of the patch (2 k-blocks x 3 planes), double-buffered in registers: the LDS
-  // reads of chunk c + 1 are issued before the MFMAs of chunk c (left to itself the compiler reads one fragment,
-  // waits, multiplies, and pays the LDS latency 48 times a tile).  The fragments are re-read for every tile: holding
-  // all 48 would cost 192 registers, i.e. leave one wavefront per SIMD, and this kernel lives on loads in flight.
-  uint4 wfr[2][6];
-  auto wload = [&](int set, int c) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) wfr[set][3 * e + pl] = Wl[(pl * NKB + 2 * c + e) * 64 + lane];
-  };
-  auto compute = [&](int set, long tile) {
+  auto compute = [&](int set, long tile, float cen, const uint8_t* next_row) {
     asm volatile("" ::: "memory");  // keeps the compiler from hoisting the (tile-invariant) fragment reads out of the loop
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    wload(0, 0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      if (c + 1 < NC) wload((c + 1) & 1, c + 1);
-      const uint4 q = raw[set][c];
-      const bf16x8 x0 = bytes_to_bf16x8(q.x, q.y, cen[set]), x1 = bytes_to_bf16x8(q.z, q.w, cen[set]);
+      uint4 wfr[6];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wfr[3 * e + pl] = Wl[(pl * NKB + 2 * c + e) * 64 + lane];
+      const uint4 q = raw[c];
+      bf16x8 x0, x1;
+      if (DBG & 1) {
+        union { uint4 u; bf16x8 v; } t0, t1;
+        t0.u = make_uint4(q.x, q.y, q.x, q.y);
+        t1.u = make_uint4(q.z, q.w, q.z, q.w);
+        x0 = t0.v, x1 = t1.v;
+      } else {
+        x0 = bytes_to_bf16x8(q.x, q.y, cen), x1 = bytes_to_bf16x8(q.z, q.w, cen);
+      }
+      if (next_row) raw[c] = *reinterpret_cast<const uint4*>(next_row + poff[c]);
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
           union { uint4 u; bf16x8 v; } wf;
-          wf.u = wfr[c & 1][3 * e + pl];
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.v, e ? x1 : x0, acc, 0, 0, 0);
+          wf.u = wfr[3 * e + pl];
+          if (DBG & 2) {
+            union { bf16x8 v; float f[4]; } xx;
+            xx.v = e ? x1 : x0;
+            acc[3 * e + pl] += __uint_as_float(wf.u.x) * xx.f[0];
+          } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e ? x1 : x0, wf.v, acc, 0, 0, 0);
+          }
         }
     }
-    // D[o][n]: this lane holds sample n = tile * 32 + l31, output channels 8g + 4h + (0..3) in registers 4g .. 4g+3
-    const long n = tile * 32 + l31;
-    if (n < a.g.n) {
-      float* yp = a.y + n * ldy + (long)pos * kCout + 4 * h;
-      const float r_s = rs[set], m_r = mr[set];
+    // D[n][o]: this lane holds output channel o = l31 of the samples tile * 32 + 8g + 4h + (0..3) in registers 4g .. 4g+3,
+    // so one store instruction writes two whole 128-byte rows of y (the channels of a sample at this position).  With the
+    // accumulator the other way round (rows = channels) every instruction wrote 32-byte pieces of 32 different lines:
+    // the stores alone then cost 0.25 ms of the kernel's 0.66.
+    __builtin_amdgcn_wave_barrier();
+    const long n0 = tile * 32;
+    const bool full = n0 + 32 <= a.g.n;  // wave-uniform: only the batch's last tile is ragged
+    float* yp = a.y + n0 * ldy + (long)pos * kCout + l31;
+    const int ldy32 = (int)ldy;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const float4 s4 = *reinterpret_cast<const float4*>(SBl + 8 * g4 + 4 * h);
-        const float4 b4 = *reinterpret_cast<const float4*>(SBl + kCout + 8 * g4 + 4 * h);
-        const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-        float v[4];
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 r4 = *reinterpret_cast<const float4*>(&rowl[wave][set][0][8 * g4 + 4 * h]);
+      const float4 m4 = *reinterpret_cast<const float4*>(&rowl[wave][set][1][8 * g4 + 4 * h]);
+      const float rv[4] = {r4.x, r4.y, r4.z, r4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[i] = fmaf(r_s, acc[4 * g4 + i], fmaf(m_r, sv[i], bv[i]));
-          if (a.act == 1) v[i] = fmaxf(v[i], 0.f);
-          else if (a.act == 2) v[i] = tanhf(v[i]);
-        }
-        *reinterpret_cast<float4*>(yp + 8 * g4) = make_float4(v[0], v[1], v[2], v[3]);
+      for (int i = 0; i < 4; ++i) {
+        float v = fmaf(rv[i], acc[4 * g4 + i], fmaf(mv[i], S_o, b2_o));
+        if (a.act == 1) v = fmaxf(v, 0.f);
+        else if (a.act == 2) v = tanhf(v);
+        const int row = 8 * g4 + 4 * h + i;
+        if ((full || n0 + row < a.g.n) && (!(DBG & 4) || v == 12345.f)) yp[row * ldy32] = v;
       }
     }
   };
   long t = t0 + wave;
-  if (t < t1) issue(0, t);
-  for (; t < t1; t += 8) {
-    const long tn = t + 4;
-    if (tn < t1) issue(1, tn);
-    compute(0, t);
-    if (tn >= t1) break;
-    if (tn + 4 < t1) issue(0, tn + 4);
-    compute(1, tn);
+  if (t < t1) {
+    const uint8_t* rp = rowptr(t);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) raw[c] = *reinterpret_cast<const uint4*>(rp + poff[c]);
+  }
+  float cen = t < t1 ? rowstats(0, t) : 0.f;
+  int set = 0;
+  for (; t < t1; t += 4) {
+    const bool more = t + 4 < t1;
+    const float cen_next = more ? rowstats(set ^ 1, t + 4) : 0.f;
+    compute(set, t, cen, more ? rowptr(t + 4) : nullptr);
+    cen = cen_next;
+    set ^= 1;
   }
 }
 
