@@ -386,6 +386,17 @@ int srl_adam_step(void* stream, float* p, const float* g, float* m, float* v, in
                   float max_norm, const double* sumsq, float* grad_norm_out,
                   const float* step_scalars);
 
+/* torch.optim.SGD / torch.optim.RMSprop on the flat buffer (modules/utils.py:268-286 accepts 'sgd' and 'rmsprop'
+ * with their torch keyword configurations), same clip / grad_scale / grad_norm_out conventions as srl_adam_step.
+ * SGD: momentum_buf may be NULL when momentum == 0; first_step != 0 initialises the buffer with the gradient
+ * (torch's first step).  RMSprop: momentum_buf NULL when momentum == 0, grad_avg NULL unless centered. */
+int srl_sgd_step(void* stream, float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
+                 float dampening, float weight_decay, int nesterov, int first_step, float grad_scale, float max_norm,
+                 const double* sumsq, float* grad_norm_out);
+int srl_rmsprop_step(void* stream, float* p, const float* g, float* square_avg, float* momentum_buf, float* grad_avg,
+                     int64_t n, float lr, float alpha, float eps, float weight_decay, float momentum, int centered,
+                     float grad_scale, float max_norm, const double* sumsq, float* grad_norm_out);
+
 /* ------------------------------------------------------------------------------------------------
  * Collectives (RCCL over xGMI), one process per GPU.  `comm` is an ncclComm_t behind void*; every
  * call is enqueued on `stream` and returns at once (stream-ordered like the kernels above).  librccl

@@ -40,10 +40,11 @@ class OracleMappo:
         self.ppo_epochs = g("ppo_epochs", 1)
         self.value_loss = g("value_loss", "mse")
         self.value_loss_config = g("value_loss_config", {})
-        assert g("optimizer", "adam") == "adam"
         self.popart = g("popart", False)
         assert not g("normalize_old_value", False), "oracle: normalize_old_value not restated"
-        self.optimizer = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], **g("optimizer_config", {}))
+        opt_cls = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "rmsprop": torch.optim.RMSprop,
+                   "sgd": torch.optim.SGD}[g("optimizer", "adam")]  # modules/utils.py:268-286
+        self.optimizer = opt_cls([p for p in net.parameters() if p.requires_grad], **g("optimizer_config", {}))
         self.version = -1
         self.frames = 0
 

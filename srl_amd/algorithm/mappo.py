@@ -141,15 +141,38 @@ class MultiAgentPPO(PytorchTrainer):
         if self.burn_in_steps and self.vtrace:
             raise NotImplementedError("burn-in together with V-trace is not on the HIP path")
 
+        # optimiser (modules/utils.py:268-286: torch.optim.{Adam, AdamW, RMSprop, SGD}(**optimizer_config))
         name = g('optimizer', 'adam')
-        if name not in ('adam', 'adamw'):
-            raise NotImplementedError(f"optimizer `{name}`: only adam / adamw are implemented on the HIP path")
+        if name not in ('adam', 'adamw', 'rmsprop', 'sgd'):
+            raise AssertionError(f"Optimizer name {name} does not match any implemented optimizers "
+                                 "(['adam', 'rmsprop', 'sgd', 'adamw']).")
         cfg = dict(g('optimizer_config', {}))
+        self._opt = name
         self._adamw = name == 'adamw'
-        self._lr = cfg.pop("lr", 1e-3)
-        self._betas = tuple(cfg.pop("betas", (0.9, 0.999)))
-        self._eps = cfg.pop("eps", 1e-8)
-        self._weight_decay = cfg.pop("weight_decay", 1e-2 if self._adamw else 0.0)
+        self._betas, self._eps = (0.9, 0.999), 1e-8
+        if name in ('adam', 'adamw'):
+            self._lr = cfg.pop("lr", 1e-3)
+            self._betas = tuple(cfg.pop("betas", (0.9, 0.999)))
+            self._eps = cfg.pop("eps", 1e-8)
+            self._weight_decay = cfg.pop("weight_decay", 1e-2 if self._adamw else 0.0)
+        elif name == 'rmsprop':  # torch defaults: lr 1e-2, alpha 0.99, eps 1e-8, no momentum, not centred
+            self._lr = cfg.pop("lr", 1e-2)
+            self._alpha = cfg.pop("alpha", 0.99)
+            self._eps = cfg.pop("eps", 1e-8)
+            self._weight_decay = cfg.pop("weight_decay", 0.0)
+            self._momentum = cfg.pop("momentum", 0.0)
+            self._centered = bool(cfg.pop("centered", False))
+        else:  # sgd
+            self._lr = cfg.pop("lr", 1e-3)
+            self._momentum = cfg.pop("momentum", 0.0)
+            self._dampening = cfg.pop("dampening", 0.0)
+            self._weight_decay = cfg.pop("weight_decay", 0.0)
+            self._nesterov = bool(cfg.pop("nesterov", False))
+            if self._nesterov and (self._momentum <= 0 or self._dampening != 0):
+                raise ValueError("Nesterov momentum requires a momentum and zero dampening")  # torch/optim/sgd.py
+        for flag in ("amsgrad", "maximize", "capturable", "differentiable", "fused", "foreach"):
+            if cfg.get(flag) in (None, False):
+                cfg.pop(flag, None)
         if cfg:
             raise NotImplementedError(f"unsupported optimizer_config entries: {sorted(cfg)}")
         value_loss = g('value_loss', 'mse')
@@ -165,8 +188,11 @@ class MultiAgentPPO(PytorchTrainer):
                                   value_loss=hip.VALUE_LOSS_KINDS[value_loss], mask_invert=1)
 
         net = policy.net
+        # optimiser state on the flat layout: Adam (exp_avg, exp_avg_sq); RMSprop (momentum_buffer, square_avg, grad_avg);
+        # SGD (momentum_buffer)
         self._m = torch.zeros_like(net.flat)
-        self._v = torch.zeros_like(net.flat)
+        self._v = torch.zeros_like(net.flat) if name != 'sgd' else None
+        self._gavg = torch.zeros_like(net.flat) if name == 'rmsprop' and self._centered else None
         self._opt_steps = 0
         self.frames = 0
         # rows (env-steps) per forward/backward chunk: bounds the activation workspace, not the arithmetic
@@ -187,16 +213,36 @@ class MultiAgentPPO(PytorchTrainer):
         ckpt = self.policy.get_checkpoint()
         net = self.policy.net
         names = net.ref_names()
-        m = net.flat_to_reference(self._m.detach().cpu())
-        v = net.flat_to_reference(self._v.detach().cpu())
-        state = {
-            i: dict(step=torch.tensor(float(self._opt_steps)), exp_avg=m[n], exp_avg_sq=v[n])
-            for i, n in enumerate(names)
-        } if self._opt_steps > 0 else {}
-        group = dict(lr=self._lr, betas=self._betas, eps=self._eps, weight_decay=self._weight_decay, amsgrad=False,
-                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
-                     # the PopArt statistics are gradient-less nn.Parameters of the reference: listed, stateless
-                     params=list(range(len(names) + (3 if net.spec.popart else 0))))
+        named = lambda t: net.flat_to_reference(t.detach().cpu())
+        step_t = torch.tensor(float(self._opt_steps))
+        state = {}
+        # the PopArt statistics are gradient-less nn.Parameters of the reference: listed, stateless
+        params = list(range(len(names) + (3 if net.spec.popart else 0)))
+        common = dict(maximize=False, foreach=None, differentiable=False, params=params)
+        if self._opt in ('adam', 'adamw'):
+            if self._opt_steps > 0:
+                m, v = named(self._m), named(self._v)
+                state = {i: dict(step=step_t.clone(), exp_avg=m[n], exp_avg_sq=v[n]) for i, n in enumerate(names)}
+            group = dict(lr=self._lr, betas=self._betas, eps=self._eps, weight_decay=self._weight_decay, amsgrad=False,
+                         capturable=False, fused=None, **common)
+        elif self._opt == 'rmsprop':
+            if self._opt_steps > 0:
+                sq, buf = named(self._v), named(self._m)
+                ga = named(self._gavg) if self._centered else None
+                for i, n in enumerate(names):
+                    state[i] = dict(step=step_t.clone(), square_avg=sq[n])
+                    if self._momentum > 0:
+                        state[i]["momentum_buffer"] = buf[n]
+                    if self._centered:
+                        state[i]["grad_avg"] = ga[n]
+            group = dict(lr=self._lr, momentum=self._momentum, alpha=self._alpha, eps=self._eps, centered=self._centered,
+                         weight_decay=self._weight_decay, capturable=False, **common)
+        else:
+            if self._opt_steps > 0 and self._momentum != 0:
+                buf = named(self._m)
+                state = {i: dict(momentum_buffer=buf[n]) for i, n in enumerate(names)}
+            group = dict(lr=self._lr, momentum=self._momentum, dampening=self._dampening, weight_decay=self._weight_decay,
+                         nesterov=self._nesterov, fused=None, **common)
         ckpt.update({"optimizer_state_dict": {"state": state, "param_groups": [group]}})
         return ckpt
 
@@ -206,17 +252,33 @@ class MultiAgentPPO(PytorchTrainer):
             net = self.policy.net
             names = net.ref_names()
             st = osd["state"]
+            flat_of = lambda key: net.reference_to_flat({n: st[i][key] for i, n in enumerate(names)})
+            slots = {'adam': (("exp_avg", "_m"), ("exp_avg_sq", "_v")), 'adamw': (("exp_avg", "_m"), ("exp_avg_sq", "_v")),
+                     'rmsprop': (("momentum_buffer", "_m"), ("square_avg", "_v"), ("grad_avg", "_gavg")),
+                     'sgd': (("momentum_buffer", "_m"),)}[self._opt]
+            for key, attr in slots:
+                buf = getattr(self, attr)
+                if buf is None:
+                    continue
+                if st and key in st[0] and st[0][key] is not None:
+                    buf.copy_(flat_of(key))
+                else:
+                    buf.zero_()
             if st:
-                self._m.copy_(net.reference_to_flat({n: st[i]["exp_avg"] for i, n in enumerate(names)}))
-                self._v.copy_(net.reference_to_flat({n: st[i]["exp_avg_sq"] for i, n in enumerate(names)}))
-                self._opt_steps = int(float(st[0]["step"]))
+                # SGD keeps no step count: a restored momentum buffer means "not the first step"
+                self._opt_steps = int(float(st[0]["step"])) if "step" in st[0] else 1
             else:
-                self._m.zero_()
-                self._v.zero_()
                 self._opt_steps = 0
             grp = osd["param_groups"][0]
-            self._lr, self._betas, self._eps = grp["lr"], tuple(grp["betas"]), grp["eps"]
+            self._lr = grp["lr"]
             self._weight_decay = grp.get("weight_decay", self._weight_decay)
+            if self._opt in ('adam', 'adamw'):
+                self._betas, self._eps = tuple(grp["betas"]), grp["eps"]
+            elif self._opt == 'rmsprop':
+                self._alpha, self._eps = grp.get("alpha", self._alpha), grp.get("eps", self._eps)
+                self._momentum = grp.get("momentum", self._momentum)
+            else:
+                self._momentum = grp.get("momentum", self._momentum)
         self.policy.load_checkpoint(checkpoint)
 
     def distributed(self, rank=None, world_size=None, init_method=None, **kwargs):
@@ -229,20 +291,24 @@ class MultiAgentPPO(PytorchTrainer):
             self._comm = comm.NativeComm.from_process_group(self.policy.device)  # None: torch.distributed collectives
         self._reducer = _BucketReducer(self.policy.net, self.grad_bucket_bytes, self._comm) if self._dist else None
 
-    def _importance_ratio(self, net, obs, avail, action, old_lp, rows, B, alive=None):
-        """exp(new_lp - old_lp) on rows [0, rows) of the sample, forward only, row-chunked; [rows, B, 1] float32."""
+    def _importance_ratio(self, net, obs, avail, action, old_lp, rows, B, alive=None, pstate=None, on_reset=None):
+        """exp(new_lp - old_lp) on rows [0, rows) of the sample, forward only; [rows, B, 1] float32.  Feed-forward nets go
+        through in row chunks; a recurrent net walks the time axis in one piece, chunked from the stored states exactly
+        like the training pass (mappo.py:243-246 analyses the same rows for the ratio and for the loss)."""
         n_all = rows * B
         flat = lambda t: t[:rows].reshape(n_all, *t.shape[2:])
         f_obs = {k: flat(v) for k, v in obs.items()}
         f_avail = None if avail is None else flat(avail)
         f_action = flat(action)
         new_lp = torch.empty(n_all, dtype=torch.float32, device=old_lp.device)
-        for r0 in range(0, n_all, self.chunk_rows):
-            r1 = min(n_all, r0 + self.chunk_rows)
+        rnn = None
+        if net.spec.num_rnn_layers:
+            rnn = self.policy._rnn_ctx_with_burn_in(obs, None, pstate, on_reset, 0, rows, B)
+        step = n_all if rnn is not None else self.chunk_rows
+        for r0 in range(0, n_all, step):
+            r1 = min(n_all, r0 + step)
             n = r1 - r0
-            if net.spec.num_rnn_layers:
-                raise NotImplementedError("V-trace with a recurrent policy is not on the HIP path")
-            logits, _ = net.forward({k: v[r0:r1] for k, v in f_obs.items()}, n, keep_tape=False)
+            logits, _ = net.forward({k: v[r0:r1] for k, v in f_obs.items()}, n, keep_tape=False, rnn=rnn)
             ent = net.ws.get("entropy", n)[:n]
             self.policy.dist_fwd(logits, f_action[r0:r1], None if f_avail is None else f_avail[r0:r1], new_lp[r0:r1], ent)
             self.policy.mask_dead(new_lp[r0:r1], None if alive is None else flat(alive).reshape(-1)[r0:r1])
@@ -295,7 +361,7 @@ class MultiAgentPPO(PytorchTrainer):
 
         # ---- the device part: everything between "leaves in HBM" and "terms ready"; no host synchronisation inside, so
         # it can be captured once into a hipGraph and replayed (use_graph) -----------------------------------------
-        scal = self._step_scalars(self.ppo_epochs) if self.use_graph and not self._dist else None
+        scal = self._step_scalars(self.ppo_epochs) if self.use_graph and not self._dist and self._opt in ('adam', 'adamw') else None
         if scal is not None:
             out = self._replay(L, have_adv, scal)
         else:
@@ -426,7 +492,7 @@ class MultiAgentPPO(PytorchTrainer):
                     trace_value = self.policy.denormalize_value(old_value) if self.popart else old_value
                     ratio = None
                     if self.vtrace:  # importance ratio of the CURRENT parameters on every rewarding step (:130-133)
-                        ratio = self._importance_ratio(net, obs, avail, action, old_lp, Tb - 1, B, alive)
+                        ratio = self._importance_ratio(net, obs, avail, action, old_lp, Tb - 1, B, alive, pstate, on_reset)
                     hip.gae_scan(reward, trace_value, done, truncated, on_reset, self.discount_rate, self.gae_lambda,
                                  adv_d, ret_d, stats=stats_local if fused_stats else None, imp_ratio=ratio,
                                  workspace=gws if fused_stats else None)
@@ -510,10 +576,18 @@ class MultiAgentPPO(PytorchTrainer):
             sumsq = net.ws.get("mappo.sumsq", 1, torch.float64)[:1]  # zeroed by srl_grad_sumsq
             gnorm = net.ws.get("mappo.gnorm", self.ppo_epochs)[epoch:epoch + 1]
             hip.grad_sumsq(net.grad, sumsq)
-            hip.adam_step(net.flat, net.grad, self._m, self._v, self._lr, self._betas[0], self._betas[1], self._eps,
-                          self._weight_decay, self._adamw, self._opt_steps + epoch + 1, grad_scale=1.0 / self._world,
-                          max_norm=-1.0 if self.max_grad_norm is None else float(self.max_grad_norm), sumsq=sumsq,
-                          grad_norm_out=gnorm, step_scalars=None if dscal is None else dscal[epoch])
+            clip = dict(grad_scale=1.0 / self._world, sumsq=sumsq, grad_norm_out=gnorm,
+                        max_norm=-1.0 if self.max_grad_norm is None else float(self.max_grad_norm))
+            if self._opt in ('adam', 'adamw'):
+                hip.adam_step(net.flat, net.grad, self._m, self._v, self._lr, self._betas[0], self._betas[1], self._eps,
+                              self._weight_decay, self._adamw, self._opt_steps + epoch + 1,
+                              step_scalars=None if dscal is None else dscal[epoch], **clip)
+            elif self._opt == 'rmsprop':
+                hip.rmsprop_step(net.flat, net.grad, self._v, self._m if self._momentum > 0 else None, self._gavg, self._lr,
+                                 self._alpha, self._eps, self._weight_decay, self._momentum, self._centered, **clip)
+            else:
+                hip.sgd_step(net.flat, net.grad, self._m if self._momentum != 0 else None, self._lr, self._momentum,
+                             self._dampening, self._weight_decay, self._nesterov, self._opt_steps + epoch == 0, **clip)
 
             if self.recompute_adv_among_epochs and epoch + 1 < self.ppo_epochs:
                 adv_d = ret_d = None

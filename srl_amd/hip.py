@@ -117,6 +117,10 @@ _SIGNATURES = {
     "srl_grad_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                c_float, c_float, c_int, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "srl_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int, c_int,
+                              c_float, c_float, c_void_p, c_void_p]),
+    "srl_rmsprop_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
+                                  c_float, c_float, c_int, c_float, c_float, c_void_p, c_void_p]),
     "srl_comm_unique_id": (c_int, [c_void_p]),
     "srl_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
     "srl_comm_world": (c_int, [c_void_p, POINTER(c_int)]),
@@ -485,6 +489,27 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, adamw, step, grad
         "srl_adam_step")
 
 
+def sgd_step(p, g, buf, lr, momentum, dampening, weight_decay, nesterov, first_step, grad_scale=1.0, max_norm=-1.0,
+             sumsq=None, grad_norm_out=None):
+    f = torch.float32
+    _check(
+        lib().srl_sgd_step(_stream(), _ptr(p, f, "p"), _ptr(g, f, "g"), _ptr(buf, f, "buf"), p.numel(), float(lr),
+                           float(momentum), float(dampening), float(weight_decay), int(nesterov), int(first_step),
+                           float(grad_scale), float(max_norm), _ptr(sumsq, torch.float64, "sumsq"),
+                           _ptr(grad_norm_out, f, "grad_norm_out")), "srl_sgd_step")
+
+
+def rmsprop_step(p, g, square_avg, buf, grad_avg, lr, alpha, eps, weight_decay, momentum, centered, grad_scale=1.0,
+                 max_norm=-1.0, sumsq=None, grad_norm_out=None):
+    f = torch.float32
+    _check(
+        lib().srl_rmsprop_step(_stream(), _ptr(p, f, "p"), _ptr(g, f, "g"), _ptr(square_avg, f, "square_avg"),
+                               _ptr(buf, f, "buf"), _ptr(grad_avg, f, "grad_avg"), p.numel(), float(lr), float(alpha),
+                               float(eps), float(weight_decay), float(momentum), int(centered), float(grad_scale),
+                               float(max_norm), _ptr(sumsq, torch.float64, "sumsq"), _ptr(grad_norm_out, f, "grad_norm_out")),
+        "srl_rmsprop_step")
+
+
 def conv_desc(n, H, W, Cin, KH, KW, stride, Cout, act=ACT_NONE) -> ConvDesc:
     return ConvDesc(int(n), int(H), int(W), int(Cin), int(KH), int(KW), int(stride), int(Cout), int(act))
 
@@ -582,4 +607,5 @@ def _wrap_for_profile(names):
 
 _wrap_for_profile(["masked_stats", "masked_normalize", "ppo_loss_fwd_bwd", "categorical_fwd", "categorical_bwd",
                    "categorical_sample", "layernorm_fwd", "layernorm_bwd", "obs_ln_stats", "im2col_obs_ln", "im2col_nhwc",
-                   "col2im_nhwc", "obs_ln_affine_bwd", "colsum", "copy2d", "grad_sumsq", "adam_step"])
+                   "col2im_nhwc", "obs_ln_affine_bwd", "colsum", "copy2d", "grad_sumsq", "adam_step", "sgd_step",
+                   "rmsprop_step"])

@@ -372,6 +372,46 @@ def gen_steps():
     save("steps_cnn.npz", **out)
 
 
+def gen_vtrace_rnn():
+    """V-trace with recurrent policies (mappo.py:243-246: the analysed rows give both the importance ratio of the trace
+    and the loss): GRU shared backbone, and LSTM separate backbones with PopArt and two epochs."""
+    out = {}
+    vt_gru = dict(obs_dim=4, action_dim=2, hidden_dim=32, num_dense_layers=1, num_rnn_layers=1, popart=False, layernorm=True,
+                  shared_backbone=True, chunk_len=8, seed=51)
+    smp = dict(T=32, B=6, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.08, p_trunc=0.0, policy_state={"hx": (1, 32)})
+    run_steps("vtgru", vt_gru, dict(popart=False, vtrace=True, optimizer_config=dict(lr=1e-3), max_grad_norm=10.0), smp, 2,
+              out=out)
+    vt_lstm = dict(obs_dim=4, action_dim=[3, 2], hidden_dim=16, num_dense_layers=1, num_rnn_layers=1, rnn_type="lstm",
+                   popart=True, layernorm=False, shared_backbone=False, chunk_len=4, seed=52)
+    smp2 = dict(T=16, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2], p_done=0.1, p_trunc=0.0,
+                policy_state={"actor_hx": (1, 32), "critic_hx": (1, 32)})
+    run_steps("vtlstm", vt_lstm, dict(popart=True, vtrace=True, ppo_epochs=2, optimizer_config=dict(lr=5e-4)), smp2, 2, out=out)
+    save("steps_vtrace_rnn.npz", **out)
+
+
+def gen_optim():
+    """The other optimisers modules/utils.py:268-286 accepts: RMSprop (plain; centred with momentum and weight decay) and
+    SGD (plain; Nesterov momentum with weight decay; momentum with dampening), full steps on the CartPole shapes."""
+    c1_sample = dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05)
+    out = {}
+    run_steps("rms", dict(C1_POLICY, seed=41), dict(popart=False, optimizer='rmsprop', optimizer_config=dict(lr=1e-3)),
+              c1_sample, 3, out=out, analyze_check=False)
+    run_steps("rmsc", dict(C1_POLICY, layernorm=True, seed=42),
+              dict(popart=False, optimizer='rmsprop', max_grad_norm=5.0,
+                   optimizer_config=dict(lr=5e-4, alpha=0.95, eps=1e-6, momentum=0.9, centered=True, weight_decay=1e-3)),
+              c1_sample, 3, out=out, analyze_check=False)
+    run_steps("sgd", dict(C1_POLICY, seed=43), dict(popart=False, optimizer='sgd', optimizer_config=dict(lr=1e-2)), c1_sample,
+              2, out=out, analyze_check=False)
+    run_steps("sgdn", dict(C1_POLICY, shared_backbone=True, seed=44),
+              dict(popart=False, optimizer='sgd', max_grad_norm=1.0,
+                   optimizer_config=dict(lr=1e-2, momentum=0.9, nesterov=True, weight_decay=1e-3)), c1_sample, 3, out=out,
+              analyze_check=False)
+    run_steps("sgdd", dict(C1_POLICY, seed=45),
+              dict(popart=False, optimizer='sgd', ppo_epochs=2, optimizer_config=dict(lr=1e-2, momentum=0.8, dampening=0.3)),
+              c1_sample, 2, out=out, analyze_check=False)
+    save("steps_optim.npz", **out)
+
+
 def gen_popart():
     """PopArt value head (the reference policy's default) and V-trace through the trainer: full steps."""
     c1_sample = dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05)

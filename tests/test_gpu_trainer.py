@@ -77,6 +77,37 @@ CASES = {
              dict(T=18, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.1,
                   policy_state={"actor_hx": (1, 16), "critic_hx": (1, 16)}), 2, "steps_rnn.npz"),
 }
+# the other optimisers modules/utils.py:268-286 accepts (gen_golden.py gen_optim)
+_C1S = dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05)
+CASES.update({
+    "rms": (dict(C1_POLICY, seed=41), dict(popart=False, optimizer='rmsprop', optimizer_config=dict(lr=1e-3)), _C1S, 3,
+            "steps_optim.npz"),
+    "rmsc": (dict(C1_POLICY, layernorm=True, seed=42),
+             dict(popart=False, optimizer='rmsprop', max_grad_norm=5.0,
+                  optimizer_config=dict(lr=5e-4, alpha=0.95, eps=1e-6, momentum=0.9, centered=True, weight_decay=1e-3)), _C1S, 3,
+             "steps_optim.npz"),
+    "sgd": (dict(C1_POLICY, seed=43), dict(popart=False, optimizer='sgd', optimizer_config=dict(lr=1e-2)), _C1S, 2,
+            "steps_optim.npz"),
+    "sgdn": (dict(C1_POLICY, shared_backbone=True, seed=44),
+             dict(popart=False, optimizer='sgd', max_grad_norm=1.0,
+                  optimizer_config=dict(lr=1e-2, momentum=0.9, nesterov=True, weight_decay=1e-3)), _C1S, 3, "steps_optim.npz"),
+    "sgdd": (dict(C1_POLICY, seed=45),
+             dict(popart=False, optimizer='sgd', ppo_epochs=2, optimizer_config=dict(lr=1e-2, momentum=0.8, dampening=0.3)),
+             _C1S, 2, "steps_optim.npz"),
+})
+# V-trace with recurrent policies (gen_golden.py gen_vtrace_rnn)
+CASES.update({
+    "vtgru": (dict(obs_dim=4, action_dim=2, hidden_dim=32, num_dense_layers=1, num_rnn_layers=1, popart=False, layernorm=True,
+                   shared_backbone=True, chunk_len=8, seed=51),
+              dict(popart=False, vtrace=True, optimizer_config=dict(lr=1e-3), max_grad_norm=10.0),
+              dict(T=32, B=6, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.08, p_trunc=0.0,
+                   policy_state={"hx": (1, 32)}), 2, "steps_vtrace_rnn.npz"),
+    "vtlstm": (dict(obs_dim=4, action_dim=[3, 2], hidden_dim=16, num_dense_layers=1, num_rnn_layers=1, rnn_type="lstm",
+                    popart=True, layernorm=False, shared_backbone=False, chunk_len=4, seed=52),
+               dict(popart=True, vtrace=True, ppo_epochs=2, optimizer_config=dict(lr=5e-4)),
+               dict(T=16, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2], p_done=0.1, p_trunc=0.0,
+                    policy_state={"actor_hx": (1, 32), "critic_hx": (1, 32)}), 2, "steps_vtrace_rnn.npz"),
+})
 # continuous actions: Normal(mean, std) with the three parametrisations of log sigma (gen_golden.py gen_continuous)
 _CBASE = dict(obs_dim=7, action_dim=3, hidden_dim=32, num_dense_layers=2, num_rnn_layers=0, popart=False, layernorm=True,
               shared_backbone=False, chunk_len=8, continuous_action=True)
