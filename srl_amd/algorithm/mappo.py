@@ -409,8 +409,10 @@ class MultiAgentPPO(PytorchTrainer):
             im = sample.info_mask[lo:hi]
             im = im.cpu().numpy() if isinstance(im, torch.Tensor) else np.asarray(im)
             elapsed = im.sum()
-            if elapsed > 0:
-                info = recursive_apply(sample.info[lo:hi] * im, lambda x: x.sum()) / elapsed
+            if elapsed > 0:  # episode statistics of a device-resident sample (ingest ring) come to the host here
+                host_info = recursive_apply(sample.info[lo:hi],
+                                            lambda x: x.cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x))
+                info = recursive_apply(host_info * im, lambda x: x.sum()) / elapsed
                 info = {k: float(v) for k, v in info.items()}
         stats = dict(frames=int(self.frames), **{k: float(v) for k, v in train_stats.items()}, **info)
         return TrainerStepResult(stats=stats, step=self.policy.version)
