@@ -120,7 +120,7 @@ def test_cartpole_closed_loop_learns_and_versions_advance():
             res = trainer.step(batch)
             ring.release(batch)
             updates += 1
-            assert res.step == trainer.policy.version == updates
+            assert res.step == trainer.policy.version == updates - 1  # the reference's versions start at -1 (api/policy.py)
             fresh[:] = [trainer.get_checkpoint()]  # newest parameters replace any not yet taken
             recent = [r for a in actors for r in a.returns[-4:]]
             curve.append(float(np.mean(recent)) if recent else 0.0)
@@ -133,7 +133,7 @@ def test_cartpole_closed_loop_learns_and_versions_advance():
     # version plumbing: a batch holds samples produced under the parameters of the last one or two updates -- never newer
     # than the trainer, and the stamps advance with the updates
     for lo, hi, ver in version_log:
-        assert 0 <= lo <= hi <= ver and ver - lo <= 2, (lo, hi, ver)
+        assert -1 <= lo <= hi <= ver and ver - lo <= 2, (lo, hi, ver)
     assert version_log[-1][1] >= version_log[5][1] + (len(version_log) - 6) - 1
     assert infer.version == trainer.policy.version - 1 or infer.version == trainer.policy.version
     # the inference replica really runs the trainer's parameters (handed over by checkpoint)
