@@ -398,6 +398,20 @@ int srl_rmsprop_step(void* stream, float* p, const float* g, float* square_avg, 
                      float grad_scale, float max_norm, const double* sumsq, float* grad_norm_out);
 
 /* ------------------------------------------------------------------------------------------------
+ * Native step driver (launch-bound configurations).  The device part of MultiAgentPPO.step (mappo.py:219-328) is
+ * captured once into a hipGraph; a plan = that executable graph (hipGraphExec_t as void*) + its static input leaves +
+ * its outputs.  srl_step_plan_run enqueues, on `stream`: one copy per input from srcs[i] (host or device memory; NULL
+ * = leave the static leaf as it is) into the static leaf, the graph launch, one copy per output to its host
+ * destination (fixed at registration or, if that was NULL, host_dsts[i]); sync != 0 waits for the stream.  One FFI
+ * crossing per trainer step instead of one host operation per leaf.  add_input / add_output return the slot index. */
+int srl_step_plan_create(void** plan_out, void* graph_exec);
+int srl_step_plan_add_input(void* plan, void* dst_device, int64_t nbytes);
+int srl_step_plan_add_output(void* plan, const void* src_device, int64_t nbytes, void* host_dst);
+int srl_step_plan_run(void* plan, void* stream, const void* const* srcs, int n_srcs, void* const* host_dsts, int n_dsts,
+                      int sync);
+int srl_step_plan_destroy(void* plan);
+
+/* ------------------------------------------------------------------------------------------------
  * Collectives (RCCL over xGMI), one process per GPU.  `comm` is an ncclComm_t behind void*; every
  * call is enqueued on `stream` and returns at once (stream-ordered like the kernels above).  librccl
  * is resolved with dlopen at first use (-ENOSYS if absent).

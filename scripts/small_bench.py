@@ -20,7 +20,10 @@ for T, B in ((32, 8), (32, 512)):
                                                            use_graph=bool(int(os.environ.get("SRL_GRAPH", "0"))))),
                           config.Policy("actor-critic", args=POLICY))
     arr = synthetic.make_sample_arrays(seed=0, T=T, B=B, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2)
-    sample = synthetic.to_sample_batch({k: torch.from_numpy(v).to("cuda:0") for k, v in arr.items()})
+    if int(os.environ.get("SRL_HOST_SAMPLE", "0")):  # a numpy sample, as the reference's buffer hands it over
+        sample = synthetic.to_sample_batch(arr)
+    else:
+        sample = synthetic.to_sample_batch({k: torch.from_numpy(v).to("cuda:0") for k, v in arr.items()})
     for _ in range(5):
         tr.step(sample)
     torch.cuda.synchronize()

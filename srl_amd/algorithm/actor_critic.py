@@ -34,6 +34,9 @@ def to_device_leaf(x, device, kind: str) -> torch.Tensor:
     Device tensors pass through (only the dtype is checked).
     """
     want = {"flag": torch.uint8, "real": torch.float32, "index": torch.int32}.get(kind)
+    if kind == "as-is":  # already in its wire dtype (wire_leaf): only the placement changes
+        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(x)
+        return t.to(device, non_blocking=True).contiguous()
     if isinstance(x, torch.Tensor):
         t = x
     else:
@@ -49,6 +52,20 @@ def to_device_leaf(x, device, kind: str) -> torch.Tensor:
     if t.dtype != want:
         t = t.to(want)
     return t.to(device, non_blocking=True).contiguous()
+
+
+def wire_leaf(x, kind: str):
+    """Like ``to_device_leaf`` but a host leaf STAYS on the host: a contiguous numpy array in the dtype the kernels read
+    (what the native step driver copies straight into a captured step's static inputs).  Device tensors pass through."""
+    if isinstance(x, torch.Tensor):
+        return to_device_leaf(x, x.device, kind) if x.is_cuda else wire_leaf(x.numpy(), kind)
+    a = np.asarray(x)
+    if a.dtype == np.bool_:
+        a = a.view(np.uint8)
+    want = {"flag": np.uint8, "real": np.float32, "index": np.int32}.get(kind)
+    if kind == "obs":
+        want = np.uint8 if a.dtype == np.uint8 else np.float32
+    return np.ascontiguousarray(a, dtype=want)
 
 
 class ActorCriticPolicy(policy_api.Policy):

@@ -31,7 +31,7 @@ import torch.distributed as dist
 
 from srl_amd import hip
 from srl_amd.algorithm import netspec as ns
-from srl_amd.algorithm.actor_critic import ActorCriticPolicy, to_device_leaf
+from srl_amd.algorithm.actor_critic import ActorCriticPolicy, to_device_leaf, wire_leaf
 from srl_amd.api.trainer import PytorchTrainer, TrainerStepResult, register
 from srl_amd.namedarray import recursive_apply
 
@@ -325,35 +325,37 @@ class MultiAgentPPO(PytorchTrainer):
         if self.recompute_adv_on_reuse:
             sample.analyzed_result.adv = sample.analyzed_result.ret = None  # :224-225
 
-        # ---- the sample's leaves on the device, in their wire dtypes ---------------------------------------------------
-        L = dict(on_reset=to_device_leaf(sample.on_reset, dev, "flag"), done=to_device_leaf(sample.done, dev, "flag"),
-                 truncated=to_device_leaf(sample.truncated, dev, "flag"), reward=to_device_leaf(sample.reward, dev, "real"),
-                 old_value=to_device_leaf(sample.analyzed_result.value, dev, "real"),
-                 old_lp=to_device_leaf(sample.analyzed_result.log_probs, dev, "real"),
-                 action=to_device_leaf(sample.action.x, dev, self.policy.action_kind()))
+        # ---- the sample's leaves in their wire dtypes: on the device -- or, for a captured step (use_graph), wherever they
+        # are: the native step driver copies them straight into the graph's static inputs ---------------------------------
+        graphed = self.use_graph and not self._dist and self._opt in ('adam', 'adamw')
+        leaf = (lambda x, kind: wire_leaf(x, kind)) if graphed else (lambda x, kind: to_device_leaf(x, dev, kind))
+        L = dict(on_reset=leaf(sample.on_reset, "flag"), done=leaf(sample.done, "flag"),
+                 truncated=leaf(sample.truncated, "flag"), reward=leaf(sample.reward, "real"),
+                 old_value=leaf(sample.analyzed_result.value, "real"), old_lp=leaf(sample.analyzed_result.log_probs, "real"),
+                 action=leaf(sample.action.x, self.policy.action_kind()))
         for k, v in sample.obs.items():
             if v is not None:
-                L[f"obs.{k}"] = to_device_leaf(v, dev, "obs")
+                L[f"obs.{k}"] = leaf(v, "obs")
         have_adv = sample.analyzed_result.adv is not None
         if have_adv:
-            L["adv"] = to_device_leaf(sample.analyzed_result.adv, dev, "real")
-            L["ret"] = to_device_leaf(sample.analyzed_result.ret, dev, "real")
+            L["adv"] = leaf(sample.analyzed_result.adv, "real")
+            L["ret"] = leaf(sample.analyzed_result.ret, "real")
         if net.spec.num_rnn_layers:
             if sample.policy_state is None:
                 raise ValueError("recurrent policy: the sample carries no policy_state")
             for k, v in sample.policy_state.items():
-                L[f"policy_state.{k}"] = to_device_leaf(v, dev, "real")
+                L[f"policy_state.{k}"] = leaf(v, "real")
 
         # shared multi-agent samples carry [Tb, B, agents, ...] leaves: every operation of the step is per (env, agent)
         # column, so the agents are folded into the batch axis (a view) and unfolded where results go back to the sample
-        agents = L["on_reset"].shape[2] if L["on_reset"].dim() == 4 else 0
+        agents = L["on_reset"].shape[2] if len(L["on_reset"].shape) == 4 else 0
         if agents:
             L = {k: v.reshape(v.shape[0], v.shape[1] * v.shape[2], *v.shape[3:]) for k, v in L.items()}
         Tb, B = L["on_reset"].shape[0], L["on_reset"].shape[1]
         boot, burn = self.bootstrap_steps, self.burn_in_steps
         lo, hi = burn, Tb - boot  # valid rows (mappo.py:259)
         n_valid = (hi - lo) * B
-        Nc = L["old_value"].shape[2] if L["old_value"].dim() > 2 else 1
+        Nc = L["old_value"].shape[2] if len(L["old_value"].shape) > 2 else 1
         if Nc != 1:
             raise NotImplementedError("value_dim > 1 through the PPO loss is not on the HIP path (the scan supports it)")
         if not have_adv and boot == 0:
@@ -361,9 +363,8 @@ class MultiAgentPPO(PytorchTrainer):
 
         # ---- the device part: everything between "leaves in HBM" and "terms ready"; no host synchronisation inside, so
         # it can be captured once into a hipGraph and replayed (use_graph) -----------------------------------------
-        scal = self._step_scalars(self.ppo_epochs) if self.use_graph and not self._dist and self._opt in ('adam', 'adamw') else None
-        if scal is not None:
-            out = self._replay(L, have_adv, scal)
+        if graphed:
+            out = self._replay(L, have_adv, self._step_scalars(self.ppo_epochs), host_results=not isinstance(sample.reward, torch.Tensor))
         else:
             out = self._device_part(L, have_adv, None)
         self._opt_steps += self.ppo_epochs
@@ -371,7 +372,9 @@ class MultiAgentPPO(PytorchTrainer):
             self.policy._popart_updates += self.ppo_epochs
 
         # ---- statistics: the only device->host synchronisation of the step (the reference syncs ~11 times per epoch) ------
-        host = out["terms"].cpu().numpy()  # [epochs, LT_COUNT + 1 (+ 2 with PopArt)]
+        host = out["terms"]  # [epochs, LT_COUNT + 1 (+ 2 with PopArt)]
+        if isinstance(host, torch.Tensor):
+            host = host.cpu().numpy()
         train_stats = defaultdict(float)
         for row in host:
             msum = max(row[hip.LT_MASK], 1e-30)
@@ -389,7 +392,9 @@ class MultiAgentPPO(PytorchTrainer):
         adv_d, ret_d = out["adv"], out["ret"]
         if agents:
             adv_d, ret_d = (t.reshape(Tb, B // agents, agents, *t.shape[2:]) for t in (adv_d, ret_d))
-        if not have_adv and not isinstance(sample.reward, torch.Tensor):
+        if not have_adv and out.get("owned"):  # the step driver already delivered fresh copies where the sample lives
+            sample.analyzed_result.adv, sample.analyzed_result.ret = adv_d, ret_d
+        elif not have_adv and not isinstance(sample.reward, torch.Tensor):
             sample.analyzed_result.adv = adv_d.cpu().numpy()
             sample.analyzed_result.ret = ret_d.cpu().numpy()
         elif not have_adv:
@@ -425,31 +430,52 @@ class MultiAgentPPO(PytorchTrainer):
         for e in range(1, epochs + 1):
             t = self._opt_steps + e
             rows.append([self._lr / (1.0 - self._betas[0]**t), (1.0 - self._betas[1]**t)**0.5])
-        return torch.tensor(rows, dtype=torch.float32)
+        return np.asarray(rows, dtype=np.float32)
 
-    def _replay(self, L, have_adv, scal):
-        key = (have_adv,) + tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(L.items()))
+    def _replay(self, L, have_adv, scal, host_results):
+        """The device part as a captured hipGraph behind the native step driver (csrc/step_plan.hip): per step ONE C call
+        copies the sample's leaves (host or device) into the graph's static inputs, launches the graph and brings the
+        loss terms -- and fresh copies of the advantages / value targets, on the host or on the device as the sample is --
+        back.  First sight of a sample signature runs eagerly (loads every kernel, sizes the workspaces), the second is
+        captured, later ones replay."""
+        dev = self.policy.device
+        keys = sorted(L)
+        key = (have_adv,) + tuple((k, tuple(L[k].shape), str(L[k].dtype).replace("torch.", "")) for k in keys)
         if key not in self._graphs:
-            # first sight of this signature: run it eagerly (loads every kernel, sizes the workspaces), capture next time
             self._graphs[key] = None
-            return self._device_part(L, have_adv, None)
+            return self._device_part({k: to_device_leaf(v, dev, "as-is") for k, v in L.items()}, have_adv, None)
         ent = self._graphs[key]
         if ent is None:
-            static = {k: v.clone() for k, v in L.items()}
-            dscal = scal.to(self.policy.device)
-            side = torch.cuda.Stream(device=self.policy.device)
+            static = {k: to_device_leaf(L[k], dev, "as-is").clone() for k in keys}
+            dscal = torch.from_numpy(scal).to(dev)
+            side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
                 out = self._device_part(static, have_adv, dscal)
-            ent = (graph, static, dscal, out)
+            plan = hip.StepPlan(graph.raw_cuda_graph_exec())
+            for k in keys:
+                plan.add_input(static[k])
+            plan.add_input(dscal)
+            terms_host = torch.empty(out["terms"].shape, dtype=out["terms"].dtype).pin_memory()
+            plan.add_output(out["terms"], terms_host)
+            plan.add_output(out["adv"], None)
+            plan.add_output(out["ret"], None)
+            ent = (graph, plan, static, dscal, out, terms_host)
             self._graphs[key] = ent
-        graph, static, dscal, out = ent
-        for k, v in L.items():
-            static[k].copy_(v, non_blocking=True)
-        dscal.copy_(scal, non_blocking=True)
-        graph.replay()
-        return out
+        graph, plan, static, dscal, out, terms_host = ent
+        ptr = lambda v: v.data_ptr() if isinstance(v, torch.Tensor) else v.ctypes.data
+        adv = ret = None
+        if not have_adv:  # fresh copies for the sample (mappo.py:254-257): numpy for a host sample, device tensors otherwise
+            shape = tuple(out["adv"].shape)
+            if host_results:
+                adv, ret = np.empty(shape, np.float32), np.empty(shape, np.float32)
+            else:
+                adv, ret = torch.empty(shape, dtype=torch.float32, device=dev), torch.empty(shape, dtype=torch.float32, device=dev)
+        plan.run([ptr(L[k]) for k in keys] + [scal.ctypes.data], [None, None if adv is None else ptr(adv),
+                                                                 None if ret is None else ptr(ret)], sync=True)
+        return dict(terms=terms_host.numpy(), adv=adv if adv is not None else out["adv"],
+                    ret=ret if ret is not None else out["ret"], owned=adv is not None)
 
     def _device_part(self, L, have_adv, dscal):
         """GAE / statistics / (PopArt) / epochs x (forward, loss, backward, [all-reduce], clip + Adam).  Returns device

@@ -121,6 +121,11 @@ _SIGNATURES = {
                               c_float, c_float, c_void_p, c_void_p]),
     "srl_rmsprop_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                   c_float, c_float, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "srl_step_plan_create": (c_int, [POINTER(c_void_p), c_void_p]),
+    "srl_step_plan_add_input": (c_int, [c_void_p, c_void_p, c_int64]),
+    "srl_step_plan_add_output": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "srl_step_plan_run": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_int, POINTER(c_void_p), c_int, c_int]),
+    "srl_step_plan_destroy": (c_int, [c_void_p]),
     "srl_comm_unique_id": (c_int, [c_void_p]),
     "srl_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
     "srl_comm_world": (c_int, [c_void_p, POINTER(c_int)]),
@@ -508,6 +513,49 @@ def rmsprop_step(p, g, square_avg, buf, grad_avg, lr, alpha, eps, weight_decay, 
                                float(eps), float(weight_decay), float(momentum), int(centered), float(grad_scale),
                                float(max_norm), _ptr(sumsq, torch.float64, "sumsq"), _ptr(grad_norm_out, f, "grad_norm_out")),
         "srl_rmsprop_step")
+
+
+class StepPlan:
+    """A captured trainer step behind one C call (csrc/step_plan.hip): static input leaves, the executable graph, outputs."""
+
+    def __init__(self, graph_exec: int):
+        h = c_void_p()
+        _check(lib().srl_step_plan_create(ctypes.byref(h), c_void_p(graph_exec)), "srl_step_plan_create")
+        self._h = h
+        self._n_in = self._n_out = 0
+        self._keep = []  # tensors the plan points into
+
+    def add_input(self, static_leaf: torch.Tensor) -> int:
+        self._keep.append(static_leaf)
+        rc = lib().srl_step_plan_add_input(self._h, static_leaf.data_ptr(), static_leaf.numel() * static_leaf.element_size())
+        if rc < 0:
+            _check(rc, "srl_step_plan_add_input")
+        self._n_in += 1
+        return rc
+
+    def add_output(self, src: torch.Tensor, host_dst: Optional[torch.Tensor] = None) -> int:
+        self._keep.extend([src, host_dst])
+        rc = lib().srl_step_plan_add_output(self._h, src.data_ptr(), src.numel() * src.element_size(),
+                                            None if host_dst is None else host_dst.data_ptr())
+        if rc < 0:
+            _check(rc, "srl_step_plan_add_output")
+        self._n_out += 1
+        return rc
+
+    def run(self, srcs: Sequence[Optional[int]], host_dsts: Optional[Sequence[Optional[int]]] = None, sync: bool = True):
+        a = (c_void_p * self._n_in)(*srcs)
+        if host_dsts is None:
+            d, nd = None, 0
+        else:
+            d, nd = (c_void_p * self._n_out)(*host_dsts), self._n_out
+        _check(lib().srl_step_plan_run(self._h, _stream(), a, self._n_in, d, nd, int(sync)), "srl_step_plan_run")
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().srl_step_plan_destroy(self._h)
+        except Exception:  # interpreter shutdown
+            pass
 
 
 def conv_desc(n, H, W, Cin, KH, KW, stride, Cout, act=ACT_NONE) -> ConvDesc:
