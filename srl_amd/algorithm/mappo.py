@@ -207,6 +207,7 @@ class MultiAgentPPO(PytorchTrainer):
         self._comm = None
         self._reducer = None
         self._gae_ws = {}
+        self._padded = None
 
     # ------------------------------------------------------------------ checkpoints (mappo.py:58-66)
     def get_checkpoint(self):
@@ -372,19 +373,22 @@ class MultiAgentPPO(PytorchTrainer):
             self.policy._popart_updates += self.ppo_epochs
 
         # ---- statistics: the only device->host synchronisation of the step (the reference syncs ~11 times per epoch) ------
-        host = out["terms"]  # [epochs, LT_COUNT + 1 (+ 2 with PopArt)]
-        if isinstance(host, torch.Tensor):
-            host = host.cpu().numpy()
+        raw = out["terms"]  # [epochs, nchunks * LT_COUNT | gradient norm (float32) | 3 PopArt sums]
+        if isinstance(raw, torch.Tensor):
+            raw = raw.cpu().numpy()
+        nch = out["nchunks"]
         train_stats = defaultdict(float)
-        for row in host:
+        for erow in raw:
+            row = erow[:nch * hip.LT_COUNT].reshape(nch, hip.LT_COUNT).sum(0)
+            tail = erow[nch * hip.LT_COUNT:]
             msum = max(row[hip.LT_MASK], 1e-30)
             if self.popart:  # PPOStepResult.denorm_value: masked mean of the de-normalised targets (:215)
-                train_stats["denorm_value"] += row[hip.LT_COUNT + 2] / max(row[hip.LT_COUNT + 1], 1e-30)
+                train_stats["denorm_value"] += tail[2] / max(tail[1], 1e-30)
             for key, slot in _STAT_TERMS:
                 train_stats[key] += row[slot] / msum
             train_stats["done"] += row[hip.LT_DONE] / max(n_valid, 1)
             train_stats["truncated"] += row[hip.LT_TRUNC] / max(n_valid, 1)
-            train_stats["grad_norm"] += row[hip.LT_COUNT]
+            train_stats["grad_norm"] += float(tail[:1].view(np.float32)[0])
         for k in train_stats:
             train_stats[k] /= self.ppo_epochs
 
@@ -474,7 +478,7 @@ class MultiAgentPPO(PytorchTrainer):
                 adv, ret = torch.empty(shape, dtype=torch.float32, device=dev), torch.empty(shape, dtype=torch.float32, device=dev)
         plan.run([ptr(L[k]) for k in keys] + [scal.ctypes.data], [None, None if adv is None else ptr(adv),
                                                                  None if ret is None else ptr(ret)], sync=True)
-        return dict(terms=terms_host.numpy(), adv=adv if adv is not None else out["adv"],
+        return dict(terms=terms_host.numpy(), nchunks=out["nchunks"], adv=adv if adv is not None else out["adv"],
                     ret=ret if ret is not None else out["ret"], owned=adv is not None)
 
     def _device_part(self, L, have_adv, dscal):
@@ -496,10 +500,20 @@ class MultiAgentPPO(PytorchTrainer):
         f64 = dict(dtype=torch.float64, device=dev)
         # step-persistent device state lives in the net's workspace: nothing below allocates in steady state
         stats_local = net.ws.get("mappo.stats_local", 3, torch.float64)[:3]
-        stats_global = net.ws.get("mappo.stats_global", 3, torch.float64)[:3]
+        # without a process group the global statistics ARE the local ones (no copy)
+        stats_global = net.ws.get("mappo.stats_global", 3, torch.float64)[:3] if self._dist else stats_local
         stats_work = None  # pending all-reduce of stats_global (joined right before its first reader)
         adv_d = ret_d = None
-        epoch_terms = []
+        # what goes back to the host, in ONE float64 block zeroed once per step: per epoch the loss-term sums of every
+        # row chunk (added up on the host), the gradient norm (a float32 in the low half of its slot) and, with PopArt,
+        # the masked sums of the value targets
+        n_valid_rows = (Tb - self.bootstrap_steps - self.burn_in_steps) * B
+        chunk_rows = n_valid_rows if net.spec.num_rnn_layers else self.chunk_rows
+        nchunks = max(1, -(-n_valid_rows // chunk_rows))
+        stride = nchunks * hip.LT_COUNT + 1 + 3
+        block = net.ws.get("mappo.out", self.ppo_epochs * stride, torch.float64)[:self.ppo_epochs * stride]
+        block.zero_()
+        block = block.view(self.ppo_epochs, stride)
 
         for epoch in range(self.ppo_epochs):
             # ---- advantages / value targets ------------------------------------------------------------------
@@ -510,8 +524,12 @@ class MultiAgentPPO(PytorchTrainer):
                 else:
                     adv_d = net.ws.get("mappo.adv", Tb * B * Nc)[:Tb * B * Nc].view(Tb, B, Nc)
                     ret_d = net.ws.get("mappo.ret", Tb * B * Nc)[:Tb * B * Nc].view(Tb, B, Nc)
-                    adv_d[Tb - 1:].zero_()  # the scan writes rows [0, Tb-1); the last row is the zero pad (:254-256)
-                    ret_d[Tb - 1:].zero_()
+                    # the scan writes rows [0, Tb-1); the last row is the zero pad (:254-256): zeroed when the buffers
+                    # first take this shape, nothing writes it afterwards
+                    if self._padded != (adv_d.data_ptr(), ret_d.data_ptr(), Tb, B, Nc):
+                        adv_d[Tb - 1:].zero_()
+                        ret_d[Tb - 1:].zero_()
+                        self._padded = (adv_d.data_ptr(), ret_d.data_ptr(), Tb, B, Nc)
                     fused_stats = boot == 1 and burn == 0
                     gws = self._gae_ws.get((B, Nc))
                     if gws is None:  # zeroed once; afterwards the scan's own last workgroup resets it
@@ -527,8 +545,8 @@ class MultiAgentPPO(PytorchTrainer):
                 mask_rows = on_reset[1 + lo:1 + hi]  # loss_mask = 1 - on_reset[1+burn : 1+Tb-boot]  (:260-261)
                 if not fused_stats:
                     hip.masked_stats(adv_d[lo:hi], mask_rows, stats_local, mask_invert=True)
-                stats_global.copy_(stats_local)
                 if self._dist:
+                    stats_global.copy_(stats_local)
                     # one 24-byte message instead of three (utils.py:58-61), issued asynchronously: it crosses the
                     # links while the first chunk's forward pass runs and is joined before the first loss kernel
                     if self._comm is not None:
@@ -542,7 +560,7 @@ class MultiAgentPPO(PytorchTrainer):
             # ---- PopArt: statistics of the value targets, then the loss sees normalised targets (:263-264, :173-176) ----
             loss_ret, pstats_local = ret_d, None
             if self.popart:
-                pstats_local = torch.zeros((Nc, 3), **f64)
+                pstats_local = block[epoch, stride - 3:].view(1, 3)  # zeroed by srl_masked_stats_cols itself
                 hip.masked_stats_cols(flat(ret_d), on_reset[1 + lo:1 + hi], pstats_local, Nc, mask_invert=True)
                 pstats = pstats_local.clone()
                 if self._dist:
@@ -564,11 +582,7 @@ class MultiAgentPPO(PytorchTrainer):
             rnn = None
             if net.spec.num_rnn_layers:  # chunk states from the sample, or from a no-grad replay of the burn-in rows
                 rnn = self.policy._rnn_ctx_with_burn_in(obs, None, pstate, on_reset, burn, hi - lo, B)
-            chunk_rows = n_valid if rnn is not None else self.chunk_rows
-            nchunks = max(1, -(-n_valid // chunk_rows))
-            terms = net.ws.get("mappo.terms", nchunks * hip.LT_COUNT, torch.float64)[:nchunks * hip.LT_COUNT]
-            terms = terms.view(nchunks, hip.LT_COUNT)
-            terms.zero_()
+            terms = block[epoch, :nchunks * hip.LT_COUNT].view(nchunks, hip.LT_COUNT)
             reducer = self._reducer if self._dist else None
             if reducer is not None:
                 reducer.begin()
@@ -602,7 +616,8 @@ class MultiAgentPPO(PytorchTrainer):
                 net.grad_ready_hook = None
                 reducer.finish()
             sumsq = net.ws.get("mappo.sumsq", 1, torch.float64)[:1]  # zeroed by srl_grad_sumsq
-            gnorm = net.ws.get("mappo.gnorm", self.ppo_epochs)[epoch:epoch + 1]
+            slot = epoch * stride + nchunks * hip.LT_COUNT
+            gnorm = block.view(-1).view(torch.float32)[2 * slot:2 * slot + 1]
             hip.grad_sumsq(net.grad, sumsq)
             clip = dict(grad_scale=1.0 / self._world, sumsq=sumsq, grad_norm_out=gnorm,
                         max_norm=-1.0 if self.max_grad_norm is None else float(self.max_grad_norm))
@@ -621,9 +636,7 @@ class MultiAgentPPO(PytorchTrainer):
                 adv_d = ret_d = None
                 have_adv = False
 
-            extra = [] if pstats_local is None else [pstats_local[0, :2]]
-            epoch_terms.append(torch.cat([terms.sum(0), gnorm.double()] + extra))
-        return dict(terms=torch.stack(epoch_terms), adv=adv_d, ret=ret_d)
+        return dict(terms=block, nchunks=nchunks, adv=adv_d, ret=ret_d)
 
 
 register('mappo', MultiAgentPPO)
