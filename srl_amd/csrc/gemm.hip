@@ -1,5 +1,9 @@
-// Dense FP32-MFMA GEMM entry point (srl_gemm).  The kernel itself lives in gemm_core.h.
+// Dense float32 GEMM entry point (srl_gemm).  Kernels: gemm_bf16x3.h (bf16 matrix cores, three exact pieces per
+// operand) for float4-stageable shapes, gemm_core.h (float32 MFMA) otherwise, skinny.h for extents <= 16.
+#include <stdlib.h>
+
 #include "gemm_core.h"
+#include "gemm_bf16x3.h"
 #include "skinny.h"
 
 static_assert(sizeof(srl_gemm_desc) == 152 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
@@ -14,6 +18,22 @@ int launch_or(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
   if (!akm && bkm) return launch<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN, GEN>(st, g, 1, split);
   if (akm && bkm) return launch<BM, BN, WM, WN, true, true, SRC_PLAIN, SRC_PLAIN, GEN>(st, g, 1, split);
   return launch<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN, GEN>(st, g, 1, split);
+}
+
+// float32 operands on the bf16 matrix cores (gemm_bf16x3.h): float4-stageable operands only
+template <int BM, int BN, int WM, int WN>
+int launch3_or(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
+  static const int kb = getenv("SRL_K3") ? atoi(getenv("SRL_K3")) : 32;
+  if (kb == 16) {
+    if (!akm && !bkm) return launch3<BM, BN, WM, WN, false, false, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
+    if (!akm && bkm) return launch3<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
+    if (akm && bkm) return launch3<BM, BN, WM, WN, true, true, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
+    return launch3<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
+  }
+  if (!akm && !bkm) return launch3<BM, BN, WM, WN, false, false, SRC_PLAIN, SRC_PLAIN, 32>(st, g, 1, split);
+  if (!akm && bkm) return launch3<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN, 32>(st, g, 1, split);
+  if (akm && bkm) return launch3<BM, BN, WM, WN, true, true, SRC_PLAIN, SRC_PLAIN, 32>(st, g, 1, split);
+  return launch3<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN, 32>(st, g, 1, split);
 }
 
 // both operands float4-loadable (aligned, leading dimensions multiples of 4): the lean instantiation
@@ -64,6 +84,11 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   }
 
   int rc;
+  if (use_bf16x3() && g.vec_a && g.vec_b && d->M > 64 && d->N > 32 && d->K >= 64) {
+    // bf16 matrix cores, three exact pieces per float32 operand (2.67x fewer matrix-pipe cycles)
+    rc = d->N > 64 ? launch3_or<128, 128, 2, 2>(st, g, d->a_kmajor, d->b_kmajor, nsplit)
+                   : launch3_or<256, 64, 4, 1>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
+  } else
   // long reductions over big outputs: 8-wavefront workgroups on 256x128 tiles (measured +6 % at K = 3136; on the
   // K = 512 shapes the 4-wavefront 128x128 tiles are faster)
   if (d->N > 64 && d->M >= 4096 && d->K >= 2048 && g.vec_a && g.vec_b && nsplit == 1)

@@ -1,0 +1,302 @@
+// float32 contractions on the BF16 matrix cores: C = epilogue( sum_k A(i,k) B(k,j) ) with float32 operands and results.
+//
+// gfx950 multiplies float32 on the matrix cores at the vector rate (157 TFLOP/s, v_mfma_f32_32x32x2_f32) and bf16 at
+// 16x that.  A float32 splits EXACTLY into three bf16 pieces, a = a0 + a1 + a2 (top / middle / low 8 significand bits;
+// truncation splits, every subtraction exact), and a product of two pieces (8 x 8 bits) is exact in the MFMA's float32
+// accumulate.  Of the nine piece products the six with i + j <= 2 are formed,
+//     a b  =  a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0   + O(2^-23 |a b|)        (dropped: a1 b2 + a2 b1 + a2 b2)
+// i.e. every product is good to 2^-23 relative -- a float32 multiply rounds at 2^-24 -- and the sums are float32 like the
+// float32 MFMA's (6 accumulations per 16 k-values instead of 16).  6 bf16 MFMAs of 32 cycles replace 8 float32 MFMAs of
+// 64: 2.67x fewer matrix-pipe cycles.  No scaling is needed (bf16 has float32's exponent range).
+//
+// Operands stay float32 in HBM.  The global -> register half of the staging (addresses, gathers of the implicit
+// convolutions, zero padding) is gemm_core.h's Stage::prepare / Stage::load unchanged; what is new is everything behind
+// it: the split when a tile is written to LDS (three planes of bf16), the fragment reads (ds_read_b128 for an operand
+// that is contiguous along k; ds_read_b64_tr_b16, the transposing LDS read of gfx950, for one that is contiguous along
+// the output index -- no transposing stores), and the MFMA loop.  The epilogue is the shared one.
+#pragma once
+#include "gemm_core.h"
+
+namespace srlgemm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#ifdef __HIPCC__
+// one operand tile in LDS: three planes of BX x KB bf16
+template <int BX, bool KMAJOR, int KB>
+struct Tile3 {
+  static constexpr int PLANE = BX * KB * 2;  // bytes
+  static constexpr int BYTES = 3 * PLANE;
+  // k-contiguous: rows of KB bf16 (PB bytes), their 16-byte chunks XOR-swizzled so that the 16 lanes of a ds_read_b128
+  // group (rows 4 apart in the same chunk) land on distinct 16-byte slots of the 256-byte bank line
+  static constexpr int PB = KB * 2, CPR = PB / 16, RPL = 256 / PB > 0 ? 256 / PB : 1;
+  __device__ static __forceinline__ int off_kc(int x, int k) {  // byte offset of element (row x, k)
+    const int c = (k * 2) >> 4;
+    return x * PB + 16 * (c ^ ((x / RPL) % CPR)) + ((k * 2) & 15);
+  }
+  // k-major: rows of BX bf16 (RB bytes); 64-byte pieces XOR-swizzled so that the four k-rows a transposed read takes
+  // (same columns, consecutive k) land on the four 64-byte quarters of the bank line
+  static constexpr int RB = BX * 2, P64 = RB / 64;
+  __device__ static __forceinline__ int off_km(int k, int x) {  // byte offset of element (k-row k, column x)
+    const int b = x * 2;
+    int pc = b >> 6;
+    if (P64 >= 4) pc ^= (k & 3);
+    else if (P64 == 2) pc ^= ((k >> 1) & 1);
+    return k * RB + 64 * pc + (b & 63);
+  }
+};
+
+__device__ __forceinline__ void split3_quad(const float* v, uint2 (&pl)[3]) {
+  uint32_t b[3][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    b[0][i] = __float_as_uint(v[i]) & 0xffff0000u;
+    const float r1 = v[i] - __uint_as_float(b[0][i]);
+    b[1][i] = __float_as_uint(r1) & 0xffff0000u;
+    b[2][i] = __float_as_uint(r1 - __uint_as_float(b[1][i]));  // at most 8 significant bits: its high half is all of it
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+    pl[p] = make_uint2(__builtin_amdgcn_perm(b[p][1], b[p][0], 0x07060302u), __builtin_amdgcn_perm(b[p][3], b[p][2], 0x07060302u));
+}
+
+// registers of a staged tile (Stage::r, float4 quads in Stage's thread -> (row, k) assignment) -> three bf16 planes in LDS
+template <class ST, int BX, bool KMAJOR, int KB, int NT>
+__device__ __forceinline__ void store3(const ST& st, uint8_t* lds) {
+  using T3 = Tile3<BX, KMAJOR, KB>;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < ST::NV; ++q) {
+    const int u = tid + q * NT;
+    if (ST::PARTIAL && u >= ST::QUADS) continue;
+    uint2 pl[3];
+    split3_quad(st.r + 4 * q, pl);
+    int off;
+    if (!KMAJOR) off = T3::off_kc(u / ST::KQ, (u % ST::KQ) * 4);
+    else off = T3::off_km(u / (BX / 4), (u % (BX / 4)) * 4);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(lds + p * T3::PLANE + off) = pl[p];
+  }
+}
+
+// the lane's fragment (8 consecutive k of one row / column) of 32-wide block `blk`, k-block kb, plane p
+template <int BX, bool KMAJOR, int KB>
+__device__ __forceinline__ bf16x8 frag3(const uint8_t* lds, int p, int x0, int kb, int lane) {
+  using T3 = Tile3<BX, KMAJOR, KB>;
+  const uint8_t* base = lds + p * T3::PLANE;
+  if (!KMAJOR) {
+    union { uint4 u; bf16x8 v; } f;
+    f.u = *reinterpret_cast<const uint4*>(base + T3::off_kc(x0 + (lane & 31), 16 * kb + 8 * (lane >> 5)));
+    return f.v;
+  }
+  // ds_read_b64_tr_b16: in each group of 16 lanes, lane 4q + p4 supplies the address of k-row q, columns 4 p4 .. + 3 of a
+  // 4 x 16 block; lane i of the group receives column i (4 k-rows).  A lane with half h needs k-rows 8h .. 8h + 7.
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const int grp = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3, h = lane >> 5;
+  const int col = x0 + 16 * (grp & 1) + 4 * p4;
+  union { s16x4 s[2]; bf16x8 v; } f;
+  f.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + T3::off_km(16 * kb + 8 * h + q, col)));
+  f.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + T3::off_km(16 * kb + 8 * h + 4 + q, col)));
+  return f.v;
+}
+
+constexpr int min_waves3(int bm, int bn, int kb) {
+  const int lds = 2 * 3 * (bm + bn) * kb * 2;  // two buffers of two three-plane tiles
+  const int by_lds = 160 * 1024 / lds;
+  return by_lds >= 3 ? 3 : (by_lds >= 2 ? 2 : 1);
+}
+
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB>
+__global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_kernel(GemmArgs g) {
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 wavefronts per workgroup");
+  static_assert(!is_obs(AMODE) && !is_obs(BMODE), "observation sources have their own bf16 kernels (obs_bf16.h)");
+  constexpr int NT = 256;
+  using SA = Stage<BM, AKM, AMODE, NT, KB>;
+  using SB = Stage<BN, BKM, BMODE, NT, KB>;
+  using TA = Tile3<BM, AKM, KB>;
+  using TB = Tile3<BN, BKM, KB>;
+  constexpr int BUF = TA::BYTES + TB::BYTES;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  unsigned lid;
+  {  // every XCD owns one contiguous run of logical workgroup ids (see gemm_kernel)
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    lid = xcd * q + (xcd < r ? xcd : r) + slot;
+  }
+  const unsigned bx = g.nbatch > 1 ? lid / g.nbatch : lid;
+  const long tile_m = bx / g.tiles_n, tile_n = bx % g.tiles_n;
+  const long m0 = tile_m * BM, n0 = tile_n * BN;
+  const long kbeg = (long)blockIdx.z * g.k_per_split;
+  const long kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+  const int by = g.nbatch > 1 ? (int)(lid % g.nbatch) : 0;
+  if (by) {
+    const long ao = (long)(by / g.a.brw) * g.a.by_stride + (long)(by % g.a.brw) * g.a.bx_stride;
+    const long bo = (long)(by / g.b.brw) * g.b.by_stride + (long)(by % g.b.brw) * g.b.bx_stride;
+    g.a.base = static_cast<const float*>(g.a.base) + ao;
+    g.b.base = static_cast<const float*>(g.b.base) + bo;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  SA sa;
+  SB sb;
+  sa.prepare(g.a, m0, g.M, kbeg, true);
+  sb.prepare(g.b, n0, g.N, kbeg, true);
+  // column sums of a dense k-major A for free (the bias gradient of a weight-gradient product): see gemm_kernel
+  constexpr bool CSUM = AKM && AMODE == SRC_PLAIN;
+  const bool do_cs = CSUM && g.a_colsum != nullptr && n0 == 0;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  auto cs_acc = [&]() {
+    if (CSUM && do_cs) {
+#pragma unroll
+      for (int q = 0; q < SA::NV; ++q) {
+        cs[0] += sa.r[4 * q]; cs[1] += sa.r[4 * q + 1]; cs[2] += sa.r[4 * q + 2]; cs[3] += sa.r[4 * q + 3];
+      }
+    }
+  };
+  // k-steps; a data-gradient tile of position-grouped rows only visits the steps whose tap reaches the gradient image
+  constexpr bool SKIP = AMODE == SRC_DGRAD;
+  uint64_t kmask = 0;
+  bool use_mask = false;
+  if (SKIP && g.a.grp_shift) {
+    const uint32_t tpos = (uint32_t)tile_m - fdiv((uint32_t)tile_m, g.a.f_img) * g.a.f_img.d;
+    const int py = (int)fdiv(tpos, g.a.f_line), px = (int)tpos - py * (int)g.a.f_line.d;
+    const int nsteps = (int)((kend - kbeg + KB - 1) / KB);  // <= 64 (host)
+    for (int t = 0; t < nsteps; ++t) {
+      const ColInfo ci = col_info<SRC_DGRAD>(g.a, (uint32_t)(kbeg + (long)t * KB));
+      if ((unsigned)(py - ci.jh) < (unsigned)g.a.OH && (unsigned)(px - ci.jw) < (unsigned)g.a.OW) kmask |= 1ull << t;
+    }
+    use_mask = true;
+  }
+  auto nextk = [&](long k) -> long {
+    if (SKIP && use_mask) {
+      if (!kmask) return -1;
+      const int t = __builtin_ctzll(kmask);
+      kmask &= kmask - 1;
+      return kbeg + (long)t * KB;
+    }
+    return k + KB < kend ? k + KB : -1;
+  };
+  long kcur = (SKIP && use_mask) ? nextk(0) : kbeg;
+  long kend_l = kend;
+  if (kcur < 0) { kcur = kbeg; kend_l = kbeg; }  // no tap reaches this pixel: one step on an all-zero tile
+  long knext = nextk(kcur);
+
+  // prologue: the first tile into LDS buffer 0, the second into registers
+  sa.load(g.a, m0, g.M, kcur, kend_l, true);
+  sb.load(g.b, n0, g.N, kcur, kend_l, true);
+  cs_acc();
+  store3<SA, BM, AKM, KB, NT>(sa, lds);
+  store3<SB, BN, BKM, KB, NT>(sb, lds + TA::BYTES);
+  __syncthreads();
+  if (knext >= 0) {
+    sa.load(g.a, m0, g.M, knext, kend, true);
+    sb.load(g.b, n0, g.N, knext, kend, true);
+  }
+
+  // one k-step on LDS buffer `cur`: per 16-deep k-block, fragments of the three planes of both operands and the six
+  // piece products per 32x32 block; after the first k-block the staging of the following tiles (registers -> the other
+  // LDS buffer with the split; global loads of the tile after that), then the single barrier of the step
+  auto kstep = [&](auto cur_c, long k1, long k2) {
+    constexpr int cur = decltype(cur_c)::value;
+    const uint8_t* la = lds + cur * BUF;
+    const uint8_t* lb = la + TA::BYTES;
+    uint8_t* nxt = lds + (cur ^ 1) * BUF;
+#pragma unroll
+    for (int kb = 0; kb < KB / 16; ++kb) {
+      bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[i][p] = frag3<BM, AKM, KB>(la, p, wm * (TM * 32) + i * 32, kb, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[j][p] = frag3<BN, BKM, KB>(lb, p, wn * (TN * 32) + j * 32, kb, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          // small terms first: they meet an accumulator that has not grown by this block's leading term yet
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+        }
+      if (kb == 0) {
+        if (k1 >= 0) {  // tile t+1: registers -> the other LDS buffer (its readers left at the last barrier)
+          cs_acc();
+          store3<SA, BM, AKM, KB, NT>(sa, nxt);
+          store3<SB, BN, BKM, KB, NT>(sb, nxt + TA::BYTES);
+        }
+        if (k2 >= 0) {  // tile t+2: global -> registers
+          sa.load(g.a, m0, g.M, k2, kend, true);
+          sb.load(g.b, n0, g.N, k2, kend, true);
+        }
+      }
+    }
+    __syncthreads();
+  };
+  for (;;) {
+    long k2 = knext >= 0 ? nextk(knext) : -1;
+    kstep(std::integral_constant<int, 0>{}, knext, k2);
+    if (knext < 0) break;
+    knext = k2;
+    k2 = knext >= 0 ? nextk(knext) : -1;
+    kstep(std::integral_constant<int, 1>{}, knext, k2);
+    if (knext < 0) break;
+    knext = k2;
+  }
+  if (CSUM && do_cs) {  // workgroup-uniform; the tiles in LDS are dead after the loop's last barrier
+    constexpr int G = BM / 4;
+    float* lf = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lf[tid * 4 + c] = cs[c];
+    __syncthreads();
+    if (tid < G) {
+      float t4[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NT / G; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t4[c] += lf[(tid + j * G) * 4 + c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (m0 + tid * 4 + c < g.M) atomicAdd(g.a_colsum + (long)by * g.a_colsum_batch + m0 + tid * 4 + c, t4[c]);
+    }
+  }
+  gemm_epilogue<TM, TN>(g, acc, m0, n0, wm, wn, l31, h, by);
+}
+
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB = 32>
+inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
+  if (!(a.vec_a && a.vec_b)) return -EINVAL;
+  const long tiles_m = srl_ceil_div(a.M, BM);
+  a.tiles_n = (int)srl_ceil_div(a.N, BN);
+  a.nbatch = batch > 1 ? batch : 1;
+  const long nblk = tiles_m * a.tiles_n * a.nbatch;
+  if (nblk > 0x7fffffffL || nsplit > 65535) return -EINVAL;
+  dim3 grid((unsigned)nblk, 1, (unsigned)nsplit);
+  hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB>), grid, dim3(256), 0, st, a);
+  return 0;
+}
+#endif  // __HIPCC__
+
+// SRL_MFMA=f32 forces the float32 MFMA kernels everywhere (A/B timing, cross-checks in the tests)
+inline bool use_bf16x3() {
+  const char* e = getenv("SRL_MFMA");
+  return !(e && e[0] == 'f');
+}
+
+}  // namespace srlgemm

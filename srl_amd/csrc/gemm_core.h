@@ -578,6 +578,106 @@ struct Stage {
   }
 };
 
+// ---- epilogue shared by the float32 and the bf16x3 kernels: bias, activation, activation-derivative mask of the
+// producer, accumulate, split-K slabs, row / column-group maps.  acc[i][j] is the 32x32 block (i, j) of the wavefront's
+// tile in the MFMA accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN], long m0, long n0, int wm, int wn, int l31,
+                                              int h, int by) {
+  // ---- epilogue: per 32x32 accumulator block, all loads batched ahead of the arithmetic and the stores ----------------
+  const long obatch = g.o.brw ? (long)(by / g.o.brw) * g.o.batch_stride + (long)(by % g.o.brw) * g.o.bx_stride
+                              : (long)by * g.o.batch_stride;
+  float* out = g.o.out + (long)blockIdx.z * g.slab + obatch;
+  if (g.o.rowmap && g.dact_src) g.dact_src += obatch;  // the activation shares the output's map
+  const float* bias = g.bias ? g.bias + (long)by * g.bias_batch : nullptr;
+  // Row addressing stays 32-bit: a 64-bit base per 32-row block plus element offsets (dense output), or offsets
+  // from the tensor base through the (image, line, pixel) map (callers keep mapped outputs below 2^32 elements).
+  const uint32_t ldo = (uint32_t)g.o.ldo, ldd = (uint32_t)g.ld_dact;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long row0 = m0 + wm * (TM * 32) + i * 32 + 4 * h;  // accumulator register r holds row0 + (r&3) + 8*(r>>2)
+    float* ob = out;
+    const float* db = g.dact_src;
+    uint32_t ro[16];
+    uint32_t okm = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cr = (r & 3) + 8 * (r >> 2);
+      const bool ok = row0 + cr < g.M;
+      okm |= (ok ? 1u : 0u) << r;
+      if (g.o.rowmap) {
+        const uint32_t rr = ok ? (uint32_t)(row0 + cr) : 0u;
+        uint32_t n = fdiv(rr, g.o.f_img);
+        uint32_t rem = rr - n * g.o.f_img.d;
+        if (g.o.grp_shift) {  // position-grouped rows (see SrcDesc::grp_shift)
+          const uint32_t tile = rr >> g.o.grp_shift, nl = rr & ((1u << g.o.grp_shift) - 1u);
+          const uint32_t gq = fdiv(tile, g.o.f_img);
+          rem = tile - gq * g.o.f_img.d;
+          n = (gq << g.o.grp_shift) + nl;
+          if (n >= (uint32_t)g.o.n_img) { n = 0; okm &= ~(1u << r); }
+        }
+        const uint32_t y = fdiv(rem, g.o.f_line);
+        const uint32_t x = rem - y * g.o.f_line.d;
+        ro[r] = n * (uint32_t)g.o.img_stride + y * (uint32_t)g.o.y_stride + x * (uint32_t)g.o.x_stride;
+      } else {
+        ro[r] = (uint32_t)cr * ldo;
+      }
+    }
+    if (!g.o.rowmap) {
+      ob += row0 * g.o.ldo;
+      if (db) db += row0 * g.ld_dact;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const long col = n0 + wn * (TN * 32) + j * 32 + l31;
+      const bool cok = col < g.N;
+      const uint32_t cb = cok ? (uint32_t)col : 0u;  // bias index
+      uint32_t cc = cb;                               // offset of the column inside an output row
+      if (g.o.cg_width) {
+        const uint32_t grp = fdiv(cb, g.o.f_cg);
+        cc = (uint32_t)((grp / g.o.cg_brw) * g.o.cg_ystride + (grp % g.o.cg_brw) * g.o.cg_xstride) + (cb - grp * g.o.cg_width);
+      }
+      const uint32_t okj = cok ? okm : 0u;
+      float v[16];
+      const float bv = bias ? bias[cb] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+      if (g.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (g.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
+      }
+      if (db) {
+        float yv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t o = g.o.rowmap ? ro[r] : (uint32_t)((r & 3) + 8 * (r >> 2)) * ldd;
+          yv[r] = ((okj >> r) & 1u) ? db[o + cc] : 1.f;
+        }
+        if (g.dact == 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = yv[r] > 0.f ? v[r] : 0.f;
+        } else if (g.dact == 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] *= 1.f - yv[r] * yv[r];
+        }
+      }
+      if (g.accumulate) {
+        float ov[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ov[r] = ((okj >> r) & 1u) ? ob[ro[r] + cc] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += ov[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if ((okj >> r) & 1u) ob[ro[r] + cc] = v[r];
+    }
+  }
+}
+
 // GEN: the dense operands may need the element-wise (unaligned / ragged leading dimension) staging path.  The
 // float4-only instantiation (GEN = false) carries no per-element pointers and needs far fewer registers.
 // Wavefronts per SIMD the register allocator is asked to fit (second __launch_bounds__ argument on AMD): three
@@ -896,98 +996,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     }
   }
 
-  // ---- epilogue: per 32x32 accumulator block, all loads batched ahead of the arithmetic and the stores ----------------
-  const long obatch = g.o.brw ? (long)(by / g.o.brw) * g.o.batch_stride + (long)(by % g.o.brw) * g.o.bx_stride
-                              : (long)by * g.o.batch_stride;
-  float* out = g.o.out + (long)blockIdx.z * g.slab + obatch;
-  if (g.o.rowmap && g.dact_src) g.dact_src += obatch;  // the activation shares the output's map
-  const float* bias = g.bias ? g.bias + (long)by * g.bias_batch : nullptr;
-  // Row addressing stays 32-bit: a 64-bit base per 32-row block plus element offsets (dense output), or offsets
-  // from the tensor base through the (image, line, pixel) map (callers keep mapped outputs below 2^32 elements).
-  const uint32_t ldo = (uint32_t)g.o.ldo, ldd = (uint32_t)g.ld_dact;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const long row0 = m0 + wm * (TM * 32) + i * 32 + 4 * h;  // accumulator register r holds row0 + (r&3) + 8*(r>>2)
-    float* ob = out;
-    const float* db = g.dact_src;
-    uint32_t ro[16];
-    uint32_t okm = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cr = (r & 3) + 8 * (r >> 2);
-      const bool ok = row0 + cr < g.M;
-      okm |= (ok ? 1u : 0u) << r;
-      if (g.o.rowmap) {
-        const uint32_t rr = ok ? (uint32_t)(row0 + cr) : 0u;
-        uint32_t n = fdiv(rr, g.o.f_img);
-        uint32_t rem = rr - n * g.o.f_img.d;
-        if (g.o.grp_shift) {  // position-grouped rows (see SrcDesc::grp_shift)
-          const uint32_t tile = rr >> g.o.grp_shift, nl = rr & ((1u << g.o.grp_shift) - 1u);
-          const uint32_t gq = fdiv(tile, g.o.f_img);
-          rem = tile - gq * g.o.f_img.d;
-          n = (gq << g.o.grp_shift) + nl;
-          if (n >= (uint32_t)g.o.n_img) { n = 0; okm &= ~(1u << r); }
-        }
-        const uint32_t y = fdiv(rem, g.o.f_line);
-        const uint32_t x = rem - y * g.o.f_line.d;
-        ro[r] = n * (uint32_t)g.o.img_stride + y * (uint32_t)g.o.y_stride + x * (uint32_t)g.o.x_stride;
-      } else {
-        ro[r] = (uint32_t)cr * ldo;
-      }
-    }
-    if (!g.o.rowmap) {
-      ob += row0 * g.o.ldo;
-      if (db) db += row0 * g.ld_dact;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const long col = n0 + wn * (TN * 32) + j * 32 + l31;
-      const bool cok = col < g.N;
-      const uint32_t cb = cok ? (uint32_t)col : 0u;  // bias index
-      uint32_t cc = cb;                               // offset of the column inside an output row
-      if (g.o.cg_width) {
-        const uint32_t grp = fdiv(cb, g.o.f_cg);
-        cc = (uint32_t)((grp / g.o.cg_brw) * g.o.cg_ystride + (grp % g.o.cg_brw) * g.o.cg_xstride) + (cb - grp * g.o.cg_width);
-      }
-      const uint32_t okj = cok ? okm : 0u;
-      float v[16];
-      const float bv = bias ? bias[cb] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
-      if (g.act == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-      } else if (g.act == 2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
-      }
-      if (db) {
-        float yv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t o = g.o.rowmap ? ro[r] : (uint32_t)((r & 3) + 8 * (r >> 2)) * ldd;
-          yv[r] = ((okj >> r) & 1u) ? db[o + cc] : 1.f;
-        }
-        if (g.dact == 1) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = yv[r] > 0.f ? v[r] : 0.f;
-        } else if (g.dact == 2) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] *= 1.f - yv[r] * yv[r];
-        }
-      }
-      if (g.accumulate) {
-        float ov[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ov[r] = ((okj >> r) & 1u) ? ob[ro[r] + cc] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += ov[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if ((okj >> r) & 1u) ob[ro[r] + cc] = v[r];
-    }
-  }
+  gemm_epilogue<TM, TN>(g, acc, m0, n0, wm, wn, l31, h, by);
 }
 
 static __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* ws, int nslab, long batch, long M, long N,
