@@ -6,11 +6,14 @@
 #include <stdlib.h>
 
 #include "gemm_core.h"
+#include "gemm_bf16x3.h"
 #include "obs_bf16.h"
 
 using namespace srlgemm;
 
 namespace {
+
+constexpr int K3 = 16;  // k-step depth of the bf16x3 kernels (48 KB of LDS per 128x128 workgroup: three per CU)
 
 inline int conv_out(int in, int k, int s) { return (in - k) / s + 1; }
 
@@ -305,8 +308,11 @@ extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const f
   g.vec_a = 1; g.vec_b = 1;
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (d->Cout > 64) rc = launch<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
-  else if (d->Cout > 32) rc = launch<256, 64, 4, 1, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
+  const bool x3 = use_bf16x3() && Kp >= 64;  // bf16 matrix cores, three exact pieces per float32 operand
+  if (d->Cout > 64) rc = x3 ? launch3<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3>(st, g, 1, 1)
+                            : launch<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
+  else if (d->Cout > 32) rc = x3 ? launch3<256, 64, 4, 1, false, false, SRC_CONV, SRC_PLAIN, K3>(st, g, 1, 1)
+                                 : launch<256, 64, 4, 1, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
   else rc = launch<256, 32, 4, 1, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
   SRL_CHECK_ARG(rc == 0, "grid too large");
   SRL_LAUNCH_CHECK();
@@ -345,8 +351,10 @@ extern "C" int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const
   g.vec_a = 1; g.vec_b = 1;
   g.a_colsum = dbias;
   hipStream_t st = (hipStream_t)stream;
-  int rc = bm == 64 ? launch<64, 256, 1, 4, true, true, SRC_PLAIN, SRC_CONV>(st, g, 1, nsplit)
-                    : launch<32, 256, 1, 4, true, true, SRC_PLAIN, SRC_CONV>(st, g, 1, nsplit);
+  int rc;
+  if (bm == 64) rc = use_bf16x3() ? launch3<64, 256, 1, 4, true, true, SRC_PLAIN, SRC_CONV, K3>(st, g, 1, nsplit)
+                                  : launch<64, 256, 1, 4, true, true, SRC_PLAIN, SRC_CONV>(st, g, 1, nsplit);
+  else rc = launch<32, 256, 1, 4, true, true, SRC_PLAIN, SRC_CONV>(st, g, 1, nsplit);
   SRL_CHECK_ARG(rc == 0, "grid too large");
   SRL_LAUNCH_CHECK();
   if (nsplit > 1) {
@@ -442,10 +450,13 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
       SRL_CHECK_ARG(fits31(g.M), "unsupported geometry (too many rows)");
     }
     int rc;
+    const bool x3 = use_bf16x3() && d->Cout % K3 == 0;  // the step mask skips whole taps: a k-step must not straddle two
     if (g.K == 0) {  // no tap reaches this class: gradient is zero there (k loop is empty, epilogue writes 0)
       rc = launch<256, 32, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);
-    } else if (ncols > 64) rc = launch<128, 128, 2, 2, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
-    else if (ncols > 32) rc = launch<256, 64, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
+    } else if (ncols > 64) rc = x3 ? launch3<128, 128, 2, 2, false, true, SRC_DGRAD, SRC_PLAIN, K3>(st, g, batch, 1)
+                                   : launch<128, 128, 2, 2, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
+    else if (ncols > 32) rc = x3 ? launch3<256, 64, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN, K3>(st, g, batch, 1)
+                                 : launch<256, 64, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
     else rc = launch<256, 32, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
     SRL_CHECK_ARG(rc == 0, "grid too large");
   }

@@ -23,7 +23,7 @@ int launch_or(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
 // float32 operands on the bf16 matrix cores (gemm_bf16x3.h): float4-stageable operands only
 template <int BM, int BN, int WM, int WN>
 int launch3_or(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
-  static const int kb = getenv("SRL_K3") ? atoi(getenv("SRL_K3")) : 32;
+  static const int kb = getenv("SRL_K3") ? atoi(getenv("SRL_K3")) : 16;
   if (kb == 16) {
     if (!akm && !bkm) return launch3<BM, BN, WM, WN, false, false, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
     if (!akm && bkm) return launch3<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
