@@ -86,6 +86,10 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   int rc;
   if (use_bf16x3() && g.vec_a && g.vec_b && d->M > 64 && d->N > 32 && d->K >= 64) {
     // bf16 matrix cores, three exact pieces per float32 operand (2.67x fewer matrix-pipe cycles)
+    static const int big = getenv("SRL_T3") ? atoi(getenv("SRL_T3")) : 0;
+    if (d->N > 64 && big == 1) rc = launch3_or<256, 128, 2, 2>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
+    else if (d->N > 64 && big == 2) rc = launch3_or<128, 256, 2, 2>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
+    else
     rc = d->N > 64 ? launch3_or<128, 128, 2, 2>(st, g, d->a_kmajor, d->b_kmajor, nsplit)
                    : launch3_or<256, 64, 4, 1>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
   } else

@@ -319,6 +319,38 @@ def test_gemm_orientations(M, N, K, akm, bkm):
     assert rel_close(C.cpu().numpy(), ref, 1e-5, scale=float(np.sqrt(K)))
 
 
+@pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K,dyn", [(512, 384, 1024, 0), (260, 200, 3136, 0), (1024, 128, 512, 12), (384, 640, 2048, 30)])
+def test_gemm_bf16x3_is_as_accurate_as_the_float32_mfma(M, N, K, dyn, akm, bkm):
+    """float32 GEMMs run on the bf16 matrix cores with three exact bf16 pieces per operand and the six leading piece
+    products (gemm_bf16x3.h).  Against float64: the error must be that of a float32 contraction -- compared here with the
+    float32-MFMA kernel (SRL_MFMA=f32) on the same inputs, element by element and in the mean.  `dyn`: operands spread over
+    2^+-dyn in magnitude (every piece keeps float32's exponent range: no scaling, no underflow)."""
+    import os
+    rng = np.random.default_rng(M + N + K + dyn)
+    spread = lambda shape: (rng.standard_normal(shape) * np.exp2(rng.uniform(-dyn, dyn, shape))).astype(np.float32)
+    A, B = spread((K, M) if akm else (M, K)), spread((K, N) if bkm else (N, K))
+    dA, dB = dev(A), dev(B)
+    ref = _gemm_ref(A, B, akm, bkm)
+    A64 = np.abs(A.astype(np.float64).T if akm else A.astype(np.float64))
+    B64 = np.abs(B.astype(np.float64) if bkm else B.astype(np.float64).T)
+    mag = A64 @ B64  # sum_k |a||b|: the scale rounding errors are relative to
+    errs = {}
+    for mode in ("bf16x3", "f32"):
+        if mode == "f32":
+            os.environ["SRL_MFMA"] = "f32"
+        try:
+            C = torch.full((M, N), np.nan, device=DEV)
+            hip.gemm(M, N, K, dA.data_ptr(), A.shape[1], akm, dB.data_ptr(), B.shape[1], bkm, C.data_ptr(), N)
+            errs[mode] = np.abs(C.cpu().numpy().astype(np.float64) - ref) / mag
+        finally:
+            os.environ.pop("SRL_MFMA", None)
+    # float32 unit roundoff is 6e-8; a K-term float32 sum stays well below K times that
+    assert errs["bf16x3"].max() <= 2e-6 and errs["f32"].max() <= 2e-6, (errs["bf16x3"].max(), errs["f32"].max())
+    assert errs["bf16x3"].mean() <= 1.5 * errs["f32"].mean() + 1e-9, (errs["bf16x3"].mean(), errs["f32"].mean())
+    assert errs["bf16x3"].max() <= 3.0 * errs["f32"].max() + 1e-9, (errs["bf16x3"].max(), errs["f32"].max())
+
+
 def test_gemm_epilogues_and_split():
     rng = np.random.default_rng(5)
     M, N, K = 700, 96, 200
