@@ -188,7 +188,7 @@ def cpu_baseline(T):
 
 
 def recorded_traffic(kernel_substr, envs, T, chunk_rows):
-    """HBM bytes per step of the kernels whose name contains `kernel_substr`, from the newest PMC passes committed
+    """HBM bytes per step of the kernels whose name contains one of `kernel_substr`, from the newest PMC passes committed
     under profiles/ (FETCH_SIZE and WRITE_SIZE in separate `rocprofv3 --pmc` runs of this script, FETCH_SIZE x2 per
     the MI355X guide's gfx950 correction: scripts/hbm_traffic.py, which records the run's configuration next to the
     table).  Counters cannot be read from inside the process, so the line carries the recorded figure and names its
@@ -206,7 +206,7 @@ def recorded_traffic(kernel_substr, envs, T, chunk_rows):
         total = 0.0
         with open(mf[:-5] + ".csv") as f:
             for r in csv.DictReader(f):
-                if kernel_substr in r["kernel"]:
+                if any(sub in r["kernel"] for sub in kernel_substr):
                     per_launch = float(r["FETCH_bytes_per_launch_corrected_x2"]) + float(r["WRITE_bytes_per_launch"])
                     total += per_launch * float(r["dispatches"]) / meta["steps_in_run"]
         return dict(traffic=round(total), traffic_unit="HBM bytes per step (fetch + write) over the same launches",
@@ -320,7 +320,7 @@ def main():
                         fp32_mfma_peak=PEAK_FP32_MFMA_TFLOPS, achieved_over_fp32_mfma_peak=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                         launches=g["calls"], ms_per_step=round(g["ms"], 3), flops_per_step=g["work"],
                         flops_per_env_step=g["work"] / (T * B),
-                        **recorded_traffic("gemm", B, T, args.chunk_rows))
+                        **recorded_traffic(("gemm", "obs_fwd_bf16", "obs_bwd_bf16"), B, T, args.chunk_rows))
         # the scan is a ~microsecond kernel: time it as back-to-back launches between two events on the launch
         # stream so that host enqueue latency does not sit inside the interval
         floor = launch_floor_us(device)
