@@ -475,6 +475,10 @@ extern "C" int srl_gae_scan(void* stream, const float* reward, const float* valu
   SRL_CHECK_ARG(T >= 0 && B >= 0 && Nc >= 1, "T, B >= 0 and Nc >= 1 required");
   hipStream_t st = (hipStream_t)stream;
   SRL_CHECK_ARG(!workspace || aligned_to(workspace, 8), "workspace must be 8-byte aligned");
+  // The ticketed reduction pays a release fence per workgroup (its own stores must have landed before the ticket): worth it
+  // where the zeroing launch is a large part of the call (<= 768 workgroups), not on grids that stream for hundreds of
+  // microseconds (measured at 2^20 environments: 547 us against 505 with the memset + atomics)
+  if ((long)B * Nc >= 98304) workspace = nullptr;
   if (stats && (!workspace || T == 0 || B == 0)) SRL_HIP_TRY(hipMemsetAsync(stats, 0, 3 * sizeof(double), st));
   if (T == 0 || B == 0) return 0;  // empty batch: nothing to scan (tensors may be null)
   SRL_CHECK_ARG(reward && value && done && truncated && on_reset && adv && ret, "null tensor");

@@ -122,7 +122,7 @@ def test_gae_tensor_gamma_lambda_golden(golden):
         run_gae(arr, gam[:-1], 0.9)
 
 
-@pytest.mark.parametrize("T,B", [(128, 4096), (128, 512), (33, 12), (64, 100000), (7, 10)])
+@pytest.mark.parametrize("T,B", [(128, 4096), (128, 512), (33, 12), (64, 90000), (7, 10)])
 def test_gae_stats_workspace_is_reproducible_and_self_resetting(T, B):
     """With a workspace the three sums need no zeroing launch: partial sums per workgroup, added in workgroup order by the
     last workgroup to finish.  Same sums as the atomic path (to float64 rounding), bitwise equal from launch to launch, and
