@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 3
+#define SRL_HIP_ABI_VERSION 4
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -191,10 +191,12 @@ typedef struct srl_ppo_hparams {
 enum { SRL_LT_POLICY = 0, SRL_LT_VALUE = 1, SRL_LT_ENTROPY = 2, SRL_LT_CLIP = 3, SRL_LT_RATIO = 4,
        SRL_LT_ADV = 5, SRL_LT_RET = 6, SRL_LT_MASK = 7, SRL_LT_DONE = 8, SRL_LT_TRUNC = 9, SRL_LT_COUNT = 10 };
 
-/* new_lp, old_lp, value, old_value, adv (raw, un-normalised), ret, entropy: float32[n]; mask uint8[n].
+/* new_lp, old_lp, entropy: float32[n]; mask uint8[n]; value, old_value, adv (raw, un-normalised), ret:
+ * float32[n, value_dim] (the reference's loss is shape-agnostic: ratio, mask and entropy broadcast over the value
+ * channels and every masked mean divides the sum over ALL channels by the mask count, mappo.py:184,197).
  * norm_stats: float64[3] global {n, s, q} for the advantage normalisation.
  * local_n: float64[1], this rank's sum(mask) — every masked mean divides by it (mappo.py:184,197,199).
- * Outputs: d_new_lp, d_value, d_entropy float32[n] = d loss / d input;
+ * Outputs: d_new_lp, d_entropy float32[n], d_value float32[n, value_dim] = d loss / d input;
  *          loss_terms float64[SRL_LT_COUNT] (zeroed, then accumulated): masked SUMS of policy loss,
  *          value loss, entropy, 1[s2<s1], ratio, adv, ret, and mask; the caller forms
  *          loss = (P + w_v*V - w_H*E) / M.  done / truncated (uint8[n], nullable) are only summed
@@ -202,9 +204,9 @@ enum { SRL_LT_POLICY = 0, SRL_LT_VALUE = 1, SRL_LT_ENTROPY = 2, SRL_LT_CLIP = 3,
  *          (mappo.py:40-41,293-296). */
 int srl_ppo_loss_fwd_bwd(void* stream, const float* new_lp, const float* old_lp, const float* value,
                          const float* old_value, const float* adv, const float* ret, const float* entropy,
-                         const uint8_t* mask, long n, const srl_ppo_hparams* hp, const double* norm_stats,
-                         const double* local_n, const uint8_t* done, const uint8_t* truncated, float* d_new_lp,
-                         float* d_value, float* d_entropy, double* loss_terms);
+                         const uint8_t* mask, long n, int value_dim, const srl_ppo_hparams* hp,
+                         const double* norm_stats, const double* local_n, const uint8_t* done, const uint8_t* truncated,
+                         float* d_new_lp, float* d_value, float* d_entropy, double* loss_terms);
 
 /* ------------------------------------------------------------------------------------------------
  * Categorical heads.  Replaces torch.distributions.Categorical log_prob / entropy / sample in

@@ -357,8 +357,12 @@ class MultiAgentPPO(PytorchTrainer):
         lo, hi = burn, Tb - boot  # valid rows (mappo.py:259)
         n_valid = (hi - lo) * B
         Nc = L["old_value"].shape[2] if len(L["old_value"].shape) > 2 else 1
-        if Nc != 1:
-            raise NotImplementedError("value_dim > 1 through the PPO loss is not on the HIP path (the scan supports it)")
+        if Nc != net.spec.value_dim:
+            raise ValueError(f"sample values have {Nc} channels, the policy's value head {net.spec.value_dim}")
+        if Nc > 1 and len(L["reward"].shape) > 2 and L["reward"].shape[2] == 1:  # one reward for every channel (broadcast, :131)
+            r = L["reward"]
+            L["reward"] = (np.ascontiguousarray(np.broadcast_to(r, (*r.shape[:2], Nc))) if isinstance(r, np.ndarray) else
+                           r.expand(*r.shape[:2], Nc).contiguous())
         if not have_adv and boot == 0:
             raise ValueError("bootstrap_steps == 0 requires advantages computed before the trainer")
 
@@ -382,10 +386,11 @@ class MultiAgentPPO(PytorchTrainer):
             row = erow[:nch * hip.LT_COUNT].reshape(nch, hip.LT_COUNT).sum(0)
             tail = erow[nch * hip.LT_COUNT:]
             msum = max(row[hip.LT_MASK], 1e-30)
-            if self.popart:  # PPOStepResult.denorm_value: masked mean of the de-normalised targets (:215)
-                train_stats["denorm_value"] += tail[2] / max(tail[1], 1e-30)
-            for key, slot in _STAT_TERMS:
-                train_stats[key] += row[slot] / msum
+            if self.popart:  # PPOStepResult.denorm_value: masked mean of the de-normalised targets (:215), all channels
+                ps = tail[1:1 + 3 * Nc].reshape(Nc, 3)
+                train_stats["denorm_value"] += ps[:, 1].sum() / max(ps[:, 0].sum(), 1e-30)
+            for key, slot in _STAT_TERMS:  # masked_select broadcasts the mask over the value channels (:205-216)
+                train_stats[key] += row[slot] / (msum * Nc if slot in (hip.LT_CLIP, hip.LT_ADV, hip.LT_RET) else msum)
             train_stats["done"] += row[hip.LT_DONE] / max(n_valid, 1)
             train_stats["truncated"] += row[hip.LT_TRUNC] / max(n_valid, 1)
             train_stats["grad_norm"] += float(tail[:1].view(np.float32)[0])
@@ -496,7 +501,7 @@ class MultiAgentPPO(PytorchTrainer):
         boot, burn = self.bootstrap_steps, self.burn_in_steps
         lo, hi = burn, Tb - boot
         n_valid = (hi - lo) * B
-        Nc = 1
+        Nc = net.spec.value_dim
         f64 = dict(dtype=torch.float64, device=dev)
         # step-persistent device state lives in the net's workspace: nothing below allocates in steady state
         stats_local = net.ws.get("mappo.stats_local", 3, torch.float64)[:3]
@@ -510,7 +515,7 @@ class MultiAgentPPO(PytorchTrainer):
         n_valid_rows = (Tb - self.bootstrap_steps - self.burn_in_steps) * B
         chunk_rows = n_valid_rows if net.spec.num_rnn_layers else self.chunk_rows
         nchunks = max(1, -(-n_valid_rows // chunk_rows))
-        stride = nchunks * hip.LT_COUNT + 1 + 3
+        stride = nchunks * hip.LT_COUNT + 1 + 3 * Nc
         block = net.ws.get("mappo.out", self.ppo_epochs * stride, torch.float64)[:self.ppo_epochs * stride]
         block.zero_()
         block = block.view(self.ppo_epochs, stride)
@@ -530,7 +535,7 @@ class MultiAgentPPO(PytorchTrainer):
                         adv_d[Tb - 1:].zero_()
                         ret_d[Tb - 1:].zero_()
                         self._padded = (adv_d.data_ptr(), ret_d.data_ptr(), Tb, B, Nc)
-                    fused_stats = boot == 1 and burn == 0
+                    fused_stats = boot == 1 and burn == 0  # the scan's own sums are those of the loss rows
                     gws = self._gae_ws.get((B, Nc))
                     if gws is None:  # zeroed once; afterwards the scan's own last workgroup resets it
                         gws = self._gae_ws[(B, Nc)] = hip.gae_scan_workspace(B, Nc, dev)
@@ -543,8 +548,12 @@ class MultiAgentPPO(PytorchTrainer):
                                  adv_d, ret_d, stats=stats_local if fused_stats else None, imp_ratio=ratio,
                                  workspace=gws if fused_stats else None)
                 mask_rows = on_reset[1 + lo:1 + hi]  # loss_mask = 1 - on_reset[1+burn : 1+Tb-boot]  (:260-261)
-                if not fused_stats:
+                if not fused_stats and Nc == 1:
                     hip.masked_stats(adv_d[lo:hi], mask_rows, stats_local, mask_invert=True)
+                elif not fused_stats:  # [n, Nc] advantages under an [n] mask: per-channel sums, the mask counted once
+                    cs = torch.zeros((Nc, 3), **f64)
+                    hip.masked_stats_cols(adv_d[lo:hi].reshape(-1, Nc), mask_rows, cs, Nc, mask_invert=True)
+                    stats_local.copy_(torch.stack([cs[0, 0], cs[:, 1].sum(), cs[:, 2].sum()]))
                 if self._dist:
                     stats_global.copy_(stats_local)
                     # one 24-byte message instead of three (utils.py:58-61), issued asynchronously: it crosses the
@@ -560,7 +569,7 @@ class MultiAgentPPO(PytorchTrainer):
             # ---- PopArt: statistics of the value targets, then the loss sees normalised targets (:263-264, :173-176) ----
             loss_ret, pstats_local = ret_d, None
             if self.popart:
-                pstats_local = block[epoch, stride - 3:].view(1, 3)  # zeroed by srl_masked_stats_cols itself
+                pstats_local = block[epoch, stride - 3 * Nc:].view(Nc, 3)  # zeroed by srl_masked_stats_cols itself
                 hip.masked_stats_cols(flat(ret_d), on_reset[1 + lo:1 + hi], pstats_local, Nc, mask_invert=True)
                 pstats = pstats_local.clone()
                 if self._dist:
@@ -599,17 +608,18 @@ class MultiAgentPPO(PytorchTrainer):
                 self.policy.dist_fwd(logits, f_action[r0:r1], c_avail, logp, ent)
                 self.policy.mask_dead(logp, None if f_alive is None else f_alive[r0:r1])
                 d_lp = net.ws.get("d_logp", n)[:n]
-                d_v = net.ws.get("d_value", n)[:n]
+                d_v = net.ws.get("d_value", n * Nc)[:n * Nc]
                 d_ent = net.ws.get("d_entropy", n)[:n]
                 if stats_work is not None:  # the global advantage statistics: first needed here
                     stats_work.join() if stats_work is self._comm else stats_work.wait()
                     stats_work = None
-                hip.ppo_loss_fwd_bwd(logp, f_oldlp[r0:r1], value.reshape(-1), f_oldv[r0:r1], f_adv[r0:r1], f_ret[r0:r1],
+                hip.ppo_loss_fwd_bwd(logp, f_oldlp[r0:r1], value.reshape(-1), f_oldv[r0 * Nc:r1 * Nc], f_adv[r0 * Nc:r1 * Nc],
+                                     f_ret[r0 * Nc:r1 * Nc],
                                      ent, f_mask[r0:r1], self._hp, stats_global, local_n, d_lp, d_v, d_ent, terms[ci],
-                                     done=f_done[r0:r1], truncated=f_trunc[r0:r1])
+                                     done=f_done[r0:r1], truncated=f_trunc[r0:r1], value_dim=Nc)
                 d_logits = net.ws.get("d_logits", logits.numel())[:logits.numel()].view_as(logits)
                 d_ls = self.policy.dist_bwd(logits, f_action[r0:r1], c_avail, d_lp, d_ent, d_logits)
-                net.backward(d_logits, d_v.view(n, 1), d_ls)
+                net.backward(d_logits, d_v.view(n, Nc), d_ls)
 
             # ---- gradient reduction, clip, Adam (mappo.py:272-284) ---------------------------------------------------
             if reducer is not None:  # the buckets not yet launched, then wait for all of them

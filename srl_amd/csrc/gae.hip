@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void gae_scan_kernel(GaeParams p) {
         p.ret[t * ncols + col] = advf + s_v[r * COLS + lc];  // mappo.py:143 (float32 add)
         const double mask = 1.0 - (double)s_or[(r + 1) * COLS + lc];  // mappo.py:260
         const double x = (double)advf * mask;                           // utils.py:52
-        acc[0] += mask;
+        // the mask is [T, B, 1]: its sum counts every (step, env) once, whatever the number of value channels (utils.py:41-47)
+        if (col % p.Nc == 0) acc[0] += mask;
         acc[1] += x;
         acc[2] += x * x;
       }

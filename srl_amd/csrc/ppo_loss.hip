@@ -29,6 +29,7 @@ struct LossArgs {
   const float *new_lp, *old_lp, *value, *old_value, *adv, *ret, *entropy;
   const uint8_t* mask;
   long n;
+  int vd;  // value channels: value / old_value / adv / ret / d_value are [n, vd], the rest [n] (broadcast over channels)
   srl_ppo_hparams hp;
   const double* norm_stats;
   const double* local_n;
@@ -54,57 +55,64 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs a) {
 
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long)gridDim.x * 256) {
     const float m = hp.mask_invert ? 1.0f - (float)a.mask[i] : (float)a.mask[i];
-    const float adv = a.adv[i];
-    const float nadv = (float)(((double)adv * (double)m - mean) / denom);  // mappo.py:187
-    const float ratio = expf(a.new_lp[i] - a.old_lp[i]);                  // mappo.py:157
+    const float ratio = expf(a.new_lp[i] - a.old_lp[i]);  // mappo.py:157
     const float rc = fminf(fmaxf(ratio, lo), hi);
-    const float s1 = ratio * nadv, s2 = rc * nadv;  // mappo.py:188-190
     const bool in_range = ratio >= lo && ratio <= hi;
-    // d min(s1,s2) / d ratio with torch's tie rule (equal -> half through each branch)
-    float gmin;
-    if (s1 < s2) gmin = nadv;
-    else if (s1 > s2) gmin = in_range ? nadv : 0.f;
-    else gmin = 0.5f * nadv + (in_range ? 0.5f * nadv : 0.f);
-    const float mn = fminf(s1, s2);
-    float pl, gfac;
-    if (hp.dual_clip) {
-      const float sg = nadv > 0.f ? 1.f : (nadv < 0.f ? -1.f : 0.f);
-      const float s3 = -sg * hp.c_clip * nadv;  // mappo.py:192
-      pl = -fmaxf(mn, s3);
-      gfac = mn > s3 ? 1.f : (mn == s3 ? 0.5f : 0.f);
-    } else {
-      pl = -mn;
-      gfac = 1.f;
-    }
-    // value loss (utils.py:230-237 when clipped)
-    const float v = a.value[i], tgt = a.ret[i];
-    float l1, dl1;
-    vloss(hp.value_loss, hp.huber_delta, v, tgt, l1, dl1);
-    float vl = l1, dvl = dl1;
-    if (hp.clip_value) {
-      const float vo = a.old_value[i];
-      const float dv = v - vo;
-      const float vc = vo + fminf(fmaxf(dv, -hp.value_eps_clip), hp.value_eps_clip);
-      float l2, dl2;
-      vloss(hp.value_loss, hp.huber_delta, vc, tgt, l2, dl2);
-      dl2 = (dv >= -hp.value_eps_clip && dv <= hp.value_eps_clip) ? dl2 : 0.f;
-      if (l1 > l2) { vl = l1; dvl = dl1; }
-      else if (l1 < l2) { vl = l2; dvl = dl2; }
-      else { vl = l1; dvl = 0.5f * (dl1 + dl2); }
+    const float w = m * inv_n;
+    const double md = (double)m;
+    float g_lp = 0.f;
+    // value channels: every term below is [T, B, vd] in the reference (ratio, mask and entropy broadcast over the
+    // channels) and every masked mean divides the sum over ALL channels by the mask count (mappo.py:184,197)
+    for (int c = 0; c < a.vd; ++c) {
+      const long e = i * a.vd + c;
+      const float adv = a.adv[e];
+      const float nadv = (float)(((double)adv * (double)m - mean) / denom);  // mappo.py:187
+      const float s1 = ratio * nadv, s2 = rc * nadv;  // mappo.py:188-190
+      // d min(s1,s2) / d ratio with torch's tie rule (equal -> half through each branch)
+      float gmin;
+      if (s1 < s2) gmin = nadv;
+      else if (s1 > s2) gmin = in_range ? nadv : 0.f;
+      else gmin = 0.5f * nadv + (in_range ? 0.5f * nadv : 0.f);
+      const float mn = fminf(s1, s2);
+      float pl, gfac;
+      if (hp.dual_clip) {
+        const float sg = nadv > 0.f ? 1.f : (nadv < 0.f ? -1.f : 0.f);
+        const float s3 = -sg * hp.c_clip * nadv;  // mappo.py:192
+        pl = -fmaxf(mn, s3);
+        gfac = mn > s3 ? 1.f : (mn == s3 ? 0.5f : 0.f);
+      } else {
+        pl = -mn;
+        gfac = 1.f;
+      }
+      // value loss (utils.py:230-237 when clipped)
+      const float v = a.value[e], tgt = a.ret[e];
+      float l1, dl1;
+      vloss(hp.value_loss, hp.huber_delta, v, tgt, l1, dl1);
+      float vl = l1, dvl = dl1;
+      if (hp.clip_value) {
+        const float vo = a.old_value[e];
+        const float dv = v - vo;
+        const float vc = vo + fminf(fmaxf(dv, -hp.value_eps_clip), hp.value_eps_clip);
+        float l2, dl2;
+        vloss(hp.value_loss, hp.huber_delta, vc, tgt, l2, dl2);
+        dl2 = (dv >= -hp.value_eps_clip && dv <= hp.value_eps_clip) ? dl2 : 0.f;
+        if (l1 > l2) { vl = l1; dvl = dl1; }
+        else if (l1 < l2) { vl = l2; dvl = dl2; }
+        else { vl = l1; dvl = 0.5f * (dl1 + dl2); }
+      }
+      g_lp += -gfac * gmin * ratio * w;                    // d(policy_loss)/d new_lp, summed over the channels
+      a.d_value[e] = hp.value_loss_weight * dvl * w;       // mappo.py:202
+      acc[SRL_LT_POLICY] += md * (double)pl;
+      acc[SRL_LT_VALUE] += md * (double)vl;
+      acc[SRL_LT_CLIP] += md * (s2 < s1 ? 1.0 : 0.0);  // mappo.py:214
+      acc[SRL_LT_ADV] += md * (double)adv;
+      acc[SRL_LT_RET] += md * (double)tgt;
     }
     const float ent = a.entropy[i];
-    const float w = m * inv_n;
-    a.d_new_lp[i] = -gfac * gmin * ratio * w;            // d(policy_loss)/d new_lp
-    a.d_value[i] = hp.value_loss_weight * dvl * w;         // mappo.py:202
+    a.d_new_lp[i] = g_lp;
     a.d_entropy[i] = -hp.entropy_bonus_weight * w;
-    const double md = (double)m;
-    acc[SRL_LT_POLICY] += md * (double)pl;
-    acc[SRL_LT_VALUE] += md * (double)vl;
     acc[SRL_LT_ENTROPY] += md * (double)ent;
-    acc[SRL_LT_CLIP] += md * (s2 < s1 ? 1.0 : 0.0);  // mappo.py:214
     acc[SRL_LT_RATIO] += md * (double)ratio;
-    acc[SRL_LT_ADV] += md * (double)adv;
-    acc[SRL_LT_RET] += md * (double)tgt;
     acc[SRL_LT_MASK] += md;
     if (a.done) acc[SRL_LT_DONE] += (double)a.done[i];
     if (a.truncated) acc[SRL_LT_TRUNC] += (double)a.truncated[i];
@@ -268,9 +276,11 @@ int make_heads(int n_heads, const int32_t* dims, Heads& h, int& atot) {
 
 extern "C" int srl_ppo_loss_fwd_bwd(void* stream, const float* new_lp, const float* old_lp, const float* value,
                                     const float* old_value, const float* adv, const float* ret, const float* entropy,
-                                    const uint8_t* mask, long n, const srl_ppo_hparams* hp, const double* norm_stats,
-                                    const double* local_n, const uint8_t* done, const uint8_t* truncated,
-                                    float* d_new_lp, float* d_value, float* d_entropy, double* loss_terms) {
+                                    const uint8_t* mask, long n, int value_dim, const srl_ppo_hparams* hp,
+                                    const double* norm_stats, const double* local_n, const uint8_t* done,
+                                    const uint8_t* truncated, float* d_new_lp, float* d_value, float* d_entropy,
+                                    double* loss_terms) {
+  SRL_CHECK_ARG(value_dim >= 1 && n >= 0, "value_dim >= 1 and n >= 0 required");
   SRL_CHECK_ARG(new_lp && old_lp && value && adv && ret && entropy && mask && hp && norm_stats && local_n,
                 "null input");
   SRL_CHECK_ARG(d_new_lp && d_value && d_entropy && loss_terms, "null output");
@@ -279,7 +289,7 @@ extern "C" int srl_ppo_loss_fwd_bwd(void* stream, const float* new_lp, const flo
   hipStream_t st = (hipStream_t)stream;
   SRL_HIP_TRY(hipMemsetAsync(loss_terms, 0, SRL_LT_COUNT * sizeof(double), st));
   if (n == 0) return 0;
-  LossArgs a{new_lp, old_lp, value, old_value, adv, ret, entropy, mask, n, *hp, norm_stats, local_n,
+  LossArgs a{new_lp, old_lp, value, old_value, adv, ret, entropy, mask, n, value_dim, *hp, norm_stats, local_n,
              done, truncated, d_new_lp, d_value, d_entropy, loss_terms};
   const unsigned grid = (unsigned)(srl_ceil_div(n, 256) < 2048 ? srl_ceil_div(n, 256) : 2048);
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(grid), dim3(256), 0, st, a);

@@ -16,7 +16,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsrlhip.so")
 _lib = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -92,7 +92,7 @@ _SIGNATURES = {
     "srl_lstm_cell_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long,
                                   c_int, c_void_p]),
     "srl_chunk_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
-    "srl_ppo_loss_fwd_bwd": (c_int, [c_void_p] + [c_void_p] * 8 + [c_long, POINTER(PpoHparams)] + [c_void_p] * 8),
+    "srl_ppo_loss_fwd_bwd": (c_int, [c_void_p] + [c_void_p] * 8 + [c_long, c_int, POINTER(PpoHparams)] + [c_void_p] * 8),
     "srl_categorical_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, POINTER(c_int32),
                                      c_void_p, c_void_p]),
     "srl_categorical_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, POINTER(c_int32),
@@ -368,13 +368,17 @@ def popart_map(x, rms, vd, out, normalize, eps):
 
 
 def ppo_loss_fwd_bwd(new_lp, old_lp, value, old_value, adv, ret, entropy, mask, hp: PpoHparams, norm_stats, local_n,
-                     d_new_lp, d_value, d_entropy, loss_terms, done=None, truncated=None):
+                     d_new_lp, d_value, d_entropy, loss_terms, done=None, truncated=None, value_dim=1):
+    """value / old_value / adv / ret / d_value hold ``value_dim`` channels per row of new_lp."""
     f = torch.float32
+    n = new_lp.numel()
+    if value.numel() != n * value_dim or adv.numel() != n * value_dim or d_value.numel() != n * value_dim:
+        raise HipError("ppo_loss_fwd_bwd: value tensors must hold value_dim channels per row")
     _check(
         lib().srl_ppo_loss_fwd_bwd(_stream(), _ptr(new_lp, f, "new_lp"), _ptr(old_lp, f, "old_lp"),
                                    _ptr(value, f, "value"), _ptr(old_value, f, "old_value"), _ptr(adv, f, "adv"),
                                    _ptr(ret, f, "ret"), _ptr(entropy, f, "entropy"), _ptr(mask, torch.uint8, "mask"),
-                                   new_lp.numel(), ctypes.byref(hp), _ptr(norm_stats, torch.float64, "norm_stats"),
+                                   n, int(value_dim), ctypes.byref(hp), _ptr(norm_stats, torch.float64, "norm_stats"),
                                    _ptr(local_n, torch.float64, "local_n"), _ptr(done, torch.uint8, "done"),
                                    _ptr(truncated, torch.uint8, "truncated"), _ptr(d_new_lp, f, "d_new_lp"),
                                    _ptr(d_value, f, "d_value"), _ptr(d_entropy, f, "d_entropy"),

@@ -389,6 +389,49 @@ def gen_vtrace_rnn():
     save("steps_vtrace_rnn.npz", **out)
 
 
+def _strip_asserts(fn):
+    """The function recompiled without its `assert` statements: what `python -O` -- which the reference's launcher uses
+    (apps/main.py:45) -- executes.  Harness-side only; the reference's source is read, not modified."""
+    import ast
+    import inspect
+    import textwrap
+    fn = inspect.unwrap(fn)  # e.g. the function under @torch.no_grad(): the decorator line is in the source and re-applies
+    tree = ast.parse(textwrap.dedent(inspect.getsource(fn)))
+
+    class Drop(ast.NodeTransformer):
+
+        def visit_Assert(self, node):
+            return ast.Pass()
+
+    tree = ast.fix_missing_locations(Drop().visit(tree))
+    ns = dict(fn.__globals__)
+    exec(compile(tree, inspect.getsourcefile(fn), "exec"), ns)
+    return ns[fn.__name__]
+
+
+def gen_value_dim():
+    """value_dim > 1 through the whole step (mappo.py:146-217 is shape-agnostic: ratio, mask and entropy broadcast over the
+    value channels).  The reference's masked_normalization ASSERTS mask.shape == x.shape (utils.py:48-53), which a [T, B, 1]
+    loss mask fails for [T, B, value_dim] advantages -- so this configuration only runs the way the launcher runs it, under
+    `python -O`: the generator swaps in that function with its asserts stripped."""
+    import legacy.algorithm.modules.utils as ref_utils
+    saved = modules.masked_normalization
+    modules.masked_normalization = ref_utils.masked_normalization = _strip_asserts(saved)
+    try:
+        out = {}
+        smp = dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05, value_dim=3)
+        run_steps("vd3", dict(C1_POLICY, value_dim=3, seed=61), dict(popart=False, optimizer_config=dict(lr=1e-3), max_grad_norm=5.0),
+                  smp, 2, out=out)
+        smp2 = dict(T=16, B=6, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2], p_done=0.1, value_dim=2)
+        run_steps("vd2pa", dict(C1_POLICY, action_dim=[3, 2], value_dim=2, popart=True, layernorm=True, shared_backbone=True,
+                                seed=62),
+                  dict(popart=True, ppo_epochs=2, clip_value=True, dual_clip=False, value_loss='huber',
+                       value_loss_config=dict(delta=10.0), optimizer_config=dict(lr=5e-4)), smp2, 2, out=out)
+        save("steps_value_dim.npz", **out)
+    finally:
+        modules.masked_normalization = ref_utils.masked_normalization = saved
+
+
 def gen_optim():
     """The other optimisers modules/utils.py:268-286 accepts: RMSprop (plain; centred with momentum and weight decay) and
     SGD (plain; Nesterov momentum with weight decay; momentum with dampening), full steps on the CartPole shapes."""

@@ -58,7 +58,7 @@ def test_gae_golden_cases(golden):
             assert rel_close(ret[:T], ref_ret, 1e-5, scale=1.0), (name, tag)
             assert (adv[T:] == 7.0).all() and (ret[T:] == 7.0).all()  # the pad row is the caller's
             mask = 1.0 - arr["on_reset"][1:].astype(np.float64)
-            n, s, q = oppo.masked_stats(np.broadcast_to(ref_adv, ref_adv.shape), np.broadcast_to(mask, ref_adv.shape))
+            n, s, q = oppo.masked_stats(ref_adv, mask)  # [T, B, 1] mask: counted once, sums over all value channels
             assert stats[0] == n
             assert abs(stats[1] - s) <= 1e-5 * max(1.0, q**0.5) and abs(stats[2] - q) <= 1e-6 * max(1, q)
         adv, _, _ = run_gae(arr, 0.99, 0.97, ratio=g[f"{name}_ratio"])
@@ -98,8 +98,8 @@ def test_gae_shapes_vs_oracle(T, B, Nc):
         assert rel_close(vadv[:T], o_vadv, 1e-5, scale=1.0)
     assert rel_close(adv[:T], o_adv, 1e-5, scale=1.0)
     assert rel_close(ret[:T], o_ret, 1e-5, scale=1.0)
-    mask = np.broadcast_to(1.0 - a["on_reset"][1:].astype(np.float64), o_adv.shape)
-    n, s, q = oppo.masked_stats(o_adv, mask)
+    # the mask is [T, B, 1]: its sum counts every (step, env) once, the value sums run over all channels (utils.py:41-55)
+    n, s, q = oppo.masked_stats(o_adv, 1.0 - a["on_reset"][1:].astype(np.float64))
     assert stats[0] == n and abs(stats[1] - s) <= 1e-6 * max(1.0, abs(s), q**0.5) and abs(stats[2] - q) <= 1e-6 * q + 1e-9
 
 

@@ -108,6 +108,16 @@ CASES.update({
                dict(T=16, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2], p_done=0.1, p_trunc=0.0,
                     policy_state={"actor_hx": (1, 32), "critic_hx": (1, 32)}), 2, "steps_vtrace_rnn.npz"),
 })
+# value_dim > 1 through the loss (gen_golden.py gen_value_dim: the reference under its launcher's `python -O` semantics)
+CASES.update({
+    "vd3": (dict(C1_POLICY, value_dim=3, seed=61), dict(popart=False, optimizer_config=dict(lr=1e-3), max_grad_norm=5.0),
+            dict(T=32, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05, value_dim=3), 2, "steps_value_dim.npz"),
+    "vd2pa": (dict(C1_POLICY, action_dim=[3, 2], value_dim=2, popart=True, layernorm=True, shared_backbone=True, seed=62),
+              dict(popart=True, ppo_epochs=2, clip_value=True, dual_clip=False, value_loss='huber',
+                   value_loss_config=dict(delta=10.0), optimizer_config=dict(lr=5e-4)),
+              dict(T=16, B=6, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2], p_done=0.1, value_dim=2), 2,
+              "steps_value_dim.npz"),
+})
 # continuous actions: Normal(mean, std) with the three parametrisations of log sigma (gen_golden.py gen_continuous)
 _CBASE = dict(obs_dim=7, action_dim=3, hidden_dim=32, num_dense_layers=2, num_rnn_layers=0, popart=False, layernorm=True,
               shared_backbone=False, chunk_len=8, continuous_action=True)
