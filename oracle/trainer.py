@@ -60,11 +60,12 @@ class OracleMappo:
             pstate = [f32(n) for n in names]
         Tb = on_reset.shape[0]
         boot, burn = self.bootstrap_steps, self.burn_in_steps
-        keep = Tb - boot  # analysed rows (mappo.py:243-246, tail_len = bootstrap_steps without vtrace)
-
         totals = {}
         out = {}
         for _ in range(self.ppo_epochs):
+            # analysed rows (mappo.py:243-246): tail_len = bootstrap_steps, or 1 while V-trace still needs the importance ratio
+            # of every rewarding step (the loss then takes the first Tb - boot of them, :159-163)
+            keep = Tb - 1 if (self.vtrace and "adv" not in out) else Tb - boot
             lp, value, ent, _ = self.net.analyze({k: v[:keep] for k, v in obs.items()}, action[:keep], on_reset[:keep],
                                                  None if pstate is None else [s[:keep] for s in pstate], burn)
             if burn:  # the analysis covers rows [burn, keep): pad in front so that row indices stay the sample's
@@ -74,8 +75,9 @@ class OracleMappo:
                 # statistics move between epochs)
                 trace_value = self.net.denormalize_value(old_value) if self.popart else old_value  # :120-124
                 kw = {}
-                if self.vtrace:  # :130-133 (bootstrap_steps == 1: the analysed rows are the rewarding rows)
-                    assert boot == 1, "oracle: V-trace restated for bootstrap_steps == 1 only"
+                if self.vtrace:  # :130-133: the analysed rows are the Tb - 1 rewarding rows
+                    assert boot >= 1 and not burn, "oracle: V-trace needs a bootstrap row; with burn-in the reference's shapes clash"
+                    assert boot == 1 or not self.net.num_rnn_layers, "oracle: V-trace with bootstrap_steps > 1 restated for feed-forward nets"
                     kw = dict(vtrace=True, imp_ratio=(lp - old_lp[:keep]).exp().detach().numpy())
                 adv, ret = ogae.adv_and_value_target(reward.numpy(), trace_value.numpy(), truncated.numpy(), done.numpy(),
                                                      on_reset.numpy(), self.discount_rate, self.gae_lambda, **kw)

@@ -136,10 +136,12 @@ class MultiAgentPPO(PytorchTrainer):
         self.ppo_epochs = g("ppo_epochs", 1)
         if self.popart and not policy.net.spec.popart:
             raise ValueError("Set popart=True in policy config to activate popart value head.")  # actor_critic_policy.py:264
-        if self.vtrace and self.bootstrap_steps != 1:
-            raise NotImplementedError("V-trace with bootstrap_steps != 1 is not on the HIP path")
+        if self.vtrace and self.bootstrap_steps != 1 and policy.net.spec.num_rnn_layers:
+            raise NotImplementedError("V-trace with bootstrap_steps != 1 and a recurrent policy is not on the HIP path")
         if self.burn_in_steps and self.vtrace:
-            raise NotImplementedError("burn-in together with V-trace is not on the HIP path")
+            # the reference itself cannot run this: analyze() drops the burn-in rows, so imp_ratio [Tb - 1 - burn] meets
+            # delta [Tb - 1] in gae_trace (gae.py:63-65) and the shapes clash
+            raise NotImplementedError("burn-in together with V-trace: the reference's own shapes clash (mappo.py:243-246, gae.py:65)")
 
         # optimiser (modules/utils.py:268-286: torch.optim.{Adam, AdamW, RMSprop, SGD}(**optimizer_config))
         name = g('optimizer', 'adam')

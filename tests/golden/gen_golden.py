@@ -386,6 +386,11 @@ def gen_vtrace_rnn():
     smp2 = dict(T=16, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2], p_done=0.1, p_trunc=0.0,
                 policy_state={"actor_hx": (1, 32), "critic_hx": (1, 32)})
     run_steps("vtlstm", vt_lstm, dict(popart=True, vtrace=True, ppo_epochs=2, optimizer_config=dict(lr=5e-4)), smp2, 2, out=out)
+    # bootstrap_steps = 2 under V-trace (feed-forward): the first epoch analyses Tb - 1 rows for the ratio, the loss takes Tb - 2
+    run_steps("vtb2", dict(C1_POLICY, chunk_len=1, seed=53), dict(popart=False, vtrace=True, bootstrap_steps=2, ppo_epochs=2,
+                                                     optimizer_config=dict(lr=1e-3)),
+              dict(T=31, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05, p_trunc=0.0, bootstrap_steps=2), 2,
+              out=out, analyze_check=False)
     save("steps_vtrace_rnn.npz", **out)
 
 

@@ -108,6 +108,10 @@ CASES.update({
                dict(T=16, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2], p_done=0.1, p_trunc=0.0,
                     policy_state={"actor_hx": (1, 32), "critic_hx": (1, 32)}), 2, "steps_vtrace_rnn.npz"),
 })
+CASES["vtb2"] = (dict(C1_POLICY, chunk_len=1, seed=53), dict(popart=False, vtrace=True, bootstrap_steps=2, ppo_epochs=2,
+                                                optimizer_config=dict(lr=1e-3)),
+                 dict(T=31, B=8, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05, p_trunc=0.0, bootstrap_steps=2), 2,
+                 "steps_vtrace_rnn.npz")
 # value_dim > 1 through the loss (gen_golden.py gen_value_dim: the reference under its launcher's `python -O` semantics)
 CASES.update({
     "vd3": (dict(C1_POLICY, value_dim=3, seed=61), dict(popart=False, optimizer_config=dict(lr=1e-3), max_grad_norm=5.0),
