@@ -20,20 +20,15 @@ int launch_or(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
   return launch<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN, GEN>(st, g, 1, split);
 }
 
-// float32 operands on the bf16 matrix cores (gemm_bf16x3.h): float4-stageable operands only
+// float32 operands on the bf16 matrix cores (gemm_bf16x3.h): float4-stageable operands only.  k-steps of 16 (48 KB of LDS per
+// 128x128 workgroup, three per CU): k-steps of 32 measured 10-25 % slower, 256x128 tiles +12 % on 4096^3 but not on the
+// network's shapes, 128x64 / 64x128 tiles (full occupancy for the FC forward) -8 %.
 template <int BM, int BN, int WM, int WN>
 int launch3_or(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
-  static const int kb = getenv("SRL_K3") ? atoi(getenv("SRL_K3")) : 16;
-  if (kb == 16) {
-    if (!akm && !bkm) return launch3<BM, BN, WM, WN, false, false, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
-    if (!akm && bkm) return launch3<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
-    if (akm && bkm) return launch3<BM, BN, WM, WN, true, true, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
-    return launch3<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
-  }
-  if (!akm && !bkm) return launch3<BM, BN, WM, WN, false, false, SRC_PLAIN, SRC_PLAIN, 32>(st, g, 1, split);
-  if (!akm && bkm) return launch3<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN, 32>(st, g, 1, split);
-  if (akm && bkm) return launch3<BM, BN, WM, WN, true, true, SRC_PLAIN, SRC_PLAIN, 32>(st, g, 1, split);
-  return launch3<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN, 32>(st, g, 1, split);
+  if (!akm && !bkm) return launch3<BM, BN, WM, WN, false, false, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
+  if (!akm && bkm) return launch3<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
+  if (akm && bkm) return launch3<BM, BN, WM, WN, true, true, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
+  return launch3<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
 }
 
 // both operands float4-loadable (aligned, leading dimensions multiples of 4): the lean instantiation
@@ -86,10 +81,6 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   int rc;
   if (use_bf16x3() && g.vec_a && g.vec_b && d->M > 64 && d->N > 32 && d->K >= 64) {
     // bf16 matrix cores, three exact pieces per float32 operand (2.67x fewer matrix-pipe cycles)
-    static const int big = getenv("SRL_T3") ? atoi(getenv("SRL_T3")) : 0;
-    if (d->N > 64 && big == 1) rc = launch3_or<256, 128, 2, 2>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
-    else if (d->N > 64 && big == 2) rc = launch3_or<128, 256, 2, 2>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
-    else
     rc = d->N > 64 ? launch3_or<128, 128, 2, 2>(st, g, d->a_kmajor, d->b_kmajor, nsplit)
                    : launch3_or<256, 64, 4, 1>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
   } else
