@@ -251,8 +251,7 @@ typedef struct srl_gemm_desc {
   const float* bias;        /* [N] added per output column, or NULL */
   int32_t act;              /* 0 none, 1 relu, 2 tanh — applied after bias */
   const float* dact_src;    /* [M, ld_dact] forward output Y; C *= act'(Y) (relu: Y>0, tanh: 1-Y^2), or NULL */
-  int64_t ld_dact; int32_t dact;  /* activation kind for dact_src (1 relu, 2 tanh; 3: dact_src is a ReLU bit mask --
-                                   * uint32 words, bit (e & 31) of word (e >> 5) for e = row * ld_dact + col) */
+  int64_t ld_dact; int32_t dact;  /* activation kind for dact_src (1 relu, 2 tanh) */
   int32_t accumulate;       /* 1: C += result (after split reduction) */
   int32_t split_k;          /* >1: K is cut into split_k slices reduced through `workspace` */
   float* workspace;         /* >= split_k * M * N floats when split_k > 1 */
@@ -326,13 +325,9 @@ typedef struct srl_conv_desc {
 /* 1 if the implicit path handles this geometry.  first_layer: 0 = NHWC activation layer, 1 = observation layer
  * with a planar (NCHW) observation, 2 = observation layer with a channels-last (NHWC) observation. */
 int srl_conv2d_supported(const srl_conv_desc* d, int first_layer);
-/* y[n,OH,OW,Cout] = act(conv(x[n,H,W,Cin], w) + bias).
- * relu_bits (or NULL; needs act == relu and Cout % 32 == 0, see srl_conv2d_relu_bits_ok): ceil(n*OH*OW*Cout / 32)
- * uint32 words that receive one bit per element of y (bit e & 31 of word e >> 5 = y[e] > 0): what the NEXT layer's
- * data gradient needs of y, at 1/32 of the bytes (pass it there as x_act with dact = 3). */
-int srl_conv2d_relu_bits_ok(const srl_conv_desc* d);
+/* y[n,OH,OW,Cout] = act(conv(x[n,H,W,Cin], w) + bias) */
 int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w, const float* bias,
-                        float* y, uint32_t* relu_bits);
+                        float* y);
 /* dw[Cout,KH,KW,Cin] += sum over (n,oh,ow) dz[.,Cout]^T patch(x); workspace: srl_conv2d_wgrad_workspace floats
  * (split over the n*OH*OW reduction) or NULL.  dbias (optional): [Cout] += sum over (n,oh,ow) dz, the bias
  * gradient, from the same pass over dz. */
@@ -342,8 +337,7 @@ int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const float* x, 
 /* Data gradient.  Input pixels are split into stride*stride parity classes, each a dense stride-1 problem
  * over only the taps that reach it (no multiply-by-zero work).  wt = the weights regrouped per class
  * (srl_conv2d_dgrad_repack, srl_conv2d_dgrad_weight_elems floats; redo after every optimiser step).
- * dx[n,H,W,Cin] = (sum over taps dz * w) * act'(x_act)   (x_act = the forward activation that has dx's shape, or NULL;
- * dact 1 relu, 2 tanh on the float32 activation, 3 = x_act is the producer's relu_bits mask of that shape) */
+ * dx[n,H,W,Cin] = (sum over taps dz * w) * act'(x_act)   (x_act = the forward activation that has dx's shape, or NULL) */
 int64_t srl_conv2d_dgrad_weight_elems(const srl_conv_desc* d);
 int srl_conv2d_dgrad_repack(void* stream, const srl_conv_desc* d, const float* w, float* wt);
 int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* wt, const float* x_act,
@@ -358,7 +352,7 @@ int64_t srl_conv2d_obs_fwd_workspace(const srl_conv_desc* d);
  * (bias + w.beta), so that the operand gather needs no table lookups; without it the affine is applied in the gather. */
 int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
-                       const float* bias, float* y, float* workspace, uint32_t* relu_bits);
+                       const float* bias, float* y, float* workspace);
 /* Space-to-depth of a planar observation for a strided first convolution (stride s | KH, KW, H, W):
  * out[n, H/s, W/s, (c, ph, pw)] = obs[n, c, a*s + ph, b*s + pw], same element type, plus the whole-observation
  * LayerNorm statistics in the same pass.  A KxK stride-s convolution on obs becomes a (K/s)x(K/s) stride-1

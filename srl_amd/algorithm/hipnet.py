@@ -182,20 +182,15 @@ class HipNet:
             hip.colsum(dz.ptr, dz.ld, rows, out_f, gb_ptr, accumulate=True)
 
     def _linear_bwd(self, L: ns.LinearSpec, x: Buf, dz: Buf, in_act: int, need_dx: bool, tag: str,
-                    dx_into: Optional[Buf] = None, dx_accumulate=False, in_bits: Optional[int] = None) -> Optional[Buf]:
-        """in_bits: the ReLU bit mask the producer of x left behind (same element order as x): the data gradient then
-        reads 1 bit instead of 4 bytes per element for the activation derivative."""
+                    dx_into: Optional[Buf] = None, dx_accumulate=False) -> Optional[Buf]:
         self._wgrad(L.out_features, L.in_features, x.rows, dz, x.ptr, x.ld, self._g(f"{L.prefix}.weight"),
                     self._g(f"{L.prefix}.bias"))
         if not need_dx:
             return None
         dx = dx_into or self._buf(f"{tag}{L.prefix}.dx", x.rows, L.in_features)
-        if in_bits is not None and in_act == hip.ACT_RELU:
-            dsrc, dkind = in_bits, hip.DACT_RELU_BITS
-        else:
-            dsrc, dkind = (x.ptr if in_act else None), in_act
         hip.gemm(x.rows, L.in_features, L.out_features, dz.ptr, dz.ld, 0, self._p(f"{L.prefix}.weight"), L.in_features,
-                 1, dx.ptr, dx.ld, dact_src=dsrc, ld_dact=x.ld, dact=dkind, accumulate=dx_accumulate)
+                 1, dx.ptr, dx.ld, dact_src=x.ptr if in_act else None, ld_dact=x.ld, dact=in_act,
+                 accumulate=dx_accumulate)
         return dx
 
     def _ln_fwd(self, L: ns.LayerNormSpec, x: Buf, tag: str):
@@ -360,7 +355,6 @@ class HipNet:
         """obs: device tensor [n, *shape] (float32 vectors; uint8 or float32 images)."""
         cur: Optional[Buf] = None
         cur_act = 0
-        cur_bits: Optional[int] = None  # ReLU bit mask of `cur`, left by the convolution that produced it
         pending_obs_ln = None
         for L in enc.layers:
             if isinstance(L, ns.LayerNormSpec):
@@ -370,14 +364,14 @@ class HipNet:
                     cur = Buf(obs.data_ptr(), L.dim, n, L.dim)
                 y, saved = self._ln_fwd(L, cur, tag)
                 tape.append(("ln", L, cur, saved, cur_act))
-                cur, cur_act, cur_bits = y, 0, None
+                cur, cur_act = y, 0
             elif isinstance(L, ns.LinearSpec):
                 if cur.cols != L.in_features:  # Flatten after the convolution stack: [n*OH*OW, C] -> [n, OH*OW*C]
                     assert cur.rows * cur.cols == n * L.in_features and cur.ld == cur.cols
                     cur = Buf(cur.ptr, L.in_features, n, L.in_features)
                 y = self._linear_fwd(L, cur, tag)
-                tape.append(("linear", L, cur, cur_bits, cur_act))  # a Flatten keeps the element order: the mask still fits
-                cur, cur_act, cur_bits = y, L.act, None
+                tape.append(("linear", L, cur, None, cur_act))
+                cur, cur_act = y, L.act
             elif isinstance(L, ns.ObsLayerNormSpec):
                 pending_obs_ln = L
             elif isinstance(L, ns.ConvSpec):
@@ -398,11 +392,6 @@ class HipNet:
                 y = self._buf(f"{tag}{L.prefix}.y", m, L.cout)
                 P = None if implicit else self._buf(f"{tag}{L.prefix}.P", m, kdim)
                 saved = None
-                # ReLU layers on the implicit path also leave one bit per output element: all the next layer's data
-                # gradient needs of y (activation derivative), at 1/32 of the bytes of reading y back
-                y_bits = None
-                if implicit and hip.conv2d_relu_bits_ok(desc):
-                    y_bits = self.ws.get(f"{tag}{L.prefix}.bits", (m * L.cout + 31) // 32 + 1, dtype=torch.int32).data_ptr()
                 if L.first:
                     c = pending_obs_ln.shape[0]
                     is_u8 = obs.dtype == torch.uint8
@@ -422,8 +411,7 @@ class HipNet:
                         hip.conv2d_obs_fwd(desc, src.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet,
                                            self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"), y.ptr,
                                            channels_last=bool(L.s2d),
-                                           ws_ptr=self.ws.get("conv_obs_fwd", hip.conv2d_obs_fwd_workspace(desc)).data_ptr(),
-                                           relu_bits_ptr=y_bits)
+                                           ws_ptr=self.ws.get("conv_obs_fwd", hip.conv2d_obs_fwd_workspace(desc)).data_ptr())
                     else:
                         hip.im2col_obs_ln(obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet, n, c, h, w,
                                           L.k, L.k, L.stride, P.ptr)
@@ -432,14 +420,14 @@ class HipNet:
                     assert cur.ld == L.cin and cur.rows == n * h * w
                     if implicit:
                         hip.conv2d_nhwc_fwd(desc, cur.ptr, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"),
-                                            y.ptr, relu_bits_ptr=y_bits)
+                                            y.ptr)
                     else:
                         hip.im2col_nhwc(cur.ptr, n, h, w, L.cin, L.k, L.k, L.stride, P.ptr)
                 if not implicit:
                     hip.gemm(m, L.cout, kdim, P.ptr, kdim, 0, self._p(f"{L.prefix}.weight"), kdim, 0, y.ptr, y.ld,
                              bias=self._p(f"{L.prefix}.bias"), act=L.act)
-                tape.append(("conv", L, cur, (P, saved, n, desc, cur_bits), cur_act))
-                cur, cur_act, cur_bits = y, L.act, y_bits
+                tape.append(("conv", L, cur, (P, saved, n, desc), cur_act))
+                cur, cur_act = y, L.act
             else:  # pragma: no cover
                 raise TypeError(L)
         return cur
@@ -453,11 +441,11 @@ class HipNet:
             if kind == "ln":
                 g = self._ln_bwd(L, x, saved, g, in_act, need_dx, tag)
             elif kind == "linear":
-                g = self._linear_bwd(L, x, g, in_act, need_dx, tag, in_bits=saved)
+                g = self._linear_bwd(L, x, g, in_act, need_dx, tag)
             elif kind == "gru":
                 g = self._gru_bwd(L, saved, g, in_act, need_dx, tag)
             elif kind == "conv":
-                P, first_saved, n, desc, in_bits = saved
+                P, first_saved, n, desc = saved
                 kdim = L.cin * L.k * L.k
                 m = g.rows
                 if P is None:  # implicit-GEMM path
@@ -478,10 +466,7 @@ class HipNet:
                         hip.conv2d_dgrad_repack(desc, wp, wt.data_ptr())
                         h, w = L.in_hw
                         dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.cin)
-                        if in_bits is not None and in_act == hip.ACT_RELU:  # the producer's ReLU mask: 1 bit per element
-                            hip.conv2d_nhwc_dgrad(desc, g.ptr, wt.data_ptr(), in_bits, hip.DACT_RELU_BITS, dx.ptr)
-                        else:
-                            hip.conv2d_nhwc_dgrad(desc, g.ptr, wt.data_ptr(), x.ptr if in_act else None, in_act, dx.ptr)
+                        hip.conv2d_nhwc_dgrad(desc, g.ptr, wt.data_ptr(), x.ptr if in_act else None, in_act, dx.ptr)
                         g = dx
                     if g is not None and idx > 0:
                         prev_out_cols = self._out_cols(records[idx - 1])
@@ -518,7 +503,7 @@ class HipNet:
         if self.grad_ready_hook is None:
             return
         done = [L.prefix]
-        if kind == "conv" and L.first and saved is not None and saved[1] is not None:
+        if kind == "conv" and L.first and saved[1] is not None:
             done.append(saved[1][4].prefix)  # the observation LayerNorm fused into the first convolution
         self.grad_ready_hook(done)
 

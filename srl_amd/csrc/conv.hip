@@ -291,13 +291,8 @@ extern "C" int srl_conv2d_supported(const srl_conv_desc* d, int first_layer) {
   return (d->Cin % 4 == 0 && d->Cout % 4 == 0) ? 1 : 0;
 }
 
-extern "C" int srl_conv2d_relu_bits_ok(const srl_conv_desc* d) {
-  return check_desc(d) == 0 && d->act == 1 && d->Cout % 32 == 0;
-}
-
 extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w,
-                                   const float* bias, float* y, uint32_t* relu_bits) {
-  SRL_CHECK_ARG(!relu_bits || srl_conv2d_relu_bits_ok(d), "relu_bits needs a ReLU layer with Cout a multiple of 32");
+                                   const float* bias, float* y) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry (needs Cin, Cout multiples of 4, < 2^31 elements)");
   SRL_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w), "null / unaligned tensor");
   if (d->n == 0) return 0;
@@ -309,7 +304,6 @@ extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const f
   g.b = plain_src(w, Kp);
   g.o = plain_out(y, d->Cout);
   g.bias = bias; g.act = d->act;
-  g.act_bits = relu_bits;
   g.k_per_split = srl_ceil_div(Kp, BK) * BK;
   g.vec_a = 1; g.vec_b = 1;
   hipStream_t st = (hipStream_t)stream;
@@ -433,9 +427,7 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
     o.y_stride = (long)d->stride * d->W * d->Cin;
     o.x_stride = (long)d->stride * d->Cin;
     g.o = o;
-    if (x_act && dact == 3) {  // ReLU bit mask of the producer (one bit per element of dx's shape): offsets, not pointers
-      g.dact_src = x_act; g.dact_off = ((long)c.ph * d->W + c.pw) * d->Cin; g.dact = 3;
-    } else if (x_act && dact) { g.dact_src = x_act + ((long)c.ph * d->W + c.pw) * d->Cin; g.dact = dact; }
+    if (x_act && dact) { g.dact_src = x_act + ((long)c.ph * d->W + c.pw) * d->Cin; g.dact = dact; }
     const int batch = 1;
     if (uniform) {  // column group (ph, pw) = ph * stride + pw, Cin columns each
       g.N = (long)nc * d->Cin;
@@ -481,8 +473,7 @@ extern "C" int64_t srl_conv2d_obs_fwd_workspace(const srl_conv_desc* d) {
 
 extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                  const float* w, const float* bias, float* y, float* workspace, uint32_t* relu_bits) {
-  SRL_CHECK_ARG(!relu_bits || srl_conv2d_relu_bits_ok(d), "relu_bits needs a ReLU layer with Cout a multiple of 32");
+                                  const float* w, const float* bias, float* y, float* workspace) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1),
                 "unsupported geometry (planar: KW, W, stride, H*W multiples of 4; channels-last: Cin multiple of 4)");
   SRL_CHECK_ARG(obs && mean && rstd && gamma && beta && w && y && aligned16(obs) && aligned16(gamma) && aligned16(beta),
@@ -494,7 +485,6 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
   GemmArgs g{};
   g.K = Kp;
   g.act = d->act;
-  g.act_bits = relu_bits;  // both float32 forms below write [n, P, Cout] dense rows: pitch and batch offset multiples of 32
   g.k_per_split = srl_ceil_div(Kp, BK) * BK;
   g.vec_a = 1;
   int rc;
@@ -511,7 +501,6 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
     a.g = obs_geom(d, obs, mean, rstd, OW);
     a.wq = reinterpret_cast<const uint4*>(wq);
     a.S = S; a.b2 = b2; a.y = y; a.P = P; a.act = d->act;
-    a.relu_bits = relu_bits;
     a.nsplit = obs_bf16_split(d->n, P, 3);
     const char* dbg = getenv("SRL_OBS_DBG");  // timing experiments (wrong results): see obs_bf16.h
     const dim3 grid(srlobs::xcd_position_grid(P, a.nsplit));

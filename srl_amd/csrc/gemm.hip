@@ -47,7 +47,6 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   const int split = d->split_k > 1 ? d->split_k : 1;
   SRL_CHECK_ARG(split == 1 || d->workspace, "split_k > 1 needs a workspace");
   SRL_CHECK_ARG(split == 1 || (!d->bias && !d->act && !d->dact_src), "split_k supports only the accumulate epilogue");
-  SRL_CHECK_ARG(d->dact >= 0 && d->dact <= 3, "dact must be 0..3");
   if (d->M == 0 || d->N == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (srlskinny::try_skinny(st, d)) {  // one extent <= 16: bandwidth kernels instead of padded MFMA tiles

@@ -107,13 +107,8 @@ struct GemmArgs {
   long slab;  // split-K: out + z*slab
   const float* bias;
   long bias_batch;  // per-batch (grid.y) stride of the bias vector
-  const float* dact_src;  // same addressing as the output (own pitch ld_dact when !rowmap); dact == 3: a bit mask, see below
+  const float* dact_src;  // same addressing as the output (own pitch ld_dact when !rowmap)
   long ld_dact;
-  // dact == 3: dact_src points at uint32 words holding one bit per element of the producer's output, bit (e & 31) of word
-  // (e >> 5) for element offset e (+ dact_off) -- the ReLU derivative at 1/32 of the bytes of reading the activation back.
-  // act_bits: where THIS product leaves that mask for its own output (act == 1, dense output, pitch a multiple of 32).
-  long dact_off;
-  uint32_t* act_bits;
   int act, dact, accumulate;
   long k_per_split;
   int vec_a, vec_b;
@@ -593,9 +588,7 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
   const long obatch = g.o.brw ? (long)(by / g.o.brw) * g.o.batch_stride + (long)(by % g.o.brw) * g.o.bx_stride
                               : (long)by * g.o.batch_stride;
   float* out = g.o.out + (long)blockIdx.z * g.slab + obatch;
-  const bool dbits = g.dact == 3;
-  const uint32_t* bits = reinterpret_cast<const uint32_t*>(g.dact_src);
-  if (g.o.rowmap && g.dact_src && !dbits) g.dact_src += obatch;  // the activation shares the output's map
+  if (g.o.rowmap && g.dact_src) g.dact_src += obatch;  // the activation shares the output's map
   const float* bias = g.bias ? g.bias + (long)by * g.bias_batch : nullptr;
   // Row addressing stays 32-bit: a 64-bit base per 32-row block plus element offsets (dense output), or offsets
   // from the tensor base through the (image, line, pixel) map (callers keep mapped outputs below 2^32 elements).
@@ -630,10 +623,9 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
         ro[r] = (uint32_t)cr * ldo;
       }
     }
-    long ebase = g.dact_off + (g.o.rowmap ? obatch : row0 * g.ld_dact);  // bit-mask source: element offset of the block's origin
     if (!g.o.rowmap) {
       ob += row0 * g.o.ldo;
-      if (db && !dbits) db += row0 * g.ld_dact;
+      if (db) db += row0 * g.ld_dact;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -657,17 +649,7 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
       }
-      if (db && dbits) {
-        uint32_t wv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {  // the 32 lanes of a half-wave read the same word (or two): broadcast loads
-          const uint32_t o = g.o.rowmap ? ro[r] : (uint32_t)((r & 3) + 8 * (r >> 2)) * ldd;
-          const long e = ebase + o + cc;
-          wv[r] = ((okj >> r) & 1u) ? (bits[e >> 5] >> (e & 31)) : 1u;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = (wv[r] & 1u) ? v[r] : 0.f;
-      } else if (db) {
+      if (db) {
         float yv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -692,17 +674,6 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if ((okj >> r) & 1u) ob[ro[r] + cc] = v[r];
-      if (g.act_bits) {  // host guarantees: act == 1, dense output, ldo and the batch offset multiples of 32
-        const long cbase = n0 + wn * (TN * 32) + j * 32;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned long long bal = __ballot(cok && v[r] > 0.f);  // lanes 0-31: this half's row, lanes 32-63: row + 4
-          if (l31 == 0 && ((okm >> r) & 1u) && cbase < g.N) {
-            const long e = (row0 + (r & 3) + 8 * (r >> 2)) * g.o.ldo + obatch + cbase;
-            g.act_bits[e >> 5] = (uint32_t)(bal >> (32 * h));
-          }
-        }
-      }
     }
   }
 }

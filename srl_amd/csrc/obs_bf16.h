@@ -128,8 +128,6 @@ struct FwdArgs {
   const float* S;   // [P][32]
   const float* b2;  // [P][32]
   float* y;         // [n][P][32]
-  uint32_t* relu_bits;  // or null: one word per (sample, position) = the 32 channels' y > 0 (the next layer's data gradient
-                        // reads these instead of y: 1/32 of the bytes)
   int P, nsplit, act;
 };
 
@@ -245,12 +243,7 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
         if (a.act == 1) v = fmaxf(v, 0.f);
         else if (a.act == 2) v = tanhf(v);
         const int row = 8 * g4 + 4 * h + i;
-        const bool rok = full || n0 + row < a.g.n;
-        if (rok && (!(DBG & 4) || v == 12345.f)) yp[row * ldy32] = v;
-        if (a.relu_bits) {  // wave-uniform; lanes 0-31 hold the 32 channels of row 8g + i, lanes 32-63 those of row 8g + 4 + i
-          const unsigned long long bal = __ballot(v > 0.f);
-          if (l31 == 0 && rok) a.relu_bits[(n0 + row) * a.P + pos] = (uint32_t)(bal >> (32 * h));
-        }
+        if ((full || n0 + row < a.g.n) && (!(DBG & 4) || v == 12345.f)) yp[row * ldy32] = v;
       }
     }
   };

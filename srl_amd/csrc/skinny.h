@@ -189,7 +189,6 @@ inline int col_threads(long N) {  // threads across the columns: a power of two 
 }
 
 inline int try_skinny(hipStream_t st, const srl_gemm_desc* d) {
-  if (d->dact == 3) return 0;  // bit-mask activation derivative: only the MFMA kernels' epilogue reads it
   const long M = d->M, N = d->N, K = d->K;
   if (M == 0 || N == 0) return 0;
   // ---- forward of a narrow head

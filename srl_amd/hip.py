@@ -53,14 +53,13 @@ _CD = POINTER(ConvDesc)
 
 _SIGNATURES = {
     "srl_conv2d_supported": (c_int, [_CD, c_int]),
-    "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "srl_conv2d_relu_bits_ok": (c_int, [_CD]),
+    "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_conv2d_wgrad_workspace": (c_int64, [_CD]),
     "srl_conv2d_nhwc_wgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_conv2d_dgrad_weight_elems": (c_int64, [_CD]),
     "srl_conv2d_dgrad_repack": (c_int, [c_void_p, _CD, c_void_p, c_void_p]),
     "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 9),
+    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 8),
     "srl_conv2d_obs_fwd_workspace": (c_int64, [_CD]),
     "srl_obs_space_to_depth": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                         c_void_p]),
@@ -577,17 +576,9 @@ def conv2d_supported(d: ConvDesc, first_layer) -> bool:
     return bool(lib().srl_conv2d_supported(ctypes.byref(d), int(first_layer)))
 
 
-DACT_RELU_BITS = 3  # the activation derivative comes from a producer's relu_bits mask instead of its float32 output
-
-
-def conv2d_relu_bits_ok(d: ConvDesc) -> bool:
-    return bool(lib().srl_conv2d_relu_bits_ok(ctypes.byref(d)))
-
-
-def conv2d_nhwc_fwd(d: ConvDesc, x_ptr, w_ptr, bias_ptr, y_ptr, relu_bits_ptr=None):
+def conv2d_nhwc_fwd(d: ConvDesc, x_ptr, w_ptr, bias_ptr, y_ptr):
     with _scope("conv_fwd", _conv_flops(d)):
-        _check(lib().srl_conv2d_nhwc_fwd(_stream(), ctypes.byref(d), x_ptr, w_ptr, bias_ptr, y_ptr, relu_bits_ptr),
-               "srl_conv2d_nhwc_fwd")
+        _check(lib().srl_conv2d_nhwc_fwd(_stream(), ctypes.byref(d), x_ptr, w_ptr, bias_ptr, y_ptr), "srl_conv2d_nhwc_fwd")
 
 
 def conv2d_wgrad_workspace(d: ConvDesc) -> int:
@@ -620,12 +611,11 @@ def conv2d_obs_fwd_workspace(d: ConvDesc) -> int:
 
 
 def conv2d_obs_fwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr,
-                   channels_last=False, ws_ptr=None, relu_bits_ptr=None):
+                   channels_last=False, ws_ptr=None):
     with _scope("conv_obs_fwd", _conv_flops(d)):
         _check(
             lib().srl_conv2d_obs_fwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), int(channels_last), mean_ptr,
-                                     rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr, ws_ptr, relu_bits_ptr),
-            "srl_conv2d_obs_fwd")
+                                     rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr, ws_ptr), "srl_conv2d_obs_fwd")
 
 
 def obs_space_to_depth(obs_ptr, is_u8, n, C, H, W, s, out_ptr, mean_ptr, rstd_ptr):
