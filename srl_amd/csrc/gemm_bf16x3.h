@@ -206,13 +206,20 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
   }
 
   // one k-step on LDS buffer `cur`: per 16-deep k-block, fragments of the three planes of both operands and the six
-  // piece products per 32x32 block; after the first k-block the staging of the following tiles (registers -> the other
-  // LDS buffer with the split; global loads of the tile after that), then the single barrier of the step
+  // piece products per 32x32 block, with the staging of the following tiles (tile t+1: registers -> the other LDS buffer
+  // with the split; tile t+2: global -> registers) INTERLEAVED with the MFMAs, then the single barrier of the step.
+  // An MFMA occupies the wavefront's issue for 8 of its 32 cycles: four or five independent VALU operations fit in its
+  // shadow.  Left to itself the compiler issues the 24 MFMAs of a step back to back and the ~100 operations of the split
+  // after them, with the matrix pipe idle (60 % busy by the counters); the staging is therefore unconditional -- a step
+  // without a successor stages an out-of-range tile: zeros, written to a buffer nobody reads -- so that the whole step is
+  // one basic block, and sched_group_barrier lays the instruction pipeline out: 1 MFMA, 4 VALU, the LDS writes and the
+  // global loads spread between them.
   auto kstep = [&](auto cur_c, long k1, long k2) {
     constexpr int cur = decltype(cur_c)::value;
     const uint8_t* la = lds + cur * BUF;
     const uint8_t* lb = la + TA::BYTES;
     uint8_t* nxt = lds + (cur ^ 1) * BUF;
+    const long k2x = k2 >= 0 ? k2 : kend;  // out of range: every load returns zeros
 #pragma unroll
     for (int kb = 0; kb < KB / 16; ++kb) {
       bf16x8 a[TM][3], b[TN][3];
@@ -224,27 +231,31 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int p = 0; p < 3; ++p) b[j][p] = frag3<BN, BKM, KB>(lb, p, wn * (TN * 32) + j * 32, kb, lane);
+      // small terms first: they meet an accumulator that has not grown by this block's leading term yet
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int t = 0; t < 6; ++t)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          // small terms first: they meet an accumulator that has not grown by this block's leading term yet
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-        }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
       if (kb == 0) {
-        if (k1 >= 0) {  // tile t+1: registers -> the other LDS buffer (its readers left at the last barrier)
-          cs_acc();
-          store3<SA, BM, AKM, KB, NT>(sa, nxt);
-          store3<SB, BN, BKM, KB, NT>(sb, nxt + TA::BYTES);
-        }
-        if (k2 >= 0) {  // tile t+2: global -> registers
-          sa.load(g.a, m0, g.M, k2, kend, true);
-          sb.load(g.b, n0, g.N, k2, kend, true);
+        (void)k1;
+        cs_acc();
+        store3<SA, BM, AKM, KB, NT>(sa, nxt);           // tile t+1 (or zeros): registers -> the other LDS buffer
+        store3<SB, BN, BKM, KB, NT>(sb, nxt + TA::BYTES);
+        sa.load(g.a, m0, g.M, k2x, kend, true);         // tile t+2 (or nothing): global -> registers
+        sb.load(g.b, n0, g.N, k2x, kend, true);
+      }
+      if (KB == 16) {  // the issue pipeline of the step: see above
+        constexpr int NM = 6 * TM * TN;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                   // four VALU operations in its shadow
+          if (m % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // an LDS write every other gap
+          if (m % 6 == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load every sixth
         }
       }
     }
