@@ -389,6 +389,22 @@ int srl_adam_step(void* stream, float* p, const float* g, float* m, float* v, in
                   float max_norm, const double* sumsq, float* grad_norm_out,
                   const float* step_scalars);
 
+/* `Convolution` encoder pieces beyond unpadded convolutions (legacy/algorithm/modules/cnn.py:99-118; policies/utils.py:53):
+ * srl_obs_ln_nhwc(_bwd): the whole-observation LayerNorm as an explicit pass, planar uint8 / float32 observation
+ *   [n,C,H,W] -> channels-last float32 [n,H,W,C] (gamma / beta [C,H,W]); backward accumulates dgamma, dbeta from
+ *   dy [n,H,W,C].  srl_pad_nhwc / srl_crop_nhwc: zero padding of an NHWC activation and its adjoint (nn.Conv2d(padding=p,
+ *   padding_mode='zeros')).  srl_maxpool2_nhwc_fwd / _bwd: MaxPool2d(2) (`use_maxpool`: in front of every layer but the
+ *   last); the backward routes to the first maximum of a window (torch's rule) and multiplies by act'(x) of the
+ *   activation that produced x (dact 0 none, 1 relu, 2 tanh). */
+int srl_obs_ln_nhwc(void* stream, const void* obs, int is_u8, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, int64_t n, int C, int H, int W, float* y);
+int srl_obs_ln_nhwc_bwd(void* stream, const float* dy, const void* obs, int is_u8, const float* mean, const float* rstd,
+                        int64_t n, int C, int H, int W, float* dgamma, float* dbeta);
+int srl_pad_nhwc(void* stream, const float* x, int64_t n, int H, int W, int C, int pad, float* y);
+int srl_crop_nhwc(void* stream, const float* yp, int64_t n, int H, int W, int C, int pad, float* x);
+int srl_maxpool2_nhwc_fwd(void* stream, const float* x, int64_t n, int H, int W, int C, float* y);
+int srl_maxpool2_nhwc_bwd(void* stream, const float* dy, const float* x, int64_t n, int H, int W, int C, int dact, float* dx);
+
 /* torch.optim.SGD / torch.optim.RMSprop on the flat buffer (modules/utils.py:268-286 accepts 'sgd' and 'rmsprop'
  * with their torch keyword configurations), same clip / grad_scale / grad_norm_out conventions as srl_adam_step.
  * SGD: momentum_buf may be NULL when momentum == 0; first_step != 0 initialises the buffer with the gradient

@@ -40,6 +40,7 @@ class OracleActorCritic:
                  num_dense_layers: int = 2,
                  rnn_type: str = "gru",
                  cnn_layers: Optional[Dict[str, List[Tuple]]] = None,
+                 use_maxpool: Optional[Dict[str, bool]] = None,
                  num_rnn_layers: int = 0,
                  popart: bool = False,
                  activation: str = "relu",
@@ -59,6 +60,7 @@ class OracleActorCritic:
         self.dense_layers, self.layernorm, self.activation = num_dense_layers, layernorm, activation
         self.shared = shared_backbone
         self.cnn_layers = cnn_layers or {}
+        self.use_maxpool = use_maxpool or {}
         self.num_rnn_layers, self.rnn_type = num_rnn_layers, rnn_type
         assert rnn_type in ("gru", "lstm") or num_rnn_layers == 0, "oracle restates the GRU and LSTM variants"
         self.params: "OrderedDict[str, torch.Tensor]" = OrderedDict()
@@ -103,12 +105,18 @@ class OracleActorCritic:
                 x = x.flatten(0, 1)  # cnn.py:131
                 cb = f"{base}.1._Convolution__model"
                 layers = self.cnn_layers[k]
+                pool = bool(self.use_maxpool.get(k, False))
+                idx = 0  # index in the reference's nn.Sequential: [MaxPool2d(2)] Conv2d act ... Flatten mlp (cnn.py:99-126)
                 for i, (_, _, stride, padding, _) in enumerate(layers):
-                    x = act(F.conv2d(x, self._p(f"{cb}.{2 * i}.weight"), self._p(f"{cb}.{2 * i}.bias"),
+                    if pool and i != len(layers) - 1:
+                        x = F.max_pool2d(x, 2)
+                        idx += 1
+                    x = act(F.conv2d(x, self._p(f"{cb}.{idx}.weight"), self._p(f"{cb}.{idx}.bias"),
                                      stride=stride, padding=padding))
+                    idx += 2
                 x = x.flatten(1)
                 j = 0
-                fb = f"{cb}.{2 * len(layers) + 1}"
+                fb = f"{cb}.{idx + 1}"
                 while f"{fb}.{3 * j}.weight" in self.params:  # cnn.py:86-91: halve until <= 8*hidden
                     x = torch.relu(F.linear(x, self._p(f"{fb}.{3 * j}.weight"), self._p(f"{fb}.{3 * j}.bias")))
                     x = F.layer_norm(x, (x.shape[-1],), self._p(f"{fb}.{3 * j + 2}.weight"),

@@ -100,7 +100,8 @@ class HipNet:
         for enc in list(spec.obs_encoders) + list(spec.state_encoders or []):
             for L in enc.layers:
                 if isinstance(L, ns.ConvSpec):
-                    per_row = max(per_row, L.out_hw[0] * L.out_hw[1] * L.cout, L.in_hw[0] * L.in_hw[1] * L.cin)
+                    per_row = max(per_row, L.out_hw[0] * L.out_hw[1] * L.cout,
+                                  (L.in_hw[0] + 2 * L.pad) * (L.in_hw[1] + 2 * L.pad) * L.cin)
                     if self.force_explicit_conv:
                         per_row = max(per_row, L.out_hw[0] * L.out_hw[1] * L.cin * L.k * L.k)
                 elif isinstance(L, ns.LinearSpec):
@@ -374,11 +375,37 @@ class HipNet:
                 cur, cur_act = y, L.act
             elif isinstance(L, ns.ObsLayerNormSpec):
                 pending_obs_ln = L
+                if L.explicit:  # written out once, channels-last float32; the convolutions then see a plain activation
+                    c, h, w = L.shape
+                    is_u8 = obs.dtype == torch.uint8
+                    if not is_u8 and obs.dtype != torch.float32:
+                        raise hip.HipError(f"image observation `{enc.key}` must be uint8 or float32, got {obs.dtype}")
+                    mean = self.ws.get(f"{tag}{L.prefix}.mean", n)
+                    rstd = self.ws.get(f"{tag}{L.prefix}.rstd", n)
+                    hip.obs_ln_stats(obs.data_ptr(), is_u8, n, c * h * w, mean.data_ptr(), rstd.data_ptr())
+                    y = self._buf(f"{tag}{L.prefix}.y", n * h * w, c)
+                    hip.obs_ln_nhwc(obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), self._p(f"{L.prefix}.weight"),
+                                    self._p(f"{L.prefix}.bias"), n, c, h, w, y.ptr)
+                    tape.append(("obsln", L, obs, (is_u8, mean, rstd, n), 0))
+                    cur, cur_act = y, 0
+            elif isinstance(L, ns.PoolSpec):
+                (h, w), (ph, pw) = L.in_hw, L.out_hw
+                assert cur.ld == L.c and cur.rows == n * h * w
+                y = self._buf(f"{tag}{L.prefix}.y", n * ph * pw, L.c)
+                hip.maxpool2_nhwc_fwd(cur.ptr, n, h, w, L.c, y.ptr)
+                tape.append(("pool", L, cur, n, cur_act))
+                cur, cur_act = y, 0  # the activation's derivative is applied by the pooling backward at the winner
             elif isinstance(L, ns.ConvSpec):
                 oh, ow = L.out_hw
                 m = n * oh * ow
                 kdim = L.cin * L.k * L.k
                 h, w = L.in_hw
+                if L.pad:  # zero-padded copy: the implicit-GEMM gather needs no bounds logic
+                    assert not L.first and cur.ld == L.cin and cur.rows == n * h * w
+                    h, w = h + 2 * L.pad, w + 2 * L.pad
+                    xp = self._buf(f"{tag}{L.prefix}.xp", n * h * w, L.cin)
+                    hip.pad_nhwc(cur.ptr, n, L.in_hw[0], L.in_hw[1], L.cin, L.pad, xp.ptr)
+                    cur = xp
                 desc = hip.conv_desc(n, h, w, L.cin, L.k, L.k, L.stride, L.cout, L.act)
                 # implicit GEMM (no patch matrix) whenever the geometry allows; explicit im2col otherwise
                 implicit = not self.force_explicit_conv and hip.conv2d_supported(desc, L.first)
@@ -444,6 +471,20 @@ class HipNet:
                 g = self._linear_bwd(L, x, g, in_act, need_dx, tag)
             elif kind == "gru":
                 g = self._gru_bwd(L, saved, g, in_act, need_dx, tag)
+            elif kind == "obsln":
+                is_u8, mean, rstd, n = saved
+                c, h, w = L.shape
+                assert g.ld == c and g.rows == n * h * w
+                hip.obs_ln_nhwc_bwd(g.ptr, x.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), n, c, h, w,
+                                    self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"))
+                g = None
+            elif kind == "pool":
+                n = saved
+                (h, w), (ph, pw) = L.in_hw, L.out_hw
+                assert g.ld == L.c and g.rows == n * ph * pw
+                dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.c)
+                hip.maxpool2_nhwc_bwd(g.ptr, x.ptr, n, h, w, L.c, in_act, dx.ptr)
+                g = dx
             elif kind == "conv":
                 P, first_saved, n, desc = saved
                 kdim = L.cin * L.k * L.k
@@ -464,10 +505,10 @@ class HipNet:
                         hip.conv2d_nhwc_wgrad(desc, x.ptr, g.ptr, gw, self.ws.get("conv_wgrad", wsz).data_ptr(), gb)
                         wt = self.ws.get(f"{L.prefix}.wt", hip.conv2d_dgrad_weight_elems(desc))
                         hip.conv2d_dgrad_repack(desc, wp, wt.data_ptr())
-                        h, w = L.in_hw
+                        h, w = L.in_hw[0] + 2 * L.pad, L.in_hw[1] + 2 * L.pad
                         dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.cin)
                         hip.conv2d_nhwc_dgrad(desc, g.ptr, wt.data_ptr(), x.ptr if in_act else None, in_act, dx.ptr)
-                        g = dx
+                        g = self._crop(L, dx, n, tag)
                     if g is not None and idx > 0:
                         prev_out_cols = self._out_cols(records[idx - 1])
                         if g.cols != prev_out_cols:
@@ -486,10 +527,10 @@ class HipNet:
                                           self._g(f"{lnspec.prefix}.bias"))
                     g = None
                 else:
-                    h, w = L.in_hw
+                    h, w = L.in_hw[0] + 2 * L.pad, L.in_hw[1] + 2 * L.pad
                     dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.cin)
                     hip.col2im_nhwc(P.ptr, n, h, w, L.cin, L.k, L.k, L.stride, x.ptr if in_act else None, in_act, dx.ptr)
-                    g = dx
+                    g = self._crop(L, dx, n, tag)
             self._notify_ready(kind, L, saved)
             if g is not None and idx > 0:
                 # a Flatten between this record's input and the previous record's output: reshape the gradient
@@ -499,8 +540,17 @@ class HipNet:
                     g = Buf(g.ptr, prev_out_cols, g.rows * g.cols // prev_out_cols, prev_out_cols)
         return g
 
+    def _crop(self, L, dx: Buf, n: int, tag: str) -> Buf:
+        """Gradient of a zero-padded input: drop the border."""
+        if not L.pad:
+            return dx
+        h, w = L.in_hw
+        out = self._buf(f"{tag}{L.prefix}.dxc", n * h * w, L.cin)
+        hip.crop_nhwc(dx.ptr, n, h, w, L.cin, L.pad, out.ptr)
+        return out
+
     def _notify_ready(self, kind, L, saved):
-        if self.grad_ready_hook is None:
+        if self.grad_ready_hook is None or kind == "pool":
             return
         done = [L.prefix]
         if kind == "conv" and L.first and saved[1] is not None:
@@ -516,6 +566,10 @@ class HipNet:
             return L.out_features
         if kind == "gru":
             return L.hidden
+        if kind == "pool":
+            return L.c
+        if kind == "obsln":
+            return L.shape[0]
         return L.cout
 
     def _trunk_fwd(self, tag, encoders, backbone, obs: Dict[str, torch.Tensor], n: int):

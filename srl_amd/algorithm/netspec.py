@@ -126,13 +126,25 @@ class ConvSpec:
     act: int
     first: bool  # reads the (layer-normed) NCHW observation directly
     s2d: int = 0  # first layer only: the observation is space-to-depth'd by this factor (= stride) before the gather
+    pad: int = 0  # zero padding on every side (in_hw is the unpadded input)
+
+
+@dataclasses.dataclass
+class PoolSpec:
+    """nn.MaxPool2d(2) between convolutions (modules/cnn.py:61-62): floor(H/2) x floor(W/2) windows, no parameters."""
+    prefix: str
+    c: int
+    in_hw: Tuple[int, int]
+    out_hw: Tuple[int, int]
 
 
 @dataclasses.dataclass
 class ObsLayerNormSpec:
-    """LayerNorm over a whole image observation (C,H,W), fused into the first convolution's gather."""
+    """LayerNorm over a whole image observation (C,H,W): fused into the first convolution's gather, or (``explicit``,
+    encoders with padding or max-pooling) written out once as a float32 channels-last image."""
     prefix: str
     shape: Tuple[int, int, int]
+    explicit: bool = False
 
 
 @dataclasses.dataclass
@@ -244,7 +256,8 @@ class _Builder:
             self.values[self.params[name].key].zero_()
 
 
-def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, act_name: str, cnn_layers: Dict):
+def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, act_name: str, cnn_layers: Dict,
+                    use_maxpool: Optional[Dict] = None):
     encs = []
     for key, shape in dims.items():
         base = f"{root}.{key}"
@@ -268,29 +281,45 @@ def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, a
         # a strided first convolution whose stride divides kernel and image is run on the space-to-depth'd
         # observation (contiguous patch rows); its weight and the LayerNorm tables then live in that layout
         k0, s0 = cfg[0][1], cfg[0][2]
-        s2d = s0 if (_allow_s2d() and s0 >= 1 and k0 % s0 == 0 and h % s0 == 0 and w % s0 == 0 and
+        pool = bool((use_maxpool or {}).get(key, False))
+        # padding or pooling: the general path -- LayerNorm written out channels-last, every convolution (the first
+        # included) an NHWC implicit GEMM over a padded / pooled activation
+        generic = pool or any(layer[3] != 0 for layer in cfg)
+        s2d = s0 if (not generic and _allow_s2d() and s0 >= 1 and k0 % s0 == 0 and h % s0 == 0 and w % s0 == 0 and
                      (c * s0 * s0) % 4 == 0) else 0
         b.layernorm(f"{base}.0", shape, s2d=s2d)
-        layers = [ObsLayerNormSpec(f"{base}.0", shape)]
+        layers = [ObsLayerNormSpec(f"{base}.0", shape, explicit=generic)]
         gain = torch.nn.init.calculate_gain(act_name)
+        idx = 0  # position in the reference's nn.Sequential (modules/cnn.py:57-72)
         for i, (cout, k, stride, padding, padding_mode) in enumerate(cfg):
-            if padding != 0:
-                raise NotImplementedError("convolutions with padding are not implemented on the HIP path")
-            oh, ow = _conv_out(h, k, stride), _conv_out(w, k, stride)
+            if padding != 0 and padding_mode != "zeros":
+                raise NotImplementedError(f"padding_mode `{padding_mode}`: only zero padding is implemented on the HIP path")
+            if isinstance(padding, (tuple, list, str)):
+                raise NotImplementedError("per-axis / named padding is not implemented on the HIP path")
+            if pool and i != len(cfg) - 1:  # the pooling layer sits BEFORE convolution i (modules/cnn.py:61-63)
+                ph, pw = h // 2, w // 2
+                if ph <= 0 or pw <= 0:
+                    raise ValueError(f"CNN Dimension error, got {(ph, pw)} after max-pooling")
+                layers.append(PoolSpec(f"{cb}.{idx}", c, (h, w), (ph, pw)))
+                h, w = ph, pw
+                idx += 1
+            oh, ow = _conv_out(h + 2 * padding, k, stride), _conv_out(w + 2 * padding, k, stride)
             if oh <= 0 or ow <= 0:
                 raise ValueError(f"CNN Dimension error, got {(oh, ow)} after convolution")
-            name = f"{cb}.{2 * i}"
-            b.conv(name, c, cout, k, ("conv_s2d" if s2d else "plain") if i == 0 else "conv_nhwc", s2d=s2d if i == 0 else 0)
+            name = f"{cb}.{idx}"
+            idx += 2  # the convolution and its activation
+            first = i == 0 and not generic
+            b.conv(name, c, cout, k, ("conv_s2d" if s2d else "plain") if first else "conv_nhwc", s2d=s2d if first else 0)
             b.orthogonal(f"{name}.weight", gain)  # modules/cnn.py:73-84 (use_orthogonal=True)
             b.zero(f"{name}.bias")
-            layers.append(ConvSpec(name, c, cout, k, stride, (h, w), (oh, ow), act, first=(i == 0),
-                                   s2d=s2d if i == 0 else 0))
+            layers.append(ConvSpec(name, c, cout, k, stride, (h, w), (oh, ow), act, first=first,
+                                   s2d=s2d if first else 0, pad=int(padding)))
             c, h, w = cout, oh, ow
         sizes = [c * h * w]
         while sizes[-1] > hidden * 8:  # modules/cnn.py:86-91
             sizes.append(sizes[-1] // 2)
         sizes.append(hidden)
-        fb = f"{cb}.{2 * len(cfg) + 1}"
+        fb = f"{cb}.{idx + 1}"  # nn.Flatten takes index idx
         for j in range(len(sizes) - 1):
             first_fc = j == 0
             b.linear(f"{fb}.{3 * j}", sizes[j], sizes[j + 1], "fc_from_chw" if first_fc else "plain",
@@ -359,8 +388,6 @@ def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim
     std_type = _unused.get("std_type", "fixed")
     if continuous_action and std_type not in ("fixed", "separate_learnable", "shared_learnable"):
         raise NotImplementedError(f"Standard deviation type {std_type} not implemented.")
-    if use_maxpool and any(use_maxpool.values()):
-        raise NotImplementedError("max-pooling convolution encoders are not on the HIP path")
     if activation not in ACTS:
         raise NotImplementedError(f"Activation function {activation} not implemented.")
     act = ACTS[activation]
@@ -378,25 +405,26 @@ def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim
     try:
         return _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation,
                       layernorm, shared_backbone, seed, popart, num_rnn_layers, rnn_type,
-                      (std_type, float(_unused.get("init_log_std", -0.5))) if continuous_action else None)
+                      (std_type, float(_unused.get("init_log_std", -0.5))) if continuous_action else None,
+                      use_maxpool=use_maxpool)
     finally:
         torch.set_num_threads(threads)
 
 
 def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation, layernorm,
-           shared_backbone, seed, popart=False, num_rnn_layers=0, rnn_type="gru", continuous=None):
+           shared_backbone, seed, popart=False, num_rnn_layers=0, rnn_type="gru", continuous=None, use_maxpool=None):
     b = _Builder(seed)
     if continuous is not None and continuous[0] != "shared_learnable":
         # one vector of log standard deviations; a direct nn.Parameter of the net, so it leads the state_dict.
         # `fixed` is excluded from the optimiser in the reference (requires_grad=False): its gradient stays zero here
         b._add("log_std", (sum(act_dims),), continuous[1] * torch.ones(sum(act_dims)) if b.init else None)
-    obs_enc = _build_encoders(b, "obs_modules_dict", obs_dims, hidden_dim, act, activation, cnn_layers)
+    obs_enc = _build_encoders(b, "obs_modules_dict", obs_dims, hidden_dim, act, activation, cnn_layers, use_maxpool)
     actor_bb = _build_backbone(b, "actor_backbone", hidden_dim * len(obs_dims), hidden_dim, num_dense_layers, act,
                                layernorm, num_rnn_layers, rnn_type)
     state_enc = critic_bb = None
     if not shared_backbone:
         sdims = state_dim or obs_dims
-        state_enc = _build_encoders(b, "state_modules_dict", sdims, hidden_dim, act, activation, cnn_layers)
+        state_enc = _build_encoders(b, "state_modules_dict", sdims, hidden_dim, act, activation, cnn_layers, use_maxpool)
         critic_bb = _build_backbone(b, "critic_backbone", hidden_dim * len(sdims), hidden_dim, num_dense_layers, act,
                                     layernorm, num_rnn_layers, rnn_type)
     b.linear("actor_head", hidden_dim, sum(act_dims))

@@ -328,53 +328,61 @@ __global__ __launch_bounds__(256) void im2col_obs_ln_kernel(const void* obs, con
   }
 }
 
-// P[(s*OH+oh)*OW+ow][(kh*KW + kw)*C + c] = x[s, oh*S+kh, ow*S+kw, c]   (NHWC, float4 along c)
+// P[(s*OH+oh)*OW+ow][(kh*KW + kw)*C + c] = x[s, oh*S+kh, ow*S+kw, c]   (NHWC; V = 4: float4 along c, V = 1: any C)
+template <int V>
 __global__ __launch_bounds__(256) void im2col_nhwc_kernel(const float* x, long n, int H, int W, int C, int KH, int KW,
                                                           int S, int OH, int OW, float* P) {
-  const int C4 = C / 4;
-  const int Kq = KH * KW * C4;
+  const int CV = C / V;
+  const int Kq = KH * KW * CV;
   const long total = n * OH * OW * (long)Kq;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int kq = (int)(e % Kq);
     const long m = e / Kq;
     const int ow = (int)(m % OW), oh = (int)((m / OW) % OH);
     const long s = m / ((long)OW * OH);
-    const int c4 = kq % C4, kw = (kq / C4) % KW, kh = kq / (C4 * KW);
-    const float4 v = *reinterpret_cast<const float4*>(x + ((s * H + oh * S + kh) * W + ow * S + kw) * C + c4 * 4);
-    *reinterpret_cast<float4*>(P + e * 4) = v;
+    const int cv = kq % CV, kw = (kq / CV) % KW, kh = kq / (CV * KW);
+    const float* src = x + ((s * H + oh * S + kh) * W + ow * S + kw) * C + cv * V;
+    if (V == 4) *reinterpret_cast<float4*>(P + e * 4) = *reinterpret_cast<const float4*>(src);
+    else P[e] = src[0];
   }
 }
 
 // dX[s,h,w,c] = sum_{kh,kw : (h-kh)%S==0, (w-kw)%S==0, in range} dP[(s,oh,ow)][(kh,kw,c)]  (* act'(y))
+template <int V>
 __global__ __launch_bounds__(256) void col2im_nhwc_kernel(const float* dP, long n, int H, int W, int C, int KH, int KW,
                                                           int S, int OH, int OW, const float* y, int dact, float* dX) {
-  const int C4 = C / 4;
-  const long total = n * H * W * (long)C4;
+  const int CV = C / V;
+  const long total = n * H * W * (long)CV;
   const long Kp = (long)KH * KW * C;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int c4 = (int)(e % C4);
-    const long pix = e / C4;
+    const int cv = (int)(e % CV);
+    const long pix = e / CV;
     const int w = (int)(pix % W), h = (int)((pix / W) % H);
     const long s = pix / ((long)W * H);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
     for (int kh = h % S; kh < KH && kh <= h; kh += S) {
       const int oh = (h - kh) / S;
       if (oh >= OH) continue;
       for (int kw = w % S; kw < KW && kw <= w; kw += S) {
         const int ow = (w - kw) / S;
         if (ow >= OW) continue;
-        const float4 v = *reinterpret_cast<const float4*>(dP + ((s * OH + oh) * OW + ow) * Kp + (kh * KW + kw) * C + c4 * 4);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        const float* src = dP + ((s * OH + oh) * OW + ow) * Kp + (kh * KW + kw) * C + cv * V;
+        if (V == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(src);
+          acc[0] += v.x; acc[1 % V] += v.y; acc[2 % V] += v.z; acc[3 % V] += v.w;
+        } else {
+          acc[0] += src[0];
+        }
       }
     }
     if (y && dact) {
-      const float4 yv = *reinterpret_cast<const float4*>(y + e * 4);
-      acc.x *= act_grad_from_output(yv.x, dact);
-      acc.y *= act_grad_from_output(yv.y, dact);
-      acc.z *= act_grad_from_output(yv.z, dact);
-      acc.w *= act_grad_from_output(yv.w, dact);
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] *= act_grad_from_output(y[e * V + j], dact);
     }
-    *reinterpret_cast<float4*>(dX + e * 4) = acc;
+    if (V == 4) *reinterpret_cast<float4*>(dX + e * 4) = make_float4(acc[0], acc[1 % V], acc[2 % V], acc[3 % V]);
+    else dX[e] = acc[0];
   }
 }
 
@@ -546,12 +554,13 @@ extern "C" int srl_im2col_obs_ln(void* stream, const void* obs, int is_u8, const
 extern "C" int srl_im2col_nhwc(void* stream, const float* x, int64_t n, int H, int W, int C, int KH, int KW, int stride,
                                float* P) {
   SRL_CHECK_ARG(x && P, "null tensor");
-  SRL_CHECK_ARG(C % 4 == 0 && KH <= H && KW <= W && stride >= 1, "needs C % 4 == 0 and a valid geometry");
+  SRL_CHECK_ARG(C >= 1 && KH <= H && KW <= W && stride >= 1, "invalid geometry");
   if (n == 0) return 0;
   const int OH = conv_out(H, KH, stride), OW = conv_out(W, KW, stride);
-  const long total = n * OH * OW * (long)KH * KW * (C / 4);
-  hipLaunchKernelGGL(im2col_nhwc_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, n, H, W, C, KH,
-                     KW, stride, OH, OW, P);
+  const int V = C % 4 == 0 ? 4 : 1;
+  const long total = n * OH * OW * (long)KH * KW * (C / V);
+  if (V == 4) hipLaunchKernelGGL(im2col_nhwc_kernel<4>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, n, H, W, C, KH, KW, stride, OH, OW, P);
+  else hipLaunchKernelGGL(im2col_nhwc_kernel<1>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, n, H, W, C, KH, KW, stride, OH, OW, P);
   SRL_LAUNCH_CHECK();
   return 0;
 }
@@ -559,12 +568,13 @@ extern "C" int srl_im2col_nhwc(void* stream, const float* x, int64_t n, int H, i
 extern "C" int srl_col2im_nhwc(void* stream, const float* dP, int64_t n, int H, int W, int C, int KH, int KW,
                                int stride, const float* y, int dact, float* dX) {
   SRL_CHECK_ARG(dP && dX, "null tensor");
-  SRL_CHECK_ARG(C % 4 == 0 && KH <= H && KW <= W && stride >= 1, "needs C % 4 == 0 and a valid geometry");
+  SRL_CHECK_ARG(C >= 1 && KH <= H && KW <= W && stride >= 1, "invalid geometry");
   if (n == 0) return 0;
   const int OH = conv_out(H, KH, stride), OW = conv_out(W, KW, stride);
-  const long total = n * H * W * (long)(C / 4);
-  hipLaunchKernelGGL(col2im_nhwc_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, dP, n, H, W, C, KH,
-                     KW, stride, OH, OW, y, dact, dX);
+  const int V = C % 4 == 0 ? 4 : 1;
+  const long total = n * H * W * (long)(C / V);
+  if (V == 4) hipLaunchKernelGGL(col2im_nhwc_kernel<4>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, dP, n, H, W, C, KH, KW, stride, OH, OW, y, dact, dX);
+  else hipLaunchKernelGGL(col2im_nhwc_kernel<1>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, dP, n, H, W, C, KH, KW, stride, OH, OW, y, dact, dX);
   SRL_LAUNCH_CHECK();
   return 0;
 }

@@ -117,6 +117,13 @@ _SIGNATURES = {
     "srl_grad_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                c_float, c_float, c_int, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "srl_obs_ln_nhwc": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_void_p]),
+    "srl_obs_ln_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                     c_void_p, c_void_p]),
+    "srl_pad_nhwc": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "srl_crop_nhwc": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "srl_maxpool2_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "srl_maxpool2_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "srl_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int, c_int,
                               c_float, c_float, c_void_p, c_void_p]),
     "srl_rmsprop_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
@@ -496,6 +503,32 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, adamw, step, grad
                             int(step), float(grad_scale), float(max_norm), _ptr(sumsq, torch.float64, "sumsq"),
                             _ptr(grad_norm_out, f, "grad_norm_out"), _ptr(step_scalars, f, "step_scalars")),
         "srl_adam_step")
+
+
+def obs_ln_nhwc(obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, n, C, H, W, y_ptr):
+    _check(lib().srl_obs_ln_nhwc(_stream(), obs_ptr, int(is_u8), mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, n, C, H, W, y_ptr),
+           "srl_obs_ln_nhwc")
+
+
+def obs_ln_nhwc_bwd(dy_ptr, obs_ptr, is_u8, mean_ptr, rstd_ptr, n, C, H, W, dgamma_ptr, dbeta_ptr):
+    _check(lib().srl_obs_ln_nhwc_bwd(_stream(), dy_ptr, obs_ptr, int(is_u8), mean_ptr, rstd_ptr, n, C, H, W, dgamma_ptr,
+                                     dbeta_ptr), "srl_obs_ln_nhwc_bwd")
+
+
+def pad_nhwc(x_ptr, n, H, W, C, pad, y_ptr):
+    _check(lib().srl_pad_nhwc(_stream(), x_ptr, n, H, W, C, pad, y_ptr), "srl_pad_nhwc")
+
+
+def crop_nhwc(yp_ptr, n, H, W, C, pad, x_ptr):
+    _check(lib().srl_crop_nhwc(_stream(), yp_ptr, n, H, W, C, pad, x_ptr), "srl_crop_nhwc")
+
+
+def maxpool2_nhwc_fwd(x_ptr, n, H, W, C, y_ptr):
+    _check(lib().srl_maxpool2_nhwc_fwd(_stream(), x_ptr, n, H, W, C, y_ptr), "srl_maxpool2_nhwc_fwd")
+
+
+def maxpool2_nhwc_bwd(dy_ptr, x_ptr, n, H, W, C, dact, dx_ptr):
+    _check(lib().srl_maxpool2_nhwc_bwd(_stream(), dy_ptr, x_ptr, n, H, W, C, int(dact), dx_ptr), "srl_maxpool2_nhwc_bwd")
 
 
 def sgd_step(p, g, buf, lr, momentum, dampening, weight_decay, nesterov, first_step, grad_scale=1.0, max_norm=-1.0,

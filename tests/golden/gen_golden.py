@@ -372,6 +372,28 @@ def gen_steps():
     save("steps_cnn.npz", **out)
 
 
+PAD_POLICY = dict(obs_dim={"obs": (4, 20, 20)}, action_dim=5, hidden_dim=32, num_dense_layers=1, num_rnn_layers=0,
+                  popart=False, layernorm=False, shared_backbone=True, chunk_len=4, seed=71,
+                  cnn_layers=dict(obs=[(8, 3, 1, 1, 'zeros'), (16, 3, 2, 1, 'zeros'), (8, 3, 1, 0, 'zeros')]))
+POOL_POLICY = dict(obs_dim={"img": (3, 23, 19), "vec": 5}, action_dim=[3, 2], hidden_dim=16, num_dense_layers=1,
+                   num_rnn_layers=0, popart=True, layernorm=True, shared_backbone=False, chunk_len=4, seed=72,
+                   activation="tanh", use_maxpool=dict(img=True),
+                   cnn_layers=dict(img=[(4, 3, 1, 0, 'zeros'), (8, 3, 1, 1, 'zeros'), (4, 3, 1, 0, 'zeros')]))
+
+
+def gen_cnn_padpool():
+    """Convolution encoders with zero padding and with nn.MaxPool2d(2) between the layers (modules/cnn.py:99-126: the pooling
+    layer sits BEFORE every convolution but the last, so the first one pools the layer-normed image itself).  Odd image
+    sizes (floor windows), three input channels, tanh, float32 frames and a vector key beside the image."""
+    out = {}
+    run_steps("cnnpad", PAD_POLICY, dict(popart=False, ppo_epochs=2, optimizer_config=dict(lr=5e-4), max_grad_norm=10.0),
+              dict(T=6, B=4, obs_spec={"obs": ((4, 20, 20), "u8")}, action_dims=5, p_done=0.1), 2, out=out, store_state="sampled")
+    run_steps("cnnpool", POOL_POLICY, dict(popart=True, optimizer_config=dict(lr=1e-3)),
+              dict(T=5, B=3, obs_spec={"img": ((3, 23, 19), "f32"), "vec": ((5,), "f32")}, action_dims=[3, 2], p_done=0.1), 2,
+              out=out)
+    save("steps_cnn_padpool.npz", **out)
+
+
 def gen_vtrace_rnn():
     """V-trace with recurrent policies (mappo.py:243-246: the analysed rows give both the importance ratio of the trace
     and the loss): GRU shared backbone, and LSTM separate backbones with PopArt and two epochs."""

@@ -32,6 +32,12 @@ CASES = {
             dict(popart=False, optimizer_config=dict(lr=5e-4), max_grad_norm=40.0, clip_value=True, value_loss="huber",
                  value_loss_config=dict(delta=10.0)),
             dict(T=4, B=3, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.1)),
+    # padded and max-pooled convolutions (the general encoder path: explicit LayerNorm, pad / pool / crop kernels)
+    "cnnpool": (dict(obs_dim={"img": (4, 22, 18)}, action_dim=4, hidden_dim=32, num_dense_layers=1, num_rnn_layers=0,
+                     popart=False, layernorm=True, shared_backbone=True, seed=6, use_maxpool=dict(img=True),
+                     cnn_layers=dict(img=[(8, 3, 1, 1, 'zeros'), (8, 3, 1, 1, 'zeros'), (8, 3, 1, 0, 'zeros')])),
+                dict(popart=False, optimizer_config=dict(lr=5e-4), max_grad_norm=10.0),
+                dict(T=4, B=3, obs_spec={"img": ((4, 22, 18), "u8")}, action_dims=4, p_done=0.1)),
 }
 
 

@@ -134,6 +134,21 @@ CASES.update({
     "cshr": (dict(_CBASE, std_type="shared_learnable", shared_backbone=True, seed=33), _CTR, _CSMP, 2,
              "steps_continuous.npz"),
 })
+# zero padding and max-pooling between the convolutions (gen_golden.py gen_cnn_padpool)
+PAD_POLICY = dict(obs_dim={"obs": (4, 20, 20)}, action_dim=5, hidden_dim=32, num_dense_layers=1, num_rnn_layers=0,
+                  popart=False, layernorm=False, shared_backbone=True, chunk_len=4, seed=71,
+                  cnn_layers=dict(obs=[(8, 3, 1, 1, 'zeros'), (16, 3, 2, 1, 'zeros'), (8, 3, 1, 0, 'zeros')]))
+POOL_POLICY = dict(obs_dim={"img": (3, 23, 19), "vec": 5}, action_dim=[3, 2], hidden_dim=16, num_dense_layers=1,
+                   num_rnn_layers=0, popart=True, layernorm=True, shared_backbone=False, chunk_len=4, seed=72,
+                   activation="tanh", use_maxpool=dict(img=True),
+                   cnn_layers=dict(img=[(4, 3, 1, 0, 'zeros'), (8, 3, 1, 1, 'zeros'), (4, 3, 1, 0, 'zeros')]))
+CASES.update({
+    "cnnpad": (PAD_POLICY, dict(popart=False, ppo_epochs=2, optimizer_config=dict(lr=5e-4), max_grad_norm=10.0),
+               dict(T=6, B=4, obs_spec={"obs": ((4, 20, 20), "u8")}, action_dims=5, p_done=0.1), 2, "steps_cnn_padpool.npz"),
+    "cnnpool": (POOL_POLICY, dict(popart=True, optimizer_config=dict(lr=1e-3)),
+                dict(T=5, B=3, obs_spec={"img": ((3, 23, 19), "f32"), "vec": ((5,), "f32")}, action_dims=[3, 2], p_done=0.1),
+                2, "steps_cnn_padpool.npz"),
+})
 
 
 def make_trainer(policy_args, trainer_args):
