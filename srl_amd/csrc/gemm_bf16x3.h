@@ -22,6 +22,13 @@ namespace srlgemm {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// timing experiments only (scripts/build_variant.sh -DSRL_GEMM3_DBG=<bits>; results are wrong): 1 no in-loop global loads,
+// 2 no in-loop LDS writes, 4 no split arithmetic, 8 no barrier, 32 / 64 every gather redirected into a 16 KB / 1 MB
+// window (gemm_core.h bload4).  DESIGN.md section 4 records what they showed.
+#ifndef SRL_GEMM3_DBG
+#define SRL_GEMM3_DBG 0
+#endif
+
 #ifdef __HIPCC__
 // one operand tile in LDS: three planes of BX x KB bf16
 template <int BX, bool KMAJOR, int KB>
@@ -51,6 +58,7 @@ __device__ __forceinline__ void split3_quad(const float* v, uint2 (&pl)[3]) {
   uint32_t b[3][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    if (SRL_GEMM3_DBG & 4) { b[0][i] = b[1][i] = b[2][i] = __float_as_uint(v[i]); continue; }
     b[0][i] = __float_as_uint(v[i]) & 0xffff0000u;
     const float r1 = v[i] - __uint_as_float(b[0][i]);
     b[1][i] = __float_as_uint(r1) & 0xffff0000u;
@@ -243,10 +251,14 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
       if (kb == 0) {
         (void)k1;
         cs_acc();
-        store3<SA, BM, AKM, KB, NT>(sa, nxt);           // tile t+1 (or zeros): registers -> the other LDS buffer
-        store3<SB, BN, BKM, KB, NT>(sb, nxt + TA::BYTES);
-        sa.load(g.a, m0, g.M, k2x, kend, true);         // tile t+2 (or nothing): global -> registers
-        sb.load(g.b, n0, g.N, k2x, kend, true);
+        if (!(SRL_GEMM3_DBG & 2)) {
+          store3<SA, BM, AKM, KB, NT>(sa, nxt);           // tile t+1 (or zeros): registers -> the other LDS buffer
+          store3<SB, BN, BKM, KB, NT>(sb, nxt + TA::BYTES);
+        }
+        if (!(SRL_GEMM3_DBG & 1)) {
+          sa.load(g.a, m0, g.M, k2x, kend, true);         // tile t+2 (or nothing): global -> registers
+          sb.load(g.b, n0, g.N, k2x, kend, true);
+        }
       }
       if (KB == 16) {  // the issue pipeline of the step: see above
         constexpr int NM = 6 * TM * TN;
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
         }
       }
     }
-    __syncthreads();
+    if (!(SRL_GEMM3_DBG & 8)) __syncthreads();
   };
   for (;;) {
     long k2 = knext >= 0 ? nextk(knext) : -1;

@@ -42,10 +42,11 @@ constexpr bool is_obs(int m) { return m == SRC_OBS || m == SRC_OBSN; }
 
 // ---- division by a runtime-invariant 32-bit divisor (valid for dividends < 2^31) ----------------------------------
 struct FastDiv {
-  uint32_t d, mul, shr;
+  uint32_t d, mul, shr, one;  // one: all ones when d == 1 (the 32-bit magic cannot express it), else 0
 };
 inline FastDiv make_fastdiv(uint32_t d) {
-  FastDiv f{d ? d : 1u, 0u, 0u};
+  FastDiv f{d ? d : 1u, 0u, 0u, 0u};
+  f.one = f.d == 1 ? 0xffffffffu : 0u;
   if (f.d != 1) {
     uint32_t lg = 31 - __builtin_clz(f.d);
     if (f.d & (f.d - 1)) lg += 1;  // ceil(log2 d)
@@ -57,7 +58,9 @@ inline FastDiv make_fastdiv(uint32_t d) {
 }
 #ifdef __HIPCC__
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
-  return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr);
+  // branch-free on purpose: written as a select on a wave-uniform divisor, the compiler branched around the multiply and
+  // cut the k-step of the k-major gathers into a dozen basic blocks (their loads then issued after the MFMAs, not among them)
+  return (__umulhi(n, f.mul) >> f.shr) | (n & f.one);
 }
 #endif
 
@@ -228,7 +231,12 @@ constexpr uint32_t kInvalidOff = 0xFFFFFF00u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)kNumRecords, 0x00020000);
 }
+#ifndef SRL_GEMM3_DBG
+#define SRL_GEMM3_DBG 0  // timing experiments only, see gemm_bf16x3.h
+#endif
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, uint32_t voff) {
+  if ((SRL_GEMM3_DBG & 32) && voff != kInvalidOff) voff &= 0x3ff0u;    // every gather lands in one 16 KB window (L1 hits)
+  if ((SRL_GEMM3_DBG & 64) && voff != kInvalidOff) voff &= 0xffff0u;   // ... in one 1 MB window (L2 hits)
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
@@ -429,7 +437,9 @@ struct Stage {
           const long k = k0 + (U8 ? NV * wave + q : BX == 256 ? wave + (NT / 64) * q : u / (BX / 4));
           const bool ok = k < kend && voff[q] != kInvalidOff;
           const RowInfo ri = row_info<MODE>(s, (uint32_t)(k < kend ? k : kend - 1));
-          const uint32_t o = ok ? voff[q] + (uint32_t)ri.off * esz : kInvalidOff;
+          // OR, not a select of the sum: the compiler sank the row decomposition under `ok` (an exec-mask branch per load),
+          // which cut the k-step into blocks; anything >= kInvalidOff is out of the descriptor's range and reads as zero
+          const uint32_t o = (voff[q] + (uint32_t)ri.off * esz) | (ok ? 0u : kInvalidOff);
           if (is_obs(MODE)) {
             if (!U8) { d_rs[q] = ok ? ri.rs : 0.f; d_mean[q] = ok ? ri.mr : 0.f; }
             if (MODE == SRC_OBS) d_gp[q] = !ok ? -1 : ri.pos + (int)(voff[q] / esz);

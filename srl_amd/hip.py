@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsrlhip.so")
+# SRL_HIP_LIB: another build of the same C ABI (kernel experiments, scripts/build_variant.sh); the default is the in-tree one
+_LIB_PATH = os.environ.get("SRL_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsrlhip.so")
 _lib = None
 
 ABI_VERSION = 4
