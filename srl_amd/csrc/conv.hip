@@ -291,6 +291,13 @@ extern "C" int srl_conv2d_supported(const srl_conv_desc* d, int first_layer) {
   return (d->Cin % 4 == 0 && d->Cout % 4 == 0) ? 1 : 0;
 }
 
+// 192 x 64 forward tiles (2 x 2 wavefronts of 96 x 32): 49 KB of LDS, 3 workgroups per CU where 256 x 64 fits 2 -- conv2 /
+// conv3 forward 0.75 / 0.42 -> 0.73 / 0.40 ms (same box).  SRL_TILE192=0: the 256 x 64 tiles (A/B switch)
+static bool tile192() {
+  static const bool on = [] { const char* e = getenv("SRL_TILE192"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w,
                                    const float* bias, float* y) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry (needs Cin, Cout multiples of 4, < 2^31 elements)");
@@ -311,7 +318,8 @@ extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const f
   const bool x3 = use_bf16x3() && Kp >= 64;  // bf16 matrix cores, three exact pieces per float32 operand
   if (d->Cout > 64) rc = x3 ? launch3<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3>(st, g, 1, 1)
                             : launch<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
-  else if (d->Cout > 32) rc = x3 ? launch3<256, 64, 4, 1, false, false, SRC_CONV, SRC_PLAIN, K3>(st, g, 1, 1)
+  else if (d->Cout > 32) rc = x3 ? (tile192() ? launch3<192, 64, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3>(st, g, 1, 1)
+                                                : launch3<256, 64, 4, 1, false, false, SRC_CONV, SRC_PLAIN, K3>(st, g, 1, 1))
                                  : launch<256, 64, 4, 1, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
   else rc = launch<256, 32, 4, 1, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
   SRL_CHECK_ARG(rc == 0, "grid too large");
