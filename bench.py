@@ -395,6 +395,9 @@ def main():
                                          "NatureCNN-512, uint8 (4,84,84) frames, Atari PPO preset",
                                 envs_per_gpu=B, rollout_len=T, global_envs=B * world, parallelism=f"dp{world}",
                                 chunk_rows=args.chunk_rows, collective_ranks=ranks_seen,
+                                collectives=("none (one rank)" if not use_dist else
+                                             "RCCL through the C ABI (srl_comm_*)" if getattr(trainer, "_comm", None) is not None
+                                             else f"torch.distributed ({backend})"),
                                 policy_loss=res.stats.get("policy_loss")),
                     roofline=roofline, roofline_gae=roofline_gae, kernel_ms_per_step=breakdown)
         if pcie is not None:

@@ -41,13 +41,34 @@ class NativeComm:
         if os.environ.get("SRL_COMM", "native") == "torch":
             return None
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        try:
-            idbuf = (ctypes.c_uint8 * 128)()
-            if rank == 0:
+        comm = cls._try_init(device, group, rank, world)
+        # every rank must take the same path: one that failed to join would otherwise wait in torch.distributed for peers
+        # that sit in an RCCL collective
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0 and comm is not None:
+            logger.warning("native RCCL communicator formed here but not on every rank: using torch.distributed collectives")
+            comm.close()
+            comm = None
+        return comm
+
+    @classmethod
+    def _try_init(cls, device, group, rank, world) -> Optional["NativeComm"]:
+        # the id broadcast happens on every rank whatever rank 0 managed to do (zeros = "no id"): a rank that raised before
+        # it would leave its peers waiting in the broadcast
+        idbuf = (ctypes.c_uint8 * 128)()
+        if rank == 0:
+            try:
                 hip._check(hip.lib().srl_comm_unique_id(idbuf), "srl_comm_unique_id")
-            t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=device)
-            dist.broadcast(t, src=0, group=group)
-            raw = bytes(t.cpu().tolist())
+            except (hip.HipError, OSError, AttributeError) as e:  # pragma: no cover - depends on the box
+                logger.warning("native RCCL communicator unavailable (%s): using torch.distributed collectives", e)
+                idbuf = (ctypes.c_uint8 * 128)()
+        t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=device)
+        dist.broadcast(t, src=0, group=group)
+        raw = bytes(t.cpu().tolist())
+        if not any(raw):
+            return None
+        try:
             handle = ctypes.c_void_p()
             with torch.cuda.device(device):
                 hip._check(hip.lib().srl_comm_init(ctypes.byref(handle), raw, rank, world), "srl_comm_init")
