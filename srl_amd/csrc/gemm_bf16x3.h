@@ -131,15 +131,22 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, h = lane >> 5;
-  unsigned lid;
-  {  // every XCD owns one contiguous run of logical workgroup ids (see gemm_kernel)
+  // One-dimensional grid of tiles x k-ranges.  Every XCD owns one contiguous run of logical workgroup ids (see
+  // gemm_kernel), and a logical id is (k-range, tile) with the tile fastest: the tiles of one k-range of a split-K
+  // product -- the 2-3 column tiles of a convolution's weight gradient read the SAME rows of both operands -- run on one
+  // XCD at the same time and share its L2 (as grid.z they were dealt round-robin over the XCDs: every line fetched
+  // from HBM once per column tile).
+  unsigned lid, kz;
+  {
     const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    lid = xcd * q + (xcd < r ? xcd : r) + slot;
+    const unsigned logical = xcd * q + (xcd < r ? xcd : r) + slot;
+    kz = logical / g.tiles_all;
+    lid = logical - kz * g.tiles_all;
   }
   const unsigned bx = g.nbatch > 1 ? lid / g.nbatch : lid;
   const long tile_m = bx / g.tiles_n, tile_n = bx % g.tiles_n;
   const long m0 = tile_m * BM, n0 = tile_n * BN;
-  const long kbeg = (long)blockIdx.z * g.k_per_split;
+  const long kbeg = (long)kz * g.k_per_split;
   const long kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
   const int by = g.nbatch > 1 ? (int)(lid % g.nbatch) : 0;
   if (by) {
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
         if (m0 + tid * 4 + c < g.M) atomicAdd(g.a_colsum + (long)by * g.a_colsum_batch + m0 + tid * 4 + c, t4[c]);
     }
   }
-  gemm_epilogue<TM, TN>(g, acc, m0, n0, wm, wn, l31, h, by);
+  gemm_epilogue<TM, TN>(g, acc, m0, n0, wm, wn, l31, h, by, kz);
 }
 
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB = 32>
@@ -309,8 +316,9 @@ inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   a.tiles_n = (int)srl_ceil_div(a.N, BN);
   a.nbatch = batch > 1 ? batch : 1;
   const long nblk = tiles_m * a.tiles_n * a.nbatch;
-  if (nblk > 0x7fffffffL || nsplit > 65535) return -EINVAL;
-  dim3 grid((unsigned)nblk, 1, (unsigned)nsplit);
+  if (nblk * nsplit > 0x7fffffffL) return -EINVAL;
+  a.tiles_all = (unsigned)nblk;
+  dim3 grid((unsigned)(nblk * nsplit), 1, 1);
   hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB>), grid, dim3(256), 0, st, a);
   return 0;
 }

@@ -116,6 +116,7 @@ struct GemmArgs {
   long k_per_split;
   int vec_a, vec_b;
   int tiles_n;
+  unsigned tiles_all;  // gemm3_kernel: tiles (x batches) per k-range; its grid is tiles_all x k-ranges in one dimension
   int nbatch;
   float* a_colsum;  // [M] += sum_k A(i, k) (k-major dense A only): the bias gradient of a weight-gradient product
   long a_colsum_batch;  // per-batch (grid.y) stride of a_colsum
@@ -593,11 +594,11 @@ struct Stage {
 // tile in the MFMA accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN], long m0, long n0, int wm, int wn, int l31,
-                                              int h, int by) {
+                                              int h, int by, unsigned kz) {  // kz: index of the k-range (split-K slab)
   // ---- epilogue: per 32x32 accumulator block, all loads batched ahead of the arithmetic and the stores ----------------
   const long obatch = g.o.brw ? (long)(by / g.o.brw) * g.o.batch_stride + (long)(by % g.o.brw) * g.o.bx_stride
                               : (long)by * g.o.batch_stride;
-  float* out = g.o.out + (long)blockIdx.z * g.slab + obatch;
+  float* out = g.o.out + (long)kz * g.slab + obatch;
   if (g.o.rowmap && g.dact_src) g.dact_src += obatch;  // the activation shares the output's map
   const float* bias = g.bias ? g.bias + (long)by * g.bias_batch : nullptr;
   // Row addressing stays 32-bit: a 64-bit base per 32-row block plus element offsets (dense output), or offsets
@@ -1006,7 +1007,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     }
   }
 
-  gemm_epilogue<TM, TN>(g, acc, m0, n0, wm, wn, l31, h, by);
+  gemm_epilogue<TM, TN>(g, acc, m0, n0, wm, wn, l31, h, by, blockIdx.z);
 }
 
 static __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* ws, int nslab, long batch, long M, long N,
