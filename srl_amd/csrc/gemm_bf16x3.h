@@ -144,7 +144,14 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
     lid = logical - kz * g.tiles_all;
   }
   const unsigned bx = g.nbatch > 1 ? lid / g.nbatch : lid;
-  const long tile_m = bx / g.tiles_n, tile_n = bx % g.tiles_n;
+  long tile_m, tile_n;
+  if (AMODE != SRC_PLAIN || BMODE != SRC_PLAIN || g.grp_n >= (unsigned)g.tiles_n) {
+    tile_m = bx / g.tiles_n; tile_n = bx % g.tiles_n;
+  } else {  // column groups (launch3): the B panels of one group stay in the XCD's L2 while the tile rows sweep past them
+    const unsigned grp = bx / g.grp_sz, r = bx - grp * g.grp_sz, c0 = grp * g.grp_n;
+    const unsigned left = (unsigned)g.tiles_n - c0, gw = left < g.grp_n ? left : g.grp_n;
+    tile_m = r / gw; tile_n = c0 + r % gw;
+  }
   const long m0 = tile_m * BM, n0 = tile_n * BN;
   const long kbeg = (long)kz * g.k_per_split;
   const long kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
@@ -309,6 +316,11 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
   gemm_epilogue<TM, TN>(g, acc, m0, n0, wm, wn, l31, h, by, kz);
 }
 
+inline bool tile_groups() {  // SRL_TILE_GROUP=0: row-major tile numbering everywhere (A/B switch)
+  static const bool on = [] { const char* e = getenv("SRL_TILE_GROUP"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB = 32>
 inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   if (!(a.vec_a && a.vec_b)) return -EINVAL;
@@ -318,6 +330,22 @@ inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   const long nblk = tiles_m * a.tiles_n * a.nbatch;
   if (nblk * nsplit > 0x7fffffffL) return -EINVAL;
   a.tiles_all = (unsigned)nblk;
+  a.grp_n = (unsigned)a.tiles_n;
+  if (AMODE == SRC_PLAIN && BMODE == SRC_PLAIN && a.nbatch == 1 && tile_groups()) {
+    // A dense product whose XCD share of tiles (one contiguous run of the numbering) exceeds the XCD's workgroup slots is
+    // worked off row after row; in row-major numbering every new tile row streams ALL of B again, from HBM once B is
+    // larger than the L2 (FC data gradient, 16384 x 3136 x 512: B = 6.4 MB re-read by each of the 16 tile rows of every
+    // XCD, 827 MB fetched per launch for 245 MB of operands).  Column groups whose B panels fit in half the 4 MB L2 are
+    // swept by all tile rows instead; A is then re-read once per group.
+    const long kr = nsplit > 1 ? a.k_per_split : a.K;
+    const double panel_b = (double)BN * (double)kr * 4.0, l2_half = 2.0 * 1024 * 1024;
+    const long run = srl_ceil_div(nblk * (long)nsplit, 8), slots = 32L * min_waves3(BM, BN, KB);
+    if (run > slots && panel_b * a.tiles_n > l2_half) {
+      const long gn = (long)(l2_half / panel_b);
+      a.grp_n = (unsigned)(gn < 1 ? 1 : gn);
+    }
+  }
+  a.grp_sz = (unsigned)tiles_m * a.grp_n;
   dim3 grid((unsigned)(nblk * nsplit), 1, 1);
   hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB>), grid, dim3(256), 0, st, a);
   return 0;

@@ -117,6 +117,9 @@ struct GemmArgs {
   int vec_a, vec_b;
   int tiles_n;
   unsigned tiles_all;  // gemm3_kernel: tiles (x batches) per k-range; its grid is tiles_all x k-ranges in one dimension
+  // gemm3_kernel, dense operands: tiles are numbered column group by column group (grp_n tile columns wide, every tile row
+  // inside a group before the next group; grp_sz = tile rows x grp_n).  grp_n >= tiles_n: plain row-major numbering.
+  unsigned grp_n, grp_sz;
   int nbatch;
   float* a_colsum;  // [M] += sum_k A(i, k) (k-major dense A only): the bias gradient of a weight-gradient product
   long a_colsum_batch;  // per-batch (grid.y) stride of a_colsum
