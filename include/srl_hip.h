@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 4
+#define SRL_HIP_ABI_VERSION 5
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -404,6 +404,23 @@ int srl_pad_nhwc(void* stream, const float* x, int64_t n, int H, int W, int C, i
 int srl_crop_nhwc(void* stream, const float* yp, int64_t n, int H, int W, int C, int pad, float* x);
 int srl_maxpool2_nhwc_fwd(void* stream, const float* x, int64_t n, int H, int W, int C, float* y);
 int srl_maxpool2_nhwc_bwd(void* stream, const float* dy, const float* x, int64_t n, int H, int W, int C, int dact, float* dx);
+
+/* The same encoder pieces for observations with one or three spatial dimensions (modules/cnn.py:60-71: nn.Conv1d /
+ * nn.Conv3d with MaxPool1d / MaxPool3d by the observation's rank; modules_test.py:385-401), on channels-last volumes
+ * [n, D, H, W, C] (Conv1d: D = H = 1).  srl_pad_ndhwc / srl_crop_ndhwc: zero border of (pd, ph, pw) voxels per side and
+ * its adjoint.  srl_maxpool_ndhwc_fwd / _bwd: windows of (wd, wh, ww) voxels, each 1 or 2, stride = window, floor; the
+ * backward as srl_maxpool2_nhwc_bwd.  srl_im2col_ndhwc: patch matrix P[(s,od,oh,ow)][(kd,kh,kw,c)] for a dense GEMM
+ * against weights laid out [Cout][KD][KH][KW][Cin]; srl_col2im_ndhwc: its adjoint (sums the taps that reach a voxel,
+ * optionally times act'(y), y = the forward activation of that voxel, dact as above). */
+int srl_pad_ndhwc(void* stream, const float* x, int64_t n, int D, int H, int W, int C, int pd, int ph, int pw, float* y);
+int srl_crop_ndhwc(void* stream, const float* yp, int64_t n, int D, int H, int W, int C, int pd, int ph, int pw, float* x);
+int srl_maxpool_ndhwc_fwd(void* stream, const float* x, int64_t n, int D, int H, int W, int C, int wd, int wh, int ww, float* y);
+int srl_maxpool_ndhwc_bwd(void* stream, const float* dy, const float* x, int64_t n, int D, int H, int W, int C, int wd, int wh,
+                          int ww, int dact, float* dx);
+int srl_im2col_ndhwc(void* stream, const float* x, int64_t n, int D, int H, int W, int C, int KD, int KH, int KW, int stride,
+                     float* P);
+int srl_col2im_ndhwc(void* stream, const float* dP, int64_t n, int D, int H, int W, int C, int KD, int KH, int KW, int stride,
+                     const float* y, int dact, float* dX);
 
 /* torch.optim.SGD / torch.optim.RMSprop on the flat buffer (modules/utils.py:268-286 accepts 'sgd' and 'rmsprop'
  * with their torch keyword configurations), same clip / grad_scale / grad_norm_out conventions as srl_adam_step.

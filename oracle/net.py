@@ -100,7 +100,9 @@ class OracleActorCritic:
                 x = act(F.linear(x, self._p(f"{base}.1.0.weight"), self._p(f"{base}.1.0.bias")))
                 x = F.layer_norm(x, (self.hidden,), self._p(f"{base}.1.2.weight"), self._p(f"{base}.1.2.bias"), 1e-5)
             else:
-                assert len(shape) == 3, "oracle restates Conv2d encoders only"
+                assert len(shape) in (2, 3, 4), "Conv1d / Conv2d / Conv3d by the observation's rank (cnn.py:60-71)"
+                conv = {2: F.conv1d, 3: F.conv2d, 4: F.conv3d}[len(shape)]
+                max_pool = {2: F.max_pool1d, 3: F.max_pool2d, 4: F.max_pool3d}[len(shape)]
                 T, B = x.shape[:2]
                 x = x.flatten(0, 1)  # cnn.py:131
                 cb = f"{base}.1._Convolution__model"
@@ -109,10 +111,9 @@ class OracleActorCritic:
                 idx = 0  # index in the reference's nn.Sequential: [MaxPool2d(2)] Conv2d act ... Flatten mlp (cnn.py:99-126)
                 for i, (_, _, stride, padding, _) in enumerate(layers):
                     if pool and i != len(layers) - 1:
-                        x = F.max_pool2d(x, 2)
+                        x = max_pool(x, 2)
                         idx += 1
-                    x = act(F.conv2d(x, self._p(f"{cb}.{idx}.weight"), self._p(f"{cb}.{idx}.bias"),
-                                     stride=stride, padding=padding))
+                    x = act(conv(x, self._p(f"{cb}.{idx}.weight"), self._p(f"{cb}.{idx}.bias"), stride=stride, padding=padding))
                     idx += 2
                 x = x.flatten(1)
                 j = 0

@@ -20,6 +20,7 @@ mask never costs a separate pass.  Activations between convolutions are NHWC, so
 output ``[n*OH*OW, Cout]`` is the next layer's input without a transpose (parameter layouts are adapted
 once, at the checkpoint boundary: ``netspec.ParamInfo``).
 """
+import math
 from collections import OrderedDict
 from typing import Dict, List, NamedTuple, Optional
 
@@ -104,6 +105,9 @@ class HipNet:
                                   (L.in_hw[0] + 2 * L.pad) * (L.in_hw[1] + 2 * L.pad) * L.cin)
                     if self.force_explicit_conv:
                         per_row = max(per_row, L.out_hw[0] * L.out_hw[1] * L.cin * L.k * L.k)
+                elif isinstance(L, ns.ConvNdSpec):
+                    vin = math.prod(d + 2 * p for d, p in zip(L.in_sp, L.pads)) * L.cin
+                    per_row = max(per_row, vin, math.prod(L.out_sp) * max(L.cout, L.cin * math.prod(L.kern)))
                 elif isinstance(L, ns.LinearSpec):
                     per_row = max(per_row, L.in_features, L.out_features)
         self.encoder_rows = max(1, (1 << 31) // (4 * per_row))
@@ -395,6 +399,28 @@ class HipNet:
                 hip.maxpool2_nhwc_fwd(cur.ptr, n, h, w, L.c, y.ptr)
                 tape.append(("pool", L, cur, n, cur_act))
                 cur, cur_act = y, 0  # the activation's derivative is applied by the pooling backward at the winner
+            elif isinstance(L, ns.PoolNdSpec):
+                assert cur.ld == L.c and cur.rows == n * math.prod(L.in_sp)
+                y = self._buf(f"{tag}{L.prefix}.y", n * math.prod(L.out_sp), L.c)
+                hip.maxpool_ndhwc_fwd(cur.ptr, n, (*L.in_sp, L.c), L.win, y.ptr)
+                tape.append(("poolnd", L, cur, n, cur_act))
+                cur, cur_act = y, 0
+            elif isinstance(L, ns.ConvNdSpec):
+                sp = L.in_sp
+                assert cur.ld == L.cin and cur.rows == n * math.prod(sp)
+                if any(L.pads):
+                    sp = tuple(d + 2 * p for d, p in zip(sp, L.pads))
+                    xp = self._buf(f"{tag}{L.prefix}.xp", n * math.prod(sp), L.cin)
+                    hip.pad_ndhwc(cur.ptr, n, (*L.in_sp, L.cin), L.pads, xp.ptr)
+                    cur = xp
+                m, kdim = n * math.prod(L.out_sp), L.cin * math.prod(L.kern)
+                P = self._buf(f"{tag}{L.prefix}.P", m, kdim)
+                hip.im2col_ndhwc(cur.ptr, n, (*sp, L.cin), L.kern, L.stride, P.ptr)
+                y = self._buf(f"{tag}{L.prefix}.y", m, L.cout)
+                hip.gemm(m, L.cout, kdim, P.ptr, kdim, 0, self._p(f"{L.prefix}.weight"), kdim, 0, y.ptr, y.ld,
+                         bias=self._p(f"{L.prefix}.bias"), act=L.act)
+                tape.append(("convnd", L, cur, (P, n, sp), cur_act))
+                cur, cur_act = y, L.act
             elif isinstance(L, ns.ConvSpec):
                 oh, ow = L.out_hw
                 m = n * oh * ow
@@ -478,6 +504,25 @@ class HipNet:
                 hip.obs_ln_nhwc_bwd(g.ptr, x.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), n, c, h, w,
                                     self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"))
                 g = None
+            elif kind == "poolnd":
+                n = saved
+                dx = self._buf(f"{tag}{L.prefix}.dx", n * math.prod(L.in_sp), L.c)
+                hip.maxpool_ndhwc_bwd(g.ptr, x.ptr, n, (*L.in_sp, L.c), L.win, in_act, dx.ptr)
+                g = dx
+            elif kind == "convnd":
+                P, n, sp = saved
+                m, kdim = g.rows, L.cin * math.prod(L.kern)
+                assert g.ld == L.cout and m == n * math.prod(L.out_sp)
+                self._wgrad(L.cout, kdim, m, g, P.ptr, kdim, self._g(f"{L.prefix}.weight"))
+                hip.colsum(g.ptr, g.ld, m, L.cout, self._g(f"{L.prefix}.bias"), accumulate=True)
+                hip.gemm(m, kdim, L.cout, g.ptr, g.ld, 0, self._p(f"{L.prefix}.weight"), kdim, 1, P.ptr, kdim)  # dP over P
+                dx = self._buf(f"{tag}{L.prefix}.dx", n * math.prod(sp), L.cin)
+                hip.col2im_ndhwc(P.ptr, n, (*sp, L.cin), L.kern, L.stride, x.ptr if in_act else None, in_act, dx.ptr)
+                if any(L.pads):
+                    dxc = self._buf(f"{tag}{L.prefix}.dxc", n * math.prod(L.in_sp), L.cin)
+                    hip.crop_ndhwc(dx.ptr, n, (*L.in_sp, L.cin), L.pads, dxc.ptr)
+                    dx = dxc
+                g = dx
             elif kind == "pool":
                 n = saved
                 (h, w), (ph, pw) = L.in_hw, L.out_hw
@@ -550,7 +595,7 @@ class HipNet:
         return out
 
     def _notify_ready(self, kind, L, saved):
-        if self.grad_ready_hook is None or kind == "pool":
+        if self.grad_ready_hook is None or kind in ("pool", "poolnd"):
             return
         done = [L.prefix]
         if kind == "conv" and L.first and saved[1] is not None:
@@ -566,7 +611,7 @@ class HipNet:
             return L.out_features
         if kind == "gru":
             return L.hidden
-        if kind == "pool":
+        if kind in ("pool", "poolnd"):
             return L.c
         if kind == "obsln":
             return L.shape[0]

@@ -46,8 +46,8 @@ class ParamInfo:
 
     def to_internal(self, t: torch.Tensor) -> torch.Tensor:
         t = t.detach().to(torch.float32).reshape(self.ref_shape)
-        if self.layout == "conv_nhwc":
-            t = t.permute(0, 2, 3, 1)
+        if self.layout == "conv_nhwc":  # [Cout, Cin, *kernel] -> [Cout, *kernel, Cin] (any number of spatial dimensions)
+            t = t.permute(0, *range(2, t.dim()), 1)
         elif self.layout == "fc_from_chw":
             c, h, w = self.chw
             t = t.reshape(self.ref_shape[0], c, h, w).permute(0, 2, 3, 1)
@@ -63,8 +63,9 @@ class ParamInfo:
 
     def to_reference(self, flat: torch.Tensor) -> torch.Tensor:
         if self.layout == "conv_nhwc":
-            co, ci, kh, kw = self.ref_shape
-            return flat.reshape(co, kh, kw, ci).permute(0, 3, 1, 2).contiguous()
+            co, ci, *kern = self.ref_shape
+            nd = len(kern)
+            return flat.reshape(co, *kern, ci).permute(0, nd + 1, *range(1, nd + 1)).contiguous()
         if self.layout == "fc_from_chw":
             c, h, w = self.chw
             return flat.reshape(self.ref_shape[0], h, w, c).permute(0, 3, 1, 2).reshape(self.ref_shape).contiguous()
@@ -136,6 +137,32 @@ class PoolSpec:
     c: int
     in_hw: Tuple[int, int]
     out_hw: Tuple[int, int]
+
+
+@dataclasses.dataclass
+class ConvNdSpec:
+    """nn.Conv1d / nn.Conv3d of an observation with one or three spatial dimensions (modules/cnn.py:60-71), on a
+    channels-last volume [n, D, H, W, C] (Conv1d: D = H = 1; the tuples below are padded with leading 1s / 0s to three
+    entries).  Explicit patch matrix + dense GEMM."""
+    prefix: str
+    cin: int
+    cout: int
+    kern: Tuple[int, int, int]
+    stride: int
+    pads: Tuple[int, int, int]
+    in_sp: Tuple[int, int, int]  # unpadded input volume
+    out_sp: Tuple[int, int, int]
+    act: int
+
+
+@dataclasses.dataclass
+class PoolNdSpec:
+    """nn.MaxPool1d(2) / nn.MaxPool3d(2) between those convolutions."""
+    prefix: str
+    c: int
+    in_sp: Tuple[int, int, int]
+    out_sp: Tuple[int, int, int]
+    win: Tuple[int, int, int]
 
 
 @dataclasses.dataclass
@@ -235,9 +262,9 @@ class _Builder:
         self._add(f"{prefix}.weight", (fout, fin), w, layout, chw, ref_name=ref_names[0])
         self._add(f"{prefix}.bias", (fout,), b, ref_name=ref_names[1])
 
-    def conv(self, prefix, cin, cout, k, layout, s2d=0):
-        w, b = self._default_wb((cout, cin, k, k))
-        self._add(f"{prefix}.weight", (cout, cin, k, k), w, layout, s2d=s2d)
+    def conv(self, prefix, cin, cout, k, layout, s2d=0, nd=2):
+        w, b = self._default_wb((cout, cin) + (k,) * nd)
+        self._add(f"{prefix}.weight", (cout, cin) + (k,) * nd, w, layout, s2d=s2d)
         self._add(f"{prefix}.bias", (cout,), b)
 
     def uniform(self, name, shape, bound):
@@ -270,9 +297,13 @@ def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, a
             encs.append(EncoderSpec(key, shape, layers, hidden))
             continue
         shape = tuple(shape)
+        if len(shape) in (2, 4):
+            encs.append(_build_nd_encoder(b, key, base, shape, hidden, act, act_name, cnn_layers.get(key),
+                                          bool((use_maxpool or {}).get(key, False))))
+            continue
         if len(shape) != 3:
-            raise NotImplementedError(f"observation `{key}` of shape {shape}: only vectors and (C,H,W) images "
-                                      "are implemented on the HIP path (Conv1d/Conv3d encoders are not)")
+            raise NotImplementedError(f"observation `{key}` of shape {shape}: vectors and observations with one to three "
+                                      "spatial dimensions (C, ...) are implemented")
         cb = f"{base}.1._Convolution__model"
         c, h, w = shape
         cfg = cnn_layers.get(key)
@@ -329,6 +360,60 @@ def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, a
             layers.append(LayerNormSpec(f"{fb}.{3 * j + 2}", sizes[j + 1]))
         encs.append(EncoderSpec(key, shape, layers, hidden))
     return encs
+
+
+def _build_nd_encoder(b: _Builder, key: str, base: str, shape, hidden: int, act: int, act_name: str, cfg, pool: bool):
+    """Convolution encoder of a (C, L) or (C, D, H, W) observation: same module sequence as the image encoder
+    (modules/cnn.py:93-135) with nn.Conv1d / nn.Conv3d and MaxPool1d / MaxPool3d."""
+    nd = len(shape) - 1
+    c = shape[0]
+    sp = (1,) * (3 - nd) + tuple(shape[1:])
+    lead = 3 - nd
+    cb = f"{base}.1._Convolution__model"
+    if cfg is None:  # modules/cnn.py:96-98 default stack
+        cfg = [(c, 5, 1, 0, "zeros"), (c * 2, 3, 1, 0, "zeros"), (c, 3, 1, 0, "zeros")]
+    b.layernorm(f"{base}.0", shape)
+    layers = [ObsLayerNormSpec(f"{base}.0", (c, 1, int(math.prod(sp))), explicit=True)]
+    gain = torch.nn.init.calculate_gain(act_name)
+    idx = 0
+    for i, (cout, k, stride, padding, padding_mode) in enumerate(cfg):
+        if padding != 0 and padding_mode != "zeros":
+            raise NotImplementedError(f"padding_mode `{padding_mode}`: only zero padding is implemented on the HIP path")
+        if isinstance(padding, (tuple, list, str)):
+            raise NotImplementedError("per-axis / named padding is not implemented on the HIP path")
+        if pool and i != len(cfg) - 1:
+            win = (1,) * lead + (2,) * nd
+            out = tuple(d // w for d, w in zip(sp, win))
+            if min(out) <= 0:
+                raise ValueError(f"CNN Dimension error, got {out[lead:]} after max-pooling")
+            layers.append(PoolNdSpec(f"{cb}.{idx}", c, sp, out, win))
+            sp = out
+            idx += 1
+        kern = (1,) * lead + (k,) * nd
+        pads = (0,) * lead + (int(padding),) * nd
+        out = tuple(_conv_out(d + 2 * p, kk, stride) if j >= lead else 1 for j, (d, p, kk) in enumerate(zip(sp, pads, kern)))
+        if min(out) <= 0:
+            raise ValueError(f"CNN Dimension error, got {out[lead:]} after convolution")
+        name = f"{cb}.{idx}"
+        idx += 2
+        b.conv(name, c, cout, k, "conv_nhwc", nd=nd)
+        b.orthogonal(f"{name}.weight", gain)
+        b.zero(f"{name}.bias")
+        layers.append(ConvNdSpec(name, c, cout, kern, stride, pads, sp, out, act))
+        c, sp = cout, out
+    vox = int(math.prod(sp))
+    sizes = [c * vox]
+    while sizes[-1] > hidden * 8:
+        sizes.append(sizes[-1] // 2)
+    sizes.append(hidden)
+    fb = f"{cb}.{idx + 1}"
+    for j in range(len(sizes) - 1):
+        first_fc = j == 0
+        b.linear(f"{fb}.{3 * j}", sizes[j], sizes[j + 1], "fc_from_chw" if first_fc else "plain", (c, 1, vox) if first_fc else None)
+        b.layernorm(f"{fb}.{3 * j + 2}", sizes[j + 1])
+        layers.append(LinearSpec(f"{fb}.{3 * j}", sizes[j], sizes[j + 1], 1))
+        layers.append(LayerNormSpec(f"{fb}.{3 * j + 2}", sizes[j + 1]))
+    return EncoderSpec(key, tuple(shape), layers, hidden)
 
 
 def _build_backbone(b: _Builder, root: str, in_dim: int, hidden: int, dense_layers: int, act: int, layernorm: bool,

@@ -115,6 +115,139 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* dy, cons
   }
 }
 
+// ---- the same pieces for any number of spatial dimensions: channels-last volumes [n, D, H, W, C] ---------------------
+// Conv1d (D = H = 1) and Conv3d encoders (modules/cnn.py:60-71 picks nn.Conv1d / Conv2d / Conv3d and the matching MaxPool
+// by the observation's rank).  Explicit patch matrix + the dense GEMM: built for parity (modules_test.py:385-401 is the
+// only user in the reference), not for speed.
+struct Vol {
+  int D, H, W, C;
+};
+
+// zero border of (pd, ph, pw) voxels on both sides of each axis; crop = its adjoint
+__global__ __launch_bounds__(256) void pad_nd_kernel(const float* x, long n, Vol v, int pd, int ph, int pw, float* y) {
+  const int Dp = v.D + 2 * pd, Hp = v.H + 2 * ph, Wp = v.W + 2 * pw;
+  const long total = n * Dp * Hp * Wp * v.C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % v.C);
+    long t = e / v.C;
+    const int w = (int)(t % Wp) - pw; t /= Wp;
+    const int h = (int)(t % Hp) - ph; t /= Hp;
+    const int d = (int)(t % Dp) - pd;
+    const long s = t / Dp;
+    const bool in = d >= 0 && d < v.D && h >= 0 && h < v.H && w >= 0 && w < v.W;
+    y[e] = in ? x[(((s * v.D + d) * v.H + h) * v.W + w) * v.C + c] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void crop_nd_kernel(const float* yp, long n, Vol v, int pd, int ph, int pw, float* x) {
+  const int Hp = v.H + 2 * ph, Wp = v.W + 2 * pw, Dp = v.D + 2 * pd;
+  const long total = n * v.D * v.H * v.W * v.C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % v.C);
+    long t = e / v.C;
+    const int w = (int)(t % v.W); t /= v.W;
+    const int h = (int)(t % v.H); t /= v.H;
+    const int d = (int)(t % v.D);
+    const long s = t / v.D;
+    x[e] = yp[(((s * Dp + d + pd) * Hp + h + ph) * Wp + w + pw) * v.C + c];
+  }
+}
+
+// max over windows of (wd, wh, ww) voxels (each 1 or 2), stride = window, floor
+__global__ __launch_bounds__(256) void maxpool_nd_fwd_kernel(const float* x, long n, Vol v, int wd, int wh, int ww, float* y) {
+  const int OD = v.D / wd, OH = v.H / wh, OW = v.W / ww;
+  const long total = n * OD * OH * OW * v.C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % v.C);
+    long t = e / v.C;
+    const int b = (int)(t % OW); t /= OW;
+    const int a = (int)(t % OH); t /= OH;
+    const int z = (int)(t % OD);
+    const long s = t / OD;
+    float m = -INFINITY;
+    for (int i = 0; i < wd; ++i)
+      for (int j = 0; j < wh; ++j)
+        for (int k = 0; k < ww; ++k)
+          m = fmaxf(m, x[(((s * v.D + z * wd + i) * v.H + a * wh + j) * v.W + b * ww + k) * v.C + c]);
+    y[e] = m;
+  }
+}
+// gradient to the first maximum of each window in (d, h, w) scan order, times act'(x); voxels no window covers get 0
+__global__ __launch_bounds__(256) void maxpool_nd_bwd_kernel(const float* dy, const float* x, long n, Vol v, int wd, int wh, int ww,
+                                                             int dact, float* dx) {
+  const int OD = v.D / wd, OH = v.H / wh, OW = v.W / ww;
+  const long total = n * v.D * v.H * v.W * v.C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % v.C);
+    long t = e / v.C;
+    const int w = (int)(t % v.W); t /= v.W;
+    const int h = (int)(t % v.H); t /= v.H;
+    const int d = (int)(t % v.D);
+    const long s = t / v.D;
+    const int z = d / wd, a = h / wh, b = w / ww;
+    float g = 0.f;
+    if (z < OD && a < OH && b < OW) {
+      float m = -INFINITY;
+      int arg = -1, idx = 0;
+      for (int i = 0; i < wd; ++i)
+        for (int j = 0; j < wh; ++j)
+          for (int k = 0; k < ww; ++k, ++idx) {
+            const float val = x[(((s * v.D + z * wd + i) * v.H + a * wh + j) * v.W + b * ww + k) * v.C + c];
+            if (arg < 0 || val > m) { m = val; arg = idx; }
+          }
+      const int mine = ((d - z * wd) * wh + (h - a * wh)) * ww + (w - b * ww);
+      if (arg == mine) g = dy[(((s * OD + z) * OH + a) * OW + b) * v.C + c];
+    }
+    dx[e] = g * act_grad_from_output(x[e], dact);
+  }
+}
+
+// P[(s, od, oh, ow)][(kd, kh, kw, c)] = x[s, od S + kd, oh S + kh, ow S + kw, c]
+__global__ __launch_bounds__(256) void im2col_nd_kernel(const float* x, long n, Vol v, int KD, int KH, int KW, int S, int OD, int OH,
+                                                        int OW, float* P) {
+  const long Kp = (long)KD * KH * KW * v.C, total = n * OD * OH * OW * Kp;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    long k = e % Kp, m = e / Kp;
+    const int c = (int)(k % v.C); k /= v.C;
+    const int kw = (int)(k % KW); k /= KW;
+    const int kh = (int)(k % KH);
+    const int kd = (int)(k / KH);
+    const int ow = (int)(m % OW); m /= OW;
+    const int oh = (int)(m % OH); m /= OH;
+    const int od = (int)(m % OD);
+    const long s = m / OD;
+    P[e] = x[(((s * v.D + od * S + kd) * v.H + oh * S + kh) * v.W + ow * S + kw) * v.C + c];
+  }
+}
+// dX[s, d, h, w, c] = sum over the taps that reach the voxel of dP[(s, od, oh, ow)][(kd, kh, kw, c)]   (* act'(y))
+__global__ __launch_bounds__(256) void col2im_nd_kernel(const float* dP, long n, Vol v, int KD, int KH, int KW, int S, int OD,
+                                                        int OH, int OW, const float* y, int dact, float* dX) {
+  const long Kp = (long)KD * KH * KW * v.C, total = n * v.D * v.H * v.W * v.C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % v.C);
+    long t = e / v.C;
+    const int w = (int)(t % v.W); t /= v.W;
+    const int h = (int)(t % v.H); t /= v.H;
+    const int d = (int)(t % v.D);
+    const long s = t / v.D;
+    float acc = 0.f;
+    for (int kd = d % S; kd < KD && kd <= d; kd += S) {
+      const int od = (d - kd) / S;
+      if (od >= OD) continue;
+      for (int kh = h % S; kh < KH && kh <= h; kh += S) {
+        const int oh = (h - kh) / S;
+        if (oh >= OH) continue;
+        for (int kw = w % S; kw < KW && kw <= w; kw += S) {
+          const int ow = (w - kw) / S;
+          if (ow >= OW) continue;
+          acc += dP[(((s * OD + od) * OH + oh) * OW + ow) * Kp + ((long)(kd * KH + kh) * KW + kw) * v.C + c];
+        }
+      }
+    }
+    if (y && dact) acc *= act_grad_from_output(y[e], dact);
+    dX[e] = acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int srl_obs_ln_nhwc(void* stream, const void* obs, int is_u8, const float* mean, const float* rstd,
@@ -171,6 +304,76 @@ extern "C" int srl_maxpool2_nhwc_bwd(void* stream, const float* dy, const float*
   if (n == 0) return 0;
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, x, (long)n, H, W, C,
                      dact, dx);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+static bool vol_ok(int D, int H, int W, int C) { return D >= 1 && H >= 1 && W >= 1 && C >= 1; }
+
+extern "C" int srl_pad_ndhwc(void* stream, const float* x, int64_t n, int D, int H, int W, int C, int pd, int ph, int pw, float* y) {
+  SRL_CHECK_ARG(x && y && vol_ok(D, H, W, C) && pd >= 0 && ph >= 0 && pw >= 0, "null tensor / bad shape");
+  if (n == 0) return 0;
+  const long total = n * (D + 2 * pd) * (H + 2 * ph) * (W + 2 * pw) * C;
+  hipLaunchKernelGGL(pad_nd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (long)n, Vol{D, H, W, C}, pd, ph, pw, y);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_crop_ndhwc(void* stream, const float* yp, int64_t n, int D, int H, int W, int C, int pd, int ph, int pw, float* x) {
+  SRL_CHECK_ARG(x && yp && vol_ok(D, H, W, C) && pd >= 0 && ph >= 0 && pw >= 0, "null tensor / bad shape");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(crop_nd_kernel, dim3(grid_for(n * D * H * W * C)), dim3(256), 0, (hipStream_t)stream, yp, (long)n, Vol{D, H, W, C}, pd, ph, pw, x);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+static bool win_ok(int D, int H, int W, int wd, int wh, int ww) {
+  return (wd == 1 || wd == 2) && (wh == 1 || wh == 2) && (ww == 1 || ww == 2) && D >= wd && H >= wh && W >= ww;
+}
+
+extern "C" int srl_maxpool_ndhwc_fwd(void* stream, const float* x, int64_t n, int D, int H, int W, int C, int wd, int wh, int ww,
+                                     float* y) {
+  SRL_CHECK_ARG(x && y && vol_ok(D, H, W, C) && win_ok(D, H, W, wd, wh, ww), "null tensor / volume smaller than the window");
+  if (n == 0) return 0;
+  const long total = n * (D / wd) * (H / wh) * (W / ww) * C;
+  hipLaunchKernelGGL(maxpool_nd_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (long)n, Vol{D, H, W, C}, wd, wh, ww, y);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_maxpool_ndhwc_bwd(void* stream, const float* dy, const float* x, int64_t n, int D, int H, int W, int C, int wd,
+                                     int wh, int ww, int dact, float* dx) {
+  SRL_CHECK_ARG(dy && x && dx && vol_ok(D, H, W, C) && win_ok(D, H, W, wd, wh, ww) && dact >= 0 && dact <= 2, "null tensor / bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(maxpool_nd_bwd_kernel, dim3(grid_for(n * D * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, x, (long)n,
+                     Vol{D, H, W, C}, wd, wh, ww, dact, dx);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+static int out_dim(int d, int k, int s) { return (d - k) / s + 1; }
+
+extern "C" int srl_im2col_ndhwc(void* stream, const float* x, int64_t n, int D, int H, int W, int C, int KD, int KH, int KW, int stride,
+                                float* P) {
+  SRL_CHECK_ARG(x && P && vol_ok(D, H, W, C) && KD >= 1 && KH >= 1 && KW >= 1 && KD <= D && KH <= H && KW <= W && stride >= 1,
+                "null tensor / invalid geometry");
+  if (n == 0) return 0;
+  const int OD = out_dim(D, KD, stride), OH = out_dim(H, KH, stride), OW = out_dim(W, KW, stride);
+  const long total = n * OD * OH * OW * (long)KD * KH * KW * C;
+  hipLaunchKernelGGL(im2col_nd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (long)n, Vol{D, H, W, C}, KD, KH, KW,
+                     stride, OD, OH, OW, P);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_col2im_ndhwc(void* stream, const float* dP, int64_t n, int D, int H, int W, int C, int KD, int KH, int KW, int stride,
+                                const float* y, int dact, float* dX) {
+  SRL_CHECK_ARG(dP && dX && vol_ok(D, H, W, C) && KD >= 1 && KH >= 1 && KW >= 1 && KD <= D && KH <= H && KW <= W && stride >= 1 &&
+                    dact >= 0 && dact <= 2, "null tensor / invalid geometry");
+  if (n == 0) return 0;
+  const int OD = out_dim(D, KD, stride), OH = out_dim(H, KH, stride), OW = out_dim(W, KW, stride);
+  hipLaunchKernelGGL(col2im_nd_kernel, dim3(grid_for(n * D * H * W * C)), dim3(256), 0, (hipStream_t)stream, dP, (long)n, Vol{D, H, W, C},
+                     KD, KH, KW, stride, OD, OH, OW, y, dact, dX);
   SRL_LAUNCH_CHECK();
   return 0;
 }

@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("SRL_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsrlhip.so")
 _lib = None
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -125,6 +125,12 @@ _SIGNATURES = {
     "srl_crop_nhwc": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "srl_maxpool2_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "srl_maxpool2_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "srl_pad_ndhwc": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 7 + [c_void_p]),
+    "srl_crop_ndhwc": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 7 + [c_void_p]),
+    "srl_maxpool_ndhwc_fwd": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 7 + [c_void_p]),
+    "srl_maxpool_ndhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_int] * 8 + [c_void_p]),
+    "srl_im2col_ndhwc": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 8 + [c_void_p]),
+    "srl_col2im_ndhwc": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 8 + [c_void_p, c_int, c_void_p]),
     "srl_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int, c_int,
                               c_float, c_float, c_void_p, c_void_p]),
     "srl_rmsprop_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
@@ -530,6 +536,31 @@ def maxpool2_nhwc_fwd(x_ptr, n, H, W, C, y_ptr):
 
 def maxpool2_nhwc_bwd(dy_ptr, x_ptr, n, H, W, C, dact, dx_ptr):
     _check(lib().srl_maxpool2_nhwc_bwd(_stream(), dy_ptr, x_ptr, n, H, W, C, int(dact), dx_ptr), "srl_maxpool2_nhwc_bwd")
+
+
+def pad_ndhwc(x_ptr, n, vol, pads, y_ptr):
+    """vol = (D, H, W, C), pads = (pd, ph, pw)."""
+    _check(lib().srl_pad_ndhwc(_stream(), x_ptr, n, *vol, *pads, y_ptr), "srl_pad_ndhwc")
+
+
+def crop_ndhwc(yp_ptr, n, vol, pads, x_ptr):
+    _check(lib().srl_crop_ndhwc(_stream(), yp_ptr, n, *vol, *pads, x_ptr), "srl_crop_ndhwc")
+
+
+def maxpool_ndhwc_fwd(x_ptr, n, vol, win, y_ptr):
+    _check(lib().srl_maxpool_ndhwc_fwd(_stream(), x_ptr, n, *vol, *win, y_ptr), "srl_maxpool_ndhwc_fwd")
+
+
+def maxpool_ndhwc_bwd(dy_ptr, x_ptr, n, vol, win, dact, dx_ptr):
+    _check(lib().srl_maxpool_ndhwc_bwd(_stream(), dy_ptr, x_ptr, n, *vol, *win, int(dact), dx_ptr), "srl_maxpool_ndhwc_bwd")
+
+
+def im2col_ndhwc(x_ptr, n, vol, kern, stride, P_ptr):
+    _check(lib().srl_im2col_ndhwc(_stream(), x_ptr, n, *vol, *kern, stride, P_ptr), "srl_im2col_ndhwc")
+
+
+def col2im_ndhwc(dP_ptr, n, vol, kern, stride, y_ptr, dact, dX_ptr):
+    _check(lib().srl_col2im_ndhwc(_stream(), dP_ptr, n, *vol, *kern, stride, y_ptr, int(dact), dX_ptr), "srl_col2im_ndhwc")
 
 
 def sgd_step(p, g, buf, lr, momentum, dampening, weight_decay, nesterov, first_step, grad_scale=1.0, max_norm=-1.0,

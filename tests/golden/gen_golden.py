@@ -394,6 +394,28 @@ def gen_cnn_padpool():
     save("steps_cnn_padpool.npz", **out)
 
 
+ND1_POLICY = dict(obs_dim={"seq": (3, 59)}, action_dim=4, hidden_dim=16, num_dense_layers=1, num_rnn_layers=0, popart=False,
+                  layernorm=True, shared_backbone=True, chunk_len=4, seed=73, use_maxpool=dict(seq=True),
+                  cnn_layers=dict(seq=[(4, 3, 1, 0, 'zeros'), (8, 3, 2, 1, 'zeros'), (4, 3, 1, 0, 'zeros')]))
+ND3_POLICY = dict(obs_dim={"vol": (2, 9, 8, 7), "vec": 3}, action_dim=[2, 3], hidden_dim=16, num_dense_layers=1,
+                  num_rnn_layers=0, popart=False, layernorm=False, shared_backbone=False, chunk_len=4, seed=74,
+                  activation="tanh", use_maxpool=dict(vol=True),
+                  cnn_layers=dict(vol=[(4, 3, 1, 1, 'zeros'), (4, 2, 1, 0, 'zeros')]))
+
+
+def gen_cnn_nd():
+    """Convolution encoders of observations with one and three spatial dimensions (modules/cnn.py:60-71: nn.Conv1d / nn.Conv3d
+    with MaxPool1d / MaxPool3d; the shapes of modules_test.py:385-401 scaled down): pooling, stride, padding, uint8 and
+    float32 observations, a vector key beside the volume."""
+    out = {}
+    run_steps("cnn1d", ND1_POLICY, dict(popart=False, ppo_epochs=2, optimizer_config=dict(lr=1e-3), max_grad_norm=10.0),
+              dict(T=6, B=4, obs_spec={"seq": ((3, 59), "f32")}, action_dims=4, p_done=0.1), 2, out=out)
+    run_steps("cnn3d", ND3_POLICY, dict(popart=False, optimizer_config=dict(lr=1e-3)),
+              dict(T=5, B=3, obs_spec={"vol": ((2, 9, 8, 7), "u8"), "vec": ((3,), "f32")}, action_dims=[2, 3], p_done=0.1), 2,
+              out=out)
+    save("steps_cnn_nd.npz", **out)
+
+
 def gen_vtrace_rnn():
     """V-trace with recurrent policies (mappo.py:243-246: the analysed rows give both the importance ratio of the trace
     and the loss): GRU shared backbone, and LSTM separate backbones with PopArt and two epochs."""

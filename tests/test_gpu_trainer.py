@@ -149,6 +149,21 @@ CASES.update({
                 dict(T=5, B=3, obs_spec={"img": ((3, 23, 19), "f32"), "vec": ((5,), "f32")}, action_dims=[3, 2], p_done=0.1),
                 2, "steps_cnn_padpool.npz"),
 })
+# observations with one / three spatial dimensions: nn.Conv1d / nn.Conv3d encoders (gen_golden.py gen_cnn_nd)
+ND1_POLICY = dict(obs_dim={"seq": (3, 59)}, action_dim=4, hidden_dim=16, num_dense_layers=1, num_rnn_layers=0, popart=False,
+                  layernorm=True, shared_backbone=True, chunk_len=4, seed=73, use_maxpool=dict(seq=True),
+                  cnn_layers=dict(seq=[(4, 3, 1, 0, 'zeros'), (8, 3, 2, 1, 'zeros'), (4, 3, 1, 0, 'zeros')]))
+ND3_POLICY = dict(obs_dim={"vol": (2, 9, 8, 7), "vec": 3}, action_dim=[2, 3], hidden_dim=16, num_dense_layers=1,
+                  num_rnn_layers=0, popart=False, layernorm=False, shared_backbone=False, chunk_len=4, seed=74,
+                  activation="tanh", use_maxpool=dict(vol=True),
+                  cnn_layers=dict(vol=[(4, 3, 1, 1, 'zeros'), (4, 2, 1, 0, 'zeros')]))
+CASES.update({
+    "cnn1d": (ND1_POLICY, dict(popart=False, ppo_epochs=2, optimizer_config=dict(lr=1e-3), max_grad_norm=10.0),
+              dict(T=6, B=4, obs_spec={"seq": ((3, 59), "f32")}, action_dims=4, p_done=0.1), 2, "steps_cnn_nd.npz"),
+    "cnn3d": (ND3_POLICY, dict(popart=False, optimizer_config=dict(lr=1e-3)),
+              dict(T=5, B=3, obs_spec={"vol": ((2, 9, 8, 7), "u8"), "vec": ((3,), "f32")}, action_dims=[2, 3], p_done=0.1), 2,
+              "steps_cnn_nd.npz"),
+})
 
 
 def make_trainer(policy_args, trainer_args):

@@ -60,9 +60,34 @@ def test_product_path_fails_loudly_without_gpu():
 def test_unsupported_configs_raise():
     base = dict(obs_dim=4, action_dim=2, num_rnn_layers=0, popart=False)
     for bad in (dict(num_rnn_layers=1, rnn_type="gtrxl"), dict(continuous_action=True, std_type="state_dependent"),
-                dict(auxiliary_head=True), dict(obs_dim={"o": (3, 10)})):
+                dict(auxiliary_head=True), dict(obs_dim={"o": (3, 10, 4, 4, 4)}),
+                dict(obs_dim={"o": (3, 12, 12)}, cnn_layers=dict(o=[(4, 3, 1, 1, "reflect")]))):
         with pytest.raises((NotImplementedError, AttributeError)):
             policy_api.make(config.Policy("actor-critic", args={**base, **bad}))
+
+
+def test_conv_encoder_param_tables_by_rank(golden):
+    """Conv1d / Conv2d (padding, pooling) / Conv3d encoders: the reference's state_dict keys -- the pooling layers shift
+    the indices inside nn.Sequential (modules/cnn.py:99-126) -- shapes, and layout round trips of every parameter."""
+    for fname, tag, pargs in (("steps_cnn_nd.npz", "cnn1d", dict(obs_dim={"seq": (3, 59)}, action_dim=4, hidden_dim=16,
+                                                                  num_dense_layers=1, num_rnn_layers=0, popart=False, layernorm=True,
+                                                                  shared_backbone=True, seed=73, use_maxpool=dict(seq=True),
+                                                                  cnn_layers=dict(seq=[(4, 3, 1, 0, 'zeros'), (8, 3, 2, 1, 'zeros'),
+                                                                                       (4, 3, 1, 0, 'zeros')]))),
+                              ("steps_cnn_nd.npz", "cnn3d", dict(obs_dim={"vol": (2, 9, 8, 7), "vec": 3}, action_dim=[2, 3],
+                                                                  hidden_dim=16, num_dense_layers=1, num_rnn_layers=0, popart=False,
+                                                                  layernorm=False, shared_backbone=False, seed=74, activation="tanh",
+                                                                  use_maxpool=dict(vol=True),
+                                                                  cnn_layers=dict(vol=[(4, 3, 1, 1, 'zeros'), (4, 2, 1, 0, 'zeros')])))):
+        g = golden(fname)
+        spec, vals = ns.build_netspec(**pargs)
+        ref = {k[len(f"{tag}_init_param:"):]: g[k] for k in g.files if k.startswith(f"{tag}_init_param:")}
+        assert sorted(ref) == sorted(vals)
+        for info in spec.params.values():
+            v = vals[info.key]
+            assert tuple(v.shape) == ref[info.key].shape == info.ref_shape, info.key
+            assert np.allclose(v.numpy(), ref[info.key], rtol=1e-4, atol=1e-4), info.key
+            assert torch.equal(info.to_reference(info.to_internal(v)), v), info.key
 
 
 def test_popart_param_table_and_init(golden):
