@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--global-envs", type=int, default=GLOBAL_ENVS, help="B_global, fixed as N grows (strong scaling)")
     ap.add_argument("--rollout-len", type=int, default=128)
     ap.add_argument("--chunk-rows", type=int, default=16384)
+    ap.add_argument("--graph", type=int, default=0, help="1: capture the update into a hipGraph and replay it (one rank only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-from-host", action="store_true", help="skip the pinned-host-fed pass (`from_pinned_host`)")
@@ -257,7 +258,7 @@ def main():
         dist.all_reduce(seen)  # every rank contributes 1 through the collective backend itself
         ranks_seen = int(round(float(seen.item())))
         assert ranks_seen == args.gpus, f"collective saw {ranks_seen} ranks, --gpus {args.gpus}"
-    trainer = trainer_api.make(config.Trainer("mappo", args=dict(TRAINER, chunk_rows=args.chunk_rows)),
+    trainer = trainer_api.make(config.Trainer("mappo", args=dict(TRAINER, chunk_rows=args.chunk_rows, use_graph=bool(args.graph))),
                                config.Policy("actor-critic", args=POLICY))
     if use_dist:
         trainer.distributed(rank=rank, world_size=world, init_method="env://")
@@ -294,6 +295,7 @@ def main():
         prof = hip.KernelProfile() if rank == 0 else None
         if prof is not None:
             hip.set_profile(prof)
+        trainer.use_graph = False  # the events wrap individual launches: this step is issued launch by launch
         trainer.step(sample)
         if prof is not None:
             hip.set_profile(None)

@@ -14,7 +14,6 @@ reference's checkpoints and the golden fixtures load directly) of:
 TEST INFRASTRUCTURE ONLY (see package doc).  Parameter *initialisation* is not restated here: the
 oracle always runs on weights handed to it (from a fixture, or from the product's own initialiser).
 """
-import math
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 

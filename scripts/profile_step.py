@@ -2,7 +2,6 @@
 import os
 import sys
 
-import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -33,7 +32,6 @@ def named_gemm(M, N, K, A, lda, akm, Bp, ldb, bkm, C, ldc, **kw):
 
 
 hip.gemm = named_gemm
-import srl_amd.algorithm.hipnet as hn
 prof = hip.KernelProfile()
 hip.set_profile(prof)
 trainer.step(sample)

@@ -24,7 +24,7 @@ from srl_amd.algorithm.hipnet import HipNet, RnnCtx
 from srl_amd.algorithm.ppo_types import PPORolloutAnalyzedResult, SampleAnalyzedResult
 from srl_amd.api import policy as policy_api
 from srl_amd.api.env_utils import DiscreteAction
-from srl_amd.namedarray import NamedArray, recursive_apply
+from srl_amd.namedarray import NamedArray
 
 
 def to_device_leaf(x, device, kind: str) -> torch.Tensor:

@@ -22,7 +22,7 @@ once, at the checkpoint boundary: ``netspec.ParamInfo``).
 """
 import math
 from collections import OrderedDict
-from typing import Dict, List, NamedTuple, Optional
+from typing import Dict, NamedTuple, Optional
 
 import torch
 

@@ -23,7 +23,6 @@ uses GLOBAL statistics.
 """
 import logging
 from collections import defaultdict
-from typing import Dict, Optional
 
 import numpy as np
 import torch

@@ -19,7 +19,7 @@ bit-identical initial weights (checked against the reference in ``tests/golden/g
 import dataclasses
 import math
 from collections import OrderedDict
-from typing import Dict, List, Optional, Sequence, Tuple, Union
+from typing import Dict, List, Optional, Tuple, Union
 
 import torch
 

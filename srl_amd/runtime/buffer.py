@@ -9,7 +9,6 @@ guarantees (time-major, batch on axis 1, every leaf contiguous) is what the trai
 import bisect
 import dataclasses
 import time
-from typing import Optional
 
 import numpy as np
 
