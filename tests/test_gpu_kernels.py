@@ -797,3 +797,129 @@ def test_conv2d_obs_space_to_depth_path(n, u8, kind):
         assert e_bf16 <= max(4 * e_f32, 2e-6), (e_bf16, e_f32)  # no worse than the float32 MFMA chain, up to noise
         for a_, b_, name in zip(outs, outs3, ("dw", "db", "dgamma", "dbeta")):
             assert rel_close(a_.cpu().numpy(), b_.cpu().numpy(), 2e-5, scale=sc if name in ("dw", "db") else float(np.sqrt(n))), name
+
+
+# ------------------------------------------------------------------------------------------------ encoder pieces, any rank
+@pytest.mark.parametrize("M,N,K,akm,bkm,split", [(16384 + 64, 3136, 512, 0, 1, 1), (4096, 1100, 2048, 0, 0, 1),
+                                                 (512, 3136, 16384, 1, 1, 5), (64, 576, 40000, 1, 1, 21)])
+def test_gemm_tile_numbering_large(M, N, K, akm, bkm, split):
+    """Shapes that take the L2-aware tile numberings of the bf16x3 kernel (column groups when B exceeds the L2, k-ranges of
+    a split-K product folded into the one-dimensional grid): the numbering must not change which tile computes what."""
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    A = torch.randn((K, M) if akm else (M, K), generator=g).to(DEV)
+    B = torch.randn((K, N) if bkm else (N, K), generator=g).to(DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ws = torch.empty(split * M * N, device=DEV) if split > 1 else None
+    hip.gemm(M, N, K, A.data_ptr(), A.shape[1], akm, B.data_ptr(), B.shape[1], bkm, C.data_ptr(), N, split_k=split,
+             workspace=None if ws is None else ws.data_ptr())
+    ref = (A.double().T if akm else A.double()) @ (B.double() if bkm else B.double().T)
+    err = (C.double() - ref).abs().max().item()
+    assert err <= 1e-5 * float(np.sqrt(K)) * 4, err
+
+
+@pytest.mark.parametrize("vol,pads", [((1, 1, 37, 3), (0, 0, 2)), ((1, 9, 7, 8), (0, 1, 1)), ((5, 4, 6, 2), (1, 2, 0))])
+def test_pad_crop_ndhwc(vol, pads):
+    rng = np.random.default_rng(sum(vol))
+    n = 3
+    D, H, W, C = vol
+    x = rng.standard_normal((n, D, H, W, C)).astype(np.float32)
+    pv = tuple(d + 2 * p for d, p in zip(vol[:3], pads))
+    y = torch.full((n, *pv, C), float("nan"), device=DEV)
+    dx_ = dev(x)
+    hip.pad_ndhwc(dx_.data_ptr(), n, vol, pads, y.data_ptr())
+    ref = np.pad(x, ((0, 0), (pads[0],) * 2, (pads[1],) * 2, (pads[2],) * 2, (0, 0)))
+    assert np.array_equal(y.cpu().numpy(), ref)
+    back = torch.empty((n, D, H, W, C), device=DEV)
+    hip.crop_ndhwc(y.data_ptr(), n, vol, pads, back.data_ptr())
+    assert np.array_equal(back.cpu().numpy(), x)
+
+
+@pytest.mark.parametrize("vol,win", [((1, 1, 59, 3), (1, 1, 2)), ((1, 23, 19, 4), (1, 2, 2)), ((9, 8, 7, 2), (2, 2, 2))])
+@pytest.mark.parametrize("dact", [0, 1, 2])
+def test_maxpool_ndhwc_matches_torch(vol, win, dact):
+    """MaxPool{1,2,3}d(2) and its backward (first maximum of a window, torch's rule) times the activation derivative; ties
+    are made frequent by quantising the input."""
+    rng = np.random.default_rng(sum(vol) + dact)
+    n = 4
+    D, H, W, C = vol
+    x = np.round(rng.standard_normal((n, D, H, W, C)) * 2).astype(np.float32) / 2
+    if dact == 1:
+        x = np.maximum(x, 0)
+    elif dact == 2:
+        x = np.tanh(x).astype(np.float32)
+    nd = sum(w == 2 for w in win)
+    xt = torch.from_numpy(x).permute(0, 4, 1, 2, 3).double().requires_grad_(True)  # [n, C, D, H, W]
+    pool = {1: torch.nn.functional.max_pool1d, 2: torch.nn.functional.max_pool2d, 3: torch.nn.functional.max_pool3d}[nd]
+    yt = pool(xt.reshape(n, C, *vol[3 - nd:3]), 2)
+    out_sp = tuple(d // w for d, w in zip(vol[:3], win))
+    y = torch.full((n, *out_sp, C), float("nan"), device=DEV)
+    dx_ = dev(x)
+    hip.maxpool_ndhwc_fwd(dx_.data_ptr(), n, vol, win, y.data_ptr())
+    yref = yt.reshape(n, C, *out_sp).permute(0, 2, 3, 4, 1).detach().numpy()
+    assert np.array_equal(y.cpu().numpy(), yref.astype(np.float32))
+    dy = rng.standard_normal((n, *out_sp, C)).astype(np.float32)
+    (yt.reshape(n, C, *out_sp) * torch.from_numpy(dy).permute(0, 4, 1, 2, 3).double()).sum().backward()
+    g = xt.grad.permute(0, 2, 3, 4, 1).numpy()
+    dref = g * {0: 1.0, 1: (x > 0), 2: 1.0 - x.astype(np.float64)**2}[dact]
+    dxo = torch.full((n, D, H, W, C), float("nan"), device=DEV)
+    ddy = dev(dy)
+    hip.maxpool_ndhwc_bwd(ddy.data_ptr(), dx_.data_ptr(), n, vol, win, dact, dxo.data_ptr())
+    assert rel_close(dxo.cpu().numpy(), dref, 1e-6, scale=1.0)
+
+
+@pytest.mark.parametrize("vol,kern,s", [((1, 1, 40, 3), (1, 1, 5), 2), ((1, 9, 9, 4), (1, 3, 3), 1), ((6, 7, 5, 2), (2, 3, 2), 1),
+                                        ((7, 7, 7, 3), (3, 3, 3), 2)])
+def test_im2col_col2im_ndhwc(vol, kern, s):
+    """The patch matrix reproduces torch's convolution of the matching rank through one GEMM, and col2im is its adjoint."""
+    rng = np.random.default_rng(sum(vol) + s)
+    n, Co = 3, 5
+    D, H, W, C = vol
+    KD, KH, KW = kern
+    x = rng.standard_normal((n, D, H, W, C)).astype(np.float32)
+    w = rng.standard_normal((Co, C, KD, KH, KW)).astype(np.float32)
+    out_sp = tuple((d - k) // s + 1 for d, k in zip(vol[:3], kern))
+    m, kdim = n * int(np.prod(out_sp)), KD * KH * KW * C
+    P = torch.full((m, kdim), float("nan"), device=DEV)
+    dx_ = dev(x)
+    hip.im2col_ndhwc(dx_.data_ptr(), n, vol, kern, s, P.data_ptr())
+    xt = torch.from_numpy(x).permute(0, 4, 1, 2, 3).double().requires_grad_(True)
+    yt = torch.nn.functional.conv3d(xt, torch.from_numpy(w).double(), stride=s)  # [n, Co, OD, OH, OW]
+    wmat = torch.from_numpy(w).permute(0, 2, 3, 4, 1).reshape(Co, kdim).double()  # [Cout][KD][KH][KW][Cin]
+    y = (P.cpu().double() @ wmat.T).reshape(n, *out_sp, Co).permute(0, 4, 1, 2, 3)
+    assert torch.allclose(y, yt.detach(), rtol=1e-6, atol=1e-6)
+    dy = rng.standard_normal(tuple(yt.shape)).astype(np.float32)
+    (yt * torch.from_numpy(dy).double()).sum().backward()
+    dP = (torch.from_numpy(dy).permute(0, 2, 3, 4, 1).reshape(m, Co).double() @ wmat).float().to(DEV)
+    ymask = rng.standard_normal((n, D, H, W, C)).astype(np.float32)
+    dym = dev(ymask)
+    dX = torch.full((n, D, H, W, C), float("nan"), device=DEV)
+    hip.col2im_ndhwc(dP.data_ptr(), n, vol, kern, s, dym.data_ptr(), 1, dX.data_ptr())
+    ref = xt.grad.permute(0, 2, 3, 4, 1).numpy() * (ymask > 0)
+    assert rel_close(dX.cpu().numpy(), ref, 2e-5, scale=1.0)
+
+
+@pytest.mark.parametrize("u8", [True, False])
+def test_obs_ln_nhwc_fwd_bwd(u8):
+    """Whole-observation LayerNorm written out channels-last (the general encoder path) against torch's layer_norm."""
+    rng = np.random.default_rng(5 + u8)
+    n, C, H, W = 6, 3, 7, 5
+    obs = rng.integers(0, 256, (n, C, H, W)).astype(np.uint8) if u8 else rng.standard_normal((n, C, H, W)).astype(np.float32)
+    gamma = rng.standard_normal((C, H, W)).astype(np.float32)
+    beta = rng.standard_normal((C, H, W)).astype(np.float32)
+    xt = torch.from_numpy(obs.astype(np.float64))
+    tg, tb = torch.from_numpy(gamma).double().requires_grad_(True), torch.from_numpy(beta).double().requires_grad_(True)
+    yt = torch.nn.functional.layer_norm(xt, (C, H, W), tg, tb, 1e-5)
+    dobs, dg, db_ = dev(obs), dev(gamma), dev(beta)
+    mean, rstd = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    hip.obs_ln_stats(dobs.data_ptr(), u8, n, C * H * W, mean.data_ptr(), rstd.data_ptr())
+    y = torch.full((n, H, W, C), float("nan"), device=DEV)
+    hip.obs_ln_nhwc(dobs.data_ptr(), u8, mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), db_.data_ptr(), n, C, H, W, y.data_ptr())
+    assert rel_close(y.cpu().numpy(), yt.permute(0, 2, 3, 1).detach().numpy(), 1e-5, scale=1.0)
+    dy = rng.standard_normal((n, H, W, C)).astype(np.float32)
+    (yt.permute(0, 2, 3, 1) * torch.from_numpy(dy).double()).sum().backward()
+    gg, gb = torch.zeros((C, H, W), device=DEV), torch.zeros((C, H, W), device=DEV)
+    ddy = dev(dy)
+    hip.obs_ln_nhwc_bwd(ddy.data_ptr(), dobs.data_ptr(), u8, mean.data_ptr(), rstd.data_ptr(), n, C, H, W, gg.data_ptr(),
+                        gb.data_ptr())
+    assert rel_close(gg.cpu().numpy(), tg.grad.numpy(), 2e-5, scale=1.0)
+    assert rel_close(gb.cpu().numpy(), tb.grad.numpy(), 2e-5, scale=1.0)
