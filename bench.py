@@ -160,6 +160,31 @@ def _cpu_steps(T, B, threads, budget_s, max_steps):
     return times
 
 
+def rollout_rate(policy, device, n=4096, reps=8):
+    """SURVEY 8d's secondary metric: rollout-inference requests/s (a10 `rollout`, reference
+    `actor_critic_policy.py:458-528`).  One request = one (4,84,84) uint8 observation in, (sampled action, log-prob, value)
+    out, host numpy on both sides as the policy worker sees them: the H2D of the observations and the D2H of the results
+    are inside the timed region.  Uses the trainer's policy (its current parameters)."""
+    import numpy as np
+    from srl_amd.api import policy as policy_api
+    from srl_amd.namedarray import NamedArray
+    rng = np.random.default_rng(0)
+    obs = torch.from_numpy(rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)).pin_memory().numpy()
+    req = policy_api.RolloutRequest(obs=NamedArray(obs=obs), is_evaluation=np.zeros((n, 1), np.uint8),
+                                    on_reset=np.zeros((n, 1), np.uint8), client_id=np.zeros((n, 1), np.int32),
+                                    request_id=np.arange(n).reshape(n, 1), received_time=np.zeros((n, 1), np.int64),
+                                    buffer_index=np.zeros((n, 1), np.int32))
+    for _ in range(3):
+        policy.rollout(req)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        policy.rollout(req)  # returns numpy: synchronises
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=n / dt, unit="requests/s", requests_per_call=n, ms_per_call=dt * 1e3,
+                note="policy.rollout on pinned host observations (uint8 frames), sampled actions; H2D and D2H inside")
+
+
 def cpu_baseline(T):
     """The oracle's restatement of the same trainer step (torch-CPU, op for op with the reference: float32-widened
     frames, float64 GAE loop, autograd loss, torch.optim.Adam) on a bounded sample of the same workload, on all
@@ -271,15 +296,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step_marks = []  # HIP events between the timed steps of the last `timed` call (no synchronisation inside the region)
+
     def timed(fn, warmup, steps):
         for _ in range(warmup):
             fn()
         sync()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
+            marks[i].record()
             r = fn()
+        marks[steps].record()
         sync()
         el = time.perf_counter() - t0
+        step_marks[:] = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
         if use_dist:
             t = torch.tensor([el], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -287,6 +318,7 @@ def main():
         return el, r
 
     elapsed, res = timed(lambda: trainer.step(sample), args.warmup, args.steps)
+    per_step = sorted(step_marks)  # this rank's device time per update (SURVEY 8d asks for median and min beside the mean)
 
     # ---- untimed extra step with per-kernel HIP events (same stream as the launches) -----------------------
     roofline = roofline_gae = breakdown = None
@@ -391,6 +423,8 @@ def main():
                     unit="env-steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_step,
                     higher_is_better=True, scaling="strong", vs_baseline=None,
                     dtype="f32 (contractions as exact bf16x3 piece products, float32 accumulate)", data="synthetic",
+                    ms_per_step_median=per_step[len(per_step) // 2] if per_step else None,
+                    ms_per_step_min=per_step[0] if per_step else None,
                     value_basis="sample resident in HBM when the timed region starts; see from_pinned_host for H2D inside",
                     config=dict(workload=f"BASELINE configs[2]: Atari-shaped PPO+GAE, {B * world} envs x {T} steps per update "
                                          f"(global batch fixed; {B} env columns per GPU x {world} GPUs data-parallel), "
@@ -405,6 +439,8 @@ def main():
         if pcie is not None:
             pcie["bound"] = ("pcie" if pcie["h2d_alone_ms"] and pcie["h2d_alone_ms"] > ms_step else "mfma")
             line["from_pinned_host"] = pcie
+        if world == 1 and not args.no_from_host:
+            line["rollout_inference"] = rollout_rate(trainer.policy, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T)
         print(json.dumps(line), flush=True)
