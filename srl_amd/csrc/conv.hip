@@ -291,6 +291,20 @@ extern "C" int srl_conv2d_supported(const srl_conv_desc* d, int first_layer) {
   return (d->Cin % 4 == 0 && d->Cout % 4 == 0) ? 1 : 0;
 }
 
+// Order of the 16-deep k-steps of a forward convolution (k = (kh, kw, c), c fastest).  Every tile re-reads its input
+// patch region once per tap that reaches a pixel, and with ~100 tiles in flight per XCD the regions of all of them (10 MB
+// for conv2 of the Atari stack) do not stay in the 4 MB L2 between two taps in ascending order.  Taps that read the SAME
+// pixels are therefore made neighbours: for stride S the taps of one parity class (kh % S, kw % S) read one pixel class, so
+// the classes are visited one after the other, the taps of a class back to back; inside, the two 16-channel blocks that
+// share a 128-byte line stay adjacent, and for more than 32 channels the line index is the outermost key (each phase then
+// touches 1 / lines-per-pixel of the region).  SRL_KPERM=0: ascending order (A/B switch).
+static void fwd_kstep_order(const srl_conv_desc* d, GemmArgs* g) {
+  static const bool on = [] { const char* e = getenv("SRL_KPERM"); return !(e && e[0] == '0'); }();
+  const int C = (int)d->Cin, n = (int)(d->KH * d->KW * C / 16);
+  if (!on || C % 16 != 0 || n < 2) return;
+  g->kp_s = (int)d->stride; g->kp_kh = (int)d->KH; g->kp_kw = (int)d->KW; g->kp_cb = C / 16;
+}
+
 // 192 x 64 forward tiles (2 x 2 wavefronts of 96 x 32): 49 KB of LDS, 3 workgroups per CU where 256 x 64 fits 2 -- conv2 /
 // conv3 forward 0.75 / 0.42 -> 0.73 / 0.40 ms (same box).  SRL_TILE192=0: the 256 x 64 tiles (A/B switch)
 static bool tile192() {
@@ -316,6 +330,7 @@ extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const f
   hipStream_t st = (hipStream_t)stream;
   int rc;
   const bool x3 = use_bf16x3() && Kp >= 64;  // bf16 matrix cores, three exact pieces per float32 operand
+  if (x3) fwd_kstep_order(d, &g);
   if (d->Cout > 64) rc = x3 ? launch3<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3>(st, g, 1, 1)
                             : launch<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
   else if (d->Cout > 32) rc = x3 ? (tile192() ? launch3<192, 64, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3>(st, g, 1, 1)

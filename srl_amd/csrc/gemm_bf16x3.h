@@ -201,6 +201,9 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
     }
     use_mask = true;
   }
+  constexpr bool PERM = AMODE == SRC_CONV && !AKM && KB == 16;  // forward convolutions: host-chosen order of the k-steps
+  KStepOrder ord;
+  ord.reset();
   auto nextk = [&](long k) -> long {
     if (SKIP && use_mask) {
       if (!kmask) return -1;
@@ -208,9 +211,10 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
       kmask &= kmask - 1;
       return kbeg + (long)t * KB;
     }
+    if (PERM && g.kp_cb) return ord.next(g) ? ord.k(g) : -1;
     return k + KB < kend ? k + KB : -1;
   };
-  long kcur = (SKIP && use_mask) ? nextk(0) : kbeg;
+  long kcur = (SKIP && use_mask) ? nextk(0) : (PERM && g.kp_cb) ? ord.k(g) : kbeg;
   long kend_l = kend;
   if (kcur < 0) { kcur = kbeg; kend_l = kbeg; }  // no tap reaches this pixel: one step on an all-zero tile
   long knext = nextk(kcur);

@@ -120,12 +120,39 @@ struct GemmArgs {
   // gemm3_kernel, dense operands: tiles are numbered column group by column group (grp_n tile columns wide, every tile row
   // inside a group before the next group; grp_sz = tile rows x grp_n).  grp_n >= tiles_n: plain row-major numbering.
   unsigned grp_n, grp_sz;
+  // bf16x3 forward convolutions: the 16-deep k-steps (k = (kh, kw, c), c fastest) are visited in the order of KStepOrder
+  // (kp_cb == 0: ascending).  A sum's terms may come in any order; the order decides which input lines are re-read soon.
+  int kp_s, kp_kh, kp_kw, kp_cb;  // stride, kernel height / width, 16-channel blocks per pixel
   int nbatch;
   float* a_colsum;  // [M] += sum_k A(i, k) (k-major dense A only): the bias gradient of a weight-gradient product
   long a_colsum_batch;  // per-batch (grid.y) stride of a_colsum
 };
 
 #ifdef __HIPCC__
+// Odometer over the k-steps of a forward convolution, slowest digit first: 128-byte line of the pixel (two 16-channel
+// blocks), parity class of the tap (kh % S, kw % S), the taps of the class, the blocks of the line.  Taps that read the
+// same input pixels become neighbours in time (see conv.hip fwd_kstep_order); a few scalar operations per step.
+struct KStepOrder {
+  int line, cy, cx, qh, qw, c2;
+  __device__ __forceinline__ void reset() { line = cy = cx = qh = qw = c2 = 0; }
+  __device__ __forceinline__ long k(const GemmArgs& g) const {
+    return (long)(((cy + g.kp_s * qh) * g.kp_kw + cx + g.kp_s * qw) * g.kp_cb + 2 * line + c2) * 16;
+  }
+  __device__ __forceinline__ bool next(const GemmArgs& g) {  // false: past the last step
+    if (++c2 < 2 && 2 * line + c2 < g.kp_cb) return true;
+    c2 = 0;
+    if (cx + g.kp_s * ++qw < g.kp_kw) return true;
+    qw = 0;
+    if (cy + g.kp_s * ++qh < g.kp_kh) return true;
+    qh = 0;
+    if (++cx < g.kp_s && cx < g.kp_kw) return true;
+    cx = 0;
+    if (++cy < g.kp_s && cy < g.kp_kh) return true;
+    cy = 0;
+    return 2 * ++line < g.kp_cb;
+  }
+};
+
 // ---- source policies ------------------------------------------------------------------------------------------------
 struct RowInfo {
   int off;  // element offset of the row's origin

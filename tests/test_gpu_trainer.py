@@ -333,8 +333,10 @@ def test_implicit_and_explicit_conv_paths_agree():
     for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
         a, b = stats[0][0][k], stats[1][0][k]
         assert abs(a - b) <= 1e-5 * max(abs(b), 1e-2), (k, a, b)
+    # one Adam step moves a weight by ~lr = 5e-4 times g / (|g| + eps): where a gradient is within rounding of zero the two
+    # implementations (different summation orders) may step it differently by a fraction of lr
     for k in stats[0][1]:
-        assert np.abs(stats[0][1][k].numpy() - stats[1][1][k].numpy()).max() <= 2e-5, k
+        assert np.abs(stats[0][1][k].numpy() - stats[1][1][k].numpy()).max() <= 5e-5, k
 
 
 def test_batcher_device_staging_matches_host_concatenation():
