@@ -407,13 +407,17 @@ int srl_maxpool2_nhwc_bwd(void* stream, const float* dy, const float* x, int64_t
 
 /* The same encoder pieces for observations with one or three spatial dimensions (modules/cnn.py:60-71: nn.Conv1d /
  * nn.Conv3d with MaxPool1d / MaxPool3d by the observation's rank; modules_test.py:385-401), on channels-last volumes
- * [n, D, H, W, C] (Conv1d: D = H = 1).  srl_pad_ndhwc / srl_crop_ndhwc: zero border of (pd, ph, pw) voxels per side and
- * its adjoint.  srl_maxpool_ndhwc_fwd / _bwd: windows of (wd, wh, ww) voxels, each 1 or 2, stride = window, floor; the
+ * [n, D, H, W, C] (Conv1d: D = H = 1).  srl_pad_ndhwc: border of (pd, ph, pw <= 8) voxels per side filled per
+ * nn.ConvNd's `padding_mode` (mode 0 zeros, 1 reflect, 2 replicate, 3 circular; torch's preconditions: reflect pad <
+ * extent, circular pad <= extent); srl_crop_ndhwc: its adjoint (mode 0: the crop; else every interior voxel also collects
+ * the border voxels that were filled from it).  srl_maxpool_ndhwc_fwd / _bwd: windows of (wd, wh, ww) voxels, each 1 or 2, stride = window, floor; the
  * backward as srl_maxpool2_nhwc_bwd.  srl_im2col_ndhwc: patch matrix P[(s,od,oh,ow)][(kd,kh,kw,c)] for a dense GEMM
  * against weights laid out [Cout][KD][KH][KW][Cin]; srl_col2im_ndhwc: its adjoint (sums the taps that reach a voxel,
  * optionally times act'(y), y = the forward activation of that voxel, dact as above). */
-int srl_pad_ndhwc(void* stream, const float* x, int64_t n, int D, int H, int W, int C, int pd, int ph, int pw, float* y);
-int srl_crop_ndhwc(void* stream, const float* yp, int64_t n, int D, int H, int W, int C, int pd, int ph, int pw, float* x);
+int srl_pad_ndhwc(void* stream, const float* x, int64_t n, int D, int H, int W, int C, int pd, int ph, int pw, int mode,
+                  float* y);
+int srl_crop_ndhwc(void* stream, const float* yp, int64_t n, int D, int H, int W, int C, int pd, int ph, int pw, int mode,
+                   float* x);
 int srl_maxpool_ndhwc_fwd(void* stream, const float* x, int64_t n, int D, int H, int W, int C, int wd, int wh, int ww, float* y);
 int srl_maxpool_ndhwc_bwd(void* stream, const float* dy, const float* x, int64_t n, int D, int H, int W, int C, int wd, int wh,
                           int ww, int dact, float* dx);

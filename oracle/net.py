@@ -108,10 +108,13 @@ class OracleActorCritic:
                 layers = self.cnn_layers[k]
                 pool = bool(self.use_maxpool.get(k, False))
                 idx = 0  # index in the reference's nn.Sequential: [MaxPool2d(2)] Conv2d act ... Flatten mlp (cnn.py:99-126)
-                for i, (_, _, stride, padding, _) in enumerate(layers):
+                for i, (_, _, stride, padding, pmode) in enumerate(layers):
                     if pool and i != len(layers) - 1:
                         x = max_pool(x, 2)
                         idx += 1
+                    if padding and pmode != "zeros":  # torch/nn/modules/conv.py _conv_forward: F.pad with the mode, then no padding
+                        x = F.pad(x, (padding, padding) * (len(shape) - 1), mode=pmode)
+                        padding = 0
                     x = act(conv(x, self._p(f"{cb}.{idx}.weight"), self._p(f"{cb}.{idx}.bias"), stride=stride, padding=padding))
                     idx += 2
                 x = x.flatten(1)

@@ -411,7 +411,7 @@ class HipNet:
                 if any(L.pads):
                     sp = tuple(d + 2 * p for d, p in zip(sp, L.pads))
                     xp = self._buf(f"{tag}{L.prefix}.xp", n * math.prod(sp), L.cin)
-                    hip.pad_ndhwc(cur.ptr, n, (*L.in_sp, L.cin), L.pads, xp.ptr)
+                    hip.pad_ndhwc(cur.ptr, n, (*L.in_sp, L.cin), L.pads, xp.ptr, L.pad_mode)
                     cur = xp
                 m, kdim = n * math.prod(L.out_sp), L.cin * math.prod(L.kern)
                 P = self._buf(f"{tag}{L.prefix}.P", m, kdim)
@@ -430,7 +430,10 @@ class HipNet:
                     assert not L.first and cur.ld == L.cin and cur.rows == n * h * w
                     h, w = h + 2 * L.pad, w + 2 * L.pad
                     xp = self._buf(f"{tag}{L.prefix}.xp", n * h * w, L.cin)
-                    hip.pad_nhwc(cur.ptr, n, L.in_hw[0], L.in_hw[1], L.cin, L.pad, xp.ptr)
+                    if L.pad_mode:  # reflect / replicate / circular borders: the general kernel (D = 1)
+                        hip.pad_ndhwc(cur.ptr, n, (1, L.in_hw[0], L.in_hw[1], L.cin), (0, L.pad, L.pad), xp.ptr, L.pad_mode)
+                    else:
+                        hip.pad_nhwc(cur.ptr, n, L.in_hw[0], L.in_hw[1], L.cin, L.pad, xp.ptr)
                     cur = xp
                 desc = hip.conv_desc(n, h, w, L.cin, L.k, L.k, L.stride, L.cout, L.act)
                 # implicit GEMM (no patch matrix) whenever the geometry allows; explicit im2col otherwise
@@ -520,7 +523,7 @@ class HipNet:
                 hip.col2im_ndhwc(P.ptr, n, (*sp, L.cin), L.kern, L.stride, x.ptr if in_act else None, in_act, dx.ptr)
                 if any(L.pads):
                     dxc = self._buf(f"{tag}{L.prefix}.dxc", n * math.prod(L.in_sp), L.cin)
-                    hip.crop_ndhwc(dx.ptr, n, (*L.in_sp, L.cin), L.pads, dxc.ptr)
+                    hip.crop_ndhwc(dx.ptr, n, (*L.in_sp, L.cin), L.pads, dxc.ptr, L.pad_mode)
                     dx = dxc
                 g = dx
             elif kind == "pool":
@@ -591,7 +594,10 @@ class HipNet:
             return dx
         h, w = L.in_hw
         out = self._buf(f"{tag}{L.prefix}.dxc", n * h * w, L.cin)
-        hip.crop_nhwc(dx.ptr, n, h, w, L.cin, L.pad, out.ptr)
+        if L.pad_mode:
+            hip.crop_ndhwc(dx.ptr, n, (1, h, w, L.cin), (0, L.pad, L.pad), out.ptr, L.pad_mode)
+        else:
+            hip.crop_nhwc(dx.ptr, n, h, w, L.cin, L.pad, out.ptr)
         return out
 
     def _notify_ready(self, kind, L, saved):

@@ -127,7 +127,8 @@ class ConvSpec:
     act: int
     first: bool  # reads the (layer-normed) NCHW observation directly
     s2d: int = 0  # first layer only: the observation is space-to-depth'd by this factor (= stride) before the gather
-    pad: int = 0  # zero padding on every side (in_hw is the unpadded input)
+    pad: int = 0  # padding on every side (in_hw is the unpadded input)
+    pad_mode: int = 0  # nn.Conv2d's padding_mode: 0 zeros, 1 reflect, 2 replicate, 3 circular
 
 
 @dataclasses.dataclass
@@ -153,6 +154,7 @@ class ConvNdSpec:
     in_sp: Tuple[int, int, int]  # unpadded input volume
     out_sp: Tuple[int, int, int]
     act: int
+    pad_mode: int = 0
 
 
 @dataclasses.dataclass
@@ -283,6 +285,24 @@ class _Builder:
             self.values[self.params[name].key].zero_()
 
 
+PAD_MODES = {"zeros": 0, "reflect": 1, "replicate": 2, "circular": 3}  # nn.ConvNd's padding_mode (modules/cnn.py:107-113)
+
+
+def _pad_mode(padding, padding_mode, extents) -> int:
+    """Validate one layer's padding against nn.ConvNd's rules; returns the mode code of the kernels."""
+    if isinstance(padding, (tuple, list, str)):
+        raise NotImplementedError("per-axis / named padding is not implemented on the HIP path")
+    if padding_mode not in PAD_MODES:
+        raise ValueError(f"padding_mode must be one of {list(PAD_MODES)}, got `{padding_mode}`")  # torch's own check
+    if padding > 8:
+        raise NotImplementedError("padding wider than 8 is not implemented on the HIP path")
+    if padding and padding_mode == "reflect" and any(padding >= d for d in extents):
+        raise ValueError("reflect padding must be smaller than the input extent")
+    if padding and padding_mode == "circular" and any(padding > d for d in extents):
+        raise ValueError("circular padding must not exceed the input extent")
+    return PAD_MODES[padding_mode] if padding else 0
+
+
 def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, act_name: str, cnn_layers: Dict,
                     use_maxpool: Optional[Dict] = None):
     encs = []
@@ -323,10 +343,6 @@ def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, a
         gain = torch.nn.init.calculate_gain(act_name)
         idx = 0  # position in the reference's nn.Sequential (modules/cnn.py:57-72)
         for i, (cout, k, stride, padding, padding_mode) in enumerate(cfg):
-            if padding != 0 and padding_mode != "zeros":
-                raise NotImplementedError(f"padding_mode `{padding_mode}`: only zero padding is implemented on the HIP path")
-            if isinstance(padding, (tuple, list, str)):
-                raise NotImplementedError("per-axis / named padding is not implemented on the HIP path")
             if pool and i != len(cfg) - 1:  # the pooling layer sits BEFORE convolution i (modules/cnn.py:61-63)
                 ph, pw = h // 2, w // 2
                 if ph <= 0 or pw <= 0:
@@ -334,6 +350,7 @@ def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, a
                 layers.append(PoolSpec(f"{cb}.{idx}", c, (h, w), (ph, pw)))
                 h, w = ph, pw
                 idx += 1
+            mode = _pad_mode(padding, padding_mode, (h, w))
             oh, ow = _conv_out(h + 2 * padding, k, stride), _conv_out(w + 2 * padding, k, stride)
             if oh <= 0 or ow <= 0:
                 raise ValueError(f"CNN Dimension error, got {(oh, ow)} after convolution")
@@ -344,7 +361,7 @@ def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, a
             b.orthogonal(f"{name}.weight", gain)  # modules/cnn.py:73-84 (use_orthogonal=True)
             b.zero(f"{name}.bias")
             layers.append(ConvSpec(name, c, cout, k, stride, (h, w), (oh, ow), act, first=first,
-                                   s2d=s2d if first else 0, pad=int(padding)))
+                                   s2d=s2d if first else 0, pad=int(padding), pad_mode=mode))
             c, h, w = cout, oh, ow
         sizes = [c * h * w]
         while sizes[-1] > hidden * 8:  # modules/cnn.py:86-91
@@ -377,10 +394,6 @@ def _build_nd_encoder(b: _Builder, key: str, base: str, shape, hidden: int, act:
     gain = torch.nn.init.calculate_gain(act_name)
     idx = 0
     for i, (cout, k, stride, padding, padding_mode) in enumerate(cfg):
-        if padding != 0 and padding_mode != "zeros":
-            raise NotImplementedError(f"padding_mode `{padding_mode}`: only zero padding is implemented on the HIP path")
-        if isinstance(padding, (tuple, list, str)):
-            raise NotImplementedError("per-axis / named padding is not implemented on the HIP path")
         if pool and i != len(cfg) - 1:
             win = (1,) * lead + (2,) * nd
             out = tuple(d // w for d, w in zip(sp, win))
@@ -389,6 +402,7 @@ def _build_nd_encoder(b: _Builder, key: str, base: str, shape, hidden: int, act:
             layers.append(PoolNdSpec(f"{cb}.{idx}", c, sp, out, win))
             sp = out
             idx += 1
+        mode = _pad_mode(padding, padding_mode, sp[lead:])
         kern = (1,) * lead + (k,) * nd
         pads = (0,) * lead + (int(padding),) * nd
         out = tuple(_conv_out(d + 2 * p, kk, stride) if j >= lead else 1 for j, (d, p, kk) in enumerate(zip(sp, pads, kern)))
@@ -399,7 +413,7 @@ def _build_nd_encoder(b: _Builder, key: str, base: str, shape, hidden: int, act:
         b.conv(name, c, cout, k, "conv_nhwc", nd=nd)
         b.orthogonal(f"{name}.weight", gain)
         b.zero(f"{name}.bias")
-        layers.append(ConvNdSpec(name, c, cout, kern, stride, pads, sp, out, act))
+        layers.append(ConvNdSpec(name, c, cout, kern, stride, pads, sp, out, act, pad_mode=mode))
         c, sp = cout, out
     vox = int(math.prod(sp))
     sizes = [c * vox]

@@ -123,22 +123,50 @@ struct Vol {
   int D, H, W, C;
 };
 
-// zero border of (pd, ph, pw) voxels on both sides of each axis; crop = its adjoint
-__global__ __launch_bounds__(256) void pad_nd_kernel(const float* x, long n, Vol v, int pd, int ph, int pw, float* y) {
+// border of (pd, ph, pw) voxels on both sides of each axis, filled per nn.ConvNd's padding_mode: 0 zeros, 1 reflect
+// (without the edge), 2 replicate, 3 circular.  Source index of padded coordinate o (already shifted by -pad) along an
+// axis of extent D, or -1 for a zero.
+__device__ __forceinline__ int pad_src(int o, int D, int mode) {
+  if (o >= 0 && o < D) return o;
+  if (mode == 1) return o < 0 ? -o : 2 * (D - 1) - o;
+  if (mode == 2) return o < 0 ? 0 : D - 1;
+  if (mode == 3) return o < 0 ? o + D : o - D;
+  return -1;
+}
+__global__ __launch_bounds__(256) void pad_nd_kernel(const float* x, long n, Vol v, int pd, int ph, int pw, int mode, float* y) {
   const int Dp = v.D + 2 * pd, Hp = v.H + 2 * ph, Wp = v.W + 2 * pw;
   const long total = n * Dp * Hp * Wp * v.C;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int c = (int)(e % v.C);
     long t = e / v.C;
-    const int w = (int)(t % Wp) - pw; t /= Wp;
-    const int h = (int)(t % Hp) - ph; t /= Hp;
-    const int d = (int)(t % Dp) - pd;
+    const int w = pad_src((int)(t % Wp) - pw, v.W, mode); t /= Wp;
+    const int h = pad_src((int)(t % Hp) - ph, v.H, mode); t /= Hp;
+    const int d = pad_src((int)(t % Dp) - pd, v.D, mode);
     const long s = t / Dp;
-    const bool in = d >= 0 && d < v.D && h >= 0 && h < v.H && w >= 0 && w < v.W;
-    y[e] = in ? x[(((s * v.D + d) * v.H + h) * v.W + w) * v.C + c] : 0.f;
+    y[e] = (d >= 0 && h >= 0 && w >= 0) ? x[(((s * v.D + d) * v.H + h) * v.W + w) * v.C + c] : 0.f;
   }
 }
-__global__ __launch_bounds__(256) void crop_nd_kernel(const float* yp, long n, Vol v, int pd, int ph, int pw, float* x) {
+// The padded coordinates (0 .. D + 2p - 1) that read interior index i along one axis: the copy itself first, then the
+// border voxels filled from it.  At most 1 + 2p of them (replicate at an edge); returns the count.
+__device__ __forceinline__ int pad_preimage(int i, int D, int p, int mode, int* out) {
+  int k = 0;
+  out[k++] = i + p;
+  if (p == 0 || mode == 0) return k;
+  if (mode == 1) {
+    if (i >= 1 && i <= p) out[k++] = p - i;
+    if (i <= D - 2 && i >= D - 1 - p) out[k++] = p + 2 * (D - 1) - i;
+  } else if (mode == 2) {
+    if (i == 0) for (int o = 0; o < p; ++o) out[k++] = o;
+    if (i == D - 1) for (int o = 0; o < p; ++o) out[k++] = p + D + o;
+  } else {
+    if (i >= D - p) out[k++] = i + p - D;
+    if (i < p) out[k++] = i + p + D;
+  }
+  return k;
+}
+constexpr int kMaxPad = 8;  // per side (host-checked): bounds the preimage lists
+// adjoint of pad_nd_kernel: x[i] = sum of the padded voxels that were filled from i (mode 0: the crop)
+__global__ __launch_bounds__(256) void crop_nd_kernel(const float* yp, long n, Vol v, int pd, int ph, int pw, int mode, float* x) {
   const int Hp = v.H + 2 * ph, Wp = v.W + 2 * pw, Dp = v.D + 2 * pd;
   const long total = n * v.D * v.H * v.W * v.C;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -148,7 +176,13 @@ __global__ __launch_bounds__(256) void crop_nd_kernel(const float* yp, long n, V
     const int h = (int)(t % v.H); t /= v.H;
     const int d = (int)(t % v.D);
     const long s = t / v.D;
-    x[e] = yp[(((s * Dp + d + pd) * Hp + h + ph) * Wp + w + pw) * v.C + c];
+    int od[1 + 2 * kMaxPad], oh[1 + 2 * kMaxPad], ow[1 + 2 * kMaxPad];
+    const int nd = pad_preimage(d, v.D, pd, mode, od), nh = pad_preimage(h, v.H, ph, mode, oh), nw = pad_preimage(w, v.W, pw, mode, ow);
+    float acc = 0.f;
+    for (int a = 0; a < nd; ++a)
+      for (int b = 0; b < nh; ++b)
+        for (int g = 0; g < nw; ++g) acc += yp[(((s * Dp + od[a]) * Hp + oh[b]) * Wp + ow[g]) * v.C + c];
+    x[e] = acc;
   }
 }
 
@@ -310,19 +344,29 @@ extern "C" int srl_maxpool2_nhwc_bwd(void* stream, const float* dy, const float*
 
 static bool vol_ok(int D, int H, int W, int C) { return D >= 1 && H >= 1 && W >= 1 && C >= 1; }
 
-extern "C" int srl_pad_ndhwc(void* stream, const float* x, int64_t n, int D, int H, int W, int C, int pd, int ph, int pw, float* y) {
-  SRL_CHECK_ARG(x && y && vol_ok(D, H, W, C) && pd >= 0 && ph >= 0 && pw >= 0, "null tensor / bad shape");
+// nn.ConvNd's own preconditions: reflect needs pad < extent, circular pad <= extent (torch raises otherwise)
+static bool pad_ok(int D, int H, int W, int pd, int ph, int pw, int mode) {
+  if (pd < 0 || ph < 0 || pw < 0 || mode < 0 || mode > 3 || pd > kMaxPad || ph > kMaxPad || pw > kMaxPad) return false;
+  if (mode == 1) return pd < D && ph < H && pw < W;
+  if (mode == 3) return pd <= D && ph <= H && pw <= W;
+  return true;
+}
+
+extern "C" int srl_pad_ndhwc(void* stream, const float* x, int64_t n, int D, int H, int W, int C, int pd, int ph, int pw, int mode,
+                             float* y) {
+  SRL_CHECK_ARG(x && y && vol_ok(D, H, W, C) && pad_ok(D, H, W, pd, ph, pw, mode), "null tensor / bad shape / padding too wide");
   if (n == 0) return 0;
   const long total = n * (D + 2 * pd) * (H + 2 * ph) * (W + 2 * pw) * C;
-  hipLaunchKernelGGL(pad_nd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (long)n, Vol{D, H, W, C}, pd, ph, pw, y);
+  hipLaunchKernelGGL(pad_nd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (long)n, Vol{D, H, W, C}, pd, ph, pw, mode, y);
   SRL_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int srl_crop_ndhwc(void* stream, const float* yp, int64_t n, int D, int H, int W, int C, int pd, int ph, int pw, float* x) {
-  SRL_CHECK_ARG(x && yp && vol_ok(D, H, W, C) && pd >= 0 && ph >= 0 && pw >= 0, "null tensor / bad shape");
+extern "C" int srl_crop_ndhwc(void* stream, const float* yp, int64_t n, int D, int H, int W, int C, int pd, int ph, int pw, int mode,
+                              float* x) {
+  SRL_CHECK_ARG(x && yp && vol_ok(D, H, W, C) && pad_ok(D, H, W, pd, ph, pw, mode), "null tensor / bad shape / padding too wide");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(crop_nd_kernel, dim3(grid_for(n * D * H * W * C)), dim3(256), 0, (hipStream_t)stream, yp, (long)n, Vol{D, H, W, C}, pd, ph, pw, x);
+  hipLaunchKernelGGL(crop_nd_kernel, dim3(grid_for(n * D * H * W * C)), dim3(256), 0, (hipStream_t)stream, yp, (long)n, Vol{D, H, W, C}, pd, ph, pw, mode, x);
   SRL_LAUNCH_CHECK();
   return 0;
 }

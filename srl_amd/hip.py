@@ -125,8 +125,8 @@ _SIGNATURES = {
     "srl_crop_nhwc": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "srl_maxpool2_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "srl_maxpool2_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
-    "srl_pad_ndhwc": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 7 + [c_void_p]),
-    "srl_crop_ndhwc": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 7 + [c_void_p]),
+    "srl_pad_ndhwc": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 8 + [c_void_p]),
+    "srl_crop_ndhwc": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 8 + [c_void_p]),
     "srl_maxpool_ndhwc_fwd": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 7 + [c_void_p]),
     "srl_maxpool_ndhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_int] * 8 + [c_void_p]),
     "srl_im2col_ndhwc": (c_int, [c_void_p, c_void_p, c_int64] + [c_int] * 8 + [c_void_p]),
@@ -538,13 +538,17 @@ def maxpool2_nhwc_bwd(dy_ptr, x_ptr, n, H, W, C, dact, dx_ptr):
     _check(lib().srl_maxpool2_nhwc_bwd(_stream(), dy_ptr, x_ptr, n, H, W, C, int(dact), dx_ptr), "srl_maxpool2_nhwc_bwd")
 
 
-def pad_ndhwc(x_ptr, n, vol, pads, y_ptr):
-    """vol = (D, H, W, C), pads = (pd, ph, pw)."""
-    _check(lib().srl_pad_ndhwc(_stream(), x_ptr, n, *vol, *pads, y_ptr), "srl_pad_ndhwc")
+PAD_MODES = {"zeros": 0, "reflect": 1, "replicate": 2, "circular": 3}  # nn.ConvNd's padding_mode
 
 
-def crop_ndhwc(yp_ptr, n, vol, pads, x_ptr):
-    _check(lib().srl_crop_ndhwc(_stream(), yp_ptr, n, *vol, *pads, x_ptr), "srl_crop_ndhwc")
+def pad_ndhwc(x_ptr, n, vol, pads, y_ptr, mode=0):
+    """vol = (D, H, W, C), pads = (pd, ph, pw), mode = PAD_MODES[padding_mode]."""
+    _check(lib().srl_pad_ndhwc(_stream(), x_ptr, n, *vol, *pads, int(mode), y_ptr), "srl_pad_ndhwc")
+
+
+def crop_ndhwc(yp_ptr, n, vol, pads, x_ptr, mode=0):
+    """The adjoint of ``pad_ndhwc``: the crop for zero padding, border voxels summed back into their sources otherwise."""
+    _check(lib().srl_crop_ndhwc(_stream(), yp_ptr, n, *vol, *pads, int(mode), x_ptr), "srl_crop_ndhwc")
 
 
 def maxpool_ndhwc_fwd(x_ptr, n, vol, win, y_ptr):

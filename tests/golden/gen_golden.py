@@ -416,6 +416,22 @@ def gen_cnn_nd():
     save("steps_cnn_nd.npz", **out)
 
 
+PADM_POLICY = dict(obs_dim={"img": (4, 12, 10), "seq": (2, 21)}, action_dim=3, hidden_dim=16, num_dense_layers=1,
+                   num_rnn_layers=0, popart=False, layernorm=False, shared_backbone=True, chunk_len=4, seed=75,
+                   cnn_layers=dict(img=[(8, 3, 1, 2, 'reflect'), (8, 3, 2, 1, 'circular'), (4, 3, 1, 1, 'zeros')],
+                                   seq=[(4, 5, 2, 3, 'replicate'), (4, 3, 1, 1, 'circular')]))
+
+
+def gen_cnn_padmode():
+    """nn.ConvNd's non-zero padding modes (modules/cnn.py:107-113 passes `padding_mode` through): reflect, circular and
+    replicate borders, with strides, on a uint8 image and a float32 sequence in one policy."""
+    out = {}
+    run_steps("padm", PADM_POLICY, dict(popart=False, ppo_epochs=2, optimizer_config=dict(lr=1e-3), max_grad_norm=10.0),
+              dict(T=5, B=4, obs_spec={"img": ((4, 12, 10), "u8"), "seq": ((2, 21), "f32")}, action_dims=3, p_done=0.1), 2,
+              out=out)
+    save("steps_cnn_padmode.npz", **out)
+
+
 def gen_vtrace_rnn():
     """V-trace with recurrent policies (mappo.py:243-246: the analysed rows give both the importance ratio of the trace
     and the loss): GRU shared backbone, and LSTM separate backbones with PopArt and two epochs."""

@@ -817,21 +817,29 @@ def test_gemm_tile_numbering_large(M, N, K, akm, bkm, split):
     assert err <= 1e-5 * float(np.sqrt(K)) * 4, err
 
 
-@pytest.mark.parametrize("vol,pads", [((1, 1, 37, 3), (0, 0, 2)), ((1, 9, 7, 8), (0, 1, 1)), ((5, 4, 6, 2), (1, 2, 0))])
-def test_pad_crop_ndhwc(vol, pads):
+@pytest.mark.parametrize("vol,pads", [((1, 1, 37, 3), (0, 0, 2)), ((1, 9, 7, 8), (0, 1, 1)), ((5, 4, 6, 2), (1, 2, 0)),
+                                      ((3, 4, 5, 2), (2, 3, 4))])
+@pytest.mark.parametrize("mode", ["zeros", "reflect", "replicate", "circular"])
+def test_pad_crop_ndhwc(vol, pads, mode):
+    """Borders per nn.ConvNd's padding_mode against torch.nn.functional.pad, and the adjoint against its autograd."""
     rng = np.random.default_rng(sum(vol))
     n = 3
     D, H, W, C = vol
     x = rng.standard_normal((n, D, H, W, C)).astype(np.float32)
     pv = tuple(d + 2 * p for d, p in zip(vol[:3], pads))
+    xt = torch.from_numpy(x).permute(0, 4, 1, 2, 3).double().requires_grad_(True)  # [n, C, D, H, W]
+    tpad = (pads[2], pads[2], pads[1], pads[1], pads[0], pads[0])
+    yt = torch.nn.functional.pad(xt, tpad, mode="constant" if mode == "zeros" else mode)
     y = torch.full((n, *pv, C), float("nan"), device=DEV)
     dx_ = dev(x)
-    hip.pad_ndhwc(dx_.data_ptr(), n, vol, pads, y.data_ptr())
-    ref = np.pad(x, ((0, 0), (pads[0],) * 2, (pads[1],) * 2, (pads[2],) * 2, (0, 0)))
-    assert np.array_equal(y.cpu().numpy(), ref)
-    back = torch.empty((n, D, H, W, C), device=DEV)
-    hip.crop_ndhwc(y.data_ptr(), n, vol, pads, back.data_ptr())
-    assert np.array_equal(back.cpu().numpy(), x)
+    hip.pad_ndhwc(dx_.data_ptr(), n, vol, pads, y.data_ptr(), hip.PAD_MODES[mode])
+    assert np.array_equal(y.cpu().numpy(), yt.permute(0, 2, 3, 4, 1).detach().numpy().astype(np.float32))
+    dy = rng.standard_normal((n, *pv, C)).astype(np.float32)
+    (yt * torch.from_numpy(dy).permute(0, 4, 1, 2, 3).double()).sum().backward()
+    back = torch.full((n, D, H, W, C), float("nan"), device=DEV)
+    ddy = dev(dy)
+    hip.crop_ndhwc(ddy.data_ptr(), n, vol, pads, back.data_ptr(), hip.PAD_MODES[mode])
+    assert rel_close(back.cpu().numpy(), xt.grad.permute(0, 2, 3, 4, 1).numpy(), 1e-6, scale=1.0)
 
 
 @pytest.mark.parametrize("vol,win", [((1, 1, 59, 3), (1, 1, 2)), ((1, 23, 19, 4), (1, 2, 2)), ((9, 8, 7, 2), (2, 2, 2))])

@@ -164,6 +164,14 @@ CASES.update({
               dict(T=5, B=3, obs_spec={"vol": ((2, 9, 8, 7), "u8"), "vec": ((3,), "f32")}, action_dims=[2, 3], p_done=0.1), 2,
               "steps_cnn_nd.npz"),
 })
+# nn.ConvNd's non-zero padding modes (gen_golden.py gen_cnn_padmode)
+CASES["padm"] = (dict(obs_dim={"img": (4, 12, 10), "seq": (2, 21)}, action_dim=3, hidden_dim=16, num_dense_layers=1,
+                      num_rnn_layers=0, popart=False, layernorm=False, shared_backbone=True, chunk_len=4, seed=75,
+                      cnn_layers=dict(img=[(8, 3, 1, 2, 'reflect'), (8, 3, 2, 1, 'circular'), (4, 3, 1, 1, 'zeros')],
+                                      seq=[(4, 5, 2, 3, 'replicate'), (4, 3, 1, 1, 'circular')])),
+                 dict(popart=False, ppo_epochs=2, optimizer_config=dict(lr=1e-3), max_grad_norm=10.0),
+                 dict(T=5, B=4, obs_spec={"img": ((4, 12, 10), "u8"), "seq": ((2, 21), "f32")}, action_dims=3, p_done=0.1), 2,
+                 "steps_cnn_padmode.npz")
 
 
 def make_trainer(policy_args, trainer_args):

@@ -61,8 +61,9 @@ def test_unsupported_configs_raise():
     base = dict(obs_dim=4, action_dim=2, num_rnn_layers=0, popart=False)
     for bad in (dict(num_rnn_layers=1, rnn_type="gtrxl"), dict(continuous_action=True, std_type="state_dependent"),
                 dict(auxiliary_head=True), dict(obs_dim={"o": (3, 10, 4, 4, 4)}),
-                dict(obs_dim={"o": (3, 12, 12)}, cnn_layers=dict(o=[(4, 3, 1, 1, "reflect")]))):
-        with pytest.raises((NotImplementedError, AttributeError)):
+                dict(obs_dim={"o": (3, 12, 12)}, cnn_layers=dict(o=[(4, 3, 1, 1, "mirror")])),
+                dict(obs_dim={"o": (3, 4, 4)}, cnn_layers=dict(o=[(4, 3, 1, 4, "reflect")]))):
+        with pytest.raises((NotImplementedError, AttributeError, ValueError)):
             policy_api.make(config.Policy("actor-critic", args={**base, **bad}))
 
 
