@@ -347,6 +347,11 @@ inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
     if (run > slots && panel_b * a.tiles_n > l2_half) {
       const long gn = (long)(l2_half / panel_b);
       a.grp_n = (unsigned)(gn < 1 ? 1 : gn);
+    } else if (tiles_m < a.tiles_n && tiles_m * tiles_m <= run) {
+      // few tile rows (a weight gradient: FC, 512 x 3136 over 5 k-ranges = 4 x 25 tiles each): an XCD's run of row-major
+      // ids is a couple of whole tile rows, i.e. ALL of B's panels; numbered down the columns it is every tile row of ~16
+      // columns -- 738 -> 347 MB fetched per launch (239 MB of operands), and the tiles that share a panel start together
+      a.grp_n = 1;
     }
   }
   a.grp_sz = (unsigned)tiles_m * a.grp_n;
