@@ -207,7 +207,13 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
       } else {
         x0 = bytes_to_bf16x8(q.x, q.y, cen), x1 = bytes_to_bf16x8(q.z, q.w, cen);
       }
-      if (next_row) raw[c] = *reinterpret_cast<const uint4*>(next_row + poff[c]);
+      // the next tile's loads go out one 128-byte run at a time (its four 32-byte chunks back to back, as soon as the
+      // last of their registers is free): issued chunk by chunk, between the MFMAs, the four requests for a line were
+      // far enough apart for the line to leave the L1 in between
+      if (next_row && (c & 3) == 3) {
+#pragma unroll
+        for (int cc = c - 3; cc <= c; ++cc) raw[cc] = *reinterpret_cast<const uint4*>(next_row + poff[cc]);
+      }
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
