@@ -28,6 +28,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #ifndef SRL_GEMM3_DBG
 #define SRL_GEMM3_DBG 0
 #endif
+// 1: the global loads of two consecutive k-steps are issued together (see gemm3_kernel); 0: one tile per step
+#ifndef SRL_GEMM3_PAIR
+#define SRL_GEMM3_PAIR 1
+#endif
 
 #ifdef __HIPCC__
 // one operand tile in LDS: three planes of BX x KB bf16
@@ -71,7 +75,7 @@ __device__ __forceinline__ void split3_quad(const float* v, uint2 (&pl)[3]) {
 
 // registers of a staged tile (Stage::r, float4 quads in Stage's thread -> (row, k) assignment) -> three bf16 planes in LDS
 template <class ST, int BX, bool KMAJOR, int KB, int NT>
-__device__ __forceinline__ void store3(const ST& st, uint8_t* lds) {
+__device__ __forceinline__ void store3(const float* regs, uint8_t* lds) {
   using T3 = Tile3<BX, KMAJOR, KB>;
   const int tid = threadIdx.x;
 #pragma unroll
@@ -79,7 +83,7 @@ __device__ __forceinline__ void store3(const ST& st, uint8_t* lds) {
     const int u = tid + q * NT;
     if (ST::PARTIAL && u >= ST::QUADS) continue;
     uint2 pl[3];
-    split3_quad(st.r + 4 * q, pl);
+    split3_quad(regs + 4 * q, pl);
     int off;
     if (!KMAJOR) off = T3::off_kc(u / ST::KQ, (u % ST::KQ) * 4);
     else off = T3::off_km(u / (BX / 4), (u % (BX / 4)) * 4);
@@ -121,8 +125,16 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
   static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 wavefronts per workgroup");
   static_assert(!is_obs(AMODE) && !is_obs(BMODE), "observation sources have their own bf16 kernels (obs_bf16.h)");
   constexpr int NT = 256;
-  using SA = Stage<BM, AKM, AMODE, NT, KB>;
-  using SB = Stage<BN, BKM, BMODE, NT, KB>;
+  // PAIR: two register sets per operand, and the global loads of two consecutive k-steps issued TOGETHER, every other
+  // step.  A k-contiguous operand is read 64 bytes per row and k-step, i.e. half a cache line, the other half one k-step
+  // (~2 us) later -- by then the line has left the 32 KB L1 (three workgroups stream 16 KB per step each) and is requested
+  // from L2 a second time.  Issued together the second request hits: dense products +2.5...4 % (FC forward 0.271 -> 0.264
+  // ms, data gradient 0.285 -> 0.275, with the mask 0.315 -> 0.301; same box).  Dense operands only: the convolutions'
+  // gathers did not move (forward) or lost (conv3 data gradient 0.486 -> 0.506), and products whose operands are both
+  // k-major read whole lines anyway.
+  constexpr bool PAIR = SRL_GEMM3_PAIR && KB == 16 && !(AKM && BKM) && AMODE == SRC_PLAIN && BMODE == SRC_PLAIN;
+  using SA = Stage<BM, AKM, AMODE, NT, KB, false, PAIR>;
+  using SB = Stage<BN, BKM, BMODE, NT, KB, false, PAIR>;
   using TA = Tile3<BM, AKM, KB>;
   using TB = Tile3<BN, BKM, KB>;
   constexpr int BUF = TA::BYTES + TB::BYTES;
@@ -179,11 +191,11 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
   constexpr bool CSUM = AKM && AMODE == SRC_PLAIN;
   const bool do_cs = CSUM && g.a_colsum != nullptr && n0 == 0;
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
-  auto cs_acc = [&]() {
+  auto cs_acc = [&](const float* r) {
     if (CSUM && do_cs) {
 #pragma unroll
       for (int q = 0; q < SA::NV; ++q) {
-        cs[0] += sa.r[4 * q]; cs[1] += sa.r[4 * q + 1]; cs[2] += sa.r[4 * q + 2]; cs[3] += sa.r[4 * q + 3];
+        cs[0] += r[4 * q]; cs[1] += r[4 * q + 1]; cs[2] += r[4 * q + 2]; cs[3] += r[4 * q + 3];
       }
     }
   };
@@ -219,14 +231,18 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
   if (kcur < 0) { kcur = kbeg; kend_l = kbeg; }  // no tap reaches this pixel: one step on an all-zero tile
   long knext = nextk(kcur);
 
-  // prologue: the first tile into LDS buffer 0, the second into registers
+  // prologue: the first tile into LDS buffer 0, the second into registers (PAIR: both loaded together, set 0 and set 1)
   sa.load(g.a, m0, g.M, kcur, kend_l, true);
   sb.load(g.b, n0, g.N, kcur, kend_l, true);
-  cs_acc();
-  store3<SA, BM, AKM, KB, NT>(sa, lds);
-  store3<SB, BN, BKM, KB, NT>(sb, lds + TA::BYTES);
+  if (PAIR) {
+    sa.template load<1>(g.a, m0, g.M, knext >= 0 ? knext : kend, kend, true);
+    sb.template load<1>(g.b, n0, g.N, knext >= 0 ? knext : kend, kend, true);
+  }
+  cs_acc(sa.r);
+  store3<SA, BM, AKM, KB, NT>(sa.r, lds);
+  store3<SB, BN, BKM, KB, NT>(sb.r, lds + TA::BYTES);
   __syncthreads();
-  if (knext >= 0) {
+  if (!PAIR && knext >= 0) {
     sa.load(g.a, m0, g.M, knext, kend, true);
     sb.load(g.b, n0, g.N, knext, kend, true);
   }
@@ -240,12 +256,17 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
   // without a successor stages an out-of-range tile: zeros, written to a buffer nobody reads -- so that the whole step is
   // one basic block, and sched_group_barrier lays the instruction pipeline out: 1 MFMA, 4 VALU, the LDS writes and the
   // global loads spread between them.
-  auto kstep = [&](auto cur_c, long k1, long k2) {
+  auto kstep = [&](auto cur_c, long k1, long k2, long k3) {  // k2 (and, PAIR, k3): the tiles whose loads this step issues
     constexpr int cur = decltype(cur_c)::value;
     const uint8_t* la = lds + cur * BUF;
     const uint8_t* lb = la + TA::BYTES;
     uint8_t* nxt = lds + (cur ^ 1) * BUF;
     const long k2x = k2 >= 0 ? k2 : kend;  // out of range: every load returns zeros
+    const long k3x = k3 >= 0 ? k3 : kend;
+    // PAIR: step A (cur == 0) writes set 1 (tile t+1) to LDS and then loads tiles t+2 -> set 0, t+3 -> set 1;
+    //       step B (cur == 1) writes set 0 (tile t+1 of its own count) and loads nothing
+    const float* ra = (PAIR && cur == 0) ? sa.r2 : sa.r;
+    const float* rb = (PAIR && cur == 0) ? sb.r2 : sb.r;
 #pragma unroll
     for (int kb = 0; kb < KB / 16; ++kb) {
       bf16x8 a[TM][3], b[TN][3];
@@ -268,14 +289,18 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
       if (kb == 0) {
         (void)k1;
-        cs_acc();
+        cs_acc(ra);
         if (!(SRL_GEMM3_DBG & 2)) {
-          store3<SA, BM, AKM, KB, NT>(sa, nxt);           // tile t+1 (or zeros): registers -> the other LDS buffer
-          store3<SB, BN, BKM, KB, NT>(sb, nxt + TA::BYTES);
+          store3<SA, BM, AKM, KB, NT>(ra, nxt);           // tile t+1 (or zeros): registers -> the other LDS buffer
+          store3<SB, BN, BKM, KB, NT>(rb, nxt + TA::BYTES);
         }
-        if (!(SRL_GEMM3_DBG & 1)) {
+        if (!(SRL_GEMM3_DBG & 1) && (!PAIR || cur == 0)) {
           sa.load(g.a, m0, g.M, k2x, kend, true);         // tile t+2 (or nothing): global -> registers
           sb.load(g.b, n0, g.N, k2x, kend, true);
+          if (PAIR) {
+            sa.template load<1>(g.a, m0, g.M, k3x, kend, true);
+            sb.template load<1>(g.b, n0, g.N, k3x, kend, true);
+          }
         }
       }
       if (KB == 16) {  // the issue pipeline of the step: see above
@@ -291,15 +316,26 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
     }
     if (!(SRL_GEMM3_DBG & 8)) __syncthreads();
   };
-  for (;;) {
-    long k2 = knext >= 0 ? nextk(knext) : -1;
-    kstep(std::integral_constant<int, 0>{}, knext, k2);
-    if (knext < 0) break;
-    knext = k2;
-    k2 = knext >= 0 ? nextk(knext) : -1;
-    kstep(std::integral_constant<int, 1>{}, knext, k2);
-    if (knext < 0) break;
-    knext = k2;
+  if (!PAIR) {
+    for (;;) {
+      long k2 = knext >= 0 ? nextk(knext) : -1;
+      kstep(std::integral_constant<int, 0>{}, knext, k2, -1);
+      if (knext < 0) break;
+      knext = k2;
+      k2 = knext >= 0 ? nextk(knext) : -1;
+      kstep(std::integral_constant<int, 1>{}, knext, k2, -1);
+      if (knext < 0) break;
+      knext = k2;
+    }
+  } else {
+    for (;;) {  // knext: tile t+1, already in set 1
+      const long k2 = knext >= 0 ? nextk(knext) : -1, k3 = k2 >= 0 ? nextk(k2) : -1;
+      kstep(std::integral_constant<int, 0>{}, knext, k2, k3);  // step A on tile t
+      if (knext < 0) break;
+      kstep(std::integral_constant<int, 1>{}, k2, -1, -1);     // step B on tile t+1: set 0 (tile t+2 or zeros) -> LDS 0
+      if (k2 < 0) break;
+      knext = k3;
+    }
   }
   if (CSUM && do_cs) {  // workgroup-uniform; the tiles in LDS are dead after the loop's last barrier
     constexpr int G = BM / 4;
