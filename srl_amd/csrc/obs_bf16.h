@@ -316,7 +316,11 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
   float s_rs[2] = {0.f, 0.f}, s_mean[2] = {0.f, 0.f}, s_cen[2] = {0.f, 0.f};
   float rsum[4] = {0.f, 0.f, 0.f, 0.f}, csum[4] = {0.f, 0.f, 0.f, 0.f};
 
+#ifndef SRL_OBSB_DBG
+#define SRL_OBSB_DBG 0  // timing experiments (wrong results): 1 no in-loop global loads, 2 no conversions, 4 no MFMAs, 8 no LDS stores
+#endif
   auto gload = [&](int set, long step) {
+    if ((SRL_OBSB_DBG & 1) && step > s0 + 2) return;
     const long n = step * KS + sr;
     const bool ok = n < a.g.n;
     const long nn = ok ? n : a.g.n - 1;
@@ -348,8 +352,14 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
       // patch bytes 16 j .. 16 j + 15 (j = sub + 8 i) -> bf16 columns: 32 bytes = chunks 2 j, 2 j + 1 of the row
       const int j = sub + 8 * i;
       union { bf16x8 v; uint4 u; } lo, hi;
-      lo.v = bytes_to_bf16x8(xb[set][i].x, xb[set][i].y, cen);
-      hi.v = bytes_to_bf16x8(xb[set][i].z, xb[set][i].w, cen);
+      if (SRL_OBSB_DBG & 2) {
+        lo.u = make_uint4(xb[set][i].x, xb[set][i].y, xb[set][i].x, xb[set][i].y);
+        hi.u = make_uint4(xb[set][i].z, xb[set][i].w, xb[set][i].z, xb[set][i].w);
+      } else {
+        lo.v = bytes_to_bf16x8(xb[set][i].x, xb[set][i].y, cen);
+        hi.v = bytes_to_bf16x8(xb[set][i].z, xb[set][i].w, cen);
+      }
+      if (SRL_OBSB_DBG & 8) continue;
       const int sw = (sr & 3) << 2;  // rows 4 apart in time share banks otherwise: see the transposed reads below
       *reinterpret_cast<uint4*>(bb + 16 * ((2 * j) ^ sw)) = lo.u;
       *reinterpret_cast<uint4*>(bb + 16 * ((2 * j + 1) ^ sw)) = hi.u;
@@ -398,7 +408,10 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
       for (int pl = 0; pl < 3; ++pl) {
         const bf16x8 af = trread(a_addr(buf, pl, kb, 0), a_addr(buf, pl, kb, 1));
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[jt], acc[jt], 0, 0, 0);
+        for (int jt = 0; jt < 2; ++jt) {
+          if (SRL_OBSB_DBG & 4) { union { bf16x8 v; float f[4]; } xa, xb2; xa.v = af; xb2.v = bf[jt]; acc[jt][pl] += xa.f[0] * xb2.f[0]; }
+          else acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[jt], acc[jt], 0, 0, 0);
+        }
       }
       if (kb == 0 && s + 1 < s1) {  // tile s+1: registers (set CUR^1) -> the other buffer (its readers left at the last barrier)
         lstore(CUR ^ 1, lds + (CUR ^ 1) * BUF);
