@@ -242,8 +242,8 @@ def recorded_traffic(kernel_substr, envs, T, chunk_rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--global-envs", type=int, default=GLOBAL_ENVS, help="B_global, fixed as N grows (strong scaling)")
     ap.add_argument("--rollout-len", type=int, default=128)
     ap.add_argument("--chunk-rows", type=int, default=16384)
