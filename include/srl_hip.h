@@ -30,12 +30,18 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 5
+#define SRL_HIP_ABI_VERSION 6
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
 /* Number of compute units / device name of the current device (host query helpers). */
 int srl_device_info(int* num_cus, int* lds_bytes_per_cu, char* name, int name_len);
+/* Host-side launch counters per kernel family since the last reset (process-wide; test / benchmark instrumentation:
+ * "did this step run on the kernels the benchmark times?").  out[0] gemm3_kernel (float32 operands as exact bf16
+ * pieces on the bf16 matrix cores), out[1] gemm_kernel (float32 MFMA), out[2] skinny kernels, out[3] / out[4] the
+ * first layer's obs_fwd_bf16_kernel / obs_bwd_bf16_kernel, out[5] the two-plane f16 variant of gemm3_kernel;
+ * entries beyond 8 are zero.  reset != 0 zeroes the counters after reading.  No reference counterpart. */
+int srl_dispatch_counts(int64_t* out, int n, int reset);
 
 /* ------------------------------------------------------------------------------------------------
  * GAE / V-trace reverse scan, fused with value masking, the return, and the advantage statistics.
@@ -368,6 +374,13 @@ int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d);
 int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
                        const float* dz, float* dw, float* db, float* dgamma, float* dbeta, float* workspace);
+
+/* Row gather behind the HBM observation ring: dst[i, :] = src[index[i], :], rows of row_bytes (a multiple of 4;
+ * 16-byte pieces when row_bytes % 16 == 0 and both bases are 16-byte aligned).  The frames `rollout` uploaded
+ * (actor_critic_policy.py:467-469) stay in a ring of fixed-size rows in HBM; a training sample names its rows by
+ * ring slot, and this gather stands in for the SECOND host-to-device crossing of the same frames in
+ * PyTorchGPUPrefetcher.push (api/trainer.py:211-228).  index: int32 [n] device, src rows addressed by slot. */
+int srl_gather_rows(void* stream, const void* src, int64_t row_bytes, const int32_t* index, int64_t n, void* dst);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser on one flat parameter buffer.

@@ -25,6 +25,7 @@ from srl_amd.algorithm.ppo_types import PPORolloutAnalyzedResult, SampleAnalyzed
 from srl_amd.api import policy as policy_api
 from srl_amd.api.env_utils import DiscreteAction
 from srl_amd.namedarray import NamedArray
+from srl_amd.runtime.obs_ring import ObsRing, RingObs
 
 
 def to_device_leaf(x, device, kind: str) -> torch.Tensor:
@@ -34,6 +35,8 @@ def to_device_leaf(x, device, kind: str) -> torch.Tensor:
     Device tensors pass through (only the dtype is checked).
     """
     want = {"flag": torch.uint8, "real": torch.float32, "index": torch.int32}.get(kind)
+    if isinstance(x, RingObs):  # rows that never left HBM since their rollout (runtime/obs_ring.py)
+        return x
     if kind == "as-is":  # already in its wire dtype (wire_leaf): only the placement changes
         t = x if isinstance(x, torch.Tensor) else torch.from_numpy(x)
         return t.to(device, non_blocking=True).contiguous()
@@ -57,6 +60,8 @@ def to_device_leaf(x, device, kind: str) -> torch.Tensor:
 def wire_leaf(x, kind: str):
     """Like ``to_device_leaf`` but a host leaf STAYS on the host: a contiguous numpy array in the dtype the kernels read
     (what the native step driver copies straight into a captured step's static inputs).  Device tensors pass through."""
+    if isinstance(x, RingObs):
+        return x
     if isinstance(x, torch.Tensor):
         return to_device_leaf(x, x.device, kind) if x.is_cuda else wire_leaf(x.numpy(), kind)
     a = np.asarray(x)
@@ -116,6 +121,7 @@ class ActorCriticPolicy(policy_api.Policy):
         self._seed = int(seed)
         self._rollout_calls = 0
         self._distributed = False
+        self._obs_ring: Optional[ObsRing] = None
         self._popart_updates, self._popart_burn_in = 0, float("inf")  # PopArtValueHead defaults (popart.py:16,28-29)
         self._popart_beta = ns.POPART_BETA
         self.denormalize_value_during_rollout = denormalize_value_during_rollout
@@ -239,6 +245,20 @@ class ActorCriticPolicy(policy_api.Policy):
         dist.broadcast(v, src=src, group=group)
         self._version = int(v.item())
 
+    # ------------------------------------------------------------------ HBM observation ring
+    def attach_obs_ring(self, ring: Optional[ObsRing]):
+        """From now on ``rollout`` stages every batch's observations in ``ring`` (in the layout this network's first
+        layer reads) and returns their ring references as ``analyzed_result.obs_ref``: the actor stores them with the
+        step, the trainer's feed binds the sample's observations to the ring rows instead of uploading the frames a
+        second time (runtime/obs_ring.py).  ``None`` detaches."""
+        if ring is not None and (dict(ring.layout) != self._net.obs_stage_layout() or
+                                 dict(ring.raw_shape) != self._net.obs_raw_shapes()):
+            raise ValueError("observation ring was built for a different network (layouts / shapes differ)")
+        self._obs_ring = ring
+
+    def make_obs_ring(self, capacity_rows: int, patch_rows: Optional[int] = None) -> ObsRing:
+        return ObsRing.for_policy(self, capacity_rows, patch_rows)
+
     # ------------------------------------------------------------------ inference
     ROLLOUT_PIECE = 2048  # rows per piece when a big host batch is streamed in (copy of piece i+1 under the compute of i)
 
@@ -248,23 +268,22 @@ class ActorCriticPolicy(policy_api.Policy):
         n = int(next(iter(host.values())).shape[0])
         if (not self.spec.num_rnn_layers and n >= 2 * self.ROLLOUT_PIECE
                 and not any(isinstance(v, torch.Tensor) for v in host.values())):
-            action, logp, value = self._rollout_streamed(host, n, requests.is_evaluation)
-            return policy_api.RolloutResult(action=DiscreteAction(action.cpu().numpy()),
-                                            analyzed_result=PPORolloutAnalyzedResult(log_probs=logp.cpu().numpy(),
-                                                                                     value=value.cpu().numpy()),
-                                            policy_state=None)
-        obs = {k: to_device_leaf(v, self.device, "obs") for k, v in host.items()}
-        state = None
-        if self.spec.num_rnn_layers:  # requests carry [n, layers, H]; the state is used as given (:473-481)
-            ps = requests.policy_state
-            if ps is None:
-                raise ValueError("recurrent policy: the request carries no policy_state")
-            state = {k: np.asarray(ps[k]) for k, _ in self._state_keys()}
-        action, logp, value = self._rollout_rows(obs, n, requests.is_evaluation, state)
-        return policy_api.RolloutResult(action=DiscreteAction(action.cpu().numpy()),
-                                        analyzed_result=PPORolloutAnalyzedResult(log_probs=logp.cpu().numpy(),
-                                                                                 value=value.cpu().numpy()),
-                                        policy_state=self._packed_last_state())
+            action, logp, value, refs = self._rollout_streamed(host, n, requests.is_evaluation)
+            state = None
+        else:
+            obs = {k: to_device_leaf(v, self.device, "obs") for k, v in host.items()}
+            state = None
+            if self.spec.num_rnn_layers:  # requests carry [n, layers, H]; the state is used as given (:473-481)
+                ps = requests.policy_state
+                if ps is None:
+                    raise ValueError("recurrent policy: the request carries no policy_state")
+                state = {k: np.asarray(ps[k]) for k, _ in self._state_keys()}
+            action, logp, value, refs = self._rollout_rows(obs, n, requests.is_evaluation, state)
+            state = self._packed_last_state()
+        analyzed = PPORolloutAnalyzedResult(log_probs=logp.cpu().numpy(), value=value.cpu().numpy(),
+                                            obs_ref=None if refs is None else refs.reshape(n, 1))
+        return policy_api.RolloutResult(action=DiscreteAction(action.cpu().numpy()), analyzed_result=analyzed,
+                                        policy_state=state)
 
     def _rollout_streamed(self, host, n, is_evaluation):
         """A big batch of host observations (the policy worker's 10 240-request batches are 289 MB of frames): rows
@@ -307,10 +326,13 @@ class ActorCriticPolicy(policy_api.Policy):
             staged[i & 1] = (dev, ev)
 
         stage(0)
+        refs = [] if self._obs_ring is not None else None
         for i, (r0, r1) in enumerate(bounds):
             dev, ev = staged[i & 1]
             main.wait_event(ev)
-            a_i, l_i, v_i = self._rollout_rows(dev, r1 - r0, is_eval[r0:r1], None)
+            a_i, l_i, v_i, r_i = self._rollout_rows(dev, r1 - r0, is_eval[r0:r1], None)
+            if refs is not None:
+                refs.append(r_i)
             action[r0:r1].copy_(a_i)
             logp[r0:r1].copy_(l_i)
             value[r0:r1].copy_(v_i)
@@ -318,11 +340,12 @@ class ActorCriticPolicy(policy_api.Policy):
                 t.record_stream(main)
             if i + 1 < len(bounds):
                 stage(i + 1)  # issued after piece i's launches: a pageable copy blocks the host, not the GPU
-        return action, logp, value
+        return action, logp, value, (None if refs is None else np.concatenate(refs))
 
     def _rollout_rows(self, obs, n, is_evaluation, state):
-        """One inference pass over ``n`` independent rows: device ``(action, log_prob [n,1], value [n,vd])``; the new
-        recurrent states are left in ``net.last_state``.  ``state``: ``{key: [n, layers, W]}`` host or device, or None."""
+        """One inference pass over ``n`` independent rows: device ``(action, log_prob [n,1], value [n,vd])`` and the rows'
+        observation-ring references (int64 numpy [n], or None without a ring); the new recurrent states are left in
+        ``net.last_state``.  ``state``: ``{key: [n, layers, W]}`` host or device, or None."""
         obs = dict(obs)  # the caller keeps its dict whole: a streamed piece must still own EVERY staged tensor (the mask
         # included) when it hands them to the main stream with record_stream
         avail = obs.pop("available_action", None)
@@ -330,6 +353,10 @@ class ActorCriticPolicy(policy_api.Policy):
             avail = avail.to(torch.uint8)
         is_eval = np.asarray(is_evaluation).reshape(-1)
         is_eval = to_device_leaf(np.broadcast_to(is_eval, (n,)) if is_eval.size == 1 else is_eval, self.device, "flag")
+        refs = None
+        if self._obs_ring is not None:  # the rows stay in HBM for the trainer; the forward below reads them from there
+            refs, staged = self._obs_ring.put({k: obs[k] for k in self._obs_ring.keys()})
+            obs.update(staged)
         rnn = None
         if self.spec.num_rnn_layers:
             rnn = self._rnn_ctx(NamedArray(**{k: v[None] for k, v in state.items()}), 1, n, None)
@@ -344,7 +371,7 @@ class ActorCriticPolicy(policy_api.Policy):
             action = torch.empty((n, len(heads)), dtype=torch.int64, device=self.device)
             hip.categorical_sample(logits, avail, is_eval, heads, self._seed, self._rollout_calls, action, logp)
         self._rollout_calls += 1
-        return action, logp, value
+        return action, logp, value, refs
 
     def _rnn_ctx_with_burn_in(self, obs, avail_unused, policy_state, on_reset, burn, T, B) -> Optional[RnnCtx]:
         """Recurrent context for rows [burn, burn + T) of leaves that start `burn` rows earlier: the `burn` rows before
@@ -358,7 +385,10 @@ class ActorCriticPolicy(policy_api.Policy):
             return self._rnn_ctx(ps, T, B, on_reset[:T])
         Cl = self._chunk_len
         K = max(T // Cl, 1)
-        win = lambda x: torch.cat([x[i * Cl:i * Cl + burn] for i in range(K)], dim=0)  # [K*burn, B, ...] time-major
+        def win(x):  # [K*burn, B, ...] time-major
+            parts = [x[i * Cl:i * Cl + burn] for i in range(K)]
+            return RingObs.cat(parts) if isinstance(x, RingObs) else torch.cat(parts, dim=0)
+
         n = K * burn * B
         w_obs = {k: win(v).reshape(n, *v.shape[2:]) for k, v in obs.items() if k != "available_action"}
         w_ps = NamedArray(**{k: win(v) for k, v in policy_state.items()})

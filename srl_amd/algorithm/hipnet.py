@@ -28,6 +28,7 @@ import torch
 
 from srl_amd import hip
 from srl_amd.algorithm import netspec as ns
+from srl_amd.runtime.obs_ring import RingObs
 
 
 class Buf(NamedTuple):
@@ -154,6 +155,25 @@ class HipNet:
         for info in self.spec.params.values():
             host[info.offset:info.offset + info.numel] = info.to_internal(torch.as_tensor(named[info.key]).cpu())
         return host
+
+    # ------------------------------------------------------------------ observation ring (runtime/obs_ring.py)
+    def _encoders(self):
+        return list(self.spec.obs_encoders) + list(self.spec.state_encoders or [])
+
+    def obs_stage_layout(self) -> Dict[str, tuple]:
+        """key -> layout in which an ``ObsRing`` keeps the rows of that observation: ("s2d", block) for an image whose
+        strided first convolution reads the space-to-depth re-tiling (the ring then also keeps the whole-observation
+        LayerNorm statistics of every row), ("raw",) otherwise."""
+        out = {}
+        for enc in self._encoders():
+            conv = next((L for L in enc.layers if isinstance(L, ns.ConvSpec) and L.first), None)
+            lay = ("s2d", int(conv.s2d)) if conv is not None and conv.s2d and not self.force_explicit_conv else ("raw",)
+            if out.setdefault(enc.key, lay) != lay:
+                out[enc.key] = ("raw",)
+        return out
+
+    def obs_raw_shapes(self) -> Dict[str, tuple]:
+        return {enc.key: ((enc.shape,) if isinstance(enc.shape, int) else tuple(enc.shape)) for enc in self._encoders()}
 
     def _p(self, name):
         return self.flat.data_ptr() + 4 * self.spec.params[name].offset
@@ -361,6 +381,14 @@ class HipNet:
         cur: Optional[Buf] = None
         cur_act = 0
         pending_obs_ln = None
+        staged = None
+        if isinstance(obs, RingObs):  # rows kept in the HBM observation ring since their rollout
+            if obs.rows != n:
+                raise hip.HipError(f"observation `{enc.key}`: {obs.rows} ring rows for {n} network rows")
+            if obs.layout[0] == "s2d":
+                staged = obs  # already in the first convolution's layout, statistics beside them
+            else:
+                obs = obs.gather_raw(self.ws, f"{tag}{enc.key}.ring")
         for L in enc.layers:
             if isinstance(L, ns.LayerNormSpec):
                 if cur is None:
@@ -453,16 +481,22 @@ class HipNet:
                     is_u8 = obs.dtype == torch.uint8
                     if not is_u8 and obs.dtype != torch.float32:
                         raise hip.HipError(f"image observation `{enc.key}` must be uint8 or float32, got {obs.dtype}")
-                    mean = self.ws.get(f"{tag}{pending_obs_ln.prefix}.mean", n)
-                    rstd = self.ws.get(f"{tag}{pending_obs_ln.prefix}.rstd", n)
                     gam, bet = self._p(f"{pending_obs_ln.prefix}.weight"), self._p(f"{pending_obs_ln.prefix}.bias")
-                    src = obs
-                    if L.s2d:
-                        src = self.ws.get(f"{tag}{L.prefix}.s2d", n * c * h * w, dtype=obs.dtype)
-                        hip.obs_space_to_depth(obs.data_ptr(), is_u8, n, c, h, w, L.s2d, src.data_ptr(), mean.data_ptr(),
-                                               rstd.data_ptr())
+                    if staged is not None and not (implicit and L.s2d and staged.layout == ("s2d", int(L.s2d))):
+                        raise hip.HipError(f"observation `{enc.key}`: ring layout {staged.layout} does not fit this network")
+                    if staged is not None:
+                        # no re-tiling pass and no statistics pass: both were done once, when the rollout uploaded the row
+                        src, mean, rstd = staged.resolve(self.ws, f"{tag}{L.prefix}")
                     else:
-                        hip.obs_ln_stats(obs.data_ptr(), is_u8, n, c * h * w, mean.data_ptr(), rstd.data_ptr())
+                        mean = self.ws.get(f"{tag}{pending_obs_ln.prefix}.mean", n)
+                        rstd = self.ws.get(f"{tag}{pending_obs_ln.prefix}.rstd", n)
+                        src = obs
+                        if L.s2d:
+                            src = self.ws.get(f"{tag}{L.prefix}.s2d", n * c * h * w, dtype=obs.dtype)
+                            hip.obs_space_to_depth(obs.data_ptr(), is_u8, n, c, h, w, L.s2d, src.data_ptr(), mean.data_ptr(),
+                                                   rstd.data_ptr())
+                        else:
+                            hip.obs_ln_stats(obs.data_ptr(), is_u8, n, c * h * w, mean.data_ptr(), rstd.data_ptr())
                     if implicit:
                         hip.conv2d_obs_fwd(desc, src.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet,
                                            self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"), y.ptr,

@@ -33,6 +33,7 @@ from srl_amd.algorithm import netspec as ns
 from srl_amd.algorithm.actor_critic import ActorCriticPolicy, to_device_leaf, wire_leaf
 from srl_amd.api.trainer import PytorchTrainer, TrainerStepResult, register
 from srl_amd.namedarray import recursive_apply
+from srl_amd.runtime.obs_ring import RingObs
 
 logger = logging.getLogger("MAPPO")
 
@@ -329,7 +330,8 @@ class MultiAgentPPO(PytorchTrainer):
 
         # ---- the sample's leaves in their wire dtypes: on the device -- or, for a captured step (use_graph), wherever they
         # are: the native step driver copies them straight into the graph's static inputs ---------------------------------
-        graphed = self.use_graph and not self._dist and self._opt in ('adam', 'adamw')
+        graphed = (self.use_graph and not self._dist and self._opt in ('adam', 'adamw')
+                   and not any(isinstance(v, RingObs) for v in sample.obs.values()))  # ring rows are bound per sample
         leaf = (lambda x, kind: wire_leaf(x, kind)) if graphed else (lambda x, kind: to_device_leaf(x, dev, kind))
         L = dict(on_reset=leaf(sample.on_reset, "flag"), done=leaf(sample.done, "flag"),
                  truncated=leaf(sample.truncated, "flag"), reward=leaf(sample.reward, "real"),

@@ -124,7 +124,7 @@ class SMACPolicy(ActorCriticPolicy):
         is_eval = np.asarray(requests.is_evaluation)
         if self._shared and is_eval.size == bs:  # one flag per environment: every agent of it evaluates (or not)
             is_eval = np.broadcast_to(is_eval.reshape(bs, 1), (bs, self._n_agents))
-        action, logp, value = self._rollout_rows(obs, n, is_eval, state)
+        action, logp, value, refs = self._rollout_rows(obs, n, is_eval, state)
         if self._use_popart and self.denormalize_value_during_rollout:
             value = self.denormalize_value(value)
         unfold = (lambda t: t.reshape(bs, self._n_agents, *t.shape[1:])) if self._shared else (lambda t: t)
@@ -133,8 +133,9 @@ class SMACPolicy(ActorCriticPolicy):
             new_state = SMACPolicyState(*(unfold(self._net.last_state[tag].permute(1, 0, 2)).cpu().numpy()
                                           for _, tag in self._state_keys()))
         return policy_api.RolloutResult(action=SMACAction(unfold(action).cpu().numpy()),
-                                        analyzed_result=PPORolloutAnalyzedResult(log_probs=unfold(logp).cpu().numpy(),
-                                                                                 value=unfold(value).cpu().numpy()),
+                                        analyzed_result=PPORolloutAnalyzedResult(
+                                            log_probs=unfold(logp).cpu().numpy(), value=unfold(value).cpu().numpy(),
+                                            obs_ref=None if refs is None else unfold(refs.reshape(n, 1))),
                                         policy_state=new_state)
 
 

@@ -50,6 +50,7 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   if (d->M == 0 || d->N == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (srlskinny::try_skinny(st, d)) {  // one extent <= 16: bandwidth kernels instead of padded MFMA tiles
+    srl_count_dispatch(SRL_DISP_SKINNY);
     SRL_LAUNCH_CHECK();
     return 0;
   }

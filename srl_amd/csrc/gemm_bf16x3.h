@@ -392,6 +392,7 @@ inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   }
   a.grp_sz = (unsigned)tiles_m * a.grp_n;
   dim3 grid((unsigned)(nblk * nsplit), 1, 1);
+  srl_count_dispatch(SRL_DISP_GEMM3);
   hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB>), grid, dim3(256), 0, st, a);
   return 0;
 }

@@ -1175,6 +1175,7 @@ inline int launch(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   const long nblk = tiles_m * a.tiles_n * a.nbatch;
   if (nblk > 0x7fffffffL || nsplit > 65535) return -EINVAL;
   dim3 grid((unsigned)nblk, 1, (unsigned)nsplit);
+  srl_count_dispatch(SRL_DISP_GEMM_F32);
   hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, GEN, KB, OBS8>), grid, dim3(WM * WN * 64), 0, st, a);
   return 0;
 }

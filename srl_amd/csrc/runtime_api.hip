@@ -1,6 +1,8 @@
 // Error reporting and device queries of libsrlhip.so.
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "srl_common.h"
 
 static thread_local char g_err[512] = "";
@@ -10,6 +12,20 @@ void srl_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+static std::atomic<long long> g_dispatch[SRL_DISP_FAMILIES];
+
+void srl_count_dispatch(int family) {
+  if (family >= 0 && family < SRL_DISP_FAMILIES) g_dispatch[family].fetch_add(1, std::memory_order_relaxed);
+}
+
+extern "C" int srl_dispatch_counts(int64_t* out, int n, int reset) {
+  SRL_CHECK_ARG(out != nullptr || n == 0, "null output");
+  for (int i = 0; i < n; ++i) out[i] = i < SRL_DISP_FAMILIES ? (int64_t)g_dispatch[i].load(std::memory_order_relaxed) : 0;
+  if (reset)
+    for (int i = 0; i < SRL_DISP_FAMILIES; ++i) g_dispatch[i].store(0, std::memory_order_relaxed);
+  return 0;
 }
 
 extern "C" int srl_abi_version(void) { return SRL_HIP_ABI_VERSION; }

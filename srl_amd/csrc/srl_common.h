@@ -12,6 +12,19 @@
 
 void srl_set_error(const char* fmt, ...);
 
+// Which kernel family an entry point chose (host-side launch counters behind srl_dispatch_counts: the tests use them to
+// assert that a step really ran on the kernels a benchmark times, include/srl_hip.h)
+enum SrlDispatch {
+  SRL_DISP_GEMM3 = 0,     // gemm3_kernel: float32 operands as exact bf16 pieces on the bf16 matrix cores
+  SRL_DISP_GEMM_F32 = 1,  // gemm_kernel: float32 MFMA
+  SRL_DISP_SKINNY = 2,    // skinny_{n,m,k}_kernel
+  SRL_DISP_OBS_FWD_BF16 = 3,
+  SRL_DISP_OBS_BWD_BF16 = 4,
+  SRL_DISP_GEMM2H = 5,    // gemm3_kernel's two-plane f16 variant (three piece products)
+  SRL_DISP_FAMILIES = 8
+};
+void srl_count_dispatch(int family);
+
 #define SRL_CHECK_ARG(cond, msg)                                   \
   do {                                                             \
     if (!(cond)) {                                                 \

@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("SRL_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsrlhip.so")
 _lib = None
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -69,6 +69,7 @@ _SIGNATURES = {
     "srl_abi_version": (c_int, []),
     "srl_last_error": (c_char_p, []),
     "srl_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "srl_dispatch_counts": (c_int, [POINTER(c_int64), c_int, c_int]),
     "srl_gae_scan": (c_int, [c_void_p] + [c_void_p] * 8 + [c_int, c_int, c_int, c_double, c_double, c_double,
                                                              c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_gae_scan_workspace_bytes": (c_long, [c_int, c_int]),
@@ -115,6 +116,7 @@ _SIGNATURES = {
     "srl_colsum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int]),
     "srl_copy2d": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int]),
     "srl_u8_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
+    "srl_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "srl_grad_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                c_float, c_float, c_int, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
@@ -254,6 +256,16 @@ def device_info():
     buf = ctypes.create_string_buffer(128)
     _check(lib().srl_device_info(ctypes.byref(n), ctypes.byref(l), buf, 128), "srl_device_info")
     return dict(num_cus=n.value, lds_bytes_per_cu=l.value, arch=buf.value.decode())
+
+
+DISPATCH_FAMILIES = ("gemm3", "gemm_f32", "skinny", "obs_fwd_bf16", "obs_bwd_bf16", "gemm2h")
+
+
+def dispatch_counts(reset: bool = False) -> dict:
+    """Launches per kernel family since the last reset (``srl_dispatch_counts``): which kernels a step really ran on."""
+    buf = (c_int64 * 8)()
+    _check(lib().srl_dispatch_counts(buf, 8, int(bool(reset))), "srl_dispatch_counts")
+    return {name: int(buf[i]) for i, name in enumerate(DISPATCH_FAMILIES)}
 
 
 def gae_scan_workspace(B, Nc, device) -> torch.Tensor:
@@ -691,6 +703,13 @@ def obs_space_to_depth(obs_ptr, is_u8, n, C, H, W, s, out_ptr, mean_ptr, rstd_pt
     with _scope("obs_space_to_depth"):
         _check(lib().srl_obs_space_to_depth(_stream(), obs_ptr, int(is_u8), n, C, H, W, s, out_ptr, mean_ptr, rstd_ptr),
                "srl_obs_space_to_depth")
+
+
+def gather_rows(src_ptr, row_bytes, index: torch.Tensor, n, dst_ptr):
+    """dst[i, :] = src[index[i], :] (``srl_gather_rows``); ``index`` int32 [>= n] on the device."""
+    with _scope("gather_rows", 2.0 * row_bytes * n):
+        _check(lib().srl_gather_rows(_stream(), src_ptr, int(row_bytes), _ptr(index, torch.int32, "index"), int(n), dst_ptr),
+               "srl_gather_rows")
 
 
 def conv2d_obs_bwd_workspace(d: ConvDesc) -> int:

@@ -37,9 +37,13 @@ def _flat_leaves(x) -> "OrderedDict[str, np.ndarray]":
 
 class SampleRing:
 
-    def __init__(self, template, batch_size: int, slots: int = 2, device: Optional[str] = None, pin: Optional[bool] = None):
+    def __init__(self, template, batch_size: int, slots: int = 2, device: Optional[str] = None, pin: Optional[bool] = None,
+                 obs_ring=None):
         """``template``: one trajectory (``SampleBatch`` / ``NamedArray`` with leaves ``[Tb, ...]``) fixing keys, dtypes
-        and trailing shapes.  ``device``: where ``get_device`` puts batches (None: host only)."""
+        and trailing shapes.  ``device``: where ``get_device`` puts batches (None: host only).  ``obs_ring``: the policy's
+        HBM observation ring (``runtime/obs_ring.py``): ``get_device`` then binds a batch's observations to the rows the
+        rollout left there (by the ``analyzed_result.obs_ref`` stamps the samples carry) and uploads only what is not --
+        the scalar leaves, and any row whose stamp is no longer alive."""
         if slots < 1 or batch_size < 1:
             raise ValueError("slots and batch_size must be positive")
         self._template = template
@@ -62,6 +66,9 @@ class SampleRing:
         self._np = [OrderedDict((k, t.numpy()) for k, t in blk.items()) for blk in self._host]
         self._dev: List[Optional["OrderedDict[str, torch.Tensor]"]] = [None] * self.slots
         self._copied: List[Optional[torch.cuda.Event]] = [None] * self.slots
+        self.obs_ring = obs_ring
+        self._ring_keys = frozenset(f"obs.{k}" for k in obs_ring.keys()) & frozenset(leaves) if obs_ring is not None else frozenset()
+        self._leases = [None] * self.slots
         self._stream = None
         self._lock = threading.Lock()
         self._free = deque(range(self.slots))
@@ -196,20 +203,35 @@ class SampleRing:
         return self._wrap(slot, self._np[slot])
 
     def _start_copy(self, slot: int):
-        """Enqueue the H2D copies of a complete slot on the side stream (idempotent until the slot is released)."""
+        """Enqueue the H2D copies of a complete slot on the side stream (idempotent until the slot is released).  Leaves
+        that an observation ring serves are not copied here (``_bind_or_copy``)."""
         if self._copied[slot] is not None:
             return
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=self.device)
         if self._dev[slot] is None:
             self._dev[slot] = OrderedDict((k, torch.empty(t.shape, dtype=t.dtype, device=self.device))
-                                          for k, t in self._host[slot].items())
+                                          for k, t in self._host[slot].items() if k not in self._ring_keys)
         with torch.cuda.stream(self._stream):
             for k, t in self._host[slot].items():
-                self._dev[slot][k].copy_(t, non_blocking=True)
+                if k not in self._ring_keys:
+                    self._dev[slot][k].copy_(t, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._stream)
         self._copied[slot] = ev
+
+    def _bind_or_copy(self, slot: int):
+        """Observation leaves of a taken slot: ``RingObs`` over the rows the rollout left in HBM (rows without a live
+        stamp are uploaded from the slot's host block on the way), or -- when the ring cannot serve the batch -- plain
+        device copies on the caller's stream."""
+        refs = self._np[slot].get("analyzed_result.obs_ref")
+        host_obs = {k[4:]: self._host[slot][k] for k in self._ring_keys}
+        bound = self.obs_ring.bind(refs, host_obs)
+        if bound is None:
+            return {k: self._host[slot][k].to(self.device, non_blocking=True) for k in self._ring_keys}
+        rows, lease = bound
+        self._leases[slot] = lease
+        return {f"obs.{k}": v for k, v in rows.items()}
 
     def get_device(self):
         """Oldest complete batch with device leaves.  Its copies run on the ring's side stream and the caller's
@@ -225,7 +247,11 @@ class SampleRing:
             nxt = self._full[0] if self._full else None
         if nxt is not None:
             self._start_copy(nxt)
-        return self._wrap(slot, self._dev[slot])
+        leaves = self._dev[slot]
+        if self._ring_keys:
+            leaves = dict(leaves)
+            leaves.update(self._bind_or_copy(slot))
+        return self._wrap(slot, leaves)
 
     def release(self, batch_or_slot):
         """Return a slot to the producers.  Host blocks are reusable once the H2D copy has finished (waited here);
@@ -236,6 +262,11 @@ class SampleRing:
         if ev is not None:
             ev.synchronize()
             self._copied[slot] = None
+        if self._leases[slot] is not None:  # the observation rows may be lapped once the consumer's work has run
+            lease, self._leases[slot] = self._leases[slot], None
+            if lease.uploaded is not None:
+                lease.uploaded.synchronize()  # patch uploads read this slot's host block
+            self.obs_ring.release(lease)
         if self._dev[slot] is not None and self._stream is not None:
             # the next copy into these device buffers must not overtake kernels still reading them
             self._stream.wait_stream(torch.cuda.current_stream(self.device))

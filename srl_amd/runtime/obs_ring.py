@@ -1,0 +1,402 @@
+"""HBM observation ring: the frames ``rollout`` uploaded stay on the device for the trainer.
+
+In the reference every observation crosses the host-device link twice: once when the policy worker runs inference on
+it (``actor_critic_policy.py:467-469``) and once more inside the training sample (``api/trainer.py:211-228``).  At Atari
+sizes the second crossing is 14.9 GB per update -- 261 ms over a 57 GB/s link against 180 ms of compute -- and it stays
+the bound at every GPU count, because copy and compute shrink together.  Nothing in the path needs it: the bytes the
+trainer wants are the bytes the rollout already put in HBM.
+
+``ObsRing`` keeps them.  It is a ring of fixed-size rows per observation key, allocated by a monotonically increasing
+*sequence number* (slot = sequence mod capacity):
+
+* ``put`` (called by ``ActorCriticPolicy.rollout`` on every inference batch) takes the batch's rows -- device tensors,
+  typically the ``InferenceBatcher``'s staging block -- and writes them into the next run of slots **in the layout the
+  network's first layer reads**: for a strided first convolution that is the space-to-depth re-tiling plus the
+  whole-observation LayerNorm statistics (``srl_obs_space_to_depth``; the pass the inference forward needs anyway, now
+  writing into the ring instead of a scratch buffer), raw rows otherwise.  It returns the rows' sequence numbers; the
+  rollout hands them back to the actor as ``analyzed_result.obs_ref``, a leaf the actor stores verbatim in every step
+  (``actor_worker.py:521-535`` copies the whole response into the memory step), so they arrive at the trainer inside
+  the sample, ``[Tb, B, 1]`` int64, with no change on the actor side.
+* ``bind`` (called by ``SampleRing.get_device``) checks a sample's references -- a row is alive iff no later allocation
+  has lapped it -- uploads only the rows that are NOT alive (terminal observations never sent for inference, rows a
+  slow sample lost to the ring, or everything when the sample carries no references: the full-copy path, through the
+  same kernels) into a *patch area* behind the ring that belongs to this sample alone, and returns a ``RingObs`` per
+  key: storage + an int32 slot index on the device.  The trainer's row
+  chunks gather their staged rows from there (``srl_gather_rows``: the same bytes per row as the space-to-depth pass it
+  replaces) and never see the host copy of the frames.
+* a *lease* pins the rows of a bound sample until ``release``: an allocation that would lap leased rows raises
+  ``BufferError`` instead of corrupting a step in flight.
+
+Sharding: one ring per GPU, holding the env columns that GPU both serves inference for and trains on.
+In-process (inference thread + trainer thread, as in the reference's local mode); thread-safe.
+"""
+import threading
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from srl_amd import hip
+
+
+class RingObs:
+    """Observation rows that live in an ``ObsRing``: ``[*lead, *raw_shape]`` in the eyes of the sample, an int32 slot per
+    row (``index``, device) or one contiguous run of slots (``span``) underneath.  Supports what the trainer does to an
+    observation leaf: slicing the leading dimension, folding / flattening the leading dimensions, concatenation."""
+
+    def __init__(self, ring: "ObsRing", key: str, lead: Tuple[int, ...], index: Optional[torch.Tensor] = None,
+                 span: Optional[int] = None):
+        self.ring, self.key, self.lead = ring, key, tuple(int(d) for d in lead)
+        self.index, self.span = index, span
+        assert (index is None) != (span is None)
+
+    # ---- the tensor-like surface the trainer uses
+    @property
+    def shape(self):
+        return (*self.lead, *self.ring.raw_shape[self.key])
+
+    @property
+    def dtype(self):
+        return self.ring.dtype[self.key]
+
+    @property
+    def device(self):
+        return torch.device(self.ring.device)
+
+    is_cuda = True
+
+    @property
+    def rows(self) -> int:
+        return int(np.prod(self.lead, dtype=np.int64))
+
+    @property
+    def layout(self):
+        return self.ring.layout[self.key]
+
+    def _flat_index(self) -> torch.Tensor:
+        if self.index is None:  # a run of slots: materialised only if somebody slices it unevenly
+            return torch.arange(self.span, self.span + self.rows, dtype=torch.int32, device=self.ring.device)
+        return self.index.reshape(-1)
+
+    def __getitem__(self, loc):
+        if not isinstance(loc, slice):
+            raise TypeError("RingObs supports slices of its leading dimension only")
+        start, stop, step = loc.indices(self.lead[0])
+        if step != 1:
+            raise TypeError("RingObs slices must be contiguous")
+        n0 = max(stop - start, 0)
+        inner = int(np.prod(self.lead[1:], dtype=np.int64))
+        if self.span is not None:
+            return RingObs(self.ring, self.key, (n0, *self.lead[1:]), span=self.span + start * inner)
+        return RingObs(self.ring, self.key, (n0, *self.lead[1:]), index=self.index.reshape(self.lead[0], -1)[start:stop])
+
+    def reshape(self, *shape):
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else tuple(shape)
+        raw = tuple(self.ring.raw_shape[self.key])
+        if len(shape) <= len(raw) or tuple(shape[len(shape) - len(raw):]) != raw:
+            raise ValueError(f"RingObs.reshape keeps the row shape {raw}; got {shape}")
+        lead = shape[:len(shape) - len(raw)]
+        if -1 in lead:
+            known = int(np.prod([d for d in lead if d != -1], dtype=np.int64))
+            lead = tuple(self.rows // max(known, 1) if d == -1 else d for d in lead)
+        if int(np.prod(lead, dtype=np.int64)) != self.rows:
+            raise ValueError(f"cannot reshape {self.rows} rows into {lead}")
+        if self.span is not None:
+            return RingObs(self.ring, self.key, lead, span=self.span)
+        return RingObs(self.ring, self.key, lead, index=self.index.reshape(-1))
+
+    @staticmethod
+    def cat(parts):
+        """Concatenation along the leading dimension (the burn-in windows of a recurrent policy)."""
+        first = parts[0]
+        idx = torch.cat([p._flat_index().reshape(p.lead[0], -1) for p in parts], dim=0)
+        return RingObs(first.ring, first.key, (idx.shape[0], *first.lead[1:]), index=idx.contiguous())
+
+    # ---- what the network reads
+    def resolve(self, ws, name: str):
+        """Contiguous staged rows ``[n, ...]`` (+ per-row LayerNorm statistics for the ``s2d`` layout, else None, None):
+        views of the ring for a run of slots, gathered into the workspace buffers ``name + .s2d / .mean / .rstd`` otherwise."""
+        r, k, n = self.ring, self.key, self.rows
+        store = r.storage[k]
+        row_elems = store[0].numel()
+        stats = r.layout[k][0] == "s2d"
+        if self.span is not None:
+            s0 = self.span
+            return (store[s0:s0 + n], r.mean[k][s0:s0 + n] if stats else None, r.rstd[k][s0:s0 + n] if stats else None)
+        idx = self.index.reshape(-1)
+        frames = ws.get(f"{name}.s2d", n * row_elems, dtype=store.dtype)[:n * row_elems].view(n, *store.shape[1:])
+        hip.gather_rows(store.data_ptr(), row_elems * store.element_size(), idx, n, frames.data_ptr())
+        if not stats:
+            return frames, None, None
+        mean = ws.get(f"{name}.mean", n)
+        rstd = ws.get(f"{name}.rstd", n)
+        hip.gather_rows(r.mean[k].data_ptr(), 4, idx, n, mean.data_ptr())
+        hip.gather_rows(r.rstd[k].data_ptr(), 4, idx, n, rstd.data_ptr())
+        return frames, mean, rstd
+
+    def gather_raw(self, ws, name: str) -> torch.Tensor:
+        """The rows as one contiguous raw tensor ``[n, *raw_shape]`` (``raw`` layout only)."""
+        if self.layout[0] != "raw":
+            raise hip.HipError(f"observation `{self.key}` is staged in the `{self.layout[0]}` layout: no raw rows in the ring")
+        frames, _, _ = self.resolve(ws, name)
+        return frames.view(self.rows, *self.ring.raw_shape[self.key])
+
+
+class ObsLease:
+    """What ``bind`` pinned for one sample: ring rows from sequence ``min_seq`` on, and a run of the patch area."""
+
+    def __init__(self, ring, min_seq):
+        self.ring, self.min_seq = ring, min_seq
+        self.patch_start = None  # first patch-area sequence number this lease holds (None: no patched rows)
+        self.uploaded = None  # event after the uploads `bind` issued from the caller's host blocks (None: there were none)
+
+
+class _Circular:
+    """Sequence-number allocator of a circular region: slot = sequence % capacity, a run never straddles the end."""
+
+    def __init__(self, capacity):
+        self.capacity, self.head = int(capacity), 0
+
+    def alloc(self, n, floor, what):
+        if n > self.capacity:
+            raise BufferError(f"{n} rows do not fit {what} of {self.capacity} rows")
+        seq = self.head
+        if seq % self.capacity + n > self.capacity:  # the tail is skipped: its sequence numbers are consumed
+            seq = (seq // self.capacity + 1) * self.capacity
+        if floor is not None and seq + n - self.capacity > floor:
+            raise BufferError(f"{what}: the allocation would overwrite rows a training step has leased "
+                              f"(capacity {self.capacity} rows)")
+        self.head = seq + n
+        return seq
+
+
+class ObsRing:
+
+    def __init__(self, layout: Dict[str, tuple], raw_shape: Dict[str, Tuple[int, ...]], capacity_rows: int, device: str,
+                 patch_rows: Optional[int] = None):
+        """``layout``: key -> ("s2d", block) | ("raw",) as ``HipNet.obs_stage_layout()`` reports it; ``raw_shape``: key -> the
+        observation's shape as the environment produces it.  ``patch_rows``: size of the patch area behind the ring, where
+        ``bind`` stages the rows of a sample that are not alive in the ring (a lapped row cannot be re-staged in the ring
+        itself: the rows it would overwrite are the sample's own next-oldest ones); default capacity / 8.  Storage is
+        allocated at the first ``put`` of a key (its dtype -- uint8 frames or float32 -- is the producer's)."""
+        if capacity_rows < 1:
+            raise ValueError("capacity_rows must be positive")
+        self.layout = {k: tuple(v) for k, v in layout.items()}
+        self.raw_shape = {k: tuple(int(d) for d in raw_shape[k]) for k in layout}
+        self.capacity, self.device = int(capacity_rows), device
+        self.patch_capacity = max(1, self.capacity // 8) if patch_rows is None else max(1, int(patch_rows))
+        self.storage: Dict[str, torch.Tensor] = {}
+        self.mean: Dict[str, torch.Tensor] = {}
+        self.rstd: Dict[str, torch.Tensor] = {}
+        self.dtype: Dict[str, torch.dtype] = {}
+        self._ring = _Circular(self.capacity)  # rows staged by rollouts: findable by sequence number until lapped
+        self._patch = _Circular(self.patch_capacity)  # rows staged by `bind` for one lease: storage slots capacity + ...
+        self._lock = threading.Lock()
+        self._leases = []
+        self._release_events = []  # recorded on the readers' streams at release: the next writer waits for them
+        self._write_events = {}  # writer stream -> event after its last put
+        self.stats = dict(rows_put=0, rows_bound=0, rows_patched=0, binds=0, binds_failed=0)
+
+    @classmethod
+    def for_policy(cls, policy, capacity_rows: int, patch_rows: Optional[int] = None) -> "ObsRing":
+        net = policy.net
+        return cls(net.obs_stage_layout(), net.obs_raw_shapes(), capacity_rows, policy.device, patch_rows)
+
+    def keys(self):
+        return self.layout.keys()
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.storage.values())
+
+    @property
+    def head(self) -> int:
+        return self._ring.head
+
+    # ------------------------------------------------------------------ storage
+    def _staged_row_shape(self, key):
+        lay, raw = self.layout[key], self.raw_shape[key]
+        if lay[0] == "s2d":
+            c, h, w = raw
+            b = int(lay[1])
+            return (h // b, w // b, c * b * b)
+        return raw
+
+    def _ensure(self, key, dtype):
+        if key in self.storage:
+            if self.dtype[key] != dtype:
+                raise hip.HipError(f"observation `{key}`: ring holds {self.dtype[key]}, got {dtype}")
+            return
+        rows = self.capacity + self.patch_capacity
+        self.dtype[key] = dtype
+        self.storage[key] = torch.empty((rows, *self._staged_row_shape(key)), dtype=dtype, device=self.device)
+        if self.layout[key][0] == "s2d":
+            self.mean[key] = torch.empty(rows, dtype=torch.float32, device=self.device)
+            self.rstd[key] = torch.empty(rows, dtype=torch.float32, device=self.device)
+
+    def _check_rows(self, obs):
+        n = None
+        for k in self.layout:
+            if k not in obs:
+                raise KeyError(f"observation key `{k}` missing from the batch (has {list(obs)})")
+            t = obs[k]
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
+                raise hip.HipError(f"observation `{k}`: the ring stages contiguous device rows")
+            if tuple(t.shape[1:]) != self.raw_shape[k]:
+                raise hip.HipError(f"observation `{k}`: rows of shape {tuple(t.shape[1:])}, expected {self.raw_shape[k]}")
+            n = t.shape[0] if n is None else n
+            if t.shape[0] != n:
+                raise hip.HipError("observation keys disagree on the number of rows")
+            self._ensure(k, t.dtype)
+        return n
+
+    def _stage(self, obs, s0, n):
+        """Write ``n`` rows into storage slots [s0, s0 + n) in each key's layout, on the current stream."""
+        for k, lay in self.layout.items():
+            t, store = obs[k], self.storage[k]
+            if lay[0] == "s2d":
+                c, h, w = self.raw_shape[k]
+                row = store[0].numel() * store.element_size()
+                hip.obs_space_to_depth(t.data_ptr(), t.dtype == torch.uint8, n, c, h, w, int(lay[1]), store.data_ptr() + s0 * row,
+                                       self.mean[k].data_ptr() + 4 * s0, self.rstd[k].data_ptr() + 4 * s0)
+            else:
+                store[s0:s0 + n].copy_(t)
+
+    def _wait_released(self, events):
+        if events:  # readers that released earlier may still be running on their stream
+            stream = torch.cuda.current_stream(self.device)
+            for ev in events:
+                stream.wait_event(ev)
+
+    # ------------------------------------------------------------------ producer side (rollout)
+    def _alloc(self, n: int) -> int:
+        """First sequence number of a run of ``n`` ring slots (never laps a leased row)."""
+        with self._lock:
+            floor = min((l.min_seq for l in self._leases if l.min_seq is not None), default=None)
+            seq = self._ring.alloc(n, floor, "observation ring")
+            events, self._release_events = self._release_events, []
+        self._wait_released(events)
+        return seq
+
+    def put(self, obs: Dict[str, torch.Tensor]):
+        """Stage one inference batch.  ``obs``: key -> device rows ``[n, *raw_shape]`` (uint8 or float32) for every key of
+        the ring.  Returns (sequence numbers int64 numpy ``[n]``, key -> ``RingObs`` over the new run of slots)."""
+        n = self._check_rows(obs)
+        seq = self._alloc(n)
+        s0 = seq % self.capacity
+        self._stage(obs, s0, n)
+        stream = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        with self._lock:
+            self._write_events[stream.cuda_stream] = ev
+            self.stats["rows_put"] += n
+        return np.arange(seq, seq + n, dtype=np.int64), {k: RingObs(self, k, (n,), span=s0) for k in self.layout}
+
+    # ------------------------------------------------------------------ consumer side (trainer)
+    def alive(self, refs: np.ndarray) -> np.ndarray:
+        with self._lock:
+            head = self._ring.head
+        return (refs >= 0) & (refs < head) & (refs + self.capacity >= head)
+
+    def _patch_rows(self, lease: ObsLease, rows: Dict[str, torch.Tensor]) -> np.ndarray:
+        """Stage rows that are not alive in the ring into the patch area, for this lease only; returns their storage slots."""
+        n = self._check_rows(rows)
+        with self._lock:
+            floor = min((l.patch_start for l in self._leases if l.patch_start is not None), default=None)
+            if floor is None and lease.patch_start is not None:
+                floor = lease.patch_start
+            seq = self._patch.alloc(n, floor, "observation ring patch area")
+            if lease.patch_start is None:
+                lease.patch_start = seq
+                if lease not in self._leases:
+                    self._leases.append(lease)
+            events, self._release_events = self._release_events, []
+        self._wait_released(events)
+        s0 = self.capacity + seq % self.patch_capacity
+        self._stage(rows, s0, n)
+        return np.arange(s0, s0 + n, dtype=np.int64)
+
+    def bind(self, refs, host_obs: Optional[Dict[str, "torch.Tensor"]] = None, piece_rows: int = 4096):
+        """``refs``: int64 ``[Tb, B]`` (or ``[Tb, B, 1]``) sequence numbers from the sample, or None (no references: every
+        row is uploaded).  ``host_obs``: key -> host rows ``[Tb, B, *raw_shape]`` (pinned torch tensors or numpy), used for
+        the rows whose reference is not alive: they are uploaded into the patch area.  Returns ``(key -> RingObs
+        [Tb, B, ...], lease)``, or None when the ring cannot serve the sample (a dead reference without a host copy, or
+        more dead rows than the patch area holds): the caller then copies the observations itself."""
+        keys = list(self.layout)
+        if refs is None:
+            if not host_obs:
+                return None
+            lead = tuple(next(iter(host_obs.values())).shape[:2])
+            refs = np.full(lead, -1, dtype=np.int64)
+        refs = np.asarray(refs)
+        if refs.ndim == 3 and refs.shape[2] == 1:
+            refs = refs[..., 0]
+        refs = refs.astype(np.int64)
+        with self._lock:  # liveness and the lease in one step: no allocation can slip in between
+            head = self._ring.head
+            ok = (refs >= 0) & (refs < head) & (refs + self.capacity >= head)
+            lease = ObsLease(self, int(refs[ok].min()) if ok.any() else None)
+            if lease.min_seq is not None:
+                self._leases.append(lease)
+        slots = np.where(ok, refs % self.capacity, -1)
+        patched = 0
+        try:
+            if not ok.all():
+                if not host_obs or any(k not in host_obs for k in keys):
+                    raise LookupError("dead observation references and no host copy")
+                if int((~ok).sum()) > self.patch_capacity:
+                    raise BufferError("more dead rows than the patch area holds")
+                host = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))) for k, v in host_obs.items()}
+                for t in range(refs.shape[0]):
+                    miss = ~ok[t]
+                    if not miss.any():
+                        continue
+                    cols = None if miss.all() else torch.from_numpy(np.nonzero(miss)[0])
+                    m = refs.shape[1] if cols is None else int(cols.numel())
+                    for c0 in range(0, m, piece_rows):
+                        c1 = min(m, c0 + piece_rows)
+                        rows = {}
+                        for k in keys:
+                            src = host[k][t]
+                            src = src[c0:c1] if cols is None else src[cols[c0:c1]]
+                            if src.dtype == torch.bool:
+                                src = src.view(torch.uint8)
+                            rows[k] = src.to(self.device, non_blocking=True).contiguous()
+                        got = self._patch_rows(lease, rows)
+                        if cols is None:
+                            slots[t, c0:c1] = got
+                        else:
+                            slots[t, cols[c0:c1].numpy()] = got
+                        patched += c1 - c0
+        except (BufferError, LookupError):
+            self.release(lease, record=False)
+            with self._lock:
+                self.stats["binds_failed"] += 1
+            return None
+        index = torch.from_numpy(slots.astype(np.int32)).to(self.device, non_blocking=True)
+        stream = torch.cuda.current_stream(self.device)
+        if patched:
+            lease.uploaded = torch.cuda.Event()
+            lease.uploaded.record(stream)
+        with self._lock:
+            events = [ev for s, ev in self._write_events.items() if s != stream.cuda_stream]
+            self.stats["rows_bound"] += refs.size
+            self.stats["rows_patched"] += patched
+            self.stats["binds"] += 1
+        for ev in events:  # rows written on the inference thread's stream
+            stream.wait_event(ev)
+        return {k: RingObs(self, k, refs.shape, index=index) for k in keys}, lease
+
+    def release(self, lease: Optional[ObsLease], record: bool = True):
+        """The step that read the leased rows has been enqueued: later allocations may lap them (after that work)."""
+        if lease is None:
+            return
+        ev = None
+        if record and torch.cuda.is_available():
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+        with self._lock:
+            if lease in self._leases:
+                self._leases.remove(lease)
+            if ev is not None:
+                self._release_events.append(ev)

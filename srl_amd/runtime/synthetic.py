@@ -129,7 +129,8 @@ def to_sample_batch(arrays: Dict[str, np.ndarray]):
                        action=DiscreteAction(arrays["action.x"]),
                        reward=arrays["reward"],
                        analyzed_result=PPORolloutAnalyzedResult(log_probs=arrays["analyzed_result.log_probs"],
-                                                                value=arrays["analyzed_result.value"]),
+                                                                value=arrays["analyzed_result.value"],
+                                                                obs_ref=arrays.get("analyzed_result.obs_ref")),
                        policy_version_steps=arrays["policy_version_steps"],
                        info_mask=arrays["info_mask"])
 

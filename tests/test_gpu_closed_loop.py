@@ -21,6 +21,7 @@ from srl_amd.envs.cartpole import CartPoleEnvironment
 from srl_amd.namedarray import NamedArray, recursive_aggregate
 from srl_amd.runtime.batcher import InferenceBatcher
 from srl_amd.runtime.ingest import SampleRing
+from srl_amd.runtime.obs_ring import RingObs
 
 srl_amd.register_all()
 pytestmark = pytest.mark.gpu
@@ -52,7 +53,7 @@ class Actor:
                                          buffer_index=np.full((1, 1), -1, np.int32), step_count=np.full((1, 1), self.t, np.int32),
                                          ready=np.ones((1, 1), np.bool_))
 
-    def act(self, action, log_prob, value, version):
+    def act(self, action, log_prob, value, version, obs_ref):
         """Record the step taken at the current observation and advance the environment (Appendix B row conventions)."""
         cur = self.cur
         done, trunc = int(cur.done[0]), int(0 if cur.truncated is None else cur.truncated[0])
@@ -68,8 +69,11 @@ class Actor:
             truncated=np.array([trunc], np.uint8), action=DiscreteAction(np.asarray(action, np.int32).reshape(1)), reward=reward,
             info=NamedArray(episode_return=cur.info["episode_return"].astype(np.float32)),
             info_mask=np.array([terminal], np.uint8),
+            # the response's analyzed_result is stored as it came (actor_worker.py:521-535): with an observation ring
+            # attached to the inference policy it carries the ring stamp of this observation
             analyzed_result=PPORolloutAnalyzedResult(log_probs=np.asarray(log_prob, np.float32).reshape(1),
-                                                     value=np.asarray(value, np.float32).reshape(1)),
+                                                     value=np.asarray(value, np.float32).reshape(1),
+                                                     obs_ref=np.asarray(obs_ref, np.int64).reshape(1)),
             policy_version_steps=np.array([version], np.int64)))
         self.cur, self.on_reset = nxt, next_on_reset
 
@@ -91,6 +95,9 @@ def test_cartpole_closed_loop_learns_and_versions_advance():
     def parameter_source():
         return fresh.pop() if fresh else None
 
+    # observations stay in HBM from the rollout that saw them to the update that trains on them (runtime/obs_ring.py)
+    obs_ring = infer.make_obs_ring(4 * N_ENVS * (T + BOOT))
+    infer.attach_obs_ring(obs_ring)
     batcher = InferenceBatcher(infer, policy_name="cartpole", batch_size=N_ENVS, parameter_source=parameter_source)
     actors = [Actor(i) for i in range(N_ENVS)]
     ring = None
@@ -105,16 +112,17 @@ def test_cartpole_closed_loop_learns_and_versions_advance():
         assert sorted(order.tolist()) == list(range(N_ENVS))
         for row, cid in enumerate(order):
             actors[cid].act(resp.action.x[row], resp.analyzed_result.log_probs[row], resp.analyzed_result.value[row],
-                            int(resp.policy_version_steps[row, 0]))
+                            int(resp.policy_version_steps[row, 0]), resp.analyzed_result.obs_ref[row])
         for a in actors:
             traj = a.pop_sample()
             if traj is None:
                 continue
             if ring is None:
-                ring = SampleRing(traj, batch_size=N_ENVS, slots=2, device="cuda:0")
+                ring = SampleRing(traj, batch_size=N_ENVS, slots=2, device="cuda:0", obs_ring=obs_ring)
             ring.put_column(traj)
         if ring is not None and ring.ready():
             batch = ring.get_device()
+            assert isinstance(batch.obs.obs, RingObs)  # bound to the rows the rollouts left in HBM, not uploaded again
             stamps = batch.policy_version_steps.cpu().numpy()
             version_log.append((int(stamps.min()), int(stamps.max()), trainer.policy.version))
             res = trainer.step(batch)
@@ -142,4 +150,5 @@ def test_cartpole_closed_loop_learns_and_versions_advance():
     assert infer.version == trainer.policy.version
     assert torch.equal(infer.net.flat, trainer.policy.net.flat)
     assert np.isfinite(list(res.stats.values())).all() and res.stats.get("episode_return", 1.0) > 0
+    assert obs_ring.stats["rows_patched"] == 0 and obs_ring.stats["binds"] == updates and obs_ring.stats["binds_failed"] == 0
     print(f"closed loop: {updates} updates, mean return {early:.1f} -> {late:.1f}; curve {[round(c) for c in curve[::8]]}")

@@ -290,6 +290,64 @@ def test_cnn_step_vs_oracle_chunked():
         assert abs(res.stats[k] - ostats[k]) <= 2e-5 * max(abs(ostats[k]), 1e-2), (k, res.stats[k], ostats[k])
 
 
+def _pong_frames(rng, Tb, B):
+    """Atari-`pong`-type frames: a flat bright background (large mean, tiny variance) with a few small sprites -- the
+    case in which an un-centred byte contraction loses digits (first convolution on bytes)."""
+    f = np.full((Tb, B, 4, 84, 84), 144, dtype=np.uint8)
+    for t in range(Tb):
+        for b in range(B):
+            for c in range(4):
+                y, x = rng.integers(0, 76, size=2)
+                f[t, b, c, y:y + 8, x:x + 2] = 236
+                y, x = rng.integers(0, 80, size=2)
+                f[t, b, c, y:y + 2, x:x + 2] = rng.integers(0, 256)
+    return f
+
+
+@pytest.mark.parametrize("frames", ["noise", "pong"])
+@pytest.mark.parametrize("kernels", ["bf16x3", "f32"])
+def test_cnn_step_at_the_benchmarked_dispatch(kernels, frames, monkeypatch):
+    """The composition bench.py times, end to end against the oracle: NatureCNN `trainer.step` x 2 with 256 rows in ONE
+    row chunk, so that every contraction is above the size gates of gemm.hip / conv.hip and runs on `gemm3_kernel` /
+    `obs_*_bf16_kernel` (asserted through the launch counters of the C ABI) -- and the same sample through the float32
+    MFMA kernels (SRL_MFMA=f32, SRL_OBS_BF16=0): both kernel sets meet the same oracle at the same tolerances.
+    Reference: mappo.py:219-328 (the step), modules/cnn.py:93-135 (the encoder)."""
+    from srl_amd import hip
+    if kernels == "f32":
+        monkeypatch.setenv("SRL_MFMA", "f32")
+        monkeypatch.setenv("SRL_OBS_BF16", "0")
+    T, B = 16, 16  # 256 loss rows, one chunk (chunk_rows 16384)
+    trainer = make_trainer(CNN_POLICY, dict(ATARI_TRAINER))
+    onet = OracleActorCritic(**CNN_POLICY)
+    onet.load_state_dict({k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()})
+    oracle = OracleMappo(onet, **ATARI_TRAINER)
+    hip.dispatch_counts(reset=True)
+    for step in range(2):
+        arrays = synthetic.make_sample_arrays(seed=70 + step, T=T, B=B, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.05)
+        if frames == "pong":
+            arrays["obs.obs"] = _pong_frames(np.random.default_rng(step), T + 1, B)
+        sample = synthetic.to_sample_batch(arrays)
+        res = trainer.step(sample)
+        ostats, oout = oracle.step(arrays)
+        assert close(sample.analyzed_result.ret, oout["ret"], 1e-5), step
+        assert close(sample.analyzed_result.adv, oout["adv"], 1e-5), step
+        for k in ("policy_loss", "value_loss", "entropy"):
+            assert abs(res.stats[k] - ostats[k]) <= 1e-5 * max(abs(ostats[k]), 1e-2), (step, k, res.stats[k], ostats[k])
+        assert abs(res.stats["grad_norm"] - ostats["grad_norm"]) <= 2e-5 * max(abs(ostats["grad_norm"]), 1e-2), step
+    counts = hip.dispatch_counts(reset=True)
+    if kernels == "bf16x3":
+        # conv2/conv3 forward, their weight and data gradients, the three FC products: all on the bf16 matrix cores,
+        # the first layer on the byte kernels, only the two heads (N = 6, N = 1) on the skinny kernels
+        assert counts["gemm_f32"] == 0, counts
+        assert counts["gemm3"] >= 2 * 9 and counts["obs_fwd_bf16"] == 2 and counts["obs_bwd_bf16"] == 2, counts
+    else:
+        assert counts["gemm3"] == 0 and counts["obs_fwd_bf16"] == 0 and counts["obs_bwd_bf16"] == 0 and counts["gemm_f32"] > 0, counts
+    sd = trainer.policy.get_checkpoint()["state_dict"]
+    osd = onet.state_dict()
+    for k in sd:
+        assert np.abs(sd[k].numpy() - osd[k].numpy()).max() <= 2e-5, k
+
+
 def test_checkpoint_roundtrip_and_reuse():
     trainer = make_trainer(C1_POLICY, dict(popart=False, optimizer_config=dict(lr=1e-3), recompute_adv_on_reuse=False))
     arrays = synthetic.make_sample_arrays(seed=1, T=16, B=4, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2)
