@@ -12,22 +12,31 @@ statistics and a bucketed all-reduce of the flat gradient per step.  A "step" is
 + statistics, forward, fused loss fwd/bwd, backward, gradient all-reduce, clip + Adam.  Synthetic data (no ALE on the
 box), random-init weights.
 
-``value`` = T * B_global * K / t with the sample RESIDENT IN HBM when the timed region starts (the task's bench
-contract), t = max over ranks of the K-step wall time between barrier + synchronize.  The same update fed from PINNED
-HOST memory -- every leaf's H2D copy inside the timed region, double-buffered on a side stream (SURVEY.md 8d's
-``t_update``; reference api/trainer.py:211-228) -- is measured in the same run and reported as ``from_pinned_host``.
+``value`` = T * B_global * K / t, t = max over ranks of the K-step wall time between barrier + synchronize, of SURVEY.md
+8d's ``t_update``: the sample lies in PINNED HOST memory in [Tb, B] namedarray layout when an update starts and every
+leaf the update needs from there is copied inside the timed region -- every leaf EXCEPT the frames, which are already in
+HBM: the rollout that produced the sample uploaded each observation once for inference (reference
+actor_critic_policy.py:467-469) and ``ObsRing`` kept it there, in the first layer's layout; the sample names its rows by
+the ring stamps the rollout returned (``analyzed_result.obs_ref``) and ``SampleRing.get_device`` binds them instead of
+sending 14.9 GB over the link a second time (runtime/obs_ring.py).  The rollout phase that fills the ring runs before
+the timed region (it IS the rollout; its rate is reported as ``rollout_inference``).  Two more figures of the same
+update, same run: ``resident_in_hbm`` (the whole sample, frames as a plain [Tb, B, 4, 84, 84] tensor, already on the
+device) and ``from_pinned_host`` (no ring: every leaf including the frames crosses the link inside the timed region,
+double-buffered on a side stream; reference api/trainer.py:211-228) -- PCIe-bound.
 
 Extra objects on the JSON line: ``roofline`` (dominant kernel family: the matrix-core contractions, timed live with
 HIP events on the launch stream in an extra untimed step), ``roofline_gae`` (the GAE scan against HBM at this batch,
 with t / t_launch_floor, and saturated), ``cpu_baseline`` (the oracle's CPU restatement of the same step on a
 bounded sample, rank 0, N = 1 only).
 
-Profiling recipe (counters in their own passes; the interpreter directly after ``--``):
-    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-from-host
+Profiling recipe (scripts/profile_bench.sh; counters in passes of their own, the interpreter directly after ``--``):
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-plain-copy
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
-    python3 scripts/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --steps-in-run 2 --envs 4096 --rollout-len 128 \
-        --chunk-rows 16384 > profiles/r02_hbm_traffic_vN.csv     (writes the matching .json with the configuration)
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES \
+        SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_sq -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
+    python3 scripts/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --steps-in-run 2 --out profiles/r03_hbm_traffic_vN.csv
+    python3 scripts/pmc_summary.py gpurun_out/pmc_sq --steps-in-run 2 --csv profiles/r03_sq_counters_vN.csv
 """
 import argparse
 import json
@@ -63,6 +72,8 @@ def device_sample(seed, T, B, device):
     gen.manual_seed(seed)
     dev = {k: torch.from_numpy(v).to(device) for k, v in arrays.items()}
     dev["obs.obs"] = torch.randint(0, 256, (T + 1, B, 4, 84, 84), dtype=torch.uint8, device=device, generator=gen)
+    # the observation-ring stamp every step carries (analyzed_result.obs_ref): none yet -- the rollout phase of main() fills it
+    dev["analyzed_result.obs_ref"] = torch.full((T + 1, B, 1), -1, dtype=torch.int64, device=device)
     return synthetic.to_sample_batch(dev)
 
 
@@ -160,31 +171,6 @@ def _cpu_steps(T, B, threads, budget_s, max_steps):
     return times
 
 
-def rollout_rate(policy, device, n=4096, reps=8):
-    """SURVEY 8d's secondary metric: rollout-inference requests/s (a10 `rollout`, reference
-    `actor_critic_policy.py:458-528`).  One request = one (4,84,84) uint8 observation in, (sampled action, log-prob, value)
-    out, host numpy on both sides as the policy worker sees them: the H2D of the observations and the D2H of the results
-    are inside the timed region.  Uses the trainer's policy (its current parameters)."""
-    import numpy as np
-    from srl_amd.api import policy as policy_api
-    from srl_amd.namedarray import NamedArray
-    rng = np.random.default_rng(0)
-    obs = torch.from_numpy(rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)).pin_memory().numpy()
-    req = policy_api.RolloutRequest(obs=NamedArray(obs=obs), is_evaluation=np.zeros((n, 1), np.uint8),
-                                    on_reset=np.zeros((n, 1), np.uint8), client_id=np.zeros((n, 1), np.int32),
-                                    request_id=np.arange(n).reshape(n, 1), received_time=np.zeros((n, 1), np.int64),
-                                    buffer_index=np.zeros((n, 1), np.int32))
-    for _ in range(3):
-        policy.rollout(req)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        policy.rollout(req)  # returns numpy: synchronises
-    dt = (time.perf_counter() - t0) / reps
-    return dict(value=n / dt, unit="requests/s", requests_per_call=n, ms_per_call=dt * 1e3,
-                note="policy.rollout on pinned host observations (uint8 frames), sampled actions; H2D and D2H inside")
-
-
 def cpu_baseline(T):
     """The oracle's restatement of the same trainer step (torch-CPU, op for op with the reference: float32-widened
     frames, float64 GAE loop, autograd loss, torch.optim.Adam) on a bounded sample of the same workload, on all
@@ -239,6 +225,41 @@ def recorded_traffic(kernel_substr, envs, T, chunk_rows):
     return dict(traffic=None, traffic_note="no PMC recording under profiles/ at this configuration")
 
 
+def recorded_counters(envs, T, chunk_rows):
+    """Matrix-pipe utilisation of the same kernel family from the newest SQ counter pass committed under profiles/
+    (scripts/pmc_summary.py spells out the normalisation): busy cycles of every SIMD's matrix pipe over SIMDs x dispatch
+    cycles, summed over the family's launches of one step.  Like `traffic`: a recorded figure, named with its source, only
+    when the recording was made at this run's configuration."""
+    import csv
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    metas = sorted(glob.glob(os.path.join(here, "profiles", "r*_sq_counters_v*.json")),
+                   key=lambda f: (int(os.path.basename(f)[1:3]), int(f.rsplit("_v", 1)[1].split(".")[0])))
+    for mf in reversed(metas):
+        with open(mf) as f:
+            meta = json.load(f)
+        if (meta.get("envs"), meta.get("rollout_len"), meta.get("chunk_rows")) != (envs, T, chunk_rows):
+            continue
+        busy = cycles = valu = wait = wave = 0.0
+        with open(mf[:-5] + ".csv") as f:
+            for r in csv.DictReader(f):
+                if not any(sub in r["kernel"] for sub in ("gemm", "obs_fwd_bf16", "obs_bwd_bf16")) or not r["SQ_VALU_MFMA_BUSY_CYCLES"]:
+                    continue
+                n = float(r["dispatches"])
+                busy += n * float(r["SQ_VALU_MFMA_BUSY_CYCLES"])
+                cycles += n * float(r["cycles_per_dispatch"])
+                valu += n * 4 * float(r["SQ_ACTIVE_INST_VALU"] or 0)
+                wait += n * float(r["SQ_WAIT_ANY"] or 0)
+                wave += n * float(r["SQ_WAVE_CYCLES"] or 0)
+        if cycles <= 0:
+            continue
+        simds = float(meta.get("simds", 1024))
+        return dict(mfma_busy=round(busy / (simds * cycles), 4), valu_busy=round(valu / (simds * cycles), 4),
+                    wait_share=round(wait / wave, 4) if wave else None,
+                    counters_source=os.path.relpath(mf[:-5] + ".csv", here), counters_commit=meta.get("commit"))
+    return dict(mfma_busy=None, counters_note="no SQ counter recording under profiles/ at this configuration")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,10 +271,23 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: capture the update into a hipGraph and replay it (one rank only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-from-host", action="store_true", help="skip the pinned-host-fed pass (`from_pinned_host`)")
-    ap.add_argument("--from-host-steps", type=int, default=6)
+    ap.add_argument("--no-from-host", action="store_true",
+                    help="skip the pinned-host-fed passes: `value` is then the resident-in-HBM figure")
+    ap.add_argument("--no-plain-copy", action="store_true", help="skip the pass without the observation ring (`from_pinned_host`)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started directly: become the launcher.  The ranks are CHILD processes (torch.distributed.run), started before this
+        # process has touched the GPU; their output (rank 0's JSON line) is relayed and their exit code returned.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -270,7 +304,9 @@ def main():
 
     import srl_amd
     from srl_amd import hip
-    from srl_amd.api import config, trainer as trainer_api
+    from srl_amd.api import config, policy as policy_api, trainer as trainer_api
+    from srl_amd.namedarray import NamedArray, recursive_apply
+    from srl_amd.runtime.ingest import SampleRing
     srl_amd.register_all()
 
     use_dist = world > 1 or args.force_dist
@@ -317,8 +353,15 @@ def main():
             el = float(t.item())
         return el, r
 
-    elapsed, res = timed(lambda: trainer.step(sample), args.warmup, args.steps)
-    per_step = sorted(step_marks)  # this rank's device time per update (SURVEY 8d asks for median and min beside the mean)
+    def rate(el, steps):
+        return T * B * world * steps / el
+
+    # ---- (1) the update with the whole sample resident in HBM ---------------------------------------------------------------
+    el_res, res = timed(lambda: trainer.step(sample), args.warmup, args.steps)
+    marks_res = sorted(step_marks)
+    resident = dict(value=rate(el_res, args.steps), unit="env-steps/s", ms_per_step=1e3 * el_res / args.steps, steps=args.steps,
+                    warmup=args.warmup, ms_per_step_median=marks_res[len(marks_res) // 2], ms_per_step_min=marks_res[0],
+                    note="whole sample, frames as a plain [Tb, B, 4, 84, 84] uint8 tensor, on the device before the timed region")
 
     # ---- untimed extra step with per-kernel HIP events (same stream as the launches) -----------------------
     roofline = roofline_gae = breakdown = None
@@ -328,7 +371,9 @@ def main():
         if prof is not None:
             hip.set_profile(prof)
         trainer.use_graph = False  # the events wrap individual launches: this step is issued launch by launch
+        hip.dispatch_counts(reset=True)
         trainer.step(sample)
+        dispatch = hip.dispatch_counts(reset=True)
         if prof is not None:
             hip.set_profile(None)
     if rank == 0 and not args.no_profile:
@@ -353,8 +398,9 @@ def main():
                         executed_basis="bf16 MFMA flops issued: 6 x algorithmic (3 x for the byte-operand first layer)",
                         fp32_mfma_peak=PEAK_FP32_MFMA_TFLOPS, achieved_over_fp32_mfma_peak=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                         launches=g["calls"], ms_per_step=round(g["ms"], 3), flops_per_step=g["work"],
-                        flops_per_env_step=g["work"] / (T * B),
-                        **recorded_traffic(("gemm", "obs_fwd_bf16", "obs_bwd_bf16"), B, T, args.chunk_rows))
+                        flops_per_env_step=g["work"] / (T * B), kernel_family_launches=dispatch,
+                        **recorded_traffic(("gemm", "obs_fwd_bf16", "obs_bwd_bf16"), B, T, args.chunk_rows),
+                        **recorded_counters(B, T, args.chunk_rows))
         # the scan is a ~microsecond kernel: time it as back-to-back launches between two events on the launch
         # stream so that host enqueue latency does not sit inside the interval
         floor = launch_floor_us(device)
@@ -373,11 +419,11 @@ def main():
                                            us_per_launch=round(big["ms"] * 1e3, 1), algorithmic_bytes=big["work"]))
         breakdown = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
 
-    # ---- the same update fed from pinned host memory: every leaf's H2D inside the timed region ------------------------
-    pcie = None
+    # ---- (2) the sample moves to pinned host memory: two slots of the ingest ring, [Tb, B] namedarray layout, wire dtypes ---
+    pcie = fed = rollout_inf = None
+    ms_step = 1e3 * el_res / args.steps
     if not args.no_from_host:
-        from srl_amd.namedarray import recursive_apply
-        from srl_amd.runtime.ingest import SampleRing
+        Tb = T + 1
         template = recursive_apply(sample[:, 0], lambda x: x.cpu().numpy())
         ring = SampleRing(template, batch_size=B, slots=2, device=device)
         for _ in range(2):
@@ -393,39 +439,84 @@ def main():
             ring.recycle(slot)
             return r
 
-        el, _ = timed(fed_step, 2, args.from_host_steps)
-        host_bytes = ring.nbytes() // 2
-        ms = 1e3 * el / args.from_host_steps
-        h2d_ms = None
-        if rank == 0:  # the copy alone, same ring, nothing else running
-            b = ring.get_device()
-            slot = b.metadata["ring_slot"]
-            ring.release(slot)
-            ring.recycle(slot)
-            torch.cuda.synchronize()
-            b2 = None
+        # ---- (2a) no observation ring: every leaf, frames included, crosses the link inside the timed region ---------------
+        if not args.no_plain_copy:
+            el, _ = timed(fed_step, 2, args.steps)
+            host_bytes = ring.nbytes() // 2
+            h2d_ms = None
+            if rank == 0:  # the copy alone, same ring, nothing else running
+                b = ring.get_device()
+                slot = b.metadata["ring_slot"]
+                ring.release(slot)
+                ring.recycle(slot)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                b2 = ring.get_device()
+                torch.cuda.synchronize()
+                h2d_ms = 1e3 * (time.perf_counter() - t0)
+                slot = b2.metadata["ring_slot"]
+                ring.release(slot)
+                ring.recycle(slot)
+                del b, b2
+            pcie = dict(value=rate(el, args.steps), unit="env-steps/s", ms_per_step=1e3 * el / args.steps, steps=args.steps,
+                        warmup=2, host_bytes_per_step_per_gpu=host_bytes, h2d_alone_ms=h2d_ms,
+                        h2d_alone_GBps=None if not h2d_ms else round(host_bytes / h2d_ms / 1e6, 1),
+                        bound="pcie" if h2d_ms and h2d_ms > ms_step else "mfma",
+                        note="no observation ring: async H2D of every leaf (14.9 GB of frames) on a side stream inside the "
+                             "timed region, double-buffered so that the copy of update k+1 runs under the compute of update k")
+
+        # ---- (2b) the rollout phase of this sample: 129 inference batches of B observations from pinned host memory, each
+        # staged once in the HBM observation ring (space-to-depth + LayerNorm statistics, the pass inference needs anyway)
+        infer = policy_api.make(config.Policy("actor-critic", args=POLICY))
+        infer.load_checkpoint(trainer.policy.get_checkpoint())
+        obs_ring = infer.make_obs_ring(Tb * B + 8 * B, patch_rows=4 * B)
+        infer.attach_obs_ring(obs_ring)
+        frames = ring.host_blocks(0)["obs.obs"]  # [Tb, B, 4, 84, 84] uint8, pinned
+        zeros = lambda dt: np.zeros((B, 1), dt)
+        stamps = np.empty((Tb, B, 1), np.int64)
+        t_roll, n_roll = 0.0, 0
+        for t in range(Tb):
+            req = policy_api.RolloutRequest(obs=NamedArray(obs=frames[t]), is_evaluation=zeros(np.uint8), on_reset=zeros(np.uint8),
+                                            client_id=zeros(np.int32), request_id=np.arange(B).reshape(B, 1),
+                                            received_time=zeros(np.int64), buffer_index=zeros(np.int32))
             t0 = time.perf_counter()
-            b2 = ring.get_device()
-            torch.cuda.synchronize()
-            h2d_ms = 1e3 * (time.perf_counter() - t0)
-            ring.release(b2.metadata["ring_slot"])
-        pcie = dict(value=T * B * world * args.from_host_steps / el, unit="env-steps/s", ms_per_step=ms,
-                    steps=args.from_host_steps, host_bytes_per_step_per_gpu=host_bytes, h2d_alone_ms=h2d_ms,
-                    h2d_alone_GBps=None if not h2d_ms else round(host_bytes / h2d_ms / 1e6, 1),
-                    note="SURVEY 8d t_update: sample in the pinned ingest ring ([Tb,B] namedarray layout, wire dtypes); "
-                         "async H2D of every leaf on a side stream inside the timed region, double-buffered so that the "
-                         "copy of update k+1 runs under the compute of update k")
+            resp = infer.rollout(req)  # returns numpy: synchronises
+            if t >= 3:
+                t_roll += time.perf_counter() - t0
+                n_roll += 1
+            stamps[t] = resp.analyzed_result.obs_ref
+        for slot in range(2):  # the actors store the stamp with each step; both slots hold this sample
+            ring.host_blocks(slot)["analyzed_result.obs_ref"][...] = stamps
+        rollout_inf = dict(value=B * n_roll / t_roll, unit="requests/s", requests_per_call=B, ms_per_call=1e3 * t_roll / n_roll,
+                           calls=n_roll,
+                           note="policy.rollout on pinned host observations (uint8 frames), sampled actions; H2D of the frames "
+                                "and D2H of the results inside; every observation staged in the HBM observation ring on the way")
+        del infer
+        ring.attach_obs_ring(obs_ring)
+
+        # ---- (2c) SURVEY 8d's t_update with the ring: the headline ---------------------------------------------------------
+        el_fed, res = timed(fed_step, args.warmup, args.steps)
+        marks_fed = sorted(step_marks)
+        ms_step = 1e3 * el_fed / args.steps
+        scalar_bytes = sum(v.nbytes for k, v in ring.host_blocks(0).items() if k != "obs.obs")
+        fed = dict(value=rate(el_fed, args.steps), ms_per_step=ms_step, ms_per_step_median=marks_fed[len(marks_fed) // 2],
+                   ms_per_step_min=marks_fed[0], h2d_bytes_per_step_per_gpu=scalar_bytes,
+                   frames_bytes_kept_in_hbm=int(frames.nbytes), obs_ring=dict(capacity_rows=obs_ring.capacity,
+                                                                               patch_rows=obs_ring.patch_capacity,
+                                                                               bytes=obs_ring.nbytes(), **obs_ring.stats))
 
     if rank == 0:
-        steps_total = T * B * world * args.steps
-        ms_step = 1e3 * elapsed / args.steps
-        line = dict(metric=f"env-steps/sec through GAE+PPO update, {B * world} envs x {T} steps", value=steps_total / elapsed,
-                    unit="env-steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_step,
+        head = fed if fed is not None else resident
+        line = dict(metric=f"env-steps/sec through GAE+PPO update, {B * world} envs x {T} steps", value=head["value"],
+                    unit="env-steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=head["ms_per_step"],
                     higher_is_better=True, scaling="strong", vs_baseline=None,
                     dtype="f32 (contractions as exact bf16x3 piece products, float32 accumulate)", data="synthetic",
-                    ms_per_step_median=per_step[len(per_step) // 2] if per_step else None,
-                    ms_per_step_min=per_step[0] if per_step else None,
-                    value_basis="sample resident in HBM when the timed region starts; see from_pinned_host for H2D inside",
+                    ms_per_step_median=head["ms_per_step_median"], ms_per_step_min=head["ms_per_step_min"],
+                    value_basis=("SURVEY 8d t_update: sample in pinned host memory ([Tb,B] namedarray layout, wire dtypes) when "
+                                 "an update starts; every leaf copied inside the timed region except the frames, which the "
+                                 "rollout already left in the HBM observation ring (bound by the sample's stamps); see "
+                                 "resident_in_hbm / from_pinned_host for the two other feeds" if fed is not None else
+                                 "sample resident in HBM when the timed region starts (--no-from-host)"),
                     config=dict(workload=f"BASELINE configs[2]: Atari-shaped PPO+GAE, {B * world} envs x {T} steps per update "
                                          f"(global batch fixed; {B} env columns per GPU x {world} GPUs data-parallel), "
                                          "NatureCNN-512, uint8 (4,84,84) frames, Atari PPO preset",
@@ -435,12 +526,13 @@ def main():
                                              "RCCL through the C ABI (srl_comm_*)" if getattr(trainer, "_comm", None) is not None
                                              else f"torch.distributed ({backend})"),
                                 policy_loss=res.stats.get("policy_loss")),
-                    roofline=roofline, roofline_gae=roofline_gae, kernel_ms_per_step=breakdown)
+                    roofline=roofline, roofline_gae=roofline_gae, kernel_ms_per_step=breakdown, resident_in_hbm=resident)
+        if fed is not None:
+            line["ring_fed"] = {k: v for k, v in fed.items() if k not in ("value", "ms_per_step", "ms_per_step_median", "ms_per_step_min")}
         if pcie is not None:
-            pcie["bound"] = ("pcie" if pcie["h2d_alone_ms"] and pcie["h2d_alone_ms"] > ms_step else "mfma")
             line["from_pinned_host"] = pcie
-        if world == 1 and not args.no_from_host:
-            line["rollout_inference"] = rollout_rate(trainer.policy, device)
+        if rollout_inf is not None:
+            line["rollout_inference"] = rollout_inf
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T)
         print(json.dumps(line), flush=True)

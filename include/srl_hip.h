@@ -486,6 +486,10 @@ int srl_step_plan_destroy(void* plan);
  *   (distributed/system/parameter_db.py:250-324) for replicas on the node.
  */
 #define SRL_COMM_ID_BYTES 128
+/* 1 when librccl and every entry point the wrappers use resolve in this process, else 0.  Touches no device and forms no
+ * communicator: ranks agree on this flag (a MIN all-reduce over their existing process group) BEFORE any of them enters
+ * srl_comm_init, whose ncclCommInitRank blocks until every rank has joined. */
+int srl_comm_available(void);
 int srl_comm_unique_id(void* id_out);
 int srl_comm_init(void** comm_out, const void* id, int rank, int world);
 int srl_comm_world(void* comm, int* world_out);

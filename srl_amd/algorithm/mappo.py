@@ -574,9 +574,18 @@ class MultiAgentPPO(PytorchTrainer):
             if self.popart:
                 pstats_local = block[epoch, stride - 3 * Nc:].view(Nc, 3)  # zeroed by srl_masked_stats_cols itself
                 hip.masked_stats_cols(flat(ret_d), on_reset[1 + lo:1 + hi], pstats_local, Nc, mask_invert=True)
-                pstats = pstats_local.clone()
-                if self._dist:
-                    dist.all_reduce(pstats)  # one message instead of utils.py:121-124's three
+                pstats = net.ws.get("mappo.pstats", 3 * Nc, torch.float64)[:3 * Nc].view(Nc, 3)
+                pstats.copy_(pstats_local)
+                if self._dist and self._comm is not None:
+                    # one message instead of utils.py:121-124's three, on the SAME communicator and side stream as the
+                    # advantage statistics and the gradient buckets: one communicator orders every collective of a step
+                    self._comm.all_reduce_f64_async(pstats)
+                    self._comm.join()
+                elif self._dist:
+                    if stats_work is not None:  # never two collectives of this step in flight on different streams
+                        stats_work.wait()
+                        stats_work = None
+                    dist.all_reduce(pstats)
                 self.policy.update_popart_from_stats(pstats, count=False)
                 loss_ret = torch.empty_like(ret_d)
                 hip.popart_map(ret_d, net.popart_state, Nc, loss_ret, True, ns.POPART_EPS)

@@ -36,11 +36,23 @@ class NativeComm:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_process_group(cls, device: str, group=None) -> Optional["NativeComm"]:
-        """Communicator over the ranks of the (default) process group, or None when it cannot be formed (the caller
-        then keeps using torch.distributed): SRL_COMM=torch, or the RCCL bootstrap failed."""
-        if os.environ.get("SRL_COMM", "native") == "torch":
+        """Communicator over the ranks of the (default) process group, or None when it is not asked for or cannot be formed
+        (the caller then keeps using torch.distributed, whose nccl backend IS RCCL): ``SRL_COMM=native`` opts in.  The
+        default stays ``torch`` until a multi-GPU run has validated the native path -- it has only ever seen one rank."""
+        if os.environ.get("SRL_COMM", "torch") != "native":
             return None
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+        # a rank on which librccl does not resolve must say so BEFORE anyone enters ncclCommInitRank (which blocks until
+        # every rank has joined): agree on availability over the existing process group first
+        try:
+            avail = int(hip.lib().srl_comm_available())
+        except (hip.HipError, OSError, AttributeError):  # pragma: no cover - depends on the box
+            avail = 0
+        flag = torch.tensor([avail], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            logger.warning("librccl does not resolve on every rank: using torch.distributed collectives")
+            return None
         comm = cls._try_init(device, group, rank, world)
         # every rank must take the same path: one that failed to join would otherwise wait in torch.distributed for peers
         # that sit in an RCCL collective

@@ -68,6 +68,8 @@ Rccl* rccl() {
 
 }  // namespace
 
+extern "C" int srl_comm_available(void) { return rccl() != nullptr ? 1 : 0; }
+
 extern "C" int srl_comm_unique_id(void* id_out) {
   SRL_CHECK_ARG(id_out, "null id buffer");
   SRL_NEED_RCCL(R);

@@ -142,6 +142,7 @@ _SIGNATURES = {
     "srl_step_plan_add_output": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_step_plan_run": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_int, POINTER(c_void_p), c_int, c_int]),
     "srl_step_plan_destroy": (c_int, [c_void_p]),
+    "srl_comm_available": (c_int, []),
     "srl_comm_unique_id": (c_int, [c_void_p]),
     "srl_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
     "srl_comm_world": (c_int, [c_void_p, POINTER(c_int)]),

@@ -87,6 +87,20 @@ class SampleRing:
     def nbytes(self) -> int:
         return sum(v.nbytes for blk in self._np for v in blk.values())
 
+    def host_blocks(self, slot: int) -> "OrderedDict[str, np.ndarray]":
+        """The slot's pinned blocks by flattened key, ``[Tb, B, ...]`` numpy views (what an exporter to actor processes
+        maps; benchmarks write the stamps of a synthetic rollout here)."""
+        return self._np[slot]
+
+    def attach_obs_ring(self, obs_ring):
+        """Serve the observation leaves from ``obs_ring`` from now on (None: copy them like every other leaf)."""
+        self.obs_ring = obs_ring
+        keys = frozenset(f"obs.{k}" for k in obs_ring.keys()) & frozenset(self._np[0]) if obs_ring is not None else frozenset()
+        self._ring_keys = keys
+        for slot in range(self.slots):  # device buffers follow the new key set at the next copy
+            if self._copied[slot] is None:
+                self._dev[slot] = None
+
     def ready(self) -> int:
         with self._lock:
             return len(self._full)

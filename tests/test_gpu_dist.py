@@ -102,7 +102,7 @@ def test_bench_script_with_two_ranks():
     env = dict(os.environ, SRL_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--global-envs", "32", "--rollout-len", "8", "--from-host-steps", "2"]
+           "--global-envs", "32", "--rollout-len", "8"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -111,6 +111,7 @@ def test_bench_script_with_two_ranks():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2
     assert line["config"]["global_envs"] == 32 and line["config"]["envs_per_gpu"] == 16 and line["value"] > 0
     assert line["config"]["collective_ranks"] == 2 and line["from_pinned_host"]["value"] > 0
+    assert line["resident_in_hbm"]["value"] > 0 and line["ring_fed"]["obs_ring"]["rows_patched"] == 0  # every stamp alive
     assert line["roofline"]["bound"] == "mfma" and "cpu_baseline" not in line  # the CPU baseline is N = 1 only
 
 
@@ -124,7 +125,7 @@ def test_bench_script_one_rank_over_rccl():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--global-envs", "16", "--rollout-len", "8", "--force-dist", "--no-cpu-baseline", "--from-host-steps", "2"]
+           "--global-envs", "16", "--rollout-len", "8", "--force-dist", "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -134,17 +135,20 @@ def test_bench_script_one_rank_over_rccl():
 
 def _native_comm_worker(rank, world, port, out):
     """One rank over RCCL (all a one-GPU box can offer): the C-ABI collectives on their side stream."""
+    import os
     import srl_amd
     from srl_amd import comm
-    torch.cuda.set_device(0)
+    os.environ["SRL_COMM"] = "native"  # opt in: torch.distributed collectives are the default
+    dev = f"cuda:{rank % torch.cuda.device_count()}"
+    torch.cuda.set_device(dev)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
-                            device_id=torch.device("cuda:0"))
+                            device_id=torch.device(dev))
     try:
-        c = comm.NativeComm.from_process_group("cuda:0")
+        c = comm.NativeComm.from_process_group(dev)
         assert c is not None and c.world == world
-        stats = torch.tensor([3.0, 1.5, 2.25], dtype=torch.float64, device="cuda:0")
-        grads = torch.arange(100000, dtype=torch.float32, device="cuda:0")
-        flat = torch.full((777,), 2.5, dtype=torch.float32, device="cuda:0")
+        stats = torch.tensor([3.0, 1.5, 2.25], dtype=torch.float64, device=dev)
+        grads = torch.arange(100000, dtype=torch.float32, device=dev)
+        flat = torch.full((777,), 2.5 if rank == 0 else -1.0, dtype=torch.float32, device=dev)
         c.all_reduce_f64_async(stats)
         c.all_reduce_f32_async(grads[:50000])
         c.all_reduce_f32_async(grads[50000:])
@@ -167,3 +171,16 @@ def test_native_rccl_wrappers_one_rank():
     assert stats == [3.0, 1.5, 2.25]
     assert gsum == float(np.arange(100000, dtype=np.float32).astype(np.float64).sum()) or abs(gsum - 4999950000.0) < 1e4
     assert fsum == 777 * 2.5
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL wants a device per rank")
+def test_native_rccl_wrappers_two_ranks():
+    """The same wrappers with two real ranks (only where the box has two GPUs): sums double, rank 0's buffer wins the
+    broadcast."""
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_native_comm_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+        for r in range(2):
+            stats, gsum, fsum = out[r]
+            assert stats == [6.0, 3.0, 4.5]
+            assert abs(gsum - 2 * 4999950000.0) < 2e4 and fsum == 777 * 2.5
