@@ -48,6 +48,9 @@ class OracleActorCritic:
                  continuous_action: bool = False,
                  **_ignored):
         self.popart = popart
+        # float32 like the reference; tests pass dtype=torch.float64 to get a higher-precision restatement of the SAME
+        # arithmetic, against which both the float32 oracle's and the device path's rounding can be measured
+        self.dtype = _ignored.get("dtype", torch.float32)
         self.continuous = continuous_action
         self.std_type = _ignored.get("std_type", "fixed")
         self.obs_dim = {"obs": obs_dim} if isinstance(obs_dim, int) else dict(obs_dim)
@@ -74,7 +77,7 @@ class OracleActorCritic:
                 self.params[k] = t.double()
             else:
                 fixed = k == "log_std" and self.continuous and self.std_type == "fixed"  # :88-89 requires_grad=False
-                self.params[k] = t.float().requires_grad_(not fixed)
+                self.params[k] = t.to(self.dtype).requires_grad_(not fixed)
 
     def state_dict(self):
         return OrderedDict((k, v.detach().clone()) for k, v in self.params.items())

@@ -49,10 +49,10 @@ class OracleMappo:
         self.frames = 0
 
     def step(self, sample: Dict[str, np.ndarray]):
-        f32 = lambda k: torch.from_numpy(np.asarray(sample[k])).float()
+        f32 = lambda k: torch.from_numpy(np.asarray(sample[k])).to(self.net.dtype)  # float32 (api/trainer.py:217)
         on_reset, done, truncated = f32("on_reset"), f32("done"), f32("truncated")
         reward, old_value, old_lp = f32("reward"), f32("analyzed_result.value"), f32("analyzed_result.log_probs")
-        action = torch.from_numpy(np.asarray(sample["action.x"])).float()
+        action = torch.from_numpy(np.asarray(sample["action.x"])).to(self.net.dtype)
         obs = {k[4:]: f32(k) for k in sample if k.startswith("obs.")}
         pstate = None
         if self.net.num_rnn_layers:
@@ -127,14 +127,14 @@ class OracleMappo:
         (``:121-124``) are sums over all ranks.  Returns (list of per-rank stats, list of per-rank padded adv/ret)."""
         assert not self.vtrace and not self.burn_in_steps and not self.net.num_rnn_layers, "oracle DP: feed-forward PPO only"
         W = len(samples)
-        f32 = lambda smp, k: torch.from_numpy(np.asarray(smp[k])).float()
+        f32 = lambda smp, k: torch.from_numpy(np.asarray(smp[k])).to(self.net.dtype)
         boot = self.bootstrap_steps
         ranks = []
         for smp in samples:
             r = dict(on_reset=f32(smp, "on_reset"), done=f32(smp, "done"), truncated=f32(smp, "truncated"),
                      reward=f32(smp, "reward"), old_value=f32(smp, "analyzed_result.value"),
                      old_lp=f32(smp, "analyzed_result.log_probs"),
-                     action=torch.from_numpy(np.asarray(smp["action.x"])).float(),
+                     action=torch.from_numpy(np.asarray(smp["action.x"])).to(self.net.dtype),
                      obs={k[4:]: f32(smp, k) for k in smp if k.startswith("obs.")})
             Tb = r["on_reset"].shape[0]
             r["keep"] = Tb - boot
