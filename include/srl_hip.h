@@ -356,9 +356,14 @@ int64_t srl_conv2d_obs_fwd_workspace(const srl_conv_desc* d);
 /* workspace (srl_conv2d_obs_fwd_workspace floats, or NULL): with it the layer runs position-batched, one GEMM per
  * output position over the samples with the LayerNorm affine folded into per-position weights (w*gamma) and biases
  * (bias + w.beta), so that the operand gather needs no table lookups; without it the affine is applied in the gather. */
+/* row_index (int32 [n], device, or NULL): sample i of the batch is row row_index[i] of `obs`, and mean / rstd are indexed
+ * by that same row -- the batch's frames are then read in place from the HBM observation ring (srl_gather_rows' comment)
+ * with no gather pass at all.  Honoured by the byte kernels only: ask srl_conv2d_obs_row_index_supported first (1 = yes);
+ * with 0 gather the rows (srl_gather_rows) and pass NULL. */
+int srl_conv2d_obs_row_index_supported(const srl_conv_desc* d, int is_u8, int channels_last);
 int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
-                       const float* bias, float* y, float* workspace);
+                       const float* bias, float* y, float* workspace, const int32_t* row_index);
 /* Space-to-depth of a planar observation for a strided first convolution (stride s | KH, KW, H, W):
  * out[n, H/s, W/s, (c, ph, pw)] = obs[n, c, a*s + ph, b*s + pw], same element type, plus the whole-observation
  * LayerNorm statistics in the same pass.  A KxK stride-s convolution on obs becomes a (K/s)x(K/s) stride-1
@@ -373,7 +378,8 @@ int srl_obs_space_to_depth(void* stream, const void* obs, int is_u8, int64_t n, 
 int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d);
 int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
-                       const float* dz, float* dw, float* db, float* dgamma, float* dbeta, float* workspace);
+                       const float* dz, float* dw, float* db, float* dgamma, float* dbeta, float* workspace,
+                       const int32_t* row_index);
 
 /* Row gather behind the HBM observation ring: dst[i, :] = src[index[i], :], rows of row_bytes (a multiple of 4;
  * 16-byte pieces when row_bytes % 16 == 0 and both bases are 16-byte aligned).  The frames `rollout` uploaded
@@ -381,6 +387,10 @@ int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, in
  * ring slot, and this gather stands in for the SECOND host-to-device crossing of the same frames in
  * PyTorchGPUPrefetcher.push (api/trainer.py:211-228).  index: int32 [n] device, src rows addressed by slot. */
 int srl_gather_rows(void* stream, const void* src, int64_t row_bytes, const int32_t* index, int64_t n, void* dst);
+/* Ring sequence numbers (the int64 stamps a sample carries, all alive: checked by the caller on the host) -> storage
+ * slots: slots[i] = refs[i] % capacity, on the device copy of the stamps, so that binding a sample costs the host two
+ * passes over them (min / max) and no upload of its own. */
+int srl_ring_slots(void* stream, const int64_t* refs, int64_t n, int64_t capacity, int32_t* slots);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser on one flat parameter buffer.

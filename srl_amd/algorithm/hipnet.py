@@ -484,7 +484,12 @@ class HipNet:
                     gam, bet = self._p(f"{pending_obs_ln.prefix}.weight"), self._p(f"{pending_obs_ln.prefix}.bias")
                     if staged is not None and not (implicit and L.s2d and staged.layout == ("s2d", int(L.s2d))):
                         raise hip.HipError(f"observation `{enc.key}`: ring layout {staged.layout} does not fit this network")
-                    if staged is not None:
+                    row_index = None
+                    if staged is not None and staged.span is None and hip.conv2d_obs_row_index_supported(desc, is_u8, True):
+                        # the byte kernels read the ring's rows in place, through the sample's slot index: no pass over
+                        # the frames besides the convolution's own
+                        src, mean, rstd, row_index = staged.in_place()
+                    elif staged is not None:
                         # no re-tiling pass and no statistics pass: both were done once, when the rollout uploaded the row
                         src, mean, rstd = staged.resolve(self.ws, f"{tag}{L.prefix}")
                     else:
@@ -500,12 +505,12 @@ class HipNet:
                     if implicit:
                         hip.conv2d_obs_fwd(desc, src.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet,
                                            self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"), y.ptr,
-                                           channels_last=bool(L.s2d),
+                                           channels_last=bool(L.s2d), row_index=row_index,
                                            ws_ptr=self.ws.get("conv_obs_fwd", hip.conv2d_obs_fwd_workspace(desc)).data_ptr())
                     else:
                         hip.im2col_obs_ln(obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet, n, c, h, w,
                                           L.k, L.k, L.stride, P.ptr)
-                    saved = (src, is_u8, mean, rstd, pending_obs_ln, bool(L.s2d))
+                    saved = (src, is_u8, mean, rstd, pending_obs_ln, bool(L.s2d), row_index)
                 else:
                     assert cur.ld == L.cin and cur.rows == n * h * w
                     if implicit:
@@ -575,12 +580,12 @@ class HipNet:
                     assert g.ld == L.cout
                     gw, gb, wp = self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"), self._p(f"{L.prefix}.weight")
                     if L.first:
-                        obs, is_u8, mean, rstd, lnspec, chlast = first_saved
+                        obs, is_u8, mean, rstd, lnspec, chlast, row_index = first_saved
                         wsz = hip.conv2d_obs_bwd_workspace(desc)
                         hip.conv2d_obs_bwd(desc, obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(),
                                            self._p(f"{lnspec.prefix}.weight"), self._p(f"{lnspec.prefix}.bias"), wp, g.ptr,
                                            gw, gb, self._g(f"{lnspec.prefix}.weight"), self._g(f"{lnspec.prefix}.bias"),
-                                           self.ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=chlast)
+                                           self.ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=chlast, row_index=row_index)
                         g = None
                     else:
                         wsz = hip.conv2d_wgrad_workspace(desc)
@@ -602,7 +607,7 @@ class HipNet:
                 # dP = dZ W, written over the patch matrix (its last reader was the weight gradient above)
                 hip.gemm(m, kdim, L.cout, g.ptr, g.ld, 0, self._p(f"{L.prefix}.weight"), kdim, 1, P.ptr, kdim)
                 if L.first:
-                    obs, is_u8, mean, rstd, lnspec, _ = first_saved
+                    obs, is_u8, mean, rstd, lnspec, _, _ = first_saved
                     c, h, w = lnspec.shape
                     hip.obs_ln_affine_bwd(P.ptr, obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), n, c, h, w, L.k,
                                           L.k, L.stride, self._g(f"{lnspec.prefix}.weight"),

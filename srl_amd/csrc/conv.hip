@@ -252,8 +252,10 @@ bool obs_bf16_ok(const srl_conv_desc* d, int is_u8, int channels_last, const voi
   return img % 16 == 0 && ((long)d->stride * d->Cin) % 16 == 0 && aligned16(obs) && d->n >= 32;
 }
 
-srlobs::ObsGeom obs_geom(const srl_conv_desc* d, const void* obs, const float* mean, const float* rstd, int OW) {
+srlobs::ObsGeom obs_geom(const srl_conv_desc* d, const void* obs, const float* mean, const float* rstd, int OW,
+                         const int32_t* row_index = nullptr) {
   srlobs::ObsGeom g{};
+  g.row_index = row_index;
   g.frames = static_cast<const uint8_t*>(obs);
   g.img_stride = (long)d->H * d->W * d->Cin;
   g.W = d->W; g.Cin = d->Cin; g.OW = OW; g.stride = d->stride;
@@ -268,7 +270,9 @@ srlobs::ObsGeom obs_geom(const srl_conv_desc* d, const void* obs, const float* m
 int obs_bf16_split(long n, int P, int per_cu) {
   const long slots = 256L * per_cu;
   long want = (4 * slots + P - 1) / P;
-  const long cap = n / 512 > 1 ? n / 512 : 1;
+  static const long rows_min = [] { const char* e = getenv("SRL_OBS_SPLIT_ROWS"); return e ? atol(e) : 512L; }();  // tuning knob
+  if (rows_min < 512) want = n / rows_min;
+  const long cap = n / rows_min > 1 ? n / rows_min : 1;
   if (want > cap) want = cap;
   return (int)(want < 1 ? 1 : want);
 }
@@ -494,9 +498,17 @@ extern "C" int64_t srl_conv2d_obs_fwd_workspace(const srl_conv_desc* d) {
   return (int64_t)OH * OW * d->Cout * (2 * (long)d->Cin * d->KH * d->KW + 2) + 64;
 }
 
+extern "C" int srl_conv2d_obs_row_index_supported(const srl_conv_desc* d, int is_u8, int channels_last) {
+  if (check_desc(d) != 0 || !srl_conv2d_supported(d, channels_last ? 2 : 1)) return 0;
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
+  return obs_bf16_ok(d, is_u8, channels_last, nullptr) && ((long)OH * OW * d->Cout) % 4 == 0 ? 1 : 0;
+}
+
 extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                  const float* w, const float* bias, float* y, float* workspace) {
+                                  const float* w, const float* bias, float* y, float* workspace, const int32_t* row_index) {
+  SRL_CHECK_ARG(row_index == nullptr || (workspace && srl_conv2d_obs_row_index_supported(d, is_u8, channels_last)),
+                "row_index is served by the byte kernels only (srl_conv2d_obs_row_index_supported)");
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1),
                 "unsupported geometry (planar: KW, W, stride, H*W multiples of 4; channels-last: Cin multiple of 4)");
   SRL_CHECK_ARG(obs && mean && rstd && gamma && beta && w && y && aligned16(obs) && aligned16(gamma) && aligned16(beta),
@@ -521,7 +533,7 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
     hipLaunchKernelGGL(srlobs::obs_fold_split_kernel<ObsIndex>, dim3((unsigned)(P * d->Cout)), dim3(256), 0, st, w, bias, gamma,
                        beta, P, (int)Kp, ix, wq, S, b2);
     srlobs::FwdArgs a{};
-    a.g = obs_geom(d, obs, mean, rstd, OW);
+    a.g = obs_geom(d, obs, mean, rstd, OW, row_index);
     a.wq = reinterpret_cast<const uint4*>(wq);
     a.S = S; a.b2 = b2; a.y = y; a.P = P; a.act = d->act;
     a.nsplit = obs_bf16_split(d->n, P, 3);
@@ -593,8 +605,10 @@ extern "C" int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d) {
 extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
                                   const float* w, const float* dz, float* dw, float* db, float* dgamma, float* dbeta,
-                                  float* workspace) {
+                                  float* workspace, const int32_t* row_index) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1), "unsupported geometry");
+  SRL_CHECK_ARG(row_index == nullptr || srl_conv2d_obs_row_index_supported(d, is_u8, channels_last),
+                "row_index is served by the byte kernels only (srl_conv2d_obs_row_index_supported)");
   SRL_CHECK_ARG(obs && mean && rstd && gamma && beta && w && dz && dw && db && dgamma && dbeta && workspace,
                 "null tensor");
   SRL_CHECK_ARG(aligned16(obs) && aligned16(dz) && aligned16(workspace) && d->Cout % 4 == 0, "unaligned tensor / Cout % 4");
@@ -613,7 +627,7 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
   const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, channels_last ? 1 : 0};
   if (obs_bf16_ok(d, is_u8, channels_last, obs) && (P * d->Cout) % 4 == 0) {
     srlobs::BwdArgs a{};
-    a.g = obs_geom(d, obs, mean, rstd, OW);
+    a.g = obs_geom(d, obs, mean, rstd, OW, row_index);
     a.dz = dz; a.R = R; a.C = C; a.P = P;
     a.nsplit = obs_bf16_split(d->n, P, 3);
     a.Q = a.nsplit > 1 ? slabs : Q;

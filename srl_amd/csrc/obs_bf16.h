@@ -41,9 +41,14 @@ struct ObsGeom {
   const float* mean;
   const float* rstd;
   long n;
+  // rows addressed through a slot index (observation ring): sample i is frames[row_index[i]], with mean / rstd indexed by
+  // the same slot; NULL: sample i is row i
+  const int32_t* row_index;
 };
 
 #ifdef __HIPCC__
+__device__ __forceinline__ long obs_slot(const ObsGeom& g, long n) { return g.row_index ? (long)g.row_index[n] : n; }
+
 // exact three-way truncation split of a float32 into bf16 pieces (returned as the high halves of float32 words)
 __device__ __forceinline__ void split3(float v, uint32_t& b0, uint32_t& b1, uint32_t& b2) {
   b0 = __float_as_uint(v) & 0xffff0000u;
@@ -170,13 +175,14 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
   auto rowptr = [&](long tile) {
     long n = tile * 32 + l31;
     if (n >= a.g.n) n = a.g.n - 1;  // clamped: the loads stay in bounds, the stores of such rows are masked
-    return a.g.frames + ((DBG & 8) ? (long)l31 : n) * a.g.img_stride + posoff;
+    return a.g.frames + ((DBG & 8) ? (long)l31 : obs_slot(a.g, n)) * a.g.img_stride + posoff;
   };
   // (rstd, -(mean - c) rstd) of the accumulator ROWS go through LDS for the wavefront's own later reads (a wavefront's
   // LDS instructions execute in order; no other wavefront touches this slice); returns the integer centre c in [0, 255]
   auto rowstats = [&](int set, long tile) {
     long n = tile * 32 + l31;
     if (n >= a.g.n) n = a.g.n - 1;
+    n = obs_slot(a.g, n);
     const float r = a.g.rstd[n], m = a.g.mean[n];
     const float c = rintf(m);
     if (h == 0) {
@@ -325,11 +331,12 @@ __global__ __launch_bounds__(256, 2) void obs_bwd_bf16_kernel(BwdArgs a) {
     const bool ok = n < a.g.n;
     const long nn = ok ? n : a.g.n - 1;
     dzr[set] = ok ? *reinterpret_cast<const float4*>(a.dz + nn * ldz + (long)pos * kCout + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const uint8_t* rowp = a.g.frames + nn * a.g.img_stride + posoff;
+    const long slot = obs_slot(a.g, nn);
+    const uint8_t* rowp = a.g.frames + slot * a.g.img_stride + posoff;
 #pragma unroll
     for (int i = 0; i < NBQ; ++i) xb[set][i] = *reinterpret_cast<const uint4*>(rowp + boff[i]);
-    s_rs[set] = ok ? a.g.rstd[nn] : 0.f;  // rows past the end contribute zeros (dz' = 0)
-    s_mean[set] = a.g.mean[nn];
+    s_rs[set] = ok ? a.g.rstd[slot] : 0.f;  // rows past the end contribute zeros (dz' = 0)
+    s_mean[set] = a.g.mean[slot];
   };
   auto lstore = [&](int set, uint8_t* buf) {
     const float d[4] = {dzr[set].x, dzr[set].y, dzr[set].z, dzr[set].w};

@@ -60,12 +60,13 @@ _SIGNATURES = {
     "srl_conv2d_dgrad_weight_elems": (c_int64, [_CD]),
     "srl_conv2d_dgrad_repack": (c_int, [c_void_p, _CD, c_void_p, c_void_p]),
     "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 8),
+    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 9),
+    "srl_conv2d_obs_row_index_supported": (c_int, [_CD, c_int, c_int]),
     "srl_conv2d_obs_fwd_workspace": (c_int64, [_CD]),
     "srl_obs_space_to_depth": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                         c_void_p]),
     "srl_conv2d_obs_bwd_workspace": (c_int64, [_CD]),
-    "srl_conv2d_obs_bwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 11),
+    "srl_conv2d_obs_bwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 12),
     "srl_abi_version": (c_int, []),
     "srl_last_error": (c_char_p, []),
     "srl_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
@@ -117,6 +118,7 @@ _SIGNATURES = {
     "srl_copy2d": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int]),
     "srl_u8_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "srl_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "srl_ring_slots": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "srl_grad_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                c_float, c_float, c_int, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
@@ -692,12 +694,18 @@ def conv2d_obs_fwd_workspace(d: ConvDesc) -> int:
     return int(lib().srl_conv2d_obs_fwd_workspace(ctypes.byref(d)))
 
 
+def conv2d_obs_row_index_supported(d: ConvDesc, is_u8, channels_last) -> bool:
+    """Whether ``conv2d_obs_fwd / bwd`` honour ``row_index`` for this geometry (the byte kernels do)."""
+    return bool(lib().srl_conv2d_obs_row_index_supported(ctypes.byref(d), int(is_u8), int(channels_last)))
+
+
 def conv2d_obs_fwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr,
-                   channels_last=False, ws_ptr=None):
+                   channels_last=False, ws_ptr=None, row_index: Optional[torch.Tensor] = None):
     with _scope("conv_obs_fwd", _conv_flops(d)):
         _check(
             lib().srl_conv2d_obs_fwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), int(channels_last), mean_ptr,
-                                     rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr, ws_ptr), "srl_conv2d_obs_fwd")
+                                     rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr, ws_ptr,
+                                     _ptr(row_index, torch.int32, "row_index")), "srl_conv2d_obs_fwd")
 
 
 def obs_space_to_depth(obs_ptr, is_u8, n, C, H, W, s, out_ptr, mean_ptr, rstd_ptr):
@@ -713,17 +721,23 @@ def gather_rows(src_ptr, row_bytes, index: torch.Tensor, n, dst_ptr):
                "srl_gather_rows")
 
 
+def ring_slots(refs: torch.Tensor, capacity: int, out: torch.Tensor):
+    """out[i] = refs[i] % capacity (``srl_ring_slots``): int64 stamps -> int32 storage slots, on the device."""
+    _check(lib().srl_ring_slots(_stream(), _ptr(refs, torch.int64, "refs"), refs.numel(), int(capacity),
+                                _ptr(out, torch.int32, "slots")), "srl_ring_slots")
+
+
 def conv2d_obs_bwd_workspace(d: ConvDesc) -> int:
     return int(lib().srl_conv2d_obs_bwd_workspace(ctypes.byref(d)))
 
 
 def conv2d_obs_bwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, dz_ptr, dw_ptr, db_ptr,
-                   dgamma_ptr, dbeta_ptr, ws_ptr, channels_last=False):
+                   dgamma_ptr, dbeta_ptr, ws_ptr, channels_last=False, row_index: Optional[torch.Tensor] = None):
     with _scope("conv_obs_bwd", _conv_flops(d)):
         _check(
             lib().srl_conv2d_obs_bwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), int(channels_last), mean_ptr,
                                      rstd_ptr, gamma_ptr, beta_ptr, w_ptr, dz_ptr, dw_ptr, db_ptr, dgamma_ptr, dbeta_ptr,
-                                     ws_ptr), "srl_conv2d_obs_bwd")
+                                     ws_ptr, _ptr(row_index, torch.int32, "row_index")), "srl_conv2d_obs_bwd")
 
 
 def _wrap_for_profile(names):

@@ -240,7 +240,8 @@ class SampleRing:
         device copies on the caller's stream."""
         refs = self._np[slot].get("analyzed_result.obs_ref")
         host_obs = {k[4:]: self._host[slot][k] for k in self._ring_keys}
-        bound = self.obs_ring.bind(refs, host_obs)
+        refs_dev = self._dev[slot].get("analyzed_result.obs_ref") if self._dev[slot] is not None else None
+        bound = self.obs_ring.bind(refs, host_obs, refs_device=refs_dev)
         if bound is None:
             return {k: self._host[slot][k].to(self.device, non_blocking=True) for k in self._ring_keys}
         rows, lease = bound

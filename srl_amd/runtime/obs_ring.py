@@ -134,6 +134,12 @@ class RingObs:
         hip.gather_rows(r.rstd[k].data_ptr(), 4, idx, n, rstd.data_ptr())
         return frames, mean, rstd
 
+    def in_place(self):
+        """``(storage rows, mean, rstd, int32 slot index [n])`` of the ``s2d`` layout for a kernel that addresses its rows
+        through the index: nothing is copied."""
+        r, k = self.ring, self.key
+        return r.storage[k], r.mean[k], r.rstd[k], self._flat_index().contiguous()
+
     def gather_raw(self, ws, name: str) -> torch.Tensor:
         """The rows as one contiguous raw tensor ``[n, *raw_shape]`` (``raw`` layout only)."""
         if self.layout[0] != "raw":
@@ -316,12 +322,15 @@ class ObsRing:
         self._stage(rows, s0, n)
         return np.arange(s0, s0 + n, dtype=np.int64)
 
-    def bind(self, refs, host_obs: Optional[Dict[str, "torch.Tensor"]] = None, piece_rows: int = 4096):
+    def bind(self, refs, host_obs: Optional[Dict[str, "torch.Tensor"]] = None, piece_rows: int = 4096,
+             refs_device: Optional[torch.Tensor] = None):
         """``refs``: int64 ``[Tb, B]`` (or ``[Tb, B, 1]``) sequence numbers from the sample, or None (no references: every
         row is uploaded).  ``host_obs``: key -> host rows ``[Tb, B, *raw_shape]`` (pinned torch tensors or numpy), used for
-        the rows whose reference is not alive: they are uploaded into the patch area.  Returns ``(key -> RingObs
-        [Tb, B, ...], lease)``, or None when the ring cannot serve the sample (a dead reference without a host copy, or
-        more dead rows than the patch area holds): the caller then copies the observations itself."""
+        the rows whose reference is not alive: they are uploaded into the patch area.  ``refs_device``: the same stamps
+        already on the device (the sample's own leaf): with every stamp alive the slot index is then computed there and
+        the host only takes their minimum and maximum.  Returns ``(key -> RingObs [Tb, B, ...], lease)``, or None when
+        the ring cannot serve the sample (a dead reference without a host copy, or more dead rows than the patch area
+        holds): the caller then copies the observations itself."""
         keys = list(self.layout)
         if refs is None:
             if not host_obs:
@@ -331,13 +340,28 @@ class ObsRing:
         refs = np.asarray(refs)
         if refs.ndim == 3 and refs.shape[2] == 1:
             refs = refs[..., 0]
-        refs = refs.astype(np.int64)
+        if refs.dtype != np.int64:
+            refs = refs.astype(np.int64)
+        lo, hi = (int(refs.min()), int(refs.max())) if refs.size else (0, -1)
         with self._lock:  # liveness and the lease in one step: no allocation can slip in between
             head = self._ring.head
-            ok = (refs >= 0) & (refs < head) & (refs + self.capacity >= head)
-            lease = ObsLease(self, int(refs[ok].min()) if ok.any() else None)
-            if lease.min_seq is not None:
+            if lo >= 0 and hi < head and lo + self.capacity >= head:  # the common case: every stamp alive
+                lease = ObsLease(self, lo)
                 self._leases.append(lease)
+                ok = None
+            else:
+                ok = (refs >= 0) & (refs < head) & (refs + self.capacity >= head)
+                lease = ObsLease(self, int(refs[ok].min()) if ok.any() else None)
+                if lease.min_seq is not None:
+                    self._leases.append(lease)
+        stream = torch.cuda.current_stream(self.device)
+        if ok is None:
+            if refs_device is not None and refs_device.is_cuda and refs_device.dtype == torch.int64 and refs_device.is_contiguous():
+                index = torch.empty(refs.shape, dtype=torch.int32, device=self.device)
+                hip.ring_slots(refs_device, self.capacity, index)
+            else:
+                index = torch.from_numpy((refs % self.capacity).astype(np.int32)).to(self.device, non_blocking=True)
+            return self._bound(keys, refs.shape, index, lease, stream, 0)
         slots = np.where(ok, refs % self.capacity, -1)
         patched = 0
         try:
@@ -374,18 +398,20 @@ class ObsRing:
                 self.stats["binds_failed"] += 1
             return None
         index = torch.from_numpy(slots.astype(np.int32)).to(self.device, non_blocking=True)
-        stream = torch.cuda.current_stream(self.device)
         if patched:
             lease.uploaded = torch.cuda.Event()
             lease.uploaded.record(stream)
+        return self._bound(keys, refs.shape, index, lease, stream, patched)
+
+    def _bound(self, keys, lead, index, lease, stream, patched):
         with self._lock:
             events = [ev for s, ev in self._write_events.items() if s != stream.cuda_stream]
-            self.stats["rows_bound"] += refs.size
+            self.stats["rows_bound"] += int(np.prod(lead))
             self.stats["rows_patched"] += patched
             self.stats["binds"] += 1
         for ev in events:  # rows written on the inference thread's stream
             stream.wait_event(ev)
-        return {k: RingObs(self, k, refs.shape, index=index) for k in keys}, lease
+        return {k: RingObs(self, k, lead, index=index) for k in keys}, lease
 
     def release(self, lease: Optional[ObsLease], record: bool = True):
         """The step that read the leased rows has been enqueued: later allocations may lap them (after that work)."""
