@@ -104,6 +104,12 @@ int srl_masked_normalize(void* stream, const float* x, const uint8_t* mask, int 
 int srl_masked_stats_cols(void* stream, const float* x, const uint8_t* mask, int mask_invert, long n,
                           int vd, double* stats);
 
+/* col_stats [vd][3] from srl_masked_stats_cols -> stats[3] = { col_stats[0][0], sum_c col_stats[c][1], sum_c col_stats[c][2] }:
+ * the sums masked_normalization takes over ALL channels of a [T, B, value_dim] advantage block under one [T, B, 1] mask
+ * (modules/utils.py:38-57 with the mask broadcast). */
+int srl_fold_col_stats(void* stream, const double* col_stats, int vd, double* stats);
+/* ratio[i] = exp(new_lp[i] - old_lp[i]): the V-trace importance ratio of mappo.py:130-133. */
+int srl_importance_ratio(void* stream, const float* new_lp, const float* old_lp, long n, float* ratio);
 /* rms <- beta * rms + (1 - beta) * {s/n, q/n, 1} (utils.py:125-130).  rescale != 0 additionally rewrites
  * the head so that its de-normalised output is unchanged: w[r,:] *= old_std/new_std,
  * b = (old_std*b + old_mean - new_mean)/new_std (popart.py:49-51; the reference only does this after

@@ -209,7 +209,6 @@ class MultiAgentPPO(PytorchTrainer):
         self._comm = None
         self._reducer = None
         self._gae_ws = {}
-        self._padded = None
 
     # ------------------------------------------------------------------ checkpoints (mappo.py:58-66)
     def get_checkpoint(self):
@@ -273,6 +272,19 @@ class MultiAgentPPO(PytorchTrainer):
             else:
                 self._opt_steps = 0
             grp = osd["param_groups"][0]
+            # the group names its optimiser by the keys only that optimiser has (torch's load_state_dict would overwrite
+            # the group and fail on foreign state; mappo.py:58-66): a checkpoint of another kind is refused, not zero-filled
+            kind_keys = {'adam': ("betas",), 'adamw': ("betas",), 'rmsprop': ("alpha", "centered"), 'sgd': ("dampening", "nesterov")}
+            foreign = [k for kind, keys in kind_keys.items() if kind_keys[kind] != kind_keys[self._opt] for k in keys if k in grp]
+            if foreign or any(k not in grp for k in kind_keys[self._opt]):
+                raise ValueError(f"optimizer_state_dict is not a `{self._opt}` state (group keys {sorted(grp)})")
+            if self._opt == 'rmsprop' and bool(grp["centered"]) != self._centered:
+                self._centered = bool(grp["centered"])
+                self._gavg = torch.zeros_like(net.flat) if self._centered else None
+                if self._centered and st and "grad_avg" in st[0]:
+                    self._gavg.copy_(flat_of("grad_avg"))
+            if self._opt == 'sgd':
+                self._dampening, self._nesterov = grp.get("dampening", self._dampening), bool(grp.get("nesterov", self._nesterov))
             self._lr = grp["lr"]
             self._weight_decay = grp.get("weight_decay", self._weight_decay)
             if self._opt in ('adam', 'adamw'):
@@ -315,7 +327,9 @@ class MultiAgentPPO(PytorchTrainer):
             ent = net.ws.get("entropy", n)[:n]
             self.policy.dist_fwd(logits, f_action[r0:r1], None if f_avail is None else f_avail[r0:r1], new_lp[r0:r1], ent)
             self.policy.mask_dead(new_lp[r0:r1], None if alive is None else flat(alive).reshape(-1)[r0:r1])
-        return torch.exp(new_lp - flat(old_lp).reshape(-1)).reshape(rows, B, 1)
+        ratio = torch.empty(n_all, dtype=torch.float32, device=old_lp.device)
+        hip.importance_ratio(new_lp, flat(old_lp).reshape(-1).contiguous(), ratio)
+        return ratio.reshape(rows, B, 1)
 
     # ------------------------------------------------------------------ the step (mappo.py:219-328)
     def step(self, sample):
@@ -532,12 +546,11 @@ class MultiAgentPPO(PytorchTrainer):
                 else:
                     adv_d = net.ws.get("mappo.adv", Tb * B * Nc)[:Tb * B * Nc].view(Tb, B, Nc)
                     ret_d = net.ws.get("mappo.ret", Tb * B * Nc)[:Tb * B * Nc].view(Tb, B, Nc)
-                    # the scan writes rows [0, Tb-1); the last row is the zero pad (:254-256): zeroed when the buffers
-                    # first take this shape, nothing writes it afterwards
-                    if self._padded != (adv_d.data_ptr(), ret_d.data_ptr(), Tb, B, Nc):
-                        adv_d[Tb - 1:].zero_()
-                        ret_d[Tb - 1:].zero_()
-                        self._padded = (adv_d.data_ptr(), ret_d.data_ptr(), Tb, B, Nc)
+                    # the scan writes rows [0, Tb-1); the last row is the zero pad (:254-256).  Zeroed every step: the
+                    # workspace is shared by every sample shape this trainer sees (and by every captured graph), so the
+                    # row may hold another shape's advantages -- B * Nc floats, nothing next to the step
+                    adv_d[Tb - 1:].zero_()
+                    ret_d[Tb - 1:].zero_()
                     fused_stats = boot == 1 and burn == 0  # the scan's own sums are those of the loss rows
                     gws = self._gae_ws.get((B, Nc))
                     if gws is None:  # zeroed once; afterwards the scan's own last workgroup resets it
@@ -554,9 +567,9 @@ class MultiAgentPPO(PytorchTrainer):
                 if not fused_stats and Nc == 1:
                     hip.masked_stats(adv_d[lo:hi], mask_rows, stats_local, mask_invert=True)
                 elif not fused_stats:  # [n, Nc] advantages under an [n] mask: per-channel sums, the mask counted once
-                    cs = torch.zeros((Nc, 3), **f64)
+                    cs = net.ws.get("mappo.col_stats", 3 * Nc, torch.float64)[:3 * Nc].view(Nc, 3)  # zeroed by the call
                     hip.masked_stats_cols(adv_d[lo:hi].reshape(-1, Nc), mask_rows, cs, Nc, mask_invert=True)
-                    stats_local.copy_(torch.stack([cs[0, 0], cs[:, 1].sum(), cs[:, 2].sum()]))
+                    hip.fold_col_stats(cs, Nc, stats_local)
                 if self._dist:
                     stats_global.copy_(stats_local)
                     # one 24-byte message instead of three (utils.py:58-61), issued asynchronously: it crosses the

@@ -73,7 +73,37 @@ __global__ __launch_bounds__(256) void popart_map_kernel(const float* x, long n,
   }
 }
 
+// per-channel sums -> the three sums of the advantage normalisation over every channel (the mask counted once)
+__global__ void fold_col_stats_kernel(const double* cs, int vd, double* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0, q = 0.0;
+    for (int c = 0; c < vd; ++c) { s += cs[3 * c + 1]; q += cs[3 * c + 2]; }
+    out[0] = cs[0]; out[1] = s; out[2] = q;
+  }
+}
+
+__global__ __launch_bounds__(256) void importance_ratio_kernel(const float* new_lp, const float* old_lp, long n, float* out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = expf(new_lp[i] - old_lp[i]);
+}
+
 }  // namespace
+
+extern "C" int srl_fold_col_stats(void* stream, const double* col_stats, int vd, double* stats) {
+  SRL_CHECK_ARG(col_stats && stats && vd >= 1 && vd <= 64, "bad arguments (1 <= value_dim <= 64)");
+  hipLaunchKernelGGL(fold_col_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, col_stats, vd, stats);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_importance_ratio(void* stream, const float* new_lp, const float* old_lp, long n, float* ratio) {
+  SRL_CHECK_ARG(n >= 0, "negative count");
+  if (n == 0) return 0;
+  SRL_CHECK_ARG(new_lp && old_lp && ratio, "null tensor");
+  const unsigned grid = (unsigned)(srl_ceil_div(n, 256L) < 2048 ? srl_ceil_div(n, 256L) : 2048);
+  hipLaunchKernelGGL(importance_ratio_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, new_lp, old_lp, n, ratio);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int srl_masked_stats_cols(void* stream, const float* x, const uint8_t* mask, int mask_invert, long n, int vd,
                                      double* stats) {

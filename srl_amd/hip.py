@@ -78,6 +78,8 @@ _SIGNATURES = {
     "srl_masked_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_double, c_int,
                                       c_void_p]),
     "srl_masked_stats_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
+    "srl_fold_col_stats": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "srl_importance_ratio": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "srl_popart_update": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                   c_int]),
     "srl_popart_map": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_double, c_int, c_void_p]),
@@ -380,6 +382,16 @@ def masked_stats_cols(x, mask, stats, vd, mask_invert=False):
         lib().srl_masked_stats_cols(_stream(), _ptr(x, torch.float32, "x"), _ptr(mask, torch.uint8, "mask"),
                                     int(mask_invert), x.numel() // vd, int(vd), _ptr(stats, torch.float64, "stats")),
         "srl_masked_stats_cols")
+
+
+def fold_col_stats(col_stats, vd, stats):
+    _check(lib().srl_fold_col_stats(_stream(), _ptr(col_stats, torch.float64, "col_stats"), int(vd),
+                                    _ptr(stats, torch.float64, "stats")), "srl_fold_col_stats")
+
+
+def importance_ratio(new_lp, old_lp, out):
+    _check(lib().srl_importance_ratio(_stream(), _ptr(new_lp, torch.float32, "new_lp"), _ptr(old_lp, torch.float32, "old_lp"),
+                                      new_lp.numel(), _ptr(out, torch.float32, "ratio")), "srl_importance_ratio")
 
 
 def popart_update(stats, rms, vd, beta, eps, w_ptr=None, b_ptr=None, in_features=0, rescale=False):

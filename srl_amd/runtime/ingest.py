@@ -133,12 +133,22 @@ class SampleRing:
             self._count += 1
             return slot, col
 
+    def _check_column(self, leaves):
+        """Every leaf of a trajectory must fit its column BEFORE one is claimed: a write that fails after the claim would
+        leave the column claimed and never committed, and the slot lost to the ring for good."""
+        blk = self._np[0]
+        for k, arr in leaves:
+            want = blk[k].shape[:1] + blk[k].shape[2:]
+            if tuple(np.shape(arr)) != want:
+                raise ValueError(f"leaf `{k}` has shape {tuple(np.shape(arr))}, the ring's columns take {want}")
+
     def put_column(self, traj) -> Optional[int]:
         """Write one trajectory (leaves ``[Tb, ...]``) into the next column; returns the slot id when that
         completed a batch, else None."""
         leaves = _flat_leaves(traj)
         if set(leaves) != set(self._np[0]):  # before a column is claimed: a bad trajectory must not leave a hole
             raise KeyError(f"trajectory keys differ from the ring's: {sorted(set(leaves) ^ set(self._np[0]))}")
+        self._check_column(leaves.items())
         slot, col = self._claim()
         blk = self._np[slot]
         for k, dst in blk.items():
@@ -154,6 +164,7 @@ class SampleRing:
         keys = {k for k, _ in leaves}
         if keys != set(self._np[0]):  # before a column is claimed: a bad message must not leave a hole in the slot
             raise KeyError(f"wire trajectory keys differ from the ring's: {sorted(keys ^ set(self._np[0]))}")
+        self._check_column(leaves)
         slot, col = self._claim()
         blk = self._np[slot]
         for k, arr in leaves:

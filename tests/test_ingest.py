@@ -150,3 +150,18 @@ def test_ring_to_device_feeds_the_trainer():
         rb = tr_b.step(recursive_aggregate(trajs, lambda xs: np.stack(xs, axis=1)))
         for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
             assert abs(ra.stats[k] - rb.stats[k]) <= 1e-6 * max(1.0, abs(rb.stats[k])), (step, k)
+
+
+def test_a_trajectory_of_the_wrong_shape_is_refused_before_a_column_is_claimed():
+    """A write that failed after the claim would leave the column claimed and never committed: the slot would neither be
+    published nor freed.  Shapes are therefore checked first, and the ring keeps every slot."""
+    ring = SampleRing(traj(0), batch_size=2, slots=1)
+    bad = traj(1, T=7)  # one row too many
+    with pytest.raises(ValueError):
+        ring.put_column(bad)
+    wire = na.dumps(bad, method="raw_bytes")
+    with pytest.raises(ValueError):
+        ring.put_wire(wire)
+    assert ring.put_column(traj(2)) is None and ring.put_column(traj(3)) == 0  # both columns still there
+    ring.release(ring.get())
+    assert ring.put_column(traj(4)) is None
