@@ -335,6 +335,11 @@ extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const f
   int rc;
   const bool x3 = use_bf16x3() && Kp >= 64;  // bf16 matrix cores, three exact pieces per float32 operand
   if (x3) fwd_kstep_order(d, &g);
+  if (x3 && use_f16x2_fwd() && d->Cout > 32) {  // A/B: two f16 pieces, three products (gemm_bf16x3.h, NP == 2)
+    rc = d->Cout > 64 ? launch3<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3, 2>(st, g, 1, 1)
+                      : (tile192() ? launch3<192, 64, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3, 2>(st, g, 1, 1)
+                                   : launch3<256, 64, 4, 1, false, false, SRC_CONV, SRC_PLAIN, K3, 2>(st, g, 1, 1));
+  } else
   if (d->Cout > 64) rc = x3 ? launch3<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3>(st, g, 1, 1)
                             : launch<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN>(st, g, 1, 1);
   else if (d->Cout > 32) rc = x3 ? (tile192() ? launch3<192, 64, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3>(st, g, 1, 1)

@@ -80,6 +80,11 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   }
 
   int rc;
+  if (use_bf16x3() && use_f16x2_fwd() && g.vec_a && g.vec_b && !d->a_kmajor && !d->b_kmajor && nsplit == 1 && d->M > 64 &&
+      d->N > 64 && d->K >= 64) {
+    // A/B: a forward product X W^T on two f16 pieces per operand, three products (gemm_bf16x3.h, NP == 2)
+    rc = launch3<128, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, 16, 2>(st, g, 1, nsplit);
+  } else
   if (use_bf16x3() && g.vec_a && g.vec_b && d->M > 64 && d->N > 32 && d->K >= 64) {
     // bf16 matrix cores, three exact pieces per float32 operand (2.67x fewer matrix-pipe cycles)
     rc = d->N > 64 ? launch3_or<128, 128, 2, 2>(st, g, d->a_kmajor, d->b_kmajor, nsplit)

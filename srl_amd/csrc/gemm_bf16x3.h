@@ -14,12 +14,21 @@
 // it: the split when a tile is written to LDS (three planes of bf16), the fragment reads (ds_read_b128 for an operand
 // that is contiguous along k; ds_read_b64_tr_b16, the transposing LDS read of gfx950, for one that is contiguous along
 // the output index -- no transposing stores), and the MFMA loop.  The epilogue is the shared one.
+//
+// NP == 2 (experimental, forward products whose operands have a known range): two f16 pieces per operand instead of three
+// bf16 ones, a = h0 + h1 + O(2^-23 |a|) (h0 = f16(a s), h1 = f16(a s - h0), s a power of two that brings the operand into
+// f16's range; 11-bit significands: 22 bits in two planes), and the THREE products h0 h0' + h0 h1' + h1 h0' -- each exact
+// in the float32 accumulate (22 bits) -- instead of six: half the matrix-pipe cycles, two thirds of the LDS traffic, a
+// split of ~3 instead of 6.5 vector operations per element.  The price is f16's exponent range: an element more than 2^16
+// below the operand's largest keeps less than 22 bits (its error is bounded by 2^-40 of that largest element instead).
 #pragma once
 #include "gemm_core.h"
 
 namespace srlgemm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // timing experiments only (scripts/build_variant.sh -DSRL_GEMM3_DBG=<bits>; results are wrong): 1 no in-loop global loads,
@@ -35,10 +44,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 #ifdef __HIPCC__
 // one operand tile in LDS: three planes of BX x KB bf16
-template <int BX, bool KMAJOR, int KB>
+template <int BX, bool KMAJOR, int KB, int NP = 3>
 struct Tile3 {
   static constexpr int PLANE = BX * KB * 2;  // bytes
-  static constexpr int BYTES = 3 * PLANE;
+  static constexpr int BYTES = NP * PLANE;
   // k-contiguous: rows of KB bf16 (PB bytes), their 16-byte chunks XOR-swizzled so that the 16 lanes of a ds_read_b128
   // group (rows 4 apart in the same chunk) land on distinct 16-byte slots of the 256-byte bank line
   static constexpr int PB = KB * 2, CPR = PB / 16, RPL = 256 / PB > 0 ? 256 / PB : 1;
@@ -73,29 +82,46 @@ __device__ __forceinline__ void split3_quad(const float* v, uint2 (&pl)[3]) {
     pl[p] = make_uint2(__builtin_amdgcn_perm(b[p][1], b[p][0], 0x07060302u), __builtin_amdgcn_perm(b[p][3], b[p][2], 0x07060302u));
 }
 
-// registers of a staged tile (Stage::r, float4 quads in Stage's thread -> (row, k) assignment) -> three bf16 planes in LDS
-template <class ST, int BX, bool KMAJOR, int KB, int NT>
-__device__ __forceinline__ void store3(const float* regs, uint8_t* lds) {
-  using T3 = Tile3<BX, KMAJOR, KB>;
+// two f16 pieces of v * scale: h0 = f16(x) (round to nearest), h1 = f16(x - h0) (the difference is exact in float32)
+__device__ __forceinline__ void split2h_quad(const float* v, float scale, uint2 (&pl)[2]) {
+  f16x2 h0[2], h1[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float x0 = v[2 * i] * scale, x1 = v[2 * i + 1] * scale;
+    h0[i] = f16x2{(_Float16)x0, (_Float16)x1};
+    h1[i] = f16x2{(_Float16)(x0 - (float)h0[i][0]), (_Float16)(x1 - (float)h0[i][1])};
+  }
+  union { f16x2 h; uint32_t u; } a0, a1, b0, b1;
+  a0.h = h0[0]; a1.h = h0[1]; b0.h = h1[0]; b1.h = h1[1];
+  pl[0] = make_uint2(a0.u, a1.u);
+  pl[1] = make_uint2(b0.u, b1.u);
+}
+
+// registers of a staged tile (Stage::r, float4 quads in Stage's thread -> (row, k) assignment) -> NP planes of 16-bit
+// pieces in LDS (three bf16 planes, or two f16 planes of the scaled operand)
+template <class ST, int BX, bool KMAJOR, int KB, int NT, int NP = 3>
+__device__ __forceinline__ void store3(const float* regs, uint8_t* lds, float scale = 1.f) {
+  using T3 = Tile3<BX, KMAJOR, KB, NP>;
   const int tid = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < ST::NV; ++q) {
     const int u = tid + q * NT;
     if (ST::PARTIAL && u >= ST::QUADS) continue;
     uint2 pl[3];
-    split3_quad(regs + 4 * q, pl);
+    if (NP == 3) split3_quad(regs + 4 * q, pl);
+    else split2h_quad(regs + 4 * q, scale, reinterpret_cast<uint2(&)[2]>(pl));
     int off;
     if (!KMAJOR) off = T3::off_kc(u / ST::KQ, (u % ST::KQ) * 4);
     else off = T3::off_km(u / (BX / 4), (u % (BX / 4)) * 4);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(lds + p * T3::PLANE + off) = pl[p];
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(lds + p * T3::PLANE + off) = pl[p];
   }
 }
 
 // the lane's fragment (8 consecutive k of one row / column) of 32-wide block `blk`, k-block kb, plane p
-template <int BX, bool KMAJOR, int KB>
+template <int BX, bool KMAJOR, int KB, int NP = 3>
 __device__ __forceinline__ bf16x8 frag3(const uint8_t* lds, int p, int x0, int kb, int lane) {
-  using T3 = Tile3<BX, KMAJOR, KB>;
+  using T3 = Tile3<BX, KMAJOR, KB, NP>;
   const uint8_t* base = lds + p * T3::PLANE;
   if (!KMAJOR) {
     union { uint4 u; bf16x8 v; } f;
@@ -113,14 +139,15 @@ __device__ __forceinline__ bf16x8 frag3(const uint8_t* lds, int p, int x0, int k
   return f.v;
 }
 
-constexpr int min_waves3(int bm, int bn, int kb) {
-  const int lds = 2 * 3 * (bm + bn) * kb * 2;  // two buffers of two three-plane tiles
+constexpr int min_waves3(int bm, int bn, int kb, int np = 3) {
+  const int lds = 2 * np * (bm + bn) * kb * 2;  // two buffers of two np-plane tiles
   const int by_lds = 160 * 1024 / lds;
   return by_lds >= 3 ? 3 : (by_lds >= 2 ? 2 : 1);
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB>
-__global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_kernel(GemmArgs g) {
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB, int NP = 3>
+__global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm3_kernel(GemmArgs g) {
+  static_assert(NP == 3 || NP == 2, "three bf16 pieces or two f16 pieces");
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 wavefronts per workgroup");
   static_assert(!is_obs(AMODE) && !is_obs(BMODE), "observation sources have their own bf16 kernels (obs_bf16.h)");
@@ -135,9 +162,10 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
   constexpr bool PAIR = SRL_GEMM3_PAIR && KB == 16 && !(AKM && BKM) && AMODE == SRC_PLAIN && BMODE == SRC_PLAIN;
   using SA = Stage<BM, AKM, AMODE, NT, KB, false, PAIR>;
   using SB = Stage<BN, BKM, BMODE, NT, KB, false, PAIR>;
-  using TA = Tile3<BM, AKM, KB>;
-  using TB = Tile3<BN, BKM, KB>;
+  using TA = Tile3<BM, AKM, KB, NP>;
+  using TB = Tile3<BN, BKM, KB, NP>;
   constexpr int BUF = TA::BYTES + TB::BYTES;
+  const float sc_a = (NP == 2 && g.scale_a) ? *g.scale_a : 1.f, sc_b = (NP == 2 && g.scale_b) ? *g.scale_b : 1.f;
   __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -239,8 +267,8 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
     sb.template load<1>(g.b, n0, g.N, knext >= 0 ? knext : kend, kend, true);
   }
   cs_acc(sa.r);
-  store3<SA, BM, AKM, KB, NT>(sa.r, lds);
-  store3<SB, BN, BKM, KB, NT>(sb.r, lds + TA::BYTES);
+  store3<SA, BM, AKM, KB, NT, NP>(sa.r, lds, sc_a);
+  store3<SB, BN, BKM, KB, NT, NP>(sb.r, lds + TA::BYTES, sc_b);
   __syncthreads();
   if (!PAIR && knext >= 0) {
     sa.load(g.a, m0, g.M, knext, kend, true);
@@ -269,30 +297,38 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
     const float* rb = (PAIR && cur == 0) ? sb.r2 : sb.r;
 #pragma unroll
     for (int kb = 0; kb < KB / 16; ++kb) {
-      bf16x8 a[TM][3], b[TN][3];
+      bf16x8 a[TM][NP], b[TN][NP];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a[i][p] = frag3<BM, AKM, KB>(la, p, wm * (TM * 32) + i * 32, kb, lane);
+        for (int p = 0; p < NP; ++p) a[i][p] = frag3<BM, AKM, KB, NP>(la, p, wm * (TM * 32) + i * 32, kb, lane);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[j][p] = frag3<BN, BKM, KB>(lb, p, wn * (TN * 32) + j * 32, kb, lane);
+        for (int p = 0; p < NP; ++p) b[j][p] = frag3<BN, BKM, KB, NP>(lb, p, wn * (TN * 32) + j * 32, kb, lane);
       // small terms first: they meet an accumulator that has not grown by this block's leading term yet
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      constexpr int NPROD = NP == 3 ? 6 : 3;
+      constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0}, PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) {
+            if (NP == 3) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+            } else {
+              union { bf16x8 b; f16x8 h; } ua, ub;
+              ua.b = a[i][PA[t]]; ub.b = b[j][PB[t]];
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ua.h, ub.h, acc[i][j], 0, 0, 0);
+            }
+          }
       if (kb == 0) {
         (void)k1;
         cs_acc(ra);
         if (!(SRL_GEMM3_DBG & 2)) {
-          store3<SA, BM, AKM, KB, NT>(ra, nxt);           // tile t+1 (or zeros): registers -> the other LDS buffer
-          store3<SB, BN, BKM, KB, NT>(rb, nxt + TA::BYTES);
+          store3<SA, BM, AKM, KB, NT, NP>(ra, nxt, sc_a);           // tile t+1 (or zeros): registers -> the other LDS buffer
+          store3<SB, BN, BKM, KB, NT, NP>(rb, nxt + TA::BYTES, sc_b);
         }
         if (!(SRL_GEMM3_DBG & 1) && (!PAIR || cur == 0)) {
           sa.load(g.a, m0, g.M, k2x, kend, true);         // tile t+2 (or nothing): global -> registers
@@ -304,13 +340,13 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
         }
       }
       if (KB == 16) {  // the issue pipeline of the step: see above
-        constexpr int NM = 6 * TM * TN;
+        constexpr int NM = NPROD * TM * TN;
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                   // four VALU operations in its shadow
-          if (m % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // an LDS write every other gap
-          if (m % 6 == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load every sixth
+          __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 4 : 5, 0);     // vector operations in its shadow
+          if (NP == 2 || m % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // LDS writes between them
+          if (m % (NP == 3 ? 6 : 3) == (NP == 3 ? 5 : 2)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // global loads
         }
       }
     }
@@ -353,6 +389,15 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB)) void gemm3_ke
         if (m0 + tid * 4 + c < g.M) atomicAdd(g.a_colsum + (long)by * g.a_colsum_batch + m0 + tid * 4 + c, t4[c]);
     }
   }
+  if (NP == 2 && (g.scale_a || g.scale_b)) {  // powers of two: exact
+    const float inv = 1.f / (sc_a * sc_b);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+  }
   gemm_epilogue<TM, TN>(g, acc, m0, n0, wm, wn, l31, h, by, kz);
 }
 
@@ -361,7 +406,7 @@ inline bool tile_groups() {  // SRL_TILE_GROUP=0: row-major tile numbering every
   return on;
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB = 32>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB = 32, int NP = 3>
 inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   if (!(a.vec_a && a.vec_b)) return -EINVAL;
   const long tiles_m = srl_ceil_div(a.M, BM);
@@ -379,7 +424,7 @@ inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
     // swept by all tile rows instead; A is then re-read once per group.
     const long kr = nsplit > 1 ? a.k_per_split : a.K;
     const double panel_b = (double)BN * (double)kr * 4.0, l2_half = 2.0 * 1024 * 1024;
-    const long run = srl_ceil_div(nblk * (long)nsplit, 8), slots = 32L * min_waves3(BM, BN, KB);
+    const long run = srl_ceil_div(nblk * (long)nsplit, 8), slots = 32L * min_waves3(BM, BN, KB, NP);
     if (run > slots && panel_b * a.tiles_n > l2_half) {
       const long gn = (long)(l2_half / panel_b);
       a.grp_n = (unsigned)(gn < 1 ? 1 : gn);
@@ -392,11 +437,18 @@ inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   }
   a.grp_sz = (unsigned)tiles_m * a.grp_n;
   dim3 grid((unsigned)(nblk * nsplit), 1, 1);
-  srl_count_dispatch(SRL_DISP_GEMM3);
-  hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB>), grid, dim3(256), 0, st, a);
+  srl_count_dispatch(NP == 3 ? SRL_DISP_GEMM3 : SRL_DISP_GEMM2H);
+  hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB, NP>), grid, dim3(256), 0, st, a);
   return 0;
 }
 #endif  // __HIPCC__
+
+// SRL_FWD_F16X2=1: forward products (dense X W^T, forward convolutions) on the two-plane f16 variant with unit scales --
+// an A/B switch for operands known to sit in f16's range (DESIGN.md records the measurement)
+inline bool use_f16x2_fwd() {
+  const char* e = getenv("SRL_FWD_F16X2");
+  return e && e[0] == '1';
+}
 
 // SRL_MFMA=f32 forces the float32 MFMA kernels everywhere (A/B timing, cross-checks in the tests)
 inline bool use_bf16x3() {

@@ -126,6 +126,10 @@ struct GemmArgs {
   int nbatch;
   float* a_colsum;  // [M] += sum_k A(i, k) (k-major dense A only): the bias gradient of a weight-gradient product
   long a_colsum_batch;  // per-batch (grid.y) stride of a_colsum
+  // gemm3_kernel's two-plane f16 variant (NP == 2): power-of-two scales that bring each operand into f16's range
+  // (|a * scale_a| <= 65504; NULL: 1.0), undone on the accumulators before the epilogue
+  const float* scale_a;
+  const float* scale_b;
 };
 
 #ifdef __HIPCC__
