@@ -271,6 +271,17 @@ typedef struct srl_gemm_desc {
                              * aligned bases, pitches and contiguous extents multiples of 4): a weight-gradient
                              * product dZ^T X then also delivers the bias gradient sum_rows dZ (mappo.py:276's
                              * backward computes both), without a second pass over dZ. */
+  /* Operand ranges (device floats, or NULL): an upper bound of max |A|, max |B|.  With BOTH given, a forward product
+   * (neither operand k-major, no split) of at least 65 x 65 x 64 runs on two f16 pieces per operand and three piece
+   * products instead of three bf16 pieces and six: the kernel scales each operand by the power of two that puts its
+   * bound into [2^13, 2^14) and undoes it on the accumulators.  Every product is then good to ~2^-22 for elements within
+   * 2^16 of the operand's largest, and to 2^-40 of that largest element below -- so hand over ranges only for operands
+   * whose small elements do not carry the result (weights; LayerNorm'd / ReLU'd activations), never for gradients.
+   * SRL_FWD_F16X2=0 ignores them. */
+  const float* a_absmax;
+  const float* b_absmax;
+  float* out_absmax;        /* *out_absmax = max(*out_absmax, max |C| of the stored elements) (atomic; split_k == 1), or NULL:
+                             * the range of the next layer's operand at no extra pass */
 } srl_gemm_desc;
 int srl_gemm(void* stream, const srl_gemm_desc* d);
 
@@ -338,8 +349,9 @@ typedef struct srl_conv_desc {
  * with a planar (NCHW) observation, 2 = observation layer with a channels-last (NHWC) observation. */
 int srl_conv2d_supported(const srl_conv_desc* d, int first_layer);
 /* y[n,OH,OW,Cout] = act(conv(x[n,H,W,Cin], w) + bias) */
+/* x_absmax / w_absmax / y_absmax: as srl_gemm_desc's a_absmax / b_absmax / out_absmax (NULL: three bf16 planes, no tracking). */
 int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w, const float* bias,
-                        float* y);
+                        float* y, const float* x_absmax, const float* w_absmax, float* y_absmax);
 /* dw[Cout,KH,KW,Cin] += sum over (n,oh,ow) dz[.,Cout]^T patch(x); workspace: srl_conv2d_wgrad_workspace floats
  * (split over the n*OH*OW reduction) or NULL.  dbias (optional): [Cout] += sum over (n,oh,ow) dz, the bias
  * gradient, from the same pass over dz. */
@@ -369,7 +381,10 @@ int64_t srl_conv2d_obs_fwd_workspace(const srl_conv_desc* d);
 int srl_conv2d_obs_row_index_supported(const srl_conv_desc* d, int is_u8, int channels_last);
 int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
-                       const float* bias, float* y, float* workspace, const int32_t* row_index);
+                       const float* bias, float* y, float* workspace, const int32_t* row_index, float* y_absmax);
+/* *out = max(*out, max_i |x[i]|) (atomic: several calls may fold into one slot; the caller zeroes it): the range of a
+ * weight tensor for the two-plane f16 products, once per parameter update. */
+int srl_absmax(void* stream, const float* x, int64_t n, float* out);
 /* Space-to-depth of a planar observation for a strided first convolution (stride s | KH, KW, H, W):
  * out[n, H/s, W/s, (c, ph, pw)] = obs[n, c, a*s + ph, b*s + pw], same element type, plus the whole-observation
  * LayerNorm statistics in the same pass.  A KxK stride-s convolution on obs becomes a (K/s)x(K/s) stride-1

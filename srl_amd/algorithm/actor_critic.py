@@ -238,6 +238,7 @@ class ActorCriticPolicy(policy_api.Policy):
         """One flat buffer, one broadcast (RCCL over xGMI on GPU ranks; also what inference replicas call to
         receive fresh parameters from the trainer, replacing the reference's filesystem push/pull)."""
         dist.broadcast(self._net.flat, src=src, group=group)
+        self._net.params_changed()
         if self.spec.popart:  # the float64 running statistics are (gradient-less) parameters of the reference's module
             # and travel with them in the DDP constructor's broadcast (api/policy.py:219-238, popart.py:8-59)
             dist.broadcast(self._net.popart_state, src=src, group=group)

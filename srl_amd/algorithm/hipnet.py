@@ -92,6 +92,13 @@ class HipNet:
         # data parallel: called with the prefixes of the parameters whose gradient has just become final during
         # backward(), so that the trainer can start reducing finished buckets while the rest is still computed
         self.grad_ready_hook = None
+        # operand ranges for the two-plane f16 forward products (gemm_bf16x3.h, NP == 2): max |weight| per layer, computed
+        # on the device when the parameters have changed (`params_changed`), and max |activation| of the convolution
+        # outputs, folded in by the producing kernel's epilogue (slots zeroed at the first use in a forward pass)
+        self._wamax = torch.zeros(64, dtype=torch.float32, device=dev)
+        self._wamax_slot: Dict[str, int] = {}
+        self._wamax_stale = set()
+        self._amax_next = -1
         # SRL_EXPLICIT_CONV=1 forces the im2col + GEMM + col2im fallback (kept for geometries the implicit
         # kernels reject, and as a cross-check of the implicit path in the tests)
         import os
@@ -131,6 +138,7 @@ class HipNet:
                 raise ValueError(f"{info.key}: shape {tuple(t.shape)} != {info.ref_shape}")
             host[info.offset:info.offset + info.numel] = info.to_internal(t)
         self.flat.copy_(host)
+        self.params_changed()
         if self.spec.popart:  # [mean(vd), mean_sq(vd), debiasing_term(1)] float64
             rms = torch.cat([torch.as_tensor(state[k]).detach().cpu().double().reshape(-1) for k in self.spec.popart_keys])
             self.popart_state.copy_(rms)
@@ -175,6 +183,36 @@ class HipNet:
     def obs_raw_shapes(self) -> Dict[str, tuple]:
         return {enc.key: ((enc.shape,) if isinstance(enc.shape, int) else tuple(enc.shape)) for enc in self._encoders()}
 
+    # ------------------------------------------------------------------ operand ranges (two-plane f16 forward products)
+    def params_changed(self):
+        """The trainer / a checkpoint load / a broadcast rewrote ``flat``: cached per-layer weight ranges are stale."""
+        self._wamax_stale = set(self._wamax_slot)
+
+    def _weight_range(self, prefix: str, numel: int) -> int:
+        """Device pointer of max |weight| of layer ``prefix`` (recomputed after ``params_changed``)."""
+        slot = self._wamax_slot.get(prefix)
+        if slot is None:
+            slot = self._wamax_slot[prefix] = len(self._wamax_slot)
+            self._wamax_stale.add(prefix)
+        ptr = self._wamax.data_ptr() + 4 * slot
+        if prefix in self._wamax_stale:
+            self._wamax[slot:slot + 1].zero_()
+            hip.absmax(self._p(f"{prefix}.weight"), numel, ptr)
+            self._wamax_stale.discard(prefix)
+        return ptr
+
+    def _act_range(self) -> int:
+        """A fresh device float for the range of an activation of this forward pass (zero until its producer ran)."""
+        amax = self.ws.get("act_absmax", 64)
+        if self._amax_next < 0:
+            amax.zero_()
+            self._amax_next = 0
+        slot = self._amax_next
+        self._amax_next += 1
+        if slot >= 64:
+            raise hip.HipError("more than 64 tracked activations in one forward pass")
+        return amax.data_ptr() + 4 * slot
+
     def _p(self, name):
         return self.flat.data_ptr() + 4 * self.spec.params[name].offset
 
@@ -189,10 +227,13 @@ class HipNet:
         t = self.ws.get(name, rows * cols)
         return Buf(t.data_ptr(), cols, rows, cols)
 
-    def _linear_fwd(self, L: ns.LinearSpec, x: Buf, tag: str) -> Buf:
+    def _linear_fwd(self, L: ns.LinearSpec, x: Buf, tag: str, x_range: Optional[int] = None) -> Buf:
+        """``x_range``: device float bounding max |x| when the producer tracked it (a convolution's output): with the
+        weight's range the product runs on two f16 pieces per operand (srl_gemm_desc::a_absmax)."""
         y = self._buf(f"{tag}{L.prefix}.y", x.rows, L.out_features)
+        w_range = self._weight_range(L.prefix, L.out_features * L.in_features) if x_range is not None else None
         hip.gemm(x.rows, L.out_features, L.in_features, x.ptr, x.ld, 0, self._p(f"{L.prefix}.weight"), L.in_features, 0,
-                 y.ptr, y.ld, bias=self._p(f"{L.prefix}.bias"), act=L.act)
+                 y.ptr, y.ld, bias=self._p(f"{L.prefix}.bias"), act=L.act, a_absmax=x_range, b_absmax=w_range)
         return y
 
     def _wgrad(self, out_f, in_f, rows, dz: Buf, x_ptr, x_ld, gw_ptr, gb_ptr=None):
@@ -380,6 +421,7 @@ class HipNet:
         """obs: device tensor [n, *shape] (float32 vectors; uint8 or float32 images)."""
         cur: Optional[Buf] = None
         cur_act = 0
+        cur_range = None  # device float bounding max |cur| (convolution outputs), or None: range unknown
         pending_obs_ln = None
         staged = None
         if isinstance(obs, RingObs):  # rows kept in the HBM observation ring since their rollout
@@ -397,14 +439,14 @@ class HipNet:
                     cur = Buf(obs.data_ptr(), L.dim, n, L.dim)
                 y, saved = self._ln_fwd(L, cur, tag)
                 tape.append(("ln", L, cur, saved, cur_act))
-                cur, cur_act = y, 0
+                cur, cur_act, cur_range = y, 0, None
             elif isinstance(L, ns.LinearSpec):
                 if cur.cols != L.in_features:  # Flatten after the convolution stack: [n*OH*OW, C] -> [n, OH*OW*C]
                     assert cur.rows * cur.cols == n * L.in_features and cur.ld == cur.cols
                     cur = Buf(cur.ptr, L.in_features, n, L.in_features)
-                y = self._linear_fwd(L, cur, tag)
+                y = self._linear_fwd(L, cur, tag, cur_range)
                 tape.append(("linear", L, cur, None, cur_act))
-                cur, cur_act = y, L.act
+                cur, cur_act, cur_range = y, L.act, None
             elif isinstance(L, ns.ObsLayerNormSpec):
                 pending_obs_ln = L
                 if L.explicit:  # written out once, channels-last float32; the convolutions then see a plain activation
@@ -419,20 +461,20 @@ class HipNet:
                     hip.obs_ln_nhwc(obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), self._p(f"{L.prefix}.weight"),
                                     self._p(f"{L.prefix}.bias"), n, c, h, w, y.ptr)
                     tape.append(("obsln", L, obs, (is_u8, mean, rstd, n), 0))
-                    cur, cur_act = y, 0
+                    cur, cur_act, cur_range = y, 0, None
             elif isinstance(L, ns.PoolSpec):
                 (h, w), (ph, pw) = L.in_hw, L.out_hw
                 assert cur.ld == L.c and cur.rows == n * h * w
                 y = self._buf(f"{tag}{L.prefix}.y", n * ph * pw, L.c)
                 hip.maxpool2_nhwc_fwd(cur.ptr, n, h, w, L.c, y.ptr)
                 tape.append(("pool", L, cur, n, cur_act))
-                cur, cur_act = y, 0  # the activation's derivative is applied by the pooling backward at the winner
+                cur, cur_act, cur_range = y, 0, None  # the activation's derivative is applied by the pooling backward at the winner
             elif isinstance(L, ns.PoolNdSpec):
                 assert cur.ld == L.c and cur.rows == n * math.prod(L.in_sp)
                 y = self._buf(f"{tag}{L.prefix}.y", n * math.prod(L.out_sp), L.c)
                 hip.maxpool_ndhwc_fwd(cur.ptr, n, (*L.in_sp, L.c), L.win, y.ptr)
                 tape.append(("poolnd", L, cur, n, cur_act))
-                cur, cur_act = y, 0
+                cur, cur_act, cur_range = y, 0, None
             elif isinstance(L, ns.ConvNdSpec):
                 sp = L.in_sp
                 assert cur.ld == L.cin and cur.rows == n * math.prod(sp)
@@ -448,7 +490,7 @@ class HipNet:
                 hip.gemm(m, L.cout, kdim, P.ptr, kdim, 0, self._p(f"{L.prefix}.weight"), kdim, 0, y.ptr, y.ld,
                          bias=self._p(f"{L.prefix}.bias"), act=L.act)
                 tape.append(("convnd", L, cur, (P, n, sp), cur_act))
-                cur, cur_act = y, L.act
+                cur, cur_act, cur_range = y, L.act, None
             elif isinstance(L, ns.ConvSpec):
                 oh, ow = L.out_hw
                 m = n * oh * ow
@@ -502,10 +544,11 @@ class HipNet:
                                                    rstd.data_ptr())
                         else:
                             hip.obs_ln_stats(obs.data_ptr(), is_u8, n, c * h * w, mean.data_ptr(), rstd.data_ptr())
+                    y_range = self._act_range() if implicit else None
                     if implicit:
                         hip.conv2d_obs_fwd(desc, src.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet,
                                            self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"), y.ptr,
-                                           channels_last=bool(L.s2d), row_index=row_index,
+                                           channels_last=bool(L.s2d), row_index=row_index, y_absmax=y_range,
                                            ws_ptr=self.ws.get("conv_obs_fwd", hip.conv2d_obs_fwd_workspace(desc)).data_ptr())
                     else:
                         hip.im2col_obs_ln(obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet, n, c, h, w,
@@ -513,16 +556,19 @@ class HipNet:
                     saved = (src, is_u8, mean, rstd, pending_obs_ln, bool(L.s2d), row_index)
                 else:
                     assert cur.ld == L.cin and cur.rows == n * h * w
+                    y_range = self._act_range() if implicit else None
                     if implicit:
+                        w_range = self._weight_range(L.prefix, L.cout * kdim) if cur_range is not None and not L.pad else None
                         hip.conv2d_nhwc_fwd(desc, cur.ptr, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"),
-                                            y.ptr)
+                                            y.ptr, x_absmax=cur_range if w_range is not None else None, w_absmax=w_range,
+                                            y_absmax=y_range)
                     else:
                         hip.im2col_nhwc(cur.ptr, n, h, w, L.cin, L.k, L.k, L.stride, P.ptr)
                 if not implicit:
                     hip.gemm(m, L.cout, kdim, P.ptr, kdim, 0, self._p(f"{L.prefix}.weight"), kdim, 0, y.ptr, y.ld,
                              bias=self._p(f"{L.prefix}.bias"), act=L.act)
                 tape.append(("conv", L, cur, (P, saved, n, desc), cur_act))
-                cur, cur_act = y, L.act
+                cur, cur_act, cur_range = y, L.act, y_range
             else:  # pragma: no cover
                 raise TypeError(L)
         return cur
@@ -732,6 +778,7 @@ class HipNet:
         hip.require_gpu()
         sp = self.spec
         self._rnn = rnn
+        self._amax_next = -1
         self.last_state = {}
         if sp.num_rnn_layers and (rnn is None or rnn.T * rnn.B != n):
             raise hip.HipError("recurrent backbone: `rnn` context missing or inconsistent with the row count")

@@ -667,6 +667,7 @@ class MultiAgentPPO(PytorchTrainer):
                 hip.sgd_step(net.flat, net.grad, self._m if self._momentum != 0 else None, self._lr, self._momentum,
                              self._dampening, self._weight_decay, self._nesterov, self._opt_steps + epoch == 0, **clip)
 
+            net.params_changed()  # cached per-layer weight ranges (two-plane f16 forward products) are stale
             if self.recompute_adv_among_epochs and epoch + 1 < self.ppo_epochs:
                 adv_d = ret_d = None
                 have_adv = False

@@ -317,7 +317,8 @@ static bool tile192() {
 }
 
 extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w,
-                                   const float* bias, float* y) {
+                                   const float* bias, float* y, const float* x_absmax, const float* w_absmax,
+                                   float* y_absmax) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry (needs Cin, Cout multiples of 4, < 2^31 elements)");
   SRL_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w), "null / unaligned tensor");
   if (d->n == 0) return 0;
@@ -331,11 +332,13 @@ extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const f
   g.bias = bias; g.act = d->act;
   g.k_per_split = srl_ceil_div(Kp, BK) * BK;
   g.vec_a = 1; g.vec_b = 1;
+  g.range_a = x_absmax; g.range_b = w_absmax; g.out_absmax = y_absmax;
   hipStream_t st = (hipStream_t)stream;
   int rc;
   const bool x3 = use_bf16x3() && Kp >= 64;  // bf16 matrix cores, three exact pieces per float32 operand
   if (x3) fwd_kstep_order(d, &g);
-  if (x3 && use_f16x2_fwd() && d->Cout > 32) {  // A/B: two f16 pieces, three products (gemm_bf16x3.h, NP == 2)
+  if (x3 && x_absmax && w_absmax && use_f16x2_fwd() && d->Cout > 32) {
+    // both operands' ranges are known: two f16 pieces each, three products (gemm_bf16x3.h, NP == 2)
     rc = d->Cout > 64 ? launch3<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3, 2>(st, g, 1, 1)
                       : (tile192() ? launch3<192, 64, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3, 2>(st, g, 1, 1)
                                    : launch3<256, 64, 4, 1, false, false, SRC_CONV, SRC_PLAIN, K3, 2>(st, g, 1, 1));
@@ -511,7 +514,8 @@ extern "C" int srl_conv2d_obs_row_index_supported(const srl_conv_desc* d, int is
 
 extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                  const float* w, const float* bias, float* y, float* workspace, const int32_t* row_index) {
+                                  const float* w, const float* bias, float* y, float* workspace, const int32_t* row_index,
+                                  float* y_absmax) {
   SRL_CHECK_ARG(row_index == nullptr || (workspace && srl_conv2d_obs_row_index_supported(d, is_u8, channels_last)),
                 "row_index is served by the byte kernels only (srl_conv2d_obs_row_index_supported)");
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1),
@@ -527,6 +531,7 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
   g.act = d->act;
   g.k_per_split = srl_ceil_div(Kp, BK) * BK;
   g.vec_a = 1;
+  g.out_absmax = y_absmax;
   int rc;
   if (workspace && aligned16(workspace) && obs_bf16_ok(d, is_u8, channels_last, obs)) {
     // bytes x (three exact bf16 planes of the folded weights) on the bf16 matrix cores: obs_bf16.h
@@ -541,6 +546,7 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
     a.g = obs_geom(d, obs, mean, rstd, OW, row_index);
     a.wq = reinterpret_cast<const uint4*>(wq);
     a.S = S; a.b2 = b2; a.y = y; a.P = P; a.act = d->act;
+    a.y_absmax = y_absmax;
     a.nsplit = obs_bf16_split(d->n, P, 3);
     const char* dbg = getenv("SRL_OBS_DBG");  // timing experiments (wrong results): see obs_bf16.h
     const dim3 grid(srlobs::xcd_position_grid(P, a.nsplit));

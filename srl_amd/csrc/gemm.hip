@@ -6,7 +6,7 @@
 #include "gemm_bf16x3.h"
 #include "skinny.h"
 
-static_assert(sizeof(srl_gemm_desc) == 152 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
+static_assert(sizeof(srl_gemm_desc) == 176 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
 
 using namespace srlgemm;
 
@@ -60,6 +60,7 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   g.a = plain_src(d->A, d->lda);
   g.b = plain_src(d->B, d->ldb);
   g.bias = d->bias; g.act = d->act;
+  g.range_a = d->a_absmax; g.range_b = d->b_absmax;
   g.dact_src = d->dact_src; g.ld_dact = d->ld_dact; g.dact = d->dact;
   const int nsplit = plan_split(d->K, split, &g.k_per_split);
   g.o = OutDesc{};
@@ -80,9 +81,10 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   }
 
   int rc;
-  if (use_bf16x3() && use_f16x2_fwd() && g.vec_a && g.vec_b && !d->a_kmajor && !d->b_kmajor && nsplit == 1 && d->M > 64 &&
-      d->N > 64 && d->K >= 64) {
-    // A/B: a forward product X W^T on two f16 pieces per operand, three products (gemm_bf16x3.h, NP == 2)
+  if (nsplit == 1) g.out_absmax = d->out_absmax;
+  if (use_bf16x3() && d->a_absmax && d->b_absmax && use_f16x2_fwd() && g.vec_a && g.vec_b && !d->a_kmajor && !d->b_kmajor &&
+      nsplit == 1 && d->M > 64 && d->N > 64 && d->K >= 64) {
+    // the caller knows both operands' ranges: two f16 pieces per operand, three products (gemm_bf16x3.h, NP == 2)
     rc = launch3<128, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, 16, 2>(st, g, 1, nsplit);
   } else
   if (use_bf16x3() && g.vec_a && g.vec_b && d->M > 64 && d->N > 32 && d->K >= 64) {

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm
   using TA = Tile3<BM, AKM, KB, NP>;
   using TB = Tile3<BN, BKM, KB, NP>;
   constexpr int BUF = TA::BYTES + TB::BYTES;
-  const float sc_a = (NP == 2 && g.scale_a) ? *g.scale_a : 1.f, sc_b = (NP == 2 && g.scale_b) ? *g.scale_b : 1.f;
+  const float sc_a = NP == 2 ? range_scale(g.range_a) : 1.f, sc_b = NP == 2 ? range_scale(g.range_b) : 1.f;
   __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm
         if (m0 + tid * 4 + c < g.M) atomicAdd(g.a_colsum + (long)by * g.a_colsum_batch + m0 + tid * 4 + c, t4[c]);
     }
   }
-  if (NP == 2 && (g.scale_a || g.scale_b)) {  // powers of two: exact
+  if (NP == 2 && (g.range_a || g.range_b)) {  // powers of two: exact
     const float inv = 1.f / (sc_a * sc_b);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -443,11 +443,11 @@ inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
 }
 #endif  // __HIPCC__
 
-// SRL_FWD_F16X2=1: forward products (dense X W^T, forward convolutions) on the two-plane f16 variant with unit scales --
-// an A/B switch for operands known to sit in f16's range (DESIGN.md records the measurement)
+// Forward products whose caller hands over the range of both operands (srl_gemm_desc::a_absmax / b_absmax, the x / w ranges of
+// srl_conv2d_nhwc_fwd) run on the two-plane f16 variant; SRL_FWD_F16X2=0 keeps them on the three bf16 planes (A/B switch)
 inline bool use_f16x2_fwd() {
   const char* e = getenv("SRL_FWD_F16X2");
-  return e && e[0] == '1';
+  return !(e && e[0] == '0');
 }
 
 // SRL_MFMA=f32 forces the float32 MFMA kernels everywhere (A/B timing, cross-checks in the tests)

@@ -126,13 +126,30 @@ struct GemmArgs {
   int nbatch;
   float* a_colsum;  // [M] += sum_k A(i, k) (k-major dense A only): the bias gradient of a weight-gradient product
   long a_colsum_batch;  // per-batch (grid.y) stride of a_colsum
-  // gemm3_kernel's two-plane f16 variant (NP == 2): power-of-two scales that bring each operand into f16's range
-  // (|a * scale_a| <= 65504; NULL: 1.0), undone on the accumulators before the epilogue
-  const float* scale_a;
-  const float* scale_b;
+  // gemm3_kernel's two-plane f16 variant (NP == 2): device floats holding (an upper bound of) max |a|, max |b|; the kernel
+  // derives the power-of-two scale that puts that maximum into [2^13, 2^14) (range_scale), undone on the accumulators
+  const float* range_a;
+  const float* range_b;
+  // max over the tile's stored outputs of |value| is folded into *out_absmax with an atomic max (the range of the next
+  // layer's operand); NULL: not tracked
+  float* out_absmax;
 };
 
 #ifdef __HIPCC__
+// power-of-two scale that brings an operand whose largest magnitude is *amax into [2^13, 2^14): f16's top, with headroom
+__device__ __forceinline__ float range_scale(const float* amax) {
+  if (!amax) return 1.f;
+  const int e = (int)((__float_as_uint(*amax) >> 23) & 0xffu);  // biased exponent: 2^(e-127) <= amax < 2^(e-126)
+  if (e == 0 || e == 255) return 1.f;                           // zero / subnormal / inf / nan: nothing to scale by
+  int se = 127 + 13 - (e - 127);
+  se = se < 87 ? 87 : (se > 167 ? 167 : se);                    // scales within 2^-40 .. 2^40
+  return __uint_as_float((uint32_t)se << 23);
+}
+__device__ __forceinline__ void absmax_commit(float* dst, float mx) {  // mx >= 0: unsigned order = float order
+  mx = wave_allmax(mx);
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(mx));
+}
+
 // Odometer over the k-steps of a forward convolution, slowest digit first: 128-byte line of the pixel (two 16-channel
 // blocks), parity class of the tap (kh % S, kw % S), the taps of the class, the blocks of the line.  Taps that read the
 // same input pixels become neighbours in time (see conv.hip fwd_kstep_order); a few scalar operations per step.
@@ -638,6 +655,7 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
   // Row addressing stays 32-bit: a 64-bit base per 32-row block plus element offsets (dense output), or offsets
   // from the tensor base through the (image, line, pixel) map (callers keep mapped outputs below 2^32 elements).
   const uint32_t ldo = (uint32_t)g.o.ldo, ldd = (uint32_t)g.ld_dact;
+  float amx = 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const long row0 = m0 + wm * (TM * 32) + i * 32 + 4 * h;  // accumulator register r holds row0 + (r&3) + 8*(r>>2)
@@ -732,8 +750,13 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if ((okj[j] >> r) & 1u) ob[ro[r] + cc] = v[r];
+      if (g.out_absmax) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) amx = fmaxf(amx, ((okj[j] >> r) & 1u) ? fabsf(v[r]) : 0.f);
+      }
     }
   }
+  if (g.out_absmax) absmax_commit(g.out_absmax, amx);
 }
 
 // GEN: the dense operands may need the element-wise (unaligned / ragged leading dimension) staging path.  The

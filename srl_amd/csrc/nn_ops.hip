@@ -619,6 +619,26 @@ extern "C" int srl_copy2d(void* stream, const float* src, int64_t lds, float* ds
   return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, float* out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  m = wave_allmax(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+}
+}  // namespace
+
+extern "C" int srl_absmax(void* stream, const float* x, int64_t n, float* out) {
+  SRL_CHECK_ARG(out && n >= 0, "null output");
+  if (n == 0) return 0;
+  SRL_CHECK_ARG(x != nullptr, "null tensor");
+  long blocks = srl_ceil_div(n, 1024);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int srl_u8_to_f32(void* stream, const uint8_t* src, float* dst, int64_t n) {
   SRL_CHECK_ARG(src && dst, "null tensor");
   if (n == 0) return 0;

@@ -134,6 +134,7 @@ struct FwdArgs {
   const float* b2;  // [P][32]
   float* y;         // [n][P][32]
   int P, nsplit, act;
+  float* y_absmax;  // max |y| folded in with an atomic max (the range of the next layer's operand), or NULL
 };
 
 // One workgroup = one output position x one range of samples.  The position's folded weights (3 planes, 48 KB) sit in
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
     }
     return c;
   };
+  float amx = 0.f;
   auto compute = [&](int set, long tile, float cen, const uint8_t* next_row) {
     asm volatile("" ::: "memory");  // keeps the compiler from hoisting the (tile-invariant) fragment reads out of the loop
     f32x16 acc;
@@ -255,7 +257,10 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
         if (a.act == 1) v = fmaxf(v, 0.f);
         else if (a.act == 2) v = tanhf(v);
         const int row = 8 * g4 + 4 * h + i;
-        if ((full || n0 + row < a.g.n) && (!(DBG & 4) || v == 12345.f)) yp[row * ldy32] = v;
+        if ((full || n0 + row < a.g.n) && (!(DBG & 4) || v == 12345.f)) {
+          yp[row * ldy32] = v;
+          amx = fmaxf(amx, fabsf(v));
+        }
       }
     }
   };
@@ -274,6 +279,7 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
     cen = cen_next;
     set ^= 1;
   }
+  if (a.y_absmax) srlgemm::absmax_commit(a.y_absmax, amx);
 }
 
 // ---- backward: Q[pos][o][k] (+ split-K slabs), R[pos][o] += sum dz, C[pos][o] += sum dz' mean -----------------------------

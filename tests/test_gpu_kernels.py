@@ -351,6 +351,55 @@ def test_gemm_bf16x3_is_as_accurate_as_the_float32_mfma(M, N, K, dyn, akm, bkm):
     assert errs["bf16x3"].max() <= 3.0 * errs["f32"].max() + 1e-9, (errs["bf16x3"].max(), errs["f32"].max())
 
 
+@pytest.mark.parametrize("kind", ["normal", "relu-x-small-w", "wide-range"])
+@pytest.mark.parametrize("M,N,K", [(512, 384, 1024), (260, 200, 3136), (16384, 512, 576)])
+def test_gemm_f16x2_forward_is_as_accurate_as_the_float32_mfma(M, N, K, kind):
+    """Forward products whose caller hands over both operands' ranges run on TWO f16 pieces per operand and three piece
+    products (gemm_bf16x3.h, NP == 2).  Same gate as the three-plane bf16 kernel: against float64, no worse than 1.5x in the
+    mean and 3x at the maximum than the float32-MFMA kernel on the same inputs -- for the operands it is meant for: weights
+    (small, narrow range) and ReLU'd / LayerNorm'd activations, and for operands spread over 2^+-8.  The ranges come from
+    srl_absmax; without them the same call takes the three-plane kernel (operands of unknown dynamic range: the `dyn`
+    cases of the test above never see this kernel)."""
+    import os
+    rng = np.random.default_rng(M + N + K)
+    if kind == "normal":
+        A, B = rng.standard_normal((M, K)), rng.standard_normal((N, K))
+    elif kind == "relu-x-small-w":  # activations after a ReLU (half zeros, a long tail) against weights ~ 1 / sqrt(K)
+        A = np.maximum(rng.standard_normal((M, K)) * 3.0, 0.0)
+        B = rng.standard_normal((N, K)) / np.sqrt(K)
+    else:
+        A = rng.standard_normal((M, K)) * np.exp2(rng.uniform(-8, 8, (M, K)))
+        B = rng.standard_normal((N, K)) * np.exp2(rng.uniform(-8, 8, (N, K)))
+    A, B = A.astype(np.float32), B.astype(np.float32)
+    dA, dB = dev(A), dev(B)
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    mag = np.abs(A.astype(np.float64)) @ np.abs(B.astype(np.float64)).T
+    rng_ab = torch.zeros(3, device=DEV)
+    hip.absmax(dA.data_ptr(), A.size, rng_ab.data_ptr())
+    hip.absmax(dB.data_ptr(), B.size, rng_ab.data_ptr() + 4)
+    assert rng_ab[:2].cpu().tolist() == [float(np.abs(A).max()), float(np.abs(B).max())]
+    errs, counts = {}, {}
+    for mode in ("f16x2", "bf16x3", "f32"):
+        if mode == "f32":
+            os.environ["SRL_MFMA"] = "f32"
+        try:
+            C = torch.full((M, N), np.nan, device=DEV)
+            hip.dispatch_counts(reset=True)
+            kw = dict(a_absmax=rng_ab.data_ptr(), b_absmax=rng_ab.data_ptr() + 4, out_absmax=rng_ab.data_ptr() + 8) if mode == "f16x2" else {}
+            hip.gemm(M, N, K, dA.data_ptr(), K, 0, dB.data_ptr(), K, 0, C.data_ptr(), N, **kw)
+            counts[mode] = hip.dispatch_counts(reset=True)
+            out = C.cpu().numpy()
+            errs[mode] = np.abs(out.astype(np.float64) - ref) / mag.clip(1e-30)
+            if mode == "f16x2":
+                assert float(rng_ab[2]) == float(np.abs(out).max())  # the epilogue's range of the result
+        finally:
+            os.environ.pop("SRL_MFMA", None)
+    assert counts["f16x2"]["gemm2h"] == 1 and counts["bf16x3"]["gemm3"] == 1 and counts["f32"]["gemm_f32"] == 1, counts
+    assert errs["f16x2"].max() <= 2e-6, errs["f16x2"].max()
+    assert errs["f16x2"].mean() <= 1.5 * errs["f32"].mean() + 1e-9, (errs["f16x2"].mean(), errs["f32"].mean(), errs["bf16x3"].mean())
+    assert errs["f16x2"].max() <= 3.0 * errs["f32"].max() + 1e-9, (errs["f16x2"].max(), errs["f32"].max(), errs["bf16x3"].max())
+
+
 def test_gemm_epilogues_and_split():
     rng = np.random.default_rng(5)
     M, N, K = 700, 96, 200

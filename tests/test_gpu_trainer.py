@@ -400,10 +400,13 @@ def test_cnn_step_at_the_benchmarked_dispatch(kernels, frames, monkeypatch):
     if kernels == "bf16x3":
         # conv2/conv3 forward, their weight and data gradients, the three FC products: all on the bf16 matrix cores,
         # the first layer on the byte kernels, only the two heads (N = 6, N = 1) on the skinny kernels
+        # (the three forward products know both operands' ranges: two f16 pieces each, `gemm2h`)
         assert counts["gemm_f32"] == 0, counts
-        assert counts["gemm3"] >= 2 * 9 and counts["obs_fwd_bf16"] == 2 and counts["obs_bwd_bf16"] == 2, counts
+        assert counts["gemm3"] + counts["gemm2h"] >= 2 * 9 and counts["gemm2h"] == 2 * 3, counts
+        assert counts["obs_fwd_bf16"] == 2 and counts["obs_bwd_bf16"] == 2, counts
     else:
-        assert counts["gemm3"] == 0 and counts["obs_fwd_bf16"] == 0 and counts["obs_bwd_bf16"] == 0 and counts["gemm_f32"] > 0, counts
+        assert counts["gemm3"] == 0 and counts["gemm2h"] == 0 and counts["obs_fwd_bf16"] == 0 and counts["obs_bwd_bf16"] == 0, counts
+        assert counts["gemm_f32"] > 0, counts
 
 
 def test_checkpoint_roundtrip_and_reuse():
