@@ -379,23 +379,23 @@ def main():
     if rank == 0 and not args.no_profile:
         summ = prof.summary()
         # every matrix-core launch group.  The contractions deliver float32 results from float32 operands but run on the
-        # bf16 matrix cores: each float32 operand is split exactly into three bf16 pieces and the six leading piece
-        # products are formed (gemm_bf16x3.h), three for the first layer whose frames are bytes (obs_bf16.h).  `achieved`
-        # counts ALGORITHMIC float32 flops; `frac` prices the bf16 flops actually executed against the bf16 peak.
-        mult = lambda k: 1.0 if os.environ.get("SRL_MFMA", "")[:1] == "f" else 6.0
-        mult_obs = lambda k: 1.0 if os.environ.get("SRL_OBS_BF16", "")[:1] == "0" else 3.0
+        # bf16 / f16 matrix cores: each float32 operand is split into three bf16 pieces and the six leading piece
+        # products are formed (gemm_bf16x3.h) -- two f16 pieces and three products for the forward products whose operand
+        # ranges are known, three products for the first layer whose frames are bytes (obs_bf16.h).  `achieved` counts
+        # ALGORITHMIC float32 flops; `frac` prices the 16-bit matrix-core flops actually issued (hip.piece_products per
+        # launch) against the bf16 / f16 peak.
         mm = {k: v for k, v in summ.items() if k == "gemm" or k.startswith("conv_")}
         g = dict(calls=sum(v["calls"] for v in mm.values()), ms=sum(v["ms"] for v in mm.values()),
-                 work=sum(v["work"] for v in mm.values()),
-                 executed=sum(v["work"] * (mult_obs(k) if k.startswith("conv_obs") else mult(k)) for k, v in mm.items()))
+                 work=sum(v["work"] for v in mm.values()), executed=sum(v["executed"] for v in mm.values()))
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12
         exe = g["executed"] / (g["ms"] * 1e-3) / 1e12
         roofline = dict(kernel="gemm3_kernel<...> / obs_*_bf16_kernel family (dense + implicit-conv launches of one step): "
-                               "float32 operands and results through exact bf16 piece products on the bf16 matrix cores",
+                               "float32 operands and results through 16-bit piece products on the bf16 / f16 matrix cores",
                         bound="mfma", achieved=round(ach, 2), unit="TFLOP/s", peak=PEAK_BF16_MFMA_TFLOPS,
                         executed=round(exe, 1), frac=round(exe / PEAK_BF16_MFMA_TFLOPS, 4),
                         achieved_basis="algorithmic float32 flops (2*M*N*K of every contraction)",
-                        executed_basis="bf16 MFMA flops issued: 6 x algorithmic (3 x for the byte-operand first layer)",
+                        executed_basis="16-bit MFMA flops issued: 6 x algorithmic for three-bf16-piece products, 3 x for the "
+                                       "two-f16-piece forward products and the byte-operand first layer",
                         fp32_mfma_peak=PEAK_FP32_MFMA_TFLOPS, achieved_over_fp32_mfma_peak=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                         launches=g["calls"], ms_per_step=round(g["ms"], 3), flops_per_step=g["work"],
                         flops_per_env_step=g["work"] / (T * B), kernel_family_launches=dispatch,
@@ -510,7 +510,7 @@ def main():
         line = dict(metric=f"env-steps/sec through GAE+PPO update, {B * world} envs x {T} steps", value=head["value"],
                     unit="env-steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=head["ms_per_step"],
                     higher_is_better=True, scaling="strong", vs_baseline=None,
-                    dtype="f32 (contractions as exact bf16x3 piece products, float32 accumulate)", data="synthetic",
+                    dtype="f32 (contractions as bf16x3 / f16x2 piece products, float32 accumulate)", data="synthetic",
                     ms_per_step_median=head["ms_per_step_median"], ms_per_step_min=head["ms_per_step_min"],
                     value_basis=("SURVEY 8d t_update: sample in pinned host memory ([Tb,B] namedarray layout, wire dtypes) when "
                                  "an update starts; every leaf copied inside the timed region except the frames, which the "

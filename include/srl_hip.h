@@ -271,13 +271,13 @@ typedef struct srl_gemm_desc {
                              * aligned bases, pitches and contiguous extents multiples of 4): a weight-gradient
                              * product dZ^T X then also delivers the bias gradient sum_rows dZ (mappo.py:276's
                              * backward computes both), without a second pass over dZ. */
-  /* Operand ranges (device floats, or NULL): an upper bound of max |A|, max |B|.  With BOTH given, a forward product
-   * (neither operand k-major, no split) of at least 65 x 65 x 64 runs on two f16 pieces per operand and three piece
-   * products instead of three bf16 pieces and six: the kernel scales each operand by the power of two that puts its
-   * bound into [2^13, 2^14) and undoes it on the accumulators.  Every product is then good to ~2^-22 for elements within
-   * 2^16 of the operand's largest, and to 2^-40 of that largest element below -- so hand over ranges only for operands
-   * whose small elements do not carry the result (weights; LayerNorm'd / ReLU'd activations), never for gradients.
-   * SRL_FWD_F16X2=0 ignores them. */
+  /* Operand ranges (device floats, or NULL): an upper bound of max |A|, max |B|.  With BOTH given, a product of at least
+   * 65 x 65 x 64 runs on two f16 pieces per operand and three piece products instead of three bf16 pieces and six: the
+   * kernel scales each operand by the power of two that puts its bound into [2^13, 2^14) and undoes it on the
+   * accumulators.  Every element is then carried to ~2^-22 relative if it lies within 2^16 of the operand's largest, and
+   * to 2^-40 of that largest element below -- so hand over ranges for operands whose dot products are carried by their
+   * large elements (weights, activations, and the gradients of a batch: what is summed over samples), not for operands
+   * whose rows may consist of small elements only and matter individually.  SRL_F16X2=0 ignores the ranges. */
   const float* a_absmax;
   const float* b_absmax;
   float* out_absmax;        /* *out_absmax = max(*out_absmax, max |C| of the stored elements) (atomic; split_k == 1), or NULL:
@@ -349,7 +349,8 @@ typedef struct srl_conv_desc {
  * with a planar (NCHW) observation, 2 = observation layer with a channels-last (NHWC) observation. */
 int srl_conv2d_supported(const srl_conv_desc* d, int first_layer);
 /* y[n,OH,OW,Cout] = act(conv(x[n,H,W,Cin], w) + bias) */
-/* x_absmax / w_absmax / y_absmax: as srl_gemm_desc's a_absmax / b_absmax / out_absmax (NULL: three bf16 planes, no tracking). */
+/* x_absmax / w_absmax / y_absmax (and the dz_absmax / dx_absmax of the gradient entry points below): as srl_gemm_desc's
+ * a_absmax / b_absmax / out_absmax (NULL: three bf16 planes, no tracking). */
 int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w, const float* bias,
                         float* y, const float* x_absmax, const float* w_absmax, float* y_absmax);
 /* dw[Cout,KH,KW,Cin] += sum over (n,oh,ow) dz[.,Cout]^T patch(x); workspace: srl_conv2d_wgrad_workspace floats
@@ -357,7 +358,7 @@ int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, co
  * gradient, from the same pass over dz. */
 int64_t srl_conv2d_wgrad_workspace(const srl_conv_desc* d);
 int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const float* x, const float* dz, float* dw,
-                          float* workspace, float* dbias);
+                          float* workspace, float* dbias, const float* x_absmax, const float* dz_absmax);
 /* Data gradient.  Input pixels are split into stride*stride parity classes, each a dense stride-1 problem
  * over only the taps that reach it (no multiply-by-zero work).  wt = the weights regrouped per class
  * (srl_conv2d_dgrad_repack, srl_conv2d_dgrad_weight_elems floats; redo after every optimiser step).
@@ -365,7 +366,7 @@ int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const float* x, 
 int64_t srl_conv2d_dgrad_weight_elems(const srl_conv_desc* d);
 int srl_conv2d_dgrad_repack(void* stream, const srl_conv_desc* d, const float* w, float* wt);
 int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* wt, const float* x_act,
-                          int dact, float* dx);
+                          int dact, float* dx, const float* dz_absmax, const float* w_absmax, float* dx_absmax);
 /* First layer: y = act(conv(LayerNorm(obs), w) + bias) with the LayerNorm over the whole observation; obs uint8 or
  * float32, mean/rstd [n] from srl_obs_ln_stats / srl_obs_space_to_depth.  channels_last = 0: obs [n,Cin,H,W],
  * gamma/beta [Cin,H,W], w [Cout,Cin,KH,KW] (the reference's layouts); channels_last = 1: obs [n,H,W,Cin],

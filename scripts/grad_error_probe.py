@@ -23,7 +23,7 @@ from test_gpu_trainer import ATARI_TRAINER, CNN_POLICY, _pong_frames
 srl_amd.register_all()
 trainer = trainer_api.make(config.Trainer("mappo", args=dict(ATARI_TRAINER)), config.Policy("actor-critic", args=CNN_POLICY))
 init = {k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()}
-arrays = synthetic.make_sample_arrays(seed=70, T=16, B=16, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.05)
+arrays = synthetic.make_sample_arrays(seed=int(os.environ.get("PROBE_SEED", "70")), T=16, B=16, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.05)
 if frames_kind == "pong":
     arrays["obs.obs"] = _pong_frames(np.random.default_rng(0), 17, 16)
 grads = {}

@@ -99,6 +99,7 @@ class HipNet:
         self._wamax_slot: Dict[str, int] = {}
         self._wamax_stale = set()
         self._amax_next = -1
+        self._gmax_next = -1
         # SRL_EXPLICIT_CONV=1 forces the im2col + GEMM + col2im fallback (kept for geometries the implicit
         # kernels reject, and as a cross-check of the implicit path in the tests)
         import os
@@ -213,6 +214,23 @@ class HipNet:
             raise hip.HipError("more than 64 tracked activations in one forward pass")
         return amax.data_ptr() + 4 * slot
 
+    def _grad_range(self, g: Optional["Buf"] = None) -> int:
+        """A fresh device float for the range of a gradient of this backward pass; with ``g`` (dense rows) it is filled
+        by one pass over ``g`` (srl_absmax) -- for gradients whose producer does not track it."""
+        amax = self.ws.get("grad_absmax", 64)
+        if self._gmax_next < 0:
+            amax.zero_()
+            self._gmax_next = 0
+        slot = self._gmax_next
+        self._gmax_next += 1
+        if slot >= 64:
+            raise hip.HipError("more than 64 tracked gradients in one backward pass")
+        ptr = amax.data_ptr() + 4 * slot
+        if g is not None:
+            assert g.ld == g.cols
+            hip.absmax(g.ptr, g.rows * g.cols, ptr)
+        return ptr
+
     def _p(self, name):
         return self.flat.data_ptr() + 4 * self.spec.params[name].offset
 
@@ -236,27 +254,33 @@ class HipNet:
                  y.ptr, y.ld, bias=self._p(f"{L.prefix}.bias"), act=L.act, a_absmax=x_range, b_absmax=w_range)
         return y
 
-    def _wgrad(self, out_f, in_f, rows, dz: Buf, x_ptr, x_ld, gw_ptr, gb_ptr=None):
-        """gw += dz^T x; gb += column sums of dz -- from the same kernel when the operands allow it."""
+    def _wgrad(self, out_f, in_f, rows, dz: Buf, x_ptr, x_ld, gw_ptr, gb_ptr=None, dz_range=None, x_range=None):
+        """gw += dz^T x; gb += column sums of dz -- from the same kernel when the operands allow it.  ``dz_range`` /
+        ``x_range``: device floats bounding the operands (both given: two f16 pieces per operand)."""
         tiles = ((out_f + 127) // 128) * ((in_f + 127) // 128)
         split = _split_for(rows, tiles)
         wsp = self.ws.get("splitk", split * out_f * in_f).data_ptr() if split > 1 else None
         fused = gb_ptr is not None and hip.gemm_colsum_ok(out_f, in_f, rows, dz.ptr, dz.ld, x_ptr, x_ld, 1)
+        if dz_range is None or x_range is None:
+            dz_range = x_range = None
         hip.gemm(out_f, in_f, rows, dz.ptr, dz.ld, 1, x_ptr, x_ld, 1, gw_ptr, in_f, accumulate=True, split_k=split,
-                 workspace=wsp, a_colsum=gb_ptr if fused else None)
+                 workspace=wsp, a_colsum=gb_ptr if fused else None, a_absmax=dz_range, b_absmax=x_range)
         if gb_ptr is not None and not fused:
             hip.colsum(dz.ptr, dz.ld, rows, out_f, gb_ptr, accumulate=True)
 
     def _linear_bwd(self, L: ns.LinearSpec, x: Buf, dz: Buf, in_act: int, need_dx: bool, tag: str,
-                    dx_into: Optional[Buf] = None, dx_accumulate=False) -> Optional[Buf]:
+                    dx_into: Optional[Buf] = None, dx_accumulate=False, x_range=None, dz_range=None, dx_range=None) -> Optional[Buf]:
+        """``x_range`` (the forward pass's range of this layer's input), ``dz_range``: both known -> the two products run on
+        two f16 pieces per operand; ``dx_range``: device float the data gradient's range is folded into."""
         self._wgrad(L.out_features, L.in_features, x.rows, dz, x.ptr, x.ld, self._g(f"{L.prefix}.weight"),
-                    self._g(f"{L.prefix}.bias"))
+                    self._g(f"{L.prefix}.bias"), dz_range, x_range)
         if not need_dx:
             return None
         dx = dx_into or self._buf(f"{tag}{L.prefix}.dx", x.rows, L.in_features)
+        w_range = self._weight_range(L.prefix, L.out_features * L.in_features) if dz_range is not None else None
         hip.gemm(x.rows, L.in_features, L.out_features, dz.ptr, dz.ld, 0, self._p(f"{L.prefix}.weight"), L.in_features,
                  1, dx.ptr, dx.ld, dact_src=x.ptr if in_act else None, ld_dact=x.ld, dact=in_act,
-                 accumulate=dx_accumulate)
+                 accumulate=dx_accumulate, a_absmax=dz_range, b_absmax=w_range, out_absmax=dx_range)
         return dx
 
     def _ln_fwd(self, L: ns.LayerNormSpec, x: Buf, tag: str):
@@ -445,7 +469,7 @@ class HipNet:
                     assert cur.rows * cur.cols == n * L.in_features and cur.ld == cur.cols
                     cur = Buf(cur.ptr, L.in_features, n, L.in_features)
                 y = self._linear_fwd(L, cur, tag, cur_range)
-                tape.append(("linear", L, cur, None, cur_act))
+                tape.append(("linear", L, cur, cur_range, cur_act))
                 cur, cur_act, cur_range = y, L.act, None
             elif isinstance(L, ns.ObsLayerNormSpec):
                 pending_obs_ln = L
@@ -567,7 +591,7 @@ class HipNet:
                 if not implicit:
                     hip.gemm(m, L.cout, kdim, P.ptr, kdim, 0, self._p(f"{L.prefix}.weight"), kdim, 0, y.ptr, y.ld,
                              bias=self._p(f"{L.prefix}.bias"), act=L.act)
-                tape.append(("conv", L, cur, (P, saved, n, desc), cur_act))
+                tape.append(("conv", L, cur, (P, saved, n, desc, cur_range), cur_act))
                 cur, cur_act, cur_range = y, L.act, y_range
             else:  # pragma: no cover
                 raise TypeError(L)
@@ -576,27 +600,36 @@ class HipNet:
     def _chain_bwd(self, records: list, dy: Buf, tag: str, need_input_grad=False) -> Optional[Buf]:
         """Walk tape records of one sequential chain backwards; dy is w.r.t. the chain's (pre-activation) output."""
         g = dy
+        g_range = None  # device float bounding max |g| when its producer tracked it
         for idx in range(len(records) - 1, -1, -1):
             kind, L, x, saved, in_act = records[idx]
             need_dx = idx > 0 or need_input_grad
             if kind == "ln":
                 g = self._ln_bwd(L, x, saved, g, in_act, need_dx, tag)
+                g_range = None
             elif kind == "linear":
-                g = self._linear_bwd(L, x, g, in_act, need_dx, tag)
+                x_range = saved  # the forward pass's range of this layer's input (a convolution's output), or None
+                if x_range is not None and g_range is None and g.ld == g.cols:
+                    g_range = self._grad_range(g)  # one pass over dz: its producer (a LayerNorm) does not track it
+                dx_range = self._grad_range() if (x_range is not None and g_range is not None and need_dx) else None
+                g = self._linear_bwd(L, x, g, in_act, need_dx, tag, x_range=x_range,
+                                     dz_range=g_range if x_range is not None else None, dx_range=dx_range)
+                g_range = dx_range
             elif kind == "gru":
                 g = self._gru_bwd(L, saved, g, in_act, need_dx, tag)
+                g_range = None
             elif kind == "obsln":
                 is_u8, mean, rstd, n = saved
                 c, h, w = L.shape
                 assert g.ld == c and g.rows == n * h * w
                 hip.obs_ln_nhwc_bwd(g.ptr, x.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), n, c, h, w,
                                     self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"))
-                g = None
+                g, g_range = None, None
             elif kind == "poolnd":
                 n = saved
                 dx = self._buf(f"{tag}{L.prefix}.dx", n * math.prod(L.in_sp), L.c)
                 hip.maxpool_ndhwc_bwd(g.ptr, x.ptr, n, (*L.in_sp, L.c), L.win, in_act, dx.ptr)
-                g = dx
+                g, g_range = dx, None
             elif kind == "convnd":
                 P, n, sp = saved
                 m, kdim = g.rows, L.cin * math.prod(L.kern)
@@ -610,16 +643,16 @@ class HipNet:
                     dxc = self._buf(f"{tag}{L.prefix}.dxc", n * math.prod(L.in_sp), L.cin)
                     hip.crop_ndhwc(dx.ptr, n, (*L.in_sp, L.cin), L.pads, dxc.ptr, L.pad_mode)
                     dx = dxc
-                g = dx
+                g, g_range = dx, None
             elif kind == "pool":
                 n = saved
                 (h, w), (ph, pw) = L.in_hw, L.out_hw
                 assert g.ld == L.c and g.rows == n * ph * pw
                 dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.c)
                 hip.maxpool2_nhwc_bwd(g.ptr, x.ptr, n, h, w, L.c, in_act, dx.ptr)
-                g = dx
+                g, g_range = dx, None
             elif kind == "conv":
-                P, first_saved, n, desc = saved
+                P, first_saved, n, desc, x_range = saved
                 kdim = L.cin * L.k * L.k
                 m = g.rows
                 if P is None:  # implicit-GEMM path
@@ -635,13 +668,22 @@ class HipNet:
                         g = None
                     else:
                         wsz = hip.conv2d_wgrad_workspace(desc)
-                        hip.conv2d_nhwc_wgrad(desc, x.ptr, g.ptr, gw, self.ws.get("conv_wgrad", wsz).data_ptr(), gb)
+                        if g_range is None and not L.pad and g.ld == g.cols:
+                            g_range = self._grad_range(g)
+                        two = g_range is not None and not L.pad
+                        hip.conv2d_nhwc_wgrad(desc, x.ptr, g.ptr, gw, self.ws.get("conv_wgrad", wsz).data_ptr(), gb,
+                                              x_absmax=x_range if two else None, dz_absmax=g_range if two and x_range is not None else None)
                         wt = self.ws.get(f"{L.prefix}.wt", hip.conv2d_dgrad_weight_elems(desc))
                         hip.conv2d_dgrad_repack(desc, wp, wt.data_ptr())
                         h, w = L.in_hw[0] + 2 * L.pad, L.in_hw[1] + 2 * L.pad
                         dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.cin)
-                        hip.conv2d_nhwc_dgrad(desc, g.ptr, wt.data_ptr(), x.ptr if in_act else None, in_act, dx.ptr)
+                        dx_range = self._grad_range() if two else None
+                        hip.conv2d_nhwc_dgrad(desc, g.ptr, wt.data_ptr(), x.ptr if in_act else None, in_act, dx.ptr,
+                                              dz_absmax=g_range if two else None,
+                                              w_absmax=self._weight_range(L.prefix, L.cout * kdim) if two else None,
+                                              dx_absmax=dx_range)
                         g = self._crop(L, dx, n, tag)
+                        g_range = dx_range
                     if g is not None and idx > 0:
                         prev_out_cols = self._out_cols(records[idx - 1])
                         if g.cols != prev_out_cols:
@@ -663,7 +705,7 @@ class HipNet:
                     h, w = L.in_hw[0] + 2 * L.pad, L.in_hw[1] + 2 * L.pad
                     dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.cin)
                     hip.col2im_nhwc(P.ptr, n, h, w, L.cin, L.k, L.k, L.stride, x.ptr if in_act else None, in_act, dx.ptr)
-                    g = self._crop(L, dx, n, tag)
+                    g, g_range = self._crop(L, dx, n, tag), None
             self._notify_ready(kind, L, saved)
             if g is not None and idx > 0:
                 # a Flatten between this record's input and the previous record's output: reshape the gradient
@@ -809,6 +851,7 @@ class HipNet:
         if self._tape is None:
             raise hip.HipError("backward() without a preceding forward(keep_tape=True)")
         sp = self.spec
+        self._gmax_next = -1
         n, a_feat, a_act, a_tape, c_feat, c_act, c_tape = self._tape
         atot = sum(sp.act_dims)
         dl = Buf(d_logits.data_ptr(), atot, n, atot)

@@ -337,7 +337,7 @@ extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const f
   int rc;
   const bool x3 = use_bf16x3() && Kp >= 64;  // bf16 matrix cores, three exact pieces per float32 operand
   if (x3) fwd_kstep_order(d, &g);
-  if (x3 && x_absmax && w_absmax && use_f16x2_fwd() && d->Cout > 32) {
+  if (x3 && x_absmax && w_absmax && use_f16x2() && d->Cout > 32) {
     // both operands' ranges are known: two f16 pieces each, three products (gemm_bf16x3.h, NP == 2)
     rc = d->Cout > 64 ? launch3<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3, 2>(st, g, 1, 1)
                       : (tile192() ? launch3<192, 64, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3, 2>(st, g, 1, 1)
@@ -364,7 +364,7 @@ extern "C" int64_t srl_conv2d_wgrad_workspace(const srl_conv_desc* d) {
 }
 
 extern "C" int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const float* x, const float* dz, float* dw,
-                                     float* workspace, float* dbias) {
+                                     float* workspace, float* dbias, const float* x_absmax, const float* dz_absmax) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry");
   SRL_CHECK_ARG(x && dz && dw && aligned16(x) && aligned16(dz), "null / unaligned tensor");
   if (d->n == 0) return 0;
@@ -387,6 +387,10 @@ extern "C" int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const
   g.a_colsum = dbias;
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  g.range_a = dz_absmax; g.range_b = x_absmax;
+  if (bm == 64 && use_bf16x3() && x_absmax && dz_absmax && use_f16x2())  // both ranges known: two f16 pieces per operand
+    rc = launch3<64, 256, 1, 4, true, true, SRC_PLAIN, SRC_CONV, K3, 2>(st, g, 1, nsplit);
+  else
   if (bm == 64) rc = use_bf16x3() ? launch3<64, 256, 1, 4, true, true, SRC_PLAIN, SRC_CONV, K3>(st, g, 1, nsplit)
                                   : launch<64, 256, 1, 4, true, true, SRC_PLAIN, SRC_CONV>(st, g, 1, nsplit);
   else rc = launch<32, 256, 1, 4, true, true, SRC_PLAIN, SRC_CONV>(st, g, 1, nsplit);
@@ -422,7 +426,8 @@ extern "C" int srl_conv2d_dgrad_repack(void* stream, const srl_conv_desc* d, con
 }
 
 extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* wt,
-                                     const float* x_act, int dact, float* dx) {
+                                     const float* x_act, int dact, float* dx, const float* dz_absmax, const float* w_absmax,
+                                     float* dx_absmax) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0) && d->stride <= 8, "unsupported geometry");
   SRL_CHECK_ARG(dz && wt && dx && aligned16(dz) && aligned16(wt), "null / unaligned tensor");
   if (d->n == 0) return 0;
@@ -484,10 +489,14 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
       g.a.n_img = g.o.n_img = (int)d->n;
       SRL_CHECK_ARG(fits31(g.M), "unsupported geometry (too many rows)");
     }
+    g.range_a = dz_absmax; g.range_b = w_absmax; g.out_absmax = dx_absmax;
     int rc;
     const bool x3 = use_bf16x3() && d->Cout % K3 == 0;  // the step mask skips whole taps: a k-step must not straddle two
     if (g.K == 0) {  // no tap reaches this class: gradient is zero there (k loop is empty, epilogue writes 0)
       rc = launch<256, 32, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);
+    } else if (x3 && dz_absmax && w_absmax && use_f16x2() && ncols > 32) {  // both ranges known: two f16 pieces per operand
+      rc = ncols > 64 ? launch3<128, 128, 2, 2, false, true, SRC_DGRAD, SRC_PLAIN, K3, 2>(st, g, batch, 1)
+                      : launch3<256, 64, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN, K3, 2>(st, g, batch, 1);
     } else if (ncols > 64) rc = x3 ? launch3<128, 128, 2, 2, false, true, SRC_DGRAD, SRC_PLAIN, K3>(st, g, batch, 1)
                                    : launch<128, 128, 2, 2, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, batch, 1);
     else if (ncols > 32) rc = x3 ? launch3<256, 64, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN, K3>(st, g, batch, 1)

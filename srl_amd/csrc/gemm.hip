@@ -23,12 +23,12 @@ int launch_or(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
 // float32 operands on the bf16 matrix cores (gemm_bf16x3.h): float4-stageable operands only.  k-steps of 16 (48 KB of LDS per
 // 128x128 workgroup, three per CU): k-steps of 32 measured 10-25 % slower, 256x128 tiles +12 % on 4096^3 but not on the
 // network's shapes, 128x64 / 64x128 tiles (full occupancy for the FC forward) -8 %.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NP = 3>
 int launch3_or(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
-  if (!akm && !bkm) return launch3<BM, BN, WM, WN, false, false, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
-  if (!akm && bkm) return launch3<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
-  if (akm && bkm) return launch3<BM, BN, WM, WN, true, true, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
-  return launch3<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN, 16>(st, g, 1, split);
+  if (!akm && !bkm) return launch3<BM, BN, WM, WN, false, false, SRC_PLAIN, SRC_PLAIN, 16, NP>(st, g, 1, split);
+  if (!akm && bkm) return launch3<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN, 16, NP>(st, g, 1, split);
+  if (akm && bkm) return launch3<BM, BN, WM, WN, true, true, SRC_PLAIN, SRC_PLAIN, 16, NP>(st, g, 1, split);
+  return launch3<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN, 16, NP>(st, g, 1, split);
 }
 
 // both operands float4-loadable (aligned, leading dimensions multiples of 4): the lean instantiation
@@ -82,10 +82,9 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
 
   int rc;
   if (nsplit == 1) g.out_absmax = d->out_absmax;
-  if (use_bf16x3() && d->a_absmax && d->b_absmax && use_f16x2_fwd() && g.vec_a && g.vec_b && !d->a_kmajor && !d->b_kmajor &&
-      nsplit == 1 && d->M > 64 && d->N > 64 && d->K >= 64) {
+  if (use_bf16x3() && d->a_absmax && d->b_absmax && use_f16x2() && g.vec_a && g.vec_b && d->M > 64 && d->N > 64 && d->K >= 64) {
     // the caller knows both operands' ranges: two f16 pieces per operand, three products (gemm_bf16x3.h, NP == 2)
-    rc = launch3<128, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, 16, 2>(st, g, 1, nsplit);
+    rc = launch3_or<128, 128, 2, 2, 2>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
   } else
   if (use_bf16x3() && g.vec_a && g.vec_b && d->M > 64 && d->N > 32 && d->K >= 64) {
     // bf16 matrix cores, three exact pieces per float32 operand (2.67x fewer matrix-pipe cycles)

@@ -443,10 +443,10 @@ inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
 }
 #endif  // __HIPCC__
 
-// Forward products whose caller hands over the range of both operands (srl_gemm_desc::a_absmax / b_absmax, the x / w ranges of
-// srl_conv2d_nhwc_fwd) run on the two-plane f16 variant; SRL_FWD_F16X2=0 keeps them on the three bf16 planes (A/B switch)
-inline bool use_f16x2_fwd() {
-  const char* e = getenv("SRL_FWD_F16X2");
+// Products whose caller hands over the range of both operands (srl_gemm_desc::a_absmax / b_absmax, the ranges of the
+// srl_conv2d_nhwc_* entry points) run on the two-plane f16 variant; SRL_F16X2=0 keeps them on the three bf16 planes (A/B)
+inline bool use_f16x2() {
+  const char* e = getenv("SRL_F16X2");
   return !(e && e[0] == '0');
 }
 

@@ -57,10 +57,10 @@ _SIGNATURES = {
     "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_absmax": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_conv2d_wgrad_workspace": (c_int64, [_CD]),
-    "srl_conv2d_nhwc_wgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srl_conv2d_nhwc_wgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_conv2d_dgrad_weight_elems": (c_int64, [_CD]),
     "srl_conv2d_dgrad_repack": (c_int, [c_void_p, _CD, c_void_p, c_void_p]),
-    "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 10),
     "srl_conv2d_obs_row_index_supported": (c_int, [_CD, c_int, c_int]),
     "srl_conv2d_obs_fwd_workspace": (c_int64, [_CD]),
@@ -216,16 +216,19 @@ class KernelProfile:
     (torch's current stream).  Used by bench.py in an untimed pass; off (``None``) otherwise."""
 
     def __init__(self):
-        self.records = []  # (name, start_event, end_event, work) ; work = algorithmic flops or bytes
+        # (name, start_event, end_event, work, executed): work = algorithmic flops or bytes; executed = matrix-core flops
+        # issued for it (algorithmic x piece products of the kernel that took the call)
+        self.records = []
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, a, b, work in self.records:
-            e = out.setdefault(name, dict(calls=0, ms=0.0, work=0.0))
+        for name, a, b, work, executed in self.records:
+            e = out.setdefault(name, dict(calls=0, ms=0.0, work=0.0, executed=0.0))
             e["calls"] += 1
             e["ms"] += a.elapsed_time(b)
             e["work"] += work
+            e["executed"] += executed
         return out
 
 
@@ -237,10 +240,25 @@ def set_profile(p: Optional[KernelProfile]):
     _prof = p
 
 
+def piece_products(kind: str = "x3") -> float:
+    """Matrix-core products issued per algorithmic multiply-add by the kernel family that takes a call: 6 for float32
+    operands as three bf16 pieces each (``x3``), 3 for two f16 pieces each (``2h``) and for the byte-operand first layer
+    (``obs``), 1 for the float32 MFMA kernels (SRL_MFMA=f32 / SRL_OBS_BF16=0)."""
+    if kind == "obs":
+        return 1.0 if os.environ.get("SRL_OBS_BF16", "")[:1] == "0" else 3.0
+    if os.environ.get("SRL_MFMA", "")[:1] == "f":
+        return 1.0
+    return 3.0 if kind == "2h" else 6.0
+
+
+def f16x2_enabled() -> bool:
+    return os.environ.get("SRL_F16X2", "")[:1] != "0" and os.environ.get("SRL_MFMA", "")[:1] != "f"
+
+
 class _scope:
 
-    def __init__(self, name, work=0.0):
-        self.name, self.work = name, work
+    def __init__(self, name, work=0.0, kind="x3"):
+        self.name, self.work, self.executed = name, work, work * piece_products(kind) if work else 0.0
 
     def __enter__(self):
         if _prof is not None:
@@ -252,7 +270,7 @@ class _scope:
     def __exit__(self, *exc):
         if _prof is not None:
             self.b.record()
-            _prof.records.append((self.name, self.a, self.b, self.work))
+            _prof.records.append((self.name, self.a, self.b, self.work, self.executed))
         return False
 
 
@@ -465,7 +483,9 @@ def gemm(M, N, K, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, bias=None, act=ACT
     ``out_absmax``: device float folded with max |C|."""
     d = GemmDesc(M, N, K, A, lda, int(a_kmajor), B, ldb, int(b_kmajor), C, ldc, bias, int(act), dact_src, ld_dact,
                  int(dact), int(accumulate), int(split_k), workspace, a_colsum, a_absmax, b_absmax, out_absmax)
-    with _scope("gemm", 2.0 * M * N * K):
+    two = (a_absmax is not None and b_absmax is not None and M > 64 and N > 64 and K >= 64 and A % 16 == 0 and B % 16 == 0 and
+           lda % 4 == 0 and ldb % 4 == 0 and f16x2_enabled())  # mirrors gemm.hip's choice of the two-plane f16 kernel
+    with _scope("gemm", 2.0 * M * N * K, "2h" if two else "x3"):
         _check(lib().srl_gemm(_stream(), ctypes.byref(d)), "srl_gemm")
 
 
@@ -677,7 +697,8 @@ def conv2d_supported(d: ConvDesc, first_layer) -> bool:
 
 
 def conv2d_nhwc_fwd(d: ConvDesc, x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax=None, w_absmax=None, y_absmax=None):
-    with _scope("conv_fwd", _conv_flops(d)):
+    two = x_absmax is not None and w_absmax is not None and d.Cout > 32 and d.Cin * d.KH * d.KW >= 64 and f16x2_enabled()
+    with _scope("conv_fwd", _conv_flops(d), "2h" if two else "x3"):
         _check(lib().srl_conv2d_nhwc_fwd(_stream(), ctypes.byref(d), x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax, w_absmax,
                                          y_absmax), "srl_conv2d_nhwc_fwd")
 
@@ -691,11 +712,12 @@ def conv2d_wgrad_workspace(d: ConvDesc) -> int:
     return int(lib().srl_conv2d_wgrad_workspace(ctypes.byref(d)))
 
 
-def conv2d_nhwc_wgrad(d: ConvDesc, x_ptr, dz_ptr, dw_ptr, ws_ptr, dbias_ptr=None):
+def conv2d_nhwc_wgrad(d: ConvDesc, x_ptr, dz_ptr, dw_ptr, ws_ptr, dbias_ptr=None, x_absmax=None, dz_absmax=None):
     """``dbias_ptr``: [Cout] += column sums of dz (the bias gradient), produced by the same kernel."""
-    with _scope("conv_wgrad", _conv_flops(d)):
-        _check(lib().srl_conv2d_nhwc_wgrad(_stream(), ctypes.byref(d), x_ptr, dz_ptr, dw_ptr, ws_ptr, dbias_ptr),
-               "srl_conv2d_nhwc_wgrad")
+    two = x_absmax is not None and dz_absmax is not None and d.Cout > 32 and f16x2_enabled()
+    with _scope("conv_wgrad", _conv_flops(d), "2h" if two else "x3"):
+        _check(lib().srl_conv2d_nhwc_wgrad(_stream(), ctypes.byref(d), x_ptr, dz_ptr, dw_ptr, ws_ptr, dbias_ptr, x_absmax,
+                                           dz_absmax), "srl_conv2d_nhwc_wgrad")
 
 
 def conv2d_dgrad_weight_elems(d: ConvDesc) -> int:
@@ -706,10 +728,11 @@ def conv2d_dgrad_repack(d: ConvDesc, w_ptr, wt_ptr):
     _check(lib().srl_conv2d_dgrad_repack(_stream(), ctypes.byref(d), w_ptr, wt_ptr), "srl_conv2d_dgrad_repack")
 
 
-def conv2d_nhwc_dgrad(d: ConvDesc, dz_ptr, wt_ptr, x_act_ptr, dact, dx_ptr):
-    with _scope("conv_dgrad", _conv_flops(d)):
-        _check(lib().srl_conv2d_nhwc_dgrad(_stream(), ctypes.byref(d), dz_ptr, wt_ptr, x_act_ptr, int(dact), dx_ptr),
-               "srl_conv2d_nhwc_dgrad")
+def conv2d_nhwc_dgrad(d: ConvDesc, dz_ptr, wt_ptr, x_act_ptr, dact, dx_ptr, dz_absmax=None, w_absmax=None, dx_absmax=None):
+    two = dz_absmax is not None and w_absmax is not None and d.Cout % 16 == 0 and f16x2_enabled()
+    with _scope("conv_dgrad", _conv_flops(d), "2h" if two else "x3"):
+        _check(lib().srl_conv2d_nhwc_dgrad(_stream(), ctypes.byref(d), dz_ptr, wt_ptr, x_act_ptr, int(dact), dx_ptr,
+                                           dz_absmax, w_absmax, dx_absmax), "srl_conv2d_nhwc_dgrad")
 
 
 def conv2d_obs_fwd_workspace(d: ConvDesc) -> int:
@@ -723,7 +746,7 @@ def conv2d_obs_row_index_supported(d: ConvDesc, is_u8, channels_last) -> bool:
 
 def conv2d_obs_fwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr,
                    channels_last=False, ws_ptr=None, row_index: Optional[torch.Tensor] = None, y_absmax=None):
-    with _scope("conv_obs_fwd", _conv_flops(d)):
+    with _scope("conv_obs_fwd", _conv_flops(d), "obs"):
         _check(
             lib().srl_conv2d_obs_fwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), int(channels_last), mean_ptr,
                                      rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr, ws_ptr,
@@ -738,7 +761,7 @@ def obs_space_to_depth(obs_ptr, is_u8, n, C, H, W, s, out_ptr, mean_ptr, rstd_pt
 
 def gather_rows(src_ptr, row_bytes, index: torch.Tensor, n, dst_ptr):
     """dst[i, :] = src[index[i], :] (``srl_gather_rows``); ``index`` int32 [>= n] on the device."""
-    with _scope("gather_rows", 2.0 * row_bytes * n):
+    with _scope("gather_rows"):
         _check(lib().srl_gather_rows(_stream(), src_ptr, int(row_bytes), _ptr(index, torch.int32, "index"), int(n), dst_ptr),
                "srl_gather_rows")
 
@@ -755,7 +778,7 @@ def conv2d_obs_bwd_workspace(d: ConvDesc) -> int:
 
 def conv2d_obs_bwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, dz_ptr, dw_ptr, db_ptr,
                    dgamma_ptr, dbeta_ptr, ws_ptr, channels_last=False, row_index: Optional[torch.Tensor] = None):
-    with _scope("conv_obs_bwd", _conv_flops(d)):
+    with _scope("conv_obs_bwd", _conv_flops(d), "obs"):
         _check(
             lib().srl_conv2d_obs_bwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), int(channels_last), mean_ptr,
                                      rstd_ptr, gamma_ptr, beta_ptr, w_ptr, dz_ptr, dw_ptr, db_ptr, dgamma_ptr, dbeta_ptr,

@@ -89,21 +89,27 @@ class SampleRing:
 
     def host_blocks(self, slot: int) -> "OrderedDict[str, np.ndarray]":
         """The slot's pinned blocks by flattened key, ``[Tb, B, ...]`` numpy views (what an exporter to actor processes
-        maps; benchmarks write the stamps of a synthetic rollout here)."""
+        maps; benchmarks write the stamps of a synthetic rollout here -- followed by ``invalidate_copies``: a complete
+        slot's copy may have been started ahead of time)."""
         return self._np[slot]
 
+    def invalidate_copies(self):
+        """Forget every host-to-device copy already started for a slot that is not checked out: its host blocks were
+        modified afterwards (``host_blocks``), or the set of leaves to copy changed.  The next ``get_device`` copies again."""
+        for slot in range(self.slots):
+            ev = self._copied[slot]
+            if ev is not None:
+                ev.synchronize()
+                self._copied[slot] = None
+            self._dev[slot] = None
+
     def attach_obs_ring(self, obs_ring):
-        """Serve the observation leaves from ``obs_ring`` from now on (None: copy them like every other leaf)."""
+        """Serve the observation leaves from ``obs_ring`` from now on (None: copy them like every other leaf).  Call it
+        with no batch checked out."""
         self.obs_ring = obs_ring
         keys = frozenset(f"obs.{k}" for k in obs_ring.keys()) & frozenset(self._np[0]) if obs_ring is not None else frozenset()
         self._ring_keys = keys
-        for slot in range(self.slots):  # device buffers follow the new key set at the next copy
-            if self._copied[slot] is None:
-                self._dev[slot] = None
-
-    def ready(self) -> int:
-        with self._lock:
-            return len(self._full)
+        self.invalidate_copies()  # copies started ahead of time carry the old key set (and possibly old stamps)
 
     # ------------------------------------------------------------------ producer side
     def _commit(self, slot: int, columns: int = 1) -> Optional[int]:
