@@ -95,7 +95,7 @@ class HipNet:
         # operand ranges for the two-plane f16 forward products (gemm_bf16x3.h, NP == 2): max |weight| per layer, computed
         # on the device when the parameters have changed (`params_changed`), and max |activation| of the convolution
         # outputs, folded in by the producing kernel's epilogue (slots zeroed at the first use in a forward pass)
-        self._wamax = torch.zeros(64, dtype=torch.float32, device=dev)
+        self._wamax = torch.zeros(256, dtype=torch.float32, device=dev)
         self._wamax_slot: Dict[str, int] = {}
         self._wamax_stale = set()
         self._amax_next = -1
@@ -185,6 +185,8 @@ class HipNet:
         return {enc.key: ((enc.shape,) if isinstance(enc.shape, int) else tuple(enc.shape)) for enc in self._encoders()}
 
     # ------------------------------------------------------------------ operand ranges (two-plane f16 forward products)
+    RANGE_SLOTS = 1024  # tracked activations / gradients per pass (a piece-wise encoder pass of a deep tower uses dozens)
+
     def params_changed(self):
         """The trainer / a checkpoint load / a broadcast rewrote ``flat``: cached per-layer weight ranges are stale."""
         self._wamax_stale = set(self._wamax_slot)
@@ -193,6 +195,8 @@ class HipNet:
         """Device pointer of max |weight| of layer ``prefix`` (recomputed after ``params_changed``)."""
         slot = self._wamax_slot.get(prefix)
         if slot is None:
+            if len(self._wamax_slot) >= self._wamax.numel():
+                return None
             slot = self._wamax_slot[prefix] = len(self._wamax_slot)
             self._wamax_stale.add(prefix)
         ptr = self._wamax.data_ptr() + 4 * slot
@@ -204,27 +208,27 @@ class HipNet:
 
     def _act_range(self) -> int:
         """A fresh device float for the range of an activation of this forward pass (zero until its producer ran)."""
-        amax = self.ws.get("act_absmax", 64)
+        amax = self.ws.get("act_absmax", self.RANGE_SLOTS)
         if self._amax_next < 0:
             amax.zero_()
             self._amax_next = 0
         slot = self._amax_next
+        if slot >= self.RANGE_SLOTS:
+            return None  # not tracked: the consumers take the three-plane kernels
         self._amax_next += 1
-        if slot >= 64:
-            raise hip.HipError("more than 64 tracked activations in one forward pass")
         return amax.data_ptr() + 4 * slot
 
     def _grad_range(self, g: Optional["Buf"] = None) -> int:
         """A fresh device float for the range of a gradient of this backward pass; with ``g`` (dense rows) it is filled
         by one pass over ``g`` (srl_absmax) -- for gradients whose producer does not track it."""
-        amax = self.ws.get("grad_absmax", 64)
+        amax = self.ws.get("grad_absmax", self.RANGE_SLOTS)
         if self._gmax_next < 0:
             amax.zero_()
             self._gmax_next = 0
         slot = self._gmax_next
+        if slot >= self.RANGE_SLOTS:
+            return None  # not tracked: the consumers take the three-plane kernels
         self._gmax_next += 1
-        if slot >= 64:
-            raise hip.HipError("more than 64 tracked gradients in one backward pass")
         ptr = amax.data_ptr() + 4 * slot
         if g is not None:
             assert g.ld == g.cols

@@ -111,6 +111,10 @@ class SampleRing:
         self._ring_keys = keys
         self.invalidate_copies()  # copies started ahead of time carry the old key set (and possibly old stamps)
 
+    def ready(self) -> int:
+        with self._lock:
+            return len(self._full)
+
     # ------------------------------------------------------------------ producer side
     def _commit(self, slot: int, columns: int = 1) -> Optional[int]:
         """Called after a column's write has finished; the writer of the last column to finish publishes the slot."""
