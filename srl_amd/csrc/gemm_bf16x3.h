@@ -82,14 +82,16 @@ __device__ __forceinline__ void split3_quad(const float* v, uint2 (&pl)[3]) {
     pl[p] = make_uint2(__builtin_amdgcn_perm(b[p][1], b[p][0], 0x07060302u), __builtin_amdgcn_perm(b[p][3], b[p][2], 0x07060302u));
 }
 
-// two f16 pieces of v * scale: h0 = f16(x) (round to nearest), h1 = f16(x - h0) (the difference is exact in float32)
+// two f16 pieces of v * scale: h0 = f16(v * scale) (round to nearest), h1 = f16(v * scale - h0) (the difference is exact in
+// float32; scale is a power of two).  Written as fused multiply-adds so that each piece is ONE mixed-precision instruction
+// (v_fma_mixlo / mixhi_f16: float32 product and sum, f16 result): two vector operations per element.
 __device__ __forceinline__ void split2h_quad(const float* v, float scale, uint2 (&pl)[2]) {
   f16x2 h0[2], h1[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const float x0 = v[2 * i] * scale, x1 = v[2 * i + 1] * scale;
-    h0[i] = f16x2{(_Float16)x0, (_Float16)x1};
-    h1[i] = f16x2{(_Float16)(x0 - (float)h0[i][0]), (_Float16)(x1 - (float)h0[i][1])};
+    const _Float16 a0 = (_Float16)__builtin_fmaf(v[2 * i], scale, 0.f), a1 = (_Float16)__builtin_fmaf(v[2 * i + 1], scale, 0.f);
+    h0[i] = f16x2{a0, a1};
+    h1[i] = f16x2{(_Float16)__builtin_fmaf(v[2 * i], scale, -(float)a0), (_Float16)__builtin_fmaf(v[2 * i + 1], scale, -(float)a1)};
   }
   union { f16x2 h; uint32_t u; } a0, a1, b0, b1;
   a0.h = h0[0]; a1.h = h0[1]; b0.h = h1[0]; b1.h = h1[1];
