@@ -656,6 +656,20 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
   // from the tensor base through the (image, line, pixel) map (callers keep mapped outputs below 2^32 elements).
   const uint32_t ldo = (uint32_t)g.o.ldo, ldd = (uint32_t)g.ld_dact;
   float amx = 0.f;
+  // Position-grouped rows (SrcDesc::grp_shift): a tile's rows are consecutive images at ONE pixel position, so the
+  // (group, pixel) decomposition belongs to the tile, not to the row -- two divisions per workgroup on the scalar unit
+  // instead of three per row on the vector unit (with K = 256 the epilogue of a stride-2 data gradient was half of the
+  // tile's vector work)
+  uint32_t grp_pix = 0, grp_n0 = 0;
+  const bool grouped = g.o.rowmap && g.o.grp_shift;
+  if (grouped) {
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(m0 >> g.o.grp_shift));
+    const uint32_t gq = fdiv(tile, g.o.f_img);
+    const uint32_t rem = tile - gq * g.o.f_img.d;
+    const uint32_t y = fdiv(rem, g.o.f_line), x = rem - y * g.o.f_line.d;
+    grp_pix = (uint32_t)__builtin_amdgcn_readfirstlane((int)(y * (uint32_t)g.o.y_stride + x * (uint32_t)g.o.x_stride));
+    grp_n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gq << g.o.grp_shift));
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const long row0 = m0 + wm * (TM * 32) + i * 32 + 4 * h;  // accumulator register r holds row0 + (r&3) + 8*(r>>2)
@@ -668,17 +682,15 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
       const int cr = (r & 3) + 8 * (r >> 2);
       const bool ok = row0 + cr < g.M;
       okm |= (ok ? 1u : 0u) << r;
-      if (g.o.rowmap) {
+      if (grouped) {
+        const uint32_t n = grp_n0 + ((uint32_t)(row0 + cr) & ((1u << g.o.grp_shift) - 1u));
+        const bool in = n < (uint32_t)g.o.n_img;
+        if (!in) okm &= ~(1u << r);
+        ro[r] = (in ? n : 0u) * (uint32_t)g.o.img_stride + grp_pix;
+      } else if (g.o.rowmap) {
         const uint32_t rr = ok ? (uint32_t)(row0 + cr) : 0u;
-        uint32_t n = fdiv(rr, g.o.f_img);
-        uint32_t rem = rr - n * g.o.f_img.d;
-        if (g.o.grp_shift) {  // position-grouped rows (see SrcDesc::grp_shift)
-          const uint32_t tile = rr >> g.o.grp_shift, nl = rr & ((1u << g.o.grp_shift) - 1u);
-          const uint32_t gq = fdiv(tile, g.o.f_img);
-          rem = tile - gq * g.o.f_img.d;
-          n = (gq << g.o.grp_shift) + nl;
-          if (n >= (uint32_t)g.o.n_img) { n = 0; okm &= ~(1u << r); }
-        }
+        const uint32_t n = fdiv(rr, g.o.f_img);
+        const uint32_t rem = rr - n * g.o.f_img.d;
         const uint32_t y = fdiv(rem, g.o.f_line);
         const uint32_t x = rem - y * g.o.f_line.d;
         ro[r] = n * (uint32_t)g.o.img_stride + y * (uint32_t)g.o.y_stride + x * (uint32_t)g.o.x_stride;
