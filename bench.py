@@ -471,7 +471,7 @@ def main():
         infer.load_checkpoint(trainer.policy.get_checkpoint())
         obs_ring = infer.make_obs_ring(Tb * B + 8 * B, patch_rows=4 * B)
         infer.attach_obs_ring(obs_ring)
-        frames = ring.host_blocks(0)["obs.obs"]  # [Tb, B, 4, 84, 84] uint8, pinned
+        frames = ring.host_tensors(0)["obs.obs"]  # [Tb, B, 4, 84, 84] uint8, pinned (torch tensor: asynchronous DMA)
         zeros = lambda dt: np.zeros((B, 1), dt)
         stamps = np.empty((Tb, B, 1), np.int64)
         t_roll, n_roll = 0.0, 0
@@ -501,7 +501,7 @@ def main():
         scalar_bytes = sum(v.nbytes for k, v in ring.host_blocks(0).items() if k != "obs.obs")
         fed = dict(value=rate(el_fed, args.steps), ms_per_step=ms_step, ms_per_step_median=marks_fed[len(marks_fed) // 2],
                    ms_per_step_min=marks_fed[0], h2d_bytes_per_step_per_gpu=scalar_bytes,
-                   frames_bytes_kept_in_hbm=int(frames.nbytes), obs_ring=dict(capacity_rows=obs_ring.capacity,
+                   frames_bytes_kept_in_hbm=int(frames.numel()), obs_ring=dict(capacity_rows=obs_ring.capacity,
                                                                                patch_rows=obs_ring.patch_capacity,
                                                                                bytes=obs_ring.nbytes(), **obs_ring.stats))
 

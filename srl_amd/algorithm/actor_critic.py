@@ -261,14 +261,14 @@ class ActorCriticPolicy(policy_api.Policy):
         return ObsRing.for_policy(self, capacity_rows, patch_rows)
 
     # ------------------------------------------------------------------ inference
-    ROLLOUT_PIECE = 2048  # rows per piece when a big host batch is streamed in (copy of piece i+1 under the compute of i)
+    ROLLOUT_PIECE = 1024  # rows per piece when a big host batch is streamed in (copy of piece i+1 under the compute of i)
 
     def rollout(self, requests: policy_api.RolloutRequest, **kwargs) -> policy_api.RolloutResult:
         hip.require_gpu()
         host = {k: v for k, v in requests.obs.items() if v is not None}
         n = int(next(iter(host.values())).shape[0])
         if (not self.spec.num_rnn_layers and n >= 2 * self.ROLLOUT_PIECE
-                and not any(isinstance(v, torch.Tensor) for v in host.values())):
+                and not any(isinstance(v, torch.Tensor) and v.is_cuda for v in host.values())):
             action, logp, value, refs = self._rollout_streamed(host, n, requests.is_evaluation)
             state = None
         else:
@@ -305,6 +305,15 @@ class ActorCriticPolicy(policy_api.Policy):
         value = torch.empty((n, self.spec.value_dim), dtype=torch.float32, device=self.device)
         arrays = {}
         for k, v in host.items():
+            if isinstance(v, torch.Tensor):  # a host tensor (pinned: the copies below are then true asynchronous DMA; a numpy
+                # view of pinned memory is pageable in torch's eyes and goes through a staging buffer)
+                t = v.view(torch.uint8) if v.dtype == torch.bool else v
+                if k == "available_action" and t.dtype != torch.uint8:
+                    t = t.to(torch.uint8)
+                elif k != "available_action" and t.dtype not in (torch.uint8, torch.float32):
+                    t = t.to(torch.float32)
+                arrays[k] = t.contiguous()
+                continue
             a = np.asarray(v)
             if a.dtype == np.bool_:
                 a = a.view(np.uint8)
@@ -312,7 +321,7 @@ class ActorCriticPolicy(policy_api.Policy):
                 a = a.astype(np.uint8)  # converted on the host: no side-stream temporary inside _rollout_rows
             elif k != "available_action" and a.dtype != np.uint8 and a.dtype != np.float32:
                 a = a.astype(np.float32)
-            arrays[k] = np.ascontiguousarray(a)
+            arrays[k] = torch.from_numpy(np.ascontiguousarray(a))
         step = self.ROLLOUT_PIECE
         bounds = [(r0, min(n, r0 + step)) for r0 in range(0, n, step)]
         staged = [None, None]  # the piece being computed and the piece being copied (fresh allocations of the side
@@ -321,7 +330,7 @@ class ActorCriticPolicy(policy_api.Policy):
         def stage(i):
             r0, r1 = bounds[i]
             with torch.cuda.stream(self._copy_stream):
-                dev = {k: torch.from_numpy(a[r0:r1]).to(self.device, non_blocking=True) for k, a in arrays.items()}
+                dev = {k: a[r0:r1].to(self.device, non_blocking=True) for k, a in arrays.items()}
                 ev = torch.cuda.Event()
                 ev.record(self._copy_stream)
             staged[i & 1] = (dev, ev)

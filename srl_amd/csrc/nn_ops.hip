@@ -620,9 +620,21 @@ extern "C" int srl_copy2d(void* stream, const float* src, int64_t lds, float* ds
 }
 
 namespace {
+// 16-byte loads over the aligned body, the ragged head / tail element-wise by the first workgroup
 __global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, float* out) {
+  const long head = (4 - (((uintptr_t)x >> 2) & 3)) & 3;  // elements before the first 16-byte boundary
+  const long h = head < n ? head : n;
+  const long nv = (n - h) / 4;
+  const float4* xv = reinterpret_cast<const float4*>(x + h);
   float m = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    const float4 v = xv[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0) {
+    for (long i = threadIdx.x; i < h; i += 256) m = fmaxf(m, fabsf(x[i]));
+    for (long i = h + 4 * nv + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+  }
   m = wave_allmax(m);
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
 }
@@ -631,9 +643,9 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, flo
 extern "C" int srl_absmax(void* stream, const float* x, int64_t n, float* out) {
   SRL_CHECK_ARG(out && n >= 0, "null output");
   if (n == 0) return 0;
-  SRL_CHECK_ARG(x != nullptr, "null tensor");
-  long blocks = srl_ceil_div(n, 1024);
-  if (blocks > 1024) blocks = 1024;
+  SRL_CHECK_ARG(x != nullptr && ((uintptr_t)x & 3) == 0, "null / unaligned tensor");
+  long blocks = srl_ceil_div(n, 4096);  // sixteen floats per thread
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
   SRL_LAUNCH_CHECK();
   return 0;

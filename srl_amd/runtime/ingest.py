@@ -93,6 +93,11 @@ class SampleRing:
         slot's copy may have been started ahead of time)."""
         return self._np[slot]
 
+    def host_tensors(self, slot: int) -> "OrderedDict[str, torch.Tensor]":
+        """The same blocks as pinned torch tensors (a copy from them is an asynchronous DMA; from their numpy views torch
+        stages through a pageable buffer)."""
+        return self._host[slot]
+
     def invalidate_copies(self):
         """Forget every host-to-device copy already started for a slot that is not checked out: its host blocks were
         modified afterwards (``host_blocks``), or the set of leaves to copy changed.  The next ``get_device`` copies again."""
