@@ -400,7 +400,11 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
   }
-  gemm_epilogue<TM, TN>(g, acc, m0, n0, wm, wn, l31, h, by, kz);
+  constexpr int EPI = AMODE == SRC_DGRAD ? 1 : 0;
+  bool interior = m0 + BM <= g.M && n0 + BN <= g.N;
+  if (g.o.rowmap && g.o.grp_shift)  // position-grouped rows: the tile's BM images must exist as well
+    interior = interior && (((fdiv((uint32_t)(m0 >> g.o.grp_shift), g.o.f_img) + 1u) << g.o.grp_shift) <= (uint32_t)g.o.n_img);
+  gemm_epilogue<TM, TN, EPI>(g, acc, m0, n0, wm, wn, l31, h, by, kz, interior);
 }
 
 inline bool tile_groups() {  // SRL_TILE_GROUP=0: row-major tile numbering everywhere (A/B switch)

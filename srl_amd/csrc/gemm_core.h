@@ -643,9 +643,13 @@ struct Stage {
 // ---- epilogue shared by the float32 and the bf16x3 kernels: bias, activation, activation-derivative mask of the
 // producer, accumulate, split-K slabs, row / column-group maps.  acc[i][j] is the 32x32 block (i, j) of the wavefront's
 // tile in the MFMA accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).
-template <int TM, int TN>
+// EPI == 1 (data gradients of the implicit convolutions): no bias, no activation, no accumulate -- known at compile time,
+// so the run-time switches and their branches are gone; `interior` (workgroup-uniform: the whole tile lies inside the
+// matrix and, for position-grouped rows, inside the batch) takes a copy of the block loop whose loads and stores are
+// unconditional (64 conditional stores per lane otherwise: an exec-mask branch each).
+template <int TM, int TN, int EPI = 0>
 __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN], long m0, long n0, int wm, int wn, int l31,
-                                              int h, int by, unsigned kz) {  // kz: index of the k-range (split-K slab)
+                                              int h, int by, unsigned kz, bool interior = false) {  // kz: k-range (split-K slab)
   // ---- epilogue: per 32x32 accumulator block, all loads batched ahead of the arithmetic and the stores ----------------
   const long obatch = g.o.brw ? (long)(by / g.o.brw) * g.o.batch_stride + (long)(by % g.o.brw) * g.o.bx_stride
                               : (long)by * g.o.batch_stride;
@@ -719,55 +723,60 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
       }
       okj[j] = cok ? okm : 0u;
     }
-    float yv[TN][16];
-    if (db) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t o = g.o.rowmap ? ro[r] : (uint32_t)((r & 3) + 8 * (r >> 2)) * ldd;
-          yv[j][r] = ((okj[j] >> r) & 1u) ? db[o + ccj[j]] : 1.f;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const uint32_t cb = cbj[j], cc = ccj[j];
-      float v[16];
-      const float bv = bias ? bias[cb] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
-      if (g.act == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-      } else if (g.act == 2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
-      }
+    auto blocks = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
+      float yv[TN][16];
       if (db) {
-        if (g.dact == 1) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = yv[j][r] > 0.f ? v[r] : 0.f;
-        } else if (g.dact == 2) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] *= 1.f - yv[j][r] * yv[j][r];
+          for (int r = 0; r < 16; ++r) {
+            const uint32_t o = g.o.rowmap ? ro[r] : (uint32_t)((r & 3) + 8 * (r >> 2)) * ldd;
+            yv[j][r] = (FULL || ((okj[j] >> r) & 1u)) ? db[o + ccj[j]] : 1.f;
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const uint32_t cb = cbj[j], cc = ccj[j];
+        float v[16];
+        const float bv = (EPI == 0 && bias) ? bias[cb] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+        if (EPI == 0 && g.act == 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else if (EPI == 0 && g.act == 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
+        }
+        if (db) {
+          if (g.dact == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = yv[j][r] > 0.f ? v[r] : 0.f;
+          } else if (g.dact == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= 1.f - yv[j][r] * yv[j][r];
+          }
+        }
+        if (EPI == 0 && g.accumulate) {
+          float ov[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ov[r] = (FULL || ((okj[j] >> r) & 1u)) ? ob[ro[r] + cc] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += ov[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (FULL || ((okj[j] >> r) & 1u)) ob[ro[r] + cc] = v[r];
+        if (g.out_absmax) {  // an upper bound is all that is asked for: elements beyond the matrix edge (computed from
+          // zero-filled operands: at most |bias|) are not masked out, which keeps this at one v_max per element
+#pragma unroll
+          for (int r = 0; r < 16; ++r) amx = fmaxf(amx, fabsf(v[r]));
         }
       }
-      if (g.accumulate) {
-        float ov[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ov[r] = ((okj[j] >> r) & 1u) ? ob[ro[r] + cc] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += ov[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if ((okj[j] >> r) & 1u) ob[ro[r] + cc] = v[r];
-      if (g.out_absmax) {  // an upper bound is all that is asked for: elements beyond the matrix edge (computed from
-        // zero-filled operands: at most |bias|) are not masked out, which keeps this at one v_max per element
-#pragma unroll
-        for (int r = 0; r < 16; ++r) amx = fmaxf(amx, fabsf(v[r]));
-      }
-    }
+    };
+    if (interior) blocks(std::true_type{});
+    else blocks(std::false_type{});
   }
   if (g.out_absmax) absmax_commit(g.out_absmax, amx);
 }
