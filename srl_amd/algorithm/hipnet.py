@@ -21,6 +21,7 @@ output ``[n*OH*OW, Cout]`` is the next layer's input without a transpose (parame
 once, at the checkpoint boundary: ``netspec.ParamInfo``).
 """
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, NamedTuple, Optional
 
@@ -56,13 +57,22 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self._bufs: Dict[str, torch.Tensor] = {}
+        self._retired = []
 
     def get(self, name: str, numel: int, dtype=torch.float32) -> torch.Tensor:
         t = self._bufs.get(name)
         if t is None or t.numel() < numel or t.dtype != dtype:
+            if t is not None:
+                # a kernel on the second stream may still be reading the buffer that is being outgrown: the allocator
+                # would hand its memory to the next request of the compute stream at once.  Kept until `release_retired`.
+                self._retired.append(t)
             t = torch.empty(max(int(numel), 1), dtype=dtype, device=self.device)
             self._bufs[name] = t
         return t
+
+    def release_retired(self):
+        """Called once the compute stream has waited for every other stream that used workspace buffers."""
+        self._retired.clear()
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self._bufs.values())
@@ -100,9 +110,15 @@ class HipNet:
         self._wamax_stale = set()
         self._amax_next = -1
         self._gmax_next = -1
+        # the weight gradients of the convolutions / the encoder's Linear run on a second stream beside the data-gradient
+        # chain (both only read dz; the kernels are bound by different things -- staging loads against epilogue traffic -- and
+        # fill each other's stalls: 156.3 -> 151.8 ms per update, same box); joined at the end of backward().
+        # SRL_WGRAD_STREAM=0: everything on the compute stream (A/B)
+        self._wgrad_side = os.environ.get("SRL_WGRAD_STREAM", "1") != "0"
+        self._side_stream = None
+        self._side_used = False
         # SRL_EXPLICIT_CONV=1 forces the im2col + GEMM + col2im fallback (kept for geometries the implicit
         # kernels reject, and as a cross-check of the implicit path in the tests)
-        import os
         self.force_explicit_conv = os.environ.get("SRL_EXPLICIT_CONV", "0") == "1"
         # rows one encoder pass may take: the gather kernels address an activation tensor with 32-bit byte offsets, so
         # the widest per-row activation bounds the rows per launch (2 GiB per tensor, half the hardware range)
@@ -218,6 +234,26 @@ class HipNet:
         self._amax_next += 1
         return amax.data_ptr() + 4 * slot
 
+    def _on_side(self, fn):
+        """Run ``fn`` (launches of a weight gradient) on the second stream, after everything enqueued so far on the
+        compute stream; without the switch, or while gradient buckets are being released (their all-reduce is ordered
+        against the compute stream only), inline."""
+        if not self._wgrad_side or self.grad_ready_hook is not None:
+            fn()
+            return
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        self._side_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side_stream):
+            fn()
+        self._side_used = True
+
+    def _join_side(self):
+        if self._side_used:
+            torch.cuda.current_stream().wait_stream(self._side_stream)
+            self._side_used = False
+        self.ws.release_retired()
+
     def _grad_range(self, g: Optional["Buf"] = None) -> int:
         """A fresh device float for the range of a gradient of this backward pass; with ``g`` (dense rows) it is filled
         by one pass over ``g`` (srl_absmax) -- for gradients whose producer does not track it."""
@@ -263,7 +299,9 @@ class HipNet:
         ``x_range``: device floats bounding the operands (both given: two f16 pieces per operand)."""
         tiles = ((out_f + 127) // 128) * ((in_f + 127) // 128)
         split = _split_for(rows, tiles)
-        wsp = self.ws.get("splitk", split * out_f * in_f).data_ptr() if split > 1 else None
+        # split-K slabs: launches on the second stream (weight gradients beside the data-gradient chain) have their own
+        wsn = "splitk_side" if torch.cuda.current_stream() == self._side_stream else "splitk"
+        wsp = self.ws.get(wsn, split * out_f * in_f).data_ptr() if split > 1 else None
         fused = gb_ptr is not None and hip.gemm_colsum_ok(out_f, in_f, rows, dz.ptr, dz.ld, x_ptr, x_ld, 1)
         if dz_range is None or x_range is None:
             dz_range = x_range = None
@@ -276,8 +314,12 @@ class HipNet:
                     dx_into: Optional[Buf] = None, dx_accumulate=False, x_range=None, dz_range=None, dx_range=None) -> Optional[Buf]:
         """``x_range`` (the forward pass's range of this layer's input), ``dz_range``: both known -> the two products run on
         two f16 pieces per operand; ``dx_range``: device float the data gradient's range is folded into."""
-        self._wgrad(L.out_features, L.in_features, x.rows, dz, x.ptr, x.ld, self._g(f"{L.prefix}.weight"),
-                    self._g(f"{L.prefix}.bias"), dz_range, x_range)
+        wg = lambda: self._wgrad(L.out_features, L.in_features, x.rows, dz, x.ptr, x.ld, self._g(f"{L.prefix}.weight"),
+                                 self._g(f"{L.prefix}.bias"), dz_range, x_range)
+        if x_range is not None and need_dx and not dx_accumulate:
+            self._on_side(wg)  # a big encoder Linear: its weight gradient beside the data gradient
+        else:
+            wg()
         if not need_dx:
             return None
         dx = dx_into or self._buf(f"{tag}{L.prefix}.dx", x.rows, L.in_features)
@@ -675,8 +717,10 @@ class HipNet:
                         if g_range is None and not L.pad and g.ld == g.cols:
                             g_range = self._grad_range(g)
                         two = g_range is not None and not L.pad
-                        hip.conv2d_nhwc_wgrad(desc, x.ptr, g.ptr, gw, self.ws.get("conv_wgrad", wsz).data_ptr(), gb,
-                                              x_absmax=x_range if two else None, dz_absmax=g_range if two and x_range is not None else None)
+                        wgrad_ws = self.ws.get("conv_wgrad", wsz).data_ptr()
+                        self._on_side(lambda d=desc, xp=x.ptr, gp=g.ptr, xr=x_range if two else None,
+                                      gr=g_range if two and x_range is not None else None: hip.conv2d_nhwc_wgrad(
+                                          d, xp, gp, gw, wgrad_ws, gb, x_absmax=xr, dz_absmax=gr))
                         wt = self.ws.get(f"{L.prefix}.wt", hip.conv2d_dgrad_weight_elems(desc))
                         hip.conv2d_dgrad_repack(desc, wp, wt.data_ptr())
                         h, w = L.in_hw[0] + 2 * L.pad, L.in_hw[1] + 2 * L.pad
@@ -814,6 +858,9 @@ class HipNet:
                 sub = Buf(g.ptr + 4 * (r0 * g.ld + col), g.ld, r1 - r0, wdt)
                 self._chain_bwd(tape, sub, tag, need_input_grad=False)
                 col += wdt
+            if len(pieces) > 1:
+                self._join_side()  # the pieces share their backward buffers: the next one must not overtake this one's
+                # weight gradients on the second stream
         self.grad_ready_hook = hook
 
     # ------------------------------------------------------------------ public: forward / backward
@@ -880,4 +927,5 @@ class HipNet:
                 self.grad_ready_hook([sp.actor_head.prefix, sp.critic_head.prefix])
             self._trunk_bwd("a:", a_tape, da)
             self._trunk_bwd("c:", c_tape, dc)
+        self._join_side()
         self._tape = None
