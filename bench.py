@@ -371,9 +371,14 @@ def main():
         if prof is not None:
             hip.set_profile(prof)
         trainer.use_graph = False  # the events wrap individual launches: this step is issued launch by launch
+        # ... and one launch at a time: the timed steps run two row-chunk pipelines and the weight gradients on streams of
+        # their own, where a kernel's duration includes what it shares the chip with; the roofline is a per-kernel figure
+        pipes, trainer.pipelines = trainer.pipelines, 1
+        side, trainer.policy.net._wgrad_side = trainer.policy.net._wgrad_side, False
         hip.dispatch_counts(reset=True)
         trainer.step(sample)
         dispatch = hip.dispatch_counts(reset=True)
+        trainer.pipelines, trainer.policy.net._wgrad_side = pipes, side
         if prof is not None:
             hip.set_profile(None)
     if rank == 0 and not args.no_profile:

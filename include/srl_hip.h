@@ -422,6 +422,9 @@ int srl_ring_slots(void* stream, const int64_t* refs, int64_t n, int64_t capacit
 /* sumsq[0] = sum g^2 in float64 (zeroed first).  With data parallelism the caller all-reduces the
  * gradients before this call (DDP semantics), so no further reduction is needed. */
 int srl_grad_sumsq(void* stream, const float* g, int64_t n, double* sumsq);
+/* dst[i] += src[i]: the flat gradients of two row-chunk pipelines that ran side by side (each accumulates into its own
+ * buffer: loss.backward() of mappo.py:274 over the chunks of one batch) become one before clip + optimiser. */
+int srl_accumulate(void* stream, float* dst, const float* src, int64_t n);
 /* Adam step with the clip coefficient min(1, max_norm / (sqrt(sumsq) + 1e-6)) applied to g on the
  * fly (max_norm < 0: no clipping; sumsq may then be NULL).  grad_scale multiplies g first
  * (1/world_size for the DDP mean).  step is the 1-based step count; weight_decay is decoupled

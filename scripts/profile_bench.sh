@@ -7,6 +7,9 @@
 set -u
 TAG=${1:-prof}; shift || true
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+# per-kernel figures: one launch at a time (the timed configuration overlaps two row-chunk pipelines and the weight gradients
+# on streams of their own; a kernel's duration then includes what it shares the chip with)
+export SRL_PIPELINES=1 SRL_WGRAD_STREAM=0
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-from-host "$@" > "$OUT/bench.json" 2> "$OUT/kt.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile "$@" > /dev/null 2> "$OUT/fetch.err"

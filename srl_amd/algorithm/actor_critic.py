@@ -411,33 +411,36 @@ class ActorCriticPolicy(policy_api.Policy):
     def action_kind(self) -> str:
         return "real" if self.spec.std_type else "index"  # continuous actions are float32 [.., A]
 
-    def _log_std(self):
+    def _log_std(self, net=None):
         """(pointer, row pitch) of log sigma: the shared vector (pitch 0) or the second head's rows."""
+        net = net or self._net
         if self.spec.std_type == "shared_learnable":
-            return self._net.log_std_rows.data_ptr(), self._net.log_std_rows.stride(0)
-        return self._net._p("log_std"), 0
+            return net.log_std_rows.data_ptr(), net.log_std_rows.stride(0)
+        return net._p("log_std"), 0
 
-    def dist_fwd(self, logits, action, avail, logp, ent):
-        """log-probability of `action` and entropy under the current head outputs (:311-324)."""
+    def dist_fwd(self, logits, action, avail, logp, ent, net=None):
+        """log-probability of `action` and entropy under the current head outputs (:311-324).  ``net``: the executor whose
+        forward pass produced ``logits`` (default: the policy's own; the trainer's second row-chunk pipeline passes its twin)."""
         if self.spec.std_type:
-            ptr, ld = self._log_std()
+            ptr, ld = self._log_std(net)
             hip.gaussian_fwd(logits, ptr, ld, action, logp, ent)
         else:
             hip.categorical_fwd(logits, action, avail, self.spec.act_dims, logp, ent)
 
-    def dist_bwd(self, logits, action, avail, d_lp, d_ent, d_logits):
+    def dist_bwd(self, logits, action, avail, d_lp, d_ent, d_logits, net=None):
         """d loss / d head outputs; returns what ``HipNet.backward`` needs besides d_logits (d log sigma rows or None)."""
         if not self.spec.std_type:
             hip.categorical_bwd(logits, action, avail, self.spec.act_dims, d_lp, d_ent, d_logits)
             return None
+        net = net or self._net
         n, A = logits.shape
-        ptr, ld = self._log_std()
-        d_ls = self._net.ws.get("d_log_std_rows", n * A)[:n * A].view(n, A)
+        ptr, ld = self._log_std(net)
+        d_ls = net.ws.get("d_log_std_rows", n * A)[:n * A].view(n, A)
         hip.gaussian_bwd(logits, ptr, ld, action, d_lp, d_ent, d_logits, d_ls)
         if self.spec.std_type == "shared_learnable":
             return d_ls
         if self.spec.std_type == "separate_learnable":  # `fixed`: requires_grad=False in the reference, no gradient
-            hip.colsum(d_ls.data_ptr(), A, n, A, self._net._g("log_std"), accumulate=True)
+            hip.colsum(d_ls.data_ptr(), A, n, A, net._g("log_std"), accumulate=True)
         return None
 
     def _packed_last_state(self):

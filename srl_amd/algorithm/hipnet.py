@@ -207,6 +207,26 @@ class HipNet:
         """The trainer / a checkpoint load / a broadcast rewrote ``flat``: cached per-layer weight ranges are stale."""
         self._wamax_stale = set(self._wamax_slot)
 
+    def refresh_weight_ranges(self):
+        """Recompute every stale weight range now, on the current stream (before two row-chunk pipelines that share the
+        slots start side by side)."""
+        for prefix in sorted(self._wamax_stale):
+            info = self.spec.params[f"{prefix}.weight"]
+            self._weight_range(prefix, info.numel)
+
+    def twin(self) -> "HipNet":
+        """A second executor over the SAME parameters (and weight ranges) with its own workspace, tape and gradient
+        buffer: two row chunks of one batch can then go through forward / backward side by side on two streams."""
+        t = object.__new__(HipNet)
+        t.__dict__.update(self.__dict__)
+        t.ws = Workspace(self.device if self.on_gpu else "cpu")
+        t.grad = torch.zeros_like(self.flat)
+        t._tape, t._rnn, t.last_state = None, None, {}
+        t.grad_ready_hook = None
+        t._amax_next = t._gmax_next = -1
+        t._side_stream, t._side_used = None, False
+        return t
+
     def _weight_range(self, prefix: str, numel: int) -> int:
         """Device pointer of max |weight| of layer ``prefix`` (recomputed after ``params_changed``)."""
         slot = self._wamax_slot.get(prefix)

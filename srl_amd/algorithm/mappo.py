@@ -22,6 +22,7 @@ sums by its LOCAL mask count, gradients are then averaged over ranks, while the 
 uses GLOBAL statistics.
 """
 import logging
+import os
 from collections import defaultdict
 
 import numpy as np
@@ -208,6 +209,15 @@ class MultiAgentPPO(PytorchTrainer):
         self._graphs = {}
         self._comm = None
         self._reducer = None
+        # EXPERIMENTAL, off by default (SRL_PIPELINES=2 / pipelines=2): two row-chunk pipelines side by side on two streams
+        # -- the chunks of a batch are independent up to the gradient sum, and their kernels fill each other's stalls: 147.4 ->
+        # 141.3 ms per update.  Not kept as the default: with the two queues running concurrently the narrow head
+        # products (skinny_n_kernel) returned slightly different outputs for a few hundred (always even-numbered) rows from
+        # run to run, although their inputs were bit-identical afterwards; chaining the chunks across the two streams
+        # or synchronising between them restores bit-reproducibility.  Unexplained, so one pipeline.
+        self.pipelines = int(g("pipelines", os.environ.get("SRL_PIPELINES", "1")))
+        self._twin = None
+        self._pipe_stream = None
         self._gae_ws = {}
 
     # ------------------------------------------------------------------ checkpoints (mappo.py:58-66)
@@ -620,31 +630,62 @@ class MultiAgentPPO(PytorchTrainer):
             reducer = self._reducer if self._dist else None
             if reducer is not None:
                 reducer.begin()
+            # Two pipelines: even chunks on the compute stream with the policy's executor, odd chunks on a second stream
+            # with its twin (same parameters, own workspace / tape / gradient buffer).  Not for recurrent nets (one chunk),
+            # not inside a graph capture.
+            two = (self.pipelines >= 2 and nchunks >= 2 and rnn is None and dscal is None and not net.force_explicit_conv)
+            nets, streams = [net], [torch.cuda.current_stream()]
+            if two:
+                if self._twin is None:
+                    self._twin = net.twin()
+                    self._pipe_stream = torch.cuda.Stream(device=dev)
+                twin = self._twin
+                twin.flat, twin.popart_state = net.flat, net.popart_state  # (re-bound by a checkpoint load)
+                # the weight-range slots are shared: they are recomputed here, before the fork.  Before the very first
+                # forward pass the layers that want one are not known yet: the second pipeline then starts after the first
+                # chunk, which discovers and fills them
+                first_sync = not net._wamax_slot
+                net.refresh_weight_ranges()
+                twin.zero_grad()
+                if stats_work is not None:  # the global advantage statistics: needed by both pipelines
+                    stats_work.join() if stats_work is self._comm else stats_work.wait()
+                    stats_work = None
+                self._pipe_stream.wait_stream(streams[0])
+                nets.append(twin)
+                streams.append(self._pipe_stream)
             for ci in range(nchunks):
                 r0, r1 = ci * chunk_rows, min(n_valid, (ci + 1) * chunk_rows)
                 n = r1 - r0
-                if reducer is not None and ci == nchunks - 1:
+                e = ci % len(nets)
+                cnet = nets[e]
+                if reducer is not None and ci == nchunks - 1 and not two:
                     net.grad_ready_hook = reducer.ready  # gradients become final in the last chunk's backward
-                c_obs = {k: v[r0:r1] for k, v in f_obs.items()}
-                c_avail = None if f_avail is None else f_avail[r0:r1]
-                logits, value = net.forward(c_obs, n, keep_tape=True, rnn=rnn)
-                logp = net.ws.get("new_logp", n)[:n]
-                ent = net.ws.get("entropy", n)[:n]
-                self.policy.dist_fwd(logits, f_action[r0:r1], c_avail, logp, ent)
-                self.policy.mask_dead(logp, None if f_alive is None else f_alive[r0:r1])
-                d_lp = net.ws.get("d_logp", n)[:n]
-                d_v = net.ws.get("d_value", n * Nc)[:n * Nc]
-                d_ent = net.ws.get("d_entropy", n)[:n]
-                if stats_work is not None:  # the global advantage statistics: first needed here
-                    stats_work.join() if stats_work is self._comm else stats_work.wait()
-                    stats_work = None
-                hip.ppo_loss_fwd_bwd(logp, f_oldlp[r0:r1], value.reshape(-1), f_oldv[r0 * Nc:r1 * Nc], f_adv[r0 * Nc:r1 * Nc],
-                                     f_ret[r0 * Nc:r1 * Nc],
-                                     ent, f_mask[r0:r1], self._hp, stats_global, local_n, d_lp, d_v, d_ent, terms[ci],
-                                     done=f_done[r0:r1], truncated=f_trunc[r0:r1], value_dim=Nc)
-                d_logits = net.ws.get("d_logits", logits.numel())[:logits.numel()].view_as(logits)
-                d_ls = self.policy.dist_bwd(logits, f_action[r0:r1], c_avail, d_lp, d_ent, d_logits)
-                net.backward(d_logits, d_v.view(n, Nc), d_ls)
+                with torch.cuda.stream(streams[e]):
+                    c_obs = {k: v[r0:r1] for k, v in f_obs.items()}
+                    c_avail = None if f_avail is None else f_avail[r0:r1]
+                    logits, value = cnet.forward(c_obs, n, keep_tape=True, rnn=rnn)
+                    logp = cnet.ws.get("new_logp", n)[:n]
+                    ent = cnet.ws.get("entropy", n)[:n]
+                    self.policy.dist_fwd(logits, f_action[r0:r1], c_avail, logp, ent, net=cnet)
+                    self.policy.mask_dead(logp, None if f_alive is None else f_alive[r0:r1])
+                    d_lp = cnet.ws.get("d_logp", n)[:n]
+                    d_v = cnet.ws.get("d_value", n * Nc)[:n * Nc]
+                    d_ent = cnet.ws.get("d_entropy", n)[:n]
+                    if stats_work is not None:  # the global advantage statistics: first needed here
+                        stats_work.join() if stats_work is self._comm else stats_work.wait()
+                        stats_work = None
+                    hip.ppo_loss_fwd_bwd(logp, f_oldlp[r0:r1], value.reshape(-1), f_oldv[r0 * Nc:r1 * Nc], f_adv[r0 * Nc:r1 * Nc],
+                                         f_ret[r0 * Nc:r1 * Nc],
+                                         ent, f_mask[r0:r1], self._hp, stats_global, local_n, d_lp, d_v, d_ent, terms[ci],
+                                         done=f_done[r0:r1], truncated=f_trunc[r0:r1], value_dim=Nc)
+                    d_logits = cnet.ws.get("d_logits", logits.numel())[:logits.numel()].view_as(logits)
+                    d_ls = self.policy.dist_bwd(logits, f_action[r0:r1], c_avail, d_lp, d_ent, d_logits, net=cnet)
+                    cnet.backward(d_logits, d_v.view(n, Nc), d_ls)
+                if two and ci == 0 and first_sync:
+                    streams[1].wait_stream(streams[0])
+            if two:
+                streams[0].wait_stream(self._pipe_stream)
+                hip.accumulate(net.grad, self._twin.grad)
 
             # ---- gradient reduction, clip, Adam (mappo.py:272-284) ---------------------------------------------------
             if reducer is not None:  # the buckets not yet launched, then wait for all of them

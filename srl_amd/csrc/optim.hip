@@ -175,6 +175,22 @@ extern "C" int srl_rmsprop_step(void* stream, float* p, const float* g, float* s
   return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void accumulate_kernel(float* dst, const float* src, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] += src[i];
+}
+}  // namespace
+
+extern "C" int srl_accumulate(void* stream, float* dst, const float* src, int64_t n) {
+  SRL_CHECK_ARG(n >= 0, "negative count");
+  if (n == 0) return 0;
+  SRL_CHECK_ARG(dst && src, "null tensor");
+  const unsigned grid = (unsigned)(srl_ceil_div(n, 256) < 2048 ? srl_ceil_div(n, 256) : 2048);
+  hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, src, (long)n);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int srl_grad_sumsq(void* stream, const float* g, int64_t n, double* sumsq) {
   SRL_CHECK_ARG(g && sumsq && n >= 0, "null tensor");
   hipStream_t st = (hipStream_t)stream;

@@ -122,6 +122,7 @@ _SIGNATURES = {
     "srl_u8_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "srl_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "srl_ring_slots": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "srl_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "srl_grad_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                c_float, c_float, c_int, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
@@ -545,6 +546,12 @@ def copy2d(src_ptr, lds, dst_ptr, ldd, rows, cols):
 def u8_to_f32(src, dst):
     _check(lib().srl_u8_to_f32(_stream(), _ptr(src, torch.uint8, "src"), _ptr(dst, torch.float32, "dst"), src.numel()),
            "srl_u8_to_f32")
+
+
+def accumulate(dst, src):
+    """dst += src (``srl_accumulate``), float32 tensors of equal size."""
+    _check(lib().srl_accumulate(_stream(), _ptr(dst, torch.float32, "dst"), _ptr(src, torch.float32, "src"), dst.numel()),
+           "srl_accumulate")
 
 
 def grad_sumsq(g, sumsq):
