@@ -8,7 +8,7 @@ from srl_amd.api import config, trainer as trainer_api
 from srl_amd.runtime import synthetic
 srl_amd.register_all()
 sample = device_sample(11, 128, 384, "cuda:0")
-for pipes in (1, 2, 2, 2):
+for pipes in (1, 2, 2, 2, 2):
     for side in ("0",):
         os.environ["SRL_WGRAD_STREAM"] = side
         tr = trainer_api.make(config.Trainer("mappo", args=dict(TRAINER, chunk_rows=16384, pipelines=pipes)), config.Policy("actor-critic", args=POLICY))

@@ -51,7 +51,16 @@ __global__ __launch_bounds__(256) void skinny_n_kernel(const float* __restrict__
         if (n < N) {
           const float4 b = bs[n * K4 + k4];
 #pragma unroll
-          for (int r = 0; r < RPW; ++r) acc[r][n] += dot4(a[r], b);
+          for (int r = 0; r < RPW; ++r) {
+            acc[r][n] += dot4(a[r], b);
+            // Keeps the compiler from pairing the accumulators of two rows into packed float32 instructions
+            // (v_pk_fma_f32).  With the packed code this kernel returned run-to-run different sums for the rows in the low
+            // half of a pair whenever a kernel of ANOTHER queue shared the compute units (the two-pipeline mode of the
+            // trainer), with bit-identical inputs; the scalar code is bit-reproducible there (scripts/pipe_probe.py;
+            // an isolated chain of v_pk_fma_f32 beside an MFMA kernel is exact -- scripts/pk_hazard_probe.hip -- so the
+            // cause is in the packed variant of THIS kernel's code, not in the instruction).
+            asm volatile("" : "+v"(acc[r][n]));
+          }
         }
     }
 #pragma unroll
