@@ -209,13 +209,13 @@ class MultiAgentPPO(PytorchTrainer):
         self._graphs = {}
         self._comm = None
         self._reducer = None
-        # EXPERIMENTAL, off by default (SRL_PIPELINES=2 / pipelines=2): two row-chunk pipelines side by side on two streams
-        # -- the chunks of a batch are independent up to the gradient sum, and their kernels fill each other's stalls: 147.4 ->
-        # 141.3 ms per update.  Not kept as the default: with the two queues running concurrently the narrow head
-        # products (skinny_n_kernel) returned slightly different outputs for a few hundred (always even-numbered) rows from
-        # run to run, although their inputs were bit-identical afterwards; chaining the chunks across the two streams
-        # or synchronising between them restores bit-reproducibility.  Unexplained, so one pipeline.
-        self.pipelines = int(g("pipelines", os.environ.get("SRL_PIPELINES", "1")))
+        # Two row-chunk pipelines side by side on two streams (pipelines=1 / SRL_PIPELINES=1: one): the chunks of a batch are
+        # independent up to the gradient sum, and their kernels -- each bound by something else -- fill each other's
+        # stalls: 147.4 -> 141.3 ms per update.  (The first version was not bit-reproducible: beside a concurrent queue the
+        # narrow head product returned different sums for a few hundred rows; traced to the packed-float32 code the
+        # compiler made of that kernel's accumulators, skinny.h -- with scalar accumulators every buffer of a step is
+        # bit-identical to the one-pipeline run)
+        self.pipelines = int(g("pipelines", os.environ.get("SRL_PIPELINES", "2")))
         self._twin = None
         self._pipe_stream = None
         self._gae_ws = {}
