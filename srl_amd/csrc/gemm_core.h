@@ -139,10 +139,10 @@ struct GemmArgs {
 // power-of-two scale that brings an operand whose largest magnitude is *amax into [2^13, 2^14): f16's top, with headroom
 __device__ __forceinline__ float range_scale(const float* amax) {
   if (!amax) return 1.f;
-  // The float was produced by device-scope atomics of the previous kernel(s) on this stream.  With kernels of ANOTHER
-  // stream running at the same time (two row-chunk pipelines) a plain load was seen to return the line an XCD's L2 had
-  // cached from an earlier pass over the same slot: an agent-scope atomic load goes to where the atomics went.
-  const float a = __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // a plain (scalar) load: the float was finished by the previous kernels of this stream.  (An agent-scope atomic load here
+  // -- tried while chasing the two-pipeline irreproducibility, which it did not cure -- turns the scale into a vector
+  // register value and cost the conv kernels a factor two to three.)
+  const float a = *amax;
   const int e = (int)((__float_as_uint(a) >> 23) & 0xffu);  // biased exponent: 2^(e-127) <= amax < 2^(e-126)
   if (e == 0 || e == 255) return 1.f;                           // zero / subnormal / inf / nan: nothing to scale by
   int se = 127 + 13 - (e - 127);
