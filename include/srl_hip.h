@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 6
+#define SRL_HIP_ABI_VERSION 7
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -282,6 +282,13 @@ typedef struct srl_gemm_desc {
   const float* b_absmax;
   float* out_absmax;        /* *out_absmax = max(*out_absmax, max |C| of the stored elements) (atomic; split_k == 1), or NULL:
                              * the range of the next layer's operand at no extra pass */
+  /* Sign masks: the ReLU derivative needs one bit of the forward output, not the float.  mask_out (act == 1, split_k == 1,
+   * N and ldc multiples of 32): bit (i * ldc + j) & 31 of word (i * ldc + j) >> 5 is set iff C[i, j] > 0.  dact_mask
+   * (dact == 1, dact_src NULL, N and ld_dact multiples of 32): the same bits of the producer, its pitch in ld_dact -- C[i, j] is kept where bit
+   * i * ld_dact + j is set and zeroed elsewhere, exactly what dact_src with the producer's floats gives at 1/32 of the
+   * bytes read (modules/cnn.py:118's nn.ReLU backward). */
+  uint32_t* mask_out;
+  const uint32_t* dact_mask;
 } srl_gemm_desc;
 int srl_gemm(void* stream, const srl_gemm_desc* d);
 
@@ -351,8 +358,11 @@ int srl_conv2d_supported(const srl_conv_desc* d, int first_layer);
 /* y[n,OH,OW,Cout] = act(conv(x[n,H,W,Cin], w) + bias) */
 /* x_absmax / w_absmax / y_absmax (and the dz_absmax / dx_absmax of the gradient entry points below): as srl_gemm_desc's
  * a_absmax / b_absmax / out_absmax (NULL: three bf16 planes, no tracking). */
+/* y_mask (ReLU layers, Cout a multiple of 32; or NULL): [ceil(n*OH*OW*Cout / 32)] words, bit e & 31 of word e >> 5 set iff
+ * element e of y is > 0 -- the one bit the backward pass needs of y where it is only the ReLU derivative that is wanted
+ * (srl_conv2d_nhwc_dgrad's x_mask, srl_gemm_desc's dact_mask): modules/cnn.py:118. */
 int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w, const float* bias,
-                        float* y, const float* x_absmax, const float* w_absmax, float* y_absmax);
+                        float* y, const float* x_absmax, const float* w_absmax, float* y_absmax, uint32_t* y_mask);
 /* dw[Cout,KH,KW,Cin] += sum over (n,oh,ow) dz[.,Cout]^T patch(x); workspace: srl_conv2d_wgrad_workspace floats
  * (split over the n*OH*OW reduction) or NULL.  dbias (optional): [Cout] += sum over (n,oh,ow) dz, the bias
  * gradient, from the same pass over dz. */
@@ -365,8 +375,11 @@ int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const float* x, 
  * dx[n,H,W,Cin] = (sum over taps dz * w) * act'(x_act)   (x_act = the forward activation that has dx's shape, or NULL) */
 int64_t srl_conv2d_dgrad_weight_elems(const srl_conv_desc* d);
 int srl_conv2d_dgrad_repack(void* stream, const srl_conv_desc* d, const float* w, float* wt);
+/* x_mask (dact == 1, x_act NULL, Cin a multiple of 32): the sign bits of x_act as written by the producing layer's y_mask -- the same dx at 1/32
+ * of the bytes read for the derivative. */
 int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* wt, const float* x_act,
-                          int dact, float* dx, const float* dz_absmax, const float* w_absmax, float* dx_absmax);
+                          int dact, float* dx, const float* dz_absmax, const float* w_absmax, float* dx_absmax,
+                          const uint32_t* x_mask);
 /* First layer: y = act(conv(LayerNorm(obs), w) + bias) with the LayerNorm over the whole observation; obs uint8 or
  * float32, mean/rstd [n] from srl_obs_ln_stats / srl_obs_space_to_depth.  channels_last = 0: obs [n,Cin,H,W],
  * gamma/beta [Cin,H,W], w [Cout,Cin,KH,KW] (the reference's layouts); channels_last = 1: obs [n,H,W,Cin],
@@ -382,7 +395,8 @@ int64_t srl_conv2d_obs_fwd_workspace(const srl_conv_desc* d);
 int srl_conv2d_obs_row_index_supported(const srl_conv_desc* d, int is_u8, int channels_last);
 int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
-                       const float* bias, float* y, float* workspace, const int32_t* row_index, float* y_absmax);
+                       const float* bias, float* y, float* workspace, const int32_t* row_index, float* y_absmax,
+                       uint32_t* y_mask);
 /* *out = max(*out, max_i |x[i]|) (atomic: several calls may fold into one slot; the caller zeroes it): the range of a
  * weight tensor for the two-plane f16 products, once per parameter update. */
 int srl_absmax(void* stream, const float* x, int64_t n, float* out);

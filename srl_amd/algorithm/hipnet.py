@@ -37,6 +37,9 @@ class Buf(NamedTuple):
     ld: int
     rows: int
     cols: int
+    # device pointer of the sign bits of a ReLU output (bit e of the word array = element e of the buffer is > 0), written
+    # by the producing convolution: all that a data gradient needs of the activation (srl_hip.h: y_mask / x_mask / dact_mask)
+    mask: Optional[int] = None
 
 
 class RnnCtx(NamedTuple):
@@ -115,6 +118,8 @@ class HipNet:
         # fill each other's stalls: 156.3 -> 151.8 ms per update, same box); joined at the end of backward().
         # SRL_WGRAD_STREAM=0: everything on the compute stream (A/B)
         self._wgrad_side = os.environ.get("SRL_WGRAD_STREAM", "1") != "0"
+        # ReLU derivatives from sign-bit masks written by the producing convolution (SRL_RELU_MASK=0: from its floats)
+        self._relu_masks = os.environ.get("SRL_RELU_MASK", "1") != "0"
         self._side_stream = None
         self._side_used = False
         # SRL_EXPLICIT_CONV=1 forces the im2col + GEMM + col2im fallback (kept for geometries the implicit
@@ -344,9 +349,10 @@ class HipNet:
             return None
         dx = dx_into or self._buf(f"{tag}{L.prefix}.dx", x.rows, L.in_features)
         w_range = self._weight_range(L.prefix, L.out_features * L.in_features) if dz_range is not None else None
+        x_mask = x.mask if in_act == hip.ACT_RELU else None
         hip.gemm(x.rows, L.in_features, L.out_features, dz.ptr, dz.ld, 0, self._p(f"{L.prefix}.weight"), L.in_features,
-                 1, dx.ptr, dx.ld, dact_src=x.ptr if in_act else None, ld_dact=x.ld, dact=in_act,
-                 accumulate=dx_accumulate, a_absmax=dz_range, b_absmax=w_range, out_absmax=dx_range)
+                 1, dx.ptr, dx.ld, dact_src=x.ptr if in_act and x_mask is None else None, ld_dact=x.ld, dact=in_act,
+                 accumulate=dx_accumulate, a_absmax=dz_range, b_absmax=w_range, out_absmax=dx_range, dact_mask=x_mask)
         return dx
 
     def _ln_fwd(self, L: ns.LayerNormSpec, x: Buf, tag: str):
@@ -533,7 +539,7 @@ class HipNet:
             elif isinstance(L, ns.LinearSpec):
                 if cur.cols != L.in_features:  # Flatten after the convolution stack: [n*OH*OW, C] -> [n, OH*OW*C]
                     assert cur.rows * cur.cols == n * L.in_features and cur.ld == cur.cols
-                    cur = Buf(cur.ptr, L.in_features, n, L.in_features)
+                    cur = Buf(cur.ptr, L.in_features, n, L.in_features, cur.mask)
                 y = self._linear_fwd(L, cur, tag, cur_range)
                 tape.append(("linear", L, cur, cur_range, cur_act))
                 cur, cur_act, cur_range = y, L.act, None
@@ -606,6 +612,8 @@ class HipNet:
                         raise hip.HipError("space-to-depth parameter layout needs the implicit convolution path "
                                            "(build the policy with SRL_EXPLICIT_CONV=1 to use the fallback)")
                 y = self._buf(f"{tag}{L.prefix}.y", m, L.cout)
+                if implicit and self._relu_masks and L.act == hip.ACT_RELU and L.cout % 32 == 0:
+                    y = y._replace(mask=self.ws.get(f"{tag}{L.prefix}.mask", m * L.cout // 32, torch.int32).data_ptr())
                 P = None if implicit else self._buf(f"{tag}{L.prefix}.P", m, kdim)
                 saved = None
                 if L.first:
@@ -638,7 +646,7 @@ class HipNet:
                     if implicit:
                         hip.conv2d_obs_fwd(desc, src.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet,
                                            self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"), y.ptr,
-                                           channels_last=bool(L.s2d), row_index=row_index, y_absmax=y_range,
+                                           channels_last=bool(L.s2d), row_index=row_index, y_absmax=y_range, y_mask=y.mask,
                                            ws_ptr=self.ws.get("conv_obs_fwd", hip.conv2d_obs_fwd_workspace(desc)).data_ptr())
                     else:
                         hip.im2col_obs_ln(obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet, n, c, h, w,
@@ -651,7 +659,7 @@ class HipNet:
                         w_range = self._weight_range(L.prefix, L.cout * kdim) if cur_range is not None and not L.pad else None
                         hip.conv2d_nhwc_fwd(desc, cur.ptr, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"),
                                             y.ptr, x_absmax=cur_range if w_range is not None else None, w_absmax=w_range,
-                                            y_absmax=y_range)
+                                            y_absmax=y_range, y_mask=y.mask)
                     else:
                         hip.im2col_nhwc(cur.ptr, n, h, w, L.cin, L.k, L.k, L.stride, P.ptr)
                 if not implicit:
@@ -746,10 +754,11 @@ class HipNet:
                         h, w = L.in_hw[0] + 2 * L.pad, L.in_hw[1] + 2 * L.pad
                         dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.cin)
                         dx_range = self._grad_range() if two else None
-                        hip.conv2d_nhwc_dgrad(desc, g.ptr, wt.data_ptr(), x.ptr if in_act else None, in_act, dx.ptr,
-                                              dz_absmax=g_range if two else None,
+                        x_mask = x.mask if in_act == hip.ACT_RELU else None  # the derivative from sign bits, not floats
+                        hip.conv2d_nhwc_dgrad(desc, g.ptr, wt.data_ptr(), x.ptr if in_act and x_mask is None else None, in_act,
+                                              dx.ptr, dz_absmax=g_range if two else None,
                                               w_absmax=self._weight_range(L.prefix, L.cout * kdim) if two else None,
-                                              dx_absmax=dx_range)
+                                              dx_absmax=dx_range, x_mask=x_mask)
                         g = self._crop(L, dx, n, tag)
                         g_range = dx_range
                     if g is not None and idx > 0:

@@ -318,9 +318,10 @@ static bool tile192() {
 
 extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w,
                                    const float* bias, float* y, const float* x_absmax, const float* w_absmax,
-                                   float* y_absmax) {
+                                   float* y_absmax, uint32_t* y_mask) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry (needs Cin, Cout multiples of 4, < 2^31 elements)");
   SRL_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w), "null / unaligned tensor");
+  SRL_CHECK_ARG(!y_mask || (d->act == 1 && d->Cout % 32 == 0), "y_mask: ReLU layers with Cout a multiple of 32");
   if (d->n == 0) return 0;
   const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
   const long Kp = (long)d->KH * d->KW * d->Cin;
@@ -333,6 +334,7 @@ extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const f
   g.k_per_split = srl_ceil_div(Kp, BK) * BK;
   g.vec_a = 1; g.vec_b = 1;
   g.range_a = x_absmax; g.range_b = w_absmax; g.out_absmax = y_absmax;
+  g.mask_out = y_mask;
   hipStream_t st = (hipStream_t)stream;
   int rc;
   const bool x3 = use_bf16x3() && Kp >= 64;  // bf16 matrix cores, three exact pieces per float32 operand
@@ -427,8 +429,10 @@ extern "C" int srl_conv2d_dgrad_repack(void* stream, const srl_conv_desc* d, con
 
 extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* wt,
                                      const float* x_act, int dact, float* dx, const float* dz_absmax, const float* w_absmax,
-                                     float* dx_absmax) {
+                                     float* dx_absmax, const uint32_t* x_mask) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0) && d->stride <= 8, "unsupported geometry");
+  SRL_CHECK_ARG(!x_mask || (dact == 1 && !x_act && d->Cin % 32 == 0),
+                "x_mask: the ReLU derivative, instead of x_act; Cin a multiple of 32");
   SRL_CHECK_ARG(dz && wt && dx && aligned16(dz) && aligned16(wt), "null / unaligned tensor");
   if (d->n == 0) return 0;
   const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
@@ -468,6 +472,7 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
     o.x_stride = (long)d->stride * d->Cin;
     g.o = o;
     if (x_act && dact) { g.dact_src = x_act + ((long)c.ph * d->W + c.pw) * d->Cin; g.dact = dact; }
+    if (x_mask) { g.dact_mask = x_mask; g.mask_off = (uint32_t)(((long)c.ph * d->W + c.pw) * d->Cin); g.dact = 1; }
     const int batch = 1;
     if (uniform) {  // column group (ph, pw) = ph * stride + pw, Cin columns each
       g.N = (long)nc * d->Cin;
@@ -524,7 +529,8 @@ extern "C" int srl_conv2d_obs_row_index_supported(const srl_conv_desc* d, int is
 extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
                                   const float* w, const float* bias, float* y, float* workspace, const int32_t* row_index,
-                                  float* y_absmax) {
+                                  float* y_absmax, uint32_t* y_mask) {
+  SRL_CHECK_ARG(!y_mask || (d->act == 1 && d->Cout % 32 == 0), "y_mask: ReLU layers with Cout a multiple of 32");
   SRL_CHECK_ARG(row_index == nullptr || (workspace && srl_conv2d_obs_row_index_supported(d, is_u8, channels_last)),
                 "row_index is served by the byte kernels only (srl_conv2d_obs_row_index_supported)");
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1),
@@ -541,6 +547,7 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
   g.k_per_split = srl_ceil_div(Kp, BK) * BK;
   g.vec_a = 1;
   g.out_absmax = y_absmax;
+  g.mask_out = y_mask;
   int rc;
   if (workspace && aligned16(workspace) && obs_bf16_ok(d, is_u8, channels_last, obs)) {
     // bytes x (three exact bf16 planes of the folded weights) on the bf16 matrix cores: obs_bf16.h
@@ -556,6 +563,7 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
     a.wq = reinterpret_cast<const uint4*>(wq);
     a.S = S; a.b2 = b2; a.y = y; a.P = P; a.act = d->act;
     a.y_absmax = y_absmax;
+    a.y_mask = y_mask;
     a.nsplit = obs_bf16_split(d->n, P, 3);
     const char* dbg = getenv("SRL_OBS_DBG");  // timing experiments (wrong results): see obs_bf16.h
     const dim3 grid(srlobs::xcd_position_grid(P, a.nsplit));
@@ -565,7 +573,9 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
       case 4: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 4>), grid, dim3(256), 0, st, a); break;
       case 8: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 8>), grid, dim3(256), 0, st, a); break;
       case 12: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 12>), grid, dim3(256), 0, st, a); break;
-      default: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 0>), grid, dim3(256), 0, st, a);
+      default:
+        if (y_mask) hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 0, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 0>), grid, dim3(256), 0, st, a);
     }
     SRL_LAUNCH_CHECK();
     return 0;

@@ -6,7 +6,7 @@
 #include "gemm_bf16x3.h"
 #include "skinny.h"
 
-static_assert(sizeof(srl_gemm_desc) == 176 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
+static_assert(sizeof(srl_gemm_desc) == 192 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
 
 using namespace srlgemm;
 
@@ -46,7 +46,12 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   SRL_CHECK_ARG(d->A && d->B && d->C, "null matrix");
   const int split = d->split_k > 1 ? d->split_k : 1;
   SRL_CHECK_ARG(split == 1 || d->workspace, "split_k > 1 needs a workspace");
-  SRL_CHECK_ARG(split == 1 || (!d->bias && !d->act && !d->dact_src), "split_k supports only the accumulate epilogue");
+  SRL_CHECK_ARG(split == 1 || (!d->bias && !d->act && !d->dact_src && !d->dact_mask && !d->mask_out),
+                "split_k supports only the accumulate epilogue");
+  SRL_CHECK_ARG(!d->mask_out || (d->act == 1 && d->N % 32 == 0 && d->ldc % 32 == 0),
+                "mask_out: ReLU outputs with N and ldc multiples of 32");
+  SRL_CHECK_ARG(!d->dact_mask || (d->dact == 1 && !d->dact_src && d->N % 32 == 0 && d->ld_dact % 32 == 0),
+                "dact_mask: the ReLU derivative, instead of dact_src; N and ld_dact multiples of 32");
   if (d->M == 0 || d->N == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (srlskinny::try_skinny(st, d)) {  // one extent <= 16: bandwidth kernels instead of padded MFMA tiles
@@ -62,6 +67,7 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   g.bias = d->bias; g.act = d->act;
   g.range_a = d->a_absmax; g.range_b = d->b_absmax;
   g.dact_src = d->dact_src; g.ld_dact = d->ld_dact; g.dact = d->dact;
+  g.mask_out = d->mask_out; g.dact_mask = d->dact_mask;
   const int nsplit = plan_split(d->K, split, &g.k_per_split);
   g.o = OutDesc{};
   g.o.f_img = g.o.f_line = make_fastdiv(1);
@@ -80,6 +86,9 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
     g.a_colsum = d->a_colsum;
   }
 
+  SRL_CHECK_ARG(!(d->mask_out || d->dact_mask) || (g.vec_a && g.vec_b && !d->a_kmajor && (d->mask_out ? !d->b_kmajor : d->b_kmajor)),
+                "sign masks: float4-stageable operands; mask_out in the forward orientation (a_kmajor 0, b_kmajor 0), dact_mask in "
+                "the data-gradient one (0, 1)");
   int rc;
   if (nsplit == 1) g.out_absmax = d->out_absmax;
   if (use_bf16x3() && d->a_absmax && d->b_absmax && use_f16x2() && g.vec_a && g.vec_b && d->M > 64 && d->N > 64 && d->K >= 64) {
@@ -99,7 +108,7 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   else if (d->N > 64) rc = launch_cfg<32, 256, 1, 4>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
   else if (d->N > 32) rc = launch_cfg<256, 64, 4, 1>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
   else rc = launch_cfg<256, 32, 4, 1>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
-  SRL_CHECK_ARG(rc == 0, "grid too large");
+  SRL_CHECK_ARG(rc == 0, "grid too large (or sign masks on a kernel without them)");
   SRL_LAUNCH_CHECK();
   if (nsplit > 1) {
     reduce_slabs(st, d->workspace, nsplit, 1L, d->M, d->N, d->C, d->ldc, 0L, d->accumulate);

@@ -32,8 +32,8 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // timing experiments only (scripts/build_variant.sh -DSRL_GEMM3_DBG=<bits>; results are wrong): 1 no in-loop global loads,
-// 2 no in-loop LDS writes, 4 no split arithmetic, 8 no barrier, 32 / 64 every gather redirected into a 16 KB / 1 MB
-// window (gemm_core.h bload4).  DESIGN.md section 4 records what they showed.
+// 2 no in-loop LDS writes, 4 no split arithmetic, 8 no barrier, 16 no epilogue, 128 one k-step only, 32 / 64 every gather
+// redirected into a 16 KB / 1 MB window (gemm_core.h bload4).  DESIGN.md section 4 records what they showed.
 #ifndef SRL_GEMM3_DBG
 #define SRL_GEMM3_DBG 0
 #endif
@@ -147,7 +147,7 @@ constexpr int min_waves3(int bm, int bn, int kb, int np = 3) {
   return by_lds >= 3 ? 3 : (by_lds >= 2 ? 2 : 1);
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB, int NP = 3>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB, int NP = 3, int MK = 0>
 __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm3_kernel(GemmArgs g) {
   static_assert(NP == 3 || NP == 2, "three bf16 pieces or two f16 pieces");
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -260,6 +260,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm
   long kend_l = kend;
   if (kcur < 0) { kcur = kbeg; kend_l = kbeg; }  // no tap reaches this pixel: one step on an all-zero tile
   long knext = nextk(kcur);
+  if (SRL_GEMM3_DBG & 128) knext = -1;
 
   // prologue: the first tile into LDS buffer 0, the second into registers (PAIR: both loaded together, set 0 and set 1)
   sa.load(g.a, m0, g.M, kcur, kend_l, true);
@@ -401,10 +402,11 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm
         for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
   }
   constexpr int EPI = AMODE == SRC_DGRAD ? 1 : 0;
+  if ((SRL_GEMM3_DBG & 16) && acc[0][0][0] != 12345.f) return;
   bool interior = m0 + BM <= g.M && n0 + BN <= g.N;
   if (g.o.rowmap && g.o.grp_shift)  // position-grouped rows: the tile's BM images must exist as well
     interior = interior && (((fdiv((uint32_t)(m0 >> g.o.grp_shift), g.o.f_img) + 1u) << g.o.grp_shift) <= (uint32_t)g.o.n_img);
-  gemm_epilogue<TM, TN, EPI>(g, acc, m0, n0, wm, wn, l31, h, by, kz, interior);
+  gemm_epilogue<TM, TN, EPI, MK>(g, acc, m0, n0, wm, wn, l31, h, by, kz, interior);
 }
 
 inline bool tile_groups() {  // SRL_TILE_GROUP=0: row-major tile numbering everywhere (A/B switch)
@@ -444,7 +446,17 @@ inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   a.grp_sz = (unsigned)tiles_m * a.grp_n;
   dim3 grid((unsigned)(nblk * nsplit), 1, 1);
   srl_count_dispatch(NP == 3 ? SRL_DISP_GEMM3 : SRL_DISP_GEMM2H);
-  hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB, NP>), grid, dim3(256), 0, st, a);
+  constexpr bool CAN_W = !AKM && !BKM && BMODE == SRC_PLAIN;  // sign masks: see launch() in gemm_core.h
+  constexpr bool CAN_R = !AKM && BKM && BMODE == SRC_PLAIN && (AMODE == SRC_PLAIN || AMODE == SRC_DGRAD);
+  if (a.mask_out) {
+    if constexpr (CAN_W) hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB, NP, 2>), grid, dim3(256), 0, st, a);
+    else return -ENOTSUP;
+  } else if (a.dact_mask && !a.dact_src) {
+    if constexpr (CAN_R) hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB, NP, 1>), grid, dim3(256), 0, st, a);
+    else return -ENOTSUP;
+  } else {
+    hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB, NP>), grid, dim3(256), 0, st, a);
+  }
   return 0;
 }
 #endif  // __HIPCC__

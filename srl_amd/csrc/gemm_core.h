@@ -31,6 +31,7 @@
 #pragma once
 #include "srl_common.h"
 #include <type_traits>
+#include <utility>
 
 namespace srlgemm {
 
@@ -112,6 +113,18 @@ struct GemmArgs {
   long bias_batch;  // per-batch (grid.y) stride of the bias vector
   const float* dact_src;  // same addressing as the output (own pitch ld_dact when !rowmap)
   long ld_dact;
+  // The ReLU derivative needs one BIT of the producer's output, not the float: a forward launch with act == 1 and mask_out
+  // sets bit e of mask_out (word e >> 5, bit e & 31) iff output element e is > 0, e = the element's offset from the start
+  // of the output tensor; a data-gradient launch with dact == 1 reads dact_mask the same way instead of dact_src (mask_off
+  // = offset of o.out inside the tensor) -- 1/32 of the bytes.  Both sides move whole words: one 32-column block of a row is
+  // one word (N, the pitches and every base offset are multiples of 32: checked by the callers), lane r of a wavefront
+  // stores / loads the word of row r of a 32 x 32 block, and the bits travel between that lane and the accumulator layout
+  // through v_writelane / ds_bpermute -- one memory instruction per block instead of one per accumulator register (which is
+  // what made an earlier version of this SLOWER than reading the floats: the read was bound by issue, not bytes).
+  // mask_out: dense outputs only (!rowmap).
+  uint32_t* mask_out;
+  const uint32_t* dact_mask;
+  uint32_t mask_off;
   int act, dact, accumulate;
   long k_per_split;
   int vec_a, vec_b;
@@ -149,9 +162,34 @@ __device__ __forceinline__ float range_scale(const float* amax) {
   se = se < 87 ? 87 : (se > 167 ? 167 : se);                    // scales within 2^-40 .. 2^40
   return __uint_as_float((uint32_t)se << 23);
 }
+// the sign words of a 32 x 32 accumulator block (layout of gemm_epilogue) into the lanes that own the rows: register R holds
+// rows cr and cr + 4 (cr = (R & 3) + 8 (R >> 2)) in the two halves of the wavefront, so one ballot is both rows' words.
+// (Compare + select per row rather than v_writelane_b32 in inline assembly: the ballot is a VALU-written SGPR, and the
+// wait states v_writelane needs after that are only inserted for instructions the compiler knows -- without them the
+// lane received the PREVIOUS ballot.)
+template <int R>
+__device__ __forceinline__ void sign_rows(const float (&v)[16], int lane31, uint32_t& wv) {
+  const unsigned long long bal = __ballot(v[R] > 0.f);
+  constexpr int cr = (R & 3) + 8 * (R >> 2);
+  wv = lane31 == cr ? (uint32_t)bal : wv;
+  wv = lane31 == cr + 4 ? (uint32_t)(bal >> 32) : wv;
+}
+template <int... R>
+__device__ __forceinline__ uint32_t sign_words(const float (&v)[16], int lane31, std::integer_sequence<int, R...>) {
+  uint32_t wv = 0;
+  (sign_rows<R>(v, lane31, wv), ...);
+  return wv;
+}
 __device__ __forceinline__ void absmax_commit(float* dst, float mx) {  // mx >= 0: unsigned order = float order
+  // One atomic per wavefront to ONE address is a serial chain through one L2 channel (~10 ns each): 51 000 wavefronts of a
+  // strided data gradient spent 0.2 ms of its 0.67 there.  The slot only grows, so a wavefront whose maximum does not exceed
+  // what a (relaxed, possibly stale -- staleness only means a superfluous atomic) load returns has nothing to add: after the
+  // first few tiles almost every wavefront leaves with the load alone.
   mx = wave_allmax(mx);
-  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(dst), __float_as_uint(mx));
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) {
+    unsigned int* d = reinterpret_cast<unsigned int*>(dst);
+    if (__float_as_uint(mx) > __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d, __float_as_uint(mx));
+  }
 }
 
 // Odometer over the k-steps of a forward convolution, slowest digit first: 128-byte line of the pixel (two 16-channel
@@ -651,7 +689,10 @@ struct Stage {
 // so the run-time switches and their branches are gone; `interior` (workgroup-uniform: the whole tile lies inside the
 // matrix and, for position-grouped rows, inside the batch) takes a copy of the block loop whose loads and stores are
 // unconditional (64 conditional stores per lane otherwise: an exec-mask branch each).
-template <int TM, int TN, int EPI = 0>
+// MK (sign masks, GemmArgs::mask_out / dact_mask): 0 none, 1 the ReLU derivative is read from dact_mask (and the float path
+// is compiled out), 2 mask_out is written.  A template parameter, not a run-time switch: the kernels sit at the register
+// limit of their occupancy, and code that is never executed still raised the pressure into spills.
+template <int TM, int TN, int EPI = 0, int MK = 0>
 __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN], long m0, long n0, int wm, int wn, int l31,
                                               int h, int by, unsigned kz, bool interior = false) {  // kz: k-range (split-K slab)
   // ---- epilogue: per 32x32 accumulator block, all loads batched ahead of the arithmetic and the stores ----------------
@@ -659,6 +700,9 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
                               : (long)by * g.o.batch_stride;
   float* out = g.o.out + (long)kz * g.slab + obatch;
   if (g.o.rowmap && g.dact_src) g.dact_src += obatch;  // the activation shares the output's map
+  const uint32_t* mk = MK == 1 ? g.dact_mask : nullptr;  // sign bits of the producer's output instead of its floats
+  uint32_t* mko = (EPI == 0 && MK == 2) ? g.mask_out : nullptr;
+  if (MK == 1) g.dact_src = nullptr;
   const float* bias = g.bias ? g.bias + (long)by * g.bias_batch : nullptr;
   // Row addressing stays 32-bit: a 64-bit base per 32-row block plus element offsets (dense output), or offsets
   // from the tensor base through the (image, line, pixel) map (callers keep mapped outputs below 2^32 elements).
@@ -682,7 +726,7 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
   for (int i = 0; i < TM; ++i) {
     const long row0 = m0 + wm * (TM * 32) + i * 32 + 4 * h;  // accumulator register r holds row0 + (r&3) + 8*(r>>2)
     float* ob = out;
-    const float* db = g.dact_src;
+    const float* db = MK == 1 ? nullptr : g.dact_src;
     uint32_t ro[16];
     uint32_t okm = 0;
 #pragma unroll
@@ -710,6 +754,28 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
       ob += row0 * g.o.ldo;
       if (db) db += row0 * g.ld_dact;
     }
+    // sign masks: the element offset (= bit number) of ROW l31 of this block row, column 0 of the output -- lane l31 moves
+    // that row's words
+    const long rowl = row0 - 4 * h + l31;  // row0 - 4 h: first row of the block row
+    const bool rowl_ok = rowl < g.M;
+    uint32_t e_rowl = 0;
+    if (MK == 1) {
+      if (grouped) {
+        const uint32_t n = grp_n0 + ((uint32_t)rowl & ((1u << g.o.grp_shift) - 1u));
+        e_rowl = g.mask_off + (uint32_t)obatch + (n < (uint32_t)g.o.n_img ? n : 0u) * (uint32_t)g.o.img_stride + grp_pix;
+      } else if (g.o.rowmap) {
+        const uint32_t rr = rowl_ok ? (uint32_t)rowl : 0u;
+        const uint32_t n = fdiv(rr, g.o.f_img);
+        const uint32_t rem = rr - n * g.o.f_img.d;
+        const uint32_t y = fdiv(rem, g.o.f_line);
+        e_rowl = g.mask_off + (uint32_t)obatch + n * (uint32_t)g.o.img_stride + y * (uint32_t)g.o.y_stride +
+                 (rem - y * g.o.f_line.d) * (uint32_t)g.o.x_stride;
+      } else {
+        e_rowl = (uint32_t)((rowl_ok ? rowl : 0L) * g.ld_dact);
+      }
+    } else if (MK == 2) {
+      e_rowl = (uint32_t)obatch + (uint32_t)((rowl_ok ? rowl : 0L) * g.o.ldo);
+    }
     // column offsets of the TN blocks, then -- before any arithmetic or store of this block row -- the loads of the
     // producer's activation for ALL of them (the derivative mask of a data gradient): their latency is paid once per block
     // row instead of once per 32x32 block (the stores of block j would otherwise sit between the loads of j and j + 1;
@@ -729,15 +795,20 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
     }
     auto blocks = [&](auto full_c) {
       constexpr bool FULL = decltype(full_c)::value;
-      float yv[TN][16];
-      if (db) {
+      float yv[MK == 1 ? 1 : TN][16];
+      if (MK != 1 && db) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const uint32_t o = g.o.rowmap ? ro[r] : (uint32_t)((r & 3) + 8 * (r >> 2)) * ldd;
-            yv[j][r] = (FULL || ((okj[j] >> r) & 1u)) ? db[o + ccj[j]] : 1.f;
+            yv[MK == 1 ? 0 : j][r] = (FULL || ((okj[j] >> r) & 1u)) ? db[o + ccj[j]] : 1.f;
           }
+      }
+      uint32_t mw[TN];  // lane l31: the sign word of row l31 of block j (column offsets: ccj[j] - l31 is this block's first)
+      if (MK == 1) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mw[j] = mk[(e_rowl + ccj[j]) >> 5];
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -753,13 +824,25 @@ __device__ __forceinline__ void gemm_epilogue(GemmArgs& g, f32x16 (&acc)[TM][TN]
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
         }
-        if (db) {
+        if (EPI == 0 && MK == 2) {  // sign bits of the ReLU output: a ballot per accumulator register = the words of two rows,
+          // dropped into the lanes that own those rows; then one store for the 32 x 32 block
+          const uint32_t wv = sign_words(v, l31, std::make_integer_sequence<int, 16>{});
+          if (h == 0 && rowl_ok && (FULL || n0 + wn * (TN * 32) + j * 32 < g.N)) mko[(e_rowl + cc) >> 5] = wv;
+        }
+        if (MK == 1) {  // the ReLU derivative from the sign words: row cr + 4 h of the block sits in lane cr + 4 h
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int cr = (r & 3) + 8 * (r >> 2);
+            const uint32_t wd = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * cr + 16 * h, (int)mw[j]);
+            v[r] = ((wd >> l31) & 1u) ? v[r] : 0.f;
+          }
+        } else if (db) {
           if (g.dact == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = yv[j][r] > 0.f ? v[r] : 0.f;
+            for (int r = 0; r < 16; ++r) v[r] = yv[MK == 1 ? 0 : j][r] > 0.f ? v[r] : 0.f;
           } else if (g.dact == 2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] *= 1.f - yv[j][r] * yv[j][r];
+            for (int r = 0; r < 16; ++r) v[r] *= 1.f - yv[MK == 1 ? 0 : j][r] * yv[MK == 1 ? 0 : j][r];
           }
         }
         if (EPI == 0 && g.accumulate) {
@@ -798,7 +881,7 @@ constexpr int min_waves(int bm, int bn, int amode, int bmode, bool gen, int nwav
   return big ? 3 : 4;
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN, int KB, bool OBS8>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, bool GEN, int KB, bool OBS8, int MK = 0>
 __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, WM * WN)) void gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1, "4 or 8 wavefronts per workgroup");
@@ -1103,7 +1186,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves(BM, BN, AMODE, BMODE, GEN, 
     }
   }
 
-  gemm_epilogue<TM, TN>(g, acc, m0, n0, wm, wn, l31, h, by, blockIdx.z);
+  gemm_epilogue<TM, TN, 0, MK>(g, acc, m0, n0, wm, wn, l31, h, by, blockIdx.z);
 }
 
 static __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* ws, int nslab, long batch, long M, long N,
@@ -1229,7 +1312,20 @@ inline int launch(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   if (nblk > 0x7fffffffL || nsplit > 65535) return -EINVAL;
   dim3 grid((unsigned)nblk, 1, (unsigned)nsplit);
   srl_count_dispatch(SRL_DISP_GEMM_F32);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, GEN, KB, OBS8>), grid, dim3(WM * WN * 64), 0, st, a);
+  // sign masks (gemm_epilogue's MK): written by products in the forward orientation, read by those in the data-gradient one
+  constexpr bool CAN_W = !AKM && !BKM && !GEN && BMODE == SRC_PLAIN;
+  constexpr bool CAN_R = !AKM && BKM && !GEN && BMODE == SRC_PLAIN && (AMODE == SRC_PLAIN || AMODE == SRC_DGRAD);
+  if (a.mask_out) {
+    if constexpr (CAN_W)
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, GEN, KB, OBS8, 2>), grid, dim3(WM * WN * 64), 0, st, a);
+    else return -ENOTSUP;
+  } else if (a.dact_mask && !a.dact_src) {
+    if constexpr (CAN_R)
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, GEN, KB, OBS8, 1>), grid, dim3(WM * WN * 64), 0, st, a);
+    else return -ENOTSUP;
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, GEN, KB, OBS8>), grid, dim3(WM * WN * 64), 0, st, a);
+  }
   return 0;
 }
 #endif

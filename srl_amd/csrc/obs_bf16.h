@@ -135,6 +135,8 @@ struct FwdArgs {
   float* y;         // [n][P][32]
   int P, nsplit, act;
   float* y_absmax;  // max |y| folded in with an atomic max (the range of the next layer's operand), or NULL
+  uint32_t* y_mask;  // [n][P] words: bit o of word (n, pos) = (y[n][pos][o] > 0), the ReLU derivative for the data gradient
+                     // of the next layer (GemmArgs::dact_mask), or NULL
 };
 
 // One workgroup = one output position x one range of samples.  The position's folded weights (3 planes, 48 KB) sit in
@@ -145,7 +147,9 @@ struct FwdArgs {
 // tile's arithmetic.
 // DBG (timing experiments only, wrong results; SRL_OBS_DBG): 1 = bytes reinterpreted instead of converted, 2 = no MFMAs,
 // 4 = no stores, 8 = the patch loads of every tile go to the first tile's rows (cache-hot)
-template <int KP, int DBG = 0>
+// MASK: also leave the sign bits of the ReLU output (FwdArgs::y_mask).  A template parameter because the kernel sits at the
+// register limit of three wavefronts per SIMD: the variant without it must stay exactly what it was.
+template <int KP, int DBG = 0, bool MASK = false>
 __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
   constexpr int NKB = KP / 16, NC = KP / 32;
   __shared__ uint4 Wl[3 * NKB * 64];
@@ -246,6 +250,7 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
     const bool full = n0 + 32 <= a.g.n;  // wave-uniform: only the batch's last tile is ragged
     float* yp = a.y + n0 * ldy + (long)pos * kCout + l31;
     const int ldy32 = (int)ldy;
+    float vv[16];  // MASK: the stored values in accumulator order
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const float4 r4 = *reinterpret_cast<const float4*>(&rowl[wave][set][0][8 * g4 + 4 * h]);
@@ -257,11 +262,17 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
         if (a.act == 1) v = fmaxf(v, 0.f);
         else if (a.act == 2) v = tanhf(v);
         const int row = 8 * g4 + 4 * h + i;
+        vv[4 * g4 + i] = v;
         if ((full || n0 + row < a.g.n) && (!(DBG & 4) || v == 12345.f)) {
           yp[row * ldy32] = v;
           amx = fmaxf(amx, fabsf(v));
         }
       }
+    }
+    if (MASK) {  // lanes = channels: a ballot per accumulator register is the sign words of two rows, dropped into the lanes of
+      // those rows (srlgemm::sign_words); then one store per tile
+      const uint32_t mword = srlgemm::sign_words(vv, l31, std::make_integer_sequence<int, 16>{});
+      if (h == 0 && (full || n0 + l31 < a.g.n)) a.y_mask[(n0 + l31) * a.P + pos] = mword;
     }
   };
   long t = t0 + wave;

@@ -199,7 +199,7 @@ inline int col_threads(long N) {  // threads across the columns: a power of two 
 
 inline int try_skinny(hipStream_t st, const srl_gemm_desc* d) {
   const long M = d->M, N = d->N, K = d->K;
-  if (M == 0 || N == 0) return 0;
+  if (M == 0 || N == 0 || d->mask_out || d->dact_mask) return 0;  // sign masks: the MFMA epilogue's business
   // ---- forward of a narrow head
   if (!d->a_kmajor && !d->b_kmajor && N <= 16 && M >= 64 && K >= 4 && K % 4 == 0 && d->lda % 4 == 0 && d->ldb % 4 == 0 &&
       al16(d->A) && al16(d->B) && !d->dact_src && d->split_k <= 1 && !d->a_colsum && N * K * 4 <= 48 * 1024) {

@@ -24,7 +24,7 @@ _lib = None
 # process), so it is only a default here, and only if the user has not chosen.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -49,7 +49,8 @@ class GemmDesc(Structure):
                 ("a_kmajor", c_int32), ("B", c_void_p), ("ldb", c_int64), ("b_kmajor", c_int32), ("C", c_void_p),
                 ("ldc", c_int64), ("bias", c_void_p), ("act", c_int32), ("dact_src", c_void_p), ("ld_dact", c_int64),
                 ("dact", c_int32), ("accumulate", c_int32), ("split_k", c_int32), ("workspace", c_void_p),
-                ("a_colsum", c_void_p), ("a_absmax", c_void_p), ("b_absmax", c_void_p), ("out_absmax", c_void_p)]
+                ("a_colsum", c_void_p), ("a_absmax", c_void_p), ("b_absmax", c_void_p), ("out_absmax", c_void_p),
+                ("mask_out", c_void_p), ("dact_mask", c_void_p)]
 
 
 class ConvDesc(Structure):
@@ -61,14 +62,14 @@ _CD = POINTER(ConvDesc)
 
 _SIGNATURES = {
     "srl_conv2d_supported": (c_int, [_CD, c_int]),
-    "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD] + [c_void_p] * 8),
     "srl_absmax": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_conv2d_wgrad_workspace": (c_int64, [_CD]),
     "srl_conv2d_nhwc_wgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_conv2d_dgrad_weight_elems": (c_int64, [_CD]),
     "srl_conv2d_dgrad_repack": (c_int, [c_void_p, _CD, c_void_p, c_void_p]),
-    "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 10),
+    "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 5),
+    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 11),
     "srl_conv2d_obs_row_index_supported": (c_int, [_CD, c_int, c_int]),
     "srl_conv2d_obs_fwd_workspace": (c_int64, [_CD]),
     "srl_obs_space_to_depth": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
@@ -484,13 +485,15 @@ def categorical_sample(logits, avail, is_eval, head_dims, seed, offset, action_o
 
 def gemm(M, N, K, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, bias=None, act=ACT_NONE, dact_src=None, ld_dact=0,
          dact=ACT_NONE, accumulate=False, split_k=1, workspace=None, a_colsum=None, a_absmax=None, b_absmax=None,
-         out_absmax=None):
+         out_absmax=None, mask_out=None, dact_mask=None):
     """Raw-pointer GEMM (``A``/``B``/``C``/... are ints from ``data_ptr()`` possibly with byte offsets).
     ``a_colsum``: [M] += sum_k A(i, k) as a by-product (k-major, float4-stageable A; see ``gemm_colsum_ok``).
     ``a_absmax`` / ``b_absmax``: device floats bounding max |A|, max |B| (both given: the two-plane f16 forward kernel);
-    ``out_absmax``: device float folded with max |C|."""
+    ``out_absmax``: device float folded with max |C|.  ``mask_out`` / ``dact_mask``: sign-bit masks of a ReLU output
+    (written by the forward product; read by a data gradient instead of ``dact_src``'s floats: srl_hip.h)."""
     d = GemmDesc(M, N, K, A, lda, int(a_kmajor), B, ldb, int(b_kmajor), C, ldc, bias, int(act), dact_src, ld_dact,
-                 int(dact), int(accumulate), int(split_k), workspace, a_colsum, a_absmax, b_absmax, out_absmax)
+                 int(dact), int(accumulate), int(split_k), workspace, a_colsum, a_absmax, b_absmax, out_absmax,
+                 mask_out, dact_mask)
     two = (a_absmax is not None and b_absmax is not None and M > 64 and N > 64 and K >= 64 and A % 16 == 0 and B % 16 == 0 and
            lda % 4 == 0 and ldb % 4 == 0 and f16x2_enabled())  # mirrors gemm.hip's choice of the two-plane f16 kernel
     with _scope("gemm", 2.0 * M * N * K, "2h" if two else "x3"):
@@ -710,11 +713,11 @@ def conv2d_supported(d: ConvDesc, first_layer) -> bool:
     return bool(lib().srl_conv2d_supported(ctypes.byref(d), int(first_layer)))
 
 
-def conv2d_nhwc_fwd(d: ConvDesc, x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax=None, w_absmax=None, y_absmax=None):
+def conv2d_nhwc_fwd(d: ConvDesc, x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax=None, w_absmax=None, y_absmax=None, y_mask=None):
     two = x_absmax is not None and w_absmax is not None and d.Cout > 32 and d.Cin * d.KH * d.KW >= 64 and f16x2_enabled()
     with _scope("conv_fwd", _conv_flops(d), "2h" if two else "x3"):
         _check(lib().srl_conv2d_nhwc_fwd(_stream(), ctypes.byref(d), x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax, w_absmax,
-                                         y_absmax), "srl_conv2d_nhwc_fwd")
+                                         y_absmax, y_mask), "srl_conv2d_nhwc_fwd")
 
 
 def absmax(x_ptr, n, out_ptr):
@@ -742,11 +745,12 @@ def conv2d_dgrad_repack(d: ConvDesc, w_ptr, wt_ptr):
     _check(lib().srl_conv2d_dgrad_repack(_stream(), ctypes.byref(d), w_ptr, wt_ptr), "srl_conv2d_dgrad_repack")
 
 
-def conv2d_nhwc_dgrad(d: ConvDesc, dz_ptr, wt_ptr, x_act_ptr, dact, dx_ptr, dz_absmax=None, w_absmax=None, dx_absmax=None):
+def conv2d_nhwc_dgrad(d: ConvDesc, dz_ptr, wt_ptr, x_act_ptr, dact, dx_ptr, dz_absmax=None, w_absmax=None, dx_absmax=None,
+                      x_mask=None):
     two = dz_absmax is not None and w_absmax is not None and d.Cout % 16 == 0 and f16x2_enabled()
     with _scope("conv_dgrad", _conv_flops(d), "2h" if two else "x3"):
         _check(lib().srl_conv2d_nhwc_dgrad(_stream(), ctypes.byref(d), dz_ptr, wt_ptr, x_act_ptr, int(dact), dx_ptr,
-                                           dz_absmax, w_absmax, dx_absmax), "srl_conv2d_nhwc_dgrad")
+                                           dz_absmax, w_absmax, dx_absmax, x_mask), "srl_conv2d_nhwc_dgrad")
 
 
 def conv2d_obs_fwd_workspace(d: ConvDesc) -> int:
@@ -759,12 +763,12 @@ def conv2d_obs_row_index_supported(d: ConvDesc, is_u8, channels_last) -> bool:
 
 
 def conv2d_obs_fwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr,
-                   channels_last=False, ws_ptr=None, row_index: Optional[torch.Tensor] = None, y_absmax=None):
+                   channels_last=False, ws_ptr=None, row_index: Optional[torch.Tensor] = None, y_absmax=None, y_mask=None):
     with _scope("conv_obs_fwd", _conv_flops(d), "obs"):
         _check(
             lib().srl_conv2d_obs_fwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), int(channels_last), mean_ptr,
                                      rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr, ws_ptr,
-                                     _ptr(row_index, torch.int32, "row_index"), y_absmax), "srl_conv2d_obs_fwd")
+                                     _ptr(row_index, torch.int32, "row_index"), y_absmax, y_mask), "srl_conv2d_obs_fwd")
 
 
 def obs_space_to_depth(obs_ptr, is_u8, n, C, H, W, s, out_ptr, mean_ptr, rstd_ptr):

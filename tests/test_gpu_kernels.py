@@ -659,6 +659,13 @@ def test_adam_matches_torch(max_norm):
 
 
 # ------------------------------------------------------------------------------------------------ implicit-GEMM convolutions
+def _signbits(a):
+    """Sign-bit mask of a tensor the way the kernels keep it: bit e & 31 of word e >> 5 = (element e > 0)."""
+    flat = np.ascontiguousarray(a).reshape(-1) > 0
+    flat = np.concatenate([flat, np.zeros((-flat.size) % 32, bool)])
+    return np.packbits(flat, bitorder="little").view(np.uint32)
+
+
 def _conv_ref(x_nhwc, w_ohwi, bias, stride, act):
     """float64 reference on the CPU: NHWC in/out, weights [Cout, KH, KW, Cin]."""
     xt = torch.from_numpy(x_nhwc).double().permute(0, 3, 1, 2).requires_grad_(True)
@@ -688,6 +695,12 @@ def test_conv2d_nhwc_implicit(n, H, Cin, k, s, Cout):
     hip.conv2d_nhwc_fwd(d, dx_.data_ptr(), dw_.data_ptr(), db_.data_ptr(), y.data_ptr())
     xt, wt, bt, yref = _conv_ref(x, w, b, s, 1)
     assert rel_close(y.cpu().numpy(), yref.permute(0, 2, 3, 1).detach().numpy(), 1e-5, scale=1.0)
+    if Cout % 32 == 0:  # the same launch also leaves the sign bits of y: exactly (y > 0), and y itself unchanged
+        ym = torch.full((n * OH * OH * Cout // 32,), -1, dtype=torch.int32, device=DEV)
+        y_m = torch.full_like(y, np.nan)
+        hip.conv2d_nhwc_fwd(d, dx_.data_ptr(), dw_.data_ptr(), db_.data_ptr(), y_m.data_ptr(), y_mask=ym.data_ptr())
+        assert torch.equal(y_m, y)
+        assert np.array_equal(ym.cpu().numpy().view(np.uint32), _signbits(y.cpu().numpy()))
     # backward: dz = upstream gradient w.r.t. the pre-activation
     dz = (rng.standard_normal((n, OH, OH, Cout)) * (yref.permute(0, 2, 3, 1).detach().numpy() > 0)).astype(np.float32)
     z = torch.nn.functional.conv2d(xt, wt, bt, stride=s)
@@ -708,6 +721,12 @@ def test_conv2d_nhwc_implicit(n, H, Cin, k, s, Cout):
     hip.conv2d_nhwc_dgrad(d, ddz.data_ptr(), wtp.data_ptr(), dx_.data_ptr(), 1, dxo.data_ptr())
     ref_dx = xt.grad.permute(0, 2, 3, 1).numpy() * (x > 0)
     assert rel_close(dxo.cpu().numpy(), ref_dx, 1e-5, scale=1.0)
+    # the ReLU derivative from the sign bits of x instead of its floats: the same gradient, bit for bit
+    if Cin % 32 == 0:
+        xm = dev(_signbits(x).view(np.int32))
+        dxm = torch.full((n, H, H, Cin), np.nan, device=DEV)
+        hip.conv2d_nhwc_dgrad(d, ddz.data_ptr(), wtp.data_ptr(), None, 1, dxm.data_ptr(), x_mask=xm.data_ptr())
+        assert torch.equal(dxm, dxo)
     torch.cuda.synchronize()
 
 
@@ -815,6 +834,13 @@ def test_conv2d_obs_space_to_depth_path(n, u8, kind):
     hip.conv2d_obs_fwd(d, s2d.data_ptr(), u8, mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), dbt.data_ptr(),
                        dw_.data_ptr(), db_.data_ptr(), y2.data_ptr(), channels_last=True, ws_ptr=fws.data_ptr())
     assert rel_close(y2.cpu().numpy(), yref.permute(0, 2, 3, 1).detach().numpy(), 1e-5, scale=1.0)
+    for wsp, yy in ((None, y), (fws.data_ptr(), y2)):  # sign bits of the ReLU output from the same launches
+        ym = torch.full((n * OH * OH * Cout // 32,), -1, dtype=torch.int32, device=DEV)
+        y_m = torch.full_like(y, np.nan)
+        hip.conv2d_obs_fwd(d, s2d.data_ptr(), u8, mean.data_ptr(), rstd.data_ptr(), dg.data_ptr(), dbt.data_ptr(),
+                           dw_.data_ptr(), db_.data_ptr(), y_m.data_ptr(), channels_last=True, ws_ptr=wsp, y_mask=ym.data_ptr())
+        assert torch.equal(y_m, yy)
+        assert np.array_equal(ym.cpu().numpy().view(np.uint32), _signbits(yy.cpu().numpy()))
     dz = (rng.standard_normal((n, OH, OH, Cout)) * (yref.permute(0, 2, 3, 1).detach().numpy() > 0)).astype(np.float32)
     z.backward(t(dz).double().permute(0, 3, 1, 2))
     ddz = dev(dz)
@@ -980,3 +1006,36 @@ def test_obs_ln_nhwc_fwd_bwd(u8):
                         gb.data_ptr())
     assert rel_close(gg.cpu().numpy(), tg.grad.numpy(), 2e-5, scale=1.0)
     assert rel_close(gb.cpu().numpy(), tb.grad.numpy(), 2e-5, scale=1.0)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 64, 128), (1000, 3136, 512), (130, 96, 72)])
+def test_gemm_sign_masks(M, N, K):
+    """srl_gemm_desc.mask_out / dact_mask: the forward product leaves the sign bits of its ReLU output; a data gradient reads
+    them instead of the floats and returns the same matrix bit for bit."""
+    rng = np.random.default_rng(M + N)
+    a, w, b = (rng.standard_normal(sh).astype(np.float32) for sh in ((M, K), (N, K), (N,)))
+    da, dw_, db_ = dev(a), dev(w), dev(b)
+    y = torch.full((M, N), np.nan, device=DEV)
+    hip.gemm(M, N, K, da.data_ptr(), K, 0, dw_.data_ptr(), K, 0, y.data_ptr(), N, bias=db_.data_ptr(), act=1)
+    if N % 32 == 0:
+        y2 = torch.full_like(y, np.nan)
+        ym = torch.full((M * N // 32,), -1, dtype=torch.int32, device=DEV)
+        hip.gemm(M, N, K, da.data_ptr(), K, 0, dw_.data_ptr(), K, 0, y2.data_ptr(), N, bias=db_.data_ptr(), act=1,
+                 mask_out=ym.data_ptr())
+        assert torch.equal(y2, y)
+        assert np.array_equal(ym.cpu().numpy().view(np.uint32), _signbits(y.cpu().numpy()))
+    # dX = dZ W' masked by the derivative of the ReLU that produced X's layer input x_in [M, N]: floats vs bits
+    x_in = np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32)
+    dz = rng.standard_normal((M, K)).astype(np.float32)
+    w2 = rng.standard_normal((K, N)).astype(np.float32)  # [out = K, in = N]: B(k, j) k-major
+    ddz, dw2, dxin = dev(dz), dev(w2), dev(x_in)
+    g_f = torch.full((M, N), np.nan, device=DEV)
+    hip.gemm(M, N, K, ddz.data_ptr(), K, 0, dw2.data_ptr(), N, 1, g_f.data_ptr(), N, dact_src=dxin.data_ptr(), ld_dact=N, dact=1)
+    if N % 32:
+        return
+    g_m = torch.full((M, N), np.nan, device=DEV)
+    xm = dev(_signbits(x_in).view(np.int32))
+    hip.gemm(M, N, K, ddz.data_ptr(), K, 0, dw2.data_ptr(), N, 1, g_m.data_ptr(), N, ld_dact=N, dact=1, dact_mask=xm.data_ptr())
+    assert torch.equal(g_m, g_f)
+    ref = (dz.astype(np.float64) @ w2.astype(np.float64)) * (x_in > 0)
+    assert rel_close(g_m.cpu().numpy(), ref, 1e-5, scale=float(np.sqrt(K)))
