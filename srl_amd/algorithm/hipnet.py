@@ -657,9 +657,11 @@ class HipNet:
                     y_range = self._act_range() if implicit else None
                     if implicit:
                         w_range = self._weight_range(L.prefix, L.cout * kdim) if cur_range is not None and not L.pad else None
+                        fws = hip.conv2d_fwd_workspace(desc) if w_range is not None else 0
                         hip.conv2d_nhwc_fwd(desc, cur.ptr, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"),
                                             y.ptr, x_absmax=cur_range if w_range is not None else None, w_absmax=w_range,
-                                            y_absmax=y_range, y_mask=y.mask)
+                                            y_absmax=y_range, y_mask=y.mask,
+                                            ws_ptr=self.ws.get(f"{L.prefix}.wq", fws).data_ptr() if fws else None)
                     else:
                         hip.im2col_nhwc(cur.ptr, n, h, w, L.cin, L.k, L.k, L.stride, P.ptr)
                 if not implicit:

@@ -62,7 +62,8 @@ _CD = POINTER(ConvDesc)
 
 _SIGNATURES = {
     "srl_conv2d_supported": (c_int, [_CD, c_int]),
-    "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD] + [c_void_p] * 8),
+    "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD] + [c_void_p] * 9),
+    "srl_conv2d_fwd_workspace": (c_int64, [_CD]),
     "srl_absmax": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_conv2d_wgrad_workspace": (c_int64, [_CD]),
     "srl_conv2d_nhwc_wgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -291,7 +292,7 @@ def device_info():
     return dict(num_cus=n.value, lds_bytes_per_cu=l.value, arch=buf.value.decode())
 
 
-DISPATCH_FAMILIES = ("gemm3", "gemm_f32", "skinny", "obs_fwd_bf16", "obs_bwd_bf16", "gemm2h")
+DISPATCH_FAMILIES = ("gemm3", "gemm_f32", "skinny", "obs_fwd_bf16", "obs_bwd_bf16", "gemm2h", "conv_is")
 
 
 def dispatch_counts(reset: bool = False) -> dict:
@@ -713,11 +714,17 @@ def conv2d_supported(d: ConvDesc, first_layer) -> bool:
     return bool(lib().srl_conv2d_supported(ctypes.byref(d), int(first_layer)))
 
 
-def conv2d_nhwc_fwd(d: ConvDesc, x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax=None, w_absmax=None, y_absmax=None, y_mask=None):
+def conv2d_fwd_workspace(d: ConvDesc) -> int:
+    """Floats of workspace with which ``conv2d_nhwc_fwd`` may take the image-stationary kernel (0: not for this geometry)."""
+    return int(lib().srl_conv2d_fwd_workspace(ctypes.byref(d)))
+
+
+def conv2d_nhwc_fwd(d: ConvDesc, x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax=None, w_absmax=None, y_absmax=None, y_mask=None,
+                    ws_ptr=None):
     two = x_absmax is not None and w_absmax is not None and d.Cout > 32 and d.Cin * d.KH * d.KW >= 64 and f16x2_enabled()
     with _scope("conv_fwd", _conv_flops(d), "2h" if two else "x3"):
         _check(lib().srl_conv2d_nhwc_fwd(_stream(), ctypes.byref(d), x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax, w_absmax,
-                                         y_absmax, y_mask), "srl_conv2d_nhwc_fwd")
+                                         y_absmax, y_mask, ws_ptr), "srl_conv2d_nhwc_fwd")
 
 
 def absmax(x_ptr, n, out_ptr):
