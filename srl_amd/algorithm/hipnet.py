@@ -125,8 +125,9 @@ class HipNet:
         # SRL_EXPLICIT_CONV=1 forces the im2col + GEMM + col2im fallback (kept for geometries the implicit
         # kernels reject, and as a cross-check of the implicit path in the tests)
         self.force_explicit_conv = os.environ.get("SRL_EXPLICIT_CONV", "0") == "1"
-        # rows one encoder pass may take: the gather kernels address an activation tensor with 32-bit byte offsets, so
-        # the widest per-row activation bounds the rows per launch (2 GiB per tensor, half the hardware range)
+        # rows one encoder pass takes.  Not an addressing limit any more (the convolution entry points walk a batch whose
+        # tensors exceed 32-bit offsets in runs of images, csrc/conv.hip images_per_launch): a footprint choice -- 16 GiB for
+        # the widest activation of the pass
         per_row = 1
         for enc in list(spec.obs_encoders) + list(spec.state_encoders or []):
             for L in enc.layers:
@@ -140,7 +141,7 @@ class HipNet:
                     per_row = max(per_row, vin, math.prod(L.out_sp) * max(L.cout, L.cin * math.prod(L.kern)))
                 elif isinstance(L, ns.LinearSpec):
                     per_row = max(per_row, L.in_features, L.out_features)
-        self.encoder_rows = max(1, (1 << 31) // (4 * per_row))
+        self.encoder_rows = max(1, (16 << 30) // (4 * per_row))
 
     # ------------------------------------------------------------------ parameters / checkpoints
     def ref_names(self):

@@ -290,10 +290,27 @@ int check_desc(const srl_conv_desc* d) {
 extern "C" int srl_conv2d_supported(const srl_conv_desc* d, int first_layer) {
   if (check_desc(d) != 0) return 0;
   const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
-  const long in_elems = d->n * d->H * d->W * d->Cin, out_elems = d->n * OH * OW * d->Cout;
-  if (!fits31(in_elems) || !fits31(out_elems) || !fits31(d->n * OH * OW)) return 0;
+  // one image must be addressable with 32-bit offsets; any NUMBER of images is fine (the entry points walk a large batch
+  // in runs of images_per_launch: a 64-bit base per run, 32-bit offsets inside it)
+  if (!fits31(4L * d->H * d->W * d->Cin) || !fits31(4L * OH * OW * d->Cout) || d->n < 0) return 0;
   if (first_layer) return obs_geometry_ok(d, first_layer == 2) ? 1 : 0;
   return (d->Cin % 4 == 0 && d->Cout % 4 == 0) ? 1 : 0;
+}
+
+// The kernels address every tensor of a launch with 32-bit offsets (bytes in the gathers, elements in the epilogue).  A batch
+// whose activations exceed that -- 2 GiB on a 288 GB part is one 16 384-row chunk of a 128 x 128 x 16 feature map -- is walked
+// in runs of this many images by the entry points below (whole 256-image groups, so that the position-grouped tiles of the
+// data gradients stay full): a 64-bit base per run, the same kernels inside it.
+static long images_per_launch(const srl_conv_desc* d, int in_esize) {
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
+  const long in_b = (long)d->H * d->W * d->Cin * in_esize, in_f = 4L * d->H * d->W * d->Cin, out_b = 4L * OH * OW * d->Cout;
+  long big = in_b > out_b ? in_b : out_b;
+  big = in_f > big ? in_f : big;  // the data gradient writes the input's shape in float32
+  long lim = ((1L << 31) - 1) / big;
+  const char* e = getenv("SRL_CONV_RUN_IMAGES");  // tests: force short runs
+  if (e && atol(e) > 0 && atol(e) < lim) lim = atol(e);
+  if (lim >= 512) lim &= ~255L;
+  return lim < 1 ? 1 : lim;
 }
 
 // Order of the 16-deep k-steps of a forward convolution (k = (kh, kw, c), c fastest).  Every tile re-reads its input
@@ -340,9 +357,9 @@ static void launch_is_fwd(hipStream_t st, const srlis::FwdArgs& a, long n) {
   else hipLaunchKernelGGL((srlis::is_fwd_kernel<H, W, C, KH, KW, S, G, TMW, TPS, D, NT, false>), dim3(grid), dim3(NT), 0, st, a);
 }
 
-extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w,
-                                   const float* bias, float* y, const float* x_absmax, const float* w_absmax,
-                                   float* y_absmax, uint32_t* y_mask, float* workspace) {
+static int conv2d_nhwc_fwd_run(void* stream, const srl_conv_desc* d, const float* x, const float* w,
+                               const float* bias, float* y, const float* x_absmax, const float* w_absmax,
+                               float* y_absmax, uint32_t* y_mask, float* workspace) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry (needs Cin, Cout multiples of 4, < 2^31 elements)");
   SRL_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w), "null / unaligned tensor");
   SRL_CHECK_ARG(!y_mask || (d->act == 1 && d->Cout % 32 == 0), "y_mask: ReLU layers with Cout a multiple of 32");
@@ -395,6 +412,23 @@ extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const f
   return 0;
 }
 
+extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w,
+                                   const float* bias, float* y, const float* x_absmax, const float* w_absmax,
+                                   float* y_absmax, uint32_t* y_mask, float* workspace) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry (needs Cin, Cout multiples of 4)");
+  const long run = images_per_launch(d, 4);
+  const long in_e = (long)d->H * d->W * d->Cin;
+  const long out_e = (long)conv_out(d->H, d->KH, d->stride) * conv_out(d->W, d->KW, d->stride) * d->Cout;
+  for (long i0 = 0; i0 < d->n || i0 == 0; i0 += run) {
+    srl_conv_desc s = *d;
+    s.n = d->n - i0 < run ? d->n - i0 : run;
+    const int rc = conv2d_nhwc_fwd_run(stream, &s, x + i0 * in_e, w, bias, y + i0 * out_e, x_absmax, w_absmax, y_absmax,
+                                       y_mask ? y_mask + i0 * out_e / 32 : nullptr, workspace);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
 extern "C" int64_t srl_conv2d_wgrad_workspace(const srl_conv_desc* d) {
   if (check_desc(d) != 0) return 0;
   const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
@@ -404,8 +438,8 @@ extern "C" int64_t srl_conv2d_wgrad_workspace(const srl_conv_desc* d) {
   return (int64_t)want_split(d->n * OH * OW, tiles, 1) * d->Cout * Kp;
 }
 
-extern "C" int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const float* x, const float* dz, float* dw,
-                                     float* workspace, float* dbias, const float* x_absmax, const float* dz_absmax) {
+static int conv2d_nhwc_wgrad_run(void* stream, const srl_conv_desc* d, const float* x, const float* dz, float* dw,
+                                 float* workspace, float* dbias, const float* x_absmax, const float* dz_absmax) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry");
   SRL_CHECK_ARG(x && dz && dw && aligned16(x) && aligned16(dz), "null / unaligned tensor");
   if (d->n == 0) return 0;
@@ -444,6 +478,21 @@ extern "C" int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const
   return 0;
 }
 
+extern "C" int srl_conv2d_nhwc_wgrad(void* stream, const srl_conv_desc* d, const float* x, const float* dz, float* dw,
+                                     float* workspace, float* dbias, const float* x_absmax, const float* dz_absmax) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry");
+  const long run = images_per_launch(d, 4);
+  const long in_e = (long)d->H * d->W * d->Cin;
+  const long out_e = (long)conv_out(d->H, d->KH, d->stride) * conv_out(d->W, d->KW, d->stride) * d->Cout;
+  for (long i0 = 0; i0 < d->n || i0 == 0; i0 += run) {  // every run adds into dw / dbias
+    srl_conv_desc s = *d;
+    s.n = d->n - i0 < run ? d->n - i0 : run;
+    const int rc = conv2d_nhwc_wgrad_run(stream, &s, x + i0 * in_e, dz + i0 * out_e, dw, workspace, dbias, x_absmax, dz_absmax);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
 extern "C" int64_t srl_conv2d_dgrad_weight_elems(const srl_conv_desc* d) {
   if (check_desc(d) != 0) return 0;
   return (int64_t)d->KH * d->KW * d->Cin * d->Cout;  // the classes partition the taps
@@ -466,9 +515,9 @@ extern "C" int srl_conv2d_dgrad_repack(void* stream, const srl_conv_desc* d, con
   return 0;
 }
 
-extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* wt,
-                                     const float* x_act, int dact, float* dx, const float* dz_absmax, const float* w_absmax,
-                                     float* dx_absmax, const uint32_t* x_mask) {
+static int conv2d_nhwc_dgrad_run(void* stream, const srl_conv_desc* d, const float* dz, const float* wt,
+                                 const float* x_act, int dact, float* dx, const float* dz_absmax, const float* w_absmax,
+                                 float* dx_absmax, const uint32_t* x_mask) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0) && d->stride <= 8, "unsupported geometry");
   SRL_CHECK_ARG(!x_mask || (dact == 1 && !x_act && d->Cin % 32 == 0),
                 "x_mask: the ReLU derivative, instead of x_act; Cin a multiple of 32");
@@ -552,6 +601,23 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
   return 0;
 }
 
+extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* wt,
+                                     const float* x_act, int dact, float* dx, const float* dz_absmax, const float* w_absmax,
+                                     float* dx_absmax, const uint32_t* x_mask) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, 0) && d->stride <= 8, "unsupported geometry");
+  const long run = images_per_launch(d, 4);
+  const long in_e = (long)d->H * d->W * d->Cin;
+  const long out_e = (long)conv_out(d->H, d->KH, d->stride) * conv_out(d->W, d->KW, d->stride) * d->Cout;
+  for (long i0 = 0; i0 < d->n || i0 == 0; i0 += run) {
+    srl_conv_desc s = *d;
+    s.n = d->n - i0 < run ? d->n - i0 : run;
+    const int rc = conv2d_nhwc_dgrad_run(stream, &s, dz + i0 * out_e, wt, x_act ? x_act + i0 * in_e : nullptr, dact, dx + i0 * in_e,
+                                         dz_absmax, w_absmax, dx_absmax, x_mask ? x_mask + i0 * in_e / 32 : nullptr);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
 extern "C" int64_t srl_conv2d_obs_fwd_workspace(const srl_conv_desc* d) {
   if (check_desc(d) != 0) return 0;
   const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
@@ -565,10 +631,10 @@ extern "C" int srl_conv2d_obs_row_index_supported(const srl_conv_desc* d, int is
   return obs_bf16_ok(d, is_u8, channels_last, nullptr) && ((long)OH * OW * d->Cout) % 4 == 0 ? 1 : 0;
 }
 
-extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
-                                  const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                  const float* w, const float* bias, float* y, float* workspace, const int32_t* row_index,
-                                  float* y_absmax, uint32_t* y_mask) {
+static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
+                              const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              const float* w, const float* bias, float* y, float* workspace, const int32_t* row_index,
+                              float* y_absmax, uint32_t* y_mask) {
   SRL_CHECK_ARG(!y_mask || (d->act == 1 && d->Cout % 32 == 0), "y_mask: ReLU layers with Cout a multiple of 32");
   SRL_CHECK_ARG(row_index == nullptr || (workspace && srl_conv2d_obs_row_index_supported(d, is_u8, channels_last)),
                 "row_index is served by the byte kernels only (srl_conv2d_obs_row_index_supported)");
@@ -660,6 +726,28 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
   return 0;
 }
 
+extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
+                                  const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  const float* w, const float* bias, float* y, float* workspace, const int32_t* row_index,
+                                  float* y_absmax, uint32_t* y_mask) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1),
+                "unsupported geometry (planar: KW, W, stride, H*W multiples of 4; channels-last: Cin multiple of 4)");
+  const long run = images_per_launch(d, is_u8 ? 1 : 4);
+  const long in_b = (long)d->H * d->W * d->Cin * (is_u8 ? 1 : 4);
+  const long out_e = (long)conv_out(d->H, d->KH, d->stride) * conv_out(d->W, d->KW, d->stride) * d->Cout;
+  for (long i0 = 0; i0 < d->n || i0 == 0; i0 += run) {
+    srl_conv_desc s = *d;
+    s.n = d->n - i0 < run ? d->n - i0 : run;
+    // with a slot index the frames (and their statistics) are addressed through it: only the index moves on
+    const long adv = row_index ? 0 : i0;
+    const int rc = conv2d_obs_fwd_run(stream, &s, static_cast<const uint8_t*>(obs) + adv * in_b, is_u8, channels_last, mean + adv,
+                                      rstd + adv, gamma, beta, w, bias, y + i0 * out_e, workspace,
+                                      row_index ? row_index + i0 : nullptr, y_absmax, y_mask ? y_mask + i0 * out_e / 32 : nullptr);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
 extern "C" int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d) {
   if (check_desc(d) != 0) return 0;
   const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
@@ -671,10 +759,10 @@ extern "C" int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d) {
   return (int64_t)((split + 1) * P * d->Cout * Kp + 2 * P * d->Cout + 64);
 }
 
-extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
-                                  const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                  const float* w, const float* dz, float* dw, float* db, float* dgamma, float* dbeta,
-                                  float* workspace, const int32_t* row_index) {
+static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
+                              const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              const float* w, const float* dz, float* dw, float* db, float* dgamma, float* dbeta,
+                              float* workspace, const int32_t* row_index) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1), "unsupported geometry");
   SRL_CHECK_ARG(row_index == nullptr || srl_conv2d_obs_row_index_supported(d, is_u8, channels_last),
                 "row_index is served by the byte kernels only (srl_conv2d_obs_row_index_supported)");
@@ -745,5 +833,25 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
   hipLaunchKernelGGL(obs_affine_kernel, dim3((unsigned)srl_ceil_div(d->Cin * d->H * d->W, 256)), dim3(256), 0, st, Q, R, C, w,
                      OH, d->Cout, ix, dgamma, dbeta);
   SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
+                                  const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  const float* w, const float* dz, float* dw, float* db, float* dgamma, float* dbeta,
+                                  float* workspace, const int32_t* row_index) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1), "unsupported geometry");
+  const long run = images_per_launch(d, is_u8 ? 1 : 4);
+  const long in_b = (long)d->H * d->W * d->Cin * (is_u8 ? 1 : 4);
+  const long out_e = (long)conv_out(d->H, d->KH, d->stride) * conv_out(d->W, d->KW, d->stride) * d->Cout;
+  for (long i0 = 0; i0 < d->n || i0 == 0; i0 += run) {  // every run adds into dw / db / dgamma / dbeta
+    srl_conv_desc s = *d;
+    s.n = d->n - i0 < run ? d->n - i0 : run;
+    const long adv = row_index ? 0 : i0;
+    const int rc = conv2d_obs_bwd_run(stream, &s, static_cast<const uint8_t*>(obs) + adv * in_b, is_u8, channels_last, mean + adv,
+                                      rstd + adv, gamma, beta, w, dz + i0 * out_e, dw, db, dgamma, dbeta, workspace,
+                                      row_index ? row_index + i0 : nullptr);
+    if (rc != 0) return rc;
+  }
   return 0;
 }

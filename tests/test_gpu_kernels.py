@@ -1081,3 +1081,84 @@ def test_conv2d_image_stationary_forward(n, H, Cin, k, s):
     err_is = np.abs(y.cpu().numpy() - ref).max()
     err_ig = np.abs(y2.cpu().numpy() - ref).max()
     assert err_is <= 2 * err_ig + 1e-7, (err_is, err_ig)
+
+
+def test_conv2d_runs_of_images(monkeypatch):
+    """A batch is walked in runs of images (csrc/conv.hip images_per_launch; SRL_CONV_RUN_IMAGES forces short runs here): forward
+    with mask and range, data gradient from the mask, weight gradient, and the first layer through a slot index -- equal to the
+    single-run call (bit for bit where no sum runs over the images)."""
+    rng = np.random.default_rng(5)
+    n, H, Cin, k, s, Cout = 1000, 20, 32, 4, 2, 64
+    x = np.maximum(rng.standard_normal((n, H, H, Cin)), 0).astype(np.float32)
+    w = (rng.standard_normal((Cout, k, k, Cin)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    d = hip.conv_desc(n, H, H, Cin, k, k, s, Cout, act=1)
+    OH = (H - k) // s + 1
+    dx_, dw_, db_ = dev(x), dev(w), dev(b)
+    dz = dev((rng.standard_normal((n, OH, OH, Cout))).astype(np.float32))
+    wtp = torch.empty(hip.conv2d_dgrad_weight_elems(d), device=DEV)
+    hip.conv2d_dgrad_repack(d, dw_.data_ptr(), wtp.data_ptr())
+    xm = dev(_signbits(x).view(np.int32))
+    ws = torch.empty(max(hip.conv2d_wgrad_workspace(d), 1), device=DEV)
+
+    def run_all():
+        y = torch.full((n, OH, OH, Cout), np.nan, device=DEV)
+        ym = torch.full((n * OH * OH * Cout // 32,), -1, dtype=torch.int32, device=DEV)
+        yr = torch.zeros(1, device=DEV)
+        hip.conv2d_nhwc_fwd(d, dx_.data_ptr(), dw_.data_ptr(), db_.data_ptr(), y.data_ptr(), y_absmax=yr.data_ptr(),
+                            y_mask=ym.data_ptr())
+        gx = torch.full((n, H, H, Cin), np.nan, device=DEV)
+        hip.conv2d_nhwc_dgrad(d, dz.data_ptr(), wtp.data_ptr(), None, 1, gx.data_ptr(), x_mask=xm.data_ptr())
+        gw, gb = torch.zeros((Cout, k, k, Cin), device=DEV), torch.zeros(Cout, device=DEV)
+        hip.conv2d_nhwc_wgrad(d, dx_.data_ptr(), dz.data_ptr(), gw.data_ptr(), ws.data_ptr(), gb.data_ptr())
+        torch.cuda.synchronize()
+        return y, ym, yr, gx, gw, gb
+
+    one = run_all()
+    monkeypatch.setenv("SRL_CONV_RUN_IMAGES", "300")  # 300 + 300 + 300 + 100
+    runs = run_all()
+    for a, b_, name in zip(one[:4], runs[:4], ("y", "mask", "range", "dx")):
+        assert torch.equal(a, b_), name
+    for a, b_, name in zip(one[4:], runs[4:], ("dw", "db")):
+        assert rel_close(b_.cpu().numpy(), a.cpu().numpy(), 1e-5, scale=float(a.abs().max())), name
+
+
+@pytest.mark.timeout(600)
+def test_conv2d_more_than_2_gib():
+    """Activation tensors beyond 32-bit byte offsets (2.2 GB of input, 43 000 images of 20x20x32): the forward pass and the data
+    gradient of the far end of the batch equal the same images presented alone."""
+    n, H, Cin, k, s, Cout = 43000, 20, 32, 4, 2, 64
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.relu(torch.randn((n, H, H, Cin), device=DEV, generator=g))
+    assert x.numel() * 4 > 2 ** 31
+    w = torch.randn((Cout, k, k, Cin), device=DEV, generator=g) * 0.05
+    b = torch.randn(Cout, device=DEV, generator=g)
+    OH = (H - k) // s + 1
+    d = hip.conv_desc(n, H, H, Cin, k, k, s, Cout, act=1)
+    y = torch.full((n, OH, OH, Cout), float("nan"), device=DEV)
+    hip.conv2d_nhwc_fwd(d, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr())
+    tail = 700  # the last images lie beyond 2^31 bytes in x
+    dt = hip.conv_desc(tail, H, H, Cin, k, k, s, Cout, act=1)
+    xt = x[n - tail:].contiguous()
+    yt = torch.empty((tail, OH, OH, Cout), device=DEV)
+    hip.conv2d_nhwc_fwd(dt, xt.data_ptr(), w.data_ptr(), b.data_ptr(), yt.data_ptr())
+    assert torch.equal(y[n - tail:], yt) and not torch.isnan(y).any()
+    dz = torch.randn((n, OH, OH, Cout), device=DEV, generator=g)
+    wtp = torch.empty(hip.conv2d_dgrad_weight_elems(d), device=DEV)
+    hip.conv2d_dgrad_repack(d, w.data_ptr(), wtp.data_ptr())
+    gx = torch.full((n, H, H, Cin), float("nan"), device=DEV)
+    hip.conv2d_nhwc_dgrad(d, dz.data_ptr(), wtp.data_ptr(), x.data_ptr(), 1, gx.data_ptr())
+    gxt = torch.empty((tail, H, H, Cin), device=DEV)
+    hip.conv2d_nhwc_dgrad(dt, dz[n - tail:].contiguous().data_ptr(), wtp.data_ptr(), xt.data_ptr(), 1, gxt.data_ptr())
+    assert torch.equal(gx[n - tail:], gxt) and not torch.isnan(gx).any()
+    # dense product with a 2.4 GB operand: the far rows against torch
+    del gx, dz, y
+    M, K, N = 300000, 2048, 64
+    a = torch.randn((M, K), device=DEV, generator=g)
+    assert a.numel() * 4 > 2 ** 31
+    wd = torch.randn((N, K), device=DEV, generator=g) * 0.02
+    out = torch.full((M, N), float("nan"), device=DEV)
+    hip.gemm(M, N, K, a.data_ptr(), K, 0, wd.data_ptr(), K, 0, out.data_ptr(), N)
+    ref = a[M - 512:].double() @ wd.double().t()
+    assert rel_close(out[M - 512:].cpu().numpy(), ref.cpu().numpy(), 1e-5, scale=float(ref.abs().max()))
+    assert not torch.isnan(out).any()
