@@ -44,9 +44,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# read when libamdhip64 is loaded, i.e. by `import torch`: the update runs on up to six streams, and with the runtime's default
+# of 4 hardware queues the ingest copy shares one with a compute pipeline (srl_amd/hip.py; INTEGRATION.md switches)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

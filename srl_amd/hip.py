@@ -20,8 +20,9 @@ _lib = None
 # The update runs on up to six streams (two row-chunk pipelines, each with a weight-gradient stream; the ingest copy stream;
 # the collectives' stream).  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that
 # share a queue serialise: with 4 the ingest ring's H2D copy queued behind a pipeline (host-fed update 337 instead of 264 ms),
-# with 8 it does not, and the ring-fed update gains ~1 %.  Read when the runtime initialises (the first HIP call of the
-# process), so it is only a default here, and only if the user has not chosen.
+# with 8 it does not, and the ring-fed update gains ~1 %.  The runtime reads it when libamdhip64 is LOADED (`import torch`), so
+# this default only takes effect in processes that import srl_amd before torch; trainer entry points export it themselves
+# (bench.py does, before its imports) -- INTEGRATION.md lists it with the other switches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ABI_VERSION = 7
