@@ -87,7 +87,7 @@ def _split_for(rows: int, tiles: int) -> int:
     (29 us for a 64 x 64 x 256 product, the longest kernel of that step; 8 slices of 2 steps + the slab sum: 8 us)."""
     want = max(1, 512 // max(tiles, 1))
     if rows < 1024:
-        return int(max(1, min(8, rows // 32)))
+        return int(max(1, min(8, rows // 64)))
     return int(max(1, min(want, rows // 512)))
 
 

@@ -23,12 +23,12 @@ int launch_or(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
 // float32 operands on the bf16 matrix cores (gemm_bf16x3.h): float4-stageable operands only.  k-steps of 16 (48 KB of LDS per
 // 128x128 workgroup, three per CU): k-steps of 32 measured 10-25 % slower, 256x128 tiles +12 % on 4096^3 but not on the
 // network's shapes, 128x64 / 64x128 tiles (full occupancy for the FC forward) -8 %.
-template <int BM, int BN, int WM, int WN, int NP = 3>
+template <int BM, int BN, int WM, int WN, int NP = 3, int KB = 16>
 int launch3_or(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
-  if (!akm && !bkm) return launch3<BM, BN, WM, WN, false, false, SRC_PLAIN, SRC_PLAIN, 16, NP>(st, g, 1, split);
-  if (!akm && bkm) return launch3<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN, 16, NP>(st, g, 1, split);
-  if (akm && bkm) return launch3<BM, BN, WM, WN, true, true, SRC_PLAIN, SRC_PLAIN, 16, NP>(st, g, 1, split);
-  return launch3<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN, 16, NP>(st, g, 1, split);
+  if (!akm && !bkm) return launch3<BM, BN, WM, WN, false, false, SRC_PLAIN, SRC_PLAIN, KB, NP>(st, g, 1, split);
+  if (!akm && bkm) return launch3<BM, BN, WM, WN, false, true, SRC_PLAIN, SRC_PLAIN, KB, NP>(st, g, 1, split);
+  if (akm && bkm) return launch3<BM, BN, WM, WN, true, true, SRC_PLAIN, SRC_PLAIN, KB, NP>(st, g, 1, split);
+  return launch3<BM, BN, WM, WN, true, false, SRC_PLAIN, SRC_PLAIN, KB, NP>(st, g, 1, split);
 }
 
 // both operands float4-loadable (aligned, leading dimensions multiples of 4): the lean instantiation
@@ -36,6 +36,11 @@ template <int BM, int BN, int WM, int WN>
 int launch_cfg(hipStream_t st, const GemmArgs& g, int akm, int bkm, int split) {
   if (g.vec_a && g.vec_b) return launch_or<BM, BN, WM, WN, false>(st, g, akm, bkm, split);
   return launch_or<BM, BN, WM, WN, true>(st, g, akm, bkm, split);
+}
+
+inline bool small_gemm() {  // SRL_SMALL_GEMM=0: the tiny products on the general kernels (A/B)
+  const char* e = getenv("SRL_SMALL_GEMM");
+  return !(e && e[0] == '0');
 }
 
 }  // namespace
@@ -91,6 +96,12 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
                 "the data-gradient one (0, 1)");
   int rc;
   if (nsplit == 1) g.out_absmax = d->out_absmax;
+  if (use_bf16x3() && small_gemm() && g.vec_a && g.vec_b && d->M * d->N <= 65536 && d->K >= 8 && d->K <= 512) {
+    // A product of a few thousand outputs (the layers of the CartPole-sized configurations) is a latency chain: on 256 x 64
+    // tiles it is ONE workgroup walking K in 16-deep steps, a memory latency each (9-11 us for 256 x 64 x 64).  64 x 64
+    // tiles with 64-deep steps: several workgroups, and K <= 64 arrives with one round of loads.
+    rc = launch3_or<64, 64, 2, 2, 3, 64>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
+  } else
   if (use_bf16x3() && d->a_absmax && d->b_absmax && use_f16x2() && g.vec_a && g.vec_b && d->M > 64 && d->N > 64 && d->K >= 64) {
     // the caller knows both operands' ranges: two f16 pieces per operand, three products (gemm_bf16x3.h, NP == 2)
     rc = launch3_or<128, 128, 2, 2, 2>(st, g, d->a_kmajor, d->b_kmajor, nsplit);

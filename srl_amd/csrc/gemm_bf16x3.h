@@ -273,9 +273,11 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm
   store3<SA, BM, AKM, KB, NT, NP>(sa.r, lds, sc_a);
   store3<SB, BN, BKM, KB, NT, NP>(sb.r, lds + TA::BYTES, sc_b);
   __syncthreads();
-  if (!PAIR && knext >= 0) {
-    sa.load(g.a, m0, g.M, knext, kend, true);
-    sb.load(g.b, n0, g.N, knext, kend, true);
+  if (!PAIR) {  // the second tile -- or, for a product of a single k-step, an out-of-range tile: zeros (the step's staging is
+    // unconditional, and the fused column sums would count the first tile twice if it were still in the registers)
+    const long kn = knext >= 0 ? knext : kend;
+    sa.load(g.a, m0, g.M, kn, kend, true);
+    sb.load(g.b, n0, g.N, kn, kend, true);
   }
 
   // one k-step on LDS buffer `cur`: per 16-deep k-block, fragments of the three planes of both operands and the six

@@ -1162,3 +1162,34 @@ def test_conv2d_more_than_2_gib():
     ref = a[M - 512:].double() @ wd.double().t()
     assert rel_close(out[M - 512:].cpu().numpy(), ref.cpu().numpy(), 1e-5, scale=float(ref.abs().max()))
     assert not torch.isnan(out).any()
+
+
+@pytest.mark.parametrize("M,N,K,akm,bkm,split,extra", [
+    (256, 64, 64, 0, 0, 1, "bias"), (256, 64, 4 * 3, 0, 0, 1, "bias"), (100, 64, 64, 0, 1, 1, "acc"),
+    (64, 64, 256, 1, 1, 4, "colsum"), (64, 64, 100, 1, 1, 1, "colsum"), (64, 8, 32, 1, 1, 1, "colsum"),
+    (8, 64, 12, 1, 1, 1, "colsum"), (1000, 8, 64, 1, 1, 1, "colsum"), (40, 128, 512, 1, 0, 2, "acc")])
+def test_gemm_small_products(M, N, K, akm, bkm, split, extra):
+    """Products of at most 65 536 outputs and K <= 512 (the layers of the CartPole-sized configurations) take 64 x 64 tiles
+    with 64-deep k-steps (gemm.hip): every orientation, a K shorter than one step, fused column sums of a single-step product
+    (whose first tile must not be counted twice), split-K -- against float64."""
+    rng = np.random.default_rng(M + N + K)
+    A = dev(rng.standard_normal((K, M) if akm else (M, K)).astype(np.float32))
+    B = dev(rng.standard_normal((K, N) if bkm else (N, K)).astype(np.float32))
+    C0 = dev(rng.standard_normal((M, N)).astype(np.float32))
+    C = C0.clone()
+    bias = dev(rng.standard_normal(N).astype(np.float32))
+    cs0 = dev(rng.standard_normal(M).astype(np.float32))
+    cs = cs0.clone()
+    ws = torch.empty(split * M * N, device=DEV) if split > 1 else None
+    hip.dispatch_counts(reset=True)
+    hip.gemm(M, N, K, A.data_ptr(), A.shape[1], akm, B.data_ptr(), B.shape[1], bkm, C.data_ptr(), N, split_k=split,
+             workspace=None if ws is None else ws.data_ptr(), accumulate=extra in ("acc", "colsum"),
+             bias=bias.data_ptr() if extra == "bias" else None, act=1 if extra == "bias" else 0,
+             a_colsum=cs.data_ptr() if extra == "colsum" else None)
+    assert hip.dispatch_counts()["gemm3"] == 1
+    Ad = A.double().T if akm else A.double()
+    ref = Ad @ (B.double() if bkm else B.double().T)
+    ref = torch.relu(ref + bias.double()) if extra == "bias" else ref + C0.double()
+    assert rel_close(C.cpu().numpy(), ref.cpu().numpy(), 1e-5, scale=float(np.sqrt(K)))
+    if extra == "colsum":
+        assert rel_close(cs.cpu().numpy(), (cs0.double() + Ad.sum(1)).cpu().numpy(), 1e-5, scale=float(np.sqrt(K)))
