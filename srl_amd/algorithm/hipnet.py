@@ -82,12 +82,11 @@ class Workspace:
 
 
 def _split_for(rows: int, tiles: int) -> int:
-    """split-K factor for weight gradients: enough workgroups to fill 256 CUs, >= 512 rows each.  A few hundred rows (the
-    CartPole-sized configurations) still go 8 ways: ONE workgroup walking 16 k-steps pays a full memory latency per step
-    (29 us for a 64 x 64 x 256 product, the longest kernel of that step; 8 slices of 2 steps + the slab sum: 8 us)."""
+    """split-K factor for weight gradients: enough workgroups to fill 256 CUs, >= 512 rows each.  (A few hundred rows -- the
+    CartPole-sized configurations -- stay in one piece: srl_gemm's small-product path walks them in 64-deep steps; on the
+    general tiles ONE workgroup walking 16-deep steps took 29 us for a 64 x 64 x 256 product, the longest kernel of that
+    step.)"""
     want = max(1, 512 // max(tiles, 1))
-    if rows < 1024:
-        return int(max(1, min(8, rows // 64)))
     return int(max(1, min(want, rows // 512)))
 
 

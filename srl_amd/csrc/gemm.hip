@@ -96,7 +96,7 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
                 "the data-gradient one (0, 1)");
   int rc;
   if (nsplit == 1) g.out_absmax = d->out_absmax;
-  if (use_bf16x3() && small_gemm() && g.vec_a && g.vec_b && d->M * d->N <= 65536 && d->K >= 8 && d->K <= 512) {
+  if (use_bf16x3() && small_gemm() && g.vec_a && g.vec_b && d->M * d->N <= 65536 && d->K >= 4 && d->K <= 512) {
     // A product of a few thousand outputs (the layers of the CartPole-sized configurations) is a latency chain: on 256 x 64
     // tiles it is ONE workgroup walking K in 16-deep steps, a memory latency each (9-11 us for 256 x 64 x 64).  64 x 64
     // tiles with 64-deep steps: several workgroups, and K <= 64 arrives with one round of loads.

@@ -496,7 +496,7 @@ def gemm(M, N, K, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, bias=None, act=ACT
     d = GemmDesc(M, N, K, A, lda, int(a_kmajor), B, ldb, int(b_kmajor), C, ldc, bias, int(act), dact_src, ld_dact,
                  int(dact), int(accumulate), int(split_k), workspace, a_colsum, a_absmax, b_absmax, out_absmax,
                  mask_out, dact_mask)
-    small = M * N <= 65536 and 8 <= K <= 512 and os.environ.get("SRL_SMALL_GEMM", "1")[:1] != "0"  # 64 x 64 tiles, three bf16 pieces
+    small = M * N <= 65536 and 4 <= K <= 512 and os.environ.get("SRL_SMALL_GEMM", "1")[:1] != "0"  # 64 x 64 tiles, three bf16 pieces
     two = (a_absmax is not None and b_absmax is not None and M > 64 and N > 64 and K >= 64 and A % 16 == 0 and B % 16 == 0 and
            lda % 4 == 0 and ldb % 4 == 0 and f16x2_enabled() and not small)  # mirrors gemm.hip's choice of the two-plane f16 kernel
     with _scope("gemm", 2.0 * M * N * K, "2h" if two else "x3"):
