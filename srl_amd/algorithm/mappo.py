@@ -636,23 +636,24 @@ class MultiAgentPPO(PytorchTrainer):
             two = (self.pipelines >= 2 and nchunks >= 2 and rnn is None and dscal is None and not net.force_explicit_conv)
             nets, streams = [net], [torch.cuda.current_stream()]
             if two:
-                if self._twin is None:
-                    self._twin = net.twin()
-                    self._pipe_stream = torch.cuda.Stream(device=dev)
-                twin = self._twin
-                twin.flat, twin.popart_state = net.flat, net.popart_state  # (re-bound by a checkpoint load)
+                npipe = min(self.pipelines, nchunks)
+                if self._twin is None or len(self._twin) != npipe - 1:
+                    self._twin = [net.twin() for _ in range(npipe - 1)]
+                    self._pipe_stream = [torch.cuda.Stream(device=dev) for _ in range(npipe - 1)]
                 # the weight-range slots are shared: they are recomputed here, before the fork.  Before the very first
-                # forward pass the layers that want one are not known yet: the second pipeline then starts after the first
+                # forward pass the layers that want one are not known yet: the other pipelines then start after the first
                 # chunk, which discovers and fills them
                 first_sync = not net._wamax_slot
                 net.refresh_weight_ranges()
-                twin.zero_grad()
-                if stats_work is not None:  # the global advantage statistics: needed by both pipelines
+                if stats_work is not None:  # the global advantage statistics: needed by every pipeline
                     stats_work.join() if stats_work is self._comm else stats_work.wait()
                     stats_work = None
-                self._pipe_stream.wait_stream(streams[0])
-                nets.append(twin)
-                streams.append(self._pipe_stream)
+                for twin, pst in zip(self._twin, self._pipe_stream):
+                    twin.flat, twin.popart_state = net.flat, net.popart_state  # (re-bound by a checkpoint load)
+                    twin.zero_grad()
+                    pst.wait_stream(streams[0])
+                    nets.append(twin)
+                    streams.append(pst)
             for ci in range(nchunks):
                 r0, r1 = ci * chunk_rows, min(n_valid, (ci + 1) * chunk_rows)
                 n = r1 - r0
@@ -682,10 +683,12 @@ class MultiAgentPPO(PytorchTrainer):
                     d_ls = self.policy.dist_bwd(logits, f_action[r0:r1], c_avail, d_lp, d_ent, d_logits, net=cnet)
                     cnet.backward(d_logits, d_v.view(n, Nc), d_ls)
                 if two and ci == 0 and first_sync:
-                    streams[1].wait_stream(streams[0])
+                    for pst in streams[1:]:
+                        pst.wait_stream(streams[0])
             if two:
-                streams[0].wait_stream(self._pipe_stream)
-                hip.accumulate(net.grad, self._twin.grad)
+                for twin, pst in zip(self._twin, self._pipe_stream):
+                    streams[0].wait_stream(pst)
+                    hip.accumulate(net.grad, twin.grad)
 
             # ---- gradient reduction, clip, Adam (mappo.py:272-284) ---------------------------------------------------
             if reducer is not None:  # the buckets not yet launched, then wait for all of them
