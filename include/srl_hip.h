@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 7
+#define SRL_HIP_ABI_VERSION 8
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -440,6 +440,27 @@ int srl_ring_slots(void* stream, const int64_t* refs, int64_t n, int64_t capacit
  * Replaces clip_grad_norm_ / get_grad_norm + torch.optim.Adam/AdamW.step
  * (mappo.py:278-284, modules/utils.py:268-295).
  */
+/* A whole small MLP chain in one launch per direction (csrc/mlp_small.hip): LayerNorm / Linear (+ ReLU / tanh) layers no
+ * wider than 128 -- the nn.Sequential of modules/utils.py:154-161 and the heads of actor_critic_policy.py:92-107 for the
+ * CartPole-sized configurations, whose update is otherwise a chain of ~40 kernels of 3-10 us.  Layer i's input width must be
+ * layer i-1's output width.  srl_mlp_fwd: y = chain(x), and every layer's input (layers 1..n-1) is left in `tape`
+ * ([rows, tape_ld], tape_ld >= srl_mlp_tape_floats) for srl_mlp_bwd, which adds the parameter gradients of every layer into
+ * gw / gb (float atomics across 16-row workgroups) given dy = d loss / d y.  The gradient w.r.t. x is not formed. */
+#define SRL_MLP_MAX_LAYERS 12
+typedef struct srl_mlp_layer {
+  int32_t kind;       /* 0: LayerNorm over `in` (w = gamma, b = beta, eps 1e-5); 1: Linear, w [out, in] row-major, b [out] */
+  int32_t in, out;    /* widths, 1..128 (LayerNorm: out ignored) */
+  int32_t act;        /* Linear: 0 none, 1 relu, 2 tanh, applied after the bias */
+  const float* w;
+  const float* b;
+  float* gw;          /* gradients (srl_mlp_bwd): same shapes as w / b, accumulated into */
+  float* gb;
+} srl_mlp_layer;
+int64_t srl_mlp_tape_floats(const srl_mlp_layer* layers, int n); /* floats per tape row; -1: chain not supported */
+int srl_mlp_fwd(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows, float* tape,
+                int64_t tape_ld, float* y, int64_t ldy);
+int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows,
+                const float* tape, int64_t tape_ld, const float* dy, int64_t lddy);
 /* sumsq[0] = sum g^2 in float64 (zeroed first).  With data parallelism the caller all-reduces the
  * gradients before this call (DDP semantics), so no further reduction is needed. */
 int srl_grad_sumsq(void* stream, const float* g, int64_t n, double* sumsq);

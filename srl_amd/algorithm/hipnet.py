@@ -123,6 +123,10 @@ class HipNet:
         self._wgrad_side = os.environ.get("SRL_WGRAD_STREAM", "1") != "0"
         # ReLU derivatives from sign-bit masks written by the producing convolution (SRL_RELU_MASK=0: from its floats)
         self._relu_masks = os.environ.get("SRL_RELU_MASK", "1") != "0"
+        # small MLP chains (every layer LayerNorm / Linear, no wider than 128) in one launch per direction (csrc/mlp_small.hip);
+        # SRL_MLP_FUSED=0: layer by layer (A/B)
+        self._mlp_fused = os.environ.get("SRL_MLP_FUSED", "1") != "0"
+        self._mlp_cache = {}
         self._side_stream = None
         self._side_used = False
         # SRL_EXPLICIT_CONV=1 forces the im2col + GEMM + col2im fallback (kept for geometries the implicit
@@ -898,6 +902,57 @@ class HipNet:
                 # weight gradients on the second stream
         self.grad_ready_hook = hook
 
+    # ------------------------------------------------------------------ small MLP chains in one launch per direction
+    def _fused_fwd(self, tag, encoders, backbone, head, obs, n: int, out: Optional[torch.Tensor] = None):
+        """The trunk (one vector-observation encoder + backbone) -- and, when ``head`` is given, the head behind it -- as ONE
+        launch if every layer is a LayerNorm or a Linear no wider than 128 (``hip.mlp_fwd``).  Returns a record for
+        ``_fused_bwd`` (``feat`` = the chain's output as a Buf, ``act`` = the activation that produced it) or None."""
+        if not self._mlp_fused or self._rnn is not None or self.spec.num_rnn_layers or len(encoders) != 1 or n > (1 << 16):
+            return None
+        enc = encoders[0]
+        x = obs.get(enc.key) if isinstance(obs, dict) else None
+        layers = list(enc.layers) + list(backbone) + ([head] if head is not None else [])
+        if isinstance(x, RingObs) and x.layout[0] != "s2d" and x.rows == n:  # raw vector rows kept in the HBM observation ring
+            x = x.gather_raw(self.ws, f"{tag}{enc.key}.ring")
+        if (not isinstance(x, torch.Tensor) or x.dtype != torch.float32 or x.dim() != 2 or x.shape[0] != n or
+                not x.is_contiguous() or not layers or len(layers) > hip.MLP_MAX_LAYERS):
+            return None
+        for L in layers:
+            if isinstance(L, ns.LayerNormSpec):
+                ok = L.dim <= hip.MLP_MAX_WIDTH
+            elif isinstance(L, ns.LinearSpec):
+                ok = max(L.in_features, L.out_features) <= hip.MLP_MAX_WIDTH
+            else:
+                ok = False
+            if not ok:
+                return None
+        key = (tag, head is not None, self.flat.data_ptr(), self.grad.data_ptr())
+        ent = self._mlp_cache.get(key)
+        if ent is None:
+            desc = []
+            for L in layers:
+                w, b = f"{L.prefix}.weight", f"{L.prefix}.bias"
+                if isinstance(L, ns.LayerNormSpec):
+                    desc.append((0, L.dim, L.dim, 0, self._p(w), self._p(b), self._g(w), self._g(b)))
+                else:
+                    desc.append((1, L.in_features, L.out_features, L.act, self._p(w), self._p(b), self._g(w), self._g(b)))
+            arr = hip.mlp_layers(desc)
+            tld = hip.mlp_tape_floats(arr)
+            if tld < 0 or desc[0][1] != x.shape[1]:
+                return None
+            last = layers[-1]
+            ent = self._mlp_cache[key] = (arr, tld, last.out_features if isinstance(last, ns.LinearSpec) else last.dim,
+                                          last.act if isinstance(last, ns.LinearSpec) else 0)
+        arr, tld, width, act = ent
+        tape = self.ws.get(f"{tag}mlp.tape", n * tld)
+        y = out if out is not None else self.ws.get(f"{tag}mlp.y", n * width)
+        hip.mlp_fwd(arr, x.data_ptr(), x.shape[1], n, tape.data_ptr(), tld, y.data_ptr(), width)
+        return dict(arr=arr, x=x, tape=tape, tld=tld, n=n, feat=Buf(y.data_ptr(), width, n, width), act=act,
+                    head=head is not None)
+
+    def _fused_bwd(self, rec, dy_ptr: int, lddy: int):
+        hip.mlp_bwd(rec["arr"], rec["x"].data_ptr(), rec["x"].shape[1], rec["n"], rec["tape"].data_ptr(), rec["tld"], dy_ptr, lddy)
+
     # ------------------------------------------------------------------ public: forward / backward
     def forward(self, obs: Dict[str, torch.Tensor], n: int, keep_tape: bool = True, rnn: Optional[RnnCtx] = None):
         """obs leaves [n, ...] on the device.  Returns (logits [n, sum(A)], value [n, value_dim]) tensors
@@ -910,18 +965,32 @@ class HipNet:
         self.last_state = {}
         if sp.num_rnn_layers and (rnn is None or rnn.T * rnn.B != n):
             raise hip.HipError("recurrent backbone: `rnn` context missing or inconsistent with the row count")
-        a_feat, a_act, a_tape = self._trunk_fwd("a:", sp.obs_encoders, sp.actor_backbone, obs, n)
-        if sp.shared_backbone:
-            c_feat, c_act, c_tape = a_feat, a_act, None
-        else:
-            c_feat, c_act, c_tape = self._trunk_fwd("c:", sp.state_encoders, sp.critic_backbone, obs, n)
         atot = sum(sp.act_dims)
         logits_t = self.ws.get("logits", n * atot)
         value_t = self.ws.get("value", n * sp.value_dim)
-        hip.gemm(n, atot, sp.hidden_dim, a_feat.ptr, a_feat.ld, 0, self._p(f"{sp.actor_head.prefix}.weight"), sp.hidden_dim, 0,
-                 logits_t.data_ptr(), atot, bias=self._p(f"{sp.actor_head.prefix}.bias"))
-        hip.gemm(n, sp.value_dim, sp.hidden_dim, c_feat.ptr, c_feat.ld, 0, self._p(f"{sp.critic_head.prefix}.weight"), sp.hidden_dim,
-                 0, value_t.data_ptr(), sp.value_dim, bias=self._p(f"{sp.critic_head.prefix}.bias"))
+        # CartPole-sized nets: trunk + head of a separate actor / critic as one launch each (trunk only when the heads share it)
+        heads_in = not sp.shared_backbone and sp.std_type != "shared_learnable"
+        fa = self._fused_fwd("a:", sp.obs_encoders, sp.actor_backbone, sp.actor_head if heads_in else None, obs, n,
+                             out=logits_t if heads_in else None)
+        if fa is not None:
+            a_feat, a_act, a_tape = fa["feat"], fa["act"], fa
+        else:
+            a_feat, a_act, a_tape = self._trunk_fwd("a:", sp.obs_encoders, sp.actor_backbone, obs, n)
+        if sp.shared_backbone:
+            c_feat, c_act, c_tape = a_feat, a_act, None
+        else:
+            fc = self._fused_fwd("c:", sp.state_encoders, sp.critic_backbone, sp.critic_head if heads_in else None, obs, n,
+                                 out=value_t if heads_in else None)
+            if fc is not None:
+                c_feat, c_act, c_tape = fc["feat"], fc["act"], fc
+            else:
+                c_feat, c_act, c_tape = self._trunk_fwd("c:", sp.state_encoders, sp.critic_backbone, obs, n)
+        if not (isinstance(a_tape, dict) and a_tape["head"]):
+            hip.gemm(n, atot, sp.hidden_dim, a_feat.ptr, a_feat.ld, 0, self._p(f"{sp.actor_head.prefix}.weight"), sp.hidden_dim, 0,
+                     logits_t.data_ptr(), atot, bias=self._p(f"{sp.actor_head.prefix}.bias"))
+        if not (isinstance(c_tape, dict) and c_tape["head"]):
+            hip.gemm(n, sp.value_dim, sp.hidden_dim, c_feat.ptr, c_feat.ld, 0, self._p(f"{sp.critic_head.prefix}.weight"),
+                     sp.hidden_dim, 0, value_t.data_ptr(), sp.value_dim, bias=self._p(f"{sp.critic_head.prefix}.bias"))
         self.log_std_rows = None
         if sp.std_type == "shared_learnable":  # log sigma from a second head on the actor features (:93, :131-132)
             ls_t = self.ws.get("log_std_rows", n * atot)
@@ -942,7 +1011,9 @@ class HipNet:
         atot = sum(sp.act_dims)
         dl = Buf(d_logits.data_ptr(), atot, n, atot)
         dv = Buf(d_value.data_ptr(), sp.value_dim, n, sp.value_dim)
-        da = self._linear_bwd(sp.actor_head, a_feat, dl, a_act, True, "a:")
+        a_head_in = isinstance(a_tape, dict) and a_tape["head"]
+        c_head_in = isinstance(c_tape, dict) and c_tape["head"]
+        da = None if a_head_in else self._linear_bwd(sp.actor_head, a_feat, dl, a_act, True, "a:")
         if sp.std_type == "shared_learnable":
             dls = Buf(d_log_std_rows.data_ptr(), atot, n, atot)
             self._linear_bwd(ns.LinearSpec("log_std", sp.hidden_dim, atot, 0), a_feat, dls, a_act, True, "a:", dx_into=da,
@@ -951,16 +1022,24 @@ class HipNet:
                 self.grad_ready_hook(["log_std"])
         if self.grad_ready_hook is not None and sp.shared_backbone:
             self.grad_ready_hook([sp.actor_head.prefix])
+
+        def trunk_bwd(tag, tape, dfeat, dhead):  # fused chains: one launch (their layers' gradients are final after it;
+            # the bucket reducer's finish() launches whatever no hook announced)
+            if isinstance(tape, dict):
+                self._fused_bwd(tape, dhead.ptr if tape["head"] else dfeat.ptr, dhead.ld if tape["head"] else dfeat.ld)
+            else:
+                self._trunk_bwd(tag, tape, dfeat)
+
         if sp.shared_backbone:
             self._linear_bwd(sp.critic_head, c_feat, dv, c_act, True, "a:", dx_into=da, dx_accumulate=True)
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook([sp.critic_head.prefix])
-            self._trunk_bwd("a:", a_tape, da)
+            trunk_bwd("a:", a_tape, da, dl)
         else:
-            dc = self._linear_bwd(sp.critic_head, c_feat, dv, c_act, True, "c:")
-            if self.grad_ready_hook is not None:
+            dc = None if c_head_in else self._linear_bwd(sp.critic_head, c_feat, dv, c_act, True, "c:")
+            if self.grad_ready_hook is not None and not (a_head_in or c_head_in):
                 self.grad_ready_hook([sp.actor_head.prefix, sp.critic_head.prefix])
-            self._trunk_bwd("a:", a_tape, da)
-            self._trunk_bwd("c:", c_tape, dc)
+            trunk_bwd("a:", a_tape, da, dl)
+            trunk_bwd("c:", c_tape, dc, dv)
         self._join_side()
         self._tape = None

@@ -1,0 +1,286 @@
+// A whole small MLP chain -- LayerNorm / Linear (+ ReLU / tanh) layers no wider than 128 -- in ONE launch forward and ONE launch
+// backward (srl_mlp_fwd / srl_mlp_bwd).
+//
+// The CartPole-sized configurations (BASELINE configs[0]: 8 envs x 32 steps, separate 2 x 64 MLPs) are not launch-bound behind
+// the captured graph any more; they are LATENCY-bound: 38 kernels of 3-10 us, each a chain of one or two dependent trips to
+// memory for a few kilobytes of work.  Here a workgroup takes 16 rows through every layer: the rows live in LDS, a layer's
+// weights are staged into LDS once per workgroup (they are L2-resident: every workgroup reads the same 16 KB), and the only
+// global traffic besides x and y is the tape -- every layer's input, which the backward pass reads back.  The backward pass
+// walks the same rows through the layers in reverse: weight / bias / LayerNorm-affine gradients are summed over the
+// workgroup's 16 rows and added to the gradient buffer with atomics, the data gradient stays in LDS.
+// Arithmetic: plain float32 FMAs (the layers are far too small for the matrix cores to matter), sums in a fixed order
+// inside a workgroup; across workgroups the atomics' order is not fixed, like the LayerNorm backward kernels' already.
+// Reference: the nn.Sequential of modules/utils.py:154-161 (mlp: LayerNorm -> Linear -> activation ...) and the heads of
+// actor_critic_policy.py:92-107, as one kernel per direction.
+#include "srl_common.h"
+
+#include "../../include/srl_hip.h"
+
+namespace {
+
+constexpr int kRB = 16;     // rows per workgroup (16 lanes per row)
+constexpr int kMaxD = 128;  // widest layer
+constexpr int kLd = kMaxD + 1;
+constexpr float kLnEps = 1e-5f;  // nn.LayerNorm default
+
+struct Layer {
+  int kind, in, out, act;  // kind 0: LayerNorm over `in` (w = gamma, b = beta); 1: Linear [out][in] (+ act: 1 relu, 2 tanh)
+  const float* w;
+  const float* b;
+  float* gw;
+  float* gb;
+  int toff;  // offset of this layer's INPUT inside a tape row (layer 0 reads x itself)
+};
+
+struct Args {
+  Layer L[SRL_MLP_MAX_LAYERS];
+  int n;
+  const float* x;
+  long ldx, rows;
+  float* tape;
+  long tld;
+  float* y;
+  long ldy;
+  const float* dy;
+  long lddy;
+};
+
+__device__ __forceinline__ float sum16(float v) {
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+  return v;
+}
+__device__ __forceinline__ float act_fwd(float v, int act) { return act == 1 ? fmaxf(v, 0.f) : (act == 2 ? tanhf(v) : v); }
+// derivative of the activation from its OUTPUT value
+__device__ __forceinline__ float act_der(float y, int act) { return act == 1 ? (y > 0.f ? 1.f : 0.f) : (act == 2 ? 1.f - y * y : 1.f); }
+
+// out[r][c + 16 j] = bias + sum_k cur[r][k] * Wt[k][c + 16 j], JN column groups per lane
+template <int JN>
+__device__ __forceinline__ void linear_rows(const float (*cur)[kLd], const float* Wt, const Layer& L, int r, int c, float* res) {
+  float acc[JN];
+#pragma unroll
+  for (int j = 0; j < JN; ++j) acc[j] = (L.b && c + 16 * j < L.out) ? L.b[c + 16 * j] : 0.f;
+  for (int k = 0; k < L.in; ++k) {
+    const float xv = cur[r][k];
+#pragma unroll
+    for (int j = 0; j < JN; ++j) acc[j] = fmaf(xv, Wt[k * kLd + c + 16 * j], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < JN; ++j) res[j] = acc[j];
+}
+
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(Args a) {
+  __shared__ float cur[kRB][kLd];
+  __shared__ float Wt[kMaxD * kLd];  // a Linear's weights, transposed: Wt[k][o]
+  const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+  const long row = (long)blockIdx.x * kRB + r;
+  const bool rok = row < a.rows;
+  for (int k = c; k < a.L[0].in; k += 16) cur[r][k] = rok ? a.x[row * a.ldx + k] : 0.f;
+  int dim = a.L[0].in;
+  for (int i = 0; i < a.n; ++i) {
+    const Layer L = a.L[i];
+    if (L.kind == 0) {  // the row's 16 lanes sit in one wavefront: LDS reads and writes of a row need no barrier
+      float s = 0.f;
+      for (int k = c; k < L.in; k += 16) s += cur[r][k];
+      const float mean = sum16(s) / (float)L.in;
+      float q = 0.f;
+      for (int k = c; k < L.in; k += 16) {
+        const float d = cur[r][k] - mean;
+        q = fmaf(d, d, q);
+      }
+      const float rstd = rsqrtf(sum16(q) / (float)L.in + kLnEps);
+      for (int k = c; k < L.in; k += 16) cur[r][k] = (cur[r][k] - mean) * rstd * L.w[k] + L.b[k];
+      dim = L.in;
+    } else {
+      __syncthreads();  // the previous Linear's readers of Wt are done
+      for (int e = tid; e < L.out * L.in; e += 256) {
+        const int o = e / L.in, k = e - o * L.in;
+        Wt[k * kLd + o] = L.w[e];
+      }
+      __syncthreads();
+      float res[8];
+      const int jn = (L.out + 15) >> 4;
+      if (jn <= 1) linear_rows<1>(cur, Wt, L, r, c, res);
+      else if (jn <= 2) linear_rows<2>(cur, Wt, L, r, c, res);
+      else if (jn <= 4) linear_rows<4>(cur, Wt, L, r, c, res);
+      else linear_rows<8>(cur, Wt, L, r, c, res);
+      // every lane of the row has finished reading cur[r][*] (same wavefront, program order): overwrite it
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < jn && c + 16 * j < L.out) cur[r][c + 16 * j] = act_fwd(res[j], L.act);
+      dim = L.out;
+    }
+    if (i + 1 < a.n && rok)  // this layer's output = the next layer's input: what the backward pass reads back
+      for (int k = c; k < dim; k += 16) a.tape[row * a.tld + a.L[i + 1].toff + k] = cur[r][k];
+  }
+  if (rok)
+    for (int k = c; k < dim; k += 16) a.y[row * a.ldy + k] = cur[r][k];
+}
+
+template <int JN>
+__device__ __forceinline__ void dgrad_rows(const float (*g)[kLd], const float* Ws, const Layer& L, int r, int c, float* res) {
+  float acc[JN];
+#pragma unroll
+  for (int j = 0; j < JN; ++j) acc[j] = 0.f;
+  for (int o = 0; o < L.out; ++o) {
+    const float gv = g[r][o];
+#pragma unroll
+    for (int j = 0; j < JN; ++j) acc[j] = fmaf(gv, Ws[o * kLd + c + 16 * j], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < JN; ++j) res[j] = acc[j];
+}
+
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(Args a) {
+  __shared__ float g[kRB][kLd];    // gradient w.r.t. the current layer's (pre-activation) output
+  __shared__ float xin[kRB][kLd];  // the current layer's input
+  __shared__ float Ws[kMaxD * kLd];  // a Linear's weights Ws[o][k]; scratch of the LayerNorm's affine gradients
+  const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+  const long row = (long)blockIdx.x * kRB + r;
+  const bool rok = row < a.rows;
+  {
+    const Layer& last = a.L[a.n - 1];
+    const int dout = last.kind == 1 ? last.out : last.in;
+    for (int k = c; k < dout; k += 16) g[r][k] = rok ? a.dy[row * a.lddy + k] : 0.f;
+  }
+  for (int i = a.n - 1; i >= 0; --i) {
+    const Layer L = a.L[i];
+    for (int k = c; k < L.in; k += 16)
+      xin[r][k] = rok ? (i == 0 ? a.x[row * a.ldx + k] : a.tape[row * a.tld + L.toff + k]) : 0.f;
+    // the activation that produced this input: its derivative (from the input's value) closes the data gradient
+    const int pact = (i > 0 && a.L[i - 1].kind == 1) ? a.L[i - 1].act : 0;
+    if (L.kind == 1) {
+      __syncthreads();  // g and xin of every row are in LDS; Ws is free
+      for (int e = tid; e < L.out * L.in; e += 256) {
+        const int o = e / L.in, k = e - o * L.in;
+        Ws[o * kLd + k] = L.w[e];
+      }
+      // weight and bias gradients of the workgroup's rows (rows past the end carry zeros)
+      for (int e = tid; e < L.out * L.in; e += 256) {
+        const int o = e / L.in, k = e - o * L.in;
+        float s = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < kRB; ++rr) s = fmaf(g[rr][o], xin[rr][k], s);
+        atomicAdd(L.gw + e, s);
+      }
+      if (tid < L.out && L.gb) {
+        float s = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < kRB; ++rr) s += g[rr][tid];
+        atomicAdd(L.gb + tid, s);
+      }
+      __syncthreads();  // Ws staged; every reader of g is done
+      if (i > 0) {
+        float res[8];
+        const int jn = (L.in + 15) >> 4;
+        if (jn <= 1) dgrad_rows<1>(g, Ws, L, r, c, res);
+        else if (jn <= 2) dgrad_rows<2>(g, Ws, L, r, c, res);
+        else if (jn <= 4) dgrad_rows<4>(g, Ws, L, r, c, res);
+        else dgrad_rows<8>(g, Ws, L, r, c, res);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < jn && c + 16 * j < L.in) g[r][c + 16 * j] = res[j] * act_der(xin[r][c + 16 * j], pact);
+      }
+    } else {
+      // LayerNorm: statistics recomputed from the input (cheaper than a trip to memory)
+      float s = 0.f;
+      for (int k = c; k < L.in; k += 16) s += xin[r][k];
+      const float mean = sum16(s) / (float)L.in;
+      float q = 0.f;
+      for (int k = c; k < L.in; k += 16) {
+        const float d = xin[r][k] - mean;
+        q = fmaf(d, d, q);
+      }
+      const float rstd = rsqrtf(sum16(q) / (float)L.in + kLnEps);
+      __syncthreads();  // Ws (scratch) is free
+      float m1 = 0.f, m2 = 0.f;
+      for (int k = c; k < L.in; k += 16) {
+        const float xh = (xin[r][k] - mean) * rstd, gy = g[r][k], gg = gy * L.w[k];
+        Ws[r * kLd + k] = gy * xh;
+        Ws[(kRB + r) * kLd + k] = gy;
+        m1 += gg;
+        m2 = fmaf(gg, xh, m2);
+      }
+      m1 = sum16(m1) / (float)L.in;
+      m2 = sum16(m2) / (float)L.in;
+      __syncthreads();
+      if (tid < L.in) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < kRB; ++rr) {
+          s1 += Ws[rr * kLd + tid];
+          s2 += Ws[(kRB + rr) * kLd + tid];
+        }
+        atomicAdd(L.gw + tid, s1);
+        atomicAdd(L.gb + tid, s2);
+      }
+      if (i > 0)
+        for (int k = c; k < L.in; k += 16) {
+          const float xh = (xin[r][k] - mean) * rstd;
+          g[r][k] = rstd * (g[r][k] * L.w[k] - m1 - xh * m2) * act_der(xin[r][k], pact);
+        }
+    }
+  }
+}
+
+int fill(Args& a, const srl_mlp_layer* layers, int n) {
+  if (!layers || n < 1 || n > SRL_MLP_MAX_LAYERS) return -1;
+  int dim = layers[0].in, toff = 0;
+  for (int i = 0; i < n; ++i) {
+    const srl_mlp_layer& s = layers[i];
+    if (s.kind != 0 && s.kind != 1) return -1;
+    if (s.in != dim || s.in < 1 || s.in > kMaxD || !s.w) return -1;
+    if (s.kind == 1 && (s.out < 1 || s.out > kMaxD || s.act < 0 || s.act > 2)) return -1;
+    if (s.kind == 0 && !s.b) return -1;
+    Layer& L = a.L[i];
+    L.kind = s.kind; L.in = s.in; L.out = s.kind == 1 ? s.out : s.in; L.act = s.kind == 1 ? s.act : 0;
+    L.w = s.w; L.b = s.b; L.gw = s.gw; L.gb = s.gb;
+    L.toff = toff;
+    if (i > 0) toff += s.in;  // layer 0 reads x
+    else toff = 0;
+    dim = L.out;
+  }
+  // tape rows: the inputs of layers 1 .. n-1
+  toff = 0;
+  for (int i = 1; i < n; ++i) {
+    a.L[i].toff = toff;
+    toff += a.L[i].in;
+  }
+  a.n = n;
+  return toff;
+}
+
+}  // namespace
+
+extern "C" int64_t srl_mlp_tape_floats(const srl_mlp_layer* layers, int n) {
+  Args a{};
+  const int t = fill(a, layers, n);
+  return t < 0 ? -1 : (t > 0 ? t : 1);
+}
+
+extern "C" int srl_mlp_fwd(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows,
+                           float* tape, int64_t tape_ld, float* y, int64_t ldy) {
+  Args a{};
+  const int t = fill(a, layers, n);
+  SRL_CHECK_ARG(t >= 0, "unsupported chain (LayerNorm / Linear layers, widths 1..128, at most SRL_MLP_MAX_LAYERS)");
+  SRL_CHECK_ARG(x && y && (n == 1 || tape) && tape_ld >= t && rows >= 0, "null tensor / short tape rows");
+  if (rows == 0) return 0;
+  a.x = x; a.ldx = ldx; a.rows = rows; a.tape = tape; a.tld = tape_ld; a.y = y; a.ldy = ldy;
+  hipLaunchKernelGGL(mlp_fwd_kernel, dim3((unsigned)srl_ceil_div(rows, (long)kRB)), dim3(256), 0, (hipStream_t)stream, a);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows,
+                           const float* tape, int64_t tape_ld, const float* dy, int64_t lddy) {
+  Args a{};
+  const int t = fill(a, layers, n);
+  SRL_CHECK_ARG(t >= 0, "unsupported chain");
+  SRL_CHECK_ARG(x && dy && (n == 1 || tape) && tape_ld >= t && rows >= 0, "null tensor / short tape rows");
+  for (int i = 0; i < n; ++i) SRL_CHECK_ARG(a.L[i].gw && (a.L[i].gb || (a.L[i].kind == 1 && !a.L[i].b)), "null gradient");
+  if (rows == 0) return 0;
+  a.x = x; a.ldx = ldx; a.rows = rows; a.tape = const_cast<float*>(tape); a.tld = tape_ld; a.dy = dy; a.lddy = lddy;
+  hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)srl_ceil_div(rows, (long)kRB)), dim3(256), 0, (hipStream_t)stream, a);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}

@@ -25,7 +25,7 @@ _lib = None
 # (bench.py does, before its imports) -- INTEGRATION.md lists it with the other switches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -54,6 +54,11 @@ class GemmDesc(Structure):
                 ("mask_out", c_void_p), ("dact_mask", c_void_p)]
 
 
+class MlpLayer(Structure):
+    _fields_ = [("kind", c_int32), ("in_", c_int32), ("out", c_int32), ("act", c_int32), ("w", c_void_p), ("b", c_void_p),
+                ("gw", c_void_p), ("gb", c_void_p)]
+
+
 class ConvDesc(Structure):
     _fields_ = [("n", c_int64), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("KH", c_int32), ("KW", c_int32),
                 ("stride", c_int32), ("Cout", c_int32), ("act", c_int32)]
@@ -66,6 +71,9 @@ _SIGNATURES = {
     "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD] + [c_void_p] * 9),
     "srl_conv2d_fwd_workspace": (c_int64, [_CD]),
     "srl_absmax": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "srl_mlp_tape_floats": (c_int64, [POINTER(MlpLayer), c_int]),
+    "srl_mlp_fwd": (c_int, [c_void_p, POINTER(MlpLayer), c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
+    "srl_mlp_bwd": (c_int, [c_void_p, POINTER(MlpLayer), c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     "srl_conv2d_wgrad_workspace": (c_int64, [_CD]),
     "srl_conv2d_nhwc_wgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_conv2d_dgrad_weight_elems": (c_int64, [_CD]),
@@ -255,6 +263,8 @@ def piece_products(kind: str = "x3") -> float:
     """Matrix-core products issued per algorithmic multiply-add by the kernel family that takes a call: 6 for float32
     operands as three bf16 pieces each (``x3``), 3 for two f16 pieces each (``2h``) and for the byte-operand first layer
     (``obs``), 1 for the float32 MFMA kernels (SRL_MFMA=f32 / SRL_OBS_BF16=0)."""
+    if kind == "f32":  # plain float32 FMA kernels (csrc/mlp_small.hip)
+        return 1.0
     if kind == "obs":
         return 1.0 if os.environ.get("SRL_OBS_BF16", "")[:1] == "0" else 3.0
     if os.environ.get("SRL_MFMA", "")[:1] == "f":
@@ -727,6 +737,34 @@ def conv2d_nhwc_fwd(d: ConvDesc, x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax=None, w
     with _scope("conv_fwd", _conv_flops(d), "2h" if two else "x3"):
         _check(lib().srl_conv2d_nhwc_fwd(_stream(), ctypes.byref(d), x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax, w_absmax,
                                          y_absmax, y_mask, ws_ptr), "srl_conv2d_nhwc_fwd")
+
+
+MLP_MAX_LAYERS, MLP_MAX_WIDTH = 12, 128
+
+
+def mlp_layers(layers):
+    """ctypes array of srl_mlp_layer from (kind, in, out, act, w, b, gw, gb) tuples (raw pointers; gw / gb may be None for a
+    forward-only chain)."""
+    arr = (MlpLayer * len(layers))()
+    for i, (kind, n_in, n_out, act, w, b, gw, gb) in enumerate(layers):
+        arr[i] = MlpLayer(int(kind), int(n_in), int(n_out), int(act), w, b, gw, gb)
+    return arr
+
+
+def mlp_tape_floats(arr) -> int:
+    return int(lib().srl_mlp_tape_floats(arr, len(arr)))
+
+
+def mlp_fwd(arr, x_ptr, ldx, rows, tape_ptr, tape_ld, y_ptr, ldy):
+    flops = 2.0 * rows * sum(l.in_ * l.out for l in arr if l.kind == 1)
+    with _scope("mlp_fwd", flops, "f32"):
+        _check(lib().srl_mlp_fwd(_stream(), arr, len(arr), x_ptr, ldx, rows, tape_ptr, tape_ld, y_ptr, ldy), "srl_mlp_fwd")
+
+
+def mlp_bwd(arr, x_ptr, ldx, rows, tape_ptr, tape_ld, dy_ptr, lddy):
+    flops = 4.0 * rows * sum(l.in_ * l.out for l in arr if l.kind == 1)
+    with _scope("mlp_bwd", flops, "f32"):
+        _check(lib().srl_mlp_bwd(_stream(), arr, len(arr), x_ptr, ldx, rows, tape_ptr, tape_ld, dy_ptr, lddy), "srl_mlp_bwd")
 
 
 def absmax(x_ptr, n, out_ptr):

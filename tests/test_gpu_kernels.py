@@ -1193,3 +1193,49 @@ def test_gemm_small_products(M, N, K, akm, bkm, split, extra):
     assert rel_close(C.cpu().numpy(), ref.cpu().numpy(), 1e-5, scale=float(np.sqrt(K)))
     if extra == "colsum":
         assert rel_close(cs.cpu().numpy(), (cs0.double() + Ad.sum(1)).cpu().numpy(), 1e-5, scale=float(np.sqrt(K)))
+
+
+@pytest.mark.parametrize("rows,dims,acts", [(256, (4, 64, 64, 2), (1, 1, 0)), (37, (10, 128, 33, 1), (2, 2, 0)),
+                                            (1000, (48, 64, 9), (1, 0))])
+def test_mlp_chain_fused(rows, dims, acts):
+    """srl_mlp_fwd / srl_mlp_bwd (csrc/mlp_small.hip): LayerNorm -> Linear (+ activation) chains as one launch per direction,
+    against float64 autograd: outputs, every parameter gradient, ragged row counts, widths that are not multiples of 16."""
+    rng = np.random.default_rng(rows)
+    t = torch
+    x = t.from_numpy(rng.standard_normal((rows, dims[0])).astype(np.float32))
+    params, layers64 = [], []
+    for i in range(len(dims) - 1):  # LayerNorm(d_i) -> Linear(d_i, d_{i+1}) + act
+        g = t.from_numpy((1 + 0.1 * rng.standard_normal(dims[i])).astype(np.float32))
+        b = t.from_numpy((0.1 * rng.standard_normal(dims[i])).astype(np.float32))
+        w = t.from_numpy((rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32))
+        wb = t.from_numpy((0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32))
+        params += [g, b, w, wb]
+    dev_p = [p_.to(DEV) for p_ in params]
+    dev_g = [t.zeros_like(p_) + 0.5 for p_ in dev_p]  # gradients are accumulated into
+    desc = []
+    for i in range(len(dims) - 1):
+        g, b, w, wb = dev_p[4 * i:4 * i + 4]
+        gg, gb, gw, gwb = dev_g[4 * i:4 * i + 4]
+        desc.append((0, dims[i], dims[i], 0, g.data_ptr(), b.data_ptr(), gg.data_ptr(), gb.data_ptr()))
+        desc.append((1, dims[i], dims[i + 1], acts[i], w.data_ptr(), wb.data_ptr(), gw.data_ptr(), gwb.data_ptr()))
+    arr = hip.mlp_layers(desc)
+    tld = hip.mlp_tape_floats(arr)
+    assert tld == sum(dims[:-1]) + sum(dims[1:-1])
+    dx = x.to(DEV)
+    tape = t.full((rows, tld), float("nan"), device=DEV)
+    y = t.full((rows, dims[-1]), float("nan"), device=DEV)
+    hip.mlp_fwd(arr, dx.data_ptr(), dims[0], rows, tape.data_ptr(), tld, y.data_ptr(), dims[-1])
+    p64 = [p_.double().requires_grad_(True) for p_ in params]
+    h = x.double()
+    for i in range(len(dims) - 1):
+        g, b, w, wb = p64[4 * i:4 * i + 4]
+        h = t.nn.functional.layer_norm(h, (dims[i],), g, b, 1e-5)
+        h = h @ w.t() + wb
+        h = t.relu(h) if acts[i] == 1 else (t.tanh(h) if acts[i] == 2 else h)
+    assert rel_close(y.cpu().numpy(), h.detach().numpy(), 1e-5, scale=1.0)
+    dy = t.from_numpy(rng.standard_normal((rows, dims[-1])).astype(np.float32))
+    h.backward(dy.double())
+    ddy = dy.to(DEV)
+    hip.mlp_bwd(arr, dx.data_ptr(), dims[0], rows, tape.data_ptr(), tld, ddy.data_ptr(), dims[-1])
+    for got, ref, name in zip(dev_g, p64, [f"{k}{i}" for i in range(len(dims) - 1) for k in ("gamma", "beta", "w", "b")]):
+        assert rel_close(got.cpu().numpy() - 0.5, ref.grad.numpy(), 2e-5, scale=float(ref.grad.abs().max()) + 1e-6), name

@@ -439,8 +439,10 @@ def test_device_resident_sample_matches_host_sample():
     host = synthetic.to_sample_batch(arrays)
     devs = synthetic.to_sample_batch({k: torch.from_numpy(v).to("cuda:0") for k, v in arrays.items()})
     ra, rb = a.step(host), b.step(devs)
-    for k in ("policy_loss", "value_loss", "grad_norm"):
+    for k in ("policy_loss", "value_loss"):  # the same forward pass
         assert ra.stats[k] == rb.stats[k]
+    # gradients: the fused small-MLP backward adds its 16-row partial sums with float atomics (order not fixed run to run)
+    assert abs(ra.stats["grad_norm"] - rb.stats["grad_norm"]) <= 1e-6 * abs(ra.stats["grad_norm"])
     assert isinstance(devs.analyzed_result.adv, torch.Tensor)
 
 
