@@ -303,7 +303,9 @@ int srl_layernorm_fwd(void* stream, const float* x, int64_t ldx, const float* ga
  * dgamma/dbeta += column sums (float32 atomics). dx may be NULL (input leaf). */
 int srl_layernorm_bwd(void* stream, const float* dy, int64_t lddy, const float* x, int64_t ldx,
                       const float* gamma, const float* mean, const float* rstd, int64_t rows, int D,
-                      float* dx, int64_t lddx, int dact, float* dgamma, float* dbeta);
+                      float* dx, int64_t lddx, int dact, float* dgamma, float* dbeta, float* dx_absmax);
+/* dx_absmax (or NULL; needs a dense dx, lddx == D): *dx_absmax = max(*dx_absmax, max |dx|) -- the range of the data gradient
+ * for the two-piece products of the layer below, from the same pass (srl_gemm_desc's out_absmax). */
 
 /* Whole-observation LayerNorm statistics for image observations [n, D] (D = C*H*W), uint8 or
  * float32 (policies/utils.py:53: nn.LayerNorm(v) over the full (C,H,W) shape). */

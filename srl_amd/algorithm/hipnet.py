@@ -371,12 +371,13 @@ class HipNet:
                           y.ld, mean.data_ptr(), rstd.data_ptr())
         return y, (mean, rstd)
 
-    def _ln_bwd(self, L: ns.LayerNormSpec, x: Buf, saved, dy: Buf, in_act: int, need_dx: bool, tag: str):
+    def _ln_bwd(self, L: ns.LayerNormSpec, x: Buf, saved, dy: Buf, in_act: int, need_dx: bool, tag: str, dx_range=None):
+        """``dx_range``: device float the data gradient's range is folded into (for the two-piece products of the layer below)."""
         mean, rstd = saved
         dx = self._buf(f"{tag}{L.prefix}.dx", x.rows, L.dim) if need_dx else None
         hip.layernorm_bwd(dy.ptr, dy.ld, x.ptr, x.ld, self._p(f"{L.prefix}.weight"), mean.data_ptr(), rstd.data_ptr(),
                           x.rows, L.dim, dx.ptr if dx else None, dx.ld if dx else 0, in_act,
-                          self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"))
+                          self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"), dx_absmax=dx_range if dx else None)
         return dx
 
     # ------------------------------------------------------------------ recurrent layers (GRU + auto reset)
@@ -540,6 +541,9 @@ class HipNet:
                 if cur is None:
                     if obs.dtype != torch.float32:
                         raise hip.HipError(f"vector observation `{enc.key}` must be float32, got {obs.dtype}")
+                    if obs.shape[0] != n or math.prod(obs.shape[1:]) != L.dim:
+                        raise hip.HipError(f"vector observation `{enc.key}`: sample rows of shape {tuple(obs.shape[1:])} for a "
+                                           f"network built for ({L.dim},) ({n} rows expected, {obs.shape[0]} given)")
                     cur = Buf(obs.data_ptr(), L.dim, n, L.dim)
                 y, saved = self._ln_fwd(L, cur, tag)
                 tape.append(("ln", L, cur, saved, cur_act))
@@ -553,6 +557,11 @@ class HipNet:
                 cur, cur_act, cur_range = y, L.act, None
             elif isinstance(L, ns.ObsLayerNormSpec):
                 pending_obs_ln = L
+                if isinstance(obs, torch.Tensor) and (obs.dim() < 2 or obs.shape[0] != n or
+                                                      math.prod(obs.shape[1:]) != math.prod(L.shape)):
+                    # the kernels take sizes from the network's spec: a sample of another shape must not reach them
+                    raise hip.HipError(f"image observation `{enc.key}`: sample rows of shape {tuple(obs.shape[1:])} "
+                                       f"for a network built for {tuple(L.shape)} ({n} rows expected, {obs.shape[0]} given)")
                 if L.explicit:  # written out once, channels-last float32; the convolutions then see a plain activation
                     c, h, w = L.shape
                     is_u8 = obs.dtype == torch.uint8
@@ -689,8 +698,13 @@ class HipNet:
             kind, L, x, saved, in_act = records[idx]
             need_dx = idx > 0 or need_input_grad
             if kind == "ln":
-                g = self._ln_bwd(L, x, saved, g, in_act, need_dx, tag)
-                g_range = None
+                # the layer below wants its gradient's range (a Linear whose input's range the forward pass tracked): the
+                # LayerNorm's backward folds it in while it writes dx, instead of one more pass over dx
+                below = records[idx - 1] if idx > 0 else None
+                want = need_dx and below is not None and below[0] == "linear" and below[3] is not None
+                dxr = self._grad_range() if want else None
+                g = self._ln_bwd(L, x, saved, g, in_act, need_dx, tag, dx_range=dxr)
+                g_range = dxr
             elif kind == "linear":
                 x_range = saved  # the forward pass's range of this layer's input (a convolution's output), or None
                 if x_range is not None and g_range is None and g.ld == g.cols:

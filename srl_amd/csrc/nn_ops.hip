@@ -158,8 +158,10 @@ constexpr int LN_MAXV = 16;  // supports D <= 1024 in the register path
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, long lddy, const float* x, long ldx,
                                                             const float* gamma, const float* mean, const float* rstd,
                                                             long rows, int D, float* dx, long lddx, int dact,
-                                                            float* dgamma, float* dbeta, long rows_per_block) {
+                                                            float* dgamma, float* dbeta, long rows_per_block,
+                                                            float* dx_absmax) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float amx = 0.f;  // max |dx| of this wavefront's rows (dx_absmax: the range of the consumer's operand at no extra pass)
   float pg[LN_MAXV], pb[LN_MAXV];
 #pragma unroll
   for (int v = 0; v < LN_MAXV; ++v) pg[v] = pb[v] = 0.f;
@@ -194,8 +196,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, lon
           float o = rs * (dyr[j] * gamma[j] - m1 - xh * m2);
           if (dact) o *= act_grad_from_output(xv, dact);  // x is the activation output that fed this LayerNorm
           dxr[j] = o;
+          amx = fmaxf(amx, fabsf(o));
         }
       }
+    }
+  }
+  if (dx_absmax) {  // the slot only grows: load first, atomic only when this wavefront has something to add (gemm_core.h)
+    amx = wave_allmax(amx);
+    if (lane == 0 && amx > 0.f) {
+      unsigned int* d = reinterpret_cast<unsigned int*>(dx_absmax);
+      if (__float_as_uint(amx) > __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d, __float_as_uint(amx));
     }
   }
   // combine the 4 wavefronts through LDS, then one atomic per column per workgroup
@@ -477,9 +487,24 @@ extern "C" int srl_layernorm_fwd(void* stream, const float* x, int64_t ldx, cons
   return 0;
 }
 
+static int layernorm_bwd_impl(void* stream, const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                              const float* mean, const float* rstd, int64_t rows, int D, float* dx, int64_t lddx, int dact,
+                              float* dgamma, float* dbeta, float* dx_absmax, int* tracked);
+
 extern "C" int srl_layernorm_bwd(void* stream, const float* dy, int64_t lddy, const float* x, int64_t ldx,
                                  const float* gamma, const float* mean, const float* rstd, int64_t rows, int D,
-                                 float* dx, int64_t lddx, int dact, float* dgamma, float* dbeta) {
+                                 float* dx, int64_t lddx, int dact, float* dgamma, float* dbeta, float* dx_absmax) {
+  SRL_CHECK_ARG(!dx_absmax || (dx && lddx == D), "dx_absmax: a dense dx");
+  int tracked = 0;
+  const int rc = layernorm_bwd_impl(stream, dy, lddy, x, ldx, gamma, mean, rstd, rows, D, dx, lddx, dact, dgamma, dbeta,
+                                    dx_absmax, &tracked);
+  if (rc != 0 || !dx_absmax || tracked || rows == 0) return rc;
+  return srl_absmax(stream, dx, rows * (int64_t)D, dx_absmax);  // the narrow / wide kernels do not track: one pass over dx
+}
+
+static int layernorm_bwd_impl(void* stream, const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                              const float* mean, const float* rstd, int64_t rows, int D, float* dx, int64_t lddx, int dact,
+                              float* dgamma, float* dbeta, float* dx_absmax, int* tracked) {
   SRL_CHECK_ARG(dy && x && gamma && mean && rstd && dgamma && dbeta, "null tensor");
   SRL_CHECK_ARG(D >= 1, "LayerNorm width must be positive");
   if (rows == 0) return 0;
@@ -521,7 +546,8 @@ extern "C" int srl_layernorm_bwd(void* stream, const float* dy, int64_t lddy, co
     return 0;
   }
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)srl_ceil_div(rows, rpb)), dim3(256), 0, (hipStream_t)stream,
-                     dy, lddy, x, ldx, gamma, mean, rstd, rows, D, dx, lddx, dact, dgamma, dbeta, rpb);
+                     dy, lddy, x, ldx, gamma, mean, rstd, rows, D, dx, lddx, dact, dgamma, dbeta, rpb, dx_absmax);
+  *tracked = 1;
   SRL_LAUNCH_CHECK();
   return 0;
 }

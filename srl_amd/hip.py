@@ -127,7 +127,7 @@ _SIGNATURES = {
     "srl_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
                                    c_void_p, c_void_p]),
     "srl_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
-                                   c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+                                   c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "srl_obs_ln_stats": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "srl_im2col_obs_ln": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64] +
                           [c_int] * 6 + [c_void_p]),
@@ -527,10 +527,10 @@ def layernorm_fwd(x_ptr, ldx, gamma_ptr, beta_ptr, rows, D, y_ptr, ldy, mean_ptr
 
 
 def layernorm_bwd(dy_ptr, lddy, x_ptr, ldx, gamma_ptr, mean_ptr, rstd_ptr, rows, D, dx_ptr, lddx, dact, dgamma_ptr,
-                  dbeta_ptr):
+                  dbeta_ptr, dx_absmax=None):
     _check(
         lib().srl_layernorm_bwd(_stream(), dy_ptr, lddy, x_ptr, ldx, gamma_ptr, mean_ptr, rstd_ptr, rows, D, dx_ptr,
-                                lddx, int(dact), dgamma_ptr, dbeta_ptr), "srl_layernorm_bwd")
+                                lddx, int(dact), dgamma_ptr, dbeta_ptr, dx_absmax), "srl_layernorm_bwd")
 
 
 def obs_ln_stats(obs_ptr, is_u8, n, D, mean_ptr, rstd_ptr):

@@ -521,8 +521,10 @@ def test_layernorm_fwd_bwd(rows, D):
     dxo = torch.empty((rows, D), device=DEV)
     dgo = torch.zeros(D, device=DEV)
     dbo = torch.zeros(D, device=DEV)
+    amax = torch.zeros(1, device=DEV)  # the data gradient's range from the same pass (whichever kernel takes the shape)
     hip.layernorm_bwd(ddy.data_ptr(), D, dx_.data_ptr(), D, dg_.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D,
-                      dxo.data_ptr(), D, 1, dgo.data_ptr(), dbo.data_ptr())
+                      dxo.data_ptr(), D, 1, dgo.data_ptr(), dbo.data_ptr(), dx_absmax=amax.data_ptr())
+    assert float(amax) == float(dxo.abs().max())
     assert rel_close(dxo.cpu().numpy(), tx.grad.numpy(), 2e-5, scale=1.0)
     assert rel_close(dgo.cpu().numpy(), tg.grad.numpy(), 2e-5, scale=float(np.sqrt(rows)))
     assert rel_close(dbo.cpu().numpy(), tb.grad.numpy(), 2e-5, scale=float(np.sqrt(rows)))

@@ -637,3 +637,16 @@ def test_float32_frames_and_mixed_observation_keys_vs_oracle():
     for k in sd:
         d = np.abs(sd[k].numpy() - osd[k].numpy())
         assert d.max() <= 1e-3 and np.mean(d > 1e-6) < 2e-3, (k, d.max())
+
+
+def test_sample_of_another_shape_is_refused_not_read():
+    """The kernels take sizes from the network's spec: observations of another shape must raise, not fault."""
+    from srl_amd import hip
+    tr = make_trainer(CNN_POLICY, dict(ATARI_TRAINER))
+    arrays = synthetic.make_sample_arrays(seed=1, T=3, B=2, obs_spec={"obs": ((4, 42, 42), "u8")}, action_dims=6)
+    with pytest.raises(hip.HipError, match="image observation"):
+        tr.step(synthetic.to_sample_batch(arrays))
+    tv = make_trainer(C1_POLICY, dict(popart=False))
+    arrays = synthetic.make_sample_arrays(seed=1, T=3, B=2, obs_spec={"obs": ((6,), "f32")}, action_dims=2)
+    with pytest.raises(hip.HipError, match="vector observation|chain"):
+        tv.step(synthetic.to_sample_batch(arrays))
