@@ -405,7 +405,9 @@ int srl_conv2d_obs_row_index_supported(const srl_conv_desc* d, int is_u8, int ch
 int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
                        const float* bias, float* y, float* workspace, const int32_t* row_index, float* y_absmax,
-                       uint32_t* y_mask);
+                       uint32_t* y_mask, int reuse_folded);
+/* reuse_folded != 0: `workspace` still holds the folded weights of the previous call with the SAME w / bias / gamma / beta
+ * and geometry (the chunks of one update): the folding kernel is skipped. */
 /* *out = max(*out, max_i |x[i]|) (atomic: several calls may fold into one slot; the caller zeroes it): the range of a
  * weight tensor for the two-plane f16 products, once per parameter update. */
 int srl_absmax(void* stream, const float* x, int64_t n, float* out);

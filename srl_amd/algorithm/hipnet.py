@@ -127,6 +127,10 @@ class HipNet:
         # SRL_MLP_FUSED=0: layer by layer (A/B)
         self._mlp_fused = os.environ.get("SRL_MLP_FUSED", "1") != "0"
         self._mlp_cache = {}
+        self._pver = [0]    # parameter version, shared with the twins (a list: one object)
+        self._in_update = [False]
+        self._derived_on = os.environ.get("SRL_DERIVED_CACHE", "1") != "0"  # 0: recompute for every chunk (A/B)
+        self._derived = {}  # per executor: what its workspace holds that was derived from which parameter version
         self._side_stream = None
         self._side_used = False
         # SRL_EXPLICIT_CONV=1 forces the im2col + GEMM + col2im fallback (kept for geometries the implicit
@@ -217,8 +221,28 @@ class HipNet:
     RANGE_SLOTS = 1024  # tracked activations / gradients per pass (a piece-wise encoder pass of a deep tower uses dozens)
 
     def params_changed(self):
-        """The trainer / a checkpoint load / a broadcast rewrote ``flat``: cached per-layer weight ranges are stale."""
+        """The trainer / a checkpoint load / a broadcast rewrote ``flat``: cached per-layer weight ranges are stale, and so is
+        everything derived from the weights that an executor keeps between chunks (``_derived_fresh``)."""
         self._wamax_stale = set(self._wamax_slot)
+        self._pver[0] += 1
+
+    def _derived_fresh(self, what: str, ptr: int) -> bool:
+        """Whether this executor's buffer ``ptr`` still holds ``what`` (weights regrouped for a data gradient, the first layer's
+        folded weights) computed from the CURRENT parameters: those depend on the weights only, yet were recomputed for every
+        chunk of an update (160 + 32 launches of 5-22 us).  Marks it fresh for the caller, who recomputes on False."""
+        if not self._in_update[0] or not self._derived_on:  # only between the chunks of one trainer update (``chunks_of_one_update``): anybody else
+            self._derived.pop(what, None)  # may have rewritten ``flat`` without saying so
+            return False
+        key, val = what, (ptr, self._pver[0], self.flat.data_ptr())
+        if self._derived.get(key) == val:
+            return True
+        self._derived[key] = val
+        return False
+
+    def chunks_of_one_update(self, on: bool):
+        """The trainer brackets the chunk loop of one update with this: inside it the parameters do not change, so what an
+        executor derived from them for the first chunk serves the following ones."""
+        self._in_update[0] = bool(on)
 
     def refresh_weight_ranges(self):
         """Recompute every stale weight range now, on the current stream (before two row-chunk pipelines that share the
@@ -238,6 +262,7 @@ class HipNet:
         t.grad_ready_hook = None
         t._amax_next = t._gmax_next = -1
         t._side_stream, t._side_used = None, False
+        t._derived = {}
         return t
 
     def _weight_range(self, prefix: str, numel: int) -> int:
@@ -661,10 +686,11 @@ class HipNet:
                             hip.obs_ln_stats(obs.data_ptr(), is_u8, n, c * h * w, mean.data_ptr(), rstd.data_ptr())
                     y_range = self._act_range() if implicit else None
                     if implicit:
+                        fws = self.ws.get(f"{L.prefix}.folded", hip.conv2d_obs_fwd_workspace(desc)).data_ptr()
                         hip.conv2d_obs_fwd(desc, src.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet,
                                            self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"), y.ptr,
                                            channels_last=bool(L.s2d), row_index=row_index, y_absmax=y_range, y_mask=y.mask,
-                                           ws_ptr=self.ws.get("conv_obs_fwd", hip.conv2d_obs_fwd_workspace(desc)).data_ptr())
+                                           ws_ptr=fws, reuse_folded=self._derived_fresh(f"{L.prefix}.folded:{desc.n >= 64}:{desc.n >= 32}", fws))
                     else:
                         hip.im2col_obs_ln(obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), gam, bet, n, c, h, w,
                                           L.k, L.k, L.stride, P.ptr)
@@ -774,7 +800,8 @@ class HipNet:
                                       gr=g_range if two and x_range is not None else None: hip.conv2d_nhwc_wgrad(
                                           d, xp, gp, gw, wgrad_ws, gb, x_absmax=xr, dz_absmax=gr))
                         wt = self.ws.get(f"{L.prefix}.wt", hip.conv2d_dgrad_weight_elems(desc))
-                        hip.conv2d_dgrad_repack(desc, wp, wt.data_ptr())
+                        if not self._derived_fresh(f"{L.prefix}.wt", wt.data_ptr()):  # once per update, not per chunk
+                            hip.conv2d_dgrad_repack(desc, wp, wt.data_ptr())
                         h, w = L.in_hw[0] + 2 * L.pad, L.in_hw[1] + 2 * L.pad
                         dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.cin)
                         dx_range = self._grad_range() if two else None

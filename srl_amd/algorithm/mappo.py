@@ -654,6 +654,7 @@ class MultiAgentPPO(PytorchTrainer):
                     pst.wait_stream(streams[0])
                     nets.append(twin)
                     streams.append(pst)
+            net.chunks_of_one_update(True)
             for ci in range(nchunks):
                 r0, r1 = ci * chunk_rows, min(n_valid, (ci + 1) * chunk_rows)
                 n = r1 - r0
@@ -685,6 +686,7 @@ class MultiAgentPPO(PytorchTrainer):
                 if two and ci == 0 and first_sync:
                     for pst in streams[1:]:
                         pst.wait_stream(streams[0])
+            net.chunks_of_one_update(False)
             if two:
                 for twin, pst in zip(self._twin, self._pipe_stream):
                     streams[0].wait_stream(pst)

@@ -634,7 +634,7 @@ extern "C" int srl_conv2d_obs_row_index_supported(const srl_conv_desc* d, int is
 static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                               const float* mean, const float* rstd, const float* gamma, const float* beta,
                               const float* w, const float* bias, float* y, float* workspace, const int32_t* row_index,
-                              float* y_absmax, uint32_t* y_mask) {
+                              float* y_absmax, uint32_t* y_mask, int reuse_folded) {
   SRL_CHECK_ARG(!y_mask || (d->act == 1 && d->Cout % 32 == 0), "y_mask: ReLU layers with Cout a multiple of 32");
   SRL_CHECK_ARG(row_index == nullptr || (workspace && srl_conv2d_obs_row_index_supported(d, is_u8, channels_last)),
                 "row_index is served by the byte kernels only (srl_conv2d_obs_row_index_supported)");
@@ -661,8 +661,9 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
     float* S = workspace + ((long)P * 3 * d->Cout * Kp) / 2;
     float* b2 = S + (long)P * d->Cout;
     const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, 1};
-    hipLaunchKernelGGL(srlobs::obs_fold_split_kernel<ObsIndex>, dim3((unsigned)(P * d->Cout)), dim3(256), 0, st, w, bias, gamma,
-                       beta, P, (int)Kp, ix, wq, S, b2);
+    if (!reuse_folded)
+      hipLaunchKernelGGL(srlobs::obs_fold_split_kernel<ObsIndex>, dim3((unsigned)(P * d->Cout)), dim3(256), 0, st, w, bias, gamma,
+                         beta, P, (int)Kp, ix, wq, S, b2);
     srlobs::FwdArgs a{};
     a.g = obs_geom(d, obs, mean, rstd, OW, row_index);
     a.wq = reinterpret_cast<const uint4*>(wq);
@@ -692,8 +693,9 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
     float* wg = workspace;
     float* b2 = wg + (long)P * d->Cout * Kp;
     const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, channels_last ? 1 : 0};
-    hipLaunchKernelGGL(obs_fold_affine_kernel, dim3((unsigned)(P * d->Cout)), dim3(256), 0, st, w, bias, gamma, beta, P,
-                       d->Cout, ix, wg, b2);
+    if (!reuse_folded)
+      hipLaunchKernelGGL(obs_fold_affine_kernel, dim3((unsigned)(P * d->Cout)), dim3(256), 0, st, w, bias, gamma, beta, P,
+                         d->Cout, ix, wg, b2);
     g.M = d->n; g.N = d->Cout;
     g.a = obs_patch_src(obs, is_u8, mean, rstd, nullptr, nullptr, d, 1, 1, channels_last);  // rows = samples
     g.a.brw = OW;
@@ -729,7 +731,7 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
 extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
                                   const float* w, const float* bias, float* y, float* workspace, const int32_t* row_index,
-                                  float* y_absmax, uint32_t* y_mask) {
+                                  float* y_absmax, uint32_t* y_mask, int reuse_folded) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1),
                 "unsupported geometry (planar: KW, W, stride, H*W multiples of 4; channels-last: Cin multiple of 4)");
   const long run = images_per_launch(d, is_u8 ? 1 : 4);
@@ -742,7 +744,8 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
     const long adv = row_index ? 0 : i0;
     const int rc = conv2d_obs_fwd_run(stream, &s, static_cast<const uint8_t*>(obs) + adv * in_b, is_u8, channels_last, mean + adv,
                                       rstd + adv, gamma, beta, w, bias, y + i0 * out_e, workspace,
-                                      row_index ? row_index + i0 : nullptr, y_absmax, y_mask ? y_mask + i0 * out_e / 32 : nullptr);
+                                      row_index ? row_index + i0 : nullptr, y_absmax, y_mask ? y_mask + i0 * out_e / 32 : nullptr,
+                                      reuse_folded || i0 > 0);
     if (rc != 0) return rc;
   }
   return 0;

@@ -79,7 +79,7 @@ _SIGNATURES = {
     "srl_conv2d_dgrad_weight_elems": (c_int64, [_CD]),
     "srl_conv2d_dgrad_repack": (c_int, [c_void_p, _CD, c_void_p, c_void_p]),
     "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 5),
-    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 11),
+    "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 11 + [c_int]),
     "srl_conv2d_obs_row_index_supported": (c_int, [_CD, c_int, c_int]),
     "srl_conv2d_obs_fwd_workspace": (c_int64, [_CD]),
     "srl_obs_space_to_depth": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
@@ -810,12 +810,14 @@ def conv2d_obs_row_index_supported(d: ConvDesc, is_u8, channels_last) -> bool:
 
 
 def conv2d_obs_fwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr,
-                   channels_last=False, ws_ptr=None, row_index: Optional[torch.Tensor] = None, y_absmax=None, y_mask=None):
+                   channels_last=False, ws_ptr=None, row_index: Optional[torch.Tensor] = None, y_absmax=None, y_mask=None,
+                   reuse_folded=False):
     with _scope("conv_obs_fwd", _conv_flops(d), "obs"):
         _check(
             lib().srl_conv2d_obs_fwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), int(channels_last), mean_ptr,
                                      rstd_ptr, gamma_ptr, beta_ptr, w_ptr, bias_ptr, y_ptr, ws_ptr,
-                                     _ptr(row_index, torch.int32, "row_index"), y_absmax, y_mask), "srl_conv2d_obs_fwd")
+                                     _ptr(row_index, torch.int32, "row_index"), y_absmax, y_mask, int(bool(reuse_folded))),
+            "srl_conv2d_obs_fwd")
 
 
 def obs_space_to_depth(obs_ptr, is_u8, n, C, H, W, s, out_ptr, mean_ptr, rstd_ptr):
