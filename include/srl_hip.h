@@ -461,6 +461,10 @@ typedef struct srl_mlp_layer {
   float* gb;
 } srl_mlp_layer;
 int64_t srl_mlp_tape_floats(const srl_mlp_layer* layers, int n); /* floats per tape row; -1: chain not supported */
+/* rows up to which the pair is worth taking over the layer-by-layer kernels (measured): 32768 when the chain's parameter
+ * gradients (<= 12288 floats) are summed in LDS over a workgroup's row blocks, 8192 when every 16-row block has to add its
+ * sums with float atomics; 0: not supported */
+int64_t srl_mlp_bwd_max_rows(const srl_mlp_layer* layers, int n);
 int srl_mlp_fwd(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows, float* tape,
                 int64_t tape_ld, float* y, int64_t ldy);
 int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows,

@@ -948,7 +948,7 @@ class HipNet:
         """The trunk (one vector-observation encoder + backbone) -- and, when ``head`` is given, the head behind it -- as ONE
         launch if every layer is a LayerNorm or a Linear no wider than 128 (``hip.mlp_fwd``).  Returns a record for
         ``_fused_bwd`` (``feat`` = the chain's output as a Buf, ``act`` = the activation that produced it) or None."""
-        if not self._mlp_fused or self._rnn is not None or self.spec.num_rnn_layers or len(encoders) != 1 or n > (1 << 16):
+        if not self._mlp_fused or self._rnn is not None or self.spec.num_rnn_layers or len(encoders) != 1:
             return None
         enc = encoders[0]
         x = obs.get(enc.key) if isinstance(obs, dict) else None
@@ -983,8 +983,10 @@ class HipNet:
                 return None
             last = layers[-1]
             ent = self._mlp_cache[key] = (arr, tld, last.out_features if isinstance(last, ns.LinearSpec) else last.dim,
-                                          last.act if isinstance(last, ns.LinearSpec) else 0)
-        arr, tld, width, act = ent
+                                          last.act if isinstance(last, ns.LinearSpec) else 0, hip.mlp_bwd_max_rows(arr))
+        arr, tld, width, act, max_rows = ent
+        if n > max_rows:
+            return None
         tape = self.ws.get(f"{tag}mlp.tape", n * tld)
         y = out if out is not None else self.ws.get(f"{tag}mlp.y", n * width)
         hip.mlp_fwd(arr, x.data_ptr(), x.shape[1], n, tape.data_ptr(), tld, y.data_ptr(), width)

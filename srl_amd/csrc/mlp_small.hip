@@ -22,6 +22,8 @@ constexpr int kRB = 16;     // rows per workgroup (16 lanes per row)
 constexpr int kMaxD = 128;  // widest layer
 constexpr int kLd = kMaxD + 1;
 constexpr float kLnEps = 1e-5f;  // nn.LayerNorm default
+constexpr int kMaxP = 12288;     // parameter-gradient floats a backward workgroup can keep in LDS (48 KB)
+constexpr int kBwdGroups = 512;  // backward workgroups at most: each walks its 16-row blocks and flushes its sums once
 
 struct Layer {
   int kind, in, out, act;  // kind 0: LayerNorm over `in` (w = gamma, b = beta); 1: Linear [out][in] (+ act: 1 relu, 2 tanh)
@@ -30,6 +32,7 @@ struct Layer {
   float* gw;
   float* gb;
   int toff;  // offset of this layer's INPUT inside a tape row (layer 0 reads x itself)
+  int pw, pb;  // offsets of this layer's weight / bias gradient sums in the backward kernel's LDS accumulator
 };
 
 struct Args {
@@ -43,6 +46,7 @@ struct Args {
   long ldy;
   const float* dy;
   long lddy;
+  int lds_acc;  // backward: parameter gradients summed in LDS over the workgroup's row blocks (they fit: <= kMaxP floats)
 };
 
 __device__ __forceinline__ float sum16(float v) {
@@ -60,6 +64,8 @@ __device__ __forceinline__ void linear_rows(const float (*cur)[kLd], const float
   float acc[JN];
 #pragma unroll
   for (int j = 0; j < JN; ++j) acc[j] = (L.b && c + 16 * j < L.out) ? L.b[c + 16 * j] : 0.f;
+  // (unrolled: with one or two workgroups per CU nothing else hides the LDS latency of a 5-read iteration)
+#pragma unroll 8
   for (int k = 0; k < L.in; ++k) {
     const float xv = cur[r][k];
 #pragma unroll
@@ -122,6 +128,7 @@ __device__ __forceinline__ void dgrad_rows(const float (*g)[kLd], const float* W
   float acc[JN];
 #pragma unroll
   for (int j = 0; j < JN; ++j) acc[j] = 0.f;
+#pragma unroll 8
   for (int o = 0; o < L.out; ++o) {
     const float gv = g[r][o];
 #pragma unroll
@@ -135,92 +142,121 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(Args a) {
   __shared__ float g[kRB][kLd];    // gradient w.r.t. the current layer's (pre-activation) output
   __shared__ float xin[kRB][kLd];  // the current layer's input
   __shared__ float Ws[kMaxD * kLd];  // a Linear's weights Ws[o][k]; scratch of the LayerNorm's affine gradients
+  // Parameter-gradient sums of this workgroup over ALL its row blocks: an element is always touched by the same thread, so
+  // no barrier guards it, and it reaches the gradient buffer with ONE atomic per workgroup at the end.  (Atomics per 16-row
+  // block were fine for 256 rows and a wall at 65 536: 35 M float atomics, 1.25 ms against 1.03 layer by layer.)
+  __shared__ float pacc[kMaxP];
   const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
-  const long row = (long)blockIdx.x * kRB + r;
-  const bool rok = row < a.rows;
-  {
-    const Layer& last = a.L[a.n - 1];
-    const int dout = last.kind == 1 ? last.out : last.in;
-    for (int k = c; k < dout; k += 16) g[r][k] = rok ? a.dy[row * a.lddy + k] : 0.f;
-  }
-  for (int i = a.n - 1; i >= 0; --i) {
-    const Layer L = a.L[i];
-    for (int k = c; k < L.in; k += 16)
-      xin[r][k] = rok ? (i == 0 ? a.x[row * a.ldx + k] : a.tape[row * a.tld + L.toff + k]) : 0.f;
-    // the activation that produced this input: its derivative (from the input's value) closes the data gradient
-    const int pact = (i > 0 && a.L[i - 1].kind == 1) ? a.L[i - 1].act : 0;
-    if (L.kind == 1) {
-      __syncthreads();  // g and xin of every row are in LDS; Ws is free
-      for (int e = tid; e < L.out * L.in; e += 256) {
-        const int o = e / L.in, k = e - o * L.in;
-        Ws[o * kLd + k] = L.w[e];
-      }
-      // weight and bias gradients of the workgroup's rows (rows past the end carry zeros)
-      for (int e = tid; e < L.out * L.in; e += 256) {
-        const int o = e / L.in, k = e - o * L.in;
-        float s = 0.f;
-#pragma unroll
-        for (int rr = 0; rr < kRB; ++rr) s = fmaf(g[rr][o], xin[rr][k], s);
-        atomicAdd(L.gw + e, s);
-      }
-      if (tid < L.out && L.gb) {
-        float s = 0.f;
-#pragma unroll
-        for (int rr = 0; rr < kRB; ++rr) s += g[rr][tid];
-        atomicAdd(L.gb + tid, s);
-      }
-      __syncthreads();  // Ws staged; every reader of g is done
-      if (i > 0) {
-        float res[8];
-        const int jn = (L.in + 15) >> 4;
-        if (jn <= 1) dgrad_rows<1>(g, Ws, L, r, c, res);
-        else if (jn <= 2) dgrad_rows<2>(g, Ws, L, r, c, res);
-        else if (jn <= 4) dgrad_rows<4>(g, Ws, L, r, c, res);
-        else dgrad_rows<8>(g, Ws, L, r, c, res);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < jn && c + 16 * j < L.in) g[r][c + 16 * j] = res[j] * act_der(xin[r][c + 16 * j], pact);
-      }
-    } else {
-      // LayerNorm: statistics recomputed from the input (cheaper than a trip to memory)
-      float s = 0.f;
-      for (int k = c; k < L.in; k += 16) s += xin[r][k];
-      const float mean = sum16(s) / (float)L.in;
-      float q = 0.f;
-      for (int k = c; k < L.in; k += 16) {
-        const float d = xin[r][k] - mean;
-        q = fmaf(d, d, q);
-      }
-      const float rstd = rsqrtf(sum16(q) / (float)L.in + kLnEps);
-      __syncthreads();  // Ws (scratch) is free
-      float m1 = 0.f, m2 = 0.f;
-      for (int k = c; k < L.in; k += 16) {
-        const float xh = (xin[r][k] - mean) * rstd, gy = g[r][k], gg = gy * L.w[k];
-        Ws[r * kLd + k] = gy * xh;
-        Ws[(kRB + r) * kLd + k] = gy;
-        m1 += gg;
-        m2 = fmaf(gg, xh, m2);
-      }
-      m1 = sum16(m1) / (float)L.in;
-      m2 = sum16(m2) / (float)L.in;
-      __syncthreads();
-      if (tid < L.in) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int rr = 0; rr < kRB; ++rr) {
-          s1 += Ws[rr * kLd + tid];
-          s2 += Ws[(kRB + rr) * kLd + tid];
-        }
-        atomicAdd(L.gw + tid, s1);
-        atomicAdd(L.gb + tid, s2);
-      }
-      if (i > 0)
-        for (int k = c; k < L.in; k += 16) {
-          const float xh = (xin[r][k] - mean) * rstd;
-          g[r][k] = rstd * (g[r][k] * L.w[k] - m1 - xh * m2) * act_der(xin[r][k], pact);
-        }
+  if (a.lds_acc)
+    for (int e = tid; e < kMaxP; e += 256) pacc[e] = 0.f;
+  const long nblk = (a.rows + kRB - 1) / kRB;
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long row = blk * kRB + r;
+    const bool rok = row < a.rows;
+    {
+      const Layer& last = a.L[a.n - 1];
+      const int dout = last.kind == 1 ? last.out : last.in;
+      for (int k = c; k < dout; k += 16) g[r][k] = rok ? a.dy[row * a.lddy + k] : 0.f;
     }
+    for (int i = a.n - 1; i >= 0; --i) {
+      const Layer L = a.L[i];
+      for (int k = c; k < L.in; k += 16)
+        xin[r][k] = rok ? (i == 0 ? a.x[row * a.ldx + k] : a.tape[row * a.tld + L.toff + k]) : 0.f;
+      // the activation that produced this input: its derivative (from the input's value) closes the data gradient
+      const int pact = (i > 0 && a.L[i - 1].kind == 1) ? a.L[i - 1].act : 0;
+      if (L.kind == 1) {
+        __syncthreads();  // g and xin of every row are in LDS; Ws is free
+        if (i > 0)
+          for (int e = tid; e < L.out * L.in; e += 256) {
+            const int o = e / L.in, k = e - o * L.in;
+            Ws[o * kLd + k] = L.w[e];
+          }
+        // weight and bias gradients of the block's rows (rows past the end carry zeros)
+        for (int e = tid; e < L.out * L.in; e += 256) {
+          const int o = e / L.in, k = e - o * L.in;
+          float s = 0.f;
+#pragma unroll
+          for (int rr = 0; rr < kRB; ++rr) s = fmaf(g[rr][o], xin[rr][k], s);
+          if (a.lds_acc) pacc[L.pw + e] += s;
+          else atomicAdd(L.gw + e, s);
+        }
+        if (tid < L.out && L.gb) {
+          float s = 0.f;
+#pragma unroll
+          for (int rr = 0; rr < kRB; ++rr) s += g[rr][tid];
+          if (a.lds_acc) pacc[L.pb + tid] += s;
+          else atomicAdd(L.gb + tid, s);
+        }
+        __syncthreads();  // Ws staged; every reader of g is done
+        if (i > 0) {
+          float res[8];
+          const int jn = (L.in + 15) >> 4;
+          if (jn <= 1) dgrad_rows<1>(g, Ws, L, r, c, res);
+          else if (jn <= 2) dgrad_rows<2>(g, Ws, L, r, c, res);
+          else if (jn <= 4) dgrad_rows<4>(g, Ws, L, r, c, res);
+          else dgrad_rows<8>(g, Ws, L, r, c, res);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < jn && c + 16 * j < L.in) g[r][c + 16 * j] = res[j] * act_der(xin[r][c + 16 * j], pact);
+        }
+      } else {
+        // LayerNorm: statistics recomputed from the input (cheaper than a trip to memory)
+        float s = 0.f;
+        for (int k = c; k < L.in; k += 16) s += xin[r][k];
+        const float mean = sum16(s) / (float)L.in;
+        float q = 0.f;
+        for (int k = c; k < L.in; k += 16) {
+          const float d = xin[r][k] - mean;
+          q = fmaf(d, d, q);
+        }
+        const float rstd = rsqrtf(sum16(q) / (float)L.in + kLnEps);
+        __syncthreads();  // Ws (scratch) is free
+        float m1 = 0.f, m2 = 0.f;
+        for (int k = c; k < L.in; k += 16) {
+          const float xh = (xin[r][k] - mean) * rstd, gy = g[r][k], gg = gy * L.w[k];
+          Ws[r * kLd + k] = gy * xh;
+          Ws[(kRB + r) * kLd + k] = gy;
+          m1 += gg;
+          m2 = fmaf(gg, xh, m2);
+        }
+        m1 = sum16(m1) / (float)L.in;
+        m2 = sum16(m2) / (float)L.in;
+        __syncthreads();
+        if (tid < L.in) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int rr = 0; rr < kRB; ++rr) {
+            s1 += Ws[rr * kLd + tid];
+            s2 += Ws[(kRB + rr) * kLd + tid];
+          }
+          if (a.lds_acc) {
+            pacc[L.pw + tid] += s1;
+            pacc[L.pb + tid] += s2;
+          } else {
+            atomicAdd(L.gw + tid, s1);
+            atomicAdd(L.gb + tid, s2);
+          }
+        }
+        if (i > 0)
+          for (int k = c; k < L.in; k += 16) {
+            const float xh = (xin[r][k] - mean) * rstd;
+            g[r][k] = rstd * (g[r][k] * L.w[k] - m1 - xh * m2) * act_der(xin[r][k], pact);
+          }
+      }
+    }
+    __syncthreads();  // the next block's loads overwrite g / xin, which layer 0's sums read across rows
   }
+  if (a.lds_acc)  // every element by the thread that summed it
+    for (int i = 0; i < a.n; ++i) {
+      const Layer L = a.L[i];
+      if (L.kind == 1) {
+        for (int e = tid; e < L.out * L.in; e += 256) atomicAdd(L.gw + e, pacc[L.pw + e]);
+        if (tid < L.out && L.gb) atomicAdd(L.gb + tid, pacc[L.pb + tid]);
+      } else if (tid < L.in) {
+        atomicAdd(L.gw + tid, pacc[L.pw + tid]);
+        atomicAdd(L.gb + tid, pacc[L.pb + tid]);
+      }
+    }
 }
 
 int fill(Args& a, const srl_mlp_layer* layers, int n) {
@@ -246,11 +282,30 @@ int fill(Args& a, const srl_mlp_layer* layers, int n) {
     a.L[i].toff = toff;
     toff += a.L[i].in;
   }
+  int poff = 0;
+  for (int i = 0; i < n; ++i) {
+    Layer& L = a.L[i];
+    L.pw = poff;
+    poff += L.kind == 1 ? L.out * L.in : L.in;
+    L.pb = poff;
+    poff += L.kind == 1 ? L.out : L.in;
+  }
+  a.lds_acc = poff <= kMaxP ? 1 : 0;
   a.n = n;
   return toff;
 }
 
 }  // namespace
+
+extern "C" int64_t srl_mlp_bwd_max_rows(const srl_mlp_layer* layers, int n) {
+  Args a{};
+  if (fill(a, layers, n) < 0) return 0;
+  // Measured against the layer-by-layer kernels on 2 x 64 nets (scripts/mlp_rows_sweep.py): 0.30 against 0.64 ms per update at
+  // 256 rows, 0.54 against 0.89 at 16 384, 1.30 against 1.03 at 65 536 -- 256 threads per CU are too few once the row count
+  // fills the chip (scripts/mlp_probe.py: a 64 x 64 Linear's backward 105 us, a LayerNorm's 84 us at 65 536 rows).  Without
+  // the LDS sums every 16-row block adds its partial sums with float atomics: a few thousand rows only.
+  return a.lds_acc ? 32768 : 8192;
+}
 
 extern "C" int64_t srl_mlp_tape_floats(const srl_mlp_layer* layers, int n) {
   Args a{};
@@ -280,7 +335,9 @@ extern "C" int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, con
   for (int i = 0; i < n; ++i) SRL_CHECK_ARG(a.L[i].gw && (a.L[i].gb || (a.L[i].kind == 1 && !a.L[i].b)), "null gradient");
   if (rows == 0) return 0;
   a.x = x; a.ldx = ldx; a.rows = rows; a.tape = const_cast<float*>(tape); a.tld = tape_ld; a.dy = dy; a.lddy = lddy;
-  hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)srl_ceil_div(rows, (long)kRB)), dim3(256), 0, (hipStream_t)stream, a);
+  long groups = srl_ceil_div(rows, (long)kRB);
+  if (a.lds_acc && groups > kBwdGroups) groups = kBwdGroups;
+  hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, a);
   SRL_LAUNCH_CHECK();
   return 0;
 }

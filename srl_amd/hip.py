@@ -72,6 +72,7 @@ _SIGNATURES = {
     "srl_conv2d_fwd_workspace": (c_int64, [_CD]),
     "srl_absmax": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_mlp_tape_floats": (c_int64, [POINTER(MlpLayer), c_int]),
+    "srl_mlp_bwd_max_rows": (c_int64, [POINTER(MlpLayer), c_int]),
     "srl_mlp_fwd": (c_int, [c_void_p, POINTER(MlpLayer), c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     "srl_mlp_bwd": (c_int, [c_void_p, POINTER(MlpLayer), c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     "srl_conv2d_wgrad_workspace": (c_int64, [_CD]),
@@ -753,6 +754,10 @@ def mlp_layers(layers):
 
 def mlp_tape_floats(arr) -> int:
     return int(lib().srl_mlp_tape_floats(arr, len(arr)))
+
+
+def mlp_bwd_max_rows(arr) -> int:
+    return int(lib().srl_mlp_bwd_max_rows(arr, len(arr)))
 
 
 def mlp_fwd(arr, x_ptr, ldx, rows, tape_ptr, tape_ld, y_ptr, ldy):
