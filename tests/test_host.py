@@ -251,3 +251,29 @@ def test_synthetic_sample_obeys_reference_invariants():
     assert (trunc * done == 0).all() and ((trunc + done)[:-1] == orr[1:]).all()  # gae.py:69-70
     assert (a["reward"][:-1] * orr[1:] == 0).all() and (a["analyzed_result.value"] * done == 0).all()  # :72, mappo.py:124
     assert a["action.x"].shape == (65, 16, 2) and a["done"].dtype == np.uint8 and a["action.x"].dtype == np.int32
+
+
+def test_executor_host_logic_of_round_3():
+    """Host-side decisions of the executor that need no GPU: split-K factors of weight gradients, and the validity window of
+    what an executor derives from the weights (only inside the trainer's chunk loop, only for the current parameter version,
+    only for the same buffer; twins keep their own record but share the version)."""
+    from srl_amd.algorithm import hipnet
+    assert hipnet._split_for(256, 1) == 1            # CartPole-sized: one piece (srl_gemm's small-product path)
+    assert hipnet._split_for(16384, 1) == 32         # >= 512 rows per slice
+    assert hipnet._split_for(16384, 100) == 5        # enough workgroups already
+    spec, vals = ns.build_netspec(obs_dim=4, action_dim=2, hidden_dim=8, num_dense_layers=1, num_rnn_layers=0, popart=False,
+                                  layernorm=False, shared_backbone=False, seed=1)
+    net = hipnet.HipNet(spec, "cpu")
+    assert not net._derived_fresh("w", 1000)         # outside an update: never cached
+    assert not net._derived_fresh("w", 1000)
+    net.chunks_of_one_update(True)
+    assert not net._derived_fresh("w", 1000)         # first chunk computes ...
+    assert net._derived_fresh("w", 1000)             # ... the following ones reuse
+    assert not net._derived_fresh("w", 2000)         # another buffer (outgrown workspace): recompute
+    twin = net.twin()
+    assert not twin._derived_fresh("w", 1000)        # a twin's workspace holds nothing yet
+    assert twin._derived_fresh("w", 1000)
+    net.params_changed()                             # optimiser step: everything derived is stale, for the twin too
+    assert not net._derived_fresh("w", 2000) and not twin._derived_fresh("w", 1000)
+    net.chunks_of_one_update(False)
+    assert not net._derived_fresh("w", 2000) and not twin._derived_fresh("w", 1000)
