@@ -1188,7 +1188,9 @@ def test_gemm_small_products(M, N, K, akm, bkm, split, extra):
              workspace=None if ws is None else ws.data_ptr(), accumulate=extra in ("acc", "colsum"),
              bias=bias.data_ptr() if extra == "bias" else None, act=1 if extra == "bias" else 0,
              a_colsum=cs.data_ptr() if extra == "colsum" else None)
-    assert hip.dispatch_counts()["gemm3"] == 1
+    import os
+    if os.environ.get("SRL_SMALL_GEMM", "1")[:1] != "0":  # (the A/B switch sends them back to the general kernels)
+        assert hip.dispatch_counts()["gemm3"] == 1
     Ad = A.double().T if akm else A.double()
     ref = Ad @ (B.double() if bkm else B.double().T)
     ref = torch.relu(ref + bias.double()) if extra == "bias" else ref + C0.double()
