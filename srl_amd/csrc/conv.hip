@@ -310,7 +310,16 @@ static long images_per_launch(const srl_conv_desc* d, int in_esize) {
   const char* e = getenv("SRL_CONV_RUN_IMAGES");  // tests: force short runs
   if (e && atol(e) > 0 && atol(e) < lim) lim = atol(e);
   if (lim >= 512) lim &= ~255L;
-  return lim < 1 ? 1 : lim;
+  if (lim < 1) lim = 1;
+  // equal runs rather than full ones and a remainder: a last run of a handful of images would fall below the sizes the byte
+  // kernels (and a slot index) need, which the caller checked for the whole batch
+  if (d->n > lim) {
+    const long nruns = srl_ceil_div(d->n, lim);
+    long r = srl_ceil_div(d->n, nruns);
+    if (r >= 512) r = (r + 255) & ~255L;
+    if (r < lim) lim = r;
+  }
+  return lim;
 }
 
 // Order of the 16-deep k-steps of a forward convolution (k = (kh, kw, c), c fastest).  Every tile re-reads its input

@@ -1116,13 +1116,48 @@ def test_conv2d_runs_of_images(monkeypatch):
         torch.cuda.synchronize()
         return y, ym, yr, gx, gw, gb
 
+    # the first layer on ring rows: frames of 1400 slots, the batch's 1000 rows through a slot index
+    slots = 1400
+    frames = torch.from_numpy(rng.integers(0, 256, (slots, 21, 21, 64), dtype=np.uint8)).to(DEV)
+    fmean = frames.reshape(slots, -1).float().mean(1)
+    frstd = 1.0 / torch.sqrt(frames.reshape(slots, -1).float().var(1, unbiased=False) + 1e-5)
+    ridx = torch.from_numpy(rng.permutation(slots)[:n].astype(np.int32)).to(DEV)
+    d1 = hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, act=1)
+    assert hip.conv2d_obs_row_index_supported(d1, True, True)
+    g1 = dev((1 + 0.1 * rng.standard_normal(21 * 21 * 64)).astype(np.float32))
+    b1 = dev((0.1 * rng.standard_normal(21 * 21 * 64)).astype(np.float32))
+    w1 = dev((rng.standard_normal(32 * 256) / 16).astype(np.float32))
+    wb1 = dev(rng.standard_normal(32).astype(np.float32))
+    dz1 = dev(rng.standard_normal((n, 20, 20, 32)).astype(np.float32))
+    fws = torch.empty(hip.conv2d_obs_fwd_workspace(d1), device=DEV)
+    bws = torch.empty(hip.conv2d_obs_bwd_workspace(d1), device=DEV)
+
+    def run_first():
+        y1 = torch.full((n, 20, 20, 32), np.nan, device=DEV)
+        m1 = torch.full((n * 400,), -1, dtype=torch.int32, device=DEV)
+        hip.conv2d_obs_fwd(d1, frames.data_ptr(), True, fmean.data_ptr(), frstd.data_ptr(), g1.data_ptr(), b1.data_ptr(),
+                           w1.data_ptr(), wb1.data_ptr(), y1.data_ptr(), channels_last=True, ws_ptr=fws.data_ptr(),
+                           row_index=ridx, y_mask=m1.data_ptr())
+        outs = [torch.zeros(32 * 256, device=DEV), torch.zeros(32, device=DEV), torch.zeros(21 * 21 * 64, device=DEV),
+                torch.zeros(21 * 21 * 64, device=DEV)]
+        hip.conv2d_obs_bwd(d1, frames.data_ptr(), True, fmean.data_ptr(), frstd.data_ptr(), g1.data_ptr(), b1.data_ptr(),
+                           w1.data_ptr(), dz1.data_ptr(), *[o.data_ptr() for o in outs], bws.data_ptr(), channels_last=True,
+                           row_index=ridx)
+        torch.cuda.synchronize()
+        return y1, m1, outs
+
     one = run_all()
-    monkeypatch.setenv("SRL_CONV_RUN_IMAGES", "300")  # 300 + 300 + 300 + 100
+    first = run_first()
+    monkeypatch.setenv("SRL_CONV_RUN_IMAGES", "300")  # 1000 images in 4 equal runs of 250
     runs = run_all()
+    first_runs = run_first()
     for a, b_, name in zip(one[:4], runs[:4], ("y", "mask", "range", "dx")):
         assert torch.equal(a, b_), name
     for a, b_, name in zip(one[4:], runs[4:], ("dw", "db")):
         assert rel_close(b_.cpu().numpy(), a.cpu().numpy(), 1e-5, scale=float(a.abs().max())), name
+    assert torch.equal(first[0], first_runs[0]) and torch.equal(first[1], first_runs[1])
+    for a, b_, name in zip(first[2], first_runs[2], ("dw1", "db1", "dgamma", "dbeta")):
+        assert rel_close(b_.cpu().numpy(), a.cpu().numpy(), 2e-5, scale=float(a.abs().max())), name
 
 
 @pytest.mark.timeout(600)
