@@ -410,6 +410,14 @@ def main():
                         flops_per_env_step=g["work"] / (T * B), kernel_family_launches=dispatch,
                         **recorded_traffic(("gemm", "obs_fwd_bf16", "obs_bwd_bf16"), B, T, args.chunk_rows),
                         **recorded_counters(B, T, args.chunk_rows))
+        # The same launches against the OTHER roof.  With float32 activations in HBM the convolution layers carry 60-75
+        # algorithmic flop per byte, below the ~104 flop / byte at which 8 TB/s feed three piece products per multiply-add at
+        # the 16-bit peak: by bytes they sit under the HBM roof, and the recorded traffic over this run's kernel time says
+        # how far under (DESIGN section 5 has the per-layer floors).
+        if roofline.get("traffic"):
+            gbs_fam = roofline["traffic"] / (g["ms"] * 1e-3) / 1e9
+            roofline["hbm"] = dict(achieved=round(gbs_fam, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs_fam / PEAK_HBM_GBS, 4),
+                                   basis="recorded HBM bytes of these launches (PMC passes) / their summed durations in this run")
         # the scan is a ~microsecond kernel: time it as back-to-back launches between two events on the launch
         # stream so that host enqueue latency does not sit inside the interval
         floor = launch_floor_us(device)
