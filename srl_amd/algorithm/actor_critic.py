@@ -11,6 +11,7 @@ inside the first convolution's gather instead of being widened to float32 first,
 uses a counter-based Philox stream keyed by ``(seed, call counter)`` instead of the global torch RNG, so a
 rollout is reproducible regardless of how requests are batched.
 """
+import os
 import functools
 from typing import Dict, List, Optional, Tuple, Union
 
@@ -261,7 +262,9 @@ class ActorCriticPolicy(policy_api.Policy):
         return ObsRing.for_policy(self, capacity_rows, patch_rows)
 
     # ------------------------------------------------------------------ inference
-    ROLLOUT_PIECE = 1024  # rows per piece when a big host batch is streamed in (copy of piece i+1 under the compute of i)
+    # (2048: the call is bound by the host's launches per piece as much as by the link -- 4096 rows in 2 pieces 2.74-2.92 ms,
+    # in 4 pieces 3.08-3.10, in 8 pieces 4.3, same box; SRL_ROLLOUT_PIECE for the A/B)
+    ROLLOUT_PIECE = int(os.environ.get('SRL_ROLLOUT_PIECE', '2048'))  # rows per piece when a big host batch is streamed in (copy of piece i+1 under the compute of i)
 
     def rollout(self, requests: policy_api.RolloutRequest, **kwargs) -> policy_api.RolloutResult:
         hip.require_gpu()
