@@ -289,7 +289,15 @@ typedef struct srl_gemm_desc {
    * bytes read (modules/cnn.py:118's nn.ReLU backward). */
   uint32_t* mask_out;
   const uint32_t* dact_mask;
+  /* B is srl_presplit's output instead of float32 (same shape, pitch and orientation): accepted only where the product takes
+   * the two-piece kernel -- both ranges given, M > 64, N > 64, K >= 64, aligned operands, and not the small-product path (more
+   * than 65 536 outputs or K > 512).  b_absmax must be the float srl_presplit was given. */
+  int32_t b_presplit;
 } srl_gemm_desc;
+/* dst[i .. i+3] (16 bytes) = the two f16 pieces of src[i .. i+3] under the scale of *absmax: what the two-piece kernels make of a
+ * B operand every time they stage a tile of it, done once -- for weights, once per parameter update (srl_gemm_desc::b_presplit,
+ * the w_presplit / wt_presplit arguments of the convolution entry points).  n a multiple of 4, 16-byte aligned pointers. */
+int srl_presplit(void* stream, const float* src, const float* absmax, float* dst, int64_t n);
 int srl_gemm(void* stream, const srl_gemm_desc* d);
 
 /* ------------------------------------------------------------------------------------------------
@@ -369,9 +377,11 @@ int srl_conv2d_supported(const srl_conv_desc* d, int first_layer);
  * run image-stationary: whole images staged once in LDS as two f16 planes, every tap's operands read from there, each
  * input byte fetched from HBM exactly once (csrc/conv_is.h).  0 from srl_conv2d_fwd_workspace: not for this geometry. */
 int64_t srl_conv2d_fwd_workspace(const srl_conv_desc* d);
+/* w_presplit != 0: `w` is srl_presplit(w, w_absmax): accepted only where the layer takes the two-piece kernel (both ranges,
+ * Cout in 33..., KH*KW*Cin >= 64; not the image-stationary path). */
 int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w, const float* bias,
                         float* y, const float* x_absmax, const float* w_absmax, float* y_absmax, uint32_t* y_mask,
-                        float* workspace);
+                        float* workspace, int w_presplit);
 /* dw[Cout,KH,KW,Cin] += sum over (n,oh,ow) dz[.,Cout]^T patch(x); workspace: srl_conv2d_wgrad_workspace floats
  * (split over the n*OH*OW reduction) or NULL.  dbias (optional): [Cout] += sum over (n,oh,ow) dz, the bias
  * gradient, from the same pass over dz. */
@@ -386,9 +396,11 @@ int64_t srl_conv2d_dgrad_weight_elems(const srl_conv_desc* d);
 int srl_conv2d_dgrad_repack(void* stream, const srl_conv_desc* d, const float* w, float* wt);
 /* x_mask (dact == 1, x_act NULL, Cin a multiple of 32): the sign bits of x_act as written by the producing layer's y_mask -- the same dx at 1/32
  * of the bytes read for the derivative. */
+/* wt_presplit != 0: `wt` is srl_presplit(wt, w_absmax) of the regrouped weights: two-piece kernel only (both ranges, Cout a
+ * multiple of 16, more than 32 packed columns). */
 int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* wt, const float* x_act,
                           int dact, float* dx, const float* dz_absmax, const float* w_absmax, float* dx_absmax,
-                          const uint32_t* x_mask);
+                          const uint32_t* x_mask, int wt_presplit);
 /* First layer: y = act(conv(LayerNorm(obs), w) + bias) with the LayerNorm over the whole observation; obs uint8 or
  * float32, mean/rstd [n] from srl_obs_ln_stats / srl_obs_space_to_depth.  channels_last = 0: obs [n,Cin,H,W],
  * gamma/beta [Cin,H,W], w [Cout,Cin,KH,KW] (the reference's layouts); channels_last = 1: obs [n,H,W,Cin],

@@ -130,6 +130,7 @@ class HipNet:
         self._pver = [0]    # parameter version, shared with the twins (a list: one object)
         self._in_update = [False]
         self._derived_on = os.environ.get("SRL_DERIVED_CACHE", "1") != "0"  # 0: recompute for every chunk (A/B)
+        self._presplit_on = self._derived_on and os.environ.get("SRL_PRESPLIT", "1") != "0"  # weights split once per update
         self._derived = {}  # per executor: what its workspace holds that was derived from which parameter version
         self._side_stream = None
         self._side_used = False
@@ -238,6 +239,17 @@ class HipNet:
             return True
         self._derived[key] = val
         return False
+
+    def _presplit(self, key: str, src_ptr: int, numel: int, range_ptr: int) -> Optional[int]:
+        """The weight tensor at ``src_ptr`` as the two f16 pieces the two-piece kernels would otherwise make of it in every tile
+        that stages it (``hip.presplit``), computed once per update and executor; None outside the trainer's chunk loop (a
+        rollout's single pass does not repay the extra launch) or with SRL_PRESPLIT=0."""
+        if not self._in_update[0] or not self._presplit_on or numel % 4 or src_ptr % 16:
+            return None
+        buf = self.ws.get(key, numel).data_ptr()
+        if not self._derived_fresh(key, buf):
+            hip.presplit(src_ptr, range_ptr, buf, numel)
+        return buf
 
     def chunks_of_one_update(self, on: bool):
         """The trainer brackets the chunk loop of one update with this: inside it the parameters do not change, so what an
@@ -348,8 +360,12 @@ class HipNet:
         weight's range the product runs on two f16 pieces per operand (srl_gemm_desc::a_absmax)."""
         y = self._buf(f"{tag}{L.prefix}.y", x.rows, L.out_features)
         w_range = self._weight_range(L.prefix, L.out_features * L.in_features) if x_range is not None else None
-        hip.gemm(x.rows, L.out_features, L.in_features, x.ptr, x.ld, 0, self._p(f"{L.prefix}.weight"), L.in_features, 0,
-                 y.ptr, y.ld, bias=self._p(f"{L.prefix}.bias"), act=L.act, a_absmax=x_range, b_absmax=w_range)
+        w, pre = self._p(f"{L.prefix}.weight"), None
+        if hip.gemm_two_piece(x.rows, L.out_features, L.in_features, x.ptr, x.ld, w, L.in_features, x_range, w_range):
+            pre = self._presplit(f"{L.prefix}.w2h", w, L.out_features * L.in_features, w_range)  # also serves the data gradient
+        hip.gemm(x.rows, L.out_features, L.in_features, x.ptr, x.ld, 0, pre or w, L.in_features, 0,
+                 y.ptr, y.ld, bias=self._p(f"{L.prefix}.bias"), act=L.act, a_absmax=x_range, b_absmax=w_range,
+                 b_presplit=pre is not None)
         return y
 
     def _wgrad(self, out_f, in_f, rows, dz: Buf, x_ptr, x_ld, gw_ptr, gb_ptr=None, dz_range=None, x_range=None):
@@ -383,9 +399,13 @@ class HipNet:
         dx = dx_into or self._buf(f"{tag}{L.prefix}.dx", x.rows, L.in_features)
         w_range = self._weight_range(L.prefix, L.out_features * L.in_features) if dz_range is not None else None
         x_mask = x.mask if in_act == hip.ACT_RELU else None
-        hip.gemm(x.rows, L.in_features, L.out_features, dz.ptr, dz.ld, 0, self._p(f"{L.prefix}.weight"), L.in_features,
+        w, pre = self._p(f"{L.prefix}.weight"), None
+        if hip.gemm_two_piece(x.rows, L.in_features, L.out_features, dz.ptr, dz.ld, w, L.in_features, dz_range, w_range):
+            pre = self._presplit(f"{L.prefix}.w2h", w, L.out_features * L.in_features, w_range)  # the forward pass's copy
+        hip.gemm(x.rows, L.in_features, L.out_features, dz.ptr, dz.ld, 0, pre or w, L.in_features,
                  1, dx.ptr, dx.ld, dact_src=x.ptr if in_act and x_mask is None else None, ld_dact=x.ld, dact=in_act,
-                 accumulate=dx_accumulate, a_absmax=dz_range, b_absmax=w_range, out_absmax=dx_range, dact_mask=x_mask)
+                 accumulate=dx_accumulate, a_absmax=dz_range, b_absmax=w_range, out_absmax=dx_range, dact_mask=x_mask,
+                 b_presplit=pre is not None)
         return dx
 
     def _ln_fwd(self, L: ns.LayerNormSpec, x: Buf, tag: str):
@@ -701,10 +721,14 @@ class HipNet:
                     if implicit:
                         w_range = self._weight_range(L.prefix, L.cout * kdim) if cur_range is not None and not L.pad else None
                         fws = hip.conv2d_fwd_workspace(desc) if w_range is not None else 0
-                        hip.conv2d_nhwc_fwd(desc, cur.ptr, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"),
-                                            y.ptr, x_absmax=cur_range if w_range is not None else None, w_absmax=w_range,
-                                            y_absmax=y_range, y_mask=y.mask,
-                                            ws_ptr=self.ws.get(f"{L.prefix}.wq", fws).data_ptr() if fws else None)
+                        xr = cur_range if w_range is not None else None
+                        w, pre = self._p(f"{L.prefix}.weight"), None
+                        if hip.conv2d_fwd_two_piece(desc, xr, w_range) and not os.environ.get("SRL_CONV_IS", "0")[:1] in "12":
+                            pre = self._presplit(f"{L.prefix}.w2h", w, L.cout * kdim, w_range)
+                        hip.conv2d_nhwc_fwd(desc, cur.ptr, pre or w, self._p(f"{L.prefix}.bias"),
+                                            y.ptr, x_absmax=xr, w_absmax=w_range, y_absmax=y_range, y_mask=y.mask,
+                                            ws_ptr=self.ws.get(f"{L.prefix}.wq", fws).data_ptr() if fws else None,
+                                            presplit=pre is not None)
                     else:
                         hip.im2col_nhwc(cur.ptr, n, h, w, L.cin, L.k, L.k, L.stride, P.ptr)
                 if not implicit:
@@ -806,10 +830,13 @@ class HipNet:
                         dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.cin)
                         dx_range = self._grad_range() if two else None
                         x_mask = x.mask if in_act == hip.ACT_RELU else None  # the derivative from sign bits, not floats
-                        hip.conv2d_nhwc_dgrad(desc, g.ptr, wt.data_ptr(), x.ptr if in_act and x_mask is None else None, in_act,
-                                              dx.ptr, dz_absmax=g_range if two else None,
-                                              w_absmax=self._weight_range(L.prefix, L.cout * kdim) if two else None,
-                                              dx_absmax=dx_range, x_mask=x_mask)
+                        wr = self._weight_range(L.prefix, L.cout * kdim) if two else None
+                        wtp, pre = wt.data_ptr(), None
+                        if hip.conv2d_dgrad_two_piece(desc, g_range if two else None, wr):
+                            pre = self._presplit(f"{L.prefix}.wt2h", wtp, hip.conv2d_dgrad_weight_elems(desc), wr)
+                        hip.conv2d_nhwc_dgrad(desc, g.ptr, pre or wtp, x.ptr if in_act and x_mask is None else None, in_act,
+                                              dx.ptr, dz_absmax=g_range if two else None, w_absmax=wr,
+                                              dx_absmax=dx_range, x_mask=x_mask, presplit=pre is not None)
                         g = self._crop(L, dx, n, tag)
                         g_range = dx_range
                     if g is not None and idx > 0:

@@ -368,7 +368,7 @@ static void launch_is_fwd(hipStream_t st, const srlis::FwdArgs& a, long n) {
 
 static int conv2d_nhwc_fwd_run(void* stream, const srl_conv_desc* d, const float* x, const float* w,
                                const float* bias, float* y, const float* x_absmax, const float* w_absmax,
-                               float* y_absmax, uint32_t* y_mask, float* workspace) {
+                               float* y_absmax, uint32_t* y_mask, float* workspace, int w_presplit) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry (needs Cin, Cout multiples of 4, < 2^31 elements)");
   SRL_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w), "null / unaligned tensor");
   SRL_CHECK_ARG(!y_mask || (d->act == 1 && d->Cout % 32 == 0), "y_mask: ReLU layers with Cout a multiple of 32");
@@ -386,7 +386,7 @@ static int conv2d_nhwc_fwd_run(void* stream, const srl_conv_desc* d, const float
   g.range_a = x_absmax; g.range_b = w_absmax; g.out_absmax = y_absmax;
   g.mask_out = y_mask;
   hipStream_t st = (hipStream_t)stream;
-  if (workspace && aligned16(workspace) && x_absmax && w_absmax && use_bf16x3() && use_f16x2() && use_conv_is() && d->n >= 512 &&
+  if (!w_presplit && workspace && aligned16(workspace) && x_absmax && w_absmax && use_bf16x3() && use_f16x2() && use_conv_is() && d->n >= 512 &&
       is_geometry(d) >= use_conv_is()) {
     // whole images staged once in LDS as two f16 planes, every tap's fragments read from there (conv_is.h)
     const int geo = is_geometry(d);
@@ -404,6 +404,9 @@ static int conv2d_nhwc_fwd_run(void* stream, const srl_conv_desc* d, const float
   int rc;
   const bool x3 = use_bf16x3() && Kp >= 64;  // bf16 matrix cores, three exact pieces per float32 operand
   if (x3) fwd_kstep_order(d, &g);
+  SRL_CHECK_ARG(!w_presplit || (x3 && x_absmax && w_absmax && use_f16x2() && d->Cout > 32),
+                "w_presplit: only layers that take the two-piece kernel");
+  g.b_presplit = w_presplit;
   if (x3 && x_absmax && w_absmax && use_f16x2() && d->Cout > 32) {
     // both operands' ranges are known: two f16 pieces each, three products (gemm_bf16x3.h, NP == 2)
     rc = d->Cout > 64 ? launch3<128, 128, 2, 2, false, false, SRC_CONV, SRC_PLAIN, K3, 2>(st, g, 1, 1)
@@ -423,7 +426,7 @@ static int conv2d_nhwc_fwd_run(void* stream, const srl_conv_desc* d, const float
 
 extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w,
                                    const float* bias, float* y, const float* x_absmax, const float* w_absmax,
-                                   float* y_absmax, uint32_t* y_mask, float* workspace) {
+                                   float* y_absmax, uint32_t* y_mask, float* workspace, int w_presplit) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry (needs Cin, Cout multiples of 4)");
   const long run = images_per_launch(d, 4);
   const long in_e = (long)d->H * d->W * d->Cin;
@@ -432,7 +435,7 @@ extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const f
     srl_conv_desc s = *d;
     s.n = d->n - i0 < run ? d->n - i0 : run;
     const int rc = conv2d_nhwc_fwd_run(stream, &s, x + i0 * in_e, w, bias, y + i0 * out_e, x_absmax, w_absmax, y_absmax,
-                                       y_mask ? y_mask + i0 * out_e / 32 : nullptr, workspace);
+                                       y_mask ? y_mask + i0 * out_e / 32 : nullptr, workspace, w_presplit);
     if (rc != 0) return rc;
   }
   return 0;
@@ -526,7 +529,7 @@ extern "C" int srl_conv2d_dgrad_repack(void* stream, const srl_conv_desc* d, con
 
 static int conv2d_nhwc_dgrad_run(void* stream, const srl_conv_desc* d, const float* dz, const float* wt,
                                  const float* x_act, int dact, float* dx, const float* dz_absmax, const float* w_absmax,
-                                 float* dx_absmax, const uint32_t* x_mask) {
+                                 float* dx_absmax, const uint32_t* x_mask, int wt_presplit) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0) && d->stride <= 8, "unsupported geometry");
   SRL_CHECK_ARG(!x_mask || (dact == 1 && !x_act && d->Cin % 32 == 0),
                 "x_mask: the ReLU derivative, instead of x_act; Cin a multiple of 32");
@@ -594,6 +597,9 @@ static int conv2d_nhwc_dgrad_run(void* stream, const srl_conv_desc* d, const flo
     g.range_a = dz_absmax; g.range_b = w_absmax; g.out_absmax = dx_absmax;
     int rc;
     const bool x3 = use_bf16x3() && d->Cout % K3 == 0;  // the step mask skips whole taps: a k-step must not straddle two
+    const bool two_piece = g.K > 0 && x3 && dz_absmax && w_absmax && use_f16x2() && ncols > 32;
+    SRL_CHECK_ARG(!wt_presplit || two_piece, "wt_presplit: only layers that take the two-piece kernel");
+    g.b_presplit = wt_presplit;
     if (g.K == 0) {  // no tap reaches this class: gradient is zero there (k loop is empty, epilogue writes 0)
       rc = launch<256, 32, 4, 1, false, true, SRC_DGRAD, SRC_PLAIN>(st, g, 1, 1);
     } else if (x3 && dz_absmax && w_absmax && use_f16x2() && ncols > 32) {  // both ranges known: two f16 pieces per operand
@@ -612,7 +618,7 @@ static int conv2d_nhwc_dgrad_run(void* stream, const srl_conv_desc* d, const flo
 
 extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* wt,
                                      const float* x_act, int dact, float* dx, const float* dz_absmax, const float* w_absmax,
-                                     float* dx_absmax, const uint32_t* x_mask) {
+                                     float* dx_absmax, const uint32_t* x_mask, int wt_presplit) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0) && d->stride <= 8, "unsupported geometry");
   const long run = images_per_launch(d, 4);
   const long in_e = (long)d->H * d->W * d->Cin;
@@ -621,7 +627,7 @@ extern "C" int srl_conv2d_nhwc_dgrad(void* stream, const srl_conv_desc* d, const
     srl_conv_desc s = *d;
     s.n = d->n - i0 < run ? d->n - i0 : run;
     const int rc = conv2d_nhwc_dgrad_run(stream, &s, dz + i0 * out_e, wt, x_act ? x_act + i0 * in_e : nullptr, dact, dx + i0 * in_e,
-                                         dz_absmax, w_absmax, dx_absmax, x_mask ? x_mask + i0 * in_e / 32 : nullptr);
+                                         dz_absmax, w_absmax, dx_absmax, x_mask ? x_mask + i0 * in_e / 32 : nullptr, wt_presplit);
     if (rc != 0) return rc;
   }
   return 0;

@@ -6,7 +6,7 @@
 #include "gemm_bf16x3.h"
 #include "skinny.h"
 
-static_assert(sizeof(srl_gemm_desc) == 192 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
+static_assert(sizeof(srl_gemm_desc) == 200 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
 
 using namespace srlgemm;
 
@@ -73,6 +73,7 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   g.range_a = d->a_absmax; g.range_b = d->b_absmax;
   g.dact_src = d->dact_src; g.ld_dact = d->ld_dact; g.dact = d->dact;
   g.mask_out = d->mask_out; g.dact_mask = d->dact_mask;
+  g.b_presplit = d->b_presplit;
   const int nsplit = plan_split(d->K, split, &g.k_per_split);
   g.o = OutDesc{};
   g.o.f_img = g.o.f_line = make_fastdiv(1);
@@ -96,13 +97,19 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
                 "the data-gradient one (0, 1)");
   int rc;
   if (nsplit == 1) g.out_absmax = d->out_absmax;
-  if (use_bf16x3() && small_gemm() && g.vec_a && g.vec_b && d->M * d->N <= 65536 && d->K >= 4 && d->K <= 512) {
+  const bool small = use_bf16x3() && small_gemm() && g.vec_a && g.vec_b && d->M * d->N <= 65536 && d->K >= 4 && d->K <= 512;
+  const bool two = !small && use_bf16x3() && d->a_absmax && d->b_absmax && use_f16x2() && g.vec_a && g.vec_b && d->M > 64 &&
+                   d->N > 64 && d->K >= 64;
+  SRL_CHECK_ARG(!d->b_presplit || (two && nsplit >= 1),
+                "b_presplit: only products that take the two-piece kernel (both ranges, M > 64, N > 64, K >= 64, aligned operands, "
+                "more than 65 536 outputs or K > 512)");
+  if (small) {
     // A product of a few thousand outputs (the layers of the CartPole-sized configurations) is a latency chain: on 256 x 64
     // tiles it is ONE workgroup walking K in 16-deep steps, a memory latency each (9-11 us for 256 x 64 x 64).  64 x 64
     // tiles with 64-deep steps: several workgroups, and K <= 64 arrives with one round of loads.
     rc = launch3_or<64, 64, 2, 2, 3, 64>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
   } else
-  if (use_bf16x3() && d->a_absmax && d->b_absmax && use_f16x2() && g.vec_a && g.vec_b && d->M > 64 && d->N > 64 && d->K >= 64) {
+  if (two) {
     // the caller knows both operands' ranges: two f16 pieces per operand, three products (gemm_bf16x3.h, NP == 2)
     rc = launch3_or<128, 128, 2, 2, 2>(st, g, d->a_kmajor, d->b_kmajor, nsplit);
   } else

@@ -101,7 +101,7 @@ __device__ __forceinline__ void split2h_quad(const float* v, float scale, uint2 
 
 // registers of a staged tile (Stage::r, float4 quads in Stage's thread -> (row, k) assignment) -> NP planes of 16-bit
 // pieces in LDS (three bf16 planes, or two f16 planes of the scaled operand)
-template <class ST, int BX, bool KMAJOR, int KB, int NT, int NP = 3>
+template <class ST, int BX, bool KMAJOR, int KB, int NT, int NP = 3, bool RAW = false>
 __device__ __forceinline__ void store3(const float* regs, uint8_t* lds, float scale = 1.f) {
   using T3 = Tile3<BX, KMAJOR, KB, NP>;
   const int tid = threadIdx.x;
@@ -110,7 +110,11 @@ __device__ __forceinline__ void store3(const float* regs, uint8_t* lds, float sc
     const int u = tid + q * NT;
     if (ST::PARTIAL && u >= ST::QUADS) continue;
     uint2 pl[3];
-    if (NP == 3) split3_quad(regs + 4 * q, pl);
+    if (RAW) {  // the operand arrives already split (BPRE; SRL_GEMM3_DBG & 256 as a timing experiment): two pieces per 16 bytes
+      pl[0] = make_uint2(__float_as_uint(regs[4 * q]), __float_as_uint(regs[4 * q + 1]));
+      pl[1] = make_uint2(__float_as_uint(regs[4 * q + 2]), __float_as_uint(regs[4 * q + 3]));
+      pl[2] = pl[0];
+    } else if (NP == 3) split3_quad(regs + 4 * q, pl);
     else split2h_quad(regs + 4 * q, scale, reinterpret_cast<uint2(&)[2]>(pl));
     int off;
     if (!KMAJOR) off = T3::off_kc(u / ST::KQ, (u % ST::KQ) * 4);
@@ -147,7 +151,11 @@ constexpr int min_waves3(int bm, int bn, int kb, int np = 3) {
   return by_lds >= 3 ? 3 : (by_lds >= 2 ? 2 : 1);
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB, int NP = 3, int MK = 0>
+// BPRE (NP == 2, dense B): B arrives ALREADY split -- every 16 bytes of it hold the two f16 pieces of four consecutive elements
+// (srl_presplit: same addresses, same strides as the float32 matrix) -- so its tiles go from the registers to LDS as they
+// are.  Weights are split once per update instead of once per tile that stages them: leaving B's split out of the kernels
+// (timing experiment) gave 5-6.5 % on the convolutions and 13-15 % on the FC products.
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB, int NP = 3, int MK = 0, bool BPRE = false>
 __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm3_kernel(GemmArgs g) {
   static_assert(NP == 3 || NP == 2, "three bf16 pieces or two f16 pieces");
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm
   }
   cs_acc(sa.r);
   store3<SA, BM, AKM, KB, NT, NP>(sa.r, lds, sc_a);
-  store3<SB, BN, BKM, KB, NT, NP>(sb.r, lds + TA::BYTES, sc_b);
+  store3<SB, BN, BKM, KB, NT, NP, BPRE || (SRL_GEMM3_DBG & 256) != 0>(sb.r, lds + TA::BYTES, sc_b);
   __syncthreads();
   if (!PAIR) {  // the second tile -- or, for a product of a single k-step, an out-of-range tile: zeros (the step's staging is
     // unconditional, and the fused column sums would count the first tile twice if it were still in the registers)
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm
         cs_acc(ra);
         if (!(SRL_GEMM3_DBG & 2)) {
           store3<SA, BM, AKM, KB, NT, NP>(ra, nxt, sc_a);           // tile t+1 (or zeros): registers -> the other LDS buffer
-          store3<SB, BN, BKM, KB, NT, NP>(rb, nxt + TA::BYTES, sc_b);
+          store3<SB, BN, BKM, KB, NT, NP, BPRE || (SRL_GEMM3_DBG & 256) != 0>(rb, nxt + TA::BYTES, sc_b);
         }
         if (!(SRL_GEMM3_DBG & 1) && (!PAIR || cur == 0)) {
           sa.load(g.a, m0, g.M, k2x, kend, true);         // tile t+2 (or nothing): global -> registers
@@ -450,14 +458,30 @@ inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   srl_count_dispatch(NP == 3 ? SRL_DISP_GEMM3 : SRL_DISP_GEMM2H);
   constexpr bool CAN_W = !AKM && !BKM && BMODE == SRC_PLAIN;  // sign masks: see launch() in gemm_core.h
   constexpr bool CAN_R = !AKM && BKM && BMODE == SRC_PLAIN && (AMODE == SRC_PLAIN || AMODE == SRC_DGRAD);
-  if (a.mask_out) {
-    if constexpr (CAN_W) hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB, NP, 2>), grid, dim3(256), 0, st, a);
+  constexpr bool CAN_PRE = NP == 2 && BMODE == SRC_PLAIN && KB == 16;  // pre-split B: the two-piece kernels, dense B
+  auto go = [&](auto mk_c, auto pre_c) {
+    constexpr int MK = decltype(mk_c)::value;
+    constexpr bool PRE = decltype(pre_c)::value;
+    hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB, NP, MK, PRE>), grid, dim3(256), 0, st, a);
+  };
+  using std::integral_constant;
+  if (a.b_presplit) {
+    if constexpr (!CAN_PRE) return -ENOTSUP;
+    else if (a.mask_out) {
+      if constexpr (CAN_W) go(integral_constant<int, 2>{}, std::true_type{});
+      else return -ENOTSUP;
+    } else if (a.dact_mask && !a.dact_src) {
+      if constexpr (CAN_R) go(integral_constant<int, 1>{}, std::true_type{});
+      else return -ENOTSUP;
+    } else go(integral_constant<int, 0>{}, std::true_type{});
+  } else if (a.mask_out) {
+    if constexpr (CAN_W) go(integral_constant<int, 2>{}, std::false_type{});
     else return -ENOTSUP;
   } else if (a.dact_mask && !a.dact_src) {
-    if constexpr (CAN_R) hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB, NP, 1>), grid, dim3(256), 0, st, a);
+    if constexpr (CAN_R) go(integral_constant<int, 1>{}, std::false_type{});
     else return -ENOTSUP;
   } else {
-    hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB, NP>), grid, dim3(256), 0, st, a);
+    go(integral_constant<int, 0>{}, std::false_type{});
   }
   return 0;
 }

@@ -125,6 +125,7 @@ struct GemmArgs {
   uint32_t* mask_out;
   const uint32_t* dact_mask;
   uint32_t mask_off;
+  int b_presplit;  // gemm3_kernel NP == 2: B holds srl_presplit's output (see BPRE)
   int act, dact, accumulate;
   long k_per_split;
   int vec_a, vec_b;

@@ -2,6 +2,7 @@
 // statistics, patch gathers (im2col) with the observation LayerNorm fused into the uint8 load path,
 // the gather form of col2im, column sums, strided copies.
 #include "srl_common.h"
+#include "gemm_bf16x3.h"
 
 namespace {
 
@@ -665,6 +666,34 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, flo
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
 }
 }  // namespace
+
+// four consecutive float32 -> the 16 bytes gemm3_kernel's BPRE variant expects in their place: the four first pieces h0 =
+// f16(x s), then the four second pieces h1 = f16(x s - h0), s = range_scale(*absmax) -- the arithmetic of split2h_quad
+namespace {
+__global__ __launch_bounds__(256) void presplit_kernel(const float4* src, const float* absmax, float4* dst, long quads) {
+  const float sc = srlgemm::range_scale(absmax);
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
+    const float4 v = src[q];
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    uint2 pl[2];
+    srlgemm::split2h_quad(f, sc, pl);
+    dst[q] = make_float4(__uint_as_float(pl[0].x), __uint_as_float(pl[0].y), __uint_as_float(pl[1].x), __uint_as_float(pl[1].y));
+  }
+}
+}  // namespace
+
+extern "C" int srl_presplit(void* stream, const float* src, const float* absmax, float* dst, int64_t n) {
+  SRL_CHECK_ARG(src && absmax && dst && n >= 0 && n % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0,
+                "null / unaligned tensor, or a length that is not a multiple of 4");
+  if (n == 0) return 0;
+  const long quads = n / 4;
+  long blocks = srl_ceil_div(quads, 256L);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(src), absmax, reinterpret_cast<float4*>(dst), quads);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int srl_absmax(void* stream, const float* x, int64_t n, float* out) {
   SRL_CHECK_ARG(out && n >= 0, "null output");

@@ -51,7 +51,7 @@ class GemmDesc(Structure):
                 ("ldc", c_int64), ("bias", c_void_p), ("act", c_int32), ("dact_src", c_void_p), ("ld_dact", c_int64),
                 ("dact", c_int32), ("accumulate", c_int32), ("split_k", c_int32), ("workspace", c_void_p),
                 ("a_colsum", c_void_p), ("a_absmax", c_void_p), ("b_absmax", c_void_p), ("out_absmax", c_void_p),
-                ("mask_out", c_void_p), ("dact_mask", c_void_p)]
+                ("mask_out", c_void_p), ("dact_mask", c_void_p), ("b_presplit", c_int32)]
 
 
 class MlpLayer(Structure):
@@ -68,7 +68,8 @@ _CD = POINTER(ConvDesc)
 
 _SIGNATURES = {
     "srl_conv2d_supported": (c_int, [_CD, c_int]),
-    "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD] + [c_void_p] * 9),
+    "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD] + [c_void_p] * 9 + [c_int]),
+    "srl_presplit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "srl_conv2d_fwd_workspace": (c_int64, [_CD]),
     "srl_absmax": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_mlp_tape_floats": (c_int64, [POINTER(MlpLayer), c_int]),
@@ -79,7 +80,7 @@ _SIGNATURES = {
     "srl_conv2d_nhwc_wgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_conv2d_dgrad_weight_elems": (c_int64, [_CD]),
     "srl_conv2d_dgrad_repack": (c_int, [c_void_p, _CD, c_void_p, c_void_p]),
-    "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 5),
+    "srl_conv2d_nhwc_dgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 5 + [c_int]),
     "srl_conv2d_obs_fwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 11 + [c_int]),
     "srl_conv2d_obs_row_index_supported": (c_int, [_CD, c_int, c_int]),
     "srl_conv2d_obs_fwd_workspace": (c_int64, [_CD]),
@@ -496,20 +497,34 @@ def categorical_sample(logits, avail, is_eval, head_dims, seed, offset, action_o
         "srl_categorical_sample")
 
 
+def gemm_two_piece(M, N, K, A, lda, B, ldb, a_absmax, b_absmax) -> bool:
+    """Whether ``gemm`` sends this product to the two-plane f16 kernel (mirrors gemm.hip): only then may B be handed over
+    pre-split (``presplit``)."""
+    small = M * N <= 65536 and 4 <= K <= 512 and os.environ.get("SRL_SMALL_GEMM", "1")[:1] != "0"  # 64 x 64 tiles, three bf16 pieces
+    return (a_absmax is not None and b_absmax is not None and M > 64 and N > 64 and K >= 64 and A % 16 == 0 and B % 16 == 0 and
+            lda % 4 == 0 and ldb % 4 == 0 and f16x2_enabled() and not small and os.environ.get("SRL_MFMA", "")[:1] != "f")
+
+
+def presplit(src_ptr, absmax_ptr, dst_ptr, n):
+    """dst = the two f16 pieces of src (float32, n a multiple of 4) under the scale of *absmax, 16 bytes per 4 elements: a B
+    operand split once instead of in every tile that stages it (``gemm(..., b_presplit=True)``, ``conv2d_nhwc_fwd /
+    dgrad(..., presplit=True)``)."""
+    _check(lib().srl_presplit(_stream(), src_ptr, absmax_ptr, dst_ptr, n), "srl_presplit")
+
+
 def gemm(M, N, K, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, bias=None, act=ACT_NONE, dact_src=None, ld_dact=0,
          dact=ACT_NONE, accumulate=False, split_k=1, workspace=None, a_colsum=None, a_absmax=None, b_absmax=None,
-         out_absmax=None, mask_out=None, dact_mask=None):
+         out_absmax=None, mask_out=None, dact_mask=None, b_presplit=False):
     """Raw-pointer GEMM (``A``/``B``/``C``/... are ints from ``data_ptr()`` possibly with byte offsets).
     ``a_colsum``: [M] += sum_k A(i, k) as a by-product (k-major, float4-stageable A; see ``gemm_colsum_ok``).
     ``a_absmax`` / ``b_absmax``: device floats bounding max |A|, max |B| (both given: the two-plane f16 forward kernel);
     ``out_absmax``: device float folded with max |C|.  ``mask_out`` / ``dact_mask``: sign-bit masks of a ReLU output
-    (written by the forward product; read by a data gradient instead of ``dact_src``'s floats: srl_hip.h)."""
+    (written by the forward product; read by a data gradient instead of ``dact_src``'s floats: srl_hip.h).
+    ``b_presplit``: B is ``presplit``'s output (only where ``gemm_two_piece`` says so)."""
     d = GemmDesc(M, N, K, A, lda, int(a_kmajor), B, ldb, int(b_kmajor), C, ldc, bias, int(act), dact_src, ld_dact,
                  int(dact), int(accumulate), int(split_k), workspace, a_colsum, a_absmax, b_absmax, out_absmax,
-                 mask_out, dact_mask)
-    small = M * N <= 65536 and 4 <= K <= 512 and os.environ.get("SRL_SMALL_GEMM", "1")[:1] != "0"  # 64 x 64 tiles, three bf16 pieces
-    two = (a_absmax is not None and b_absmax is not None and M > 64 and N > 64 and K >= 64 and A % 16 == 0 and B % 16 == 0 and
-           lda % 4 == 0 and ldb % 4 == 0 and f16x2_enabled() and not small)  # mirrors gemm.hip's choice of the two-plane f16 kernel
+                 mask_out, dact_mask, int(bool(b_presplit)))
+    two = gemm_two_piece(M, N, K, A, lda, B, ldb, a_absmax, b_absmax)
     with _scope("gemm", 2.0 * M * N * K, "2h" if two else "x3"):
         _check(lib().srl_gemm(_stream(), ctypes.byref(d)), "srl_gemm")
 
@@ -732,12 +747,18 @@ def conv2d_fwd_workspace(d: ConvDesc) -> int:
     return int(lib().srl_conv2d_fwd_workspace(ctypes.byref(d)))
 
 
+def conv2d_fwd_two_piece(d: ConvDesc, x_absmax, w_absmax) -> bool:
+    """Whether ``conv2d_nhwc_fwd`` takes the two-plane f16 kernel (mirrors conv.hip): only then may the weights be pre-split."""
+    return (x_absmax is not None and w_absmax is not None and d.Cout > 32 and d.Cin * d.KH * d.KW >= 64 and f16x2_enabled() and
+            os.environ.get("SRL_MFMA", "")[:1] != "f")
+
+
 def conv2d_nhwc_fwd(d: ConvDesc, x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax=None, w_absmax=None, y_absmax=None, y_mask=None,
-                    ws_ptr=None):
-    two = x_absmax is not None and w_absmax is not None and d.Cout > 32 and d.Cin * d.KH * d.KW >= 64 and f16x2_enabled()
+                    ws_ptr=None, presplit=False):
+    two = conv2d_fwd_two_piece(d, x_absmax, w_absmax)
     with _scope("conv_fwd", _conv_flops(d), "2h" if two else "x3"):
         _check(lib().srl_conv2d_nhwc_fwd(_stream(), ctypes.byref(d), x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax, w_absmax,
-                                         y_absmax, y_mask, ws_ptr), "srl_conv2d_nhwc_fwd")
+                                         y_absmax, y_mask, ws_ptr, int(bool(presplit))), "srl_conv2d_nhwc_fwd")
 
 
 MLP_MAX_LAYERS, MLP_MAX_WIDTH = 12, 128
@@ -797,12 +818,21 @@ def conv2d_dgrad_repack(d: ConvDesc, w_ptr, wt_ptr):
     _check(lib().srl_conv2d_dgrad_repack(_stream(), ctypes.byref(d), w_ptr, wt_ptr), "srl_conv2d_dgrad_repack")
 
 
+def conv2d_dgrad_two_piece(d: ConvDesc, dz_absmax, w_absmax) -> bool:
+    """Whether ``conv2d_nhwc_dgrad`` takes the two-plane f16 kernel for every parity class (mirrors conv.hip)."""
+    s = d.stride
+    uniform = d.KH % s == 0 and d.KW % s == 0 and d.H % s == 0 and d.W % s == 0
+    ncols = (s * s if uniform else 1) * d.Cin
+    return (dz_absmax is not None and w_absmax is not None and d.Cout % 16 == 0 and ncols > 32 and f16x2_enabled() and uniform and
+            os.environ.get("SRL_MFMA", "")[:1] != "f")
+
+
 def conv2d_nhwc_dgrad(d: ConvDesc, dz_ptr, wt_ptr, x_act_ptr, dact, dx_ptr, dz_absmax=None, w_absmax=None, dx_absmax=None,
-                      x_mask=None):
+                      x_mask=None, presplit=False):
     two = dz_absmax is not None and w_absmax is not None and d.Cout % 16 == 0 and f16x2_enabled()
     with _scope("conv_dgrad", _conv_flops(d), "2h" if two else "x3"):
         _check(lib().srl_conv2d_nhwc_dgrad(_stream(), ctypes.byref(d), dz_ptr, wt_ptr, x_act_ptr, int(dact), dx_ptr,
-                                           dz_absmax, w_absmax, dx_absmax, x_mask), "srl_conv2d_nhwc_dgrad")
+                                           dz_absmax, w_absmax, dx_absmax, x_mask, int(bool(presplit))), "srl_conv2d_nhwc_dgrad")
 
 
 def conv2d_obs_fwd_workspace(d: ConvDesc) -> int:

@@ -1278,3 +1278,60 @@ def test_mlp_chain_fused(rows, dims, acts):
     hip.mlp_bwd(arr, dx.data_ptr(), dims[0], rows, tape.data_ptr(), tld, ddy.data_ptr(), dims[-1])
     for got, ref, name in zip(dev_g, p64, [f"{k}{i}" for i in range(len(dims) - 1) for k in ("gamma", "beta", "w", "b")]):
         assert rel_close(got.cpu().numpy() - 0.5, ref.grad.numpy(), 2e-5, scale=float(ref.grad.abs().max()) + 1e-6), name
+
+
+def test_presplit_weights_give_the_same_bits():
+    """srl_presplit + b_presplit / presplit=True: a B operand split once instead of in every tile -- the same pieces, so the
+    same results bit for bit: dense forward and data-gradient orientations, the forward convolution, the strided and the
+    stride-1 data gradient (with sign masks); and a product that does not take the two-piece kernel refuses it."""
+    rng = np.random.default_rng(11)
+    M, N, K = 1000, 512, 3136
+    a, w = dev(rng.standard_normal((M, K)).astype(np.float32)), dev((rng.standard_normal((N, K)) * 0.02).astype(np.float32))
+    ar, wr = a.abs().max().reshape(1), w.abs().max().reshape(1)
+    w2 = torch.empty_like(w)
+    hip.presplit(w.data_ptr(), wr.data_ptr(), w2.data_ptr(), w.numel())
+    bias = dev(rng.standard_normal(N).astype(np.float32))
+    y0, y1 = torch.empty((M, N), device=DEV), torch.full((M, N), np.nan, device=DEV)
+    kw = dict(bias=bias.data_ptr(), act=1, a_absmax=ar.data_ptr(), b_absmax=wr.data_ptr())
+    assert hip.gemm_two_piece(M, N, K, a.data_ptr(), K, w.data_ptr(), K, ar.data_ptr(), wr.data_ptr())
+    hip.gemm(M, N, K, a.data_ptr(), K, 0, w.data_ptr(), K, 0, y0.data_ptr(), N, **kw)
+    hip.gemm(M, N, K, a.data_ptr(), K, 0, w2.data_ptr(), K, 0, y1.data_ptr(), N, b_presplit=True, **kw)
+    assert torch.equal(y0, y1)
+    dz = dev(rng.standard_normal((M, N)).astype(np.float32))
+    dzr = dz.abs().max().reshape(1)
+    g0, g1 = torch.empty((M, K), device=DEV), torch.full((M, K), np.nan, device=DEV)
+    hip.gemm(M, K, N, dz.data_ptr(), N, 0, w.data_ptr(), K, 1, g0.data_ptr(), K, a_absmax=dzr.data_ptr(), b_absmax=wr.data_ptr())
+    hip.gemm(M, K, N, dz.data_ptr(), N, 0, w2.data_ptr(), K, 1, g1.data_ptr(), K, a_absmax=dzr.data_ptr(), b_absmax=wr.data_ptr(),
+             b_presplit=True)
+    assert torch.equal(g0, g1)
+    with pytest.raises(hip.HipError, match="b_presplit"):  # no ranges: three bf16 pieces, which cannot take pre-split pieces
+        hip.gemm(M, N, K, a.data_ptr(), K, 0, w2.data_ptr(), K, 0, y1.data_ptr(), N, b_presplit=True)
+    for (n, H, Cin, k, s_, Cout) in ((600, 20, 32, 4, 2, 64), (600, 9, 64, 3, 1, 64)):
+        x = dev(np.maximum(rng.standard_normal((n, H, H, Cin)), 0).astype(np.float32))
+        cw = dev((rng.standard_normal((Cout, k, k, Cin)) / np.sqrt(k * k * Cin)).astype(np.float32))
+        cb = dev(rng.standard_normal(Cout).astype(np.float32))
+        d = hip.conv_desc(n, H, H, Cin, k, k, s_, Cout, act=1)
+        OH = (H - k) // s_ + 1
+        xr, cwr = x.abs().max().reshape(1), cw.abs().max().reshape(1)
+        cw2 = torch.empty_like(cw)
+        hip.presplit(cw.data_ptr(), cwr.data_ptr(), cw2.data_ptr(), cw.numel())
+        ya, yb = torch.empty((n, OH, OH, Cout), device=DEV), torch.full((n, OH, OH, Cout), np.nan, device=DEV)
+        assert hip.conv2d_fwd_two_piece(d, xr.data_ptr(), cwr.data_ptr())
+        hip.conv2d_nhwc_fwd(d, x.data_ptr(), cw.data_ptr(), cb.data_ptr(), ya.data_ptr(), x_absmax=xr.data_ptr(), w_absmax=cwr.data_ptr())
+        hip.conv2d_nhwc_fwd(d, x.data_ptr(), cw2.data_ptr(), cb.data_ptr(), yb.data_ptr(), x_absmax=xr.data_ptr(), w_absmax=cwr.data_ptr(),
+                            presplit=True)
+        assert torch.equal(ya, yb)
+        cdz = dev(rng.standard_normal((n, OH, OH, Cout)).astype(np.float32))
+        cdzr = cdz.abs().max().reshape(1)
+        wt = torch.empty(hip.conv2d_dgrad_weight_elems(d), device=DEV)
+        hip.conv2d_dgrad_repack(d, cw.data_ptr(), wt.data_ptr())
+        wt2 = torch.empty_like(wt)
+        hip.presplit(wt.data_ptr(), cwr.data_ptr(), wt2.data_ptr(), wt.numel())
+        xm = dev(_signbits(x.cpu().numpy()).view(np.int32))
+        da, db_ = torch.empty_like(x), torch.full_like(x, np.nan)
+        assert hip.conv2d_dgrad_two_piece(d, cdzr.data_ptr(), cwr.data_ptr())
+        hip.conv2d_nhwc_dgrad(d, cdz.data_ptr(), wt.data_ptr(), None, 1, da.data_ptr(), dz_absmax=cdzr.data_ptr(),
+                              w_absmax=cwr.data_ptr(), x_mask=xm.data_ptr())
+        hip.conv2d_nhwc_dgrad(d, cdz.data_ptr(), wt2.data_ptr(), None, 1, db_.data_ptr(), dz_absmax=cdzr.data_ptr(),
+                              w_absmax=cwr.data_ptr(), x_mask=xm.data_ptr(), presplit=True)
+        assert torch.equal(da, db_)
