@@ -402,8 +402,10 @@ def test_cnn_step_at_the_benchmarked_dispatch(kernels, frames, monkeypatch):
         # the first layer on the byte kernels, only the two heads (N = 6, N = 1) on the skinny kernels
         # (every one of them knows both operands' ranges -- tracked by the producing kernels -- and runs on two f16 pieces
         # per operand, `gemm2h`: conv2 / conv3 / FC x forward, weight gradient, data gradient)
-        assert counts["gemm_f32"] == 0 and counts["gemm3"] == 0, counts
-        assert counts["gemm2h"] == 2 * 9, counts
+        import os
+        if os.environ.get("SRL_F16X2", "1")[:1] != "0":  # (that A/B switch sends them back to three bf16 pieces: `gemm3`)
+            assert counts["gemm_f32"] == 0 and counts["gemm3"] == 0, counts
+            assert counts["gemm2h"] == 2 * 9, counts
         assert counts["obs_fwd_bf16"] == 2 and counts["obs_bwd_bf16"] == 2, counts
     else:
         assert counts["gemm3"] == 0 and counts["gemm2h"] == 0 and counts["obs_fwd_bf16"] == 0 and counts["obs_bwd_bf16"] == 0, counts
