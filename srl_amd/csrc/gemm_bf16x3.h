@@ -15,7 +15,7 @@
 // that is contiguous along k; ds_read_b64_tr_b16, the transposing LDS read of gfx950, for one that is contiguous along
 // the output index -- no transposing stores), and the MFMA loop.  The epilogue is the shared one.
 //
-// NP == 2 (experimental, forward products whose operands have a known range): two f16 pieces per operand instead of three
+// NP == 2 (every product whose operands both have a tracked range -- all contractions of the benchmarked update): two f16 pieces per operand instead of three
 // bf16 ones, a = h0 + h1 + O(2^-23 |a|) (h0 = f16(a s), h1 = f16(a s - h0), s a power of two that brings the operand into
 // f16's range; 11-bit significands: 22 bits in two planes), and the THREE products h0 h0' + h0 h1' + h1 h0' -- each exact
 // in the float32 accumulate (22 bits) -- instead of six: half the matrix-pipe cycles, two thirds of the LDS traffic, a
