@@ -1,0 +1,521 @@
+// Image-stationary convolutions over pre-split ("h2") activations (round 4).
+//
+// What round 3's implicit GEMMs and this round's first attempt (h2gemm.h's CONV mode: measured level with them, 476 / 315 us
+// for conv2 / conv3 forward) have in common: every tap of a convolution re-stages its patch rows into LDS, so the bytes
+// pushed into LDS are KH*KW/stride^2 times the input (4x conv2, 9x conv3) and a CU takes in only ~30 GB/s through that
+// path whatever feeds it (the same 1.45 us per 40-48 KB k-step with 3 or 4 stages in flight, with 12 or 24 MFMAs per
+// wavefront in it).  Here an image enters LDS ONCE (linear DMA, 1 KB per instruction, no address arithmetic) and every tap
+// reads its operand from there; the weights never enter LDS at all:
+//   * a wavefront keeps the weights of ITS 16 output channels in registers for the whole launch (16 x K f16 pairs: 128-144
+//     registers; persistent workgroups, one per CU, walk batches of images);
+//   * the positions operand of v_mfma_f32_16x16x32_f16 (16 positions x 32 channels) is two ds_read_b128 per piece product
+//     triple, at an address that is ONE lane register plus an immediate: images are stored PLANAR -- per 32-channel block,
+//     per group g of 8 channels (h2gemm.h's grouping) and per piece, an array of 16-byte entries indexed by pixel -- so a tap
+//     is a constant entry offset, 16 consecutive entries are 16 distinct bank groups whatever the tap (the 16-lane banking
+//     groups of ds_read_b128 mix two g: plane pitches are multiples of 256 B), and blocks of 16 output positions are cut
+//     along the INPUT grid's numbering (a block never wraps a row: positions beyond the output's width are idle lanes)
+//     which keeps every read conflict-free (brute-forced over all bases and taps: 4 LDS cycles per read);
+//   * a stride-2 layer's input is stored parity-class-major by its producer (class (y & 1, x & 1), then y >> 1, x >> 1):
+//     each tap then walks consecutive entries of one class, like a stride-1 layer;
+//   * the data gradients are the same kernel on a zero-bordered grid (the border is zeroed once, DMA lanes that would land
+//     on it are masked off) with the regrouped weights: conv3's as a 3x3 stride-1 problem on an 11x11 grid, conv2's as four
+//     2x2 stride-1 problems (one per parity class of the input pixel) sharing their positions operand, 128 "channels".
+//   No barrier inside a batch; one per batch (the next batch's DMA was issued a whole batch earlier).
+#pragma once
+#include "h2gemm.h"
+
+namespace srlh2 {
+
+typedef float h2_f32x4 __attribute__((ext_vector_type(4)));
+
+enum { H2C_F2 = 0, H2C_F3 = 1, H2C_D3 = 2, H2C_D2 = 3 };
+enum { H2S_LINEAR = 0, H2S_PLANAR = 1, H2S_ROWS = 2, H2S_ROWSWZ = 3 };  // where an LDS entry's 16 bytes come from
+enum { H2D_PLANAR = 0, H2D_ROWS = 1, H2D_F32_ROUTED = 2 };    // where a result goes
+
+// Geometry of one instantiation.  Output positions are enumerated as entries e = oy * GW + ox of the LDS grid (ox < OW,
+// oy < OH valid); the LDS entry of tap t for output entry e is e + tap_u(t); W's k-block of (tap t, channel block c) is
+// tap_k(t) * CB + c.
+template <int ID> struct H2Geo;
+
+// conv2 forward: 20x20x32 -> 9x9x64, 4x4 stride 2.  The input comes from the first layer, whose workgroups own ONE output
+// position over many samples: it can only write whole pixels (128-byte rows of h2p), not per-image planes.  So this layer's
+// image is h2p ROWS in parity-class-major pixel order, copied to LDS as it lies (pixel-major, linear DMA) with the 16-byte
+// slots of pixel P XOR-ed by sigma(P) = bit 1 of P -> slot bit 0, bit 2 of P -> slot bit 2 (one of the 192 bit-linear maps
+// under which 16 consecutive pixels read by the mixed-group lanes of a ds_read_b128 fall into 16 different bank groups); a
+// tap's address is then (lane base + tap offset) ^ a byte of a per-lane table: two vector operations per tap.
+template <> struct H2Geo<H2C_F2> {
+  static constexpr int CB = 1, NCH = 64, NTAP = 16, GW = 10, OH = 9, OW = 9, NPIX_L = 400, G = 1, PLANE_E = 400;
+  static constexpr int SRC = H2S_ROWSWZ, PAD = 0, SH = 20, SW = 20, SPIX = 400;
+  static constexpr int DST = H2D_PLANAR, OPIX = 81, OCH = 64;
+  static constexpr bool ZERO_BORDER = false;
+  __host__ __device__ static constexpr int tap_u(int t) { return (((t >> 2) & 1) * 2 + (t & 1)) * 100 + (t >> 3) * 10 + ((t & 3) >> 1); }
+  __host__ __device__ static constexpr int tap_k(int t) { return t; }
+};
+// conv3 forward: 9x9x64 (planar, 81 entries) -> 7x7x64, 3x3 stride 1; result as h2p rows for the Linear behind it
+template <> struct H2Geo<H2C_F3> {
+  static constexpr int CB = 2, NCH = 64, NTAP = 9, GW = 9, OH = 7, OW = 7, NPIX_L = 81, G = 3, PLANE_E = 256;
+  static constexpr int SRC = H2S_PLANAR, PAD = 0, SH = 9, SW = 9, SPIX = 81;
+  static constexpr int DST = H2D_ROWS, OPIX = 49, OCH = 64;
+  static constexpr bool ZERO_BORDER = false;
+  __host__ __device__ static constexpr int tap_u(int t) { return (t / 3) * 9 + t % 3; }
+  __host__ __device__ static constexpr int tap_k(int t) { return t; }
+};
+// conv3 data gradient: dz 7x7x64 (h2p rows) on an 11x11 zero-bordered grid -> dx 9x9x64 (planar); out (y, x) reads
+// grid (y + 2 - ky, x + 2 - kx)
+template <> struct H2Geo<H2C_D3> {
+  static constexpr int CB = 2, NCH = 64, NTAP = 9, GW = 11, OH = 9, OW = 9, NPIX_L = 121, G = 2, PLANE_E = 256;
+  static constexpr int SRC = H2S_ROWS, PAD = 2, SH = 7, SW = 7, SPIX = 49;
+  static constexpr int DST = H2D_PLANAR, OPIX = 81, OCH = 64;
+  static constexpr bool ZERO_BORDER = true;
+  __host__ __device__ static constexpr int tap_u(int t) { return (2 - t / 3) * 11 + (2 - t % 3); }
+  __host__ __device__ static constexpr int tap_k(int t) { return t; }
+};
+// conv2 data gradient: dz 9x9x64 (planar) on an 11x11 zero-bordered grid -> the four parity classes of dx 20x20x32, float32
+// NHWC; class-grid pixel (a, b) reads grid (a + 1 - dy, b + 1 - dx); 128 channels = (class, cin)
+template <> struct H2Geo<H2C_D2> {
+  static constexpr int CB = 2, NCH = 128, NTAP = 4, GW = 11, OH = 10, OW = 10, NPIX_L = 121, G = 2, PLANE_E = 256;
+  static constexpr int SRC = H2S_PLANAR, PAD = 1, SH = 9, SW = 9, SPIX = 81;
+  static constexpr int DST = H2D_F32_ROUTED, OPIX = 400, OCH = 32;
+  static constexpr bool ZERO_BORDER = true;
+  __host__ __device__ static constexpr int tap_u(int t) { return (1 - t / 2) * 11 + (1 - t % 2); }
+  __host__ __device__ static constexpr int tap_k(int t) { return t; }
+};
+
+struct H2ConvArgs {
+  const void* x;   // images (format per geometry)
+  const void* w;   // h2p rows [NCH][K]
+  const float* sx;
+  const float* sw;
+  int64_t n;       // images
+  const float* bias;  // [NCH] or null
+  int32_t act;        // 1 relu
+  void* out;
+  float* out_scale;        // h2 outputs: the scale used, written for the consumers
+  const float* bound_in;   // h2 outputs: max |x| ...
+  const float* bound_w;    // ... * max row 1-norm of w ...
+  const float* bound_b;    // ... + max |bias| (or null)
+  float* out_absmax;       // required
+  // ReLU sign bits.  "h2 order": one byte per group of 8 channels, bit j = element j of the group (h2p_elem), bytes in
+  // [image][pixel][32-block][group] order -- what a lane of these kernels holds.  "natural": bit c of the 32-bit word of a
+  // pixel's 32-channel block (what round 3's kernels write: the first layer's y_mask).
+  uint8_t* mask_out;       // forward kernels (F2, F3): h2 order, required
+  const void* mask_in;     // data gradients: the relu derivative at the OUTPUT elements, required: D3 reads h2 order, D2 natural order
+};
+
+#ifdef __HIPCC__
+
+// planar image bytes
+template <int ID> constexpr int h2c_src_img_bytes() { return H2Geo<ID>::SPIX * H2Geo<ID>::CB * 128; }
+template <int ID> constexpr int h2c_slot_bytes() { return H2Geo<ID>::CB * 8 * H2Geo<ID>::PLANE_E * 16; }  // (pixel-major: the same bytes)
+
+// x of lane ^ 32 (v_permlane32_swap: one vector operation, no LDS)
+__device__ __forceinline__ uint32_t h2_xor32(uint32_t x, bool upper) {
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+  typedef unsigned h2_u32x2 __attribute__((ext_vector_type(2)));
+  const h2_u32x2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return upper ? r[0] : r[1];
+#else
+  (void)upper;
+  return (uint32_t)__shfl_xor((int)x, 32);
+#endif
+}
+
+#ifndef SRL_H2C_SCHED
+#define SRL_H2C_SCHED 1
+#endif
+// timing experiments (wrong results): 1 no DMA after the first batches, 2 no MFMA chain, 4 no stores
+#ifndef SRL_H2C_DBG
+#define SRL_H2C_DBG 0
+#endif
+
+template <int ID, int NSLOT>
+__global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
+  using GE = H2Geo<ID>;
+  constexpr int CB = GE::CB, NKB = GE::NTAP * CB, NPL = CB * 8, PLANE_B = GE::PLANE_E * 16;
+  constexpr int SLOT = NPL * PLANE_B;
+  constexpr int NCG = GE::NCH / 16;              // channel groups of 16
+  constexpr int NPH = 8 / NCG;                   // position halves (8 wavefronts)
+  static_assert(NCG == 4 || NCG == 8, "");
+  constexpr int NE = (GE::OH - 1) * GE::GW + GE::OW;   // entries to walk per image
+  constexpr int NB_IMG = (NE + 15) / 16;               // blocks of 16 entries per image
+  constexpr int NBT = NB_IMG * GE::G;                  // blocks per batch
+  static_assert(NBT % NPH == 0, "blocks split evenly over the position halves");
+  constexpr int NDMA = SLOT / 1024;                    // DMA instructions per batch
+  constexpr int NDW = (NDMA + 7) / 8;                  // ... per wavefront
+  static_assert(SLOT % 1024 == 0, "");
+  constexpr int KROW = NKB * 128;                      // bytes of one row of w
+  constexpr int IMGB = h2c_src_img_bytes<ID>();
+  constexpr bool ROUTED = GE::DST == H2D_F32_ROUTED;
+  constexpr int OIMGB = GE::OPIX * GE::OCH * 4;        // output image bytes (every format: 4 bytes per element)
+  constexpr int MIMGB = GE::OPIX * GE::OCH / 8;        // mask bytes per output image
+  extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = wid % NCG, ph = wid / NCG;
+  const int p = lane & 15, quad = lane >> 4;
+  const bool up = quad >> 1;
+
+  // ---- this wavefront's weights: rows cg*16 + p, every k-block, both pieces: lane (channel p, group quad)
+  h2_f16x8 wf[NKB][2];
+  {
+    const uint8_t* wr = static_cast<const uint8_t*>(a.w) + (size_t)(cg * 16 + p) * KROW + quad * 32;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      wf[kb][0] = *reinterpret_cast<const h2_f16x8*>(wr + kb * 128);
+      wf[kb][1] = *reinterpret_cast<const h2_f16x8*>(wr + kb * 128 + 16);
+    }
+    // the loads are waited for HERE: otherwise the compiler places its counted vmcnt waits at the first use of each
+    // fragment, inside the batch loop, where they would also wait for the DMA of the NEXT batch (issued just before)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(wf[kb][0]), "+v"(wf[kb][1]));
+  }
+  const float inv = 1.f / (*a.sx * *a.sw);
+  float oscale = 1.f;
+  if (!ROUTED) {
+    float bound = *a.bound_in * *a.bound_w;
+    if (a.bound_b) bound += *a.bound_b;
+    oscale = h2_scale_for(bound);
+    if (blockIdx.x == 0 && tid == 0) *a.out_scale = oscale;
+  }
+  float bq[4] = {0.f, 0.f, 0.f, 0.f};  // bias of channels cg*16 + 4 quad + r
+  if (a.bias) {
+    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + cg * 16 + 4 * quad);
+    bq[0] = b4.x; bq[1] = b4.y; bq[2] = b4.z; bq[3] = b4.w;
+  }
+  const float lo = a.act == 1 ? 0.f : -3.0e38f;   // relu as a clamp: no branch in the epilogue
+  constexpr bool MASK_IN = ID == H2C_D3 || ID == H2C_D2, MASK_OUT = !MASK_IN;
+
+  if (GE::ZERO_BORDER) {  // borders are never written by the DMA (masked lanes): zero every slot once
+    for (int i = tid; i < NSLOT * SLOT / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+  }
+
+  const h2_i32x4 rx = h2_rsrc(a.x);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+  const long nbatch = (a.n + GE::G - 1) / GE::G;
+
+  // ---- DMA: instruction j = wid + 8 q fills LDS entries 64 j .. 64 j + 63 of a slot; entry = plane * PLANE_E + e,
+  // e = image * NPIX_L + grid cell.  Per-lane source offsets (relative to the batch's first image) and image numbers are
+  // batch-invariant: computed once.
+  uint32_t dvoff[NDW];
+  int dimg[NDW];   // image of the batch this lane's entry belongs to; -1: never loaded (border / padding)
+#pragma unroll
+  for (int q = 0; q < NDW; ++q) {
+    const int j = wid + 8 * q;
+    const int nent = j * 64 + lane;
+    if (GE::SRC == H2S_LINEAR) {
+      dvoff[q] = (uint32_t)(nent * 16);
+      dimg[q] = j < NDMA ? 0 : -1;
+    } else if (GE::SRC == H2S_ROWSWZ) {   // LDS slot (pixel P, position s) <- the pixel's slot s ^ sigma(P)
+      const int P = nent >> 3, sl = nent & 7;
+      dvoff[q] = (uint32_t)(P * 128 + 16 * (sl ^ (((P >> 1) & 1) | (((P >> 2) & 1) << 2))));
+      dimg[q] = j < NDMA ? 0 : -1;
+    } else {
+      const int plane = nent / GE::PLANE_E, e = nent - plane * GE::PLANE_E;
+      const int il = e / GE::NPIX_L, cell = e - il * GE::NPIX_L;
+      const int gy = cell / GE::GW, gx = cell - gy * GE::GW;
+      const int sy = gy - GE::PAD, sx = gx - GE::PAD;
+      const bool ok = j < NDMA && il < GE::G && (unsigned)sy < (unsigned)GE::SH && (unsigned)sx < (unsigned)GE::SW;
+      const int sp = sy * GE::SW + sx;
+      if (GE::SRC == H2S_PLANAR) dvoff[q] = (uint32_t)(il * IMGB + plane * (GE::SPIX * 16) + sp * 16);
+      else dvoff[q] = (uint32_t)((il * GE::SPIX + sp) * (CB * 128) + plane * 16);  // rows: the plane index IS the 16-byte slot of the pixel's row
+      dimg[q] = ok ? il : -1;
+      if (!ok) dvoff[q] = 0;
+    }
+  }
+  auto issue = [&](long b, int s) {
+    const long img0 = b * GE::G;
+    const int left = (int)(a.n - img0 < GE::G ? a.n - img0 : GE::G);  // images of this batch that exist
+    const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)(img0 * (long)IMGB));
+#pragma unroll
+    for (int q = 0; q < NDW; ++q) {
+      const uint32_t ldsa = __builtin_amdgcn_readfirstlane(lds0 + s * SLOT + (wid + 8 * q) * 1024);
+      if (dimg[q] >= 0 && dimg[q] < left)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(ldsa), "v"(dvoff[q]), "s"(rx), "s"(soff) : "memory");
+    }
+  };
+
+  // ---- per-lane output constants
+  const int g_out = 2 * (quad & 1) + (cg & 1), ocb = cg >> 1;
+  uint32_t lane_out;      // byte offset of this lane's store inside an output image, pixel (0, 0)
+  uint32_t lane_mout;     // byte offset of this lane's mask byte inside an image's mask, pixel 0
+  int pix_step_y, pix_step_x;   // output pixel index = oy * pix_step_y + ox * pix_step_x (+ class offset, folded into lane_out)
+  if (ROUTED) {
+    const int cls = cg >> 1, py = cls >> 1, px = cls & 1;
+    lane_out = (uint32_t)(((py * 20 + px) * GE::OCH + 16 * (cg & 1) + 4 * quad) * 4);
+    pix_step_y = 40; pix_step_x = 2;
+    lane_mout = 0;
+  } else {
+    lane_out = GE::DST == H2D_PLANAR ? (uint32_t)((((ocb * 4 + g_out) * 2 + (up ? 1 : 0)) * GE::OPIX) * 16)
+                                     : (uint32_t)(ocb * 128 + g_out * 32 + (up ? 16 : 0));
+    pix_step_y = GE::OW; pix_step_x = 1;
+    lane_mout = (uint32_t)(ocb * 4 + g_out);
+  }
+  constexpr int PIXB = ROUTED ? GE::OCH * 4 : (GE::DST == H2D_PLANAR ? 16 : GE::OCH * 4);   // bytes per output pixel step
+  const uint32_t lane_base = GE::SRC == H2S_ROWSWZ ? (uint32_t)(p * 128 + quad * 32) : (uint32_t)(quad * 2 * PLANE_B + p * 16);
+  // ROWSWZ: byte u of this table = 16 * sigma(P) for a pixel P = (block base, a multiple of 8) + p + u (mod 8)
+  uint32_t swz_lo = 0, swz_hi = 0;
+  if (GE::SRC == H2S_ROWSWZ) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = (p + u) & 7;
+      const uint32_t t = (uint32_t)((((k >> 1) & 1) | (((k >> 2) & 1) << 2)) * 16);
+      if (u < 4) swz_lo |= t << (8 * u);
+      else swz_hi |= t << (8 * (u - 4));
+    }
+  }
+  float amax = 0.f;
+
+  // ---- the deferred epilogue of a block: what the NEXT block's MFMA chain runs beside
+  struct Meta {
+    uint32_t pixoff;   // pixel index of this lane's position inside its image
+    bool ok;           // lane holds a real output
+    long img;          // image (uniform)
+  };
+  // Stores and the mask loads go through buffer descriptors whose extent is the tensor: a lane without a real output uses
+  // an out-of-range offset, which the hardware drops (stores) or answers with zero (loads) -- no divergent branch, so the
+  // whole epilogue stays in the basic block of the MFMA chain it is scheduled into.
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(a.n * OIMGB), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_mo = __builtin_amdgcn_make_buffer_rsrc(MASK_OUT ? (void*)a.mask_out : a.out, 0, (int)(a.n * MIMGB), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_mi = __builtin_amdgcn_make_buffer_rsrc(MASK_IN ? const_cast<void*>(a.mask_in) : a.out, 0,
+                                                                       (int)(ID == H2C_D3 ? a.n * MIMGB : a.n * GE::OPIX * 4), 0x00020000);
+  constexpr uint32_t OOB = 0x80000000u;
+  auto epilogue = [&](const h2_f32x4& acc, const Meta& m) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] * inv + bq[r], lo);
+    const bool ok = m.ok && !(SRL_H2C_DBG & 4);
+    const uint32_t img32 = (uint32_t)m.img;
+    if (MASK_IN) {
+      uint32_t bits;
+      if (ID == H2C_D3) {   // h2 order: byte of (pixel, block, group), this lane's nibble
+        const uint32_t off = m.ok ? m.pixoff * (GE::OCH / 8) + lane_mout : OOB;
+        bits = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(r_mi, off, img32 * (uint32_t)MIMGB, 0) >> (up ? 4 : 0);
+      } else {              // natural order: word of the pixel's 32 channels
+        const int cls = cg >> 1, py = cls >> 1, px = cls & 1;
+        const uint32_t off = m.ok ? (m.pixoff + py * 20 + px) * 4 : OOB;
+        bits = __builtin_amdgcn_raw_buffer_load_b32(r_mi, off, img32 * (uint32_t)(GE::OPIX * 4), 0) >> (16 * (cg & 1) + 4 * quad);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (bits >> r) & 1u ? v[r] : 0.f;
+    }
+    {
+      const float m4 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      amax = fmaxf(amax, m.ok ? m4 : 0.f);
+    }
+    const uint32_t ooff = ok ? m.pixoff * PIXB + lane_out : OOB;
+    typedef uint32_t h2_u32x4 __attribute__((ext_vector_type(4)));
+    if (ROUTED) {
+      h2_u32x4 d = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+      __builtin_amdgcn_raw_buffer_store_b128(d, r_out, ooff, img32 * (uint32_t)OIMGB, 0);
+    } else {
+      // two pieces of the four values; lanes (quad, quad ^ 2) complete each other's 16-byte chunks: the lower one ends up
+      // with the first pieces of elements 0..7 of group g_out, the upper one with the second pieces
+      uint32_t h0a, h0b, h1a, h1b;
+      h2_split_pair(v[0], v[1], oscale, h0a, h1a);
+      h2_split_pair(v[2], v[3], oscale, h0b, h1b);
+      const uint32_t r0 = h2_xor32(up ? h0a : h1a, up), r1 = h2_xor32(up ? h0b : h1b, up);
+      h2_u32x4 chunk;
+      chunk[0] = up ? r0 : h0a; chunk[1] = up ? r1 : h0b; chunk[2] = up ? h1a : r0; chunk[3] = up ? h1b : r1;
+      __builtin_amdgcn_raw_buffer_store_b128(chunk, r_out, ooff, img32 * (uint32_t)OIMGB, 0);
+      if (MASK_OUT) {
+        uint32_t nib = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+        const uint32_t other = h2_xor32(nib, up);
+        const uint32_t moff = (ok && !up) ? m.pixoff * (GE::OCH / 8) + lane_mout : OOB;
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(nib | (other << 4)), r_mo, moff, img32 * (uint32_t)MIMGB, 0);
+      }
+    }
+  };
+
+  // ---- one block: 3 NKB MFMAs on the block's entries, fragments fetched PD k-blocks ahead (LDS latency is ~4-8 MFMAs), with
+  // the PREVIOUS block's epilogue inside the chain -- early in it for wavefronts 0-3, in the middle for wavefronts 4-7: the two
+  // wavefronts of a SIMD (w, w + 4) run the same code between the same barriers, and what overlaps one's vector work and
+  // stores is the other's matrix work.  (sched_group_barrier was tried for a per-instruction interleave: with the directives
+  // in the block the compiler placed a vector write to a store's data register directly behind the store -- a missing wait
+  // state, wrong results -- so the order is written out in the source instead.)
+  constexpr int PD = CB == 1 ? 3 : 2;
+  const bool late = wid >= 4;
+  auto block = [&](const uint8_t* xb, h2_f32x4& pacc, Meta& pm, const Meta& nm) {
+    h2_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    h2_f16x8 xr[PD + 1][2];
+    auto fetch = [&](int kb) {
+      const int t = kb / CB, c = kb - t * CB;
+      if (GE::SRC == H2S_ROWSWZ) {
+        const int U = GE::tap_u(t), u8 = U & 7;
+        const uint32_t x = ((u8 < 4 ? swz_lo : swz_hi) >> (8 * (u8 & 3))) & 0xffu;
+        const uint32_t a0 = (uint32_t)(uintptr_t)(xb + U * 128);
+        const uint8_t* q0 = xb + U * 128 + (long)((a0 ^ x) - a0);          // same address with bits 4 and 6 flipped by x
+        const uint8_t* q1 = xb + U * 128 + (long)((a0 ^ x ^ 16u) - a0);
+        xr[kb % (PD + 1)][0] = *reinterpret_cast<const h2_f16x8*>(q0);
+        xr[kb % (PD + 1)][1] = *reinterpret_cast<const h2_f16x8*>(q1);
+      } else {
+        const int off = (c * 8) * PLANE_B + GE::tap_u(t) * 16;
+        xr[kb % (PD + 1)][0] = *reinterpret_cast<const h2_f16x8*>(xb + off);
+        xr[kb % (PD + 1)][1] = *reinterpret_cast<const h2_f16x8*>(xb + off + PLANE_B);
+      }
+    };
+#pragma unroll
+    for (int kb = 0; kb < PD; ++kb) fetch(kb);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb + PD < NKB) fetch(kb + PD);
+      if (kb == 1 && !late) epilogue(pacc, pm);
+      if (kb == NKB / 2 + 1 && late) epilogue(pacc, pm);
+      const int t = kb / CB, c = kb - t * CB;
+      const int kw = GE::tap_k(t) * CB + c;
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kw][1], xr[kb % (PD + 1)][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kw][0], xr[kb % (PD + 1)][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kw][0], xr[kb % (PD + 1)][0], acc, 0, 0, 0);
+    }
+    pacc = acc;
+    pm = nm;
+  };
+
+  h2_f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+  Meta pm = {0u, false, 0};
+  // this lane's entry inside a block, walked block by block: (oy, ox) of entry 16 bi + p
+  auto compute = [&](long b, int s) {
+    const uint8_t* slot = lds + s * SLOT + lane_base;
+    for (int jb = ph * (NBT / NPH); jb < (ph + 1) * (NBT / NPH); ++jb) {
+      const int il = jb / NB_IMG, bi = jb - il * NB_IMG;
+      const int e = bi * 16 + p;
+      const int oy = (e * (65536 / GE::GW + 1)) >> 16, ox = e - oy * GE::GW;   // e < 128
+      Meta nm;
+      nm.img = b * GE::G + il;
+      nm.ok = ox < GE::OW && oy < GE::OH && nm.img < a.n;
+      nm.pixoff = (uint32_t)(oy * pix_step_y + ox * pix_step_x);
+      if (SRL_H2C_DBG & 2) { epilogue(pacc, pm); pm = nm; continue; }
+      block(slot + (il * GE::NPIX_L + bi * 16) * (GE::SRC == H2S_ROWSWZ ? 128 : 16), pacc, pm, nm);
+    }
+  };
+
+  // ring of NSLOT slots: batches b, b + grid, ... of this workgroup; the DMA of the batch NSLOT-1 ahead is issued right
+  // after the barrier that frees its slot.  The last block's stores of a batch are issued inside the NEXT batch's first
+  // block, so the vmcnt(0) at the top of a batch rarely waits for a store.
+  long b = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < NSLOT - 1; ++s)
+    if (b + (long)s * gridDim.x < nbatch) issue(b + (long)s * gridDim.x, s);
+  int s_cur = 0, s_nxt = NSLOT - 1;
+  for (; b < nbatch; b += gridDim.x) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const long bn = b + (long)(NSLOT - 1) * gridDim.x;
+    if (bn < nbatch && !(SRL_H2C_DBG & 1)) issue(bn, s_nxt);
+    compute(b, s_cur);
+    s_cur = s_cur + 1 == NSLOT ? 0 : s_cur + 1;
+    s_nxt = s_nxt + 1 == NSLOT ? 0 : s_nxt + 1;
+  }
+  epilogue(pacc, pm);
+  {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0) {
+      const float cur = __hip_atomic_load(a.out_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (amax > cur) atomicMax(reinterpret_cast<int*>(a.out_absmax), __float_as_int(amax));
+    }
+  }
+}
+
+template <int ID, int NSLOT = 2>
+inline int h2conv_launch(hipStream_t st, const H2ConvArgs& a, int max_blocks = 256) {
+  constexpr int SLOT = h2c_slot_bytes<ID>();
+  static_assert(NSLOT * SLOT <= 160 * 1024, "LDS");
+  static bool attr_set = false;
+  auto kern = h2conv_kernel<ID, NSLOT>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT);
+    attr_set = true;
+  }
+  const long nbatch = (a.n + H2Geo<ID>::G - 1) / H2Geo<ID>::G;
+  if (nbatch <= 0) return 0;
+  const long grid = nbatch < max_blocks ? nbatch : max_blocks;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), NSLOT * SLOT, st, a);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// float32 NHWC [n, H, W, C] -> planar h2 images [n][C/32][4][2][NPIX][16 B]; order 0: entry = y * W + x; order 2: parity-class
+// major (the layout a stride-2 consumer reads): entry = ((y & 1) * 2 + (x & 1)) * (H/2 * W/2) + (y >> 1) * (W/2) + (x >> 1)
+__host__ __device__ inline int h2_entry(int y, int x, int H, int W, int order) {
+  return order == 2 ? ((y & 1) * 2 + (x & 1)) * ((H / 2) * (W / 2)) + (y >> 1) * (W / 2) + (x >> 1) : y * W + x;
+}
+__global__ void h2_pack_planar_kernel(const float* __restrict__ src, int64_t n, int H, int W, int C, int order, const float* absmax,
+                                      const float* scale_in, float* scale_out, uint8_t* __restrict__ dst) {
+  const float scale = scale_in ? *scale_in : h2_scale_for(*absmax);
+  if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+  const int64_t ngrp = n * H * W * (C / 8);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ngrp; t += (int64_t)gridDim.x * blockDim.x) {
+    const int gi = (int)(t % (C / 8));
+    int64_t r = t / (C / 8);
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int64_t img = r / H;
+    const int blk = gi >> 2, g = gi & 3;
+    const float* s = src + ((img * H + y) * W + x) * C + blk * 32;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = s[h2p_elem(g, j)];
+    uint4 h0, h1;
+    h2_split_pair(v[0], v[1], scale, h0.x, h1.x);
+    h2_split_pair(v[2], v[3], scale, h0.y, h1.y);
+    h2_split_pair(v[4], v[5], scale, h0.z, h1.z);
+    h2_split_pair(v[6], v[7], scale, h0.w, h1.w);
+    const int NP = H * W, e = h2_entry(y, x, H, W, order);
+    uint8_t* d = dst + img * (int64_t)(NP * C * 4);
+    *reinterpret_cast<uint4*>(d + ((int64_t)((blk * 4 + g) * 2 + 0) * NP + e) * 16) = h0;
+    *reinterpret_cast<uint4*>(d + ((int64_t)((blk * 4 + g) * 2 + 1) * NP + e) * 16) = h1;
+  }
+}
+// float32 NHWC -> h2p rows [n][NPIX][C] with the pixels of an image in `order` (h2_entry)
+__global__ void h2_pack_pixrows_kernel(const float* __restrict__ src, int64_t n, int H, int W, int C, int order, const float* absmax,
+                                       const float* scale_in, float* scale_out, uint8_t* __restrict__ dst) {
+  const float scale = scale_in ? *scale_in : h2_scale_for(*absmax);
+  if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+  const int64_t ngrp = n * H * W * (C / 8);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ngrp; t += (int64_t)gridDim.x * blockDim.x) {
+    const int gi = (int)(t % (C / 8));
+    int64_t r = t / (C / 8);
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int64_t img = r / H;
+    const int blk = gi >> 2, g = gi & 3;
+    const float* s = src + ((img * H + y) * W + x) * C + blk * 32;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = s[h2p_elem(g, j)];
+    uint4 h0, h1;
+    h2_split_pair(v[0], v[1], scale, h0.x, h1.x);
+    h2_split_pair(v[2], v[3], scale, h0.y, h1.y);
+    h2_split_pair(v[4], v[5], scale, h0.z, h1.z);
+    h2_split_pair(v[6], v[7], scale, h0.w, h1.w);
+    uint4* d = reinterpret_cast<uint4*>(dst + ((img * (int64_t)(H * W) + h2_entry(y, x, H, W, order)) * C + blk * 32) * 4 + g * 32);
+    d[0] = h0;
+    d[1] = h1;
+  }
+}
+__global__ void h2_unpack_planar_kernel(const uint8_t* __restrict__ src, int64_t n, int H, int W, int C, int order, const float* scale,
+                                        float* __restrict__ dst) {
+  const float inv = 1.f / *scale;
+  const int64_t ngrp = n * H * W * (C / 8);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ngrp; t += (int64_t)gridDim.x * blockDim.x) {
+    const int gi = (int)(t % (C / 8));
+    int64_t r = t / (C / 8);
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int64_t img = r / H;
+    const int blk = gi >> 2, g = gi & 3;
+    const int NP = H * W, e = h2_entry(y, x, H, W, order);
+    const uint8_t* d = src + img * (int64_t)(NP * C * 4);
+    const _Float16* p0 = reinterpret_cast<const _Float16*>(d + ((int64_t)((blk * 4 + g) * 2 + 0) * NP + e) * 16);
+    const _Float16* p1 = reinterpret_cast<const _Float16*>(d + ((int64_t)((blk * 4 + g) * 2 + 1) * NP + e) * 16);
+    float* o = dst + ((img * H + y) * W + x) * C + blk * 32;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[h2p_elem(g, j)] = ((float)p0[j] + (float)p1[j]) * inv;
+  }
+}
+
+#endif  // __HIPCC__
+
+}  // namespace srlh2

@@ -1,0 +1,521 @@
+// Contractions over PRE-SPLIT operands (round 4): OUT^T[ch, pos] = sum_k W[ch, k] X[pos, k], both operands stored as two f16
+// pieces per element ("h2p" format, below), staged into LDS by the DMA path (buffer_load ... lds: no register, no vector
+// operation and no LDS store instruction is spent on staging), consumed by 32x32x16 f16 MFMAs as the three piece products
+// h0 h0' + h0 h1' + h1 h0' (gemm_bf16x3.h: exact in the float32 accumulate).
+//
+// Why: the round-3 kernels (gemm3_kernel) were staging-bound -- every tile loaded float32 operands into registers, split
+// them (2.5 vector operations per element) and wrote the planes to LDS with ds_write_b64 (85 B/clk/CU); leaving the in-loop
+// loads out gained 30-42 %, the split 7-28 %.  Here an activation is split ONCE, by the epilogue of the kernel that produces
+// it (same 4 bytes per element in HBM as the float32 it replaces), weights once per update, and the consumers move bytes.
+//
+// h2p format of a tensor whose innermost extent C is a multiple of 32: every aligned block of 32 elements is 128 bytes =
+// 4 groups x { 8 first pieces (16 B), 8 second pieces (16 B) }; group g holds elements base(g) + {0,1,2,3, 8,9,10,11} of the
+// block, base(g) = 4 (g >> 1) + 16 (g & 1).  That order is what a 32x32 MFMA accumulator holds per lane when the block index
+// is the accumulator's ROW index (lane half h, registers 0-7 / 8-15: groups 2h / 2h+1), so a producer stores 64 contiguous
+// bytes per lane with no cross-lane movement; a contraction does not care about the order of its summation index as long as
+// both operands agree, and both are h2p along k.  value = (h0 + h1) / scale, scale a power of two kept in a device float
+// beside the tensor (h2_scale_for: chosen from an upper BOUND of the tensor's magnitude that is known before the tensor is
+// produced -- max |x| max_row |w|_1 + max |b| -- so that a producer can split while it stores; f16 overflow is impossible by
+// construction; what a loose bound costs is absolute resolution of the small elements, 2^-25 / scale).
+//
+// Pipeline: a workgroup of 8 wavefronts owns NCB x 32 channels x 256 positions.  A k-step is 32 k-values: the X tile is 256
+// rows x 128 B, the W tile NCB*32 rows x 128 B, rows XOR-swizzled in 16-byte slots ((row >> 1) & 7: conflict-free
+// ds_read_b128 fragments) by permuting the SOURCE addresses of the DMA, whose LDS side is linear.  S stages form a ring;
+// step t+S-1 is issued right after the barrier of step t, completion is counted (s_waitcnt vmcnt(N), never 0 in the loop),
+// one raw s_barrier per step.  Wavefront w: position block w & 3 (64 positions), k-half w >> 2 (16 of the step's 32
+// k-values): each wavefront reads 4 + 4 fragments and issues 12 (NCB = 2) MFMAs per step; the two k-halves are added
+// through LDS once, after the loop.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace srlh2 {
+
+typedef _Float16 h2_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2_f16x2 __attribute__((ext_vector_type(2)));
+typedef float h2_f32x16 __attribute__((ext_vector_type(16)));
+typedef int h2_i32x4 __attribute__((ext_vector_type(4)));
+
+enum { H2X_DENSE = 0, H2X_CONV = 1, H2X_GROUPED = 2 };
+enum { H2O_F32 = 0, H2O_H2P = 1 };
+
+// element j (0..7) of group g (0..3) of a 32-block -> element index inside the block
+__host__ __device__ inline int h2p_elem(int g, int j) { return 4 * (g >> 1) + 16 * (g & 1) + (j & 3) + 8 * (j >> 2); }
+
+// power-of-two scale for a tensor bounded by `bound`: bound * scale in [2^14, 2^15)
+__host__ __device__ inline float h2_scale_for(float bound) {
+  if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
+  int e;
+  frexpf(bound, &e);  // bound = m 2^e, m in [0.5, 1)
+  int p = 15 - e;
+  if (p > 100) p = 100;
+  if (p < -100) p = -100;
+  return ldexpf(1.f, p);
+}
+
+struct H2Args {
+  const void* x;  // positions operand, h2p rows
+  const void* w;  // channels operand, h2p [NC][K]
+  const float* sx;  // device floats: scales of x and w
+  const float* sw;
+  int64_t M;        // positions (DENSE / CONV: rows; GROUPED: images)
+  int32_t NC;       // channels (rows of w), a multiple of 32
+  int32_t nk;       // k-steps of 32 (DENSE / CONV); GROUPED: taps * cbk
+  uint32_t w_row_bytes;  // K * 4
+  uint32_t x_row_bytes;  // DENSE: row pitch; CONV / GROUPED: image pitch (H * W * Cin * 4 / OH * OW * Cout * 4)
+  // CONV (forward): input H x W x Cin, output OH x OW, stride; taps KH x KW.  GROUPED (data gradient): "input" is dz
+  // [OH, OW, Cout], rows of a tile are images at ONE pixel (a, b) of the per-class grid GH x GW
+  int32_t H, W, C, OH, OW, stride, KH, KW;
+  int32_t GH, GW;       // GROUPED: pixel grid per parity class
+  int32_t tiles_c;      // channel tiles (NC / (NCB * 32))
+  uint32_t koff_x[64];  // CONV: byte offset of k-step t inside the image relative to the row's first pixel
+  uint32_t koff_w[64];  // CONV: byte offset of k-step t inside a row of w
+  // epilogue
+  const float* bias;     // [NC] or null
+  int32_t act;           // 1: relu
+  int32_t out_fmt;       // H2O_*
+  void* out;
+  uint32_t out_row_bytes;   // DENSE / CONV: pitch of an output row (position); GROUPED: image pitch
+  int32_t out_C;            // GROUPED: channels per pixel of the output (Cin of the layer); classes = NC / out_C
+  int32_t out_H, out_W;     // GROUPED: output image
+  float* out_scale;         // H2O_H2P: the scale this launch uses is written here (for the consumers)
+  const float* bound_in;    // H2O_H2P: device float, max |x| (measured by x's producer) ...
+  const float* bound_w;     // ... times this device float (max row 1-norm of w, in x's units) ...
+  const float* bound_b;     // ... plus this one (max |bias|, or null) bounds |out|
+  float* out_absmax;        // max |out| folded in (atomic max), or null
+  uint32_t* mask_out;       // relu sign bits of out, natural element order, or null
+  const uint32_t* mask_in;  // out *= bit of this mask at the output element (relu derivative), or null
+};
+
+#ifdef __HIPCC__
+
+__device__ __forceinline__ h2_i32x4 h2_rsrc(const void* p) {
+  const uint64_t a = (uint64_t)p;
+  h2_i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));
+  r[2] = -1;
+  r[3] = 0x00020000;
+  return r;
+}
+
+// NI DMA instructions of one wavefront into LDS at m0 = lds, lds + 8 KB, ...; instruction i reads 64 x 16 bytes at
+// rsrc + voff[i] + soff.  One statement: the compiler schedules nothing between the M0 writes and their readers.
+template <int NI>
+__device__ __forceinline__ void h2_dma(uint32_t lds, const uint32_t (&voff)[4], h2_i32x4 rsrc, uint32_t soff) {
+  static_assert(NI >= 1 && NI <= 4, "");
+  if (NI == 4)
+    asm volatile(
+        "s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds"
+        ::"s"(lds), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(rsrc), "s"(soff)
+        : "memory", "scc");
+  else if (NI == 2)
+    asm volatile(
+        "s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+        ::"s"(lds), "v"(voff[0]), "v"(voff[1]), "s"(rsrc), "s"(soff)
+        : "memory", "scc");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff[0]), "s"(rsrc),
+                 "s"(soff)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void h2_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// two f16 pieces of v * scale, packed: lo = pieces of a, hi = pieces of b
+__device__ __forceinline__ void h2_split_pair(float a, float b, float scale, uint32_t& p0, uint32_t& p1) {
+  const _Float16 a0 = (_Float16)__builtin_fmaf(a, scale, 0.f), b0 = (_Float16)__builtin_fmaf(b, scale, 0.f);
+  const _Float16 a1 = (_Float16)__builtin_fmaf(a, scale, -(float)a0), b1 = (_Float16)__builtin_fmaf(b, scale, -(float)b0);
+  union { h2_f16x2 h; uint32_t u; } x, y;
+  x.h = h2_f16x2{a0, b0};
+  y.h = h2_f16x2{a1, b1};
+  p0 = x.u;
+  p1 = y.u;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// float32 [rows, C] (pitch ld floats) -> h2p rows (pitch C * 4 bytes) under *scale_out = h2_scale_for(*absmax * (headroom))
+// One thread per group of 8 elements.  scale: if scale_in != null use *scale_in, else derive from *absmax and write *scale_out.
+__global__ void h2_pack_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int C, const float* absmax,
+                               const float* scale_in, float* scale_out, uint8_t* __restrict__ dst) {
+  const float scale = scale_in ? *scale_in : h2_scale_for(*absmax);
+  if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+  const int64_t ngrp = rows * (C / 8);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ngrp; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / (C / 8);
+    const int gi = (int)(t - row * (C / 8));
+    const int blk = gi >> 2, g = gi & 3;
+    const float* s = src + row * ld + blk * 32;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = s[h2p_elem(g, j)];
+    uint4 h0, h1;
+    h2_split_pair(v[0], v[1], scale, h0.x, h1.x);
+    h2_split_pair(v[2], v[3], scale, h0.y, h1.y);
+    h2_split_pair(v[4], v[5], scale, h0.z, h1.z);
+    h2_split_pair(v[6], v[7], scale, h0.w, h1.w);
+    uint4* d = reinterpret_cast<uint4*>(dst + (row * C + blk * 32) * 4 + g * 32);
+    d[0] = h0;
+    d[1] = h1;
+  }
+}
+
+// h2p rows -> float32 (tests, fallbacks)
+__global__ void h2_unpack_kernel(const uint8_t* __restrict__ src, int64_t rows, int C, const float* scale, float* __restrict__ dst,
+                                 int64_t ld) {
+  const float inv = 1.f / *scale;
+  const int64_t ngrp = rows * (C / 8);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ngrp; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / (C / 8);
+    const int gi = (int)(t - row * (C / 8));
+    const int blk = gi >> 2, g = gi & 3;
+    const _Float16* s = reinterpret_cast<const _Float16*>(src + (row * C + blk * 32) * 4 + g * 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[row * ld + blk * 32 + h2p_elem(g, j)] = ((float)s[j] + (float)s[8 + j]) * inv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NCB, int XMODE, int S>
+__global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
+  static_assert(NCB == 2 || NCB == 4, "64 or 128 channels per workgroup");
+  static_assert(S == 3 || S == 4, "ring depth");
+  constexpr int BP = 256;
+  constexpr int XT = BP * 128, WT = NCB * 32 * 128, STAGE = XT + WT;
+  constexpr int NWI = NCB / 2;    // W-tile DMA instructions per wavefront and step (NCB * 4 instructions over 8 wavefronts)
+  constexpr int L = 4 + NWI;      // DMA instructions per wavefront and step
+  extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wid & 3, kh = wid >> 2;
+  // logical tile id: every XCD owns one contiguous run
+  unsigned lid;
+  {
+    const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    lid = xcd * q + (xcd < r ? xcd : r) + slot;
+  }
+  const unsigned tile_c = lid % (unsigned)g.tiles_c, tile_p = lid / (unsigned)g.tiles_c;
+  const int c0 = tile_c * (NCB * 32);
+
+  // ---- X rows of this wavefront's DMA instructions: instruction q covers tile rows 8 (wid + 8 q) .. + 7, lane i -> row + (i >> 3),
+  // 16-byte slot (i & 7) ^ f(row)
+  uint32_t xv[4];
+  long m0 = 0;            // first position of the tile (DENSE / CONV) or first image (GROUPED)
+  uint32_t gsoff = 0;     // GROUPED: byte offset of the tile's pixel inside an image, before the tap
+  int ga = 0, gb = 0;     // GROUPED: the tile's pixel on the class grid
+  if (XMODE == H2X_GROUPED) {
+    const unsigned P = (unsigned)(g.GH * g.GW);
+    const unsigned ig = tile_p / P, p = tile_p - ig * P;
+    m0 = (long)ig * BP;
+    ga = p / g.GW;
+    gb = p - ga * g.GW;
+  } else {
+    m0 = (long)tile_p * BP;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = 8 * (wid + 8 * q) + (lane >> 3);
+    const int slot = (lane & 7) ^ ((row >> 1) & 7);
+    long m = m0 + row;
+    if (m >= g.M) m = g.M - 1;
+    uint32_t base;
+    if (XMODE == H2X_DENSE) base = (uint32_t)m * g.x_row_bytes;
+    else if (XMODE == H2X_GROUPED) base = (uint32_t)m * g.x_row_bytes;
+    else {
+      const uint32_t ohw = (uint32_t)(g.OH * g.OW);
+      const uint32_t img = (uint32_t)m / ohw, rem = (uint32_t)m - img * ohw;
+      const uint32_t oy = rem / (uint32_t)g.OW, ox = rem - oy * (uint32_t)g.OW;
+      base = img * g.x_row_bytes + ((oy * g.stride) * g.W + ox * g.stride) * (uint32_t)g.C * 4u;
+    }
+    xv[q] = base + 16u * slot;
+  }
+  uint32_t wv[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < NWI; ++q) {
+    const int row = 8 * (wid + 8 * q) + (lane >> 3);
+    const int slot = (lane & 7) ^ ((row >> 1) & 7);
+    int ch = c0 + row;
+    if (ch >= g.NC) ch = g.NC - 1;
+    wv[q] = (uint32_t)ch * g.w_row_bytes + 16u * slot;
+  }
+  const h2_i32x4 rx = h2_rsrc(g.x), rw = h2_rsrc(g.w);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+  const uint32_t lds_x = __builtin_amdgcn_readfirstlane(lds0 + wid * 1024);        // + stage * STAGE
+  const uint32_t lds_w = __builtin_amdgcn_readfirstlane(lds0 + XT + wid * 1024);
+
+  // ---- k-step sequence
+  int nsteps = g.nk;
+  uint64_t vmask = 0;  // GROUPED: valid taps
+  const int cbk = XMODE == H2X_GROUPED ? g.C / 32 : 1;
+  if (XMODE == H2X_GROUPED) {
+    // taps (dy, dx) of the per-class problem: dz position (ga - dy, gb - dx); class-uniform geometry (host checks)
+    const int TH = g.KH / g.stride, TW = g.KW / g.stride;
+    nsteps = 0;
+    for (int t = 0; t < TH * TW; ++t) {
+      const int dy = t / TW, dx = t - dy * TW;
+      if ((unsigned)(ga - dy) < (unsigned)g.OH && (unsigned)(gb - dx) < (unsigned)g.OW) { vmask |= 1ull << t; ++nsteps; }
+    }
+    nsteps *= cbk;
+    (void)gsoff;
+  }
+  int gt = -1, gcb = cbk - 1;  // GROUPED iterator state: current tap, channel block
+  auto step_offsets = [&](int t, uint32_t& sx, uint32_t& sw) {
+    if (XMODE == H2X_DENSE) {
+      sx = sw = (uint32_t)t * 128u;
+    } else if (XMODE == H2X_CONV) {
+      sx = g.koff_x[t];
+      sw = g.koff_w[t];
+    } else {
+      if (++gcb == cbk) {
+        gcb = 0;
+        gt = __builtin_ctzll(vmask);
+        vmask &= vmask - 1;
+      }
+      const int TW = g.KW / g.stride;
+      const int dy = gt / TW, dx = gt - dy * TW;
+      sx = (uint32_t)(((ga - dy) * g.OW + (gb - dx)) * g.C * 4 + gcb * 128);
+      sw = (uint32_t)((gt * cbk + gcb) * 128);
+    }
+  };
+  // the offsets of the step issued NEXT are fetched one issue early (CONV: scalar loads from the kernel arguments, whose
+  // latency would otherwise sit between the barrier and the DMA instructions of every step)
+  uint32_t nsx = 0, nsw = 0;
+  step_offsets(0, nsx, nsw);
+  auto issue_off = [&](uint32_t stage_off, int t) {
+    const uint32_t sx = __builtin_amdgcn_readfirstlane(nsx), sw = __builtin_amdgcn_readfirstlane(nsw);
+    h2_dma<4>(lds_x + stage_off, xv, rx, sx);
+    h2_dma<NWI>(lds_w + stage_off, wv, rw, sw);
+    if (t + 1 < nsteps) step_offsets(t + 1, nsx, nsw);
+  };
+  auto issue = [&](int stage, int t) { issue_off((uint32_t)stage * STAGE, t); };
+
+  h2_f32x16 acc[NCB][2];
+#pragma unroll
+  for (int i = 0; i < NCB; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: row r = lane & 31 of a 32-row block, group 2 kh + (lane >> 5), plane p: slot (2 g + p) ^ f(r)
+  const int fr_r = lane & 31, fr_f = (fr_r >> 1) & 7;
+  const int fr_off0 = fr_r * 128 + 16 * ((4 * kh + 2 * (lane >> 5)) ^ fr_f);
+  const int fr_off1 = fr_r * 128 + 16 * ((4 * kh + 2 * (lane >> 5) + 1) ^ fr_f);
+
+  auto compute = [&](uint32_t stage_off) {
+    const uint8_t* sx = lds + stage_off + wp * (64 * 128);
+    const uint8_t* sw = lds + stage_off + XT;
+    h2_f16x8 xf[2][2], wf[NCB][2];
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      wf[i][0] = *reinterpret_cast<const h2_f16x8*>(sw + i * 4096 + fr_off0);
+      wf[i][1] = *reinterpret_cast<const h2_f16x8*>(sw + i * 4096 + fr_off1);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      xf[j][0] = *reinterpret_cast<const h2_f16x8*>(sx + j * 4096 + fr_off0);
+      xf[j][1] = *reinterpret_cast<const h2_f16x8*>(sx + j * 4096 + fr_off1);
+    }
+    // small terms first
+#pragma unroll
+    for (int i = 0; i < NCB; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][1], xf[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NCB; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][0], xf[j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NCB; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][0], xf[j][0], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- ring: prologue S-1 steps, then per step { wait own DMA of step t; barrier; issue step t+S-1; compute step t }.
+  // At the wait of step t the steps up to t+S-2 have been issued: with (S-2) L instructions allowed in flight step t has
+  // landed (in-order completion); the last S-1 steps, with nothing left to issue, drain completely.
+  const int nk = nsteps;
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) issue(s, s);
+  uint32_t st_cur = 0, st_nxt = (S - 1) * STAGE;  // byte offsets of the stage being computed / being filled
+  for (int t = 0; t < nk; ++t) {
+    const bool more = t + (S - 1) < nk;
+    if (more) h2_wait_vm<L*(S - 2)>();
+    else h2_wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (more) issue_off(st_nxt, t + S - 1);
+    compute(st_cur);
+    st_cur = st_cur + STAGE == S * STAGE ? 0 : st_cur + STAGE;
+    st_nxt = st_nxt + STAGE == S * STAGE ? 0 : st_nxt + STAGE;
+  }
+
+  // ---- add the two k-halves: wavefront kh keeps channel blocks [kh * NCB/2, (kh+1) * NCB/2) and receives its partner's sums
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // every wavefront is past its last fragment read: the ring is free
+  constexpr int NH = NCB / 2;
+  h2_f32x16 fin[NH][2];
+  // (static register indices only: an accumulator array indexed by the runtime k-half would live in scratch memory)
+  auto exchange = [&](auto kh_c) {
+    constexpr int KH_ = decltype(kh_c)::value;
+    float4* ex = reinterpret_cast<float4*>(lds) + (size_t)wid * (NH * 2 * 4 * 64);
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const h2_f32x16& a = acc[(1 - KH_) * NH + i][j];
+          ex[((i * 2 + j) * 4 + q) * 64 + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+        }
+    __syncthreads();
+    const float4* ey = reinterpret_cast<const float4*>(lds) + (size_t)(wid ^ 4) * (NH * 2 * 4 * 64);
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = ey[((i * 2 + j) * 4 + q) * 64 + lane];
+          const h2_f32x16& a = acc[KH_ * NH + i][j];
+          fin[i][j][4 * q] = a[4 * q] + v.x;
+          fin[i][j][4 * q + 1] = a[4 * q + 1] + v.y;
+          fin[i][j][4 * q + 2] = a[4 * q + 2] + v.z;
+          fin[i][j][4 * q + 3] = a[4 * q + 3] + v.w;
+        }
+  };
+  if (kh == 0) exchange(std::integral_constant<int, 0>{});
+  else exchange(std::integral_constant<int, 1>{});
+
+  // ---- epilogue: lane = position (column), registers = channels (rows): r -> channel (r & 3) + 8 (r >> 2) + 4 h
+  const float inv = 1.f / (*g.sx * *g.sw);
+  float oscale = 1.f;
+  if (g.out_fmt == H2O_H2P) {
+    float bound = *g.bound_in * *g.bound_w;
+    if (g.bound_b) bound += *g.bound_b;
+    oscale = h2_scale_for(bound);
+    if (lid == 0 && tid == 0) *g.out_scale = oscale;
+  }
+  const int hl = lane >> 5, pl = lane & 31;
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int cb = c0 / 32 + kh * NH + i;  // global channel block
+    if (cb * 32 >= g.NC) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long row = m0 + wp * 64 + j * 32 + pl;  // position or image
+      const bool ok = row < g.M;
+      // output address of this (row, channel block)
+      uint8_t* optr;
+      long elem0;  // element index of channel 0 of the block (mask addressing)
+      if (XMODE == H2X_GROUPED) {
+        const int cpb = g.out_C / 32;  // channel blocks per class
+        const int cls = cb / cpb, cbl = cb - cls * cpb;
+        const int py = cls / g.stride, px = cls - py * g.stride;
+        const long pix = (long)(ga * g.stride + py) * g.out_W + (gb * g.stride + px);
+        elem0 = ((long)row * g.out_H * g.out_W + pix) * g.out_C + cbl * 32;
+        optr = static_cast<uint8_t*>(g.out) + elem0 * 4;
+      } else {
+        optr = static_cast<uint8_t*>(g.out) + (long)row * g.out_row_bytes + (long)cb * 128;
+        elem0 = ((long)row * g.out_row_bytes) / 4 + (long)cb * 32;
+      }
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = fin[i][j][r] * inv;
+      if (g.bias) {  // registers 4q .. 4q+3: channels 8q + 4 hl + {0..3} of the block
+        const float4* bq = reinterpret_cast<const float4*>(g.bias + cb * 32 + 4 * hl);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b4 = bq[2 * q];
+          v[4 * q] += b4.x; v[4 * q + 1] += b4.y; v[4 * q + 2] += b4.z; v[4 * q + 3] += b4.w;
+        }
+      }
+      if (g.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      }
+      if (g.mask_in) {
+        const uint32_t mw = ok ? g.mask_in[elem0 >> 5] : 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (!((mw >> ((r & 3) + 8 * (r >> 2) + 4 * hl)) & 1u)) v[r] = 0.f;
+      }
+      if (g.mask_out) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bits |= (v[r] > 0.f ? 1u : 0u) << ((r & 3) + 8 * (r >> 2) + 4 * hl);
+        bits |= (uint32_t)__shfl_xor((int)bits, 32);
+        if (ok && hl == 0) g.mask_out[elem0 >> 5] = bits;
+      }
+      if (g.out_absmax) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, ok ? fabsf(v[r]) : 0.f);
+      }
+      if (!ok) continue;
+      if (g.out_fmt == H2O_H2P) {
+        // registers 0-7: group 2 hl, registers 8-15: group 2 hl + 1; 64 contiguous bytes per lane
+        uint4 h0a, h1a, h0b, h1b;
+        h2_split_pair(v[0], v[1], oscale, h0a.x, h1a.x);
+        h2_split_pair(v[2], v[3], oscale, h0a.y, h1a.y);
+        h2_split_pair(v[4], v[5], oscale, h0a.z, h1a.z);
+        h2_split_pair(v[6], v[7], oscale, h0a.w, h1a.w);
+        h2_split_pair(v[8], v[9], oscale, h0b.x, h1b.x);
+        h2_split_pair(v[10], v[11], oscale, h0b.y, h1b.y);
+        h2_split_pair(v[12], v[13], oscale, h0b.z, h1b.z);
+        h2_split_pair(v[14], v[15], oscale, h0b.w, h1b.w);
+        uint4* d = reinterpret_cast<uint4*>(optr + hl * 64);
+        d[0] = h0a;
+        d[1] = h1a;
+        d[2] = h0b;
+        d[3] = h1b;
+      } else {
+        float* d = reinterpret_cast<float*>(optr);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(d + 8 * q + 4 * hl) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      }
+    }
+  }
+  if (g.out_absmax) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0) {
+      const float cur = __hip_atomic_load(g.out_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (amax > cur) atomicMax(reinterpret_cast<int*>(g.out_absmax), __float_as_int(amax));  // non-negative floats order as ints
+    }
+  }
+}
+
+template <int NCB, int XMODE, int S>
+inline int h2gemm_launch(hipStream_t st, H2Args a) {
+  constexpr int BP = 256;
+  constexpr int STAGE = BP * 128 + NCB * 32 * 128;
+  a.tiles_c = (a.NC + NCB * 32 - 1) / (NCB * 32);
+  long tiles_p;
+  if (XMODE == H2X_GROUPED) tiles_p = ((a.M + BP - 1) / BP) * (long)(a.GH * a.GW);
+  else tiles_p = (a.M + BP - 1) / BP;
+  const long nblk = tiles_p * a.tiles_c;
+  if (nblk <= 0 || nblk > 0x7fffffffL) return -22;
+  static bool attr_set = false;
+  auto kern = h2gemm_kernel<NCB, XMODE, S>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S * STAGE);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), S * STAGE, st, a);
+  return 0;
+}
+
+#endif  // __HIPCC__
+
+}  // namespace srlh2
