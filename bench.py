@@ -135,6 +135,42 @@ def gae_microbench(sample, targs, device, reps=200, big_B=None):
     return dict(ms=a.elapsed_time(b) / reps, work=19.0 * T * B + 7.0 * B)
 
 
+def mlp_roofline(device, T=128, B=4096, steps=10):
+    """The MLP the north star names, at the metric's batch: BASELINE configs[0]'s separate actor / critic 2 x 64 nets
+    (102.5 kFLOP per sample and epoch, forward + backward) over 4096 envs x 128 steps through the same trainer --
+    GAE scan, loss, optimiser included in the time, so the fraction is a floor for the contractions alone."""
+    from srl_amd import hip
+    from srl_amd.api import config, trainer as trainer_api
+    from srl_amd.runtime import synthetic
+    pol = dict(obs_dim=4, action_dim=2, hidden_dim=64, num_dense_layers=2, num_rnn_layers=0, popart=False, layernorm=False,
+               shared_backbone=False, seed=1)
+    tr = trainer_api.make(config.Trainer("mappo", args=dict(popart=False, optimizer_config=dict(lr=3e-4))),
+                          config.Policy("actor-critic-separate", args=pol))
+    arrays = synthetic.make_sample_arrays(seed=0, T=T, B=B, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05)
+    sample = synthetic.to_sample_batch({k: torch.from_numpy(v).to(device) for k, v in arrays.items()})
+    for _ in range(3):
+        tr.step(sample)
+    hip.dispatch_counts(reset=True)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(steps):
+        tr.step(sample)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    disp = hip.dispatch_counts(reset=True)
+    flops = 102.5e3 * T * B
+    ach = flops / (ms * 1e-3) / 1e12
+    return dict(kernel="actor / critic 2 x 64 MLPs (CartPole-shaped nets of BASELINE configs[0]) at 4096 envs x 128 steps, whole update",
+                bound="mfma", achieved=round(ach, 3), unit="TFLOP/s", peak=PEAK_FP32_MFMA_TFLOPS, frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 5),
+                ms_per_step=round(ms, 3), env_steps_per_s=round(T * B / (ms * 1e-3)), flops_per_step=flops, traffic=None,
+                kernel_family_launches={k: v // steps for k, v in disp.items()} if isinstance(disp, dict) else disp,
+                note="64-wide layers: 102.5 kFLOP per env-step against ~1 KB of activations moved, so the update is bound by its "
+                     "element-wise / LayerNorm-free chain and launch count long before the matrix pipe; frac is against the float32 "
+                     "MFMA peak (SURVEY 8d)")
+
+
 def physical_cores():
     """Physical cores this process may run on: distinct (package, core) pairs of the CPUs in its affinity mask."""
     try:
@@ -202,6 +238,11 @@ def cpu_baseline(T):
                        f"(= physical cores of the affinity mask; {logical} logical), median {med:.3f} s, min {mn:.3f} s")
 
 
+def _kernel_digest():
+    from srl_amd.provenance import kernel_sources_digest
+    return kernel_sources_digest()
+
+
 def recorded_traffic(kernel_substr, envs, T, chunk_rows):
     """HBM bytes per step of the kernels whose name contains one of `kernel_substr`, from the newest PMC passes committed
     under profiles/ (FETCH_SIZE and WRITE_SIZE in separate `rocprofv3 --pmc` runs of this script, FETCH_SIZE x2 per
@@ -218,6 +259,9 @@ def recorded_traffic(kernel_substr, envs, T, chunk_rows):
             meta = json.load(f)
         if (meta.get("envs"), meta.get("rollout_len"), meta.get("chunk_rows")) != (envs, T, chunk_rows):
             continue
+        if meta.get("kernel_sources") != _kernel_digest():   # a recording of other kernels says nothing about this run
+            return dict(traffic=None, traffic_note=f"newest PMC recording ({os.path.basename(mf)}) was taken from other kernel "
+                                                   f"sources ({meta.get('kernel_sources')} vs {_kernel_digest()}): not attached")
         total = 0.0
         with open(mf[:-5] + ".csv") as f:
             for r in csv.DictReader(f):
@@ -225,7 +269,8 @@ def recorded_traffic(kernel_substr, envs, T, chunk_rows):
                     per_launch = float(r["FETCH_bytes_per_launch_corrected_x2"]) + float(r["WRITE_bytes_per_launch"])
                     total += per_launch * float(r["dispatches"]) / meta["steps_in_run"]
         return dict(traffic=round(total), traffic_unit="HBM bytes per step (fetch + write) over the same launches",
-                    traffic_source=os.path.relpath(mf[:-5] + ".csv", here), traffic_commit=meta.get("commit"))
+                    traffic_source=os.path.relpath(mf[:-5] + ".csv", here), traffic_commit=meta.get("commit"),
+                    traffic_kernel_sources=meta.get("kernel_sources"))
     return dict(traffic=None, traffic_note="no PMC recording under profiles/ at this configuration")
 
 
@@ -244,6 +289,9 @@ def recorded_counters(envs, T, chunk_rows):
             meta = json.load(f)
         if (meta.get("envs"), meta.get("rollout_len"), meta.get("chunk_rows")) != (envs, T, chunk_rows):
             continue
+        if meta.get("kernel_sources") != _kernel_digest():
+            return dict(mfma_busy=None, counters_note=f"newest SQ counter recording ({os.path.basename(mf)}) was taken from other "
+                                                      "kernel sources: not attached")
         busy = cycles = valu = wait = wave = 0.0
         with open(mf[:-5] + ".csv") as f:
             for r in csv.DictReader(f):
@@ -260,7 +308,8 @@ def recorded_counters(envs, T, chunk_rows):
         simds = float(meta.get("simds", 1024))
         return dict(mfma_busy=round(busy / (simds * cycles), 4), valu_busy=round(valu / (simds * cycles), 4),
                     wait_share=round(wait / wave, 4) if wave else None,
-                    counters_source=os.path.relpath(mf[:-5] + ".csv", here), counters_commit=meta.get("commit"))
+                    counters_source=os.path.relpath(mf[:-5] + ".csv", here), counters_commit=meta.get("commit"),
+                    counters_kernel_sources=meta.get("kernel_sources"))
     return dict(mfma_busy=None, counters_note="no SQ counter recording under profiles/ at this configuration")
 
 
@@ -269,6 +318,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--seeds", default="0,1,2", help="data seeds of the resident leg (SURVEY 8d: 0, 1, 2); the first one feeds the other legs")
     ap.add_argument("--global-envs", type=int, default=GLOBAL_ENVS, help="B_global, fixed as N grows (strong scaling)")
     ap.add_argument("--rollout-len", type=int, default=128)
     ap.add_argument("--chunk-rows", type=int, default=16384)
@@ -329,7 +379,6 @@ def main():
         trainer.distributed(rank=rank, world_size=world, init_method="env://")
 
     T, B = args.rollout_len, args.global_envs // world
-    sample = device_sample(1000 + rank, T, B, device)
 
     def sync():
         if use_dist:
@@ -360,15 +409,30 @@ def main():
     def rate(el, steps):
         return T * B * world * steps / el
 
-    # ---- (1) the update with the whole sample resident in HBM ---------------------------------------------------------------
-    el_res, res = timed(lambda: trainer.step(sample), args.warmup, args.steps)
-    marks_res = sorted(step_marks)
-    resident = dict(value=rate(el_res, args.steps), unit="env-steps/s", ms_per_step=1e3 * el_res / args.steps, steps=args.steps,
+    # ---- (1) the update with the whole sample resident in HBM, data seeds 0, 1, 2 ---------------------------------
+    # one sample at a time (14.9 GB of frames each); the last one (seed 0 + rank offset) stays for the legs below
+    seeds = [int(s) for s in args.seeds.split(",")] if args.seeds else [0]
+    per_seed, all_marks, el_res, res = {}, [], 0.0, None
+    sample = None
+    for i, sd in enumerate(reversed(seeds)):   # ... so that seeds[0] is the sample the remaining legs run on
+        sample = None
+        torch.cuda.empty_cache()
+        sample = device_sample(1000 * sd + rank, T, B, device)
+        el, res = timed(lambda: trainer.step(sample), args.warmup if i == 0 else 2, args.steps)
+        ms = sorted(step_marks)
+        per_seed[str(sd)] = dict(ms_per_step=1e3 * el / args.steps, ms_per_step_median=ms[len(ms) // 2], ms_per_step_min=ms[0])
+        all_marks += ms
+        el_res += el
+    marks_res = sorted(all_marks)
+    n_res = args.steps * len(seeds)
+    resident = dict(value=rate(el_res, n_res), unit="env-steps/s", ms_per_step=1e3 * el_res / n_res, steps=n_res,
                     warmup=args.warmup, ms_per_step_median=marks_res[len(marks_res) // 2], ms_per_step_min=marks_res[0],
-                    note="whole sample, frames as a plain [Tb, B, 4, 84, 84] uint8 tensor, on the device before the timed region")
+                    data_seeds=seeds, per_seed=per_seed,
+                    note="whole sample, frames as a plain [Tb, B, 4, 84, 84] uint8 tensor, on the device before the timed region; "
+                         "median / min over the timed updates of every seed")
 
     # ---- untimed extra step with per-kernel HIP events (same stream as the launches) -----------------------
-    roofline = roofline_gae = breakdown = None
+    roofline = roofline_gae = roofline_mlp = breakdown = None
     if not args.no_profile:
         # EVERY rank takes this step (its collectives need all of them); only rank 0 wraps its launches in events
         prof = hip.KernelProfile() if rank == 0 else None
@@ -401,7 +465,11 @@ def main():
         roofline = dict(kernel="gemm3_kernel<...> / obs_*_bf16_kernel family (dense + implicit-conv launches of one step): "
                                "float32 operands and results through 16-bit piece products on the bf16 / f16 matrix cores",
                         bound="mfma", achieved=round(ach, 2), unit="TFLOP/s", peak=PEAK_BF16_MFMA_TFLOPS,
-                        executed=round(exe, 1), frac=round(exe / PEAK_BF16_MFMA_TFLOPS, 4),
+                        executed=round(exe, 1), frac=round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                        frac_basis="achieved (algorithmic float32 TFLOP/s) / peak of the pipe the work runs on (16-bit MFMA, dense)",
+                        mfma_issue_frac=round(exe / PEAK_BF16_MFMA_TFLOPS, 4),
+                        frac_of_emulation_ceiling=round(ach / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4),
+                        emulation_ceiling_basis="16-bit peak / 3: a float32 multiply-add costs at least three piece products",
                         achieved_basis="algorithmic float32 flops (2*M*N*K of every contraction)",
                         executed_basis="16-bit MFMA flops issued: 6 x algorithmic for three-bf16-piece products, 3 x for the "
                                        "two-f16-piece forward products and the byte-operand first layer",
@@ -435,10 +503,14 @@ def main():
                                            frac=round(big_gbs / PEAK_HBM_GBS, 4),
                                            us_per_launch=round(big["ms"] * 1e3, 1), algorithmic_bytes=big["work"]))
         breakdown = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+        try:
+            roofline_mlp = mlp_roofline(device)
+        except Exception as e:  # the secondary figure must not take the benchmark down
+            roofline_mlp = dict(error=repr(e))
 
     # ---- (2) the sample moves to pinned host memory: two slots of the ingest ring, [Tb, B] namedarray layout, wire dtypes ---
     pcie = fed = rollout_inf = None
-    ms_step = 1e3 * el_res / args.steps
+    ms_step = 1e3 * el_res / n_res
     if not args.no_from_host:
         Tb = T + 1
         template = recursive_apply(sample[:, 0], lambda x: x.cpu().numpy())
@@ -543,7 +615,8 @@ def main():
                                              "RCCL through the C ABI (srl_comm_*)" if getattr(trainer, "_comm", None) is not None
                                              else f"torch.distributed ({backend})"),
                                 policy_loss=res.stats.get("policy_loss")),
-                    roofline=roofline, roofline_gae=roofline_gae, kernel_ms_per_step=breakdown, resident_in_hbm=resident)
+                    roofline=roofline, roofline_gae=roofline_gae, roofline_mlp=roofline_mlp, kernel_ms_per_step=breakdown,
+                    resident_in_hbm=resident)
         if fed is not None:
             line["ring_fed"] = {k: v for k, v in fed.items() if k not in ("value", "ms_per_step", "ms_per_step_median", "ms_per_step_min")}
         if pcie is not None:

@@ -446,10 +446,11 @@ int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, in
  * ring slot, and this gather stands in for the SECOND host-to-device crossing of the same frames in
  * PyTorchGPUPrefetcher.push (api/trainer.py:211-228).  index: int32 [n] device, src rows addressed by slot. */
 int srl_gather_rows(void* stream, const void* src, int64_t row_bytes, const int32_t* index, int64_t n, void* dst);
-/* Ring sequence numbers (the int64 stamps a sample carries, all alive: checked by the caller on the host) -> storage
- * slots: slots[i] = refs[i] % capacity, on the device copy of the stamps, so that binding a sample costs the host two
- * passes over them (min / max) and no upload of its own. */
-int srl_ring_slots(void* stream, const int64_t* refs, int64_t n, int64_t capacity, int32_t* slots);
+/* Ring stamps (the int64 values a sample carries, all alive: checked by the caller on the host) -> storage slots:
+ * slots[i] = (refs[i] - base) % capacity, on the device copy of the stamps, so that binding a sample costs the host two
+ * passes over them (min / max) and no upload of its own.  base = what a stamp carries besides the sequence number (the
+ * ring's generation in its high bits, and the +1 that keeps 0 -- what a zero-filled sample field holds -- invalid). */
+int srl_ring_slots(void* stream, const int64_t* refs, int64_t n, int64_t capacity, int64_t base, int32_t* slots);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser on one flat parameter buffer.

@@ -12,10 +12,19 @@ recording made at its own configuration).  The passes themselves (interpreter di
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d <write_dir> -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-from-host --no-profile
 """
 import argparse
+import os
 import csv
 import glob
 import json
 import subprocess
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+
+def _digest():
+    from srl_amd.provenance import kernel_sources_digest
+    return kernel_sources_digest()
+
 from collections import defaultdict
 
 ap = argparse.ArgumentParser()
@@ -53,7 +62,7 @@ try:
 except OSError:
     commit = None
 meta = dict(envs=args.envs, rollout_len=args.rollout_len, chunk_rows=args.chunk_rows, steps_in_run=args.steps_in_run,
-            commit=commit, command="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 "
+            commit=commit, kernel_sources=_digest(), command="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 "
                                    "--no-cpu-baseline --no-from-host --no-profile")
 with open(args.out[:-4] + ".json", "w") as fh:
     json.dump(meta, fh, indent=1)

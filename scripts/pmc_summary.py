@@ -19,10 +19,19 @@ Normalisation (MI355X: 256 CUs x 4 SIMDs = 1024 SIMDs, 8 XCDs, 32 shader engines
   * valu_per_mfma = (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA (SQ_INSTS_VALU includes the MFMAs).
 """
 import argparse
+import os
 import csv
 import glob
 import json
 import subprocess
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+
+def _digest():
+    from srl_amd.provenance import kernel_sources_digest
+    return kernel_sources_digest()
+
 from collections import defaultdict
 
 ap = argparse.ArgumentParser()
@@ -76,7 +85,7 @@ else:
         commit = None
     with open(args.csv[:-4] + ".json", "w") as fh:
         json.dump(dict(envs=args.envs, rollout_len=args.rollout_len, chunk_rows=args.chunk_rows, steps_in_run=args.steps_in_run,
-                       commit=commit, simds=SIMDS, normalisation="mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8); "
+                       commit=commit, kernel_sources=_digest(), simds=SIMDS, normalisation="mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8); "
                        "see scripts/pmc_summary.py",
                        command="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY "
                                "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -- python3 bench.py --steps 1 --warmup 1 "

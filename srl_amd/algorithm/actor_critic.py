@@ -368,8 +368,11 @@ class ActorCriticPolicy(policy_api.Policy):
         is_eval = to_device_leaf(np.broadcast_to(is_eval, (n,)) if is_eval.size == 1 else is_eval, self.device, "flag")
         refs = None
         if self._obs_ring is not None:  # the rows stay in HBM for the trainer; the forward below reads them from there
-            refs, staged = self._obs_ring.put({k: obs[k] for k in self._obs_ring.keys()})
-            obs.update(staged)
+            # a ring full of rows a training step has leased does not fail the request: the rows go unstaged (stamp -1), the
+            # forward reads the batch's own rows, and the trainer uploads them from the sample when it binds it
+            refs, staged = self._obs_ring.put_or_skip({k: obs[k] for k in self._obs_ring.keys()})
+            if staged is not None:
+                obs.update(staged)
         rnn = None
         if self.spec.num_rnn_layers:
             rnn = self._rnn_ctx(NamedArray(**{k: v[None] for k, v in state.items()}), 1, n, None)

@@ -518,4 +518,319 @@ __global__ void h2_unpack_planar_kernel(const uint8_t* __restrict__ src, int64_t
 
 #endif  // __HIPCC__
 
+// =====================================================================================================================
+// Weight gradients, image-stationary:  dW[cout][tap][cin] += sum over images and positions dz[pos][cout] x[pos + tap][cin].
+// The summation index is the POSITION, which is the slow index of both operands as they lie in LDS (entries of 8 channels):
+// both MFMA operands are fetched with ds_read_b64_tr_b16 (4 positions x 16 channels per 16 lanes, delivered per channel).
+//   v_mfma_f32_16x16x32_f16: A = dz^T (16 output channels x 32 positions), B = x (32 positions x 16 input channels of one tap),
+//   D = 16 cout x 16 cin of that tap.  The 32 positions of a K-chunk are 32 consecutive entries of the INPUT grid's numbering
+//   (as in the forward kernel); dz is staged on that same grid with its unused columns zero, so a position that is not an
+//   output contributes nothing and needs no test.  Entry order inside a chunk: octet o, element e -> entry 4 o + e (e < 4),
+//   16 + 4 o + e - 4 (e >= 4): the 32 lanes of a transposed read then cover 8 consecutive entries of two channel groups,
+//   and with the planes of groups 2, 3 skewed by 128 bytes those are 32 distinct 8-byte bank slots.
+// Accumulators stay in registers over ALL images of a (persistent) workgroup: 16-18 tiles of 16x16 per wavefront; a launch
+// ends with one float32 slab [cout][K] (+ the bias gradient) per workgroup, summed by h2_wgrad_reduce_kernel.
+enum { H2W_C2 = 0, H2W_C3 = 1 };
+
+template <int ID> struct H2WGeo;
+// conv2: x = a1, h2p rows in parity-class-major pixel order (pixel-major in LDS, sigma-swizzled like the forward kernel);
+// dz = dz2 planar 9x9x64, staged on the 10-wide class grid.  Wavefront w: every cout block, taps 2w, 2w+1, both cin blocks.
+template <> struct H2WGeo<H2W_C2> {
+  static constexpr int CIN = 32, NTAP = 16, GW = 10, OH = 9, OW = 9, XPIX = 400, ZPIX = 81, ZW = 9;
+  static constexpr bool X_ROWS = true, Z_ROWS = false;
+  static constexpr int MC = 4, NN = 4;   // cout blocks x (tap, cin block) pairs per wavefront
+  __host__ __device__ static constexpr int tap_u(int t) { return (((t >> 2) & 1) * 2 + (t & 1)) * 100 + (t >> 3) * 10 + ((t & 3) >> 1); }
+};
+// conv3: x = a2 planar 9x9x64; dz = dz3, h2p rows [49][64], staged planar on the 9-wide grid.  Wavefront w: cout half w & 1,
+// 9 of the 36 (tap, cin block) pairs.
+template <> struct H2WGeo<H2W_C3> {
+  static constexpr int CIN = 64, NTAP = 9, GW = 9, OH = 7, OW = 7, XPIX = 81, ZPIX = 49, ZW = 7;
+  static constexpr bool X_ROWS = false, Z_ROWS = true;
+  static constexpr int MC = 2, NN = 9;
+  __host__ __device__ static constexpr int tap_u(int t) { return (t / 3) * 9 + t % 3; }
+};
+
+struct H2WgradArgs {
+  const void* x;    // activations of the layer's input
+  const void* dz;   // gradient of the layer's output (64 channels)
+  const float* sx;
+  const float* sz;
+  int64_t n;
+  float* slabs;     // [grid][64 * K + 64] float32: partial dW ([cout][tap][cin]) and db of each workgroup
+};
+
+#ifdef __HIPCC__
+
+typedef short h2_s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ h2_s16x4 h2_tr_read(const uint8_t* p) {
+  typedef __attribute__((address_space(3))) h2_s16x4 lds_s16x4;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+}
+
+template <int ID, int NSLOT>
+__global__ __launch_bounds__(512, 2) void h2wgrad_kernel(H2WgradArgs a) {
+  using GE = H2WGeo<ID>;
+  constexpr int CBX = GE::CIN / 32;                       // 32-channel blocks of x
+  constexpr int NE = (GE::OH - 1) * GE::GW + GE::OW;      // grid entries that can be outputs
+  constexpr int NCHUNK = (NE + 31) / 32;
+  constexpr int ZE = NCHUNK * 32;                         // dz grid entries staged per image (zero beyond the outputs)
+  constexpr int ZPLANE = ZE * 16;                         // bytes of one dz plane
+  constexpr int ZBYTES = 16 * ZPLANE + 128;               // 2 blocks x 4 groups x 2 pieces, groups 2, 3 skewed by 128 bytes
+  constexpr int XE = GE::X_ROWS ? GE::XPIX : ((GE::XPIX + 15) / 16) * 16;   // x entries per plane (planar) / pixels (rows)
+  constexpr int XPLANE = XE * 16;
+  constexpr int XBYTES = GE::X_ROWS ? GE::XPIX * 128 : CBX * 8 * XPLANE + 128;
+  constexpr int XB_AL = (XBYTES + 1023) / 1024 * 1024, ZB_AL = (ZBYTES + 1023) / 1024 * 1024;
+  constexpr int SLOT = XB_AL + ZB_AL;
+  constexpr int NDX = XB_AL / 1024, NDZ = ZB_AL / 1024, NDMA = NDX + NDZ, NDW = (NDMA + 7) / 8;
+  constexpr int K = GE::NTAP * GE::CIN;
+  constexpr int XIMGB = GE::XPIX * GE::CIN * 4, ZIMGB = GE::ZPIX * 64 * 4;
+  static_assert(NSLOT * SLOT <= 160 * 1024, "LDS");
+  extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int o = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+
+  // zero every slot once: the dz grid's unused entries (and the skew gaps) are never written by the DMA
+  for (int i = tid; i < NSLOT * SLOT / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  // ---- DMA: instruction j = wid + 8 qd; j < NDX fills x's region, the rest dz's.  Per-lane source offsets are
+  // batch-invariant; -1 marks lanes that never load.
+  const h2_i32x4 rx = h2_rsrc(a.x), rz = h2_rsrc(a.dz);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+  int dvoff[NDW];
+#pragma unroll
+  for (int qd = 0; qd < NDW; ++qd) {
+    const int j = wid + 8 * qd;
+    int off = -1;
+    if (j < NDX) {
+      const int b = j * 1024 + lane * 16;   // byte inside x's region
+      if (GE::X_ROWS) {
+        const int P = b >> 7, sl = (b >> 4) & 7;
+        if (P < GE::XPIX) off = P * 128 + 16 * (sl ^ (((P >> 1) & 1) | (((P >> 2) & 1) << 2)));
+      } else {
+        // plane pl_i = ((cb * 4 + g) * 2 + piece) at pl_i * XPLANE + (g >= 2 ? 128 : 0)
+        const int pl_i = b / XPLANE;
+        if (pl_i < CBX * 8) {
+          const int g = (pl_i >> 1) & 3;
+          const int e = (b - pl_i * XPLANE - (g >= 2 ? 128 : 0));
+          if (e >= 0 && (e >> 4) < GE::XPIX && b - (g >= 2 ? 128 : 0) >= pl_i * XPLANE) off = pl_i * (GE::XPIX * 16) + (e >> 4) * 16;
+        }
+      }
+    } else if (j < NDMA) {
+      const int b = (j - NDX) * 1024 + lane * 16;
+      // dz planes: index pl_i at pl_i * ZPLANE + (g >= 2 ? 128 : 0); entry = grid cell (oy, ox) of the GW-wide grid
+      int pl_i = b / ZPLANE;
+      if (pl_i > 15) pl_i = 15;
+      const int g = (pl_i >> 1) & 3;
+      int rel = b - pl_i * ZPLANE - (g >= 2 ? 128 : 0);
+      // the skew pushes the tail of plane pl_i into what would be plane pl_i + 1's first 128 bytes: attribute them back
+      if (rel < 0 && pl_i > 0) {
+        const int pp = pl_i - 1, gp = (pp >> 1) & 3;
+        const int relp = b - pp * ZPLANE - (gp >= 2 ? 128 : 0);
+        if (relp < ZPLANE) { pl_i = pp; rel = relp; }
+      }
+      if (rel >= 0 && rel < ZPLANE) {
+        const int e = rel >> 4, oy = e / GE::GW, ox = e - oy * GE::GW;
+        if (ox < GE::OW && oy < GE::OH) {
+          const int zp = oy * GE::ZW + ox;
+          off = GE::Z_ROWS ? zp * 256 + pl_i * 16 : pl_i * (GE::ZPIX * 16) + zp * 16;
+        }
+      }
+    }
+    dvoff[qd] = off;
+  }
+  auto issue = [&](long img, int s) {
+    const uint32_t sox = __builtin_amdgcn_readfirstlane((uint32_t)(img * (long)XIMGB));
+    const uint32_t soz = __builtin_amdgcn_readfirstlane((uint32_t)(img * (long)ZIMGB));
+#pragma unroll
+    for (int qd = 0; qd < NDW; ++qd) {
+      const int j = wid + 8 * qd;
+      const uint32_t ldsa = __builtin_amdgcn_readfirstlane(lds0 + s * SLOT + j * 1024);
+      if (dvoff[qd] >= 0) {
+        if (j < NDX) asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(ldsa), "v"(dvoff[qd]), "s"(rx), "s"(sox) : "memory");
+        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(ldsa), "v"(dvoff[qd]), "s"(rz), "s"(soz) : "memory");
+      }
+    }
+  };
+
+  // ---- operand addresses of this lane inside a slot.  A transposed read: lane 4 q + p of octet o names position 4 o + q
+  // (first read; + 16: second) and the 8 bytes of channels 4 p .. 4 p + 3 of a 16-channel block c16: group 2 (p & 1) + (c16 & 1),
+  // elements 4 (p >> 1) .. of its entry.
+  auto zplane = [&](int cb32, int g, int pl) { return ((cb32 * 4 + g) * 2 + pl) * ZPLANE + (g >= 2 ? 128 : 0); };
+  auto xplane = [&](int cb32, int g, int pl) { return ((cb32 * 4 + g) * 2 + pl) * XPLANE + (g >= 2 ? 128 : 0); };
+  const int ent = 4 * o + q, half8 = 8 * (p >> 1);
+  // cout blocks of this wavefront
+  const int mc0 = GE::MC == 4 ? 0 : (wid & 1) * 2;
+  const int nn0 = GE::MC == 4 ? wid * GE::NN : (wid >> 1) * GE::NN;   // first (tap, cin block) pair
+  uint32_t za[GE::MC];   // piece 0, chunk 0, read 0
+#pragma unroll
+  for (int m = 0; m < GE::MC; ++m) {
+    const int cbk = mc0 + m;
+    za[m] = (uint32_t)(XB_AL + zplane(cbk >> 1, 2 * (p & 1) + (cbk & 1), 0) + ent * 16 + half8);
+  }
+  // x: per cin block c16x of the pair (pair index nn -> tap = nn / (CIN/16), c16x = nn % (CIN/16))
+  constexpr int CPB = GE::CIN / 16;
+  uint32_t swz_lo = 0, swz_hi = 0;
+  if (GE::X_ROWS) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = (ent + u) & 7;
+      const uint32_t t = (uint32_t)((((k >> 1) & 1) | (((k >> 2) & 1) << 2)) * 16);
+      if (u < 4) swz_lo |= t << (8 * u);
+      else swz_hi |= t << (8 * (u - 4));
+    }
+  }
+
+  h2_f32x4 acc[GE::MC][GE::NN];
+#pragma unroll
+  for (int m = 0; m < GE::MC; ++m)
+#pragma unroll
+    for (int n2 = 0; n2 < GE::NN; ++n2) acc[m][n2] = h2_f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbs = 0.f;   // bias gradient of cout (lane & 15) of block mc0 (conv2: wavefronts 0..3 take block wid; conv3: 0, 1 take their two)
+
+  auto frag = [&](const uint8_t* p0, const uint8_t* p1) {
+    union { h2_s16x4 s[2]; h2_f16x8 v; } f;
+    f.s[0] = h2_tr_read(p0);
+    f.s[1] = h2_tr_read(p1);
+    return f.v;
+  };
+  auto compute = [&](int s) {
+    const uint8_t* slot = lds + s * SLOT;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+      h2_f16x8 af[GE::MC][2];
+#pragma unroll
+      for (int m = 0; m < GE::MC; ++m)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const uint8_t* b = slot + za[m] + pl * ZPLANE + c * 512;
+          af[m][pl] = frag(b, b + 256);
+        }
+      // bias gradient from the fragments a wavefront holds anyway (first pieces + second pieces of its 8 positions)
+      {
+        const bool mine = GE::MC == 4 ? wid < 4 : wid < 2;
+        if (mine) {
+#pragma unroll
+          for (int m = 0; m < GE::MC; ++m) {
+            if (GE::MC == 4 && m != (wid & 3)) continue;
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t += (float)af[m][0][e] + (float)af[m][1][e];
+            if (GE::MC == 4) dbs += t;
+            else if (m == 0) dbs += t;   // conv3: block mc0 here, block mc0 + 1 below
+          }
+        }
+      }
+#pragma unroll
+      for (int n2 = 0; n2 < GE::NN; ++n2) {
+        const int nn = nn0 + n2;   // wavefront-uniform at run time for conv3 (nn0 runtime) -> addresses computed, not immediates
+        const int tap = nn / CPB, c16x = nn - tap * CPB;
+        h2_f16x8 xf[2];
+        if (GE::X_ROWS) {
+          // tap_u needs a compile-time tap for the table index: conv2 has nn0 = 4 wid -> tap = 2 wid + (n2 >> 1): runtime.
+          // U mod 8 at run time: table byte selected with a shift
+          const int U = GE::tap_u(tap);
+          const int P0 = c * 32 + U;   // + ent (+16)
+          const uint32_t u8 = (uint32_t)(U & 7);
+          const uint32_t x = (uint32_t)(((((uint64_t)swz_hi << 32) | swz_lo) >> (8 * u8)) & 0xffu);
+          const uint32_t g0 = (uint32_t)((2 * (2 * (p & 1) + c16x)) * 16);
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            const uint32_t a0 = (uint32_t)((P0 + ent) * 128) + ((g0 + pl * 16) ^ x) + half8;
+            const uint32_t a1 = (uint32_t)((P0 + ent + 16) * 128) + ((g0 + pl * 16) ^ x) + half8;   // + 16 pixels: same low bits
+            xf[pl] = frag(slot + a0, slot + a1);
+          }
+        } else {
+          const int U = GE::tap_u(tap);
+          const int cb32 = c16x >> 1;
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            const uint32_t a0 = (uint32_t)(xplane(cb32, 2 * (p & 1) + (c16x & 1), pl) + (c * 32 + U + ent) * 16 + half8);
+            xf[pl] = frag(slot + a0, slot + a0 + 256);
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < GE::MC; ++m) {
+          acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][1], xf[0], acc[m][n2], 0, 0, 0);
+          acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][0], xf[1], acc[m][n2], 0, 0, 0);
+          acc[m][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][0], xf[0], acc[m][n2], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  long img = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < NSLOT - 1; ++s)
+    if (img + (long)s * gridDim.x < a.n) issue(img + (long)s * gridDim.x, s);
+  int s_cur = 0, s_nxt = NSLOT - 1;
+  for (; img < a.n; img += gridDim.x) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const long in = img + (long)(NSLOT - 1) * gridDim.x;
+    if (in < a.n) issue(in, s_nxt);
+    compute(s_cur);
+    s_cur = s_cur + 1 == NSLOT ? 0 : s_cur + 1;
+    s_nxt = s_nxt + 1 == NSLOT ? 0 : s_nxt + 1;
+  }
+
+  // ---- slab of this workgroup: dW[cout][tap][cin] (cout = 16 block + 4 (lane >> 4) + r, cin = 16 c16x + (lane & 15)), then db
+  const float inv = 1.f / (*a.sx * *a.sz);
+  float* slab = a.slabs + (size_t)blockIdx.x * (64 * K + 64);
+#pragma unroll
+  for (int m = 0; m < GE::MC; ++m)
+#pragma unroll
+    for (int n2 = 0; n2 < GE::NN; ++n2) {
+      const int nn = nn0 + n2, tap = nn / CPB, c16x = nn - tap * CPB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cout = 16 * (mc0 + m) + 4 * (lane >> 4) + r;
+        slab[(size_t)cout * K + tap * GE::CIN + c16x * 16 + (lane & 15)] = acc[m][n2][r] * inv;
+      }
+    }
+  {
+    // db: lane (cout i = lane & 15, octet o) summed over the 4 octets
+    float t = dbs;
+    t += __shfl_xor(t, 16);
+    t += __shfl_xor(t, 32);
+    const bool mine = GE::MC == 4 ? wid < 4 : wid < 2;
+    if (mine && lane < 16) slab[64 * K + 16 * (GE::MC == 4 ? wid : mc0) + lane] = t / *a.sz;
+  }
+}
+
+// dst[i] (+)= sum over slabs; i < 64 K: weight gradient, then 64 bias gradients
+__global__ void h2_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, int per_slab, int nw, float* __restrict__ gw,
+                                       float* __restrict__ gb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per_slab) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += slabs[(size_t)k * per_slab + i];
+  if (i < nw) gw[i] += s;
+  else if (gb) gb[i - nw] += s;
+}
+
+template <int ID, int NSLOT>
+inline int h2wgrad_launch(hipStream_t st, const H2WgradArgs& a, int grid) {
+  using GE = H2WGeo<ID>;
+  auto kern = h2wgrad_kernel<ID, NSLOT>;
+  constexpr int CBX = GE::CIN / 32;
+  constexpr int NE = (GE::OH - 1) * GE::GW + GE::OW, NCHUNK = (NE + 31) / 32, ZE = NCHUNK * 32;
+  constexpr int ZBYTES = 16 * ZE * 16 + 128;
+  constexpr int XE = GE::X_ROWS ? GE::XPIX : ((GE::XPIX + 15) / 16) * 16;
+  constexpr int XBYTES = GE::X_ROWS ? GE::XPIX * 128 : CBX * 8 * XE * 16 + 128;
+  constexpr int SLOT = (XBYTES + 1023) / 1024 * 1024 + (ZBYTES + 1023) / 1024 * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), NSLOT * SLOT, st, a);
+  return 0;
+}
+
+#endif  // __HIPCC__ (weight gradients)
+
 }  // namespace srlh2

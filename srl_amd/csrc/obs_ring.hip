@@ -29,19 +29,19 @@ __global__ __launch_bounds__(256) void gather_rows4_kernel(const uint32_t* __res
 }
 
 // ring sequence numbers -> storage slots
-__global__ __launch_bounds__(256) void ring_slots_kernel(const int64_t* __restrict__ refs, long n, long capacity,
+__global__ __launch_bounds__(256) void ring_slots_kernel(const int64_t* __restrict__ refs, long n, long capacity, long base,
                                                          int32_t* __restrict__ slots) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) slots[i] = (int32_t)(refs[i] % capacity);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) slots[i] = (int32_t)((refs[i] - base) % capacity);
 }
 
 }  // namespace
 
-extern "C" int srl_ring_slots(void* stream, const int64_t* refs, int64_t n, int64_t capacity, int32_t* slots) {
+extern "C" int srl_ring_slots(void* stream, const int64_t* refs, int64_t n, int64_t capacity, int64_t base, int32_t* slots) {
   SRL_CHECK_ARG(refs && slots && n >= 0 && capacity > 0 && capacity <= 0x7fffffffL, "null tensor / capacity out of range");
   if (n == 0) return 0;
   long blocks = srl_ceil_div(n, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(ring_slots_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, refs, (long)n, (long)capacity, slots);
+  hipLaunchKernelGGL(ring_slots_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, refs, (long)n, (long)capacity, (long)base, slots);
   SRL_LAUNCH_CHECK();
   return 0;
 }

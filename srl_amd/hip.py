@@ -141,7 +141,7 @@ _SIGNATURES = {
     "srl_copy2d": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int]),
     "srl_u8_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "srl_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
-    "srl_ring_slots": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "srl_ring_slots": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "srl_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "srl_grad_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
@@ -868,9 +868,9 @@ def gather_rows(src_ptr, row_bytes, index: torch.Tensor, n, dst_ptr):
                "srl_gather_rows")
 
 
-def ring_slots(refs: torch.Tensor, capacity: int, out: torch.Tensor):
-    """out[i] = refs[i] % capacity (``srl_ring_slots``): int64 stamps -> int32 storage slots, on the device."""
-    _check(lib().srl_ring_slots(_stream(), _ptr(refs, torch.int64, "refs"), refs.numel(), int(capacity),
+def ring_slots(refs: torch.Tensor, capacity: int, out: torch.Tensor, base: int = 0):
+    """out[i] = (refs[i] - base) % capacity (``srl_ring_slots``): int64 stamps -> int32 storage slots, on the device."""
+    _check(lib().srl_ring_slots(_stream(), _ptr(refs, torch.int64, "refs"), refs.numel(), int(capacity), int(base),
                                 _ptr(out, torch.int32, "slots")), "srl_ring_slots")
 
 

@@ -69,6 +69,7 @@ class SampleRing:
         self.obs_ring = obs_ring
         self._ring_keys = frozenset(f"obs.{k}" for k in obs_ring.keys()) & frozenset(leaves) if obs_ring is not None else frozenset()
         self._leases = [None] * self.slots
+        self._fallback_copied = [None] * self.slots  # event after the plain copies of a slot the observation ring could not serve
         self._stream = None
         self._lock = threading.Lock()
         self._free = deque(range(self.slots))
@@ -269,7 +270,13 @@ class SampleRing:
         refs_dev = self._dev[slot].get("analyzed_result.obs_ref") if self._dev[slot] is not None else None
         bound = self.obs_ring.bind(refs, host_obs, refs_device=refs_dev)
         if bound is None:
-            return {k: self._host[slot][k].to(self.device, non_blocking=True) for k in self._ring_keys}
+            # plain copies on the caller's stream, from this slot's pinned host block: `release` must not hand the block
+            # back to the producers before they (and whatever patch uploads a bind that failed midway had enqueued) are done
+            out = {k: self._host[slot][k].to(self.device, non_blocking=True) for k in self._ring_keys}
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._fallback_copied[slot] = ev
+            return out
         rows, lease = bound
         self._leases[slot] = lease
         return {f"obs.{k}": v for k, v in rows.items()}
@@ -303,6 +310,10 @@ class SampleRing:
         if ev is not None:
             ev.synchronize()
             self._copied[slot] = None
+        ev = self._fallback_copied[slot]
+        if ev is not None:
+            ev.synchronize()
+            self._fallback_copied[slot] = None
         if self._leases[slot] is not None:  # the observation rows may be lapped once the consumer's work has run
             lease, self._leases[slot] = self._leases[slot], None
             if lease.uploaded is not None:

@@ -30,6 +30,7 @@ trainer wants are the bytes the rollout already put in HBM.
 Sharding: one ring per GPU, holding the env columns that GPU both serves inference for and trains on.
 In-process (inference thread + trainer thread, as in the reference's local mode); thread-safe.
 """
+import itertools
 import threading
 from typing import Dict, Optional, Tuple
 
@@ -176,7 +177,12 @@ class _Circular:
         return seq
 
 
+_GENERATIONS = itertools.count(1)
+
+
 class ObsRing:
+    GEN_SHIFT = 44                      # sequence numbers below 2^44 rows (17 T): more than any run stages
+    SEQ_MASK = (1 << GEN_SHIFT) - 1
 
     def __init__(self, layout: Dict[str, tuple], raw_shape: Dict[str, Tuple[int, ...]], capacity_rows: int, device: str,
                  patch_rows: Optional[int] = None):
@@ -199,9 +205,18 @@ class ObsRing:
         self._patch = _Circular(self.patch_capacity)  # rows staged by `bind` for one lease: storage slots capacity + ...
         self._lock = threading.Lock()
         self._leases = []
-        self._release_events = []  # recorded on the readers' streams at release: the next writer waits for them
+        # Events recorded on the readers' streams at release; the next WRITER of a region waits for them before it stages
+        # rows there.  One list per region: the ring's writer is the inference stream, the patch area's writer is the
+        # trainer's own stream (where waiting on its own event orders nothing) -- with one shared list whichever allocator
+        # came first took the events away from the other, and a `put` could overwrite rows a released step still read.
+        self._release_events = {"ring": [], "patch": []}
         self._write_events = {}  # writer stream -> event after its last put
-        self.stats = dict(rows_put=0, rows_bound=0, rows_patched=0, binds=0, binds_failed=0)
+        # A stamp = generation << GEN_SHIFT | (sequence number + 1): 0 -- what a zero-filled `analyzed_result` of a step that
+        # never went through inference holds -- and negatives are dead by construction, and a stamp of another ring (a
+        # recreated ring, another policy worker's) does not decode in this one.
+        self.generation = int(next(_GENERATIONS))
+        self._stamp_base = (self.generation << self.GEN_SHIFT) + 1
+        self.stats = dict(rows_put=0, rows_bound=0, rows_patched=0, binds=0, binds_failed=0, puts_unstaged=0)
 
     @classmethod
     def for_policy(cls, policy, capacity_rows: int, patch_rows: Optional[int] = None) -> "ObsRing":
@@ -267,6 +282,12 @@ class ObsRing:
             else:
                 store[s0:s0 + n].copy_(t)
 
+    def _decode(self, refs: np.ndarray):
+        """Stamps -> (sequence numbers, mask of stamps that are this ring's at all)."""
+        mine = (refs >> self.GEN_SHIFT) == self.generation
+        low = refs & self.SEQ_MASK
+        return low - 1, mine & (low >= 1)
+
     def _wait_released(self, events):
         if events:  # readers that released earlier may still be running on their stream
             stream = torch.cuda.current_stream(self.device)
@@ -279,13 +300,14 @@ class ObsRing:
         with self._lock:
             floor = min((l.min_seq for l in self._leases if l.min_seq is not None), default=None)
             seq = self._ring.alloc(n, floor, "observation ring")
-            events, self._release_events = self._release_events, []
+            events, self._release_events["ring"] = self._release_events["ring"], []
         self._wait_released(events)
         return seq
 
     def put(self, obs: Dict[str, torch.Tensor]):
         """Stage one inference batch.  ``obs``: key -> device rows ``[n, *raw_shape]`` (uint8 or float32) for every key of
-        the ring.  Returns (sequence numbers int64 numpy ``[n]``, key -> ``RingObs`` over the new run of slots)."""
+        the ring.  Returns (stamps int64 numpy ``[n]``, key -> ``RingObs`` over the new run of slots).  Raises BufferError
+        when the run would lap rows a training step has leased (``put_or_skip`` for callers that must not fail)."""
         n = self._check_rows(obs)
         seq = self._alloc(n)
         s0 = seq % self.capacity
@@ -296,13 +318,26 @@ class ObsRing:
         with self._lock:
             self._write_events[stream.cuda_stream] = ev
             self.stats["rows_put"] += n
-        return np.arange(seq, seq + n, dtype=np.int64), {k: RingObs(self, k, (n,), span=s0) for k in self.layout}
+        return np.arange(seq, seq + n, dtype=np.int64) + self._stamp_base, {k: RingObs(self, k, (n,), span=s0) for k in self.layout}
+
+    def put_or_skip(self, obs: Dict[str, torch.Tensor]):
+        """``put``, or -- when the ring is full of leased rows (rollouts running beside a training step that holds a lease)
+        -- nothing staged: (stamps of -1, None).  The forward pass then reads the caller's own rows, and the trainer uploads
+        these rows from the sample's host copy when it binds it (a dead stamp)."""
+        try:
+            return self.put(obs)
+        except BufferError:
+            n = next(iter(obs.values())).shape[0]
+            with self._lock:
+                self.stats["puts_unstaged"] += 1
+            return np.full(n, -1, dtype=np.int64), None
 
     # ------------------------------------------------------------------ consumer side (trainer)
     def alive(self, refs: np.ndarray) -> np.ndarray:
         with self._lock:
             head = self._ring.head
-        return (refs >= 0) & (refs < head) & (refs + self.capacity >= head)
+        seq, mine = self._decode(np.asarray(refs, dtype=np.int64))
+        return mine & (seq < head) & (seq + self.capacity >= head)
 
     def _patch_rows(self, lease: ObsLease, rows: Dict[str, torch.Tensor]) -> np.ndarray:
         """Stage rows that are not alive in the ring into the patch area, for this lease only; returns their storage slots."""
@@ -316,7 +351,7 @@ class ObsRing:
                 lease.patch_start = seq
                 if lease not in self._leases:
                     self._leases.append(lease)
-            events, self._release_events = self._release_events, []
+            events, self._release_events["patch"] = self._release_events["patch"], []
         self._wait_released(events)
         s0 = self.capacity + seq % self.patch_capacity
         self._stage(rows, s0, n)
@@ -342,27 +377,31 @@ class ObsRing:
             refs = refs[..., 0]
         if refs.dtype != np.int64:
             refs = refs.astype(np.int64)
-        lo, hi = (int(refs.min()), int(refs.max())) if refs.size else (0, -1)
+        # every stamp this ring's own and alive <=> min and max carry its generation and their sequence numbers are alive
+        lo, hi = (int(refs.min()), int(refs.max())) if refs.size else (self._stamp_base, self._stamp_base - 1)
+        same_gen = (lo >> self.GEN_SHIFT) == self.generation and (hi >> self.GEN_SHIFT) == self.generation and (lo & self.SEQ_MASK) >= 1
+        lo, hi = (lo & self.SEQ_MASK) - 1, (hi & self.SEQ_MASK) - 1
         with self._lock:  # liveness and the lease in one step: no allocation can slip in between
             head = self._ring.head
-            if lo >= 0 and hi < head and lo + self.capacity >= head:  # the common case: every stamp alive
+            if same_gen and hi < head and lo + self.capacity >= head:  # the common case: every stamp alive
                 lease = ObsLease(self, lo)
                 self._leases.append(lease)
                 ok = None
             else:
-                ok = (refs >= 0) & (refs < head) & (refs + self.capacity >= head)
-                lease = ObsLease(self, int(refs[ok].min()) if ok.any() else None)
+                seq, mine = self._decode(refs)
+                ok = mine & (seq < head) & (seq + self.capacity >= head)
+                lease = ObsLease(self, int(seq[ok].min()) if ok.any() else None)
                 if lease.min_seq is not None:
                     self._leases.append(lease)
         stream = torch.cuda.current_stream(self.device)
         if ok is None:
             if refs_device is not None and refs_device.is_cuda and refs_device.dtype == torch.int64 and refs_device.is_contiguous():
                 index = torch.empty(refs.shape, dtype=torch.int32, device=self.device)
-                hip.ring_slots(refs_device, self.capacity, index)
+                hip.ring_slots(refs_device, self.capacity, index, base=self._stamp_base)
             else:
-                index = torch.from_numpy((refs % self.capacity).astype(np.int32)).to(self.device, non_blocking=True)
+                index = torch.from_numpy(((refs - self._stamp_base) % self.capacity).astype(np.int32)).to(self.device, non_blocking=True)
             return self._bound(keys, refs.shape, index, lease, stream, 0)
-        slots = np.where(ok, refs % self.capacity, -1)
+        slots = np.where(ok, seq % self.capacity, -1)
         patched = 0
         try:
             if not ok.all():
@@ -425,4 +464,5 @@ class ObsRing:
             if lease in self._leases:
                 self._leases.remove(lease)
             if ev is not None:
-                self._release_events.append(ev)
+                self._release_events["ring"].append(ev)
+                self._release_events["patch"].append(ev)

@@ -153,127 +153,6 @@ class FilesystemParameterDB(ParameterDBClient):
                 time.sleep(1)
             else:
                 raise missing
-        raise missing
-
-    def list_names(self):
-        raise NotImplementedError()
-
-    def clear(self, name=None):
-        raise NotImplementedError()
-
-    def gc(self, name, max_untagged_version_count=None, max_untagged_version_ttl=None):
-        raise NotImplementedError()
-
-    def push(self, name, checkpoint, version: str, tags: Union[None, str, List[str]] = None,
-             metadata: Dict[str, Any] = None) -> str:
-        raise NotImplementedError()
-
-    def tag(self, name, identifier, new_tag):
-        raise NotImplementedError()
-
-    def get(self, name, identifier="latest", block: bool = False, retry_times=60, mode="pytorch") -> Any:
-        raise NotImplementedError()
-
-    def list_versions(self, name) -> List[str]:
-        raise NotImplementedError()
-
-    def list_tags(self, name) -> List[Tuple[str, str]]:
-        raise NotImplementedError()
-
-    def has_tag(self, name, tag) -> bool:
-        raise NotImplementedError()
-
-    def version_of(self, name, identifier) -> int:
-        raise NotImplementedError()
-
-
-class FilesystemParameterDB(ParameterDBClient):
-
-    def __init__(self, experiment_name, trial_name, root: str, user_namespace: str = "default"):
-        super().__init__(experiment_name, trial_name)
-        self.root = root
-        self._workdir = os.path.join(root, user_namespace, experiment_name, trial_name)
-        os.makedirs(self._workdir, exist_ok=True, mode=0o775)
-
-    @staticmethod
-    def purge(experiment_name, trial_name, root: str, user_namespace: str = "default"):
-        d = os.path.join(root, user_namespace, experiment_name, trial_name)
-        if os.path.exists(d):
-            shutil.rmtree(d)
-
-    # ------------------------------------------------------------------ paths
-    def _path_of(self, name, identifier):
-        return os.path.join(self._workdir, name, str(identifier))
-
-    def _is_tag(self, name, tag):
-        return os.path.islink(self._path_of(name, tag))
-
-    def _list_all(self, name):
-        d = os.path.join(self._workdir, name)
-        return [f for f in os.listdir(d) if not f.endswith(".tmp")] if os.path.isdir(d) else []
-
-    # ------------------------------------------------------------------ writes
-    def push(self, name, checkpoint, version: str, tags=None, metadata=None):
-        assert metadata is None, "metadata queries need the reference's MongoDB-backed store"
-        version = str(version)
-        path = self._path_of(name, version)
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        tmp = path + ".tmp"
-        torch.save(checkpoint, tmp)
-        os.replace(tmp, path)  # readers never see a half-written file
-        self.tag(name, version, "latest")
-        for t in ([tags] if isinstance(tags, str) else (tags or [])):
-            self.tag(name, version, t)
-        return version
-
-    def tag(self, name, identifier, new_tag):
-        identifier = str(identifier)
-        if self._is_tag(name, identifier):
-            identifier = os.readlink(self._path_of(name, identifier))
-        if not os.path.exists(self._path_of(name, identifier)):
-            raise FileNotFoundError(f"no version `{identifier}` of policy `{name}`")
-        tmp_path, new_path = self._path_of(name, new_tag + ".tmp"), self._path_of(name, new_tag)
-        if os.path.lexists(tmp_path):
-            os.remove(tmp_path)
-        os.symlink(identifier, tmp_path)
-        os.replace(tmp_path, new_path)  # atomic re-point
-
-    def clear(self, name=None):
-        shutil.rmtree(self._workdir if name is None else os.path.join(self._workdir, name))
-
-    def gc(self, name, max_untagged_version_count=None, max_untagged_version_ttl=None):
-        if max_untagged_version_ttl is not None:
-            raise NotImplementedError()
-        tagged = set(v for _, v in self.list_tags(name))
-        untagged = [v for v in self.list_versions(name) if v not in tagged]
-        doomed = untagged[:-max_untagged_version_count] if max_untagged_version_count else []
-        for v in doomed:
-            os.remove(self._path_of(name, v))
-        return len(doomed)
-
-    # ------------------------------------------------------------------ reads
-    def get(self, name, identifier="latest", block=False, retry_times=60, mode="pytorch"):
-        path = self._path_of(name, identifier)
-        while retry_times >= 0:
-            if not os.path.lexists(path):
-                if not block:
-                    raise FileNotFoundError(f"Read checkpoint failed {name} {identifier}.")
-                time.sleep(1)
-                retry_times -= 1
-                continue
-            try:
-                if mode == "pytorch":
-                    return torch.load(path, map_location="cpu", weights_only=False)
-                if mode == "bytes":
-                    with open(path, "rb") as f:
-                        return f.read()
-                raise NotImplementedError(mode)
-            except FileNotFoundError:
-                raise
-            except OSError:
-                time.sleep(0.005)
-                retry_times -= 1
-        raise FileNotFoundError(f"Read checkpoint failed {name} {identifier}.")
 
     def list_names(self):
         return [n for n in os.listdir(self._workdir) if len(self.list_tags(n)) > 0]

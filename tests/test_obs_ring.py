@@ -36,9 +36,12 @@ def test_allocation_never_straddles_the_end_and_liveness_follows_the_head():
     r = cpu_ring(10)
     assert r._alloc(4) == 0 and r._alloc(4) == 4
     assert r._alloc(4) == 10  # slots 8, 9 are skipped: the run starts a new lap at slot 0
-    refs = np.array([-1, 0, 3, 4, 7, 8, 10, 13, 14])
+    base = (r.generation << r.GEN_SHIFT) + 1  # stamp of sequence number 0
+    refs = np.array([-1, 0, 3, 4, 7, 8, 10, 13, 14]) + base
     #        head = 14: rows 0..3 were lapped by 10..13, rows 4..7 are alive, 8 / 9 were never written but are in range
     assert r.alive(refs).tolist() == [False, False, False, True, True, True, True, True, False]
+    # 0 (a zero-filled field), negatives and bare sequence numbers (no generation) are never alive
+    assert r.alive(np.array([0, -1, 4, 7])).tolist() == [False] * 4
     with pytest.raises(BufferError):
         r._alloc(11)
 
@@ -179,9 +182,58 @@ def test_rollout_reads_its_rows_from_the_ring_and_matches_the_plain_rollout():
         assert np.array_equal(ra.analyzed_result.value, rb.analyzed_result.value)
         assert "obs_ref" not in list(ra.analyzed_result.keys())
         seen.append(rb.analyzed_result.obs_ref[:, 0])
-    assert seen[0].tolist() == list(range(0, 40)) and seen[1].tolist() == list(range(40, 80))
-    assert seen[2].tolist() == list(range(100, 140))
+    base = (ring.generation << ring.GEN_SHIFT) + 1  # a stamp = generation | sequence number + 1: never 0
+    assert seen[0].tolist() == list(range(base, base + 40)) and seen[1].tolist() == list(range(base + 40, base + 80))
+    assert seen[2].tolist() == list(range(base + 100, base + 140))
     assert ring.alive(np.concatenate(seen)).tolist() == [False] * 40 + [True] * 80
+    # what a step that never went through inference carries (a zero-filled analyzed_result), negatives, and the stamps of
+    # ANOTHER ring (a recreated one, another policy worker's) are dead here whatever this ring's head is
+    other = b.make_obs_ring(100)
+    assert other.generation != ring.generation
+    foreign = seen[2] - base + ((other.generation << other.GEN_SHIFT) + 1)
+    assert not ring.alive(np.array([0, -1, -7], dtype=np.int64)).any() and not ring.alive(foreign).any()
+    assert not other.alive(seen[2]).any()
+
+
+@pytest.mark.gpu
+def test_zero_stamps_are_patched_and_a_full_ring_degrades_instead_of_failing():
+    """(a) Rows whose stamp is 0 while the ring's head is still below its capacity -- terminal observations that never went
+    through inference: the reference actor zero-fills their analyzed_result -- are uploaded from the host copy, not bound to
+    sequence number 0's frame.  (b) A rollout that would lap rows a training step has leased stages nothing and still answers;
+    its rows carry dead stamps."""
+    rng = np.random.default_rng(11)
+    pol = policy_api.make(config.Policy("actor-critic", args=dict(CNN_POLICY, seed=3)))
+    Tb, B = 3, 8
+    oring = pol.make_obs_ring(64, patch_rows=Tb * B)
+    pol.attach_obs_ring(oring)
+    frames = rng.integers(0, 256, size=(Tb, B, 4, 84, 84), dtype=np.uint8)
+    refs = _rollout_through_ring(pol, frames)
+    refs[1, 2:5] = 0  # never sent for inference
+    host = {"obs": torch.from_numpy(frames)}
+    bound = oring.bind(refs, host)
+    assert bound is not None and oring.stats["rows_patched"] == 3
+    rows, lease = bound
+    assert lease.min_seq == 0
+    from srl_amd import hip
+    from srl_amd.algorithm.hipnet import Workspace
+    n = Tb * B
+    got, mean, rstd = rows["obs"].reshape(n, 4, 84, 84).resolve(Workspace("cuda:0"), "check")
+    raw = torch.from_numpy(frames).to("cuda:0").reshape(n, 4, 84, 84)
+    ref, rm, rr = torch.empty_like(got), torch.empty(n, device="cuda:0"), torch.empty(n, device="cuda:0")
+    hip.obs_space_to_depth(raw.data_ptr(), True, n, 4, 84, 84, 4, ref.data_ptr(), rm.data_ptr(), rr.data_ptr())
+    assert torch.equal(got, ref) and torch.equal(mean[:n], rm)
+    # (b) the lease pins sequence 0 on: 64 - 24 = 40 free rows; a 48-row request cannot be staged
+    big = rng.integers(0, 256, size=(48, 4, 84, 84), dtype=np.uint8)
+    plain = policy_api.make(config.Policy("actor-critic", args=dict(CNN_POLICY, seed=3)))
+    req = lambda: policy_api.RolloutRequest(obs=NamedArray(obs=big), is_evaluation=np.ones((48, 1), np.uint8),
+                                            on_reset=np.zeros((48, 1), np.uint8))
+    ra, rb = plain.rollout(req()), pol.rollout(req())
+    assert oring.stats["puts_unstaged"] == 1
+    assert np.array_equal(ra.action.x, rb.action.x) and np.array_equal(ra.analyzed_result.value, rb.analyzed_result.value)
+    assert (rb.analyzed_result.obs_ref == -1).all() and not oring.alive(rb.analyzed_result.obs_ref[:, 0]).any()
+    oring.release(lease)
+    rc = pol.rollout(req())  # released: staged again
+    assert oring.alive(rc.analyzed_result.obs_ref[:, 0]).all() and oring.stats["puts_unstaged"] == 1
 
 
 @pytest.mark.gpu
