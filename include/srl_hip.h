@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 8
+#define SRL_HIP_ABI_VERSION 9
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -439,6 +439,88 @@ int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, in
                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
                        const float* dz, float* dw, float* db, float* dgamma, float* dbeta, float* workspace,
                        const int32_t* row_index);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pre-split ("h2") operands and the kernels over them (round 4: csrc/h2gemm.h, csrc/h2conv.h).
+ * The contractions of the update run as three f16 piece products per multiply-add (gemm_bf16x3.h); the round-3 kernels
+ * split every float32 operand again in every tile that staged it and were bound by that staging.  Here a tensor is split
+ * ONCE, by the kernel that produces it, into two f16 pieces per element -- 4 bytes, what the float32 took -- and the
+ * consumers move bytes (buffer_load ... lds, no register staging):
+ *   value = (h0 + h1) / scale, scale a power of two in a device float beside the tensor, derived from an upper BOUND of the
+ *   tensor's magnitude that is known before the tensor exists (max |input| x max row 1-norm of the weights + max |bias|),
+ *   so a producer can split while it stores and an f16 overflow is impossible by construction;
+ *   "h2p rows": a row of C elements (C a multiple of 32) is C / 32 blocks of 128 bytes = 4 groups x {8 first pieces,
+ *   8 second pieces}; group g holds elements 4 (g >> 1) + 16 (g & 1) + {0,1,2,3, 8,9,10,11} of its block (what one lane of
+ *   a 32x32 MFMA accumulator holds);  "planar image": the same 16-byte entries as [block][group][piece][pixel] per image.
+ * Replaces, for the Atari network of modules/cnn.py:93-135 + actor_critic_policies/utils.py:33-63 (20x20x32 -> 9x9x64 ->
+ * 7x7x64 -> Linear 3136 -> 512), the forward, data-gradient and weight-gradient contractions of mappo.py:243-284.
+ */
+/* float32 rows [rows, C] (pitch ld) <-> h2p rows (pitch C).  Scale: *scale_in if given, else derived from *absmax and
+ * written to *scale_out. */
+int srl_h2_pack_rows(void* stream, const float* src, int64_t ld, int64_t rows, int32_t C, const float* absmax,
+                     const float* scale_in, float* scale_out, void* dst);
+int srl_h2_unpack_rows(void* stream, const void* src, int64_t rows, int32_t C, const float* scale, float* dst, int64_t ld);
+/* float32 NHWC images <-> h2 images.  layout 0: planar, raster pixel order; 1: h2p rows [n][H*W][C], raster order; 2: h2p
+ * rows with the pixels of an image in parity-class-major order ((y & 1, x & 1), then y >> 1, x >> 1: what a stride-2
+ * layer reads; pack only). */
+int srl_h2_pack_image(void* stream, const float* src, int64_t n, int32_t H, int32_t W, int32_t C, int32_t layout,
+                      const float* absmax, const float* scale_in, float* scale_out, void* dst);
+int srl_h2_unpack_image(void* stream, const void* src, int64_t n, int32_t H, int32_t W, int32_t C, int32_t layout,
+                        const float* scale, float* dst);
+/* A weight matrix as h2p rows dst [rows][K] under the scale of *absmax (= max |w|, srl_absmax), with *rownorm_out = max over
+ * rows of sum_k |.| (the factor of the output bound), once per parameter update.  mode 0: w is [rows][K]; 1: w is [K][rows]
+ * (its transpose is packed: the data gradient of a Linear); 2: the data-gradient regrouping of a convolution weight
+ * w [Cout][KH][KW][Cin] described by d: rows = stride^2 Cin as (parity class, cin), K = (KH/stride)(KW/stride) Cout as (tap, cout). */
+int srl_h2_weights(void* stream, const float* w, int32_t rows, int32_t K, int32_t mode, const srl_conv_desc* d,
+                   const float* absmax, float* scale_out, float* rownorm_out, void* dst);
+
+/* Image-stationary convolutions of the Atari stack (csrc/h2conv.h): an image enters LDS once, every tap reads it there,
+ * the weights of a wavefront's 16 output channels stay in registers.
+ *   kind 0  conv2 forward   x: h2p rows [n][400][32] in parity-class order (srl_conv2d_obs_fwd_h2) -> out: planar [n] 9x9x64
+ *   kind 1  conv3 forward   x: planar 9x9x64 -> out: h2p rows [n][49][64] (= [n][3136], the Linear's operand)
+ *   kind 2  conv3 data gradient   x: dz as h2p rows [n][49][64], w: srl_h2_weights mode 2 -> out: planar 9x9x64
+ *   kind 3  conv2 data gradient   x: dz planar 9x9x64, w: mode 2 (128 rows) -> out: float32 NHWC [n,20,20,32]
+ * forward kinds: out = relu(conv + bias), mask_out = sign bytes in h2 order (one byte per group of 8 channels, bit j =
+ * element j of the group; [image][pixel][block][group]); data gradients: out *= the ReLU derivative read from mask_in
+ * (kind 2: h2 order, what kind 0 wrote; kind 3: natural order, 32-bit word per pixel, what srl_conv2d_obs_fwd writes).
+ * *out_absmax = max(*out_absmax, max |out|) (the bound_in of the next layer). */
+typedef struct srl_h2_conv_args {
+  const void* x; const void* w;
+  const float* sx; const float* sw;      /* scales of x and w (device floats) */
+  int64_t n;
+  const float* bias; int32_t act;
+  void* out; float* out_scale;
+  const float* bound_in; const float* bound_w; const float* bound_b;   /* |out| <= *bound_in * *bound_w + *bound_b (bound_b may be NULL) */
+  float* out_absmax;
+  void* mask_out; const void* mask_in;
+} srl_h2_conv_args;
+int srl_h2_conv(void* stream, int32_t kind, const srl_h2_conv_args* a);
+/* Weight gradients, image-stationary: gw [64][KH][KW][Cin] += sum dz^T patches(x), gb [64] += sum dz (gb may be NULL).
+ * kind 0: conv2 (x as kind 0's input, dz planar 9x9x64); kind 1: conv3 (x planar 9x9x64, dz h2p rows [n][49][64]).
+ * workspace: srl_h2_wgrad_workspace(kind) floats (one slab per persistent workgroup, summed by a second launch). */
+int64_t srl_h2_wgrad_workspace(int32_t kind);
+int srl_h2_wgrad(void* stream, int32_t kind, const void* x, const void* dz, const float* sx, const float* sz, int64_t n,
+                 float* workspace, float* gw, float* gb);
+/* Dense product over h2p rows through an LDS-DMA ring (csrc/h2gemm.h): out[M, NC] = act(x[M, K] w[NC, K]^T + bias).
+ * out_h2 0: float32 [M][NC]; 1: h2p rows (needs the bound's factors).  mask_out: ReLU sign bits of out, natural order
+ * (bit c of the word of a row's 32-channel block); mask_in: out *= derivative bit at the output element, natural order or
+ * (mask_in_h2order) the h2 order srl_h2_conv's forward kinds write.  Replaces nn.Linear forward / data gradient
+ * (modules/utils.py:154-161) for the encoder's 3136 -> 512 layer. */
+typedef struct srl_h2_gemm_desc {
+  const void* x; const void* w; const float* sx; const float* sw;
+  int64_t M; int32_t NC; int32_t K;
+  const float* bias; int32_t act;
+  int32_t out_h2; void* out; float* out_scale;
+  const float* bound_in; const float* bound_w; const float* bound_b;
+  float* out_absmax; uint32_t* mask_out; const uint32_t* mask_in; int32_t mask_in_h2order;
+} srl_h2_gemm_desc;
+int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d);
+/* srl_conv2d_obs_fwd with the output as the h2p rows kind 0 above reads (ent_order 2) instead of float32: byte kernels
+ * only (uint8 channels-last frames, Cout 32), y_mask / y_absmax / workspace required; *y_scale = the scale used. */
+int srl_conv2d_obs_fwd_h2(void* stream, const srl_conv_desc* d, const void* obs, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, const float* w, const float* bias, void* y_h2, float* y_scale,
+                          float* workspace, const int32_t* row_index, float* y_absmax, uint32_t* y_mask, int reuse_folded,
+                          int ent_order);
 
 /* Row gather behind the HBM observation ring: dst[i, :] = src[index[i], :], rows of row_bytes (a multiple of 4;
  * 16-byte pieces when row_bytes % 16 == 0 and both bases are 16-byte aligned).  The frames `rollout` uploaded

@@ -396,6 +396,59 @@ template <int ID> static void run_is_dgrad(const char* name, int64_t n, int64_t 
   for (void* p : {(void*)dz, (void*)w, (void*)act, (void*)wg, (void*)xp, (void*)wp, (void*)y, (void*)yr, (void*)yu, (void*)mk}) CK(hipFree(p));
 }
 
+// dw[co][ky][kx][ci] = sum_{img,oy,ox} dz[img,oy,ox,co] x[img, oy st + ky, ox st + kx, ci]; db[co] = sum dz
+__global__ void ref_wgrad(const float* x, const float* dz, int64_t n, int H, int W, int C, int KH, int KW, int st, int Cout, float* dw, float* db) {
+  const int OH = (H - KH) / st + 1, OW = (W - KW) / st + 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = KH * KW * C;
+  if (i >= Cout * K + Cout) return;
+  double s = 0;
+  if (i >= Cout * K) {
+    const int co = i - Cout * K;
+    for (int64_t r = 0; r < n * OH * OW; ++r) s += dz[r * Cout + co];
+    db[co] = (float)s;
+    return;
+  }
+  const int ci = i % C; int r = i / C; const int kx = r % KW; r /= KW; const int ky = r % KH; const int co = r / KH;
+  for (int64_t img = 0; img < n; ++img)
+    for (int oy = 0; oy < OH; ++oy) for (int ox = 0; ox < OW; ++ox)
+      s += (double)dz[((img * OH + oy) * OW + ox) * Cout + co] * (double)x[((img * H + oy * st + ky) * W + ox * st + kx) * C + ci];
+  dw[i] = (float)s;
+}
+
+template <int ID> static void run_is_wgrad(const char* name, int64_t n, int64_t nt) {
+  constexpr bool C2 = ID == H2W_C2;
+  const int H = C2 ? 20 : 9, W = H, C = C2 ? 32 : 64, KH = C2 ? 4 : 3, KW = KH, st = C2 ? 2 : 1, Cout = 64;
+  const int OH = (H - KH) / st + 1, OW = OH, K = KH * KW * C;
+  printf("%s: IS conv wgrad n=%ld x %dx%dx%d, dz %dx%dx%d -> dw [%d][%d]\n", name, (long)n, H, W, C, OH, OW, Cout, Cout, K);
+  const int64_t nx = n > nt ? n : nt;
+  float* x = dalloc<float>(nx * H * W * C); float* dz = dalloc<float>(nx * OH * OW * Cout);
+  fill(x, nx * H * W * C, 51, 2.f, 1); fill(dz, nx * OH * OW * Cout, 52, 1e-3f, 0);
+  float *sx, *sz; float* ax = absmax_of(x, nx * H * W * C); float* az = absmax_of(dz, nx * OH * OW * Cout);
+  float* xp;
+  if (C2) { xp = dalloc<float>(nx * H * W * C); sx = dalloc<float>(1); h2_pack_pixrows_kernel<<<2048, 256>>>(x, nx, H, W, C, 2, ax, nullptr, sx, (uint8_t*)xp); }
+  else xp = pack_planar(x, nx, H, W, C, 0, ax, &sx);
+  float* zp = C2 ? pack_planar(dz, nx, OH, OW, Cout, 0, az, &sz) : pack(dz, nx * OH * OW, Cout, az, &sz);
+  const int grid = 256, per = Cout * K + Cout;
+  float* slabs = dalloc<float>((int64_t)grid * per);
+  float* gw = dalloc<float>(Cout * K); float* gb = dalloc<float>(Cout); float* rw = dalloc<float>(Cout * K); float* rb = dalloc<float>(Cout);
+  H2WgradArgs a = {};
+  a.x = xp; a.dz = zp; a.sx = sx; a.sz = sz; a.n = n; a.slabs = slabs;
+  auto go = [&] { h2wgrad_launch<ID, C2 ? 2 : 3>(0, a, grid); };
+  go();
+  h2_wgrad_reduce_kernel<<<(per + 255) / 256, 256>>>(slabs, grid, per, Cout * K, gw, gb);
+  CK(hipDeviceSynchronize());
+  ref_wgrad<<<(per + 63) / 64, 64>>>(x, dz, n, H, W, C, KH, KW, st, Cout, rw, rb);
+  g_all_ok &= report("dw vs float64", gw, rw, Cout * K, 2e-6);
+  g_all_ok &= report("db vs float64", gb, rb, Cout, 2e-6);
+  if (nt > 0) {
+    a.n = nx;
+    const double ms = time_ms(go, 20);
+    printf("  TIME n=%ld: %.1f us  (%.2f TB/s of x + dz bytes)\n", (long)nt, ms * 1e3, (nx * H * W * C * 4.0 + nx * OH * OW * Cout * 4.0) / ms * 1e-9);
+  }
+  for (void* p : {(void*)x, (void*)dz, (void*)xp, (void*)zp, (void*)slabs}) CK(hipFree(p));
+}
+
 int main(int argc, char** argv) {
   const int64_t nc = argc > 1 ? atol(argv[1]) : 1000;
   const int64_t nt = argc > 2 ? atol(argv[2]) : 16384;
@@ -414,6 +467,8 @@ int main(int argc, char** argv) {
   if (want("if3")) run_is_fwd<H2C_F3>("conv3", nc, nt);
   if (want("id3")) run_is_dgrad<H2C_D3>("conv3", nc, nt);
   if (want("id2")) run_is_dgrad<H2C_D2>("conv2", nc, nt);
+  if (want("iw3")) run_is_wgrad<H2W_C3>("conv3", nc > 256 ? 256 + 37 : nc, nt);
+  if (want("iw2")) run_is_wgrad<H2W_C2>("conv2", nc > 256 ? 256 + 37 : nc, nt);
   printf(g_all_ok ? "ALL OK\n" : "SOME FAILED\n");
   return g_all_ok ? 0 : 1;
 }

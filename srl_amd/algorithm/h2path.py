@@ -1,0 +1,184 @@
+"""The Atari encoder (modules/cnn.py:93-135: 8x8/4 -> 4x4/2 -> 3x3/1 convolutions, Flatten, Linear 3136 -> 512, ReLU after each)
+on pre-split ("h2") activations: ``csrc/h2conv.h`` (image-stationary convolutions, their data and weight gradients) and
+``csrc/h2gemm.h`` (the Linear's products through an LDS-DMA ring).  Round 3's kernels kept activations float32 in HBM and
+split them into two f16 pieces again in every tile that staged them (the staging was what bounded them); here the producer's
+epilogue splits once and writes the pieces -- the same 4 bytes per element -- and the consumers move bytes.
+
+One object per executor (``HipNet`` and its twin): workspace buffers, the per-update weight preparations and the device
+floats that carry scales / ranges between kernels.  ``forward`` returns the Linear's float32 output (what the layers behind
+the encoder read); ``backward`` takes the gradient with respect to it.  Formats between the layers:
+
+    frames (uint8, space-to-depth'd)  --obs_fwd_h2-->  a1: h2p rows, parity-class pixel order      + sign words (natural order)
+    a1  --conv2 fwd-->  a2: planar 9x9x64 + sign bytes (h2 order)  --conv3 fwd-->  a3: h2p rows [n, 3136] + sign bytes
+    a3  --Linear (h2gemm)-->  y float32 [n, 512] + sign words
+    dy (float32) --pack--> h2p rows --Linear dgrad (h2gemm, mask a3)--> dz3: h2p rows --conv3 dgrad (mask a2)--> dz2: planar
+    dz2 --conv2 dgrad (mask a1)--> dz1: float32 NHWC --> the first layer's backward (obs_bwd, round 2)
+    weight gradients: conv3 (a2, dz3), conv2 (a1, dz2) image-stationary; the Linear's through the round-3 kernel.
+"""
+import os
+from typing import Optional
+
+import torch
+
+from srl_amd import hip
+from srl_amd.algorithm import netspec as ns
+
+ENABLED = os.environ.get("SRL_H2", "1") != "0"
+
+# device floats of one executor (indices into the `h2.slots` workspace tensor)
+(S_A1, M_A1, S_A2, M_A2, S_A3, M_A3, S_DY, M_DY, S_DZ3, M_DZ3, S_DZ2, M_DZ2, M_DZ1,
+ S_W2, R_W2, B_W2, S_W3, R_W3, B_W3, S_WF, R_WF, S_W3G, R_W3G, S_W2G, R_W2G, S_WFT, R_WFT, N_SLOTS) = range(28)
+
+
+def match(layers) -> Optional[tuple]:
+    """(obs LayerNorm, conv1, conv2, conv3, Linear) when the encoder starts with exactly the stack these kernels are compiled
+    for (h2conv.h's geometries), else None."""
+    if len(layers) < 5:
+        return None
+    ln, c1, c2, c3, fc = layers[:5]
+    if not (isinstance(ln, ns.ObsLayerNormSpec) and not ln.explicit and tuple(ln.shape) == (4, 84, 84)):
+        return None
+    if not all(isinstance(c, ns.ConvSpec) for c in (c1, c2, c3)) or not isinstance(fc, ns.LinearSpec):
+        return None
+    geo = [(c.cin, c.cout, c.k, c.stride, tuple(c.in_hw), c.pad, c.act) for c in (c1, c2, c3)]
+    want = [(4, 32, 8, 4, (84, 84), 0, hip.ACT_RELU), (32, 64, 4, 2, (20, 20), 0, hip.ACT_RELU), (64, 64, 3, 1, (9, 9), 0, hip.ACT_RELU)]
+    if geo != want or not (c1.first and c1.s2d == 4) or c2.first or c3.first:
+        return None
+    if (fc.in_features, fc.act) != (3136, hip.ACT_RELU) or fc.out_features % 32:
+        return None
+    return ln, c1, c2, c3, fc
+
+
+class H2Cnn:
+
+    def __init__(self, net, layers):
+        self.net = net
+        self.ln, self.c1, self.c2, self.c3, self.fc = layers
+        self.H = self.fc.out_features
+
+    # ------------------------------------------------------------------ helpers
+    def _slots(self):
+        return self.net.ws.get("h2.slots", N_SLOTS)
+
+    def _slot(self, i):
+        return self._slots().data_ptr() + 4 * i
+
+    def _bytes(self, name, nbytes):
+        return self.net.ws.get(name, (nbytes + 3) // 4).data_ptr()
+
+    def _prepare_weights(self):
+        """Once per parameter version and executor: h2p copies of the weights in the orientations the kernels read, their
+        scales and the row norms that bound the outputs."""
+        net = self.net
+        key = "h2.weights"
+        marker = self._bytes(key, 16)
+        if net._derived_fresh(key, marker):
+            return
+        p = net._p
+        desc2 = hip.conv_desc(1, 20, 20, 32, 4, 4, 2, 64, hip.ACT_RELU)
+        desc3 = hip.conv_desc(1, 9, 9, 64, 3, 3, 1, 64, hip.ACT_RELU)
+        for L, K, s_w, r_w, b_w, name in ((self.c2, 512, S_W2, R_W2, B_W2, "w2"), (self.c3, 576, S_W3, R_W3, B_W3, "w3")):
+            amax = net._weight_range(L.prefix, 64 * K)
+            hip.h2_weights(p(f"{L.prefix}.weight"), 64, K, 0, amax, self._slot(s_w), self._slot(r_w), self._bytes(f"h2.{name}", 64 * K * 4))
+            self._slots()[b_w:b_w + 1].zero_()
+            hip.absmax(p(f"{L.prefix}.bias"), 64, self._slot(b_w))
+        amax = net._weight_range(self.c3.prefix, 64 * 576)
+        hip.h2_weights(p(f"{self.c3.prefix}.weight"), 64, 576, 2, amax, self._slot(S_W3G), self._slot(R_W3G),
+                       self._bytes("h2.w3g", 64 * 576 * 4), desc=desc3)
+        amax = net._weight_range(self.c2.prefix, 64 * 512)
+        hip.h2_weights(p(f"{self.c2.prefix}.weight"), 128, 256, 2, amax, self._slot(S_W2G), self._slot(R_W2G),
+                       self._bytes("h2.w2g", 128 * 256 * 4), desc=desc2)
+        amax = net._weight_range(self.fc.prefix, self.H * 3136)
+        hip.h2_weights(p(f"{self.fc.prefix}.weight"), self.H, 3136, 0, amax, self._slot(S_WF), self._slot(R_WF),
+                       self._bytes("h2.wf", self.H * 3136 * 4))
+        hip.h2_weights(p(f"{self.fc.prefix}.weight"), 3136, self.H, 1, amax, self._slot(S_WFT), self._slot(R_WFT),
+                       self._bytes("h2.wft", self.H * 3136 * 4))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, tag, staged, obs, n, is_u8, src, mean, rstd, row_index):
+        """The four layers on `n` rows.  src / mean / rstd / row_index: the first layer's staged frames and statistics as
+        `_encoder_fwd` resolved them.  Returns (y Buf float32 [n, H] with its sign mask, saved)."""
+        from srl_amd.algorithm.hipnet import Buf
+        net, ws = self.net, self.net.ws
+        self._prepare_weights()
+        slots = self._slots()
+        slots[M_A1:M_A1 + 1].zero_()
+        slots[M_A2:M_A2 + 1].zero_()
+        slots[M_A3:M_A3 + 1].zero_()
+        a1 = self._bytes(f"{tag}h2.a1", n * 400 * 32 * 4)
+        a2 = self._bytes(f"{tag}h2.a2", n * 81 * 64 * 4)
+        a3 = self._bytes(f"{tag}h2.a3", n * 49 * 64 * 4)
+        m1 = ws.get(f"{tag}h2.m1", n * 400, torch.int32).data_ptr()
+        m2 = self._bytes(f"{tag}h2.m2", n * 81 * 8)
+        m3 = self._bytes(f"{tag}h2.m3", n * 49 * 8)
+        # first layer: frames -> a1
+        desc1 = hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, hip.ACT_RELU)
+        fws = ws.get(f"{self.c1.prefix}.folded", hip.conv2d_obs_fwd_workspace(desc1)).data_ptr()
+        reuse = net._derived_fresh(f"{self.c1.prefix}.folded:h2", fws)
+        hip.conv2d_obs_fwd_h2(desc1, src.data_ptr(), mean.data_ptr(), rstd.data_ptr(), net._p(f"{self.ln.prefix}.weight"),
+                              net._p(f"{self.ln.prefix}.bias"), net._p(f"{self.c1.prefix}.weight"), net._p(f"{self.c1.prefix}.bias"),
+                              a1, self._slot(S_A1), fws, row_index, self._slot(M_A1), m1, reuse_folded=reuse, ent_order=2)
+        # conv2, conv3
+        hip.h2_conv(hip.H2_CONV2_FWD, a1, self._bytes("h2.w2", 0), self._slot(S_A1), self._slot(S_W2), n, a2, self._slot(M_A2),
+                    bias=net._p(f"{self.c2.prefix}.bias"), act=1, out_scale=self._slot(S_A2), bound_in=self._slot(M_A1),
+                    bound_w=self._slot(R_W2), bound_b=self._slot(B_W2), mask_out=m2)
+        hip.h2_conv(hip.H2_CONV3_FWD, a2, self._bytes("h2.w3", 0), self._slot(S_A2), self._slot(S_W3), n, a3, self._slot(M_A3),
+                    bias=net._p(f"{self.c3.prefix}.bias"), act=1, out_scale=self._slot(S_A3), bound_in=self._slot(M_A2),
+                    bound_w=self._slot(R_W3), bound_b=self._slot(B_W3), mask_out=m3)
+        # Linear: float32 out (the layers behind it take the ReLU derivative from these floats, as after `_linear_fwd`)
+        y = net._buf(f"{tag}{self.fc.prefix}.y", n, self.H)
+        hip.h2_gemm(a3, self._bytes("h2.wf", 0), self._slot(S_A3), self._slot(S_WF), n, self.H, 3136, y.ptr,
+                    bias=net._p(f"{self.fc.prefix}.bias"), act=1)
+        saved = dict(n=n, a1=a1, a2=a2, a3=a3, m1=m1, m2=m2, m3=m3, first=(src, is_u8, mean, rstd, row_index), tag=tag)
+        return y, saved
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, saved, dy):
+        """dy: Buf float32 [n, H], the gradient with respect to the Linear's pre-activation (its ReLU derivative already
+        applied by the layer above).  Adds every parameter gradient of the five layers."""
+        net, ws = self.net, self.net.ws
+        n, tag = saved["n"], saved["tag"]
+        g = net._g
+        slots = self._slots()
+        for i in (M_DY, M_DZ3, M_DZ2, M_DZ1):
+            slots[i:i + 1].zero_()
+        assert dy.ld == dy.cols == self.H and dy.rows == n
+        # dy -> h2p rows (its range from one pass: the producer is a float32 kernel)
+        hip.absmax(dy.ptr, n * self.H, self._slot(M_DY))
+        dyh = self._bytes(f"{tag}h2.dy", n * self.H * 4)
+        hip.h2_pack_rows(dy.ptr, self.H, n, self.H, dyh, absmax=self._slot(M_DY), scale_out=self._slot(S_DY))
+        # Linear: weight gradient through the round-3 kernel on a float32 copy of a3 (beside the data-gradient chain)
+        a3f = net._buf(f"{tag}h2.a3f", n, 3136)
+        hip.h2_unpack_rows(saved["a3"], n, 3136, self._slot(S_A3), a3f.ptr, 3136)
+        net._on_side(lambda: net._wgrad(self.H, 3136, n, dy, a3f.ptr, 3136, g(f"{self.fc.prefix}.weight"), g(f"{self.fc.prefix}.bias"),
+                                        None, None))
+        # Linear data gradient -> dz3 (h2p rows [n, 49, 64]), ReLU derivative of a3 from its sign bytes
+        dz3 = self._bytes(f"{tag}h2.dz3", n * 3136 * 4)
+        hip.h2_gemm(dyh, self._bytes("h2.wft", 0), self._slot(S_DY), self._slot(S_WFT), n, 3136, self.H, dz3, out_h2=True,
+                    out_scale=self._slot(S_DZ3), bound_in=self._slot(M_DY), bound_w=self._slot(R_WFT), out_absmax=self._slot(M_DZ3),
+                    mask_in=saved["m3"], mask_in_h2order=True)
+        # conv3: weight gradient (a2, dz3) beside its data gradient -> dz2 (planar)
+        wws3 = ws.get("h2.wgrad3", hip.h2_wgrad_workspace(hip.H2_WGRAD_CONV3)).data_ptr()
+        net._on_side(lambda: hip.h2_wgrad(hip.H2_WGRAD_CONV3, saved["a2"], dz3, self._slot(S_A2), self._slot(S_DZ3), n, wws3,
+                                          g(f"{self.c3.prefix}.weight"), g(f"{self.c3.prefix}.bias")))
+        dz2 = self._bytes(f"{tag}h2.dz2", n * 81 * 64 * 4)
+        hip.h2_conv(hip.H2_CONV3_DGRAD, dz3, self._bytes("h2.w3g", 0), self._slot(S_DZ3), self._slot(S_W3G), n, dz2, self._slot(M_DZ2),
+                    out_scale=self._slot(S_DZ2), bound_in=self._slot(M_DZ3), bound_w=self._slot(R_W3G), mask_in=saved["m2"])
+        # conv2: weight gradient (a1, dz2) beside its data gradient -> dz1 (float32 NHWC for the first layer's backward)
+        wws2 = ws.get("h2.wgrad2", hip.h2_wgrad_workspace(hip.H2_WGRAD_CONV2)).data_ptr()
+        net._on_side(lambda: hip.h2_wgrad(hip.H2_WGRAD_CONV2, saved["a1"], dz2, self._slot(S_A1), self._slot(S_DZ2), n, wws2,
+                                          g(f"{self.c2.prefix}.weight"), g(f"{self.c2.prefix}.bias")))
+        dz1 = net._buf(f"{tag}h2.dz1", n * 400, 32)
+        hip.h2_conv(hip.H2_CONV2_DGRAD, dz2, self._bytes("h2.w2g", 0), self._slot(S_DZ2), self._slot(S_W2G), n, dz1.ptr, self._slot(M_DZ1),
+                    mask_in=saved["m1"])
+        # first layer: the round-2 byte kernel
+        src, is_u8, mean, rstd, row_index = saved["first"]
+        desc1 = hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, hip.ACT_RELU)
+        wsz = hip.conv2d_obs_bwd_workspace(desc1)
+        hip.conv2d_obs_bwd(desc1, src.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), net._p(f"{self.ln.prefix}.weight"),
+                           net._p(f"{self.ln.prefix}.bias"), net._p(f"{self.c1.prefix}.weight"), dz1.ptr, g(f"{self.c1.prefix}.weight"),
+                           g(f"{self.c1.prefix}.bias"), g(f"{self.ln.prefix}.weight"), g(f"{self.ln.prefix}.bias"),
+                           ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=True, row_index=row_index)
+
+    def prefixes(self):
+        return [self.ln.prefix, self.c1.prefix, self.c2.prefix, self.c3.prefix, self.fc.prefix]

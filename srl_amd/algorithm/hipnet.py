@@ -275,6 +275,7 @@ class HipNet:
         t._amax_next = t._gmax_next = -1
         t._side_stream, t._side_used = None, False
         t._derived = {}
+        t._h2_blocks = {}
         return t
 
     def _weight_range(self, prefix: str, numel: int) -> int:
@@ -291,6 +292,19 @@ class HipNet:
             hip.absmax(self._p(f"{prefix}.weight"), numel, ptr)
             self._wamax_stale.discard(prefix)
         return ptr
+
+    H2_MIN_ROWS = int(os.environ.get("SRL_H2_MIN_ROWS", "256"))
+
+    def _h2_for(self, enc):
+        """This executor's pre-split block for an encoder that starts with the Atari stack (h2path.match), or None."""
+        from srl_amd.algorithm import h2path
+        if not h2path.ENABLED or not self.on_gpu:
+            return None
+        cache = self.__dict__.setdefault("_h2_blocks", {})
+        if enc.key not in cache:
+            m = h2path.match(enc.layers)
+            cache[enc.key] = h2path.H2Cnn(self, m) if m is not None else None
+        return cache[enc.key]
 
     def _act_range(self) -> int:
         """A fresh device float for the range of an activation of this forward pass (zero until its producer ran)."""
@@ -581,7 +595,12 @@ class HipNet:
                 staged = obs  # already in the first convolution's layout, statistics beside them
             else:
                 obs = obs.gather_raw(self.ws, f"{tag}{enc.key}.ring")
+        h2 = self._h2_for(enc)
+        skip = 0
         for L in enc.layers:
+            if skip:  # layers the pre-split block below has already run
+                skip -= 1
+                continue
             if isinstance(L, ns.LayerNormSpec):
                 if cur is None:
                     if obs.dtype != torch.float32:
@@ -704,6 +723,14 @@ class HipNet:
                                                    rstd.data_ptr())
                         else:
                             hip.obs_ln_stats(obs.data_ptr(), is_u8, n, c * h * w, mean.data_ptr(), rstd.data_ptr())
+                    if (h2 is not None and implicit and is_u8 and L.s2d and n >= self.H2_MIN_ROWS
+                            and hip.conv2d_obs_row_index_supported(desc, is_u8, True)):
+                        # the whole convolution stack and the Linear behind it on pre-split activations (h2path.py)
+                        y2, saved2 = h2.forward(tag, staged, obs, n, is_u8, src, mean, rstd, row_index)
+                        tape.append(("h2cnn", h2, None, saved2, 0))
+                        cur, cur_act, cur_range = y2, h2.fc.act, None
+                        skip = 3
+                        continue
                     y_range = self._act_range() if implicit else None
                     if implicit:
                         fws = self.ws.get(f"{L.prefix}.folded", hip.conv2d_obs_fwd_workspace(desc)).data_ptr()
@@ -763,6 +790,12 @@ class HipNet:
                 g = self._linear_bwd(L, x, g, in_act, need_dx, tag, x_range=x_range,
                                      dz_range=g_range if x_range is not None else None, dx_range=dx_range)
                 g_range = dx_range
+            elif kind == "h2cnn":
+                L.backward(saved, g)
+                g, g_range = None, None
+                if self.grad_ready_hook is not None:
+                    self.grad_ready_hook(L.prefixes())
+                continue
             elif kind == "gru":
                 g = self._gru_bwd(L, saved, g, in_act, need_dx, tag)
                 g_range = None
@@ -895,6 +928,8 @@ class HipNet:
         kind, L = record[0], record[1]
         if kind == "ln":
             return L.dim
+        if kind == "h2cnn":
+            return L.H
         if kind == "linear":
             return L.out_features
         if kind == "gru":

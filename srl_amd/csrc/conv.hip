@@ -649,13 +649,16 @@ extern "C" int srl_conv2d_obs_row_index_supported(const srl_conv_desc* d, int is
 static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                               const float* mean, const float* rstd, const float* gamma, const float* beta,
                               const float* w, const float* bias, float* y, float* workspace, const int32_t* row_index,
-                              float* y_absmax, uint32_t* y_mask, int reuse_folded) {
+                              float* y_absmax, uint32_t* y_mask, int reuse_folded, uint8_t* y_h2 = nullptr, float* y_scale = nullptr,
+                              int ent_order = 0) {
+  SRL_CHECK_ARG(!y_h2 || (y_scale && y_mask && y_absmax && workspace && obs_bf16_ok(d, is_u8, channels_last, obs)),
+                "h2 output: byte kernels only, with y_scale, y_mask, y_absmax and the folded-weights workspace");
   SRL_CHECK_ARG(!y_mask || (d->act == 1 && d->Cout % 32 == 0), "y_mask: ReLU layers with Cout a multiple of 32");
   SRL_CHECK_ARG(row_index == nullptr || (workspace && srl_conv2d_obs_row_index_supported(d, is_u8, channels_last)),
                 "row_index is served by the byte kernels only (srl_conv2d_obs_row_index_supported)");
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1),
                 "unsupported geometry (planar: KW, W, stride, H*W multiples of 4; channels-last: Cin multiple of 4)");
-  SRL_CHECK_ARG(obs && mean && rstd && gamma && beta && w && y && aligned16(obs) && aligned16(gamma) && aligned16(beta),
+  SRL_CHECK_ARG(obs && mean && rstd && gamma && beta && w && (y || y_h2) && aligned16(obs) && aligned16(gamma) && aligned16(beta),
                 "null / unaligned tensor");
   if (d->n == 0) return 0;
   const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
@@ -676,10 +679,14 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
     float* S = workspace + ((long)P * 3 * d->Cout * Kp) / 2;
     float* b2 = S + (long)P * d->Cout;
     const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, 1};
-    if (!reuse_folded)
+    float* bound = b2 + (long)P * d->Cout;  // one of the workspace's 64 spare floats: upper bound of |y| from the folded weights
+    if (!reuse_folded) {
+      (void)hipMemsetAsync(bound, 0, sizeof(float), st);
       hipLaunchKernelGGL(srlobs::obs_fold_split_kernel<ObsIndex>, dim3((unsigned)(P * d->Cout)), dim3(256), 0, st, w, bias, gamma,
-                         beta, P, (int)Kp, ix, wq, S, b2);
+                         beta, P, (int)Kp, ix, wq, S, b2, bound, sqrtf((float)((long)d->H * d->W * d->Cin)));
+    }
     srlobs::FwdArgs a{};
+    a.y_h2 = y_h2; a.bound = bound; a.y_scale = y_scale; a.ent_order = ent_order; a.OH = OH;
     a.g = obs_geom(d, obs, mean, rstd, OW, row_index);
     a.wq = reinterpret_cast<const uint4*>(wq);
     a.S = S; a.b2 = b2; a.y = y; a.P = P; a.act = d->act;
@@ -695,7 +702,8 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
       case 8: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 8>), grid, dim3(256), 0, st, a); break;
       case 12: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 12>), grid, dim3(256), 0, st, a); break;
       default:
-        if (y_mask) hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 0, true>), grid, dim3(256), 0, st, a);
+        if (y_h2) hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 0, true, true>), grid, dim3(256), 0, st, a);
+        else if (y_mask) hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 0, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 0>), grid, dim3(256), 0, st, a);
     }
     SRL_LAUNCH_CHECK();
@@ -761,6 +769,29 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
                                       rstd + adv, gamma, beta, w, bias, y + i0 * out_e, workspace,
                                       row_index ? row_index + i0 : nullptr, y_absmax, y_mask ? y_mask + i0 * out_e / 32 : nullptr,
                                       reuse_folded || i0 > 0);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+extern "C" int srl_conv2d_obs_fwd_h2(void* stream, const srl_conv_desc* d, const void* obs, const float* mean, const float* rstd,
+                                     const float* gamma, const float* beta, const float* w, const float* bias, void* y_h2,
+                                     float* y_scale, float* workspace, const int32_t* row_index, float* y_absmax, uint32_t* y_mask,
+                                     int reuse_folded, int ent_order) {
+  SRL_CHECK_ARG(srl_conv2d_supported(d, 2), "unsupported geometry");
+  SRL_CHECK_ARG(ent_order == 0 || (ent_order == 2 && conv_out(d->H, d->KH, d->stride) % 2 == 0 && conv_out(d->W, d->KW, d->stride) % 2 == 0),
+                "ent_order: 0 (raster) or 2 (parity-class major: even output extents)");
+  const long run = images_per_launch(d, 1);
+  const long in_b = (long)d->H * d->W * d->Cin;
+  const long out_e = (long)conv_out(d->H, d->KH, d->stride) * conv_out(d->W, d->KW, d->stride) * d->Cout;
+  for (long i0 = 0; i0 < d->n || i0 == 0; i0 += run) {
+    srl_conv_desc s = *d;
+    s.n = d->n - i0 < run ? d->n - i0 : run;
+    const long adv = row_index ? 0 : i0;
+    const int rc = conv2d_obs_fwd_run(stream, &s, static_cast<const uint8_t*>(obs) + adv * in_b, 1, 1, mean + adv, rstd + adv, gamma,
+                                      beta, w, bias, nullptr, workspace, row_index ? row_index + i0 : nullptr, y_absmax,
+                                      y_mask ? y_mask + i0 * out_e / 32 : nullptr, reuse_folded || i0 > 0,
+                                      static_cast<uint8_t*>(y_h2) + i0 * out_e * 4, y_scale, ent_order);
     if (rc != 0) return rc;
   }
   return 0;

@@ -441,7 +441,7 @@ inline int h2conv_launch(hipStream_t st, const H2ConvArgs& a, int max_blocks = 2
 __host__ __device__ inline int h2_entry(int y, int x, int H, int W, int order) {
   return order == 2 ? ((y & 1) * 2 + (x & 1)) * ((H / 2) * (W / 2)) + (y >> 1) * (W / 2) + (x >> 1) : y * W + x;
 }
-__global__ void h2_pack_planar_kernel(const float* __restrict__ src, int64_t n, int H, int W, int C, int order, const float* absmax,
+static __global__ void h2_pack_planar_kernel(const float* __restrict__ src, int64_t n, int H, int W, int C, int order, const float* absmax,
                                       const float* scale_in, float* scale_out, uint8_t* __restrict__ dst) {
   const float scale = scale_in ? *scale_in : h2_scale_for(*absmax);
   if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
@@ -469,7 +469,7 @@ __global__ void h2_pack_planar_kernel(const float* __restrict__ src, int64_t n, 
   }
 }
 // float32 NHWC -> h2p rows [n][NPIX][C] with the pixels of an image in `order` (h2_entry)
-__global__ void h2_pack_pixrows_kernel(const float* __restrict__ src, int64_t n, int H, int W, int C, int order, const float* absmax,
+static __global__ void h2_pack_pixrows_kernel(const float* __restrict__ src, int64_t n, int H, int W, int C, int order, const float* absmax,
                                        const float* scale_in, float* scale_out, uint8_t* __restrict__ dst) {
   const float scale = scale_in ? *scale_in : h2_scale_for(*absmax);
   if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
@@ -495,7 +495,7 @@ __global__ void h2_pack_pixrows_kernel(const float* __restrict__ src, int64_t n,
     d[1] = h1;
   }
 }
-__global__ void h2_unpack_planar_kernel(const uint8_t* __restrict__ src, int64_t n, int H, int W, int C, int order, const float* scale,
+static __global__ void h2_unpack_planar_kernel(const uint8_t* __restrict__ src, int64_t n, int H, int W, int C, int order, const float* scale,
                                         float* __restrict__ dst) {
   const float inv = 1.f / *scale;
   const int64_t ngrp = n * H * W * (C / 8);
@@ -563,6 +563,11 @@ struct H2WgradArgs {
 
 typedef short h2_s16x4 __attribute__((ext_vector_type(4)));
 
+// byte offset of plane index (cb * 4 + g) * 2 + piece inside a staged planar image whose planes are `plane` bytes: groups 2, 3
+// lie 128 bytes (mod 256) off groups 0, 1 of the same block -- the 32 lanes of a transposed read take both -- and each block
+// starts 256 bytes later so that the skewed planes do not run into the next block
+__host__ __device__ constexpr int h2w_plane_base(int idx, int plane) { return idx * plane + (idx >> 3) * 256 + (((idx >> 1) & 3) >= 2 ? 128 : 0); }
+
 __device__ __forceinline__ h2_s16x4 h2_tr_read(const uint8_t* p) {
   typedef __attribute__((address_space(3))) h2_s16x4 lds_s16x4;
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
@@ -576,10 +581,10 @@ __global__ __launch_bounds__(512, 2) void h2wgrad_kernel(H2WgradArgs a) {
   constexpr int NCHUNK = (NE + 31) / 32;
   constexpr int ZE = NCHUNK * 32;                         // dz grid entries staged per image (zero beyond the outputs)
   constexpr int ZPLANE = ZE * 16;                         // bytes of one dz plane
-  constexpr int ZBYTES = 16 * ZPLANE + 128;               // 2 blocks x 4 groups x 2 pieces, groups 2, 3 skewed by 128 bytes
+  constexpr int ZBYTES = 16 * ZPLANE + 512;               // 2 blocks x 4 groups x 2 pieces; groups 2, 3 skewed by 128 bytes, blocks by 256
   constexpr int XE = GE::X_ROWS ? GE::XPIX : ((GE::XPIX + 15) / 16) * 16;   // x entries per plane (planar) / pixels (rows)
   constexpr int XPLANE = XE * 16;
-  constexpr int XBYTES = GE::X_ROWS ? GE::XPIX * 128 : CBX * 8 * XPLANE + 128;
+  constexpr int XBYTES = GE::X_ROWS ? GE::XPIX * 128 : CBX * 8 * XPLANE + CBX * 256;
   constexpr int XB_AL = (XBYTES + 1023) / 1024 * 1024, ZB_AL = (ZBYTES + 1023) / 1024 * 1024;
   constexpr int SLOT = XB_AL + ZB_AL;
   constexpr int NDX = XB_AL / 1024, NDZ = ZB_AL / 1024, NDMA = NDX + NDZ, NDW = (NDMA + 7) / 8;
@@ -611,32 +616,25 @@ __global__ __launch_bounds__(512, 2) void h2wgrad_kernel(H2WgradArgs a) {
         const int P = b >> 7, sl = (b >> 4) & 7;
         if (P < GE::XPIX) off = P * 128 + 16 * (sl ^ (((P >> 1) & 1) | (((P >> 2) & 1) << 2)));
       } else {
-        // plane pl_i = ((cb * 4 + g) * 2 + piece) at pl_i * XPLANE + (g >= 2 ? 128 : 0)
-        const int pl_i = b / XPLANE;
-        if (pl_i < CBX * 8) {
-          const int g = (pl_i >> 1) & 3;
-          const int e = (b - pl_i * XPLANE - (g >= 2 ? 128 : 0));
-          if (e >= 0 && (e >> 4) < GE::XPIX && b - (g >= 2 ? 128 : 0) >= pl_i * XPLANE) off = pl_i * (GE::XPIX * 16) + (e >> 4) * 16;
+        // plane pl_i = (cb * 4 + g) * 2 + piece lies at h2w_plane_base(pl_i, XPLANE)
+#pragma unroll
+        for (int pl_i = 0; pl_i < CBX * 8; ++pl_i) {
+          const int rel = b - h2w_plane_base(pl_i, XPLANE);
+          if (rel >= 0 && rel < XPLANE && (rel >> 4) < GE::XPIX) off = pl_i * (GE::XPIX * 16) + (rel >> 4) * 16;
         }
       }
     } else if (j < NDMA) {
       const int b = (j - NDX) * 1024 + lane * 16;
-      // dz planes: index pl_i at pl_i * ZPLANE + (g >= 2 ? 128 : 0); entry = grid cell (oy, ox) of the GW-wide grid
-      int pl_i = b / ZPLANE;
-      if (pl_i > 15) pl_i = 15;
-      const int g = (pl_i >> 1) & 3;
-      int rel = b - pl_i * ZPLANE - (g >= 2 ? 128 : 0);
-      // the skew pushes the tail of plane pl_i into what would be plane pl_i + 1's first 128 bytes: attribute them back
-      if (rel < 0 && pl_i > 0) {
-        const int pp = pl_i - 1, gp = (pp >> 1) & 3;
-        const int relp = b - pp * ZPLANE - (gp >= 2 ? 128 : 0);
-        if (relp < ZPLANE) { pl_i = pp; rel = relp; }
-      }
-      if (rel >= 0 && rel < ZPLANE) {
-        const int e = rel >> 4, oy = e / GE::GW, ox = e - oy * GE::GW;
-        if (ox < GE::OW && oy < GE::OH) {
-          const int zp = oy * GE::ZW + ox;
-          off = GE::Z_ROWS ? zp * 256 + pl_i * 16 : pl_i * (GE::ZPIX * 16) + zp * 16;
+      // dz planes at h2w_plane_base(pl_i, ZPLANE); entry = grid cell (oy, ox) of the GW-wide grid
+#pragma unroll
+      for (int pl_i = 0; pl_i < 16; ++pl_i) {
+        const int rel = b - h2w_plane_base(pl_i, ZPLANE);
+        if (rel >= 0 && rel < ZPLANE) {
+          const int e = rel >> 4, oy = e / GE::GW, ox = e - oy * GE::GW;
+          if (ox < GE::OW && oy < GE::OH) {
+            const int zp = oy * GE::ZW + ox;
+            off = GE::Z_ROWS ? zp * 256 + pl_i * 16 : pl_i * (GE::ZPIX * 16) + zp * 16;
+          }
         }
       }
     }
@@ -659,8 +657,8 @@ __global__ __launch_bounds__(512, 2) void h2wgrad_kernel(H2WgradArgs a) {
   // ---- operand addresses of this lane inside a slot.  A transposed read: lane 4 q + p of octet o names position 4 o + q
   // (first read; + 16: second) and the 8 bytes of channels 4 p .. 4 p + 3 of a 16-channel block c16: group 2 (p & 1) + (c16 & 1),
   // elements 4 (p >> 1) .. of its entry.
-  auto zplane = [&](int cb32, int g, int pl) { return ((cb32 * 4 + g) * 2 + pl) * ZPLANE + (g >= 2 ? 128 : 0); };
-  auto xplane = [&](int cb32, int g, int pl) { return ((cb32 * 4 + g) * 2 + pl) * XPLANE + (g >= 2 ? 128 : 0); };
+  auto zplane = [&](int cb32, int g, int pl) { return h2w_plane_base((cb32 * 4 + g) * 2 + pl, ZPLANE); };
+  auto xplane = [&](int cb32, int g, int pl) { return h2w_plane_base((cb32 * 4 + g) * 2 + pl, XPLANE); };
   const int ent = 4 * o + q, half8 = 8 * (p >> 1);
   // cout blocks of this wavefront
   const int mc0 = GE::MC == 4 ? 0 : (wid & 1) * 2;
@@ -689,7 +687,7 @@ __global__ __launch_bounds__(512, 2) void h2wgrad_kernel(H2WgradArgs a) {
   for (int m = 0; m < GE::MC; ++m)
 #pragma unroll
     for (int n2 = 0; n2 < GE::NN; ++n2) acc[m][n2] = h2_f32x4{0.f, 0.f, 0.f, 0.f};
-  float dbs = 0.f;   // bias gradient of cout (lane & 15) of block mc0 (conv2: wavefronts 0..3 take block wid; conv3: 0, 1 take their two)
+  float dbs[2] = {0.f, 0.f};   // bias gradient of cout (lane & 15): conv2, wavefronts 0..3: block wid in [0]; conv3, wavefronts 0, 1: their two blocks
 
   auto frag = [&](const uint8_t* p0, const uint8_t* p1) {
     union { h2_s16x4 s[2]; h2_f16x8 v; } f;
@@ -719,8 +717,8 @@ __global__ __launch_bounds__(512, 2) void h2wgrad_kernel(H2WgradArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) t += (float)af[m][0][e] + (float)af[m][1][e];
-            if (GE::MC == 4) dbs += t;
-            else if (m == 0) dbs += t;   // conv3: block mc0 here, block mc0 + 1 below
+            if (GE::MC == 4) dbs[0] += t;
+            else dbs[m & 1] += t;
           }
         }
       }
@@ -793,16 +791,19 @@ __global__ __launch_bounds__(512, 2) void h2wgrad_kernel(H2WgradArgs a) {
     }
   {
     // db: lane (cout i = lane & 15, octet o) summed over the 4 octets
-    float t = dbs;
-    t += __shfl_xor(t, 16);
-    t += __shfl_xor(t, 32);
     const bool mine = GE::MC == 4 ? wid < 4 : wid < 2;
-    if (mine && lane < 16) slab[64 * K + 16 * (GE::MC == 4 ? wid : mc0) + lane] = t / *a.sz;
+#pragma unroll
+    for (int m = 0; m < (GE::MC == 4 ? 1 : 2); ++m) {
+      float t = dbs[m];
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      if (mine && lane < 16) slab[64 * K + 16 * (GE::MC == 4 ? wid : mc0 + m) + lane] = t / *a.sz;
+    }
   }
 }
 
 // dst[i] (+)= sum over slabs; i < 64 K: weight gradient, then 64 bias gradients
-__global__ void h2_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, int per_slab, int nw, float* __restrict__ gw,
+static __global__ void h2_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, int per_slab, int nw, float* __restrict__ gw,
                                        float* __restrict__ gb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= per_slab) return;
@@ -818,9 +819,9 @@ inline int h2wgrad_launch(hipStream_t st, const H2WgradArgs& a, int grid) {
   auto kern = h2wgrad_kernel<ID, NSLOT>;
   constexpr int CBX = GE::CIN / 32;
   constexpr int NE = (GE::OH - 1) * GE::GW + GE::OW, NCHUNK = (NE + 31) / 32, ZE = NCHUNK * 32;
-  constexpr int ZBYTES = 16 * ZE * 16 + 128;
+  constexpr int ZBYTES = 16 * ZE * 16 + 512;
   constexpr int XE = GE::X_ROWS ? GE::XPIX : ((GE::XPIX + 15) / 16) * 16;
-  constexpr int XBYTES = GE::X_ROWS ? GE::XPIX * 128 : CBX * 8 * XE * 16 + 128;
+  constexpr int XBYTES = GE::X_ROWS ? GE::XPIX * 128 : CBX * 8 * XE * 16 + CBX * 256;
   constexpr int SLOT = (XBYTES + 1023) / 1024 * 1024 + (ZBYTES + 1023) / 1024 * 1024;
   static bool attr_set = false;
   if (!attr_set) {

@@ -85,6 +85,7 @@ struct H2Args {
   float* out_absmax;        // max |out| folded in (atomic max), or null
   uint32_t* mask_out;       // relu sign bits of out, natural element order, or null
   const uint32_t* mask_in;  // out *= bit of this mask at the output element (relu derivative), or null
+  int32_t mask_in_h2;       // mask_in's bits are in h2 order (bit 8 g + j of a 32-block's word: what h2conv.h's forward kernels write)
 };
 
 #ifdef __HIPCC__
@@ -143,7 +144,7 @@ __device__ __forceinline__ void h2_split_pair(float a, float b, float scale, uin
 // ---------------------------------------------------------------------------------------------------------------------
 // float32 [rows, C] (pitch ld floats) -> h2p rows (pitch C * 4 bytes) under *scale_out = h2_scale_for(*absmax * (headroom))
 // One thread per group of 8 elements.  scale: if scale_in != null use *scale_in, else derive from *absmax and write *scale_out.
-__global__ void h2_pack_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int C, const float* absmax,
+static __global__ void h2_pack_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int C, const float* absmax,
                                const float* scale_in, float* scale_out, uint8_t* __restrict__ dst) {
   const float scale = scale_in ? *scale_in : h2_scale_for(*absmax);
   if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
@@ -168,7 +169,7 @@ __global__ void h2_pack_kernel(const float* __restrict__ src, int64_t ld, int64_
 }
 
 // h2p rows -> float32 (tests, fallbacks)
-__global__ void h2_unpack_kernel(const uint8_t* __restrict__ src, int64_t rows, int C, const float* scale, float* __restrict__ dst,
+static __global__ void h2_unpack_kernel(const uint8_t* __restrict__ src, int64_t rows, int C, const float* scale, float* __restrict__ dst,
                                  int64_t ld) {
   const float inv = 1.f / *scale;
   const int64_t ngrp = rows * (C / 8);
@@ -447,8 +448,8 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
       if (g.mask_in) {
         const uint32_t mw = ok ? g.mask_in[elem0 >> 5] : 0u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (!((mw >> ((r & 3) + 8 * (r >> 2) + 4 * hl)) & 1u)) v[r] = 0.f;
+        for (int r = 0; r < 16; ++r)   // h2 order: registers 0-7 are group 2 hl, 8-15 group 2 hl + 1: bit 16 hl + r
+          if (!((mw >> (g.mask_in_h2 ? 16 * hl + r : (r & 3) + 8 * (r >> 2) + 4 * hl)) & 1u)) v[r] = 0.f;
       }
       if (g.mask_out) {
         uint32_t bits = 0;

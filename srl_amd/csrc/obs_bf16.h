@@ -23,6 +23,7 @@
 // two >= 16 bytes, 16-byte aligned samples.
 #pragma once
 #include "gemm_core.h"
+#include "h2gemm.h"
 
 namespace srlobs {
 
@@ -98,12 +99,12 @@ inline unsigned xcd_position_grid(int P, int nsplit) { return 8u * (unsigned)((P
 template <class Index>
 __global__ __launch_bounds__(256) void obs_fold_split_kernel(const float* w, const float* bias, const float* gamma,
                                                              const float* beta, int P, int Kp, Index ix, uint16_t* wq,
-                                                             float* S, float* b2) {
-  __shared__ double red[8];
+                                                             float* S, float* b2, float* bound = nullptr, float sqrt_n = 0.f) {
+  __shared__ double red[12];
   const int pos = blockIdx.x / kCout, o = blockIdx.x % kCout;
   const int oh = pos / ix.OW, ow = pos % ix.OW;
   const int nkb = Kp / 16;
-  double acc[2] = {0.0, 0.0};  // sum_k w gamma, sum_k w beta
+  double acc[3] = {0.0, 0.0, 0.0};  // sum_k w gamma, sum_k w beta, sum_k (w gamma)^2
   for (int k = threadIdx.x; k < Kp; k += 256) {
     int ci, kh, kw;
     ix.split_k(k, ci, kh, kw);
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void obs_fold_split_kernel(const float* w, con
     const float wg = wv * gamma[p];  // the float32 product the float32 path folds as well
     acc[0] += (double)wg;
     acc[1] += (double)wv * (double)beta[p];
+    acc[2] += (double)wg * (double)wg;
     uint32_t b[3];
     split3(wg, b[0], b[1], b[2]);
     const int c = k >> 5, h = (k >> 4) & 1, e = (k >> 3) & 1, j = k & 7;
@@ -119,10 +121,14 @@ __global__ __launch_bounds__(256) void obs_fold_split_kernel(const float* w, con
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) wq[((((long)pos * 3 + pl) * nkb + kb) * 64 + lane) * 8 + j] = (uint16_t)(b[pl] >> 16);
   }
-  block_sum<2, 256>(acc, red);
+  block_sum<3, 256>(acc, red);
   if (threadIdx.x == 0) {
     S[pos * kCout + o] = (float)acc[0];
-    b2[pos * kCout + o] = (float)((bias ? (double)bias[o] : 0.0) + acc[1]);
+    const double bb = (bias ? (double)bias[o] : 0.0) + acc[1];
+    b2[pos * kCout + o] = (float)bb;
+    // |y| = |sum_k xhat_k wg_k + b2| <= |xhat_patch|_2 |wg|_2 + |b2| <= sqrt(N) |wg|_2 + |b2|: the normalised observation has
+    // sum of squares <= N over ALL its N elements (Cauchy-Schwarz; holds for any frame)
+    if (bound) atomicMax(reinterpret_cast<int*>(bound), __float_as_int((float)(sqrt(acc[2]) * (double)sqrt_n + fabs(bb)) * 1.0001f));
   }
 }
 
@@ -137,6 +143,14 @@ struct FwdArgs {
   float* y_absmax;  // max |y| folded in with an atomic max (the range of the next layer's operand), or NULL
   uint32_t* y_mask;  // [n][P] words: bit o of word (n, pos) = (y[n][pos][o] > 0), the ReLU derivative for the data gradient
                      // of the next layer (GemmArgs::dact_mask), or NULL
+  // H2OUT: instead of y, the pre-split activation the image-stationary convolution behind this layer reads (h2conv.h):
+  // rows of h2p, [n][P][32 channels -> 128 bytes], the P positions of a sample in `ent_order` (h2_entry: 2 = parity-class
+  // major for a stride-2 consumer), under the power-of-two scale derived from *bound (obs_fold_split_kernel: an upper bound
+  // of |y| from the folded weights, known before a single sample is seen); *y_scale = that scale, for the consumers
+  uint8_t* y_h2;
+  const float* bound;
+  float* y_scale;
+  int ent_order, OH;
 };
 
 // One workgroup = one output position x one range of samples.  The position's folded weights (3 planes, 48 KB) sit in
@@ -149,7 +163,7 @@ struct FwdArgs {
 // 4 = no stores, 8 = the patch loads of every tile go to the first tile's rows (cache-hot)
 // MASK: also leave the sign bits of the ReLU output (FwdArgs::y_mask).  A template parameter because the kernel sits at the
 // register limit of three wavefronts per SIMD: the variant without it must stay exactly what it was.
-template <int KP, int DBG = 0, bool MASK = false>
+template <int KP, int DBG = 0, bool MASK = false, bool H2OUT = false>
 __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
   constexpr int NKB = KP / 16, NC = KP / 32;
   __shared__ uint4 Wl[3 * NKB * 64];
@@ -163,6 +177,16 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
     for (int i = 0; i < 3 * NKB * 64 / 256; ++i) Wl[tid + 256 * i] = src[tid + 256 * i];
   }
   const float S_o = a.S[pos * kCout + l31], b2_o = a.b2[pos * kCout + l31];  // this lane's output channel is l31
+  __shared__ __attribute__((aligned(16))) float sbl[2][32];  // H2OUT: S and b2 of the position's 32 channels (lanes hold samples there)
+  float oscale = 1.f;
+  int ent = 0;
+  if (H2OUT) {
+    if (tid < 32) { sbl[0][tid] = a.S[pos * kCout + tid]; sbl[1][tid] = a.b2[pos * kCout + tid]; }
+    oscale = srlh2::h2_scale_for(*a.bound);
+    if (blockIdx.x == 0 && tid == 0) *a.y_scale = oscale;
+    const int py = pos / a.g.OW, px = pos % a.g.OW;
+    ent = a.ent_order == 2 ? ((py & 1) * 2 + (px & 1)) * ((a.OH / 2) * (a.g.OW / 2)) + (py >> 1) * (a.g.OW / 2) + (px >> 1) : pos;
+  }
   __syncthreads();
   const long ntiles = (a.g.n + 31) / 32;
   const long t0 = ntiles * split / a.nsplit, t1 = ntiles * (split + 1) / a.nsplit;
@@ -237,7 +261,10 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
             xx.v = e ? x1 : x0;
             acc[3 * e + pl] += __uint_as_float(wf.u.x) * xx.f[0];
           } else {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e ? x1 : x0, wf.v, acc, 0, 0, 0);
+            // H2OUT: operands swapped -- D[o][n], lanes = samples: a lane then holds 16 channels of ONE sample, which is what
+            // a 16-byte chunk of h2p is made of
+            if (H2OUT) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.v, e ? x1 : x0, acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e ? x1 : x0, wf.v, acc, 0, 0, 0);
           }
         }
     }
@@ -248,6 +275,47 @@ __global__ __launch_bounds__(256, 3) void obs_fwd_bf16_kernel(FwdArgs a) {
     __builtin_amdgcn_wave_barrier();
     const long n0 = tile * 32;
     const bool full = n0 + 32 <= a.g.n;  // wave-uniform: only the batch's last tile is ragged
+    if (H2OUT) {
+      // lane = sample n0 + l31 (both halves h), register r = channel (r & 3) + 8 (r >> 2) + 4 h: registers 0-7 are group 2 h of
+      // h2p, registers 8-15 group 2 h + 1 -- 64 contiguous bytes per lane, the two halves complete the sample's 128-byte row
+      const float rv = rowl[wave][set][0][l31], mv = rowl[wave][set][1][l31];
+      const bool ok = full || n0 + l31 < a.g.n;
+      float v[16];
+      uint32_t bits = 0;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 s4 = *reinterpret_cast<const float4*>(&sbl[0][8 * g4 + 4 * h]);
+        const float4 b4 = *reinterpret_cast<const float4*>(&sbl[1][8 * g4 + 4 * h]);
+        const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float t = fmaf(rv, acc[4 * g4 + i], fmaf(mv, sv[i], bv[i]));
+          if (a.act == 1) t = fmaxf(t, 0.f);
+          else if (a.act == 2) t = tanhf(t);
+          v[4 * g4 + i] = t;
+          if (ok) amx = fmaxf(amx, fabsf(t));
+          bits |= (t > 0.f ? 1u : 0u) << (8 * g4 + 4 * h + i);
+        }
+      }
+      uint4 c[4];
+      srlh2::h2_split_pair(v[0], v[1], oscale, c[0].x, c[1].x);
+      srlh2::h2_split_pair(v[2], v[3], oscale, c[0].y, c[1].y);
+      srlh2::h2_split_pair(v[4], v[5], oscale, c[0].z, c[1].z);
+      srlh2::h2_split_pair(v[6], v[7], oscale, c[0].w, c[1].w);
+      srlh2::h2_split_pair(v[8], v[9], oscale, c[2].x, c[3].x);
+      srlh2::h2_split_pair(v[10], v[11], oscale, c[2].y, c[3].y);
+      srlh2::h2_split_pair(v[12], v[13], oscale, c[2].z, c[3].z);
+      srlh2::h2_split_pair(v[14], v[15], oscale, c[2].w, c[3].w);
+      if (ok) {
+        uint4* d = reinterpret_cast<uint4*>(a.y_h2 + ((n0 + l31) * (long)a.P + ent) * 128 + h * 64);
+        d[0] = c[0]; d[1] = c[1]; d[2] = c[2]; d[3] = c[3];
+      }
+      if (MASK) {
+        bits |= (uint32_t)__shfl_xor((int)bits, 32);
+        if (ok && h == 0) a.y_mask[(n0 + l31) * a.P + pos] = bits;
+      }
+      return;
+    }
     float* yp = a.y + n0 * ldy + (long)pos * kCout + l31;
     const int ldy32 = (int)ldy;
     float vv[16];  // MASK: the stored values in accumulator order

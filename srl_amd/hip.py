@@ -25,7 +25,7 @@ _lib = None
 # (bench.py does, before its imports) -- INTEGRATION.md lists it with the other switches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -65,6 +65,21 @@ class ConvDesc(Structure):
 
 
 _CD = POINTER(ConvDesc)
+
+class H2ConvArgs(Structure):
+    """``srl_h2_conv_args`` (include/srl_hip.h)."""
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("sx", c_void_p), ("sw", c_void_p), ("n", c_int64), ("bias", c_void_p),
+                ("act", c_int32), ("out", c_void_p), ("out_scale", c_void_p), ("bound_in", c_void_p), ("bound_w", c_void_p),
+                ("bound_b", c_void_p), ("out_absmax", c_void_p), ("mask_out", c_void_p), ("mask_in", c_void_p)]
+
+
+class H2GemmDesc(Structure):
+    """``srl_h2_gemm_desc`` (include/srl_hip.h)."""
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("sx", c_void_p), ("sw", c_void_p), ("M", c_int64), ("NC", c_int32), ("K", c_int32),
+                ("bias", c_void_p), ("act", c_int32), ("out_h2", c_int32), ("out", c_void_p), ("out_scale", c_void_p),
+                ("bound_in", c_void_p), ("bound_w", c_void_p), ("bound_b", c_void_p), ("out_absmax", c_void_p),
+                ("mask_out", c_void_p), ("mask_in", c_void_p), ("mask_in_h2order", c_int32)]
+
 
 _SIGNATURES = {
     "srl_conv2d_supported": (c_int, [_CD, c_int]),
@@ -168,6 +183,16 @@ _SIGNATURES = {
     "srl_step_plan_add_output": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_step_plan_run": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_int, POINTER(c_void_p), c_int, c_int]),
     "srl_step_plan_destroy": (c_int, [c_void_p]),
+    "srl_h2_pack_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srl_h2_unpack_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64]),
+    "srl_h2_pack_image": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srl_h2_unpack_image": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "srl_h2_weights": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srl_h2_conv": (c_int, [c_void_p, c_int32, POINTER(H2ConvArgs)]),
+    "srl_h2_wgrad_workspace": (c_int64, [c_int32]),
+    "srl_h2_wgrad": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "srl_h2_gemm": (c_int, [c_void_p, POINTER(H2GemmDesc)]),
+    "srl_conv2d_obs_fwd_h2": (c_int, [c_void_p, POINTER(ConvDesc)] + [c_void_p] * 13 + [c_int, c_int]),
     "srl_comm_available": (c_int, []),
     "srl_comm_unique_id": (c_int, [c_void_p]),
     "srl_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
@@ -305,7 +330,7 @@ def device_info():
     return dict(num_cus=n.value, lds_bytes_per_cu=l.value, arch=buf.value.decode())
 
 
-DISPATCH_FAMILIES = ("gemm3", "gemm_f32", "skinny", "obs_fwd_bf16", "obs_bwd_bf16", "gemm2h", "conv_is")
+DISPATCH_FAMILIES = ("gemm3", "gemm_f32", "skinny", "obs_fwd_bf16", "obs_bwd_bf16", "gemm2h", "conv_is", "h2")
 
 
 def dispatch_counts(reset: bool = False) -> dict:
@@ -911,3 +936,69 @@ _wrap_for_profile(["masked_stats", "masked_normalize", "ppo_loss_fwd_bwd", "cate
                    "categorical_sample", "layernorm_fwd", "layernorm_bwd", "obs_ln_stats", "im2col_obs_ln", "im2col_nhwc",
                    "col2im_nhwc", "obs_ln_affine_bwd", "colsum", "copy2d", "grad_sumsq", "adam_step", "sgd_step",
                    "rmsprop_step"])
+
+
+# ------------------------------------------------------------------------------------------------ pre-split ("h2") kernels
+H2_CONV2_FWD, H2_CONV3_FWD, H2_CONV3_DGRAD, H2_CONV2_DGRAD = 0, 1, 2, 3
+H2_WGRAD_CONV2, H2_WGRAD_CONV3 = 0, 1
+
+
+def _vp(v):
+    """Device pointer (int) or None -> c_void_p."""
+    return c_void_p(int(v)) if v else None
+
+
+def h2_pack_rows(src_ptr, ld, rows, C, dst_ptr, absmax=None, scale_in=None, scale_out=None):
+    _check(lib().srl_h2_pack_rows(_stream(), _vp(src_ptr), int(ld), int(rows), int(C), _vp(absmax), _vp(scale_in), _vp(scale_out),
+                                  _vp(dst_ptr)), "srl_h2_pack_rows")
+
+
+def h2_unpack_rows(src_ptr, rows, C, scale, dst_ptr, ld):
+    _check(lib().srl_h2_unpack_rows(_stream(), _vp(src_ptr), int(rows), int(C), _vp(scale), _vp(dst_ptr), int(ld)), "srl_h2_unpack_rows")
+
+
+def h2_pack_image(src_ptr, n, H, W, C, layout, dst_ptr, absmax=None, scale_in=None, scale_out=None):
+    _check(lib().srl_h2_pack_image(_stream(), _vp(src_ptr), int(n), int(H), int(W), int(C), int(layout), _vp(absmax), _vp(scale_in),
+                                   _vp(scale_out), _vp(dst_ptr)), "srl_h2_pack_image")
+
+
+def h2_unpack_image(src_ptr, n, H, W, C, layout, scale, dst_ptr):
+    _check(lib().srl_h2_unpack_image(_stream(), _vp(src_ptr), int(n), int(H), int(W), int(C), int(layout), _vp(scale), _vp(dst_ptr)),
+           "srl_h2_unpack_image")
+
+
+def h2_weights(w_ptr, rows, K, mode, absmax, scale_out, rownorm_out, dst_ptr, desc=None):
+    _check(lib().srl_h2_weights(_stream(), _vp(w_ptr), int(rows), int(K), int(mode), ctypes.byref(desc) if desc is not None else None,
+                                _vp(absmax), _vp(scale_out), _vp(rownorm_out), _vp(dst_ptr)), "srl_h2_weights")
+
+
+def h2_conv(kind, x, w, sx, sw, n, out, out_absmax, bias=None, act=0, out_scale=None, bound_in=None, bound_w=None, bound_b=None,
+            mask_out=None, mask_in=None):
+    a = H2ConvArgs(_vp(x), _vp(w), _vp(sx), _vp(sw), int(n), _vp(bias), int(act), _vp(out), _vp(out_scale), _vp(bound_in), _vp(bound_w),
+                   _vp(bound_b), _vp(out_absmax), _vp(mask_out), _vp(mask_in))
+    _check(lib().srl_h2_conv(_stream(), int(kind), ctypes.byref(a)), "srl_h2_conv")
+
+
+def h2_wgrad_workspace(kind) -> int:
+    return int(lib().srl_h2_wgrad_workspace(int(kind)))
+
+
+def h2_wgrad(kind, x, dz, sx, sz, n, workspace, gw, gb=None):
+    _check(lib().srl_h2_wgrad(_stream(), int(kind), _vp(x), _vp(dz), _vp(sx), _vp(sz), int(n), _vp(workspace), _vp(gw), _vp(gb)),
+           "srl_h2_wgrad")
+
+
+def h2_gemm(x, w, sx, sw, M, NC, K, out, bias=None, act=0, out_h2=False, out_scale=None, bound_in=None, bound_w=None, bound_b=None,
+            out_absmax=None, mask_out=None, mask_in=None, mask_in_h2order=False):
+    d = H2GemmDesc(_vp(x), _vp(w), _vp(sx), _vp(sw), int(M), int(NC), int(K), _vp(bias), int(act), int(bool(out_h2)), _vp(out),
+                   _vp(out_scale), _vp(bound_in), _vp(bound_w), _vp(bound_b), _vp(out_absmax), _vp(mask_out), _vp(mask_in),
+                   int(bool(mask_in_h2order)))
+    _check(lib().srl_h2_gemm(_stream(), ctypes.byref(d)), "srl_h2_gemm")
+
+
+def conv2d_obs_fwd_h2(desc, obs_ptr, mean, rstd, gamma, beta, w, bias, y_h2, y_scale, ws_ptr, row_index, y_absmax, y_mask,
+                      reuse_folded=False, ent_order=2):
+    ri = _ptr(row_index, torch.int32, "row_index") if isinstance(row_index, torch.Tensor) else row_index
+    _check(lib().srl_conv2d_obs_fwd_h2(_stream(), ctypes.byref(desc), _vp(obs_ptr), _vp(mean), _vp(rstd), _vp(gamma), _vp(beta), _vp(w),
+                                       _vp(bias), _vp(y_h2), _vp(y_scale), _vp(ws_ptr), _vp(ri), _vp(y_absmax), _vp(y_mask),
+                                       int(bool(reuse_folded)), int(ent_order)), "srl_conv2d_obs_fwd_h2")

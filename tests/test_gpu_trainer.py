@@ -304,6 +304,30 @@ def _pong_frames(rng, Tb, B):
     return f
 
 
+def _trunk_activations(net, n):
+    """The four ReLU outputs of the NatureCNN trunk as float32 NHWC vectors, from whichever buffers the forward pass left: the
+    round-3 kernels' float32 activations, or the pre-split ones of the h2 block (h2path.py) unpacked."""
+    from srl_amd import hip
+    P = "obs_modules_dict.obs."
+    bufs = net.ws._bufs
+    if "a:h2.a1" not in bufs:
+        return [bufs[f"a:{P}1._Convolution__model.{idx}.y"] for idx in (0, 2, 4)] + [bufs[f"a:{P}1._Convolution__model.7.0.y"]]
+    from srl_amd.algorithm import h2path
+    slots = bufs["h2.slots"]
+    sp = lambda i: slots.data_ptr() + 4 * i
+    a1 = torch.empty(n * 400 * 32, device="cuda:0")
+    hip.h2_unpack_rows(bufs["a:h2.a1"].data_ptr(), n * 400, 32, sp(h2path.S_A1), a1.data_ptr(), 32)
+    # rows of a sample are in parity-class order: entry = ((y & 1) * 2 + (x & 1)) * 100 + (y >> 1) * 10 + (x >> 1)
+    yy, xx = np.meshgrid(np.arange(20), np.arange(20), indexing="ij")
+    ent = torch.from_numpy((((yy & 1) * 2 + (xx & 1)) * 100 + (yy >> 1) * 10 + (xx >> 1)).reshape(-1)).to("cuda:0")
+    a1 = a1.view(n, 400, 32)[:, ent, :].reshape(-1)
+    a2 = torch.empty(n * 81 * 64, device="cuda:0")
+    hip.h2_unpack_image(bufs["a:h2.a2"].data_ptr(), n, 9, 9, 64, 0, sp(h2path.S_A2), a2.data_ptr())
+    a3 = torch.empty(n * 49 * 64, device="cuda:0")
+    hip.h2_unpack_rows(bufs["a:h2.a3"].data_ptr(), n * 49, 64, sp(h2path.S_A3), a3.data_ptr(), 64)
+    return [a1, a2, a3, bufs[f"a:{P}1._Convolution__model.7.0.y"]]
+
+
 def _relu_flips(net, state64, frames):
     """How many ReLU units of the NatureCNN trunk got a different sign on the device than in a float64 forward pass from the
     same parameters.  A pre-activation within float32 rounding of zero flips its gradient mask -- in the reference's own
@@ -311,20 +335,23 @@ def _relu_flips(net, state64, frames):
     import torch.nn.functional as F
     P = "obs_modules_dict.obs."
     x = F.layer_norm(torch.from_numpy(frames).double(), (4, 84, 84), state64[P + "0.weight"], state64[P + "0.bias"])
+    acts = _trunk_activations(net, frames.shape[0])
     flips = 0
-    for idx, stride in ((0, 4), (2, 2), (4, 1)):
+    for li, (idx, stride) in enumerate(((0, 4), (2, 2), (4, 1))):
         w = state64[f"{P}1._Convolution__model.{idx}.weight"]
         x = F.relu(F.conv2d(x, w, state64[f"{P}1._Convolution__model.{idx}.bias"], stride=stride))
         ref = x.permute(0, 2, 3, 1).reshape(-1)  # the device keeps activations NHWC
-        got = net.ws._bufs[f"a:{P}1._Convolution__model.{idx}.y"][:ref.numel()].cpu()
+        got = acts[li][:ref.numel()].cpu()
         flips += int(((got > 0) != (ref > 0)).sum())
+        # the activations themselves, against float64 (the pre-split ones carry every element to ~2^-22 of the tensor's bound)
+        assert float((got.double() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-6), (idx, float((got.double() - ref).abs().max()))
     x = F.relu(F.linear(x.flatten(1), state64[P + "1._Convolution__model.7.0.weight"], state64[P + "1._Convolution__model.7.0.bias"]))
-    got = net.ws._bufs[f"a:{P}1._Convolution__model.7.0.y"][:x.numel()].cpu()
+    got = acts[3][:x.numel()].cpu()
     return flips + int(((got > 0) != (x.reshape(-1) > 0)).sum())
 
 
 @pytest.mark.parametrize("frames", ["noise", "pong"])
-@pytest.mark.parametrize("kernels", ["bf16x3", "f32"])
+@pytest.mark.parametrize("kernels", ["h2", "bf16x3", "f32"])
 def test_cnn_step_at_the_benchmarked_dispatch(kernels, frames, monkeypatch):
     """The composition bench.py times, end to end against the oracle: NatureCNN `trainer.step` x 2 with 256 rows in ONE
     row chunk, so that every contraction is above the size gates of gemm.hip / conv.hip and runs on `gemm3_kernel` /
@@ -341,6 +368,10 @@ def test_cnn_step_at_the_benchmarked_dispatch(kernels, frames, monkeypatch):
     gradient is below the rounding noise is moved by the SIGN of that noise, in the reference as much as here); both sides
     start every step from the same parameters (the optimiser moments are each side's own)."""
     from srl_amd import hip
+    from srl_amd.algorithm import h2path
+    # "h2": the default since round 4 -- the convolution stack and its Linear on pre-split activations (h2path.py: csrc/h2conv.h,
+    # csrc/h2gemm.h); "bf16x3": round 3's kernels (SRL_H2=0); "f32": the float32 MFMA kernels
+    monkeypatch.setattr(h2path, "ENABLED", kernels == "h2")
     if kernels == "f32":
         monkeypatch.setenv("SRL_MFMA", "f32")
         monkeypatch.setenv("SRL_OBS_BF16", "0")
@@ -397,7 +428,13 @@ def test_cnn_step_at_the_benchmarked_dispatch(kernels, frames, monkeypatch):
             total += err.size
     assert tight >= 0.9 * total, (tight, total)  # the widened tolerances are the exception
     counts = hip.dispatch_counts(reset=True)
-    if kernels == "bf16x3":
+    if kernels == "h2":
+        # per step: conv2, conv3, Linear forward; Linear and both convolutions' data gradients; both convolutions' weight
+        # gradients -- 8 launches of the pre-split family; the Linear's weight gradient on round 3's kernel; the first layer on the
+        # byte kernels; nothing on the float32 MFMA kernels
+        assert counts["h2"] == 2 * 8 and counts["gemm_f32"] == 0 and counts["gemm2h"] + counts["gemm3"] == 2, counts
+        assert counts["obs_fwd_bf16"] == 2 and counts["obs_bwd_bf16"] == 2, counts
+    elif kernels == "bf16x3":
         # conv2/conv3 forward, their weight and data gradients, the three FC products: all on the bf16 matrix cores,
         # the first layer on the byte kernels, only the two heads (N = 6, N = 1) on the skinny kernels
         # (every one of them knows both operands' ranges -- tracked by the producing kernels -- and runs on two f16 pieces
