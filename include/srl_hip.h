@@ -293,6 +293,10 @@ typedef struct srl_gemm_desc {
    * the two-piece kernel -- both ranges given, M > 64, N > 64, K >= 64, aligned operands, and not the small-product path (more
    * than 65 536 outputs or K > 512).  b_absmax must be the float srl_presplit was given. */
   int32_t b_presplit;
+  /* B (b_kmajor 1, N a multiple of 32, ldb == N) is h2p rows (the pre-split format of the srl_h2_* kernels) under this scale
+   * (device float) instead of float32: a weight-gradient product dZ^T X whose X was never written as float32.  Needs a_absmax
+   * and takes the two-piece kernel; b_absmax is ignored. */
+  const float* b_h2_scale;
 } srl_gemm_desc;
 /* dst[i .. i+3] (16 bytes) = the two f16 pieces of src[i .. i+3] under the scale of *absmax: what the two-piece kernels make of a
  * B operand every time they stage a tile of it, done once -- for weights, once per parameter update (srl_gemm_desc::b_presplit,

@@ -436,7 +436,7 @@ template <int ID> static void run_is_wgrad(const char* name, int64_t n, int64_t 
   a.x = xp; a.dz = zp; a.sx = sx; a.sz = sz; a.n = n; a.slabs = slabs;
   auto go = [&] { h2wgrad_launch<ID, C2 ? 2 : 3>(0, a, grid); };
   go();
-  h2_wgrad_reduce_kernel<<<(per + 255) / 256, 256>>>(slabs, grid, per, Cout * K, gw, gb);
+  h2_wgrad_reduce_kernel<<<(per + 63) / 64, 256>>>(slabs, grid, per, Cout * K, gw, gb);
   CK(hipDeviceSynchronize());
   ref_wgrad<<<(per + 63) / 64, 64>>>(x, dz, n, H, W, C, KH, KW, st, Cout, rw, rb);
   g_all_ok &= report("dw vs float64", gw, rw, Cout * K, 2e-6);

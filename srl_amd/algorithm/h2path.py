@@ -147,11 +147,9 @@ class H2Cnn:
         hip.absmax(dy.ptr, n * self.H, self._slot(M_DY))
         dyh = self._bytes(f"{tag}h2.dy", n * self.H * 4)
         hip.h2_pack_rows(dy.ptr, self.H, n, self.H, dyh, absmax=self._slot(M_DY), scale_out=self._slot(S_DY))
-        # Linear: weight gradient through the round-3 kernel on a float32 copy of a3 (beside the data-gradient chain)
-        a3f = net._buf(f"{tag}h2.a3f", n, 3136)
-        hip.h2_unpack_rows(saved["a3"], n, 3136, self._slot(S_A3), a3f.ptr, 3136)
-        net._on_side(lambda: net._wgrad(self.H, 3136, n, dy, a3f.ptr, 3136, g(f"{self.fc.prefix}.weight"), g(f"{self.fc.prefix}.bias"),
-                                        None, None))
+        # Linear: weight gradient through the round-3 two-piece kernel, a3 read as the h2p rows it is (gemm_bf16x3.h, BPRE == 2),
+        # beside the data-gradient chain
+        net._on_side(lambda: self._fc_wgrad(n, dy, saved["a3"]))
         # Linear data gradient -> dz3 (h2p rows [n, 49, 64]), ReLU derivative of a3 from its sign bytes
         dz3 = self._bytes(f"{tag}h2.dz3", n * 3136 * 4)
         hip.h2_gemm(dyh, self._bytes("h2.wft", 0), self._slot(S_DY), self._slot(S_WFT), n, 3136, self.H, dz3, out_h2=True,
@@ -179,6 +177,21 @@ class H2Cnn:
                            net._p(f"{self.ln.prefix}.bias"), net._p(f"{self.c1.prefix}.weight"), dz1.ptr, g(f"{self.c1.prefix}.weight"),
                            g(f"{self.c1.prefix}.bias"), g(f"{self.ln.prefix}.weight"), g(f"{self.ln.prefix}.bias"),
                            ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=True, row_index=row_index)
+
+    def _fc_wgrad(self, n, dy, a3):
+        net, g = self.net, self.net._g
+        H = self.H
+        tiles = ((H + 127) // 128) * ((3136 + 127) // 128)
+        from srl_amd.algorithm.hipnet import _split_for
+        split = _split_for(n, tiles)
+        side = net._side_stream is not None and torch.cuda.current_stream() == net._side_stream
+        wsp = net.ws.get("splitk_side" if side else "splitk", split * H * 3136).data_ptr() if split > 1 else None
+        gb = g(f"{self.fc.prefix}.bias")
+        fused = hip.gemm_colsum_ok(H, 3136, n, dy.ptr, dy.ld, a3, 3136, 1)
+        hip.gemm(H, 3136, n, dy.ptr, dy.ld, 1, a3, 3136, 1, g(f"{self.fc.prefix}.weight"), 3136, accumulate=True, split_k=split,
+                 workspace=wsp, a_colsum=gb if fused else None, a_absmax=self._slot(M_DY), b_h2_scale=self._slot(S_A3))
+        if not fused:
+            hip.colsum(dy.ptr, dy.ld, n, H, gb, accumulate=True)
 
     def prefixes(self):
         return [self.ln.prefix, self.c1.prefix, self.c2.prefix, self.c3.prefix, self.fc.prefix]

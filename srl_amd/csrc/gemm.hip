@@ -6,7 +6,7 @@
 #include "gemm_bf16x3.h"
 #include "skinny.h"
 
-static_assert(sizeof(srl_gemm_desc) == 200 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
+static_assert(sizeof(srl_gemm_desc) == 208 && sizeof(srl_ppo_hparams) == 44, "ABI struct layout (mirrored in srl_amd/hip.py)");
 
 using namespace srlgemm;
 
@@ -74,6 +74,7 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   g.dact_src = d->dact_src; g.ld_dact = d->ld_dact; g.dact = d->dact;
   g.mask_out = d->mask_out; g.dact_mask = d->dact_mask;
   g.b_presplit = d->b_presplit;
+  g.b_h2_scale = d->b_h2_scale;
   const int nsplit = plan_split(d->K, split, &g.k_per_split);
   g.o = OutDesc{};
   g.o.f_img = g.o.f_line = make_fastdiv(1);
@@ -98,8 +99,10 @@ extern "C" int srl_gemm(void* stream, const srl_gemm_desc* d) {
   int rc;
   if (nsplit == 1) g.out_absmax = d->out_absmax;
   const bool small = use_bf16x3() && small_gemm() && g.vec_a && g.vec_b && d->M * d->N <= 65536 && d->K >= 4 && d->K <= 512;
-  const bool two = !small && use_bf16x3() && d->a_absmax && d->b_absmax && use_f16x2() && g.vec_a && g.vec_b && d->M > 64 &&
-                   d->N > 64 && d->K >= 64;
+  const bool two = !small && use_bf16x3() && d->a_absmax && (d->b_absmax || d->b_h2_scale) && use_f16x2() && g.vec_a && g.vec_b &&
+                   d->M > 64 && d->N > 64 && d->K >= 64;
+  SRL_CHECK_ARG(!d->b_h2_scale || (two && d->b_kmajor && d->N % 32 == 0 && d->ldb == d->N && !d->b_presplit),
+                "b_h2_scale: a k-major dense B of h2p rows (N a multiple of 32, ldb == N) on the two-piece kernel (a_absmax given)");
   SRL_CHECK_ARG(!d->b_presplit || (two && nsplit >= 1),
                 "b_presplit: only products that take the two-piece kernel (both ranges, M > 64, N > 64, K >= 64, aligned operands, "
                 "more than 65 536 outputs or K > 512)");

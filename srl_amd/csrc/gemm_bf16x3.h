@@ -101,7 +101,7 @@ __device__ __forceinline__ void split2h_quad(const float* v, float scale, uint2 
 
 // registers of a staged tile (Stage::r, float4 quads in Stage's thread -> (row, k) assignment) -> NP planes of 16-bit
 // pieces in LDS (three bf16 planes, or two f16 planes of the scaled operand)
-template <class ST, int BX, bool KMAJOR, int KB, int NT, int NP = 3, bool RAW = false>
+template <class ST, int BX, bool KMAJOR, int KB, int NT, int NP = 3, int RAW = 0>
 __device__ __forceinline__ void store3(const float* regs, uint8_t* lds, float scale = 1.f) {
   using T3 = Tile3<BX, KMAJOR, KB, NP>;
   const int tid = threadIdx.x;
@@ -109,8 +109,20 @@ __device__ __forceinline__ void store3(const float* regs, uint8_t* lds, float sc
   for (int q = 0; q < ST::NV; ++q) {
     const int u = tid + q * NT;
     if (ST::PARTIAL && u >= ST::QUADS) continue;
+    if (RAW == 2) {
+      // the operand is h2p rows (h2gemm.h): the 16 bytes this thread loaded at columns x .. x + 3 of k-row k are 8 elements of ONE
+      // piece -- slot (x / 4) % 8 of the 32-column block x / 32: group g = slot >> 1, piece slot & 1, columns 4 (g >> 1) + 16 (g & 1)
+      // + {0..3} and + {8..11} of the block -- and go to that piece's plane as two 8-byte runs
+      static_assert(RAW != 2 || (KMAJOR && NP == 2), "h2p rows: a k-major operand of the two-piece kernel");
+      const int k = u / (BX / 4), x = (u % (BX / 4)) * 4;
+      const int sl = (x >> 2) & 7, g = sl >> 1, c0 = (x & ~31) + 4 * (g >> 1) + 16 * (g & 1);
+      uint8_t* pb = lds + (sl & 1) * T3::PLANE;
+      *reinterpret_cast<uint2*>(pb + T3::off_km(k, c0)) = make_uint2(__float_as_uint(regs[4 * q]), __float_as_uint(regs[4 * q + 1]));
+      *reinterpret_cast<uint2*>(pb + T3::off_km(k, c0 + 8)) = make_uint2(__float_as_uint(regs[4 * q + 2]), __float_as_uint(regs[4 * q + 3]));
+      continue;
+    }
     uint2 pl[3];
-    if (RAW) {  // the operand arrives already split (BPRE; SRL_GEMM3_DBG & 256 as a timing experiment): two pieces per 16 bytes
+    if (RAW == 1) {  // the operand arrives already split (BPRE; SRL_GEMM3_DBG & 256 as a timing experiment): two pieces per 16 bytes
       pl[0] = make_uint2(__float_as_uint(regs[4 * q]), __float_as_uint(regs[4 * q + 1]));
       pl[1] = make_uint2(__float_as_uint(regs[4 * q + 2]), __float_as_uint(regs[4 * q + 3]));
       pl[2] = pl[0];
@@ -155,7 +167,7 @@ constexpr int min_waves3(int bm, int bn, int kb, int np = 3) {
 // (srl_presplit: same addresses, same strides as the float32 matrix) -- so its tiles go from the registers to LDS as they
 // are.  Weights are split once per update instead of once per tile that stages them: leaving B's split out of the kernels
 // (timing experiment) gave 5-6.5 % on the convolutions and 13-15 % on the FC products.
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB, int NP = 3, int MK = 0, bool BPRE = false>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AMODE, int BMODE, int KB, int NP = 3, int MK = 0, int BPRE = 0>
 __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm3_kernel(GemmArgs g) {
   static_assert(NP == 3 || NP == 2, "three bf16 pieces or two f16 pieces");
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm
   using TA = Tile3<BM, AKM, KB, NP>;
   using TB = Tile3<BN, BKM, KB, NP>;
   constexpr int BUF = TA::BYTES + TB::BYTES;
-  const float sc_a = NP == 2 ? range_scale(g.range_a) : 1.f, sc_b = NP == 2 ? range_scale(g.range_b) : 1.f;
+  const float sc_a = NP == 2 ? range_scale(g.range_a) : 1.f, sc_b = BPRE == 2 ? *g.b_h2_scale : NP == 2 ? range_scale(g.range_b) : 1.f;
   __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm
   }
   cs_acc(sa.r);
   store3<SA, BM, AKM, KB, NT, NP>(sa.r, lds, sc_a);
-  store3<SB, BN, BKM, KB, NT, NP, BPRE || (SRL_GEMM3_DBG & 256) != 0>(sb.r, lds + TA::BYTES, sc_b);
+  store3<SB, BN, BKM, KB, NT, NP, BPRE ? BPRE : ((SRL_GEMM3_DBG & 256) != 0 ? 1 : 0)>(sb.r, lds + TA::BYTES, sc_b);
   __syncthreads();
   if (!PAIR) {  // the second tile -- or, for a product of a single k-step, an out-of-range tile: zeros (the step's staging is
     // unconditional, and the fused column sums would count the first tile twice if it were still in the registers)
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm
         cs_acc(ra);
         if (!(SRL_GEMM3_DBG & 2)) {
           store3<SA, BM, AKM, KB, NT, NP>(ra, nxt, sc_a);           // tile t+1 (or zeros): registers -> the other LDS buffer
-          store3<SB, BN, BKM, KB, NT, NP, BPRE || (SRL_GEMM3_DBG & 256) != 0>(rb, nxt + TA::BYTES, sc_b);
+          store3<SB, BN, BKM, KB, NT, NP, BPRE ? BPRE : ((SRL_GEMM3_DBG & 256) != 0 ? 1 : 0)>(rb, nxt + TA::BYTES, sc_b);
         }
         if (!(SRL_GEMM3_DBG & 1) && (!PAIR || cur == 0)) {
           sa.load(g.a, m0, g.M, k2x, kend, true);         // tile t+2 (or nothing): global -> registers
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(WM * WN * 64, min_waves3(BM, BN, KB, NP)) void gemm
         if (m0 + tid * 4 + c < g.M) atomicAdd(g.a_colsum + (long)by * g.a_colsum_batch + m0 + tid * 4 + c, t4[c]);
     }
   }
-  if (NP == 2 && (g.range_a || g.range_b)) {  // powers of two: exact
+  if (NP == 2 && (g.range_a || g.range_b || BPRE == 2)) {  // powers of two: exact
     const float inv = 1.f / (sc_a * sc_b);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -461,27 +473,32 @@ inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   constexpr bool CAN_PRE = NP == 2 && BMODE == SRC_PLAIN && KB == 16;  // pre-split B: the two-piece kernels, dense B
   auto go = [&](auto mk_c, auto pre_c) {
     constexpr int MK = decltype(mk_c)::value;
-    constexpr bool PRE = decltype(pre_c)::value;
+    constexpr int PRE = decltype(pre_c)::value;
     hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, AKM, BKM, AMODE, BMODE, KB, NP, MK, PRE>), grid, dim3(256), 0, st, a);
   };
   using std::integral_constant;
-  if (a.b_presplit) {
+  constexpr bool CAN_H2 = NP == 2 && BKM && BMODE == SRC_PLAIN && KB == 16;  // B as h2p rows: the two-piece kernels, k-major dense B
+  if (a.b_h2_scale) {
+    if constexpr (!CAN_H2) return -ENOTSUP;
+    else if (a.mask_out || a.dact_mask || a.b_presplit) return -ENOTSUP;
+    else go(integral_constant<int, 0>{}, integral_constant<int, 2>{});
+  } else if (a.b_presplit) {
     if constexpr (!CAN_PRE) return -ENOTSUP;
     else if (a.mask_out) {
-      if constexpr (CAN_W) go(integral_constant<int, 2>{}, std::true_type{});
+      if constexpr (CAN_W) go(integral_constant<int, 2>{}, integral_constant<int, 1>{});
       else return -ENOTSUP;
     } else if (a.dact_mask && !a.dact_src) {
-      if constexpr (CAN_R) go(integral_constant<int, 1>{}, std::true_type{});
+      if constexpr (CAN_R) go(integral_constant<int, 1>{}, integral_constant<int, 1>{});
       else return -ENOTSUP;
-    } else go(integral_constant<int, 0>{}, std::true_type{});
+    } else go(integral_constant<int, 0>{}, integral_constant<int, 1>{});
   } else if (a.mask_out) {
-    if constexpr (CAN_W) go(integral_constant<int, 2>{}, std::false_type{});
+    if constexpr (CAN_W) go(integral_constant<int, 2>{}, integral_constant<int, 0>{});
     else return -ENOTSUP;
   } else if (a.dact_mask && !a.dact_src) {
-    if constexpr (CAN_R) go(integral_constant<int, 1>{}, std::false_type{});
+    if constexpr (CAN_R) go(integral_constant<int, 1>{}, integral_constant<int, 0>{});
     else return -ENOTSUP;
   } else {
-    go(integral_constant<int, 0>{}, std::false_type{});
+    go(integral_constant<int, 0>{}, integral_constant<int, 0>{});
   }
   return 0;
 }

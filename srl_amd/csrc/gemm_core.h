@@ -126,6 +126,7 @@ struct GemmArgs {
   const uint32_t* dact_mask;
   uint32_t mask_off;
   int b_presplit;  // gemm3_kernel NP == 2: B holds srl_presplit's output (see BPRE)
+  const float* b_h2_scale;  // gemm3_kernel NP == 2, k-major dense B: B is h2p rows under this scale (BPRE == 2)
   int act, dact, accumulate;
   long k_per_split;
   int vec_a, vec_b;

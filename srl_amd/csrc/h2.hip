@@ -166,7 +166,7 @@ extern "C" int srl_h2_wgrad(void* stream, int32_t kind, const void* x, const voi
   srl_count_dispatch(SRL_DISP_H2);
   if (kind == H2W_C2) h2wgrad_launch<H2W_C2, 2>(st, a, grid);
   else h2wgrad_launch<H2W_C3, 3>(st, a, grid);
-  hipLaunchKernelGGL(h2_wgrad_reduce_kernel, dim3((unsigned)srl_ceil_div(per, 256)), dim3(256), 0, st, workspace, grid, per, 64 * K, gw, gb);
+  hipLaunchKernelGGL(h2_wgrad_reduce_kernel, dim3((unsigned)srl_ceil_div(per, 64)), dim3(256), 0, st, workspace, grid, per, 64 * K, gw, gb);
   SRL_LAUNCH_CHECK();
   return 0;
 }

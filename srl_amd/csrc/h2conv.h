@@ -802,15 +802,32 @@ __global__ __launch_bounds__(512, 2) void h2wgrad_kernel(H2WgradArgs a) {
   }
 }
 
-// dst[i] (+)= sum over slabs; i < 64 K: weight gradient, then 64 bias gradients
-static __global__ void h2_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, int per_slab, int nw, float* __restrict__ gw,
-                                       float* __restrict__ gb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= per_slab) return;
-  float s = 0.f;
-  for (int k = 0; k < nslab; ++k) s += slabs[(size_t)k * per_slab + i];
-  if (i < nw) gw[i] += s;
-  else if (gb) gb[i - nw] += s;
+// dst[i] += sum over slabs; i < nw: weight gradient, then the bias gradients.  64 outputs per workgroup, four groups of 64
+// threads each taking every fourth slab with four loads in flight (one thread per output walking 256 slabs one after the other
+// was a chain of dependent-latency loads: 63 us per call)
+static __global__ __launch_bounds__(256) void h2_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslab, int per_slab, int nw,
+                                                                     float* __restrict__ gw, float* __restrict__ gb) {
+  __shared__ float part[4][64];
+  const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < per_slab) {
+    int k = sg;
+    for (; k + 12 < nslab; k += 16) {
+      s0 += slabs[(size_t)k * per_slab + i];
+      s1 += slabs[(size_t)(k + 4) * per_slab + i];
+      s2 += slabs[(size_t)(k + 8) * per_slab + i];
+      s3 += slabs[(size_t)(k + 12) * per_slab + i];
+    }
+    for (; k < nslab; k += 4) s0 += slabs[(size_t)k * per_slab + i];
+  }
+  part[sg][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sg == 0 && i < per_slab) {
+    const float s = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+    if (i < nw) gw[i] += s;
+    else if (gb) gb[i - nw] += s;
+  }
 }
 
 template <int ID, int NSLOT>

@@ -51,7 +51,7 @@ class GemmDesc(Structure):
                 ("ldc", c_int64), ("bias", c_void_p), ("act", c_int32), ("dact_src", c_void_p), ("ld_dact", c_int64),
                 ("dact", c_int32), ("accumulate", c_int32), ("split_k", c_int32), ("workspace", c_void_p),
                 ("a_colsum", c_void_p), ("a_absmax", c_void_p), ("b_absmax", c_void_p), ("out_absmax", c_void_p),
-                ("mask_out", c_void_p), ("dact_mask", c_void_p), ("b_presplit", c_int32)]
+                ("mask_out", c_void_p), ("dact_mask", c_void_p), ("b_presplit", c_int32), ("b_h2_scale", c_void_p)]
 
 
 class MlpLayer(Structure):
@@ -539,7 +539,7 @@ def presplit(src_ptr, absmax_ptr, dst_ptr, n):
 
 def gemm(M, N, K, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, bias=None, act=ACT_NONE, dact_src=None, ld_dact=0,
          dact=ACT_NONE, accumulate=False, split_k=1, workspace=None, a_colsum=None, a_absmax=None, b_absmax=None,
-         out_absmax=None, mask_out=None, dact_mask=None, b_presplit=False):
+         out_absmax=None, mask_out=None, dact_mask=None, b_presplit=False, b_h2_scale=None):
     """Raw-pointer GEMM (``A``/``B``/``C``/... are ints from ``data_ptr()`` possibly with byte offsets).
     ``a_colsum``: [M] += sum_k A(i, k) as a by-product (k-major, float4-stageable A; see ``gemm_colsum_ok``).
     ``a_absmax`` / ``b_absmax``: device floats bounding max |A|, max |B| (both given: the two-plane f16 forward kernel);
@@ -548,7 +548,7 @@ def gemm(M, N, K, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, bias=None, act=ACT
     ``b_presplit``: B is ``presplit``'s output (only where ``gemm_two_piece`` says so)."""
     d = GemmDesc(M, N, K, A, lda, int(a_kmajor), B, ldb, int(b_kmajor), C, ldc, bias, int(act), dact_src, ld_dact,
                  int(dact), int(accumulate), int(split_k), workspace, a_colsum, a_absmax, b_absmax, out_absmax,
-                 mask_out, dact_mask, int(bool(b_presplit)))
+                 mask_out, dact_mask, int(bool(b_presplit)), b_h2_scale)
     two = gemm_two_piece(M, N, K, A, lda, B, ldb, a_absmax, b_absmax)
     with _scope("gemm", 2.0 * M * N * K, "2h" if two else "x3"):
         _check(lib().srl_gemm(_stream(), ctypes.byref(d)), "srl_gemm")

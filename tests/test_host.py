@@ -40,7 +40,7 @@ def test_cabi_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert hip.lib().srl_abi_version() == hip.ABI_VERSION
     # struct layouts the binding assumes
-    assert ctypes.sizeof(hip.PpoHparams) == 44 and ctypes.sizeof(hip.GemmDesc) == 200
+    assert ctypes.sizeof(hip.PpoHparams) == 44 and ctypes.sizeof(hip.GemmDesc) == 208
 
 
 def test_product_path_fails_loudly_without_gpu():
