@@ -22,6 +22,7 @@ __global__ void fill_kernel(float* p, int64_t n, uint64_t seed, float amp, int k
     const uint32_t h = hash32(seed * 0x9e3779b97f4a7c15ull + i);
     float u = (float)(h >> 8) * (1.f / 16777216.f) * 2.f - 1.f;
     if (kind == 1) { u = u < 0.f ? 0.f : u * u * 3.f; }
+    if (kind == 2) { u = fabsf(u) + 0.1f; }
     p[i] = u * amp;
   }
 }
@@ -288,6 +289,15 @@ static void run_dgrad(const char* name, int64_t n, int H, int W, int C, int KH, 
   const float* got = y;
   if (h2out) { h2_unpack_kernel<<<2048, 256>>>((const uint8_t*)y, n * H * W, C, osc, yu, C); got = yu; }
   g_all_ok &= report("dx vs float64", got, yr, n * H * W * C, 2e-6);
+  if (getenv("H2_PERIMG") && n <= 64) {
+    std::vector<float> hg(n * H * W * C), hr(n * H * W * C);
+    CK(hipMemcpy(hg.data(), got, hg.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hr.data(), yr, hr.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t img = 0; img < n; ++img) {
+      int bad = 0, first = -1;
+      for (int i = 0; i < H * W * C; ++i) if (fabsf(hg[img * H * W * C + i] - hr[img * H * W * C + i]) > 1e-7f) { if (first < 0) first = i; ++bad; }
+      printf("    image %ld: %d wrong of %d (first at pixel %d ch %d)\n", (long)img, bad, H * W * C, first / C, first % C);
+    }
+  }
   float oamh, rmh; float* rm = absmax_of(yr, n * H * W * C);
   CK(hipMemcpy(&oamh, oam, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&rmh, rm, 4, hipMemcpyDeviceToHost));
   printf("  absmax %.5g (ref %.5g)\n", oamh, rmh);
@@ -347,7 +357,7 @@ template <int ID> static void run_is_fwd(const char* name, int64_t n, int64_t nt
     const double ms = time_ms([&] { h2conv_launch<ID>(0, a); }, 20);
     printf("  TIME n=%ld: %.1f us  (%.1f TFLOP/s float32-equivalent; %.2f TB/s of in+out bytes)\n", (long)nt, ms * 1e3,
            2.0 * Mx * Cout * K / ms * 1e-9, (nx * H * W * C * 4.0 + Mx * Cout * 4.0) / ms * 1e-9);
-    if constexpr (ID == H2C_F2) printf("  3 slots: %.1f us\n", 1e3 * time_ms([&] { h2conv_launch<ID, 3>(0, a); }, 20));
+    if constexpr (ID == H2C_F2 || ID == H2C_F3) printf("  3 slots: %.1f us\n", 1e3 * time_ms([&] { h2conv_launch<ID, 3>(0, a); }, 20));
     printf("  128 workgroups: %.1f us\n", 1e3 * time_ms([&] { h2conv_launch<ID>(0, a, 128); }, 20));
 
   }
@@ -363,7 +373,7 @@ template <int ID> static void run_is_dgrad(const char* name, int64_t n, int64_t 
   printf("%s: IS conv dgrad n=%ld dz %dx%dx%d -> dx %dx%dx%d k%d s%d\n", name, (long)n, OH, OW, Cout, H, W, C, KH, st);
   const int64_t nx = n > nt ? n : nt;
   float* dz = dalloc<float>(nx * OH * OW * Cout); float* w = dalloc<float>((int64_t)Cout * KH * KW * C); float* act = dalloc<float>(nx * H * W * C);
-  fill(dz, nx * OH * OW * Cout, 41, 1e-3f, 0); fill(w, (int64_t)Cout * KH * KW * C, 42, 0.05f); fill(act, nx * H * W * C, 43, 1.f, 1);
+  fill(dz, nx * OH * OW * Cout, 41, 1e-3f, 0); fill(w, (int64_t)Cout * KH * KW * C, 42, 0.05f); fill(act, nx * H * W * C, 43, 1.f, getenv("H2_ALLPOS") ? 2 : 1);
   float* wg = dalloc<float>((int64_t)NC * Kg);
   regroup_kernel<<<(NC * Kg + 255) / 256, 256>>>(w, C, KH, KW, st, Cout, wg);
   float *sx, *sw; float* ax = absmax_of(dz, nx * OH * OW * Cout); float* aw = absmax_of(wg, (int64_t)NC * Kg);
@@ -384,6 +394,15 @@ template <int ID> static void run_is_dgrad(const char* name, int64_t n, int64_t 
   const float* got = y;
   if (D3) { h2_unpack_planar_kernel<<<2048, 256>>>((const uint8_t*)y, n, H, W, C, 0, osc, yu); got = yu; }
   g_all_ok &= report("dx vs float64", got, yr, n * H * W * C, 2e-6);
+  if (getenv("H2_PERIMG") && n <= 64) {
+    std::vector<float> hg(n * H * W * C), hr(n * H * W * C);
+    CK(hipMemcpy(hg.data(), got, hg.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hr.data(), yr, hr.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t img = 0; img < n; ++img) {
+      int bad = 0, first = -1;
+      for (int i = 0; i < H * W * C; ++i) if (fabsf(hg[img * H * W * C + i] - hr[img * H * W * C + i]) > 1e-7f) { if (first < 0) first = i; ++bad; }
+      printf("    image %ld: %d wrong of %d (first at pixel %d ch %d)\n", (long)img, bad, H * W * C, first / C, first % C);
+    }
+  }
   float oamh, rmh; float* rm = absmax_of(yr, n * H * W * C);
   CK(hipMemcpy(&oamh, oam, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&rmh, rm, 4, hipMemcpyDeviceToHost));
   printf("  absmax %.5g (ref %.5g)\n", oamh, rmh);
@@ -455,7 +474,7 @@ int main(int argc, char** argv) {
   g_stages = argc > 3 ? atoi(argv[3]) : 3;
   const std::string only = argc > 4 ? argv[4] : "";
   printf("h2_probe: check n=%ld, time n=%ld, stages=%d\n", (long)nc, (long)nt, g_stages);
-  auto want = [&](const char* k) { return only.empty() || only.find(k) != std::string::npos; };
+  auto want = [&](const char* k) { return only.empty() || ("," + only + ",").find(std::string(",") + k + ",") != std::string::npos; };
   if (want("fc")) run_dense("FC forward", nc, 512, 3136, false, nt);
   if (want("fcd")) run_dense("FC dgrad-shaped", nc, 3136 - 3136 % 64, 512, true, nt);
   if (want("c2")) run_conv("conv2", nc, 20, 20, 32, 4, 4, 2, 64, nt, false);

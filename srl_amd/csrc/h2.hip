@@ -139,7 +139,7 @@ extern "C" int srl_h2_conv(void* stream, int32_t kind, const srl_h2_conv_args* p
   srl_count_dispatch(SRL_DISP_H2);
   switch (kind) {
     case H2C_F2: h2conv_launch<H2C_F2, 3>(st, a); break;
-    case H2C_F3: h2conv_launch<H2C_F3, 2>(st, a); break;
+    case H2C_F3: h2conv_launch<H2C_F3, 3>(st, a); break;
     case H2C_D3: h2conv_launch<H2C_D3, 2>(st, a); break;
     default: h2conv_launch<H2C_D2, 2>(st, a); break;
   }

@@ -44,6 +44,7 @@ template <int ID> struct H2Geo;
 // under which 16 consecutive pixels read by the mixed-group lanes of a ds_read_b128 fall into 16 different bank groups); a
 // tap's address is then (lane base + tap offset) ^ a byte of a per-lane table: two vector operations per tap.
 template <> struct H2Geo<H2C_F2> {
+  static constexpr int CGW = 1;   // channel groups of 16 per wavefront (they share the positions' fragments)
   static constexpr int CB = 1, NCH = 64, NTAP = 16, GW = 10, OH = 9, OW = 9, NPIX_L = 400, G = 1, PLANE_E = 400;
   static constexpr int SRC = H2S_ROWSWZ, PAD = 0, SH = 20, SW = 20, SPIX = 400;
   static constexpr int DST = H2D_PLANAR, OPIX = 81, OCH = 64;
@@ -53,7 +54,8 @@ template <> struct H2Geo<H2C_F2> {
 };
 // conv3 forward: 9x9x64 (planar, 81 entries) -> 7x7x64, 3x3 stride 1; result as h2p rows for the Linear behind it
 template <> struct H2Geo<H2C_F3> {
-  static constexpr int CB = 2, NCH = 64, NTAP = 9, GW = 9, OH = 7, OW = 7, NPIX_L = 81, G = 3, PLANE_E = 256;
+  static constexpr int CGW = 1;   // channel groups of 16 per wavefront (they share the positions' fragments)
+  static constexpr int CB = 2, NCH = 64, NTAP = 9, GW = 9, OH = 7, OW = 7, NPIX_L = 81, G = 2, PLANE_E = 176;
   static constexpr int SRC = H2S_PLANAR, PAD = 0, SH = 9, SW = 9, SPIX = 81;
   static constexpr int DST = H2D_ROWS, OPIX = 49, OCH = 64;
   static constexpr bool ZERO_BORDER = false;
@@ -63,6 +65,7 @@ template <> struct H2Geo<H2C_F3> {
 // conv3 data gradient: dz 7x7x64 (h2p rows) on an 11x11 zero-bordered grid -> dx 9x9x64 (planar); out (y, x) reads
 // grid (y + 2 - ky, x + 2 - kx)
 template <> struct H2Geo<H2C_D3> {
+  static constexpr int CGW = 1;   // channel groups of 16 per wavefront (they share the positions' fragments)
   static constexpr int CB = 2, NCH = 64, NTAP = 9, GW = 11, OH = 9, OW = 9, NPIX_L = 121, G = 2, PLANE_E = 256;
   static constexpr int SRC = H2S_ROWS, PAD = 2, SH = 7, SW = 7, SPIX = 49;
   static constexpr int DST = H2D_PLANAR, OPIX = 81, OCH = 64;
@@ -73,6 +76,7 @@ template <> struct H2Geo<H2C_D3> {
 // conv2 data gradient: dz 9x9x64 (planar) on an 11x11 zero-bordered grid -> the four parity classes of dx 20x20x32, float32
 // NHWC; class-grid pixel (a, b) reads grid (a + 1 - dy, b + 1 - dx); 128 channels = (class, cin)
 template <> struct H2Geo<H2C_D2> {
+  static constexpr int CGW = 2;   // channel groups of 16 per wavefront (they share the positions' fragments)
   static constexpr int CB = 2, NCH = 128, NTAP = 4, GW = 11, OH = 10, OW = 10, NPIX_L = 121, G = 2, PLANE_E = 256;
   static constexpr int SRC = H2S_PLANAR, PAD = 1, SH = 9, SW = 9, SPIX = 81;
   static constexpr int DST = H2D_F32_ROUTED, OPIX = 400, OCH = 32;
@@ -134,8 +138,9 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
   constexpr int CB = GE::CB, NKB = GE::NTAP * CB, NPL = CB * 8, PLANE_B = GE::PLANE_E * 16;
   constexpr int SLOT = NPL * PLANE_B;
   constexpr int NCG = GE::NCH / 16;              // channel groups of 16
-  constexpr int NPH = 8 / NCG;                   // position halves (8 wavefronts)
-  static_assert(NCG == 4 || NCG == 8, "");
+  constexpr int CGW = GE::CGW, NWG = NCG / CGW;  // ... CGW of them per wavefront: NWG wavefronts across the channels
+  constexpr int NPH = 8 / NWG;                   // position halves (8 wavefronts)
+  static_assert(NWG == 4 || NWG == 8, "");
   constexpr int NE = (GE::OH - 1) * GE::GW + GE::OW;   // entries to walk per image
   constexpr int NB_IMG = (NE + 15) / 16;               // blocks of 16 entries per image
   constexpr int NBT = NB_IMG * GE::G;                  // blocks per batch
@@ -148,27 +153,40 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
   constexpr bool ROUTED = GE::DST == H2D_F32_ROUTED;
   constexpr int OIMGB = GE::OPIX * GE::OCH * 4;        // output image bytes (every format: 4 bytes per element)
   constexpr int MIMGB = GE::OPIX * GE::OCH / 8;        // mask bytes per output image
+  constexpr bool MASK_IN = ID == H2C_D3 || ID == H2C_D2, MASK_OUT = !MASK_IN;
+  // data gradients: the ReLU-derivative bits of a batch's output images ride in with the batch (their own DMA instructions,
+  // behind the image in the slot) and are read from LDS.  Loaded from global memory inside the epilogue they cost far more than
+  // their bytes: vmcnt counts in order, so waiting for a mask word waited for every DMA instruction of the batch prefetched
+  // just before it (waves parked in s_waitcnt 48-57 % of their cycles, matrix pipe 37-46 % busy)
+  constexpr int MREG = MASK_IN ? (GE::G * MIMGB + 1023) / 1024 * 1024 : 0;
+  constexpr int SLOTM = SLOT + MREG;                   // a slot with its mask region
+  constexpr int NDM = MREG / 1024;                     // mask DMA instructions per batch
   extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cg = wid % NCG, ph = wid / NCG;
+  const int cg0 = (wid % NWG) * CGW, ph = wid / NWG;   // first channel group of this wavefront, its position half
   const int p = lane & 15, quad = lane >> 4;
   const bool up = quad >> 1;
 
   // ---- this wavefront's weights: rows cg*16 + p, every k-block, both pieces: lane (channel p, group quad)
-  h2_f16x8 wf[NKB][2];
+  h2_f16x8 wf[CGW][NKB][2];
   {
-    const uint8_t* wr = static_cast<const uint8_t*>(a.w) + (size_t)(cg * 16 + p) * KROW + quad * 32;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      wf[kb][0] = *reinterpret_cast<const h2_f16x8*>(wr + kb * 128);
-      wf[kb][1] = *reinterpret_cast<const h2_f16x8*>(wr + kb * 128 + 16);
+    for (int c = 0; c < CGW; ++c) {
+      const uint8_t* wr = static_cast<const uint8_t*>(a.w) + (size_t)((cg0 + c) * 16 + p) * KROW + quad * 32;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        wf[c][kb][0] = *reinterpret_cast<const h2_f16x8*>(wr + kb * 128);
+        wf[c][kb][1] = *reinterpret_cast<const h2_f16x8*>(wr + kb * 128 + 16);
+      }
     }
     // the loads are waited for HERE: otherwise the compiler places its counted vmcnt waits at the first use of each
     // fragment, inside the batch loop, where they would also wait for the DMA of the NEXT batch (issued just before)
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(wf[kb][0]), "+v"(wf[kb][1]));
+    for (int c = 0; c < CGW; ++c)
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(wf[c][kb][0]), "+v"(wf[c][kb][1]));
   }
   const float inv = 1.f / (*a.sx * *a.sw);
   float oscale = 1.f;
@@ -178,20 +196,25 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
     oscale = h2_scale_for(bound);
     if (blockIdx.x == 0 && tid == 0) *a.out_scale = oscale;
   }
-  float bq[4] = {0.f, 0.f, 0.f, 0.f};  // bias of channels cg*16 + 4 quad + r
-  if (a.bias) {
-    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + cg * 16 + 4 * quad);
-    bq[0] = b4.x; bq[1] = b4.y; bq[2] = b4.z; bq[3] = b4.w;
+  float bq[CGW][4];  // bias of channels (cg0 + c) * 16 + 4 quad + r
+#pragma unroll
+  for (int c = 0; c < CGW; ++c) {
+    bq[c][0] = bq[c][1] = bq[c][2] = bq[c][3] = 0.f;
+    if (a.bias) {
+      const float4 b4 = *reinterpret_cast<const float4*>(a.bias + (cg0 + c) * 16 + 4 * quad);
+      bq[c][0] = b4.x; bq[c][1] = b4.y; bq[c][2] = b4.z; bq[c][3] = b4.w;
+    }
   }
   const float lo = a.act == 1 ? 0.f : -3.0e38f;   // relu as a clamp: no branch in the epilogue
-  constexpr bool MASK_IN = ID == H2C_D3 || ID == H2C_D2, MASK_OUT = !MASK_IN;
 
   if (GE::ZERO_BORDER) {  // borders are never written by the DMA (masked lanes): zero every slot once
-    for (int i = tid; i < NSLOT * SLOT / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < NSLOT * SLOTM / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
   }
 
   const h2_i32x4 rx = h2_rsrc(a.x);
+  h2_i32x4 rmd = h2_rsrc(MASK_IN ? a.mask_in : a.x);   // the mask as a DMA source, bounded: lanes beyond the last image read zeros
+  rmd[2] = MASK_IN ? (int)(a.n * MIMGB) : 0;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
   const long nbatch = (a.n + GE::G - 1) / GE::G;
 
@@ -230,28 +253,43 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
     const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)(img0 * (long)IMGB));
 #pragma unroll
     for (int q = 0; q < NDW; ++q) {
-      const uint32_t ldsa = __builtin_amdgcn_readfirstlane(lds0 + s * SLOT + (wid + 8 * q) * 1024);
+      const uint32_t ldsa = __builtin_amdgcn_readfirstlane(lds0 + s * SLOTM + (wid + 8 * q) * 1024);
       if (dimg[q] >= 0 && dimg[q] < left)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(ldsa), "v"(dvoff[q]), "s"(rx), "s"(soff) : "memory");
     }
+    if (MASK_IN && wid < NDM) {   // the batch's mask bytes, linear
+      const uint32_t ldsa = __builtin_amdgcn_readfirstlane(lds0 + s * SLOTM + SLOT + wid * 1024);
+      const uint32_t msoff = __builtin_amdgcn_readfirstlane((uint32_t)(img0 * (long)MIMGB));
+      const uint32_t mvoff = (uint32_t)(wid * 1024 + lane * 16);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(ldsa), "v"(mvoff), "s"(rmd), "s"(msoff) : "memory");
+    }
   };
 
-  // ---- per-lane output constants
-  const int g_out = 2 * (quad & 1) + (cg & 1), ocb = cg >> 1;
-  uint32_t lane_out;      // byte offset of this lane's store inside an output image, pixel (0, 0)
-  uint32_t lane_mout;     // byte offset of this lane's mask byte inside an image's mask, pixel 0
+  // ---- per-lane output constants, per channel group c of the wavefront
+  uint32_t lane_out[CGW];      // byte offset of this lane's store inside an output image, pixel (0, 0)
+  uint32_t lane_mout[CGW];     // byte offset of this lane's mask byte inside an image's mask, pixel 0
+  int mi_shift[CGW], mi_pix[CGW];  // data gradients, natural-order mask_in: bit shift inside the pixel's word, pixel offset of the class
   int pix_step_y, pix_step_x;   // output pixel index = oy * pix_step_y + ox * pix_step_x (+ class offset, folded into lane_out)
-  if (ROUTED) {
-    const int cls = cg >> 1, py = cls >> 1, px = cls & 1;
-    lane_out = (uint32_t)(((py * 20 + px) * GE::OCH + 16 * (cg & 1) + 4 * quad) * 4);
-    pix_step_y = 40; pix_step_x = 2;
-    lane_mout = 0;
-  } else {
-    lane_out = GE::DST == H2D_PLANAR ? (uint32_t)((((ocb * 4 + g_out) * 2 + (up ? 1 : 0)) * GE::OPIX) * 16)
-                                     : (uint32_t)(ocb * 128 + g_out * 32 + (up ? 16 : 0));
-    pix_step_y = GE::OW; pix_step_x = 1;
-    lane_mout = (uint32_t)(ocb * 4 + g_out);
+#pragma unroll
+  for (int c = 0; c < CGW; ++c) {
+    const int cg = cg0 + c;
+    const int g_out = 2 * (quad & 1) + (cg & 1), ocb = cg >> 1;
+    if (ROUTED) {
+      const int cls = cg >> 1, py = cls >> 1, px = cls & 1;
+      lane_out[c] = (uint32_t)(((py * 20 + px) * GE::OCH + 16 * (cg & 1) + 4 * quad) * 4);
+      lane_mout[c] = 0;
+      mi_shift[c] = 16 * (cg & 1) + 4 * quad;
+      mi_pix[c] = py * 20 + px;
+    } else {
+      lane_out[c] = GE::DST == H2D_PLANAR ? (uint32_t)((((ocb * 4 + g_out) * 2 + (up ? 1 : 0)) * GE::OPIX) * 16)
+                                          : (uint32_t)(ocb * 128 + g_out * 32 + (up ? 16 : 0));
+      lane_mout[c] = (uint32_t)(ocb * 4 + g_out);
+      mi_shift[c] = 0;
+      mi_pix[c] = 0;
+    }
   }
+  if (ROUTED) { pix_step_y = 40; pix_step_x = 2; }
+  else { pix_step_y = GE::OW; pix_step_x = 1; }
   constexpr int PIXB = ROUTED ? GE::OCH * 4 : (GE::DST == H2D_PLANAR ? 16 : GE::OCH * 4);   // bytes per output pixel step
   const uint32_t lane_base = GE::SRC == H2S_ROWSWZ ? (uint32_t)(p * 128 + quad * 32) : (uint32_t)(quad * 2 * PLANE_B + p * 16);
   // ROWSWZ: byte u of this table = 16 * sigma(P) for a pixel P = (block base, a multiple of 8) + p + u (mod 8)
@@ -272,43 +310,38 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
     uint32_t pixoff;   // pixel index of this lane's position inside its image
     bool ok;           // lane holds a real output
     long img;          // image (uniform)
+    uint32_t bits[CGW];   // data gradients: the ReLU-derivative bits of this lane's four channels per channel group (bits 0..3)
   };
-  // Stores and the mask loads go through buffer descriptors whose extent is the tensor: a lane without a real output uses
-  // an out-of-range offset, which the hardware drops (stores) or answers with zero (loads) -- no divergent branch, so the
-  // whole epilogue stays in the basic block of the MFMA chain it is scheduled into.
+  // Stores go through buffer descriptors whose extent is the tensor: a lane without a real output uses an out-of-range offset,
+  // which the hardware drops -- no divergent branch in the epilogue.
+  // The image's base goes into the VECTOR offset and soffset is the constant 0, on purpose: a buffer store of more than 64 bits
+  // needs a wait state before its data registers are overwritten, and the compiler (ROCm 7.2) pads that hazard only when
+  // soffset is NOT a register.  With the base in an SGPR soffset it emitted `buffer_store_dwordx4 v[138:141], ..., s87 offen`
+  // directly followed by `v_max_f32 v140, ...` / an MFMA writing v[138:141], and one 64-byte segment in ~10^5 was lost or
+  // stale, differently from run to run (found as 16 wrong values of one pixel; the same pattern was behind the "wrong results
+  // with sched_group_barrier" of the first version of this kernel).
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(a.n * OIMGB), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_mo = __builtin_amdgcn_make_buffer_rsrc(MASK_OUT ? (void*)a.mask_out : a.out, 0, (int)(a.n * MIMGB), 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_mi = __builtin_amdgcn_make_buffer_rsrc(MASK_IN ? const_cast<void*>(a.mask_in) : a.out, 0,
-                                                                       (int)(ID == H2C_D3 ? a.n * MIMGB : a.n * GE::OPIX * 4), 0x00020000);
   constexpr uint32_t OOB = 0x80000000u;
-  auto epilogue = [&](const h2_f32x4& acc, const Meta& m) {
+  auto epilogue1 = [&](const h2_f32x4& acc, const Meta& m, const float (&bqc)[4], uint32_t lane_out_c, uint32_t lane_mout_c, uint32_t mbits) {
     float v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] * inv + bq[r], lo);
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] * inv + bqc[r], lo);
     const bool ok = m.ok && !(SRL_H2C_DBG & 4);
     const uint32_t img32 = (uint32_t)m.img;
     if (MASK_IN) {
-      uint32_t bits;
-      if (ID == H2C_D3) {   // h2 order: byte of (pixel, block, group), this lane's nibble
-        const uint32_t off = m.ok ? m.pixoff * (GE::OCH / 8) + lane_mout : OOB;
-        bits = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(r_mi, off, img32 * (uint32_t)MIMGB, 0) >> (up ? 4 : 0);
-      } else {              // natural order: word of the pixel's 32 channels
-        const int cls = cg >> 1, py = cls >> 1, px = cls & 1;
-        const uint32_t off = m.ok ? (m.pixoff + py * 20 + px) * 4 : OOB;
-        bits = __builtin_amdgcn_raw_buffer_load_b32(r_mi, off, img32 * (uint32_t)(GE::OPIX * 4), 0) >> (16 * (cg & 1) + 4 * quad);
-      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (bits >> r) & 1u ? v[r] : 0.f;
+      for (int r = 0; r < 4; ++r) v[r] = (mbits >> r) & 1u ? v[r] : 0.f;
     }
     {
       const float m4 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
       amax = fmaxf(amax, m.ok ? m4 : 0.f);
     }
-    const uint32_t ooff = ok ? m.pixoff * PIXB + lane_out : OOB;
+    const uint32_t ooff = ok ? m.pixoff * PIXB + lane_out_c : OOB;
     typedef uint32_t h2_u32x4 __attribute__((ext_vector_type(4)));
     if (ROUTED) {
       h2_u32x4 d = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-      __builtin_amdgcn_raw_buffer_store_b128(d, r_out, ooff, img32 * (uint32_t)OIMGB, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(d, r_out, ooff + img32 * (uint32_t)OIMGB, 0, 0);
     } else {
       // two pieces of the four values; lanes (quad, quad ^ 2) complete each other's 16-byte chunks: the lower one ends up
       // with the first pieces of elements 0..7 of group g_out, the upper one with the second pieces
@@ -318,14 +351,18 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
       const uint32_t r0 = h2_xor32(up ? h0a : h1a, up), r1 = h2_xor32(up ? h0b : h1b, up);
       h2_u32x4 chunk;
       chunk[0] = up ? r0 : h0a; chunk[1] = up ? r1 : h0b; chunk[2] = up ? h1a : r0; chunk[3] = up ? h1b : r1;
-      __builtin_amdgcn_raw_buffer_store_b128(chunk, r_out, ooff, img32 * (uint32_t)OIMGB, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(chunk, r_out, ooff + img32 * (uint32_t)OIMGB, 0, 0);
       if (MASK_OUT) {
         uint32_t nib = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
         const uint32_t other = h2_xor32(nib, up);
-        const uint32_t moff = (ok && !up) ? m.pixoff * (GE::OCH / 8) + lane_mout : OOB;
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(nib | (other << 4)), r_mo, moff, img32 * (uint32_t)MIMGB, 0);
+        const uint32_t moff = (ok && !up) ? m.pixoff * (GE::OCH / 8) + lane_mout_c : OOB;
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(nib | (other << 4)), r_mo, moff + img32 * (uint32_t)MIMGB, 0, 0);
       }
     }
+  };
+  auto epilogue = [&](const h2_f32x4 (&accs)[CGW], const Meta& m) {
+#pragma unroll
+    for (int c = 0; c < CGW; ++c) epilogue1(accs[c], m, bq[c], lane_out[c], lane_mout[c], m.bits[c]);
   };
 
   // ---- one block: 3 NKB MFMAs on the block's entries, fragments fetched PD k-blocks ahead (LDS latency is ~4-8 MFMAs), with
@@ -336,8 +373,10 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
   // state, wrong results -- so the order is written out in the source instead.)
   constexpr int PD = CB == 1 ? 3 : 2;
   const bool late = wid >= 4;
-  auto block = [&](const uint8_t* xb, h2_f32x4& pacc, Meta& pm, const Meta& nm) {
-    h2_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  auto block = [&](const uint8_t* xb, h2_f32x4 (&pacc)[CGW], Meta& pm, const Meta& nm) {
+    h2_f32x4 acc[CGW];
+#pragma unroll
+    for (int c = 0; c < CGW; ++c) acc[c] = h2_f32x4{0.f, 0.f, 0.f, 0.f};
     h2_f16x8 xr[PD + 1][2];
     auto fetch = [&](int kb) {
       const int t = kb / CB, c = kb - t * CB;
@@ -364,19 +403,27 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
       if (kb == NKB / 2 + 1 && late) epilogue(pacc, pm);
       const int t = kb / CB, c = kb - t * CB;
       const int kw = GE::tap_k(t) * CB + c;
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kw][1], xr[kb % (PD + 1)][0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kw][0], xr[kb % (PD + 1)][1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kw][0], xr[kb % (PD + 1)][0], acc, 0, 0, 0);
+#pragma unroll
+      for (int cc = 0; cc < CGW; ++cc) {
+        acc[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][kw][1], xr[kb % (PD + 1)][0], acc[cc], 0, 0, 0);
+        acc[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][kw][0], xr[kb % (PD + 1)][1], acc[cc], 0, 0, 0);
+        acc[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][kw][0], xr[kb % (PD + 1)][0], acc[cc], 0, 0, 0);
+      }
     }
-    pacc = acc;
+#pragma unroll
+    for (int c = 0; c < CGW; ++c) pacc[c] = acc[c];
     pm = nm;
   };
 
-  h2_f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
-  Meta pm = {0u, false, 0};
+  h2_f32x4 pacc[CGW];
+#pragma unroll
+  for (int c = 0; c < CGW; ++c) pacc[c] = h2_f32x4{0.f, 0.f, 0.f, 0.f};
+  Meta pm = {};
+  pm.ok = false;
   // this lane's entry inside a block, walked block by block: (oy, ox) of entry 16 bi + p
   auto compute = [&](long b, int s) {
-    const uint8_t* slot = lds + s * SLOT + lane_base;
+    const uint8_t* slot = lds + s * SLOTM + lane_base;
+    const uint8_t* mreg = lds + s * SLOTM + SLOT;
     for (int jb = ph * (NBT / NPH); jb < (ph + 1) * (NBT / NPH); ++jb) {
       const int il = jb / NB_IMG, bi = jb - il * NB_IMG;
       const int e = bi * 16 + p;
@@ -385,6 +432,15 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
       nm.img = b * GE::G + il;
       nm.ok = ox < GE::OW && oy < GE::OH && nm.img < a.n;
       nm.pixoff = (uint32_t)(oy * pix_step_y + ox * pix_step_x);
+#pragma unroll
+      for (int c = 0; c < CGW; ++c) {
+        nm.bits[c] = 0u;
+        if (MASK_IN) {   // from the slot's mask region (idle lanes read some other in-region byte: their outputs are dropped)
+          const uint32_t po = nm.ok ? nm.pixoff : 0u;
+          if (ID == H2C_D3) nm.bits[c] = (uint32_t)mreg[il * MIMGB + po * (GE::OCH / 8) + lane_mout[c]] >> (up ? 4 : 0);
+          else nm.bits[c] = *reinterpret_cast<const uint32_t*>(mreg + il * MIMGB + (po + mi_pix[c]) * 4) >> mi_shift[c];
+        }
+      }
       if (SRL_H2C_DBG & 2) { epilogue(pacc, pm); pm = nm; continue; }
       block(slot + (il * GE::NPIX_L + bi * 16) * (GE::SRC == H2S_ROWSWZ ? 128 : 16), pacc, pm, nm);
     }
@@ -420,7 +476,8 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
 
 template <int ID, int NSLOT = 2>
 inline int h2conv_launch(hipStream_t st, const H2ConvArgs& a, int max_blocks = 256) {
-  constexpr int SLOT = h2c_slot_bytes<ID>();
+  constexpr bool MASK_IN_L = ID == H2C_D3 || ID == H2C_D2;
+  constexpr int SLOT = h2c_slot_bytes<ID>() + (MASK_IN_L ? (H2Geo<ID>::G * (H2Geo<ID>::OPIX * H2Geo<ID>::OCH / 8) + 1023) / 1024 * 1024 : 0);
   static_assert(NSLOT * SLOT <= 160 * 1024, "LDS");
   static bool attr_set = false;
   auto kern = h2conv_kernel<ID, NSLOT>;
