@@ -976,7 +976,11 @@ def h2_conv(kind, x, w, sx, sw, n, out, out_absmax, bias=None, act=0, out_scale=
             mask_out=None, mask_in=None):
     a = H2ConvArgs(_vp(x), _vp(w), _vp(sx), _vp(sw), int(n), _vp(bias), int(act), _vp(out), _vp(out_scale), _vp(bound_in), _vp(bound_w),
                    _vp(bound_b), _vp(out_absmax), _vp(mask_out), _vp(mask_in))
-    _check(lib().srl_h2_conv(_stream(), int(kind), ctypes.byref(a)), "srl_h2_conv")
+    # algorithmic flops of the convolution each kind stands for (data gradients: the forward layer's count)
+    flops = 2.0 * int(n) * (81 * 64 * 512 if kind in (H2_CONV2_FWD, H2_CONV2_DGRAD) else 49 * 64 * 576)
+    name = ("conv_fwd", "conv_fwd", "conv_dgrad", "conv_dgrad")[int(kind)]
+    with _scope(name, flops, "2h"):
+        _check(lib().srl_h2_conv(_stream(), int(kind), ctypes.byref(a)), "srl_h2_conv")
 
 
 def h2_wgrad_workspace(kind) -> int:
@@ -984,8 +988,10 @@ def h2_wgrad_workspace(kind) -> int:
 
 
 def h2_wgrad(kind, x, dz, sx, sz, n, workspace, gw, gb=None):
-    _check(lib().srl_h2_wgrad(_stream(), int(kind), _vp(x), _vp(dz), _vp(sx), _vp(sz), int(n), _vp(workspace), _vp(gw), _vp(gb)),
-           "srl_h2_wgrad")
+    flops = 2.0 * int(n) * (81 * 64 * 512 if kind == H2_WGRAD_CONV2 else 49 * 64 * 576)
+    with _scope("conv_wgrad", flops, "2h"):
+        _check(lib().srl_h2_wgrad(_stream(), int(kind), _vp(x), _vp(dz), _vp(sx), _vp(sz), int(n), _vp(workspace), _vp(gw), _vp(gb)),
+               "srl_h2_wgrad")
 
 
 def h2_gemm(x, w, sx, sw, M, NC, K, out, bias=None, act=0, out_h2=False, out_scale=None, bound_in=None, bound_w=None, bound_b=None,
@@ -993,12 +999,14 @@ def h2_gemm(x, w, sx, sw, M, NC, K, out, bias=None, act=0, out_h2=False, out_sca
     d = H2GemmDesc(_vp(x), _vp(w), _vp(sx), _vp(sw), int(M), int(NC), int(K), _vp(bias), int(act), int(bool(out_h2)), _vp(out),
                    _vp(out_scale), _vp(bound_in), _vp(bound_w), _vp(bound_b), _vp(out_absmax), _vp(mask_out), _vp(mask_in),
                    int(bool(mask_in_h2order)))
-    _check(lib().srl_h2_gemm(_stream(), ctypes.byref(d)), "srl_h2_gemm")
+    with _scope("gemm", 2.0 * int(M) * int(NC) * int(K), "2h"):
+        _check(lib().srl_h2_gemm(_stream(), ctypes.byref(d)), "srl_h2_gemm")
 
 
 def conv2d_obs_fwd_h2(desc, obs_ptr, mean, rstd, gamma, beta, w, bias, y_h2, y_scale, ws_ptr, row_index, y_absmax, y_mask,
                       reuse_folded=False, ent_order=2):
     ri = _ptr(row_index, torch.int32, "row_index") if isinstance(row_index, torch.Tensor) else row_index
-    _check(lib().srl_conv2d_obs_fwd_h2(_stream(), ctypes.byref(desc), _vp(obs_ptr), _vp(mean), _vp(rstd), _vp(gamma), _vp(beta), _vp(w),
-                                       _vp(bias), _vp(y_h2), _vp(y_scale), _vp(ws_ptr), _vp(ri), _vp(y_absmax), _vp(y_mask),
-                                       int(bool(reuse_folded)), int(ent_order)), "srl_conv2d_obs_fwd_h2")
+    with _scope("conv_obs_fwd", _conv_flops(desc), "obs"):
+        _check(lib().srl_conv2d_obs_fwd_h2(_stream(), ctypes.byref(desc), _vp(obs_ptr), _vp(mean), _vp(rstd), _vp(gamma), _vp(beta), _vp(w),
+                                           _vp(bias), _vp(y_h2), _vp(y_scale), _vp(ws_ptr), _vp(ri), _vp(y_absmax), _vp(y_mask),
+                                           int(bool(reuse_folded)), int(ent_order)), "srl_conv2d_obs_fwd_h2")

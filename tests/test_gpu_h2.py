@@ -1,0 +1,353 @@
+"""Parity of the pre-split ("h2") kernels of round 4 -- csrc/h2gemm.h, csrc/h2conv.h, the h2 output of the first layer --
+through the C ABI (`srl_h2_*`, `srl_conv2d_obs_fwd_h2`), against float64 torch references of the operations they replace:
+nn.Conv2d forward / its data and weight gradients (legacy/algorithm/modules/cnn.py:93-135) and nn.Linear forward / data
+gradient (modules/utils.py:154-161) as autograd forms them.
+
+Tolerance: a contraction of K terms on two f16 pieces per operand carries every product to 2^-22 relative and accumulates in
+float32 (gemm_bf16x3.h); results are compared at 2e-6 of the tensor's largest magnitude, the bar the round-3 two-piece
+kernels are held to.  Sizes: small ragged batches in full, the benchmark's 16 384-image chunks on sampled images.  Every
+kernel is also run three times on the same inputs and must return the same bits: a scheduling hazard (one was found in this
+round's development: a 128-bit buffer store whose data registers were overwritten one instruction later) shows up as a value
+that differs from run to run long before it shows up against a tolerance."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _hip():
+    from srl_amd import hip
+    hip.require_gpu()
+    return hip
+
+
+def _f(*shape, seed=0, relu=False, amp=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = (torch.rand(*shape, device=DEV, generator=g) * 2 - 1) * amp
+    return torch.where(x < 0, torch.zeros_like(x), x * x * 3) if relu else x
+
+
+def _slot(*vals):
+    return torch.tensor(list(vals) if vals else [0.0], dtype=torch.float32, device=DEV)
+
+
+def _absmax(hip, x):
+    s = _slot(0.0)
+    hip.absmax(x.data_ptr(), x.numel(), s.data_ptr())
+    return s
+
+
+def _close(got, ref, tol=2e-6):
+    ref = ref.to(torch.float64)
+    err = float((got.to(torch.float64) - ref).abs().max())
+    assert err <= tol * max(float(ref.abs().max()), 1e-30), (err, float(ref.abs().max()))
+
+
+class Packed:
+    """An activation in one of the h2 layouts with its scale slot."""
+
+    def __init__(self, hip, x_nhwc, layout):
+        n, H, W, C = x_nhwc.shape
+        self.buf = torch.empty(n * H * W * C, dtype=torch.float32, device=DEV)
+        self.scale = _slot(0.0)
+        self.amax = _absmax(hip, x_nhwc)
+        hip.h2_pack_image(x_nhwc.data_ptr(), n, H, W, C, layout, self.buf.data_ptr(), absmax=self.amax.data_ptr(),
+                          scale_out=self.scale.data_ptr())
+
+
+def _weights(hip, w, rows, K, mode, desc=None):
+    """h2p weights + (scale, row-norm) slots.  w: the float32 tensor as the layer stores it."""
+    amax = _absmax(hip, w)
+    dst = torch.empty(rows * K, dtype=torch.float32, device=DEV)
+    s, r = _slot(0.0), _slot(0.0)
+    hip.h2_weights(w.data_ptr(), rows, K, mode, amax.data_ptr(), s.data_ptr(), r.data_ptr(), dst.data_ptr(), desc=desc)
+    return dst, s, r
+
+
+def _mask_h2(act_nhwc):
+    """Sign bytes in h2 order of a [n, H, W, C] activation: byte (pixel, block, group), bit j = element j of the group."""
+    n, H, W, C = act_nhwc.shape
+    a = (act_nhwc > 0).reshape(n * H * W, C // 32, 32)
+    idx = torch.tensor([[4 * (g >> 1) + 16 * (g & 1) + (j & 3) + 8 * (j >> 2) for j in range(8)] for g in range(4)], device=DEV)
+    bits = a[:, :, idx]                       # [pix, blk, g, j]
+    w = (2 ** torch.arange(8, device=DEV)).to(torch.int32)
+    return (bits.to(torch.int32) * w).sum(-1).to(torch.uint8).contiguous()
+
+
+def _mask_natural(act_nhwc):
+    n, H, W, C = act_nhwc.shape
+    a = (act_nhwc > 0).reshape(-1, 32).to(torch.int64)
+    w = 2 ** torch.arange(32, device=DEV, dtype=torch.int64)
+    v = (a * w).sum(-1)
+    return torch.where(v >= 2**31, v - 2**32, v).to(torch.int32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ formats
+def test_pack_unpack_round_trip_every_layout():
+    hip = _hip()
+    x = _f(37, 64, seed=1, amp=3.0)
+    amax = _absmax(hip, x)
+    buf, back, s = torch.empty_like(x), torch.empty_like(x), _slot(0.0)
+    hip.h2_pack_rows(x.data_ptr(), 64, 37, 64, buf.data_ptr(), absmax=amax.data_ptr(), scale_out=s.data_ptr())
+    hip.h2_unpack_rows(buf.data_ptr(), 37, 64, s.data_ptr(), back.data_ptr(), 64)
+    scale = float(s.item())
+    assert scale == 2.0 ** round(np.log2(scale)) and float(amax.item()) * scale < 2**15  # a power of two, no f16 overflow
+    # two f16 pieces: 22 bits of every element that is within 2^11 of the scaled bound, 2^-25 / scale absolute below
+    assert float((back - x).abs().max()) <= max(2.0**-22 * float(x.abs().max()), 2.0**-24 / scale)
+    img = _f(5, 20, 20, 32, seed=2, relu=True)
+    for layout, unpack_layout in ((0, 0), (1, 1)):
+        p = Packed(hip, img, layout)
+        out = torch.empty_like(img)
+        hip.h2_unpack_image(p.buf.data_ptr(), 5, 20, 20, 32, unpack_layout, p.scale.data_ptr(), out.data_ptr())
+        assert float((out - img).abs().max()) <= 2.0**-21 * float(img.abs().max())
+    # parity-class order = a permutation of the raster rows
+    p2, p1 = Packed(hip, img, 2), Packed(hip, img, 1)
+    yy, xx = np.meshgrid(np.arange(20), np.arange(20), indexing="ij")
+    ent = torch.from_numpy((((yy & 1) * 2 + (xx & 1)) * 100 + (yy >> 1) * 10 + (xx >> 1)).reshape(-1)).to(DEV)
+    assert torch.equal(p2.buf.view(5, 400, 32)[:, ent], p1.buf.view(5, 400, 32))
+
+
+# ------------------------------------------------------------------------------------------------ forward convolutions
+def _conv_case(kind):
+    return dict(c2=(20, 32, 4, 2, 9), c3=(9, 64, 3, 1, 7))[kind]
+
+
+@pytest.mark.parametrize("kind,n", [("c2", 5), ("c2", 301), ("c3", 7), ("c3", 301)])
+def test_conv_forward_vs_float64(kind, n):
+    hip = _hip()
+    H, C, k, st, OH = _conv_case(kind)
+    x = _f(n, H, H, C, seed=3, relu=True, amp=2.0)
+    w = _f(64, k, k, C, seed=4, amp=0.05)     # [Cout, KH, KW, Cin]: the layout the layers keep
+    b = _f(64, seed=5, amp=0.1)
+    xp = Packed(hip, x, 2 if kind == "c2" else 0)
+    wp, sw, rw = _weights(hip, w, 64, k * k * C, 0)
+    out = torch.zeros(n * OH * OH * 64, device=DEV)
+    mask = torch.zeros(n * OH * OH * 8, dtype=torch.uint8, device=DEV)
+    osc, oam, bb = _slot(0.0), _slot(0.0), _absmax(hip, b)
+    run = lambda: hip.h2_conv(hip.H2_CONV2_FWD if kind == "c2" else hip.H2_CONV3_FWD, xp.buf.data_ptr(), wp.data_ptr(), xp.scale.data_ptr(),
+                              sw.data_ptr(), n, out.data_ptr(), oam.data_ptr(), bias=b.data_ptr(), act=1, out_scale=osc.data_ptr(),
+                              bound_in=xp.amax.data_ptr(), bound_w=rw.data_ptr(), bound_b=bb.data_ptr(), mask_out=mask.data_ptr())
+    run()
+    first = (out.clone(), mask.clone())
+    ref = F.relu(F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(), stride=st)).permute(0, 2, 3, 1).contiguous()
+    got = torch.empty(n, OH, OH, 64, device=DEV)
+    if kind == "c2":
+        hip.h2_unpack_image(out.data_ptr(), n, OH, OH, 64, 0, osc.data_ptr(), got.data_ptr())
+    else:
+        hip.h2_unpack_rows(out.data_ptr(), n * OH * OH, 64, osc.data_ptr(), got.data_ptr(), 64)
+    _close(got, ref)
+    # the bound really bounds, the measured range is the range, the sign bytes are the signs (up to values at rounding distance of 0)
+    assert float(ref.abs().max()) * float(osc.item()) < 2**15 and abs(float(oam.item()) - float(ref.abs().max())) <= 1e-5 * float(ref.abs().max())
+    want_mask = _mask_h2(ref.float())
+    assert int((mask != want_mask.reshape(-1)).sum()) <= 2
+    for _ in range(2):   # bit-reproducible
+        run()
+        assert torch.equal(out, first[0]) and torch.equal(mask, first[1])
+
+
+# ------------------------------------------------------------------------------------------------ data gradients
+@pytest.mark.parametrize("kind,n", [("c3", 3), ("c3", 300), ("c2", 2), ("c2", 6), ("c2", 300)])
+def test_conv_data_gradient_vs_float64(kind, n):
+    hip = _hip()
+    H, C, k, st, OH = _conv_case(kind)
+    dz = _f(n, OH, OH, 64, seed=6, amp=1e-3)
+    w = _f(64, k, k, C, seed=7, amp=0.05)
+    act = _f(n, H, H, C, seed=8, relu=True)          # the forward activation whose ReLU derivative gates dx
+    desc = hip.conv_desc(1, H, H, C, k, k, st, 64, 1)
+    rows, K = st * st * C, (k // st) * (k // st) * 64
+    wg, sw, rw = _weights(hip, w, rows, K, 2, desc)
+    if kind == "c3":
+        zp = torch.empty_like(dz).reshape(-1)
+        sz, az = _slot(0.0), _absmax(hip, dz)
+        hip.h2_pack_rows(dz.data_ptr(), 64, n * OH * OH, 64, zp.data_ptr(), absmax=az.data_ptr(), scale_out=sz.data_ptr())
+        mask = _mask_h2(act)
+    else:
+        p = Packed(hip, dz, 0)
+        zp, sz, az = p.buf, p.scale, p.amax
+        mask = _mask_natural(act)
+    out = torch.zeros(n * H * H * C, device=DEV)
+    osc, oam = _slot(0.0), _slot(0.0)
+    run = lambda: hip.h2_conv(hip.H2_CONV3_DGRAD if kind == "c3" else hip.H2_CONV2_DGRAD, zp.data_ptr(), wg.data_ptr(), sz.data_ptr(),
+                              sw.data_ptr(), n, out.data_ptr(), oam.data_ptr(), out_scale=osc.data_ptr(), bound_in=az.data_ptr(),
+                              bound_w=rw.data_ptr(), mask_in=mask.data_ptr())
+    run()
+    first = out.clone()
+    ref = F.conv_transpose2d(dz.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=st).permute(0, 2, 3, 1) * (act > 0)
+    if kind == "c3":
+        got = torch.empty(n, H, H, C, device=DEV)
+        hip.h2_unpack_image(out.data_ptr(), n, H, H, C, 0, osc.data_ptr(), got.data_ptr())
+    else:
+        got = out.view(n, H, H, C)
+    _close(got, ref)
+    for _ in range(3):
+        run()
+        assert torch.equal(out, first)
+
+
+# ------------------------------------------------------------------------------------------------ weight gradients
+@pytest.mark.parametrize("kind,n", [("c3", 5), ("c3", 293), ("c2", 5), ("c2", 293)])
+def test_conv_weight_gradient_vs_float64(kind, n):
+    hip = _hip()
+    H, C, k, st, OH = _conv_case(kind)
+    x = _f(n, H, H, C, seed=9, relu=True, amp=2.0)
+    dz = _f(n, OH, OH, 64, seed=10, amp=1e-3)
+    xp = Packed(hip, x, 2 if kind == "c2" else 0)
+    if kind == "c2":
+        zp = Packed(hip, dz, 0)
+        zbuf, sz = zp.buf, zp.scale
+    else:
+        zbuf, sz, az = torch.empty_like(dz).reshape(-1), _slot(0.0), _absmax(hip, dz)
+        hip.h2_pack_rows(dz.data_ptr(), 64, n * OH * OH, 64, zbuf.data_ptr(), absmax=az.data_ptr(), scale_out=sz.data_ptr())
+    code = hip.H2_WGRAD_CONV2 if kind == "c2" else hip.H2_WGRAD_CONV3
+    ws = torch.empty(hip.h2_wgrad_workspace(code), device=DEV)
+    K = k * k * C
+    gw0, gb0 = _f(64, K, seed=11, amp=1e-2), _f(64, seed=12, amp=1e-2)   # the kernels ADD into the gradient buffers
+    gw, gb = gw0.clone(), gb0.clone()
+    hip.h2_wgrad(code, xp.buf.data_ptr(), zbuf.data_ptr(), xp.scale.data_ptr(), sz.data_ptr(), n, ws.data_ptr(), gw.data_ptr(), gb.data_ptr())
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(False)
+    wd = torch.zeros(64, C, k, k, dtype=torch.float64, device=DEV, requires_grad=True)
+    bd = torch.zeros(64, dtype=torch.float64, device=DEV, requires_grad=True)
+    (F.conv2d(xd, wd, bd, stride=st) * dz.double().permute(0, 3, 1, 2)).sum().backward()
+    _close(gw - gw0, wd.grad.permute(0, 2, 3, 1).reshape(64, K))
+    _close(gb - gb0, bd.grad)
+    gw2, gb2 = gw0.clone(), gb0.clone()
+    hip.h2_wgrad(code, xp.buf.data_ptr(), zbuf.data_ptr(), xp.scale.data_ptr(), sz.data_ptr(), n, ws.data_ptr(), gw2.data_ptr(), gb2.data_ptr())
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+
+
+# ------------------------------------------------------------------------------------------------ the Linear's products
+@pytest.mark.parametrize("M", [77, 1000])
+def test_linear_forward_and_data_gradient_vs_float64(M):
+    hip = _hip()
+    K, N = 3136, 512
+    x = _f(M, K, seed=13, relu=True, amp=2.0)
+    w = _f(N, K, seed=14, amp=0.03)
+    b = _f(N, seed=15, amp=0.1)
+    xbuf, sx, ax = torch.empty_like(x), _slot(0.0), _absmax(hip, x)
+    hip.h2_pack_rows(x.data_ptr(), K, M, K, xbuf.data_ptr(), absmax=ax.data_ptr(), scale_out=sx.data_ptr())
+    wp, sw, rw = _weights(hip, w, N, K, 0)
+    y = torch.zeros(M, N, device=DEV)
+    mo = torch.zeros(M * N // 32, dtype=torch.int32, device=DEV)
+    hip.h2_gemm(xbuf.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(), M, N, K, y.data_ptr(), bias=b.data_ptr(), act=1, mask_out=mo.data_ptr())
+    ref = F.relu(x.double() @ w.double().t() + b.double())
+    _close(y, ref)
+    assert int((mo != _mask_natural(ref.float().view(M, 1, 1, N))).sum()) <= 1
+    # data gradient: dx = (dy W) * relu'(x), dx as h2p rows, the derivative from x's sign bytes in h2 order
+    dy = _f(M, N, seed=16, amp=1e-3)
+    dbuf, sd, ad = torch.empty_like(dy), _slot(0.0), _absmax(hip, dy)
+    hip.h2_pack_rows(dy.data_ptr(), N, M, N, dbuf.data_ptr(), absmax=ad.data_ptr(), scale_out=sd.data_ptr())
+    wt, swt, rwt = _weights(hip, w, K, N, 1)   # transposed: rows = input features
+    mask = _mask_h2(x.view(M, 1, 1, K))
+    dx = torch.zeros(M * K, device=DEV)
+    osc, oam = _slot(0.0), _slot(0.0)
+    run = lambda: hip.h2_gemm(dbuf.data_ptr(), wt.data_ptr(), sd.data_ptr(), swt.data_ptr(), M, K, N, dx.data_ptr(), out_h2=True,
+                              out_scale=osc.data_ptr(), bound_in=ad.data_ptr(), bound_w=rwt.data_ptr(), out_absmax=oam.data_ptr(),
+                              mask_in=mask.data_ptr(), mask_in_h2order=True)
+    run()
+    first = dx.clone()
+    got = torch.empty(M, K, device=DEV)
+    hip.h2_unpack_rows(dx.data_ptr(), M, K, osc.data_ptr(), got.data_ptr(), K)
+    _close(got, (dy.double() @ w.double()) * (x > 0))
+    run()
+    assert torch.equal(dx, first)
+
+
+def test_linear_weight_gradient_reads_h2p_rows():
+    """dW = dy^T x with x never written as float32: the round-3 two-piece kernel stages the h2p rows as they are
+    (srl_gemm_desc::b_h2_scale)."""
+    hip = _hip()
+    M, K, N = 1111, 3136, 512
+    x = _f(M, K, seed=17, relu=True, amp=2.0)
+    dy = _f(M, N, seed=18, amp=1e-3)
+    xbuf, sx, ax = torch.empty_like(x), _slot(0.0), _absmax(hip, x)
+    hip.h2_pack_rows(x.data_ptr(), K, M, K, xbuf.data_ptr(), absmax=ax.data_ptr(), scale_out=sx.data_ptr())
+    ad = _absmax(hip, dy)
+    gw = torch.zeros(N, K, device=DEV)
+    hip.dispatch_counts(reset=True)
+    hip.gemm(N, K, M, dy.data_ptr(), N, 1, xbuf.data_ptr(), K, 1, gw.data_ptr(), K, accumulate=True, a_absmax=ad.data_ptr(),
+             b_h2_scale=sx.data_ptr())
+    assert hip.dispatch_counts(reset=True)["gemm2h"] == 1
+    _close(gw, dy.double().t() @ x.double())
+
+
+# ------------------------------------------------------------------------------------------------ benchmark-size launches
+def test_benchmark_size_chunk_on_sampled_images():
+    """One 16 384-image chunk -- the launches bench.py times -- through conv2 forward, its weight gradient and conv2's data
+    gradient, checked against float64 on 48 sampled images (forward / data gradient) and in full (weight gradient)."""
+    hip = _hip()
+    n = 16384
+    x = _f(n, 20, 20, 32, seed=19, relu=True, amp=2.0)
+    w = _f(64, 4, 4, 32, seed=20, amp=0.05)
+    b = _f(64, seed=21, amp=0.1)
+    xp = Packed(hip, x, 2)
+    wp, sw, rw = _weights(hip, w, 64, 512, 0)
+    out = torch.zeros(n * 81 * 64, device=DEV)
+    mask = torch.zeros(n * 81 * 8, dtype=torch.uint8, device=DEV)
+    osc, oam, bb = _slot(0.0), _slot(0.0), _absmax(hip, b)
+    hip.h2_conv(hip.H2_CONV2_FWD, xp.buf.data_ptr(), wp.data_ptr(), xp.scale.data_ptr(), sw.data_ptr(), n, out.data_ptr(), oam.data_ptr(),
+                bias=b.data_ptr(), act=1, out_scale=osc.data_ptr(), bound_in=xp.amax.data_ptr(), bound_w=rw.data_ptr(),
+                bound_b=bb.data_ptr(), mask_out=mask.data_ptr())
+    got = torch.empty(n, 9, 9, 64, device=DEV)
+    hip.h2_unpack_image(out.data_ptr(), n, 9, 9, 64, 0, osc.data_ptr(), got.data_ptr())
+    pick = torch.from_numpy(np.random.default_rng(0).choice(n, 48, replace=False)).to(DEV)
+    pick = torch.cat([pick, torch.tensor([0, 1, n - 2, n - 1], device=DEV)])
+    ref = F.relu(F.conv2d(x[pick].double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(), stride=2)).permute(0, 2, 3, 1)
+    _close(got[pick], ref)
+    # weight gradient over the whole chunk (dz = a smooth function of the forward output keeps the reference cheap)
+    dz = (got * 1e-3).contiguous()
+    zp = Packed(hip, dz, 0)
+    ws = torch.empty(hip.h2_wgrad_workspace(hip.H2_WGRAD_CONV2), device=DEV)
+    gw, gb = torch.zeros(64, 512, device=DEV), torch.zeros(64, device=DEV)
+    hip.h2_wgrad(hip.H2_WGRAD_CONV2, xp.buf.data_ptr(), zp.buf.data_ptr(), xp.scale.data_ptr(), zp.scale.data_ptr(), n, ws.data_ptr(),
+                 gw.data_ptr(), gb.data_ptr())
+    wd = torch.zeros(64, 32, 4, 4, dtype=torch.float64, device=DEV, requires_grad=True)
+    for i0 in range(0, n, 2048):   # float64 reference in pieces
+        (F.conv2d(x[i0:i0 + 2048].double().permute(0, 3, 1, 2), wd, stride=2) * dz[i0:i0 + 2048].double().permute(0, 3, 1, 2)).sum().backward()
+    _close(gw, wd.grad.permute(0, 2, 3, 1).reshape(64, 512), tol=4e-6)   # 1.3 M terms per element
+    _close(gb, dz.double().sum((0, 1, 2)), tol=4e-6)
+    # data gradient
+    desc = hip.conv_desc(1, 20, 20, 32, 4, 4, 2, 64, 1)
+    wg, swg, rwg = _weights(hip, w, 128, 256, 2, desc)
+    m1 = _mask_natural(x)
+    dx = torch.zeros(n, 20, 20, 32, device=DEV)
+    oam2 = _slot(0.0)
+    hip.h2_conv(hip.H2_CONV2_DGRAD, zp.buf.data_ptr(), wg.data_ptr(), zp.scale.data_ptr(), swg.data_ptr(), n, dx.data_ptr(), oam2.data_ptr(),
+                mask_in=m1.data_ptr())
+    ref = F.conv_transpose2d(dz[pick].double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=2).permute(0, 2, 3, 1) * (x[pick] > 0)
+    _close(dx[pick], ref)
+
+
+# ------------------------------------------------------------------------------------------------ first layer
+def test_first_layer_h2_output_equals_its_float32_output():
+    """srl_conv2d_obs_fwd_h2 = srl_conv2d_obs_fwd with the result written as h2p rows in parity-class order: the same
+    accumulators, so after unpacking the two agree to the pieces' 2^-22; sign words and the measured range are identical."""
+    hip = _hip()
+    n = 300
+    g = torch.Generator(device=DEV).manual_seed(22)
+    frames = torch.randint(0, 256, (n, 4, 84, 84), dtype=torch.uint8, device=DEV, generator=g)
+    s2d, mean, rstd = torch.empty(n, 21, 21, 64, dtype=torch.uint8, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    hip.obs_space_to_depth(frames.data_ptr(), True, n, 4, 84, 84, 4, s2d.data_ptr(), mean.data_ptr(), rstd.data_ptr())
+    desc = hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, 1)
+    gamma, beta = 1 + _f(21 * 21 * 64, seed=23, amp=0.2), _f(21 * 21 * 64, seed=24, amp=0.2)
+    w, b = _f(32, 256, seed=25, amp=0.06), _f(32, seed=26, amp=0.1)
+    ws = torch.empty(hip.conv2d_obs_fwd_workspace(desc), device=DEV)
+    y = torch.empty(n, 400, 32, device=DEV)
+    ym, yam = torch.zeros(n * 400, dtype=torch.int32, device=DEV), _slot(0.0)
+    hip.conv2d_obs_fwd(desc, s2d.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), b.data_ptr(),
+                       y.data_ptr(), channels_last=True, y_absmax=yam.data_ptr(), y_mask=ym.data_ptr(), ws_ptr=ws.data_ptr())
+    yh = torch.zeros(n * 400 * 32, device=DEV)
+    hm, ham, hs = torch.zeros(n * 400, dtype=torch.int32, device=DEV), _slot(0.0), _slot(0.0)
+    hip.conv2d_obs_fwd_h2(desc, s2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), b.data_ptr(),
+                          yh.data_ptr(), hs.data_ptr(), ws.data_ptr(), None, ham.data_ptr(), hm.data_ptr(), reuse_folded=False, ent_order=2)
+    back = torch.empty(n * 400, 32, device=DEV)
+    hip.h2_unpack_rows(yh.data_ptr(), n * 400, 32, hs.data_ptr(), back.data_ptr(), 32)
+    yy, xx = np.meshgrid(np.arange(20), np.arange(20), indexing="ij")
+    ent = torch.from_numpy((((yy & 1) * 2 + (xx & 1)) * 100 + (yy >> 1) * 10 + (xx >> 1)).reshape(-1)).to(DEV)
+    back = back.view(n, 400, 32)[:, ent]
+    assert float((back - y).abs().max()) <= 2.0**-21 * float(y.abs().max())
+    assert torch.equal(hm, ym) and float(ham.item()) == float(yam.item())
+    assert float(y.abs().max()) * float(hs.item()) < 2**15   # the a-priori bound holds
