@@ -165,7 +165,7 @@ template <int NCB, int XMODE> static int launch(H2Args a) {
 
 static bool g_all_ok = true;
 
-static void run_dense(const char* name, int64_t M, int NC, int K, bool h2out, int64_t Mt) {
+static void run_dense(const char* name, int64_t M, int NC, int K, bool h2out, int64_t Mt, int ncb = 0) {
   printf("%s: dense M=%ld NC=%d K=%d out=%s\n", name, (long)M, NC, K, h2out ? "h2p" : "f32");
   const int64_t Mx = M > Mt ? M : Mt;
   float* x = dalloc<float>(Mx * K); float* w = dalloc<float>((int64_t)NC * K); float* b = dalloc<float>(NC);
@@ -181,7 +181,8 @@ static void run_dense(const char* name, int64_t M, int NC, int K, bool h2out, in
   a.x = xp; a.w = wp; a.sx = sx; a.sw = sw; a.M = M; a.NC = NC; a.nk = K / 32; a.w_row_bytes = K * 4; a.x_row_bytes = K * 4;
   a.bias = b; a.act = 1; a.out_fmt = h2out ? H2O_H2P : H2O_F32; a.out = y; a.out_row_bytes = NC * 4;
   a.out_scale = osc; a.bound_in = ax; a.bound_w = wn; a.bound_b = ab; a.out_absmax = oam; a.mask_out = mk;
-  if (NC % 128 == 0) launch<4, H2X_DENSE>(a); else launch<2, H2X_DENSE>(a);
+  auto go = [&] { if (ncb == 8) h2gemm_launch<8, H2X_DENSE, 2, false>(0, a); else if (ncb == 4 || (ncb == 0 && NC % 128 == 0)) launch<4, H2X_DENSE>(a); else launch<2, H2X_DENSE>(a); };
+  go();
   CK(hipDeviceSynchronize());
   ref_dense<<<(unsigned)((M * NC + 255) / 256), 256>>>(x, w, b, M, NC, K, 1, yr);
   const float* got = y;
@@ -195,7 +196,7 @@ static void run_dense(const char* name, int64_t M, int NC, int K, bool h2out, in
   printf("  mask bits differing %llu of %ld (sign of values near 0); absmax %.5g (ref %.5g); out scale %g, bound %.4g\n", mdh, (long)(M * NC), oamh, rmh, osch, axh * wnh);
   if (Mt > 0) {
     a.M = Mt; a.mask_out = mk;
-    const double ms = time_ms([&] { if (NC % 128 == 0) launch<4, H2X_DENSE>(a); else launch<2, H2X_DENSE>(a); }, 20);
+    const double ms = time_ms(go, 20);
     printf("  TIME M=%ld: %.1f us  (%.1f TFLOP/s float32-equivalent)\n", (long)Mt, ms * 1e3, 2.0 * Mt * NC * K / ms * 1e-9);
   }
   for (void* p : {(void*)x, (void*)w, (void*)b, (void*)xp, (void*)wp, (void*)y, (void*)yr, (void*)yu, (void*)mk, (void*)mkr}) CK(hipFree(p));
@@ -477,6 +478,9 @@ int main(int argc, char** argv) {
   auto want = [&](const char* k) { return only.empty() || ("," + only + ",").find(std::string(",") + k + ",") != std::string::npos; };
   if (want("fc")) run_dense("FC forward", nc, 512, 3136, false, nt);
   if (want("fcd")) run_dense("FC dgrad-shaped", nc, 3136 - 3136 % 64, 512, true, nt);
+  if (want("fcd4")) run_dense("FC dgrad-shaped, 128-channel tiles", nc, 3136, 512, true, nt, 4);
+  if (want("fcd8")) run_dense("FC dgrad-shaped, 256-channel tiles unsplit", nc, 3136, 512, true, nt, 8);
+  if (want("fc8")) run_dense("FC forward, 256-channel tiles unsplit", nc, 512, 3136, false, nt, 8);
   if (want("c2")) run_conv("conv2", nc, 20, 20, 32, 4, 4, 2, 64, nt, false);
   if (want("c2p")) run_conv("conv2", nc, 20, 20, 32, 4, 4, 2, 64, nt, true);
   if (want("c3")) run_conv("conv3", nc, 9, 9, 64, 3, 3, 1, 64, nt, false);

@@ -184,10 +184,14 @@ static __global__ void h2_unpack_kernel(const uint8_t* __restrict__ src, int64_t
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NCB, int XMODE, int S>
+// KSPLIT (the default geometry): wavefront w = (position block w & 3, k-half w >> 2), every wavefront all NCB channel blocks.
+// !KSPLIT (NCB = 8, the data gradient of a wide Linear: 256 channels per workgroup, a third less staged per flop): wavefront
+// w = (position block w & 3, channel half w >> 2), both k-halves of every step; no exchange at the end.
+template <int NCB, int XMODE, int S, bool KSPLIT = true>
 __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
-  static_assert(NCB == 2 || NCB == 4, "64 or 128 channels per workgroup");
-  static_assert(S == 3 || S == 4, "ring depth");
+  static_assert(NCB == 2 || NCB == 4 || (NCB == 8 && !KSPLIT), "64, 128 or (unsplit) 256 channels per workgroup");
+  static_assert(S == 2 || S == 3 || S == 4, "ring depth");
+  constexpr int NCW = KSPLIT ? NCB : NCB / 2;   // channel blocks per wavefront
   constexpr int BP = 256;
   constexpr int XT = BP * 128, WT = NCB * 32 * 128, STAGE = XT + WT;
   constexpr int NWI = NCB / 2;    // W-tile DMA instructions per wavefront and step (NCB * 4 instructions over 8 wavefronts)
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wp = wid & 3, kh = wid >> 2;
+  const int wp = wid & 3, kh = KSPLIT ? wid >> 2 : 0, chalf = KSPLIT ? 0 : wid >> 2;
   // logical tile id: every XCD owns one contiguous run
   unsigned lid;
   {
@@ -298,9 +302,9 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
   };
   auto issue = [&](int stage, int t) { issue_off((uint32_t)stage * STAGE, t); };
 
-  h2_f32x16 acc[NCB][2];
+  h2_f32x16 acc[NCW][2];
 #pragma unroll
-  for (int i = 0; i < NCB; ++i)
+  for (int i = 0; i < NCW; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -308,36 +312,40 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
 
   // fragment addresses: row r = lane & 31 of a 32-row block, group 2 kh + (lane >> 5), plane p: slot (2 g + p) ^ f(r)
   const int fr_r = lane & 31, fr_f = (fr_r >> 1) & 7;
-  const int fr_off0 = fr_r * 128 + 16 * ((4 * kh + 2 * (lane >> 5)) ^ fr_f);
-  const int fr_off1 = fr_r * 128 + 16 * ((4 * kh + 2 * (lane >> 5) + 1) ^ fr_f);
+  auto fr_off = [&](int khh, int pl) { return fr_r * 128 + 16 * ((4 * khh + 2 * (lane >> 5) + pl) ^ fr_f); };
 
   auto compute = [&](uint32_t stage_off) {
     const uint8_t* sx = lds + stage_off + wp * (64 * 128);
-    const uint8_t* sw = lds + stage_off + XT;
-    h2_f16x8 xf[2][2], wf[NCB][2];
+    const uint8_t* sw = lds + stage_off + XT + chalf * (NCW * 4096);
 #pragma unroll
-    for (int i = 0; i < NCB; ++i) {
-      wf[i][0] = *reinterpret_cast<const h2_f16x8*>(sw + i * 4096 + fr_off0);
-      wf[i][1] = *reinterpret_cast<const h2_f16x8*>(sw + i * 4096 + fr_off1);
+    for (int k2 = 0; k2 < (KSPLIT ? 1 : 2); ++k2) {
+      const int khh = KSPLIT ? kh : k2;
+      const int o0 = fr_off(khh, 0), o1 = fr_off(khh, 1);
+      h2_f16x8 xf[2][2], wf[NCW][2];
+#pragma unroll
+      for (int i = 0; i < NCW; ++i) {
+        wf[i][0] = *reinterpret_cast<const h2_f16x8*>(sw + i * 4096 + o0);
+        wf[i][1] = *reinterpret_cast<const h2_f16x8*>(sw + i * 4096 + o1);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        xf[j][0] = *reinterpret_cast<const h2_f16x8*>(sx + j * 4096 + o0);
+        xf[j][1] = *reinterpret_cast<const h2_f16x8*>(sx + j * 4096 + o1);
+      }
+      // small terms first
+#pragma unroll
+      for (int i = 0; i < NCW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][1], xf[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NCW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][0], xf[j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NCW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][0], xf[j][0], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      xf[j][0] = *reinterpret_cast<const h2_f16x8*>(sx + j * 4096 + fr_off0);
-      xf[j][1] = *reinterpret_cast<const h2_f16x8*>(sx + j * 4096 + fr_off1);
-    }
-    // small terms first
-#pragma unroll
-    for (int i = 0; i < NCB; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][1], xf[j][0], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NCB; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][0], xf[j][1], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NCB; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][0], xf[j][0], acc[i][j], 0, 0, 0);
   };
 
   // ---- ring: prologue S-1 steps, then per step { wait own DMA of step t; barrier; issue step t+S-1; compute step t }.
@@ -360,42 +368,51 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
     st_nxt = st_nxt + STAGE == S * STAGE ? 0 : st_nxt + STAGE;
   }
 
-  // ---- add the two k-halves: wavefront kh keeps channel blocks [kh * NCB/2, (kh+1) * NCB/2) and receives its partner's sums
+  // ---- KSPLIT: add the two k-halves: wavefront kh keeps channel blocks [kh * NCB/2, (kh+1) * NCB/2) and receives its partner's sums
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // every wavefront is past its last fragment read: the ring is free
-  constexpr int NH = NCB / 2;
+  constexpr int NH = KSPLIT ? NCB / 2 : NCW;
   h2_f32x16 fin[NH][2];
   // (static register indices only: an accumulator array indexed by the runtime k-half would live in scratch memory)
   auto exchange = [&](auto kh_c) {
     constexpr int KH_ = decltype(kh_c)::value;
-    float4* ex = reinterpret_cast<float4*>(lds) + (size_t)wid * (NH * 2 * 4 * 64);
+    if constexpr (KSPLIT) {
+      float4* ex = reinterpret_cast<float4*>(lds) + (size_t)wid * (NH * 2 * 4 * 64);
 #pragma unroll
-    for (int i = 0; i < NH; ++i)
+      for (int i = 0; i < NH; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const h2_f32x16& a = acc[(1 - KH_) * NH + i][j];
-          ex[((i * 2 + j) * 4 + q) * 64 + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-        }
-    __syncthreads();
-    const float4* ey = reinterpret_cast<const float4*>(lds) + (size_t)(wid ^ 4) * (NH * 2 * 4 * 64);
+          for (int q = 0; q < 4; ++q) {
+            const h2_f32x16& a = acc[(1 - KH_) * NH + i][j];
+            ex[((i * 2 + j) * 4 + q) * 64 + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+          }
+      __syncthreads();
+      const float4* ey = reinterpret_cast<const float4*>(lds) + (size_t)(wid ^ 4) * (NH * 2 * 4 * 64);
 #pragma unroll
-    for (int i = 0; i < NH; ++i)
+      for (int i = 0; i < NH; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = ey[((i * 2 + j) * 4 + q) * 64 + lane];
-          const h2_f32x16& a = acc[KH_ * NH + i][j];
-          fin[i][j][4 * q] = a[4 * q] + v.x;
-          fin[i][j][4 * q + 1] = a[4 * q + 1] + v.y;
-          fin[i][j][4 * q + 2] = a[4 * q + 2] + v.z;
-          fin[i][j][4 * q + 3] = a[4 * q + 3] + v.w;
-        }
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = ey[((i * 2 + j) * 4 + q) * 64 + lane];
+            const h2_f32x16& a = acc[KH_ * NH + i][j];
+            fin[i][j][4 * q] = a[4 * q] + v.x;
+            fin[i][j][4 * q + 1] = a[4 * q + 1] + v.y;
+            fin[i][j][4 * q + 2] = a[4 * q + 2] + v.z;
+            fin[i][j][4 * q + 3] = a[4 * q + 3] + v.w;
+          }
+    }
   };
-  if (kh == 0) exchange(std::integral_constant<int, 0>{});
-  else exchange(std::integral_constant<int, 1>{});
+  if constexpr (KSPLIT) {
+    if (kh == 0) exchange(std::integral_constant<int, 0>{});
+    else exchange(std::integral_constant<int, 1>{});
+  } else {
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fin[i][j] = acc[i][j];
+  }
 
   // ---- epilogue: lane = position (column), registers = channels (rows): r -> channel (r & 3) + 8 (r >> 2) + 4 h
   const float inv = 1.f / (*g.sx * *g.sw);
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
   float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < NH; ++i) {
-    const int cb = c0 / 32 + kh * NH + i;  // global channel block
+    const int cb = c0 / 32 + (KSPLIT ? kh : chalf) * NH + i;  // global channel block
     if (cb * 32 >= g.NC) continue;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -497,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
   }
 }
 
-template <int NCB, int XMODE, int S>
+template <int NCB, int XMODE, int S, bool KSPLIT = true>
 inline int h2gemm_launch(hipStream_t st, H2Args a) {
   constexpr int BP = 256;
   constexpr int STAGE = BP * 128 + NCB * 32 * 128;
@@ -508,7 +525,7 @@ inline int h2gemm_launch(hipStream_t st, H2Args a) {
   const long nblk = tiles_p * a.tiles_c;
   if (nblk <= 0 || nblk > 0x7fffffffL) return -22;
   static bool attr_set = false;
-  auto kern = h2gemm_kernel<NCB, XMODE, S>;
+  auto kern = h2gemm_kernel<NCB, XMODE, S, KSPLIT>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S * STAGE);
     attr_set = true;

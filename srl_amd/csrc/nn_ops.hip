@@ -663,11 +663,15 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, flo
     for (long i = h + 4 * nv + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
   }
   m = wave_allmax(m);
-  // thousands of wavefronts folding into ONE address: the atomics serialise at ~10 ns each (8 192 of them were 85 of this
-  // kernel's 98 us on a 33 MB tensor).  The slot only grows: read it first, and only a larger value goes through the atomic.
-  if ((threadIdx.x & 63) == 0 && m > 0.f) {
-    const float cur = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (m > cur) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+  // Thousands of wavefronts folding into ONE address serialise at ~10 ns per atomic (8 192 of them were 85 of this kernel's
+  // 98 us on a 33 MB tensor; reading the slot first does not help -- they all start together and all read the old value).  So:
+  // at most 512 workgroups (the launcher), one atomic each.
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
   }
 }
 }  // namespace
@@ -704,8 +708,8 @@ extern "C" int srl_absmax(void* stream, const float* x, int64_t n, float* out) {
   SRL_CHECK_ARG(out && n >= 0, "null output");
   if (n == 0) return 0;
   SRL_CHECK_ARG(x != nullptr && ((uintptr_t)x & 3) == 0, "null / unaligned tensor");
-  long blocks = srl_ceil_div(n, 4096);  // sixteen floats per thread
-  if (blocks > 8192) blocks = 8192;
+  long blocks = srl_ceil_div(n, 4096);  // at least sixteen floats per thread
+  if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
   SRL_LAUNCH_CHECK();
   return 0;
