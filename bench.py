@@ -614,6 +614,9 @@ def main():
                                 collectives=("none (one rank)" if not use_dist else
                                              "RCCL through the C ABI (srl_comm_*)" if getattr(trainer, "_comm", None) is not None
                                              else f"torch.distributed ({backend})"),
+                                pipelines=getattr(trainer, "pipelines", None),
+                                grad_buckets=(None if getattr(trainer, "_reducer", None) is None else
+                                              dict(trainer._reducer.stats, buckets=len(trainer._reducer.buckets))),
                                 policy_loss=res.stats.get("policy_loss")),
                     roofline=roofline, roofline_gae=roofline_gae, roofline_mlp=roofline_mlp, kernel_ms_per_step=breakdown,
                     resident_in_hbm=resident)

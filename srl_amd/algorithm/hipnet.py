@@ -1053,10 +1053,12 @@ class HipNet:
         y = out if out is not None else self.ws.get(f"{tag}mlp.y", n * width)
         hip.mlp_fwd(arr, x.data_ptr(), x.shape[1], n, tape.data_ptr(), tld, y.data_ptr(), width)
         return dict(arr=arr, x=x, tape=tape, tld=tld, n=n, feat=Buf(y.data_ptr(), width, n, width), act=act,
-                    head=head is not None)
+                    head=head is not None, prefixes=[L.prefix for L in layers])
 
     def _fused_bwd(self, rec, dy_ptr: int, lddy: int):
         hip.mlp_bwd(rec["arr"], rec["x"].data_ptr(), rec["x"].shape[1], rec["n"], rec["tape"].data_ptr(), rec["tld"], dy_ptr, lddy)
+        if self.grad_ready_hook is not None:  # one launch: every layer of the chain is final behind it
+            self.grad_ready_hook(rec["prefixes"])
 
     # ------------------------------------------------------------------ public: forward / backward
     def forward(self, obs: Dict[str, torch.Tensor], n: int, keep_tape: bool = True, rnn: Optional[RnnCtx] = None):
@@ -1128,8 +1130,7 @@ class HipNet:
         if self.grad_ready_hook is not None and sp.shared_backbone:
             self.grad_ready_hook([sp.actor_head.prefix])
 
-        def trunk_bwd(tag, tape, dfeat, dhead):  # fused chains: one launch (their layers' gradients are final after it;
-            # the bucket reducer's finish() launches whatever no hook announced)
+        def trunk_bwd(tag, tape, dfeat, dhead):  # fused chains: one launch, all of its layers released behind it
             if isinstance(tape, dict):
                 self._fused_bwd(tape, dhead.ptr if tape["head"] else dfeat.ptr, dhead.ld if tape["head"] else dfeat.ld)
             else:

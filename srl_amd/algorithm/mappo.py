@@ -22,6 +22,7 @@ sums by its LOCAL mask count, gradients are then averaged over ranks, while the 
 uses GLOBAL statistics.
 """
 import logging
+import contextlib
 import os
 from collections import defaultdict
 
@@ -48,12 +49,20 @@ class _BucketReducer:
     api/policy.py:219-238): the flat gradient is cut into contiguous buckets in parameter order; as soon as every
     parameter of a bucket has its final gradient the bucket's all-reduce is launched asynchronously (RCCL runs it on
     its own stream while the compute stream continues with the earlier layers); `finish` launches what is left and
-    makes the compute stream wait.  Sum over ranks; the mean is folded into the Adam kernel."""
+    makes the compute stream wait.  Sum over ranks; the mean is folded into the Adam kernel.
+
+    Several row-chunk pipelines (`begin(grads=[net.grad, twin.grad, ...])`): every pipeline accumulates into its own
+    gradient buffer on its own stream, so a bucket is final when the LAST chunk of EACH pipeline has announced its
+    parameters.  Each announcement leaves an event on its pipeline's stream; when the last pipeline completes a bucket, a
+    reduction stream waits for those events, folds the other pipelines' slices into the first buffer (srl_accumulate on
+    just that slice) and launches the slice's all-reduce from there -- none of the pipelines waits."""
 
     def __init__(self, net, bucket_bytes, comm=None):
         self.net = net
         self.comm = comm  # srl_amd.comm.NativeComm (RCCL through the C ABI on a side stream) or None (torch.distributed)
         self.buckets = []  # [lo, hi, frozenset of the parameter prefixes inside]
+        self.stats = dict(epochs=0, launched_in_backward=0, launched_in_finish=0, slices_folded=0)
+        self._fold_stream = None
         lo, pending, size = None, set(), 0
         for name, info in net.spec.params.items():
             prefix = name.rsplit(".", 1)[0]
@@ -74,30 +83,78 @@ class _BucketReducer:
             self.buckets.append([lo, net.spec.total_params, pending])
         self.buckets = [(lo, hi, frozenset(p)) for lo, hi, p in self.buckets]
         self.begin()
+        self.stats["epochs"] = 0
 
-    def begin(self):
-        """Start of an epoch's backward pass: nothing launched, every parameter pending.  (The bucket layout is
-        built once per trainer; only this per-epoch state is reset.)"""
-        self.pending = [set(b[2]) for b in self.buckets]
+    def begin(self, grads=None):
+        """Start of an epoch's backward pass: nothing launched, every parameter pending in every pipeline.  (The bucket
+        layout is built once per trainer; only this per-epoch state is reset.)  ``grads``: the pipelines' flat gradient
+        buffers, the first one is the buffer that is reduced; None = one pipeline, ``net.grad``."""
+        self.grads = [self.net.grad] if grads is None else list(grads)
+        self.pending = [[set(b[2]) for b in self.buckets] for _ in self.grads]
+        self.events = [[None] * len(self.buckets) for _ in self.grads]
         self.launched = [False] * len(self.buckets)
         self.works = []
+        self._finishing = False
+        self.stats["epochs"] += 1
+
+    def _fold(self, i):
+        """The other pipelines' slices of bucket ``i`` into the first buffer, on the reduction stream, after the point each
+        pipeline's stream had reached when it completed the bucket (`finish`: after their tails)."""
+        if self._fold_stream is None:
+            self._fold_stream = torch.cuda.Stream(device=self.grads[0].device)
+        lo, hi, _ = self.buckets[i]
+        for ev in (pipe[i] for pipe in self.events):
+            if ev is not None:
+                self._fold_stream.wait_event(ev)
+        with torch.cuda.stream(self._fold_stream):
+            for g in self.grads[1:]:
+                hip.accumulate(self.grads[0][lo:hi], g[lo:hi])
+        self.stats["slices_folded"] += len(self.grads) - 1
 
     def _launch(self, i):
         lo, hi, _ = self.buckets[i]
-        if self.comm is not None:
-            self.comm.all_reduce_f32_async(self.net.grad[lo:hi])
-        else:
-            self.works.append(dist.all_reduce(self.net.grad[lo:hi], async_op=True))
+        many = len(self.grads) > 1
+        if many:
+            self._fold(i)
+        with torch.cuda.stream(self._fold_stream) if many else contextlib.nullcontext():
+            if self.comm is not None:
+                self.comm.all_reduce_f32_async(self.grads[0][lo:hi])  # picks up after the current stream's tail
+            else:
+                self.works.append(dist.all_reduce(self.grads[0][lo:hi], async_op=True))
         self.launched[i] = True
+        self.stats["launched_in_finish" if self._finishing else "launched_in_backward"] += 1
 
-    def ready(self, prefixes):
-        for i, pend in enumerate(self.pending):
+    def ready(self, prefixes, pipe=0):
+        """Pipeline ``pipe``'s gradients of these parameters are final in its stream order (called from the backward pass of
+        that pipeline's last chunk, on its stream)."""
+        many = len(self.grads) > 1
+        for i, pend in enumerate(self.pending[pipe]):
             if not self.launched[i] and pend:
                 pend.difference_update(prefixes)
                 if not pend:
-                    self._launch(i)
+                    if many:
+                        self.events[pipe][i] = self._mark()
+                    if all(not other[i] for other in self.pending):
+                        self._launch(i)
 
-    def finish(self):
+    @staticmethod
+    def _mark():
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def hook(self, pipe):
+        return self.ready if pipe == 0 else (lambda prefixes: self.ready(prefixes, pipe))
+
+    def finish(self, streams=()):
+        """Launch what the backward passes did not release (``streams``: the pipelines' streams, all of their work enqueued),
+        then make the current stream wait for every bucket."""
+        self._finishing = True
+        if len(self.grads) > 1 and not all(self.launched):
+            if self._fold_stream is None:
+                self._fold_stream = torch.cuda.Stream(device=self.grads[0].device)
+            for st in streams:
+                self._fold_stream.wait_stream(st)
         for i in range(len(self.buckets)):
             if not self.launched[i]:
                 self._launch(i)
@@ -105,6 +162,8 @@ class _BucketReducer:
             self.comm.join()  # the compute stream waits for the side stream's collectives
         for w in self.works:
             w.wait()
+        if len(self.grads) > 1:
+            torch.cuda.current_stream().wait_stream(self._fold_stream)
 
 
 class MultiAgentPPO(PytorchTrainer):
@@ -628,8 +687,6 @@ class MultiAgentPPO(PytorchTrainer):
                 rnn = self.policy._rnn_ctx_with_burn_in(obs, None, pstate, on_reset, burn, hi - lo, B)
             terms = block[epoch, :nchunks * hip.LT_COUNT].view(nchunks, hip.LT_COUNT)
             reducer = self._reducer if self._dist else None
-            if reducer is not None:
-                reducer.begin()
             # Two pipelines: even chunks on the compute stream with the policy's executor, odd chunks on a second stream
             # with its twin (same parameters, own workspace / tape / gradient buffer).  Not for recurrent nets (one chunk),
             # not inside a graph capture.
@@ -654,14 +711,18 @@ class MultiAgentPPO(PytorchTrainer):
                     pst.wait_stream(streams[0])
                     nets.append(twin)
                     streams.append(pst)
+            if reducer is not None:
+                reducer.begin([x.grad for x in nets])
             net.chunks_of_one_update(True)
             for ci in range(nchunks):
                 r0, r1 = ci * chunk_rows, min(n_valid, (ci + 1) * chunk_rows)
                 n = r1 - r0
                 e = ci % len(nets)
                 cnet = nets[e]
-                if reducer is not None and ci == nchunks - 1 and not two:
-                    net.grad_ready_hook = reducer.ready  # gradients become final in the last chunk's backward
+                if reducer is not None and ci + len(nets) >= nchunks:
+                    # a pipeline's gradients become final in the backward pass of ITS last chunk; a bucket goes out when
+                    # every pipeline has released it (api/policy.py:219-238: what DDP's bucketing does)
+                    cnet.grad_ready_hook = reducer.hook(e)
                 with torch.cuda.stream(streams[e]):
                     c_obs = {k: v[r0:r1] for k, v in f_obs.items()}
                     c_avail = None if f_avail is None else f_avail[r0:r1]
@@ -687,15 +748,18 @@ class MultiAgentPPO(PytorchTrainer):
                     for pst in streams[1:]:
                         pst.wait_stream(streams[0])
             net.chunks_of_one_update(False)
-            if two:
+            if two and reducer is None:
                 for twin, pst in zip(self._twin, self._pipe_stream):
                     streams[0].wait_stream(pst)
                     hip.accumulate(net.grad, twin.grad)
 
             # ---- gradient reduction, clip, Adam (mappo.py:272-284) ---------------------------------------------------
-            if reducer is not None:  # the buckets not yet launched, then wait for all of them
-                net.grad_ready_hook = None
-                reducer.finish()
+            if reducer is not None:  # the buckets not yet launched (folding the pipelines' slices), then wait for all of them
+                for x in nets:
+                    x.grad_ready_hook = None
+                reducer.finish(streams[1:])
+                for pst in streams[1:]:
+                    streams[0].wait_stream(pst)
             sumsq = net.ws.get("mappo.sumsq", 1, torch.float64)[:1]  # zeroed by srl_grad_sumsq
             slot = epoch * stride + nchunks * hip.LT_COUNT
             gnorm = block.view(-1).view(torch.float32)[2 * slot:2 * slot + 1]

@@ -98,3 +98,36 @@ def test_bucket_reducer_cuts_and_readiness():
     assert sorted(fired) == [1, 2]
     r.ready([f"{cm}.0", "obs_modules_dict.obs.0"])
     assert sorted(fired) == [0, 1, 2] and fired[-1] == 0
+
+
+def test_bucket_reducer_with_two_pipelines_waits_for_both():
+    """Two row-chunk pipelines with their own gradient buffers: a bucket leaves when the last chunk of EACH pipeline has
+    released it, whichever comes second, and each release leaves one stream marker for the fold to wait on."""
+    from srl_amd.algorithm import netspec as ns
+    from srl_amd.algorithm.mappo import _BucketReducer
+    spec, _ = ns.build_netspec(obs_dim=4, action_dim=3, hidden_dim=64, num_dense_layers=2, shared_backbone=False)
+
+    class Net:
+        pass
+
+    net = Net()
+    net.spec, net.grad = spec, torch.zeros(spec.total_params)
+    r = _BucketReducer(net, 8192)
+    assert len(r.buckets) >= 3
+    fired, marks = [], []
+    r._launch = lambda i: (fired.append(i), r.launched.__setitem__(i, True))
+    r._mark = lambda: marks.append(len(marks)) or len(marks)
+    r.begin([net.grad, torch.zeros(spec.total_params)])
+    every = sorted({p for b in r.buckets for p in b[2]})
+    last = r.buckets[-1][2]
+    both = [i for i, b in enumerate(r.buckets) if b[2] <= last]  # (a bucket may hold only the bias of the tail's first layer)
+    r.hook(0)(sorted(last))  # pipeline 0 releases the tail bucket: pipeline 1 still holds it
+    assert fired == [] and len(marks) == len(both) < len(r.buckets) and all(r.events[0][i] is not None for i in both)
+    r.hook(1)(every)  # pipeline 1 releases everything: only what both have released goes
+    assert fired == both and len(marks) == len(both) + len(r.buckets)
+    r.hook(0)(every)
+    assert sorted(fired) == list(range(len(r.buckets))) and len(marks) == 2 * len(r.buckets)
+    assert all(ev is not None for pipe in r.events for ev in pipe)
+    r.begin()  # one pipeline again: no markers
+    r.ready(every)
+    assert len(marks) == 2 * len(r.buckets) and all(r.launched)

@@ -37,7 +37,7 @@ def _rank_arrays(step, rank, world, unequal=False):
     return {k: np.ascontiguousarray(v[:, rank * half:(rank + 1) * half]) for k, v in full.items()}
 
 
-def _worker(rank, world, port, out, unequal=False):
+def _worker(rank, world, port, out, unequal=False, pipelines=2):
     import srl_amd
     from srl_amd.api import config, trainer as trainer_api
     from srl_amd.runtime import synthetic
@@ -45,7 +45,8 @@ def _worker(rank, world, port, out, unequal=False):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         # different seeds: joining the group must adopt rank 0's parameters (what the DDP constructor does)
-        trainer = trainer_api.make(config.Trainer("mappo", args=TRAINER), config.Policy("actor-critic", args=dict(POLICY, seed=7 + rank)))
+        trainer = trainer_api.make(config.Trainer("mappo", args=dict(TRAINER, pipelines=pipelines)),
+                                   config.Policy("actor-critic", args=dict(POLICY, seed=7 + rank)))
         trainer.distributed(rank=rank, world_size=world, init_method=None)
         init = {k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()}
         stats = []
@@ -53,14 +54,19 @@ def _worker(rank, world, port, out, unequal=False):
             res = trainer.step(synthetic.to_sample_batch(_rank_arrays(step, rank, world, unequal)))
             stats.append(res.stats)
         final = {k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()}
-        out[rank] = dict(init=init, final=final, stats=stats)
+        out[rank] = dict(init=init, final=final, stats=stats, reducer=dict(trainer._reducer.stats),
+                         buckets=len(trainer._reducer.buckets))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("unequal", [False, True], ids=["split-batch", "unequal-mask-counts"])
-def test_two_rank_trainer_matches_ddp_semantics(unequal):
-    """`unequal`: the ranks' masks hold very different counts.  Reference semantics (mappo.py:184,197,199 under DDP): each
+@pytest.mark.parametrize("unequal,pipelines", [(False, 2), (True, 2), (False, 1)],
+                         ids=["split-batch", "unequal-mask-counts", "one-pipeline"])
+def test_two_rank_trainer_matches_ddp_semantics(unequal, pipelines):
+    """144 rows per rank in chunks of 100: with the default two pipelines each chunk is the LAST chunk of its pipeline, so
+    both backward passes release buckets (`_BucketReducer.ready` on device, one event per pipeline and bucket) and every
+    bucket's all-reduce is launched from inside the second backward pass after the other pipeline's slice was folded in;
+    with one pipeline the second chunk's backward releases them.  `unequal`: the ranks' masks hold very different counts.  Reference semantics (mappo.py:184,197,199 under DDP): each
     rank divides its masked sums by its LOCAL count, the gradients are then averaged over ranks with equal weight, while the
     advantage normalisation uses the GLOBAL statistics -- not a global masked mean of the loss."""
     from oracle.net import OracleActorCritic
@@ -71,8 +77,13 @@ def test_two_rank_trainer_matches_ddp_semantics(unequal):
         assert counts[0] > 1.15 * counts[1], counts
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), out, unequal), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), out, unequal, pipelines), nprocs=world, join=True)
         res = {r: out[r] for r in range(world)}
+    for r in range(world):  # the overlap ran: every bucket of every epoch left from inside a backward pass
+        red, nb = res[r]["reducer"], res[r]["buckets"]
+        epochs = STEPS * TRAINER["ppo_epochs"]
+        assert nb >= 3 and red["launched_in_backward"] == nb * epochs and red["launched_in_finish"] == 0, red
+        assert red["slices_folded"] == (nb * epochs if pipelines == 2 else 0), red
     for k in res[0]["init"]:  # both ranks start from rank 0's parameters and stay identical
         assert np.array_equal(res[0]["init"][k], res[1]["init"][k]), k
         assert np.array_equal(res[0]["final"][k], res[1]["final"][k]), k
@@ -102,7 +113,7 @@ def test_bench_script_with_two_ranks():
     env = dict(os.environ, SRL_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--global-envs", "32", "--rollout-len", "8"]
+           "--global-envs", "32", "--rollout-len", "8", "--chunk-rows", "64"]  # 128 rows per rank: one chunk per pipeline
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -113,6 +124,11 @@ def test_bench_script_with_two_ranks():
     assert line["config"]["collective_ranks"] == 2 and line["from_pinned_host"]["value"] > 0
     assert line["resident_in_hbm"]["value"] > 0 and line["ring_fed"]["obs_ring"]["rows_patched"] == 0  # every stamp alive
     assert line["roofline"]["bound"] == "mfma" and "cpu_baseline" not in line  # the CPU baseline is N = 1 only
+    # the NatureCNN's buckets leave from inside the backward passes of the two pipelines' last chunks, layer by layer
+    gb = line["config"]["grad_buckets"]
+    assert line["config"]["pipelines"] == 2 and gb["buckets"] >= 2 and gb["launched_in_finish"] == 0, gb
+    assert gb["launched_in_backward"] == gb["buckets"] * gb["epochs"], gb
+    assert 0.8 * gb["launched_in_backward"] <= gb["slices_folded"] <= gb["launched_in_backward"], gb  # (one-chunk legs: no fold)
 
 
 def test_bench_script_one_rank_over_rccl():
