@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 9
+#define SRL_HIP_ABI_VERSION 10
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -375,17 +375,11 @@ int srl_conv2d_supported(const srl_conv_desc* d, int first_layer);
 /* y_mask (ReLU layers, Cout a multiple of 32; or NULL): [ceil(n*OH*OW*Cout / 32)] words, bit e & 31 of word e >> 5 set iff
  * element e of y is > 0 -- the one bit the backward pass needs of y where it is only the ReLU derivative that is wanted
  * (srl_conv2d_nhwc_dgrad's x_mask, srl_gemm_desc's dact_mask): modules/cnn.py:118. */
-/* workspace (srl_conv2d_fwd_workspace floats, 16-byte aligned; or NULL; EXPERIMENTAL, only with SRL_CONV_IS=1 in the
- * environment -- measured equal to / slower than the implicit GEMM so far): with it, both ranges and >= 512 images, the layers
- * whose feature maps fit in LDS (the 20x20x32 -> 9x9x64 and 9x9x64 -> 7x7x64 layers of modules/cnn.py:93-135's Atari stack)
- * run image-stationary: whole images staged once in LDS as two f16 planes, every tap's operands read from there, each
- * input byte fetched from HBM exactly once (csrc/conv_is.h).  0 from srl_conv2d_fwd_workspace: not for this geometry. */
-int64_t srl_conv2d_fwd_workspace(const srl_conv_desc* d);
 /* w_presplit != 0: `w` is srl_presplit(w, w_absmax): accepted only where the layer takes the two-piece kernel (both ranges,
- * Cout in 33..., KH*KW*Cin >= 64; not the image-stationary path). */
+ * Cout in 33..., KH*KW*Cin >= 64). */
 int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w, const float* bias,
                         float* y, const float* x_absmax, const float* w_absmax, float* y_absmax, uint32_t* y_mask,
-                        float* workspace, int w_presplit);
+                        int w_presplit);
 /* dw[Cout,KH,KW,Cin] += sum over (n,oh,ow) dz[.,Cout]^T patch(x); workspace: srl_conv2d_wgrad_workspace floats
  * (split over the n*OH*OW reduction) or NULL.  dbias (optional): [Cout] += sum over (n,oh,ow) dz, the bias
  * gradient, from the same pass over dz. */

@@ -49,9 +49,7 @@ for (H, Cin, k, s, Cout) in ((20, 32, 4, 2, 64), (9, 64, 3, 1, 64)):
     ym = torch.zeros(y.numel() // 32, dtype=torch.int32, device=DEV)
     xm = torch.randint(-2 ** 31, 2 ** 31 - 1, (x.numel() // 32,), dtype=torch.int32, device=DEV)
     P = lambda t: t.data_ptr()
-    fws = torch.empty(max(hip.conv2d_fwd_workspace(d), 4), device=DEV)
-    cases = (("fwd stationary", lambda: hip.conv2d_nhwc_fwd(d, P(x), P(w), P(b), P(y), x_absmax=P(xr), w_absmax=P(wr), y_absmax=P(yr), ws_ptr=P(fws))),
-             ("fwd stationary+mask", lambda: hip.conv2d_nhwc_fwd(d, P(x), P(w), P(b), P(y), x_absmax=P(xr), w_absmax=P(wr), y_absmax=P(yr), y_mask=P(ym), ws_ptr=P(fws))),
+    cases = (
              ("fwd", lambda: hip.conv2d_nhwc_fwd(d, P(x), P(w), P(b), P(y), x_absmax=P(xr), w_absmax=P(wr), y_absmax=P(yr))),
              ("fwd+mask", lambda: hip.conv2d_nhwc_fwd(d, P(x), P(w), P(b), P(y), x_absmax=P(xr), w_absmax=P(wr), y_absmax=P(yr), y_mask=P(ym))),
              ("wgrad", lambda: hip.conv2d_nhwc_wgrad(d, P(x), P(dz), P(gw), P(ws), P(gb), x_absmax=P(xr), dz_absmax=P(dzr))),

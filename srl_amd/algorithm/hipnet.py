@@ -747,14 +747,12 @@ class HipNet:
                     y_range = self._act_range() if implicit else None
                     if implicit:
                         w_range = self._weight_range(L.prefix, L.cout * kdim) if cur_range is not None and not L.pad else None
-                        fws = hip.conv2d_fwd_workspace(desc) if w_range is not None else 0
                         xr = cur_range if w_range is not None else None
                         w, pre = self._p(f"{L.prefix}.weight"), None
-                        if hip.conv2d_fwd_two_piece(desc, xr, w_range) and not os.environ.get("SRL_CONV_IS", "0")[:1] in "12":
+                        if hip.conv2d_fwd_two_piece(desc, xr, w_range):
                             pre = self._presplit(f"{L.prefix}.w2h", w, L.cout * kdim, w_range)
                         hip.conv2d_nhwc_fwd(desc, cur.ptr, pre or w, self._p(f"{L.prefix}.bias"),
                                             y.ptr, x_absmax=xr, w_absmax=w_range, y_absmax=y_range, y_mask=y.mask,
-                                            ws_ptr=self.ws.get(f"{L.prefix}.wq", fws).data_ptr() if fws else None,
                                             presplit=pre is not None)
                     else:
                         hip.im2col_nhwc(cur.ptr, n, h, w, L.cin, L.k, L.k, L.stride, P.ptr)

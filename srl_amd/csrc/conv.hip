@@ -8,7 +8,6 @@
 #include "gemm_core.h"
 #include "gemm_bf16x3.h"
 #include "obs_bf16.h"
-#include "conv_is.h"
 
 using namespace srlgemm;
 
@@ -343,32 +342,9 @@ static bool tile192() {
   return on;
 }
 
-// Image-stationary forward (conv_is.h) for the geometries it is instantiated for; 0: not this one
-static int use_conv_is() {  // SRL_CONV_IS: 0 (default) off, 1 both geometries, 2 the 9x9x64 layer only
-  const char* e = getenv("SRL_CONV_IS");  // read per call: the tests switch it
-  return e ? atoi(e) : 0;
-}
-static int is_geometry(const srl_conv_desc* d) {
-  if (d->Cout != 64) return 0;
-  if (d->H == 20 && d->W == 20 && d->Cin == 32 && d->KH == 4 && d->KW == 4 && d->stride == 2) return 1;
-  if (d->H == 9 && d->W == 9 && d->Cin == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1) return 2;
-  return 0;
-}
-extern "C" int64_t srl_conv2d_fwd_workspace(const srl_conv_desc* d) {
-  if (check_desc(d) != 0 || !is_geometry(d)) return 0;
-  return (int64_t)d->Cout * d->KH * d->KW * d->Cin;  // the weights as two f16 planes: as many bytes as the float32 weights
-}
-template <int H, int W, int C, int KH, int KW, int S, int G, int TMW, int TPS, int D, int NT>
-static void launch_is_fwd(hipStream_t st, const srlis::FwdArgs& a, long n) {
-  const long npass = srl_ceil_div(n, (long)G);
-  const unsigned grid = (unsigned)(npass < 256 ? npass : 256);  // one workgroup per CU, each a contiguous run of passes
-  if (a.y_mask) hipLaunchKernelGGL((srlis::is_fwd_kernel<H, W, C, KH, KW, S, G, TMW, TPS, D, NT, true>), dim3(grid), dim3(NT), 0, st, a);
-  else hipLaunchKernelGGL((srlis::is_fwd_kernel<H, W, C, KH, KW, S, G, TMW, TPS, D, NT, false>), dim3(grid), dim3(NT), 0, st, a);
-}
-
 static int conv2d_nhwc_fwd_run(void* stream, const srl_conv_desc* d, const float* x, const float* w,
                                const float* bias, float* y, const float* x_absmax, const float* w_absmax,
-                               float* y_absmax, uint32_t* y_mask, float* workspace, int w_presplit) {
+                               float* y_absmax, uint32_t* y_mask, int w_presplit) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry (needs Cin, Cout multiples of 4, < 2^31 elements)");
   SRL_CHECK_ARG(x && w && y && aligned16(x) && aligned16(w), "null / unaligned tensor");
   SRL_CHECK_ARG(!y_mask || (d->act == 1 && d->Cout % 32 == 0), "y_mask: ReLU layers with Cout a multiple of 32");
@@ -386,21 +362,6 @@ static int conv2d_nhwc_fwd_run(void* stream, const srl_conv_desc* d, const float
   g.range_a = x_absmax; g.range_b = w_absmax; g.out_absmax = y_absmax;
   g.mask_out = y_mask;
   hipStream_t st = (hipStream_t)stream;
-  if (!w_presplit && workspace && aligned16(workspace) && x_absmax && w_absmax && use_bf16x3() && use_f16x2() && use_conv_is() && d->n >= 512 &&
-      is_geometry(d) >= use_conv_is()) {
-    // whole images staged once in LDS as two f16 planes, every tap's fragments read from there (conv_is.h)
-    const int geo = is_geometry(d);
-    _Float16* wq = reinterpret_cast<_Float16*>(workspace);
-    hipLaunchKernelGGL(srlis::is_prep_kernel, dim3(64), dim3(256), 0, st, w, w_absmax, wq, d->KH * d->KW, d->Cin);
-    srlis::FwdArgs a{};
-    a.x = x; a.wq = reinterpret_cast<const uint4*>(wq); a.bias = bias; a.y = y; a.y_mask = y_mask; a.y_absmax = y_absmax;
-    a.x_absmax = x_absmax; a.w_absmax = w_absmax; a.n = d->n; a.act = d->act;
-    srl_count_dispatch(SRL_DISP_CONV_IS);
-    if (geo == 1) launch_is_fwd<20, 20, 32, 4, 4, 2, 1, 1, 2, 4, 512>(st, a, d->n);
-    else launch_is_fwd<9, 9, 64, 3, 3, 1, 2, 1, 1, 3, 512>(st, a, d->n);
-    SRL_LAUNCH_CHECK();
-    return 0;
-  }
   int rc;
   const bool x3 = use_bf16x3() && Kp >= 64;  // bf16 matrix cores, three exact pieces per float32 operand
   if (x3) fwd_kstep_order(d, &g);
@@ -426,7 +387,7 @@ static int conv2d_nhwc_fwd_run(void* stream, const srl_conv_desc* d, const float
 
 extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w,
                                    const float* bias, float* y, const float* x_absmax, const float* w_absmax,
-                                   float* y_absmax, uint32_t* y_mask, float* workspace, int w_presplit) {
+                                   float* y_absmax, uint32_t* y_mask, int w_presplit) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 0), "unsupported geometry (needs Cin, Cout multiples of 4)");
   const long run = images_per_launch(d, 4);
   const long in_e = (long)d->H * d->W * d->Cin;
@@ -435,7 +396,7 @@ extern "C" int srl_conv2d_nhwc_fwd(void* stream, const srl_conv_desc* d, const f
     srl_conv_desc s = *d;
     s.n = d->n - i0 < run ? d->n - i0 : run;
     const int rc = conv2d_nhwc_fwd_run(stream, &s, x + i0 * in_e, w, bias, y + i0 * out_e, x_absmax, w_absmax, y_absmax,
-                                       y_mask ? y_mask + i0 * out_e / 32 : nullptr, workspace, w_presplit);
+                                       y_mask ? y_mask + i0 * out_e / 32 : nullptr, w_presplit);
     if (rc != 0) return rc;
   }
   return 0;

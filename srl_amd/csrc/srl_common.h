@@ -21,9 +21,8 @@ enum SrlDispatch {
   SRL_DISP_OBS_FWD_BF16 = 3,
   SRL_DISP_OBS_BWD_BF16 = 4,
   SRL_DISP_GEMM2H = 5,    // gemm3_kernel's two-plane f16 variant (three piece products)
-  SRL_DISP_CONV_IS = 6,   // conv_is.h: image-stationary convolutions (two f16 planes, three piece products)
-  SRL_DISP_H2 = 7,        // h2gemm.h / h2conv.h: pre-split operands staged by LDS-DMA (round 4)
-  SRL_DISP_FAMILIES = 8
+  SRL_DISP_H2 = 6,        // h2gemm.h / h2conv.h: pre-split operands staged by LDS-DMA (round 4)
+  SRL_DISP_FAMILIES = 7
 };
 void srl_count_dispatch(int family);
 

@@ -25,7 +25,7 @@ _lib = None
 # (bench.py does, before its imports) -- INTEGRATION.md lists it with the other switches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -83,9 +83,8 @@ class H2GemmDesc(Structure):
 
 _SIGNATURES = {
     "srl_conv2d_supported": (c_int, [_CD, c_int]),
-    "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD] + [c_void_p] * 9 + [c_int]),
+    "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD] + [c_void_p] * 8 + [c_int]),
     "srl_presplit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
-    "srl_conv2d_fwd_workspace": (c_int64, [_CD]),
     "srl_absmax": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_mlp_tape_floats": (c_int64, [POINTER(MlpLayer), c_int]),
     "srl_mlp_bwd_max_rows": (c_int64, [POINTER(MlpLayer), c_int]),
@@ -330,7 +329,7 @@ def device_info():
     return dict(num_cus=n.value, lds_bytes_per_cu=l.value, arch=buf.value.decode())
 
 
-DISPATCH_FAMILIES = ("gemm3", "gemm_f32", "skinny", "obs_fwd_bf16", "obs_bwd_bf16", "gemm2h", "conv_is", "h2")
+DISPATCH_FAMILIES = ("gemm3", "gemm_f32", "skinny", "obs_fwd_bf16", "obs_bwd_bf16", "gemm2h", "h2")
 
 
 def dispatch_counts(reset: bool = False) -> dict:
@@ -767,11 +766,6 @@ def conv2d_supported(d: ConvDesc, first_layer) -> bool:
     return bool(lib().srl_conv2d_supported(ctypes.byref(d), int(first_layer)))
 
 
-def conv2d_fwd_workspace(d: ConvDesc) -> int:
-    """Floats of workspace with which ``conv2d_nhwc_fwd`` may take the image-stationary kernel (0: not for this geometry)."""
-    return int(lib().srl_conv2d_fwd_workspace(ctypes.byref(d)))
-
-
 def conv2d_fwd_two_piece(d: ConvDesc, x_absmax, w_absmax) -> bool:
     """Whether ``conv2d_nhwc_fwd`` takes the two-plane f16 kernel (mirrors conv.hip): only then may the weights be pre-split."""
     return (x_absmax is not None and w_absmax is not None and d.Cout > 32 and d.Cin * d.KH * d.KW >= 64 and f16x2_enabled() and
@@ -779,11 +773,11 @@ def conv2d_fwd_two_piece(d: ConvDesc, x_absmax, w_absmax) -> bool:
 
 
 def conv2d_nhwc_fwd(d: ConvDesc, x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax=None, w_absmax=None, y_absmax=None, y_mask=None,
-                    ws_ptr=None, presplit=False):
+                    presplit=False):
     two = conv2d_fwd_two_piece(d, x_absmax, w_absmax)
     with _scope("conv_fwd", _conv_flops(d), "2h" if two else "x3"):
         _check(lib().srl_conv2d_nhwc_fwd(_stream(), ctypes.byref(d), x_ptr, w_ptr, bias_ptr, y_ptr, x_absmax, w_absmax,
-                                         y_absmax, y_mask, ws_ptr, int(bool(presplit))), "srl_conv2d_nhwc_fwd")
+                                         y_absmax, y_mask, int(bool(presplit))), "srl_conv2d_nhwc_fwd")
 
 
 MLP_MAX_LAYERS, MLP_MAX_WIDTH = 12, 128

@@ -1048,49 +1048,6 @@ def test_gemm_sign_masks(M, N, K):
     assert rel_close(g_m.cpu().numpy(), ref, 1e-5, scale=float(np.sqrt(K)))
 
 
-@needs_f16x2
-@pytest.mark.parametrize("n,H,Cin,k,s", [(513, 20, 32, 4, 2), (1030, 9, 64, 3, 1), (2048, 20, 32, 4, 2), (600, 9, 64, 3, 1)])
-def test_conv2d_image_stationary_forward(n, H, Cin, k, s):
-    """csrc/conv_is.h: with a workspace and both operand ranges the 20x20x32 and 9x9x64 layers run image-stationary (whole
-    images staged in LDS as two f16 planes).  Against float64, against the implicit-GEMM kernel on the same ranges, with the
-    sign mask and the folded output range; image counts that leave the last pass and the last workgroup short."""
-    Cout = 64
-    rng = np.random.default_rng(n)
-    x = np.maximum(rng.standard_normal((n, H, H, Cin)), 0).astype(np.float32)
-    x[::7] *= 1e-3  # images far below the operand's range: carried by the second plane
-    w = (rng.standard_normal((Cout, k, k, Cin)) / np.sqrt(k * k * Cin)).astype(np.float32)
-    b = rng.standard_normal(Cout).astype(np.float32)
-    d = hip.conv_desc(n, H, H, Cin, k, k, s, Cout, act=1)
-    OH = (H - k) // s + 1
-    dx_, dw_, db_ = dev(x), dev(w), dev(b)
-    xr, wr = dx_.abs().max().reshape(1), dw_.abs().max().reshape(1)
-    ws = torch.empty(hip.conv2d_fwd_workspace(d), device=DEV)
-    assert ws.numel() > 0
-    y = torch.full((n, OH, OH, Cout), np.nan, device=DEV)
-    ym = torch.full((n * OH * OH * Cout // 32,), -1, dtype=torch.int32, device=DEV)
-    yr = torch.zeros(1, device=DEV)
-    hip.dispatch_counts(reset=True)
-    import os
-    os.environ["SRL_CONV_IS"] = "1"  # opt-in: measured slower than / equal to the implicit GEMM so far (DESIGN section 7)
-    try:
-        hip.conv2d_nhwc_fwd(d, dx_.data_ptr(), dw_.data_ptr(), db_.data_ptr(), y.data_ptr(), x_absmax=xr.data_ptr(),
-                            w_absmax=wr.data_ptr(), y_absmax=yr.data_ptr(), y_mask=ym.data_ptr(), ws_ptr=ws.data_ptr())
-    finally:
-        del os.environ["SRL_CONV_IS"]
-    assert hip.dispatch_counts()["conv_is"] == 1
-    xt, wt, bt, yref = _conv_ref(x, w, b, s, 1)
-    ref = yref.permute(0, 2, 3, 1).detach().numpy()
-    assert rel_close(y.cpu().numpy(), ref, 1e-5, scale=1.0)
-    assert np.array_equal(ym.cpu().numpy().view(np.uint32), _signbits(y.cpu().numpy()))
-    assert float(yr) == float(y.abs().max())
-    y2 = torch.full_like(y, np.nan)  # the implicit-GEMM kernel on the same two-piece arithmetic
-    hip.conv2d_nhwc_fwd(d, dx_.data_ptr(), dw_.data_ptr(), db_.data_ptr(), y2.data_ptr(), x_absmax=xr.data_ptr(),
-                        w_absmax=wr.data_ptr())
-    err_is = np.abs(y.cpu().numpy() - ref).max()
-    err_ig = np.abs(y2.cpu().numpy() - ref).max()
-    assert err_is <= 2 * err_ig + 1e-7, (err_is, err_ig)
-
-
 def test_conv2d_runs_of_images(monkeypatch):
     """A batch is walked in runs of images (csrc/conv.hip images_per_launch; SRL_CONV_RUN_IMAGES forces short runs here): forward
     with mask and range, data gradient from the mask, weight gradient, and the first layer through a slot index -- equal to the
