@@ -42,6 +42,14 @@ int srl_device_info(int* num_cus, int* lds_bytes_per_cu, char* name, int name_le
  * first layer's obs_fwd_bf16_kernel / obs_bwd_bf16_kernel, out[5] the two-plane f16 variant of gemm3_kernel;
  * entries beyond 8 are zero.  reset != 0 zeroes the counters after reading.  No reference counterpart. */
 int srl_dispatch_counts(int64_t* out, int n, int reset);
+/* The same per INSTANTIATION: keys[i] = family << 56 | p0 << 40 | p1 << 24 | p2 << 8 | flags, counts[i] launches; returns the
+ * number of distinct keys seen (at most 256; the first `cap` are written).  gemm3 / gemm2h / gemm_f32: p0 x p1 = the tile
+ * (rows x columns of the output), p2 = the split-K factor, flags = A mode << 5 | B mode << 2 | A k-major << 1 | B k-major (modes:
+ * 0 plain, 1 convolution patches, 2 data-gradient patches, 3 / 4 first-layer frames); h2: p0 = 1 convolution / 2 weight gradient
+ * / 3 dense product, p1 = the kind (srl_h2_conv / srl_h2_wgrad) or the 32-channel blocks per workgroup, p2 = the depth of the
+ * LDS-DMA ring; first layer: p0 = the K depth, p1 = 1 with the h2 output, p2 = the position split.  Tests assert on these that
+ * a benchmark-sized call ran the instantiation the benchmark times. */
+int srl_dispatch_tiles(uint64_t* keys, int64_t* counts, int cap, int reset);
 
 /* ------------------------------------------------------------------------------------------------
  * GAE / V-trace reverse scan, fused with value masking, the return, and the advantage statistics.

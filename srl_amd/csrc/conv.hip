@@ -656,7 +656,7 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
     a.nsplit = obs_bf16_split(d->n, P, 3);
     const char* dbg = getenv("SRL_OBS_DBG");  // timing experiments (wrong results): see obs_bf16.h
     const dim3 grid(srlobs::xcd_position_grid(P, a.nsplit));
-    srl_count_dispatch(SRL_DISP_OBS_FWD_BF16);
+    srl_count_dispatch(SRL_DISP_OBS_FWD_BF16, 256, y_h2 ? 1 : 0, a.nsplit);
     switch (dbg ? atoi(dbg) : 0) {
       case 3: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 3>), grid, dim3(256), 0, st, a); break;
       case 4: hipLaunchKernelGGL((srlobs::obs_fwd_bf16_kernel<256, 4>), grid, dim3(256), 0, st, a); break;
@@ -799,7 +799,7 @@ static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* 
     a.nsplit = obs_bf16_split(d->n, P, 3);
     a.Q = a.nsplit > 1 ? slabs : Q;
     a.slab = (long)P * d->Cout * Kp;
-    srl_count_dispatch(SRL_DISP_OBS_BWD_BF16);
+    srl_count_dispatch(SRL_DISP_OBS_BWD_BF16, 256, 0, a.nsplit);
     hipLaunchKernelGGL(srlobs::obs_bwd_bf16_kernel<256>, dim3(srlobs::xcd_position_grid(P, a.nsplit)), dim3(256), 0, st, a);
     SRL_LAUNCH_CHECK();
     if (a.nsplit > 1) {

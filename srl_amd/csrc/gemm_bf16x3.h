@@ -467,7 +467,7 @@ inline int launch3(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   }
   a.grp_sz = (unsigned)tiles_m * a.grp_n;
   dim3 grid((unsigned)(nblk * nsplit), 1, 1);
-  srl_count_dispatch(NP == 3 ? SRL_DISP_GEMM3 : SRL_DISP_GEMM2H);
+  srl_count_dispatch(NP == 3 ? SRL_DISP_GEMM3 : SRL_DISP_GEMM2H, BM, BN, nsplit, AMODE << 5 | BMODE << 2 | (int)AKM << 1 | (int)BKM);
   constexpr bool CAN_W = !AKM && !BKM && BMODE == SRC_PLAIN;  // sign masks: see launch() in gemm_core.h
   constexpr bool CAN_R = !AKM && BKM && BMODE == SRC_PLAIN && (AMODE == SRC_PLAIN || AMODE == SRC_DGRAD);
   constexpr bool CAN_PRE = NP == 2 && BMODE == SRC_PLAIN && KB == 16;  // pre-split B: the two-piece kernels, dense B

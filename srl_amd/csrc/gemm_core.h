@@ -1313,7 +1313,7 @@ inline int launch(hipStream_t st, GemmArgs a, int batch, int nsplit) {
   const long nblk = tiles_m * a.tiles_n * a.nbatch;
   if (nblk > 0x7fffffffL || nsplit > 65535) return -EINVAL;
   dim3 grid((unsigned)nblk, 1, (unsigned)nsplit);
-  srl_count_dispatch(SRL_DISP_GEMM_F32);
+  srl_count_dispatch(SRL_DISP_GEMM_F32, BM, BN, nsplit, AMODE << 5 | BMODE << 2 | (int)AKM << 1 | (int)BKM);
   // sign masks (gemm_epilogue's MK): written by products in the forward orientation, read by those in the data-gradient one
   constexpr bool CAN_W = !AKM && !BKM && !GEN && BMODE == SRC_PLAIN;
   constexpr bool CAN_R = !AKM && BKM && !GEN && BMODE == SRC_PLAIN && (AMODE == SRC_PLAIN || AMODE == SRC_DGRAD);

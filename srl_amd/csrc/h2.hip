@@ -136,7 +136,7 @@ extern "C" int srl_h2_conv(void* stream, int32_t kind, const srl_h2_conv_args* p
   const bool fwd = kind == H2C_F2 || kind == H2C_F3;
   SRL_CHECK_ARG(fwd ? a.mask_out != nullptr : a.mask_in != nullptr, "forward kinds write mask_out, data gradients read mask_in");
   SRL_CHECK_ARG(kind == H2C_D2 || (a.out_scale && a.bound_in && a.bound_w), "h2 outputs need out_scale and the bound's factors");
-  srl_count_dispatch(SRL_DISP_H2);
+  srl_count_dispatch(SRL_DISP_H2, 1, kind, fwd ? 3 : 2);
   switch (kind) {
     case H2C_F2: h2conv_launch<H2C_F2, 3>(st, a); break;
     case H2C_F3: h2conv_launch<H2C_F3, 3>(st, a); break;
@@ -163,7 +163,7 @@ extern "C" int srl_h2_wgrad(void* stream, int32_t kind, const void* x, const voi
   a.x = x; a.dz = dz; a.sx = sx; a.sz = sz; a.n = n; a.slabs = workspace;
   const int grid = n < kWgradGrid ? (int)n : kWgradGrid;
   const int K = kind == H2W_C2 ? 16 * 32 : 9 * 64, per = 64 * K + 64;
-  srl_count_dispatch(SRL_DISP_H2);
+  srl_count_dispatch(SRL_DISP_H2, 2, kind, kind == H2W_C2 ? 2 : 3);
   if (kind == H2W_C2) h2wgrad_launch<H2W_C2, 2>(st, a, grid);
   else h2wgrad_launch<H2W_C3, 3>(st, a, grid);
   hipLaunchKernelGGL(h2_wgrad_reduce_kernel, dim3((unsigned)srl_ceil_div(per, 64)), dim3(256), 0, st, workspace, grid, per, 64 * K, gw, gb);
@@ -183,7 +183,7 @@ extern "C" int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d) {
   a.bias = d->bias; a.act = d->act; a.out_fmt = d->out_h2 ? H2O_H2P : H2O_F32; a.out = d->out; a.out_row_bytes = (uint32_t)d->NC * 4u;
   a.out_scale = d->out_scale; a.bound_in = d->bound_in; a.bound_w = d->bound_w; a.bound_b = d->bound_b; a.out_absmax = d->out_absmax;
   a.mask_out = d->mask_out; a.mask_in = d->mask_in; a.mask_in_h2 = d->mask_in_h2order;
-  srl_count_dispatch(SRL_DISP_H2);
+  srl_count_dispatch(SRL_DISP_H2, 3, d->NC >= 128 ? 4 : 2, 3);
   int rc;
   if (d->NC >= 128) rc = h2gemm_launch<4, H2X_DENSE, 3>((hipStream_t)stream, a);
   else rc = h2gemm_launch<2, H2X_DENSE, 3>((hipStream_t)stream, a);

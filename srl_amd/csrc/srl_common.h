@@ -25,6 +25,14 @@ enum SrlDispatch {
   SRL_DISP_FAMILIES = 7
 };
 void srl_count_dispatch(int family);
+// ... and which instantiation: one counter per (family, three 16-bit template parameters, flags), srl_dispatch_tiles.
+// gemm3 / gemm_f32: BM, BN, split-K factor, flags = AMODE << 5 | BMODE << 2 | AKM << 1 | BKM; h2: 1 conv / 2 wgrad / 3 gemm, the
+// kind (or NCB), the ring depth; first layer: KP, h2 output?, position split.
+void srl_count_tile(int family, int p0, int p1, int p2, int flags);
+inline void srl_count_dispatch(int family, int p0, int p1, int p2, int flags = 0) {
+  srl_count_dispatch(family);
+  srl_count_tile(family, p0, p1, p2, flags);
+}
 
 #define SRL_CHECK_ARG(cond, msg)                                   \
   do {                                                             \

@@ -86,6 +86,7 @@ _SIGNATURES = {
     "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD] + [c_void_p] * 8 + [c_int]),
     "srl_presplit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "srl_absmax": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "srl_dispatch_tiles": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "srl_mlp_tape_floats": (c_int64, [POINTER(MlpLayer), c_int]),
     "srl_mlp_bwd_max_rows": (c_int64, [POINTER(MlpLayer), c_int]),
     "srl_mlp_fwd": (c_int, [c_void_p, POINTER(MlpLayer), c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
@@ -337,6 +338,28 @@ def dispatch_counts(reset: bool = False) -> dict:
     buf = (c_int64 * 8)()
     _check(lib().srl_dispatch_counts(buf, 8, int(bool(reset))), "srl_dispatch_counts")
     return {name: int(buf[i]) for i, name in enumerate(DISPATCH_FAMILIES)}
+
+
+def dispatch_tiles(reset: bool = False) -> dict:
+    """Launches per kernel INSTANTIATION since the last reset (``srl_dispatch_tiles``), keyed ``family:p0xp1:k<p2>[:flags]`` --
+    e.g. ``gemm2h:64x256:k8:f7`` (tile, split-K factor, operand modes), ``h2:conv:0:s3`` (kind, ring depth), ``h2:gemm:4:s3``."""
+    keys, counts = (ctypes.c_uint64 * 256)(), (c_int64 * 256)()
+    n = lib().srl_dispatch_tiles(keys, counts, 256, int(bool(reset)))
+    if n < 0:
+        raise HipError(f"srl_dispatch_tiles: {lib().srl_last_error().decode(errors='replace')}")
+    out = {}
+    for i in range(min(n, 256)):
+        k = int(keys[i])
+        fam, p0, p1, p2, fl = k >> 56, (k >> 40) & 0xffff, (k >> 24) & 0xffff, (k >> 8) & 0xffff, k & 0xff
+        name = DISPATCH_FAMILIES[fam] if fam < len(DISPATCH_FAMILIES) else f"family{fam}"
+        if name == "h2":
+            label = f"h2:{ {1: 'conv', 2: 'wgrad', 3: 'gemm'}.get(p0, p0)}:{p1}:s{p2}"
+        elif name.startswith("obs_"):
+            label = f"{name}:k{p0}:{'h2' if p1 else 'f32'}:split{p2}"
+        else:
+            label = f"{name}:{p0}x{p1}:k{p2}:f{fl}"
+        out[label] = out.get(label, 0) + int(counts[i])
+    return out
 
 
 def gae_scan_workspace(B, Nc, device) -> torch.Tensor:

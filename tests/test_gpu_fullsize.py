@@ -84,9 +84,13 @@ def test_step_full_size_chunking_and_repeatability():
     the same weights must repeat; returned advantages obey the masked statistics reported in the stats."""
     sample, _ = device_sample(7)
     results = []
+    from conftest import BENCH_CHUNK_TILES
     for chunk in (16384, 8192, 16384):
         tr = make(chunk)
+        hip.dispatch_tiles(reset=True)
         res = tr.step(synthetic.to_sample_batch(dict(sample)))
+        nchunks = -(-T * B // chunk)
+        assert hip.dispatch_tiles(reset=True) == {k: v * nchunks for k, v in BENCH_CHUNK_TILES.items()}, chunk
         sd = tr.policy.get_checkpoint()["state_dict"]
         results.append((res.stats, sd))
     (s0, p0), (s1, p1), (s2, p2) = results

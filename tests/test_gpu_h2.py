@@ -111,14 +111,27 @@ def test_pack_unpack_round_trip_every_layout():
     assert torch.equal(p2.buf.view(5, 400, 32)[:, ent], p1.buf.view(5, 400, 32))
 
 
+def _pick(n, count=48):
+    """All images of a small batch; of a benchmark-size chunk (n = 16 384) 48 sampled ones plus both ends -- the float64
+    reference is then computed for those only."""
+    if n <= 2048:
+        return torch.arange(n, device=DEV)
+    idx = torch.from_numpy(np.random.default_rng(n).choice(n, count, replace=False)).to(DEV)
+    return torch.cat([idx, torch.tensor([0, 1, n - 2, n - 1], device=DEV)])
+
+
+BENCH_N = 16384  # images per chunk of the benchmarked update (bench.py --chunk-rows)
+
+
 # ------------------------------------------------------------------------------------------------ forward convolutions
 def _conv_case(kind):
     return dict(c2=(20, 32, 4, 2, 9), c3=(9, 64, 3, 1, 7))[kind]
 
 
-@pytest.mark.parametrize("kind,n", [("c2", 5), ("c2", 301), ("c3", 7), ("c3", 301)])
+@pytest.mark.parametrize("kind,n", [("c2", 5), ("c2", 301), ("c3", 7), ("c3", 301), ("c2", BENCH_N), ("c3", BENCH_N)])
 def test_conv_forward_vs_float64(kind, n):
     hip = _hip()
+    hip.dispatch_tiles(reset=True)
     H, C, k, st, OH = _conv_case(kind)
     x = _f(n, H, H, C, seed=3, relu=True, amp=2.0)
     w = _f(64, k, k, C, seed=4, amp=0.05)     # [Cout, KH, KW, Cin]: the layout the layers keep
@@ -132,27 +145,31 @@ def test_conv_forward_vs_float64(kind, n):
                               sw.data_ptr(), n, out.data_ptr(), oam.data_ptr(), bias=b.data_ptr(), act=1, out_scale=osc.data_ptr(),
                               bound_in=xp.amax.data_ptr(), bound_w=rw.data_ptr(), bound_b=bb.data_ptr(), mask_out=mask.data_ptr())
     run()
+    assert hip.dispatch_tiles(reset=True) == {f"h2:conv:{0 if kind == 'c2' else 1}:s3": 1}
     first = (out.clone(), mask.clone())
-    ref = F.relu(F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(), stride=st)).permute(0, 2, 3, 1).contiguous()
+    pick = _pick(n)
+    ref = F.relu(F.conv2d(x[pick].double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(), stride=st)).permute(0, 2, 3, 1).contiguous()
     got = torch.empty(n, OH, OH, 64, device=DEV)
     if kind == "c2":
         hip.h2_unpack_image(out.data_ptr(), n, OH, OH, 64, 0, osc.data_ptr(), got.data_ptr())
     else:
         hip.h2_unpack_rows(out.data_ptr(), n * OH * OH, 64, osc.data_ptr(), got.data_ptr(), 64)
-    _close(got, ref)
+    _close(got[pick], ref)
     # the bound really bounds, the measured range is the range, the sign bytes are the signs (up to values at rounding distance of 0)
-    assert float(ref.abs().max()) * float(osc.item()) < 2**15 and abs(float(oam.item()) - float(ref.abs().max())) <= 1e-5 * float(ref.abs().max())
+    top = float(got.abs().max())
+    assert top * float(osc.item()) < 2**15 and abs(float(oam.item()) - top) <= 1e-5 * top and float(ref.abs().max()) <= top * (1 + 1e-5)
     want_mask = _mask_h2(ref.float())
-    assert int((mask != want_mask.reshape(-1)).sum()) <= 2
+    assert int((mask.view(n, -1)[pick] != want_mask.reshape(len(pick), -1)).sum()) <= 2
     for _ in range(2):   # bit-reproducible
         run()
         assert torch.equal(out, first[0]) and torch.equal(mask, first[1])
 
 
 # ------------------------------------------------------------------------------------------------ data gradients
-@pytest.mark.parametrize("kind,n", [("c3", 3), ("c3", 300), ("c2", 2), ("c2", 6), ("c2", 300)])
+@pytest.mark.parametrize("kind,n", [("c3", 3), ("c3", 300), ("c2", 2), ("c2", 6), ("c2", 300), ("c3", BENCH_N), ("c2", BENCH_N)])
 def test_conv_data_gradient_vs_float64(kind, n):
     hip = _hip()
+    hip.dispatch_tiles(reset=True)
     H, C, k, st, OH = _conv_case(kind)
     dz = _f(n, OH, OH, 64, seed=6, amp=1e-3)
     w = _f(64, k, k, C, seed=7, amp=0.05)
@@ -175,23 +192,27 @@ def test_conv_data_gradient_vs_float64(kind, n):
                               sw.data_ptr(), n, out.data_ptr(), oam.data_ptr(), out_scale=osc.data_ptr(), bound_in=az.data_ptr(),
                               bound_w=rw.data_ptr(), mask_in=mask.data_ptr())
     run()
+    assert hip.dispatch_tiles(reset=True) == {f"h2:conv:{2 if kind == 'c3' else 3}:s2": 1}
     first = out.clone()
-    ref = F.conv_transpose2d(dz.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=st).permute(0, 2, 3, 1) * (act > 0)
+    pick = _pick(n)
+    ref = F.conv_transpose2d(dz[pick].double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=st).permute(0, 2, 3, 1) * (act[pick] > 0)
     if kind == "c3":
         got = torch.empty(n, H, H, C, device=DEV)
         hip.h2_unpack_image(out.data_ptr(), n, H, H, C, 0, osc.data_ptr(), got.data_ptr())
     else:
         got = out.view(n, H, H, C)
-    _close(got, ref)
+    _close(got[pick], ref)
     for _ in range(3):
         run()
         assert torch.equal(out, first)
 
 
 # ------------------------------------------------------------------------------------------------ weight gradients
-@pytest.mark.parametrize("kind,n", [("c3", 5), ("c3", 293), ("c2", 5), ("c2", 293)])
+@pytest.mark.parametrize("kind,n", [("c3", 5), ("c3", 293), ("c2", 5), ("c2", 293), ("c3", BENCH_N), ("c2", BENCH_N)])
 def test_conv_weight_gradient_vs_float64(kind, n):
+    """(n = 16 384: every slab of the 256-workgroup launch and the reduction over them; 1.3 M / 0.8 M terms per element.)"""
     hip = _hip()
+    hip.dispatch_tiles(reset=True)
     H, C, k, st, OH = _conv_case(kind)
     x = _f(n, H, H, C, seed=9, relu=True, amp=2.0)
     dz = _f(n, OH, OH, 64, seed=10, amp=1e-3)
@@ -208,21 +229,24 @@ def test_conv_weight_gradient_vs_float64(kind, n):
     gw0, gb0 = _f(64, K, seed=11, amp=1e-2), _f(64, seed=12, amp=1e-2)   # the kernels ADD into the gradient buffers
     gw, gb = gw0.clone(), gb0.clone()
     hip.h2_wgrad(code, xp.buf.data_ptr(), zbuf.data_ptr(), xp.scale.data_ptr(), sz.data_ptr(), n, ws.data_ptr(), gw.data_ptr(), gb.data_ptr())
-    xd = x.double().permute(0, 3, 1, 2).requires_grad_(False)
+    assert hip.dispatch_tiles(reset=True) == {f"h2:wgrad:{0 if kind == 'c2' else 1}:s{2 if kind == 'c2' else 3}": 1}
     wd = torch.zeros(64, C, k, k, dtype=torch.float64, device=DEV, requires_grad=True)
     bd = torch.zeros(64, dtype=torch.float64, device=DEV, requires_grad=True)
-    (F.conv2d(xd, wd, bd, stride=st) * dz.double().permute(0, 3, 1, 2)).sum().backward()
-    _close(gw - gw0, wd.grad.permute(0, 2, 3, 1).reshape(64, K))
-    _close(gb - gb0, bd.grad)
+    for i0 in range(0, n, 2048):   # the float64 reference in pieces
+        (F.conv2d(x[i0:i0 + 2048].double().permute(0, 3, 1, 2), wd, bd, stride=st) * dz[i0:i0 + 2048].double().permute(0, 3, 1, 2)).sum().backward()
+    tol = 1e-6 if n <= 2048 else 4e-6
+    _close(gw - gw0, wd.grad.permute(0, 2, 3, 1).reshape(64, K), tol=tol)
+    _close(gb - gb0, bd.grad, tol=tol)
     gw2, gb2 = gw0.clone(), gb0.clone()
     hip.h2_wgrad(code, xp.buf.data_ptr(), zbuf.data_ptr(), xp.scale.data_ptr(), sz.data_ptr(), n, ws.data_ptr(), gw2.data_ptr(), gb2.data_ptr())
     assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
 
 
 # ------------------------------------------------------------------------------------------------ the Linear's products
-@pytest.mark.parametrize("M", [77, 1000])
+@pytest.mark.parametrize("M", [77, 1000, BENCH_N])
 def test_linear_forward_and_data_gradient_vs_float64(M):
     hip = _hip()
+    hip.dispatch_tiles(reset=True)
     K, N = 3136, 512
     x = _f(M, K, seed=13, relu=True, amp=2.0)
     w = _f(N, K, seed=14, amp=0.03)
@@ -233,6 +257,7 @@ def test_linear_forward_and_data_gradient_vs_float64(M):
     y = torch.zeros(M, N, device=DEV)
     mo = torch.zeros(M * N // 32, dtype=torch.int32, device=DEV)
     hip.h2_gemm(xbuf.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(), M, N, K, y.data_ptr(), bias=b.data_ptr(), act=1, mask_out=mo.data_ptr())
+    assert hip.dispatch_tiles(reset=True) == {"h2:gemm:4:s3": 1}
     ref = F.relu(x.double() @ w.double().t() + b.double())
     _close(y, ref)
     assert int((mo != _mask_natural(ref.float().view(M, 1, 1, N))).sum()) <= 1
@@ -256,22 +281,36 @@ def test_linear_forward_and_data_gradient_vs_float64(M):
     assert torch.equal(dx, first)
 
 
-def test_linear_weight_gradient_reads_h2p_rows():
+@pytest.mark.parametrize("M", [1111, BENCH_N])
+def test_linear_weight_gradient_reads_h2p_rows(M):
     """dW = dy^T x with x never written as float32: the round-3 two-piece kernel stages the h2p rows as they are
-    (srl_gemm_desc::b_h2_scale)."""
+    (srl_gemm_desc::b_h2_scale).  With the split-K factor, the workspace and the fused bias sum `H2Cnn._fc_wgrad` passes for that
+    row count (16 384 rows: the 128 x 128 tiles over 5 k-ranges the benchmark launches)."""
+    from srl_amd.algorithm.hipnet import _split_for
     hip = _hip()
-    M, K, N = 1111, 3136, 512
+    K, N = 3136, 512
     x = _f(M, K, seed=17, relu=True, amp=2.0)
     dy = _f(M, N, seed=18, amp=1e-3)
     xbuf, sx, ax = torch.empty_like(x), _slot(0.0), _absmax(hip, x)
     hip.h2_pack_rows(x.data_ptr(), K, M, K, xbuf.data_ptr(), absmax=ax.data_ptr(), scale_out=sx.data_ptr())
     ad = _absmax(hip, dy)
-    gw = torch.zeros(N, K, device=DEV)
+    gw, gb = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    split = _split_for(M, ((N + 127) // 128) * ((K + 127) // 128))
+    ws = torch.empty(max(split * N * K, 4), device=DEV)
+    fused = hip.gemm_colsum_ok(N, K, M, dy.data_ptr(), N, xbuf.data_ptr(), K, 1)
     hip.dispatch_counts(reset=True)
-    hip.gemm(N, K, M, dy.data_ptr(), N, 1, xbuf.data_ptr(), K, 1, gw.data_ptr(), K, accumulate=True, a_absmax=ad.data_ptr(),
+    hip.dispatch_tiles(reset=True)
+    hip.gemm(N, K, M, dy.data_ptr(), N, 1, xbuf.data_ptr(), K, 1, gw.data_ptr(), K, accumulate=True, split_k=split,
+             workspace=ws.data_ptr() if split > 1 else None, a_colsum=gb.data_ptr() if fused else None, a_absmax=ad.data_ptr(),
              b_h2_scale=sx.data_ptr())
     assert hip.dispatch_counts(reset=True)["gemm2h"] == 1
-    _close(gw, dy.double().t() @ x.double())
+    tiles = hip.dispatch_tiles(reset=True)
+    assert list(tiles) == [f"gemm2h:128x128:k{split}:f3"], tiles
+    if M == BENCH_N:
+        assert split == 5 and fused
+    _close(gw, dy.double().t() @ x.double(), tol=2e-6 if M < 2048 else 4e-6)
+    if fused:
+        _close(gb, dy.double().sum(0), tol=4e-6)
 
 
 # ------------------------------------------------------------------------------------------------ benchmark-size launches
@@ -351,3 +390,60 @@ def test_first_layer_h2_output_equals_its_float32_output():
     assert float((back - y).abs().max()) <= 2.0**-21 * float(y.abs().max())
     assert torch.equal(hm, ym) and float(ham.item()) == float(yam.item())
     assert float(y.abs().max()) * float(hs.item()) < 2**15   # the a-priori bound holds
+
+
+def test_first_layer_at_benchmark_size():
+    """Both first-layer kernels on one 16 384-frame chunk exactly as `H2Cnn` calls them: frames read in place from a slot buffer
+    through `row_index` (the HBM observation ring), forward with the h2p output in parity-class order + sign words + measured range,
+    backward for dW / db / dgamma / dbeta.  Forward against float64 on sampled frames, the four gradients against float64 over
+    the whole chunk (autograd in pieces of 1024 frames)."""
+    hip = _hip()
+    n, slots = BENCH_N, BENCH_N + 64
+    g = torch.Generator(device=DEV).manual_seed(31)
+    frames = torch.randint(0, 256, (slots, 4, 84, 84), dtype=torch.uint8, device=DEV, generator=g)
+    frames[::5] //= 16   # dark frames: small variance, large rstd
+    s2d, mean, rstd = torch.empty(slots, 21, 21, 64, dtype=torch.uint8, device=DEV), torch.empty(slots, device=DEV), torch.empty(slots, device=DEV)
+    hip.obs_space_to_depth(frames.data_ptr(), True, slots, 4, 84, 84, 4, s2d.data_ptr(), mean.data_ptr(), rstd.data_ptr())
+    del frames
+    rows = torch.randperm(slots, device=DEV, generator=g)[:n].to(torch.int32)
+    desc = hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, 1)
+    gamma, beta = 1 + _f(21, 21, 64, seed=32, amp=0.2), _f(21, 21, 64, seed=33, amp=0.2)
+    w, b = _f(32, 2, 2, 64, seed=34, amp=0.06), _f(32, seed=35, amp=0.1)
+    ws = torch.empty(hip.conv2d_obs_fwd_workspace(desc), device=DEV)
+    yh = torch.zeros(n * 400 * 32, device=DEV)
+    hm, ham, hs = torch.zeros(n * 400, dtype=torch.int32, device=DEV), _slot(0.0), _slot(0.0)
+    hip.dispatch_tiles(reset=True)
+    hip.conv2d_obs_fwd_h2(desc, s2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), b.data_ptr(),
+                          yh.data_ptr(), hs.data_ptr(), ws.data_ptr(), rows, ham.data_ptr(), hm.data_ptr(), reuse_folded=False, ent_order=2)
+    assert hip.dispatch_tiles(reset=True) == {"obs_fwd_bf16:k256:h2:split8": 1}
+    y = torch.empty(n * 400, 32, device=DEV)
+    hip.h2_unpack_rows(yh.data_ptr(), n * 400, 32, hs.data_ptr(), y.data_ptr(), 32)
+    yy, xx = np.meshgrid(np.arange(20), np.arange(20), indexing="ij")
+    ent = torch.from_numpy((((yy & 1) * 2 + (xx & 1)) * 100 + (yy >> 1) * 10 + (xx >> 1)).reshape(-1)).to(DEV)
+    y = y.view(n, 400, 32)[:, ent].reshape(n, 20, 20, 32)   # raster order
+
+    def pre_activation(idx, gam, bet, wt, bias):   # float64, from the bytes
+        xs = s2d[rows[idx].long()].double()
+        mu = xs.mean((1, 2, 3), keepdim=True)
+        xhat = (xs - mu) / torch.sqrt(xs.var((1, 2, 3), unbiased=False, keepdim=True) + 1e-5)
+        return F.conv2d((xhat * gam + bet).permute(0, 3, 1, 2), wt.permute(0, 3, 1, 2), bias).permute(0, 2, 3, 1)
+
+    pick = _pick(n)
+    ref = F.relu(pre_activation(pick, gamma.double(), beta.double(), w.double(), b.double()))
+    _close(y[pick], ref)
+    top = float(y.abs().max())
+    assert abs(float(ham.item()) - top) <= 1e-5 * top and top * float(hs.item()) < 2**15 and float(ref.abs().max()) <= top * (1 + 1e-5)
+    # backward: dz gated by the forward's own ReLU
+    dz = (_f(n, 20, 20, 32, seed=36, amp=1e-3) * (y > 0)).contiguous()
+    outs = [torch.zeros(32 * 256, device=DEV), torch.zeros(32, device=DEV), torch.zeros(21 * 21 * 64, device=DEV), torch.zeros(21 * 21 * 64, device=DEV)]
+    wsb = torch.empty(hip.conv2d_obs_bwd_workspace(desc), device=DEV)
+    hip.conv2d_obs_bwd(desc, s2d.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(),
+                       dz.data_ptr(), *[o.data_ptr() for o in outs], wsb.data_ptr(), channels_last=True, row_index=rows)
+    assert hip.dispatch_tiles(reset=True) == {"obs_bwd_bf16:k256:f32:split8": 1}
+    leaves = [t.double().requires_grad_(True) for t in (w, b, gamma, beta)]
+    for i0 in range(0, n, 1024):
+        idx = torch.arange(i0, min(n, i0 + 1024), device=DEV)
+        (pre_activation(idx, leaves[2], leaves[3], leaves[0], leaves[1]) * dz[idx].double()).sum().backward()
+    for got, leaf, name in zip(outs, leaves, ("dw", "db", "dgamma", "dbeta")):
+        err = float((got.double() - leaf.grad.reshape(-1)).abs().max()) / float(leaf.grad.abs().max())
+        assert err <= 1e-5, (name, err)

@@ -385,6 +385,7 @@ def test_cnn_step_at_the_benchmarked_dispatch(kernels, frames, monkeypatch):
         onet.load_state_dict({k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()})
         oracles[dt] = (onet, OracleMappo(onet, **ATARI_TRAINER))
     hip.dispatch_counts(reset=True)
+    hip.dispatch_tiles(reset=True)
     tight = total = 0
     carried = {}  # gradient uncertainty of the steps so far: Adam's first moment carries it into the later updates
     for step in range(2):
@@ -428,7 +429,10 @@ def test_cnn_step_at_the_benchmarked_dispatch(kernels, frames, monkeypatch):
             total += err.size
     assert tight >= 0.9 * total, (tight, total)  # the widened tolerances are the exception
     counts = hip.dispatch_counts(reset=True)
+    tiles = hip.dispatch_tiles(reset=True)
     if kernels == "h2":
+        from conftest import BENCH_CHUNK_TILES, tile_kinds
+        assert tile_kinds(tiles) == tile_kinds(BENCH_CHUNK_TILES), tiles  # the instantiations a 16 384-row chunk of the benchmark runs
         # per step: conv2, conv3, Linear forward; Linear and both convolutions' data gradients; both convolutions' weight
         # gradients -- 8 launches of the pre-split family; the Linear's weight gradient on round 3's kernel; the first layer on the
         # byte kernels; nothing on the float32 MFMA kernels
