@@ -539,6 +539,15 @@ int srl_gather_rows(void* stream, const void* src, int64_t row_bytes, const int3
  * passes over them (min / max) and no upload of its own.  base = what a stamp carries besides the sequence number (the
  * ring's generation in its high bits, and the +1 that keeps 0 -- what a zero-filled sample field holds -- invalid). */
 int srl_ring_slots(void* stream, const int64_t* refs, int64_t n, int64_t capacity, int64_t base, int32_t* slots);
+/* Stack-aware staging: a frame-stacked observation [C, H, W] (atari_wrappers.py:211-242 `FrameStack`: the C latest frames, the
+ * newest last; reset() = C copies of the first frame) differs from the same environment's previous one by one plane, and the
+ * previous one is still in the ring.  Row slot0 + i of `store` (rows of C*H*W uint8 in srl_obs_space_to_depth's block-4 layout)
+ * becomes [channels 1..C-1 of row prev[i], planes[i]]; prev[i] < 0: C copies of planes[i].  mean / rstd [slot]: the
+ * whole-observation LayerNorm statistics of the assembled row, bit-identical to srl_obs_space_to_depth's on the full stack.
+ * A rollout request then carries H*W bytes instead of C*H*W over the host link (actor_critic_policy.py:467-469 uploads the
+ * whole stack every step).  planes: uint8 [n, H, W] device; prev: int32 [n] device (storage slots). */
+int srl_ring_stack_push(void* stream, void* store, const void* planes, const int32_t* prev, int64_t slot0, int64_t n, int C, int H,
+                        int W, float* mean, float* rstd);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser on one flat parameter buffer.

@@ -264,13 +264,23 @@ class ActorCriticPolicy(policy_api.Policy):
     # ------------------------------------------------------------------ inference
     # (2048: the call is bound by the host's launches per piece as much as by the link -- 4096 rows in 2 pieces 2.74-2.92 ms,
     # in 4 pieces 3.08-3.10, in 8 pieces 4.3, same box; SRL_ROLLOUT_PIECE for the A/B)
+    RING_PREV_KEY = "ring_prev"
     ROLLOUT_PIECE = int(os.environ.get('SRL_ROLLOUT_PIECE', '2048'))  # rows per piece when a big host batch is streamed in (copy of piece i+1 under the compute of i)
 
     def rollout(self, requests: policy_api.RolloutRequest, **kwargs) -> policy_api.RolloutResult:
         hip.require_gpu()
         host = {k: v for k, v in requests.obs.items() if v is not None}
         n = int(next(iter(host.values())).shape[0])
-        if (not self.spec.num_rnn_layers and n >= 2 * self.ROLLOUT_PIECE
+        # Stack-aware requests (atari_wrappers.py:211-242 `FrameStack`): `ring_prev` [n, 1] int64 holds the observation-ring
+        # stamp of the same environment's previous observation (0 at an episode start) and the frame-stack keys carry only
+        # their newest plane [n, 1, H, W]; the ring assembles the rows (ObsRing.put_stacked) -- a quarter of the bytes over
+        # the host link that actor_critic_policy.py:467-469 moves, same actions, log-probabilities and values.
+        prev = host.pop(self.RING_PREV_KEY, None)
+        if prev is not None and self._obs_ring is None:
+            raise ValueError("stack-aware requests (`ring_prev`) need an observation ring attached to the policy")
+        if prev is not None:
+            prev = (prev.cpu().numpy() if isinstance(prev, torch.Tensor) else np.asarray(prev)).astype(np.int64).reshape(n)
+        if (prev is None and not self.spec.num_rnn_layers and n >= 2 * self.ROLLOUT_PIECE
                 and not any(isinstance(v, torch.Tensor) and v.is_cuda for v in host.values())):
             action, logp, value, refs = self._rollout_streamed(host, n, requests.is_evaluation)
             state = None
@@ -282,7 +292,7 @@ class ActorCriticPolicy(policy_api.Policy):
                 if ps is None:
                     raise ValueError("recurrent policy: the request carries no policy_state")
                 state = {k: np.asarray(ps[k]) for k, _ in self._state_keys()}
-            action, logp, value, refs = self._rollout_rows(obs, n, requests.is_evaluation, state)
+            action, logp, value, refs = self._rollout_rows(obs, n, requests.is_evaluation, state, prev=prev)
             state = self._packed_last_state()
         analyzed = PPORolloutAnalyzedResult(log_probs=logp.cpu().numpy(), value=value.cpu().numpy(),
                                             obs_ref=None if refs is None else refs.reshape(n, 1))
@@ -355,7 +365,7 @@ class ActorCriticPolicy(policy_api.Policy):
                 stage(i + 1)  # issued after piece i's launches: a pageable copy blocks the host, not the GPU
         return action, logp, value, (None if refs is None else np.concatenate(refs))
 
-    def _rollout_rows(self, obs, n, is_evaluation, state):
+    def _rollout_rows(self, obs, n, is_evaluation, state, prev=None):
         """One inference pass over ``n`` independent rows: device ``(action, log_prob [n,1], value [n,vd])`` and the rows'
         observation-ring references (int64 numpy [n], or None without a ring); the new recurrent states are left in
         ``net.last_state``.  ``state``: ``{key: [n, layers, W]}`` host or device, or None."""
@@ -367,7 +377,12 @@ class ActorCriticPolicy(policy_api.Policy):
         is_eval = np.asarray(is_evaluation).reshape(-1)
         is_eval = to_device_leaf(np.broadcast_to(is_eval, (n,)) if is_eval.size == 1 else is_eval, self.device, "flag")
         refs = None
-        if self._obs_ring is not None:  # the rows stay in HBM for the trainer; the forward below reads them from there
+        if prev is not None:  # stack-aware: the ring assembles each row from its predecessor and the uploaded plane
+            ring = self._obs_ring
+            planes = {k: obs[k] for k in ring.keys() if tuple(obs[k].shape[1:]) != ring.raw_shape[k]}
+            refs, staged = ring.put_stacked(planes, prev, full={k: obs[k] for k in ring.keys() if k not in planes})
+            obs.update(staged)
+        elif self._obs_ring is not None:  # the rows stay in HBM for the trainer; the forward below reads them from there
             # a ring full of rows a training step has leased does not fail the request: the rows go unstaged (stamp -1), the
             # forward reads the batch's own rows, and the trainer uploads them from the sample when it binds it
             refs, staged = self._obs_ring.put_or_skip({k: obs[k] for k in self._obs_ring.keys()})

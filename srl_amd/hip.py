@@ -157,6 +157,7 @@ _SIGNATURES = {
     "srl_u8_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "srl_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "srl_ring_slots": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "srl_ring_stack_push": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "srl_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "srl_grad_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
@@ -914,6 +915,15 @@ def ring_slots(refs: torch.Tensor, capacity: int, out: torch.Tensor, base: int =
     """out[i] = (refs[i] - base) % capacity (``srl_ring_slots``): int64 stamps -> int32 storage slots, on the device."""
     _check(lib().srl_ring_slots(_stream(), _ptr(refs, torch.int64, "refs"), refs.numel(), int(capacity), int(base),
                                 _ptr(out, torch.int32, "slots")), "srl_ring_slots")
+
+
+def ring_stack_push(store: torch.Tensor, planes: torch.Tensor, prev: torch.Tensor, slot0: int, C: int, H: int, W: int,
+                    mean: torch.Tensor, rstd: torch.Tensor):
+    """Rows ``slot0 ...`` of the ring's space-to-depth storage = [channels 1.. of row prev[i], planes[i]] (``srl_ring_stack_push``)."""
+    n = planes.shape[0]
+    _check(lib().srl_ring_stack_push(_stream(), _ptr(store, torch.uint8, "store"), _ptr(planes, torch.uint8, "planes"),
+                                     _ptr(prev, torch.int32, "prev"), int(slot0), int(n), int(C), int(H), int(W),
+                                     _ptr(mean, torch.float32, "mean"), _ptr(rstd, torch.float32, "rstd")), "srl_ring_stack_push")
 
 
 def conv2d_obs_bwd_workspace(d: ConvDesc) -> int:

@@ -270,9 +270,11 @@ class ObsRing:
             self._ensure(k, t.dtype)
         return n
 
-    def _stage(self, obs, s0, n):
+    def _stage(self, obs, s0, n, keys=None):
         """Write ``n`` rows into storage slots [s0, s0 + n) in each key's layout, on the current stream."""
         for k, lay in self.layout.items():
+            if keys is not None and k not in keys:
+                continue
             t, store = obs[k], self.storage[k]
             if lay[0] == "s2d":
                 c, h, w = self.raw_shape[k]
@@ -319,6 +321,75 @@ class ObsRing:
             self._write_events[stream.cuda_stream] = ev
             self.stats["rows_put"] += n
         return np.arange(seq, seq + n, dtype=np.int64) + self._stamp_base, {k: RingObs(self, k, (n,), span=s0) for k in self.layout}
+
+    def stackable(self, key: str) -> bool:
+        """Whether ``put_stacked`` can assemble this key's rows from single planes: uint8 frame stacks [C, H, W] staged in the
+        block-4 space-to-depth layout."""
+        lay, raw = self.layout[key], self.raw_shape[key]
+        return lay[0] == "s2d" and int(lay[1]) == 4 and len(raw) == 3 and raw[1] % 4 == 0 and raw[2] % 4 == 0 and raw[1] * raw[2] % 16 == 0
+
+    def put_stacked(self, planes: Dict[str, torch.Tensor], prev, full: Optional[Dict[str, torch.Tensor]] = None):
+        """Stage one inference batch of FRAME-STACKED observations from their newest planes (the reference's `FrameStack`,
+        atari_wrappers.py:211-242: the C latest frames, newest last; reset = C copies).  ``planes``: key -> device uint8
+        ``[n, H, W]`` (or ``[n, 1, H, W]``), the newest frame of each row; ``prev``: int64 ``[n]`` -- the stamp this ring returned
+        for the SAME environment's previous observation, or 0 at an episode start (the stack is then C copies of the plane);
+        ``full``: the ring's other keys, whole rows as for ``put``.  Row i becomes [channels 1.. of row prev[i], planes[i]] and
+        is, byte for byte and statistic for statistic, what ``put`` would have staged from the whole stack -- for a quarter of
+        the bytes over the host link.  Raises LookupError when a previous observation is no longer in the ring (the caller then
+        sends whole stacks through ``put``), BufferError as ``put``."""
+        full = full or {}
+        for k in self.layout:
+            if (k in planes) == (k in full):
+                raise KeyError(f"observation key `{k}`: exactly one of `planes` / `full` must hold it")
+            if k in planes and not self.stackable(k):
+                raise hip.HipError(f"observation `{k}` is not a uint8 frame stack in the block-4 space-to-depth layout")
+        tensors = {}
+        for k, t in planes.items():
+            c, h, w = self.raw_shape[k]
+            if t.dim() == 4 and t.shape[1] == 1:
+                t = t[:, 0]
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == torch.uint8 and tuple(t.shape[1:]) == (h, w)):
+                raise hip.HipError(f"observation `{k}`: the newest planes must be contiguous device uint8 [n, {h}, {w}]")
+            tensors[k] = t
+            self._ensure(k, torch.uint8)
+        n = next(iter(tensors.values())).shape[0]
+        if any(t.shape[0] != n for t in tensors.values()) or (full and self._check_rows_subset(full) != n):
+            raise hip.HipError("observation keys disagree on the number of rows")
+        prev = np.asarray(prev, dtype=np.int64).reshape(-1)
+        if prev.shape[0] != n:
+            raise hip.HipError("`prev`: one stamp per row")
+        seq = self._alloc(n)
+        s0, head = seq % self.capacity, seq + n
+        pseq, mine = self._decode(prev)
+        fresh = prev == 0
+        ok = fresh | (mine & (pseq < seq) & (pseq + self.capacity >= head))   # still there once this run is written
+        if not ok.all():
+            raise LookupError(f"{int((~ok).sum())} of {n} previous observations are no longer in the ring: send whole stacks")
+        slots = torch.from_numpy(np.where(fresh, -1, pseq % self.capacity).astype(np.int32)).to(self.device, non_blocking=True)
+        for k, t in tensors.items():
+            c, h, w = self.raw_shape[k]
+            hip.ring_stack_push(self.storage[k], t, slots, s0, c, h, w, self.mean[k], self.rstd[k])
+        if full:
+            self._stage(full, s0, n, keys=list(full))
+        stream = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        with self._lock:
+            self._write_events[stream.cuda_stream] = ev
+            self.stats["rows_put"] += n
+            self.stats["rows_put_stacked"] = self.stats.get("rows_put_stacked", 0) + n
+        return np.arange(seq, seq + n, dtype=np.int64) + self._stamp_base, {k: RingObs(self, k, (n,), span=s0) for k in self.layout}
+
+    def _check_rows_subset(self, obs):
+        n = None
+        for k, t in obs.items():
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()) or tuple(t.shape[1:]) != self.raw_shape[k]:
+                raise hip.HipError(f"observation `{k}`: the ring stages contiguous device rows of shape {self.raw_shape[k]}")
+            n = t.shape[0] if n is None else n
+            if t.shape[0] != n:
+                raise hip.HipError("observation keys disagree on the number of rows")
+            self._ensure(k, t.dtype)
+        return n
 
     def put_or_skip(self, obs: Dict[str, torch.Tensor]):
         """``put``, or -- when the ring is full of leased rows (rollouts running beside a training step that holds a lease)

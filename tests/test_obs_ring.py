@@ -195,6 +195,72 @@ def test_rollout_reads_its_rows_from_the_ring_and_matches_the_plain_rollout():
     assert not other.alive(seen[2]).any()
 
 
+def _stacked_episode_frames(rng, T, B, p_reset=0.15):
+    """Frame stacks as the reference's `FrameStack` wrapper produces them (atari_wrappers.py:211-242): obs[t, b] = the four
+    latest planes of environment b, newest last; at a reset the stack is four copies of the first plane.  Returns
+    (stacks [T, B, 4, 84, 84], newest planes [T, B, 1, 84, 84], reset flags [T, B])."""
+    planes = rng.integers(0, 256, size=(T, B, 1, 84, 84), dtype=np.uint8)
+    reset = rng.random((T, B)) < p_reset
+    reset[0] = True
+    stacks = np.empty((T, B, 4, 84, 84), np.uint8)
+    for t in range(T):
+        for b in range(B):
+            if reset[t, b]:
+                stacks[t, b] = planes[t, b]
+            else:
+                stacks[t, b, :3] = stacks[t - 1, b, 1:]
+                stacks[t, b, 3] = planes[t, b, 0]
+    return stacks, planes, reset
+
+
+@pytest.mark.gpu
+def test_stack_aware_requests_match_whole_stack_requests_bit_for_bit():
+    """Requests that carry the newest plane + the stamp of the previous observation (`ring_prev`; 0 at an episode start): the
+    ring assembles the rows (srl_ring_stack_push).  Same staged bytes and LayerNorm statistics as whole-stack requests, same
+    actions / log-probabilities / values (Philox stream included), stamps that bind the same rows for the trainer; a previous
+    observation the ring has lapped raises LookupError."""
+    rng = np.random.default_rng(11)
+    T, B = 7, 24
+    stacks, planes, reset = _stacked_episode_frames(rng, T, B)
+    a = policy_api.make(config.Policy("actor-critic", args=dict(CNN_POLICY, seed=7)))
+    b = policy_api.make(config.Policy("actor-critic", args=dict(CNN_POLICY, seed=7)))
+    ring_a, ring_b = a.make_obs_ring(T * B), b.make_obs_ring(T * B)
+    a.attach_obs_ring(ring_a)
+    b.attach_obs_ring(ring_b)
+    prev = np.zeros((B, 1), np.int64)
+    refs_a, refs_b = [], []
+    for t in range(T):
+        flags = dict(is_evaluation=np.zeros((B, 1), np.uint8), on_reset=reset[t].astype(np.uint8).reshape(B, 1))
+        ra = a.rollout(policy_api.RolloutRequest(obs=NamedArray(obs=stacks[t]), **flags))
+        prev[reset[t], 0] = 0   # the actor: no predecessor at an episode start
+        rb = b.rollout(policy_api.RolloutRequest(obs=NamedArray(obs=planes[t], ring_prev=prev.copy()), **flags))
+        assert np.array_equal(ra.action.x, rb.action.x)
+        assert np.array_equal(ra.analyzed_result.log_probs, rb.analyzed_result.log_probs)
+        assert np.array_equal(ra.analyzed_result.value, rb.analyzed_result.value)
+        prev = rb.analyzed_result.obs_ref.copy()   # the stamp the actor keeps for this environment's next request
+        refs_a.append(ra.analyzed_result.obs_ref)
+        refs_b.append(rb.analyzed_result.obs_ref)
+    assert torch.equal(ring_a.storage["obs"][:T * B], ring_b.storage["obs"][:T * B])
+    assert torch.equal(ring_a.mean["obs"][:T * B], ring_b.mean["obs"][:T * B]) and torch.equal(ring_a.rstd["obs"][:T * B], ring_b.rstd["obs"][:T * B])
+    assert ring_b.stats["rows_put_stacked"] == T * B and ring_b.stats["rows_put"] == T * B
+    # the trainer's side: the stamps bind the same rows
+    bound_a, lease_a = ring_a.bind(np.stack(refs_a))
+    bound_b, lease_b = ring_b.bind(np.stack(refs_b))
+    assert torch.equal(bound_a["obs"].index, bound_b["obs"].index)
+    ring_a.release(lease_a)
+    ring_b.release(lease_b)
+    # a predecessor the ring no longer holds: the ring says so and the caller sends the whole stack
+    for _ in range(2):   # two more laps' worth of rows
+        ring_b.put({"obs": torch.from_numpy(stacks[:4].reshape(-1, 4, 84, 84)).cuda()})
+    with pytest.raises(LookupError):
+        b.rollout(policy_api.RolloutRequest(obs=NamedArray(obs=planes[0], ring_prev=refs_b[0]), is_evaluation=np.zeros((B, 1), np.uint8),
+                                            on_reset=np.zeros((B, 1), np.uint8)))
+    foreign = refs_a[-1]   # another ring's stamps are not predecessors here either
+    with pytest.raises(LookupError):
+        b.rollout(policy_api.RolloutRequest(obs=NamedArray(obs=planes[0], ring_prev=foreign), is_evaluation=np.zeros((B, 1), np.uint8),
+                                            on_reset=np.zeros((B, 1), np.uint8)))
+
+
 @pytest.mark.gpu
 def test_zero_stamps_are_patched_and_a_full_ring_degrades_instead_of_failing():
     """(a) Rows whose stamp is 0 while the ring's head is still below its capacity -- terminal observations that never went
