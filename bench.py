@@ -75,7 +75,19 @@ def device_sample(seed, T, B, device):
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     dev = {k: torch.from_numpy(v).to(device) for k, v in arrays.items()}
-    dev["obs.obs"] = torch.randint(0, 256, (T + 1, B, 4, 84, 84), dtype=torch.uint8, device=device, generator=gen)
+    # frame stacks as the reference's FrameStack wrapper produces them (atari_wrappers.py:211-242): the four latest planes of
+    # each environment, newest last; four copies of the first plane where the sample says the episode starts
+    planes = torch.randint(0, 256, (T + 1, B, 84, 84), dtype=torch.uint8, device=device, generator=gen)
+    obs = torch.empty((T + 1, B, 4, 84, 84), dtype=torch.uint8, device=device)
+    fresh = dev["on_reset"].reshape(T + 1, B).bool()
+    for t in range(T + 1):
+        rep = planes[t][:, None].expand(-1, 4, -1, -1)
+        if t == 0:
+            obs[t] = rep
+        else:
+            obs[t] = torch.where(fresh[t][:, None, None, None], rep, torch.cat([obs[t - 1][:, 1:], planes[t][:, None]], dim=1))
+    dev["obs.obs"] = obs
+    del planes
     # the observation-ring stamp every step carries (analyzed_result.obs_ref): none yet -- the rollout phase of main() fills it
     dev["analyzed_result.obs_ref"] = torch.full((T + 1, B, 1), -1, dtype=torch.int64, device=device)
     return synthetic.to_sample_batch(dev)
@@ -327,6 +339,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-from-host", action="store_true",
                     help="skip the pinned-host-fed passes: `value` is then the resident-in-HBM figure")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the rollout-beside-update leg (`closed_loop`)")
     ap.add_argument("--no-plain-copy", action="store_true", help="skip the pass without the observation ring (`from_pinned_host`)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank")
     args = ap.parse_args()
@@ -509,7 +522,7 @@ def main():
             roofline_mlp = dict(error=repr(e))
 
     # ---- (2) the sample moves to pinned host memory: two slots of the ingest ring, [Tb, B] namedarray layout, wire dtypes ---
-    pcie = fed = rollout_inf = None
+    pcie = fed = rollout_inf = last_stamps = None
     ms_step = 1e3 * el_res / n_res
     if not args.no_from_host:
         Tb = T + 1
@@ -555,32 +568,72 @@ def main():
                              "timed region, double-buffered so that the copy of update k+1 runs under the compute of update k")
 
         # ---- (2b) the rollout phase of this sample: 129 inference batches of B observations from pinned host memory, each
-        # staged once in the HBM observation ring (space-to-depth + LayerNorm statistics, the pass inference needs anyway)
-        infer = policy_api.make(config.Policy("actor-critic", args=POLICY))
-        infer.load_checkpoint(trainer.policy.get_checkpoint())
-        obs_ring = infer.make_obs_ring(Tb * B + 8 * B, patch_rows=4 * B)
-        infer.attach_obs_ring(obs_ring)
+        # staged once in the HBM observation ring (space-to-depth + LayerNorm statistics, the pass inference needs anyway).
+        # Twice: whole stacks per request (what actor_critic_policy.py:467-469 uploads), and stack-aware requests -- the
+        # newest plane + the stamp of the environment's previous observation, the ring assembles the row (ObsRing.put_stacked):
+        # a quarter of the bytes over the link, the same actions / log-probabilities / values (checked here on every batch).
         frames = ring.host_tensors(0)["obs.obs"]  # [Tb, B, 4, 84, 84] uint8, pinned (torch tensor: asynchronous DMA)
+        fresh = ring.host_blocks(0)["on_reset"].reshape(Tb, B).astype(bool).copy()
+        fresh[0] = True
+        planes = torch.empty((Tb, B, 1, 84, 84), dtype=torch.uint8).pin_memory()
+        planes.copy_(frames[:, :, 3:4])
         zeros = lambda dt: np.zeros((B, 1), dt)
-        stamps = np.empty((Tb, B, 1), np.int64)
-        t_roll, n_roll = 0.0, 0
-        for t in range(Tb):
-            req = policy_api.RolloutRequest(obs=NamedArray(obs=frames[t]), is_evaluation=zeros(np.uint8), on_reset=zeros(np.uint8),
-                                            client_id=zeros(np.int32), request_id=np.arange(B).reshape(B, 1),
-                                            received_time=zeros(np.int64), buffer_index=zeros(np.int32))
-            t0 = time.perf_counter()
-            resp = infer.rollout(req)  # returns numpy: synchronises
-            if t >= 3:
-                t_roll += time.perf_counter() - t0
-                n_roll += 1
-            stamps[t] = resp.analyzed_result.obs_ref
+
+        def request(obs):
+            return policy_api.RolloutRequest(obs=obs, is_evaluation=zeros(np.uint8), on_reset=zeros(np.uint8), client_id=zeros(np.int32),
+                                             request_id=np.arange(B).reshape(B, 1), received_time=zeros(np.int64),
+                                             buffer_index=zeros(np.int32))
+
+        def new_inference_policy(capacity):
+            pol = policy_api.make(config.Policy("actor-critic", args=POLICY))
+            pol.load_checkpoint(trainer.policy.get_checkpoint())
+            pol.attach_obs_ring(pol.make_obs_ring(capacity, patch_rows=4 * B))
+            return pol
+
+        def rollout_phase(pol, stacked, keep=None, check=None, prev=None):
+            """Tb ticks; returns (stamps [Tb, B, 1], seconds per tick after three warm-up ticks, last stamps)."""
+            stamps = np.empty((Tb, B, 1), np.int64)
+            prev = np.zeros((B, 1), np.int64) if prev is None else prev
+            t_roll, n_roll = 0.0, 0
+            for t in range(Tb):
+                if stacked:
+                    prev = np.where(fresh[t][:, None], 0, prev)
+                    req = request(NamedArray(obs=planes[t], ring_prev=prev))
+                else:
+                    req = request(NamedArray(obs=frames[t]))
+                t0 = time.perf_counter()
+                resp = pol.rollout(req)  # returns numpy: synchronises
+                if t >= 3:
+                    t_roll += time.perf_counter() - t0
+                    n_roll += 1
+                out = (resp.action.x, resp.analyzed_result.log_probs, resp.analyzed_result.value)
+                if keep is not None:
+                    keep.append(out)
+                if check is not None and not all(np.array_equal(x, y) for x, y in zip(out, check[t])):
+                    raise RuntimeError(f"stack-aware rollout differs from the whole-stack rollout at tick {t}")
+                stamps[t] = prev = resp.analyzed_result.obs_ref
+            return stamps, t_roll / max(n_roll, 1), prev
+
+        whole, whole_out = new_inference_policy(Tb * B + 8 * B), []
+        _, s_whole, _ = rollout_phase(whole, False, keep=whole_out)
+        del whole
+        torch.cuda.empty_cache()
+        # the ring the updates below read: room for the sample being trained on AND the one the next rollout phase writes
+        infer = new_inference_policy(2 * Tb * B + 8 * B)
+        obs_ring = infer._obs_ring
+        stamps, s_stack, last_stamps = rollout_phase(infer, True, check=whole_out)
+        del whole_out
         for slot in range(2):  # the actors store the stamp with each step; both slots hold this sample
             ring.host_blocks(slot)["analyzed_result.obs_ref"][...] = stamps
-        rollout_inf = dict(value=B * n_roll / t_roll, unit="requests/s", requests_per_call=B, ms_per_call=1e3 * t_roll / n_roll,
-                           calls=n_roll,
-                           note="policy.rollout on pinned host observations (uint8 frames), sampled actions; H2D of the frames "
-                                "and D2H of the results inside; every observation staged in the HBM observation ring on the way")
-        del infer
+        rollout_inf = dict(value=B / s_stack, unit="requests/s", requests_per_call=B, ms_per_call=1e3 * s_stack, calls=Tb - 3,
+                           h2d_bytes_per_request=84 * 84 + 8,
+                           note="policy.rollout on pinned host observations, sampled actions; stack-aware requests: the newest "
+                                "uint8 plane + the ring stamp of the environment's previous observation, the row assembled in the "
+                                "HBM observation ring (srl_ring_stack_push); H2D of the planes and D2H of the results inside",
+                           identical_to_whole_stack=True,
+                           whole_stack=dict(value=B / s_whole, unit="requests/s", ms_per_call=1e3 * s_whole,
+                                            h2d_bytes_per_request=4 * 84 * 84,
+                                            note="the same batches with the whole (4, 84, 84) stack per request"))
         ring.attach_obs_ring(obs_ring)
 
         # ---- (2c) SURVEY 8d's t_update with the ring: the headline ---------------------------------------------------------
@@ -593,6 +646,53 @@ def main():
                    frames_bytes_kept_in_hbm=int(frames.numel()), obs_ring=dict(capacity_rows=obs_ring.capacity,
                                                                                patch_rows=obs_ring.patch_capacity,
                                                                                bytes=obs_ring.nbytes(), **obs_ring.stats))
+
+    # ---- (3) closed loop on this GPU: the rollout phase of sample k+1 (stack-aware requests, its own thread and stream) runs
+    # WHILE the update on sample k runs; a sample is trained on once, with the stamps its own rollout phase returned ---------
+    closed = None
+    if fed is not None and not args.no_closed_loop and not use_dist:
+        import threading
+        b0 = ring.get_device()  # one slot checked out and released (not recycled): the "next sample" slot
+        nxt = b0.metadata["ring_slot"]
+        ring.release(nxt)
+        del b0
+        roll_stream = torch.cuda.Stream(device=device, priority=-1)  # short inference kernels go ahead of the update's queue
+        state = dict(prev=last_stamps, err=None, roll_s=[])
+
+        def produce(slot):
+            try:
+                with torch.cuda.stream(roll_stream):
+                    t0 = time.perf_counter()
+                    st, _, state["prev"] = rollout_phase(infer, True, prev=state["prev"])
+                    state["roll_s"].append(time.perf_counter() - t0)
+                ring.host_blocks(slot)["analyzed_result.obs_ref"][...] = st
+                ring.recycle(slot)  # complete: every column of the slot carries the new stamps
+            except BaseException as e:  # surfaced by the main thread
+                state["err"] = e
+
+        def closed_iteration():
+            nonlocal nxt
+            th = threading.Thread(target=produce, args=(nxt,))
+            th.start()
+            bt = ring.get_device()
+            r = trainer.step(bt)
+            cur = bt.metadata["ring_slot"]
+            ring.release(cur)
+            th.join()
+            if state["err"] is not None:
+                raise state["err"]
+            nxt = cur
+            return r
+
+        n_closed = max(2, min(args.steps, 8))
+        el_c, _ = timed(closed_iteration, 1, n_closed)
+        closed = dict(value=rate(el_c, n_closed), unit="env-steps/s", ms_per_iteration=1e3 * el_c / n_closed, iterations=n_closed,
+                      rollout_phase_ms=round(1e3 * float(np.mean(state["roll_s"][1:])), 1),
+                      rollout_ticks_per_iteration=Tb, requests_per_tick=B, obs_ring=dict(capacity_rows=obs_ring.capacity, **obs_ring.stats),
+                      note="one iteration = the update on sample k (ring-fed, as the headline) with the whole rollout phase of sample "
+                           "k+1 (Tb stack-aware inference batches from pinned host memory, results back to the host) running beside "
+                           "it on the same GPU; every sample is trained on with the stamps of its own rollout phase")
+        ring.recycle(nxt)
 
     if rank == 0:
         head = fed if fed is not None else resident
@@ -626,6 +726,8 @@ def main():
             line["from_pinned_host"] = pcie
         if rollout_inf is not None:
             line["rollout_inference"] = rollout_inf
+        if closed is not None:
+            line["closed_loop"] = closed
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T)
         print(json.dumps(line), flush=True)

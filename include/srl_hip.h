@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 10
+#define SRL_HIP_ABI_VERSION 11
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -146,11 +146,12 @@ int srl_gaussian_bwd(void* stream, const float* mean, int ld_mean, const float* 
                      const float* action, long n, int A, const float* d_logp, const float* d_entropy,
                      float* d_mean, float* d_log_std);
 
-/* action = mean where is_eval (or sampled: Box-Muller on Philox4x32-10 counters (row, dim, offset) keyed by seed),
- * logp = its log-probability. */
+/* action = mean where is_eval (or sampled: Box-Muller on Philox4x32-10 counters (row0 + row, dim, offset) keyed by seed),
+ * logp = its log-probability.  row0: the first row's number in the caller's whole batch -- a batch that goes through in
+ * pieces (copy of piece i+1 under the compute of piece i) samples exactly what it would in one call. */
 int srl_gaussian_sample(void* stream, const float* mean, int ld_mean, const float* log_std, int ld_log_std,
                         const uint8_t* is_eval, long n, int A, uint64_t seed, uint64_t offset, float* action,
-                        float* logp);
+                        float* logp, int64_t row0);
 
 /* ------------------------------------------------------------------------------------------------
  * Recurrent backbone: GRU cell between the GEMMs, one time step per launch.
@@ -244,11 +245,11 @@ int srl_categorical_bwd(void* stream, const float* logits, int ld_logits, const 
                         const uint8_t* avail, long n, int n_heads, const int32_t* host_head_dims,
                         const float* d_logp, const float* d_entropy, float* d_logits, int ld_dlogits);
 /* Rollout: action = argmax if is_eval[row] else inverse-CDF sample with Philox4x32-10
- * (key = seed, counter = {row, head, offset}); logp [n] = sum over heads of log p(action).
- * action_out int64 [n, n_heads] (dtype of actor_critic_policy.py:515). */
+ * (key = seed, counter = {row0 + row, head, offset}); logp [n] = sum over heads of log p(action).
+ * action_out int64 [n, n_heads] (dtype of actor_critic_policy.py:515).  row0: as for srl_gaussian_sample. */
 int srl_categorical_sample(void* stream, const float* logits, int ld_logits, const uint8_t* avail,
                            const uint8_t* is_eval, long n, int n_heads, const int32_t* host_head_dims,
-                           uint64_t seed, uint64_t offset, int64_t* action_out, float* logp);
+                           uint64_t seed, uint64_t offset, int64_t* action_out, float* logp, int64_t row0);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense contraction on the FP32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA chains).

@@ -280,9 +280,10 @@ class ActorCriticPolicy(policy_api.Policy):
             raise ValueError("stack-aware requests (`ring_prev`) need an observation ring attached to the policy")
         if prev is not None:
             prev = (prev.cpu().numpy() if isinstance(prev, torch.Tensor) else np.asarray(prev)).astype(np.int64).reshape(n)
-        if (prev is None and not self.spec.num_rnn_layers and n >= 2 * self.ROLLOUT_PIECE
+        # (stack-aware requests carry a quarter of the bytes: they go through in pieces only from four times the rows)
+        if (not self.spec.num_rnn_layers and n >= (8 if prev is not None else 2) * self.ROLLOUT_PIECE
                 and not any(isinstance(v, torch.Tensor) and v.is_cuda for v in host.values())):
-            action, logp, value, refs = self._rollout_streamed(host, n, requests.is_evaluation)
+            action, logp, value, refs = self._rollout_streamed(host, n, requests.is_evaluation, prev)
             state = None
         else:
             obs = {k: to_device_leaf(v, self.device, "obs") for k, v in host.items()}
@@ -294,16 +295,31 @@ class ActorCriticPolicy(policy_api.Policy):
                 state = {k: np.asarray(ps[k]) for k, _ in self._state_keys()}
             action, logp, value, refs = self._rollout_rows(obs, n, requests.is_evaluation, state, prev=prev)
             state = self._packed_last_state()
-        analyzed = PPORolloutAnalyzedResult(log_probs=logp.cpu().numpy(), value=value.cpu().numpy(),
-                                            obs_ref=None if refs is None else refs.reshape(n, 1))
-        return policy_api.RolloutResult(action=DiscreteAction(action.cpu().numpy()), analyzed_result=analyzed,
-                                        policy_state=state)
+        h_action, h_logp, h_value = self._results_to_host(action, logp, value)
+        analyzed = PPORolloutAnalyzedResult(log_probs=h_logp, value=h_value, obs_ref=None if refs is None else refs.reshape(n, 1))
+        return policy_api.RolloutResult(action=DiscreteAction(h_action), analyzed_result=analyzed, policy_state=state)
 
-    def _rollout_streamed(self, host, n, is_evaluation):
+    def _results_to_host(self, *tensors):
+        """Device results -> numpy: asynchronous copies into pinned blocks kept per policy, ONE stream synchronisation for all of
+        them (three `.cpu()` calls are three synchronisations through pageable staging)."""
+        pins = self.__dict__.setdefault("_result_pins", {})
+        out = []
+        for i, t in enumerate(tensors):
+            key = (i, t.dtype)
+            pin = pins.get(key)
+            if pin is None or pin.numel() < t.numel():
+                pin = pins[key] = torch.empty(max(t.numel(), 1024), dtype=t.dtype).pin_memory()
+            view = pin[:t.numel()].view(t.shape)
+            view.copy_(t, non_blocking=True)
+            out.append(view)
+        torch.cuda.current_stream().synchronize()
+        return [v.numpy().copy() for v in out]
+
+    def _rollout_streamed(self, host, n, is_evaluation, prev=None):
         """A big batch of host observations (the policy worker's 10 240-request batches are 289 MB of frames): rows
         go through in pieces, the H2D copy of piece i+1 on a side stream under the network pass of piece i, so the
-        call costs about max(copy, compute) instead of their sum.  Each piece is one Philox call (sampling stays
-        reproducible for a given batch; evaluation-mode outputs do not depend on the split at all)."""
+        call costs about max(copy, compute) instead of their sum.  The pieces share the call's Philox offset and number their rows
+        within the whole batch (`row0`): the sampled actions do not depend on the split."""
         if getattr(self, "_copy_stream", None) is None:
             self._copy_stream = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream()
@@ -353,7 +369,8 @@ class ActorCriticPolicy(policy_api.Policy):
         for i, (r0, r1) in enumerate(bounds):
             dev, ev = staged[i & 1]
             main.wait_event(ev)
-            a_i, l_i, v_i, r_i = self._rollout_rows(dev, r1 - r0, is_eval[r0:r1], None)
+            a_i, l_i, v_i, r_i = self._rollout_rows(dev, r1 - r0, is_eval[r0:r1], None, prev=None if prev is None else prev[r0:r1],
+                                                    row0=r0, count_call=i + 1 == len(bounds))
             if refs is not None:
                 refs.append(r_i)
             action[r0:r1].copy_(a_i)
@@ -365,7 +382,7 @@ class ActorCriticPolicy(policy_api.Policy):
                 stage(i + 1)  # issued after piece i's launches: a pageable copy blocks the host, not the GPU
         return action, logp, value, (None if refs is None else np.concatenate(refs))
 
-    def _rollout_rows(self, obs, n, is_evaluation, state, prev=None):
+    def _rollout_rows(self, obs, n, is_evaluation, state, prev=None, row0=0, count_call=True):
         """One inference pass over ``n`` independent rows: device ``(action, log_prob [n,1], value [n,vd])`` and the rows'
         observation-ring references (int64 numpy [n], or None without a ring); the new recurrent states are left in
         ``net.last_state``.  ``state``: ``{key: [n, layers, W]}`` host or device, or None."""
@@ -397,11 +414,12 @@ class ActorCriticPolicy(policy_api.Policy):
         if self.spec.std_type:  # Normal(mean, std): the mean when evaluating, a sample otherwise (:499-506)
             action = torch.empty((n, sum(heads)), dtype=torch.float32, device=self.device)
             ptr, ld = self._log_std()
-            hip.gaussian_sample(logits, ptr, ld, is_eval, self._seed, self._rollout_calls, action, logp)
+            hip.gaussian_sample(logits, ptr, ld, is_eval, self._seed, self._rollout_calls, action, logp, row0=row0)
         else:
             action = torch.empty((n, len(heads)), dtype=torch.int64, device=self.device)
-            hip.categorical_sample(logits, avail, is_eval, heads, self._seed, self._rollout_calls, action, logp)
-        self._rollout_calls += 1
+            hip.categorical_sample(logits, avail, is_eval, heads, self._seed, self._rollout_calls, action, logp, row0=row0)
+        if count_call:  # one Philox offset per rollout() call: the pieces of a streamed batch share it and differ by row0
+            self._rollout_calls += 1
         return action, logp, value, refs
 
     def _rnn_ctx_with_burn_in(self, obs, avail_unused, policy_state, on_reset, burn, T, B) -> Optional[RnnCtx]:

@@ -59,9 +59,10 @@ __device__ __forceinline__ uint4 philox(uint4 c, uint2 k) {
 __global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* mean, int ld_mean, const float* log_std,
                                                               int ld_ls, const uint8_t* is_eval, long n, int A,
                                                               uint64_t seed, uint64_t offset, float* action,
-                                                              float* logp) {
+                                                              float* logp, long row0) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const uint64_t ctr_row = (uint64_t)(row0 + i);  // the row's number in the caller's whole batch
   const bool greedy = is_eval && is_eval[i];
   float lp = 0.f;
   for (int j = 0; j < A; ++j) {
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* mean,
     const float sd = expf(log_std[i * ld_ls + j]);
     float x = mu;  // evaluation: the mean (actor_critic_policy.py:504)
     if (!greedy) {
-      const uint4 rnd = philox(make_uint4((uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)j, (uint32_t)offset),
+      const uint4 rnd = philox(make_uint4((uint32_t)ctr_row, (uint32_t)(ctr_row >> 32), (uint32_t)j, (uint32_t)offset),
                                make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
       const float u1 = ((float)(rnd.x >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
       const float u2 = (float)(rnd.y >> 8) * (1.0f / 16777216.0f);
@@ -111,12 +112,12 @@ extern "C" int srl_gaussian_bwd(void* stream, const float* mean, int ld_mean, co
 
 extern "C" int srl_gaussian_sample(void* stream, const float* mean, int ld_mean, const float* log_std, int ld_log_std,
                                    const uint8_t* is_eval, long n, int A, uint64_t seed, uint64_t offset, float* action,
-                                   float* logp) {
+                                   float* logp, int64_t row0) {
   SRL_CHECK_ARG(n >= 0 && A >= 1 && ld_mean >= A && (ld_log_std == 0 || ld_log_std >= A), "bad extents");
   if (n == 0) return 0;
   SRL_CHECK_ARG(mean && log_std && action && logp, "null tensor");
   hipLaunchKernelGGL(gaussian_sample_kernel, dim3((unsigned)srl_ceil_div(n, 256L)), dim3(256), 0, (hipStream_t)stream,
-                     mean, ld_mean, log_std, ld_log_std, is_eval, n, A, seed, offset, action, logp);
+                     mean, ld_mean, log_std, ld_log_std, is_eval, n, A, seed, offset, action, logp, (long)row0);
   SRL_LAUNCH_CHECK();
   return 0;
 }

@@ -218,9 +218,10 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
 __global__ __launch_bounds__(256) void categorical_sample_kernel(const float* logits, int ld, const uint8_t* avail,
                                                                  const uint8_t* is_eval, long n, Heads h, int atot,
                                                                  uint64_t seed, uint64_t offset, int64_t* action_out,
-                                                                 float* logp) {
+                                                                 float* logp, long row0) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const uint64_t ctr_row = (uint64_t)(row0 + i);  // the row's number in the caller's whole batch: pieces of it sample alike
   const float* row = logits + i * ld;
   const uint8_t* av = avail ? avail + i * atot : nullptr;
   const bool greedy = is_eval && is_eval[i];
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) void categorical_sample_kernel(const float* lo
     for (int j = 0; j < d; ++j) se += expf(masked_logit(row, av, s + j) - mx);
     int pick = amax;
     if (!greedy) {
-      const uint4 rnd = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)k,
+      const uint4 rnd = philox4x32_10(make_uint4((uint32_t)ctr_row, (uint32_t)(ctr_row >> 32), (uint32_t)k,
                                                  (uint32_t)offset),
                                       make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
       const float u = (float)(rnd.x >> 8) * (1.0f / 16777216.0f) * se;  // uniform in [0, se)
@@ -328,7 +329,7 @@ extern "C" int srl_categorical_bwd(void* stream, const float* logits, int ld_log
 
 extern "C" int srl_categorical_sample(void* stream, const float* logits, int ld_logits, const uint8_t* avail,
                                       const uint8_t* is_eval, long n, int n_heads, const int32_t* host_head_dims,
-                                      uint64_t seed, uint64_t offset, int64_t* action_out, float* logp) {
+                                      uint64_t seed, uint64_t offset, int64_t* action_out, float* logp, int64_t row0) {
   Heads h;
   int atot;
   SRL_CHECK_ARG(make_heads(n_heads, host_head_dims, h, atot) == 0, "bad head dims");
@@ -336,7 +337,7 @@ extern "C" int srl_categorical_sample(void* stream, const float* logits, int ld_
   if (n == 0) return 0;
   hipLaunchKernelGGL(categorical_sample_kernel, dim3((unsigned)srl_ceil_div(n, 256)), dim3(256), 0,
                      (hipStream_t)stream, logits, ld_logits, avail, is_eval, n, h, atot, seed, offset, action_out,
-                     logp);
+                     logp, (long)row0);
   SRL_LAUNCH_CHECK();
   return 0;
 }

@@ -25,7 +25,7 @@ _lib = None
 # (bench.py does, before its imports) -- INTEGRATION.md lists it with the other switches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -123,7 +123,7 @@ _SIGNATURES = {
     "srl_gaussian_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),
     "srl_gaussian_sample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_uint64,
-                                    c_uint64, c_void_p, c_void_p]),
+                                    c_uint64, c_void_p, c_void_p, c_int64]),
     "srl_gru_mask_state": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "srl_gru_cell_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "srl_gru_cell_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
@@ -139,7 +139,7 @@ _SIGNATURES = {
     "srl_categorical_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, POINTER(c_int32),
                                      c_void_p, c_void_p, c_void_p, c_int]),
     "srl_categorical_sample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int,
-                                        POINTER(c_int32), c_uint64, c_uint64, c_void_p, c_void_p]),
+                                        POINTER(c_int32), c_uint64, c_uint64, c_void_p, c_void_p, c_int64]),
     "srl_gemm": (c_int, [c_void_p, POINTER(GemmDesc)]),
     "srl_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
                                    c_void_p, c_void_p]),
@@ -430,12 +430,12 @@ def gaussian_bwd(mean, log_std_ptr, ld_ls, action, d_logp, d_ent, d_mean, d_log_
                                   _ptr(d_mean, f, "d_mean"), _ptr(d_log_std, f, "d_log_std")), "srl_gaussian_bwd")
 
 
-def gaussian_sample(mean, log_std_ptr, ld_ls, is_eval, seed, offset, action, logp):
+def gaussian_sample(mean, log_std_ptr, ld_ls, is_eval, seed, offset, action, logp, row0=0):
     n, A = mean.shape
     _check(lib().srl_gaussian_sample(_stream(), _ptr(mean, torch.float32, "mean"), mean.stride(0), log_std_ptr, int(ld_ls),
                                      _ptr(is_eval, torch.uint8, "is_eval"), n, A, int(seed) & (2**64 - 1),
                                      int(offset) & (2**64 - 1), _ptr(action, torch.float32, "action"),
-                                     _ptr(logp, torch.float32, "logp")), "srl_gaussian_sample")
+                                     _ptr(logp, torch.float32, "logp"), int(row0)), "srl_gaussian_sample")
 
 
 def gru_mask_state(h_ptr, reset_ptr, N, H, out_ptr):
@@ -535,13 +535,13 @@ def categorical_bwd(logits, action, avail, head_dims, d_logp, d_entropy, d_logit
                                   _ptr(d_logits, torch.float32, "d_logits"), d_logits.shape[1]), "srl_categorical_bwd")
 
 
-def categorical_sample(logits, avail, is_eval, head_dims, seed, offset, action_out, logp):
+def categorical_sample(logits, avail, is_eval, head_dims, seed, offset, action_out, logp, row0=0):
     n = logits.shape[0]
     _check(
         lib().srl_categorical_sample(_stream(), _ptr(logits, torch.float32, "logits"), logits.shape[1],
                                      _ptr(avail, torch.uint8, "avail"), _ptr(is_eval, torch.uint8, "is_eval"), n,
                                      len(head_dims), _i32_array(head_dims), int(seed), int(offset),
-                                     _ptr(action_out, torch.int64, "action_out"), _ptr(logp, torch.float32, "logp")),
+                                     _ptr(action_out, torch.int64, "action_out"), _ptr(logp, torch.float32, "logp"), int(row0)),
         "srl_categorical_sample")
 
 
