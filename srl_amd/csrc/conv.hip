@@ -8,6 +8,7 @@
 #include "gemm_core.h"
 #include "gemm_bf16x3.h"
 #include "obs_bf16.h"
+#include "obs_h2.h"
 
 using namespace srlgemm;
 
@@ -641,6 +642,48 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
     float* b2 = S + (long)P * d->Cout;
     const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, 1};
     float* bound = b2 + (long)P * d->Cout;  // one of the workspace's 64 spare floats: upper bound of |y| from the folded weights
+    // h2 output on the Atari geometry: blocks of 2 x 4 positions per workgroup, two f16 weight pieces in registers (obs_h2.h)
+    static const bool blocks_on = [] { const char* e = getenv("SRL_OBS_H2BLOCK"); return !(e && e[0] == '0'); }();
+    if (y_h2 && blocks_on && ent_order == 2 && d->Cin == 64 && d->KH == 2 && d->KW == 2 && d->stride == 1 && d->Cout == 32 &&
+        OH % srlobs::kBlkH == 0 && OW % srlobs::kBlkW == 0 && OH % 2 == 0 && OW % 2 == 0 && d->n * (long)P * 128 < 0x7fffffffL &&
+        4 * (d->n + 32) + (long)P * d->Cout <= (long)P * d->Cout * Kp / 2) {  // (the records fit behind the two planes)
+      float* winv = workspace + (long)P * d->Cout * Kp;  // behind the two f16 planes, inside the room of the three bf16 ones
+      if (!reuse_folded) {
+        (void)hipMemsetAsync(bound, 0, sizeof(float), st);
+        hipLaunchKernelGGL(srlobs::obs_fold_h2_kernel<ObsIndex>, dim3((unsigned)(P * d->Cout)), dim3(256), 0, st, w, bias, gamma, beta,
+                           P, ix, wq, winv, S, b2, bound, sqrtf((float)((long)d->H * d->W * d->Cin)));
+      }
+      srlobs::FwdH2Args h{};
+      const long n_pad = srl_ceil_div(d->n, (long)srlobs::kTile) * srlobs::kTile;
+      uint4* meta = reinterpret_cast<uint4*>(winv + (long)P * d->Cout);  // per-sample records of this launch, behind winv
+      hipLaunchKernelGGL(srlobs::obs_meta_kernel, dim3((unsigned)srl_ceil_div(n_pad, 256L)), dim3(256), 0, st, row_index, mean, rstd,
+                         (long)d->n, n_pad, meta);
+      h.frames = static_cast<const uint8_t*>(obs); h.img_stride = (long)d->H * d->W * d->Cin; h.meta = meta;
+      h.n = d->n; h.wq = reinterpret_cast<const uint4*>(wq); h.winv = winv; h.S = S; h.b2 = b2;
+      h.y_h2 = y_h2; h.bound = bound; h.y_scale = y_scale; h.y_mask = y_mask; h.y_absmax = y_absmax;
+      h.GW = d->W; h.OW = OW; h.OH = OH; h.P = P; h.act = d->act;
+      const long units = (long)(P / (srlobs::kBlkH * srlobs::kBlkW)) * srl_ceil_div(d->n, (long)srlobs::kTile);
+      const unsigned grid = (unsigned)(units < 512 ? units : 512);  // two workgroups per CU: two wavefronts per SIMD
+      constexpr int lds = srlobs::kStages * srlobs::kStageBytes + srlobs::kMeta * srlobs::kTile * 16 + 4 * 96 * 4;  // stages, records, tables
+      auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, h);
+      };
+      srl_count_dispatch(SRL_DISP_OBS_FWD_BF16, 256, 2, (int)grid);
+      const char* dbg = getenv("SRL_OBS_DBG");  // timing experiments (wrong results): see obs_h2.h
+      switch (dbg ? atoi(dbg) : 0) {
+        case 1: go(srlobs::obs_fwd_h2_kernel<1, 1>); break;
+        case 2: go(srlobs::obs_fwd_h2_kernel<1, 2>); break;
+        case 4: go(srlobs::obs_fwd_h2_kernel<1, 4>); break;
+        case 7: go(srlobs::obs_fwd_h2_kernel<1, 7>); break;
+        default:
+          if (d->act == 1) go(srlobs::obs_fwd_h2_kernel<1>);
+          else if (d->act == 2) go(srlobs::obs_fwd_h2_kernel<2>);
+          else go(srlobs::obs_fwd_h2_kernel<0>);
+      }
+      SRL_LAUNCH_CHECK();
+      return 0;
+    }
     if (!reuse_folded) {
       (void)hipMemsetAsync(bound, 0, sizeof(float), st);
       hipLaunchKernelGGL(srlobs::obs_fold_split_kernel<ObsIndex>, dim3((unsigned)(P * d->Cout)), dim3(256), 0, st, w, bias, gamma,

@@ -356,7 +356,7 @@ def dispatch_tiles(reset: bool = False) -> dict:
         if name == "h2":
             label = f"h2:{ {1: 'conv', 2: 'wgrad', 3: 'gemm'}.get(p0, p0)}:{p1}:s{p2}"
         elif name.startswith("obs_"):
-            label = f"{name}:k{p0}:{'h2' if p1 else 'f32'}:split{p2}"
+            label = f"{name}:k{p0}:{('f32', 'h2', 'h2blk')[min(p1, 2)]}:split{p2}"  # h2blk: obs_h2.h, p2 = its persistent workgroups
         else:
             label = f"{name}:{p0}x{p1}:k{p2}:f{fl}"
         out[label] = out.get(label, 0) + int(counts[i])

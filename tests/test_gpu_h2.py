@@ -362,8 +362,8 @@ def test_benchmark_size_chunk_on_sampled_images():
 
 # ------------------------------------------------------------------------------------------------ first layer
 def test_first_layer_h2_output_equals_its_float32_output():
-    """srl_conv2d_obs_fwd_h2 = srl_conv2d_obs_fwd with the result written as h2p rows in parity-class order: the same
-    accumulators, so after unpacking the two agree to the pieces' 2^-22; sign words and the measured range are identical."""
+    """srl_conv2d_obs_fwd_h2 = srl_conv2d_obs_fwd with the result written as h2p rows in parity-class order; after unpacking
+    the two agree to the pieces' precision, the sign words except where the value is at rounding distance of zero."""
     hip = _hip()
     n = 300
     g = torch.Generator(device=DEV).manual_seed(22)
@@ -387,8 +387,12 @@ def test_first_layer_h2_output_equals_its_float32_output():
     yy, xx = np.meshgrid(np.arange(20), np.arange(20), indexing="ij")
     ent = torch.from_numpy((((yy & 1) * 2 + (xx & 1)) * 100 + (yy >> 1) * 10 + (xx >> 1)).reshape(-1)).to(DEV)
     back = back.view(n, 400, 32)[:, ent]
-    assert float((back - y).abs().max()) <= 2.0**-21 * float(y.abs().max())
-    assert torch.equal(hm, ym) and float(ham.item()) == float(yam.item())
+    # (obs_h2.h: the folded weights as two f16 pieces, 2^-22 of a channel's largest weight each, where obs_bf16.h's three
+    # bf16 pieces are exact -- both are checked against float64 in test_first_layer_at_benchmark_size)
+    assert float((back - y).abs().max()) <= 2.0**-19 * float(y.abs().max())
+    flips = (hm != ym)
+    assert int(flips.sum()) <= 4 and float(y.view(n * 400, 32)[flips.view(-1)].abs().max() if flips.any() else 0.0) <= 1e-5
+    assert abs(float(ham.item()) - float(yam.item())) <= 1e-5 * float(yam.item())
     assert float(y.abs().max()) * float(hs.item()) < 2**15   # the a-priori bound holds
 
 
@@ -415,7 +419,7 @@ def test_first_layer_at_benchmark_size():
     hip.dispatch_tiles(reset=True)
     hip.conv2d_obs_fwd_h2(desc, s2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), b.data_ptr(),
                           yh.data_ptr(), hs.data_ptr(), ws.data_ptr(), rows, ham.data_ptr(), hm.data_ptr(), reuse_folded=False, ent_order=2)
-    assert hip.dispatch_tiles(reset=True) == {"obs_fwd_bf16:k256:h2:split8": 1}
+    assert hip.dispatch_tiles(reset=True) == {"obs_fwd_bf16:k256:h2blk:split512": 1}   # obs_h2.h: 512 persistent workgroups
     y = torch.empty(n * 400, 32, device=DEV)
     hip.h2_unpack_rows(yh.data_ptr(), n * 400, 32, hs.data_ptr(), y.data_ptr(), 32)
     yy, xx = np.meshgrid(np.arange(20), np.arange(20), indexing="ij")
