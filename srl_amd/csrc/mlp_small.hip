@@ -297,9 +297,22 @@ int fill(Args& a, const srl_mlp_layer* layers, int n) {
 
 }  // namespace
 
+#include "mlp_mfma.h"
+
+// rows from which the matrix-core chain (mlp_mfma.h) takes over from the FMA chain; SRL_MLP_MFMA=0 switches it off (A/B)
+static long mfma_min_rows() {
+  static const long v = [] { const char* e = getenv("SRL_MLP_MFMA"); return e ? (e[0] == '0' ? (1L << 62) : atol(e)) : 512L; }();
+  return v;
+}
+
 extern "C" int64_t srl_mlp_bwd_max_rows(const srl_mlp_layer* layers, int n) {
   Args a{};
   if (fill(a, layers, n) < 0) return 0;
+  {
+    MArgs m{};
+    m.a = a;
+    if (mfma_min_rows() < (1L << 40) && mm_plan(m)) return 1L << 30;  // the matrix-core chain: any row count
+  }
   // Measured against the layer-by-layer kernels on 2 x 64 nets (scripts/mlp_rows_sweep.py): 0.30 against 0.64 ms per update at
   // 256 rows, 0.54 against 0.89 at 16 384, 1.30 against 1.03 at 65 536 -- 256 threads per CU are too few once the row count
   // fills the chip (scripts/mlp_probe.py: a 64 x 64 Linear's backward 105 us, a LayerNorm's 84 us at 65 536 rows).  Without
@@ -321,6 +334,20 @@ extern "C" int srl_mlp_fwd(void* stream, const srl_mlp_layer* layers, int n, con
   SRL_CHECK_ARG(x && y && (n == 1 || tape) && tape_ld >= t && rows >= 0, "null tensor / short tape rows");
   if (rows == 0) return 0;
   a.x = x; a.ldx = ldx; a.rows = rows; a.tape = tape; a.tld = tape_ld; a.y = y; a.ldy = ldy;
+  MArgs m{};
+  m.a = a;
+  if (rows >= mfma_min_rows() && mm_plan(m)) {
+    const long tiles4 = srl_ceil_div(rows, 128L);
+    const int lds = 4 * m.fwd_floats;
+    static int attr = 0;
+    if (lds > attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr = lds;
+    }
+    hipLaunchKernelGGL(mlp_fwd_mfma_kernel, dim3((unsigned)(tiles4 < 512 ? tiles4 : 512)), dim3(256), lds, (hipStream_t)stream, m);
+    SRL_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(mlp_fwd_kernel, dim3((unsigned)srl_ceil_div(rows, (long)kRB)), dim3(256), 0, (hipStream_t)stream, a);
   SRL_LAUNCH_CHECK();
   return 0;
@@ -335,6 +362,21 @@ extern "C" int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, con
   for (int i = 0; i < n; ++i) SRL_CHECK_ARG(a.L[i].gw && (a.L[i].gb || (a.L[i].kind == 1 && !a.L[i].b)), "null gradient");
   if (rows == 0) return 0;
   a.x = x; a.ldx = ldx; a.rows = rows; a.tape = const_cast<float*>(tape); a.tld = tape_ld; a.dy = dy; a.lddy = lddy;
+  MArgs m{};
+  m.a = a;
+  if (rows >= mfma_min_rows() && mm_plan(m)) {
+    const long tiles4 = srl_ceil_div(rows, 128L);
+    const long tiles = 4L * (2 * 32 * kTld + m.npg * 64);
+    const int lds = 4 * (int)(m.bwd_floats + (tiles > kMaxP ? tiles : kMaxP));
+    static int attr = 0;
+    if (lds > attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr = lds;
+    }
+    hipLaunchKernelGGL(mlp_bwd_mfma_kernel, dim3((unsigned)(tiles4 < 256 ? tiles4 : 256)), dim3(256), lds, (hipStream_t)stream, m);
+    SRL_LAUNCH_CHECK();
+    return 0;
+  }
   long groups = srl_ceil_div(rows, (long)kRB);
   if (a.lds_acc && groups > kBwdGroups) groups = kBwdGroups;
   hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, a);

@@ -1198,10 +1198,14 @@ def test_gemm_small_products(M, N, K, akm, bkm, split, extra):
 
 
 @pytest.mark.parametrize("rows,dims,acts", [(256, (4, 64, 64, 2), (1, 1, 0)), (37, (10, 128, 33, 1), (2, 2, 0)),
-                                            (1000, (48, 64, 9), (1, 0))])
+                                            (1000, (48, 64, 9), (1, 0)), (5003, (4, 64, 64, 2), (2, 1, 0)),
+                                            (65536, (4, 64, 64, 1), (2, 2, 0)), (700, (33, 40, 6), (2, 0))])
 def test_mlp_chain_fused(rows, dims, acts):
     """srl_mlp_fwd / srl_mlp_bwd (csrc/mlp_small.hip): LayerNorm -> Linear (+ activation) chains as one launch per direction,
-    against float64 autograd: outputs, every parameter gradient, ragged row counts, widths that are not multiples of 16."""
+    against float64 autograd: outputs, every parameter gradient, ragged row counts, widths that are not multiples of 16.
+    From 512 rows on, chains no wider than 64 run on the float32 matrix cores (csrc/mlp_mfma.h): the cases with 700+ rows.
+    (65 536 rows: smooth activations -- among that many rows one has a ReLU pre-activation within float32 rounding of zero, and
+    the float64 reference then takes the other branch: both float32 chains agree with each other there to 5e-6.)"""
     rng = np.random.default_rng(rows)
     t = torch
     x = t.from_numpy(rng.standard_normal((rows, dims[0])).astype(np.float32))
@@ -1241,6 +1245,7 @@ def test_mlp_chain_fused(rows, dims, acts):
     hip.mlp_bwd(arr, dx.data_ptr(), dims[0], rows, tape.data_ptr(), tld, ddy.data_ptr(), dims[-1])
     for got, ref, name in zip(dev_g, p64, [f"{k}{i}" for i in range(len(dims) - 1) for k in ("gamma", "beta", "w", "b")]):
         assert rel_close(got.cpu().numpy() - 0.5, ref.grad.numpy(), 2e-5, scale=float(ref.grad.abs().max()) + 1e-6), name
+    assert hip.mlp_bwd_max_rows(arr) >= (1 << 30 if max(dims) <= 64 else 8192)  # the matrix-core chain takes any row count
 
 
 @needs_f16x2
