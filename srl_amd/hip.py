@@ -290,11 +290,13 @@ def set_profile(p: Optional[KernelProfile]):
 def piece_products(kind: str = "x3") -> float:
     """Matrix-core products issued per algorithmic multiply-add by the kernel family that takes a call: 6 for float32
     operands as three bf16 pieces each (``x3``), 3 for two f16 pieces each (``2h``) and for the byte-operand first layer
-    (``obs``), 1 for the float32 MFMA kernels (SRL_MFMA=f32 / SRL_OBS_BF16=0)."""
+    (``obs``; ``obs2``: 2, the block kernel with two f16 weight pieces), 1 for the float32 MFMA kernels (SRL_MFMA=f32 / SRL_OBS_BF16=0)."""
     if kind == "f32":  # plain float32 FMA kernels (csrc/mlp_small.hip)
         return 1.0
     if kind == "obs":
         return 1.0 if os.environ.get("SRL_OBS_BF16", "")[:1] == "0" else 3.0
+    if kind == "obs2":  # csrc/obs_h2.h: byte operand x two f16 weight pieces
+        return 2.0 if os.environ.get("SRL_OBS_H2BLOCK", "")[:1] != "0" else 3.0
     if os.environ.get("SRL_MFMA", "")[:1] == "f":
         return 1.0
     return 3.0 if kind == "2h" else 6.0
@@ -1033,7 +1035,7 @@ def h2_gemm(x, w, sx, sw, M, NC, K, out, bias=None, act=0, out_h2=False, out_sca
 def conv2d_obs_fwd_h2(desc, obs_ptr, mean, rstd, gamma, beta, w, bias, y_h2, y_scale, ws_ptr, row_index, y_absmax, y_mask,
                       reuse_folded=False, ent_order=2):
     ri = _ptr(row_index, torch.int32, "row_index") if isinstance(row_index, torch.Tensor) else row_index
-    with _scope("conv_obs_fwd", _conv_flops(desc), "obs"):
+    with _scope("conv_obs_fwd", _conv_flops(desc), "obs2"):
         _check(lib().srl_conv2d_obs_fwd_h2(_stream(), ctypes.byref(desc), _vp(obs_ptr), _vp(mean), _vp(rstd), _vp(gamma), _vp(beta), _vp(w),
                                            _vp(bias), _vp(y_h2), _vp(y_scale), _vp(ws_ptr), _vp(ri), _vp(y_absmax), _vp(y_mask),
                                            int(bool(reuse_folded)), int(ent_order)), "srl_conv2d_obs_fwd_h2")
