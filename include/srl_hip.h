@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 11
+#define SRL_HIP_ABI_VERSION 12
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -185,6 +185,26 @@ int srl_lstm_cell_fwd(void* stream, float* pre, const float* cin, const uint8_t*
 int srl_lstm_cell_bwd(void* stream, const float* dy, const float* carry_h, const float* carry_c,
                       const uint8_t* reset_next, float* gates, const float* cin, const float* cnew, long N,
                       int H, float* dc_in);
+
+/* The whole time loop of a chunk in one launch (csrc/rnn_seq.hip; H in {32, 64}: srl_rnn_seq_supported(kind, H), kind 0
+ * GRU, 1 LSTM).  Same buffers, layouts and saved values as C calls of the per-step entry points above with the srl_gemm of
+ * W_hh between them (autoreset_rnn.py:42-66: the rows are independent, only the steps are serial; float32 matrix cores, a
+ * wavefront per 32 rows with the state in registers): every block is
+ * [C][N][.], step c at offset c * N rows; reset [C][N] uint8 or NULL, reset[c] masks the state entering step c (c >= 1;
+ * hin[0] / cin[0] are the caller's, already masked).
+ * srl_lstm_seq_fwd: pre = W_ih x + b_ih on entry -> activated gates; y, cnew, hin[1..], cin[1..] written.
+ * srl_lstm_seq_bwd: gates -> d pre in place (d h_in / d c_in are carried inside the kernel); dy [C][N][ld_dy] or NULL.
+ * srl_gru_seq_fwd: gi = W_ih x + b_ih on entry -> gates (r, z, n); gh written (its n part kept); y, hin[1..] written.
+ * srl_gru_seq_bwd: gates -> d gi, gh -> d gh in place. */
+int srl_rnn_seq_supported(int kind, int H);
+int srl_lstm_seq_fwd(void* stream, float* pre, const float* w_hh, const float* b_hh, float* hin, float* cin,
+                     const uint8_t* reset, int64_t N, int H, int C, float* y, float* cnew);
+int srl_lstm_seq_bwd(void* stream, const float* dy, int64_t ld_dy, float* gates, const float* w_hh, const float* cin,
+                     const float* cnew, const uint8_t* reset, int64_t N, int H, int C);
+int srl_gru_seq_fwd(void* stream, float* gi, float* gh, const float* w_hh, const float* b_hh, float* hin,
+                    const uint8_t* reset, int64_t N, int H, int C, float* y);
+int srl_gru_seq_bwd(void* stream, const float* dy, int64_t ld_dy, float* gates, float* gh, const float* w_hh,
+                    const float* hin, const uint8_t* reset, int64_t N, int H, int C);
 
 /* Rows of D floats between time-major [T*B] and chunk-major order: dst[(c, k*B + b)] = src[((k*C + c), b)]
  * (modules/utils.py:164-182 `to_chunk`: torch.cat(torch.split(x, C, dim=0), dim=1)); inverse != 0 undoes it. */

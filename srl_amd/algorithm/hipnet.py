@@ -475,7 +475,10 @@ class HipNet:
             hip.gru_mask_state(y.ptr, rptr(0), N, H, hin.ptr)
             hip.copy2d(h0[l].data_ptr() + 4 * H, SW, y.ptr, H, N, H)
             hip.gru_mask_state(y.ptr, rptr(0), N, H, cin.ptr)
-            for c in range(C):
+            seq = hip.rnn_seq_supported("lstm", H)  # the chunk's time loop inside one launch (csrc/rnn_seq.hip)
+            if seq:
+                hip.lstm_seq_fwd(pre.ptr, w_hh, b_hh, hin.ptr, cin.ptr, rptr(0), N, H, C, y.ptr, cnew.ptr)
+            for c in range(0 if seq else C):
                 o4, o1 = 4 * c * N * 4 * H, 4 * c * N * H
                 hip.gemm(N, 4 * H, H, hin.ptr + o1, H, 0, w_hh, H, 0, pre.ptr + o4, 4 * H, bias=b_hh, accumulate=True)
                 nxt = c + 1 < C
@@ -495,7 +498,10 @@ class HipNet:
             y = self._buf(f"{tag}{G.prefix}.y{l}", n, H)
             hip.gemm(n, 3 * H, H, inp.ptr, inp.ld, 0, w_ih, H, 0, gi.ptr, 3 * H, bias=b_ih)  # every step at once
             hip.gru_mask_state(h0[l].data_ptr(), rptr(0), N, H, hin.ptr)
-            for c in range(C):
+            seq = hip.rnn_seq_supported("gru", H)
+            if seq:
+                hip.gru_seq_fwd(gi.ptr, gh.ptr, w_hh, b_hh, hin.ptr, rptr(0), N, H, C, y.ptr)
+            for c in range(0 if seq else C):
                 o3, o1 = 4 * c * N * 3 * H, 4 * c * N * H
                 hip.gemm(N, 3 * H, H, hin.ptr + o1, H, 0, w_hh, H, 0, gh.ptr + o3, 3 * H, bias=b_hh)
                 nxt = c + 1 < C
@@ -531,7 +537,10 @@ class HipNet:
             dh = [self._buf(f"{tag}{G.prefix}.dh{i}", N, H) for i in range(2)]
             dc = [self._buf(f"{tag}{G.prefix}.dc{i}", N, H) for i in range(2)]
             ch = cc = None
-            for c in range(C - 1, -1, -1):
+            seq = hip.rnn_seq_supported("lstm", H)
+            if seq:
+                hip.lstm_seq_bwd(dout.ptr, dout.ld, pre.ptr, w_hh, cin.ptr, cnew.ptr, rptr(0), N, H, C)
+            for c in range(-1 if seq else C - 1, -1, -1):
                 o4, o1 = 4 * c * N * 4 * H, 4 * c * N * H
                 hip.lstm_cell_bwd(dout.ptr + 4 * c * N * dout.ld, ch, cc, rptr(c + 1) if c + 1 < C else None, pre.ptr + o4,
                                   cin.ptr + o1, cnew.ptr + o1, N, H, dc[c & 1].ptr)
@@ -554,7 +563,10 @@ class HipNet:
             w_ih, w_hh = self._p(f"{G.prefix}.weight_ih_l{l}"), self._p(f"{G.prefix}.weight_hh_l{l}")
             dh = [self._buf(f"{tag}{G.prefix}.dh{i}", N, H) for i in range(2)]
             carry = None
-            for c in range(C - 1, -1, -1):
+            seq = hip.rnn_seq_supported("gru", H)
+            if seq:
+                hip.gru_seq_bwd(dout.ptr, dout.ld, gi.ptr, gh.ptr, w_hh, hin.ptr, rptr(0), N, H, C)
+            for c in range(-1 if seq else C - 1, -1, -1):
                 o3, o1 = 4 * c * N * 3 * H, 4 * c * N * H
                 cur = dh[c & 1]
                 hip.gru_cell_bwd(dout.ptr + 4 * c * N * dout.ld, carry, rptr(c + 1) if c + 1 < C else None, gi.ptr + o3,

@@ -25,7 +25,7 @@ _lib = None
 # (bench.py does, before its imports) -- INTEGRATION.md lists it with the other switches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -125,6 +125,11 @@ _SIGNATURES = {
     "srl_gaussian_sample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, c_uint64,
                                     c_uint64, c_void_p, c_void_p, c_int64]),
     "srl_gru_mask_state": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "srl_rnn_seq_supported": (c_int, [c_int, c_int]),
+    "srl_lstm_seq_fwd": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "srl_lstm_seq_bwd": (c_int, [c_void_p, c_void_p, c_int64] + [c_void_p] * 5 + [c_int64, c_int, c_int]),
+    "srl_gru_seq_fwd": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]),
+    "srl_gru_seq_bwd": (c_int, [c_void_p, c_void_p, c_int64] + [c_void_p] * 5 + [c_int64, c_int, c_int]),
     "srl_gru_cell_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "srl_gru_cell_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
                                  c_void_p]),
@@ -438,6 +443,31 @@ def gaussian_sample(mean, log_std_ptr, ld_ls, is_eval, seed, offset, action, log
                                      _ptr(is_eval, torch.uint8, "is_eval"), n, A, int(seed) & (2**64 - 1),
                                      int(offset) & (2**64 - 1), _ptr(action, torch.float32, "action"),
                                      _ptr(logp, torch.float32, "logp"), int(row0)), "srl_gaussian_sample")
+
+
+def rnn_seq_supported(kind: str, H: int) -> bool:
+    """Whether the time loop of a chunk runs inside one launch for this cell and width (``srl_rnn_seq_supported``; SRL_RNN_SEQ=0
+    switches it off for an A/B)."""
+    return os.environ.get("SRL_RNN_SEQ", "1")[:1] != "0" and bool(lib().srl_rnn_seq_supported(1 if kind == "lstm" else 0, int(H)))
+
+
+def lstm_seq_fwd(pre_ptr, w_hh, b_hh, hin_ptr, cin_ptr, reset_ptr, N, H, C, y_ptr, cnew_ptr):
+    _check(lib().srl_lstm_seq_fwd(_stream(), pre_ptr, w_hh, b_hh, hin_ptr, cin_ptr, reset_ptr, int(N), int(H), int(C), y_ptr, cnew_ptr),
+           "srl_lstm_seq_fwd")
+
+
+def lstm_seq_bwd(dy_ptr, ld_dy, gates_ptr, w_hh, cin_ptr, cnew_ptr, reset_ptr, N, H, C):
+    _check(lib().srl_lstm_seq_bwd(_stream(), dy_ptr, int(ld_dy), gates_ptr, w_hh, cin_ptr, cnew_ptr, reset_ptr, int(N), int(H), int(C)),
+           "srl_lstm_seq_bwd")
+
+
+def gru_seq_fwd(gi_ptr, gh_ptr, w_hh, b_hh, hin_ptr, reset_ptr, N, H, C, y_ptr):
+    _check(lib().srl_gru_seq_fwd(_stream(), gi_ptr, gh_ptr, w_hh, b_hh, hin_ptr, reset_ptr, int(N), int(H), int(C), y_ptr), "srl_gru_seq_fwd")
+
+
+def gru_seq_bwd(dy_ptr, ld_dy, gates_ptr, gh_ptr, w_hh, hin_ptr, reset_ptr, N, H, C):
+    _check(lib().srl_gru_seq_bwd(_stream(), dy_ptr, int(ld_dy), gates_ptr, gh_ptr, w_hh, hin_ptr, reset_ptr, int(N), int(H), int(C)),
+           "srl_gru_seq_bwd")
 
 
 def gru_mask_state(h_ptr, reset_ptr, N, H, out_ptr):
