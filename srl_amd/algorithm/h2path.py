@@ -173,10 +173,17 @@ class H2Cnn:
         src, is_u8, mean, rstd, row_index = saved["first"]
         desc1 = hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, hip.ACT_RELU)
         wsz = hip.conv2d_obs_bwd_workspace(desc1)
+        # Inside the trainer's chunk loop the position sums (Q, R, C) of the chunks add up in this executor's workspace and the four
+        # gradients are formed ONCE, behind the executor's last chunk (srl_conv2d_obs_bwd's `phase`); anybody else: a call of its own
+        phase = 3
+        if net._in_update[0] and net.last_chunk is not None and n >= 4096 and os.environ.get("SRL_OBS_BWD_DEFER", "1")[:1] != "0":
+            first = net._obs_bwd_open is not True
+            phase = (1 if first else 0) | (2 if net.last_chunk else 0)
+            net._obs_bwd_open = not net.last_chunk
         hip.conv2d_obs_bwd(desc1, src.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), net._p(f"{self.ln.prefix}.weight"),
                            net._p(f"{self.ln.prefix}.bias"), net._p(f"{self.c1.prefix}.weight"), dz1.ptr, g(f"{self.c1.prefix}.weight"),
                            g(f"{self.c1.prefix}.bias"), g(f"{self.ln.prefix}.weight"), g(f"{self.ln.prefix}.bias"),
-                           ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=True, row_index=row_index)
+                           ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=True, row_index=row_index, phase=phase)
 
     def _fc_wgrad(self, n, dy, a3):
         net, g = self.net, self.net._g

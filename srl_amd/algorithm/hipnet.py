@@ -129,6 +129,10 @@ class HipNet:
         self._mlp_cache = {}
         self._pver = [0]    # parameter version, shared with the twins (a list: one object)
         self._in_update = [False]
+        # set by the trainer's chunk loop before every chunk (True: this executor's last chunk of the update; None outside the loop):
+        # what may accumulate over the chunks of an update in an executor's own workspace is closed behind the last one
+        self.last_chunk = None
+        self._obs_bwd_open = False
         self._derived_on = os.environ.get("SRL_DERIVED_CACHE", "1") != "0"  # 0: recompute for every chunk (A/B)
         self._presplit_on = self._derived_on and os.environ.get("SRL_PRESPLIT", "1") != "0"  # weights split once per update
         self._derived = {}  # per executor: what its workspace holds that was derived from which parameter version
@@ -255,6 +259,8 @@ class HipNet:
         """The trainer brackets the chunk loop of one update with this: inside it the parameters do not change, so what an
         executor derived from them for the first chunk serves the following ones."""
         self._in_update[0] = bool(on)
+        if not on:
+            self.last_chunk = None
 
     def refresh_weight_ranges(self):
         """Recompute every stale weight range now, on the current stream (before two row-chunk pipelines that share the

@@ -718,11 +718,14 @@ class MultiAgentPPO(PytorchTrainer):
             if reducer is not None:
                 reducer.begin([x.grad for x in nets])
             net.chunks_of_one_update(True)
+            for x in nets:
+                x._obs_bwd_open = False  # (an accumulation a failed update left open is not continued)
             for ci in range(nchunks):
                 r0, r1 = ci * chunk_rows, min(n_valid, (ci + 1) * chunk_rows)
                 n = r1 - r0
                 e = ci % len(nets)
                 cnet = nets[e]
+                cnet.last_chunk = ci + len(nets) >= nchunks  # this executor's last chunk of the update
                 if reducer is not None and ci + len(nets) >= nchunks:
                     # a pipeline's gradients become final in the backward pass of ITS last chunk; a bucket goes out when
                     # every pipeline has released it (api/policy.py:219-238: what DDP's bucketing does)
@@ -752,6 +755,8 @@ class MultiAgentPPO(PytorchTrainer):
                     for pst in streams[1:]:
                         pst.wait_stream(streams[0])
             net.chunks_of_one_update(False)
+            for x in nets:
+                x.last_chunk = None
             if two and reducer is None:
                 for twin, pst in zip(self._twin, self._pipe_stream):
                     streams[0].wait_stream(pst)

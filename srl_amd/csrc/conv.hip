@@ -815,7 +815,7 @@ extern "C" int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d) {
 static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                               const float* mean, const float* rstd, const float* gamma, const float* beta,
                               const float* w, const float* dz, float* dw, float* db, float* dgamma, float* dbeta,
-                              float* workspace, const int32_t* row_index) {
+                              float* workspace, const int32_t* row_index, int phase = 3) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1), "unsupported geometry");
   SRL_CHECK_ARG(row_index == nullptr || srl_conv2d_obs_row_index_supported(d, is_u8, channels_last),
                 "row_index is served by the byte kernels only (srl_conv2d_obs_row_index_supported)");
@@ -833,22 +833,28 @@ static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* 
   float* C = R + (long)P * d->Cout;  // bf16 path: mean correction of Q (zero otherwise)
   float* slabs = C + (((long)P * d->Cout + 3) & ~3L);
   // R[pos, o] = sum_n dz[(n, pos), o]: column sums of the A tiles the batched product below stages anyway
-  if (hipMemsetAsync(R, 0, sizeof(float) * 2 * P * d->Cout, st) != hipSuccess) return -EIO;
+  // phase (the byte kernels with split slabs only; 3 otherwise): bit 0 = this call opens an accumulation (Q, R, C start from
+  // zero), bit 1 = it closes one (dW, db, dgamma, dbeta are formed from the sums): dW etc. are linear in (Q, R, C), so the chunks
+  // of one update can share ONE finalisation (two launches, 59 us per 16 384-frame chunk) instead of one each
+  const bool first = (phase & 1) != 0, last = (phase & 2) != 0;
+  if (first && hipMemsetAsync(R, 0, sizeof(float) * 2 * P * d->Cout, st) != hipSuccess) return -EIO;
   const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, channels_last ? 1 : 0};
   if (obs_bf16_ok(d, is_u8, channels_last, obs) && (P * d->Cout) % 4 == 0) {
     srlobs::BwdArgs a{};
     a.g = obs_geom(d, obs, mean, rstd, OW, row_index);
     a.dz = dz; a.R = R; a.C = C; a.P = P;
     a.nsplit = obs_bf16_split(d->n, P, 3);
+    SRL_CHECK_ARG(phase == 3 || a.nsplit > 1, "phase: accumulation over calls needs the split slabs (more samples per call)");
     a.Q = a.nsplit > 1 ? slabs : Q;
     a.slab = (long)P * d->Cout * Kp;
     srl_count_dispatch(SRL_DISP_OBS_BWD_BF16, 256, 0, a.nsplit);
     hipLaunchKernelGGL(srlobs::obs_bwd_bf16_kernel<256>, dim3(srlobs::xcd_position_grid(P, a.nsplit)), dim3(256), 0, st, a);
     SRL_LAUNCH_CHECK();
     if (a.nsplit > 1) {
-      reduce_slabs(st, slabs, a.nsplit, (long)P, (long)d->Cout, Kp, Q, Kp, (long)d->Cout * Kp, 0);
+      reduce_slabs(st, slabs, a.nsplit, (long)P, (long)d->Cout, Kp, Q, Kp, (long)d->Cout * Kp, first ? 0 : 1);
       SRL_LAUNCH_CHECK();
     }
+    if (!last) return 0;
     hipLaunchKernelGGL(obs_dw_kernel, dim3((unsigned)srl_ceil_div(d->Cout * Kp, kDwEL)), dim3(256), 0, st, Q, R, C, gamma, beta,
                        P, d->Cout, ix, dw, db);
     hipLaunchKernelGGL(obs_affine_kernel, dim3((unsigned)srl_ceil_div(d->Cin * d->H * d->W, 256)), dim3(256), 0, st, Q, R, C, w,
@@ -856,6 +862,7 @@ static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* 
     SRL_LAUNCH_CHECK();
     return 0;
   }
+  SRL_CHECK_ARG(phase == 3, "phase: only the byte kernels accumulate over calls");
   int rc;
   // Q[pos][o][k] = sum_n dz[(n,pos), o] * xhat[n, patch(pos)[k]]   — one batched GEMM over the P output positions
   GemmArgs g{};
@@ -892,8 +899,9 @@ static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* 
 extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
                                   const float* w, const float* dz, float* dw, float* db, float* dgamma, float* dbeta,
-                                  float* workspace, const int32_t* row_index) {
+                                  float* workspace, const int32_t* row_index, int phase) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1), "unsupported geometry");
+  SRL_CHECK_ARG(phase >= 0 && phase <= 3, "phase: bit 0 opens, bit 1 closes an accumulation over calls");
   const long run = images_per_launch(d, is_u8 ? 1 : 4);
   const long in_b = (long)d->H * d->W * d->Cin * (is_u8 ? 1 : 4);
   const long out_e = (long)conv_out(d->H, d->KH, d->stride) * conv_out(d->W, d->KW, d->stride) * d->Cout;
@@ -901,9 +909,13 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
     srl_conv_desc s = *d;
     s.n = d->n - i0 < run ? d->n - i0 : run;
     const long adv = row_index ? 0 : i0;
+    // several runs per call: each closes its own accumulation, unless the caller accumulates over calls -- then the runs of a
+    // call are links of that chain
+    const bool only = d->n <= run || phase == 3;
     const int rc = conv2d_obs_bwd_run(stream, &s, static_cast<const uint8_t*>(obs) + adv * in_b, is_u8, channels_last, mean + adv,
                                       rstd + adv, gamma, beta, w, dz + i0 * out_e, dw, db, dgamma, dbeta, workspace,
-                                      row_index ? row_index + i0 : nullptr);
+                                      row_index ? row_index + i0 : nullptr,
+                                      only ? phase : ((i0 == 0 ? phase & 1 : 0) | (i0 + run >= d->n ? phase & 2 : 0)));
     if (rc != 0) return rc;
   }
   return 0;
