@@ -26,7 +26,8 @@ from srl_amd.algorithm import netspec as ns
 ENABLED = os.environ.get("SRL_H2", "1") != "0"
 
 # device floats of one executor (indices into the `h2.slots` workspace tensor)
-(S_A1, M_A1, S_A2, M_A2, S_A3, M_A3, S_DY, M_DY, S_DZ3, M_DZ3, S_DZ2, M_DZ2, M_DZ1,
+# (the measured ranges of a pass sit side by side: one fill zeroes the forward's three, one the backward's four)
+(M_A1, M_A2, M_A3, M_DY, M_DZ3, M_DZ2, M_DZ1, S_A1, S_A2, S_A3, S_DY, S_DZ3, S_DZ2,
  S_W2, R_W2, B_W2, S_W3, R_W3, B_W3, S_WF, R_WF, S_W3G, R_W3G, S_W2G, R_W2G, S_WFT, R_WFT, N_SLOTS) = range(28)
 
 
@@ -102,9 +103,7 @@ class H2Cnn:
         net, ws = self.net, self.net.ws
         self._prepare_weights()
         slots = self._slots()
-        slots[M_A1:M_A1 + 1].zero_()
-        slots[M_A2:M_A2 + 1].zero_()
-        slots[M_A3:M_A3 + 1].zero_()
+        slots[M_A1:M_A3 + 1].zero_()
         a1 = self._bytes(f"{tag}h2.a1", n * 400 * 32 * 4)
         a2 = self._bytes(f"{tag}h2.a2", n * 81 * 64 * 4)
         a3 = self._bytes(f"{tag}h2.a3", n * 49 * 64 * 4)
@@ -140,8 +139,7 @@ class H2Cnn:
         n, tag = saved["n"], saved["tag"]
         g = net._g
         slots = self._slots()
-        for i in (M_DY, M_DZ3, M_DZ2, M_DZ1):
-            slots[i:i + 1].zero_()
+        slots[M_DY:M_DZ1 + 1].zero_()
         assert dy.ld == dy.cols == self.H and dy.rows == n
         # dy -> h2p rows (its range from one pass: the producer is a float32 kernel)
         hip.absmax(dy.ptr, n * self.H, self._slot(M_DY))

@@ -231,6 +231,96 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, lon
   }
 }
 
+// D a multiple of 256, at most 1024 (the 512-wide feature LayerNorm of the Atari nets), 16-byte aligned rows: a lane owns float4
+// columns 4 lane + 256 v, a row's x and dy are read ONCE into registers and serve both the row sums and dx (the kernel above
+// reads them twice in 4-byte pieces: 50 us on 16 384 x 512, this one ~half).  Same sums, same flush.
+template <int NV>
+__global__ __launch_bounds__(512) void layernorm_bwd_vec_kernel(const float* dy, long lddy, const float* x, long ldx,
+                                                                const float* gamma, const float* mean, const float* rstd,
+                                                                long rows, float* dx, long lddx, int dact, float* dgamma,
+                                                                float* dbeta, long rows_per_block, float* dx_absmax) {
+  constexpr int D = 256 * NV;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float amx = 0.f;
+  float4 g4[NV], pg[NV], pb[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    g4[v] = *reinterpret_cast<const float4*>(gamma + 4 * lane + 256 * v);
+    pg[v] = pb[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (long row = r0 + wid; row < r1; row += 8) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 xv[NV], dv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      xv[v] = *reinterpret_cast<const float4*>(x + row * ldx + 4 * lane + 256 * v);
+      dv[v] = *reinterpret_cast<const float4*>(dy + row * lddy + 4 * lane + 256 * v);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const float xa[4] = {xv[v].x, xv[v].y, xv[v].z, xv[v].w}, da[4] = {dv[v].x, dv[v].y, dv[v].z, dv[v].w};
+      const float ga[4] = {g4[v].x, g4[v].y, g4[v].z, g4[v].w};
+      float* pga = reinterpret_cast<float*>(&pg[v]);
+      float* pba = reinterpret_cast<float*>(&pb[v]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = (xa[q] - mu) * rs, g = da[q] * ga[q];
+        s1 += g;
+        s2 += g * xh;
+        pga[q] += da[q] * xh;
+        pba[q] += da[q];
+      }
+    }
+    if (dx) {
+      const float m1 = wave_allsum(s1) / (float)D, m2 = wave_allsum(s2) / (float)D;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const float xa[4] = {xv[v].x, xv[v].y, xv[v].z, xv[v].w}, da[4] = {dv[v].x, dv[v].y, dv[v].z, dv[v].w};
+        const float ga[4] = {g4[v].x, g4[v].y, g4[v].z, g4[v].w};
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float xh = (xa[q] - mu) * rs;
+          o[q] = rs * (da[q] * ga[q] - m1 - xh * m2);
+          if (dact) o[q] *= act_grad_from_output(xa[q], dact);
+          amx = fmaxf(amx, fabsf(o[q]));
+        }
+        *reinterpret_cast<float4*>(dx + row * lddx + 4 * lane + 256 * v) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+  if (dx_absmax) {
+    amx = wave_allmax(amx);
+    if (lane == 0 && amx > 0.f) {
+      unsigned int* d = reinterpret_cast<unsigned int*>(dx_absmax);
+      if (__float_as_uint(amx) > __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d, __float_as_uint(amx));
+    }
+  }
+  // the 8 wavefronts' column sums fold in LDS, then one atomic per column and workgroup (at most 256 workgroups: the 2 D float
+  // atomics of each were the kernel's floor at 1024 workgroups -- 1 M atomics, ~36 us)
+  __shared__ float sg[2][D];
+  for (int e = threadIdx.x; e < 2 * D; e += 512) sg[0][e] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const float* pga = reinterpret_cast<const float*>(&pg[v]);
+    const float* pba = reinterpret_cast<const float*>(&pb[v]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      atomicAdd(&sg[0][4 * lane + 256 * v + q], pga[q]);
+      atomicAdd(&sg[1][4 * lane + 256 * v + q], pba[q]);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < D; e += 512) {
+    atomicAdd(dgamma + e, sg[0][e]);
+    atomicAdd(dbeta + e, sg[1][e]);
+  }
+}
+
 // Wide rows (D > 1024: the halving Linear towers behind the default convolution stack, modules/cnn.py:86-91): one
 // workgroup per row for dx, and a separate column pass for dgamma / dbeta in which a thread owns one column and walks a
 // slab of rows (coalesced across the workgroup), one atomic per column per slab.
@@ -543,6 +633,26 @@ static int layernorm_bwd_impl(void* stream, const float* dy, int64_t lddy, const
     else if (D <= 64) SRL_LN_BWD(16);
     else SRL_LN_BWD(32);
 #undef SRL_LN_BWD
+    SRL_LAUNCH_CHECK();
+    return 0;
+  }
+  const bool vec_ok = D % 256 == 0 && D <= 1024 && ldx % 4 == 0 && lddy % 4 == 0 && (!dx || lddx % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(gamma) |
+                        reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+  if (vec_ok) {
+    long rpv = srl_ceil_div(rows, 256L);  // at most 256 workgroups of 8 wavefronts
+    if (rpv < 8) rpv = 8;
+#define SRL_LN_VEC(NV)                                                                                                         \
+  hipLaunchKernelGGL(layernorm_bwd_vec_kernel<NV>, dim3((unsigned)srl_ceil_div(rows, rpv)), dim3(512), 0, (hipStream_t)stream, dy, \
+                     lddy, x, ldx, gamma, mean, rstd, rows, dx, lddx, dact, dgamma, dbeta, rpv, dx_absmax)
+    switch (D / 256) {
+      case 1: SRL_LN_VEC(1); break;
+      case 2: SRL_LN_VEC(2); break;
+      case 3: SRL_LN_VEC(3); break;
+      default: SRL_LN_VEC(4); break;
+    }
+#undef SRL_LN_VEC
+    *tracked = 1;
     SRL_LAUNCH_CHECK();
     return 0;
   }

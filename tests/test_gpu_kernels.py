@@ -501,7 +501,7 @@ def test_gemm_strided_views():
 # ------------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("rows,D", [(1, 4), (1000, 4), (777, 64), (300, 512), (65, 100), (5000, 16), (3333, 32), (4099, 128),
                                     (257, 20), (1031, 96), (90000, 64), (513, 66), (37, 1024), (37, 1408), (3000, 2816),
-                                    (5, 11264)])
+                                    (5, 11264), (16384, 512), (1000, 256), (777, 768)])
 def test_layernorm_fwd_bwd(rows, D):
     rng = np.random.default_rng(rows + D)
     x = (rng.standard_normal((rows, D)) * 2 + 0.5).astype(np.float32)
