@@ -272,13 +272,15 @@ class MultiAgentPPO(PytorchTrainer):
         self._graphs = {}
         self._comm = None
         self._reducer = None
-        # Two row-chunk pipelines side by side on two streams (pipelines=1 / SRL_PIPELINES=1: one): the chunks of a batch are
+        # Row-chunk pipelines side by side on streams of their own (default 4; pipelines=1 / SRL_PIPELINES=1: one; round 4, same
+        # box: 1 -> 112.5, 2 -> 111.0-112.4, 3 -> 110.4, 4 -> 108.7-109.2, 6 -> 112.5 ms, the runtime has 8 hardware queues):
+        # the chunks of a batch are
         # independent up to the gradient sum, and their kernels -- each bound by something else -- fill each other's
         # stalls: 147.4 -> 141.3 ms per update.  (The first version was not bit-reproducible: beside a concurrent queue the
         # narrow head product returned different sums for a few hundred rows; traced to the packed-float32 code the
         # compiler made of that kernel's accumulators, skinny.h -- with scalar accumulators every buffer of a step is
         # bit-identical to the one-pipeline run)
-        self.pipelines = int(g("pipelines", os.environ.get("SRL_PIPELINES", "2")))
+        self.pipelines = int(g("pipelines", os.environ.get("SRL_PIPELINES", "4")))
         self._twin = None
         self._pipe_stream = None
         self._gae_ws = {}

@@ -126,7 +126,7 @@ def test_bench_script_with_two_ranks():
     assert line["roofline"]["bound"] == "mfma" and "cpu_baseline" not in line  # the CPU baseline is N = 1 only
     # the NatureCNN's buckets leave from inside the backward passes of the two pipelines' last chunks, layer by layer
     gb = line["config"]["grad_buckets"]
-    assert line["config"]["pipelines"] == 2 and gb["buckets"] >= 2 and gb["launched_in_finish"] == 0, gb
+    assert line["config"]["pipelines"] >= 2 and gb["buckets"] >= 2 and gb["launched_in_finish"] == 0, gb
     assert gb["launched_in_backward"] == gb["buckets"] * gb["epochs"], gb
     assert 0.8 * gb["launched_in_backward"] <= gb["slices_folded"] <= gb["launched_in_backward"], gb  # (one-chunk legs: no fold)
 
