@@ -1304,3 +1304,111 @@ def test_presplit_weights_give_the_same_bits():
         hip.conv2d_nhwc_dgrad(d, cdz.data_ptr(), wt2.data_ptr(), None, 1, db_.data_ptr(), dz_absmax=cdzr.data_ptr(),
                               w_absmax=cwr.data_ptr(), x_mask=xm.data_ptr(), presplit=True)
         assert torch.equal(da, db_)
+
+
+# ------------------------------------------------------------------------------------------------ recurrent time loop in one launch
+@pytest.mark.parametrize("kind,H,N,C", [("lstm", 64, 100, 7), ("lstm", 32, 33, 3), ("gru", 64, 257, 5), ("gru", 32, 64, 1)])
+def test_rnn_time_loop_in_one_launch_matches_the_per_step_path(kind, H, N, C):
+    """srl_lstm_seq_fwd/bwd, srl_gru_seq_fwd/bwd (csrc/rnn_seq.hip) against C calls of the per-step entry points with the W_hh
+    product between them (csrc/gru.hip, what `HipNet` ran before and still runs for other widths): the same buffers in, the same
+    saved values and gradients out (1e-5: the products sum in a different order), ragged row counts, auto-resets inside the chunk."""
+    G = 4 if kind == "lstm" else 3
+    g = torch.Generator(device=DEV).manual_seed(H + N + C)
+    f = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    w_hh, b_hh = f(G * H, H) / H ** 0.5, 0.1 * f(G * H)
+    pre0 = f(C, N, G * H)                       # W_ih x + b_ih of every step
+    h0, c0 = 0.5 * f(N, H), 0.5 * f(N, H)
+    reset = (torch.rand(C, N, device=DEV, generator=g) < 0.2).to(torch.uint8)
+    dy = f(C, N, H)
+    rp = lambda c: reset.data_ptr() + c * N
+
+    def buffers():
+        pre, gh = pre0.clone(), torch.zeros(C, N, 3 * H, device=DEV)
+        hin, cin = torch.zeros(C, N, H, device=DEV), torch.zeros(C, N, H, device=DEV)
+        hip.gru_mask_state(h0.data_ptr(), rp(0), N, H, hin.data_ptr())
+        hip.gru_mask_state(c0.data_ptr(), rp(0), N, H, cin.data_ptr())
+        return pre, gh, hin, cin, torch.zeros(C, N, H, device=DEV), torch.zeros(C, N, H, device=DEV)
+
+    def step_path():
+        pre, gh, hin, cin, y, cnew = buffers()
+        for c in range(C):
+            nxt = c + 1 < C
+            if kind == "lstm":
+                hip.gemm(N, 4 * H, H, hin[c].data_ptr(), H, 0, w_hh.data_ptr(), H, 0, pre[c].data_ptr(), 4 * H, bias=b_hh.data_ptr(), accumulate=True)
+                hip.lstm_cell_fwd(pre[c].data_ptr(), cin[c].data_ptr(), rp(c + 1) if nxt else None, N, H, y[c].data_ptr(), cnew[c].data_ptr(),
+                                  hin[c + 1].data_ptr() if nxt else None, cin[c + 1].data_ptr() if nxt else None)
+            else:
+                hip.gemm(N, 3 * H, H, hin[c].data_ptr(), H, 0, w_hh.data_ptr(), H, 0, gh[c].data_ptr(), 3 * H, bias=b_hh.data_ptr())
+                hip.gru_cell_fwd(pre[c].data_ptr(), gh[c].data_ptr(), hin[c].data_ptr(), rp(c + 1) if nxt else None, N, H, y[c].data_ptr(),
+                                 hin[c + 1].data_ptr() if nxt else None)
+        fwd = [t.clone() for t in (pre, gh, hin, cin, y, cnew)]
+        dh = [torch.zeros(N, H, device=DEV) for _ in range(2)]
+        dc = [torch.zeros(N, H, device=DEV) for _ in range(2)]
+        ch = cc = None
+        for c in range(C - 1, -1, -1):
+            nxt = c + 1 < C
+            if kind == "lstm":
+                hip.lstm_cell_bwd(dy[c].data_ptr(), ch, cc, rp(c + 1) if nxt else None, pre[c].data_ptr(), cin[c].data_ptr(), cnew[c].data_ptr(),
+                                  N, H, dc[c & 1].data_ptr())
+                hip.gemm(N, H, 4 * H, pre[c].data_ptr(), 4 * H, 0, w_hh.data_ptr(), H, 1, dh[c & 1].data_ptr(), H)
+                ch, cc = dh[c & 1].data_ptr(), dc[c & 1].data_ptr()
+            else:
+                hip.gru_cell_bwd(dy[c].data_ptr(), ch, rp(c + 1) if nxt else None, pre[c].data_ptr(), gh[c].data_ptr(), hin[c].data_ptr(), N, H,
+                                 dh[c & 1].data_ptr())
+                hip.gemm(N, H, 3 * H, gh[c].data_ptr(), 3 * H, 0, w_hh.data_ptr(), H, 1, dh[c & 1].data_ptr(), H, accumulate=True)
+                ch = dh[c & 1].data_ptr()
+        return fwd, [pre.clone(), gh.clone()]
+
+    def seq_path():
+        pre, gh, hin, cin, y, cnew = buffers()
+        if kind == "lstm":
+            hip.lstm_seq_fwd(pre.data_ptr(), w_hh.data_ptr(), b_hh.data_ptr(), hin.data_ptr(), cin.data_ptr(), rp(0), N, H, C, y.data_ptr(), cnew.data_ptr())
+        else:
+            hip.gru_seq_fwd(pre.data_ptr(), gh.data_ptr(), w_hh.data_ptr(), b_hh.data_ptr(), hin.data_ptr(), rp(0), N, H, C, y.data_ptr())
+        fwd = [t.clone() for t in (pre, gh, hin, cin, y, cnew)]
+        if kind == "lstm":
+            hip.lstm_seq_bwd(dy.data_ptr(), H, pre.data_ptr(), w_hh.data_ptr(), cin.data_ptr(), cnew.data_ptr(), rp(0), N, H, C)
+        else:
+            hip.gru_seq_bwd(dy.data_ptr(), H, pre.data_ptr(), gh.data_ptr(), w_hh.data_ptr(), hin.data_ptr(), rp(0), N, H, C)
+        return fwd, [pre.clone(), gh.clone()]
+
+    assert hip.rnn_seq_supported(kind, H) and not hip.rnn_seq_supported(kind, 48)
+    (f1, b1), (f2, b2) = step_path(), seq_path()
+    names = ("gates", "gh", "hin", "cin", "y", "cnew")
+    for name, u, v in zip(names, f1, f2):
+        if kind == "gru" and name in ("cin", "cnew"):
+            continue
+        assert float((u - v).abs().max()) <= 1e-5 * max(1.0, float(u.abs().max())), name
+    for name, u, v in zip(("d pre / d gi", "d gh"), b1, b2):
+        assert float((u - v).abs().max()) <= 2e-5 * max(1.0, float(u.abs().max())), name
+
+
+def test_first_layer_position_sums_accumulate_over_calls():
+    """srl_conv2d_obs_bwd's `phase`: two calls that share one accumulation (open, then close) add the same four gradients as two
+    calls of their own -- the trainer's chunks share one finalisation that way."""
+    n = 2048
+    g = torch.Generator(device=DEV).manual_seed(5)
+    frames = torch.randint(0, 256, (2 * n, 4, 84, 84), dtype=torch.uint8, device=DEV, generator=g)
+    s2d, mean, rstd = torch.empty(2 * n, 21, 21, 64, dtype=torch.uint8, device=DEV), torch.empty(2 * n, device=DEV), torch.empty(2 * n, device=DEV)
+    hip.obs_space_to_depth(frames.data_ptr(), True, 2 * n, 4, 84, 84, 4, s2d.data_ptr(), mean.data_ptr(), rstd.data_ptr())
+    f = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    gamma, beta, w = 1 + 0.2 * f(21 * 21 * 64), 0.2 * f(21 * 21 * 64), 0.06 * f(32, 256)
+    dz = 1e-3 * f(2 * n, 400, 32)
+    desc = hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, 1)
+    ws = torch.empty(hip.conv2d_obs_bwd_workspace(desc), device=DEV)
+    idx = [torch.arange(0, n, device=DEV, dtype=torch.int32), torch.arange(n, 2 * n, device=DEV, dtype=torch.int32)]
+
+    def run(phases):
+        outs = [torch.zeros(32 * 256, device=DEV), torch.zeros(32, device=DEV), torch.zeros(21 * 21 * 64, device=DEV), torch.zeros(21 * 21 * 64, device=DEV)]
+        for half, ph in enumerate(phases):
+            hip.conv2d_obs_bwd(desc, s2d.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(),
+                               dz[half * n:(half + 1) * n].data_ptr(), *[o.data_ptr() for o in outs], ws.data_ptr(), channels_last=True,
+                               row_index=idx[half], phase=ph)
+        return outs
+    own, shared = run((3, 3)), run((1, 2))
+    for name, u, v in zip(("dw", "db", "dgamma", "dbeta"), own, shared):
+        assert float((u - v).abs().max()) <= 2e-6 * float(u.abs().max()), name
+    with pytest.raises(hip.HipError):   # only the byte kernels with split slabs accumulate over calls
+        small = hip.conv_desc(8, 21, 21, 64, 2, 2, 1, 32, 1)
+        hip.conv2d_obs_bwd(small, s2d.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(),
+                           dz.data_ptr(), *[o.data_ptr() for o in own], ws.data_ptr(), channels_last=True, phase=1)
