@@ -46,7 +46,7 @@ import time
 
 # read when libamdhip64 is loaded, i.e. by `import torch`: the update runs on up to six streams, and with the runtime's default
 # of 4 hardware queues the ingest copy shares one with a compute pipeline (srl_amd/hip.py; INTEGRATION.md switches)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -23,7 +23,7 @@ _lib = None
 # with 8 it does not, and the ring-fed update gains ~1 %.  The runtime reads it when libamdhip64 is LOADED (`import torch`), so
 # this default only takes effect in processes that import srl_amd before torch; trainer entry points export it themselves
 # (bench.py does, before its imports) -- INTEGRATION.md lists it with the other switches.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 ABI_VERSION = 13
 
