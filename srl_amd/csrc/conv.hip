@@ -663,11 +663,12 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
       h.y_h2 = y_h2; h.bound = bound; h.y_scale = y_scale; h.y_mask = y_mask; h.y_absmax = y_absmax;
       h.GW = d->W; h.OW = OW; h.OH = OH; h.P = P; h.act = d->act;
       const long units = (long)(P / (srlobs::kBlkH * srlobs::kBlkW)) * srl_ceil_div(d->n, (long)srlobs::kTile);
-      const unsigned grid = (unsigned)(units < 512 ? units : 512);  // two workgroups per CU: two wavefronts per SIMD
-      constexpr int lds = srlobs::kStages * srlobs::kStageBytes + srlobs::kMeta * srlobs::kTile * 16 + 4 * 96 * 4;  // stages, records, tables
+      const long wgs = 256L * (srlobs::kWaves == 4 ? 2 : 1);  // two wavefronts per SIMD: two 4-wave workgroups or one 8-wave one per CU
+      const unsigned grid = (unsigned)(units < wgs ? units : wgs);
+      constexpr int lds = srlobs::kStages * srlobs::kStageBytes + srlobs::kMeta * srlobs::kTile * 16 + srlobs::kWaves * 96 * 4;  // stages, records, tables
       auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, h);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * srlobs::kWaves), lds, st, h);
       };
       srl_count_dispatch(SRL_DISP_OBS_FWD_BF16, 256, 2, (int)grid);
       const char* dbg = getenv("SRL_OBS_DBG");  // timing experiments (wrong results): see obs_h2.h

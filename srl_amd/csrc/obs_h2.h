@@ -4,18 +4,23 @@
 // obs_bf16.h gives every output position a workgroup of its own: the 256 patch bytes of a sample are fetched once per position,
 // i.e. every byte of a frame four times (2 x 2 overlapping patches of the space-to-depth grid), by different workgroups at
 // different times -- 1.08 GB of frame reads per 16 384-frame chunk where the frames are 0.46 GB -- and the position's weights
-// are re-read from LDS for every tile.  Here a workgroup owns a 2 x 2 BLOCK of positions (4 wavefronts, one position each, one
-// wavefront per SIMD with the whole register file) and walks the samples in tiles of 32:
-//   * the block's 3 x 3 pixels of a sample (576 bytes: 3 runs of 192) come in ONCE, by LDS-DMA, one wave-instruction per sample
-//     (the slot of the sample is wave-uniform: a scalar load, a scalar base, no per-lane index arithmetic), into a 3-stage
-//     ring of 32-sample tiles; 0.94 GB per chunk instead of 1.08, in whole 192-byte runs;
+// are re-read from LDS for every tile.  Here a workgroup owns a 2 x 4 BLOCK of positions (8 wavefronts, one position each, two
+// wavefronts per SIMD) and walks the samples in tiles of 32:
+//   * the block's 3 x 5 pixels of a sample (960 bytes: 3 runs of 320) come in ONCE, by LDS-DMA, one wave-instruction per sample,
+//     into a 3-stage ring of 32-sample tiles; 0.79 GB of requested bytes per chunk (1.15 KB of 128-byte lines per sample and
+//     block: 0.94 GB fetched) instead of 1.08;
 //   * a position's folded weights w * gamma do not change with the sample: they stay in REGISTERS for the whole walk -- as two
 //     f16 pieces under a power-of-two scale per output channel (22 significand bits; the bytes, minus the integer centre of
 //     the sample's mean, are exact in f16): 2 MFMAs per 16 k-values instead of obs_bf16.h's 3 bf16 pieces.  128 VGPRs -- the
-//     A/B operands of an MFMA must be architectural registers, so one position per wavefront is what fits;
+//     A/B operands of an MFMA must be architectural registers, so one position per wavefront is what fits beside the working
+//     set in the 256 registers of a wavefront that shares its SIMD with another;
+//   * per-sample records {slot, rstd, mean} are written by a tiny pre-pass and prefetched by DMA four tiles ahead: no dependent
+//     scalar loads in the loop (row_index -> mean / rstd is two memory latencies deep), no 64-bit divisions (cursors);
 //   * D[channel][sample] (weights as the A operand): a lane holds 16 channels of one sample = 64 contiguous bytes of the
 //     sample's h2p row at this position, two lanes complete the 128-byte line;
-//   * the only LDS traffic besides the DMA is 8 conflict-free ds_read_b128 per lane and tile (37 chunks between samples).
+//   * the only LDS traffic besides the DMA is 8 conflict-free ds_read_b128 per lane and tile (61 chunks between samples).
+// Measured on 16 384 frames (scripts/obs_fwd_bench.py; consecutive / permuted slots): obs_bf16.h 642 / 733 us; 2 x 2 blocks, 4
+// wavefronts, one workgroup per CU 600 / 693; the same, two workgroups per CU 512 / 583; 2 x 4 blocks, 8 wavefronts 462 / 542.
 // Same arithmetic contract as obs_bf16.h (its header): y = act(rstd_n (sum_k (x - c_n) wg - (mean_n - c_n) S) + b2).
 #pragma once
 #include "obs_bf16.h"
@@ -24,11 +29,14 @@ namespace srlobs {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kBlkH = 2, kBlkW = 2;        // positions per workgroup: 2 rows x 2 columns, one per wavefront
+constexpr int kBlkH = 2, kBlkW = 4;        // positions per workgroup: 2 rows x 4 columns, one per wavefront (8 wavefronts)
+constexpr int kWaves = kBlkH * kBlkW;
 constexpr int kTile = 32;                   // samples per tile
-constexpr int kChunks = 3 * 12;             // 16-byte chunks of the block's 3 x 3 pixels of one sample
-constexpr int kSampleBytes = 37 * 16;       // an ODD number of chunks between samples: the 16 lanes of a ds_read_b128 group
+constexpr int kRowChunks = (kBlkW + 1) * 4; // 16-byte chunks of one row of the block's pixels ((kBlkW + 1) pixels of 64 bytes)
+constexpr int kChunks = 3 * kRowChunks;     // ... of the block's 3 rows of one sample
+constexpr int kSampleBytes = (kChunks + 1) * 16;  // an ODD number of chunks between samples: the 16 lanes of a ds_read_b128 group
                                             // (16 samples, one chunk each) then fall on 16 different 16-byte bank groups
+static_assert(kChunks % 2 == 0 && kChunks <= 64, "one LDS-DMA instruction per sample");
 constexpr int kStageBytes = kTile * kSampleBytes;
 constexpr int kStages = 3;
 constexpr int kMeta = 5;                     // tiles of per-sample records in flight: the one computed .. four ahead
@@ -139,9 +147,9 @@ __device__ __forceinline__ void obs_bytes_to_f16(uint32_t d, uint32_t negc, uint
 // ACT: the activation (0 none, 1 ReLU, 2 tanh).  DBG (timing experiments, wrong results; SRL_OBS_DBG): 1 = no output stores, 2 = no LDS
 // reads / conversions / MFMAs, 4 = no DMA
 template <int ACT, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void obs_fwd_h2_kernel(FwdH2Args a) {
+__global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void obs_fwd_h2_kernel(FwdH2Args a) {
   extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
-  // [kStages][32 samples][37 chunks][16 B] | meta ring [kMeta][32] x 16 B | tables [4 waves][3][32] float
+  // [kStages][32 samples][kChunks + 1 chunks][16 B] | meta ring [kMeta][32] x 16 B | tables [kWaves][3][32] float
   uint4* const metal = reinterpret_cast<uint4*>(lds + kStages * kStageBytes);
   float* const tabs = reinterpret_cast<float*>(metal + kMeta * kTile);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
@@ -157,10 +165,10 @@ __global__ __launch_bounds__(256, 2) void obs_fwd_h2_kernel(FwdH2Args a) {
 
   // DMA: one instruction = one sample's 36 chunks (3 rows x 12), lane = chunk
   const bool dma_lane = lane < kChunks;
-  const uint32_t dvoff = (uint32_t)((lane / 12) * (a.GW * 64) + (lane % 12) * 16);
+  const uint32_t dvoff = (uint32_t)((lane / kRowChunks) * (a.GW * 64) + (lane % kRowChunks) * 16);
   // fragment reads: patch bytes 32 c + 16 h of this wave's position (py, px) of the block: row py + (c >> 2), chunk 4 px + 2 (c & 3) + h
-  const int py = wave >> 1, px = wave & 1;
-  const uint32_t rdbase = (uint32_t)(l31 * kSampleBytes + (py * 12 + px * 4 + h) * 16);
+  const int py = wave / kBlkW, px = wave % kBlkW;
+  const uint32_t rdbase = (uint32_t)(l31 * kSampleBytes + (py * kRowChunks + px * 4 + h) * 16);
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(a.y_h2, 0, (int)(a.n * (long)a.P * 128), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_msk = __builtin_amdgcn_make_buffer_rsrc(a.y_mask, 0, (int)(a.n * (long)a.P * 4), 0x00020000);
 
@@ -199,13 +207,14 @@ __global__ __launch_bounds__(256, 2) void obs_fwd_h2_kernel(FwdH2Args a) {
 #define SRL_OBS_DMA(STAGE)                                                                            \
   do {                                                                                                \
     const long blkoff_ = ((long)((cd.blk / nbx) * kBlkH) * GW + (cd.blk % nbx) * kBlkW) * 64 + dvoff; \
-    const uint4* m_ = metal + cd.ent * kTile + 8 * wave;                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                \
+    constexpr int per_ = kTile / kWaves;                                                              \
+    const uint4* m_ = metal + cd.ent * kTile + per_ * wave;                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < per_; ++i_) {                                                \
       const uint32_t slot_ = m_[i_].x;                    \
       if (dma_lane && !(DBG & 4))                                                                     \
-        obs_dma(lds0 + (STAGE) * kStageBytes + (8 * wave + i_) * kSampleBytes, frames + (long)slot_ * img_stride + blkoff_); \
+        obs_dma(lds0 + (STAGE) * kStageBytes + (per_ * wave + i_) * kSampleBytes, frames + (long)slot_ * img_stride + blkoff_); \
     }                                                                                                 \
-    issued += 8;                                                                                      \
+    issued += per_;                                                                                   \
     if ((STAGE) == 0) mark0 = issued;                                                                 \
     else if ((STAGE) == 1) mark1 = issued;                                                            \
     else mark2 = issued;                                                                              \
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void obs_fwd_h2_kernel(FwdH2Args a) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int c = 0; c < ((DBG & 2) ? 0 : 8); ++c) {
-      const uint4 q = *reinterpret_cast<const uint4*>(sb + (c >> 2) * 192 + (c & 3) * 32);
+      const uint4 q = *reinterpret_cast<const uint4*>(sb + (c >> 2) * (kRowChunks * 16) + (c & 3) * 32);
       union { uint32_t u[4]; f16x8 v; } x0, x1;
       obs_bytes_to_f16(q.x, nc.u, x0.u[0], x0.u[1]);
       obs_bytes_to_f16(q.y, nc.u, x0.u[2], x0.u[3]);

@@ -419,7 +419,7 @@ def test_first_layer_at_benchmark_size():
     hip.dispatch_tiles(reset=True)
     hip.conv2d_obs_fwd_h2(desc, s2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), b.data_ptr(),
                           yh.data_ptr(), hs.data_ptr(), ws.data_ptr(), rows, ham.data_ptr(), hm.data_ptr(), reuse_folded=False, ent_order=2)
-    assert hip.dispatch_tiles(reset=True) == {"obs_fwd_bf16:k256:h2blk:split512": 1}   # obs_h2.h: 512 persistent workgroups
+    assert hip.dispatch_tiles(reset=True) == {"obs_fwd_bf16:k256:h2blk:split256": 1}   # obs_h2.h: 256 persistent workgroups
     y = torch.empty(n * 400, 32, device=DEV)
     hip.h2_unpack_rows(yh.data_ptr(), n * 400, 32, hs.data_ptr(), y.data_ptr(), 32)
     yy, xx = np.meshgrid(np.arange(20), np.arange(20), indexing="ij")
