@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 13
+#define SRL_HIP_ABI_VERSION 14
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -465,11 +465,14 @@ int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d);
 /* phase: 3 = a call of its own (what every caller passes but the trainer's chunk loop); otherwise bit 0 = this call opens an
  * accumulation over calls (the sums Q, R, C in `workspace` start from zero), bit 1 = it closes one (the four gradients are formed
  * from the sums and ADDED into dw / db / dgamma / dbeta): the gradients are linear in the sums, so the chunks of one update share one
- * finalisation.  The workspace must not be touched between the calls of an accumulation; byte kernels with split slabs only. */
+ * finalisation.  The workspace must not be touched between the calls of an accumulation; byte kernels with split slabs only.
+ * dz_absmax (ABI 14, nullable): a device float >= max |dz| (the h2 data gradient that produced dz measures it).  With it, the
+ * Atari geometry (64-channel space-to-depth'd frames, 2x2 taps, 32 channels) runs the block kernel of csrc/obs_h2.h, which needs
+ * the bound for the power-of-two scale of its three f16 pieces of dz; without it, the bf16 kernel of csrc/obs_bf16.h. */
 int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
                        const float* dz, float* dw, float* db, float* dgamma, float* dbeta, float* workspace,
-                       const int32_t* row_index, int phase);
+                       const int32_t* row_index, int phase, const float* dz_absmax);
 
 /* ------------------------------------------------------------------------------------------------
  * Pre-split ("h2") operands and the kernels over them (round 4: csrc/h2gemm.h, csrc/h2conv.h).

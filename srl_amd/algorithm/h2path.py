@@ -181,7 +181,8 @@ class H2Cnn:
         hip.conv2d_obs_bwd(desc1, src.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), net._p(f"{self.ln.prefix}.weight"),
                            net._p(f"{self.ln.prefix}.bias"), net._p(f"{self.c1.prefix}.weight"), dz1.ptr, g(f"{self.c1.prefix}.weight"),
                            g(f"{self.c1.prefix}.bias"), g(f"{self.ln.prefix}.weight"), g(f"{self.ln.prefix}.bias"),
-                           ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=True, row_index=row_index, phase=phase)
+                           ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=True, row_index=row_index, phase=phase,
+                           dz_absmax_ptr=self._slot(M_DZ1))
 
     def _fc_wgrad(self, n, dy, a3):
         net, g = self.net, self.net._g

@@ -802,6 +802,13 @@ extern "C" int srl_conv2d_obs_fwd_h2(void* stream, const srl_conv_desc* d, const
   return 0;
 }
 
+// sample ranges per block of positions of obs_bwd_h2_kernel: one workgroup per CU
+static int obs_bwd_h2_split(long P) {
+  const long blocks = P / (srlobs::kBlkH * srlobs::kBlkW);
+  long s = blocks > 0 ? 256 / blocks : 1;
+  return (int)(s < 1 ? 1 : s);
+}
+
 extern "C" int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d) {
   if (check_desc(d) != 0) return 0;
   const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
@@ -810,13 +817,16 @@ extern "C" int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d) {
   long split = want_split(d->n, tiles, P);
   const long split16 = obs_bf16_split(d->n, (int)P, 3);
   if (split16 > split) split = split16;
-  return (int64_t)((split + 1) * P * d->Cout * Kp + 2 * P * d->Cout + 64);
+  const long split_h2 = obs_bwd_h2_split(P);
+  if (split_h2 > split) split = split_h2;
+  // + the per-sample records and the rstd bound of the block kernel (obs_h2.h)
+  return (int64_t)((split + 1) * P * d->Cout * Kp + 2 * P * d->Cout + 64 + 4 * (d->n + 32) + 4);
 }
 
 static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                               const float* mean, const float* rstd, const float* gamma, const float* beta,
                               const float* w, const float* dz, float* dw, float* db, float* dgamma, float* dbeta,
-                              float* workspace, const int32_t* row_index, int phase = 3) {
+                              float* workspace, const int32_t* row_index, int phase = 3, const float* dz_absmax = nullptr) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1), "unsupported geometry");
   SRL_CHECK_ARG(row_index == nullptr || srl_conv2d_obs_row_index_supported(d, is_u8, channels_last),
                 "row_index is served by the byte kernels only (srl_conv2d_obs_row_index_supported)");
@@ -840,6 +850,49 @@ static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* 
   const bool first = (phase & 1) != 0, last = (phase & 2) != 0;
   if (first && hipMemsetAsync(R, 0, sizeof(float) * 2 * P * d->Cout, st) != hipSuccess) return -EIO;
   const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, channels_last ? 1 : 0};
+  // the Atari geometry with a measured bound of |dz|: blocks of 2 x 4 positions per workgroup, frames and dz by LDS-DMA (obs_h2.h)
+  static const bool blocks_on = [] { const char* e = getenv("SRL_OBS_BWD_H2BLOCK"); return !(e && e[0] == '0'); }();
+  if (dz_absmax && blocks_on && obs_bf16_ok(d, is_u8, channels_last, obs) && d->Cin == 64 && d->KH == 2 && d->KW == 2 &&
+      d->stride == 1 && d->Cout == 32 && OH % srlobs::kBlkH == 0 && OW % srlobs::kBlkW == 0 && d->n >= 2048) {
+    srlobs::BwdH2Args a{};
+    const long n_pad = srl_ceil_div(d->n, (long)srlobs::kTile) * srlobs::kTile;
+    float* rstd_max = C + (((long)P * d->Cout + 3) & ~3L);
+    uint4* meta = reinterpret_cast<uint4*>(rstd_max + 4);
+    float* slabs_h2 = rstd_max + 4 + 4 * n_pad;
+    if (hipMemsetAsync(rstd_max, 0, sizeof(float), st) != hipSuccess) return -EIO;
+    hipLaunchKernelGGL(srlobs::obs_meta_kernel, dim3((unsigned)srl_ceil_div(n_pad, 256L)), dim3(256), 0, st, row_index, mean, rstd,
+                       (long)d->n, n_pad, meta, rstd_max);
+    a.frames = static_cast<const uint8_t*>(obs); a.img_stride = (long)d->H * d->W * d->Cin; a.meta = meta; a.n = d->n;
+    a.dz = dz; a.dz_bound = dz_absmax; a.rstd_bound = rstd_max; a.Q = slabs_h2; a.slab = (long)P * d->Cout * Kp; a.R = R; a.C = C;
+    a.GW = d->W; a.OW = OW; a.OH = OH; a.P = P; a.nsplit = obs_bwd_h2_split(P);
+    const unsigned grid = (unsigned)((P / (srlobs::kBlkH * srlobs::kBlkW)) * a.nsplit);
+    auto go = [&](auto kern) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, srlobs::kLdsB);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * srlobs::kWaves), srlobs::kLdsB, st, a);
+    };
+    srl_count_dispatch(SRL_DISP_OBS_BWD_BF16, 256, 2, a.nsplit);
+    const char* dbg = getenv("SRL_OBSB_DBG");  // timing experiments (wrong results): see obs_h2.h
+    switch (dbg ? atoi(dbg) : 0) {
+      case 1: go(srlobs::obs_bwd_h2_kernel<1>); break;
+      case 2: go(srlobs::obs_bwd_h2_kernel<2>); break;
+      case 3: go(srlobs::obs_bwd_h2_kernel<3>); break;
+      case 4: go(srlobs::obs_bwd_h2_kernel<4>); break;
+      case 8: go(srlobs::obs_bwd_h2_kernel<8>); break;
+      case 12: go(srlobs::obs_bwd_h2_kernel<12>); break;
+      case 15: go(srlobs::obs_bwd_h2_kernel<15>); break;
+      default: go(srlobs::obs_bwd_h2_kernel<0>);
+    }
+    SRL_LAUNCH_CHECK();
+    reduce_slabs(st, slabs_h2, a.nsplit, (long)P, (long)d->Cout, Kp, Q, Kp, (long)d->Cout * Kp, first ? 0 : 1);
+    SRL_LAUNCH_CHECK();
+    if (!last) return 0;
+    hipLaunchKernelGGL(obs_dw_kernel, dim3((unsigned)srl_ceil_div(d->Cout * Kp, kDwEL)), dim3(256), 0, st, Q, R, C, gamma, beta,
+                       P, d->Cout, ix, dw, db);
+    hipLaunchKernelGGL(obs_affine_kernel, dim3((unsigned)srl_ceil_div(d->Cin * d->H * d->W, 256)), dim3(256), 0, st, Q, R, C, w,
+                       OH, d->Cout, ix, dgamma, dbeta);
+    SRL_LAUNCH_CHECK();
+    return 0;
+  }
   if (obs_bf16_ok(d, is_u8, channels_last, obs) && (P * d->Cout) % 4 == 0) {
     srlobs::BwdArgs a{};
     a.g = obs_geom(d, obs, mean, rstd, OW, row_index);
@@ -900,7 +953,7 @@ static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* 
 extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
                                   const float* w, const float* dz, float* dw, float* db, float* dgamma, float* dbeta,
-                                  float* workspace, const int32_t* row_index, int phase) {
+                                  float* workspace, const int32_t* row_index, int phase, const float* dz_absmax) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, channels_last ? 2 : 1), "unsupported geometry");
   SRL_CHECK_ARG(phase >= 0 && phase <= 3, "phase: bit 0 opens, bit 1 closes an accumulation over calls");
   const long run = images_per_launch(d, is_u8 ? 1 : 4);
@@ -916,7 +969,7 @@ extern "C" int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const vo
     const int rc = conv2d_obs_bwd_run(stream, &s, static_cast<const uint8_t*>(obs) + adv * in_b, is_u8, channels_last, mean + adv,
                                       rstd + adv, gamma, beta, w, dz + i0 * out_e, dw, db, dgamma, dbeta, workspace,
                                       row_index ? row_index + i0 : nullptr,
-                                      only ? phase : ((i0 == 0 ? phase & 1 : 0) | (i0 + run >= d->n ? phase & 2 : 0)));
+                                      only ? phase : ((i0 == 0 ? phase & 1 : 0) | (i0 + run >= d->n ? phase & 2 : 0)), dz_absmax);
     if (rc != 0) return rc;
   }
   return 0;

@@ -106,13 +106,25 @@ __global__ __launch_bounds__(256) void obs_fold_h2_kernel(const float* w, const 
 
 // per-sample record of a launch: the slot of the sample's frame and its LayerNorm statistics side by side, so that the main kernel
 // finds both with ONE LDS-DMA per tile and no dependent scalar loads (row_index -> mean / rstd is two memory latencies deep)
+// rstd_max (optional, zeroed by the caller): the largest rstd of the launch, for the weight gradient's scale
 __global__ __launch_bounds__(256) void obs_meta_kernel(const int32_t* row_index, const float* mean, const float* rstd, long n,
-                                                       long n_pad, uint4* meta) {
+                                                       long n_pad, uint4* meta, float* rstd_max = nullptr) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_pad) return;
-  const long smp = i < n ? i : n - 1;
-  const long slot = row_index ? (long)row_index[smp] : smp;
-  meta[i] = make_uint4((uint32_t)slot, __float_as_uint(rstd[slot]), __float_as_uint(mean[slot]), 0u);
+  float rs = 0.f;
+  if (i < n_pad) {
+    const long smp = i < n ? i : n - 1;
+    const long slot = row_index ? (long)row_index[smp] : smp;
+    rs = rstd[slot];
+    const float mu = mean[slot];
+    union { _Float16 f[2]; uint32_t u; } nc;   // -(1024 + round(mean)) twice: what the byte -> f16 conversions add
+    nc.f[0] = nc.f[1] = (_Float16)(-(1024.f + rintf(mu)));
+    meta[i] = make_uint4((uint32_t)slot, __float_as_uint(rs), __float_as_uint(mu), nc.u);
+  }
+  if (rstd_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rs = fmaxf(rs, __shfl_xor(rs, o));
+    if ((threadIdx.x & 63) == 0 && rs > 0.f) atomicMax(reinterpret_cast<int*>(rstd_max), __float_as_int(rs));
+  }
 }
 
 __device__ __forceinline__ void obs_wait_vm_dyn(int n) {
@@ -128,6 +140,12 @@ __device__ __forceinline__ void obs_wait_vm_dyn(int n) {
 // 16 bytes per active lane into LDS at `lds` + 16 lane, from the lane's own address
 __device__ __forceinline__ void obs_dma(uint32_t lds, const void* src) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(src)
+               : "memory");
+}
+
+// the same from a wavefront-uniform base (scalar registers) + the lane's 32-bit byte offset: no 64-bit vector arithmetic
+__device__ __forceinline__ void obs_dma_s(uint32_t lds, const void* sbase, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds)), "v"(voff), "s"(sbase)
                : "memory");
 }
 
@@ -337,6 +355,326 @@ __global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void obs_fwd_h2_k
 #undef SRL_OBS_META
 #undef SRL_OBS_DMA
 #undef SRL_OBS_FINISH
+}
+#endif  // __HIPCC__
+
+// ---- weight gradient in the same block structure -------------------------------------------------------------------------------
+// Q[pos][o][k] = sum_n dz'[n,pos,o] (x[n,pos,k] - c_n), R = sum dz, C = sum dz' (mean - c) as obs_bwd_bf16_kernel (obs_bf16.h), for
+// the finalisation kernels of conv.hip -- but a workgroup owns a 2 x 4 block of positions and ONE nsplit-th of the samples of the
+// launch: the frames come in once per block by LDS-DMA as BYTES (the forward's tiles, 16 samples each) and go to the matrix cores
+// through ds_read_b64_tr_b8, the transposing byte read of gfx950 -- of 16 row addresses x 8 bytes a lane receives one byte column
+// of the even (lanes 0-7) or odd (lanes 8-15) addresses: with even / odd addresses pointing at the same 8 samples, 8 bytes apart,
+// ONE read hands a wavefront the 32-column x 16-sample B operand of a 32x32x16 MFMA (8 bytes per lane = 8 consecutive samples of
+// its column), converted in registers (a byte minus the sample's integer centre is exact in f16).  obs_bf16.h converts while
+// STAGING and keeps a 16-bit image of every patch in LDS (4 x the bytes; 63 % of its LDS cycles were bank conflicts).  dz' =
+// dz rstd_n is the A operand: the float32 rows come in by LDS-DMA too (a tile ahead), are split into THREE f16 pieces under the
+// power-of-two scale of the bound max |dz| max rstd (33 significand bits from the bound down: at 2^-15 of the bound and above
+// nothing float32 holds is dropped) into a per-wavefront image, and fetched with ds_read_b64_tr_b16.  A wavefront = one position,
+// all 256 patch columns: 8 accumulator tiles, 24 MFMAs per 16 samples.
+constexpr int kTileB = 16;                                  // samples per tile of the weight gradient (= the MFMA's k)
+constexpr int kSampleBytesB = (kChunks + 2) * 16;           // 62 chunks = 248 dwords = 8 x 31 banks: 8 samples x 32 bytes of a read
+constexpr int kStageBytesB = kTileB * kSampleBytesB;        //   of 32 lanes fall on 64 different banks
+constexpr int kStagesB = 4;                                 // frames and dz rows are fetched three tiles ahead
+constexpr int kMetaB = 8;                                   // records seven tiles ahead: in LDS a tile before the frames' fetch reads the slots
+constexpr int kLdsB = kStagesB * kStageBytesB + kMetaB * kTileB * 16 + kWaves * (3 * 1024 + kStagesB * 2048);
+
+struct BwdH2Args {
+  const uint8_t* frames;
+  long img_stride;
+  const uint4* meta;        // [ceil(n / 32) * 32] x {slot, rstd, mean, -(1024 + round(mean)) as two f16}
+  long n;
+  const float* dz;          // [n][P][32]
+  const float* dz_bound;    // device float: max |dz|
+  const float* rstd_bound;  // device float: max rstd over the launch's samples (obs_meta_kernel)
+  float* Q;                 // [nsplit][P][32][256] slabs
+  long slab;
+  float* R;                 // [P][32], atomically accumulated
+  float* C;                 // [P][32], atomically accumulated
+  int GW, OW, OH, P, nsplit;
+};
+
+#ifdef __HIPCC__
+// The schedule of a workgroup, tile it of its sample range: [wait: frames of it landed | barrier | fetch of tile it + 3 (records of
+// it + 6, frames, dz rows) | A fragments of dz'(it) from the wavefront's image | dz(it + 1): float32 rows -> three f16 planes, into
+// the same image (the fragments are in registers by then), in one basic block with the 24 MFMAs of tile it so that the compiler
+// interleaves the two].  Every tile issues the SAME number of memory operations in the same order (past the end: the last tile
+// again), which makes the two s_waitcnt of a tile compile-time constants.
+// DBG (timing experiments, wrong results): 1 no frame DMA, 2 no dz DMA, 4 no B reads / conversions / MFMAs, 8 no dz staging
+template <int DBG = 0>
+__global__ __launch_bounds__(512, 1) void obs_bwd_h2_kernel(BwdH2Args a) {
+  extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+  // [4][16 samples][62 chunks][16 B] | record ring [8][16] x 16 B | per wavefront: 3 planes [16 samples][32 channels] f16 | per
+  // wavefront: 4 x [16 samples][32 channels] float32 (dz as it comes)
+  uint4* const metal = reinterpret_cast<uint4*>(lds + kStagesB * kStageBytesB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)lds, ldsm = lds0 + kStagesB * kStageBytesB;
+  constexpr int kPlanes0 = kStagesB * kStageBytesB + kMetaB * kTileB * 16;
+  uint8_t* const myp = lds + kPlanes0 + wave * 3072;
+  constexpr int kRaw0 = kPlanes0 + kWaves * 3072;
+  const uint8_t* const myraw = lds + kRaw0 + wave * (kStagesB * 2048);
+  const uint32_t ldsraw = lds0 + kRaw0 + wave * (kStagesB * 2048);
+
+  const int nbx = a.OW / kBlkW;
+  const int blk = blockIdx.x / a.nsplit, split = blockIdx.x % a.nsplit;
+  const long ntiles = (a.n + kTileB - 1) / kTileB;
+  const long t0 = ntiles * split / a.nsplit, t1 = ntiles * (split + 1) / a.nsplit;
+  const int nu = (int)(t1 - t0);
+  if (nu <= 0) return;
+  const int py = wave / kBlkW, px = wave % kBlkW;
+  const int oy = (blk / nbx) * kBlkH + py, ox = (blk % nbx) * kBlkW + px;
+  const int pos = oy * a.OW + ox;
+  const float scale = srlh2::h2_scale_for(*a.dz_bound * *a.rstd_bound), inv_scale = 1.0f / scale;
+
+  const bool dma_lane = lane < kChunks;
+  const uint32_t blkoff = (uint32_t)(((blk / nbx) * kBlkH * a.GW + (blk % nbx) * kBlkW) * 64 +
+                                     (lane / kRowChunks) * (a.GW * 64) + (lane % kRowChunks) * 16);
+  const uint8_t* const frames = a.frames;
+  const uint4* const meta = a.meta + t0 * kTileB;
+  const long img_stride = a.img_stride, nsamp = a.n;
+  const uint32_t ldzb = (uint32_t)a.P * kCout * 4;          // bytes per sample of dz (the whole tensor: < 4 GiB, checked by the host)
+  const float* const dzpos = a.dz + (long)pos * kCout;      // wavefront-uniform: the position's first row
+  const uint32_t dzlane = (uint32_t)(lane & 7) * 16;
+
+  // B operand (bytes): lane L of group g = L >> 4 supplies the address of sample 8 (g >> 1) + ((L & 15) >> 1), byte column
+  // 16 (g & 1) + 8 (L & 1) of the 32-column tile; patch tile t: row t >> 2 of the patch, bytes 32 (t & 3) .. + 31 of its 128
+  const int g16 = lane >> 4, j16 = lane & 15;
+  const uint32_t bbase = (uint32_t)((8 * (g16 >> 1) + (j16 >> 1)) * kSampleBytesB + (py * kRowChunks + px * 4) * 16 + 16 * (g16 & 1) + 8 * (j16 & 1));
+  // A operand (16-bit planes, 64-byte rows): ds_read_b64_tr_b16, lane 4 q + p of a group supplies row q, columns 4 p .. 4 p + 3
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const uint8_t* const pa = myp + (8 * h + q4) * 64 + (16 * (g16 & 1) + 4 * p4) * 2;
+  // dz staging: lane -> sample lane >> 2 of the tile, channels 8 (lane & 3) .. + 7
+  const int ds_s = lane >> 2, ds_q = lane & 3;
+  uint8_t* const pdst = myp + ds_s * 64 + ds_q * 16;
+  const uint8_t* const praw = myraw + ds_s * 128 + ds_q * 32;
+
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  f32x2 rsum[4], csum[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rsum[i] = csum[i] = f32x2{0.f, 0.f};
+
+  // records of tile j -> ring entry j & 7 (wavefront 0, lanes 0..15)
+  auto issue_meta = [&](int j) __attribute__((always_inline)) {
+    if (wave == 0) {
+      const int jc = j < nu ? j : nu - 1;
+      if (lane < kTileB) obs_dma(ldsm + (uint32_t)(j & 7) * (kTileB * 16), meta + jc * kTileB + lane);
+    }
+  };
+  // slots of the wavefront's two samples of tile j, from the ring (uniform address: a broadcast) -> scalar registers
+  uint32_t slot0 = 0, slot1 = 0;
+  auto read_slots = [&](int j) __attribute__((always_inline)) {
+    const uint4* m_ = metal + (j & 7) * kTileB + 2 * wave;
+    slot0 = __builtin_amdgcn_readfirstlane(m_[0].x);
+    slot1 = __builtin_amdgcn_readfirstlane(m_[1].x);
+  };
+  // tile j: records of j + 4, frames (2 samples per wavefront, slots read before), dz rows (2 x 8 samples x 128 bytes)
+  auto issue = [&](int j) __attribute__((always_inline)) {
+    issue_meta(j + 4);
+    if (dma_lane && !((DBG & 1) && j > 3)) {
+      obs_dma_s(lds0 + (j & 3) * kStageBytesB + (2 * wave) * kSampleBytesB, frames + (long)slot0 * img_stride, blkoff);
+      obs_dma_s(lds0 + (j & 3) * kStageBytesB + (2 * wave + 1) * kSampleBytesB, frames + (long)slot1 * img_stride, blkoff);
+    }
+    const int jc = j < nu ? j : nu - 1;
+    const uint32_t smp0 = (uint32_t)((t0 + jc) * kTileB) + (lane >> 3), last = (uint32_t)(nsamp - 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t smp = smp0 + 8 * i < last ? smp0 + 8 * i : last;
+      if (!((DBG & 2) && j > 3)) obs_dma_s(ldsraw + (j & 3) * 2048 + i * 1024, dzpos, smp * ldzb + dzlane);
+    }
+  };
+  // dz rows of tile j (raw image j & 3) -> three f16 planes; R / C sums.  In three steps (loads | 4 x a pair of channels | stores)
+  // for the main loop to place between its MFMAs.
+  float st_rss, st_mcs, st_okf;
+  f32x2 st_d[4];
+  uint32_t st_pl[3][4];
+  auto stage_load = [&](int j) __attribute__((always_inline)) {
+    const uint4 mrec = metal[(j & 7) * kTileB + ds_s];
+    const bool ok = (t0 + j) * kTileB + ds_s < nsamp && j < nu && !((DBG & 8) && j > 3);
+    const float mean_n = __uint_as_float(mrec.z);
+    st_rss = ok ? __uint_as_float(mrec.y) * scale : 0.f;   // dz -> scaled dz'; 0 past the end
+    st_mcs = (mean_n - rintf(mean_n)) * inv_scale;         // scaled dz' -> its share of C
+    st_okf = ok ? 1.f : 0.f;
+    const float4* rp = reinterpret_cast<const float4*>(praw + (j & 3) * 2048);
+    const float4 d0 = rp[0], d1 = rp[1];
+    st_d[0] = f32x2{d0.x, d0.y}; st_d[1] = f32x2{d0.z, d0.w}; st_d[2] = f32x2{d1.x, d1.y}; st_d[3] = f32x2{d1.z, d1.w};
+  };
+  // a pair of channels in three steps of four vector instructions (u = 0, 1, 2)
+  typedef decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) pkh_t;
+  f32x2 st_r;
+  auto stage_unit = [&](int i, int u) __attribute__((always_inline)) {
+    union { pkh_t hv; uint32_t w; } c;
+    if (u == 0) {
+      rsum[i] += st_d[i] * st_okf;
+      st_r = st_d[i] * st_rss;
+      csum[i] += st_r * st_mcs;
+    } else {
+      // round-to-zero pieces: the residuals stay exact (v - h0 has fewer bits than v), 10 + 10 + 11 bits below the leading one
+      c.w = st_pl[u - 1][i];
+      st_r = st_r - f32x2{(float)c.hv[0], (float)c.hv[1]};
+    }
+    c.hv = __builtin_amdgcn_cvt_pkrtz(st_r[0], st_r[1]);
+    st_pl[u][i] = c.w;
+  };
+  auto stage_pair = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) stage_unit(i, u);
+  };
+  auto stage_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      *reinterpret_cast<uint4*>(pdst + p * 1024) = make_uint4(st_pl[p][0], st_pl[p][1], st_pl[p][2], st_pl[p][3]);
+  };
+  auto stage_dz = [&](int j) __attribute__((always_inline)) {
+    stage_load(j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_pair(i);
+    stage_store();
+  };
+  // wave 0 issues one operation more per tile (the records)
+#define SRL_OBSB_WAIT(N0, N)                                                                 \
+  do {                                                                                       \
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(" #N0 ")" ::: "memory");                    \
+    else asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                               \
+  } while (0)
+
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) v2i lds_v2i;
+  typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+  // centres of a tile's samples 8 h .. 8 h + 7, as f16 pairs -(1024 + c)
+  uint32_t negc[4];
+  auto load_negc = [&](int j) __attribute__((always_inline)) {
+    const uint4* mr = metal + (j & 7) * kTileB + 8 * h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) negc[i] = __builtin_amdgcn_perm(mr[2 * i + 1].w, mr[2 * i].w, 0x05040100u);
+  };
+  // bytes (b0 .. b7) of a transposed read = samples 8 h .. 8 h + 7 of this lane's column -> b - c_sample, exact in f16
+  // (0x6400 | b = 1024 + b); half a read (4 samples) per call: four vector instructions
+  auto conv_half = [&](uint32_t raw, uint32_t na, uint32_t nb, uint32_t& o0, uint32_t& o1) __attribute__((always_inline)) {
+    union { uint32_t u; h2t v; } w0, w1, c0, c1;
+    w0.u = __builtin_amdgcn_perm(0x64646464u, raw, 0x05010400u);
+    w1.u = __builtin_amdgcn_perm(0x64646464u, raw, 0x05030402u);
+    c0.u = na; c1.u = nb;
+    w0.v = w0.v + c0.v; w1.v = w1.v + c1.v;
+    o0 = w0.u; o1 = w1.u;
+  };
+  union XB { uint32_t u[4]; f16x8 v; };
+  XB xb0[4], xb1[4];   // B operands of patch row 0 / row 1, four column tiles each
+  v2i raw[4];
+
+  for (int m = 0; m < 4; ++m) issue_meta(m);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int j = 0; j < 3; ++j) {
+    read_slots(j);
+    issue(j);
+  }
+  read_slots(3);
+  SRL_OBSB_WAIT(10, 8);  // behind dz(0): two tiles of 5 / 4 operations
+  asm volatile("s_barrier" ::: "memory");  // (the frames of tile 0 came in through all eight wavefronts)
+  stage_dz(0);
+  load_negc(0);
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const v2i r = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(lds + bbase + tt * 32));
+    conv_half((uint32_t)r.x, negc[0], negc[1], xb0[tt].u[0], xb0[tt].u[1]);
+    conv_half((uint32_t)r.y, negc[2], negc[3], xb0[tt].u[2], xb0[tt].u[3]);
+  }
+
+  // Tile it: the MFMAs of patch row 0 (its B operands were converted under the previous tile's MFMAs), then those of row 1.
+  // Between them, in the order written (sched_barrier: nothing moves across) and at most two four-instruction units per gap: the
+  // conversions of row 1, of row 0 of tile it + 1, and the staging of dz(it + 1).  An MFMA occupies the matrix pipeline for 32
+  // cycles and the vector issue for 8 of them; left to the compiler, the vector work came as one block ahead of 24 back-to-back
+  // MFMAs and the two wavefronts of a SIMD, in step through the barrier, queued for the vector unit and then for the matrix unit
+  // (both 41-45 % busy, one after the other).
+  for (int it = 0; it < nu; ++it) {
+    SRL_OBSB_WAIT(5, 4);  // all but the last tile's fetch: frames and dz of tile it + 1 are in
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    issue(it + 3);
+    f16x8 af[3];  // A fragments: three pieces of dz'(it)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      union { s16x4 s[2]; f16x8 v; } u;
+      u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + p * 1024));
+      u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + p * 1024 + 4 * 64));
+      af[p] = u.v;
+    }
+    const uint8_t* sb = lds + (it & 3) * kStageBytesB + bbase + kRowChunks * 16;        // row 1 of tile it
+    const uint8_t* sbn = lds + ((it + 1) & 3) * kStageBytesB + bbase;                    // row 0 of tile it + 1
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) raw[tt] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(sb + tt * 32));
+    stage_load(it + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(DBG & 4)) {
+#pragma unroll
+      for (int g = 0; g < 24; ++g) {
+        if (g < 12) acc[g & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g >> 2], xb0[g & 3].v, acc[g & 3], 0, 0, 0);
+        else acc[4 + (g & 3)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[(g - 12) >> 2], xb1[g & 3].v, acc[4 + (g & 3)], 0, 0, 0);
+        // conversions
+        if (g < 8) {
+          const int tt = g >> 1;
+          if (g & 1) conv_half((uint32_t)raw[tt].y, negc[2], negc[3], xb1[tt].u[2], xb1[tt].u[3]);
+          else conv_half((uint32_t)raw[tt].x, negc[0], negc[1], xb1[tt].u[0], xb1[tt].u[1]);
+        } else if (g == 8) {
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) raw[tt] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(sbn + tt * 32));
+          load_negc(it + 1);
+        } else if (g >= 12 && g < 20) {
+          const int tt = (g - 12) >> 1;
+          if (g & 1) conv_half((uint32_t)raw[tt].y, negc[2], negc[3], xb0[tt].u[2], xb0[tt].u[3]);
+          else conv_half((uint32_t)raw[tt].x, negc[0], negc[1], xb0[tt].u[0], xb0[tt].u[1]);
+        } else if (g == 20) {
+          read_slots(it + 4);  // for the next tile's fetch (its records came in seven tiles ahead): no LDS round trip behind the barrier
+        }
+        // staging: pairs 0, 1 in gaps 0-5, pair 2 in gaps 9-11, pair 3 in gaps 12-14, the stores in gap 15
+        if (g < 6) stage_unit(g / 3, g % 3);
+        else if (g >= 9 && g < 12) stage_unit(2, g - 9);
+        else if (g >= 12 && g < 15) stage_unit(3, g - 12);
+        else if (g == 15) stage_store();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) stage_pair(i);
+      stage_store();
+      read_slots(it + 4);
+    }
+  }
+#undef SRL_OBSB_WAIT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // R / C: lanes with the same channel group (lane & 3) hold different samples: fold through LDS, one atomic per channel and wavefront
+  {
+    float* red = reinterpret_cast<float*>(lds) + wave * (64 * 16);
+    const float cs = 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[lane * 16 + 2 * i] = rsum[i][0];
+      red[lane * 16 + 2 * i + 1] = rsum[i][1];
+      red[lane * 16 + 8 + 2 * i] = csum[i][0] * cs;
+      red[lane * 16 + 8 + 2 * i + 1] = csum[i][1] * cs;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (a wavefront's own LDS traffic is ordered)
+    const int ch = lane & 31, which = lane >> 5;  // channel ch = 8 q + i: lanes with lane & 3 == q, value which * 8 + i
+    const int qq = ch >> 3, ii = ch & 7;
+    float tsum = 0.f;
+    for (int s16 = 0; s16 < 16; ++s16) tsum += red[(4 * s16 + qq) * 16 + which * 8 + ii];
+    atomicAdd((which ? a.C : a.R) + pos * kCout + ch, tsum);
+  }
+  // D[o][k]: registers 4 g .. 4 g + 3 hold channels 8 g + 4 h + (0..3) of patch column 32 t + l31
+  const float inv = inv_scale;
+  float* qo = a.Q + (long)split * a.slab + (long)pos * kCout * 256;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = 8 * (r >> 2) + (r & 3) + 4 * h;
+      qo[(long)o * 256 + 32 * t + l31] = acc[t][r] * inv;
+    }
 }
 #endif  // __HIPCC__
 

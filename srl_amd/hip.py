@@ -25,7 +25,7 @@ _lib = None
 # (bench.py does, before its imports) -- INTEGRATION.md lists it with the other switches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -102,7 +102,7 @@ _SIGNATURES = {
     "srl_obs_space_to_depth": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                         c_void_p]),
     "srl_conv2d_obs_bwd_workspace": (c_int64, [_CD]),
-    "srl_conv2d_obs_bwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 12 + [c_int]),
+    "srl_conv2d_obs_bwd": (c_int, [c_void_p, _CD, c_void_p, c_int, c_int] + [c_void_p] * 12 + [c_int, c_void_p]),
     "srl_abi_version": (c_int, []),
     "srl_last_error": (c_char_p, []),
     "srl_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
@@ -963,14 +963,17 @@ def conv2d_obs_bwd_workspace(d: ConvDesc) -> int:
 
 
 def conv2d_obs_bwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, beta_ptr, w_ptr, dz_ptr, dw_ptr, db_ptr,
-                   dgamma_ptr, dbeta_ptr, ws_ptr, channels_last=False, row_index: Optional[torch.Tensor] = None, phase: int = 3):
+                   dgamma_ptr, dbeta_ptr, ws_ptr, channels_last=False, row_index: Optional[torch.Tensor] = None, phase: int = 3,
+                   dz_absmax_ptr=None):
     """``phase``: 3 = a call of its own; bit 0 opens / bit 1 closes an accumulation of the position sums over several calls (the
-    chunks of one update then share one finalisation; ``srl_hip.h``)."""
+    chunks of one update then share one finalisation; ``srl_hip.h``).  ``dz_absmax_ptr``: device float >= max |dz| (selects the
+    block kernel of ``csrc/obs_h2.h`` on the Atari geometry)."""
     with _scope("conv_obs_bwd", _conv_flops(d), "obs"):
         _check(
             lib().srl_conv2d_obs_bwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), int(channels_last), mean_ptr,
                                      rstd_ptr, gamma_ptr, beta_ptr, w_ptr, dz_ptr, dw_ptr, db_ptr, dgamma_ptr, dbeta_ptr,
-                                     ws_ptr, _ptr(row_index, torch.int32, "row_index"), int(phase)), "srl_conv2d_obs_bwd")
+                                     ws_ptr, _ptr(row_index, torch.int32, "row_index"), int(phase),
+                                     dz_absmax_ptr or None), "srl_conv2d_obs_bwd")
 
 
 def _wrap_for_profile(names):

@@ -444,10 +444,60 @@ def test_first_layer_at_benchmark_size():
     hip.conv2d_obs_bwd(desc, s2d.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(),
                        dz.data_ptr(), *[o.data_ptr() for o in outs], wsb.data_ptr(), channels_last=True, row_index=rows)
     assert hip.dispatch_tiles(reset=True) == {"obs_bwd_bf16:k256:f32:split8": 1}
+    # ... and with the measured bound of |dz| that the trainer's data gradient hands over: the block kernel of obs_h2.h
+    outs_blk = [torch.zeros_like(o) for o in outs]
+    bound = dz.abs().max().reshape(1).clone()
+    hip.conv2d_obs_bwd(desc, s2d.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(),
+                       dz.data_ptr(), *[o.data_ptr() for o in outs_blk], wsb.data_ptr(), channels_last=True, row_index=rows,
+                       dz_absmax_ptr=bound.data_ptr())
+    assert hip.dispatch_tiles(reset=True) == {"obs_bwd_bf16:k256:h2blk:split5": 1}   # 50 blocks of 2 x 4 positions x 5 sample ranges
     leaves = [t.double().requires_grad_(True) for t in (w, b, gamma, beta)]
     for i0 in range(0, n, 1024):
         idx = torch.arange(i0, min(n, i0 + 1024), device=DEV)
         (pre_activation(idx, leaves[2], leaves[3], leaves[0], leaves[1]) * dz[idx].double()).sum().backward()
-    for got, leaf, name in zip(outs, leaves, ("dw", "db", "dgamma", "dbeta")):
-        err = float((got.double() - leaf.grad.reshape(-1)).abs().max()) / float(leaf.grad.abs().max())
-        assert err <= 1e-5, (name, err)
+    for kernel, res in (("bf16", outs), ("block", outs_blk)):
+        for got, leaf, name in zip(res, leaves, ("dw", "db", "dgamma", "dbeta")):
+            err = float((got.double() - leaf.grad.reshape(-1)).abs().max()) / float(leaf.grad.abs().max())
+            assert err <= 1e-5, (kernel, name, err)
+
+
+@pytest.mark.parametrize("n1,n2,indexed,slack", [(2500, 2077, True, 1.0), (4096, 2048, False, 37.0)])
+def test_first_layer_block_weight_gradient_ragged_and_accumulated(n1, n2, indexed, slack):
+    """obs_h2.h's weight gradient on sample counts that are no multiple of its 16-sample tiles, frames in place (row_index) or
+    consecutive, a bound of |dz| that is exact or loose, and the position sums accumulated over two calls (`phase`): against
+    obs_bf16.h's kernel (exact bf16 pieces, checked against float64 above) on the same samples in one call."""
+    hip = _hip()
+    n, slots = n1 + n2, n1 + n2 + 40
+    g = torch.Generator(device=DEV).manual_seed(41)
+    frames = torch.randint(0, 256, (slots, 4, 84, 84), dtype=torch.uint8, device=DEV, generator=g)
+    frames[::7] //= 32
+    s2d, mean, rstd = torch.empty(slots, 21, 21, 64, dtype=torch.uint8, device=DEV), torch.empty(slots, device=DEV), torch.empty(slots, device=DEV)
+    hip.obs_space_to_depth(frames.data_ptr(), True, slots, 4, 84, 84, 4, s2d.data_ptr(), mean.data_ptr(), rstd.data_ptr())
+    rows = torch.randperm(slots, device=DEV, generator=g)[:n].to(torch.int32) if indexed else None
+    gamma, beta = 1 + _f(21, 21, 64, seed=42, amp=0.2), _f(21, 21, 64, seed=43, amp=0.2)
+    w = _f(32, 2, 2, 64, seed=44, amp=0.06)
+    dz = (_f(n, 20, 20, 32, seed=45, amp=1e-3) * (_f(n, 20, 20, 32, seed=46) > 0)).contiguous()
+    dz[n1 - 3:n1 + 5] *= 50.0   # the largest rows sit at the seam of the two calls
+    bound = (dz.abs().max() * slack).reshape(1).clone()
+
+    def call(i0, cnt, phase, with_bound, outs, ws):
+        desc = hip.conv_desc(cnt, 21, 21, 64, 2, 2, 1, 32, 1)
+        hip.conv2d_obs_bwd(desc, s2d.data_ptr() + (0 if indexed else i0 * 21 * 21 * 64), True, mean.data_ptr() + (0 if indexed else 4 * i0),
+                           rstd.data_ptr() + (0 if indexed else 4 * i0), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(),
+                           dz.data_ptr() + 4 * i0 * 400 * 32, *[o.data_ptr() for o in outs], ws.data_ptr(), channels_last=True,
+                           row_index=rows[i0:i0 + cnt].contiguous() if indexed else None, phase=phase,
+                           dz_absmax_ptr=bound.data_ptr() if with_bound else None)
+
+    shapes = (32 * 256, 32, 21 * 21 * 64, 21 * 21 * 64)
+    ref, got = [torch.zeros(k, device=DEV) for k in shapes], [torch.zeros(k, device=DEV) for k in shapes]
+    ws = torch.empty(hip.conv2d_obs_bwd_workspace(hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, 1)), device=DEV)
+    hip.dispatch_tiles(reset=True)
+    call(0, n, 3, False, ref, ws)
+    assert set(hip.dispatch_tiles(reset=True)) == {"obs_bwd_bf16:k256:f32:split8"}
+    call(0, n1, 1, True, got, ws)
+    assert all(float(o.abs().max()) == 0.0 for o in got)   # an open accumulation forms no gradients yet
+    call(n1, n2, 2, True, got, ws)
+    assert hip.dispatch_tiles(reset=True) == {"obs_bwd_bf16:k256:h2blk:split5": 2}
+    for a, b, name in zip(got, ref, ("dw", "db", "dgamma", "dbeta")):
+        err = float((a - b).abs().max()) / float(b.abs().max())
+        assert err <= 3e-6, (name, err)   # float32 accumulation in a different order; the pieces drop nothing at this slack
