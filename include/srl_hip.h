@@ -468,7 +468,7 @@ int64_t srl_conv2d_obs_bwd_workspace(const srl_conv_desc* d);
  * finalisation.  The workspace must not be touched between the calls of an accumulation; byte kernels with split slabs only.
  * dz_absmax (ABI 14, nullable): a device float >= max |dz| (the h2 data gradient that produced dz measures it).  With it, the
  * Atari geometry (64-channel space-to-depth'd frames, 2x2 taps, 32 channels) runs the block kernel of csrc/obs_h2.h, which needs
- * the bound for the power-of-two scale of its three f16 pieces of dz; without it, the bf16 kernel of csrc/obs_bf16.h. */
+ * the bound for the power-of-two scale of its f16 pieces of dz; without it, the bf16 kernel of csrc/obs_bf16.h. */
 int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                        const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
                        const float* dz, float* dw, float* db, float* dgamma, float* dbeta, float* workspace,

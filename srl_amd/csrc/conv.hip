@@ -662,9 +662,12 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
       h.n = d->n; h.wq = reinterpret_cast<const uint4*>(wq); h.winv = winv; h.S = S; h.b2 = b2;
       h.y_h2 = y_h2; h.bound = bound; h.y_scale = y_scale; h.y_mask = y_mask; h.y_absmax = y_absmax;
       h.GW = d->W; h.OW = OW; h.OH = OH; h.P = P; h.act = d->act;
-      const long units = (long)(P / (srlobs::kBlkH * srlobs::kBlkW)) * srl_ceil_div(d->n, (long)srlobs::kTile);
-      const long wgs = 256L * (srlobs::kWaves == 4 ? 2 : 1);  // two wavefronts per SIMD: two 4-wave workgroups or one 8-wave one per CU
-      const unsigned grid = (unsigned)(units < wgs ? units : wgs);
+      // one workgroup per CU: every block of positions x as many ranges of the launch's tiles as make that many
+      const long nblk = P / (srlobs::kBlkH * srlobs::kBlkW), ntiles = srl_ceil_div(d->n, (long)srlobs::kTile);
+      long nsplit = nblk < 256 ? 256 / nblk : 1;
+      if (nsplit > ntiles) nsplit = ntiles;
+      h.nsplit = (int)nsplit;
+      const unsigned grid = (unsigned)(nblk * nsplit);
       constexpr int lds = srlobs::kStages * srlobs::kStageBytes + srlobs::kMeta * srlobs::kTile * 16 + srlobs::kWaves * 96 * 4;  // stages, records, tables
       auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -853,7 +856,7 @@ static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* 
   // the Atari geometry with a measured bound of |dz|: blocks of 2 x 4 positions per workgroup, frames and dz by LDS-DMA (obs_h2.h)
   static const bool blocks_on = [] { const char* e = getenv("SRL_OBS_BWD_H2BLOCK"); return !(e && e[0] == '0'); }();
   if (dz_absmax && blocks_on && obs_bf16_ok(d, is_u8, channels_last, obs) && d->Cin == 64 && d->KH == 2 && d->KW == 2 &&
-      d->stride == 1 && d->Cout == 32 && OH % srlobs::kBlkH == 0 && OW % srlobs::kBlkW == 0 && d->n >= 2048) {
+      d->stride == 1 && d->Cout == 32 && OH % srlobs::kBlkH == 0 && OW % srlobs::kBlkW == 0 && d->n * (long)P * 128 < 0xffffffffL) {
     srlobs::BwdH2Args a{};
     const long n_pad = srl_ceil_div(d->n, (long)srlobs::kTile) * srlobs::kTile;
     float* rstd_max = C + (((long)P * d->Cout + 3) & ~3L);
@@ -865,6 +868,7 @@ static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* 
     a.frames = static_cast<const uint8_t*>(obs); a.img_stride = (long)d->H * d->W * d->Cin; a.meta = meta; a.n = d->n;
     a.dz = dz; a.dz_bound = dz_absmax; a.rstd_bound = rstd_max; a.Q = slabs_h2; a.slab = (long)P * d->Cout * Kp; a.R = R; a.C = C;
     a.GW = d->W; a.OW = OW; a.OH = OH; a.P = P; a.nsplit = obs_bwd_h2_split(P);
+    if (a.nsplit > srl_ceil_div(d->n, (long)srlobs::kTileB)) a.nsplit = (int)srl_ceil_div(d->n, (long)srlobs::kTileB);  // (a range of tiles each)
     const unsigned grid = (unsigned)((P / (srlobs::kBlkH * srlobs::kBlkW)) * a.nsplit);
     auto go = [&](auto kern) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, srlobs::kLdsB);
@@ -877,7 +881,10 @@ static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* 
       case 2: go(srlobs::obs_bwd_h2_kernel<2>); break;
       case 3: go(srlobs::obs_bwd_h2_kernel<3>); break;
       case 4: go(srlobs::obs_bwd_h2_kernel<4>); break;
+      case 7: go(srlobs::obs_bwd_h2_kernel<7>); break;
       case 8: go(srlobs::obs_bwd_h2_kernel<8>); break;
+      case 19: go(srlobs::obs_bwd_h2_kernel<19>); break;
+      case 23: go(srlobs::obs_bwd_h2_kernel<23>); break;
       case 12: go(srlobs::obs_bwd_h2_kernel<12>); break;
       case 15: go(srlobs::obs_bwd_h2_kernel<15>); break;
       default: go(srlobs::obs_bwd_h2_kernel<0>);

@@ -39,7 +39,7 @@ constexpr int kSampleBytes = (kChunks + 1) * 16;  // an ODD number of chunks bet
 static_assert(kChunks % 2 == 0 && kChunks <= 64, "one LDS-DMA instruction per sample");
 constexpr int kStageBytes = kTile * kSampleBytes;
 constexpr int kStages = 3;
-constexpr int kMeta = 5;                     // tiles of per-sample records in flight: the one computed .. four ahead
+constexpr int kMeta = 8;                     // ring of per-sample record tiles: fetched five tiles ahead of the one computed
 
 struct FwdH2Args {
   const uint8_t* frames;     // [slot][GH][GW][64] uint8 (space-to-depth'd stacks)
@@ -55,7 +55,7 @@ struct FwdH2Args {
   float* y_scale;
   uint32_t* y_mask;          // [n][P]
   float* y_absmax;
-  int GW, OW, OH, P, act;
+  int GW, OW, OH, P, act, nsplit;
 };
 
 #ifdef __HIPCC__
@@ -173,70 +173,79 @@ __global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void obs_fwd_h2_k
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds, ldsm = lds0 + kStages * kStageBytes;
 
-  const int nbx = a.OW / kBlkW, nblk = (a.OH / kBlkH) * nbx;
+  // a workgroup = one block of positions x one of nsplit ranges of the launch's 32-sample tiles
+  const int nbx = a.OW / kBlkW;
+  const int blk = blockIdx.x / a.nsplit, split = blockIdx.x % a.nsplit;
   const long ntiles = (a.n + kTile - 1) / kTile;
-  const long units = (long)nblk * ntiles;
-  const long u0 = units * blockIdx.x / gridDim.x, u1 = units * (blockIdx.x + 1) / gridDim.x;
-  if (u0 >= u1) return;
+  const long t0 = ntiles * split / a.nsplit, t1 = ntiles * (split + 1) / a.nsplit;
+  const int nu = (int)(t1 - t0);
+  if (nu <= 0) return;
   const float oscale = srlh2::h2_scale_for(*a.bound);
   if (blockIdx.x == 0 && tid == 0) *a.y_scale = oscale;
 
-  // DMA: one instruction = one sample's 36 chunks (3 rows x 12), lane = chunk
+  // DMA: one instruction = one sample's 60 chunks (3 rows x 20) of the block's frame window, lane = chunk
   const bool dma_lane = lane < kChunks;
-  const uint32_t dvoff = (uint32_t)((lane / kRowChunks) * (a.GW * 64) + (lane % kRowChunks) * 16);
+  const uint32_t blkoff = (uint32_t)(((blk / nbx) * kBlkH * a.GW + (blk % nbx) * kBlkW) * 64 +
+                                     (lane / kRowChunks) * (a.GW * 64) + (lane % kRowChunks) * 16);
   // fragment reads: patch bytes 32 c + 16 h of this wave's position (py, px) of the block: row py + (c >> 2), chunk 4 px + 2 (c & 3) + h
   const int py = wave / kBlkW, px = wave % kBlkW;
   const uint32_t rdbase = (uint32_t)(l31 * kSampleBytes + (py * kRowChunks + px * 4 + h) * 16);
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(a.y_h2, 0, (int)(a.n * (long)a.P * 128), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_msk = __builtin_amdgcn_make_buffer_rsrc(a.y_mask, 0, (int)(a.n * (long)a.P * 4), 0x00020000);
 
-  uint4 wf[32];  // [k-block][piece]: this position's folded weights, A-operand fragments
-  int cur_blk = -1, pos = 0, ent = 0;
   float* const tb = tabs + wave * 96;
-  int issued = 0;                        // VMEM operations this wavefront has issued through asm / buffer builtins
-  int mark0 = 0, mark1 = 0, mark2 = 0;   // `issued` right after the DMA of the tile in that stage
-  const uint4* const wq = a.wq;
-  const float* const g_winv = a.winv;
-  const float* const g_S = a.S;
-  const float* const g_b2 = a.b2;
-  const int OW = a.OW, OH = a.OH, P = a.P;
+  const int P = a.P;
   const uint8_t* const frames = a.frames;
-  const uint4* const meta = a.meta;
+  const uint4* const meta = a.meta + t0 * kTile;
   const long img_stride = a.img_stride, nsamp = a.n;
-  const int GW = a.GW;
-  // Cursors instead of divisions (a 64-bit division is hundreds of instructions): (block, tile) of the tile being computed, of
-  // the tile whose frames are fetched (two ahead) and the tile whose records are fetched (four ahead), and their ring entries
-  struct Cur { int blk, tile, ent; };
-  auto advance = [&](Cur& c) __attribute__((always_inline)) {
-    if (++c.tile == (int)ntiles) { c.tile = 0; ++c.blk; }
-    if (++c.ent == kMeta) c.ent = 0;
+  const int oy = (blk / nbx) * kBlkH + py, ox = (blk % nbx) * kBlkW + px;
+  const int pos = oy * a.OW + ox;
+  const int ent = ((oy & 1) * 2 + (ox & 1)) * ((a.OH / 2) * (a.OW / 2)) + (oy >> 1) * (a.OW / 2) + (ox >> 1);
+  // this position's folded weights, A-operand fragments [k-block][piece]: 128 registers for the whole launch
+  uint4 wf[32];
+  {
+    const uint4* src = a.wq + (long)pos * 2 * 16 * 64 + lane;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) wf[2 * kb + pl] = src[(pl * 16 + kb) * 64];
+    if (lane < 32) {
+      tb[lane] = a.winv[pos * kCout + lane];
+      tb[32 + lane] = a.S[pos * kCout + lane];
+      tb[64 + lane] = a.b2[pos * kCout + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wf[i].x), "+v"(wf[i].y), "+v"(wf[i].z), "+v"(wf[i].w));
+  }
+  // Every tile issues the same memory operations in the same order -- [records of tile j + 5 (wavefront 0)] [frames of tile
+  // j + 2: four samples per wavefront] [five stores of tile j] -- past the end of the range the last tile's again, so that the
+  // s_waitcnt in front of a tile's frames is a constant.  (It was a count kept in registers and a 25-way branch tree per wait,
+  // with cursors over (block, tile) units: 147 us of the kernel's 447 ran without any load, store or MFMA in it.)
+  auto issue_meta = [&](int j) __attribute__((always_inline)) {   // records of tile j -> ring entry j & 7
+    if (wave == 0) {
+      const int jc = j < nu ? j : nu - 1;
+      if (lane < kTile) obs_dma(ldsm + (uint32_t)(j & 7) * (kTile * 16), meta + jc * kTile + lane);
+    }
   };
-  Cur cc{(int)(u0 / ntiles), (int)(u0 % ntiles), 0}, cd = cc, cm = cc;
-  // the tile's 32 records -> ring entry: wavefront 0 only, lanes 0..31
-#define SRL_OBS_META()                                                                                \
-  do {                                                                                                \
-    if (wave == 0) {                                                                                  \
-      if (lane < kTile) obs_dma(ldsm + (uint32_t)cm.ent * (kTile * 16), meta + (long)cm.tile * kTile + lane); \
-      issued += 1;                                                                                    \
-    }                                                                                                 \
-    advance(cm);                                                                                      \
-  } while (0)
-  // the tile's frames: 8 samples per wavefront, the slot read from the ring (the same address in every lane: a broadcast)
-#define SRL_OBS_DMA(STAGE)                                                                            \
-  do {                                                                                                \
-    const long blkoff_ = ((long)((cd.blk / nbx) * kBlkH) * GW + (cd.blk % nbx) * kBlkW) * 64 + dvoff; \
-    constexpr int per_ = kTile / kWaves;                                                              \
-    const uint4* m_ = metal + cd.ent * kTile + per_ * wave;                                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < per_; ++i_) {                                                \
-      const uint32_t slot_ = m_[i_].x;                    \
-      if (dma_lane && !(DBG & 4))                                                                     \
-        obs_dma(lds0 + (STAGE) * kStageBytes + (per_ * wave + i_) * kSampleBytes, frames + (long)slot_ * img_stride + blkoff_); \
-    }                                                                                                 \
-    issued += per_;                                                                                   \
-    if ((STAGE) == 0) mark0 = issued;                                                                 \
-    else if ((STAGE) == 1) mark1 = issued;                                                            \
-    else mark2 = issued;                                                                              \
-    advance(cd);                                                                                      \
+  // slots of the wavefront's four samples of tile j, from the ring (uniform addresses: broadcasts) -> scalar registers
+  uint32_t slot[4] = {0, 0, 0, 0};
+  auto read_slots = [&](int j) __attribute__((always_inline)) {
+    const uint4* m_ = metal + (j & 7) * kTile + 4 * wave;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) slot[i] = __builtin_amdgcn_readfirstlane(m_[i].x);
+  };
+  auto issue = [&](int j, int stage_j) __attribute__((always_inline)) {
+    issue_meta(j + 3);
+    if (dma_lane && !(DBG & 4)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        obs_dma_s(lds0 + stage_j * kStageBytes + (4 * wave + i) * kSampleBytes, frames + (long)slot[i] * img_stride, blkoff);
+    }
+  };
+#define SRL_OBS_WAIT(N0, N)                                                                 \
+  do {                                                                                      \
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(" #N0 ")" ::: "memory");                   \
+    else asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                              \
   } while (0)
 
   // epilogue of a tile: lane = sample 32 tilep + l31 (both halves), register r = channel (r & 3) + 8 (r >> 2) + 4 h
@@ -281,52 +290,33 @@ __global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void obs_fwd_h2_k
     bits_ |= (uint32_t)__shfl_xor((int)bits_, 32);                                                                        \
     const uint32_t moff = (ok_ && h == 0) ? (uint32_t)(((n0_ + l31) * (long)P + pos) * 4) : 0x80000000u;                 \
     __builtin_amdgcn_raw_buffer_store_b32(bits_, r_msk, moff, 0, 0);                                                      \
-    issued += 5;                                                                                                          \
   } while (0)
 
   float amx = 0.f;
-  const int nu = (int)(u1 - u0);
-  for (int m = 0; m < 4 && m < nu; ++m) SRL_OBS_META();
+  for (int m = 0; m < 5; ++m) issue_meta(m);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  SRL_OBS_DMA(0);
-  if (nu > 1) SRL_OBS_DMA(1);
+  for (int j = 0; j < 2; ++j) {   // the two tiles ahead of the loop, with the five (dropped) stores of a tile each: the same counts
+    read_slots(j);
+    issue(j, j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, r_out, 0x80000000u + 16 * i, 0, 0);   // (distinct: not merged)
+    }
+    __builtin_amdgcn_raw_buffer_store_b32(0u, r_msk, 0x80000000u, 0, 0);
+  }
+  read_slots(2);
   int stage = 0;
   for (int it = 0; it < nu; ++it) {
-    obs_wait_vm_dyn(issued - (stage == 0 ? mark0 : stage == 1 ? mark1 : mark2));
+    SRL_OBS_WAIT(15, 14);  // behind the frames of tile it: the stores of it - 2 and one tile's [records] frames stores
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (it + 4 < nu) SRL_OBS_META();               // (ahead of the frames below: their mark covers it two tiles on)
-    if (it + 2 < nu) {
-      if (stage == 0) SRL_OBS_DMA(2);              // into the stage the previous tile has just left
-      else if (stage == 1) SRL_OBS_DMA(0);
-      else SRL_OBS_DMA(1);
-    }
-    const int blk = cc.blk;
-    if (blk != cur_blk) {
-      const int oy = (blk / nbx) * kBlkH + py, ox = (blk % nbx) * kBlkW + px;
-      pos = oy * OW + ox;
-      ent = ((oy & 1) * 2 + (ox & 1)) * ((OH / 2) * (OW / 2)) + (oy >> 1) * (OW / 2) + (ox >> 1);
-      const uint4* src = wq + (long)pos * 2 * 16 * 64 + lane;
-#pragma unroll
-      for (int kb = 0; kb < 16; ++kb)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) wf[2 * kb + pl] = src[(pl * 16 + kb) * 64];
-      if (lane < 32) {
-        tb[lane] = g_winv[pos * kCout + lane];
-        tb[32 + lane] = g_S[pos * kCout + lane];
-        tb[64 + lane] = g_b2[pos * kCout + lane];
-      }
-      cur_blk = blk;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wf[i].x), "+v"(wf[i].y), "+v"(wf[i].z), "+v"(wf[i].w));
-    }
-    const int tile_now = cc.tile;
+    issue(it + 2, stage == 0 ? 2 : stage - 1);   // into the stage the previous tile has just left
+    const int tile_now = (int)t0 + it;
     const uint8_t* sb = lds + stage * kStageBytes + rdbase;
-    const uint4 mrec = metal[cc.ent * kTile + l31];
+    const uint4 mrec = metal[(it & 7) * kTile + l31];
     const float rv = __uint_as_float(mrec.y), mean_n = __uint_as_float(mrec.z);
-    const float cen = rintf(mean_n);
-    const float mv = -(mean_n - cen) * rv;
-    union { _Float16 f[2]; uint32_t u; } nc;
-    nc.f[0] = nc.f[1] = (_Float16)(-(1024.f + cen));
+    const float mv = -(mean_n - rintf(mean_n)) * rv;
+    const uint32_t ncu = mrec.w;   // -(1024 + round(mean)) as two f16
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -334,10 +324,10 @@ __global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void obs_fwd_h2_k
     for (int c = 0; c < ((DBG & 2) ? 0 : 8); ++c) {
       const uint4 q = *reinterpret_cast<const uint4*>(sb + (c >> 2) * (kRowChunks * 16) + (c & 3) * 32);
       union { uint32_t u[4]; f16x8 v; } x0, x1;
-      obs_bytes_to_f16(q.x, nc.u, x0.u[0], x0.u[1]);
-      obs_bytes_to_f16(q.y, nc.u, x0.u[2], x0.u[3]);
-      obs_bytes_to_f16(q.z, nc.u, x1.u[0], x1.u[1]);
-      obs_bytes_to_f16(q.w, nc.u, x1.u[2], x1.u[3]);
+      obs_bytes_to_f16(q.x, ncu, x0.u[0], x0.u[1]);
+      obs_bytes_to_f16(q.y, ncu, x0.u[2], x0.u[3]);
+      obs_bytes_to_f16(q.z, ncu, x1.u[0], x1.u[1]);
+      obs_bytes_to_f16(q.w, ncu, x1.u[2], x1.u[3]);
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -348,12 +338,12 @@ __global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void obs_fwd_h2_k
         }
     }
     SRL_OBS_FINISH(acc, rv, mv, tile_now);
-    advance(cc);
+    read_slots(it + 3);  // for the next tile's fetch (its records came in five tiles ahead): no LDS round trip behind the barrier
     stage = stage == kStages - 1 ? 0 : stage + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (a.y_absmax) srlgemm::absmax_commit(a.y_absmax, amx);
-#undef SRL_OBS_META
-#undef SRL_OBS_DMA
+#undef SRL_OBS_WAIT
 #undef SRL_OBS_FINISH
 }
 #endif  // __HIPCC__
@@ -367,16 +357,21 @@ __global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void obs_fwd_h2_k
 // ONE read hands a wavefront the 32-column x 16-sample B operand of a 32x32x16 MFMA (8 bytes per lane = 8 consecutive samples of
 // its column), converted in registers (a byte minus the sample's integer centre is exact in f16).  obs_bf16.h converts while
 // STAGING and keeps a 16-bit image of every patch in LDS (4 x the bytes; 63 % of its LDS cycles were bank conflicts).  dz' =
-// dz rstd_n is the A operand: the float32 rows come in by LDS-DMA too (a tile ahead), are split into THREE f16 pieces under the
-// power-of-two scale of the bound max |dz| max rstd (33 significand bits from the bound down: at 2^-15 of the bound and above
-// nothing float32 holds is dropped) into a per-wavefront image, and fetched with ds_read_b64_tr_b16.  A wavefront = one position,
-// all 256 patch columns: 8 accumulator tiles, 24 MFMAs per 16 samples.
+// dz rstd_n is the A operand: the float32 rows come in by LDS-DMA too (three tiles ahead), are split into kPiecesB = 2 f16 pieces
+// under the power-of-two scale of the bound max |dz| max rstd -- what every h2 operand of the update carries (h2gemm.h: 22
+// significand bits; the bytes are exact, so a product drops nothing else) -- into a per-wavefront image, and fetched with
+// ds_read_b64_tr_b16.  A wavefront = one position, all 256 patch columns: 8 accumulator tiles, 16 MFMAs per 16 samples.
+// (Three pieces: + 51 us of MFMA time per 16 384-frame launch for 2^-33 instead of 2^-22 of an element; the vector and the matrix
+// instructions of a SIMD's two wavefronts were measured NOT to overlap here -- MFMA-only 153 us + vector-only 98 us = 324 us of
+// the launch without memory traffic, whether interleaved inside each wavefront's stream, alternated between the two wavefronts
+// of a SIMD, or with the accumulators in AGPRs -- so work removed is time removed.)
 constexpr int kTileB = 16;                                  // samples per tile of the weight gradient (= the MFMA's k)
 constexpr int kSampleBytesB = (kChunks + 2) * 16;           // 62 chunks = 248 dwords = 8 x 31 banks: 8 samples x 32 bytes of a read
 constexpr int kStageBytesB = kTileB * kSampleBytesB;        //   of 32 lanes fall on 64 different banks
+constexpr int kPiecesB = 2;                                 // f16 pieces of dz' (as every h2 operand: 22 significand bits)
 constexpr int kStagesB = 4;                                 // frames and dz rows are fetched three tiles ahead
 constexpr int kMetaB = 8;                                   // records seven tiles ahead: in LDS a tile before the frames' fetch reads the slots
-constexpr int kLdsB = kStagesB * kStageBytesB + kMetaB * kTileB * 16 + kWaves * (3 * 1024 + kStagesB * 2048);
+constexpr int kLdsB = kStagesB * kStageBytesB + kMetaB * kTileB * 16 + kWaves * (kPiecesB * 1024 + kStagesB * 2048 + 64);
 
 struct BwdH2Args {
   const uint8_t* frames;
@@ -394,12 +389,12 @@ struct BwdH2Args {
 };
 
 #ifdef __HIPCC__
-// The schedule of a workgroup, tile it of its sample range: [wait: frames of it landed | barrier | fetch of tile it + 3 (records of
-// it + 6, frames, dz rows) | A fragments of dz'(it) from the wavefront's image | dz(it + 1): float32 rows -> three f16 planes, into
-// the same image (the fragments are in registers by then), in one basic block with the 24 MFMAs of tile it so that the compiler
-// interleaves the two].  Every tile issues the SAME number of memory operations in the same order (past the end: the last tile
-// again), which makes the two s_waitcnt of a tile compile-time constants.
-// DBG (timing experiments, wrong results): 1 no frame DMA, 2 no dz DMA, 4 no B reads / conversions / MFMAs, 8 no dz staging
+// The schedule of a workgroup, tile it of its sample range: [wait: all but the last tile's fetch landed | barrier | fetch of tile
+// it + 3 (records of it + 7, frames, dz rows) | the MFMAs of tile it, whose A fragments and first B operands are in registers when
+// the barrier opens; in their gaps the conversions of the next B operands, dz(it + 1): float32 rows -> f16 planes -> the next
+// tile's A fragments, and the LDS reads of what comes after].  Every tile issues the SAME number of memory operations in the same
+// order (past the end: the last tile again), which makes the s_waitcnt of a tile a compile-time constant.
+// DBG (timing experiments, wrong results): 1 no frame DMA, 2 no dz DMA, 4 no MFMAs, 8 dz staged as zeros, 16 no vector work between the MFMAs
 template <int DBG = 0>
 __global__ __launch_bounds__(512, 1) void obs_bwd_h2_kernel(BwdH2Args a) {
   extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
@@ -409,8 +404,8 @@ __global__ __launch_bounds__(512, 1) void obs_bwd_h2_kernel(BwdH2Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds, ldsm = lds0 + kStagesB * kStageBytesB;
   constexpr int kPlanes0 = kStagesB * kStageBytesB + kMetaB * kTileB * 16;
-  uint8_t* const myp = lds + kPlanes0 + wave * 3072;
-  constexpr int kRaw0 = kPlanes0 + kWaves * 3072;
+  uint8_t* const myp = lds + kPlanes0 + wave * (kPiecesB * 1024);
+  constexpr int kRaw0 = kPlanes0 + kWaves * (kPiecesB * 1024);
   const uint8_t* const myraw = lds + kRaw0 + wave * (kStagesB * 2048);
   const uint32_t ldsraw = lds0 + kRaw0 + wave * (kStagesB * 2048);
 
@@ -490,7 +485,7 @@ __global__ __launch_bounds__(512, 1) void obs_bwd_h2_kernel(BwdH2Args a) {
   // for the main loop to place between its MFMAs.
   float st_rss, st_mcs, st_okf;
   f32x2 st_d[4];
-  uint32_t st_pl[3][4];
+  uint32_t st_pl[kPiecesB][4];
   auto stage_load = [&](int j) __attribute__((always_inline)) {
     const uint4 mrec = metal[(j & 7) * kTileB + ds_s];
     const bool ok = (t0 + j) * kTileB + ds_s < nsamp && j < nu && !((DBG & 8) && j > 3);
@@ -502,30 +497,31 @@ __global__ __launch_bounds__(512, 1) void obs_bwd_h2_kernel(BwdH2Args a) {
     const float4 d0 = rp[0], d1 = rp[1];
     st_d[0] = f32x2{d0.x, d0.y}; st_d[1] = f32x2{d0.z, d0.w}; st_d[2] = f32x2{d1.x, d1.y}; st_d[3] = f32x2{d1.z, d1.w};
   };
-  // a pair of channels in three steps of four vector instructions (u = 0, 1, 2)
-  typedef decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) pkh_t;
+  // a pair of channels in kPiecesB steps of four vector instructions
+  typedef _Float16 st_h2t __attribute__((ext_vector_type(2)));
   f32x2 st_r;
   auto stage_unit = [&](int i, int u) __attribute__((always_inline)) {
-    union { pkh_t hv; uint32_t w; } c;
+    if (u >= kPiecesB) return;
+    union { st_h2t hv; uint32_t w; } c;
     if (u == 0) {
       rsum[i] += st_d[i] * st_okf;
       st_r = st_d[i] * st_rss;
       csum[i] += st_r * st_mcs;
     } else {
-      // round-to-zero pieces: the residuals stay exact (v - h0 has fewer bits than v), 10 + 10 + 11 bits below the leading one
+      // the residual of a rounded piece is exact in float32 (v - h0 has fewer bits than v): 11 + 11 bits from the leading one down
       c.w = st_pl[u - 1][i];
       st_r = st_r - f32x2{(float)c.hv[0], (float)c.hv[1]};
     }
-    c.hv = __builtin_amdgcn_cvt_pkrtz(st_r[0], st_r[1]);
+    c.hv = __builtin_convertvector(st_r, st_h2t);
     st_pl[u][i] = c.w;
   };
   auto stage_pair = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) stage_unit(i, u);
+    for (int u = 0; u < kPiecesB; ++u) stage_unit(i, u);
   };
   auto stage_store = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < kPiecesB; ++p)
       *reinterpret_cast<uint4*>(pdst + p * 1024) = make_uint4(st_pl[p][0], st_pl[p][1], st_pl[p][2], st_pl[p][3]);
   };
   auto stage_dz = [&](int j) __attribute__((always_inline)) {
@@ -546,12 +542,16 @@ __global__ __launch_bounds__(512, 1) void obs_bwd_h2_kernel(BwdH2Args a) {
   typedef int v2i __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) v2i lds_v2i;
   typedef _Float16 h2t __attribute__((ext_vector_type(2)));
-  // centres of a tile's samples 8 h .. 8 h + 7, as f16 pairs -(1024 + c)
+  // centres of a tile's samples 8 h .. 8 h + 7, as f16 pairs -(1024 + c): the records' fourth words, gathered by the wavefront
+  // into 32 contiguous bytes of its own (two tiles ahead), so that a lane fetches its four pairs with one ds_read_b128
   uint32_t negc[4];
+  uint8_t* const mycen = lds + kRaw0 + kWaves * (kStagesB * 2048) + wave * 64;
+  auto cen_write = [&](int j) __attribute__((always_inline)) {
+    if (lane < kTileB) *reinterpret_cast<uint16_t*>(mycen + (j & 1) * 32 + lane * 2) = (uint16_t)metal[(j & 7) * kTileB + lane].w;
+  };
   auto load_negc = [&](int j) __attribute__((always_inline)) {
-    const uint4* mr = metal + (j & 7) * kTileB + 8 * h;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) negc[i] = __builtin_amdgcn_perm(mr[2 * i + 1].w, mr[2 * i].w, 0x05040100u);
+    const uint4 c = *reinterpret_cast<const uint4*>(mycen + (j & 1) * 32 + 16 * h);
+    negc[0] = c.x; negc[1] = c.y; negc[2] = c.z; negc[3] = c.w;
   };
   // bytes (b0 .. b7) of a transposed read = samples 8 h .. 8 h + 7 of this lane's column -> b - c_sample, exact in f16
   // (0x6400 | b = 1024 + b); half a read (4 samples) per call: four vector instructions
@@ -564,8 +564,29 @@ __global__ __launch_bounds__(512, 1) void obs_bwd_h2_kernel(BwdH2Args a) {
     o0 = w0.u; o1 = w1.u;
   };
   union XB { uint32_t u[4]; f16x8 v; };
-  XB xb0[4], xb1[4];   // B operands of patch row 0 / row 1, four column tiles each
-  v2i raw[4];
+  // B operands, two column tiles at a time.  A tile's 24 MFMAs come in four groups of six (patch row 0 tiles 0-1, 2-3, row 1
+  // tiles 0-1, 2-3); while a group runs from one pair, the next group's bytes are converted into the other.
+  XB xbA[2], xbB[2];
+  v2i raw[2];
+  auto read_raw = [&](int j, int q) __attribute__((always_inline)) {   // group q (0..3) of tile j
+    const uint8_t* sb = lds + (j & 3) * kStageBytesB + bbase + (q >> 1) * (kRowChunks * 16) + (q & 1) * 64;
+    raw[0] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(sb));
+    raw[1] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(sb + 32));
+  };
+  auto conv_unit = [&](XB* xb, int u) __attribute__((always_inline)) {   // u = 2 * tile + half
+    if (u & 1) conv_half((uint32_t)raw[u >> 1].y, negc[2], negc[3], xb[u >> 1].u[2], xb[u >> 1].u[3]);
+    else conv_half((uint32_t)raw[u >> 1].x, negc[0], negc[1], xb[u >> 1].u[0], xb[u >> 1].u[1]);
+  };
+  struct AF { f16x8 p[kPiecesB]; };   // A fragments: the pieces of dz'
+  auto read_af = [&](AF& af) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < kPiecesB; ++p) {
+      union { s16x4 s[2]; f16x8 v; } u;
+      u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + p * 1024));
+      u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + p * 1024 + 4 * 64));
+      af.p[p] = u.v;
+    }
+  };
 
   for (int m = 0; m < 4; ++m) issue_meta(m);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -576,73 +597,61 @@ __global__ __launch_bounds__(512, 1) void obs_bwd_h2_kernel(BwdH2Args a) {
   read_slots(3);
   SRL_OBSB_WAIT(10, 8);  // behind dz(0): two tiles of 5 / 4 operations
   asm volatile("s_barrier" ::: "memory");  // (the frames of tile 0 came in through all eight wavefronts)
+  AF afA, afB;
   stage_dz(0);
+  read_af(afA);
+  cen_write(0);
+  cen_write(1);
   load_negc(0);
+  read_raw(0, 0);
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt) {
-    const v2i r = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(lds + bbase + tt * 32));
-    conv_half((uint32_t)r.x, negc[0], negc[1], xb0[tt].u[0], xb0[tt].u[1]);
-    conv_half((uint32_t)r.y, negc[2], negc[3], xb0[tt].u[2], xb0[tt].u[3]);
-  }
+  for (int u = 0; u < 4; ++u) conv_unit(xbA, u);
+  read_raw(0, 1);
 
-  // Tile it: the MFMAs of patch row 0 (its B operands were converted under the previous tile's MFMAs), then those of row 1.
-  // Between them, in the order written (sched_barrier: nothing moves across) and at most two four-instruction units per gap: the
-  // conversions of row 1, of row 0 of tile it + 1, and the staging of dz(it + 1).  An MFMA occupies the matrix pipeline for 32
-  // cycles and the vector issue for 8 of them; left to the compiler, the vector work came as one block ahead of 24 back-to-back
-  // MFMAs and the two wavefronts of a SIMD, in step through the barrier, queued for the vector unit and then for the matrix unit
-  // (both 41-45 % busy, one after the other).
-  for (int it = 0; it < nu; ++it) {
+  // Tile it.  Everything its first MFMAs need is in registers when the barrier opens (the A fragments and the first pair of B
+  // operands were fetched under the previous tile's MFMAs); between the MFMAs, in the order written (sched_barrier: nothing moves
+  // across) and at most two four-instruction units per gap: the conversions of the next group, the staging of dz(it + 1), the
+  // LDS reads of what comes after.  An MFMA occupies the matrix pipeline for 32 cycles and the vector issue for 8 of them; left
+  // to the compiler, the vector work came as one block ahead of 24 back-to-back MFMAs and the two wavefronts of a SIMD, in step
+  // through the barrier, queued for the vector unit and then for the matrix unit (both 41-45 % busy, one after the other).
+  auto tile = [&](int it, const AF& af, AF& afn) __attribute__((always_inline)) {
     SRL_OBSB_WAIT(5, 4);  // all but the last tile's fetch: frames and dz of tile it + 1 are in
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     issue(it + 3);
-    f16x8 af[3];  // A fragments: three pieces of dz'(it)
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      union { s16x4 s[2]; f16x8 v; } u;
-      u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + p * 1024));
-      u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + p * 1024 + 4 * 64));
-      af[p] = u.v;
-    }
-    const uint8_t* sb = lds + (it & 3) * kStageBytesB + bbase + kRowChunks * 16;        // row 1 of tile it
-    const uint8_t* sbn = lds + ((it + 1) & 3) * kStageBytesB + bbase;                    // row 0 of tile it + 1
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) raw[tt] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(sb + tt * 32));
-    stage_load(it + 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(DBG & 4)) {
 #pragma unroll
-      for (int g = 0; g < 24; ++g) {
-        if (g < 12) acc[g & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[g >> 2], xb0[g & 3].v, acc[g & 3], 0, 0, 0);
-        else acc[4 + (g & 3)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[(g - 12) >> 2], xb1[g & 3].v, acc[4 + (g & 3)], 0, 0, 0);
-        // conversions
-        if (g < 8) {
-          const int tt = g >> 1;
-          if (g & 1) conv_half((uint32_t)raw[tt].y, negc[2], negc[3], xb1[tt].u[2], xb1[tt].u[3]);
-          else conv_half((uint32_t)raw[tt].x, negc[0], negc[1], xb1[tt].u[0], xb1[tt].u[1]);
-        } else if (g == 8) {
-#pragma unroll
-          for (int tt = 0; tt < 4; ++tt) raw[tt] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i*)(sbn + tt * 32));
-          load_negc(it + 1);
-        } else if (g >= 12 && g < 20) {
-          const int tt = (g - 12) >> 1;
-          if (g & 1) conv_half((uint32_t)raw[tt].y, negc[2], negc[3], xb0[tt].u[2], xb0[tt].u[3]);
-          else conv_half((uint32_t)raw[tt].x, negc[0], negc[1], xb0[tt].u[0], xb0[tt].u[1]);
-        } else if (g == 20) {
-          read_slots(it + 4);  // for the next tile's fetch (its records came in seven tiles ahead): no LDS round trip behind the barrier
-        }
-        // staging: pairs 0, 1 in gaps 0-5, pair 2 in gaps 9-11, pair 3 in gaps 12-14, the stores in gap 15
-        if (g < 6) stage_unit(g / 3, g % 3);
-        else if (g >= 9 && g < 12) stage_unit(2, g - 9);
-        else if (g >= 12 && g < 15) stage_unit(3, g - 12);
-        else if (g == 15) stage_store();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) stage_pair(i);
-      stage_store();
-      read_slots(it + 4);
+    for (int g = 0; g < 24; ++g) {
+      const int k = g / 6, j = g % 6;
+      XB* const cur = (k & 1) ? xbB : xbA;
+      XB* const nxt = (k & 1) ? xbA : xbB;
+      if (!(DBG & 4) && (j >> 1) < kPiecesB) acc[2 * k + (j & 1)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af.p[j >> 1], cur[j & 1].v, acc[2 * k + (j & 1)], 0, 0, 0);
+      if (DBG & 16) {
+      } else if (j < 4) conv_unit(nxt, j);                                     // group k + 1 (k = 3: group 0 of tile it + 1)
+      else if (j == 4) read_raw(k < 2 ? it : it + 1, (k + 2) & 3);             // the bytes of group k + 2
+      // staging of dz(it + 1), three units per pair of channels; the centres of tile it + 1 before its first conversions
+      if (DBG & 16) {
+      } else if (g == 0) stage_load(it + 1);
+      else if (g == 1) stage_unit(0, 0);
+      else if (g == 3) stage_unit(0, 1);
+      else if (g == 4) stage_unit(0, 2);
+      else if (g == 5) { stage_unit(1, 0); cen_write(it + 2); }
+      else if (g == 7) stage_unit(1, 1);
+      else if (g == 9) stage_unit(1, 2);
+      else if (g == 10) stage_unit(2, 0);
+      else if (g == 11) stage_unit(2, 1);
+      else if (g == 13) stage_unit(2, 2);
+      else if (g == 15) stage_unit(3, 0);
+      else if (g == 16) { stage_unit(3, 1); load_negc(it + 1); }
+      else if (g == 17) stage_unit(3, 2);
+      else if (g == 18) stage_store();
+      else if (g == 20) read_af(afn);
+      else if (g == 23) read_slots(it + 4);  // for the next tile's fetch (its records came in seven tiles ahead)
+      __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  for (int it = 0; it < nu; it += 2) {
+    tile(it, afA, afB);
+    if (it + 1 < nu) tile(it + 1, afB, afA);
   }
 #undef SRL_OBSB_WAIT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
