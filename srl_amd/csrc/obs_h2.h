@@ -251,40 +251,56 @@ __global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void obs_fwd_h2_k
   // epilogue of a tile: lane = sample 32 tilep + l31 (both halves), register r = channel (r & 3) + 8 (r >> 2) + 4 h
 #define SRL_OBS_FINISH(accp, rvp, mvp, tilep)                                                                                                \
   do {                                                                                                                    \
+    typedef float f2_ __attribute__((ext_vector_type(2)));                                                                \
+    typedef _Float16 hh2_ __attribute__((ext_vector_type(2)));                                                            \
     const long n0_ = (long)tilep * kTile;                                                                                 \
     const bool ok_ = n0_ + l31 < nsamp;                                                                                   \
-    float v_[16];                                                                                                         \
     uint32_t bits_ = 0;                                                                                                   \
+    uint32_t c4[4][4];                                                                                                    \
+    /* pairs of channels on the packed float32 instructions: 8 vector instructions per value (14 one value at a time; the  \
+       vector and the matrix instructions of a SIMD do not overlap here, see the weight gradient below) */                 \
     _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                                                    \
       const float4 i4 = *reinterpret_cast<const float4*>(tb + 8 * g4 + 4 * h);                                            \
       const float4 s4 = *reinterpret_cast<const float4*>(tb + 32 + 8 * g4 + 4 * h);                                       \
       const float4 b4 = *reinterpret_cast<const float4*>(tb + 64 + 8 * g4 + 4 * h);                                       \
-      const float iv[4] = {i4.x, i4.y, i4.z, i4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};    \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                     \
-        float t = fmaf(rvp * iv[i], accp[4 * g4 + i], fmaf(mvp, sv[i], bv[i]));                                           \
-        if (ACT == 1) t = fmaxf(t, 0.f);                                                                                  \
-        else if (ACT == 2) t = tanhf(t);                                                                                  \
-        v_[4 * g4 + i] = t;                                                                                               \
-        if (ok_) amx = fmaxf(amx, fabsf(t));                                                                              \
-        bits_ |= (t > 0.f ? 1u : 0u) << (8 * g4 + 4 * h + i);                                                             \
+      const f2_ iv[2] = {{i4.x, i4.y}, {i4.z, i4.w}}, sv[2] = {{s4.x, s4.y}, {s4.z, s4.w}}, bv[2] = {{b4.x, b4.y}, {b4.z, b4.w}}; \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                     \
+        const f2_ a2 = {accp[4 * g4 + 2 * i], accp[4 * g4 + 2 * i + 1]};                                                  \
+        f2_ t = (iv[i] * rvp) * a2 + (sv[i] * mvp + bv[i]);   /* contracted to fused multiply-adds, as one value at a time */ \
+        const int k_ = 8 * g4 + 4 * h + 2 * i;                                                                            \
+        if (ACT == 1) {                                                                                                   \
+          t[0] = fmaxf(t[0], 0.f); t[1] = fmaxf(t[1], 0.f);                                                               \
+          /* rows past the batch repeat its last sample (obs_meta_kernel): their values change no maximum */              \
+          amx = __builtin_fmaxf(__builtin_fmaxf(amx, t[0]), t[1]);                                                        \
+          /* t >= +0: positive <=> a non-zero word */                                                                      \
+          const uint32_t p0_ = __float_as_uint(t[0]) < 1u ? __float_as_uint(t[0]) : 1u, p1_ = __float_as_uint(t[1]) < 1u ? __float_as_uint(t[1]) : 1u; \
+          bits_ |= p0_ << k_;                                                                                             \
+          bits_ |= p1_ << (k_ + 1);                                                                                       \
+        } else {                                                                                                          \
+          if (ACT == 2) { t[0] = tanhf(t[0]); t[1] = tanhf(t[1]); }                                                       \
+          amx = fmaxf(amx, fmaxf(fabsf(t[0]), fabsf(t[1])));                                                              \
+          bits_ |= (t[0] > 0.f ? 1u : 0u) << k_;                                                                          \
+          bits_ |= (t[1] > 0.f ? 1u : 0u) << (k_ + 1);                                                                    \
+        }                                                                                                                 \
+        /* the two f16 pieces of the pair (srlh2::h2_split_pair, packed): t s exact (a power of two), h0 rounded, the     \
+           residual exact, h1 rounded */                                                                                  \
+        const f2_ vs = t * oscale;                                                                                        \
+        union { hh2_ v; uint32_t u; } h0_, h1_;                                                                           \
+        h0_.v = __builtin_convertvector(vs, hh2_);                                                                        \
+        const f2_ r_ = vs - f2_{(float)h0_.v[0], (float)h0_.v[1]};                                                        \
+        h1_.v = __builtin_convertvector(r_, hh2_);                                                                        \
+        /* value 4 g4 + 2 i (+ 1) of the lane: pair j = 2 g4 + i -> word (j & 3) of chunk 2 (j >> 2) (h0) / + 1 (h1) */     \
+        c4[2 * ((2 * g4 + i) >> 2)][(2 * g4 + i) & 3] = h0_.u;                                                            \
+        c4[2 * ((2 * g4 + i) >> 2) + 1][(2 * g4 + i) & 3] = h1_.u;                                                        \
       }                                                                                                                   \
     }                                                                                                                     \
-    uint4 c4[4];                                                                                                          \
-    srlh2::h2_split_pair(v_[0], v_[1], oscale, c4[0].x, c4[1].x);                                                         \
-    srlh2::h2_split_pair(v_[2], v_[3], oscale, c4[0].y, c4[1].y);                                                         \
-    srlh2::h2_split_pair(v_[4], v_[5], oscale, c4[0].z, c4[1].z);                                                         \
-    srlh2::h2_split_pair(v_[6], v_[7], oscale, c4[0].w, c4[1].w);                                                         \
-    srlh2::h2_split_pair(v_[8], v_[9], oscale, c4[2].x, c4[3].x);                                                         \
-    srlh2::h2_split_pair(v_[10], v_[11], oscale, c4[2].y, c4[3].y);                                                       \
-    srlh2::h2_split_pair(v_[12], v_[13], oscale, c4[2].z, c4[3].z);                                                       \
-    srlh2::h2_split_pair(v_[14], v_[15], oscale, c4[2].w, c4[3].w);                                                       \
     /* rows past the batch: an offset beyond the buffer drops the store -- the same number of stores whatever the tile.     \
        (Whole 128-byte lines per instruction, through an LDS transposition, were timed equal: the L2 merges the pieces;      \
        non-temporal stores, which do not merge, 15-65 % slower.) */                                                        \
     const uint32_t ooff = (ok_ && !(DBG & 1)) ? (uint32_t)(((n0_ + l31) * (long)P + ent) * 128 + h * 64) : 0x80000000u;    \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                                         \
-      u32x4 d = {c4[i].x, c4[i].y, c4[i].z, c4[i].w};                                                                     \
+      u32x4 d = {c4[i][0], c4[i][1], c4[i][2], c4[i][3]};                                                                 \
       __builtin_amdgcn_raw_buffer_store_b128(d, r_out, ooff + 16 * i, 0, 0);                                              \
     }                                                                                                                     \
     bits_ |= (uint32_t)__shfl_xor((int)bits_, 32);                                                                        \
