@@ -307,7 +307,7 @@ def recorded_counters(envs, T, chunk_rows):
         busy = cycles = valu = wait = wave = 0.0
         with open(mf[:-5] + ".csv") as f:
             for r in csv.DictReader(f):
-                if not any(sub in r["kernel"] for sub in ("gemm", "obs_fwd_bf16", "obs_bwd_bf16", "obs_fwd_h2", "h2conv", "h2wgrad")) or not r["SQ_VALU_MFMA_BUSY_CYCLES"]:
+                if not any(sub in r["kernel"] for sub in ("gemm", "obs_fwd_bf16", "obs_bwd_bf16", "obs_fwd_h2", "obs_bwd_h2", "h2conv", "h2wgrad")) or not r["SQ_VALU_MFMA_BUSY_CYCLES"]:
                     continue
                 n = float(r["dispatches"])
                 busy += n * float(r["SQ_VALU_MFMA_BUSY_CYCLES"])
@@ -476,7 +476,7 @@ def main():
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12
         exe = g["executed"] / (g["ms"] * 1e-3) / 1e12
         roofline = dict(kernel="h2conv_kernel / h2wgrad_kernel / h2gemm_kernel / gemm3_kernel (Linear weight gradient) / obs_fwd_h2_kernel / "
-                               "obs_bwd_bf16_kernel: every contraction of one step (image-stationary convolutions on pre-split f16 "
+                               "obs_bwd_h2_kernel: every contraction of one step (image-stationary convolutions on pre-split f16 "
                                "activations, the Linear's products, the first layer on bytes): float32 operands and results "
                                "through 16-bit piece products on the f16 / bf16 matrix cores",
                         bound="mfma", achieved=round(ach, 2), unit="TFLOP/s", peak=PEAK_BF16_MFMA_TFLOPS,
@@ -487,13 +487,13 @@ def main():
                         emulation_ceiling_basis="16-bit peak / 3: a float32 multiply-add costs at least three piece products",
                         achieved_basis="algorithmic float32 flops (2*M*N*K of every contraction)",
                         executed_basis="16-bit MFMA flops issued: 3 x algorithmic for products of two f16 pieces per operand (every "
-                                       "convolution and Linear product), 2 x for the first layer's forward (bytes x two f16 weight "
-                                       "pieces), 3 x for its weight gradient (bytes x three bf16 pieces), 6 x where an operand range is "
-                                       "unknown (three bf16 pieces per operand)",
+                                       "convolution and Linear product), 2 x for the first layer (bytes x two f16 pieces of the folded "
+                                       "weights forward, of dz' in the weight gradient), 6 x where an operand range is unknown (three "
+                                       "bf16 pieces per operand)",
                         fp32_mfma_peak=PEAK_FP32_MFMA_TFLOPS, achieved_over_fp32_mfma_peak=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                         launches=g["calls"], ms_per_step=round(g["ms"], 3), flops_per_step=g["work"],
                         flops_per_env_step=g["work"] / (T * B), kernel_family_launches=dispatch,
-                        **recorded_traffic(("gemm", "obs_fwd_bf16", "obs_bwd_bf16", "obs_fwd_h2", "h2conv", "h2wgrad"), B, T, args.chunk_rows),
+                        **recorded_traffic(("gemm", "obs_fwd_bf16", "obs_bwd_bf16", "obs_fwd_h2", "obs_bwd_h2", "h2conv", "h2wgrad"), B, T, args.chunk_rows),
                         **recorded_counters(B, T, args.chunk_rows))
         # The same launches against the OTHER roof.  With float32 activations in HBM the convolution layers carry 60-75
         # algorithmic flop per byte, below the ~104 flop / byte at which 8 TB/s feed three piece products per multiply-add at

@@ -968,7 +968,8 @@ def conv2d_obs_bwd(d: ConvDesc, obs_ptr, is_u8, mean_ptr, rstd_ptr, gamma_ptr, b
     """``phase``: 3 = a call of its own; bit 0 opens / bit 1 closes an accumulation of the position sums over several calls (the
     chunks of one update then share one finalisation; ``srl_hip.h``).  ``dz_absmax_ptr``: device float >= max |dz| (selects the
     block kernel of ``csrc/obs_h2.h`` on the Atari geometry)."""
-    with _scope("conv_obs_bwd", _conv_flops(d), "obs"):
+    # with a bound of |dz| the Atari geometry runs obs_h2.h's weight gradient: bytes x two f16 pieces of dz'
+    with _scope("conv_obs_bwd", _conv_flops(d), "obs2" if dz_absmax_ptr and os.environ.get("SRL_OBS_BWD_H2BLOCK", "")[:1] != "0" else "obs"):
         _check(
             lib().srl_conv2d_obs_bwd(_stream(), ctypes.byref(d), obs_ptr, int(is_u8), int(channels_last), mean_ptr,
                                      rstd_ptr, gamma_ptr, beta_ptr, w_ptr, dz_ptr, dw_ptr, db_ptr, dgamma_ptr, dbeta_ptr,
