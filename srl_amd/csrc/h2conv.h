@@ -292,15 +292,23 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
   else { pix_step_y = GE::OW; pix_step_x = 1; }
   constexpr int PIXB = ROUTED ? GE::OCH * 4 : (GE::DST == H2D_PLANAR ? 16 : GE::OCH * 4);   // bytes per output pixel step
   const uint32_t lane_base = GE::SRC == H2S_ROWSWZ ? (uint32_t)(p * 128 + quad * 32) : (uint32_t)(quad * 2 * PLANE_B + p * 16);
-  // ROWSWZ: byte u of this table = 16 * sigma(P) for a pixel P = (block base, a multiple of 8) + p + u (mod 8)
-  uint32_t swz_lo = 0, swz_hi = 0;
+  // ROWSWZ: an entry U pixels on from the block's base lies at (base + 128 U) ^ x, x = 16 sigma(P) of the pixel P = base + p + U
+  // (mod 8): bits 4 and 6 of an address whose other low bits belong to the lane (bit 4 clear, bit 6 = quad >> 1; block, tap,
+  // stage and image offsets are multiples of 128) -- so per U mod 8 the XOR is a per-lane CONSTANT displacement, for both
+  // pieces (x and x ^ 16).  Eight displacements per piece, once per launch; a block adds its base to them (16 additions) and
+  // every fragment read is table register + immediate.  (Computed per read -- shift, mask, two XORs, two subtractions, two
+  // additions -- the address arithmetic was 300 of the 700 vector instructions beside a block's 144 MFMAs, and the vector
+  // and matrix instructions of a SIMD do not overlap here: obs_h2.h.)
+  int swz_d0[8], swz_d1[8];
   if (GE::SRC == H2S_ROWSWZ) {
+    static_assert(GE::SRC != H2S_ROWSWZ || SLOTM % 128 == 0, "slot stride must keep address bits 4-6");
+    const uint32_t a_ref = (uint32_t)(uintptr_t)(lds + lane_base);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int k = (p + u) & 7;
-      const uint32_t t = (uint32_t)((((k >> 1) & 1) | (((k >> 2) & 1) << 2)) * 16);
-      if (u < 4) swz_lo |= t << (8 * u);
-      else swz_hi |= t << (8 * (u - 4));
+      const uint32_t x = (uint32_t)((((k >> 1) & 1) | (((k >> 2) & 1) << 2)) * 16);
+      swz_d0[u] = u * 128 + (int)((a_ref ^ x) - a_ref);
+      swz_d1[u] = u * 128 + (int)((a_ref ^ x ^ 16u) - a_ref);
     }
   }
   float amax = 0.f;
@@ -378,16 +386,21 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
 #pragma unroll
     for (int c = 0; c < CGW; ++c) acc[c] = h2_f32x4{0.f, 0.f, 0.f, 0.f};
     h2_f16x8 xr[PD + 1][2];
+    const uint8_t* tq0[8];
+    const uint8_t* tq1[8];
+    if (GE::SRC == H2S_ROWSWZ) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        tq0[u] = xb + swz_d0[u];
+        tq1[u] = xb + swz_d1[u];
+      }
+    }
     auto fetch = [&](int kb) {
       const int t = kb / CB, c = kb - t * CB;
       if (GE::SRC == H2S_ROWSWZ) {
         const int U = GE::tap_u(t), u8 = U & 7;
-        const uint32_t x = ((u8 < 4 ? swz_lo : swz_hi) >> (8 * (u8 & 3))) & 0xffu;
-        const uint32_t a0 = (uint32_t)(uintptr_t)(xb + U * 128);
-        const uint8_t* q0 = xb + U * 128 + (long)((a0 ^ x) - a0);          // same address with bits 4 and 6 flipped by x
-        const uint8_t* q1 = xb + U * 128 + (long)((a0 ^ x ^ 16u) - a0);
-        xr[kb % (PD + 1)][0] = *reinterpret_cast<const h2_f16x8*>(q0);
-        xr[kb % (PD + 1)][1] = *reinterpret_cast<const h2_f16x8*>(q1);
+        xr[kb % (PD + 1)][0] = *reinterpret_cast<const h2_f16x8*>(tq0[u8] + (U - u8) * 128);
+        xr[kb % (PD + 1)][1] = *reinterpret_cast<const h2_f16x8*>(tq1[u8] + (U - u8) * 128);
       } else {
         const int off = (c * 8) * PLANE_B + GE::tap_u(t) * 16;
         xr[kb % (PD + 1)][0] = *reinterpret_cast<const h2_f16x8*>(xb + off);
