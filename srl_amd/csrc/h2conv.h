@@ -132,6 +132,15 @@ __device__ __forceinline__ uint32_t h2_xor32(uint32_t x, bool upper) {
 #define SRL_H2C_DBG 0
 #endif
 
+// k-blocks (tap, channel block) of a block's MFMA chain whose tap row is in the row mask RM (bit r = taps r * TPR .. + TPR - 1)
+template <int NKB> struct H2ActiveKb { int n; int kb[NKB]; };
+template <int RM, int NTAP, int CB, int TPR> constexpr H2ActiveKb<NTAP * CB> h2_active_kbs() {
+  H2ActiveKb<NTAP * CB> a{};
+  for (int kb = 0; kb < NTAP * CB; ++kb)
+    if ((RM >> ((kb / CB) / TPR)) & 1) a.kb[a.n++] = kb;
+  return a;
+}
+
 template <int ID, int NSLOT>
 __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
   using GE = H2Geo<ID>;
@@ -381,7 +390,11 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
   // state, wrong results -- so the order is written out in the source instead.)
   constexpr int PD = CB == 1 ? 3 : 2;
   const bool late = wid >= 4;
-  auto block = [&](const uint8_t* xb, h2_f32x4 (&pacc)[CGW], Meta& pm, const Meta& nm) {
+  // rows_c: the tap rows that can contribute to this block (a data gradient's first and last blocks of an image see only
+  // zero border through some: conv3's 9 x 9 outputs on the 11-wide grid skip 12 of their 63 tap-blocks); all rows otherwise
+  auto block = [&](auto rows_c, const uint8_t* xb, h2_f32x4 (&pacc)[CGW], Meta& pm, const Meta& nm) {
+    constexpr int TPR = ID == H2C_D3 ? 3 : GE::NTAP;   // taps per tap row (one row = everything, where nothing is skipped)
+    constexpr H2ActiveKb<NKB> AK = h2_active_kbs<decltype(rows_c)::value, GE::NTAP, CB, TPR>();
     h2_f32x4 acc[CGW];
 #pragma unroll
     for (int c = 0; c < CGW; ++c) acc[c] = h2_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -395,32 +408,34 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
         tq1[u] = xb + swz_d1[u];
       }
     }
-    auto fetch = [&](int kb) {
+    auto fetch = [&](int i) {   // i-th active k-block
+      const int kb = AK.kb[i];
       const int t = kb / CB, c = kb - t * CB;
       if (GE::SRC == H2S_ROWSWZ) {
         const int U = GE::tap_u(t), u8 = U & 7;
-        xr[kb % (PD + 1)][0] = *reinterpret_cast<const h2_f16x8*>(tq0[u8] + (U - u8) * 128);
-        xr[kb % (PD + 1)][1] = *reinterpret_cast<const h2_f16x8*>(tq1[u8] + (U - u8) * 128);
+        xr[i % (PD + 1)][0] = *reinterpret_cast<const h2_f16x8*>(tq0[u8] + (U - u8) * 128);
+        xr[i % (PD + 1)][1] = *reinterpret_cast<const h2_f16x8*>(tq1[u8] + (U - u8) * 128);
       } else {
         const int off = (c * 8) * PLANE_B + GE::tap_u(t) * 16;
-        xr[kb % (PD + 1)][0] = *reinterpret_cast<const h2_f16x8*>(xb + off);
-        xr[kb % (PD + 1)][1] = *reinterpret_cast<const h2_f16x8*>(xb + off + PLANE_B);
+        xr[i % (PD + 1)][0] = *reinterpret_cast<const h2_f16x8*>(xb + off);
+        xr[i % (PD + 1)][1] = *reinterpret_cast<const h2_f16x8*>(xb + off + PLANE_B);
       }
     };
 #pragma unroll
-    for (int kb = 0; kb < PD; ++kb) fetch(kb);
+    for (int i = 0; i < PD; ++i) fetch(i);
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      if (kb + PD < NKB) fetch(kb + PD);
-      if (kb == 1 && !late) epilogue(pacc, pm);
-      if (kb == NKB / 2 + 1 && late) epilogue(pacc, pm);
+    for (int i = 0; i < AK.n; ++i) {
+      if (i + PD < AK.n) fetch(i + PD);
+      if (i == 1 && !late) epilogue(pacc, pm);
+      if (i == AK.n / 2 + 1 && late) epilogue(pacc, pm);
+      const int kb = AK.kb[i];
       const int t = kb / CB, c = kb - t * CB;
       const int kw = GE::tap_k(t) * CB + c;
 #pragma unroll
       for (int cc = 0; cc < CGW; ++cc) {
-        acc[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][kw][1], xr[kb % (PD + 1)][0], acc[cc], 0, 0, 0);
-        acc[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][kw][0], xr[kb % (PD + 1)][1], acc[cc], 0, 0, 0);
-        acc[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][kw][0], xr[kb % (PD + 1)][0], acc[cc], 0, 0, 0);
+        acc[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][kw][1], xr[i % (PD + 1)][0], acc[cc], 0, 0, 0);
+        acc[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][kw][0], xr[i % (PD + 1)][1], acc[cc], 0, 0, 0);
+        acc[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cc][kw][0], xr[i % (PD + 1)][0], acc[cc], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -455,7 +470,19 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
         }
       }
       if (SRL_H2C_DBG & 2) { epilogue(pacc, pm); pm = nm; continue; }
-      block(slot + (il * GE::NPIX_L + bi * 16) * (GE::SRC == H2S_ROWSWZ ? 128 : 16), pacc, pm, nm);
+      const uint8_t* xb_ = slot + (il * GE::NPIX_L + bi * 16) * (GE::SRC == H2S_ROWSWZ ? 128 : 16);
+      if (ID == H2C_D3 && !(SRL_H2C_DBG & 8)) {
+        // output rows of block bi: entries 16 bi .. + 15 of the 11-wide grid; tap row ky reads dz row y - ky, which exists for
+        // 0 <= y - ky <= 6: block 0 (y = 0, 1) never through ky = 2, block 5 (y = 7, 8) never through ky = 0, block 6 (y = 8) only
+        // through ky = 2
+        static_assert(ID != H2C_D3 || (NB_IMG == 7 && GE::GW == 11 && GE::NTAP == 9), "row masks below are conv3's");
+        if (bi == 0) block(std::integral_constant<int, 0b011>{}, xb_, pacc, pm, nm);
+        else if (bi == 5) block(std::integral_constant<int, 0b110>{}, xb_, pacc, pm, nm);
+        else if (bi == 6) block(std::integral_constant<int, 0b100>{}, xb_, pacc, pm, nm);
+        else block(std::integral_constant<int, 0b111>{}, xb_, pacc, pm, nm);
+      } else {
+        block(std::integral_constant<int, (1 << 30) - 1>{}, xb_, pacc, pm, nm);
+      }
     }
   };
 
