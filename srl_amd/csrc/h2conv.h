@@ -351,8 +351,10 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
       for (int r = 0; r < 4; ++r) v[r] = (mbits >> r) & 1u ? v[r] : 0.f;
     }
     {
-      const float m4 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-      amax = fmaxf(amax, m.ok ? m4 : 0.f);
+      // (vector instructions cost what matrix instructions cost here, DESIGN 4: max3, and the exchanges below without selects)
+      const float m3 = __builtin_fmaxf(__builtin_fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2]));
+      const float m5 = __builtin_fmaxf(__builtin_fmaxf(m3, fabsf(v[3])), amax);
+      amax = m.ok ? m5 : amax;
     }
     const uint32_t ooff = ok ? m.pixoff * PIXB + lane_out_c : OOB;
     typedef uint32_t h2_u32x4 __attribute__((ext_vector_type(4)));
@@ -360,20 +362,34 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
       h2_u32x4 d = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
       __builtin_amdgcn_raw_buffer_store_b128(d, r_out, ooff + img32 * (uint32_t)OIMGB, 0, 0);
     } else {
-      // two pieces of the four values; lanes (quad, quad ^ 2) complete each other's 16-byte chunks: the lower one ends up
-      // with the first pieces of elements 0..7 of group g_out, the upper one with the second pieces
+      // two pieces of the four values; lanes (quad, quad ^ 2) = (L, L + 32) complete each other's 16-byte chunks: the lower one
+      // ends up with the first pieces of elements 0..7 of group g_out, the upper one with the second pieces.
+      // v_permlane32_swap a, b exchanges a's upper 32 lanes with b's lower 32: with a = first pieces, b = second pieces, the
+      // lower lane holds (own first, partner's first) and the upper lane (partner's second, own second) afterwards -- no selects.
       uint32_t h0a, h0b, h1a, h1b;
       h2_split_pair(v[0], v[1], oscale, h0a, h1a);
       h2_split_pair(v[2], v[3], oscale, h0b, h1b);
-      const uint32_t r0 = h2_xor32(up ? h0a : h1a, up), r1 = h2_xor32(up ? h0b : h1b, up);
       h2_u32x4 chunk;
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+      typedef unsigned h2_u32x2 __attribute__((ext_vector_type(2)));
+      const h2_u32x2 sa = __builtin_amdgcn_permlane32_swap(h0a, h1a, false, false);
+      const h2_u32x2 sb = __builtin_amdgcn_permlane32_swap(h0b, h1b, false, false);
+      chunk[0] = sa[0]; chunk[1] = sb[0]; chunk[2] = sa[1]; chunk[3] = sb[1];
+#else
+      const uint32_t r0 = h2_xor32(up ? h0a : h1a, up), r1 = h2_xor32(up ? h0b : h1b, up);
       chunk[0] = up ? r0 : h0a; chunk[1] = up ? r1 : h0b; chunk[2] = up ? h1a : r0; chunk[3] = up ? h1b : r1;
+#endif
       __builtin_amdgcn_raw_buffer_store_b128(chunk, r_out, ooff + img32 * (uint32_t)OIMGB, 0, 0);
       if (MASK_OUT) {
         uint32_t nib = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
-        const uint32_t other = h2_xor32(nib, up);
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+        const h2_u32x2 sn = __builtin_amdgcn_permlane32_swap(nib, nib, false, false);   // lower lanes: (own, partner's)
+        const uint32_t byte = sn[0] | (sn[1] << 4);
+#else
+        const uint32_t byte = nib | (h2_xor32(nib, up) << 4);
+#endif
         const uint32_t moff = (ok && !up) ? m.pixoff * (GE::OCH / 8) + lane_mout_c : OOB;
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(nib | (other << 4)), r_mo, moff + img32 * (uint32_t)MIMGB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)byte, r_mo, moff + img32 * (uint32_t)MIMGB, 0, 0);
       }
     }
   };
