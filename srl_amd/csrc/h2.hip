@@ -136,6 +136,7 @@ extern "C" int srl_h2_conv(void* stream, int32_t kind, const srl_h2_conv_args* p
   const bool fwd = kind == H2C_F2 || kind == H2C_F3;
   SRL_CHECK_ARG(fwd ? a.mask_out != nullptr : a.mask_in != nullptr, "forward kinds write mask_out, data gradients read mask_in");
   SRL_CHECK_ARG(kind == H2C_D2 || (a.out_scale && a.bound_in && a.bound_w), "h2 outputs need out_scale and the bound's factors");
+  SRL_CHECK_ARG((kind != H2C_D2 && kind != H2C_D3) || a.act == 0, "data gradients take no activation (act = 0)");
   srl_count_dispatch(SRL_DISP_H2, 1, kind, fwd ? 3 : 2);
   switch (kind) {
     case H2C_F2: h2conv_launch<H2C_F2, 3>(st, a); break;

@@ -342,13 +342,14 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
   constexpr uint32_t OOB = 0x80000000u;
   auto epilogue1 = [&](const h2_f32x4& acc, const Meta& m, const float (&bqc)[4], uint32_t lane_out_c, uint32_t lane_mout_c, uint32_t mbits) {
     float v[4];
+    constexpr bool CLAMP = ID == H2C_F2 || ID == H2C_F3;   // data gradients take no activation (srl_h2_conv checks)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] * inv + bqc[r], lo);
+    for (int r = 0; r < 4; ++r) v[r] = CLAMP ? fmaxf(acc[r] * inv + bqc[r], lo) : acc[r] * inv + bqc[r];
     const bool ok = m.ok && !(SRL_H2C_DBG & 4);
     const uint32_t img32 = (uint32_t)m.img;
-    if (MASK_IN) {
+    if (MASK_IN) {   // bit r -> all ones / zero (v_bfe_i32), and: two vector instructions per value
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (mbits >> r) & 1u ? v[r] : 0.f;
+      for (int r = 0; r < 4; ++r) v[r] = __uint_as_float(__float_as_uint(v[r]) & (uint32_t)__builtin_amdgcn_sbfe((int)mbits, r, 1));
     }
     {
       // (vector instructions cost what matrix instructions cost here, DESIGN 4: max3, and the exchanges below without selects)
