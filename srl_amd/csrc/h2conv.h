@@ -469,8 +469,11 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
   auto compute = [&](long b, int s) {
     const uint8_t* slot = lds + s * SLOTM + lane_base;
     const uint8_t* mreg = lds + s * SLOTM + SLOT;
-    for (int jb = ph * (NBT / NPH); jb < (ph + 1) * (NBT / NPH); ++jb) {
-      const int il = jb / NB_IMG, bi = jb - il * NB_IMG;
+#pragma unroll
+    for (int jj = 0; jj < NBT / NPH; ++jj) {   // unrolled: a block's accumulators are handed to the next block's chain by renaming
+      const int jb = ph * (NBT / NPH) + jj;
+      // (a position half = one image of the batch where the counts agree: the block index is then the unrolled counter itself)
+      const int il = NBT / NPH == NB_IMG ? ph : jb / NB_IMG, bi = NBT / NPH == NB_IMG ? jj : jb - il * NB_IMG;
       const int e = bi * 16 + p;
       const int oy = (e * (65536 / GE::GW + 1)) >> 16, ox = e - oy * GE::GW;   // e < 128
       Meta nm;
