@@ -405,7 +405,9 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
   // stores is the other's matrix work.  (sched_group_barrier was tried for a per-instruction interleave: with the directives
   // in the block the compiler placed a vector write to a store's data register directly behind the store -- a missing wait
   // state, wrong results -- so the order is written out in the source instead.)
-  constexpr int PD = CB == 1 ? 3 : 2;
+  // (conv2's data gradient, two channel groups per wavefront: one k-block ahead -- with two, the two instantiations of the
+  // position half below spill 20 bytes and the kernel runs at 352 us instead of 286)
+  constexpr int PD = CB == 1 ? 3 : (ID == H2C_D2 ? 1 : 2);
   const bool late = wid >= 4;
   // rows_c: the tap rows that can contribute to this block (a data gradient's first and last blocks of an image see only
   // zero border through some: conv3's 9 x 9 outputs on the 11-wide grid skip 12 of their 63 tap-blocks); all rows otherwise
@@ -466,16 +468,16 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
   Meta pm = {};
   pm.ok = false;
   // this lane's entry inside a block, walked block by block: (oy, ox) of entry 16 bi + p
-  // phc_c: the wavefront's position half as a constant (two instantiations, chosen by a uniform branch per batch; -1: the run-time
-  // value): every block's index inside its image is then known at compile time, and with it the entry arithmetic and the row
-  // masks (conv2 forward 302 -> 277 us, conv3 forward 198 -> 188, conv3 data gradient 278 -> 267)
+  // phc_c: the wavefront's position half as a constant (two instantiations, chosen by a uniform branch per batch): every block's
+  // index inside its image is then known at compile time, and with it the entry arithmetic and the row masks (conv2 forward
+  // 302 -> 277 us, conv3 forward 198 -> 188, conv3 data gradient 278 -> 267, conv2 data gradient 290 -> 286)
   auto compute = [&](auto phc_c, long b, int s) {
     constexpr int phc = decltype(phc_c)::value;
     const uint8_t* slot = lds + s * SLOTM + lane_base;
     const uint8_t* mreg = lds + s * SLOTM + SLOT;
 #pragma unroll
     for (int jj = 0; jj < NBT / NPH; ++jj) {   // unrolled: a block's accumulators are handed to the next block's chain by renaming
-      const int jb = (phc < 0 ? ph : phc) * (NBT / NPH) + jj;
+      const int jb = phc * (NBT / NPH) + jj;
       const int il = jb / NB_IMG, bi = jb - il * NB_IMG;
       const int e = bi * 16 + p;
       const int oy = (e * (65536 / GE::GW + 1)) >> 16, ox = e - oy * GE::GW;   // e < 128
@@ -522,9 +524,7 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
     __builtin_amdgcn_s_barrier();
     const long bn = b + (long)(NSLOT - 1) * gridDim.x;
     if (bn < nbatch && !(SRL_H2C_DBG & 1)) issue(bn, s_nxt);
-    // (conv2's data gradient, two channel groups per wavefront, spills with both instantiations' live ranges: 286 -> 352 us)
-    if (ID == H2C_D2) compute(std::integral_constant<int, -1>{}, b, s_cur);
-    else if (ph == 0) compute(std::integral_constant<int, 0>{}, b, s_cur);
+    if (ph == 0) compute(std::integral_constant<int, 0>{}, b, s_cur);
     else compute(std::integral_constant<int, NPH - 1>{}, b, s_cur);
     s_cur = s_cur + 1 == NSLOT ? 0 : s_cur + 1;
     s_nxt = s_nxt + 1 == NSLOT ? 0 : s_nxt + 1;
