@@ -810,7 +810,12 @@ __global__ __launch_bounds__(512, 2) void h2wgrad_kernel(H2WgradArgs a) {
   for (int m = 0; m < GE::MC; ++m)
 #pragma unroll
     for (int n2 = 0; n2 < GE::NN; ++n2) acc[m][n2] = h2_f32x4{0.f, 0.f, 0.f, 0.f};
-  float dbs[2] = {0.f, 0.f};   // bias gradient of cout (lane & 15): conv2, wavefronts 0..3: block wid in [0]; conv3, wavefronts 0, 1: their two blocks
+  // bias gradient: D[cout i][any column] of the products with ones -- lane l, register r: cout 4 (l >> 4) + r of the block.
+  // conv2, wavefronts 0..3: block wid in [0]; conv3, wavefronts 0, 1: their two blocks
+  h2_f32x4 dbacc[2] = {h2_f32x4{0.f, 0.f, 0.f, 0.f}, h2_f32x4{0.f, 0.f, 0.f, 0.f}};
+  h2_f16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
 
   auto frag = [&](const uint8_t* p0, const uint8_t* p1) {
     union { h2_s16x4 s[2]; h2_f16x8 v; } f;
@@ -830,18 +835,19 @@ __global__ __launch_bounds__(512, 2) void h2wgrad_kernel(H2WgradArgs a) {
           const uint8_t* b = slot + za[m] + pl * ZPLANE + c * 512;
           af[m][pl] = frag(b, b + 256);
         }
-      // bias gradient from the fragments a wavefront holds anyway (first pieces + second pieces of its 8 positions)
+      // bias gradient from the fragments a wavefront holds anyway: both pieces against a fragment of ones on the matrix cores
+      // (two MFMAs per cout block and chunk).  As 16 conversions + 16 additions per piece pair on the vector unit it made the
+      // two (conv3) / four (conv2) wavefronts that own the sums ~ 20-30 % longer than the others, which wait for them at every
+      // image's barrier -- and vector time is not hidden under matrix time here.
       {
         const bool mine = GE::MC == 4 ? wid < 4 : wid < 2;
         if (mine) {
 #pragma unroll
           for (int m = 0; m < GE::MC; ++m) {
             if (GE::MC == 4 && m != (wid & 3)) continue;
-            float t = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t += (float)af[m][0][e] + (float)af[m][1][e];
-            if (GE::MC == 4) dbs[0] += t;
-            else dbs[m & 1] += t;
+            h2_f32x4& d = dbacc[GE::MC == 4 ? 0 : (m & 1)];
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][0], ones, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][1], ones, d, 0, 0, 0);
           }
         }
       }
@@ -913,13 +919,16 @@ __global__ __launch_bounds__(512, 2) void h2wgrad_kernel(H2WgradArgs a) {
       }
     }
   {
-    // db: lane (cout i = lane & 15, octet o) summed over the 4 octets
+    // db: cout i = lane (< 16) of the block sits in register i & 3 of the lanes 16 (i >> 2) .. + 15 (every column the same sum)
     const bool mine = GE::MC == 4 ? wid < 4 : wid < 2;
 #pragma unroll
     for (int m = 0; m < (GE::MC == 4 ? 1 : 2); ++m) {
-      float t = dbs[m];
-      t += __shfl_xor(t, 16);
-      t += __shfl_xor(t, 32);
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = __shfl(dbacc[m][r], 16 * ((lane & 15) >> 2));
+        if ((lane & 3) == r) t = v;
+      }
       if (mine && lane < 16) slab[64 * K + 16 * (GE::MC == 4 ? wid : mc0 + m) + lane] = t / *a.sz;
     }
   }
