@@ -184,9 +184,14 @@ extern "C" int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d) {
   a.bias = d->bias; a.act = d->act; a.out_fmt = d->out_h2 ? H2O_H2P : H2O_F32; a.out = d->out; a.out_row_bytes = (uint32_t)d->NC * 4u;
   a.out_scale = d->out_scale; a.bound_in = d->bound_in; a.bound_w = d->bound_w; a.bound_b = d->bound_b; a.out_absmax = d->out_absmax;
   a.mask_out = d->mask_out; a.mask_in = d->mask_in; a.mask_in_h2 = d->mask_in_h2order;
-  srl_count_dispatch(SRL_DISP_H2, 3, d->NC >= 128 ? 4 : 2, 3);
+  // a wide output over a short reduction (the Linear's data gradient: 3136 channels, K = 512): 256 channels per workgroup, both
+  // k-halves in every wavefront -- a third less staged per multiply-add, on a two-stage ring (240 -> 220 us per 16 384 rows)
+  static const bool wide_on = [] { const char* e = getenv("SRL_H2GEMM_WIDE"); return !(e && e[0] == '0'); }();
+  const bool wide = wide_on && d->NC >= 1024 && d->K <= 1024;
+  srl_count_dispatch(SRL_DISP_H2, 3, wide ? 8 : (d->NC >= 128 ? 4 : 2), wide ? 2 : 3);
   int rc;
-  if (d->NC >= 128) rc = h2gemm_launch<4, H2X_DENSE, 3>((hipStream_t)stream, a);
+  if (wide) rc = h2gemm_launch<8, H2X_DENSE, 2, false>((hipStream_t)stream, a);
+  else if (d->NC >= 128) rc = h2gemm_launch<4, H2X_DENSE, 3>((hipStream_t)stream, a);
   else rc = h2gemm_launch<2, H2X_DENSE, 3>((hipStream_t)stream, a);
   SRL_CHECK_ARG(rc == 0, "grid too large");
   SRL_LAUNCH_CHECK();

@@ -272,7 +272,9 @@ def test_linear_forward_and_data_gradient_vs_float64(M):
     run = lambda: hip.h2_gemm(dbuf.data_ptr(), wt.data_ptr(), sd.data_ptr(), swt.data_ptr(), M, K, N, dx.data_ptr(), out_h2=True,
                               out_scale=osc.data_ptr(), bound_in=ad.data_ptr(), bound_w=rwt.data_ptr(), out_absmax=oam.data_ptr(),
                               mask_in=mask.data_ptr(), mask_in_h2order=True)
+    hip.dispatch_tiles(reset=True)
     run()
+    assert hip.dispatch_tiles(reset=True) == {"h2:gemm:8:s2": 1}   # wide output, short reduction: 256 channels per workgroup
     first = dx.clone()
     got = torch.empty(M, K, device=DEV)
     hip.h2_unpack_rows(dx.data_ptr(), M, K, osc.data_ptr(), got.data_ptr(), K)
