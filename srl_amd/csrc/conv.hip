@@ -668,7 +668,8 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
       if (nsplit > ntiles) nsplit = ntiles;
       h.nsplit = (int)nsplit;
       const unsigned grid = (unsigned)(nblk * nsplit);
-      constexpr int lds = srlobs::kStages * srlobs::kStageBytes + srlobs::kMeta * srlobs::kTile * 16 + srlobs::kWaves * 96 * 4;  // stages, records, tables
+      constexpr int lds = srlobs::kStages * srlobs::kStageBytes + srlobs::kMeta * srlobs::kTile * 16 + srlobs::kWaves * 96 * 4 +
+                          (SRL_OBS_LINE_STORES ? srlobs::kWaves * srlobs::kTile * 144 : 0);  // stages, records, tables, store rows
       auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * srlobs::kWaves), lds, st, h);

@@ -162,6 +162,9 @@ __device__ __forceinline__ void obs_bytes_to_f16(uint32_t d, uint32_t negc, uint
   hi = b.u;
 }
 
+#ifndef SRL_OBS_LINE_STORES
+#define SRL_OBS_LINE_STORES 1
+#endif
 // ACT: the activation (0 none, 1 ReLU, 2 tanh).  DBG (timing experiments, wrong results; SRL_OBS_DBG): 1 = no output stores, 2 = no LDS
 // reads / conversions / MFMAs, 4 = no DMA
 template <int ACT, int DBG = 0>
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void obs_fwd_h2_k
   // [kStages][32 samples][kChunks + 1 chunks][16 B] | meta ring [kMeta][32] x 16 B | tables [kWaves][3][32] float
   uint4* const metal = reinterpret_cast<uint4*>(lds + kStages * kStageBytes);
   float* const tabs = reinterpret_cast<float*>(metal + kMeta * kTile);
+  uint8_t* const trbuf = reinterpret_cast<uint8_t*>(tabs + kWaves * 96);   // SRL_OBS_LINE_STORES: [kWaves][32 rows][144 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
   const uint32_t lds0 = (uint32_t)(uintptr_t)lds, ldsm = lds0 + kStages * kStageBytes;
 
@@ -295,13 +299,29 @@ __global__ __launch_bounds__(64 * kWaves, kWaves == 4 ? 2 : 1) void obs_fwd_h2_k
       }                                                                                                                   \
     }                                                                                                                     \
     /* rows past the batch: an offset beyond the buffer drops the store -- the same number of stores whatever the tile.     \
-       (Whole 128-byte lines per instruction, through an LDS transposition, were timed equal: the L2 merges the pieces;      \
-       non-temporal stores, which do not merge, 15-65 % slower.) */                                                        \
+       (Non-temporal stores, which do not merge in L2: 15-65 % slower.  Whole 128-byte rows per instruction were timed equal   \
+       on the first block kernel; on this one, whose loads, stores and compute add up, 449 -> 387 us.) */                     \
+    if (SRL_OBS_LINE_STORES) {                                                                                            \
+      /* through the wavefront's own LDS rows (144-byte pitch: conflict-free 16-byte slots): an instruction then stores 8     \
+         whole 128-byte rows instead of two 16-byte pieces of 32 rows */                                                     \
+      uint8_t* tr_ = trbuf + wave * (kTile * 144);                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                       \
+        *reinterpret_cast<uint4*>(tr_ + l31 * 144 + h * 64 + 16 * i) = make_uint4(c4[i][0], c4[i][1], c4[i][2], c4[i][3]); \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                     \
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                                       \
+        const int smp_ = 8 * i + (lane >> 3);                                                                             \
+        const uint4 q_ = *reinterpret_cast<const uint4*>(tr_ + smp_ * 144 + (lane & 7) * 16);                             \
+        const uint32_t oo_ = (n0_ + smp_ < nsamp && !(DBG & 1)) ? (uint32_t)(((n0_ + smp_) * (long)P + ent) * 128 + (lane & 7) * 16) : 0x80000000u; \
+        u32x4 d = {q_.x, q_.y, q_.z, q_.w};                                                                               \
+        __builtin_amdgcn_raw_buffer_store_b128(d, r_out, oo_, 0, 0);                                                      \
+      }                                                                                                                   \
+    } else {                                                                                                              \
     const uint32_t ooff = (ok_ && !(DBG & 1)) ? (uint32_t)(((n0_ + l31) * (long)P + ent) * 128 + h * 64) : 0x80000000u;    \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                                         \
       u32x4 d = {c4[i][0], c4[i][1], c4[i][2], c4[i][3]};                                                                 \
       __builtin_amdgcn_raw_buffer_store_b128(d, r_out, ooff + 16 * i, 0, 0);                                              \
+    }                                                                                                                     \
     }                                                                                                                     \
     bits_ |= (uint32_t)__shfl_xor((int)bits_, 32);                                                                        \
     const uint32_t moff = (ok_ && h == 0) ? (uint32_t)(((n0_ + l31) * (long)P + pos) * 4) : 0x80000000u;                 \
