@@ -269,6 +269,13 @@ class ActorCriticPolicy(policy_api.Policy):
 
     def rollout(self, requests: policy_api.RolloutRequest, **kwargs) -> policy_api.RolloutResult:
         hip.require_gpu()
+        self._net._serving[0] += 1   # what the executor derives from the parameters survives from one request batch to the next
+        try:
+            return self._rollout(requests, **kwargs)
+        finally:
+            self._net._serving[0] -= 1
+
+    def _rollout(self, requests: policy_api.RolloutRequest, **kwargs) -> policy_api.RolloutResult:
         host = {k: v for k, v in requests.obs.items() if v is not None}
         n = int(next(iter(host.values())).shape[0])
         # Stack-aware requests (atari_wrappers.py:211-242 `FrameStack`): `ring_prev` [n, 1] int64 holds the observation-ring

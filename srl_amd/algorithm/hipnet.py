@@ -129,6 +129,10 @@ class HipNet:
         self._mlp_cache = {}
         self._pver = [0]    # parameter version, shared with the twins (a list: one object)
         self._in_update = [False]
+        # > 0 while the policy serves rollout requests (ActorCriticPolicy.rollout): like the chunks of one update, consecutive
+        # requests see the same parameters unless somebody said otherwise (``params_changed``), so what an executor derived from
+        # them -- folded first-layer weights, pre-split weight copies: 8 launches, 225 us of a 1.28 ms request batch -- is kept
+        self._serving = [0]
         # set by the trainer's chunk loop before every chunk (True: this executor's last chunk of the update; None outside the loop):
         # what may accumulate over the chunks of an update in an executor's own workspace is closed behind the last one
         self.last_chunk = None
@@ -235,10 +239,14 @@ class HipNet:
         """Whether this executor's buffer ``ptr`` still holds ``what`` (weights regrouped for a data gradient, the first layer's
         folded weights) computed from the CURRENT parameters: those depend on the weights only, yet were recomputed for every
         chunk of an update (160 + 32 launches of 5-22 us).  Marks it fresh for the caller, who recomputes on False."""
-        if not self._in_update[0] or not self._derived_on:  # only between the chunks of one trainer update (``chunks_of_one_update``): anybody else
-            self._derived.pop(what, None)  # may have rewritten ``flat`` without saying so
+        if not (self._in_update[0] or self._serving[0]) or not self._derived_on:  # only between the chunks of one trainer update
+            # (``chunks_of_one_update``) and between the request batches a policy serves (whose parameters change through
+            # load_state_dict / broadcast_parameters / the trainer, all of which say so): anybody else may have rewritten ``flat``
+            self._derived.pop(ptr, None)
             return False
-        key, val = what, (ptr, self._pver[0], self.flat.data_ptr())
+        # keyed by the BUFFER: two kinds of derived data may share one (the first layer's folded weights in the block kernel's
+        # and in the per-position kernel's format, chosen by the row count of a call) -- fresh is what was written there last
+        key, val = ptr, (what, self._pver[0], self.flat.data_ptr())
         if self._derived.get(key) == val:
             return True
         self._derived[key] = val

@@ -633,6 +633,33 @@ def test_streamed_rollout_matches_one_piece():
     assert pol.rollout(req_s).action.x.shape == (64, 1)
 
 
+def test_served_batches_keep_derived_weights_until_the_parameters_change():
+    """Between the request batches a policy serves, what its executor derived from the parameters (the first layer's folded
+    weights, the pre-split weight copies of the h2 path) is kept -- and dropped when the parameters change through
+    `load_checkpoint` (a parameter pull): the next batch must be what a policy built from those parameters gives."""
+    n = 4096   # the h2 path's row count
+    rng = np.random.default_rng(17)
+    obs = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    req = policy_api.RolloutRequest(obs=NamedArray(obs=obs), is_evaluation=np.ones((n, 1), np.uint8), on_reset=np.zeros((n, 1), np.uint8))
+    pol = policy_api.make(config.Policy("actor-critic", args=CNN_POLICY))
+    other = policy_api.make(config.Policy("actor-critic", args=dict(CNN_POLICY, seed=CNN_POLICY.get("seed", 1) + 5)))
+    from srl_amd import hip
+    hip.dispatch_counts(reset=True)
+    first = pol.rollout(req)
+    launches_first = sum(hip.dispatch_counts(reset=True).values())
+    again = pol.rollout(req)
+    launches_again = sum(hip.dispatch_counts(reset=True).values())
+    assert launches_again == launches_first   # (the derived-weight kernels are not in the counted families; the products are)
+    assert np.array_equal(first.action.x, again.action.x) and np.array_equal(first.analyzed_result.value, again.analyzed_result.value)
+    want = other.rollout(req)
+    assert not np.array_equal(want.analyzed_result.value, first.analyzed_result.value)
+    pol.load_checkpoint(other.get_checkpoint())   # (api/policy.py's parameter pull)
+    got = pol.rollout(req)
+    assert np.array_equal(got.action.x, want.action.x)
+    assert np.array_equal(got.analyzed_result.value, want.analyzed_result.value)
+    assert np.array_equal(got.analyzed_result.log_probs, want.analyzed_result.log_probs)
+
+
 def test_streamed_rollout_with_action_mask_matches_one_piece():
     """The availability mask of a streamed piece is staged on the side stream like the frames: a piece must sample
     with ITS OWN mask (every action legal under it) and give the one-piece result."""
