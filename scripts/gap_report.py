@@ -9,7 +9,7 @@ rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) f
 rows.sort()
 ends = [i for i, r in enumerate(rows) if "adam" in r[2].lower()]
 print(len(rows), "kernels,", len(ends), "optimiser steps")
-for a, b in list(zip(ends[:-1], ends[1:]))[-2:]:
+for a, b in list(zip(ends[:-1], ends[1:])):
     seg = rows[a + 1:b + 1]
     t0, t1 = seg[0][0], max(r[1] for r in seg)
     busy, cur_s, cur_e, gaps = 0, seg[0][0], seg[0][1], []
