@@ -49,6 +49,7 @@ template <> struct H2Geo<H2C_F2> {
   static constexpr int SRC = H2S_ROWSWZ, PAD = 0, SH = 20, SW = 20, SPIX = 400;
   static constexpr int DST = H2D_PLANAR, OPIX = 81, OCH = 64;
   static constexpr bool ZERO_BORDER = false;
+  static constexpr bool DENSE = false;
   __host__ __device__ static constexpr int tap_u(int t) { return (((t >> 2) & 1) * 2 + (t & 1)) * 100 + (t >> 3) * 10 + ((t & 3) >> 1); }
   __host__ __device__ static constexpr int tap_k(int t) { return t; }
 };
@@ -59,6 +60,7 @@ template <> struct H2Geo<H2C_F3> {
   static constexpr int SRC = H2S_PLANAR, PAD = 0, SH = 9, SW = 9, SPIX = 81;
   static constexpr int DST = H2D_ROWS, OPIX = 49, OCH = 64;
   static constexpr bool ZERO_BORDER = false;
+  static constexpr bool DENSE = false;
   __host__ __device__ static constexpr int tap_u(int t) { return (t / 3) * 9 + t % 3; }
   __host__ __device__ static constexpr int tap_k(int t) { return t; }
 };
@@ -70,6 +72,10 @@ template <> struct H2Geo<H2C_D3> {
   static constexpr int SRC = H2S_ROWS, PAD = 2, SH = 7, SW = 7, SPIX = 49;
   static constexpr int DST = H2D_PLANAR, OPIX = 81, OCH = 64;
   static constexpr bool ZERO_BORDER = true;
+  // outputs enumerated densely (16 consecutive OUTPUT pixels per block, 81 = 5 blocks + 1 pixel) instead of along the 11-wide
+  // input grid (97 entries in 7 blocks): a lane's grid entry is its output index + 2 rows' worth of border, a per-lane
+  // address again -- 42 instead of 51 tap-blocks per image after the border's tap rows are skipped
+  static constexpr bool DENSE = true;
   __host__ __device__ static constexpr int tap_u(int t) { return (2 - t / 3) * 11 + (2 - t % 3); }
   __host__ __device__ static constexpr int tap_k(int t) { return t; }
 };
@@ -81,6 +87,7 @@ template <> struct H2Geo<H2C_D2> {
   static constexpr int SRC = H2S_PLANAR, PAD = 1, SH = 9, SW = 9, SPIX = 81;
   static constexpr int DST = H2D_F32_ROUTED, OPIX = 400, OCH = 32;
   static constexpr bool ZERO_BORDER = true;
+  static constexpr bool DENSE = true;   // (as conv3's: 100 outputs in 7 blocks either way, but the last block is row 9 alone)
   __host__ __device__ static constexpr int tap_u(int t) { return (1 - t / 2) * 11 + (1 - t % 2); }
   __host__ __device__ static constexpr int tap_k(int t) { return t; }
 };
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
   constexpr int CGW = GE::CGW, NWG = NCG / CGW;  // ... CGW of them per wavefront: NWG wavefronts across the channels
   constexpr int NPH = 8 / NWG;                   // position halves (8 wavefronts)
   static_assert(NWG == 4 || NWG == 8, "");
-  constexpr int NE = (GE::OH - 1) * GE::GW + GE::OW;   // entries to walk per image
+  constexpr int NE = GE::DENSE ? GE::OH * GE::OW : (GE::OH - 1) * GE::GW + GE::OW;   // entries to walk per image
   constexpr int NB_IMG = (NE + 15) / 16;               // blocks of 16 entries per image
   constexpr int NBT = NB_IMG * GE::G;                  // blocks per batch
   static_assert(NBT % NPH == 0 && NPH <= 2, "blocks split evenly over the (at most two) position halves");
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
   // rows_c: the tap rows that can contribute to this block (a data gradient's first and last blocks of an image see only
   // zero border through some: conv3's 9 x 9 outputs on the 11-wide grid skip 12 of their 63 tap-blocks); all rows otherwise
   auto block = [&](auto rows_c, const uint8_t* xb, h2_f32x4 (&pacc)[CGW], Meta& pm, const Meta& nm) {
-    constexpr int TPR = ID == H2C_D3 ? 3 : GE::NTAP;   // taps per tap row (one row = everything, where nothing is skipped)
+    constexpr int TPR = ID == H2C_D3 ? 3 : (ID == H2C_D2 ? 2 : GE::NTAP);   // taps per tap row (one row = everything, where nothing is skipped)
     constexpr H2ActiveKb<NKB> AK = h2_active_kbs<decltype(rows_c)::value, GE::NTAP, CB, TPR>();
     h2_f32x4 acc[CGW];
 #pragma unroll
@@ -480,7 +487,8 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
       const int jb = phc * (NBT / NPH) + jj;
       const int il = jb / NB_IMG, bi = jb - il * NB_IMG;
       const int e = bi * 16 + p;
-      const int oy = (e * (65536 / GE::GW + 1)) >> 16, ox = e - oy * GE::GW;   // e < 128
+      constexpr int EW = GE::DENSE ? GE::OW : GE::GW;   // entries per row of the enumeration
+      const int oy = (e * (65536 / EW + 1)) >> 16, ox = e - oy * EW;   // e < 128
       Meta nm;
       nm.img = b * GE::G + il;
       nm.ok = ox < GE::OW && oy < GE::OH && nm.img < a.n;
@@ -495,16 +503,25 @@ __global__ __launch_bounds__(512, 2) void h2conv_kernel(H2ConvArgs a) {
         }
       }
       if (SRL_H2C_DBG & 2) { epilogue(pacc, pm); pm = nm; continue; }
-      const uint8_t* xb_ = slot + (il * GE::NPIX_L + bi * 16) * (GE::SRC == H2S_ROWSWZ ? 128 : 16);
+      // (dense enumeration: output (oy, ox) sits at grid entry oy * GW + ox = e + oy * (GW - OW))
+      const uint8_t* xb_ = slot + (il * GE::NPIX_L + bi * 16) * (GE::SRC == H2S_ROWSWZ ? 128 : 16) +
+                           (GE::DENSE ? oy * ((GE::GW - GE::OW) * 16) : 0);
       if (ID == H2C_D3 && !(SRL_H2C_DBG & 8)) {
-        // output rows of block bi: entries 16 bi .. + 15 of the 11-wide grid; tap row ky reads dz row y - ky, which exists for
-        // 0 <= y - ky <= 6: block 0 (y = 0, 1) never through ky = 2, block 5 (y = 7, 8) never through ky = 0, block 6 (y = 8) only
+        // output rows of block bi: outputs 16 bi .. + 15 of the 9-wide image; tap row ky reads dz row y - ky, which exists for
+        // 0 <= y - ky <= 6: block 0 (y = 0, 1) never through ky = 2, block 4 (y = 7, 8) never through ky = 0, block 5 (y = 8) only
         // through ky = 2
-        static_assert(ID != H2C_D3 || (NB_IMG == 7 && GE::GW == 11 && GE::NTAP == 9), "row masks below are conv3's");
+        static_assert(ID != H2C_D3 || (NB_IMG == 6 && GE::GW == 11 && GE::OW == 9 && GE::NTAP == 9 && GE::SRC != H2S_ROWSWZ),
+                      "row masks below are conv3's");
         if (bi == 0) block(std::integral_constant<int, 0b011>{}, xb_, pacc, pm, nm);
-        else if (bi == 5) block(std::integral_constant<int, 0b110>{}, xb_, pacc, pm, nm);
-        else if (bi == 6) block(std::integral_constant<int, 0b100>{}, xb_, pacc, pm, nm);
+        else if (bi == 4) block(std::integral_constant<int, 0b110>{}, xb_, pacc, pm, nm);
+        else if (bi == 5) block(std::integral_constant<int, 0b100>{}, xb_, pacc, pm, nm);
         else block(std::integral_constant<int, 0b111>{}, xb_, pacc, pm, nm);
+      } else if (ID == H2C_D2 && !(SRL_H2C_DBG & 8)) {
+        // class-grid rows of block bi: outputs 16 bi .. + 15 of the 10-wide class image; tap row dy reads dz row a - dy, which
+        // exists for 0 <= a - dy <= 8: block 6 (a = 9 alone) only through dy = 1
+        static_assert(ID != H2C_D2 || (NB_IMG == 7 && GE::GW == 11 && GE::OW == 10 && GE::NTAP == 4), "row mask below is conv2's");
+        if (bi == 6) block(std::integral_constant<int, 0b10>{}, xb_, pacc, pm, nm);
+        else block(std::integral_constant<int, 0b11>{}, xb_, pacc, pm, nm);
       } else {
         block(std::integral_constant<int, (1 << 30) - 1>{}, xb_, pacc, pm, nm);
       }
