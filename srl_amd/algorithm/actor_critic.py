@@ -281,7 +281,8 @@ class ActorCriticPolicy(policy_api.Policy):
         # Stack-aware requests (atari_wrappers.py:211-242 `FrameStack`): `ring_prev` [n, 1] int64 holds the observation-ring
         # stamp of the same environment's previous observation (0 at an episode start) and the frame-stack keys carry only
         # their newest plane [n, 1, H, W]; the ring assembles the rows (ObsRing.put_stacked) -- a quarter of the bytes over
-        # the host link that actor_critic_policy.py:467-469 moves, same actions, log-probabilities and values.
+        # the host link that actor_critic_policy.py:467-469 moves, same actions, log-probabilities and values.  A request whose
+        # predecessors the ring no longer holds raises `obs_ring.WholeStackNeeded` (dead or -1 stamps must not be sent).
         prev = host.pop(self.RING_PREV_KEY, None)
         if prev is not None and self._obs_ring is None:
             raise ValueError("stack-aware requests (`ring_prev`) need an observation ring attached to the policy")
@@ -404,7 +405,13 @@ class ActorCriticPolicy(policy_api.Policy):
         if prev is not None:  # stack-aware: the ring assembles each row from its predecessor and the uploaded plane
             ring = self._obs_ring
             planes = {k: obs[k] for k in ring.keys() if tuple(obs[k].shape[1:]) != ring.raw_shape[k]}
-            refs, staged = ring.put_stacked(planes, prev, full={k: obs[k] for k in ring.keys() if k not in planes})
+            try:
+                refs, staged = ring.put_stacked(planes, prev, full={k: obs[k] for k in ring.keys() if k not in planes})
+            except (LookupError, BufferError) as e:
+                # planes alone cannot be served any other way (the non-stacked path degrades through `put_or_skip`; here there
+                # is no whole row to fall back on): a defined per-request error, nothing staged, no slot consumed
+                from srl_amd.runtime.obs_ring import WholeStackNeeded
+                raise WholeStackNeeded(f"stack-aware request refused ({e}); send whole frame stacks without `ring_prev`") from e
             obs.update(staged)
         elif self._obs_ring is not None:  # the rows stay in HBM for the trainer; the forward below reads them from there
             # a ring full of rows a training step has leased does not fail the request: the rows go unstaged (stamp -1), the

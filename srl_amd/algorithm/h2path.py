@@ -25,10 +25,14 @@ from srl_amd.algorithm import netspec as ns
 
 ENABLED = os.environ.get("SRL_H2", "1") != "0"
 
-# device floats of one executor (indices into the `h2.slots` workspace tensor)
+# device floats of one block.  Two arrays, indexed by the same enumeration: what a PASS measures and derives (ranges of the
+# activations / gradients and the power-of-two scales made of them: data-dependent, so one array per forward pass -- per `tag`,
+# i.e. per trunk and per piece of `_trunk_fwd`: a second forward before the first one's backward must not overwrite them) and
+# what depends on the WEIGHTS only (one array per block and parameter version).
 # (the measured ranges of a pass sit side by side: one fill zeroes the forward's three, one the backward's four)
 (M_A1, M_A2, M_A3, M_DY, M_DZ3, M_DZ2, M_DZ1, S_A1, S_A2, S_A3, S_DY, S_DZ3, S_DZ2,
  S_W2, R_W2, B_W2, S_W3, R_W3, B_W3, S_WF, R_WF, S_W3G, R_W3G, S_W2G, R_W2G, S_WFT, R_WFT, N_SLOTS) = range(28)
+N_PASS_SLOTS = S_W2  # indices below: per pass; from here on: per weights
 
 
 def match(layers) -> Optional[tuple]:
@@ -56,77 +60,87 @@ class H2Cnn:
         self.net = net
         self.ln, self.c1, self.c2, self.c3, self.fc = layers
         self.H = self.fc.out_features
+        # every workspace buffer of this block carries the block's own name: an executor may hold several (separate actor and
+        # critic encoders both read the key "obs"; two image keys under one trunk), each with its own weights and scales
+        self.pfx = f"h2[{self.c1.prefix}]."
+        # the first layer's position sums (Q, R, C) of the chunks so far are accumulating in this block's workspace
+        # (srl_conv2d_obs_bwd's `phase`): whoever runs this encoder's next backward continues, the executor's last chunk closes
+        self.open = False
+        self._open_ws = None
 
     # ------------------------------------------------------------------ helpers
-    def _slots(self):
-        return self.net.ws.get("h2.slots", N_SLOTS)
+    def _slots(self, tag=None):
+        """tag None: the per-weights array; else the array of the pass `tag`."""
+        return self.net.ws.get(f"{self.pfx}wslots" if tag is None else f"{tag}{self.pfx}slots", N_SLOTS)
 
-    def _slot(self, i):
-        return self._slots().data_ptr() + 4 * i
+    def _slot(self, i, tag=None):
+        assert (i < N_PASS_SLOTS) == (tag is not None), i
+        return self._slots(tag).data_ptr() + 4 * i
 
     def _bytes(self, name, nbytes):
         return self.net.ws.get(name, (nbytes + 3) // 4).data_ptr()
 
+    def _wbytes(self, name, nbytes):
+        return self._bytes(self.pfx + name, nbytes)
+
     def _prepare_weights(self):
-        """Once per parameter version and executor: h2p copies of the weights in the orientations the kernels read, their
+        """Once per parameter version and block: h2p copies of the weights in the orientations the kernels read, their
         scales and the row norms that bound the outputs."""
         net = self.net
-        key = "h2.weights"
+        key = self.pfx + "weights"
         marker = self._bytes(key, 16)
         if net._derived_fresh(key, marker):
             return
         p = net._p
+        W = self._slot
         desc2 = hip.conv_desc(1, 20, 20, 32, 4, 4, 2, 64, hip.ACT_RELU)
         desc3 = hip.conv_desc(1, 9, 9, 64, 3, 3, 1, 64, hip.ACT_RELU)
         for L, K, s_w, r_w, b_w, name in ((self.c2, 512, S_W2, R_W2, B_W2, "w2"), (self.c3, 576, S_W3, R_W3, B_W3, "w3")):
             amax = net._weight_range(L.prefix, 64 * K)
-            hip.h2_weights(p(f"{L.prefix}.weight"), 64, K, 0, amax, self._slot(s_w), self._slot(r_w), self._bytes(f"h2.{name}", 64 * K * 4))
+            hip.h2_weights(p(f"{L.prefix}.weight"), 64, K, 0, amax, W(s_w), W(r_w), self._wbytes(name, 64 * K * 4))
             self._slots()[b_w:b_w + 1].zero_()
-            hip.absmax(p(f"{L.prefix}.bias"), 64, self._slot(b_w))
+            hip.absmax(p(f"{L.prefix}.bias"), 64, W(b_w))
         amax = net._weight_range(self.c3.prefix, 64 * 576)
-        hip.h2_weights(p(f"{self.c3.prefix}.weight"), 64, 576, 2, amax, self._slot(S_W3G), self._slot(R_W3G),
-                       self._bytes("h2.w3g", 64 * 576 * 4), desc=desc3)
+        hip.h2_weights(p(f"{self.c3.prefix}.weight"), 64, 576, 2, amax, W(S_W3G), W(R_W3G), self._wbytes("w3g", 64 * 576 * 4), desc=desc3)
         amax = net._weight_range(self.c2.prefix, 64 * 512)
-        hip.h2_weights(p(f"{self.c2.prefix}.weight"), 128, 256, 2, amax, self._slot(S_W2G), self._slot(R_W2G),
-                       self._bytes("h2.w2g", 128 * 256 * 4), desc=desc2)
+        hip.h2_weights(p(f"{self.c2.prefix}.weight"), 128, 256, 2, amax, W(S_W2G), W(R_W2G), self._wbytes("w2g", 128 * 256 * 4), desc=desc2)
         amax = net._weight_range(self.fc.prefix, self.H * 3136)
-        hip.h2_weights(p(f"{self.fc.prefix}.weight"), self.H, 3136, 0, amax, self._slot(S_WF), self._slot(R_WF),
-                       self._bytes("h2.wf", self.H * 3136 * 4))
-        hip.h2_weights(p(f"{self.fc.prefix}.weight"), 3136, self.H, 1, amax, self._slot(S_WFT), self._slot(R_WFT),
-                       self._bytes("h2.wft", self.H * 3136 * 4))
+        hip.h2_weights(p(f"{self.fc.prefix}.weight"), self.H, 3136, 0, amax, W(S_WF), W(R_WF), self._wbytes("wf", self.H * 3136 * 4))
+        hip.h2_weights(p(f"{self.fc.prefix}.weight"), 3136, self.H, 1, amax, W(S_WFT), W(R_WFT), self._wbytes("wft", self.H * 3136 * 4))
 
     # ------------------------------------------------------------------ forward
     def forward(self, tag, staged, obs, n, is_u8, src, mean, rstd, row_index):
         """The four layers on `n` rows.  src / mean / rstd / row_index: the first layer's staged frames and statistics as
         `_encoder_fwd` resolved them.  Returns (y Buf float32 [n, H] with its sign mask, saved)."""
-        from srl_amd.algorithm.hipnet import Buf
         net, ws = self.net, self.net.ws
         self._prepare_weights()
-        slots = self._slots()
-        slots[M_A1:M_A3 + 1].zero_()
-        a1 = self._bytes(f"{tag}h2.a1", n * 400 * 32 * 4)
-        a2 = self._bytes(f"{tag}h2.a2", n * 81 * 64 * 4)
-        a3 = self._bytes(f"{tag}h2.a3", n * 49 * 64 * 4)
-        m1 = ws.get(f"{tag}h2.m1", n * 400, torch.int32).data_ptr()
-        m2 = self._bytes(f"{tag}h2.m2", n * 81 * 8)
-        m3 = self._bytes(f"{tag}h2.m3", n * 49 * 8)
+        t = f"{tag}{self.pfx}"
+        W = self._slot
+        P = lambda i: self._slot(i, tag)
+        self._slots(tag)[M_A1:M_A3 + 1].zero_()
+        a1 = self._bytes(f"{t}a1", n * 400 * 32 * 4)
+        a2 = self._bytes(f"{t}a2", n * 81 * 64 * 4)
+        a3 = self._bytes(f"{t}a3", n * 49 * 64 * 4)
+        m1 = ws.get(f"{t}m1", n * 400, torch.int32).data_ptr()
+        m2 = self._bytes(f"{t}m2", n * 81 * 8)
+        m3 = self._bytes(f"{t}m3", n * 49 * 8)
         # first layer: frames -> a1
         desc1 = hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, hip.ACT_RELU)
         fws = ws.get(f"{self.c1.prefix}.folded", hip.conv2d_obs_fwd_workspace(desc1)).data_ptr()
         reuse = net._derived_fresh(f"{self.c1.prefix}.folded:h2", fws)
         hip.conv2d_obs_fwd_h2(desc1, src.data_ptr(), mean.data_ptr(), rstd.data_ptr(), net._p(f"{self.ln.prefix}.weight"),
                               net._p(f"{self.ln.prefix}.bias"), net._p(f"{self.c1.prefix}.weight"), net._p(f"{self.c1.prefix}.bias"),
-                              a1, self._slot(S_A1), fws, row_index, self._slot(M_A1), m1, reuse_folded=reuse, ent_order=2)
+                              a1, P(S_A1), fws, row_index, P(M_A1), m1, reuse_folded=reuse, ent_order=2)
         # conv2, conv3
-        hip.h2_conv(hip.H2_CONV2_FWD, a1, self._bytes("h2.w2", 0), self._slot(S_A1), self._slot(S_W2), n, a2, self._slot(M_A2),
-                    bias=net._p(f"{self.c2.prefix}.bias"), act=1, out_scale=self._slot(S_A2), bound_in=self._slot(M_A1),
-                    bound_w=self._slot(R_W2), bound_b=self._slot(B_W2), mask_out=m2)
-        hip.h2_conv(hip.H2_CONV3_FWD, a2, self._bytes("h2.w3", 0), self._slot(S_A2), self._slot(S_W3), n, a3, self._slot(M_A3),
-                    bias=net._p(f"{self.c3.prefix}.bias"), act=1, out_scale=self._slot(S_A3), bound_in=self._slot(M_A2),
-                    bound_w=self._slot(R_W3), bound_b=self._slot(B_W3), mask_out=m3)
+        hip.h2_conv(hip.H2_CONV2_FWD, a1, self._wbytes("w2", 0), P(S_A1), W(S_W2), n, a2, P(M_A2),
+                    bias=net._p(f"{self.c2.prefix}.bias"), act=1, out_scale=P(S_A2), bound_in=P(M_A1),
+                    bound_w=W(R_W2), bound_b=W(B_W2), mask_out=m2)
+        hip.h2_conv(hip.H2_CONV3_FWD, a2, self._wbytes("w3", 0), P(S_A2), W(S_W3), n, a3, P(M_A3),
+                    bias=net._p(f"{self.c3.prefix}.bias"), act=1, out_scale=P(S_A3), bound_in=P(M_A2),
+                    bound_w=W(R_W3), bound_b=W(B_W3), mask_out=m3)
         # Linear: float32 out (the layers behind it take the ReLU derivative from these floats, as after `_linear_fwd`)
         y = net._buf(f"{tag}{self.fc.prefix}.y", n, self.H)
-        hip.h2_gemm(a3, self._bytes("h2.wf", 0), self._slot(S_A3), self._slot(S_WF), n, self.H, 3136, y.ptr,
+        hip.h2_gemm(a3, self._wbytes("wf", 0), P(S_A3), W(S_WF), n, self.H, 3136, y.ptr,
                     bias=net._p(f"{self.fc.prefix}.bias"), act=1)
         saved = dict(n=n, a1=a1, a2=a2, a3=a3, m1=m1, m2=m2, m3=m3, first=(src, is_u8, mean, rstd, row_index), tag=tag)
         return y, saved
@@ -138,53 +152,68 @@ class H2Cnn:
         net, ws = self.net, self.net.ws
         n, tag = saved["n"], saved["tag"]
         g = net._g
-        slots = self._slots()
-        slots[M_DY:M_DZ1 + 1].zero_()
+        t = f"{tag}{self.pfx}"
+        W = self._slot
+        P = lambda i: self._slot(i, tag)
+        self._slots(tag)[M_DY:M_DZ1 + 1].zero_()
         assert dy.ld == dy.cols == self.H and dy.rows == n
         # dy -> h2p rows (its range from one pass: the producer is a float32 kernel)
-        hip.absmax(dy.ptr, n * self.H, self._slot(M_DY))
-        dyh = self._bytes(f"{tag}h2.dy", n * self.H * 4)
-        hip.h2_pack_rows(dy.ptr, self.H, n, self.H, dyh, absmax=self._slot(M_DY), scale_out=self._slot(S_DY))
-        # Linear: weight gradient through the round-3 two-piece kernel, a3 read as the h2p rows it is (gemm_bf16x3.h, BPRE == 2),
-        # beside the data-gradient chain
-        net._on_side(lambda: self._fc_wgrad(n, dy, saved["a3"]))
+        hip.absmax(dy.ptr, n * self.H, P(M_DY))
+        dyh = self._bytes(f"{t}dy", n * self.H * 4)
+        hip.h2_pack_rows(dy.ptr, self.H, n, self.H, dyh, absmax=P(M_DY), scale_out=P(S_DY))
+        # Linear: weight gradient beside the data-gradient chain
+        net._on_side(lambda: self._fc_wgrad(n, dy, dyh, saved["a3"], tag))
         # Linear data gradient -> dz3 (h2p rows [n, 49, 64]), ReLU derivative of a3 from its sign bytes
-        dz3 = self._bytes(f"{tag}h2.dz3", n * 3136 * 4)
-        hip.h2_gemm(dyh, self._bytes("h2.wft", 0), self._slot(S_DY), self._slot(S_WFT), n, 3136, self.H, dz3, out_h2=True,
-                    out_scale=self._slot(S_DZ3), bound_in=self._slot(M_DY), bound_w=self._slot(R_WFT), out_absmax=self._slot(M_DZ3),
+        dz3 = self._bytes(f"{t}dz3", n * 3136 * 4)
+        hip.h2_gemm(dyh, self._wbytes("wft", 0), P(S_DY), W(S_WFT), n, 3136, self.H, dz3, out_h2=True,
+                    out_scale=P(S_DZ3), bound_in=P(M_DY), bound_w=W(R_WFT), out_absmax=P(M_DZ3),
                     mask_in=saved["m3"], mask_in_h2order=True)
         # conv3: weight gradient (a2, dz3) beside its data gradient -> dz2 (planar)
-        wws3 = ws.get("h2.wgrad3", hip.h2_wgrad_workspace(hip.H2_WGRAD_CONV3)).data_ptr()
-        net._on_side(lambda: hip.h2_wgrad(hip.H2_WGRAD_CONV3, saved["a2"], dz3, self._slot(S_A2), self._slot(S_DZ3), n, wws3,
+        wws3 = ws.get(self.pfx + "wgrad3", hip.h2_wgrad_workspace(hip.H2_WGRAD_CONV3)).data_ptr()
+        net._on_side(lambda: hip.h2_wgrad(hip.H2_WGRAD_CONV3, saved["a2"], dz3, P(S_A2), P(S_DZ3), n, wws3,
                                           g(f"{self.c3.prefix}.weight"), g(f"{self.c3.prefix}.bias")))
-        dz2 = self._bytes(f"{tag}h2.dz2", n * 81 * 64 * 4)
-        hip.h2_conv(hip.H2_CONV3_DGRAD, dz3, self._bytes("h2.w3g", 0), self._slot(S_DZ3), self._slot(S_W3G), n, dz2, self._slot(M_DZ2),
-                    out_scale=self._slot(S_DZ2), bound_in=self._slot(M_DZ3), bound_w=self._slot(R_W3G), mask_in=saved["m2"])
+        dz2 = self._bytes(f"{t}dz2", n * 81 * 64 * 4)
+        hip.h2_conv(hip.H2_CONV3_DGRAD, dz3, self._wbytes("w3g", 0), P(S_DZ3), W(S_W3G), n, dz2, P(M_DZ2),
+                    out_scale=P(S_DZ2), bound_in=P(M_DZ3), bound_w=W(R_W3G), mask_in=saved["m2"])
         # conv2: weight gradient (a1, dz2) beside its data gradient -> dz1 (float32 NHWC for the first layer's backward)
-        wws2 = ws.get("h2.wgrad2", hip.h2_wgrad_workspace(hip.H2_WGRAD_CONV2)).data_ptr()
-        net._on_side(lambda: hip.h2_wgrad(hip.H2_WGRAD_CONV2, saved["a1"], dz2, self._slot(S_A1), self._slot(S_DZ2), n, wws2,
+        wws2 = ws.get(self.pfx + "wgrad2", hip.h2_wgrad_workspace(hip.H2_WGRAD_CONV2)).data_ptr()
+        net._on_side(lambda: hip.h2_wgrad(hip.H2_WGRAD_CONV2, saved["a1"], dz2, P(S_A1), P(S_DZ2), n, wws2,
                                           g(f"{self.c2.prefix}.weight"), g(f"{self.c2.prefix}.bias")))
-        dz1 = net._buf(f"{tag}h2.dz1", n * 400, 32)
-        hip.h2_conv(hip.H2_CONV2_DGRAD, dz2, self._bytes("h2.w2g", 0), self._slot(S_DZ2), self._slot(S_W2G), n, dz1.ptr, self._slot(M_DZ1),
+        dz1 = net._buf(f"{t}dz1", n * 400, 32)
+        hip.h2_conv(hip.H2_CONV2_DGRAD, dz2, self._wbytes("w2g", 0), P(S_DZ2), W(S_W2G), n, dz1.ptr, P(M_DZ1),
                     mask_in=saved["m1"])
-        # first layer: the round-2 byte kernel
-        src, is_u8, mean, rstd, row_index = saved["first"]
+        self.first_layer_bwd(n, saved["first"], dz1.ptr, P(M_DZ1))
+
+    def first_layer_bwd(self, n, first, dz_ptr, dz_absmax_ptr):
+        """The first layer's weight / bias / LayerNorm-affine gradients from dz (float32 NHWC [n, 20, 20, 32]) with its measured
+        range.  Inside the trainer's chunk loop the position sums (Q, R, C) of an executor's chunks add up in this block's
+        workspace and the four gradients are formed ONCE, behind the executor's last chunk (srl_conv2d_obs_bwd's `phase`).
+        Whether a call continues an accumulation is decided from the block's STATE, never from `n`: a ragged last chunk --
+        including one below H2_MIN_ROWS, which `HipNet._chain_bwd` sends here from the layer-by-layer path -- must add to and
+        close what the chunks before it opened.  Only OPENING one asks for a full-sized chunk."""
+        net = self.net
+        src, is_u8, mean, rstd, row_index = first
         desc1 = hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, hip.ACT_RELU)
         wsz = hip.conv2d_obs_bwd_workspace(desc1)
-        # Inside the trainer's chunk loop the position sums (Q, R, C) of the chunks add up in this executor's workspace and the four
-        # gradients are formed ONCE, behind the executor's last chunk (srl_conv2d_obs_bwd's `phase`); anybody else: a call of its own
         phase = 3
-        if net._in_update[0] and net.last_chunk is not None and n >= 4096 and os.environ.get("SRL_OBS_BWD_DEFER", "1")[:1] != "0":
-            first = net._obs_bwd_open is not True
-            phase = (1 if first else 0) | (2 if net.last_chunk else 0)
-            net._obs_bwd_open = not net.last_chunk
+        defer = net._in_update[0] and net.last_chunk is not None and os.environ.get("SRL_OBS_BWD_DEFER", "1")[:1] != "0"
+        if self.open or (defer and n >= 4096):
+            assert net.last_chunk is not None, "an open first-layer accumulation outside the trainer's chunk loop"
+            phase = (0 if self.open else 1) | (2 if net.last_chunk else 0)
+        wst = net.ws.get(self.pfx + "conv_obs_bwd", wsz)
+        if self.open and wst is not self._open_ws:  # (chunks only shrink towards the tail; a grown buffer would have dropped the sums)
+            raise hip.HipError("first-layer accumulation: the workspace was reallocated under an open accumulation")
+        if phase != 3:
+            self.open = not net.last_chunk
+            self._open_ws = wst if self.open else None
+        g = net._g
         hip.conv2d_obs_bwd(desc1, src.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(), net._p(f"{self.ln.prefix}.weight"),
-                           net._p(f"{self.ln.prefix}.bias"), net._p(f"{self.c1.prefix}.weight"), dz1.ptr, g(f"{self.c1.prefix}.weight"),
+                           net._p(f"{self.ln.prefix}.bias"), net._p(f"{self.c1.prefix}.weight"), dz_ptr, g(f"{self.c1.prefix}.weight"),
                            g(f"{self.c1.prefix}.bias"), g(f"{self.ln.prefix}.weight"), g(f"{self.ln.prefix}.bias"),
-                           ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=True, row_index=row_index, phase=phase,
-                           dz_absmax_ptr=self._slot(M_DZ1))
+                           wst.data_ptr(), channels_last=True, row_index=row_index, phase=phase,
+                           dz_absmax_ptr=dz_absmax_ptr)
 
-    def _fc_wgrad(self, n, dy, a3):
+    def _fc_wgrad(self, n, dy, dyh, a3, tag):
         net, g = self.net, self.net._g
         H = self.H
         tiles = ((H + 127) // 128) * ((3136 + 127) // 128)
@@ -195,7 +224,7 @@ class H2Cnn:
         gb = g(f"{self.fc.prefix}.bias")
         fused = hip.gemm_colsum_ok(H, 3136, n, dy.ptr, dy.ld, a3, 3136, 1)
         hip.gemm(H, 3136, n, dy.ptr, dy.ld, 1, a3, 3136, 1, g(f"{self.fc.prefix}.weight"), 3136, accumulate=True, split_k=split,
-                 workspace=wsp, a_colsum=gb if fused else None, a_absmax=self._slot(M_DY), b_h2_scale=self._slot(S_A3))
+                 workspace=wsp, a_colsum=gb if fused else None, a_absmax=self._slot(M_DY, tag), b_h2_scale=self._slot(S_A3, tag))
         if not fused:
             hip.colsum(dy.ptr, dy.ld, n, H, gb, accumulate=True)
 

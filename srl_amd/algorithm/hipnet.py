@@ -136,7 +136,6 @@ class HipNet:
         # set by the trainer's chunk loop before every chunk (True: this executor's last chunk of the update; None outside the loop):
         # what may accumulate over the chunks of an update in an executor's own workspace is closed behind the last one
         self.last_chunk = None
-        self._obs_bwd_open = False
         self._derived_on = os.environ.get("SRL_DERIVED_CACHE", "1") != "0"  # 0: recompute for every chunk (A/B)
         self._presplit_on = self._derived_on and os.environ.get("SRL_PRESPLIT", "1") != "0"  # weights split once per update
         self._derived = {}  # per executor: what its workspace holds that was derived from which parameter version
@@ -314,11 +313,20 @@ class HipNet:
         from srl_amd.algorithm import h2path
         if not h2path.ENABLED or not self.on_gpu:
             return None
+        # one block per ENCODER (keyed by its first layer's parameter prefix, not by the observation key: the separate actor
+        # and critic encoders of `shared_backbone=False` both read "obs" and have weights, gradients and scales of their own)
         cache = self.__dict__.setdefault("_h2_blocks", {})
-        if enc.key not in cache:
+        key = enc.layers[0].prefix if enc.layers else None
+        if key not in cache:
             m = h2path.match(enc.layers)
-            cache[enc.key] = h2path.H2Cnn(self, m) if m is not None else None
-        return cache[enc.key]
+            cache[key] = h2path.H2Cnn(self, m) if m is not None else None
+        return cache[key]
+
+    def reset_open_accumulations(self):
+        """The trainer, in front of a chunk loop: an accumulation a failed update left open is not continued."""
+        for blk in self.__dict__.get("_h2_blocks", {}).values():
+            if blk is not None:
+                blk.open, blk._open_ws = False, None
 
     def _act_range(self) -> int:
         """A fresh device float for the range of an activation of this forward pass (zero until its producer ran)."""
@@ -865,11 +873,17 @@ class HipNet:
                     gw, gb, wp = self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"), self._p(f"{L.prefix}.weight")
                     if L.first:
                         obs, is_u8, mean, rstd, lnspec, chlast, row_index = first_saved
+                        blk = self.__dict__.get("_h2_blocks", {}).get(lnspec.prefix)
                         wsz = hip.conv2d_obs_bwd_workspace(desc)
-                        hip.conv2d_obs_bwd(desc, obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(),
-                                           self._p(f"{lnspec.prefix}.weight"), self._p(f"{lnspec.prefix}.bias"), wp, g.ptr,
-                                           gw, gb, self._g(f"{lnspec.prefix}.weight"), self._g(f"{lnspec.prefix}.bias"),
-                                           self.ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=chlast, row_index=row_index)
+                        if blk is not None and blk.open:
+                            # a ragged last chunk below H2_MIN_ROWS: the executor's earlier chunks left their position sums open
+                            # in the pre-split block's workspace -- this chunk adds to them and closes (h2path.first_layer_bwd)
+                            blk.first_layer_bwd(n, (obs, is_u8, mean, rstd, row_index), g.ptr, self._grad_range(g))
+                        else:
+                            hip.conv2d_obs_bwd(desc, obs.data_ptr(), is_u8, mean.data_ptr(), rstd.data_ptr(),
+                                               self._p(f"{lnspec.prefix}.weight"), self._p(f"{lnspec.prefix}.bias"), wp, g.ptr,
+                                               gw, gb, self._g(f"{lnspec.prefix}.weight"), self._g(f"{lnspec.prefix}.bias"),
+                                               self.ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=chlast, row_index=row_index)
                         g = None
                     else:
                         wsz = hip.conv2d_wgrad_workspace(desc)

@@ -153,6 +153,9 @@ class _BucketReducer:
         if len(self.grads) > 1 and not all(self.launched):
             if self._fold_stream is None:
                 self._fold_stream = torch.cuda.Stream(device=self.grads[0].device)
+            # every pipeline's tail, the FIRST one's (the current stream) included: a bucket nobody released carries no event
+            # from any pipeline, and its fold + all-reduce read all of their buffers
+            self._fold_stream.wait_stream(torch.cuda.current_stream())
             for st in streams:
                 self._fold_stream.wait_stream(st)
         for i in range(len(self.buckets)):
@@ -721,7 +724,7 @@ class MultiAgentPPO(PytorchTrainer):
                 reducer.begin([x.grad for x in nets])
             net.chunks_of_one_update(True)
             for x in nets:
-                x._obs_bwd_open = False  # (an accumulation a failed update left open is not continued)
+                x.reset_open_accumulations()  # (an accumulation a failed update left open is not continued)
             for ci in range(nchunks):
                 r0, r1 = ci * chunk_rows, min(n_valid, (ci + 1) * chunk_rows)
                 n = r1 - r0

@@ -906,13 +906,14 @@ static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* 
     a.g = obs_geom(d, obs, mean, rstd, OW, row_index);
     a.dz = dz; a.R = R; a.C = C; a.P = P;
     a.nsplit = obs_bf16_split(d->n, P, 3);
-    SRL_CHECK_ARG(phase == 3 || a.nsplit > 1, "phase: accumulation over calls needs the split slabs (more samples per call)");
-    a.Q = a.nsplit > 1 ? slabs : Q;
+    // an accumulation over calls goes through the slab + reduce even when one slab holds the call (a ragged last chunk)
+    const bool via_slabs = a.nsplit > 1 || phase != 3;
+    a.Q = via_slabs ? slabs : Q;
     a.slab = (long)P * d->Cout * Kp;
     srl_count_dispatch(SRL_DISP_OBS_BWD_BF16, 256, 0, a.nsplit);
     hipLaunchKernelGGL(srlobs::obs_bwd_bf16_kernel<256>, dim3(srlobs::xcd_position_grid(P, a.nsplit)), dim3(256), 0, st, a);
     SRL_LAUNCH_CHECK();
-    if (a.nsplit > 1) {
+    if (via_slabs) {
       reduce_slabs(st, slabs, a.nsplit, (long)P, (long)d->Cout, Kp, Q, Kp, (long)d->Cout * Kp, first ? 0 : 1);
       SRL_LAUNCH_CHECK();
     }

@@ -164,7 +164,9 @@ class _Circular:
     def __init__(self, capacity):
         self.capacity, self.head = int(capacity), 0
 
-    def alloc(self, n, floor, what):
+    def alloc(self, n, floor, what, check=None):
+        """``check(seq)``: the caller's last word on the run [seq, seq + n) before the head moves (raises to refuse it: nothing
+        has been consumed then)."""
         if n > self.capacity:
             raise BufferError(f"{n} rows do not fit {what} of {self.capacity} rows")
         seq = self.head
@@ -173,11 +175,20 @@ class _Circular:
         if floor is not None and seq + n - self.capacity > floor:
             raise BufferError(f"{what}: the allocation would overwrite rows a training step has leased "
                               f"(capacity {self.capacity} rows)")
+        if check is not None:
+            check(seq)
         self.head = seq + n
         return seq
 
 
 _GENERATIONS = itertools.count(1)
+
+
+class WholeStackNeeded(LookupError):
+    """A stack-aware rollout request (newest planes + ``ring_prev`` stamps) could not be served: a predecessor is no longer in
+    the ring (lapped, another ring's stamp, or the -1 an unstaged row got from ``put_or_skip`` -- such stamps must not be sent
+    as ``ring_prev``), or the ring is full of leased rows.  Nothing was staged and no ring slot was consumed; the client sends
+    the same request again with whole frame stacks (no ``ring_prev``)."""
 
 
 class ObsRing:
@@ -297,11 +308,12 @@ class ObsRing:
                 stream.wait_event(ev)
 
     # ------------------------------------------------------------------ producer side (rollout)
-    def _alloc(self, n: int) -> int:
-        """First sequence number of a run of ``n`` ring slots (never laps a leased row)."""
+    def _alloc(self, n: int, check=None) -> int:
+        """First sequence number of a run of ``n`` ring slots (never laps a leased row).  ``check(seq)`` runs under the lock
+        before the run is taken; if it raises, the head has not moved."""
         with self._lock:
             floor = min((l.min_seq for l in self._leases if l.min_seq is not None), default=None)
-            seq = self._ring.alloc(n, floor, "observation ring")
+            seq = self._ring.alloc(n, floor, "observation ring", check)
             events, self._release_events["ring"] = self._release_events["ring"], []
         self._wait_released(events)
         return seq
@@ -358,13 +370,18 @@ class ObsRing:
         prev = np.asarray(prev, dtype=np.int64).reshape(-1)
         if prev.shape[0] != n:
             raise hip.HipError("`prev`: one stamp per row")
-        seq = self._alloc(n)
-        s0, head = seq % self.capacity, seq + n
         pseq, mine = self._decode(prev)
         fresh = prev == 0
-        ok = fresh | (mine & (pseq < seq) & (pseq + self.capacity >= head))   # still there once this run is written
-        if not ok.all():
-            raise LookupError(f"{int((~ok).sum())} of {n} previous observations are no longer in the ring: send whole stacks")
+
+        def predecessors_survive(seq):
+            # validated against the run this call WOULD take, before it takes it: a refused call burns no slots and laps nobody
+            # else's predecessors (a dead stamp -- a lapped row, another ring's stamp, the -1 of `put_or_skip` -- is refused here)
+            ok = fresh | (mine & (pseq < seq) & (pseq + self.capacity >= seq + n))  # still there once this run is written
+            if not ok.all():
+                raise LookupError(f"{int((~ok).sum())} of {n} previous observations are no longer in the ring: send whole stacks")
+
+        seq = self._alloc(n, predecessors_survive)
+        s0 = seq % self.capacity
         slots = torch.from_numpy(np.where(fresh, -1, pseq % self.capacity).astype(np.int32)).to(self.device, non_blocking=True)
         for k, t in tensors.items():
             c, h, w = self.raw_shape[k]

@@ -153,6 +153,7 @@ class FilesystemParameterDB(ParameterDBClient):
                 time.sleep(1)
             else:
                 raise missing
+        raise missing  # the budget is spent: the file never appeared (``block``), or every read lost its race
 
     def list_names(self):
         return [n for n in os.listdir(self._workdir) if len(self.list_tags(n)) > 0]

@@ -290,6 +290,62 @@ def test_cnn_step_vs_oracle_chunked():
         assert abs(res.stats[k] - ostats[k]) <= 2e-5 * max(abs(ostats[k]), 1e-2), (k, res.stats[k], ostats[k])
 
 
+def test_separate_actor_and_critic_cnn_on_the_presplit_path_vs_oracle():
+    """`shared_backbone=False` (the reference's default `actor-critic` registration, actor_critic_policy.py:146-166) with the
+    Atari stack: the actor's and the critic's encoder both read the key "obs" and have weights of their own.  With 288 rows per
+    chunk both go through the pre-split block (h2path.py, >= H2_MIN_ROWS rows), each with ITS weights, scales and gradients --
+    two chunks per update, so that the second chunk's forward runs over the first one's buffers: loss terms, the gradient norm
+    and every parameter after two steps against the float32 oracle."""
+    from srl_amd import hip
+    pargs = dict(CNN_POLICY, shared_backbone=False, seed=6)
+    trainer = make_trainer(pargs, dict(ATARI_TRAINER, chunk_rows=288))
+    onet = OracleActorCritic(**pargs)
+    onet.load_state_dict({k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()})
+    oracle = OracleMappo(onet, **ATARI_TRAINER)
+    hip.dispatch_counts(reset=True)
+    for step in range(2):
+        arrays = synthetic.make_sample_arrays(seed=31 + step, T=18, B=32, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.05)
+        sample = synthetic.to_sample_batch(arrays)
+        res = trainer.step(sample)
+        ostats, oout = oracle.step(arrays)
+        assert close(sample.analyzed_result.ret, oout["ret"], 1e-5), step
+        for k in ("policy_loss", "value_loss", "entropy"):
+            assert abs(res.stats[k] - ostats[k]) <= 1e-5 * max(abs(ostats[k]), 1e-2), (step, k, res.stats[k], ostats[k])
+        assert abs(res.stats["grad_norm"] - ostats["grad_norm"]) <= 5e-5 * max(abs(ostats["grad_norm"]), 1e-2), step
+    counts = hip.dispatch_counts(reset=True)
+    assert counts["h2"] == 2 * 2 * 2 * 8, counts  # steps x chunks x encoders x the block's eight launches
+    net = trainer.policy.net
+    assert len([b for b in net._h2_blocks.values() if b is not None]) == 2  # one block per encoder, not per observation key
+    sd, osd = trainer.policy.get_checkpoint()["state_dict"], onet.state_dict()
+    moved = 0
+    for k in sd:
+        assert np.abs(sd[k].numpy() - osd[k].numpy()).max() <= 5e-5, (k, np.abs(sd[k].numpy() - osd[k].numpy()).max())
+        moved += int(k.startswith("critic") or "state_modules" in k)
+    assert moved > 0, list(sd)  # the critic's own encoder parameters exist and were compared
+
+
+@pytest.mark.parametrize("tail,pipelines", [(512, 1), (100, 1), (512, 2)])
+def test_first_layer_accumulation_with_a_ragged_last_chunk(tail, pipelines, monkeypatch):
+    """The chunks of an update share one finalisation of the first layer's gradients (srl_conv2d_obs_bwd `phase`): a last chunk
+    shorter than the others -- 512 rows: still on the pre-split block; 100 rows: below H2_MIN_ROWS, on the layer-by-layer path --
+    must add to and close what the chunks before it opened.  Against the same step with SRL_OBS_BWD_DEFER=0 (every chunk
+    finalises by itself): conv1 / observation LayerNorm gradients to float32 summation-order accuracy."""
+    T, B, chunk = 1, 2 * 4096 + tail, 4096
+    arrays = synthetic.make_sample_arrays(seed=5, T=T, B=B, obs_spec=synthetic.ATARI_OBS, action_dims=6, p_done=0.05)
+    grads = {}
+    for defer in ("1", "0"):
+        monkeypatch.setenv("SRL_OBS_BWD_DEFER", defer)
+        trainer = make_trainer(CNN_POLICY, dict(ATARI_TRAINER, chunk_rows=chunk, pipelines=pipelines))
+        trainer.step(synthetic.to_sample_batch(arrays))
+        net = trainer.policy.net
+        grads[defer] = {k: v.clone() for k, v in net.flat_to_reference(net.grad.detach().cpu()).items()}
+        assert not any(b.open for x in [net] + list(trainer._twin or []) for b in x._h2_blocks.values() if b is not None)
+    for k, g0 in grads["0"].items():
+        g1 = grads["1"][k]
+        scale = float(g0.abs().max())
+        assert float((g1 - g0).abs().max()) <= 2e-5 * max(scale, 1e-8), (k, float((g1 - g0).abs().max()), scale)
+
+
 def _pong_frames(rng, Tb, B):
     """Atari-`pong`-type frames: a flat bright background (large mean, tiny variance) with a few small sprites -- the
     case in which an un-centred byte contraction loses digits (first convolution on bytes)."""
@@ -310,21 +366,22 @@ def _trunk_activations(net, n):
     from srl_amd import hip
     P = "obs_modules_dict.obs."
     bufs = net.ws._bufs
-    if "a:h2.a1" not in bufs:
+    H2 = f"a:h2[{P}1._Convolution__model.0]."  # the block's own name in front of its buffers (h2path.H2Cnn.pfx), under the pass tag
+    if H2 + "a1" not in bufs:
         return [bufs[f"a:{P}1._Convolution__model.{idx}.y"] for idx in (0, 2, 4)] + [bufs[f"a:{P}1._Convolution__model.7.0.y"]]
     from srl_amd.algorithm import h2path
-    slots = bufs["h2.slots"]
+    slots = bufs[H2 + "slots"]
     sp = lambda i: slots.data_ptr() + 4 * i
     a1 = torch.empty(n * 400 * 32, device="cuda:0")
-    hip.h2_unpack_rows(bufs["a:h2.a1"].data_ptr(), n * 400, 32, sp(h2path.S_A1), a1.data_ptr(), 32)
+    hip.h2_unpack_rows(bufs[H2 + "a1"].data_ptr(), n * 400, 32, sp(h2path.S_A1), a1.data_ptr(), 32)
     # rows of a sample are in parity-class order: entry = ((y & 1) * 2 + (x & 1)) * 100 + (y >> 1) * 10 + (x >> 1)
     yy, xx = np.meshgrid(np.arange(20), np.arange(20), indexing="ij")
     ent = torch.from_numpy((((yy & 1) * 2 + (xx & 1)) * 100 + (yy >> 1) * 10 + (xx >> 1)).reshape(-1)).to("cuda:0")
     a1 = a1.view(n, 400, 32)[:, ent, :].reshape(-1)
     a2 = torch.empty(n * 81 * 64, device="cuda:0")
-    hip.h2_unpack_image(bufs["a:h2.a2"].data_ptr(), n, 9, 9, 64, 0, sp(h2path.S_A2), a2.data_ptr())
+    hip.h2_unpack_image(bufs[H2 + "a2"].data_ptr(), n, 9, 9, 64, 0, sp(h2path.S_A2), a2.data_ptr())
     a3 = torch.empty(n * 49 * 64, device="cuda:0")
-    hip.h2_unpack_rows(bufs["a:h2.a3"].data_ptr(), n * 49, 64, sp(h2path.S_A3), a3.data_ptr(), 64)
+    hip.h2_unpack_rows(bufs[H2 + "a3"].data_ptr(), n * 49, 64, sp(h2path.S_A3), a3.data_ptr(), 64)
     return [a1, a2, a3, bufs[f"a:{P}1._Convolution__model.7.0.y"]]
 
 

@@ -252,13 +252,20 @@ def test_stack_aware_requests_match_whole_stack_requests_bit_for_bit():
     # a predecessor the ring no longer holds: the ring says so and the caller sends the whole stack
     for _ in range(2):   # two more laps' worth of rows
         ring_b.put({"obs": torch.from_numpy(stacks[:4].reshape(-1, 4, 84, 84)).cuda()})
-    with pytest.raises(LookupError):
+    from srl_amd.runtime.obs_ring import WholeStackNeeded
+    head = ring_b.head
+    with pytest.raises(WholeStackNeeded):   # (a LookupError: the policy's defined per-request refusal)
         b.rollout(policy_api.RolloutRequest(obs=NamedArray(obs=planes[0], ring_prev=refs_b[0]), is_evaluation=np.zeros((B, 1), np.uint8),
                                             on_reset=np.zeros((B, 1), np.uint8)))
     foreign = refs_a[-1]   # another ring's stamps are not predecessors here either
     with pytest.raises(LookupError):
         b.rollout(policy_api.RolloutRequest(obs=NamedArray(obs=planes[0], ring_prev=foreign), is_evaluation=np.zeros((B, 1), np.uint8),
                                             on_reset=np.zeros((B, 1), np.uint8)))
+    unstaged = np.full((B, 1), -1, np.int64)   # what `put_or_skip` hands out for a row it could not stage
+    with pytest.raises(WholeStackNeeded):
+        b.rollout(policy_api.RolloutRequest(obs=NamedArray(obs=planes[0], ring_prev=unstaged), is_evaluation=np.zeros((B, 1), np.uint8),
+                                            on_reset=np.zeros((B, 1), np.uint8)))
+    assert ring_b.head == head   # a refused request consumed no ring slots (and so lapped nobody else's predecessor)
 
 
 @pytest.mark.gpu

@@ -41,6 +41,18 @@ def test_push_tag_get_gc_match_the_reference_listing(tmp_path, golden):
     assert db.list_versions("pol") == []
 
 
+def test_get_raises_when_the_retry_budget_is_spent(tmp_path):
+    """parameter_db.py:193-217 of the reference: a checkpoint that never appears is a FileNotFoundError, blocking or not --
+    never a silent None that a caller would load as a checkpoint."""
+    db = FilesystemParameterDB("exp", "trial", root=str(tmp_path), user_namespace="ns")
+    with pytest.raises(FileNotFoundError):
+        db.get("p", "latest", block=True, retry_times=0)
+    with pytest.raises(FileNotFoundError):
+        db.get("p", "latest", block=False)
+    with pytest.raises(FileNotFoundError):
+        db.version_of("p", "latest")
+
+
 def test_sample_admission_rule():
     arr = synthetic.make_sample_arrays(seed=0, T=4, B=3, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2)
     s = synthetic.to_sample_batch(arr)
