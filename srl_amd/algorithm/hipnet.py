@@ -161,6 +161,12 @@ class HipNet:
                 elif isinstance(L, ns.LinearSpec):
                     per_row = max(per_row, L.in_features, L.out_features)
         self.encoder_rows = max(1, (16 << 30) // (4 * per_row))
+        # the pre-split block addresses an activation with 31-bit byte offsets (srl_h2_conv: n * 20 * 20 * 32 * 4 < 2 GiB): an encoder
+        # it serves goes through in pieces of at most 32 768 rows (`analyze` on a whole 4096 x 128 sample; the trainer's own row
+        # chunks are smaller anyway)
+        from srl_amd.algorithm import h2path
+        if h2path.ENABLED and any(h2path.match(enc.layers) is not None for enc in self._encoders()):
+            self.encoder_rows = min(self.encoder_rows, 32768)
 
     # ------------------------------------------------------------------ parameters / checkpoints
     def ref_names(self):

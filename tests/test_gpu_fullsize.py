@@ -48,6 +48,30 @@ def check_gae_vs_oracle(sample, arr, gamma=0.99, lmbda=0.97, popart_net=None):
     assert (adv[Tn:] == 0).all() and (ret[Tn:] == 0).all()  # the zero pad row (mappo.py:254-256)
 
 
+def check_analyze_rows_vs_oracle(tr, smp, sample, arr, picks=64):
+    """Full-size NETWORK outputs against the oracle, not only properties: `policy.analyze(target="ppo")` over ALL 4096 x 128 rows
+    of the sample (actor_critic_policy.py:338-390; the encoder walks them in pieces of 32 768 rows on the kernels the benchmark
+    times), then new log-probability, state value and entropy of 64 sampled (t, b) positions against the float32
+    `OracleActorCritic` evaluated on just those rows, 1e-5 relative (BASELINE.json's bar)."""
+    from oracle.net import OracleActorCritic
+    t_all, b_all = arr["reward"].shape[0] - 1, arr["reward"].shape[1]
+    ar = tr.policy.analyze(smp[:t_all], target="ppo")
+    rng = np.random.default_rng(123)
+    # spread over the pieces and row chunks: the first and last rows of the sample, the rest uniformly
+    ts = np.concatenate([[0, t_all - 1], rng.integers(0, t_all, picks - 2)])
+    bs = np.concatenate([[0, b_all - 1], rng.integers(0, b_all, picks - 2)])
+    got = [x[ts, bs].detach().cpu().numpy().reshape(picks) for x in (ar.new_action_log_probs, ar.state_values, ar.entropy)]
+    onet = OracleActorCritic(**POLICY)
+    onet.load_state_dict({k: v.numpy() for k, v in tr.policy.get_checkpoint()["state_dict"].items()})
+    frames = sample["obs.obs"][torch.from_numpy(ts).cuda(), torch.from_numpy(bs).cuda()].cpu()   # [picks, 4, 84, 84] uint8
+    action = torch.from_numpy(arr["action.x"][ts, bs].astype(np.int64))[None]
+    with torch.no_grad():
+        lp, val, ent, _ = onet.analyze({"obs": frames[None].float()}, action, None)
+    for name, g, o in zip(("log-prob", "value", "entropy"), got, (lp, val, ent)):
+        o = o.numpy().reshape(picks)
+        assert (np.abs(g - o) <= 1e-5 * np.maximum(np.abs(o), 1.0)).all(), (name, float(np.abs(g - o).max()))
+
+
 def make(chunk_rows):
     return trainer_api.make(config.Trainer("mappo", args=dict(TRAINER, chunk_rows=chunk_rows)),
                             config.Policy("actor-critic", args=POLICY))
@@ -114,6 +138,8 @@ def test_config2_step_4096_envs():
     for chunk in (16384, 32768, 16384):
         tr = make(chunk)
         smp = synthetic.to_sample_batch(dict(sample))
+        if not results:
+            check_analyze_rows_vs_oracle(tr, smp, sample, arr)
         res = tr.step(smp)
         results.append((res.stats, tr.policy.get_checkpoint()["state_dict"]))
         if chunk == 16384 and len(results) == 1:
