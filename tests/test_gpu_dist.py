@@ -37,7 +37,7 @@ def _rank_arrays(step, rank, world, unequal=False):
     return {k: np.ascontiguousarray(v[:, rank * half:(rank + 1) * half]) for k, v in full.items()}
 
 
-def _worker(rank, world, port, out, unequal=False, pipelines=2):
+def _worker(rank, world, port, out, unequal=False, pipelines=2, chunk_rows=100):
     import srl_amd
     from srl_amd.api import config, trainer as trainer_api
     from srl_amd.runtime import synthetic
@@ -45,7 +45,7 @@ def _worker(rank, world, port, out, unequal=False, pipelines=2):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         # different seeds: joining the group must adopt rank 0's parameters (what the DDP constructor does)
-        trainer = trainer_api.make(config.Trainer("mappo", args=dict(TRAINER, pipelines=pipelines)),
+        trainer = trainer_api.make(config.Trainer("mappo", args=dict(TRAINER, pipelines=pipelines, chunk_rows=chunk_rows)),
                                    config.Policy("actor-critic", args=dict(POLICY, seed=7 + rank)))
         trainer.distributed(rank=rank, world_size=world, init_method=None)
         init = {k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()}
@@ -55,20 +55,23 @@ def _worker(rank, world, port, out, unequal=False, pipelines=2):
             stats.append(res.stats)
         final = {k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()}
         out[rank] = dict(init=init, final=final, stats=stats, reducer=dict(trainer._reducer.stats),
-                         buckets=len(trainer._reducer.buckets))
+                         buckets=len(trainer._reducer.buckets), pipes=1 + len(trainer._twin or []))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("unequal,pipelines", [(False, 2), (True, 2), (False, 1)],
-                         ids=["split-batch", "unequal-mask-counts", "one-pipeline"])
-def test_two_rank_trainer_matches_ddp_semantics(unequal, pipelines):
+@pytest.mark.parametrize("unequal,pipelines,chunk_rows", [(False, 2, 100), (True, 2, 100), (False, 1, 100), (False, 4, 30)],
+                         ids=["split-batch", "unequal-mask-counts", "one-pipeline", "default-four-pipelines"])
+def test_two_rank_trainer_matches_ddp_semantics(unequal, pipelines, chunk_rows):
     """144 rows per rank in chunks of 100: with the default two pipelines each chunk is the LAST chunk of its pipeline, so
     both backward passes release buckets (`_BucketReducer.ready` on device, one event per pipeline and bucket) and every
     bucket's all-reduce is launched from inside the second backward pass after the other pipeline's slice was folded in;
     with one pipeline the second chunk's backward releases them.  `unequal`: the ranks' masks hold very different counts.  Reference semantics (mappo.py:184,197,199 under DDP): each
     rank divides its masked sums by its LOCAL count, the gradients are then averaged over ranks with equal weight, while the
-    advantage normalisation uses the GLOBAL statistics -- not a global masked mean of the loss."""
+    advantage normalisation uses the GLOBAL statistics -- not a global masked mean of the loss.
+    `default-four-pipelines`: 144 rows per rank in chunks of 30 = five chunks on the trainer's DEFAULT four pipelines (the first
+    executor takes chunks 0 and 4, its three twins one each): a bucket leaves when the fourth pipeline has released it, after
+    THREE twin slices were folded into the first buffer on the reduction stream -- on device, nothing left for `finish`."""
     from oracle.net import OracleActorCritic
     from oracle.trainer import OracleMappo
     world = 2
@@ -77,13 +80,14 @@ def test_two_rank_trainer_matches_ddp_semantics(unequal, pipelines):
         assert counts[0] > 1.15 * counts[1], counts
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), out, unequal, pipelines), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), out, unequal, pipelines, chunk_rows), nprocs=world, join=True)
         res = {r: out[r] for r in range(world)}
     for r in range(world):  # the overlap ran: every bucket of every epoch left from inside a backward pass
         red, nb = res[r]["reducer"], res[r]["buckets"]
         epochs = STEPS * TRAINER["ppo_epochs"]
         assert nb >= 3 and red["launched_in_backward"] == nb * epochs and red["launched_in_finish"] == 0, red
-        assert red["slices_folded"] == (nb * epochs if pipelines == 2 else 0), red
+        assert res[r]["pipes"] == pipelines, res[r]["pipes"]
+        assert red["slices_folded"] == nb * epochs * (pipelines - 1), red
     for k in res[0]["init"]:  # both ranks start from rank 0's parameters and stay identical
         assert np.array_equal(res[0]["init"][k], res[1]["init"][k]), k
         assert np.array_equal(res[0]["final"][k], res[1]["final"][k]), k
