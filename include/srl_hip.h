@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 14
+#define SRL_HIP_ABI_VERSION 15
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -270,6 +270,33 @@ int srl_categorical_bwd(void* stream, const float* logits, int ld_logits, const 
 int srl_categorical_sample(void* stream, const float* logits, int ld_logits, const uint8_t* avail,
                            const uint8_t* is_eval, long n, int n_heads, const int32_t* host_head_dims,
                            uint64_t seed, uint64_t offset, int64_t* action_out, float* logp, int64_t row0);
+
+/* ------------------------------------------------------------------------------------------------
+ * Phasic Policy Gradient, auxiliary phase (ABI 15).
+ *
+ * srl_categorical_log_softmax: out[i, head h] = masked logits - logsumexp over the head -- the `.logits` of the
+ * torch.distributions.Categorical objects `analyze(target="ppg_aux_phase")` returns and the trainer's cache keeps
+ * (actor_critic_policy.py:266-270, 417-435; phasic_policy_gradient.py:215-221), unavailable actions at -1e10 before the
+ * normalisation (:135-136).  logits [n, sum(head_dims)] (row stride ld_logits), avail uint8 [n, sum(head_dims)] or NULL.
+ *
+ * srl_ppg_aux_loss_fwd_bwd: MultiAgentPPG._compute_aux_loss (phasic_policy_gradient.py:262-280) and its autograd backward with
+ * respect to the network's outputs, one pass:
+ *   L = aux_value_loss + beta_clone * policy_distance + value_head_weight * value_head_loss
+ *   policy_distance = sum_heads sum_rows KL(old_h || new_h) (1 - done) / sum_rows (1 - done)      (_policy_distance, :140-144;
+ *                     KL as torch.distributions.kl_divergence of two Categoricals: 0 where p == 0, +inf where q == 0 < p)
+ *   *_value_loss    = 1/2 sum (v - target)^2 (1 - done) / sum_rows (1 - done)                     (_paper_value_loss, :146-147)
+ * logq_old [n, A]: normalised log-probabilities kept by the cache entry; logits [n, A]: the current policy's raw logits;
+ * aux_value / pred_value / target float32 [n, value_dim]; done uint8 [n] (the entry's info_mask, :264);
+ * undone_count: device float64, sum_rows (1 - done) (srl_masked_stats with mask_invert).
+ * Outputs: d_logits [n, A] (row stride ld_dlogits; zero at unavailable actions), d_aux, d_pred [n, value_dim] = d L / d input;
+ * terms float64[3] (zeroed by the call) = {aux_value_loss, value_head_loss, policy_distance}. */
+int srl_categorical_log_softmax(void* stream, const float* logits, int ld_logits, const uint8_t* avail, long n, int n_heads,
+                                const int32_t* host_head_dims, float* out, int ld_out);
+int srl_ppg_aux_loss_fwd_bwd(void* stream, const float* logq_old, int ld_old, const float* logits, int ld_logits,
+                             const uint8_t* avail, long n, int n_heads, const int32_t* host_head_dims, const float* aux_value,
+                             const float* pred_value, const float* target, int value_dim, const uint8_t* done,
+                             const double* undone_count, float beta_clone, float value_head_weight, float* d_logits,
+                             int ld_dlogits, float* d_aux, float* d_pred, double* terms);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense contraction on the FP32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA chains).

@@ -10,6 +10,7 @@ reference's checkpoints and the golden fixtures load directly) of:
 * ``Convolution`` (Conv2d, pad 0)  ``legacy/algorithm/modules/cnn.py:39-135``
 * ``AutoResetRNN`` (GRU)           ``legacy/algorithm/modules/autoreset_rnn.py:42-66``
 * ``_ppo_analyze`` / ``rollout``   ``actor_critic_policy.py:338-390`` / ``:458-528``
+* ``_ppg_phase2_analyze``          ``actor_critic_policy.py:417-435`` (``analyze_aux``; the loss side is ``oracle/ppg.py``)
 
 TEST INFRASTRUCTURE ONLY (see package doc).  Parameter *initialisation* is not restated here: the
 oracle always runs on weights handed to it (from a fixture, or from the product's own initialiser).
@@ -211,6 +212,9 @@ class OracleActorCritic:
             logits = logits.masked_fill(obs["available_action"] == 0, -1e10)  # actor_critic_policy.py:135-136
         head = "critic_head._PopArtValueHead__" if self.popart else "critic_head."  # popart.py:21-22,39-40
         value = F.linear(c_feat, self._p(head + "weight"), self._p(head + "bias"))
+        # PPG's auxiliary value head reads the ACTOR's features (actor_critic_policy.py:105-107, 139-140)
+        self._aux_value = (F.linear(a_feat, self._p("auxiliary_value_head.weight"), self._p("auxiliary_value_head.bias"))
+                           if "auxiliary_value_head.weight" in self.params else None)
         return logits, value, new_state
 
     # ------------------------------------------------------------------ PopArt (popart.py:8-59, modules/utils.py:70-151)
@@ -294,6 +298,23 @@ class OracleActorCritic:
         lp = torch.stack([d.log_prob(action[..., i]) for i, d in enumerate(dists)], -1).sum(-1, keepdim=True)
         ent = torch.stack([d.entropy() for d in dists], -1).sum(-1, keepdim=True)
         return lp, value, ent, logits
+
+    def analyze_aux(self, obs, on_reset, policy_state=None):
+        """PPG auxiliary-phase analysis (actor_critic_policy.py:417-435): per action head the NORMALISED log-probabilities
+        (``Categorical(logits=...).logits``) [T,B,A_h], the auxiliary value and the critic head's value [T,B,value_dim]; recurrent
+        nets are chunked from the stored states exactly as in ``analyze``."""
+        if self.num_rnn_layers == 0:
+            logits, value, _ = self.forward(obs)
+            aux = self._aux_value
+        else:
+            T = on_reset.shape[0]
+            n = T // self.chunk_len
+            chunk = lambda x: torch.cat(torch.split(x, T // n, dim=0), dim=1)
+            unchunk = lambda x: torch.cat(torch.split(x, x.shape[1] // n, dim=1), dim=0)
+            state = tuple(chunk(s)[0].transpose(0, 1) for s in policy_state)
+            logits, value, _ = self.forward({k: chunk(v) for k, v in obs.items()}, state, chunk(on_reset))
+            logits, value, aux = unchunk(logits), unchunk(value), unchunk(self._aux_value)
+        return [d.logits for d in self._heads(logits)], aux, value
 
     @torch.no_grad()
     def rollout_eval(self, obs, policy_state=(None, None)):

@@ -22,7 +22,8 @@ import torch.distributed as dist
 from srl_amd import hip
 from srl_amd.algorithm import netspec as ns
 from srl_amd.algorithm.hipnet import HipNet, RnnCtx
-from srl_amd.algorithm.ppo_types import PPORolloutAnalyzedResult, SampleAnalyzedResult
+from srl_amd.algorithm.ppo_types import (CategoricalLogits, PPGPhase1AnalyzedResult, PPGPhase2AnalyzedResult, PPORolloutAnalyzedResult,
+                                         SampleAnalyzedResult)
 from srl_amd.api import policy as policy_api
 from srl_amd.api.env_utils import DiscreteAction
 from srl_amd.namedarray import NamedArray
@@ -504,9 +505,65 @@ class ActorCriticPolicy(policy_api.Policy):
 
     # ------------------------------------------------------------------ training-side analysis
     def analyze(self, sample, target="ppo", **kwargs):
-        if target != "ppo":
-            raise ValueError(f"Analyze method for algorithm {target} not implemented for {self.__class__.__name__}")
-        return self._ppo_analyze(sample, **kwargs)
+        """actor_critic_policy.py:272-296."""
+        if target == "ppo":
+            return self._ppo_analyze(sample, **kwargs)
+        if target == "ppg_ppo_phase":
+            return self._ppg_phase1_analyze(sample, **kwargs)
+        if target == "ppg_aux_phase":
+            return self._ppg_phase2_analyze(sample, **kwargs)
+        raise ValueError(f"Analyze method for algorithm {target} not implemented for {self.__class__.__name__}")
+
+    def _ppg_phase1_analyze(self, sample, **kwargs):
+        """actor_critic_policy.py:392-415: the PPO analysis plus the auxiliary head's values (which take no gradient there)."""
+        if self.spec.aux_head is None:
+            raise RuntimeError("Cannot run ppg analysis without auxiliary_head. Try setting auxiliary_head=True.")
+        ar = self._ppo_analyze(sample, **kwargs)
+        T, B = ar.new_action_log_probs.shape[:2]
+        reward = to_device_leaf(sample.reward, self.device, "real")
+        return PPGPhase1AnalyzedResult(old_action_log_probs=ar.old_action_log_probs, new_action_log_probs=ar.new_action_log_probs,
+                                       aux_values=self._net.aux_value.view(T, B, -1), state_values=ar.state_values,
+                                       reward=reward, entropy=ar.entropy)
+
+    def _ppg_phase2_analyze(self, sample, **kwargs):
+        """actor_critic_policy.py:417-435: the current action distributions (per head, as normalised log-probabilities -- with
+        unavailable actions at -1e10 before the normalisation, :135-136), the auxiliary and the critic head's values.  ``sample``
+        carries ``obs``, ``on_reset`` and, for a recurrent policy, ``policy_state`` (the auxiliary phase's cache entry).  The
+        forward context is kept: ``backward_ppg_aux`` follows."""
+        if self.spec.aux_head is None:
+            raise RuntimeError("Cannot run ppg analysis without auxiliary_head. Try setting auxiliary_head=True.")
+        if self.spec.std_type:
+            raise NotImplementedError("the auxiliary phase is built for categorical action heads")
+        T, B = sample.on_reset.shape[0], sample.on_reset.shape[1]
+        n = T * B
+        obs = {k: to_device_leaf(v, self.device, "obs").reshape(n, *v.shape[2:]) for k, v in sample.obs.items() if v is not None}
+        avail = obs.pop("available_action", None)
+        obs.pop("is_alive", None)
+        rnn = None
+        if self.spec.num_rnn_layers:
+            if sample.policy_state is None:
+                raise ValueError("recurrent policy: the sample carries no policy_state")
+            ps = {k: to_device_leaf(v, self.device, "real") for k, v in sample.policy_state.items()}
+            rnn = self._rnn_ctx_with_burn_in({k: to_device_leaf(v, self.device, "obs") for k, v in sample.obs.items() if v is not None},
+                                             None, ps, to_device_leaf(sample.on_reset, self.device, "flag"), 0, T, B)
+        logits, value = self._net.forward(obs, n, keep_tape=True, rnn=rnn)
+        logq = torch.empty_like(logits)
+        hip.categorical_log_softmax(logits, avail, self.spec.act_dims, logq)
+        self._analysis = (logits, None, avail, n)
+        dists, start = [], 0
+        for d in self.spec.act_dims:
+            dists.append(CategoricalLogits(logq[:, start:start + d].reshape(T, B, d)))
+            start += d
+        self._aux_logq = logq
+        return PPGPhase2AnalyzedResult(action_dists=dists, auxiliary_value=self._net.aux_value.view(T, B, -1),
+                                       predicted_value=value.view(T, B, -1))
+
+    def backward_ppg_aux(self, d_logits: torch.Tensor, d_aux: torch.Tensor, d_value: torch.Tensor):
+        """Back-propagate the auxiliary loss's gradients with respect to the raw logits, the auxiliary values and the critic head's
+        values of the last ``analyze(target="ppg_aux_phase")`` into ``net.grad``."""
+        _, _, _, n = self._analysis
+        self._net.backward(d_logits.reshape(n, -1), d_value.reshape(n, -1), None, d_aux=d_aux.reshape(n, -1))
+        self._analysis = None
 
     def _ppo_analyze(self, sample, burn_in_steps=0, **kwargs):
         """New log-probs, state values and entropy for every row of ``sample`` (leaves ``[T, B, ...]``).
@@ -576,3 +633,5 @@ policy_api.register("actor-critic-separate-continuous-action",
                                       continuous_action=True))  # :539-540
 policy_api.register("actor-critic-shared",
                     functools.partial(ActorCriticPolicy, shared_backbone=True, auxiliary_head=False))
+policy_api.register("actor-critic-auxiliary",
+                    functools.partial(ActorCriticPolicy, shared_backbone=False, auxiliary_head=True))  # :535-536

@@ -168,6 +168,7 @@ class H2Cnn:
         hip.h2_gemm(dyh, self._wbytes("wft", 0), P(S_DY), W(S_WFT), n, 3136, self.H, dz3, out_h2=True,
                     out_scale=P(S_DZ3), bound_in=P(M_DY), bound_w=W(R_WFT), out_absmax=P(M_DZ3),
                     mask_in=saved["m3"], mask_in_h2order=True)
+        net._release([self.fc.prefix])   # data parallel: the Linear's 6.4 MB bucket leaves under the convolutions' backward
         # conv3: weight gradient (a2, dz3) beside its data gradient -> dz2 (planar)
         wws3 = ws.get(self.pfx + "wgrad3", hip.h2_wgrad_workspace(hip.H2_WGRAD_CONV3)).data_ptr()
         net._on_side(lambda: hip.h2_wgrad(hip.H2_WGRAD_CONV3, saved["a2"], dz3, P(S_A2), P(S_DZ3), n, wws3,
@@ -175,6 +176,7 @@ class H2Cnn:
         dz2 = self._bytes(f"{t}dz2", n * 81 * 64 * 4)
         hip.h2_conv(hip.H2_CONV3_DGRAD, dz3, self._wbytes("w3g", 0), P(S_DZ3), W(S_W3G), n, dz2, P(M_DZ2),
                     out_scale=P(S_DZ2), bound_in=P(M_DZ3), bound_w=W(R_W3G), mask_in=saved["m2"])
+        net._release([self.c3.prefix])
         # conv2: weight gradient (a1, dz2) beside its data gradient -> dz1 (float32 NHWC for the first layer's backward)
         wws2 = ws.get(self.pfx + "wgrad2", hip.h2_wgrad_workspace(hip.H2_WGRAD_CONV2)).data_ptr()
         net._on_side(lambda: hip.h2_wgrad(hip.H2_WGRAD_CONV2, saved["a1"], dz2, P(S_A1), P(S_DZ2), n, wws2,
@@ -182,7 +184,9 @@ class H2Cnn:
         dz1 = net._buf(f"{t}dz1", n * 400, 32)
         hip.h2_conv(hip.H2_CONV2_DGRAD, dz2, self._wbytes("w2g", 0), P(S_DZ2), W(S_W2G), n, dz1.ptr, P(M_DZ1),
                     mask_in=saved["m1"])
+        net._release([self.c2.prefix])
         self.first_layer_bwd(n, saved["first"], dz1.ptr, P(M_DZ1))
+        net._release([self.ln.prefix, self.c1.prefix])
 
     def first_layer_bwd(self, n, first, dz_ptr, dz_absmax_ptr):
         """The first layer's weight / bias / LayerNorm-affine gradients from dz (float32 NHWC [n, 20, 20, 32]) with its measured

@@ -348,9 +348,10 @@ class HipNet:
 
     def _on_side(self, fn):
         """Run ``fn`` (launches of a weight gradient) on the second stream, after everything enqueued so far on the
-        compute stream; without the switch, or while gradient buckets are being released (their all-reduce is ordered
-        against the compute stream only), inline."""
-        if not self._wgrad_side or self.grad_ready_hook is not None:
+        compute stream; without the switch, inline.  (While gradient buckets are being released, too: ``_release`` records a
+        bucket's event behind BOTH streams -- until round 5 such passes ran everything inline, which cost the last chunk of every
+        pipeline, i.e. EVERY chunk of an 8-GPU shard, the overlap.)"""
+        if not self._wgrad_side:
             fn()
             return
         if self._side_stream is None:
@@ -359,6 +360,20 @@ class HipNet:
         with torch.cuda.stream(self._side_stream):
             fn()
         self._side_used = True
+
+    def _release(self, prefixes):
+        """Data parallel: the gradients of these parameters are final in this executor's order of work.  Their weight gradients
+        may be running on the second stream: the hook then runs under THAT stream, behind a wait for the compute stream, so the
+        event the reducer records (and a bucket's fold / all-reduce, if this call completes it) comes after everything both
+        streams have enqueued -- and the compute stream goes on with the data-gradient chain without waiting for anybody."""
+        if self.grad_ready_hook is None:
+            return
+        if self._side_used:
+            self._side_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side_stream):
+                self.grad_ready_hook(prefixes)
+        else:
+            self.grad_ready_hook(prefixes)
 
     def _join_side(self):
         if self._side_used:
@@ -831,9 +846,7 @@ class HipNet:
             elif kind == "h2cnn":
                 L.backward(saved, g)
                 g, g_range = None, None
-                if self.grad_ready_hook is not None:
-                    self.grad_ready_hook(L.prefixes())
-                continue
+                continue   # (the block released its layers one by one)
             elif kind == "gru":
                 g = self._gru_bwd(L, saved, g, in_act, need_dx, tag)
                 g_range = None
@@ -965,7 +978,7 @@ class HipNet:
         done = [L.prefix]
         if kind == "conv" and L.first and saved[1] is not None:
             done.append(saved[1][4].prefix)  # the observation LayerNorm fused into the first convolution
-        self.grad_ready_hook(done)
+        self._release(done)
 
     @staticmethod
     def _out_cols(record):
@@ -1101,8 +1114,7 @@ class HipNet:
 
     def _fused_bwd(self, rec, dy_ptr: int, lddy: int):
         hip.mlp_bwd(rec["arr"], rec["x"].data_ptr(), rec["x"].shape[1], rec["n"], rec["tape"].data_ptr(), rec["tld"], dy_ptr, lddy)
-        if self.grad_ready_hook is not None:  # one launch: every layer of the chain is final behind it
-            self.grad_ready_hook(rec["prefixes"])
+        self._release(rec["prefixes"])  # one launch: every layer of the chain is final behind it
 
     # ------------------------------------------------------------------ public: forward / backward
     def forward(self, obs: Dict[str, torch.Tensor], n: int, keep_tape: bool = True, rnn: Optional[RnnCtx] = None):
@@ -1120,7 +1132,8 @@ class HipNet:
         logits_t = self.ws.get("logits", n * atot)
         value_t = self.ws.get("value", n * sp.value_dim)
         # CartPole-sized nets: trunk + head of a separate actor / critic as one launch each (trunk only when the heads share it)
-        heads_in = not sp.shared_backbone and sp.std_type != "shared_learnable"
+        # (not with PPG's auxiliary value head: it reads the actor trunk's features beside the actor head)
+        heads_in = not sp.shared_backbone and sp.std_type != "shared_learnable" and sp.aux_head is None
         fa = self._fused_fwd("a:", sp.obs_encoders, sp.actor_backbone, sp.actor_head if heads_in else None, obs, n,
                              out=logits_t if heads_in else None)
         if fa is not None:
@@ -1148,12 +1161,20 @@ class HipNet:
             hip.gemm(n, atot, sp.hidden_dim, a_feat.ptr, a_feat.ld, 0, self._p("log_std.weight"), sp.hidden_dim, 0,
                      ls_t.data_ptr(), atot, bias=self._p("log_std.bias"))
             self.log_std_rows = ls_t[:n * atot].view(n, atot)
+        self.aux_value = None
+        if sp.aux_head is not None:  # PPG: a second value estimate from the ACTOR's features (actor_critic_policy.py:139-140)
+            aux_t = self.ws.get("aux_value", n * sp.value_dim)
+            hip.gemm(n, sp.value_dim, sp.hidden_dim, a_feat.ptr, a_feat.ld, 0, self._p(f"{sp.aux_head.prefix}.weight"), sp.hidden_dim, 0,
+                     aux_t.data_ptr(), sp.value_dim, bias=self._p(f"{sp.aux_head.prefix}.bias"))
+            self.aux_value = aux_t[:n * sp.value_dim].view(n, sp.value_dim)
         self._tape = (n, a_feat, a_act, a_tape, c_feat, c_act, c_tape) if keep_tape else None
         return logits_t[:n * atot].view(n, atot), value_t[:n * sp.value_dim].view(n, sp.value_dim)
 
-    def backward(self, d_logits: torch.Tensor, d_value: torch.Tensor, d_log_std_rows: Optional[torch.Tensor] = None):
+    def backward(self, d_logits: torch.Tensor, d_value: torch.Tensor, d_log_std_rows: Optional[torch.Tensor] = None,
+                 d_aux: Optional[torch.Tensor] = None):
         """Accumulate d loss / d parameters into ``self.grad`` given d loss / d logits and d loss / d value (and, with a
-        `shared_learnable` Gaussian head, d loss / d log sigma per row)."""
+        `shared_learnable` Gaussian head, d loss / d log sigma per row; with PPG's auxiliary head, d loss / d auxiliary value
+        -- None in the PPO phase, where that head takes no gradient: phasic_policy_gradient.py:177-180)."""
         if self._tape is None:
             raise hip.HipError("backward() without a preceding forward(keep_tape=True)")
         sp = self.spec
@@ -1169,10 +1190,14 @@ class HipNet:
             dls = Buf(d_log_std_rows.data_ptr(), atot, n, atot)
             self._linear_bwd(ns.LinearSpec("log_std", sp.hidden_dim, atot, 0), a_feat, dls, a_act, True, "a:", dx_into=da,
                              dx_accumulate=True)
-            if self.grad_ready_hook is not None:
-                self.grad_ready_hook(["log_std"])
-        if self.grad_ready_hook is not None and sp.shared_backbone:
-            self.grad_ready_hook([sp.actor_head.prefix])
+            self._release(["log_std"])
+        if sp.aux_head is not None:
+            if d_aux is not None:
+                dax = Buf(d_aux.data_ptr(), sp.value_dim, n, sp.value_dim)
+                self._linear_bwd(sp.aux_head, a_feat, dax, a_act, True, "a:", dx_into=da, dx_accumulate=True)
+            self._release([sp.aux_head.prefix])
+        if sp.shared_backbone:
+            self._release([sp.actor_head.prefix])
 
         def trunk_bwd(tag, tape, dfeat, dhead):  # fused chains: one launch, all of its layers released behind it
             if isinstance(tape, dict):
@@ -1182,13 +1207,12 @@ class HipNet:
 
         if sp.shared_backbone:
             self._linear_bwd(sp.critic_head, c_feat, dv, c_act, True, "a:", dx_into=da, dx_accumulate=True)
-            if self.grad_ready_hook is not None:
-                self.grad_ready_hook([sp.critic_head.prefix])
+            self._release([sp.critic_head.prefix])
             trunk_bwd("a:", a_tape, da, dl)
         else:
             dc = None if c_head_in else self._linear_bwd(sp.critic_head, c_feat, dv, c_act, True, "c:")
-            if self.grad_ready_hook is not None and not (a_head_in or c_head_in):
-                self.grad_ready_hook([sp.actor_head.prefix, sp.critic_head.prefix])
+            if not (a_head_in or c_head_in):
+                self._release([sp.actor_head.prefix, sp.critic_head.prefix])
             trunk_bwd("a:", a_tape, da, dl)
             trunk_bwd("c:", c_tape, dc, dv)
         self._join_side()

@@ -203,6 +203,7 @@ class NetSpec:
     std_type: Optional[str] = None  # continuous actions: "fixed" | "separate_learnable" | "shared_learnable" (log_std)
     rnn_state_width: int = 0  # per-layer width of the stored policy state (H, or 2H for LSTM: cat(h, c))
     popart_keys: Tuple[str, str, str] = ()  # state_dict keys of the float64 running statistics (set in __post_init__)
+    aux_head: Optional[LinearSpec] = None  # PPG: auxiliary value head on the actor's features (`auxiliary_head=True`)
 
     def __post_init__(self):
         if not self.popart_keys:
@@ -482,8 +483,8 @@ def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim
     layout) when ``seed`` is given, else ``None``."""
     if num_rnn_layers and rnn_type not in ("gru", "lstm"):
         raise NotImplementedError(f"rnn_type `{rnn_type}`: only the GRU and LSTM cells of AutoResetRNN are on the HIP path")
-    if auxiliary_head:
-        raise NotImplementedError("the auxiliary value head (PPG) is not on the HIP path")
+    if auxiliary_head and shared_backbone:  # actor_critic_policy.py:196-197
+        raise AttributeError("Cannot use shared backbone when requiring auxiliary value head.")
     std_type = _unused.get("std_type", "fixed")
     if continuous_action and std_type not in ("fixed", "separate_learnable", "shared_learnable"):
         raise NotImplementedError(f"Standard deviation type {std_type} not implemented.")
@@ -505,13 +506,14 @@ def build_netspec(obs_dim, action_dim, hidden_dim=128, state_dim=None, value_dim
         return _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation,
                       layernorm, shared_backbone, seed, popart, num_rnn_layers, rnn_type,
                       (std_type, float(_unused.get("init_log_std", -0.5))) if continuous_action else None,
-                      use_maxpool=use_maxpool)
+                      use_maxpool=use_maxpool, auxiliary_head=bool(auxiliary_head))
     finally:
         torch.set_num_threads(threads)
 
 
 def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num_dense_layers, act, activation, layernorm,
-           shared_backbone, seed, popart=False, num_rnn_layers=0, rnn_type="gru", continuous=None, use_maxpool=None):
+           shared_backbone, seed, popart=False, num_rnn_layers=0, rnn_type="gru", continuous=None, use_maxpool=None,
+           auxiliary_head=False):
     b = _Builder(seed)
     if continuous is not None and continuous[0] != "shared_learnable":
         # one vector of log standard deviations; a direct nn.Parameter of the net, so it leads the state_dict.
@@ -549,6 +551,10 @@ def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num
         b.linear("critic_head", hidden_dim, value_dim)
         b.orthogonal("critic_head.weight", 0.01)
         b.zero("critic_head.bias")
+    if auxiliary_head:  # PPG's second value head, on the ACTOR's features (actor_critic_policy.py:105-107); the module's last child
+        b.linear("auxiliary_value_head", hidden_dim, value_dim)
+        b.orthogonal("auxiliary_value_head.weight", 0.01)
+        b.zero("auxiliary_value_head.bias")
 
     off = 0
     for info in b.params.values():
@@ -557,7 +563,8 @@ def _build(obs_dims, state_dim, act_dims, cnn_layers, hidden_dim, value_dim, num
     spec = NetSpec(obs_enc, actor_bb, state_enc, critic_bb, LinearSpec("actor_head", hidden_dim, sum(act_dims), 0),
                    LinearSpec("critic_head", hidden_dim, value_dim, 0), act_dims, hidden_dim, value_dim, shared_backbone,
                    b.params, off, popart, num_rnn_layers,
-                   std_type, (2 * hidden_dim if rnn_type == "lstm" else hidden_dim) if num_rnn_layers else 0)
+                   std_type, (2 * hidden_dim if rnn_type == "lstm" else hidden_dim) if num_rnn_layers else 0,
+                   aux_head=LinearSpec("auxiliary_value_head", hidden_dim, value_dim, 0) if auxiliary_head else None)
     return spec, (b.values if b.init else None)
 
 

@@ -2,9 +2,10 @@
 
 ``PPORolloutAnalyzedResult``: ``actor_critic_policy.py:22-25`` (namedarray stored in every sample).
 ``SampleAnalyzedResult``:     ``mappo.py:21-33`` (what ``policy.analyze(target="ppo")`` returns).
+``PPGPhase1AnalyzedResult`` / ``PPGPhase2AnalyzedResult`` / ``AuxiliaryStepResult``: ``phasic_policy_gradient.py:15-57``.
 """
 import dataclasses
-from typing import Optional
+from typing import List, Optional
 
 import torch
 
@@ -28,3 +29,45 @@ class SampleAnalyzedResult:
     new_action_log_probs: torch.Tensor  # [T, B, 1]
     state_values: torch.Tensor  # [T, B, value_dim]
     entropy: Optional[torch.Tensor] = None  # [T, B, 1]
+
+
+@dataclasses.dataclass
+class PPGPhase1AnalyzedResult:
+    """``policy.analyze(target="ppg_ppo_phase")`` (phasic_policy_gradient.py:15-29): the PPO quantities plus the auxiliary value."""
+    old_action_log_probs: torch.Tensor  # [T, B, 1]
+    new_action_log_probs: torch.Tensor  # [T, B, 1]
+    aux_values: torch.Tensor  # [T, B, value_dim]; takes no gradient in the PPO phase
+    state_values: torch.Tensor  # [T, B, value_dim]
+    reward: torch.Tensor  # [T, B, value_dim or 1]
+    entropy: Optional[torch.Tensor] = None  # [T, B, 1]
+
+
+class CategoricalLogits:
+    """What the auxiliary phase needs of a ``torch.distributions.Categorical`` (actor_critic_policy.py:266-270): ``logits`` are the
+    NORMALISED log-probabilities [..., A] of one action head (as ``Categorical.logits``), ``probs`` their exponentials."""
+
+    def __init__(self, logits: torch.Tensor):
+        self.logits = logits
+
+    @property
+    def probs(self):
+        return self.logits.exp()
+
+    def detach_cpu(self):
+        return CategoricalLogits(self.logits.detach().cpu())
+
+
+@dataclasses.dataclass
+class PPGPhase2AnalyzedResult:
+    """``policy.analyze(target="ppg_aux_phase")`` (phasic_policy_gradient.py:32-44)."""
+    action_dists: List[CategoricalLogits]  # one per action head, [T, B, A_h]
+    auxiliary_value: torch.Tensor  # [T, B, value_dim], from the actor's features
+    predicted_value: torch.Tensor  # [T, B, value_dim], from the critic head
+
+
+@dataclasses.dataclass
+class AuxiliaryStepResult:
+    """phasic_policy_gradient.py:47-54."""
+    auxiliary_value_loss: float
+    value_head_loss: float
+    policy_distance: float

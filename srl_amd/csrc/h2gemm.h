@@ -86,6 +86,8 @@ struct H2Args {
   uint32_t* mask_out;       // relu sign bits of out, natural element order, or null
   const uint32_t* mask_in;  // out *= bit of this mask at the output element (relu derivative), or null
   int32_t mask_in_h2;       // mask_in's bits are in h2 order (bit 8 g + j of a 32-block's word: what h2conv.h's forward kernels write)
+  int32_t stagger;          // first-round workgroups of odd XCDs start this many units of 64 x 127 cycles late (see the kernel)
+  int32_t dbg;              // timing experiments (wrong results; SRL_H2G_DBG): 1 no DMA, 2 no fragment reads / MFMAs, 4 no epilogue stores
 };
 
 #ifdef __HIPCC__
@@ -201,6 +203,13 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wid & 3, kh = KSPLIT ? wid >> 2 : 0, chalf = KSPLIT ? 0 : wid >> 2;
+  // Every workgroup of a round reaches its epilogue at the same time: the chip then writes a round's whole output in one burst
+  // (the Linear's data gradient: 64 MB per round at the HBM write rate, 52 of its 212 us) while no wavefront computes, and reads
+  // nothing while they all compute.  The first round's workgroups of the odd XCDs start half a tile late: one half's stores
+  // and ring fills then fall into the other half's MFMA time, and the phase carries over to the later rounds (a CU picks its
+  // next tile when it finishes one).  The last, partial round leaves the slack that pays for the delay.
+  if (g.stagger > 0 && blockIdx.x < 256u && (blockIdx.x & 1u))
+    for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   // logical tile id: every XCD owns one contiguous run
   unsigned lid;
   {
@@ -296,8 +305,10 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
   step_offsets(0, nsx, nsw);
   auto issue_off = [&](uint32_t stage_off, int t) {
     const uint32_t sx = __builtin_amdgcn_readfirstlane(nsx), sw = __builtin_amdgcn_readfirstlane(nsw);
-    h2_dma<4>(lds_x + stage_off, xv, rx, sx);
-    h2_dma<NWI>(lds_w + stage_off, wv, rw, sw);
+    if (!(g.dbg & 1)) {
+      h2_dma<4>(lds_x + stage_off, xv, rx, sx);
+      h2_dma<NWI>(lds_w + stage_off, wv, rw, sw);
+    }
     if (t + 1 < nsteps) step_offsets(t + 1, nsx, nsw);
   };
   auto issue = [&](int stage, int t) { issue_off((uint32_t)stage * STAGE, t); };
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (more) issue_off(st_nxt, t + S - 1);
-    compute(st_cur);
+    if (!(g.dbg & 2)) compute(st_cur);
     st_cur = st_cur + STAGE == S * STAGE ? 0 : st_cur + STAGE;
     st_nxt = st_nxt + STAGE == S * STAGE ? 0 : st_nxt + STAGE;
   }
@@ -402,6 +413,7 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
             fin[i][j][4 * q + 2] = a[4 * q + 2] + v.z;
             fin[i][j][4 * q + 3] = a[4 * q + 3] + v.w;
           }
+      __syncthreads();  // the epilogue's transposition blocks (lds + wid * 4096) lie inside other wavefronts' exchange regions
     }
   };
   if constexpr (KSPLIT) {
@@ -478,6 +490,48 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
       if (g.out_absmax) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) amax = fmaxf(amax, ok ? fabsf(v[r]) : 0.f);
+      }
+      if (g.dbg & 4) continue;
+      if (XMODE != H2X_GROUPED) {
+        // Whole lines per store instruction.  A lane holds 64 bytes of ITS row (position): stored from there, an instruction
+        // wrote 64 pieces of 16 bytes to 64 different lines (the Linear's data gradient: 72 of its 230 us were these stores).
+        // Through the wavefront's own 4 KB of LDS (32 rows x 128 bytes, 16-byte slots XOR-swizzled by row & 7: conflict-free both
+        // ways) eight lanes carry one row's 128 bytes and an instruction writes eight complete lines.  The ring is free here
+        // (barrier above); a wavefront's LDS operations execute in order, so no barrier between the blocks either.
+        uint8_t* tb = lds + wid * 4096;
+        uint4* trow = reinterpret_cast<uint4*>(tb + pl * 128);
+        const int sw = pl & 7;
+        if (g.out_fmt == H2O_H2P) {
+          // registers 0-7: group 2 hl, registers 8-15: group 2 hl + 1 -> slots 4 hl .. 4 hl + 3 of the row's 128 bytes
+          uint4 h0a, h1a, h0b, h1b;
+          h2_split_pair(v[0], v[1], oscale, h0a.x, h1a.x);
+          h2_split_pair(v[2], v[3], oscale, h0a.y, h1a.y);
+          h2_split_pair(v[4], v[5], oscale, h0a.z, h1a.z);
+          h2_split_pair(v[6], v[7], oscale, h0a.w, h1a.w);
+          h2_split_pair(v[8], v[9], oscale, h0b.x, h1b.x);
+          h2_split_pair(v[10], v[11], oscale, h0b.y, h1b.y);
+          h2_split_pair(v[12], v[13], oscale, h0b.z, h1b.z);
+          h2_split_pair(v[14], v[15], oscale, h0b.w, h1b.w);
+          trow[(4 * hl + 0) ^ sw] = h0a;
+          trow[(4 * hl + 1) ^ sw] = h1a;
+          trow[(4 * hl + 2) ^ sw] = h0b;
+          trow[(4 * hl + 3) ^ sw] = h1b;
+        } else {
+          // float32: registers 4q .. 4q+3 = channels 8q + 4 hl + {0..3} -> slot 2 q + hl
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            trow[(2 * q + hl) ^ sw] = make_uint4(__float_as_uint(v[4 * q]), __float_as_uint(v[4 * q + 1]), __float_as_uint(v[4 * q + 2]),
+                                                 __float_as_uint(v[4 * q + 3]));
+        }
+        const int rr = lane >> 3, pp = lane & 7;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const uint4 val = *reinterpret_cast<const uint4*>(tb + (8 * it + rr) * 128 + 16 * (pp ^ rr));
+          const long rowg = m0 + wp * 64 + j * 32 + 8 * it + rr;
+          if (rowg < g.M)
+            *reinterpret_cast<uint4*>(static_cast<uint8_t*>(g.out) + rowg * (long)g.out_row_bytes + (long)cb * 128 + 16 * pp) = val;
+        }
+        continue;
       }
       if (!ok) continue;
       if (g.out_fmt == H2O_H2P) {

@@ -25,7 +25,7 @@ _lib = None
 # (bench.py does, before its imports) -- INTEGRATION.md lists it with the other switches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -145,6 +145,10 @@ _SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_int]),
     "srl_categorical_sample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int,
                                         POINTER(c_int32), c_uint64, c_uint64, c_void_p, c_void_p, c_int64]),
+    "srl_categorical_log_softmax": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_long, c_int, POINTER(c_int32), c_void_p, c_int]),
+    "srl_ppg_aux_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_int, POINTER(c_int32), c_void_p,
+                                          c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int, c_void_p,
+                                          c_void_p, c_void_p]),
     "srl_gemm": (c_int, [c_void_p, POINTER(GemmDesc)]),
     "srl_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
                                    c_void_p, c_void_p]),
@@ -575,6 +579,32 @@ def categorical_sample(logits, avail, is_eval, head_dims, seed, offset, action_o
                                      len(head_dims), _i32_array(head_dims), int(seed), int(offset),
                                      _ptr(action_out, torch.int64, "action_out"), _ptr(logp, torch.float32, "logp"), int(row0)),
         "srl_categorical_sample")
+
+
+def categorical_log_softmax(logits, avail, head_dims, out):
+    """out[i, head] = masked logits - logsumexp: ``Categorical(logits=...).logits`` per action head (srl_hip.h, PPG)."""
+    n = logits.shape[0]
+    _check(
+        lib().srl_categorical_log_softmax(_stream(), _ptr(logits, torch.float32, "logits"), logits.shape[1],
+                                          _ptr(avail, torch.uint8, "avail"), n, len(head_dims), _i32_array(head_dims),
+                                          _ptr(out, torch.float32, "out"), out.shape[1]), "srl_categorical_log_softmax")
+
+
+def ppg_aux_loss_fwd_bwd(logq_old, logits, avail, head_dims, aux_value, pred_value, target, done, undone_count, beta_clone,
+                         value_head_weight, d_logits, d_aux, d_pred, terms):
+    """The auxiliary phase's joint loss and its gradient with respect to (raw logits, auxiliary value, critic value)
+    (phasic_policy_gradient.py:262-280; srl_hip.h).  ``terms`` float64[3]: auxiliary value loss, value head loss, policy distance."""
+    n = logits.shape[0]
+    vd = aux_value.shape[1] if aux_value.dim() > 1 else 1
+    _check(
+        lib().srl_ppg_aux_loss_fwd_bwd(_stream(), _ptr(logq_old, torch.float32, "logq_old"), logq_old.shape[1],
+                                       _ptr(logits, torch.float32, "logits"), logits.shape[1], _ptr(avail, torch.uint8, "avail"), n,
+                                       len(head_dims), _i32_array(head_dims), _ptr(aux_value, torch.float32, "aux_value"),
+                                       _ptr(pred_value, torch.float32, "pred_value"), _ptr(target, torch.float32, "target"), vd,
+                                       _ptr(done, torch.uint8, "done"), _ptr(undone_count, torch.float64, "undone_count"),
+                                       float(beta_clone), float(value_head_weight), _ptr(d_logits, torch.float32, "d_logits"),
+                                       d_logits.shape[1], _ptr(d_aux, torch.float32, "d_aux"), _ptr(d_pred, torch.float32, "d_pred"),
+                                       _ptr(terms, torch.float64, "terms")), "srl_ppg_aux_loss_fwd_bwd")
 
 
 def gemm_two_piece(M, N, K, A, lda, B, ldb, a_absmax, b_absmax) -> bool:

@@ -878,6 +878,151 @@ def gen_host():
     save("host.npz", **out)
 
 
+# ------------------------------------------------------------------------------------------------ PPG (second half)
+PPG_CASES = {
+    # multi-discrete MLP, LayerNorm; one case with an availability mask in the observation (-1e10 logits, :135-136)
+    "aux": (dict(obs_dim=4, action_dim=[3, 2], hidden_dim=32, num_dense_layers=1, num_rnn_layers=0, popart=False, layernorm=True,
+                 chunk_len=8, seed=81),
+            dict(popart=False, ppg_epochs=3, max_grad_norm=5.0, beta_clone=1.0, aux_value_head_weight=0.5,
+                 ppg_optimizer_config=dict(lr=1e-3)),
+            dict(T=16, B=6, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2], p_done=0.1)),
+    "auxmask": (dict(obs_dim=5, action_dim=4, hidden_dim=16, num_dense_layers=2, num_rnn_layers=0,
+                     popart=False, layernorm=False, chunk_len=4, seed=82, activation="tanh"),
+                dict(popart=False, ppg_epochs=2, beta_clone=2.0, aux_value_head_weight=1.0, ppg_optimizer_config=dict(lr=5e-4)),
+                dict(T=8, B=5, obs_spec={"obs": ((5,), "f32")}, action_dims=4, p_done=0.15, available_action=True)),
+    # PopArt: the stored targets are de-normalised returns, normalised on entering the phase (:222-225)
+    "auxpa": (dict(obs_dim=4, action_dim=2, hidden_dim=32, num_dense_layers=2, num_rnn_layers=0, popart=True, layernorm=True,
+                   chunk_len=8, seed=83, value_dim=2),
+              dict(popart=True, ppg_epochs=2, max_grad_norm=1.0, beta_clone=1.0, aux_value_head_weight=1.0),
+              dict(T=16, B=4, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.1, value_dim=2)),
+    # GRU backbones: chunked analysis from the stored states (:419-426)
+    "auxgru": (dict(obs_dim=4, action_dim=3, hidden_dim=16, num_dense_layers=1, num_rnn_layers=1, popart=False, layernorm=True,
+                    chunk_len=4, seed=84),
+               dict(popart=False, ppg_epochs=2, max_grad_norm=10.0, beta_clone=1.0, aux_value_head_weight=1.0,
+                    ppg_optimizer_config=dict(lr=1e-3)),
+               dict(T=8, B=5, obs_spec=synthetic.CARTPOLE_OBS, action_dims=3, p_done=0.1,
+                    policy_state={"actor_hx": (1, 16), "critic_hx": (1, 16)})),
+}
+
+
+def ppg_entry_arrays(arrays, T, seed, value_dim=1):
+    """What MultiAgentPPG.step puts into its local cache (:193-203): the first T rows of obs / policy_state / info_mask / on_reset
+    and a value target per row (here: drawn, the phase-1 code that would produce it cannot run)."""
+    rng = np.random.default_rng(seed)
+    e = {k: v[:T] for k, v in arrays.items() if k.startswith("obs.") or k.startswith("policy_state.") or k in ("info_mask", "on_reset")}
+    e["value"] = (2.0 * rng.standard_normal((T, arrays["on_reset"].shape[1], value_dim))).astype(np.float32)
+    # info_mask marks episode ends ("done" of the auxiliary loss, :264): make sure some rows are masked
+    e["info_mask"] = (rng.random(e["info_mask"].shape) < 0.2).astype(np.uint8)
+    return e
+
+
+def gen_ppg():
+    """The runnable pieces of the reference's Phasic Policy Gradient: the `actor-critic-auxiliary` policy's two analysis targets
+    (actor_critic_policy.py:392-435) and the auxiliary phase -- `_compute_aux_loss`, backward, clip, `ppg_aux_optimizer.step()`
+    (phasic_policy_gradient.py:205-243, 262-280), driven from here statement for statement because `MultiAgentPPG.step` itself
+    raises before any arithmetic (:169 `_compute_adv` does not exist; `SampleBatch` drops :193's `value`): the cache entry is a
+    plain NamedArray carrying the attributes `_compute_aux_loss` reads."""
+    import legacy.algorithm.ppo.phasic_policy_gradient as ppg
+    from oracle.ppg import OraclePPGAux
+    out = {}
+    for tag, (pargs, targs, skw) in PPG_CASES.items():
+        trainer = api.trainer.make(api.config.Trainer("mappg", args=targs), api.config.Policy("actor-critic-auxiliary", args=pargs))
+        if pargs.get("popart"):
+            object.__setattr__(trainer.policy.net, "module", trainer.policy.net)
+        net = trainer.policy.net
+        sd0 = sd_to_np(net.state_dict())
+        spec = check_init(dict(pargs, auxiliary_head=True, shared_backbone=False), net.state_dict())
+        for k, v in sd0.items():
+            out[f"{tag}_init_param:{k}"] = v
+        T = skw["T"]
+        arrays = synthetic.make_sample_arrays(seed=300, **skw)
+        sample = ref_sample({k: v.copy() for k, v in arrays.items()})
+        ts = recursive_apply(sample, lambda x: torch.from_numpy(x).float())
+        # ---- analyze(target="ppg_ppo_phase") on the sample's first T rows
+        with torch.no_grad():
+            r1 = trainer.policy.analyze(ts[:T], target="ppg_ppo_phase")
+        out[f"{tag}_p1_new_lp"], out[f"{tag}_p1_value"] = r1.new_action_log_probs.numpy(), r1.state_values.numpy()
+        out[f"{tag}_p1_aux"], out[f"{tag}_p1_entropy"] = r1.aux_values.numpy(), r1.entropy.numpy()
+        # ---- the cache entry and the auxiliary phase
+        vd = pargs.get("value_dim", 1)
+        e = ppg_entry_arrays(arrays, T, seed=7, value_dim=vd)
+        if pargs.get("popart"):  # statistics away from their initial zeros
+            with torch.no_grad():
+                net.critic_head._PopArtValueHead__rms._RunningMeanStd__mean.copy_(torch.tensor([0.3, -0.2][:vd], dtype=torch.float64))
+                net.critic_head._PopArtValueHead__rms._RunningMeanStd__mean_sq.copy_(torch.tensor([1.7, 2.5][:vd], dtype=torch.float64))
+                net.critic_head._PopArtValueHead__rms._RunningMeanStd__debiasing_term.fill_(0.9)
+            sd0 = sd_to_np(net.state_dict())
+            for k, v in sd0.items():
+                out[f"{tag}_init_param:{k}"] = v
+        obs = NamedArray(**{k[4:]: v for k, v in e.items() if k.startswith("obs.")})
+        ps = {k[len("policy_state."):]: v for k, v in e.items() if k.startswith("policy_state.")}
+        entry_sample = NamedArray(obs=obs, policy_state=NamedArray(**ps) if ps else None, info_mask=e["info_mask"],
+                                  on_reset=e["on_reset"], value=e["value"])
+        entry = ppg._PPGLocalCache.CacheEntry(sample=entry_sample)
+        to_t = lambda smp: recursive_apply(smp, lambda x: torch.from_numpy(x).to(dtype=torch.float32))
+        # :209-225
+        r2 = trainer.policy.analyze(to_t(entry.sample), target="ppg_aux_phase")
+        entry.action_dists = [modules.distribution_detach_to_cpu(d) for d in r2.action_dists]
+        if trainer.popart:
+            entry.sample.value = trainer.policy.normalize_value(torch.from_numpy(entry.sample.value)).cpu().detach().numpy()
+        for h, d in enumerate(r2.action_dists):
+            out[f"{tag}_p2_logq{h}"] = d.logits.detach().numpy()
+        out[f"{tag}_p2_aux"], out[f"{tag}_p2_pred"] = r2.auxiliary_value.detach().numpy(), r2.predicted_value.detach().numpy()
+        out[f"{tag}_entry_value"], out[f"{tag}_entry_info_mask"] = e["value"], e["info_mask"]
+        # the oracle on the same entry
+        onet = OracleActorCritic(**pargs)
+        onet.load_state_dict(sd0)
+        oaux = OraclePPGAux(onet, beta_clone=targs.get("beta_clone", 1), aux_value_head_weight=targs.get("aux_value_head_weight", 1),
+                            max_grad_norm=targs.get("max_grad_norm"), popart=targs.get("popart", False),
+                            ppg_optimizer_config=targs.get("ppg_optimizer_config", {}))
+        oaux.enter(e)
+        for h, d in enumerate(r2.action_dists):
+            assert torch.allclose(oaux.old[h], d.logits.detach(), rtol=1e-5, atol=1e-6), (tag, h)
+        # The distributions were kept under the parameters above.  In the algorithm's own flow the first auxiliary epoch then runs
+        # on the SAME parameters: KL = 0 and its gradient is float32 rounding noise, which Adam's first steps turn into full-size
+        # moves -- nothing two implementations can agree on.  To pin the loss and its backward on general inputs the parameters are
+        # moved first (a seeded perturbation, as if policy updates had happened in between), on both sides.
+        prng = torch.Generator().manual_seed(1234)
+        with torch.no_grad():
+            for k, p_ in net.state_dict().items():
+                if p_.dtype == torch.float32:
+                    p_.add_(0.03 * torch.randn(p_.shape, generator=prng))
+        sd1 = sd_to_np(net.state_dict())
+        for k, v in sd1.items():
+            out[f"{tag}_pert_param:{k}"] = v
+        for k, p_ in onet.params.items():
+            p_.data.copy_(torch.from_numpy(sd1[k]).to(p_.dtype))
+        # :232-243
+        version0 = trainer.policy.version
+        names = ("auxiliary_value_loss", "value_head_loss", "policy_distance")
+        for ep in range(targs["ppg_epochs"]):
+            res = trainer.policy.analyze(to_t(entry.sample), target="ppg_aux_phase")
+            aux_l, metrics = trainer._compute_aux_loss(entry, res)
+            trainer.ppg_aux_optimizer.zero_grad()
+            aux_l.backward()
+            gn = None
+            if trainer.max_grad_norm is not None:
+                gn = torch.nn.utils.clip_grad_norm_(trainer.policy.parameters(), trainer.max_grad_norm)
+            trainer.ppg_aux_optimizer.step()
+            trainer.policy.inc_version()
+            o = oaux.epoch(e)
+            vals = [float(getattr(metrics, n).detach()) for n in names] + [float(aux_l.detach()), float(gn) if gn is not None else -1.0]
+            for n, v in zip(names, vals):
+                assert abs(o[n] - v) <= 1e-5 * max(1.0, abs(v)), (tag, ep, n, o[n], v)
+            if gn is not None:
+                assert abs(o["grad_norm"] - float(gn)) <= 2e-5 * max(1.0, float(gn)), (tag, ep, o["grad_norm"], float(gn))
+            out[f"{tag}_epoch{ep}_terms"] = np.array(vals, dtype=np.float64)
+        assert trainer.policy.version == version0 + targs["ppg_epochs"]
+        sd = sd_to_np(net.state_dict())
+        osd = onet.state_dict()
+        for k, v in sd.items():
+            assert np.allclose(osd[k].numpy(), v, rtol=1e-4, atol=1e-6), (tag, k)
+            out[f"{tag}_final_param:{k}"] = v
+        print(f"ppg case {tag}: terms {out[f'{tag}_epoch0_terms']}")
+    out["term_names"] = np.array(["auxiliary_value_loss", "value_head_loss", "policy_distance", "loss", "grad_norm"])
+    save("ppg.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gae", "norm", "loss", "steps", "rollout", "host"]
     for w in which:

@@ -24,8 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_registries_use_reference_names():
-    assert {"actor-critic", "actor-critic-separate", "actor-critic-shared"} <= set(policy_api.ALL_POLICY_CLASSES)
-    assert {"mappo"} <= set(trainer_api.ALL_TRAINER_CLASSES)
+    assert {"actor-critic", "actor-critic-separate", "actor-critic-shared", "actor-critic-auxiliary"} <= set(policy_api.ALL_POLICY_CLASSES)
+    assert {"mappo", "mappg"} <= set(trainer_api.ALL_TRAINER_CLASSES)
     assert {"gae", "null"} <= set(trainer_api.ALL_TRAJ_POSTPROCESSOR_CLASSES)
     with pytest.raises(KeyError):
         environment.register("cartpole", object)
@@ -60,7 +60,8 @@ def test_product_path_fails_loudly_without_gpu():
 def test_unsupported_configs_raise():
     base = dict(obs_dim=4, action_dim=2, num_rnn_layers=0, popart=False)
     for bad in (dict(num_rnn_layers=1, rnn_type="gtrxl"), dict(continuous_action=True, std_type="state_dependent"),
-                dict(auxiliary_head=True), dict(obs_dim={"o": (3, 10, 4, 4, 4)}),
+                dict(auxiliary_head=True, shared_backbone=True),  # actor_critic_policy.py:196-197: the auxiliary head needs separate trunks
+                dict(obs_dim={"o": (3, 10, 4, 4, 4)}),
                 dict(obs_dim={"o": (3, 12, 12)}, cnn_layers=dict(o=[(4, 3, 1, 1, "mirror")])),
                 dict(obs_dim={"o": (3, 4, 4)}, cnn_layers=dict(o=[(4, 3, 1, 4, "reflect")]))):
         with pytest.raises((NotImplementedError, AttributeError, ValueError)):

@@ -227,3 +227,53 @@ def test_oracle_data_parallel_emulation_reduces_to_single_rank():
         assert np.allclose(v.numpy(), nets[1].state_dict()[k].numpy(), rtol=1e-6, atol=1e-7), k
         if "_RunningMeanStd__" not in k:  # doubled data moves the PopArt EMA identically (means), so everything matches
             assert np.allclose(v.numpy(), nets[2].state_dict()[k].numpy(), rtol=1e-4, atol=1e-6), k
+
+
+# ------------------------------------------------------------------------------------------------ PPG
+@pytest.mark.parametrize("tag", ["aux", "auxmask", "auxpa", "auxgru"])
+def test_ppg_auxiliary_phase_oracle_vs_reference_golden(tag, golden):
+    """oracle/ppg.py + OracleActorCritic.analyze_aux against what the reference's runnable PPG pieces produced
+    (tests/golden/gen_golden.py gen_ppg): both analysis targets of the `actor-critic-auxiliary` policy, then the auxiliary phase
+    -- loss terms and gradient norm of every epoch, every parameter after the epochs."""
+    import torch
+    from oracle.net import OracleActorCritic
+    from oracle.ppg import OraclePPGAux
+    from ppg_cases import PPG_CASES, entry_arrays, params_of
+    from srl_amd.runtime import synthetic
+    g = golden("ppg.npz")
+    pargs, targs, skw = PPG_CASES[tag]
+    T = skw["T"]
+    arrays = synthetic.make_sample_arrays(seed=300, **skw)
+    net = OracleActorCritic(**pargs)
+    net.load_state_dict(params_of(g, tag, "init"))
+    f32 = lambda a: torch.from_numpy(np.asarray(a)).float()
+    obs = {k[4:]: f32(v[:T]) for k, v in arrays.items() if k.startswith("obs.")}
+    ps = [f32(arrays[n][:T]) for n in ("policy_state.actor_hx", "policy_state.critic_hx") if n in arrays] or None
+    with torch.no_grad():
+        lp, value, ent, _ = net.analyze(obs, f32(arrays["action.x"][:T]), f32(arrays["on_reset"][:T]), ps)
+    unchunk_aux = net._aux_value
+    if net.num_rnn_layers:  # analyze() returned trajectory-major values; the auxiliary values are still chunk-major
+        n = T // net.chunk_len
+        unchunk_aux = torch.cat(torch.split(unchunk_aux, unchunk_aux.shape[1] // n, dim=1), dim=0)
+    for name, got in (("new_lp", lp), ("value", value), ("entropy", ent), ("aux", unchunk_aux)):
+        ref = g[f"{tag}_p1_{name}"]
+        assert np.abs(got.detach().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), name
+    e = entry_arrays(arrays, T, g, tag)
+    aux = OraclePPGAux(net, beta_clone=targs.get("beta_clone", 1), aux_value_head_weight=targs.get("aux_value_head_weight", 1),
+                       max_grad_norm=targs.get("max_grad_norm"), popart=targs.get("popart", False),
+                       ppg_optimizer_config=targs.get("ppg_optimizer_config", {}))
+    aux.enter(e)
+    for h, d in enumerate(aux.old):
+        assert np.abs(d.numpy() - g[f"{tag}_p2_logq{h}"]).max() <= 1e-5
+    for k, v in params_of(g, tag, "pert").items():
+        net.params[k].data.copy_(torch.from_numpy(v).to(net.params[k].dtype))
+    names = list(g["term_names"])
+    for ep in range(targs["ppg_epochs"]):
+        o = aux.epoch(e)
+        ref = dict(zip(names, g[f"{tag}_epoch{ep}_terms"]))
+        for k in ("auxiliary_value_loss", "value_head_loss", "policy_distance", "loss"):
+            assert abs(o[k] - ref[k]) <= 1e-5 * max(1.0, abs(ref[k])), (ep, k, o[k], ref[k])
+        if ref["grad_norm"] >= 0:
+            assert abs(o["grad_norm"] - ref["grad_norm"]) <= 2e-5 * max(1.0, ref["grad_norm"]), ep
+    for k, v in params_of(g, tag, "final").items():
+        assert np.abs(net.params[k].detach().numpy() - v).max() <= 2e-5, k
