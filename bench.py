@@ -496,6 +496,8 @@ def main():
     ap.add_argument("--no-from-host", action="store_true",
                     help="skip the pinned-host-fed passes: `value` is then the resident-in-HBM figure")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the rollout-beside-update leg (`closed_loop`)")
+    ap.add_argument("--rollout-groups", type=int, default=2,
+                    help="closed loop: inference policies (policy workers) sharing the observation ring, each serving B / groups environments")
     ap.add_argument("--no-plain-copy", action="store_true", help="skip the pass without the observation ring (`from_pinned_host`)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank")
     ap.add_argument("--no-configs", action="store_true",
@@ -742,30 +744,33 @@ def main():
         fresh[0] = True
         planes = torch.empty((Tb, B, 1, 84, 84), dtype=torch.uint8).pin_memory()
         planes.copy_(frames[:, :, 3:4])
-        zeros = lambda dt: np.zeros((B, 1), dt)
 
-        def request(obs):
-            return policy_api.RolloutRequest(obs=obs, is_evaluation=zeros(np.uint8), on_reset=zeros(np.uint8), client_id=zeros(np.int32),
-                                             request_id=np.arange(B).reshape(B, 1), received_time=zeros(np.int64),
-                                             buffer_index=zeros(np.int32))
+        def request(obs, n=B):
+            zeros_n = lambda dt: np.zeros((n, 1), dt)
+            return policy_api.RolloutRequest(obs=obs, is_evaluation=zeros_n(np.uint8), on_reset=zeros_n(np.uint8), client_id=zeros_n(np.int32),
+                                             request_id=np.arange(n).reshape(n, 1), received_time=zeros_n(np.int64),
+                                             buffer_index=zeros_n(np.int32))
 
-        def new_inference_policy(capacity):
+        def new_inference_policy(capacity, ring=None):
             pol = policy_api.make(config.Policy("actor-critic", args=POLICY))
             pol.load_checkpoint(trainer.policy.get_checkpoint())
-            pol.attach_obs_ring(pol.make_obs_ring(capacity, patch_rows=4 * B))
+            pol.attach_obs_ring(pol.make_obs_ring(capacity, patch_rows=4 * B) if ring is None else ring)
             return pol
 
-        def rollout_phase(pol, stacked, keep=None, check=None, prev=None):
-            """Tb ticks; returns (stamps [Tb, B, 1], seconds per tick after three warm-up ticks, last stamps)."""
-            stamps = np.empty((Tb, B, 1), np.int64)
-            prev = np.zeros((B, 1), np.int64) if prev is None else prev
+        def rollout_phase(pol, stacked, keep=None, check=None, prev=None, cols=(0, B)):
+            """Tb ticks over the env columns [cols[0], cols[1]); returns (stamps [Tb, columns, 1], seconds per tick after three
+            warm-up ticks, last stamps)."""
+            c0, c1 = cols
+            nb = c1 - c0
+            stamps = np.empty((Tb, nb, 1), np.int64)
+            prev = np.zeros((nb, 1), np.int64) if prev is None else prev
             t_roll, n_roll = 0.0, 0
             for t in range(Tb):
                 if stacked:
-                    prev = np.where(fresh[t][:, None], 0, prev)
-                    req = request(NamedArray(obs=planes[t], ring_prev=prev))
+                    prev = np.where(fresh[t][c0:c1, None], 0, prev)
+                    req = request(NamedArray(obs=planes[t][c0:c1], ring_prev=prev), nb)
                 else:
-                    req = request(NamedArray(obs=frames[t]))
+                    req = request(NamedArray(obs=frames[t][c0:c1]), nb)
                 t0 = time.perf_counter()
                 resp = pol.rollout(req)  # returns numpy: synchronises
                 if t >= 3:
@@ -821,17 +826,40 @@ def main():
         nxt = b0.metadata["ring_slot"]
         ring.release(nxt)
         del b0
-        roll_stream = torch.cuda.Stream(device=device, priority=-1)  # short inference kernels go ahead of the update's queue
-        state = dict(prev=last_stamps, err=None, roll_s=[])
+        # The rollout side as the reference runs it: SEVERAL policy workers, each serving its share of the actors
+        # (distributed/system/policy_worker.py:162-242; the actors' env ring, actor_worker.py:634-748, keeps one group's environments
+        # stepping while another group's requests are in flight).  Here: `groups` inference policies (same parameters, own executor
+        # and stream, ONE shared observation ring), each walking its own columns tick by tick in its own thread: one group's H2D of
+        # planes and D2H of results cross the link while another group's kernels run.
+        G = max(1, int(args.rollout_groups))
+        while B % G:
+            G -= 1
+        infers = [infer] + [new_inference_policy(0, ring=obs_ring) for _ in range(G - 1)]
+        roll_streams = [torch.cuda.Stream(device=device, priority=-1) for _ in range(G)]  # short inference kernels go ahead of the update's queue
+        gcols = [(g * (B // G), (g + 1) * (B // G)) for g in range(G)]
+        state = dict(prev=[last_stamps[c0:c1] for c0, c1 in gcols], err=None, roll_s=[])
+
+        def produce_group(g, out):
+            try:
+                with torch.cuda.stream(roll_streams[g]):
+                    out[g], _, state["prev"][g] = rollout_phase(infers[g], True, prev=state["prev"][g], cols=gcols[g])
+            except BaseException as e:  # surfaced by the main thread
+                state["err"] = e
 
         def produce(slot):
             try:
-                with torch.cuda.stream(roll_stream):
-                    t0 = time.perf_counter()
-                    st, _, state["prev"] = rollout_phase(infer, True, prev=state["prev"])
-                    state["roll_s"].append(time.perf_counter() - t0)
-                ring.host_blocks(slot)["analyzed_result.obs_ref"][...] = st
-                ring.recycle(slot)  # complete: every column of the slot carries the new stamps
+                t0 = time.perf_counter()
+                out = [None] * G
+                ths = [threading.Thread(target=produce_group, args=(g, out)) for g in range(1, G)]
+                for th_ in ths:
+                    th_.start()
+                produce_group(0, out)
+                for th_ in ths:
+                    th_.join()
+                state["roll_s"].append(time.perf_counter() - t0)
+                if state["err"] is None:
+                    ring.host_blocks(slot)["analyzed_result.obs_ref"][...] = np.concatenate(out, axis=1)
+                    ring.recycle(slot)  # complete: every column of the slot carries the new stamps
             except BaseException as e:  # surfaced by the main thread
                 state["err"] = e
 
@@ -853,10 +881,13 @@ def main():
         el_c, _ = timed(closed_iteration, 1, n_closed)
         closed = dict(value=rate(el_c, n_closed), unit="env-steps/s", ms_per_iteration=1e3 * el_c / n_closed, iterations=n_closed,
                       rollout_phase_ms=round(1e3 * float(np.mean(state["roll_s"][1:])), 1),
-                      rollout_ticks_per_iteration=Tb, requests_per_tick=B, obs_ring=dict(capacity_rows=obs_ring.capacity, **obs_ring.stats),
+                      rollout_ticks_per_iteration=Tb, requests_per_tick=B, rollout_groups=G,
+                      update_alone_ms=round(ms_step, 2), obs_ring=dict(capacity_rows=obs_ring.capacity, **obs_ring.stats),
                       note="one iteration = the update on sample k (ring-fed, as the headline) with the whole rollout phase of sample "
                            "k+1 (Tb stack-aware inference batches from pinned host memory, results back to the host) running beside "
-                           "it on the same GPU; every sample is trained on with the stamps of its own rollout phase")
+                           "it on the same GPU; every sample is trained on with the stamps of its own rollout phase.  The rollout side "
+                           f"is {G} inference policies (policy workers), each serving {B // G} of the environments on its own stream "
+                           "and thread into the one shared observation ring, so that one group's link transfers overlap another's kernels")
         ring.recycle(nxt)
 
     if rank == 0:

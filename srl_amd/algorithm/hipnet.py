@@ -193,12 +193,18 @@ class HipNet:
 
     def reference_state(self) -> "OrderedDict[str, torch.Tensor]":
         host = self.flat.detach().cpu()
-        out = OrderedDict((info.key, info.to_reference(host[info.offset:info.offset + info.numel]))
-                          for info in self.spec.params.values())
-        if self.spec.popart:
-            rms, vd = self.popart_state.detach().cpu(), self.spec.value_dim
-            out[self.spec.popart_keys[0]], out[self.spec.popart_keys[1]] = rms[:vd].clone(), rms[vd:2 * vd].clone()
-            out[self.spec.popart_keys[2]] = rms[2 * vd:].clone()
+        out = OrderedDict()
+        params = list(self.spec.params.values())
+        # the PopArt head's float64 running statistics sit right behind its weight and bias, as in the reference module's
+        # state_dict (popart.py:19-31) -- i.e. in front of PPG's auxiliary head, the net's last child
+        head = self.spec.popart_keys[0].split(".")[0] + "." if self.spec.popart else None
+        last_of_head = max((i for i, info in enumerate(params) if head and info.key.startswith(head)), default=-1)
+        for i, info in enumerate(params):
+            out[info.key] = info.to_reference(host[info.offset:info.offset + info.numel])
+            if i == last_of_head:
+                rms, vd = self.popart_state.detach().cpu(), self.spec.value_dim
+                out[self.spec.popart_keys[0]], out[self.spec.popart_keys[1]] = rms[:vd].clone(), rms[vd:2 * vd].clone()
+                out[self.spec.popart_keys[2]] = rms[2 * vd:].clone()
         return out
 
     def flat_to_reference(self, flat_host: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":

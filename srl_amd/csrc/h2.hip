@@ -191,11 +191,6 @@ extern "C" int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d) {
   srl_count_dispatch(SRL_DISP_H2, 3, wide ? 8 : (d->NC >= 128 ? 4 : 2), wide ? 2 : 3);
   static const int dbg = [] { const char* e = getenv("SRL_H2G_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
-  // start-up skew between the XCDs (h2gemm.h): units of 64 x 127 cycles (~3.4 us); SRL_H2G_STAGGER overrides
-  static const int stagger_env = [] { const char* e = getenv("SRL_H2G_STAGGER"); return e ? atoi(e) : -1; }();
-  const long tiles_wide = ((d->M + 255) / 256) * ((d->NC + 255) / 256);
-  a.stagger = stagger_env >= 0 ? stagger_env : 0;
-  if (!(wide && tiles_wide > 256)) a.stagger = 0;   // (a launch of one round or less has no later round to carry the phase into)
   int rc;
   if (wide) rc = h2gemm_launch<8, H2X_DENSE, 2, false>((hipStream_t)stream, a);
   else if (d->NC >= 128) rc = h2gemm_launch<4, H2X_DENSE, 3>((hipStream_t)stream, a);

@@ -86,7 +86,6 @@ struct H2Args {
   uint32_t* mask_out;       // relu sign bits of out, natural element order, or null
   const uint32_t* mask_in;  // out *= bit of this mask at the output element (relu derivative), or null
   int32_t mask_in_h2;       // mask_in's bits are in h2 order (bit 8 g + j of a 32-block's word: what h2conv.h's forward kernels write)
-  int32_t stagger;          // first-round workgroups of odd XCDs start this many units of 64 x 127 cycles late (see the kernel)
   int32_t dbg;              // timing experiments (wrong results; SRL_H2G_DBG): 1 no DMA, 2 no fragment reads / MFMAs, 4 no epilogue stores
 };
 
@@ -203,13 +202,6 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wid & 3, kh = KSPLIT ? wid >> 2 : 0, chalf = KSPLIT ? 0 : wid >> 2;
-  // Every workgroup of a round reaches its epilogue at the same time: the chip then writes a round's whole output in one burst
-  // (the Linear's data gradient: 64 MB per round at the HBM write rate, 52 of its 212 us) while no wavefront computes, and reads
-  // nothing while they all compute.  The first round's workgroups of the odd XCDs start half a tile late: one half's stores
-  // and ring fills then fall into the other half's MFMA time, and the phase carries over to the later rounds (a CU picks its
-  // next tile when it finishes one).  The last, partial round leaves the slack that pays for the delay.
-  if (g.stagger > 0 && blockIdx.x < 256u && (blockIdx.x & 1u))
-    for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   // logical tile id: every XCD owns one contiguous run
   unsigned lid;
   {

@@ -25,8 +25,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMB = 2;          // 32-channel blocks per side of a layer at most
-constexpr int kTld = 68;        // floats per row of a transposition tile (64 + 4: float4 stores stay aligned)
-constexpr int kMaxAcc = 12;     // persistent dW accumulator blocks of a chain at most (192 accumulator registers)
+constexpr int kMaxAcc = 12;     // dW accumulator blocks of a chain at most (48 KB of LDS, shared by the workgroup)
 
 struct MArgs {
   Args a;
@@ -39,6 +38,12 @@ struct MArgs {
 };
 
 __device__ __forceinline__ int mm_ch(int e, int hb) { return (e & 3) + 8 * (e >> 2) + 4 * hb; }
+// how many of a block's 16 k-pairs (register e of both half-lanes) hold channels below `dim`: registers 4g .. 4g + 3 carry channels
+// 8g .. 8g + 7, so a 4-wide input needs 4 of the 16 MFMAs of its block (the others multiply padding zeros)
+__device__ __forceinline__ int mm_ne(int dim, int blk) {
+  const int left = dim - 32 * blk;
+  return left >= 32 ? 16 : (left <= 0 ? 0 : 4 * ((left + 7) >> 3));
+}
 
 // rows [row] of a row-major [rows][ld] matrix, columns 0 .. dim - 1, into the accumulator layout (zeros beyond dim / the rows)
 __device__ __forceinline__ void mm_load(const float* base, long ld, long row, bool rok, int dim, int hb, float (&v)[kMB][16]) {
@@ -97,20 +102,20 @@ __device__ __forceinline__ void mm_ln_stats(const float (&v)[kMB][16], int dim, 
 }
 
 // stage the chain's parameters into LDS in operand order (every thread of the workgroup)
-__device__ __forceinline__ void mm_stage(const MArgs& m, float* sm, int tid, bool bwd) {
+__device__ __forceinline__ void mm_stage(const MArgs& m, float* sm, int tid, bool bwd, int nthr = 256) {
   for (int i = 0; i < m.a.n; ++i) {
     const Layer L = m.a.L[i];
     if (L.kind == 1) {
       const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5;
       if (!bwd) {
-        for (int e = tid; e < nbo * nbi * 1024; e += 256) {
+        for (int e = tid; e < nbo * nbi * 1024; e += nthr) {
           const int l = e & 63, e16 = (e >> 6) & 15, blk = e >> 10, ib = blk % nbi, ob = blk / nbi;
           const int o = 32 * ob + (l & 31), k = 32 * ib + mm_ch(e16, l >> 5);
           sm[m.wf[i] + e] = (o < L.out && k < L.in) ? L.w[o * L.in + k] : 0.f;
         }
-        for (int c = tid; c < nbo * 32; c += 256) sm[m.tb[i] + c] = (c < L.out && L.b) ? L.b[c] : 0.f;
+        for (int c = tid; c < nbo * 32; c += nthr) sm[m.tb[i] + c] = (c < L.out && L.b) ? L.b[c] : 0.f;
       } else if (i > 0) {
-        for (int e = tid; e < nbo * nbi * 1024; e += 256) {
+        for (int e = tid; e < nbo * nbi * 1024; e += nthr) {
           const int l = e & 63, e16 = (e >> 6) & 15, blk = e >> 10, ob = blk % nbo, ib = blk / nbo;
           const int k = 32 * ib + (l & 31), o = 32 * ob + mm_ch(e16, l >> 5);
           sm[m.wt[i] + e] = (o < L.out && k < L.in) ? L.w[o * L.in + k] : 0.f;
@@ -119,7 +124,7 @@ __device__ __forceinline__ void mm_stage(const MArgs& m, float* sm, int tid, boo
     } else {
       const int nb = (L.in + 31) >> 5;
       const int off = bwd ? m.wt[i] : m.wf[i];
-      for (int c = tid; c < nb * 32; c += 256) {
+      for (int c = tid; c < nb * 32; c += nthr) {
         sm[off + c] = c < L.in ? L.w[c] : 0.f;
         if (!bwd) sm[off + nb * 32 + c] = c < L.in ? L.b[c] : 0.f;
       }
@@ -179,8 +184,10 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(MArgs m) {
             for (int ib = 0; ib < kMB; ++ib)
               if (ib < nbi) {
                 const float* wfr = sm + m.wf[i] + (ob * nbi + ib) * 1024 + lane;
+                const int ne = mm_ne(L.in, ib);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfr[64 * e], cur[ib][e], acc[ob], 0, 0, 0);
+                for (int e = 0; e < 16; ++e)
+                  if (e < ne) acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfr[64 * e], cur[ib][e], acc[ob], 0, 0, 0);
               }
           }
         }
@@ -208,39 +215,61 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(MArgs m) {
   }
 }
 
-// one 32 x 32 block of a weight gradient: rows of the two transposition tiles are the k dimension
-__device__ __forceinline__ void mm_wgrad_block(f32x16& acc, const float* dT, const float* xT, int ob, int ib, int lane) {
-  const float* ap = dT + (lane >> 5) * kTld + 32 * ob + (lane & 31);
-  const float* bp = xT + (lane >> 5) * kTld + 32 * ib + (lane & 31);
+// ---- backward -------------------------------------------------------------------------------------------------------------------
+// Round 4 kept one persistent 32 x 32 accumulator block per (out block, in block) of every Linear in REGISTERS, per wavefront: 12
+// blocks = 192 accumulator registers, 512 registers per wavefront, one wavefront per SIMD, 184 bytes of scratch per lane -- 358 us
+// per 131 072 rows of a 4-64-64-2 chain whose MFMAs take 24.  Now the weight-gradient blocks live in LDS, shared by the
+// workgroup: a wavefront forms a tile's 32 x 32 contribution in 16 registers (16 MFMAs over the tile's 32 rows) and adds it with
+// ds_add_f32 (64 lanes x 16 adds against 1024 matrix-pipe cycles); bias / LayerNorm-affine column sums go the same way.  The
+// transposition tiles shrink to one 32-channel half per operand (36-float pitch: conflict-free both ways), so that eight
+// wavefronts -- two per SIMD, under 256 registers -- fit beside the parameters and the accumulators.
+constexpr int kTh = 36;         // floats per row of a half tile (32 + 4)
+
+__device__ __forceinline__ void mm_half_write(float* T, int r, int hb, const float (&v)[16]) {
 #pragma unroll
-  for (int mm = 0; mm < 16; ++mm) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * mm * kTld], bp[2 * mm * kTld], acc, 0, 0, 0);
+  for (int j = 0; j < 4; ++j)
+    *reinterpret_cast<float4*>(T + r * kTh + 8 * j + 4 * hb) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
 }
 
-__device__ __forceinline__ void mm_tile_write(float* T, int r, int hb, const float (&v)[kMB][16]) {
-#pragma unroll
-  for (int ib = 0; ib < kMB; ++ib)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<float4*>(T + r * kTld + 32 * ib + 8 * j + 4 * hb) = make_float4(v[ib][4 * j], v[ib][4 * j + 1], v[ib][4 * j + 2], v[ib][4 * j + 3]);
+// column sums of a half tile into shared per-channel sums: lane = (channel c, row half)
+__device__ __forceinline__ void mm_half_colsum(const float* T, float* dst, int lane) {
+  const int c = lane & 31, r0 = (lane >> 5) * 16;
+  float s = 0.f;
+#pragma unroll 8
+  for (int rr = 0; rr < 16; ++rr) s += T[(r0 + rr) * kTh + c];
+  atomicAdd(dst + c, s);
 }
 
-__global__ __launch_bounds__(256, 1) void mlp_bwd_mfma_kernel(MArgs m) {
+// one 32 x 32 block of a weight gradient: the rows of the two half tiles are the k dimension; added into the shared block
+__device__ __forceinline__ void mm_wgrad_block(float* blk, const float* dH, const float* xH, int lane) {
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const float* ap = dH + (lane >> 5) * kTh + (lane & 31);
+  const float* bp = xH + (lane >> 5) * kTh + (lane & 31);
+#pragma unroll
+  for (int mm = 0; mm < 16; ++mm) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * mm * kTh], bp[2 * mm * kTh], acc, 0, 0, 0);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) atomicAdd(blk + e * 64 + lane, acc[e]);
+}
+
+// kBwdWaves wavefronts per workgroup: 8 where the chain's parameters and accumulator blocks leave room for eight pairs of half
+// tiles in LDS, else 6 or 4 (mm_bwd_waves)
+template <int kBwdWaves>
+__global__ __launch_bounds__(64 * kBwdWaves, kBwdWaves >= 8 ? 2 : 1) void mlp_bwd_mfma_kernel(MArgs m) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const Args& a = m.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hb = lane >> 5;
-  // LDS: parameters (m.bwd_floats) | per wavefront: dT, xT tiles, per-lane sums [npg][64]
-  float* const dT = sm + m.bwd_floats + wave * (2 * 32 * kTld + m.npg * 64);
-  float* const xT = dT + 32 * kTld;
-  float* const pgs = xT + 32 * kTld;
-  mm_stage(m, sm, tid, true);
-  for (int e = lane; e < m.npg * 64; e += 64) pgs[e] = 0.f;
+  // LDS: parameters (m.bwd_floats) | shared accumulator blocks [nacc][16][64] | shared per-channel sums [npg][64] | per wavefront: dH, xH
+  float* const accs = sm + m.bwd_floats;
+  float* const pgs = accs + m.nacc * 1024;
+  float* const dH = pgs + m.npg * 64 + wave * (2 * 32 * kTh);
+  float* const xH = dH + 32 * kTh;
+  mm_stage(m, sm, tid, true, 64 * kBwdWaves);
+  for (int e = tid; e < m.nacc * 1024 + m.npg * 64; e += 64 * kBwdWaves) accs[e] = 0.f;
   __syncthreads();
-  f32x16 A0, A1, A2, A3, A4, A5, A6, A7, A8, A9, A10, A11;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) A0[e] = A1[e] = A2[e] = A3[e] = A4[e] = A5[e] = A6[e] = A7[e] = A8[e] = A9[e] = A10[e] = A11[e] = 0.f;
-#define SRL_MM_BLOCKS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
   const long ntiles = (a.rows + 31) / 32;
-  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+  for (long tile = (long)blockIdx.x * kBwdWaves + wave; tile < ntiles; tile += (long)gridDim.x * kBwdWaves) {
     const long row = tile * 32 + r;
     const bool rok = row < a.rows;
     float d[kMB][16], xin[kMB][16];
@@ -256,22 +285,18 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_mfma_kernel(MArgs m) {
       const int pact = (i > 0 && a.L[i - 1].kind == 1) ? a.L[i - 1].act : 0;
       if (L.kind == 1) {
         const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5;
-        mm_tile_write(dT, r, hb, d);
-        mm_tile_write(xT, r, hb, xin);
         // (a wavefront's LDS operations execute in order: its own tiles need no barrier)
-        if (L.gb) {  // bias gradient: column sums of dz, channel = lane
-          float s = 0.f;
-#pragma unroll 8
-          for (int rr = 0; rr < 32; ++rr) s += dT[rr * kTld + lane];
-          pgs[m.pg[i] * 64 + lane] += s;
-        }
-        for (int ob = 0; ob < nbo; ++ob)
-          for (int ib = 0; ib < nbi; ++ib) {
-            switch (m.accb[i] + ob * nbi + ib) {
-#define SRL_MM_CASE(k) case k: mm_wgrad_block(A##k, dT, xT, ob, ib, lane); break;
-              SRL_MM_BLOCKS(SRL_MM_CASE)
-#undef SRL_MM_CASE
-            }
+#pragma unroll
+        for (int ob = 0; ob < kMB; ++ob)
+          if (ob < nbo) {
+            mm_half_write(dH, r, hb, d[ob]);
+            if (L.gb) mm_half_colsum(dH, pgs + m.pg[i] * 64 + 32 * ob, lane);  // bias gradient: column sums of dz
+#pragma unroll
+            for (int ib = 0; ib < kMB; ++ib)
+              if (ib < nbi) {
+                mm_half_write(xH, r, hb, xin[ib]);
+                mm_wgrad_block(accs + (m.accb[i] + ob * nbi + ib) * 1024, dH, xH, lane);
+              }
           }
         if (i > 0) {
           f32x16 acc[kMB];
@@ -284,8 +309,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_mfma_kernel(MArgs m) {
               for (int ob = 0; ob < kMB; ++ob)
                 if (ob < nbo) {
                   const float* wfr = sm + m.wt[i] + (ib * nbo + ob) * 1024 + lane;
+                  const int ne = mm_ne(L.out, ob);
 #pragma unroll
-                  for (int e = 0; e < 16; ++e) acc[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfr[64 * e], d[ob][e], acc[ib], 0, 0, 0);
+                  for (int e = 0; e < 16; ++e)
+                    if (e < ne) acc[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfr[64 * e], d[ob][e], acc[ib], 0, 0, 0);
                 }
             }
           }
@@ -302,42 +329,37 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_mfma_kernel(MArgs m) {
         const int nb = (L.in + 31) >> 5;
         float gg[kMB][16];
         float m1 = 0.f, m2 = 0.f;
-        mm_tile_write(xT, r, hb, d);  // gy: its column sums are dbeta
 #pragma unroll
-        for (int ib = 0; ib < kMB; ++ib)
+        for (int ib = 0; ib < kMB; ++ib) {
+          float gyx[16];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ib < nb) g4 = *reinterpret_cast<const float4*>(gt + 32 * ib + 8 * j + 4 * hb);
             const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-            float gyx[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int e = 4 * j + q;
               const bool in = 32 * ib + mm_ch(e, hb) < L.in;
               const float xh = in ? (xin[ib][e] - mean) * rstd : 0.f;
               xin[ib][e] = in ? xin[ib][e] : 0.f;
-              gyx[q] = d[ib][e] * xh;
+              gyx[e] = d[ib][e] * xh;
               gg[ib][e] = d[ib][e] * gv[q];
               m1 += gg[ib][e];
               m2 = fmaf(gg[ib][e], xh, m2);
             }
-            *reinterpret_cast<float4*>(dT + r * kTld + 32 * ib + 8 * j + 4 * hb) = make_float4(gyx[0], gyx[1], gyx[2], gyx[3]);  // dgamma's terms
           }
+          if (ib < nb) {
+            mm_half_write(dH, r, hb, gyx);     // dgamma's terms
+            mm_half_write(xH, r, hb, d[ib]);   // gy: its column sums are dbeta
+            mm_half_colsum(dH, pgs + m.pg[i] * 64 + 32 * ib, lane);
+            mm_half_colsum(xH, pgs + (m.pg[i] + 1) * 64 + 32 * ib, lane);
+          }
+        }
         m1 += __shfl_xor(m1, 32);
         m2 += __shfl_xor(m2, 32);
         m1 /= (float)L.in;
         m2 /= (float)L.in;
-        {
-          float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
-          for (int rr = 0; rr < 32; ++rr) {
-            s1 += dT[rr * kTld + lane];
-            s2 += xT[rr * kTld + lane];
-          }
-          pgs[m.pg[i] * 64 + lane] += s1;
-          pgs[(m.pg[i] + 1) * 64 + lane] += s2;
-        }
         if (i > 0) {
 #pragma unroll
           for (int ib = 0; ib < kMB; ++ib)
@@ -351,58 +373,35 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_mfma_kernel(MArgs m) {
       }
     }
   }
-  // ---- fold the wavefronts' sums in LDS, then one atomic per parameter and workgroup --------------------------------------------
-  // (the per-lane sums sit inside the region that becomes the fold buffer: each wavefront takes its own out first)
-  float pgv[2 * SRL_MLP_MAX_LAYERS];
-#pragma unroll
-  for (int q = 0; q < 2 * SRL_MLP_MAX_LAYERS; ++q) pgv[q] = q < m.npg ? pgs[q * 64 + lane] : 0.f;
-  __syncthreads();  // every wavefront is past its tiles: the tile region is free
-  float* const red = sm + m.bwd_floats;  // [kMaxP]: fits the tile region (mm_plan)
-  for (int e = tid; e < kMaxP; e += 256) red[e] = 0.f;
+  // ---- the workgroup's sums: one atomic per parameter and workgroup ----------------------------------------------------------
   __syncthreads();
   for (int i = 0; i < a.n; ++i) {
     const Layer L = a.L[i];
     if (L.kind == 1) {
       const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5;
-      for (int ob = 0; ob < nbo; ++ob)
-        for (int ib = 0; ib < nbi; ++ib) {
-          // accumulator of dz^T x: rows = out channel (register e, half hb), columns = in channel (lane & 31)
-          const int k = 32 * ib + (lane & 31);
-          float* const dst = red + L.pw + k;
-          const bool kok = k < L.in;
-          switch (m.accb[i] + ob * nbi + ib) {
-#define SRL_MM_CASE(kk)                                                                  \
-  case kk:                                                                               \
-    _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                     \
-      const int o = 32 * ob + mm_ch(e, hb);                                              \
-      if (o < L.out && kok) atomicAdd(dst + o * L.in, A##kk[e]);                         \
-    }                                                                                    \
-    break;
-            SRL_MM_BLOCKS(SRL_MM_CASE)
-#undef SRL_MM_CASE
-          }
-        }
+      // accumulator of dz^T x: rows = out channel (register e, half hb), columns = in channel (lane & 31)
+      for (int idx = tid; idx < nbo * nbi * 1024; idx += 64 * kBwdWaves) {
+        const int l = idx & 63, e = (idx >> 6) & 15, blk = idx >> 10, ob = blk / nbi, ib = blk - ob * nbi;
+        const int o = 32 * ob + mm_ch(e, l >> 5), k = 32 * ib + (l & 31);
+        if (o < L.out && k < L.in) atomicAdd(L.gw + o * L.in + k, accs[(m.accb[i] + blk) * 1024 + (idx & 1023)]);
+      }
+      if (L.gb)
+        for (int c = tid; c < L.out; c += 64 * kBwdWaves) atomicAdd(L.gb + c, pgs[m.pg[i] * 64 + c]);
+    } else {
+      for (int c = tid; c < L.in; c += 64 * kBwdWaves) {
+        atomicAdd(L.gw + c, pgs[m.pg[i] * 64 + c]);
+        atomicAdd(L.gb + c, pgs[(m.pg[i] + 1) * 64 + c]);
+      }
     }
   }
-#pragma unroll
-  for (int q = 0; q < 2 * SRL_MLP_MAX_LAYERS; ++q) {
-    // which layer's sums sit in slot q: found by walking the layers (uniform, a handful of iterations)
-    for (int i = 0; i < a.n; ++i) {
-      const Layer L = a.L[i];
-      if (L.kind == 1 && L.gb && m.pg[i] == q && lane < L.out) atomicAdd(red + L.pb + lane, pgv[q]);
-      if (L.kind == 0 && m.pg[i] == q && lane < L.in) atomicAdd(red + L.pw + lane, pgv[q]);
-      if (L.kind == 0 && m.pg[i] + 1 == q && lane < L.in) atomicAdd(red + L.pb + lane, pgv[q]);
-    }
-  }
-  __syncthreads();
-  for (int i = 0; i < a.n; ++i) {
-    const Layer L = a.L[i];
-    const int nw = L.kind == 1 ? L.out * L.in : L.in, nbv = L.kind == 1 ? L.out : L.in;
-    for (int e = tid; e < nw; e += 256) atomicAdd(L.gw + e, red[L.pw + e]);
-    if (L.gb)
-      for (int e = tid; e < nbv; e += 256) atomicAdd(L.gb + e, red[L.pb + e]);
-  }
-#undef SRL_MM_BLOCKS
+}
+
+// LDS of the backward kernel: parameters | shared accumulator blocks | shared per-channel sums | two half tiles per wavefront
+inline long mm_bwd_lds_bytes(const MArgs& m, int waves) { return 4L * (m.bwd_floats + m.nacc * 1024 + m.npg * 64 + waves * 2 * 32 * kTh); }
+inline int mm_bwd_waves(const MArgs& m) {
+  for (int w = 8; w >= 4; w -= 2)
+    if (mm_bwd_lds_bytes(m, w) <= 158 * 1024) return w;
+  return 0;
 }
 
 // LDS plan of a chain for the MFMA kernels; false: not eligible
@@ -427,10 +426,9 @@ inline bool mm_plan(MArgs& m) {
     }
   }
   m.fwd_floats = f; m.bwd_floats = b; m.nacc = nacc; m.npg = npg;
-  if (nacc > kMaxAcc || !a.lds_acc) return false;
-  const long fwd_bytes = 4L * f, tiles = 4L * (2 * 32 * kTld + npg * 64);
-  const long bwd_bytes = 4L * b + 4L * (tiles > kMaxP ? tiles : kMaxP);
-  return fwd_bytes <= 150 * 1024 && bwd_bytes <= 150 * 1024;
+  if (nacc > kMaxAcc) return false;
+  const long fwd_bytes = 4L * f;
+  return fwd_bytes <= 150 * 1024 && mm_bwd_waves(m) > 0;
 }
 
 }  // namespace
