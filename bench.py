@@ -496,7 +496,7 @@ def main():
     ap.add_argument("--no-from-host", action="store_true",
                     help="skip the pinned-host-fed passes: `value` is then the resident-in-HBM figure")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the rollout-beside-update leg (`closed_loop`)")
-    ap.add_argument("--rollout-groups", type=int, default=2,
+    ap.add_argument("--rollout-groups", type=int, default=1,
                     help="closed loop: inference policies (policy workers) sharing the observation ring, each serving B / groups environments")
     ap.add_argument("--no-plain-copy", action="store_true", help="skip the pass without the observation ring (`from_pinned_host`)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank")

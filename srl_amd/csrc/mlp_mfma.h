@@ -34,7 +34,8 @@ struct MArgs {
   int wt[SRL_MLP_MAX_LAYERS];    // backward: Linear transposed fragments [nbi][nbo][16][64] (layers > 0); LayerNorm: gamma table
   int accb[SRL_MLP_MAX_LAYERS];  // backward: first accumulator block of a Linear
   int pg[SRL_MLP_MAX_LAYERS];    // backward: offset of the layer's per-lane sums (Linear: bias gradient; LayerNorm: dgamma | dbeta)
-  int fwd_floats, bwd_floats, nacc, npg;
+  int fwd_floats, bwd_floats, nacc, npg, nlin;
+  int dbg;   // timing experiments (wrong results; SRL_MLP_DBG): 2 no weight-gradient blocks, 4 no data gradient, 8 no final global adds
 };
 
 __device__ __forceinline__ int mm_ch(int e, int hb) { return (e & 3) + 8 * (e >> 2) + 4 * hb; }
@@ -43,6 +44,20 @@ __device__ __forceinline__ int mm_ch(int e, int hb) { return (e & 3) + 8 * (e >>
 __device__ __forceinline__ int mm_ne(int dim, int blk) {
   const int left = dim - 32 * blk;
   return left >= 32 ? 16 : (left <= 0 ? 0 : 4 * ((left + 7) >> 3));
+}
+
+// NE MFMAs of one (out block, in block) product as straight-line code (a run-time bound inside the unrolled loop put every MFMA into
+// a basic block of its own: the operand reads could no longer run ahead, fwd 83 -> 170 us)
+template <int NE>
+__device__ __forceinline__ void mm_chain_n(f32x16& acc, const float* wfr, const float (&v)[16]) {
+#pragma unroll
+  for (int e = 0; e < NE; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wfr[64 * e], v[e], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mm_chain(f32x16& acc, const float* wfr, const float (&v)[16], int ne) {
+  if (ne == 16) mm_chain_n<16>(acc, wfr, v);
+  else if (ne == 4) mm_chain_n<4>(acc, wfr, v);
+  else if (ne == 8) mm_chain_n<8>(acc, wfr, v);
+  else if (ne == 12) mm_chain_n<12>(acc, wfr, v);
 }
 
 // rows [row] of a row-major [rows][ld] matrix, columns 0 .. dim - 1, into the accumulator layout (zeros beyond dim / the rows)
@@ -184,10 +199,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(MArgs m) {
             for (int ib = 0; ib < kMB; ++ib)
               if (ib < nbi) {
                 const float* wfr = sm + m.wf[i] + (ob * nbi + ib) * 1024 + lane;
-                const int ne = mm_ne(L.in, ib);
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                  if (e < ne) acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfr[64 * e], cur[ib][e], acc[ob], 0, 0, 0);
+                mm_chain(acc[ob], wfr, cur[ib], mm_ne(L.in, ib));
               }
           }
         }
@@ -217,13 +229,18 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(MArgs m) {
 
 // ---- backward -------------------------------------------------------------------------------------------------------------------
 // Round 4 kept one persistent 32 x 32 accumulator block per (out block, in block) of every Linear in REGISTERS, per wavefront: 12
-// blocks = 192 accumulator registers, 512 registers per wavefront, one wavefront per SIMD, 184 bytes of scratch per lane -- 358 us
-// per 131 072 rows of a 4-64-64-2 chain whose MFMAs take 24.  Now the weight-gradient blocks live in LDS, shared by the
-// workgroup: a wavefront forms a tile's 32 x 32 contribution in 16 registers (16 MFMAs over the tile's 32 rows) and adds it with
-// ds_add_f32 (64 lanes x 16 adds against 1024 matrix-pipe cycles); bias / LayerNorm-affine column sums go the same way.  The
-// transposition tiles shrink to one 32-channel half per operand (36-float pitch: conflict-free both ways), so that eight
-// wavefronts -- two per SIMD, under 256 registers -- fit beside the parameters and the accumulators.
-constexpr int kTh = 36;         // floats per row of a half tile (32 + 4)
+// blocks = 192 accumulator registers, 512 registers per wavefront, 184 bytes of scratch per lane -- 358 us per 131 072 rows of a
+// chain whose MFMAs take ~40.  First attempt of round 5: the blocks in LDS, shared by the workgroup, every wavefront adding its
+// tile's 32 x 32 contribution with ds_add_f32 -- no scratch, two wavefronts per SIMD, and SLOWER where it mattered: a ds_add_f32
+// wave-instruction takes ~160 cycles (leave-out: 229 us with, 90 without the adds on a 4-64-64-2 chain).  Now the blocks are OWNED:
+// the four wavefronts of a workgroup walk four tiles side by side; at a Linear layer each writes its tile's dz and x halves to
+// LDS, and after a barrier wavefront w forms block (w mod blocks) of that layer over the tiles of ALL four (or, with 2 / 1 blocks,
+// over its share of them) -- so a wavefront accumulates ONE block per Linear layer, 16 registers each, for the whole launch, and
+// the sums meet in LDS once, at the end.
+constexpr int kTh = 36;         // floats per row of a half tile (32 + 4: conflict-free writes and transposed reads)
+constexpr int kBwdWaves = 4;
+constexpr int kMaxLin = 4;      // Linear layers of an eligible chain at most (one accumulator block per wavefront and layer)
+constexpr int kTileF = 2 * kMB * 32 * kTh;   // floats of a wavefront's tile area: dz halves | x halves
 
 __device__ __forceinline__ void mm_half_write(float* T, int r, int hb, const float (&v)[16]) {
 #pragma unroll
@@ -231,52 +248,48 @@ __device__ __forceinline__ void mm_half_write(float* T, int r, int hb, const flo
     *reinterpret_cast<float4*>(T + r * kTh + 8 * j + 4 * hb) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
 }
 
-// column sums of a half tile into shared per-channel sums: lane = (channel c, row half)
+// column sums of a half tile into this wavefront's per-channel sums: lane = (channel c, row half)
 __device__ __forceinline__ void mm_half_colsum(const float* T, float* dst, int lane) {
   const int c = lane & 31, r0 = (lane >> 5) * 16;
   float s = 0.f;
 #pragma unroll 8
   for (int rr = 0; rr < 16; ++rr) s += T[(r0 + rr) * kTh + c];
-  atomicAdd(dst + c, s);
+  s += __shfl_xor(s, 32);
+  if (lane < 32) dst[c] += s;
 }
 
-// one 32 x 32 block of a weight gradient: the rows of the two half tiles are the k dimension; added into the shared block
-__device__ __forceinline__ void mm_wgrad_block(float* blk, const float* dH, const float* xH, int lane) {
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+// one tile's contribution to a 32 x 32 block of a weight gradient: the rows of the two half tiles are the k dimension
+__device__ __forceinline__ void mm_wgrad_tile(f32x16& acc, const float* dH, const float* xH, int lane) {
   const float* ap = dH + (lane >> 5) * kTh + (lane & 31);
   const float* bp = xH + (lane >> 5) * kTh + (lane & 31);
 #pragma unroll
   for (int mm = 0; mm < 16; ++mm) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * mm * kTh], bp[2 * mm * kTh], acc, 0, 0, 0);
-#pragma unroll
-  for (int e = 0; e < 16; ++e) atomicAdd(blk + e * 64 + lane, acc[e]);
 }
 
-// kBwdWaves wavefronts per workgroup: 8 where the chain's parameters and accumulator blocks leave room for eight pairs of half
-// tiles in LDS, else 6 or 4 (mm_bwd_waves)
-template <int kBwdWaves>
-__global__ __launch_bounds__(64 * kBwdWaves, kBwdWaves >= 8 ? 2 : 1) void mlp_bwd_mfma_kernel(MArgs m) {
+__global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const Args& a = m.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hb = lane >> 5;
-  // LDS: parameters (m.bwd_floats) | shared accumulator blocks [nacc][16][64] | shared per-channel sums [npg][64] | per wavefront: dH, xH
-  float* const accs = sm + m.bwd_floats;
-  float* const pgs = accs + m.nacc * 1024;
-  float* const dH = pgs + m.npg * 64 + wave * (2 * 32 * kTh);
-  float* const xH = dH + 32 * kTh;
+  // LDS: parameters (m.bwd_floats) | per wavefront: per-channel sums [npg][64] | per wavefront: tile area (dz halves | x halves)
+  float* const pgs = sm + m.bwd_floats + wave * (m.npg * 64);
+  float* const tiles = sm + m.bwd_floats + kBwdWaves * (m.npg * 64);
+  float* const myT = tiles + wave * kTileF;
   mm_stage(m, sm, tid, true, 64 * kBwdWaves);
-  for (int e = tid; e < m.nacc * 1024 + m.npg * 64; e += 64 * kBwdWaves) accs[e] = 0.f;
+  for (int e = lane; e < m.npg * 64; e += 64) pgs[e] = 0.f;
   __syncthreads();
+  f32x16 W0, W1, W2, W3;   // this wavefront's block of the chain's 1st .. 4th Linear layer (counted from the input side)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) W0[e] = W1[e] = W2[e] = W3[e] = 0.f;
   const long ntiles = (a.rows + 31) / 32;
-  for (long tile = (long)blockIdx.x * kBwdWaves + wave; tile < ntiles; tile += (long)gridDim.x * kBwdWaves) {
-    const long row = tile * 32 + r;
+  for (long tile0 = (long)blockIdx.x * kBwdWaves; tile0 < ntiles; tile0 += (long)gridDim.x * kBwdWaves) {
+    const long row = (tile0 + wave) * 32 + r;   // (a tile beyond the rows: zeros all the way, its wavefront keeps the barriers' count)
     const bool rok = row < a.rows;
     float d[kMB][16], xin[kMB][16];
     {
       const Layer& last = a.L[a.n - 1];
       mm_load(a.dy, a.lddy, row, rok, last.kind == 1 ? last.out : last.in, hb, d);
     }
+    int lin = m.nlin;
     for (int i = a.n - 1; i >= 0; --i) {
       const Layer L = a.L[i];
       if (i == 0) mm_load(a.x, a.ldx, row, rok, L.in, hb, xin);
@@ -284,35 +297,47 @@ __global__ __launch_bounds__(64 * kBwdWaves, kBwdWaves >= 8 ? 2 : 1) void mlp_bw
       // the activation that produced this input: its derivative (from the input's value) closes the data gradient
       const int pact = (i > 0 && a.L[i - 1].kind == 1) ? a.L[i - 1].act : 0;
       if (L.kind == 1) {
+        --lin;
         const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5;
-        // (a wavefront's LDS operations execute in order: its own tiles need no barrier)
 #pragma unroll
         for (int ob = 0; ob < kMB; ++ob)
           if (ob < nbo) {
-            mm_half_write(dH, r, hb, d[ob]);
-            if (L.gb) mm_half_colsum(dH, pgs + m.pg[i] * 64 + 32 * ob, lane);  // bias gradient: column sums of dz
-#pragma unroll
-            for (int ib = 0; ib < kMB; ++ib)
-              if (ib < nbi) {
-                mm_half_write(xH, r, hb, xin[ib]);
-                mm_wgrad_block(accs + (m.accb[i] + ob * nbi + ib) * 1024, dH, xH, lane);
-              }
+            mm_half_write(myT + ob * 32 * kTh, r, hb, d[ob]);
+            if (L.gb) mm_half_colsum(myT + ob * 32 * kTh, pgs + m.pg[i] * 64 + 32 * ob, lane);  // bias gradient: column sums of dz
           }
+#pragma unroll
+        for (int ib = 0; ib < kMB; ++ib)
+          if (ib < nbi) mm_half_write(myT + (kMB + ib) * 32 * kTh, r, hb, xin[ib]);
+        __syncthreads();
+        if (!(m.dbg & 2)) {
+          // this wavefront's block of the layer, over its share of the four tiles: 4 blocks -> every tile; 2 -> two tiles; 1 -> its own
+          const int nblk = nbo * nbi, b = wave % nblk, ob = b / nbi, ib = b - ob * nbi;
+          const int per = nblk >= kBwdWaves ? kBwdWaves : nblk, t0 = (wave / nblk) * per;
+          for (int t = t0; t < t0 + per; ++t) {
+            const float* T = tiles + t * kTileF;
+            const float* dH = T + ob * 32 * kTh;
+            const float* xH = T + (kMB + ib) * 32 * kTh;
+            switch (lin) {
+              case 0: mm_wgrad_tile(W0, dH, xH, lane); break;
+              case 1: mm_wgrad_tile(W1, dH, xH, lane); break;
+              case 2: mm_wgrad_tile(W2, dH, xH, lane); break;
+              default: mm_wgrad_tile(W3, dH, xH, lane); break;
+            }
+          }
+        }
+        __syncthreads();   // the tile areas are rewritten by the next layer below
         if (i > 0) {
           f32x16 acc[kMB];
 #pragma unroll
           for (int ib = 0; ib < kMB; ++ib) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[ib][e] = 0.f;
-            if (ib < nbi) {
+            if (ib < nbi && !(m.dbg & 4)) {
 #pragma unroll
               for (int ob = 0; ob < kMB; ++ob)
                 if (ob < nbo) {
                   const float* wfr = sm + m.wt[i] + (ib * nbo + ob) * 1024 + lane;
-                  const int ne = mm_ne(L.out, ob);
-#pragma unroll
-                  for (int e = 0; e < 16; ++e)
-                    if (e < ne) acc[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfr[64 * e], d[ob][e], acc[ib], 0, 0, 0);
+                  mm_chain(acc[ib], wfr, d[ob], mm_ne(L.out, ob));
                 }
             }
           }
@@ -322,7 +347,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, kBwdWaves >= 8 ? 2 : 1) void mlp_bw
             for (int e = 0; e < 16; ++e) d[ib][e] = acc[ib][e] * act_der(xin[ib][e], pact);
         }
       } else {
-        // LayerNorm: statistics recomputed from the input; dgamma / dbeta = column sums of gy * xhat / gy
+        // LayerNorm: statistics recomputed from the input; dgamma / dbeta = column sums of gy * xhat / gy (own tile area: no barrier)
         float mean, rstd;
         mm_ln_stats(xin, L.in, hb, mean, rstd);
         const float* gt = sm + m.wt[i];
@@ -350,10 +375,10 @@ __global__ __launch_bounds__(64 * kBwdWaves, kBwdWaves >= 8 ? 2 : 1) void mlp_bw
             }
           }
           if (ib < nb) {
-            mm_half_write(dH, r, hb, gyx);     // dgamma's terms
-            mm_half_write(xH, r, hb, d[ib]);   // gy: its column sums are dbeta
-            mm_half_colsum(dH, pgs + m.pg[i] * 64 + 32 * ib, lane);
-            mm_half_colsum(xH, pgs + (m.pg[i] + 1) * 64 + 32 * ib, lane);
+            mm_half_write(myT, r, hb, gyx);                     // dgamma's terms
+            mm_half_write(myT + 32 * kTh, r, hb, d[ib]);       // gy: its column sums are dbeta
+            mm_half_colsum(myT, pgs + m.pg[i] * 64 + 32 * ib, lane);
+            mm_half_colsum(myT + 32 * kTh, pgs + (m.pg[i] + 1) * 64 + 32 * ib, lane);
           }
         }
         m1 += __shfl_xor(m1, 32);
@@ -373,10 +398,40 @@ __global__ __launch_bounds__(64 * kBwdWaves, kBwdWaves >= 8 ? 2 : 1) void mlp_bw
       }
     }
   }
-  // ---- the workgroup's sums: one atomic per parameter and workgroup ----------------------------------------------------------
+  // ---- the workgroup's sums meet in LDS (the tile region is free), then one atomic per parameter and workgroup ---------------
   __syncthreads();
-  for (int i = 0; i < a.n; ++i) {
+  float* const accs = tiles;   // [nacc][16][64]
+  for (int e = tid; e < m.nacc * 1024; e += 64 * kBwdWaves) accs[e] = 0.f;
+  __syncthreads();
+  {
+    int lin = 0;
+    for (int i = 0; i < a.n; ++i) {
+      const Layer L = a.L[i];
+      if (L.kind != 1) continue;
+      const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5, nblk = nbo * nbi;
+      float* blk = accs + (m.accb[i] + wave % nblk) * 1024 + lane;
+      // (wavefronts that shared a block add into the same 4 KB: 16 LDS adds per wavefront and layer, once per launch)
+#define SRL_MM_FOLD(Wk)                                                     \
+  _Pragma("unroll") for (int e = 0; e < 16; ++e) atomicAdd(blk + e * 64, Wk[e]);
+      switch (lin) {
+        case 0: SRL_MM_FOLD(W0) break;
+        case 1: SRL_MM_FOLD(W1) break;
+        case 2: SRL_MM_FOLD(W2) break;
+        default: SRL_MM_FOLD(W3) break;
+      }
+#undef SRL_MM_FOLD
+      ++lin;
+    }
+  }
+  __syncthreads();
+  for (int i = 0; i < ((m.dbg & 8) ? 0 : a.n); ++i) {
     const Layer L = a.L[i];
+    auto psum = [&](int slot, int c) {   // the four wavefronts' per-channel sums
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < kBwdWaves; ++w) s += sm[m.bwd_floats + w * (m.npg * 64) + slot * 64 + c];
+      return s;
+    };
     if (L.kind == 1) {
       const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5;
       // accumulator of dz^T x: rows = out channel (register e, half hb), columns = in channel (lane & 31)
@@ -386,28 +441,27 @@ __global__ __launch_bounds__(64 * kBwdWaves, kBwdWaves >= 8 ? 2 : 1) void mlp_bw
         if (o < L.out && k < L.in) atomicAdd(L.gw + o * L.in + k, accs[(m.accb[i] + blk) * 1024 + (idx & 1023)]);
       }
       if (L.gb)
-        for (int c = tid; c < L.out; c += 64 * kBwdWaves) atomicAdd(L.gb + c, pgs[m.pg[i] * 64 + c]);
+        for (int c = tid; c < L.out; c += 64 * kBwdWaves) atomicAdd(L.gb + c, psum(m.pg[i], c));
     } else {
       for (int c = tid; c < L.in; c += 64 * kBwdWaves) {
-        atomicAdd(L.gw + c, pgs[m.pg[i] * 64 + c]);
-        atomicAdd(L.gb + c, pgs[(m.pg[i] + 1) * 64 + c]);
+        atomicAdd(L.gw + c, psum(m.pg[i], c));
+        atomicAdd(L.gb + c, psum(m.pg[i] + 1, c));
       }
     }
   }
 }
 
-// LDS of the backward kernel: parameters | shared accumulator blocks | shared per-channel sums | two half tiles per wavefront
-inline long mm_bwd_lds_bytes(const MArgs& m, int waves) { return 4L * (m.bwd_floats + m.nacc * 1024 + m.npg * 64 + waves * 2 * 32 * kTh); }
-inline int mm_bwd_waves(const MArgs& m) {
-  for (int w = 8; w >= 4; w -= 2)
-    if (mm_bwd_lds_bytes(m, w) <= 158 * 1024) return w;
-  return 0;
+// LDS of the backward kernel: parameters | per-channel sums and a tile area per wavefront (the accumulator blocks reuse the tile
+// region at the end)
+inline long mm_bwd_lds_bytes(const MArgs& m) {
+  const long tiles = (long)kBwdWaves * kTileF, accs = (long)m.nacc * 1024;
+  return 4L * (m.bwd_floats + kBwdWaves * m.npg * 64 + (tiles > accs ? tiles : accs));
 }
 
 // LDS plan of a chain for the MFMA kernels; false: not eligible
 inline bool mm_plan(MArgs& m) {
   const Args& a = m.a;
-  int f = 0, b = 0, nacc = 0, npg = 0;
+  int f = 0, b = 0, nacc = 0, npg = 0, nlin = 0;
   for (int i = 0; i < a.n; ++i) {
     const Layer& L = a.L[i];
     if (L.in > 32 * kMB || L.out > 32 * kMB) return false;
@@ -418,6 +472,7 @@ inline bool mm_plan(MArgs& m) {
       m.wt[i] = b; if (i > 0) b += nbo * nbi * 1024;
       m.accb[i] = nacc; nacc += nbo * nbi;
       m.pg[i] = npg; npg += 1;
+      ++nlin;
     } else {
       m.wf[i] = f; f += 2 * nbi * 32;
       m.wt[i] = b; b += nbi * 32;
@@ -425,10 +480,10 @@ inline bool mm_plan(MArgs& m) {
       m.pg[i] = npg; npg += 2;
     }
   }
-  m.fwd_floats = f; m.bwd_floats = b; m.nacc = nacc; m.npg = npg;
+  m.fwd_floats = f; m.bwd_floats = b; m.nacc = nacc; m.npg = npg; m.nlin = nlin;
   if (nacc > kMaxAcc) return false;
   const long fwd_bytes = 4L * f;
-  return fwd_bytes <= 150 * 1024 && mm_bwd_waves(m) > 0;
+  return fwd_bytes <= 150 * 1024 && nlin <= kMaxLin && mm_bwd_lds_bytes(m) <= 158 * 1024;
 }
 
 }  // namespace

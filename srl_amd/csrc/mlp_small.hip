@@ -365,17 +365,16 @@ extern "C" int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, con
   MArgs m{};
   m.a = a;
   if (rows >= mfma_min_rows() && mm_plan(m)) {
-    const int waves = mm_bwd_waves(m);
-    const long groups = srl_ceil_div(rows, 32L * waves);
-    const int lds = (int)mm_bwd_lds_bytes(m, waves);
-    const unsigned grid = (unsigned)(groups < 256 ? groups : 256);
-    auto go = [&](auto kern) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), lds, (hipStream_t)stream, m);
-    };
-    if (waves == 8) go(mlp_bwd_mfma_kernel<8>);
-    else if (waves == 6) go(mlp_bwd_mfma_kernel<6>);
-    else go(mlp_bwd_mfma_kernel<4>);
+    static const int dbg = [] { const char* e = getenv("SRL_MLP_DBG"); return e ? atoi(e) : 0; }();
+    m.dbg = dbg;
+    const long groups = srl_ceil_div(rows, 32L * kBwdWaves);
+    const int lds = (int)mm_bwd_lds_bytes(m);
+    static int attr = 0;
+    if (lds > attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr = lds;
+    }
+    hipLaunchKernelGGL(mlp_bwd_mfma_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(64 * kBwdWaves), lds, (hipStream_t)stream, m);
     SRL_LAUNCH_CHECK();
     return 0;
   }

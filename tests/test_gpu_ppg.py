@@ -151,9 +151,10 @@ def test_mappg_step_flow_cache_and_checkpoint():
     r_ppg = ppg.step(s0)
     r_ppo = ppo.step(synthetic.to_sample_batch(synthetic.make_sample_arrays(seed=1, **skw)))
     for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
-        assert r_ppg.stats[f"ppo_{k}"] == r_ppo.stats[k], k
+        assert abs(r_ppg.stats[f"ppo_{k}"] - r_ppo.stats[k]) <= 1e-6 * max(abs(r_ppo.stats[k]), 1e-2), k
     a, b = ppg.policy.get_checkpoint()["state_dict"], ppo.policy.get_checkpoint()["state_dict"]
-    assert all(torch.equal(a[k], b[k]) for k in a)
+    # (the fused chains sum their parameter gradients with float atomics: equal to summation order, not bitwise)
+    assert all(torch.allclose(a[k].double(), b[k].double(), rtol=0, atol=1e-6) for k in a)
     assert len(ppg._cache) == 1 and "ppg_policy_distance" not in r_ppg.stats and ppg.policy.version == 1
     aux_head0 = a["auxiliary_value_head.weight"].clone()
     r2 = ppg.step(synthetic.to_sample_batch(synthetic.make_sample_arrays(seed=2, **skw)))
