@@ -147,7 +147,7 @@ def gae_microbench(sample, targs, device, reps=200, big_B=None):
     return dict(ms=a.elapsed_time(b) / reps, work=19.0 * T * B + 7.0 * B)
 
 
-def mlp_roofline(device, T=128, B=4096, steps=10):
+def mlp_roofline(device, T=128, B=4096, steps=10, trainer_args=None):
     """The MLP the north star names, at the metric's batch: BASELINE configs[0]'s separate actor / critic 2 x 64 nets
     (102.5 kFLOP per sample and epoch, forward + backward) over 4096 envs x 128 steps through the same trainer --
     GAE scan, loss, optimiser included in the time, so the fraction is a floor for the contractions alone."""
@@ -156,7 +156,7 @@ def mlp_roofline(device, T=128, B=4096, steps=10):
     from srl_amd.runtime import synthetic
     pol = dict(obs_dim=4, action_dim=2, hidden_dim=64, num_dense_layers=2, num_rnn_layers=0, popart=False, layernorm=False,
                shared_backbone=False, seed=1)
-    tr = trainer_api.make(config.Trainer("mappo", args=dict(popart=False, optimizer_config=dict(lr=3e-4))),
+    tr = trainer_api.make(config.Trainer("mappo", args=dict(popart=False, optimizer_config=dict(lr=3e-4), **(trainer_args or {}))),
                           config.Policy("actor-critic-separate", args=pol))
     arrays = synthetic.make_sample_arrays(seed=0, T=T, B=B, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05)
     sample = synthetic.to_sample_batch({k: torch.from_numpy(v).to(device) for k, v in arrays.items()})

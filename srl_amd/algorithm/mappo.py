@@ -261,11 +261,13 @@ class MultiAgentPPO(PytorchTrainer):
         self._opt_steps = 0
         self.frames = 0
         # rows (env-steps) per forward/backward chunk: bounds the activation workspace, not the arithmetic.  Default: 16 384 for
-        # nets with a convolution / pooling encoder (26 KB of taped activations per frame); 131 072 for vector-observation nets,
-        # whose tape is a few hundred bytes per row and whose fused chains (csrc/mlp_mfma.h) only fill the chip from ~64 K rows
+        # nets with a convolution / pooling encoder (26 KB of taped activations per frame); 2^20 for vector-observation nets,
+        # whose tape is a few hundred bytes per row (1 GB at that size) and whose fused chains (csrc/mlp_mfma.h) pay their
+        # per-workgroup parameter staging and gradient fold once per launch (the C1-shaped update at 4096 x 128: 3.08 ms in four
+        # chunks of 131 072 on four pipelines, 2.69 ms in one)
         convolutional = any(not isinstance(L, (ns.LinearSpec, ns.LayerNormSpec)) for enc in
                             list(net.spec.obs_encoders) + list(net.spec.state_encoders or []) for L in enc.layers)
-        self.chunk_rows = int(g("chunk_rows", 16384 if convolutional else 131072))
+        self.chunk_rows = int(g("chunk_rows", 16384 if convolutional else 1 << 20))
         self._world = 1
         self._dist = False
         # capture the device part of a step into a hipGraph per sample signature and replay it (launch-bound small

@@ -284,16 +284,24 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
   for (long tile0 = (long)blockIdx.x * kBwdWaves; tile0 < ntiles; tile0 += (long)gridDim.x * kBwdWaves) {
     const long row = (tile0 + wave) * 32 + r;   // (a tile beyond the rows: zeros all the way, its wavefront keeps the barriers' count)
     const bool rok = row < a.rows;
-    float d[kMB][16], xin[kMB][16];
+    float d[kMB][16], xin[kMB][16], xnext[kMB][16];
     {
       const Layer& last = a.L[a.n - 1];
       mm_load(a.dy, a.lddy, row, rok, last.kind == 1 ? last.out : last.in, hb, d);
+      if (a.n == 1) mm_load(a.x, a.ldx, row, rok, last.in, hb, xnext);
+      else mm_load(a.tape + last.toff, a.tld, row, rok, last.in, hb, xnext);
     }
     int lin = m.nlin;
     for (int i = a.n - 1; i >= 0; --i) {
       const Layer L = a.L[i];
-      if (i == 0) mm_load(a.x, a.ldx, row, rok, L.in, hb, xin);
-      else mm_load(a.tape + L.toff, a.tld, row, rok, L.in, hb, xin);
+      // this layer's input was requested one layer earlier; the next layer's goes out now, under this layer's arithmetic (one
+      // wavefront per SIMD: nobody else hides a 2 us miss)
+#pragma unroll
+      for (int ib = 0; ib < kMB; ++ib)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xin[ib][e] = xnext[ib][e];
+      if (i == 1) mm_load(a.x, a.ldx, row, rok, a.L[0].in, hb, xnext);
+      else if (i > 1) mm_load(a.tape + a.L[i - 1].toff, a.tld, row, rok, a.L[i - 1].in, hb, xnext);
       // the activation that produced this input: its derivative (from the input's value) closes the data gradient
       const int pact = (i > 0 && a.L[i - 1].kind == 1) ? a.L[i - 1].act : 0;
       if (L.kind == 1) {

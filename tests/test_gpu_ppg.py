@@ -148,6 +148,7 @@ def test_mappg_step_flow_cache_and_checkpoint():
     ppo = trainer_api.make(config.Trainer("mappo", args=dict(popart=True, ppo_epochs=2, max_grad_norm=5.0, optimizer_config=dict(lr=1e-3))),
                            config.Policy("actor-critic-auxiliary", args=pargs))
     s0 = synthetic.to_sample_batch(synthetic.make_sample_arrays(seed=1, **skw))
+    v0 = ppg.policy.version
     r_ppg = ppg.step(s0)
     r_ppo = ppo.step(synthetic.to_sample_batch(synthetic.make_sample_arrays(seed=1, **skw)))
     for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
@@ -155,11 +156,11 @@ def test_mappg_step_flow_cache_and_checkpoint():
     a, b = ppg.policy.get_checkpoint()["state_dict"], ppo.policy.get_checkpoint()["state_dict"]
     # (the fused chains sum their parameter gradients with float atomics: equal to summation order, not bitwise)
     assert all(torch.allclose(a[k].double(), b[k].double(), rtol=0, atol=1e-6) for k in a)
-    assert len(ppg._cache) == 1 and "ppg_policy_distance" not in r_ppg.stats and ppg.policy.version == 1
+    assert len(ppg._cache) == 1 and "ppg_policy_distance" not in r_ppg.stats and ppg.policy.version == v0 + 1
     aux_head0 = a["auxiliary_value_head.weight"].clone()
     r2 = ppg.step(synthetic.to_sample_batch(synthetic.make_sample_arrays(seed=2, **skw)))
     assert len(ppg._cache) == 0 and ppg._aux_steps == 4   # 2 cached samples x 2 epochs
-    assert ppg.policy.version == 2 + 4                    # one per PPO step (:184... mappo.py:305-307 here), one per auxiliary epoch
+    assert ppg.policy.version == v0 + 2 + 4               # one per PPO step (:184... mappo.py:305-307 here), one per auxiliary epoch
     for k in ("ppg_auxiliary_value_loss", "ppg_value_head_loss", "ppg_policy_distance"):
         assert np.isfinite(r2.stats[k]) and r2.stats[k] >= 0, k
     c = ppg.policy.get_checkpoint()["state_dict"]
