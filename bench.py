@@ -822,6 +822,8 @@ def main():
     closed = None
     if fed is not None and not args.no_closed_loop and not use_dist:
         import threading
+        if os.environ.get("SRL_SWITCH_INTERVAL"):
+            sys.setswitchinterval(float(os.environ["SRL_SWITCH_INTERVAL"]))
         b0 = ring.get_device()  # one slot checked out and released (not recycled): the "next sample" slot
         nxt = b0.metadata["ring_slot"]
         ring.release(nxt)

@@ -83,6 +83,54 @@ __global__ __launch_bounds__(256) void skinny_n_kernel(const float* __restrict__
   }
 }
 
+// Short rows (K / 4 = KL lanes < 64; the 64-wide hidden layers of the multi-agent nets): with one wavefront per row 64 - KL lanes
+// idle and every output costs six shuffle steps -- 455 us for a 307 200 x 64 -> 9 head (SMAC, full size) whose bytes take 16.
+// Here a wavefront carries 64 / KL rows side by side (lane = row slot x KL + float4 column), RPW such groups in flight, and the
+// sums close inside aligned groups of KL lanes (log2 KL shuffle steps).  Needs N <= KL (lane kk of a row's group keeps output kk).
+template <int NB, int KL>
+__global__ __launch_bounds__(256) void skinny_n_short_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
+                                                             long ldb, float* __restrict__ C, long ldc,
+                                                             const float* __restrict__ bias, long M, int N, int act, int accumulate) {
+  extern __shared__ float4 bs[];  // [N][KL]
+  for (int e = threadIdx.x; e < N * KL; e += 256) {
+    const int n = e / KL, k4 = e - n * KL;
+    bs[e] = *reinterpret_cast<const float4*>(B + (long)n * ldb + 4 * k4);
+  }
+  __syncthreads();
+  constexpr int G = 64 / KL, RPW = 4;
+  const int lane = threadIdx.x & 63, g = lane / KL, kk = lane % KL;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  for (long row0 = wave * (RPW * G); row0 < M; row0 += nwaves * (RPW * G)) {
+    float4 a[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const long row = row0 + r * G + g < M ? row0 + r * G + g : M - 1;
+      a[r] = reinterpret_cast<const float4*>(A + row * lda)[kk];
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      float v = 0.f;
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+        if (n < N) {
+          float s = dot4(a[r], bs[n * KL + kk]);
+          asm volatile("" : "+v"(s));  // (scalar accumulators: see skinny_n_kernel)
+#pragma unroll
+          for (int off = KL / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+          if (kk == n) v = s;
+        }
+      const long row = row0 + r * G + g;
+      if (kk < N && row < M) {
+        if (bias) v += bias[kk];
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = tanhf(v);
+        float* c = C + row * ldc + kk;
+        *c = accumulate ? *c + v : v;
+      }
+    }
+  }
+}
+
 // A workgroup owns 16 consecutive columns of B / C (four float4 column-threads x 64 row-lanes) and a slab of k rows:
 // a wavefront reads 64-byte row segments of B, the 64 row-lanes combine through LDS and four threads send the
 // workgroup's M x 16 partial sums as atomics (a split over rows only would end in M x N atomics per workgroup, which is
@@ -206,7 +254,16 @@ inline int try_skinny(hipStream_t st, const srl_gemm_desc* d) {
     long blocks = srl_ceil_div(M, 32L);  // every workgroup stages B once: few, fat workgroups
     if (blocks > 512) blocks = 512;
     const size_t lds = (size_t)N * K * 4;
-    if (N <= 8)
+    auto short_rows = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, d->A, d->lda, d->B, d->ldb, d->C, d->ldc, d->bias, M, (int)N,
+                         d->act, d->accumulate);
+    };
+    if (K == 64 && N <= 8) short_rows(skinny_n_short_kernel<8, 16>);
+    else if (K == 64) short_rows(skinny_n_short_kernel<16, 16>);
+    else if (K == 128 && N <= 8) short_rows(skinny_n_short_kernel<8, 32>);
+    else if (K == 128) short_rows(skinny_n_short_kernel<16, 32>);
+    else if (K == 32 && N <= 8) short_rows(skinny_n_short_kernel<8, 8>);
+    else if (N <= 8)
       hipLaunchKernelGGL(skinny_n_kernel<8>, dim3((unsigned)blocks), dim3(256), lds, st, d->A, d->lda, d->B, d->ldb, d->C,
                          d->ldc, d->bias, M, (int)N, (int)K, d->act, d->accumulate);
     else
