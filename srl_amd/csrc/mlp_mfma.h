@@ -35,7 +35,7 @@ struct MArgs {
   int accb[SRL_MLP_MAX_LAYERS];  // backward: first accumulator block of a Linear
   int pg[SRL_MLP_MAX_LAYERS];    // backward: offset of the layer's per-lane sums (Linear: bias gradient; LayerNorm: dgamma | dbeta)
   int fwd_floats, bwd_floats, nacc, npg, nlin;
-  int dbg;   // timing experiments (wrong results; SRL_MLP_DBG): 2 no weight-gradient blocks, 4 no data gradient, 8 no final global adds
+  int dbg;   // timing experiments (wrong results; SRL_MLP_DBG): 2 no weight-gradient blocks, 4 no data gradient, 8 no final global adds, 16 no column sums, 32 no parameter staging, 64 no global loads
 };
 
 __device__ __forceinline__ int mm_ch(int e, int hb) { return (e & 3) + 8 * (e >> 2) + 4 * hb; }
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
   float* const pgs = sm + m.bwd_floats + wave * (m.npg * 64);
   float* const tiles = sm + m.bwd_floats + kBwdWaves * (m.npg * 64);
   float* const myT = tiles + wave * kTileF;
-  mm_stage(m, sm, tid, true, 64 * kBwdWaves);
+  if (!(m.dbg & 32)) mm_stage(m, sm, tid, true, 64 * kBwdWaves);
   for (int e = lane; e < m.npg * 64; e += 64) pgs[e] = 0.f;
   __syncthreads();
   f32x16 W0, W1, W2, W3;   // this wavefront's block of the chain's 1st .. 4th Linear layer (counted from the input side)
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
   const long ntiles = (a.rows + 31) / 32;
   for (long tile0 = (long)blockIdx.x * kBwdWaves; tile0 < ntiles; tile0 += (long)gridDim.x * kBwdWaves) {
     const long row = (tile0 + wave) * 32 + r;   // (a tile beyond the rows: zeros all the way, its wavefront keeps the barriers' count)
-    const bool rok = row < a.rows;
+    const bool rok = row < a.rows && !(m.dbg & 64);
     float d[kMB][16], xin[kMB][16], xnext[kMB][16];
     {
       const Layer& last = a.L[a.n - 1];
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
         for (int ob = 0; ob < kMB; ++ob)
           if (ob < nbo) {
             mm_half_write(myT + ob * 32 * kTh, r, hb, d[ob]);
-            if (L.gb) mm_half_colsum(myT + ob * 32 * kTh, pgs + m.pg[i] * 64 + 32 * ob, lane);  // bias gradient: column sums of dz
+            if (L.gb && !(m.dbg & 16)) mm_half_colsum(myT + ob * 32 * kTh, pgs + m.pg[i] * 64 + 32 * ob, lane);  // bias gradient: column sums of dz
           }
 #pragma unroll
         for (int ib = 0; ib < kMB; ++ib)
