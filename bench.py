@@ -496,7 +496,7 @@ def main():
     ap.add_argument("--no-from-host", action="store_true",
                     help="skip the pinned-host-fed passes: `value` is then the resident-in-HBM figure")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the rollout-beside-update leg (`closed_loop`)")
-    ap.add_argument("--rollout-groups", type=int, default=1,
+    ap.add_argument("--rollout-groups", type=int, default=2,
                     help="closed loop: inference policies (policy workers) sharing the observation ring, each serving B / groups environments")
     ap.add_argument("--no-plain-copy", action="store_true", help="skip the pass without the observation ring (`from_pinned_host`)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank")
@@ -828,11 +828,11 @@ def main():
         nxt = b0.metadata["ring_slot"]
         ring.release(nxt)
         del b0
-        # The rollout side as the reference runs it: SEVERAL policy workers, each serving its share of the actors
-        # (distributed/system/policy_worker.py:162-242; the actors' env ring, actor_worker.py:634-748, keeps one group's environments
-        # stepping while another group's requests are in flight).  Here: `groups` inference policies (same parameters, own executor
-        # and stream, ONE shared observation ring), each walking its own columns tick by tick in its own thread: one group's H2D of
-        # planes and D2H of results cross the link while another group's kernels run.
+        # The rollout side as the reference runs it: the actors' environments in GROUPS (the env ring, actor_worker.py:634-748: one
+        # group steps while another group's inference requests are in flight), served by `groups` inference policies (same
+        # parameters, own executor and stream, ONE shared observation ring) from one host thread through `rollout_async`: one
+        # group's H2D of planes and D2H of results cross the link while another group's kernels run.  (Two THREADS calling the
+        # synchronous `rollout` made it slower, 209 -> 248 ms per iteration: the host side of a tick is what it is, twice.)
         G = max(1, int(args.rollout_groups))
         while B % G:
             G -= 1
@@ -841,27 +841,33 @@ def main():
         gcols = [(g * (B // G), (g + 1) * (B // G)) for g in range(G)]
         state = dict(prev=[last_stamps[c0:c1] for c0, c1 in gcols], err=None, roll_s=[])
 
-        def produce_group(g, out):
-            try:
-                with torch.cuda.stream(roll_streams[g]):
-                    out[g], _, state["prev"][g] = rollout_phase(infers[g], True, prev=state["prev"][g], cols=gcols[g])
-            except BaseException as e:  # surfaced by the main thread
-                state["err"] = e
+        def rollout_phase_groups(prevs):
+            """Tb ticks of G groups from ONE host thread: a group's tick t + 1 is issued (`rollout_async`: H2D of its planes, network
+            pass, sampling, D2H of the results -- all enqueued on the group's stream) as soon as its tick t has come back, while the
+            other groups' ticks are in flight.  Returns (stamps [Tb, B, 1], last stamps per group)."""
+            stamps = np.empty((Tb, B, 1), np.int64)
+            pending = [None] * G
+            prevs = list(prevs)
+            for t in range(Tb + 1):
+                for g in range(G):
+                    c0, c1 = gcols[g]
+                    if pending[g] is not None:
+                        resp = pending[g].result()
+                        stamps[t - 1, c0:c1] = prevs[g] = resp.analyzed_result.obs_ref
+                        pending[g] = None
+                    if t < Tb:
+                        prev = np.where(fresh[t][c0:c1, None], 0, prevs[g])
+                        with torch.cuda.stream(roll_streams[g]):
+                            pending[g] = infers[g].rollout_async(request(NamedArray(obs=planes[t][c0:c1], ring_prev=prev), c1 - c0))
+            return stamps, prevs
 
         def produce(slot):
             try:
                 t0 = time.perf_counter()
-                out = [None] * G
-                ths = [threading.Thread(target=produce_group, args=(g, out)) for g in range(1, G)]
-                for th_ in ths:
-                    th_.start()
-                produce_group(0, out)
-                for th_ in ths:
-                    th_.join()
+                st, state["prev"] = rollout_phase_groups(state["prev"])
                 state["roll_s"].append(time.perf_counter() - t0)
-                if state["err"] is None:
-                    ring.host_blocks(slot)["analyzed_result.obs_ref"][...] = np.concatenate(out, axis=1)
-                    ring.recycle(slot)  # complete: every column of the slot carries the new stamps
+                ring.host_blocks(slot)["analyzed_result.obs_ref"][...] = st
+                ring.recycle(slot)  # complete: every column of the slot carries the new stamps
             except BaseException as e:  # surfaced by the main thread
                 state["err"] = e
 
@@ -888,8 +894,9 @@ def main():
                       note="one iteration = the update on sample k (ring-fed, as the headline) with the whole rollout phase of sample "
                            "k+1 (Tb stack-aware inference batches from pinned host memory, results back to the host) running beside "
                            "it on the same GPU; every sample is trained on with the stamps of its own rollout phase.  The rollout side "
-                           f"is {G} inference policies (policy workers), each serving {B // G} of the environments on its own stream "
-                           "and thread into the one shared observation ring, so that one group's link transfers overlap another's kernels")
+                           f"is {G} group(s) of {B // G} environments, each with its inference policy and stream on the one shared "
+                           "observation ring, issued from one host thread (rollout_async): a group's link transfers run under the "
+                           "other groups' kernels")
         ring.recycle(nxt)
 
     if rank == 0:

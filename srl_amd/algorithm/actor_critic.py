@@ -75,6 +75,28 @@ def wire_leaf(x, kind: str):
     return np.ascontiguousarray(a, dtype=want)
 
 
+class PendingRollout:
+    """An issued ``rollout`` (``ActorCriticPolicy.rollout_async``): ``result()`` waits for its stream position and returns the
+    ``RolloutResult`` (numpy leaves, copied out of the policy's pinned blocks, which the next call reuses)."""
+
+    def __init__(self, policy, views, done, refs, state, n):
+        self._policy, self._views, self._done, self._refs, self._state, self._n = policy, views, done, refs, state, n
+
+    def result(self) -> policy_api.RolloutResult:
+        if self._policy is None:
+            raise RuntimeError("PendingRollout.result() was already taken")
+        pol, self._policy = self._policy, None
+        try:
+            self._done.synchronize()
+            h_action, h_logp, h_value = [v.numpy().copy() for v in self._views]
+        finally:
+            pol._net._serving[0] -= 1
+            pol._pending_rollout = False
+        refs = self._refs
+        analyzed = PPORolloutAnalyzedResult(log_probs=h_logp, value=h_value, obs_ref=None if refs is None else refs.reshape(self._n, 1))
+        return policy_api.RolloutResult(action=DiscreteAction(h_action), analyzed_result=analyzed, policy_state=self._state)
+
+
 class ActorCriticPolicy(policy_api.Policy):
 
     def __init__(self,
@@ -269,14 +291,27 @@ class ActorCriticPolicy(policy_api.Policy):
     ROLLOUT_PIECE = int(os.environ.get('SRL_ROLLOUT_PIECE', '2048'))  # rows per piece when a big host batch is streamed in (copy of piece i+1 under the compute of i)
 
     def rollout(self, requests: policy_api.RolloutRequest, **kwargs) -> policy_api.RolloutResult:
+        return self.rollout_async(requests, **kwargs).result()
+
+    def rollout_async(self, requests: policy_api.RolloutRequest, **kwargs) -> "PendingRollout":
+        """``rollout`` in two halves: everything is ISSUED on the current stream here -- the requests' H2D copies, the network pass,
+        the sampling, the results' D2H copies into pinned blocks -- and ``PendingRollout.result()`` waits for that stream position
+        and builds the ``RolloutResult``.  A policy worker that serves two groups of actors through two policies (one per stream,
+        one shared observation ring) keeps one group's link transfers under the other's kernels from ONE host thread: the reference's
+        actors do the same with their environment ring (actor_worker.py:634-748).  One call in flight per policy."""
         hip.require_gpu()
+        if self.__dict__.get("_pending_rollout"):
+            raise RuntimeError("rollout_async: the previous call's result() has not been taken (one call in flight per policy)")
         self._net._serving[0] += 1   # what the executor derives from the parameters survives from one request batch to the next
         try:
-            return self._rollout(requests, **kwargs)
-        finally:
+            pend = self._rollout(requests, **kwargs)
+        except BaseException:
             self._net._serving[0] -= 1
+            raise
+        self._pending_rollout = True
+        return pend
 
-    def _rollout(self, requests: policy_api.RolloutRequest, **kwargs) -> policy_api.RolloutResult:
+    def _rollout(self, requests: policy_api.RolloutRequest, **kwargs) -> "PendingRollout":
         host = {k: v for k, v in requests.obs.items() if v is not None}
         n = int(next(iter(host.values())).shape[0])
         # Stack-aware requests (atari_wrappers.py:211-242 `FrameStack`): `ring_prev` [n, 1] int64 holds the observation-ring
@@ -304,13 +339,12 @@ class ActorCriticPolicy(policy_api.Policy):
                 state = {k: np.asarray(ps[k]) for k, _ in self._state_keys()}
             action, logp, value, refs = self._rollout_rows(obs, n, requests.is_evaluation, state, prev=prev)
             state = self._packed_last_state()
-        h_action, h_logp, h_value = self._results_to_host(action, logp, value)
-        analyzed = PPORolloutAnalyzedResult(log_probs=h_logp, value=h_value, obs_ref=None if refs is None else refs.reshape(n, 1))
-        return policy_api.RolloutResult(action=DiscreteAction(h_action), analyzed_result=analyzed, policy_state=state)
+        views, done = self._results_to_host_async(action, logp, value)
+        return PendingRollout(self, views, done, refs, state, n)
 
-    def _results_to_host(self, *tensors):
-        """Device results -> numpy: asynchronous copies into pinned blocks kept per policy, ONE stream synchronisation for all of
-        them (three `.cpu()` calls are three synchronisations through pageable staging)."""
+    def _results_to_host_async(self, *tensors):
+        """Device results -> pinned blocks kept per policy: asynchronous copies and ONE event behind them (three `.cpu()` calls are
+        three synchronisations through pageable staging)."""
         pins = self.__dict__.setdefault("_result_pins", {})
         out = []
         for i, t in enumerate(tensors):
@@ -321,8 +355,9 @@ class ActorCriticPolicy(policy_api.Policy):
             view = pin[:t.numel()].view(t.shape)
             view.copy_(t, non_blocking=True)
             out.append(view)
-        torch.cuda.current_stream().synchronize()
-        return [v.numpy().copy() for v in out]
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream())
+        return out, done
 
     def _rollout_streamed(self, host, n, is_evaluation, prev=None):
         """A big batch of host observations (the policy worker's 10 240-request batches are 289 MB of frames): rows

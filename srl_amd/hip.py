@@ -247,7 +247,15 @@ def require_gpu():
         raise HipError("no MI355X / ROCm device visible: the hot path has no CPU fallback")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """The current HIP stream of the current device, as the integer the C ABI takes.  (Through torch's C entry points: the Python
+    route -- torch.cuda.current_stream().cuda_stream -- costs ~8 us, eleven times per rollout call and ~550 times per update.)"""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
