@@ -128,7 +128,7 @@ def test_aux_loss_kernel_vs_oracle(n, heads, vd, mask):
                              pred.detach().to(dev), tgt.to(dev), done.reshape(n).to(dev), count[0:1], beta, vhw, d_logits, d_aux, d_pred, out)
     got = out.cpu().numpy()
     for i, k in enumerate(("auxiliary_value_loss", "value_head_loss", "policy_distance")):
-        assert abs(got[i] - float(terms[k])) <= 1e-5 * max(abs(float(terms[k])), 1e-3), (k, got[i], float(terms[k]))
+        assert abs(got[i] - float(terms[k].detach())) <= 1e-5 * max(abs(float(terms[k].detach())), 1e-3), (k, got[i], float(terms[k].detach()))
     for name, g_dev, g_ref in (("logits", d_logits, z_new.grad), ("aux", d_aux, aux.grad), ("pred", d_pred, pred.grad)):
         scale = float(g_ref.abs().max())
         assert float((g_dev.cpu() - g_ref).abs().max()) <= 1e-5 * max(scale, 1e-8), (name, float((g_dev.cpu() - g_ref).abs().max()), scale)
