@@ -397,8 +397,13 @@ def cpu_baseline(T):
     torch.set_num_threads(cores)
     med, mn = float(np.median(t_all)), float(min(t_all))
     med1, mn1 = float(np.median(t_one)), float(min(t_one))
+    every = dict(sweep, **{str(cores): round(T * B_all / med, 1)})
+    best_threads = max(every, key=every.get)
     return dict(value=T * B_all / med, unit="env-steps/s", cores=cores, kind="port", best=T * B_all / mn,
                 logical_cpus=logical, other_thread_counts=sweep,
+                best_thread_count=dict(threads=int(best_threads), value=every[best_threads],
+                                       note="torch-CPU does not scale to every core of this host on this step: the thread count of the "
+                                            "sweep (16 / 32 / 64 / all physical cores) that did best, same sample"),
                 one_thread=dict(value=T * B_one / med1, best=T * B_one / mn1, cores=1,
                                 sample=f"{T}x{B_one} env-steps, {len(t_one)} timed steps, median {med1:.3f} s, min {mn1:.3f} s"),
                 sample=f"{T}x{B_all} env-steps (B reduced from {GLOBAL_ENVS}: the path is row-independent, cost linear "

@@ -1,8 +1,9 @@
 """DESIGN.md Â§4's per-launch table from the newest recording under profiles/ (kernel stats, HBM traffic, SQ counters):
-python scripts/design_table.py [version, default 5]"""
+python scripts/design_table.py [round, default 05] [version, default 1]"""
 import csv, os, sys
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-v = sys.argv[1] if len(sys.argv) > 1 else "5"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "05"
+v = sys.argv[2] if len(sys.argv) > 2 else "1"
 
 
 def col(path, key, sub, field):
@@ -29,9 +30,9 @@ print("| launch (kernel) | flops | MFMA floor | bytes | HBM floor | measured | Ã
 print("|---|---|---|---|---|---|---|---|---|---|")
 total = 0.0
 for label, sub, gf, pp, mb in ROWS:
-    k, ns = col(f"r04_bench_kernel_stats_v{v}.csv", "Name", sub, "AverageNs")
-    t, _ = col(f"r04_hbm_traffic_v{v}.csv", "kernel", sub, None)
-    c, _ = col(f"r04_sq_counters_v{v}.csv", "kernel", sub, None)
+    k, ns = col(f"r{rnd}_bench_kernel_stats_v{v}.csv", "Name", sub, "AverageNs")
+    t, _ = col(f"r{rnd}_hbm_traffic_v{v}.csv", "kernel", sub, None)
+    c, _ = col(f"r{rnd}_sq_counters_v{v}.csv", "kernel", sub, None)
     us = ns / 1e3
     mf, hf = gf * pp / 2.5, mb / 8.0   # us: G flops x products / 2.5 PFLOP/s; MB / 8 TB/s
     traffic = (float(t["FETCH_bytes_per_launch_corrected_x2"]) + float(t["WRITE_bytes_per_launch"])) / 1e6
@@ -40,3 +41,10 @@ for label, sub, gf, pp, mb in ROWS:
     print(f"| {label} | {gf} G | {mf:.0f} Âµs{' (Ã—2)' if pp == 2 else ''} | {mb} MB | {hf:.0f} Âµs | {us:.0f} Âµs{extra} | {us / max(mf, hf):.1f} | "
           f"{traffic:.0f} MB | {float(c['mfma_busy']):.2f} | {float(c['valu_busy']):.2f} |")
 print(f"\nsum of the eleven launches: {total / 1e3:.2f} ms per chunk = {total * 32 / 1e3:.1f} ms per update")
+alg = sum(r[4] for r in ROWS)
+tr = 0.0
+for label, sub, gf, pp, mb in ROWS:
+    t, _ = col(f"r{rnd}_hbm_traffic_v{v}.csv", "kernel", sub, None)
+    tr += (float(t["FETCH_bytes_per_launch_corrected_x2"]) + float(t["WRITE_bytes_per_launch"])) / 1e6
+print(f"algorithmic bytes of the eleven launches: {alg / 1e3:.2f} GB per chunk = {alg * 32 / 1e3:.0f} GB per update; counted traffic {tr / 1e3:.2f} GB per chunk = "
+      f"{tr * 32 / 1e3:.0f} GB per update = {tr / alg:.2f} x")
