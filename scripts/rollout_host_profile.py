@@ -35,5 +35,5 @@ for t in range(40):
     issue.append(t1 - t0); total.append(t2 - t0)
 print(f"n={n}: issue (host only) {1e3 * np.median(issue):.3f} ms, whole tick {1e3 * np.median(total):.3f} ms")
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22)
-print(s.getvalue()[-5200:])
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
+print(s.getvalue()[-9500:])

@@ -326,6 +326,8 @@ def f16x2_enabled() -> bool:
 class _scope:
 
     def __init__(self, name, work=0.0, kind="x3"):
+        if _prof is None:   # (the common case: no environment look-ups, nothing kept, on ~550 launches per update)
+            return
         self.name, self.work, self.executed = name, work, work * piece_products(kind) if work else 0.0
 
     def __enter__(self):
