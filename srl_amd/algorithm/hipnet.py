@@ -126,6 +126,7 @@ class HipNet:
         # small MLP chains (every layer LayerNorm / Linear, no wider than 128) in one launch per direction (csrc/mlp_small.hip);
         # SRL_MLP_FUSED=0: layer by layer (A/B)
         self._mlp_fused = os.environ.get("SRL_MLP_FUSED", "1") != "0"
+        self._enc_fused = os.environ.get("SRL_ENC_FUSED", "1") != "0"
         self._mlp_cache = {}
         self._pver = [0]    # parameter version, shared with the twins (a list: one object)
         self._in_update = [False]
@@ -656,6 +657,16 @@ class HipNet:
                 staged = obs  # already in the first convolution's layout, statistics beside them
             else:
                 obs = obs.gather_raw(self.ws, f"{tag}{enc.key}.ring")
+        # a vector encoder in front of a recurrent backbone (the multi-agent nets: LayerNorm -> Linear -> LayerNorm -> Linear ->
+        # LayerNorm, 64 wide) as ONE launch per direction: the whole-trunk fusion above stops at the recurrent cell, and layer by
+        # layer these 307 200-row products and LayerNorms were ~2 ms of the SMAC-sized step (SRL_ENC_FUSED=0: layer by layer, A/B)
+        if (self._mlp_fused and self._enc_fused and staged is None and isinstance(obs, torch.Tensor) and obs.dim() == 2
+                and obs.dtype == torch.float32 and enc.layers and all(isinstance(L, (ns.LayerNormSpec, ns.LinearSpec)) for L in enc.layers)
+                and (isinstance(enc.layers[-1], ns.LayerNormSpec) or enc.layers[-1].act == 0) and n >= 512):
+            rec = self._fused_layers_fwd((tag, "enc", enc.key), f"{tag}enc.{enc.key}.", list(enc.layers), obs, n)
+            if rec is not None:
+                tape.append(("fusedenc", rec, None, None, 0))
+                return rec["feat"]
         h2 = self._h2_for(enc)
         skip = 0
         for L in enc.layers:
@@ -849,6 +860,10 @@ class HipNet:
                 g = self._linear_bwd(L, x, g, in_act, need_dx, tag, x_range=x_range,
                                      dz_range=g_range if x_range is not None else None, dx_range=dx_range)
                 g_range = dx_range
+            elif kind == "fusedenc":
+                self._fused_bwd(L, g.ptr, g.ld)   # (releases its layers' buckets itself)
+                g, g_range = None, None
+                continue
             elif kind == "h2cnn":
                 L.backward(saved, g)
                 g, g_range = None, None
@@ -993,6 +1008,8 @@ class HipNet:
             return L.dim
         if kind == "h2cnn":
             return L.H
+        if kind == "fusedenc":
+            return L["feat"].cols
         if kind == "linear":
             return L.out_features
         if kind == "gru":
@@ -1080,6 +1097,10 @@ class HipNet:
         layers = list(enc.layers) + list(backbone) + ([head] if head is not None else [])
         if isinstance(x, RingObs) and x.layout[0] != "s2d" and x.rows == n:  # raw vector rows kept in the HBM observation ring
             x = x.gather_raw(self.ws, f"{tag}{enc.key}.ring")
+        return self._fused_layers_fwd((tag, head is not None), tag, layers, x, n, out, head is not None)
+
+    def _fused_layers_fwd(self, key, tag, layers, x, n: int, out: Optional[torch.Tensor] = None, head=False):
+        """``layers`` (LayerNorm / Linear, no wider than 128) on the float32 rows ``x`` [n, in] as one launch, or None."""
         if (not isinstance(x, torch.Tensor) or x.dtype != torch.float32 or x.dim() != 2 or x.shape[0] != n or
                 not x.is_contiguous() or not layers or len(layers) > hip.MLP_MAX_LAYERS):
             return None
@@ -1092,7 +1113,7 @@ class HipNet:
                 ok = False
             if not ok:
                 return None
-        key = (tag, head is not None, self.flat.data_ptr(), self.grad.data_ptr())
+        key = (*key, self.flat.data_ptr(), self.grad.data_ptr())
         ent = self._mlp_cache.get(key)
         if ent is None:
             desc = []
@@ -1116,7 +1137,7 @@ class HipNet:
         y = out if out is not None else self.ws.get(f"{tag}mlp.y", n * width)
         hip.mlp_fwd(arr, x.data_ptr(), x.shape[1], n, tape.data_ptr(), tld, y.data_ptr(), width)
         return dict(arr=arr, x=x, tape=tape, tld=tld, n=n, feat=Buf(y.data_ptr(), width, n, width), act=act,
-                    head=head is not None, prefixes=[L.prefix for L in layers])
+                    head=head, prefixes=[L.prefix for L in layers])
 
     def _fused_bwd(self, rec, dy_ptr: int, lddy: int):
         hip.mlp_bwd(rec["arr"], rec["x"].data_ptr(), rec["x"].shape[1], rec["n"], rec["tape"].data_ptr(), rec["tld"], dy_ptr, lddy)
