@@ -640,6 +640,11 @@ int srl_grad_sumsq(void* stream, const float* g, int64_t n, double* sumsq);
 /* dst[i] += src[i]: the flat gradients of two row-chunk pipelines that ran side by side (each accumulates into its own
  * buffer: loss.backward() of mappo.py:274 over the chunks of one batch) become one before clip + optimiser. */
 int srl_accumulate(void* stream, float* dst, const float* src, int64_t n);
+/* dst[i] += srcs[0][i] + ... + srcs[k-1][i], added left to right (ABI 15): the slices of ALL the other pipelines into the first
+ * buffer in ONE launch when a gradient bucket is folded (k launches before: with four pipelines three per bucket, each with its
+ * host latency in the tail of a data-parallel update).  srcs: HOST array of k <= SRL_ACCUMULATE_MAX device pointers. */
+#define SRL_ACCUMULATE_MAX 7
+int srl_accumulate_n(void* stream, float* dst, const float* const* srcs, int32_t k, int64_t n);
 /* Adam step with the clip coefficient min(1, max_norm / (sqrt(sumsq) + 1e-6)) applied to g on the
  * fly (max_norm < 0: no clipping; sumsq may then be NULL).  grad_scale multiplies g first
  * (1/world_size for the DDP mean).  step is the 1-based step count; weight_decay is decoupled

@@ -107,8 +107,7 @@ class _BucketReducer:
             if ev is not None:
                 self._fold_stream.wait_event(ev)
         with torch.cuda.stream(self._fold_stream):
-            for g in self.grads[1:]:
-                hip.accumulate(self.grads[0][lo:hi], g[lo:hi])
+            hip.accumulate_n(self.grads[0][lo:hi], [g[lo:hi] for g in self.grads[1:]])   # one launch, added in pipeline order
         self.stats["slices_folded"] += len(self.grads) - 1
 
     def _launch(self, i):
@@ -765,9 +764,9 @@ class MultiAgentPPO(PytorchTrainer):
             for x in nets:
                 x.last_chunk = None
             if two and reducer is None:
-                for twin, pst in zip(self._twin, self._pipe_stream):
+                for pst in self._pipe_stream:
                     streams[0].wait_stream(pst)
-                    hip.accumulate(net.grad, twin.grad)
+                hip.accumulate_n(net.grad, [twin.grad for twin in self._twin])   # one launch, added in pipeline order
 
             # ---- gradient reduction, clip, Adam (mappo.py:272-284) ---------------------------------------------------
             if reducer is not None:  # the buckets not yet launched (folding the pipelines' slices), then wait for all of them

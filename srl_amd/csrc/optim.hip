@@ -179,6 +179,18 @@ namespace {
 __global__ __launch_bounds__(256) void accumulate_kernel(float* dst, const float* src, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] += src[i];
 }
+struct AccSrcs {
+  const float* p[SRL_ACCUMULATE_MAX];
+  int k;
+};
+// dst += src_0 + src_1 + ... in that order (left to right: the same sums as k launches of accumulate_kernel)
+__global__ __launch_bounds__(256) void accumulate_n_kernel(float* dst, AccSrcs s, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = dst[i];
+    for (int j = 0; j < s.k; ++j) v += s.p[j][i];
+    dst[i] = v;
+  }
+}
 }  // namespace
 
 extern "C" int srl_accumulate(void* stream, float* dst, const float* src, int64_t n) {
@@ -187,6 +199,22 @@ extern "C" int srl_accumulate(void* stream, float* dst, const float* src, int64_
   SRL_CHECK_ARG(dst && src, "null tensor");
   const unsigned grid = (unsigned)(srl_ceil_div(n, 256) < 2048 ? srl_ceil_div(n, 256) : 2048);
   hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, src, (long)n);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srl_accumulate_n(void* stream, float* dst, const float* const* srcs, int32_t k, int64_t n) {
+  SRL_CHECK_ARG(n >= 0 && k >= 0 && k <= SRL_ACCUMULATE_MAX, "negative count / more sources than SRL_ACCUMULATE_MAX");
+  if (n == 0 || k == 0) return 0;
+  SRL_CHECK_ARG(dst && srcs, "null tensor");
+  AccSrcs s{};
+  s.k = k;
+  for (int j = 0; j < k; ++j) {
+    SRL_CHECK_ARG(srcs[j], "null source");
+    s.p[j] = srcs[j];
+  }
+  const unsigned grid = (unsigned)(srl_ceil_div(n, 256) < 2048 ? srl_ceil_div(n, 256) : 2048);
+  hipLaunchKernelGGL(accumulate_n_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, s, (long)n);
   SRL_LAUNCH_CHECK();
   return 0;
 }

@@ -168,6 +168,7 @@ _SIGNATURES = {
     "srl_ring_slots": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "srl_ring_stack_push": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "srl_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
+    "srl_accumulate_n": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_int32, c_int64]),
     "srl_grad_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                c_float, c_float, c_int, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p]),
@@ -705,6 +706,18 @@ def copy2d(src_ptr, lds, dst_ptr, ldd, rows, cols):
 def u8_to_f32(src, dst):
     _check(lib().srl_u8_to_f32(_stream(), _ptr(src, torch.uint8, "src"), _ptr(dst, torch.float32, "dst"), src.numel()),
            "srl_u8_to_f32")
+
+
+ACCUMULATE_MAX = 7
+
+
+def accumulate_n(dst, srcs):
+    """dst += srcs[0] + srcs[1] + ... (``srl_accumulate_n``: one launch, added left to right), float32 tensors of equal size."""
+    srcs = list(srcs)
+    while srcs:
+        part, srcs = srcs[:ACCUMULATE_MAX], srcs[ACCUMULATE_MAX:]
+        arr = (c_void_p * len(part))(*[_ptr(t, torch.float32, "src") for t in part])
+        _check(lib().srl_accumulate_n(_stream(), _ptr(dst, torch.float32, "dst"), arr, len(part), dst.numel()), "srl_accumulate_n")
 
 
 def accumulate(dst, src):
