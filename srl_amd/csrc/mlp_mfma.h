@@ -266,6 +266,13 @@ __device__ __forceinline__ void mm_wgrad_tile(f32x16& acc, const float* dH, cons
   for (int mm = 0; mm < 16; ++mm) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * mm * kTh], bp[2 * mm * kTh], acc, 0, 0, 0);
 }
 
+#ifdef SRL_MLP_PROF   // variant builds only (scripts/mlp_prof.sh): shader-clock stamps of workgroup phases, read back through mlp_prof_dump
+__device__ long long g_mlp_prof[256 * 40];
+#define SRL_MLP_STAMP(k) do { if (tid == 0 && blockIdx.x < 256) g_mlp_prof[blockIdx.x * 40 + (k)] = clock64(); } while (0)
+#else
+#define SRL_MLP_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const Args& a = m.a;
@@ -274,6 +281,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
   float* const pgs = sm + m.bwd_floats + wave * (m.npg * 64);
   float* const tiles = sm + m.bwd_floats + kBwdWaves * (m.npg * 64);
   float* const myT = tiles + wave * kTileF;
+  SRL_MLP_STAMP(0);
   if (!(m.dbg & 32)) mm_stage(m, sm, tid, true, 64 * kBwdWaves);
   for (int e = lane; e < m.npg * 64; e += 64) pgs[e] = 0.f;
   __syncthreads();
@@ -281,7 +289,11 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
 #pragma unroll
   for (int e = 0; e < 16; ++e) W0[e] = W1[e] = W2[e] = W3[e] = 0.f;
   const long ntiles = (a.rows + 31) / 32;
+  SRL_MLP_STAMP(1);
+  int it_ = 0;
   for (long tile0 = (long)blockIdx.x * kBwdWaves; tile0 < ntiles; tile0 += (long)gridDim.x * kBwdWaves) {
+    if (it_ < 16) SRL_MLP_STAMP(8 + it_);
+    ++it_;
     const long row = (tile0 + wave) * 32 + r;   // (a tile beyond the rows: zeros all the way, its wavefront keeps the barriers' count)
     const bool rok = row < a.rows && !(m.dbg & 64);
     float d[kMB][16], xin[kMB][16], xnext[kMB][16];
@@ -307,6 +319,12 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
       if (L.kind == 1) {
         --lin;
         const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5;
+#ifdef SRL_MLP_PROF
+#define SRL_MLP_LSTAMP(k) do { if (it_ == 2) SRL_MLP_STAMP(20 + 5 * lin + (k)); } while (0)
+#else
+#define SRL_MLP_LSTAMP(k) do { } while (0)
+#endif
+        SRL_MLP_LSTAMP(0);
 #pragma unroll
         for (int ob = 0; ob < kMB; ++ob)
           if (ob < nbo) {
@@ -316,7 +334,9 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
 #pragma unroll
         for (int ib = 0; ib < kMB; ++ib)
           if (ib < nbi) mm_half_write(myT + (kMB + ib) * 32 * kTh, r, hb, xin[ib]);
+        SRL_MLP_LSTAMP(1);
         __syncthreads();
+        SRL_MLP_LSTAMP(2);
         if (!(m.dbg & 2)) {
           // this wavefront's block of the layer, over its share of the four tiles: 4 blocks -> every tile; 2 -> two tiles; 1 -> its own
           const int nblk = nbo * nbi, b = wave % nblk, ob = b / nbi, ib = b - ob * nbi;
@@ -333,7 +353,9 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
             }
           }
         }
+        SRL_MLP_LSTAMP(3);
         __syncthreads();   // the tile areas are rewritten by the next layer below
+        SRL_MLP_LSTAMP(4);
         if (i > 0) {
           f32x16 acc[kMB];
 #pragma unroll
@@ -408,30 +430,27 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
   }
   // ---- the workgroup's sums meet in LDS (the tile region is free), then one atomic per parameter and workgroup ---------------
   __syncthreads();
-  float* const accs = tiles;   // [nacc][16][64]
-  for (int e = tid; e < m.nacc * 1024; e += 64 * kBwdWaves) accs[e] = 0.f;
-  __syncthreads();
+  SRL_MLP_STAMP(2);
+  int lin_of[SRL_MLP_MAX_LAYERS];
   {
-    int lin = 0;
-    for (int i = 0; i < a.n; ++i) {
-      const Layer L = a.L[i];
-      if (L.kind != 1) continue;
-      const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5, nblk = nbo * nbi;
-      float* blk = accs + (m.accb[i] + wave % nblk) * 1024 + lane;
-      // (wavefronts that shared a block add into the same 4 KB: 16 LDS adds per wavefront and layer, once per launch)
-#define SRL_MM_FOLD(Wk)                                                     \
-  _Pragma("unroll") for (int e = 0; e < 16; ++e) atomicAdd(blk + e * 64, Wk[e]);
-      switch (lin) {
-        case 0: SRL_MM_FOLD(W0) break;
-        case 1: SRL_MM_FOLD(W1) break;
-        case 2: SRL_MM_FOLD(W2) break;
-        default: SRL_MM_FOLD(W3) break;
-      }
-#undef SRL_MM_FOLD
-      ++lin;
-    }
+    int k = 0;
+    for (int i = 0; i < a.n; ++i) lin_of[i] = a.L[i].kind == 1 ? k++ : -1;
+  }
+  // every wavefront parks its blocks in a slot of its own [wave][Linear layer][16][64] (plain stores: a ds_add_f32 wave-instruction
+  // took ~800 cycles here, 19 us of a 142 us launch for 48 of them per wavefront); the sums over the wavefronts that shared a block
+  // are formed by the threads that send them to the gradient buffer
+  float* const accs = tiles;
+  {
+#define SRL_MM_PARK(Wk, k)                                                                    \
+  if ((k) < m.nlin) {                                                                          \
+    float* slot = accs + (wave * kMaxLin + (k)) * 1024 + lane;                                \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) slot[e * 64] = Wk[e];                       \
+  }
+    SRL_MM_PARK(W0, 0) SRL_MM_PARK(W1, 1) SRL_MM_PARK(W2, 2) SRL_MM_PARK(W3, 3)
+#undef SRL_MM_PARK
   }
   __syncthreads();
+  SRL_MLP_STAMP(3);
   for (int i = 0; i < ((m.dbg & 8) ? 0 : a.n); ++i) {
     const Layer L = a.L[i];
     auto psum = [&](int slot, int c) {   // the four wavefronts' per-channel sums
@@ -443,10 +462,15 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
     if (L.kind == 1) {
       const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5;
       // accumulator of dz^T x: rows = out channel (register e, half hb), columns = in channel (lane & 31)
-      for (int idx = tid; idx < nbo * nbi * 1024; idx += 64 * kBwdWaves) {
+      const int nblk = nbo * nbi;
+      for (int idx = tid; idx < nblk * 1024; idx += 64 * kBwdWaves) {
         const int l = idx & 63, e = (idx >> 6) & 15, blk = idx >> 10, ob = blk / nbi, ib = blk - ob * nbi;
         const int o = 32 * ob + mm_ch(e, l >> 5), k = 32 * ib + (l & 31);
-        if (o < L.out && k < L.in) atomicAdd(L.gw + o * L.in + k, accs[(m.accb[i] + blk) * 1024 + (idx & 1023)]);
+        if (o < L.out && k < L.in) {
+          float v = 0.f;   // the wavefronts that formed this block: blk, blk + nblk, ...
+          for (int w = blk; w < kBwdWaves; w += nblk) v += accs[(w * kMaxLin + lin_of[i]) * 1024 + (idx & 1023)];
+          atomicAdd(L.gw + o * L.in + k, v);
+        }
       }
       if (L.gb)
         for (int c = tid; c < L.out; c += 64 * kBwdWaves) atomicAdd(L.gb + c, psum(m.pg[i], c));
@@ -457,12 +481,13 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
       }
     }
   }
+  SRL_MLP_STAMP(4);
 }
 
 // LDS of the backward kernel: parameters | per-channel sums and a tile area per wavefront (the accumulator blocks reuse the tile
 // region at the end)
 inline long mm_bwd_lds_bytes(const MArgs& m) {
-  const long tiles = (long)kBwdWaves * kTileF, accs = (long)m.nacc * 1024;
+  const long tiles = (long)kBwdWaves * kTileF, accs = (long)kBwdWaves * kMaxLin * 1024;
   return 4L * (m.bwd_floats + kBwdWaves * m.npg * 64 + (tiles > accs ? tiles : accs));
 }
 

@@ -384,3 +384,10 @@ extern "C" int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, con
   SRL_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef SRL_MLP_PROF
+// variant builds only: the phase stamps of the last mlp_bwd_mfma_kernel launch (scripts/mlp_prof.sh)
+extern "C" int mlp_prof_dump(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mlp_prof), sizeof(long long) * n);
+}
+#endif
