@@ -16,6 +16,7 @@ the encoder read); ``backward`` takes the gradient with respect to it.  Formats 
     weight gradients: conv3 (a2, dz3), conv2 (a1, dz2) image-stationary; the Linear's through the round-3 kernel.
 """
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -57,7 +58,9 @@ def match(layers) -> Optional[tuple]:
 class H2Cnn:
 
     def __init__(self, net, layers):
-        self.net = net
+        # (a proxy: the executor keeps its blocks in `_h2_blocks`; a strong reference back would make every dropped trainer wait
+        # for the cycle collector with tens of GB of workspace -- an OOM in a process that builds several, e.g. the test suite)
+        self.net = weakref.proxy(net)
         self.ln, self.c1, self.c2, self.c3, self.fc = layers
         self.H = self.fc.out_features
         # every workspace buffer of this block carries the block's own name: an executor may hold several (separate actor and

@@ -192,7 +192,10 @@ extern "C" int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d) {
   static const int dbg = [] { const char* e = getenv("SRL_H2G_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
   int rc;
-  if (wide) rc = h2gemm_launch<8, H2X_DENSE, 2, false>((hipStream_t)stream, a);
+  // (two 4-wavefront workgroups of 128 x 256 per CU on half k-steps instead of one 8-wavefront workgroup of 256 x 256: h2gemm.h HALF)
+  static const bool half_on = [] { const char* e = getenv("SRL_H2GEMM_HALF"); return e && e[0] == '1'; }();
+  if (wide && half_on) rc = h2gemm_launch<8, H2X_DENSE, 3, false, true>((hipStream_t)stream, a);
+  else if (wide) rc = h2gemm_launch<8, H2X_DENSE, 2, false>((hipStream_t)stream, a);
   else if (d->NC >= 128) rc = h2gemm_launch<4, H2X_DENSE, 3>((hipStream_t)stream, a);
   else rc = h2gemm_launch<2, H2X_DENSE, 3>((hipStream_t)stream, a);
   SRL_CHECK_ARG(rc == 0, "grid too large");

@@ -103,22 +103,22 @@ __device__ __forceinline__ h2_i32x4 h2_rsrc(const void* p) {
 
 // NI DMA instructions of one wavefront into LDS at m0 = lds, lds + 8 KB, ...; instruction i reads 64 x 16 bytes at
 // rsrc + voff[i] + soff.  One statement: the compiler schedules nothing between the M0 writes and their readers.
-template <int NI>
+template <int NI, int STRIDE = 0x2000>
 __device__ __forceinline__ void h2_dma(uint32_t lds, const uint32_t (&voff)[4], h2_i32x4 rsrc, uint32_t soff) {
   static_assert(NI >= 1 && NI <= 4, "");
   if (NI == 4)
     asm volatile(
         "s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds"
-        ::"s"(lds), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(rsrc), "s"(soff)
+        "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
+        "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+        "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds"
+        ::"s"(lds), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(rsrc), "s"(soff), "n"(STRIDE)
         : "memory", "scc");
   else if (NI == 2)
     asm volatile(
         "s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
-        ::"s"(lds), "v"(voff[0]), "v"(voff[1]), "s"(rsrc), "s"(soff)
+        "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+        ::"s"(lds), "v"(voff[0]), "v"(voff[1]), "s"(rsrc), "s"(soff), "n"(STRIDE)
         : "memory", "scc");
   else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff[0]), "s"(rsrc),
@@ -188,20 +188,29 @@ static __global__ void h2_unpack_kernel(const uint8_t* __restrict__ src, int64_t
 // KSPLIT (the default geometry): wavefront w = (position block w & 3, k-half w >> 2), every wavefront all NCB channel blocks.
 // !KSPLIT (NCB = 8, the data gradient of a wide Linear: 256 channels per workgroup, a third less staged per flop): wavefront
 // w = (position block w & 3, channel half w >> 2), both k-halves of every step; no exchange at the end.
-template <int NCB, int XMODE, int S, bool KSPLIT = true>
-__global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
+// HALF (round 5; NCB = 8, dense, unsplit): 128 positions x 256 channels per workgroup of FOUR wavefronts, k-steps of 16 k-values
+// (64-byte rows: one k-half of the h2p block), S stages of 24 KB -- so that TWO workgroups share a CU.  With one 8-wavefront
+// workgroup per CU a tile's ring fill, k-loop and 256 KB of stores run one after the other (leave-outs, DESIGN section 4: 89 + 45 +
+// 84 us of the Linear's data gradient); a second resident workgroup is what the hardware can overlap them with.
+template <int NCB, int XMODE, int S, bool KSPLIT = true, bool HALF = false>
+__global__ __launch_bounds__(HALF ? 256 : 512, 2) void h2gemm_kernel(H2Args g) {
   static_assert(NCB == 2 || NCB == 4 || (NCB == 8 && !KSPLIT), "64, 128 or (unsplit) 256 channels per workgroup");
   static_assert(S == 2 || S == 3 || S == 4, "ring depth");
+  static_assert(!HALF || (NCB == 8 && !KSPLIT && XMODE == H2X_DENSE), "half steps: the dense 256-channel geometry");
   constexpr int NCW = KSPLIT ? NCB : NCB / 2;   // channel blocks per wavefront
-  constexpr int BP = 256;
-  constexpr int XT = BP * 128, WT = NCB * 32 * 128, STAGE = XT + WT;
-  constexpr int NWI = NCB / 2;    // W-tile DMA instructions per wavefront and step (NCB * 4 instructions over 8 wavefronts)
-  constexpr int L = 4 + NWI;      // DMA instructions per wavefront and step
+  constexpr int BP = HALF ? 128 : 256;          // positions per workgroup
+  constexpr int PITCH = HALF ? 64 : 128;        // bytes of a row per k-step in LDS
+  constexpr int NWAVES = HALF ? 4 : 8;
+  constexpr int XT = BP * PITCH, WT = NCB * 32 * PITCH, STAGE = XT + WT;
+  constexpr int NXI = XT / 1024 / NWAVES;       // X-tile DMA instructions per wavefront and step (1 KB each)
+  constexpr int NWI = WT / 1024 / NWAVES;       // W-tile DMA instructions per wavefront and step
+  constexpr int DSTRIDE = NWAVES * 1024;        // LDS distance between a wavefront's consecutive DMA instructions
+  constexpr int L = NXI + NWI;                  // DMA instructions per wavefront and step
   extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wp = wid & 3, kh = KSPLIT ? wid >> 2 : 0, chalf = KSPLIT ? 0 : wid >> 2;
+  const int wp = HALF ? wid & 1 : wid & 3, kh = KSPLIT ? wid >> 2 : 0, chalf = KSPLIT ? 0 : (HALF ? wid >> 1 : wid >> 2);
   // logical tile id: every XCD owns one contiguous run
   unsigned lid;
   {
@@ -227,9 +236,12 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
     m0 = (long)tile_p * BP;
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = 8 * (wid + 8 * q) + (lane >> 3);
-    const int slot = (lane & 7) ^ ((row >> 1) & 7);
+  for (int q = 0; q < 4; ++q) xv[q] = 0;
+#pragma unroll
+  for (int q = 0; q < NXI; ++q) {
+    // an instruction = 1 KB: 8 rows of 128 bytes (slot = 16-byte piece, XOR (row >> 1) & 7) or, HALF, 16 rows of 64 (XOR (row >> 2) & 3)
+    const int row = HALF ? 16 * (wid + NWAVES * q) + (lane >> 2) : 8 * (wid + NWAVES * q) + (lane >> 3);
+    const int slot = HALF ? (lane & 3) ^ ((row >> 2) & 3) : (lane & 7) ^ ((row >> 1) & 7);
     long m = m0 + row;
     if (m >= g.M) m = g.M - 1;
     uint32_t base;
@@ -246,8 +258,8 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
   uint32_t wv[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int q = 0; q < NWI; ++q) {
-    const int row = 8 * (wid + 8 * q) + (lane >> 3);
-    const int slot = (lane & 7) ^ ((row >> 1) & 7);
+    const int row = HALF ? 16 * (wid + NWAVES * q) + (lane >> 2) : 8 * (wid + NWAVES * q) + (lane >> 3);
+    const int slot = HALF ? (lane & 3) ^ ((row >> 2) & 3) : (lane & 7) ^ ((row >> 1) & 7);
     int ch = c0 + row;
     if (ch >= g.NC) ch = g.NC - 1;
     wv[q] = (uint32_t)ch * g.w_row_bytes + 16u * slot;
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
   const uint32_t lds_w = __builtin_amdgcn_readfirstlane(lds0 + XT + wid * 1024);
 
   // ---- k-step sequence
-  int nsteps = g.nk;
+  int nsteps = HALF ? 2 * g.nk : g.nk;
   uint64_t vmask = 0;  // GROUPED: valid taps
   const int cbk = XMODE == H2X_GROUPED ? g.C / 32 : 1;
   if (XMODE == H2X_GROUPED) {
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
   int gt = -1, gcb = cbk - 1;  // GROUPED iterator state: current tap, channel block
   auto step_offsets = [&](int t, uint32_t& sx, uint32_t& sw) {
     if (XMODE == H2X_DENSE) {
-      sx = sw = (uint32_t)t * 128u;
+      sx = sw = (uint32_t)t * (uint32_t)PITCH;
     } else if (XMODE == H2X_CONV) {
       sx = g.koff_x[t];
       sw = g.koff_w[t];
@@ -298,8 +310,8 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
   auto issue_off = [&](uint32_t stage_off, int t) {
     const uint32_t sx = __builtin_amdgcn_readfirstlane(nsx), sw = __builtin_amdgcn_readfirstlane(nsw);
     if (!(g.dbg & 1)) {
-      h2_dma<4>(lds_x + stage_off, xv, rx, sx);
-      h2_dma<NWI>(lds_w + stage_off, wv, rw, sw);
+      h2_dma<NXI, DSTRIDE>(lds_x + stage_off, xv, rx, sx);
+      h2_dma<NWI, DSTRIDE>(lds_w + stage_off, wv, rw, sw);
     }
     if (t + 1 < nsteps) step_offsets(t + 1, nsx, nsw);
   };
@@ -314,26 +326,30 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment addresses: row r = lane & 31 of a 32-row block, group 2 kh + (lane >> 5), plane p: slot (2 g + p) ^ f(r)
-  const int fr_r = lane & 31, fr_f = (fr_r >> 1) & 7;
-  auto fr_off = [&](int khh, int pl) { return fr_r * 128 + 16 * ((4 * khh + 2 * (lane >> 5) + pl) ^ fr_f); };
+  // (HALF: a staged row is one k-half, 4 slots: group (lane >> 5), plane p at slot (2 group + p) ^ ((r >> 2) & 3))
+  const int fr_r = lane & 31, fr_f = HALF ? (fr_r >> 2) & 3 : (fr_r >> 1) & 7;
+  auto fr_off = [&](int khh, int pl) {
+    return HALF ? fr_r * 64 + 16 * ((2 * (lane >> 5) + pl) ^ fr_f) : fr_r * 128 + 16 * ((4 * khh + 2 * (lane >> 5) + pl) ^ fr_f);
+  };
+  constexpr int BLK = 32 * PITCH;   // bytes of a 32-row block of a staged tile
 
   auto compute = [&](uint32_t stage_off) {
-    const uint8_t* sx = lds + stage_off + wp * (64 * 128);
-    const uint8_t* sw = lds + stage_off + XT + chalf * (NCW * 4096);
+    const uint8_t* sx = lds + stage_off + wp * (2 * BLK);
+    const uint8_t* sw = lds + stage_off + XT + chalf * (NCW * BLK);
 #pragma unroll
-    for (int k2 = 0; k2 < (KSPLIT ? 1 : 2); ++k2) {
+    for (int k2 = 0; k2 < ((KSPLIT || HALF) ? 1 : 2); ++k2) {
       const int khh = KSPLIT ? kh : k2;
       const int o0 = fr_off(khh, 0), o1 = fr_off(khh, 1);
       h2_f16x8 xf[2][2], wf[NCW][2];
 #pragma unroll
       for (int i = 0; i < NCW; ++i) {
-        wf[i][0] = *reinterpret_cast<const h2_f16x8*>(sw + i * 4096 + o0);
-        wf[i][1] = *reinterpret_cast<const h2_f16x8*>(sw + i * 4096 + o1);
+        wf[i][0] = *reinterpret_cast<const h2_f16x8*>(sw + i * BLK + o0);
+        wf[i][1] = *reinterpret_cast<const h2_f16x8*>(sw + i * BLK + o1);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        xf[j][0] = *reinterpret_cast<const h2_f16x8*>(sx + j * 4096 + o0);
-        xf[j][1] = *reinterpret_cast<const h2_f16x8*>(sx + j * 4096 + o1);
+        xf[j][0] = *reinterpret_cast<const h2_f16x8*>(sx + j * BLK + o0);
+        xf[j][1] = *reinterpret_cast<const h2_f16x8*>(sx + j * BLK + o1);
       }
       // small terms first
 #pragma unroll
@@ -560,10 +576,10 @@ __global__ __launch_bounds__(512, 2) void h2gemm_kernel(H2Args g) {
   }
 }
 
-template <int NCB, int XMODE, int S, bool KSPLIT = true>
+template <int NCB, int XMODE, int S, bool KSPLIT = true, bool HALF = false>
 inline int h2gemm_launch(hipStream_t st, H2Args a) {
-  constexpr int BP = 256;
-  constexpr int STAGE = BP * 128 + NCB * 32 * 128;
+  constexpr int BP = HALF ? 128 : 256, PITCH = HALF ? 64 : 128;
+  constexpr int STAGE = BP * PITCH + NCB * 32 * PITCH;
   a.tiles_c = (a.NC + NCB * 32 - 1) / (NCB * 32);
   long tiles_p;
   if (XMODE == H2X_GROUPED) tiles_p = ((a.M + BP - 1) / BP) * (long)(a.GH * a.GW);
@@ -571,12 +587,12 @@ inline int h2gemm_launch(hipStream_t st, H2Args a) {
   const long nblk = tiles_p * a.tiles_c;
   if (nblk <= 0 || nblk > 0x7fffffffL) return -22;
   static bool attr_set = false;
-  auto kern = h2gemm_kernel<NCB, XMODE, S, KSPLIT>;
+  auto kern = h2gemm_kernel<NCB, XMODE, S, KSPLIT, HALF>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S * STAGE);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), S * STAGE, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(HALF ? 256 : 512), S * STAGE, st, a);
   return 0;
 }
 

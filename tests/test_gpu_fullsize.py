@@ -70,6 +70,12 @@ def check_analyze_rows_vs_oracle(tr, smp, sample, arr, picks=64):
     for name, g, o in zip(("log-prob", "value", "entropy"), got, (lp, val, ent)):
         o = o.numpy().reshape(picks)
         assert (np.abs(g - o) <= 1e-5 * np.maximum(np.abs(o), 1.0)).all(), (name, float(np.abs(g - o).max()))
+    # the analysis taped every piece of the whole sample (~50 GB of activations): hand it back before the step allocates its own
+    del ar
+    tr.policy._analysis = None
+    tr.policy.net._tape = None
+    tr.policy.net.ws._bufs.clear()
+    torch.cuda.empty_cache()
 
 
 def make(chunk_rows):
@@ -144,7 +150,10 @@ def test_config2_step_4096_envs():
         results.append((res.stats, tr.policy.get_checkpoint()["state_dict"]))
         if chunk == 16384 and len(results) == 1:
             check_gae_vs_oracle(smp, arr)
-        del tr
+        del tr, smp, res
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
     (s0, p0), (s1, p1), (s2, p2) = results
     for k in s0:
         tol = 1e-5 if k in ("policy_loss", "value_loss", "entropy") else 1e-4
