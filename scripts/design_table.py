@@ -22,8 +22,8 @@ ROWS = [  # label, kernel substring, flops (G), piece products, bytes (MB)
     ("conv3 forward (`h2conv_kernel<1,3>`)", "h2conv_kernel<1, 3>", 59.2, 3, 545),
     ("conv3 data gradient (`h2conv_kernel<2,2>`)", "h2conv_kernel<2, 2>", 59.2, 3, 545),
     ("conv3 weight gradient (`h2wgrad_kernel<1,3>`)", "h2wgrad_kernel<1, 3>", 59.2, 3, 545),
-    ("Linear forward (`h2gemm_kernel<4,0,3>`)", "h2gemm_kernel<4, 0, 3, true>", 52.6, 3, 245),
-    ("Linear data gradient (`h2gemm_kernel<8,0,2,false>`)", "h2gemm_kernel<8, 0, 2, false>", 52.6, 3, 245),
+    ("Linear forward (`h2gemm_kernel<4,0,3>`)", "h2gemm_kernel<4, 0, 3, true", 52.6, 3, 245),
+    ("Linear data gradient (`h2gemm_kernel<8,0,2,false>`)", "h2gemm_kernel<8, 0, 2, false", 52.6, 3, 245),
     ("Linear weight gradient (`gemm3_kernel<128,128,…,2>`, split-K 5)", "gemm3_kernel<128, 128", 52.6, 3, 245),
 ]
 print("| launch (kernel) | flops | MFMA floor | bytes | HBM floor | measured | × larger floor | traffic | MFMA busy | vector busy |")

@@ -188,16 +188,18 @@ extern "C" int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d) {
   // k-halves in every wavefront -- a third less staged per multiply-add, on a two-stage ring (240 -> 220 us per 16 384 rows)
   static const bool wide_on = [] { const char* e = getenv("SRL_H2GEMM_WIDE"); return !(e && e[0] == '0'); }();
   const bool wide = wide_on && d->NC >= 1024 && d->K <= 1024;
-  static const bool half_cnt = [] { const char* e = getenv("SRL_H2GEMM_HALF"); return !(e && e[0] == '0'); }();
+  static const bool half_cnt = [] { const char* e = getenv("SRL_H2GEMM_HALF"); return e && e[0] == '1'; }();
   srl_count_dispatch(SRL_DISP_H2, 3, wide ? 8 : (d->NC >= 128 ? 4 : 2), wide && !half_cnt ? 2 : 3);
   static const int dbg = [] { const char* e = getenv("SRL_H2G_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
   int rc;
   // (two 4-wavefront workgroups of 128 x 256 per CU on half k-steps instead of one 8-wavefront workgroup of 256 x 256: h2gemm.h HALF)
-  // 209.5 -> 192.3 us per 16 384 rows of the Linear's data gradient, same box (SRL_H2GEMM_HALF=0: the 8-wavefront kernel, A/B); its
-  // leave-outs then overlap (no DMA 138, no MFMAs 149, no stores 143) and what is left is the ring fill itself: 1.5 x the bytes of
-  // the 256 x 256 tile per multiply-add at ~33 GB/s per CU
-  static const bool half_on = [] { const char* e = getenv("SRL_H2GEMM_HALF"); return !(e && e[0] == '0'); }();
+  // Alone 209.5 -> 192.3 us per 16 384 rows of the Linear's data gradient (same box; its leave-outs then overlap: no DMA 138, no
+  // MFMAs 149, no stores 143) -- but inside the update, beside the three other row-chunk pipelines, the update gets SLOWER (91.1 /
+  // 91.6 ms with the 8-wavefront kernel, 92.4 / 92.4 with this one, alternating runs on one box): the smaller tile stages 1.5 x the
+  // bytes per multiply-add (613 against 452 MB of counted traffic per launch) and that is what the neighbours compete for.  Opt-in
+  // (SRL_H2GEMM_HALF=1) for the record.
+  static const bool half_on = [] { const char* e = getenv("SRL_H2GEMM_HALF"); return e && e[0] == '1'; }();
   if (wide && half_on) rc = h2gemm_launch<8, H2X_DENSE, 3, false, true>((hipStream_t)stream, a);
   else if (wide) rc = h2gemm_launch<8, H2X_DENSE, 2, false>((hipStream_t)stream, a);
   else if (d->NC >= 128) rc = h2gemm_launch<4, H2X_DENSE, 3>((hipStream_t)stream, a);
