@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 15
+#define SRL_HIP_ABI_VERSION 16
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -614,7 +614,10 @@ int srl_ring_stack_push(void* stream, void* store, const void* planes, const int
  * CartPole-sized configurations, whose update is otherwise a chain of ~40 kernels of 3-10 us.  Layer i's input width must be
  * layer i-1's output width.  srl_mlp_fwd: y = chain(x), and every layer's input (layers 1..n-1) is left in `tape`
  * ([rows, tape_ld], tape_ld >= srl_mlp_tape_floats) for srl_mlp_bwd, which adds the parameter gradients of every layer into
- * gw / gb (float atomics across 16-row workgroups) given dy = d loss / d y.  The gradient w.r.t. x is not formed. */
+ * gw / gb (float atomics across 16-row workgroups) given dy = d loss / d y.  The gradient w.r.t. x is not formed.
+ * From 512 rows, chains no wider than 64 with at most 8 layers run on the float32 matrix cores (csrc/mlp_mfma.h) and keep NO
+ * tape -- srl_mlp_bwd walks the chain forward again from x, which must still hold the rows srl_mlp_fwd saw, under the same
+ * parameters: srl_mlp_tape_floats_at returns 0 for such a (chain, rows) pair and `tape` may then be NULL in both calls. */
 #define SRL_MLP_MAX_LAYERS 12
 typedef struct srl_mlp_layer {
   int32_t kind;       /* 0: LayerNorm over `in` (w = gamma, b = beta, eps 1e-5); 1: Linear, w [out, in] row-major, b [out] */
@@ -626,6 +629,7 @@ typedef struct srl_mlp_layer {
   float* gb;
 } srl_mlp_layer;
 int64_t srl_mlp_tape_floats(const srl_mlp_layer* layers, int n); /* floats per tape row; -1: chain not supported */
+int64_t srl_mlp_tape_floats_at(const srl_mlp_layer* layers, int n, int64_t rows); /* ... at this row count (0: no tape kept) */
 /* rows up to which the pair is worth taking over the layer-by-layer kernels (measured): 32768 when the chain's parameter
  * gradients (<= 12288 floats) are summed in LDS over a workgroup's row blocks, 8192 when every 16-row block has to add its
  * sums with float atomics; 0: not supported */

@@ -1133,14 +1133,16 @@ class HipNet:
         arr, tld, width, act, max_rows = ent
         if n > max_rows:
             return None
-        tape = self.ws.get(f"{tag}mlp.tape", n * tld)
+        # (the matrix-core chain keeps no tape: its backward pass walks forward again from x -- hip.mlp_tape_floats_at is 0 there)
+        tape = self.ws.get(f"{tag}mlp.tape", n * tld) if hip.mlp_tape_floats_at(arr, n) else None
         y = out if out is not None else self.ws.get(f"{tag}mlp.y", n * width)
-        hip.mlp_fwd(arr, x.data_ptr(), x.shape[1], n, tape.data_ptr(), tld, y.data_ptr(), width)
+        hip.mlp_fwd(arr, x.data_ptr(), x.shape[1], n, tape.data_ptr() if tape is not None else 0, tld, y.data_ptr(), width)
         return dict(arr=arr, x=x, tape=tape, tld=tld, n=n, feat=Buf(y.data_ptr(), width, n, width), act=act,
                     head=head, prefixes=[L.prefix for L in layers])
 
     def _fused_bwd(self, rec, dy_ptr: int, lddy: int):
-        hip.mlp_bwd(rec["arr"], rec["x"].data_ptr(), rec["x"].shape[1], rec["n"], rec["tape"].data_ptr(), rec["tld"], dy_ptr, lddy)
+        hip.mlp_bwd(rec["arr"], rec["x"].data_ptr(), rec["x"].shape[1], rec["n"], rec["tape"].data_ptr() if rec["tape"] is not None else 0,
+                    rec["tld"], dy_ptr, lddy)
         self._release(rec["prefixes"])  # one launch: every layer of the chain is final behind it
 
     # ------------------------------------------------------------------ public: forward / backward

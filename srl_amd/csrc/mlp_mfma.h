@@ -1,4 +1,4 @@
-// The fused MLP chain of mlp_small.hip on the float32 matrix cores, for row counts that fill the chip (round 4).
+// The fused MLP chain of mlp_small.hip on the float32 matrix cores, for row counts that fill the chip (rounds 4-5).
 //
 // mlp_small.hip walks 16 rows per workgroup through the layers with scalar FMAs: right for 256 rows (latency-bound), 4 % of the
 // float32-MFMA roof at 65 536.  Here a WAVEFRONT owns 32 rows and keeps them in registers through the whole chain:
@@ -10,13 +10,16 @@
 //     its two k-values -- so the weights' k order is permuted once at staging and NO data moves between layers;
 //   * bias = the accumulator's initial value, activation / LayerNorm on the accumulator registers (a row's features are 16
 //     registers in each of two lanes: sums are in-lane adds and one cross-lane exchange);
-//   * the tape (every layer's input, for the backward pass) is the only traffic besides x and y.
-// Backward: the data gradient is the same chain with W^T fragments; the weight gradient dW[o][k] = sum_rows dz[r][o] x[r][k]
-// reduces over ROWS, so both operands go through a 32-row transposition tile in LDS (rows become the k dimension) and the
-// products accumulate in persistent accumulator blocks -- one 32 x 32 block per (out block, in block) of every Linear, for all
-// the rows a wavefront walks -- that are folded across the workgroup in LDS and reach the gradient buffer once per workgroup.
+//   * NO TAPE (round 5): x and y are the only traffic.  The tape -- every layer's input, 1 KB per row of a 2 x 64 chain, written
+//     in 16-byte pieces -- was what the forward launch took its time for (545 MB, 257 us at 524 288 rows against 72 us of MFMAs)
+//     and the backward launch waited on; the backward pass walks the chain forward again from x (16 bytes per row), every layer's
+//     input staying in registers, for 136 more MFMAs per 32 rows.
+// Backward: the data gradient is the same chain with the SAME fragments read transposed (rows of 65 floats: conflict-free both
+// ways); the weight gradient dW[o][k] = sum_rows dz[r][o] x[r][k] reduces over ROWS, so both operands go through a 32-row
+// transposition tile in LDS (rows become the k dimension) and the products accumulate in persistent accumulator blocks -- one
+// 32 x 32 block per (out block, in block) of every Linear, for all the rows a workgroup walks -- that meet in LDS once, at the end.
 // Bias / LayerNorm-affine gradients are column sums of the same tiles, kept per lane in LDS.
-// Eligible chains: widths <= 64 (two 32-channel blocks), <= 12 accumulator blocks; the others keep mlp_small.hip's kernels.
+// Eligible chains: widths <= 64 (two 32-channel blocks), <= 8 layers of which <= 4 Linear; the others keep mlp_small.hip's kernels.
 // Reference: modules/utils.py:154-161 (mlp), actor_critic_policy.py:92-107 (heads).
 #pragma once
 
@@ -25,17 +28,18 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMB = 2;          // 32-channel blocks per side of a layer at most
-constexpr int kMaxAcc = 12;     // dW accumulator blocks of a chain at most (48 KB of LDS, shared by the workgroup)
+constexpr int kMaxAcc = 12;     // dW accumulator blocks of a chain at most
+constexpr int kMaxNL = 8;       // layers of an eligible chain at most (their inputs stay in registers through the backward pass)
+constexpr int kFP = 65;         // floats per fragment row: 64 lanes + 1, so that the data gradient's transposed reads hit 32 banks
+constexpr int kFB = 16 * kFP;   // floats per 32 x 32 weight block
 
 struct MArgs {
   Args a;
-  int wf[SRL_MLP_MAX_LAYERS];    // LDS float offset: Linear forward fragments [nbo][nbi][16][64]; LayerNorm: gamma | beta tables
+  int wf[SRL_MLP_MAX_LAYERS];    // LDS float offset: Linear fragments [nbo][nbi][16][kFP]; LayerNorm: gamma | beta tables
   int tb[SRL_MLP_MAX_LAYERS];    // Linear: bias table [nbo * 32]
-  int wt[SRL_MLP_MAX_LAYERS];    // backward: Linear transposed fragments [nbi][nbo][16][64] (layers > 0); LayerNorm: gamma table
-  int accb[SRL_MLP_MAX_LAYERS];  // backward: first accumulator block of a Linear
   int pg[SRL_MLP_MAX_LAYERS];    // backward: offset of the layer's per-lane sums (Linear: bias gradient; LayerNorm: dgamma | dbeta)
-  int fwd_floats, bwd_floats, nacc, npg, nlin;
-  int dbg;   // timing experiments (wrong results; SRL_MLP_DBG): 2 no weight-gradient blocks, 4 no data gradient, 8 no final global adds, 16 no column sums, 32 no parameter staging, 64 no global loads
+  int par_floats, nacc, npg, nlin;
+  int dbg;   // timing experiments (wrong results; SRL_MLP_DBG): 2 no weight-gradient blocks, 4 no data gradient, 8 no final global adds, 16 no column sums, 32 no parameter staging, 64 no global loads, 128 no forward walk
 };
 
 __device__ __forceinline__ int mm_ch(int e, int hb) { return (e & 3) + 8 * (e >> 2) + 4 * hb; }
@@ -47,17 +51,20 @@ __device__ __forceinline__ int mm_ne(int dim, int blk) {
 }
 
 // NE MFMAs of one (out block, in block) product as straight-line code (a run-time bound inside the unrolled loop put every MFMA into
-// a basic block of its own: the operand reads could no longer run ahead, fwd 83 -> 170 us)
-template <int NE>
+// a basic block of its own: the operand reads could no longer run ahead, fwd 83 -> 170 us).  TR: the block read transposed (the
+// data gradient): `wfr` then points at this lane's row of the block and register e sits at column mm_ch(e, 0).
+template <int NE, bool TR>
 __device__ __forceinline__ void mm_chain_n(f32x16& acc, const float* wfr, const float (&v)[16]) {
 #pragma unroll
-  for (int e = 0; e < NE; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wfr[64 * e], v[e], acc, 0, 0, 0);
+  for (int e = 0; e < NE; ++e)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(TR ? wfr[(e & 3) + 8 * (e >> 2)] : wfr[kFP * e], v[e], acc, 0, 0, 0);
 }
+template <bool TR>
 __device__ __forceinline__ void mm_chain(f32x16& acc, const float* wfr, const float (&v)[16], int ne) {
-  if (ne == 16) mm_chain_n<16>(acc, wfr, v);
-  else if (ne == 4) mm_chain_n<4>(acc, wfr, v);
-  else if (ne == 8) mm_chain_n<8>(acc, wfr, v);
-  else if (ne == 12) mm_chain_n<12>(acc, wfr, v);
+  if (ne == 16) mm_chain_n<16, TR>(acc, wfr, v);
+  else if (ne == 4) mm_chain_n<4, TR>(acc, wfr, v);
+  else if (ne == 8) mm_chain_n<8, TR>(acc, wfr, v);
+  else if (ne == 12) mm_chain_n<12, TR>(acc, wfr, v);
 }
 
 // rows [row] of a row-major [rows][ld] matrix, columns 0 .. dim - 1, into the accumulator layout (zeros beyond dim / the rows)
@@ -116,34 +123,84 @@ __device__ __forceinline__ void mm_ln_stats(const float (&v)[kMB][16], int dim, 
   rstd = rsqrtf(q / (float)dim + kLnEps);
 }
 
-// stage the chain's parameters into LDS in operand order (every thread of the workgroup)
-__device__ __forceinline__ void mm_stage(const MArgs& m, float* sm, int tid, bool bwd, int nthr = 256) {
+// stage the chain's parameters into LDS in operand order (every thread of the workgroup); ONE copy serves both directions
+__device__ __forceinline__ void mm_stage(const MArgs& m, float* sm, int tid, int nthr) {
   for (int i = 0; i < m.a.n; ++i) {
     const Layer L = m.a.L[i];
     if (L.kind == 1) {
       const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5;
-      if (!bwd) {
-        for (int e = tid; e < nbo * nbi * 1024; e += nthr) {
-          const int l = e & 63, e16 = (e >> 6) & 15, blk = e >> 10, ib = blk % nbi, ob = blk / nbi;
-          const int o = 32 * ob + (l & 31), k = 32 * ib + mm_ch(e16, l >> 5);
-          sm[m.wf[i] + e] = (o < L.out && k < L.in) ? L.w[o * L.in + k] : 0.f;
-        }
-        for (int c = tid; c < nbo * 32; c += nthr) sm[m.tb[i] + c] = (c < L.out && L.b) ? L.b[c] : 0.f;
-      } else if (i > 0) {
-        for (int e = tid; e < nbo * nbi * 1024; e += nthr) {
-          const int l = e & 63, e16 = (e >> 6) & 15, blk = e >> 10, ob = blk % nbo, ib = blk / nbo;
-          const int k = 32 * ib + (l & 31), o = 32 * ob + mm_ch(e16, l >> 5);
-          sm[m.wt[i] + e] = (o < L.out && k < L.in) ? L.w[o * L.in + k] : 0.f;
-        }
+      for (int e = tid; e < nbo * nbi * 1024; e += nthr) {
+        const int l = e & 63, e16 = (e >> 6) & 15, blk = e >> 10, ib = blk % nbi, ob = blk / nbi;
+        const int o = 32 * ob + (l & 31), k = 32 * ib + mm_ch(e16, l >> 5);
+        sm[m.wf[i] + blk * kFB + e16 * kFP + l] = (o < L.out && k < L.in) ? L.w[o * L.in + k] : 0.f;
       }
+      for (int c = tid; c < nbo * 32; c += nthr) sm[m.tb[i] + c] = (c < L.out && L.b) ? L.b[c] : 0.f;
     } else {
       const int nb = (L.in + 31) >> 5;
-      const int off = bwd ? m.wt[i] : m.wf[i];
       for (int c = tid; c < nb * 32; c += nthr) {
-        sm[off + c] = c < L.in ? L.w[c] : 0.f;
-        if (!bwd) sm[off + nb * 32 + c] = c < L.in ? L.b[c] : 0.f;
+        sm[m.wf[i] + c] = c < L.in ? L.w[c] : 0.f;
+        sm[m.wf[i] + nb * 32 + c] = c < L.in ? L.b[c] : 0.f;
       }
     }
+  }
+}
+
+// layer i applied to the rows held in `cur` (accumulator layout in, accumulator layout out)
+__device__ __forceinline__ void mm_layer_fwd(const MArgs& m, const float* sm, int i, float (&cur)[kMB][16], int lane, int hb) {
+  const Layer L = m.a.L[i];
+  if (L.kind == 0) {
+    float mean, rstd;
+    mm_ln_stats(cur, L.in, hb, mean, rstd);
+    const float* gt = sm + m.wf[i];
+    const int nb = (L.in + 31) >> 5;
+#pragma unroll
+    for (int ib = 0; ib < kMB; ++ib)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = g4;
+        if (ib < nb) {
+          g4 = *reinterpret_cast<const float4*>(gt + 32 * ib + 8 * j + 4 * hb);
+          b4 = *reinterpret_cast<const float4*>(gt + nb * 32 + 32 * ib + 8 * j + 4 * hb);
+        }
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[ib][4 * j + q] = fmaf((cur[ib][4 * j + q] - mean) * rstd, gv[q], bv[q]);
+      }
+    return;
+  }
+  const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5;
+  f32x16 acc[kMB];
+#pragma unroll
+  for (int ob = 0; ob < kMB; ++ob) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[ob][e] = 0.f;
+    if (ob < nbo) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 b4 = *reinterpret_cast<const float4*>(sm + m.tb[i] + 32 * ob + 8 * j + 4 * hb);
+        acc[ob][4 * j] = b4.x; acc[ob][4 * j + 1] = b4.y; acc[ob][4 * j + 2] = b4.z; acc[ob][4 * j + 3] = b4.w;
+      }
+#pragma unroll
+      for (int ib = 0; ib < kMB; ++ib)
+        if (ib < nbi) mm_chain<false>(acc[ob], sm + m.wf[i] + (ob * nbi + ib) * kFB + lane, cur[ib], mm_ne(L.in, ib));
+    }
+  }
+  // (blocks beyond the layer: zeros.  The activation is wave-uniform: branches, not a select over an evaluated tanh)
+  if (L.act == 1) {
+#pragma unroll
+    for (int ob = 0; ob < kMB; ++ob)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cur[ob][e] = fmaxf(acc[ob][e], 0.f);
+  } else if (L.act == 2) {
+#pragma unroll
+    for (int ob = 0; ob < kMB; ++ob)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cur[ob][e] = tanhf(acc[ob][e]);
+  } else {
+#pragma unroll
+    for (int ob = 0; ob < kMB; ++ob)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cur[ob][e] = acc[ob][e];
   }
 }
 
@@ -151,7 +208,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(MArgs m) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const Args& a = m.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hb = lane >> 5;
-  mm_stage(m, sm, tid, false);
+  mm_stage(m, sm, tid, 256);
   __syncthreads();
   const long ntiles = (a.rows + 31) / 32;
   for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
@@ -159,71 +216,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_mfma_kernel(MArgs m) {
     const bool rok = row < a.rows;
     float cur[kMB][16];
     mm_load(a.x, a.ldx, row, rok, a.L[0].in, hb, cur);
-    int dim = a.L[0].in;
-    for (int i = 0; i < a.n; ++i) {
-      const Layer L = a.L[i];
-      if (i > 0) mm_store(a.tape + L.toff, a.tld, row, rok, L.in, hb, cur);  // this layer's input: what the backward pass reads back
-      if (L.kind == 0) {
-        float mean, rstd;
-        mm_ln_stats(cur, L.in, hb, mean, rstd);
-        const float* gt = sm + m.wf[i];
-        const int nb = (L.in + 31) >> 5;
-#pragma unroll
-        for (int ib = 0; ib < kMB; ++ib)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = g4;
-            if (ib < nb) {
-              g4 = *reinterpret_cast<const float4*>(gt + 32 * ib + 8 * j + 4 * hb);
-              b4 = *reinterpret_cast<const float4*>(gt + nb * 32 + 32 * ib + 8 * j + 4 * hb);
-            }
-            const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cur[ib][4 * j + q] = fmaf((cur[ib][4 * j + q] - mean) * rstd, gv[q], bv[q]);
-          }
-        dim = L.in;
-      } else {
-        const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5;
-        f32x16 acc[kMB];
-#pragma unroll
-        for (int ob = 0; ob < kMB; ++ob) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[ob][e] = 0.f;
-          if (ob < nbo) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float4 b4 = *reinterpret_cast<const float4*>(sm + m.tb[i] + 32 * ob + 8 * j + 4 * hb);
-              acc[ob][4 * j] = b4.x; acc[ob][4 * j + 1] = b4.y; acc[ob][4 * j + 2] = b4.z; acc[ob][4 * j + 3] = b4.w;
-            }
-#pragma unroll
-            for (int ib = 0; ib < kMB; ++ib)
-              if (ib < nbi) {
-                const float* wfr = sm + m.wf[i] + (ob * nbi + ib) * 1024 + lane;
-                mm_chain(acc[ob], wfr, cur[ib], mm_ne(L.in, ib));
-              }
-          }
-        }
-        // (blocks beyond the layer: zeros.  The activation is wave-uniform: branches, not a select over an evaluated tanh)
-        if (L.act == 1) {
-#pragma unroll
-          for (int ob = 0; ob < kMB; ++ob)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cur[ob][e] = fmaxf(acc[ob][e], 0.f);
-        } else if (L.act == 2) {
-#pragma unroll
-          for (int ob = 0; ob < kMB; ++ob)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cur[ob][e] = tanhf(acc[ob][e]);
-        } else {
-#pragma unroll
-          for (int ob = 0; ob < kMB; ++ob)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cur[ob][e] = acc[ob][e];
-        }
-        dim = L.out;
-      }
-    }
-    mm_store(a.y, a.ldy, row, rok, dim, hb, cur);
+    for (int i = 0; i < a.n; ++i) mm_layer_fwd(m, sm, i, cur, lane, hb);
+    const Layer& last = a.L[a.n - 1];
+    mm_store(a.y, a.ldy, row, rok, last.kind == 1 ? last.out : last.in, hb, cur);
   }
 }
 
@@ -258,36 +253,64 @@ __device__ __forceinline__ void mm_half_colsum(const float* T, float* dst, int l
   if (lane < 32) dst[c] += s;
 }
 
-// one tile's contribution to a 32 x 32 block of a weight gradient: the rows of the two half tiles are the k dimension
-__device__ __forceinline__ void mm_wgrad_tile(f32x16& acc, const float* dH, const float* xH, int lane) {
-  const float* ap = dH + (lane >> 5) * kTh + (lane & 31);
-  const float* bp = xH + (lane >> 5) * kTh + (lane & 31);
+// NT tiles' contributions to a 32 x 32 block of a weight gradient, as one straight line of 16 NT MFMAs (the operand reads of the
+// next tile run under the MFMAs of this one): the rows of the two half tiles are the k dimension
+template <int NT>
+__device__ __forceinline__ void mm_wgrad_tiles(f32x16& acc, const float* tiles, int t0, int ob, int ib, int lane) {
+  const float* ap = tiles + t0 * kTileF + ob * 32 * kTh + (lane >> 5) * kTh + (lane & 31);
+  const float* bp = tiles + t0 * kTileF + (kMB + ib) * 32 * kTh + (lane >> 5) * kTh + (lane & 31);
 #pragma unroll
-  for (int mm = 0; mm < 16; ++mm) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * mm * kTh], bp[2 * mm * kTh], acc, 0, 0, 0);
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int mm = 0; mm < 16; ++mm)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[t * kTileF + 2 * mm * kTh], bp[t * kTileF + 2 * mm * kTh], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mm_wgrad_block(f32x16& acc, const float* tiles, int per, int t0, int ob, int ib, int lane) {
+  if (per == 4) mm_wgrad_tiles<4>(acc, tiles, t0, ob, ib, lane);
+  else if (per == 2) mm_wgrad_tiles<2>(acc, tiles, t0, ob, ib, lane);
+  else mm_wgrad_tiles<1>(acc, tiles, t0, ob, ib, lane);
 }
 
 #ifdef SRL_MLP_PROF   // variant builds only (scripts/mlp_prof.sh): shader-clock stamps of workgroup phases, read back through mlp_prof_dump
 __device__ long long g_mlp_prof[256 * 40];
 #define SRL_MLP_STAMP(k) do { if (tid == 0 && blockIdx.x < 256) g_mlp_prof[blockIdx.x * 40 + (k)] = clock64(); } while (0)
+#define SRL_MLP_LSTAMP(k) do { if (it_ == 2) SRL_MLP_STAMP(20 + 5 * lin + (k)); } while (0)
 #else
 #define SRL_MLP_STAMP(k) do { } while (0)
+#define SRL_MLP_LSTAMP(k) do { } while (0)
 #endif
 
+template <int I> struct mm_ic { static constexpr int value = I; };
+// f(mm_ic<0>), f(mm_ic<1>), ... as separate inlined calls: the layer index is a constant in every copy of the body from the
+// front end on (an unrolled loop left the per-layer register arrays in scratch)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void mm_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(mm_ic<I>{});
+    mm_static_for<N, I + 1>(f);
+  }
+}
+
+// NL: the chain's layer count rounded up (4 / 6 / 8) -- the layer loops are unrolled so that every layer's input has registers of
+// its own (`xs`), 32 per layer
+template <int NL>
 __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const Args& a = m.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hb = lane >> 5;
-  // LDS: parameters (m.bwd_floats) | per wavefront: per-channel sums [npg][64] | per wavefront: tile area (dz halves | x halves)
-  float* const pgs = sm + m.bwd_floats + wave * (m.npg * 64);
-  float* const tiles = sm + m.bwd_floats + kBwdWaves * (m.npg * 64);
+  // LDS: parameters (m.par_floats) | per wavefront: per-channel sums [npg][64] | per wavefront: tile area (dz halves | x halves)
+  float* const pgs = sm + m.par_floats + wave * (m.npg * 64);
+  float* const tiles = sm + m.par_floats + kBwdWaves * (m.npg * 64);
   float* const myT = tiles + wave * kTileF;
   SRL_MLP_STAMP(0);
-  if (!(m.dbg & 32)) mm_stage(m, sm, tid, true, 64 * kBwdWaves);
+  if (!(m.dbg & 32)) mm_stage(m, sm, tid, 64 * kBwdWaves);
   for (int e = lane; e < m.npg * 64; e += 64) pgs[e] = 0.f;
   __syncthreads();
   f32x16 W0, W1, W2, W3;   // this wavefront's block of the chain's 1st .. 4th Linear layer (counted from the input side)
 #pragma unroll
   for (int e = 0; e < 16; ++e) W0[e] = W1[e] = W2[e] = W3[e] = 0.f;
+  // this lane's row of a weight block read transposed: lane = in channel k, its row of the fragment is e16(k), half hb(k)
+  const int trow = ((r & 3) + 4 * (r >> 3)) * kFP + ((r >> 2) & 1) * 32 + 4 * hb;
   const long ntiles = (a.rows + 31) / 32;
   SRL_MLP_STAMP(1);
   int it_ = 0;
@@ -296,34 +319,35 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
     ++it_;
     const long row = (tile0 + wave) * 32 + r;   // (a tile beyond the rows: zeros all the way, its wavefront keeps the barriers' count)
     const bool rok = row < a.rows && !(m.dbg & 64);
-    float d[kMB][16], xin[kMB][16], xnext[kMB][16];
+    float d[kMB][16], xs[NL][kMB][16];
     {
       const Layer& last = a.L[a.n - 1];
-      mm_load(a.dy, a.lddy, row, rok, last.kind == 1 ? last.out : last.in, hb, d);
-      if (a.n == 1) mm_load(a.x, a.ldx, row, rok, last.in, hb, xnext);
-      else mm_load(a.tape + last.toff, a.tld, row, rok, last.in, hb, xnext);
+      mm_load(a.dy, a.lddy, row, rok, last.kind == 1 ? last.out : last.in, hb, d);   // (first: it arrives under the forward walk)
+      float cur[kMB][16];
+      mm_load(a.x, a.ldx, row, rok, a.L[0].in, hb, cur);
+      // the chain forward again, every layer's input kept (the last layer's output is not needed)
+      mm_static_for<NL>([&](auto IC) __attribute__((always_inline)) {
+        constexpr int i = decltype(IC)::value;
+        if (i < a.n) {
+#pragma unroll
+          for (int ib = 0; ib < kMB; ++ib)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xs[i][ib][e] = cur[ib][e];
+          if (i + 1 < a.n && !(m.dbg & 128)) mm_layer_fwd(m, sm, i, cur, lane, hb);
+        }
+      });
     }
     int lin = m.nlin;
-    for (int i = a.n - 1; i >= 0; --i) {
+    mm_static_for<NL>([&](auto IC) __attribute__((always_inline)) {
+      constexpr int i = NL - 1 - decltype(IC)::value;
+      if (i >= a.n) return;
       const Layer L = a.L[i];
-      // this layer's input was requested one layer earlier; the next layer's goes out now, under this layer's arithmetic (one
-      // wavefront per SIMD: nobody else hides a 2 us miss)
-#pragma unroll
-      for (int ib = 0; ib < kMB; ++ib)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) xin[ib][e] = xnext[ib][e];
-      if (i == 1) mm_load(a.x, a.ldx, row, rok, a.L[0].in, hb, xnext);
-      else if (i > 1) mm_load(a.tape + a.L[i - 1].toff, a.tld, row, rok, a.L[i - 1].in, hb, xnext);
+      float (&xin)[kMB][16] = xs[i];
       // the activation that produced this input: its derivative (from the input's value) closes the data gradient
-      const int pact = (i > 0 && a.L[i - 1].kind == 1) ? a.L[i - 1].act : 0;
+      const int pact = (i > 0 && a.L[i > 0 ? i - 1 : 0].kind == 1) ? a.L[i > 0 ? i - 1 : 0].act : 0;
       if (L.kind == 1) {
         --lin;
         const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5;
-#ifdef SRL_MLP_PROF
-#define SRL_MLP_LSTAMP(k) do { if (it_ == 2) SRL_MLP_STAMP(20 + 5 * lin + (k)); } while (0)
-#else
-#define SRL_MLP_LSTAMP(k) do { } while (0)
-#endif
         SRL_MLP_LSTAMP(0);
 #pragma unroll
         for (int ob = 0; ob < kMB; ++ob)
@@ -341,16 +365,11 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
           // this wavefront's block of the layer, over its share of the four tiles: 4 blocks -> every tile; 2 -> two tiles; 1 -> its own
           const int nblk = nbo * nbi, b = wave % nblk, ob = b / nbi, ib = b - ob * nbi;
           const int per = nblk >= kBwdWaves ? kBwdWaves : nblk, t0 = (wave / nblk) * per;
-          for (int t = t0; t < t0 + per; ++t) {
-            const float* T = tiles + t * kTileF;
-            const float* dH = T + ob * 32 * kTh;
-            const float* xH = T + (kMB + ib) * 32 * kTh;
-            switch (lin) {
-              case 0: mm_wgrad_tile(W0, dH, xH, lane); break;
-              case 1: mm_wgrad_tile(W1, dH, xH, lane); break;
-              case 2: mm_wgrad_tile(W2, dH, xH, lane); break;
-              default: mm_wgrad_tile(W3, dH, xH, lane); break;
-            }
+          switch (lin) {
+            case 0: mm_wgrad_block(W0, tiles, per, t0, ob, ib, lane); break;
+            case 1: mm_wgrad_block(W1, tiles, per, t0, ob, ib, lane); break;
+            case 2: mm_wgrad_block(W2, tiles, per, t0, ob, ib, lane); break;
+            default: mm_wgrad_block(W3, tiles, per, t0, ob, ib, lane); break;
           }
         }
         SRL_MLP_LSTAMP(3);
@@ -365,10 +384,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
             if (ib < nbi && !(m.dbg & 4)) {
 #pragma unroll
               for (int ob = 0; ob < kMB; ++ob)
-                if (ob < nbo) {
-                  const float* wfr = sm + m.wt[i] + (ib * nbo + ob) * 1024 + lane;
-                  mm_chain(acc[ib], wfr, d[ob], mm_ne(L.out, ob));
-                }
+                if (ob < nbo) mm_chain<true>(acc[ib], sm + m.wf[i] + (ob * nbi + ib) * kFB + trow, d[ob], mm_ne(L.out, ob));
             }
           }
 #pragma unroll
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
         // LayerNorm: statistics recomputed from the input; dgamma / dbeta = column sums of gy * xhat / gy (own tile area: no barrier)
         float mean, rstd;
         mm_ln_stats(xin, L.in, hb, mean, rstd);
-        const float* gt = sm + m.wt[i];
+        const float* gt = sm + m.wf[i];
         const int nb = (L.in + 31) >> 5;
         float gg[kMB][16];
         float m1 = 0.f, m2 = 0.f;
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
             }
         }
       }
-    }
+    });
   }
   // ---- the workgroup's sums meet in LDS (the tile region is free), then one atomic per parameter and workgroup ---------------
   __syncthreads();
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
     auto psum = [&](int slot, int c) {   // the four wavefronts' per-channel sums
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < kBwdWaves; ++w) s += sm[m.bwd_floats + w * (m.npg * 64) + slot * 64 + c];
+      for (int w = 0; w < kBwdWaves; ++w) s += sm[m.par_floats + w * (m.npg * 64) + slot * 64 + c];
       return s;
     };
     if (L.kind == 1) {
@@ -488,35 +504,33 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
 // region at the end)
 inline long mm_bwd_lds_bytes(const MArgs& m) {
   const long tiles = (long)kBwdWaves * kTileF, accs = (long)kBwdWaves * kMaxLin * 1024;
-  return 4L * (m.bwd_floats + kBwdWaves * m.npg * 64 + (tiles > accs ? tiles : accs));
+  return 4L * (m.par_floats + kBwdWaves * m.npg * 64 + (tiles > accs ? tiles : accs));
 }
 
 // LDS plan of a chain for the MFMA kernels; false: not eligible
 inline bool mm_plan(MArgs& m) {
   const Args& a = m.a;
-  int f = 0, b = 0, nacc = 0, npg = 0, nlin = 0;
+  if (a.n > kMaxNL) return false;
+  int f = 0, nacc = 0, npg = 0, nlin = 0;
   for (int i = 0; i < a.n; ++i) {
     const Layer& L = a.L[i];
     if (L.in > 32 * kMB || L.out > 32 * kMB) return false;
     const int nbi = (L.in + 31) >> 5, nbo = (L.out + 31) >> 5;
     if (L.kind == 1) {
-      m.wf[i] = f; f += nbo * nbi * 1024;
+      m.wf[i] = f; f += nbo * nbi * kFB;
+      f = (f + 3) & ~3;   // (the tables are read as float4)
       m.tb[i] = f; f += nbo * 32;
-      m.wt[i] = b; if (i > 0) b += nbo * nbi * 1024;
-      m.accb[i] = nacc; nacc += nbo * nbi;
+      nacc += nbo * nbi;
       m.pg[i] = npg; npg += 1;
       ++nlin;
     } else {
       m.wf[i] = f; f += 2 * nbi * 32;
-      m.wt[i] = b; b += nbi * 32;
-      m.accb[i] = nacc;
       m.pg[i] = npg; npg += 2;
     }
   }
-  m.fwd_floats = f; m.bwd_floats = b; m.nacc = nacc; m.npg = npg; m.nlin = nlin;
+  m.par_floats = f; m.nacc = nacc; m.npg = npg; m.nlin = nlin;
   if (nacc > kMaxAcc) return false;
-  const long fwd_bytes = 4L * f;
-  return fwd_bytes <= 150 * 1024 && nlin <= kMaxLin && mm_bwd_lds_bytes(m) <= 158 * 1024;
+  return 4L * f <= 150 * 1024 && nlin <= kMaxLin && mm_bwd_lds_bytes(m) <= 158 * 1024;
 }
 
 }  // namespace

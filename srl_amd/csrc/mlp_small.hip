@@ -298,6 +298,7 @@ int fill(Args& a, const srl_mlp_layer* layers, int n) {
 }  // namespace
 
 #include "mlp_mfma.h"
+#include "mlp_sig.h"
 
 // rows from which the matrix-core chain (mlp_mfma.h) takes over from the FMA chain; SRL_MLP_MFMA=0 switches it off (A/B)
 static long mfma_min_rows() {
@@ -326,19 +327,37 @@ extern "C" int64_t srl_mlp_tape_floats(const srl_mlp_layer* layers, int n) {
   return t < 0 ? -1 : (t > 0 ? t : 1);
 }
 
+// the matrix-core chain keeps no tape: its backward pass walks the chain forward again from x
+static bool mfma_takes(const Args& a, long rows, MArgs& m) {
+  m = MArgs{};
+  m.a = a;
+  return rows >= mfma_min_rows() && mm_plan(m);
+}
+
+extern "C" int64_t srl_mlp_tape_floats_at(const srl_mlp_layer* layers, int n, int64_t rows) {
+  Args a{};
+  const int t = fill(a, layers, n);
+  if (t < 0) return -1;
+  MArgs m;
+  return mfma_takes(a, rows, m) ? 0 : (t > 0 ? t : 1);
+}
+
 extern "C" int srl_mlp_fwd(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows,
                            float* tape, int64_t tape_ld, float* y, int64_t ldy) {
   Args a{};
   const int t = fill(a, layers, n);
   SRL_CHECK_ARG(t >= 0, "unsupported chain (LayerNorm / Linear layers, widths 1..128, at most SRL_MLP_MAX_LAYERS)");
-  SRL_CHECK_ARG(x && y && (n == 1 || tape) && tape_ld >= t && rows >= 0, "null tensor / short tape rows");
+  SRL_CHECK_ARG(x && y && rows >= 0, "null tensor");
   if (rows == 0) return 0;
   a.x = x; a.ldx = ldx; a.rows = rows; a.tape = tape; a.tld = tape_ld; a.y = y; a.ldy = ldy;
-  MArgs m{};
-  m.a = a;
-  if (rows >= mfma_min_rows() && mm_plan(m)) {
+  MArgs m;
+  if (mfma_takes(a, rows, m)) {
+    if (sx_fwd(a, (hipStream_t)stream)) {   // a shape with a kernel of its own (mlp_sig.h)
+      SRL_LAUNCH_CHECK();
+      return 0;
+    }
     const long tiles4 = srl_ceil_div(rows, 128L);
-    const int lds = 4 * m.fwd_floats;
+    const int lds = 4 * m.par_floats;
     static int attr = 0;
     if (lds > attr) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -348,9 +367,22 @@ extern "C" int srl_mlp_fwd(void* stream, const srl_mlp_layer* layers, int n, con
     SRL_LAUNCH_CHECK();
     return 0;
   }
+  SRL_CHECK_ARG((n == 1 || tape) && tape_ld >= t, "null tape / short tape rows");
   hipLaunchKernelGGL(mlp_fwd_kernel, dim3((unsigned)srl_ceil_div(rows, (long)kRB)), dim3(256), 0, (hipStream_t)stream, a);
   SRL_LAUNCH_CHECK();
   return 0;
+}
+
+template <int NL>
+static void launch_bwd_mfma(const MArgs& m, long rows, hipStream_t st) {
+  const long groups = srl_ceil_div(rows, 32L * kBwdWaves);
+  const int lds = (int)mm_bwd_lds_bytes(m);
+  static int attr = 0;
+  if (lds > attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_mfma_kernel<NL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = lds;
+  }
+  hipLaunchKernelGGL(mlp_bwd_mfma_kernel<NL>, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(64 * kBwdWaves), lds, st, m);
 }
 
 extern "C" int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows,
@@ -358,26 +390,25 @@ extern "C" int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, con
   Args a{};
   const int t = fill(a, layers, n);
   SRL_CHECK_ARG(t >= 0, "unsupported chain");
-  SRL_CHECK_ARG(x && dy && (n == 1 || tape) && tape_ld >= t && rows >= 0, "null tensor / short tape rows");
+  SRL_CHECK_ARG(x && dy && rows >= 0, "null tensor");
   for (int i = 0; i < n; ++i) SRL_CHECK_ARG(a.L[i].gw && (a.L[i].gb || (a.L[i].kind == 1 && !a.L[i].b)), "null gradient");
   if (rows == 0) return 0;
   a.x = x; a.ldx = ldx; a.rows = rows; a.tape = const_cast<float*>(tape); a.tld = tape_ld; a.dy = dy; a.lddy = lddy;
-  MArgs m{};
-  m.a = a;
-  if (rows >= mfma_min_rows() && mm_plan(m)) {
+  MArgs m;
+  if (mfma_takes(a, rows, m)) {
     static const int dbg = [] { const char* e = getenv("SRL_MLP_DBG"); return e ? atoi(e) : 0; }();
     m.dbg = dbg;
-    const long groups = srl_ceil_div(rows, 32L * kBwdWaves);
-    const int lds = (int)mm_bwd_lds_bytes(m);
-    static int attr = 0;
-    if (lds > attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr = lds;
+    if (sx_bwd(a, dbg, (hipStream_t)stream)) {
+      SRL_LAUNCH_CHECK();
+      return 0;
     }
-    hipLaunchKernelGGL(mlp_bwd_mfma_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(64 * kBwdWaves), lds, (hipStream_t)stream, m);
+    if (n <= 4) launch_bwd_mfma<4>(m, rows, (hipStream_t)stream);
+    else if (n <= 6) launch_bwd_mfma<6>(m, rows, (hipStream_t)stream);
+    else launch_bwd_mfma<8>(m, rows, (hipStream_t)stream);
     SRL_LAUNCH_CHECK();
     return 0;
   }
+  SRL_CHECK_ARG((n == 1 || tape) && tape_ld >= t, "null tape / short tape rows");
   long groups = srl_ceil_div(rows, (long)kRB);
   if (a.lds_acc && groups > kBwdGroups) groups = kBwdGroups;
   hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, a);

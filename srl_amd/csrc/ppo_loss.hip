@@ -118,10 +118,14 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs a) {
     if (a.truncated) acc[SRL_LT_TRUNC] += (double)a.truncated[i];
   }
   block_sum<SRL_LT_COUNT, 256>(acc, red);
+  // the block's SRL_LT_COUNT sums leave as ONE atomic instruction (lane i adds term i: one request for the line they share)
+  __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int i = 0; i < SRL_LT_COUNT; ++i) atomicAdd(&a.terms[i], acc[i]);
+    for (int i = 0; i < SRL_LT_COUNT; ++i) red[i] = acc[i];
   }
+  __syncthreads();
+  if (threadIdx.x < SRL_LT_COUNT) atomicAdd(&a.terms[threadIdx.x], red[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -292,7 +296,10 @@ extern "C" int srl_ppo_loss_fwd_bwd(void* stream, const float* new_lp, const flo
   if (n == 0) return 0;
   LossArgs a{new_lp, old_lp, value, old_value, adv, ret, entropy, mask, n, value_dim, *hp, norm_stats, local_n,
              done, truncated, d_new_lp, d_value, d_entropy, loss_terms};
-  const unsigned grid = (unsigned)(srl_ceil_div(n, 256) < 2048 ? srl_ceil_div(n, 256) : 2048);
+  // (every block ends in SRL_LT_COUNT float64 atomics on ONE line, which the L2 serialises at ~10 ns each: 2048 blocks
+  // spent 0.2 ms there at 524 288 rows; the grid is capped where the loop's loads still cover the latency)
+  static const long cap = getenv("SRL_LOSS_GRID") ? atol(getenv("SRL_LOSS_GRID")) : 512;
+  const unsigned grid = (unsigned)(srl_ceil_div(n, 256) < cap ? srl_ceil_div(n, 256) : cap);
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(grid), dim3(256), 0, st, a);
   SRL_LAUNCH_CHECK();
   return 0;

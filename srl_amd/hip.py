@@ -25,7 +25,7 @@ _lib = None
 # (bench.py does, before its imports) -- INTEGRATION.md lists it with the other switches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -88,6 +88,7 @@ _SIGNATURES = {
     "srl_absmax": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_dispatch_tiles": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "srl_mlp_tape_floats": (c_int64, [POINTER(MlpLayer), c_int]),
+    "srl_mlp_tape_floats_at": (c_int64, [POINTER(MlpLayer), c_int, c_int64]),
     "srl_mlp_bwd_max_rows": (c_int64, [POINTER(MlpLayer), c_int]),
     "srl_mlp_fwd": (c_int, [c_void_p, POINTER(MlpLayer), c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     "srl_mlp_bwd": (c_int, [c_void_p, POINTER(MlpLayer), c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
@@ -903,6 +904,11 @@ def mlp_layers(layers):
 
 def mlp_tape_floats(arr) -> int:
     return int(lib().srl_mlp_tape_floats(arr, len(arr)))
+
+
+def mlp_tape_floats_at(arr, rows: int) -> int:
+    """Floats per tape row at this row count: 0 when the pair keeps no tape (the matrix-core chain walks forward again)."""
+    return int(lib().srl_mlp_tape_floats_at(arr, len(arr), int(rows)))
 
 
 def mlp_bwd_max_rows(arr) -> int:

@@ -5,6 +5,8 @@ vectors generated from the real reference (``tests/golden/*.npz``).  Tolerances:
 1e-5 relative (the bar BASELINE.json states); network pieces are float32 MFMA chains checked at 1e-5
 relative to the scale of the output (float64-referenced where cheap).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1412,3 +1414,76 @@ def test_first_layer_position_sums_accumulate_over_calls():
         small = hip.conv_desc(8, 21, 21, 64, 2, 2, 1, 32, 1)
         hip.conv2d_obs_bwd(small, s2d.data_ptr(), True, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(),
                            dz.data_ptr(), *[o.data_ptr() for o in own], ws.data_ptr(), channels_last=True, phase=1)
+
+
+_SIG_CHAINS = {
+    "c1-actor": [(0, 4, 4, 0), (1, 4, 64, 1), (0, 64, 64, 0), (1, 64, 64, 1), (1, 64, 64, 1), (1, 64, 2, 0)],
+    "c1-critic": [(0, 4, 4, 0), (1, 4, 64, 1), (0, 64, 64, 0), (1, 64, 64, 1), (1, 64, 64, 1), (1, 64, 1, 0)],
+    "smac-obs": [(0, 30, 30, 0), (1, 30, 64, 1), (0, 64, 64, 0), (1, 64, 64, 1), (0, 64, 64, 0)],
+    "smac-state": [(0, 48, 48, 0), (1, 48, 64, 1), (0, 64, 64, 0), (1, 64, 64, 1), (0, 64, 64, 0)],
+}
+
+
+@pytest.mark.parametrize("rows,chain", [(4096, "c1-actor"), (5003, "c1-critic"), (131072, "c1-actor"), (6001, "smac-obs"),
+                                        (3001, "smac-state")])
+def test_mlp_chain_shape_kernels_match_the_generic_ones(rows, chain):
+    """csrc/mlp_sig.h: the towers of BASELINE configs[0] (LayerNorm 4, 4 -> 64 ReLU, LayerNorm 64, 64 -> 64 ReLU, 64 -> 64 ReLU, 64 ->
+    2 | 1) and the encoders of configs[3]'s multi-agent policy (LayerNorm 30 | 48, -> 64 ReLU, LayerNorm, 64 -> 64 ReLU, LayerNorm)
+    have kernels instantiated for their shape.  Same fragments, same MFMA order: outputs equal the generic matrix-core chain's
+    (SRL_MLP_SIG=0, run in a child process) to the compiler's choice of fused multiply-adds in the LayerNorm arithmetic (1e-6),
+    gradients to the order of the float atomics as well, and both agree with float64 autograd."""
+    import subprocess, sys, json
+    code = r'''
+import sys, json, numpy as np, torch
+from srl_amd import hip
+rows, chain = int(sys.argv[1]), json.loads(sys.argv[2])
+rng = np.random.default_rng(rows)
+din, dout = chain[0][1], (chain[-1][2] if chain[-1][0] == 1 else chain[-1][1])
+host, dev_p, dev_g, desc = [], [], [], []
+for kind, i, o, act in chain:
+    if kind == 0:
+        w, b = 1 + 0.1 * rng.standard_normal(i), 0.1 * rng.standard_normal(i)
+    else:
+        w, b = rng.standard_normal((o, i)) / np.sqrt(i), 0.1 * rng.standard_normal(o)
+    w, b = torch.from_numpy(w.astype(np.float32)), torch.from_numpy(b.astype(np.float32))
+    host += [w, b]
+    dw, db = w.cuda(), b.cuda()
+    gw, gb = torch.zeros_like(dw), torch.zeros_like(db)
+    dev_p += [dw, db]; dev_g += [gw, gb]
+    desc.append((kind, i, o, act, dw.data_ptr(), db.data_ptr(), gw.data_ptr(), gb.data_ptr()))
+arr = hip.mlp_layers(desc)
+assert hip.mlp_tape_floats_at(arr, rows) == 0
+x = torch.from_numpy(rng.standard_normal((rows, din)).astype(np.float32))
+dy = torch.from_numpy(rng.standard_normal((rows, dout)).astype(np.float32))
+dx, ddy = x.cuda(), dy.cuda()
+y = torch.full((rows, dout), float("nan"), device="cuda")
+hip.mlp_fwd(arr, dx.data_ptr(), din, rows, 0, 0, y.data_ptr(), dout)
+hip.mlp_bwd(arr, dx.data_ptr(), din, rows, 0, 0, ddy.data_ptr(), dout)
+torch.cuda.synchronize()
+p64 = [p.double().requires_grad_(True) for p in host]
+h = x.double()
+for li, (kind, i, o, act) in enumerate(chain):
+    w, b = p64[2 * li], p64[2 * li + 1]
+    h = torch.nn.functional.layer_norm(h, (i,), w, b, 1e-5) if kind == 0 else h @ w.t() + b
+    h = torch.relu(h) if act == 1 else h
+h.backward(dy.double())
+err_y = float((y.cpu().double() - h.detach()).abs().max())
+err_g = max(float((g.cpu().double() - p.grad).abs().max() / (p.grad.abs().max() + 1e-6)) for g, p in zip(dev_g, p64))
+np.save(sys.argv[3], np.concatenate([y.cpu().numpy().ravel()] + [g.cpu().numpy().ravel() for g in dev_g]))
+print(json.dumps(dict(err_y=err_y, err_g=err_g, n_y=rows * dout)))
+'''
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for sig in ("1", "0"):
+            env = dict(os.environ, SRL_MLP_SIG=sig, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            r = subprocess.run([sys.executable, "-c", code, str(rows), json.dumps(_SIG_CHAINS[chain]), f"{td}/o{sig}.npy"], env=env,
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[sig] = (json.loads(r.stdout.strip().splitlines()[-1]), np.load(f"{td}/o{sig}.npy"))
+    for sig in ("1", "0"):
+        assert outs[sig][0]["err_y"] < 1e-5 and outs[sig][0]["err_g"] < 2e-5, (sig, outs[sig][0])
+    n_y = outs["1"][0]["n_y"]
+    assert np.allclose(outs["1"][1][:n_y], outs["0"][1][:n_y], rtol=0, atol=1e-6 * np.abs(outs["0"][1][:n_y]).max())
+    g1, g0 = outs["1"][1][n_y:], outs["0"][1][n_y:]
+    assert np.allclose(g1, g0, rtol=0, atol=2e-5 * np.abs(g0).max())
