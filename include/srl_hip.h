@@ -638,6 +638,11 @@ int srl_mlp_fwd(void* stream, const srl_mlp_layer* layers, int n, const float* x
                 int64_t tape_ld, float* y, int64_t ldy);
 int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows,
                 const float* tape, int64_t tape_ld, const float* dy, int64_t lddy);
+/* ... and d loss / d x into dx [rows, lddx] as well -- for a chain that sits BEHIND other layers (the LayerNorm + head after a
+ * recurrent cell, actor_critic_policy.py:117-140 with modules/recurrent.py's cells in front): only for (chain, rows) pairs that
+ * keep no tape (srl_mlp_tape_floats_at == 0); x carries no pending activation. */
+int srl_mlp_bwd_dx(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows, const float* dy,
+                   int64_t lddy, float* dx, int64_t lddx);
 /* sumsq[0] = sum g^2 in float64 (zeroed first).  With data parallelism the caller all-reduces the
  * gradients before this call (DDP semantics), so no further reduction is needed. */
 int srl_grad_sumsq(void* stream, const float* g, int64_t n, double* sumsq);

@@ -127,6 +127,9 @@ class HipNet:
         # SRL_MLP_FUSED=0: layer by layer (A/B)
         self._mlp_fused = os.environ.get("SRL_MLP_FUSED", "1") != "0"
         self._enc_fused = os.environ.get("SRL_ENC_FUSED", "1") != "0"
+        # recurrent nets over vector observations: the whole pass in chunk-major row order (forward(): `cm`); SRL_RNN_CM=0: A/B
+        self._cm_enabled = os.environ.get("SRL_RNN_CM", "1") != "0"
+        self._cm = False
         self._mlp_cache = {}
         self._pver = [0]    # parameter version, shared with the twins (a list: one object)
         self._in_update = [False]
@@ -499,10 +502,10 @@ class HipNet:
         n, K = T * B, T // C
         N = K * B
         assert x.rows == n and x.cols == H and x.ld == H and T % C == 0
-        if K > 1:
+        if K > 1 and not self._cm:
             xc = self._buf(f"{tag}{G.prefix}.xc", n, H)
             hip.chunk_rows(x.ptr, xc.ptr, T, B, C, H)
-        else:
+        else:  # (one chunk, or the whole pass runs on chunk-major rows already)
             xc = x
         h0 = ctx.h0[tag]
         SW = G.state_width
@@ -560,7 +563,7 @@ class HipNet:
             hip.copy2d(y.ptr + 4 * (C - 1) * N * H, H, last[l].data_ptr(), H, N, H)
             saved.append((inp, gi, gh, hin))
             inp = y
-        if K > 1:
+        if K > 1 and not self._cm:
             ytm = self._buf(f"{tag}{G.prefix}.ytm", n, H)
             hip.chunk_rows(inp.ptr, ytm.ptr, T, B, C, H, inverse=True)
         else:
@@ -574,7 +577,7 @@ class HipNet:
         N = K * B
         rs = ctx.reset
         rptr = (lambda c: rs.data_ptr() + c * N) if rs is not None else (lambda c: None)
-        if K > 1:
+        if K > 1 and not self._cm:
             dyc = self._buf(f"{tag}{G.prefix}.dyc", n, H)
             assert dy.ld == H
             hip.chunk_rows(dy.ptr, dyc.ptr, T, B, C, H)
@@ -636,7 +639,7 @@ class HipNet:
             hip.gemm(n, H, 3 * H, gi.ptr, 3 * H, 0, w_ih, H, 1, dx.ptr, H, dact_src=inp.ptr if act else None, ld_dact=inp.ld,
                      dact=act)
             dout = dx
-        if K > 1:
+        if K > 1 and not self._cm:
             dxt = self._buf(f"{tag}{G.prefix}.dxt", n, H)
             hip.chunk_rows(dout.ptr, dxt.ptr, T, B, C, H, inverse=True)
             return dxt
@@ -864,6 +867,9 @@ class HipNet:
                 self._fused_bwd(L, g.ptr, g.ld)   # (releases its layers' buckets itself)
                 g, g_range = None, None
                 continue
+            elif kind == "fusedtail":   # what follows the recurrent layers, head included: g is d loss / d head output
+                g, g_range = self._fused_bwd(L, g.ptr, g.ld), None
+                continue
             elif kind == "h2cnn":
                 L.backward(saved, g)
                 g, g_range = None, None
@@ -1008,7 +1014,7 @@ class HipNet:
             return L.dim
         if kind == "h2cnn":
             return L.H
-        if kind == "fusedenc":
+        if kind in ("fusedenc", "fusedtail"):
             return L["feat"].cols
         if kind == "linear":
             return L.out_features
@@ -1020,7 +1026,10 @@ class HipNet:
             return L.shape[0]
         return L.cout
 
-    def _trunk_fwd(self, tag, encoders, backbone, obs: Dict[str, torch.Tensor], n: int):
+    def _trunk_fwd(self, tag, encoders, backbone, obs: Dict[str, torch.Tensor], n: int, head=None, head_out=None):
+        """``head`` / ``head_out``: the head behind this trunk and the tensor its output goes to -- when the layers that follow the
+        last recurrent layer are LayerNorm / Linear no wider than 64, they and the head run as ONE launch per direction
+        (`fusedtail`; the tape's last field says whether the head went in)."""
         for enc in encoders:
             if enc.key not in obs:
                 raise KeyError(f"observation key `{enc.key}` missing from the sample (has {list(obs)})")
@@ -1052,7 +1061,15 @@ class HipNet:
                 col += o.cols
         bb_tape = []
         cur, cur_act = feat, 0
-        for L in backbone:
+        last_rnn = max((i for i, L in enumerate(backbone) if isinstance(L, ns.GruSpec)), default=-1)
+        for li, L in enumerate(backbone):
+            if (head is not None and li == last_rnn + 1 and last_rnn >= 0 and self._mlp_fused and self._enc_fused and n >= 512
+                    and cur_act == 0 and all(isinstance(M, (ns.LayerNormSpec, ns.LinearSpec)) for M in backbone[li:])):
+                rec = self._fused_layers_fwd((tag, "tail"), f"{tag}tail.", list(backbone[li:]) + [head], cur, n, out=head_out, head=True,
+                                             need_dx=True)
+                if rec is not None:
+                    bb_tape.append(("fusedtail", rec, None, None, 0))
+                    return rec["feat"], 0, (enc_tapes, bb_tape, widths, pieces, True)
             if isinstance(L, ns.LinearSpec):
                 y = self._linear_fwd(L, cur, tag)
                 bb_tape.append(("linear", L, cur, None, cur_act))
@@ -1066,10 +1083,10 @@ class HipNet:
                 y, saved = self._ln_fwd(L, cur, tag)
                 bb_tape.append(("ln", L, cur, saved, cur_act))
                 cur, cur_act = y, 0
-        return cur, cur_act, (enc_tapes, bb_tape, widths, pieces)
+        return cur, cur_act, (enc_tapes, bb_tape, widths, pieces, False)
 
     def _trunk_bwd(self, tag, trunk_tape, dfeat: Buf):
-        enc_tapes, bb_tape, widths, pieces = trunk_tape
+        enc_tapes, bb_tape, widths, pieces, _ = trunk_tape
         g = self._chain_bwd(bb_tape, dfeat, tag, need_input_grad=True) if bb_tape else dfeat
         hook = self.grad_ready_hook
         for pi, (r0, r1) in enumerate(pieces):
@@ -1099,11 +1116,19 @@ class HipNet:
             x = x.gather_raw(self.ws, f"{tag}{enc.key}.ring")
         return self._fused_layers_fwd((tag, head is not None), tag, layers, x, n, out, head is not None)
 
-    def _fused_layers_fwd(self, key, tag, layers, x, n: int, out: Optional[torch.Tensor] = None, head=False):
-        """``layers`` (LayerNorm / Linear, no wider than 128) on the float32 rows ``x`` [n, in] as one launch, or None."""
-        if (not isinstance(x, torch.Tensor) or x.dtype != torch.float32 or x.dim() != 2 or x.shape[0] != n or
-                not x.is_contiguous() or not layers or len(layers) > hip.MLP_MAX_LAYERS):
-            return None
+    def _fused_layers_fwd(self, key, tag, layers, x, n: int, out: Optional[torch.Tensor] = None, head=False, need_dx=False):
+        """``layers`` (LayerNorm / Linear, no wider than 128) on the float32 rows ``x`` [n, in] (a tensor, or a dense Buf of the
+        workspace) as one launch, or None.  ``need_dx``: the backward pass must also return d loss / d x (the chain sits behind
+        other layers) -- only chains that keep no tape can."""
+        if isinstance(x, Buf):
+            if x.rows != n or x.ld != x.cols or not layers or len(layers) > hip.MLP_MAX_LAYERS:
+                return None
+            xptr, xcols = x.ptr, x.cols
+        else:
+            if (not isinstance(x, torch.Tensor) or x.dtype != torch.float32 or x.dim() != 2 or x.shape[0] != n or
+                    not x.is_contiguous() or not layers or len(layers) > hip.MLP_MAX_LAYERS):
+                return None
+            xptr, xcols = x.data_ptr(), x.shape[1]
         for L in layers:
             if isinstance(L, ns.LayerNormSpec):
                 ok = L.dim <= hip.MLP_MAX_WIDTH
@@ -1125,7 +1150,7 @@ class HipNet:
                     desc.append((1, L.in_features, L.out_features, L.act, self._p(w), self._p(b), self._g(w), self._g(b)))
             arr = hip.mlp_layers(desc)
             tld = hip.mlp_tape_floats(arr)
-            if tld < 0 or desc[0][1] != x.shape[1]:
+            if tld < 0 or desc[0][1] != xcols:
                 return None
             last = layers[-1]
             ent = self._mlp_cache[key] = (arr, tld, last.out_features if isinstance(last, ns.LinearSpec) else last.dim,
@@ -1134,16 +1159,32 @@ class HipNet:
         if n > max_rows:
             return None
         # (the matrix-core chain keeps no tape: its backward pass walks forward again from x -- hip.mlp_tape_floats_at is 0 there)
-        tape = self.ws.get(f"{tag}mlp.tape", n * tld) if hip.mlp_tape_floats_at(arr, n) else None
+        taped = hip.mlp_tape_floats_at(arr, n) != 0
+        if need_dx and taped:
+            return None
+        tape = self.ws.get(f"{tag}mlp.tape", n * tld) if taped else None
         y = out if out is not None else self.ws.get(f"{tag}mlp.y", n * width)
-        hip.mlp_fwd(arr, x.data_ptr(), x.shape[1], n, tape.data_ptr() if tape is not None else 0, tld, y.data_ptr(), width)
-        return dict(arr=arr, x=x, tape=tape, tld=tld, n=n, feat=Buf(y.data_ptr(), width, n, width), act=act,
-                    head=head, prefixes=[L.prefix for L in layers])
+        hip.mlp_fwd(arr, xptr, xcols, n, tape.data_ptr() if tape is not None else 0, tld, y.data_ptr(), width)
+        return dict(arr=arr, x=x, xptr=xptr, xcols=xcols, tape=tape, tld=tld, n=n, feat=Buf(y.data_ptr(), width, n, width), act=act,
+                    head=head, prefixes=[L.prefix for L in layers], need_dx=need_dx, tag=tag)
 
-    def _fused_bwd(self, rec, dy_ptr: int, lddy: int):
-        hip.mlp_bwd(rec["arr"], rec["x"].data_ptr(), rec["x"].shape[1], rec["n"], rec["tape"].data_ptr() if rec["tape"] is not None else 0,
-                    rec["tld"], dy_ptr, lddy)
+    def _fused_bwd(self, rec, dy_ptr: int, lddy: int) -> Optional[Buf]:
+        dx = None
+        if rec["need_dx"]:
+            dx = self._buf(f"{rec['tag']}mlp.dx", rec["n"], rec["xcols"])
+            hip.mlp_bwd_dx(rec["arr"], rec["xptr"], rec["xcols"], rec["n"], dy_ptr, lddy, dx.ptr, dx.ld)
+        else:
+            hip.mlp_bwd(rec["arr"], rec["xptr"], rec["xcols"], rec["n"], rec["tape"].data_ptr() if rec["tape"] is not None else 0,
+                        rec["tld"], dy_ptr, lddy)
         self._release(rec["prefixes"])  # one launch: every layer of the chain is final behind it
+        return dx
+
+    @staticmethod
+    def _head_in(tape) -> bool:
+        """Whether the tower's head ran inside its trunk's last launch (a fused chain, or a trunk ending in a `fusedtail`)."""
+        if isinstance(tape, dict):
+            return bool(tape["head"])
+        return bool(tape is not None and len(tape) > 4 and tape[4])
 
     # ------------------------------------------------------------------ public: forward / backward
     def forward(self, obs: Dict[str, torch.Tensor], n: int, keep_tape: bool = True, rnn: Optional[RnnCtx] = None):
@@ -1160,6 +1201,27 @@ class HipNet:
         atot = sum(sp.act_dims)
         logits_t = self.ws.get("logits", n * atot)
         value_t = self.ws.get("value", n * sp.value_dim)
+        # Recurrent nets over vector observations, more than one chunk: the recurrent layers want the rows chunk-major (step c of
+        # every chunk side by side), everything else is row-wise.  Instead of re-ordering the 64-wide features in front of and
+        # behind every recurrent layer, in both directions (8 launches, 0.45 ms of the SMAC-sized step), the OBSERVATIONS are put
+        # into chunk-major order once, the whole pass runs on them, and only the heads' outputs (and their gradients on the way
+        # back) are put back into time-major order: a fifth of the bytes.
+        encs = list(sp.obs_encoders) + ([] if sp.shared_backbone else list(sp.state_encoders))
+        cm = bool(self._cm_enabled and sp.num_rnn_layers and rnn is not None and rnn.T // rnn.C > 1
+                  and sp.std_type != "shared_learnable" and sp.aux_head is None
+                  and all(isinstance(obs.get(e.key), torch.Tensor) and obs[e.key].dim() == 2 and obs[e.key].dtype == torch.float32
+                          and obs[e.key].is_contiguous() for e in encs))
+        self._cm = cm
+        logits_out, value_out = logits_t, value_t
+        if cm:
+            obs = dict(obs)
+            for key in {e.key for e in encs}:
+                x = obs[key]
+                xc = self.ws.get(f"cm.obs.{key}", x.numel())[:x.numel()].view(x.shape)
+                hip.chunk_rows(x.data_ptr(), xc.data_ptr(), rnn.T, rnn.B, rnn.C, x.shape[1])
+                obs[key] = xc
+            logits_t = self.ws.get("cm.logits", n * atot)
+            value_t = self.ws.get("cm.value", n * sp.value_dim)
         # CartPole-sized nets: trunk + head of a separate actor / critic as one launch each (trunk only when the heads share it)
         # (not with PPG's auxiliary value head: it reads the actor trunk's features beside the actor head)
         heads_in = not sp.shared_backbone and sp.std_type != "shared_learnable" and sp.aux_head is None
@@ -1168,7 +1230,8 @@ class HipNet:
         if fa is not None:
             a_feat, a_act, a_tape = fa["feat"], fa["act"], fa
         else:
-            a_feat, a_act, a_tape = self._trunk_fwd("a:", sp.obs_encoders, sp.actor_backbone, obs, n)
+            a_feat, a_act, a_tape = self._trunk_fwd("a:", sp.obs_encoders, sp.actor_backbone, obs, n,
+                                                    head=sp.actor_head if heads_in else None, head_out=logits_t)
         if sp.shared_backbone:
             c_feat, c_act, c_tape = a_feat, a_act, None
         else:
@@ -1177,11 +1240,12 @@ class HipNet:
             if fc is not None:
                 c_feat, c_act, c_tape = fc["feat"], fc["act"], fc
             else:
-                c_feat, c_act, c_tape = self._trunk_fwd("c:", sp.state_encoders, sp.critic_backbone, obs, n)
-        if not (isinstance(a_tape, dict) and a_tape["head"]):
+                c_feat, c_act, c_tape = self._trunk_fwd("c:", sp.state_encoders, sp.critic_backbone, obs, n,
+                                                        head=sp.critic_head if heads_in else None, head_out=value_t)
+        if not self._head_in(a_tape):
             hip.gemm(n, atot, sp.hidden_dim, a_feat.ptr, a_feat.ld, 0, self._p(f"{sp.actor_head.prefix}.weight"), sp.hidden_dim, 0,
                      logits_t.data_ptr(), atot, bias=self._p(f"{sp.actor_head.prefix}.bias"))
-        if not (isinstance(c_tape, dict) and c_tape["head"]):
+        if not self._head_in(c_tape):
             hip.gemm(n, sp.value_dim, sp.hidden_dim, c_feat.ptr, c_feat.ld, 0, self._p(f"{sp.critic_head.prefix}.weight"),
                      sp.hidden_dim, 0, value_t.data_ptr(), sp.value_dim, bias=self._p(f"{sp.critic_head.prefix}.bias"))
         self.log_std_rows = None
@@ -1197,6 +1261,10 @@ class HipNet:
                      aux_t.data_ptr(), sp.value_dim, bias=self._p(f"{sp.aux_head.prefix}.bias"))
             self.aux_value = aux_t[:n * sp.value_dim].view(n, sp.value_dim)
         self._tape = (n, a_feat, a_act, a_tape, c_feat, c_act, c_tape) if keep_tape else None
+        if cm:  # the heads' outputs back into time-major order
+            hip.chunk_rows(logits_t.data_ptr(), logits_out.data_ptr(), rnn.T, rnn.B, rnn.C, atot, inverse=True)
+            hip.chunk_rows(value_t.data_ptr(), value_out.data_ptr(), rnn.T, rnn.B, rnn.C, sp.value_dim, inverse=True)
+            logits_t, value_t = logits_out, value_out
         return logits_t[:n * atot].view(n, atot), value_t[:n * sp.value_dim].view(n, sp.value_dim)
 
     def backward(self, d_logits: torch.Tensor, d_value: torch.Tensor, d_log_std_rows: Optional[torch.Tensor] = None,
@@ -1212,8 +1280,13 @@ class HipNet:
         atot = sum(sp.act_dims)
         dl = Buf(d_logits.data_ptr(), atot, n, atot)
         dv = Buf(d_value.data_ptr(), sp.value_dim, n, sp.value_dim)
-        a_head_in = isinstance(a_tape, dict) and a_tape["head"]
-        c_head_in = isinstance(c_tape, dict) and c_tape["head"]
+        if self._cm:  # the pass ran on chunk-major rows (forward()): so do the gradients
+            rnn = self._rnn
+            dlc, dvc = self._buf("cm.d_logits", n, atot), self._buf("cm.d_value", n, sp.value_dim)
+            hip.chunk_rows(dl.ptr, dlc.ptr, rnn.T, rnn.B, rnn.C, atot)
+            hip.chunk_rows(dv.ptr, dvc.ptr, rnn.T, rnn.B, rnn.C, sp.value_dim)
+            dl, dv = dlc, dvc
+        a_head_in, c_head_in = self._head_in(a_tape), self._head_in(c_tape)
         da = None if a_head_in else self._linear_bwd(sp.actor_head, a_feat, dl, a_act, True, "a:")
         if sp.std_type == "shared_learnable":
             dls = Buf(d_log_std_rows.data_ptr(), atot, n, atot)
@@ -1231,8 +1304,8 @@ class HipNet:
         def trunk_bwd(tag, tape, dfeat, dhead):  # fused chains: one launch, all of its layers released behind it
             if isinstance(tape, dict):
                 self._fused_bwd(tape, dhead.ptr if tape["head"] else dfeat.ptr, dhead.ld if tape["head"] else dfeat.ld)
-            else:
-                self._trunk_bwd(tag, tape, dfeat)
+            else:  # (a trunk whose last record took the head in starts from the head's gradient)
+                self._trunk_bwd(tag, tape, dhead if tape[4] else dfeat)
 
         if sp.shared_backbone:
             self._linear_bwd(sp.critic_head, c_feat, dv, c_act, True, "a:", dx_into=da, dx_accumulate=True)

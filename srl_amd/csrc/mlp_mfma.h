@@ -375,7 +375,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
         SRL_MLP_LSTAMP(3);
         __syncthreads();   // the tile areas are rewritten by the next layer below
         SRL_MLP_LSTAMP(4);
-        if (i > 0) {
+        if (i > 0 || a.dx) {
           f32x16 acc[kMB];
 #pragma unroll
           for (int ib = 0; ib < kMB; ++ib) {
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
         m2 += __shfl_xor(m2, 32);
         m1 /= (float)L.in;
         m2 /= (float)L.in;
-        if (i > 0) {
+        if (i > 0 || a.dx) {
 #pragma unroll
           for (int ib = 0; ib < kMB; ++ib)
 #pragma unroll
@@ -443,6 +443,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_mfma_kernel(MArgs m
         }
       }
     });
+    if (a.dx) mm_store(a.dx, a.lddx, row, row < a.rows, a.L[0].in, hb, d);   // d loss / d x (the chain's input carries no activation)
   }
   // ---- the workgroup's sums meet in LDS (the tile region is free), then one atomic per parameter and workgroup ---------------
   __syncthreads();

@@ -68,6 +68,8 @@ struct XArgs {
   long ldy;
   const float* dy;
   long lddy;
+  float* dx;
+  long lddx;
   const float* w[kMaxNL];
   const float* b[kMaxNL];
   float* gw[kMaxNL];
@@ -246,7 +248,8 @@ __device__ __forceinline__ void sx_half_write(float* T, int r, int hb, const flo
       *reinterpret_cast<float4*>(T + r * kTh + 8 * j + 4 * hb) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
 }
 
-template <class S>
+// DX: d loss / d x is formed and stored as well (chains behind a recurrent layer)
+template <class S, bool DX>
 __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_sig_kernel(XArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hb = lane >> 5;
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_sig_kernel(XArgs a)
           mm_wgrad_tiles<per>(Wb[lin], tiles, t0, ob, ib, lane);
         }
         __syncthreads();   // the tile areas are rewritten by the next layer below
-        if constexpr (i > 0) {
+        if constexpr (i > 0 || DX) {
           f32x16 acc[kMB];
           mm_static_for<nbi>([&](auto IB) __attribute__((always_inline)) {
             constexpr int ib = decltype(IB)::value;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_sig_kernel(XArgs a)
         m2 += __shfl_xor(m2, 32);
         m1 /= (float)in;
         m2 /= (float)in;
-        if constexpr (i > 0) {
+        if constexpr (i > 0 || DX) {
 #pragma unroll
           for (int ib = 0; ib < kMB; ++ib)
 #pragma unroll
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(64 * kBwdWaves, 1) void mlp_bwd_sig_kernel(XArgs a)
         }
       }
     });
+    if constexpr (DX) sx_store<S::in(0)>(a.dx, a.lddx, row, row < a.rows, hb, d);   // (the chain's input carries no activation)
   }
   // ---- the workgroup's sums meet in LDS (the tile region is free), then one atomic per parameter and workgroup ---------------
   __syncthreads();
@@ -435,7 +439,7 @@ constexpr long sx_bwd_lds_bytes() {
 
 inline void sx_args(const Args& a, XArgs& x) {
   x = XArgs{};
-  x.x = a.x; x.ldx = a.ldx; x.rows = a.rows; x.y = a.y; x.ldy = a.ldy; x.dy = a.dy; x.lddy = a.lddy;
+  x.x = a.x; x.ldx = a.ldx; x.rows = a.rows; x.y = a.y; x.ldy = a.ldy; x.dy = a.dy; x.lddy = a.lddy; x.dx = a.dx; x.lddx = a.lddx;
   for (int i = 0; i < a.n && i < kMaxNL; ++i) {
     x.w[i] = a.L[i].w; x.b[i] = a.L[i].b; x.gw[i] = a.L[i].gw; x.gb[i] = a.L[i].gb;
   }
@@ -457,21 +461,33 @@ bool sx_try_fwd(const Args& a, hipStream_t st) {
   hipLaunchKernelGGL(mlp_fwd_sig_kernel<S>, dim3((unsigned)(tiles4 < 768 ? tiles4 : 768)), dim3(256), lds, st, x);
   return true;
 }
-template <class S>
+template <class S, bool DX>
+void sx_launch_bwd(const XArgs& x, long rows, hipStream_t st) {
+  const long groups = srl_ceil_div(rows, 32L * kBwdWaves);
+  constexpr int lds = (int)sx_bwd_lds_bytes<S>();
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_sig_kernel<S, DX>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((mlp_bwd_sig_kernel<S, DX>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(64 * kBwdWaves), lds, st, x);
+}
+// WITH_DX: whether the shape is instantiated with the input gradient too (the chains behind a recurrent layer; the others would
+// only add compile time)
+template <class S, bool WITH_DX>
 bool sx_try_bwd(const Args& a, int dbg, hipStream_t st) {
-  if (!S::matches(a)) return false;
+  if (!S::matches(a) || (a.dx && !WITH_DX)) return false;
   static_assert(sx_bwd_lds_bytes<S>() <= 158 * 1024, "chain does not fit");
   XArgs x;
   sx_args(a, x);
   x.dbg = dbg;
-  const long groups = srl_ceil_div(a.rows, 32L * kBwdWaves);
-  constexpr int lds = (int)sx_bwd_lds_bytes<S>();
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_sig_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr = true;
+  if constexpr (WITH_DX) {
+    if (a.dx) {
+      sx_launch_bwd<S, true>(x, a.rows, st);
+      return true;
+    }
   }
-  hipLaunchKernelGGL(mlp_bwd_sig_kernel<S>, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(64 * kBwdWaves), lds, st, x);
+  sx_launch_bwd<S, false>(x, a.rows, st);
   return true;
 }
 
@@ -485,13 +501,23 @@ using SigC1Actor = MSig<SRL_SIG_LN(4), SRL_SIG_LIN(4, 64, 1), SRL_SIG_LN(64), SR
 using SigC1Critic = MSig<SRL_SIG_LN(4), SRL_SIG_LIN(4, 64, 1), SRL_SIG_LN(64), SRL_SIG_LIN(64, 64, 1), SRL_SIG_LIN(64, 64, 1), SRL_SIG_LIN(64, 1, 0)>;
 using SigSmacObs = MSig<SRL_SIG_LN(30), SRL_SIG_LIN(30, 64, 1), SRL_SIG_LN(64), SRL_SIG_LIN(64, 64, 1), SRL_SIG_LN(64)>;
 using SigSmacState = MSig<SRL_SIG_LN(48), SRL_SIG_LIN(48, 64, 1), SRL_SIG_LN(64), SRL_SIG_LIN(64, 64, 1), SRL_SIG_LN(64)>;
+//  * what follows that policy's recurrent cells: LayerNorm 64 and the head (9 actions on 3m / 1 value), with the gradient w.r.t. the
+//    cell's output.
+using SigSmacActorTail = MSig<SRL_SIG_LN(64), SRL_SIG_LIN(64, 9, 0)>;
+using SigSmacCriticTail = MSig<SRL_SIG_LN(64), SRL_SIG_LIN(64, 1, 0)>;
 
-template <class... Ss>
-struct SigList {
-  static bool fwd(const Args& a, hipStream_t st) { return (sx_try_fwd<Ss>(a, st) || ...); }
-  static bool bwd(const Args& a, int dbg, hipStream_t st) { return (sx_try_bwd<Ss>(a, dbg, st) || ...); }
+template <class S, bool WITH_DX = false>
+struct SigE {
+  using sig = S;
+  static constexpr bool dx = WITH_DX;
 };
-using Sigs = SigList<SigC1Actor, SigC1Critic, SigSmacObs, SigSmacState>;
+template <class... Es>
+struct SigList {
+  static bool fwd(const Args& a, hipStream_t st) { return (sx_try_fwd<typename Es::sig>(a, st) || ...); }
+  static bool bwd(const Args& a, int dbg, hipStream_t st) { return (sx_try_bwd<typename Es::sig, Es::dx>(a, dbg, st) || ...); }
+};
+using Sigs = SigList<SigE<SigC1Actor>, SigE<SigC1Critic>, SigE<SigSmacObs>, SigE<SigSmacState>, SigE<SigSmacActorTail, true>,
+                     SigE<SigSmacCriticTail, true>>;
 
 inline bool sx_enabled() {
   static const bool v = [] { const char* e = getenv("SRL_MLP_SIG"); return !(e && e[0] == '0'); }();

@@ -46,6 +46,8 @@ struct Args {
   long ldy;
   const float* dy;
   long lddy;
+  float* dx;   // backward, matrix-core chains only: d loss / d x [rows, lddx] is stored here (null: not formed)
+  long lddx;
   int lds_acc;  // backward: parameter gradients summed in LDS over the workgroup's row blocks (they fit: <= kMaxP floats)
 };
 
@@ -385,8 +387,22 @@ static void launch_bwd_mfma(const MArgs& m, long rows, hipStream_t st) {
   hipLaunchKernelGGL(mlp_bwd_mfma_kernel<NL>, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(64 * kBwdWaves), lds, st, m);
 }
 
+static int mlp_bwd_impl(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows,
+                        const float* tape, int64_t tape_ld, const float* dy, int64_t lddy, float* dx, int64_t lddx);
+
 extern "C" int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows,
                            const float* tape, int64_t tape_ld, const float* dy, int64_t lddy) {
+  return mlp_bwd_impl(stream, layers, n, x, ldx, rows, tape, tape_ld, dy, lddy, nullptr, 0);
+}
+
+extern "C" int srl_mlp_bwd_dx(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows,
+                              const float* dy, int64_t lddy, float* dx, int64_t lddx) {
+  SRL_CHECK_ARG(dx && layers && n >= 1 && lddx >= layers[0].in, "null dx / short dx rows");
+  return mlp_bwd_impl(stream, layers, n, x, ldx, rows, nullptr, 0, dy, lddy, dx, lddx);
+}
+
+static int mlp_bwd_impl(void* stream, const srl_mlp_layer* layers, int n, const float* x, int64_t ldx, int64_t rows,
+                        const float* tape, int64_t tape_ld, const float* dy, int64_t lddy, float* dx, int64_t lddx) {
   Args a{};
   const int t = fill(a, layers, n);
   SRL_CHECK_ARG(t >= 0, "unsupported chain");
@@ -394,6 +410,7 @@ extern "C" int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, con
   for (int i = 0; i < n; ++i) SRL_CHECK_ARG(a.L[i].gw && (a.L[i].gb || (a.L[i].kind == 1 && !a.L[i].b)), "null gradient");
   if (rows == 0) return 0;
   a.x = x; a.ldx = ldx; a.rows = rows; a.tape = const_cast<float*>(tape); a.tld = tape_ld; a.dy = dy; a.lddy = lddy;
+  a.dx = dx; a.lddx = lddx;
   MArgs m;
   if (mfma_takes(a, rows, m)) {
     static const int dbg = [] { const char* e = getenv("SRL_MLP_DBG"); return e ? atoi(e) : 0; }();
@@ -408,6 +425,7 @@ extern "C" int srl_mlp_bwd(void* stream, const srl_mlp_layer* layers, int n, con
     SRL_LAUNCH_CHECK();
     return 0;
   }
+  SRL_CHECK_ARG(!dx, "srl_mlp_bwd_dx: only chains and row counts that keep no tape (srl_mlp_tape_floats_at == 0) form dx");
   SRL_CHECK_ARG((n == 1 || tape) && tape_ld >= t, "null tape / short tape rows");
   long groups = srl_ceil_div(rows, (long)kRB);
   if (a.lds_acc && groups > kBwdGroups) groups = kBwdGroups;

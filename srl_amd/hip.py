@@ -92,6 +92,7 @@ _SIGNATURES = {
     "srl_mlp_bwd_max_rows": (c_int64, [POINTER(MlpLayer), c_int]),
     "srl_mlp_fwd": (c_int, [c_void_p, POINTER(MlpLayer), c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     "srl_mlp_bwd": (c_int, [c_void_p, POINTER(MlpLayer), c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
+    "srl_mlp_bwd_dx": (c_int, [c_void_p, POINTER(MlpLayer), c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     "srl_conv2d_wgrad_workspace": (c_int64, [_CD]),
     "srl_conv2d_nhwc_wgrad": (c_int, [c_void_p, _CD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_conv2d_dgrad_weight_elems": (c_int64, [_CD]),
@@ -925,6 +926,13 @@ def mlp_bwd(arr, x_ptr, ldx, rows, tape_ptr, tape_ld, dy_ptr, lddy):
     flops = 4.0 * rows * sum(l.in_ * l.out for l in arr if l.kind == 1)
     with _scope("mlp_bwd", flops, "f32"):
         _check(lib().srl_mlp_bwd(_stream(), arr, len(arr), x_ptr, ldx, rows, tape_ptr, tape_ld, dy_ptr, lddy), "srl_mlp_bwd")
+
+
+def mlp_bwd_dx(arr, x_ptr, ldx, rows, dy_ptr, lddy, dx_ptr, lddx):
+    """``mlp_bwd`` that also stores d loss / d x (chains that keep no tape only: ``mlp_tape_floats_at`` == 0)."""
+    flops = 4.0 * rows * sum(l.in_ * l.out for l in arr if l.kind == 1)
+    with _scope("mlp_bwd", flops, "f32"):
+        _check(lib().srl_mlp_bwd_dx(_stream(), arr, len(arr), x_ptr, ldx, rows, dy_ptr, lddy, dx_ptr, lddx), "srl_mlp_bwd_dx")
 
 
 def absmax(x_ptr, n, out_ptr):
