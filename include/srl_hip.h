@@ -604,6 +604,24 @@ int srl_ring_slots(void* stream, const int64_t* refs, int64_t n, int64_t capacit
 int srl_ring_stack_push(void* stream, void* store, const void* planes, const int32_t* prev, int64_t slot0, int64_t n, int C, int H,
                         int W, float* mean, float* rstd);
 
+/* LayerNorm over D features (eps 1e-5) and the 1-2 Linear heads that read its output, in one launch per direction
+ * (csrc/ln_heads.hip): the tail of the reference's shared-backbone actor-critic -- features -> actor logits, critic value
+ * (actor_critic_policy.py:117-140; the CNN / MLP base ends in a LayerNorm, modules/utils.py:154-161).  D in 256 | 512 | 1024; the
+ * heads' outputs together at most SRL_LN_HEADS_MAX_OUT and (outputs + 2) * D * 32 bytes <= 160 KB (srl_ln_heads_supported).
+ * x [n, ldx], head h: W[h] [head_dims[h], D] row-major, b[h] (may be NULL), y[h] [n, ldy[h]].  The normalised features are not
+ * stored: mean / rstd [n] are, and srl_ln_heads_bwd forms the features again from x.  Backward: dy[h] [n, lddy[h]] -> dx
+ * [n, lddx] = d loss / d x times the derivative of the activation that produced x (in_act, from x's value), and dgamma, dbeta,
+ * dW[h], db[h] are ADDED to (float atomics); dx_absmax (optional, zeroed by the caller) receives max |dx|. */
+#define SRL_LN_HEADS_MAX_OUT 8
+int srl_ln_heads_supported(int D, int n_heads, const int32_t* head_dims);
+int srl_ln_heads_fwd(void* stream, const float* x, int64_t ldx, int64_t n, int D, const float* gamma, const float* beta, int n_heads,
+                     const float* const* W, const float* const* b, const int32_t* head_dims, float* const* y, const int64_t* ldy,
+                     float* mean, float* rstd);
+int srl_ln_heads_bwd(void* stream, const float* x, int64_t ldx, int64_t n, int D, const float* gamma, const float* beta,
+                     const float* mean, const float* rstd, int n_heads, const float* const* W, const int32_t* head_dims,
+                     const float* const* dy, const int64_t* lddy, int in_act, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                     float* const* dW, float* const* db, float* dx_absmax);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimiser on one flat parameter buffer.
  * Replaces clip_grad_norm_ / get_grad_norm + torch.optim.Adam/AdamW.step

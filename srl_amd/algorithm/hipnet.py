@@ -129,6 +129,9 @@ class HipNet:
         self._enc_fused = os.environ.get("SRL_ENC_FUSED", "1") != "0"
         # recurrent nets over vector observations: the whole pass in chunk-major row order (forward(): `cm`); SRL_RNN_CM=0: A/B
         self._cm_enabled = os.environ.get("SRL_RNN_CM", "1") != "0"
+        # an encoder's closing LayerNorm + the heads right behind it as one launch per direction (csrc/ln_heads.hip); SRL_LN_HEADS=0: A/B
+        self._lnheads = os.environ.get("SRL_LN_HEADS", "1") != "0"
+        self._lnheads_dv = None
         self._cm = False
         self._mlp_cache = {}
         self._pver = [0]    # parameter version, shared with the twins (a list: one object)
@@ -646,8 +649,10 @@ class HipNet:
         return dout
 
     # ------------------------------------------------------------------ encoders
-    def _encoder_fwd(self, enc: ns.EncoderSpec, obs: torch.Tensor, n: int, tag: str, tape: list) -> Buf:
-        """obs: device tensor [n, *shape] (float32 vectors; uint8 or float32 images)."""
+    def _encoder_fwd(self, enc: ns.EncoderSpec, obs: torch.Tensor, n: int, tag: str, tape: list, lnheads=None) -> Buf:
+        """obs: device tensor [n, *shape] (float32 vectors; uint8 or float32 images).  ``lnheads``: ``(heads, outs)`` when the
+        encoder's closing LayerNorm and the heads behind it are to run as one launch (`_lnheads_ok`): the record `lnheads` then
+        closes the tape and the heads' outputs are in ``outs``."""
         cur: Optional[Buf] = None
         cur_act = 0
         cur_range = None  # device float bounding max |cur| (convolution outputs), or None: range unknown
@@ -676,6 +681,16 @@ class HipNet:
             if skip:  # layers the pre-split block below has already run
                 skip -= 1
                 continue
+            if lnheads is not None and L is enc.layers[-1] and cur is not None and cur.ld == cur.cols == L.dim and cur.rows == n:
+                heads, outs = lnheads
+                mean = self.ws.get(f"{tag}{L.prefix}.mean", n)
+                rstd = self.ws.get(f"{tag}{L.prefix}.rstd", n)
+                hip.ln_heads_fwd(cur.ptr, cur.ld, n, L.dim, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"),
+                                 [self._p(f"{h.prefix}.weight") for h in heads], [self._p(f"{h.prefix}.bias") for h in heads],
+                                 [h.out_features for h in heads], [o.data_ptr() for o in outs], [h.out_features for h in heads],
+                                 mean.data_ptr(), rstd.data_ptr())
+                tape.append(("lnheads", L, cur, (mean, rstd, heads), cur_act))
+                return None
             if isinstance(L, ns.LayerNormSpec):
                 if cur is None:
                     if obs.dtype != torch.float32:
@@ -867,6 +882,19 @@ class HipNet:
                 self._fused_bwd(L, g.ptr, g.ld)   # (releases its layers' buckets itself)
                 g, g_range = None, None
                 continue
+            elif kind == "lnheads":   # closing LayerNorm + heads: g is d loss / d first head's output, the second head's gradient
+                # was left in self._lnheads_dv by backward()
+                mean, rstd, heads = saved
+                dys = [g] + ([self._lnheads_dv] if len(heads) > 1 else [])
+                dx = self._buf(f"{tag}{L.prefix}.dx", x.rows, L.dim)
+                hip.ln_heads_bwd(x.ptr, x.ld, x.rows, L.dim, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"),
+                                 mean.data_ptr(), rstd.data_ptr(), [self._p(f"{h.prefix}.weight") for h in heads],
+                                 [h.out_features for h in heads], [d.ptr for d in dys], [d.ld for d in dys], in_act, dx.ptr, dx.ld,
+                                 self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"),
+                                 [self._g(f"{h.prefix}.weight") for h in heads], [self._g(f"{h.prefix}.bias") for h in heads])
+                self._release([h.prefix for h in heads] + [L.prefix])
+                g, g_range = dx, None
+                continue
             elif kind == "fusedtail":   # what follows the recurrent layers, head included: g is d loss / d head output
                 g, g_range = self._fused_bwd(L, g.ptr, g.ld), None
                 continue
@@ -1016,6 +1044,8 @@ class HipNet:
             return L.H
         if kind in ("fusedenc", "fusedtail"):
             return L["feat"].cols
+        if kind == "lnheads":
+            return L.dim
         if kind == "linear":
             return L.out_features
         if kind == "gru":
@@ -1026,7 +1056,16 @@ class HipNet:
             return L.shape[0]
         return L.cout
 
-    def _trunk_fwd(self, tag, encoders, backbone, obs: Dict[str, torch.Tensor], n: int, head=None, head_out=None):
+    def _lnheads_ok(self, encoders, backbone, heads, n) -> bool:
+        """The encoder's closing LayerNorm and the heads right behind it (no backbone layers between) as one launch."""
+        if not self._lnheads or backbone or len(encoders) != 1 or n > self.encoder_rows or not heads or n < 64:
+            return False
+        last = encoders[0].layers[-1] if encoders[0].layers else None
+        if not isinstance(last, ns.LayerNormSpec) or len(encoders[0].layers) < 2 or any(h.in_features != last.dim or h.act for h in heads):
+            return False
+        return hip.ln_heads_supported(last.dim, [h.out_features for h in heads])
+
+    def _trunk_fwd(self, tag, encoders, backbone, obs: Dict[str, torch.Tensor], n: int, head=None, head_out=None, lnheads=None):
         """``head`` / ``head_out``: the head behind this trunk and the tensor its output goes to -- when the layers that follow the
         last recurrent layer are LayerNorm / Linear no wider than 64, they and the head run as ONE launch per direction
         (`fusedtail`; the tape's last field says whether the head went in)."""
@@ -1047,9 +1086,11 @@ class HipNet:
             tapes, outs = [], []
             for enc in encoders:
                 tape = []
-                outs.append(self._encoder_fwd(enc, obs[enc.key][r0:r1], r1 - r0, ptag, tape))
+                outs.append(self._encoder_fwd(enc, obs[enc.key][r0:r1], r1 - r0, ptag, tape, lnheads=lnheads))
                 tapes.append(tape)
             enc_tapes.append(tapes)
+            if lnheads is not None and tapes[0] and tapes[0][-1][0] == "lnheads":   # (one piece, one encoder: _lnheads_ok)
+                return None, 0, (enc_tapes, [], widths, pieces, "lnheads")
             if len(pieces) == 1 and len(outs) == 1:
                 feat = outs[0]
                 break
@@ -1180,11 +1221,12 @@ class HipNet:
         return dx
 
     @staticmethod
-    def _head_in(tape) -> bool:
-        """Whether the tower's head ran inside its trunk's last launch (a fused chain, or a trunk ending in a `fusedtail`)."""
+    def _head_in(tape):
+        """Whether the tower's head ran inside its trunk's last launch: a fused chain, a trunk ending in a `fusedtail` (True), or
+        an encoder closing in `lnheads` ("lnheads": with a shared backbone BOTH heads ran there).  Falsy otherwise."""
         if isinstance(tape, dict):
             return bool(tape["head"])
-        return bool(tape is not None and len(tape) > 4 and tape[4])
+        return tape[4] if (tape is not None and len(tape) > 4) else False
 
     # ------------------------------------------------------------------ public: forward / backward
     def forward(self, obs: Dict[str, torch.Tensor], n: int, keep_tape: bool = True, rnn: Optional[RnnCtx] = None):
@@ -1230,8 +1272,13 @@ class HipNet:
         if fa is not None:
             a_feat, a_act, a_tape = fa["feat"], fa["act"], fa
         else:
+            lnh = None
+            if sp.std_type != "shared_learnable" and sp.aux_head is None and not sp.num_rnn_layers:
+                hs = [sp.actor_head, sp.critic_head] if sp.shared_backbone else [sp.actor_head]
+                if self._lnheads_ok(sp.obs_encoders, sp.actor_backbone, hs, n):
+                    lnh = (hs, [logits_t, value_t][:len(hs)])
             a_feat, a_act, a_tape = self._trunk_fwd("a:", sp.obs_encoders, sp.actor_backbone, obs, n,
-                                                    head=sp.actor_head if heads_in else None, head_out=logits_t)
+                                                    head=sp.actor_head if heads_in else None, head_out=logits_t, lnheads=lnh)
         if sp.shared_backbone:
             c_feat, c_act, c_tape = a_feat, a_act, None
         else:
@@ -1240,12 +1287,15 @@ class HipNet:
             if fc is not None:
                 c_feat, c_act, c_tape = fc["feat"], fc["act"], fc
             else:
+                lnh = None
+                if sp.aux_head is None and not sp.num_rnn_layers and self._lnheads_ok(sp.state_encoders, sp.critic_backbone, [sp.critic_head], n):
+                    lnh = ([sp.critic_head], [value_t])
                 c_feat, c_act, c_tape = self._trunk_fwd("c:", sp.state_encoders, sp.critic_backbone, obs, n,
-                                                        head=sp.critic_head if heads_in else None, head_out=value_t)
+                                                        head=sp.critic_head if heads_in else None, head_out=value_t, lnheads=lnh)
         if not self._head_in(a_tape):
             hip.gemm(n, atot, sp.hidden_dim, a_feat.ptr, a_feat.ld, 0, self._p(f"{sp.actor_head.prefix}.weight"), sp.hidden_dim, 0,
                      logits_t.data_ptr(), atot, bias=self._p(f"{sp.actor_head.prefix}.bias"))
-        if not self._head_in(c_tape):
+        if not self._head_in(c_tape) and not (sp.shared_backbone and self._head_in(a_tape) == "lnheads"):
             hip.gemm(n, sp.value_dim, sp.hidden_dim, c_feat.ptr, c_feat.ld, 0, self._p(f"{sp.critic_head.prefix}.weight"),
                      sp.hidden_dim, 0, value_t.data_ptr(), sp.value_dim, bias=self._p(f"{sp.critic_head.prefix}.bias"))
         self.log_std_rows = None
@@ -1298,7 +1348,7 @@ class HipNet:
                 dax = Buf(d_aux.data_ptr(), sp.value_dim, n, sp.value_dim)
                 self._linear_bwd(sp.aux_head, a_feat, dax, a_act, True, "a:", dx_into=da, dx_accumulate=True)
             self._release([sp.aux_head.prefix])
-        if sp.shared_backbone:
+        if sp.shared_backbone and not a_head_in:
             self._release([sp.actor_head.prefix])
 
         def trunk_bwd(tag, tape, dfeat, dhead):  # fused chains: one launch, all of its layers released behind it
@@ -1307,14 +1357,18 @@ class HipNet:
             else:  # (a trunk whose last record took the head in starts from the head's gradient)
                 self._trunk_bwd(tag, tape, dhead if tape[4] else dfeat)
 
-        if sp.shared_backbone:
+        if sp.shared_backbone and a_head_in == "lnheads":   # both heads' gradients go into the closing launch
+            self._lnheads_dv = dv
+            trunk_bwd("a:", a_tape, da, dl)
+        elif sp.shared_backbone:
             self._linear_bwd(sp.critic_head, c_feat, dv, c_act, True, "a:", dx_into=da, dx_accumulate=True)
             self._release([sp.critic_head.prefix])
             trunk_bwd("a:", a_tape, da, dl)
         else:
             dc = None if c_head_in else self._linear_bwd(sp.critic_head, c_feat, dv, c_act, True, "c:")
-            if not (a_head_in or c_head_in):
-                self._release([sp.actor_head.prefix, sp.critic_head.prefix])
+            rel = [h.prefix for h, inside in ((sp.actor_head, a_head_in), (sp.critic_head, c_head_in)) if not inside]
+            if rel:   # (a head that ran inside its trunk's closing launch is released there)
+                self._release(rel)
             trunk_bwd("a:", a_tape, da, dl)
             trunk_bwd("c:", c_tape, dc, dv)
         self._join_side()

@@ -154,6 +154,12 @@ _SIGNATURES = {
     "srl_gemm": (c_int, [c_void_p, POINTER(GemmDesc)]),
     "srl_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
                                    c_void_p, c_void_p]),
+    "srl_ln_heads_supported": (c_int, [c_int, c_int, POINTER(c_int32)]),
+    "srl_ln_heads_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, POINTER(c_void_p),
+                                 POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p), POINTER(c_int64), c_void_p, c_void_p]),
+    "srl_ln_heads_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                 POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_int64,
+                                 c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
     "srl_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "srl_obs_ln_stats": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p]),
@@ -670,6 +676,33 @@ def layernorm_bwd(dy_ptr, lddy, x_ptr, ldx, gamma_ptr, mean_ptr, rstd_ptr, rows,
     _check(
         lib().srl_layernorm_bwd(_stream(), dy_ptr, lddy, x_ptr, ldx, gamma_ptr, mean_ptr, rstd_ptr, rows, D, dx_ptr,
                                 lddx, int(dact), dgamma_ptr, dbeta_ptr, dx_absmax), "srl_layernorm_bwd")
+
+
+def _ptr_array(ptrs):
+    return (c_void_p * len(ptrs))(*[p if p else None for p in ptrs])
+
+
+def ln_heads_supported(D: int, head_dims) -> bool:
+    """Whether LayerNorm(D) + these heads run as one launch per direction (csrc/ln_heads.hip)."""
+    return bool(lib().srl_ln_heads_supported(int(D), len(head_dims), _i32_array(head_dims)))
+
+
+def ln_heads_fwd(x_ptr, ldx, n, D, gamma_ptr, beta_ptr, w_ptrs, b_ptrs, head_dims, y_ptrs, ldys, mean_ptr, rstd_ptr):
+    """LayerNorm over D + the heads reading it: y[h] = LN(x) W[h]^T + b[h]; the normalised features are not stored."""
+    flops = 2.0 * n * D * sum(head_dims)
+    with _scope("ln_heads_fwd", flops, "f32"):
+        _check(lib().srl_ln_heads_fwd(_stream(), x_ptr, ldx, n, int(D), gamma_ptr, beta_ptr, len(head_dims), _ptr_array(w_ptrs), _ptr_array(b_ptrs),
+                                      _i32_array(head_dims), _ptr_array(y_ptrs), (c_int64 * len(ldys))(*ldys), mean_ptr, rstd_ptr),
+               "srl_ln_heads_fwd")
+
+
+def ln_heads_bwd(x_ptr, ldx, n, D, gamma_ptr, beta_ptr, mean_ptr, rstd_ptr, w_ptrs, head_dims, dy_ptrs, lddys, in_act, dx_ptr, lddx,
+                 dgamma_ptr, dbeta_ptr, dw_ptrs, db_ptrs, dx_absmax=None):
+    flops = 4.0 * n * D * sum(head_dims)
+    with _scope("ln_heads_bwd", flops, "f32"):
+        _check(lib().srl_ln_heads_bwd(_stream(), x_ptr, ldx, n, int(D), gamma_ptr, beta_ptr, mean_ptr, rstd_ptr, len(head_dims),
+                                      _ptr_array(w_ptrs), _i32_array(head_dims), _ptr_array(dy_ptrs), (c_int64 * len(lddys))(*lddys), int(in_act),
+                                      dx_ptr, lddx, dgamma_ptr, dbeta_ptr, _ptr_array(dw_ptrs), _ptr_array(db_ptrs), dx_absmax), "srl_ln_heads_bwd")
 
 
 def obs_ln_stats(obs_ptr, is_u8, n, D, mean_ptr, rstd_ptr):

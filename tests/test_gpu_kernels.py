@@ -1487,3 +1487,51 @@ print(json.dumps(dict(err_y=err_y, err_g=err_g, n_y=rows * dout)))
     assert np.allclose(outs["1"][1][:n_y], outs["0"][1][:n_y], rtol=0, atol=1e-6 * np.abs(outs["0"][1][:n_y]).max())
     g1, g0 = outs["1"][1][n_y:], outs["0"][1][n_y:]
     assert np.allclose(g1, g0, rtol=0, atol=2e-5 * np.abs(g0).max())
+
+
+@pytest.mark.parametrize("n,D,heads,in_act", [(1000, 512, (6, 1), 1), (257, 256, (3,), 0), (4099, 512, (7, 1), 2), (64, 1024, (2, 1), 1)])
+def test_ln_heads_fused(n, D, heads, in_act):
+    """srl_ln_heads_fwd / srl_ln_heads_bwd (csrc/ln_heads.hip): LayerNorm(D) + the heads behind it as one launch per direction,
+    against float64 autograd -- head outputs, the stored statistics, dx (times the derivative of the activation that produced x)
+    and every parameter gradient (added to what the buffers held); ragged row counts, one and two heads."""
+    rng = np.random.default_rng(n + D)
+    t = torch
+    pre = t.from_numpy(rng.standard_normal((n, D)))
+    x64 = t.relu(pre) if in_act == 1 else (t.tanh(pre) if in_act == 2 else pre)
+    x64 = x64.float().double()   # the values the kernel sees
+    g64 = t.from_numpy(1 + 0.1 * rng.standard_normal(D)).float().double().requires_grad_(True)
+    b64 = t.from_numpy(0.1 * rng.standard_normal(D)).float().double().requires_grad_(True)
+    W64 = [t.from_numpy(rng.standard_normal((a, D)) / np.sqrt(D)).float().double().requires_grad_(True) for a in heads]
+    hb64 = [t.from_numpy(0.1 * rng.standard_normal(a)).float().double().requires_grad_(True) for a in heads]
+    assert hip.ln_heads_supported(D, heads)
+    xin = x64.clone().requires_grad_(True)
+    feat = t.nn.functional.layer_norm(xin, (D,), g64, b64, 1e-5)
+    ys = [feat @ W.t() + hb for W, hb in zip(W64, hb64)]
+    dys = [t.from_numpy(rng.standard_normal((n, a))).float() for a in heads]
+    t.autograd.backward(ys, [d.double() for d in dys])
+    x = dev(x64.float().numpy())
+    g, b = dev(g64.detach().float().numpy()), dev(b64.detach().float().numpy())
+    W, hb = [dev(w.detach().float().numpy()) for w in W64], [dev(v.detach().float().numpy()) for v in hb64]
+    y = [t.full((n, a), float("nan"), device=DEV) for a in heads]
+    mean, rstd = t.empty(n, device=DEV), t.empty(n, device=DEV)
+    hip.ln_heads_fwd(x.data_ptr(), D, n, D, g.data_ptr(), b.data_ptr(), [w.data_ptr() for w in W], [v.data_ptr() for v in hb], list(heads),
+                     [o.data_ptr() for o in y], list(heads), mean.data_ptr(), rstd.data_ptr())
+    for got, ref in zip(y, ys):
+        assert rel_close(got.cpu().numpy(), ref.detach().numpy(), 1e-5, scale=float(ref.abs().max()))
+    assert rel_close(mean.cpu().numpy(), x64.mean(1).numpy(), 1e-5, scale=1.0)
+    assert rel_close(rstd.cpu().numpy(), (1 / t.sqrt(x64.var(1, unbiased=False) + 1e-5)).numpy(), 1e-5, scale=float(rstd.max()))
+    dg, db_ = t.full((D,), 0.5, device=DEV), t.full((D,), 0.5, device=DEV)
+    dW, dhb = [t.full((a, D), 0.5, device=DEV) for a in heads], [t.full((a,), 0.5, device=DEV) for a in heads]
+    dx = t.full((n, D), float("nan"), device=DEV)
+    amax = t.zeros(1, device=DEV)
+    ddy = [dev(d.numpy()) for d in dys]
+    hip.ln_heads_bwd(x.data_ptr(), D, n, D, g.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), [w.data_ptr() for w in W],
+                     list(heads), [d.data_ptr() for d in ddy], list(heads), in_act, dx.data_ptr(), D, dg.data_ptr(), db_.data_ptr(),
+                     [w.data_ptr() for w in dW], [v.data_ptr() for v in dhb], dx_absmax=amax.data_ptr())
+    der = (x64 > 0).double() if in_act == 1 else ((1 - x64 * x64) if in_act == 2 else t.ones_like(x64))
+    ref_dx = xin.grad * der
+    assert rel_close(dx.cpu().numpy(), ref_dx.numpy(), 2e-5, scale=float(ref_dx.abs().max()))
+    assert abs(float(amax) - float(dx.abs().max())) <= 1e-6 * float(dx.abs().max())
+    for got, ref, name in [(dg, g64, "dgamma"), (db_, b64, "dbeta")] + [(a_, b_, f"dW{i}") for i, (a_, b_) in enumerate(zip(dW, W64))] + \
+            [(a_, b_, f"db{i}") for i, (a_, b_) in enumerate(zip(dhb, hb64))]:
+        assert rel_close(got.cpu().numpy() - 0.5, ref.grad.numpy(), 2e-5, scale=float(ref.grad.abs().max()) + 1e-6), name
