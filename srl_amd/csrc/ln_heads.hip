@@ -18,6 +18,7 @@ namespace {
 constexpr float kEps = 1e-5f;       // nn.LayerNorm default
 constexpr int kMaxOut = SRL_LN_HEADS_MAX_OUT;   // outputs of all heads together at most
 constexpr int kWaves = 8;           // wavefronts per workgroup
+constexpr int kDbGroups = 8;        // workgroups that form the heads' bias gradients
 
 struct LhArgs {
   const float* x;
@@ -39,6 +40,7 @@ struct LhArgs {
   float* dW[2];
   float* db[2];
   float* dx_absmax;
+  int dbg;   // timing experiments (wrong results; SRL_LNH_DBG): 1 no final atomics, 2 no LDS meeting either, 4 no row loop
 };
 
 __device__ __forceinline__ float allsum(float v) {
@@ -166,17 +168,16 @@ __global__ __launch_bounds__(64 * kWaves) void ln_heads_bwd_kernel(LhArgs a) {
       for (int k = 0; k < NV; ++k) w[o][k] = 0.f;
     }
   }
-  float accw[kMaxOut][NV], accg[NV], accb[NV], accd[kMaxOut];   // dW, dgamma, dbeta of this lane's channels; db
+  float accw[kMaxOut][NV], accg[NV], accb[NV];   // dW, dgamma, dbeta of this lane's channels
 #pragma unroll
   for (int k = 0; k < NV; ++k) accg[k] = accb[k] = 0.f;
 #pragma unroll
   for (int o = 0; o < kMaxOut; ++o) {
-    accd[o] = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) accw[o][k] = 0.f;
   }
   float amax = 0.f;
-  for (long row = (long)blockIdx.x * kWaves + wave; row < a.n; row += (long)gridDim.x * kWaves) {
+  for (long row = (long)blockIdx.x * kWaves + wave; row < ((a.dbg & 4) ? 0 : a.n); row += (long)gridDim.x * kWaves) {
     float x[NV];
     load_row<NV>(a.x + row * a.ldx, lane, x);
     const float mean = a.mean[row], rstd = a.rstd[row];
@@ -202,8 +203,6 @@ __global__ __launch_bounds__(64 * kWaves) void ln_heads_bwd_kernel(LhArgs a) {
       m1 += gg[k];
       m2 = fmaf(gg[k], xh[k], m2);
     }
-#pragma unroll
-    for (int o = 0; o < kMaxOut; ++o) accd[o] += dyv[o];
     m1 = allsum(m1) / (float)D;
     m2 = allsum(m2) / (float)D;
     float dx[NV];
@@ -222,6 +221,7 @@ __global__ __launch_bounds__(64 * kWaves) void ln_heads_bwd_kernel(LhArgs a) {
   }
   // every wavefront parks its sums in a slot of its own (plain stores), then the workgroup's threads add the slots and send
   // one atomic per parameter
+  if (a.dbg & 2) return;   // (uniform)
   const int per = (AT + 2) * D;
   float* slot = sm + (long)wave * per;
 #pragma unroll
@@ -235,17 +235,35 @@ __global__ __launch_bounds__(64 * kWaves) void ln_heads_bwd_kernel(LhArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int wv = 0; wv < kWaves; ++wv) s += sm[(long)wv * per + e];
+    if (a.dbg & 1) continue;
     float* dst = o == AT ? a.dgamma + c : (o == AT + 1 ? a.dbeta + c : (o < A0 ? a.dW[0] + (long)o * D + c : a.dW[1] + (long)(o - A0) * D + c));
     atomicAdd(dst, s);
   }
-  // bias gradients: every lane of a wavefront holds the same sums; one lane per wavefront adds them
-  if (lane == 0) {
+  // bias gradients = column sums of dy.  NOT one atomic per wavefront from the sums the row loop could keep: 2048 atomics on one
+  // address take ~80 ns each, one after the other (160 us of a 17 us kernel).  The first kDbGroups workgroups sum a slice of dy's
+  // rows each -- 460 KB in all -- and send one atomic per output.
+  const int G = gridDim.x < kDbGroups ? (int)gridDim.x : kDbGroups;
+  if ((int)blockIdx.x < G && (a.db[0] || a.db[1])) {
+    __syncthreads();   // the slots above are read
+    float s[kMaxOut];
 #pragma unroll
-    for (int o = 0; o < kMaxOut; ++o)
-      if (o < AT) {
-        float* dst = o < A0 ? a.db[0] : a.db[1];
-        if (dst) atomicAdd(dst + (o < A0 ? o : o - A0), accd[o]);
-      }
+    for (int o = 0; o < kMaxOut; ++o) s[o] = 0.f;
+    const long r0 = a.n * blockIdx.x / G, r1 = a.n * (blockIdx.x + 1) / G;
+    for (long row = r0 + tid; row < r1; row += 64 * kWaves) {
+#pragma unroll
+      for (int o = 0; o < kMaxOut; ++o)
+        if (o < AT) s[o] += o < A0 ? a.dy[0][row * a.lddy[0] + o] : a.dy[1][row * a.lddy[1] + o - A0];
+    }
+    const float tot = allsum8(s, lane);   // lanes 0..7: the wavefront's total of slot8(lane)
+    if (lane < 8) sm[wave * 8 + slot8(lane)] = tot;
+    __syncthreads();
+    if (tid < AT) {
+      float v = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < kWaves; ++wv) v += sm[wv * 8 + tid];
+      float* dst = tid < A0 ? a.db[0] : a.db[1];
+      if (dst) atomicAdd(dst + (tid < A0 ? tid : tid - A0), v);
+    }
   }
 }
 
@@ -333,6 +351,8 @@ extern "C" int srl_ln_heads_bwd(void* stream, const float* x, int64_t ldx, int64
     SRL_CHECK_ARG(dy[h] && lddy[h] >= head_dims[h] && dW[h], "null head gradient");
     a.W[h] = W[h]; a.A[h] = head_dims[h]; a.dy[h] = dy[h]; a.lddy[h] = lddy[h]; a.dW[h] = dW[h]; a.db[h] = db ? db[h] : nullptr;
   }
+  static const int dbg = [] { const char* e = getenv("SRL_LNH_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;
   if (D == 256) launch_bwd<4>(a, st);
   else if (D == 512) launch_bwd<8>(a, st);
