@@ -149,7 +149,14 @@ class H2Cnn:
         return y, saved
 
     # ------------------------------------------------------------------ backward
-    def backward(self, saved, dy):
+    def open_backward(self, saved) -> int:
+        """Zero the backward pass's measured ranges and return the address of dy's: a producer that tracks max |dy| while it writes
+        dy (srl_ln_heads_bwd) leaves it there and calls ``backward(..., dy_ranged=True)``."""
+        tag = saved["tag"]
+        self._slots(tag)[M_DY:M_DZ1 + 1].zero_()
+        return self._slot(M_DY, tag)
+
+    def backward(self, saved, dy, dy_ranged=False):
         """dy: Buf float32 [n, H], the gradient with respect to the Linear's pre-activation (its ReLU derivative already
         applied by the layer above).  Adds every parameter gradient of the five layers."""
         net, ws = self.net, self.net.ws
@@ -158,10 +165,11 @@ class H2Cnn:
         t = f"{tag}{self.pfx}"
         W = self._slot
         P = lambda i: self._slot(i, tag)
-        self._slots(tag)[M_DY:M_DZ1 + 1].zero_()
         assert dy.ld == dy.cols == self.H and dy.rows == n
-        # dy -> h2p rows (its range from one pass: the producer is a float32 kernel)
-        hip.absmax(dy.ptr, n * self.H, P(M_DY))
+        if not dy_ranged:
+            self.open_backward(saved)
+            # dy -> h2p rows (its range from one pass: the producer is a float32 kernel that did not track it)
+            hip.absmax(dy.ptr, n * self.H, P(M_DY))
         dyh = self._bytes(f"{t}dy", n * self.H * 4)
         hip.h2_pack_rows(dy.ptr, self.H, n, self.H, dyh, absmax=P(M_DY), scale_out=P(S_DY))
         # Linear: weight gradient beside the data-gradient chain

@@ -887,19 +887,23 @@ class HipNet:
                 mean, rstd, heads = saved
                 dys = [g] + ([self._lnheads_dv] if len(heads) > 1 else [])
                 dx = self._buf(f"{tag}{L.prefix}.dx", x.rows, L.dim)
+                # a pre-split block below wants max |dx|: tracked here while dx is written, instead of one more pass over it
+                below = records[idx - 1] if idx > 0 else None
+                amax = below[1].open_backward(below[3]) if (below is not None and below[0] == "h2cnn") else None
                 hip.ln_heads_bwd(x.ptr, x.ld, x.rows, L.dim, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"),
                                  mean.data_ptr(), rstd.data_ptr(), [self._p(f"{h.prefix}.weight") for h in heads],
                                  [h.out_features for h in heads], [d.ptr for d in dys], [d.ld for d in dys], in_act, dx.ptr, dx.ld,
                                  self._g(f"{L.prefix}.weight"), self._g(f"{L.prefix}.bias"),
-                                 [self._g(f"{h.prefix}.weight") for h in heads], [self._g(f"{h.prefix}.bias") for h in heads])
+                                 [self._g(f"{h.prefix}.weight") for h in heads], [self._g(f"{h.prefix}.bias") for h in heads],
+                                 dx_absmax=amax)
                 self._release([h.prefix for h in heads] + [L.prefix])
-                g, g_range = dx, None
+                g, g_range = dx, ("tracked" if amax is not None else None)
                 continue
             elif kind == "fusedtail":   # what follows the recurrent layers, head included: g is d loss / d head output
                 g, g_range = self._fused_bwd(L, g.ptr, g.ld), None
                 continue
             elif kind == "h2cnn":
-                L.backward(saved, g)
+                L.backward(saved, g, dy_ranged=(g_range == "tracked"))
                 g, g_range = None, None
                 continue   # (the block released its layers one by one)
             elif kind == "gru":
