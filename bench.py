@@ -178,9 +178,10 @@ def mlp_roofline(device, T=128, B=4096, steps=10, trainer_args=None):
                 bound="mfma", achieved=round(ach, 3), unit="TFLOP/s", peak=PEAK_FP32_MFMA_TFLOPS, frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 5),
                 ms_per_step=round(ms, 3), env_steps_per_s=round(T * B / (ms * 1e-3)), flops_per_step=flops, traffic=None,
                 kernel_family_launches={k: v // steps for k, v in disp.items()} if isinstance(disp, dict) else disp,
-                note="64-wide layers: 102.5 kFLOP per env-step against ~1 KB of activations moved, so the update is bound by its "
-                     "element-wise / LayerNorm-free chain and launch count long before the matrix pipe; frac is against the float32 "
-                     "MFMA peak (SURVEY 8d)")
+                note="each tower is ONE launch per direction (csrc/mlp_sig.h: the chain's shape is a template argument; no tape -- the "
+                     "backward pass walks the chain forward again from the 16-byte observation rows): 168 float32 MFMAs per 32 rows "
+                     "forward, 496 backward; `frac` counts the ALGORITHMIC 102.5 kFLOP per env-step over the whole update (GAE scan, "
+                     "loss, optimiser included) against the float32-MFMA peak (SURVEY 8d)")
 
 
 def smac_config_leg(device, steps=10):
@@ -320,7 +321,7 @@ def other_configs(line, device):
                      "executor, not per row; the rest of `fixed_cost_ms_per_update` is host launch latency and pipeline ramps "
                      "(4 row chunks = one per pipeline: nothing left to overlap)",
                 gae_scan_ms=kms.get("gae_scan"), grad_sumsq_ms=kms.get("grad_sumsq"), adam_step_ms=kms.get("adam_step"),
-                layernorm_and_loss_ms=round(sum(v for k, v in kms.items() if k.startswith("layernorm") or k.startswith("ppo_loss") or
+                layernorm_and_loss_ms=round(sum(v for k, v in kms.items() if k.startswith("layernorm") or k.startswith("ln_heads") or k.startswith("ppo_loss") or
                                                 k.startswith("categorical")), 3),
                 profiled_kernel_launches_per_update=shard.get("launches_per_step")))
         if "error" not in shard_dist:
