@@ -278,3 +278,22 @@ def test_executor_host_logic_of_round_3():
     assert not net._derived_fresh("w", 2000) and not twin._derived_fresh("w", 1000)
     net.chunks_of_one_update(False)
     assert not net._derived_fresh("w", 2000) and not twin._derived_fresh("w", 1000)
+
+
+def test_host_side_queries_of_the_fused_kernels():
+    """The planning queries the Python side makes before a launch are host code (no GPU): which (chain, rows) pairs keep no
+    tape (srl_mlp_tape_floats_at -- the matrix-core chains walk forward again in their backward pass) and which LayerNorm + heads
+    tails run as one launch (srl_ln_heads_supported)."""
+    from srl_amd import hip
+    chain = [(0, 4, 4, 0, 1, 1, 1, 1), (1, 4, 64, 1, 1, 1, 1, 1), (0, 64, 64, 0, 1, 1, 1, 1), (1, 64, 2, 0, 1, 1, 1, 1)]
+    arr = hip.mlp_layers(chain)
+    full = hip.mlp_tape_floats(arr)
+    assert full == 4 + 64 + 64
+    assert hip.mlp_tape_floats_at(arr, 511) == full        # the FMA chain keeps every layer's input
+    assert hip.mlp_tape_floats_at(arr, 512) == 0           # the matrix-core chain keeps none
+    wide = hip.mlp_layers([(1, 4, 128, 1, 1, 1, 1, 1), (1, 128, 2, 0, 1, 1, 1, 1)])
+    assert hip.mlp_tape_floats_at(wide, 65536) == hip.mlp_tape_floats(wide) == 128   # wider than 64: not a matrix-core chain
+    assert hip.ln_heads_supported(512, (6, 1)) and hip.ln_heads_supported(256, (8,)) and hip.ln_heads_supported(1024, (2, 1))
+    assert not hip.ln_heads_supported(512, (8, 1))     # nine outputs
+    assert not hip.ln_heads_supported(1024, (6, 1))    # (outputs + 2) * D * 32 bytes of LDS
+    assert not hip.ln_heads_supported(384, (6, 1)) and not hip.ln_heads_supported(512, ())
