@@ -576,6 +576,10 @@ typedef struct srl_h2_gemm_desc {
   float* out_absmax; uint32_t* mask_out; const uint32_t* mask_in; int32_t mask_in_h2order;
 } srl_h2_gemm_desc;
 int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d);
+/* ... with the reduction split over `ksplits` workgroups per tile: out is [ksplits][M][NC] float32 slabs of raw partial sums (no
+ * bias / activation / masks / h2 output: the consumer adds the slabs, e.g. srl_ln_heads_fwd's x_slabs).  For row counts that leave
+ * most CUs without a tile -- the Linear forward (modules/cnn.py:128-133) of an inference batch.  NC a multiple of 128. */
+int srl_h2_gemm_splitk(void* stream, const srl_h2_gemm_desc* d, int32_t ksplits);
 /* srl_conv2d_obs_fwd with the output as the h2p rows kind 0 above reads (ent_order 2) instead of float32: byte kernels
  * only (uint8 channels-last frames, Cout 32), y_mask / y_absmax / workspace required; *y_scale = the scale used. */
 int srl_conv2d_obs_fwd_h2(void* stream, const srl_conv_desc* d, const void* obs, const float* mean, const float* rstd,
@@ -611,12 +615,15 @@ int srl_ring_stack_push(void* stream, void* store, const void* planes, const int
  * x [n, ldx], head h: W[h] [head_dims[h], D] row-major, b[h] (may be NULL), y[h] [n, ldy[h]].  The normalised features are not
  * stored: mean / rstd [n] are, and srl_ln_heads_bwd forms the features again from x.  Backward: dy[h] [n, lddy[h]] -> dx
  * [n, lddx] = d loss / d x times the derivative of the activation that produced x (in_act, from x's value), and dgamma, dbeta,
- * dW[h], db[h] are ADDED to (float atomics); dx_absmax (optional, zeroed by the caller) receives max |dx|. */
+ * dW[h], db[h] are ADDED to (float atomics); dx_absmax (optional, zeroed by the caller) receives max |dx|.
+ * Forward only (inference: nothing is kept for a backward pass): x may be the raw output of a split product -- x_slabs slabs,
+ * x_slab_stride floats apart (srl_h2_gemm_splitk) -- finished while it is read: x = act(sum of the slabs + x_bias), x_act as
+ * srl_mlp_layer::act; (1, 0, NULL, 0) for a plain x. */
 #define SRL_LN_HEADS_MAX_OUT 8
 int srl_ln_heads_supported(int D, int n_heads, const int32_t* head_dims);
 int srl_ln_heads_fwd(void* stream, const float* x, int64_t ldx, int64_t n, int D, const float* gamma, const float* beta, int n_heads,
                      const float* const* W, const float* const* b, const int32_t* head_dims, float* const* y, const int64_t* ldy,
-                     float* mean, float* rstd);
+                     float* mean, float* rstd, int x_slabs, int64_t x_slab_stride, const float* x_bias, int x_act);
 int srl_ln_heads_bwd(void* stream, const float* x, int64_t ldx, int64_t n, int D, const float* gamma, const float* beta,
                      const float* mean, const float* rstd, int n_heads, const float* const* W, const int32_t* head_dims,
                      const float* const* dy, const int64_t* lddy, int in_act, float* dx, int64_t lddx, float* dgamma, float* dbeta,

@@ -112,9 +112,21 @@ class H2Cnn:
         hip.h2_weights(p(f"{self.fc.prefix}.weight"), 3136, self.H, 1, amax, W(S_WFT), W(R_WFT), self._wbytes("wft", self.H * 3136 * 4))
 
     # ------------------------------------------------------------------ forward
-    def forward(self, tag, staged, obs, n, is_u8, src, mean, rstd, row_index):
+    # (inference batches: the Linear's 3136-long reduction split over this many workgroups per tile when the rows alone leave most
+    # CUs idle -- 2048 rows are 32 tiles: 104 us; SRL_FC_SPLITK=1 switches it off, A/B)
+    FC_SPLITK = int(os.environ.get("SRL_FC_SPLITK", "0"))
+
+    def fc_splits(self, n: int) -> int:
+        tiles = -(-n // 256) * (self.H // 128)
+        if self.FC_SPLITK:
+            return self.FC_SPLITK if n <= 8192 else 1
+        return max(1, min(8, 256 // tiles)) if (tiles <= 128 and self.H % 128 == 0) else 1
+
+    def forward(self, tag, staged, obs, n, is_u8, src, mean, rstd, row_index, split_fc=False):
         """The four layers on `n` rows.  src / mean / rstd / row_index: the first layer's staged frames and statistics as
-        `_encoder_fwd` resolved them.  Returns (y Buf float32 [n, H] with its sign mask, saved)."""
+        `_encoder_fwd` resolved them.  Returns (y Buf float32 [n, H] with its sign mask, saved).  ``split_fc`` (inference, the
+        consumer finishes the product: `srl_ln_heads_fwd`'s x_slabs): y is then slab 0 of `saved["fc_slabs"]` = (slabs, stride in
+        floats, bias pointer, activation) raw partial sums."""
         net, ws = self.net, self.net.ws
         self._prepare_weights()
         t = f"{tag}{self.pfx}"
@@ -142,10 +154,16 @@ class H2Cnn:
                     bias=net._p(f"{self.c3.prefix}.bias"), act=1, out_scale=P(S_A3), bound_in=P(M_A2),
                     bound_w=W(R_W3), bound_b=W(B_W3), mask_out=m3)
         # Linear: float32 out (the layers behind it take the ReLU derivative from these floats, as after `_linear_fwd`)
+        ks = self.fc_splits(n) if split_fc else 1
+        saved = dict(n=n, a1=a1, a2=a2, a3=a3, m1=m1, m2=m2, m3=m3, first=(src, is_u8, mean, rstd, row_index), tag=tag)
+        if ks > 1:
+            y = net._buf(f"{tag}{self.fc.prefix}.yslabs", ks * n, self.H)
+            hip.h2_gemm_splitk(a3, self._wbytes("wf", 0), P(S_A3), W(S_WF), n, self.H, 3136, y.ptr, ks)
+            saved["fc_slabs"] = (ks, n * self.H, net._p(f"{self.fc.prefix}.bias"), self.fc.act)
+            return y._replace(rows=n), saved
         y = net._buf(f"{tag}{self.fc.prefix}.y", n, self.H)
         hip.h2_gemm(a3, self._wbytes("wf", 0), P(S_A3), W(S_WF), n, self.H, 3136, y.ptr,
                     bias=net._p(f"{self.fc.prefix}.bias"), act=1)
-        saved = dict(n=n, a1=a1, a2=a2, a3=a3, m1=m1, m2=m2, m3=m3, first=(src, is_u8, mean, rstd, row_index), tag=tag)
         return y, saved
 
     # ------------------------------------------------------------------ backward

@@ -132,6 +132,7 @@ class HipNet:
         # an encoder's closing LayerNorm + the heads right behind it as one launch per direction (csrc/ln_heads.hip); SRL_LN_HEADS=0: A/B
         self._lnheads = os.environ.get("SRL_LN_HEADS", "1") != "0"
         self._lnheads_dv = None
+        self._infer = False
         self._cm = False
         self._mlp_cache = {}
         self._pver = [0]    # parameter version, shared with the twins (a list: one object)
@@ -685,10 +686,12 @@ class HipNet:
                 heads, outs = lnheads
                 mean = self.ws.get(f"{tag}{L.prefix}.mean", n)
                 rstd = self.ws.get(f"{tag}{L.prefix}.rstd", n)
+                slabs = tape[-1][3].get("fc_slabs") if (tape and tape[-1][0] == "h2cnn") else None
+                ks, stride, xb, xact = slabs if slabs else (1, 0, None, 0)
                 hip.ln_heads_fwd(cur.ptr, cur.ld, n, L.dim, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"),
                                  [self._p(f"{h.prefix}.weight") for h in heads], [self._p(f"{h.prefix}.bias") for h in heads],
                                  [h.out_features for h in heads], [o.data_ptr() for o in outs], [h.out_features for h in heads],
-                                 mean.data_ptr(), rstd.data_ptr())
+                                 mean.data_ptr(), rstd.data_ptr(), x_slabs=ks, x_slab_stride=stride, x_bias=xb, x_act=xact)
                 tape.append(("lnheads", L, cur, (mean, rstd, heads), cur_act))
                 return None
             if isinstance(L, ns.LayerNormSpec):
@@ -816,7 +819,10 @@ class HipNet:
                     if (h2 is not None and implicit and is_u8 and L.s2d and n >= self.H2_MIN_ROWS
                             and hip.conv2d_obs_row_index_supported(desc, is_u8, True)):
                         # the whole convolution stack and the Linear behind it on pre-split activations (h2path.py)
-                        y2, saved2 = h2.forward(tag, staged, obs, n, is_u8, src, mean, rstd, row_index)
+                        # (inference with the closing LayerNorm + heads as the consumer: the Linear's reduction may be split
+                        # over workgroups, the consumer adds the slabs)
+                        split = bool(lnheads is not None and self._infer and len(enc.layers) == 6 and enc.layers[4] is h2.fc)
+                        y2, saved2 = h2.forward(tag, staged, obs, n, is_u8, src, mean, rstd, row_index, split_fc=split)
                         tape.append(("h2cnn", h2, None, saved2, 0))
                         cur, cur_act, cur_range = y2, h2.fc.act, None
                         skip = 3
@@ -1240,6 +1246,7 @@ class HipNet:
         hip.require_gpu()
         sp = self.spec
         self._rnn = rnn
+        self._infer = not keep_tape   # nothing of this pass is kept for a backward pass
         self._amax_next = -1
         self.last_state = {}
         if sp.num_rnn_layers and (rnn is None or rnn.T * rnn.B != n):

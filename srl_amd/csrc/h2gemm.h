@@ -87,6 +87,11 @@ struct H2Args {
   const uint32_t* mask_in;  // out *= bit of this mask at the output element (relu derivative), or null
   int32_t mask_in_h2;       // mask_in's bits are in h2 order (bit 8 g + j of a 32-block's word: what h2conv.h's forward kernels write)
   int32_t dbg;              // timing experiments (wrong results; SRL_H2G_DBG): 1 no DMA, 2 no fragment reads / MFMAs, 4 no epilogue stores
+  // DENSE only: the reduction split over `ksplits` workgroups per tile, split s writing its raw partial sums (no bias, activation or
+  // mask: the consumer adds the slabs) to out + s * slab_bytes.  A few hundred rows times a long reduction (the Linear forward of
+  // an inference batch: 2048 x 512 over K = 3136 is 32 tiles on 256 CUs, each filling 4.8 MB at a CU's ~33 GB/s: 104 us).
+  int32_t ksplits;
+  int64_t slab_bytes;
 };
 
 #ifdef __HIPCC__
@@ -217,6 +222,11 @@ __global__ __launch_bounds__(HALF ? 256 : 512, 2) void h2gemm_kernel(H2Args g) {
     const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     lid = xcd * q + (xcd < r ? xcd : r) + slot;
   }
+  unsigned ks = 0;   // this workgroup's slice of the reduction
+  if (XMODE == H2X_DENSE && g.ksplits > 1) {
+    ks = lid % (unsigned)g.ksplits;
+    lid /= (unsigned)g.ksplits;
+  }
   const unsigned tile_c = lid % (unsigned)g.tiles_c, tile_p = lid / (unsigned)g.tiles_c;
   const int c0 = tile_c * (NCB * 32);
 
@@ -271,6 +281,11 @@ __global__ __launch_bounds__(HALF ? 256 : 512, 2) void h2gemm_kernel(H2Args g) {
 
   // ---- k-step sequence
   int nsteps = HALF ? 2 * g.nk : g.nk;
+  int step0 = 0;
+  if (XMODE == H2X_DENSE && g.ksplits > 1) {
+    step0 = (int)((long)ks * nsteps / g.ksplits);
+    nsteps = (int)((long)(ks + 1) * nsteps / g.ksplits) - step0;
+  }
   uint64_t vmask = 0;  // GROUPED: valid taps
   const int cbk = XMODE == H2X_GROUPED ? g.C / 32 : 1;
   if (XMODE == H2X_GROUPED) {
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512, 2) void h2gemm_kernel(H2Args g) {
   int gt = -1, gcb = cbk - 1;  // GROUPED iterator state: current tap, channel block
   auto step_offsets = [&](int t, uint32_t& sx, uint32_t& sw) {
     if (XMODE == H2X_DENSE) {
-      sx = sw = (uint32_t)t * (uint32_t)PITCH;
+      sx = sw = (uint32_t)(t + step0) * (uint32_t)PITCH;
     } else if (XMODE == H2X_CONV) {
       sx = g.koff_x[t];
       sw = g.koff_w[t];
@@ -537,7 +552,8 @@ __global__ __launch_bounds__(HALF ? 256 : 512, 2) void h2gemm_kernel(H2Args g) {
           const uint4 val = *reinterpret_cast<const uint4*>(tb + (8 * it + rr) * 128 + 16 * (pp ^ rr));
           const long rowg = m0 + wp * 64 + j * 32 + 8 * it + rr;
           if (rowg < g.M)
-            *reinterpret_cast<uint4*>(static_cast<uint8_t*>(g.out) + rowg * (long)g.out_row_bytes + (long)cb * 128 + 16 * pp) = val;
+            *reinterpret_cast<uint4*>(static_cast<uint8_t*>(g.out) + (long)ks * g.slab_bytes + rowg * (long)g.out_row_bytes + (long)cb * 128 +
+                                      16 * pp) = val;
         }
         continue;
       }
@@ -584,7 +600,8 @@ inline int h2gemm_launch(hipStream_t st, H2Args a) {
   long tiles_p;
   if (XMODE == H2X_GROUPED) tiles_p = ((a.M + BP - 1) / BP) * (long)(a.GH * a.GW);
   else tiles_p = (a.M + BP - 1) / BP;
-  const long nblk = tiles_p * a.tiles_c;
+  if (a.ksplits < 1 || XMODE != H2X_DENSE) a.ksplits = 1;
+  const long nblk = tiles_p * a.tiles_c * a.ksplits;
   if (nblk <= 0 || nblk > 0x7fffffffL) return -22;
   static bool attr_set = false;
   auto kern = h2gemm_kernel<NCB, XMODE, S, KSPLIT, HALF>;

@@ -40,6 +40,12 @@ struct LhArgs {
   float* dW[2];
   float* db[2];
   float* dx_absmax;
+  // forward: x = act(sum of x_slabs slabs (x_slab_stride floats apart) + x_bias) -- the raw partial sums of a split product
+  // (srl_h2_gemm_splitk) finished while they are read
+  int x_slabs;
+  long x_slab_stride;
+  const float* x_bias;
+  int x_act;
   int dbg;   // timing experiments (wrong results; SRL_LNH_DBG): 1 no final atomics, 2 no LDS meeting either, 4 no row loop
 };
 
@@ -115,9 +121,26 @@ __global__ __launch_bounds__(64 * kWaves) void ln_heads_fwd_kernel(LhArgs a) {
   }
   const int so = slot8(lane);
   const float bias = so < AT ? (so < a.A[0] ? (a.b[0] ? a.b[0][so] : 0.f) : (a.b[1] ? a.b[1][so - a.A[0]] : 0.f)) : 0.f;
+  float xb[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) xb[k] = 0.f;
+  if (a.x_bias) load_row<NV>(a.x_bias, lane, xb);
   for (long row = (long)blockIdx.x * kWaves + wave; row < a.n; row += (long)gridDim.x * kWaves) {
     float x[NV];
     load_row<NV>(a.x + row * a.ldx, lane, x);
+    if (a.x_slabs > 1 || a.x_bias || a.x_act) {
+      for (int sl = 1; sl < a.x_slabs; ++sl) {
+        float t[NV];
+        load_row<NV>(a.x + sl * a.x_slab_stride + row * a.ldx, lane, t);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) x[k] += t[k];
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        x[k] += xb[k];
+        x[k] = a.x_act == 1 ? fmaxf(x[k], 0.f) : (a.x_act == 2 ? tanhf(x[k]) : x[k]);
+      }
+    }
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) s += x[k];
@@ -295,13 +318,17 @@ extern "C" int srl_ln_heads_supported(int D, int n_heads, const int32_t* head_di
 
 extern "C" int srl_ln_heads_fwd(void* stream, const float* x, int64_t ldx, int64_t n, int D, const float* gamma, const float* beta,
                                 int n_heads, const float* const* W, const float* const* b, const int32_t* head_dims,
-                                float* const* y, const int64_t* ldy, float* mean, float* rstd) {
+                                float* const* y, const int64_t* ldy, float* mean, float* rstd, int x_slabs, int64_t x_slab_stride,
+                                const float* x_bias, int x_act) {
   SRL_CHECK_ARG(check_common(x, ldx, D, gamma, beta, W, head_dims, n_heads) > 0,
                 "unsupported (D in 256 | 512 | 1024, 1-2 heads, <= SRL_LN_HEADS_MAX_OUT outputs, 16-byte aligned rows)");
   SRL_CHECK_ARG(y && ldy && mean && rstd && n >= 0, "null output");
+  SRL_CHECK_ARG(x_slabs >= 1 && (x_slabs == 1 || x_slab_stride % 4 == 0) && x_act >= 0 && x_act <= 2 &&
+                (!x_bias || (reinterpret_cast<uintptr_t>(x_bias) & 15) == 0), "x_slabs >= 1, aligned slabs / bias, x_act 0..2");
   if (n == 0) return 0;
   LhArgs a{};
   a.x = x; a.ldx = ldx; a.n = n; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd;
+  a.x_slabs = x_slabs; a.x_slab_stride = x_slab_stride; a.x_bias = x_bias; a.x_act = x_act;
   for (int h = 0; h < n_heads; ++h) {
     SRL_CHECK_ARG(y[h] && ldy[h] >= head_dims[h], "null head output / short rows");
     a.W[h] = W[h]; a.b[h] = b ? b[h] : nullptr; a.A[h] = head_dims[h]; a.y[h] = y[h]; a.ldy[h] = ldy[h];

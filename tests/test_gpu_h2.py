@@ -283,6 +283,40 @@ def test_linear_forward_and_data_gradient_vs_float64(M):
     assert torch.equal(dx, first)
 
 
+@pytest.mark.parametrize("M,ks", [(77, 3), (2048, 8), (4096, 4), (1000, 98)])
+def test_linear_forward_split_over_workgroups_and_finished_by_its_consumer(M, ks):
+    """srl_h2_gemm_splitk: the reduction of the Linear forward split over `ks` workgroups per tile, raw partial sums in [ks][M][N]
+    slabs -- their sum equals the unsplit product -- and srl_ln_heads_fwd's x_slabs finishing them (slabs added, bias, ReLU) while
+    it reads: heads' outputs and statistics equal those on the finished product (the inference path of `H2Cnn.forward`)."""
+    hip = _hip()
+    K, N = 3136, 512
+    x = _f(M, K, seed=23, relu=True, amp=2.0)
+    w = _f(N, K, seed=24, amp=0.03)
+    b = _f(N, seed=25, amp=0.1)
+    xbuf, sx, ax = torch.empty_like(x), _slot(0.0), _absmax(hip, x)
+    hip.h2_pack_rows(x.data_ptr(), K, M, K, xbuf.data_ptr(), absmax=ax.data_ptr(), scale_out=sx.data_ptr())
+    wp, sw, rw = _weights(hip, w, N, K, 0)
+    y = torch.zeros(M, N, device=DEV)
+    hip.h2_gemm(xbuf.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(), M, N, K, y.data_ptr(), bias=b.data_ptr(), act=1)
+    slabs = torch.full((ks, M, N), float("nan"), device=DEV)
+    hip.h2_gemm_splitk(xbuf.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(), M, N, K, slabs.data_ptr(), ks)
+    fin = F.relu(slabs.double().sum(0) + b.double())
+    _close(fin.float(), F.relu(x.double() @ w.double().t() + b.double()))
+    assert float((fin.float() - y).abs().max()) <= 1e-5 * float(y.abs().max())
+    heads = (6, 1)
+    g, be = 1 + 0.1 * _f(N, seed=26), 0.1 * _f(N, seed=27)
+    W, hb = [_f(a, N, seed=28 + i, amp=0.05) for i, a in enumerate(heads)], [_f(a, seed=30 + i, amp=0.1) for i, a in enumerate(heads)]
+    outs = []
+    for xin, kw in ((y, {}), (slabs, dict(x_slabs=ks, x_slab_stride=M * N, x_bias=b.data_ptr(), x_act=1))):
+        o = [torch.full((M, a), float("nan"), device=DEV) for a in heads]
+        mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        hip.ln_heads_fwd(xin.data_ptr(), N, M, N, g.data_ptr(), be.data_ptr(), [t.data_ptr() for t in W], [t.data_ptr() for t in hb],
+                         list(heads), [t.data_ptr() for t in o], list(heads), mean.data_ptr(), rstd.data_ptr(), **kw)
+        outs.append(o + [mean, rstd])
+    for a_, b_ in zip(*outs):
+        assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(a_.abs().max()), 1e-6)
+
+
 @pytest.mark.parametrize("M", [1111, BENCH_N])
 def test_linear_weight_gradient_reads_h2p_rows(M):
     """dW = dy^T x with x never written as float32: the round-3 two-piece kernel stages the h2p rows as they are
