@@ -112,15 +112,14 @@ class H2Cnn:
         hip.h2_weights(p(f"{self.fc.prefix}.weight"), 3136, self.H, 1, amax, W(S_WFT), W(R_WFT), self._wbytes("wft", self.H * 3136 * 4))
 
     # ------------------------------------------------------------------ forward
-    # (inference batches: the Linear's 3136-long reduction split over this many workgroups per tile when the rows alone leave most
-    # CUs idle -- 2048 rows are 32 tiles: 104 us; SRL_FC_SPLITK=1 switches it off, A/B)
-    FC_SPLITK = int(os.environ.get("SRL_FC_SPLITK", "0"))
+    # Inference batches: the Linear's 3136-long reduction split over FC_SPLITK workgroups per tile -- the rows alone leave most CUs
+    # idle (2048 rows are 32 tiles: 104 us; in 8 k-ranges 27 + 4 us for adding the slabs).  The SAME eight k-ranges for every row
+    # count that takes this path: a row's result must not depend on the batch it arrives in (the streamed pieces of a large batch
+    # and one small batch sample the same actions, bit for bit).  SRL_FC_SPLITK=1 switches it off (A/B).
+    FC_SPLITK = int(os.environ.get("SRL_FC_SPLITK", "8"))
 
     def fc_splits(self, n: int) -> int:
-        tiles = -(-n // 256) * (self.H // 128)
-        if self.FC_SPLITK:
-            return self.FC_SPLITK if n <= 8192 else 1
-        return max(1, min(8, 256 // tiles)) if (tiles <= 128 and self.H % 128 == 0) else 1
+        return self.FC_SPLITK if (n <= 8192 and self.H % 128 == 0 and self.FC_SPLITK > 1) else 1
 
     def forward(self, tag, staged, obs, n, is_u8, src, mean, rstd, row_index, split_fc=False):
         """The four layers on `n` rows.  src / mean / rstd / row_index: the first layer's staged frames and statistics as
