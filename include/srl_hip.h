@@ -611,7 +611,7 @@ int srl_ring_stack_push(void* stream, void* store, const void* planes, const int
 /* LayerNorm over D features (eps 1e-5) and the 1-2 Linear heads that read its output, in one launch per direction
  * (csrc/ln_heads.hip): the tail of the reference's shared-backbone actor-critic -- features -> actor logits, critic value
  * (actor_critic_policy.py:117-140; the CNN / MLP base ends in a LayerNorm, modules/utils.py:154-161).  D in 256 | 512 | 1024; the
- * heads' outputs together at most SRL_LN_HEADS_MAX_OUT and (outputs + 2) * D * 32 bytes <= 160 KB (srl_ln_heads_supported).
+ * heads' outputs together at most SRL_LN_HEADS_MAX_OUT (srl_ln_heads_supported).
  * x [n, ldx], head h: W[h] [head_dims[h], D] row-major, b[h] (may be NULL), y[h] [n, ldy[h]].  The normalised features are not
  * stored: mean / rstd [n] are, and srl_ln_heads_bwd forms the features again from x.  Backward: dy[h] [n, lddy[h]] -> dx
  * [n, lddx] = d loss / d x times the derivative of the activation that produced x (in_act, from x's value), and dgamma, dbeta,

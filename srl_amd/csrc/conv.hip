@@ -12,6 +12,16 @@
 
 using namespace srlgemm;
 
+// First-layer block kernels (obs_h2.h): XCD-contiguous numbering of the (position block, sample range) workgroups, so that the
+// blocks an XCD works on are neighbours in the frame and share window rows / columns in ITS L2.  Measured (scripts/obs_xcd_traffic.sh,
+// scripts/ab_bench.sh): the forward's fetched bytes per launch fall by a third (494 -> 326 counter MB), the weight gradient's by a
+// sixth (872 -> 729) -- and the update gets 0.4 ms SLOWER (87.9 / 88.6 -> 88.3 / 89.0 ms, alternating runs on one box): these
+// kernels are bound by their vector work, not by the frames' bytes.  Opt-in (SRL_OBS_XCD=1).
+static int obs_xcd_order() {
+  static const int v = [] { const char* e = getenv("SRL_OBS_XCD"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v;
+}
+
 namespace {
 
 constexpr int K3 = 16;  // k-step depth of the bf16x3 kernels (48 KB of LDS per 128x128 workgroup: three per CU)
@@ -667,6 +677,7 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
       long nsplit = nblk < 256 ? 256 / nblk : 1;
       if (nsplit > ntiles) nsplit = ntiles;
       h.nsplit = (int)nsplit;
+      h.xcd = obs_xcd_order();
       const unsigned grid = (unsigned)(nblk * nsplit);
       constexpr int lds = srlobs::kStages * srlobs::kStageBytes + srlobs::kMeta * srlobs::kTile * 16 + srlobs::kWaves * 96 * 4 +
                           (SRL_OBS_LINE_STORES ? srlobs::kWaves * srlobs::kTile * 144 : 0);  // stages, records, tables, store rows
@@ -869,6 +880,7 @@ static int conv2d_obs_bwd_run(void* stream, const srl_conv_desc* d, const void* 
     a.frames = static_cast<const uint8_t*>(obs); a.img_stride = (long)d->H * d->W * d->Cin; a.meta = meta; a.n = d->n;
     a.dz = dz; a.dz_bound = dz_absmax; a.rstd_bound = rstd_max; a.Q = slabs_h2; a.slab = (long)P * d->Cout * Kp; a.R = R; a.C = C;
     a.GW = d->W; a.OW = OW; a.OH = OH; a.P = P; a.nsplit = obs_bwd_h2_split(P);
+    a.xcd = obs_xcd_order();
     if (a.nsplit > srl_ceil_div(d->n, (long)srlobs::kTileB)) a.nsplit = (int)srl_ceil_div(d->n, (long)srlobs::kTileB);  // (a range of tiles each)
     const unsigned grid = (unsigned)((P / (srlobs::kBlkH * srlobs::kBlkW)) * a.nsplit);
     auto go = [&](auto kern) {

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * kWaves) void ln_heads_fwd_kernel(LhArgs a) {
   }
 }
 
-// Backward.  LDS: one slot of (AT + 2) * D floats per wavefront for the parameter sums at the end (AT = the heads' outputs).
+// Backward.  LDS: D floats per wavefront, for the parameter sums at the end.
 template <int NV>
 __global__ __launch_bounds__(64 * kWaves) void ln_heads_bwd_kernel(LhArgs a) {
   constexpr int D = 64 * NV;
@@ -245,22 +245,27 @@ __global__ __launch_bounds__(64 * kWaves) void ln_heads_bwd_kernel(LhArgs a) {
   // every wavefront parks its sums in a slot of its own (plain stores), then the workgroup's threads add the slots and send
   // one atomic per parameter
   if (a.dbg & 2) return;   // (uniform)
-  const int per = (AT + 2) * D;
-  float* slot = sm + (long)wave * per;
+  // The workgroup's sums meet in LDS one PLANE (one head output's dW row set, dgamma, dbeta) at a time: every wavefront parks its D
+  // sums of the plane (plain stores), the threads add the eight slots and send one atomic per parameter.  (All planes at once
+  // were 147 KB of LDS per workgroup: inside the update such a workgroup waits for a CU that a persistent kernel of another
+  // row-chunk pipeline has left entirely.)
 #pragma unroll
-  for (int o = 0; o < kMaxOut; ++o)
-    if (o < AT) store_row<NV>(slot + o * D, lane, accw[o]);
-  store_row<NV>(slot + AT * D, lane, accg);
-  store_row<NV>(slot + (AT + 1) * D, lane, accb);
-  __syncthreads();
-  for (int e = tid; e < per; e += 64 * kWaves) {
-    const int o = e / D, c = e - o * D;
-    float s = 0.f;
+  for (int o = 0; o < kMaxOut + 2; ++o) {
+    if (o < kMaxOut && o >= AT) continue;   // (uniform)
+    float* mine = sm + wave * D;
+    if (o < kMaxOut) store_row<NV>(mine, lane, accw[o < kMaxOut ? o : 0]);
+    else if (o == kMaxOut) store_row<NV>(mine, lane, accg);
+    else store_row<NV>(mine, lane, accb);
+    __syncthreads();
+    for (int c = tid; c < D; c += 64 * kWaves) {
+      float sum = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < kWaves; ++wv) s += sm[(long)wv * per + e];
-    if (a.dbg & 1) continue;
-    float* dst = o == AT ? a.dgamma + c : (o == AT + 1 ? a.dbeta + c : (o < A0 ? a.dW[0] + (long)o * D + c : a.dW[1] + (long)(o - A0) * D + c));
-    atomicAdd(dst, s);
+      for (int wv = 0; wv < kWaves; ++wv) sum += sm[wv * D + c];
+      if (a.dbg & 1) continue;
+      float* dst = o == kMaxOut ? a.dgamma + c : (o == kMaxOut + 1 ? a.dbeta + c : (o < A0 ? a.dW[0] + (long)o * D + c : a.dW[1] + (long)(o - A0) * D + c));
+      atomicAdd(dst, sum);
+    }
+    __syncthreads();
   }
   // bias gradients = column sums of dy.  NOT one atomic per wavefront from the sums the row loop could keep: 2048 atomics on one
   // address take ~80 ns each, one after the other (160 us of a 17 us kernel).  The first kDbGroups workgroups sum a slice of dy's
@@ -343,7 +348,7 @@ extern "C" int srl_ln_heads_fwd(void* stream, const float* x, int64_t ldx, int64
   return 0;
 }
 
-static long bwd_lds_bytes(int D, int at) { return (long)kWaves * (at + 2) * D * 4; }
+static long bwd_lds_bytes(int D, int at) { (void)at; return (long)kWaves * D * 4; }
 
 template <int NV>
 static void launch_bwd(const LhArgs& a, hipStream_t st) {

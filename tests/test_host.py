@@ -295,5 +295,4 @@ def test_host_side_queries_of_the_fused_kernels():
     assert hip.mlp_tape_floats_at(wide, 65536) == hip.mlp_tape_floats(wide) == 128   # wider than 64: not a matrix-core chain
     assert hip.ln_heads_supported(512, (6, 1)) and hip.ln_heads_supported(256, (8,)) and hip.ln_heads_supported(1024, (2, 1))
     assert not hip.ln_heads_supported(512, (8, 1))     # nine outputs
-    assert not hip.ln_heads_supported(1024, (6, 1))    # (outputs + 2) * D * 32 bytes of LDS
     assert not hip.ln_heads_supported(384, (6, 1)) and not hip.ln_heads_supported(512, ())
