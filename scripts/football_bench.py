@@ -63,3 +63,7 @@ tot = sum(v["ms"] for v in summ.values())
 print(f"kernel time {tot:.1f} ms in {sum(v['calls'] for v in summ.values())} launches")
 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:10]:
     print(f"  {v['ms']:9.2f} ms  calls={v['calls']:4d}  {k}")
+hip.dispatch_tiles(reset=True)
+tr.step(sample)
+torch.cuda.synchronize()
+print("launches per kernel instantiation:", hip.dispatch_tiles(reset=True))

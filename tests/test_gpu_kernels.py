@@ -1535,3 +1535,48 @@ def test_ln_heads_fused(n, D, heads, in_act):
     for got, ref, name in [(dg, g64, "dgamma"), (db_, b64, "dbeta")] + [(a_, b_, f"dW{i}") for i, (a_, b_) in enumerate(zip(dW, W64))] + \
             [(a_, b_, f"db{i}") for i, (a_, b_) in enumerate(zip(dhb, hb64))]:
         assert rel_close(got.cpu().numpy() - 0.5, ref.grad.numpy(), 2e-5, scale=float(ref.grad.abs().max()) + 1e-6), name
+
+
+@pytest.mark.parametrize("rows,chain", [(2000, [(0, 64, 64, 0), (1, 64, 5, 0)]), (4097, [(0, 64, 64, 0), (1, 64, 9, 0)]),
+                                        (1024, [(1, 48, 64, 2), (0, 64, 64, 0), (1, 64, 3, 0)])])
+def test_mlp_chain_backward_with_input_gradient(rows, chain):
+    """srl_mlp_bwd_dx: a fused chain that sits BEHIND other layers (LayerNorm + head after a recurrent cell) also returns d loss /
+    d x -- generic matrix-core kernels (5 / 3 outputs) and the kernels instantiated for configs[3]'s tails (9 outputs) -- against
+    float64 autograd: dx and every parameter gradient; such a chain keeps no tape."""
+    rng = np.random.default_rng(rows)
+    t = torch
+    din, dout = chain[0][1], chain[-1][2]
+    host, dev_g, desc, keep = [], [], [], []
+    for kind, i, o, act in chain:
+        if kind == 0:
+            w, b = 1 + 0.1 * rng.standard_normal(i), 0.1 * rng.standard_normal(i)
+        else:
+            w, b = rng.standard_normal((o, i)) / np.sqrt(i), 0.1 * rng.standard_normal(o)
+        w, b = t.from_numpy(w.astype(np.float32)), t.from_numpy(b.astype(np.float32))
+        host += [w, b]
+        dw, db_ = w.to(DEV), b.to(DEV)
+        gw, gb = t.zeros_like(dw), t.zeros_like(db_)
+        keep += [dw, db_]
+        dev_g += [gw, gb]
+        desc.append((kind, i, o, act, dw.data_ptr(), db_.data_ptr(), gw.data_ptr(), gb.data_ptr()))
+    arr = hip.mlp_layers(desc)
+    assert hip.mlp_tape_floats_at(arr, rows) == 0
+    x = t.from_numpy(rng.standard_normal((rows, din)).astype(np.float32))
+    dy = t.from_numpy(rng.standard_normal((rows, dout)).astype(np.float32))
+    dx_dev, ddy = x.to(DEV), dy.to(DEV)
+    y = t.full((rows, dout), float("nan"), device=DEV)
+    dxo = t.full((rows, din), float("nan"), device=DEV)
+    hip.mlp_fwd(arr, dx_dev.data_ptr(), din, rows, 0, 0, y.data_ptr(), dout)
+    hip.mlp_bwd_dx(arr, dx_dev.data_ptr(), din, rows, ddy.data_ptr(), dout, dxo.data_ptr(), din)
+    p64 = [p_.double().requires_grad_(True) for p_ in host]
+    x64 = x.double().requires_grad_(True)
+    h = x64
+    for li, (kind, i, o, act) in enumerate(chain):
+        w, b = p64[2 * li], p64[2 * li + 1]
+        h = t.nn.functional.layer_norm(h, (i,), w, b, 1e-5) if kind == 0 else h @ w.t() + b
+        h = t.relu(h) if act == 1 else (t.tanh(h) if act == 2 else h)
+    h.backward(dy.double())
+    assert rel_close(y.cpu().numpy(), h.detach().numpy(), 1e-5, scale=float(h.detach().abs().max()))
+    assert rel_close(dxo.cpu().numpy(), x64.grad.numpy(), 2e-5, scale=float(x64.grad.abs().max()))
+    for k, (g, p_) in enumerate(zip(dev_g, p64)):
+        assert rel_close(g.cpu().numpy(), p_.grad.numpy(), 2e-5, scale=float(p_.grad.abs().max()) + 1e-6), k
