@@ -266,3 +266,40 @@ def test_smac_config_full_size_step_vs_oracle():
         assert abs(r1.stats[k] - r2.stats[k]) <= 1e-6 * max(1.0, abs(r2.stats[k])), k
     d = (t1.policy.net.flat - t2.policy.net.flat).abs()  # split-K partial sums land in launch order: not bitwise
     assert float(d.max()) <= 5e-4 and float((d > 1e-6).float().mean()) < 1e-3
+
+
+def test_config0_towers_at_the_metric_batch_vs_oracle():
+    """BASELINE.json configs[0]'s nets (separate 2 x 64 actor / critic towers on 4 observations) at the METRIC's batch -- 4096 envs x
+    128 steps, the update `roofline_mlp` times: each tower one launch per direction on the kernels instantiated for its shape
+    (csrc/mlp_sig.h), no activation tape.  The whole step against the CPU oracle on all 524 288 rows: GAE returns 1e-5, loss terms
+    and gradient norm 2e-5, and the parameters after the step (Adam's first step moves an element by ~lr whatever its gradient's
+    size: elements whose gradient is zero to rounding aside, they agree)."""
+    from oracle.net import OracleActorCritic
+    from oracle.trainer import OracleMappo
+    from srl_amd import hip
+    T, B = 128, 4096
+    pol = dict(obs_dim=4, action_dim=2, hidden_dim=64, num_dense_layers=2, num_rnn_layers=0, popart=False, layernorm=False,
+               shared_backbone=False, seed=1)
+    tr_args = dict(popart=False, optimizer_config=dict(lr=3e-4))
+    tr = trainer_api.make(config.Trainer("mappo", args=tr_args), config.Policy("actor-critic-separate", args=pol))
+    onet = OracleActorCritic(**{k: v for k, v in pol.items() if k not in ("seed", "popart")})
+    onet.load_state_dict({k: v.numpy() for k, v in tr.policy.get_checkpoint()["state_dict"].items()})
+    oracle = OracleMappo(onet, **tr_args)
+    arrays = synthetic.make_sample_arrays(seed=0, T=T, B=B, obs_spec=synthetic.CARTPOLE_OBS, action_dims=2, p_done=0.05)
+    sample = synthetic.to_sample_batch({k: torch.from_numpy(v).cuda() for k, v in arrays.items()})
+    hip.dispatch_counts(reset=True)
+    res = tr.step(sample)
+    ostats, oout = oracle.step(arrays)
+    ret = sample.analyzed_result.ret.cpu().numpy()
+    err = np.abs(ret - oout["ret"]) / np.maximum(np.abs(oout["ret"]), 1.0)
+    assert err.max() <= 1e-5, err.max()
+    for k in ("policy_loss", "value_loss", "entropy", "grad_norm", "importance_weight"):
+        assert abs(res.stats[k] - ostats[k]) <= 2e-5 * max(abs(ostats[k]), 1e-2), (k, res.stats[k], ostats[k])
+    got = tr.policy.get_checkpoint()["state_dict"]
+    far = total = 0
+    for k, v in onet.state_dict().items():
+        d = np.abs(got[k].cpu().numpy().astype(np.float64) - (v.detach().numpy() if hasattr(v, 'detach') else np.asarray(v)).astype(np.float64))
+        far += int((d > 1e-6).sum())
+        total += d.size
+        assert d.max() <= 2 * 3e-4 * 1.01, (k, float(d.max()))
+    assert far <= max(2, total // 100), (far, total)
