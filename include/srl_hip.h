@@ -578,8 +578,10 @@ typedef struct srl_h2_gemm_desc {
 int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d);
 /* ... with the reduction split over `ksplits` workgroups per tile: out is [ksplits][M][NC] float32 slabs of raw partial sums (no
  * bias / activation / masks / h2 output: the consumer adds the slabs, e.g. srl_ln_heads_fwd's x_slabs).  For row counts that leave
- * most CUs without a tile -- the Linear forward (modules/cnn.py:128-133) of an inference batch.  NC a multiple of 128. */
-int srl_h2_gemm_splitk(void* stream, const srl_h2_gemm_desc* d, int32_t ksplits);
+ * most CUs without a tile -- the Linear forward (modules/cnn.py:128-133) of an inference batch -- or, `wide` != 0 (256 channels
+ * per workgroup, NC a multiple of 256), for a training chunk: fewer operand bytes staged per multiply-add, the k-ranges restore
+ * the workgroup count.  NC a multiple of 128. */
+int srl_h2_gemm_splitk(void* stream, const srl_h2_gemm_desc* d, int32_t ksplits, int32_t wide);
 /* srl_conv2d_obs_fwd with the output as the h2p rows kind 0 above reads (ent_order 2) instead of float32: byte kernels
  * only (uint8 channels-last frames, Cout 32), y_mask / y_absmax / workspace required; *y_scale = the scale used. */
 int srl_conv2d_obs_fwd_h2(void* stream, const srl_conv_desc* d, const void* obs, const float* mean, const float* rstd,
@@ -618,12 +620,14 @@ int srl_ring_stack_push(void* stream, void* store, const void* planes, const int
  * dW[h], db[h] are ADDED to (float atomics); dx_absmax (optional, zeroed by the caller) receives max |dx|.
  * Forward only (inference: nothing is kept for a backward pass): x may be the raw output of a split product -- x_slabs slabs,
  * x_slab_stride floats apart (srl_h2_gemm_splitk) -- finished while it is read: x = act(sum of the slabs + x_bias), x_act as
- * srl_mlp_layer::act; (1, 0, NULL, 0) for a plain x. */
+ * srl_mlp_layer::act; x_out (optional, [n, ldxo]): the finished x is written there too -- a training pass keeps it for
+ * srl_ln_heads_bwd; (1, 0, NULL, 0, NULL, 0) for a plain x. */
 #define SRL_LN_HEADS_MAX_OUT 8
 int srl_ln_heads_supported(int D, int n_heads, const int32_t* head_dims);
 int srl_ln_heads_fwd(void* stream, const float* x, int64_t ldx, int64_t n, int D, const float* gamma, const float* beta, int n_heads,
                      const float* const* W, const float* const* b, const int32_t* head_dims, float* const* y, const int64_t* ldy,
-                     float* mean, float* rstd, int x_slabs, int64_t x_slab_stride, const float* x_bias, int x_act);
+                     float* mean, float* rstd, int x_slabs, int64_t x_slab_stride, const float* x_bias, int x_act, float* x_out,
+                     int64_t ldxo);
 int srl_ln_heads_bwd(void* stream, const float* x, int64_t ldx, int64_t n, int D, const float* gamma, const float* beta,
                      const float* mean, const float* rstd, int n_heads, const float* const* W, const int32_t* head_dims,
                      const float* const* dy, const int64_t* lddy, int in_act, float* dx, int64_t lddx, float* dgamma, float* dbeta,

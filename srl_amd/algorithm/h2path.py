@@ -121,11 +121,19 @@ class H2Cnn:
     def fc_splits(self, n: int) -> int:
         return self.FC_SPLITK if (n <= 8192 and self.H % 128 == 0 and self.FC_SPLITK > 1) else 1
 
-    def forward(self, tag, staged, obs, n, is_u8, src, mean, rstd, row_index, split_fc=False):
+    # Training chunks with the closing LayerNorm + heads as the consumer (opt-in, SRL_FC_TRAIN_SPLITK=2): 256 channels per workgroup
+    # stage a third fewer bytes per multiply-add (the forward is bound by its ring fill) but are only 128 tiles at 16 384
+    # rows -- two k-ranges restore the workgroup count, and the consumer adds the slabs and writes the finished rows for the backward
+    # pass.  Measured, alternating runs on one box: 85.66 / 85.36 ms per update unsplit, 85.54 / 85.67 with two ranges, 86.0 / 86.1
+    # with three / four: what the smaller fill gains the slabs' traffic takes back.  Off by default.
+    FC_TRAIN_SPLITK = int(os.environ.get("SRL_FC_TRAIN_SPLITK", "1"))
+
+    def forward(self, tag, staged, obs, n, is_u8, src, mean, rstd, row_index, split_fc=None):
         """The four layers on `n` rows.  src / mean / rstd / row_index: the first layer's staged frames and statistics as
-        `_encoder_fwd` resolved them.  Returns (y Buf float32 [n, H] with its sign mask, saved).  ``split_fc`` (inference, the
-        consumer finishes the product: `srl_ln_heads_fwd`'s x_slabs): y is then slab 0 of `saved["fc_slabs"]` = (slabs, stride in
-        floats, bias pointer, activation) raw partial sums."""
+        `_encoder_fwd` resolved them.  Returns (y Buf float32 [n, H], saved).  ``split_fc`` ("infer" | "train": the consumer
+        finishes the product -- `srl_ln_heads_fwd`'s x_slabs): the Linear writes raw partial sums, `saved["fc_slabs"]` = (pointer,
+        slabs, stride in floats, bias pointer, activation) tells the consumer where; y is then only valid BEHIND the consumer's
+        launch ("train": it writes the finished rows there; "infer": nothing does, nothing reads them)."""
         net, ws = self.net, self.net.ws
         self._prepare_weights()
         t = f"{tag}{self.pfx}"
@@ -153,14 +161,18 @@ class H2Cnn:
                     bias=net._p(f"{self.c3.prefix}.bias"), act=1, out_scale=P(S_A3), bound_in=P(M_A2),
                     bound_w=W(R_W3), bound_b=W(B_W3), mask_out=m3)
         # Linear: float32 out (the layers behind it take the ReLU derivative from these floats, as after `_linear_fwd`)
-        ks = self.fc_splits(n) if split_fc else 1
         saved = dict(n=n, a1=a1, a2=a2, a3=a3, m1=m1, m2=m2, m3=m3, first=(src, is_u8, mean, rstd, row_index), tag=tag)
-        if ks > 1:
-            y = net._buf(f"{tag}{self.fc.prefix}.yslabs", ks * n, self.H)
-            hip.h2_gemm_splitk(a3, self._wbytes("wf", 0), P(S_A3), W(S_WF), n, self.H, 3136, y.ptr, ks)
-            saved["fc_slabs"] = (ks, n * self.H, net._p(f"{self.fc.prefix}.bias"), self.fc.act)
-            return y._replace(rows=n), saved
         y = net._buf(f"{tag}{self.fc.prefix}.y", n, self.H)
+        ks, wide = 1, False
+        if split_fc == "infer":
+            ks = self.fc_splits(n)
+        elif split_fc == "train" and self.FC_TRAIN_SPLITK > 1 and self.H % 256 == 0 and n >= 8192:
+            ks, wide = self.FC_TRAIN_SPLITK, True
+        if ks > 1:
+            slabs = net._buf(f"{tag}{self.fc.prefix}.yslabs", ks * n, self.H)
+            hip.h2_gemm_splitk(a3, self._wbytes("wf", 0), P(S_A3), W(S_WF), n, self.H, 3136, slabs.ptr, ks, wide=wide)
+            saved["fc_slabs"] = (slabs.ptr, ks, n * self.H, net._p(f"{self.fc.prefix}.bias"), self.fc.act, wide)
+            return y, saved
         hip.h2_gemm(a3, self._wbytes("wf", 0), P(S_A3), W(S_WF), n, self.H, 3136, y.ptr,
                     bias=net._p(f"{self.fc.prefix}.bias"), act=1)
         return y, saved

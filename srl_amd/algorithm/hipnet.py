@@ -687,11 +687,14 @@ class HipNet:
                 mean = self.ws.get(f"{tag}{L.prefix}.mean", n)
                 rstd = self.ws.get(f"{tag}{L.prefix}.rstd", n)
                 slabs = tape[-1][3].get("fc_slabs") if (tape and tape[-1][0] == "h2cnn") else None
-                ks, stride, xb, xact = slabs if slabs else (1, 0, None, 0)
-                hip.ln_heads_fwd(cur.ptr, cur.ld, n, L.dim, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"),
+                xptr, ks, stride, xb, xact, keep = slabs if slabs else (cur.ptr, 1, 0, None, 0, False)
+                # (a split product: this launch adds the slabs, the bias and the ReLU while it reads them -- and, when a backward
+                # pass follows, writes the finished rows to `cur`)
+                hip.ln_heads_fwd(xptr, cur.ld, n, L.dim, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"),
                                  [self._p(f"{h.prefix}.weight") for h in heads], [self._p(f"{h.prefix}.bias") for h in heads],
                                  [h.out_features for h in heads], [o.data_ptr() for o in outs], [h.out_features for h in heads],
-                                 mean.data_ptr(), rstd.data_ptr(), x_slabs=ks, x_slab_stride=stride, x_bias=xb, x_act=xact)
+                                 mean.data_ptr(), rstd.data_ptr(), x_slabs=ks, x_slab_stride=stride, x_bias=xb, x_act=xact,
+                                 x_out=cur.ptr if (slabs and not self._infer) else None, ldxo=cur.ld)
                 tape.append(("lnheads", L, cur, (mean, rstd, heads), cur_act))
                 return None
             if isinstance(L, ns.LayerNormSpec):
@@ -821,7 +824,9 @@ class HipNet:
                         # the whole convolution stack and the Linear behind it on pre-split activations (h2path.py)
                         # (inference with the closing LayerNorm + heads as the consumer: the Linear's reduction may be split
                         # over workgroups, the consumer adds the slabs)
-                        split = bool(lnheads is not None and self._infer and len(enc.layers) == 6 and enc.layers[4] is h2.fc)
+                        split = None
+                        if lnheads is not None and len(enc.layers) == 6 and enc.layers[4] is h2.fc:
+                            split = "infer" if self._infer else "train"
                         y2, saved2 = h2.forward(tag, staged, obs, n, is_u8, src, mean, rstd, row_index, split_fc=split)
                         tape.append(("h2cnn", h2, None, saved2, 0))
                         cur, cur_act, cur_range = y2, h2.fc.act, None

@@ -175,7 +175,7 @@ extern "C" int srl_h2_wgrad(void* stream, int32_t kind, const void* x, const voi
 // The dense product with its reduction split over `ksplits` workgroups per tile: slab s of out ([ksplits][M][NC] float32) receives
 // the raw partial sums of k-range s; bias, activation, masks and the h2 output format are the consumer's (srl_ln_heads_fwd adds the
 // slabs while it reads).  For row counts that leave most CUs without a tile: the Linear forward of an inference batch.
-extern "C" int srl_h2_gemm_splitk(void* stream, const srl_h2_gemm_desc* d, int32_t ksplits) {
+extern "C" int srl_h2_gemm_splitk(void* stream, const srl_h2_gemm_desc* d, int32_t ksplits, int32_t wide) {
   SRL_CHECK_ARG(d && d->x && d->w && d->sx && d->sw && d->out && d->M >= 0 && d->NC >= 128 && d->NC % 128 == 0 && d->K > 0 && d->K % 32 == 0,
                 "null tensor / NC not a multiple of 128 / K not a multiple of 32");
   SRL_CHECK_ARG(!d->out_h2 && !d->bias && !d->act && !d->mask_out && !d->mask_in && !d->out_absmax, "split products write raw float32 partial sums");
@@ -187,8 +187,11 @@ extern "C" int srl_h2_gemm_splitk(void* stream, const srl_h2_gemm_desc* d, int32
   a.w_row_bytes = (uint32_t)d->K * 4u; a.x_row_bytes = (uint32_t)d->K * 4u;
   a.out_fmt = H2O_F32; a.out = d->out; a.out_row_bytes = (uint32_t)d->NC * 4u;
   a.ksplits = ksplits; a.slab_bytes = d->M * (int64_t)d->NC * 4;
-  srl_count_dispatch(SRL_DISP_H2, 3, 4, 3);
-  const int rc = h2gemm_launch<4, H2X_DENSE, 3>((hipStream_t)stream, a);
+  // wide: 256 channels per workgroup (a third less staged per multiply-add; NC a multiple of 256) on the two-stage ring -- for
+  // row counts that fill the chip even so (the training chunk: 64 row tiles x 2 channel tiles x 2 k-ranges = 256 workgroups)
+  SRL_CHECK_ARG(!wide || d->NC % 256 == 0, "wide tiles: NC a multiple of 256");
+  srl_count_dispatch(SRL_DISP_H2, 3, wide ? 8 : 4, wide ? 2 : 3);
+  const int rc = wide ? h2gemm_launch<8, H2X_DENSE, 2, false>((hipStream_t)stream, a) : h2gemm_launch<4, H2X_DENSE, 3>((hipStream_t)stream, a);
   SRL_CHECK_ARG(rc == 0, "grid too large");
   SRL_LAUNCH_CHECK();
   return 0;

@@ -46,6 +46,8 @@ struct LhArgs {
   long x_slab_stride;
   const float* x_bias;
   int x_act;
+  float* x_out;      // (optional) the finished x is also written here [n, ldxo]: what a backward pass will read
+  long ldxo;
   int dbg;   // timing experiments (wrong results; SRL_LNH_DBG): 1 no final atomics, 2 no LDS meeting either, 4 no row loop
 };
 
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(64 * kWaves) void ln_heads_fwd_kernel(LhArgs a) {
         x[k] += xb[k];
         x[k] = a.x_act == 1 ? fmaxf(x[k], 0.f) : (a.x_act == 2 ? tanhf(x[k]) : x[k]);
       }
+      if (a.x_out) store_row<NV>(a.x_out + row * a.ldxo, lane, x);
     }
     float s = 0.f;
 #pragma unroll
@@ -324,7 +327,7 @@ extern "C" int srl_ln_heads_supported(int D, int n_heads, const int32_t* head_di
 extern "C" int srl_ln_heads_fwd(void* stream, const float* x, int64_t ldx, int64_t n, int D, const float* gamma, const float* beta,
                                 int n_heads, const float* const* W, const float* const* b, const int32_t* head_dims,
                                 float* const* y, const int64_t* ldy, float* mean, float* rstd, int x_slabs, int64_t x_slab_stride,
-                                const float* x_bias, int x_act) {
+                                const float* x_bias, int x_act, float* x_out, int64_t ldxo) {
   SRL_CHECK_ARG(check_common(x, ldx, D, gamma, beta, W, head_dims, n_heads) > 0,
                 "unsupported (D in 256 | 512 | 1024, 1-2 heads, <= SRL_LN_HEADS_MAX_OUT outputs, 16-byte aligned rows)");
   SRL_CHECK_ARG(y && ldy && mean && rstd && n >= 0, "null output");
@@ -334,6 +337,9 @@ extern "C" int srl_ln_heads_fwd(void* stream, const float* x, int64_t ldx, int64
   LhArgs a{};
   a.x = x; a.ldx = ldx; a.n = n; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd;
   a.x_slabs = x_slabs; a.x_slab_stride = x_slab_stride; a.x_bias = x_bias; a.x_act = x_act;
+  SRL_CHECK_ARG(!x_out || ((x_slabs > 1 || x_bias || x_act) && ldxo % 4 == 0 && (reinterpret_cast<uintptr_t>(x_out) & 15) == 0),
+                "x_out: only with a finishing step (slabs / bias / activation), 16-byte aligned rows");
+  a.x_out = x_out; a.ldxo = ldxo;
   for (int h = 0; h < n_heads; ++h) {
     SRL_CHECK_ARG(y[h] && ldy[h] >= head_dims[h], "null head output / short rows");
     a.W[h] = W[h]; a.b[h] = b ? b[h] : nullptr; a.A[h] = head_dims[h]; a.y[h] = y[h]; a.ldy[h] = ldy[h];

@@ -157,7 +157,7 @@ _SIGNATURES = {
     "srl_ln_heads_supported": (c_int, [c_int, c_int, POINTER(c_int32)]),
     "srl_ln_heads_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, POINTER(c_void_p),
                                  POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p), POINTER(c_int64), c_void_p, c_void_p, c_int, c_int64,
-                                 c_void_p, c_int]),
+                                 c_void_p, c_int, c_void_p, c_int64]),
     "srl_ln_heads_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                  POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_int64,
                                  c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
@@ -212,7 +212,7 @@ _SIGNATURES = {
     "srl_h2_wgrad_workspace": (c_int64, [c_int32]),
     "srl_h2_wgrad": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "srl_h2_gemm": (c_int, [c_void_p, POINTER(H2GemmDesc)]),
-    "srl_h2_gemm_splitk": (c_int, [c_void_p, POINTER(H2GemmDesc), c_int32]),
+    "srl_h2_gemm_splitk": (c_int, [c_void_p, POINTER(H2GemmDesc), c_int32, c_int32]),
     "srl_conv2d_obs_fwd_h2": (c_int, [c_void_p, POINTER(ConvDesc)] + [c_void_p] * 13 + [c_int, c_int]),
     "srl_comm_available": (c_int, []),
     "srl_comm_unique_id": (c_int, [c_void_p]),
@@ -690,14 +690,14 @@ def ln_heads_supported(D: int, head_dims) -> bool:
 
 
 def ln_heads_fwd(x_ptr, ldx, n, D, gamma_ptr, beta_ptr, w_ptrs, b_ptrs, head_dims, y_ptrs, ldys, mean_ptr, rstd_ptr, x_slabs=1,
-                 x_slab_stride=0, x_bias=None, x_act=0):
+                 x_slab_stride=0, x_bias=None, x_act=0, x_out=None, ldxo=0):
     """LayerNorm over D + the heads reading it: y[h] = LN(x) W[h]^T + b[h]; the normalised features are not stored.  ``x_slabs``
     > 1: x is the raw output of ``h2_gemm_splitk`` and is finished (slabs added, bias, activation) while it is read."""
     flops = 2.0 * n * D * sum(head_dims)
     with _scope("ln_heads_fwd", flops, "f32"):
         _check(lib().srl_ln_heads_fwd(_stream(), x_ptr, ldx, n, int(D), gamma_ptr, beta_ptr, len(head_dims), _ptr_array(w_ptrs), _ptr_array(b_ptrs),
                                       _i32_array(head_dims), _ptr_array(y_ptrs), (c_int64 * len(ldys))(*ldys), mean_ptr, rstd_ptr,
-                                      int(x_slabs), int(x_slab_stride), x_bias, int(x_act)), "srl_ln_heads_fwd")
+                                      int(x_slabs), int(x_slab_stride), x_bias, int(x_act), x_out, int(ldxo)), "srl_ln_heads_fwd")
 
 
 def ln_heads_bwd(x_ptr, ldx, n, D, gamma_ptr, beta_ptr, mean_ptr, rstd_ptr, w_ptrs, head_dims, dy_ptrs, lddys, in_act, dx_ptr, lddx,
@@ -1172,11 +1172,12 @@ def h2_gemm(x, w, sx, sw, M, NC, K, out, bias=None, act=0, out_h2=False, out_sca
         _check(lib().srl_h2_gemm(_stream(), ctypes.byref(d)), "srl_h2_gemm")
 
 
-def h2_gemm_splitk(x, w, sx, sw, M, NC, K, out, ksplits):
-    """``h2_gemm`` with its reduction split over ``ksplits`` workgroups per tile: ``out`` = [ksplits][M][NC] float32 raw partial sums."""
+def h2_gemm_splitk(x, w, sx, sw, M, NC, K, out, ksplits, wide=False):
+    """``h2_gemm`` with its reduction split over ``ksplits`` workgroups per tile: ``out`` = [ksplits][M][NC] float32 raw partial sums.
+    ``wide``: 256 channels per workgroup (training chunks)."""
     d = H2GemmDesc(_vp(x), _vp(w), _vp(sx), _vp(sw), int(M), int(NC), int(K), None, 0, 0, _vp(out), None, None, None, None, None, None, None, 0)
     with _scope("gemm", 2.0 * int(M) * int(NC) * int(K), "2h"):
-        _check(lib().srl_h2_gemm_splitk(_stream(), ctypes.byref(d), int(ksplits)), "srl_h2_gemm_splitk")
+        _check(lib().srl_h2_gemm_splitk(_stream(), ctypes.byref(d), int(ksplits), int(bool(wide))), "srl_h2_gemm_splitk")
 
 
 def conv2d_obs_fwd_h2(desc, obs_ptr, mean, rstd, gamma, beta, w, bias, y_h2, y_scale, ws_ptr, row_index, y_absmax, y_mask,

@@ -539,3 +539,33 @@ def test_first_layer_block_weight_gradient_ragged_and_accumulated(n1, n2, indexe
     for a, b, name in zip(got, ref, ("dw", "db", "dgamma", "dbeta")):
         err = float((a - b).abs().max()) / float(b.abs().max())
         assert err <= 3e-6, (name, err)   # float32 accumulation in a different order; the pieces drop nothing at this slack
+
+
+def test_linear_forward_wide_split_with_finished_rows_written():
+    """The training-chunk variant of the split Linear forward (opt-in, `SRL_FC_TRAIN_SPLITK`): 256 channels per workgroup over two
+    k-ranges, and `srl_ln_heads_fwd` writing the finished rows (`x_out`) a backward pass will read: they equal the unsplit product."""
+    hip = _hip()
+    M, K, N, ks = 9000, 3136, 512, 2
+    x = _f(M, K, seed=33, relu=True, amp=2.0)
+    w = _f(N, K, seed=34, amp=0.03)
+    b = _f(N, seed=35, amp=0.1)
+    xbuf, sx, ax = torch.empty_like(x), _slot(0.0), _absmax(hip, x)
+    hip.h2_pack_rows(x.data_ptr(), K, M, K, xbuf.data_ptr(), absmax=ax.data_ptr(), scale_out=sx.data_ptr())
+    wp, sw, rw = _weights(hip, w, N, K, 0)
+    y = torch.zeros(M, N, device=DEV)
+    hip.h2_gemm(xbuf.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(), M, N, K, y.data_ptr(), bias=b.data_ptr(), act=1)
+    slabs = torch.full((ks, M, N), float("nan"), device=DEV)
+    hip.dispatch_tiles(reset=True)
+    hip.h2_gemm_splitk(xbuf.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(), M, N, K, slabs.data_ptr(), ks, wide=True)
+    assert hip.dispatch_tiles(reset=True) == {"h2:gemm:8:s2": 1}
+    heads = (6, 1)
+    g, be = 1 + 0.1 * _f(N, seed=36), 0.1 * _f(N, seed=37)
+    W, hb = [_f(a, N, seed=38 + i, amp=0.05) for i, a in enumerate(heads)], [_f(a, seed=40 + i, amp=0.1) for i, a in enumerate(heads)]
+    o = [torch.empty(M, a, device=DEV) for a in heads]
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    xo = torch.full((M, N), float("nan"), device=DEV)
+    hip.ln_heads_fwd(slabs.data_ptr(), N, M, N, g.data_ptr(), be.data_ptr(), [t.data_ptr() for t in W], [t.data_ptr() for t in hb],
+                     list(heads), [t.data_ptr() for t in o], list(heads), mean.data_ptr(), rstd.data_ptr(), x_slabs=ks,
+                     x_slab_stride=M * N, x_bias=b.data_ptr(), x_act=1, x_out=xo.data_ptr(), ldxo=N)
+    assert float((xo - y).abs().max()) <= 1e-5 * float(y.abs().max())
+    _close(xo, F.relu(x.double() @ w.double().t() + b.double()))
