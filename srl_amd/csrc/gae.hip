@@ -52,12 +52,11 @@ __device__ __forceinline__ void stats_finish(const GaeParams& p, double (&acc)[3
   __syncthreads();
   block_sum<3, 256>(acc, red);
   if (p.ws == nullptr) {
-    // the three sums leave as ONE atomic instruction (lane i adds sum i: one request for the line they share -- three instructions
-    // from a thousand workgroups are three thousand serialised visits of that line at ~10 ns each)
-    __syncthreads();
-    if (threadIdx.x == 0) red[0] = acc[0], red[1] = acc[1], red[2] = acc[2];
-    __syncthreads();
-    if (threadIdx.x < 3) atomicAdd(&p.stats[threadIdx.x], red[threadIdx.x]);
+    if (threadIdx.x == 0) {
+      atomicAdd(&p.stats[0], acc[0]);
+      atomicAdd(&p.stats[1], acc[1]);
+      atomicAdd(&p.stats[2], acc[2]);
+    }
     return;
   }
   StatsWs* ws = static_cast<StatsWs*>(p.ws);
@@ -437,10 +436,11 @@ __global__ __launch_bounds__(256) void masked_stats_kernel(const float* x, const
     acc[2] += v * v;
   }
   block_sum<3, 256>(acc, red);
-  __syncthreads();   // (one atomic instruction per workgroup: stats_finish)
-  if (threadIdx.x == 0) red[0] = acc[0], red[1] = acc[1], red[2] = acc[2];
-  __syncthreads();
-  if (threadIdx.x < 3) atomicAdd(&stats[threadIdx.x], red[threadIdx.x]);
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[0], acc[0]);
+    atomicAdd(&stats[1], acc[1]);
+    atomicAdd(&stats[2], acc[2]);
+  }
 }
 
 __global__ __launch_bounds__(256) void masked_normalize_kernel(const float* x, const uint8_t* mask, int invert, long n,
@@ -522,7 +522,7 @@ extern "C" int srl_masked_stats(void* stream, const float* x, const uint8_t* mas
   hipStream_t st = (hipStream_t)stream;
   SRL_HIP_TRY(hipMemsetAsync(stats, 0, 3 * sizeof(double), st));
   if (n == 0) return 0;
-  const unsigned grid = (unsigned)(srl_ceil_div(n, 256) < 512 ? srl_ceil_div(n, 256) : 512);
+  const unsigned grid = (unsigned)(srl_ceil_div(n, 256) < 2048 ? srl_ceil_div(n, 256) : 2048);
   hipLaunchKernelGGL(masked_stats_kernel, dim3(grid), dim3(256), 0, st, x, mask, mask_invert, n, stats);
   SRL_LAUNCH_CHECK();
   return 0;
