@@ -1326,7 +1326,7 @@ class HipNet:
             hip.gemm(n, sp.value_dim, sp.hidden_dim, a_feat.ptr, a_feat.ld, 0, self._p(f"{sp.aux_head.prefix}.weight"), sp.hidden_dim, 0,
                      aux_t.data_ptr(), sp.value_dim, bias=self._p(f"{sp.aux_head.prefix}.bias"))
             self.aux_value = aux_t[:n * sp.value_dim].view(n, sp.value_dim)
-        self._tape = (n, a_feat, a_act, a_tape, c_feat, c_act, c_tape) if keep_tape else None
+        self._tape = (n, a_feat, a_act, a_tape, c_feat, c_act, c_tape, cm, rnn) if keep_tape else None
         if cm:  # the heads' outputs back into time-major order
             hip.chunk_rows(logits_t.data_ptr(), logits_out.data_ptr(), rnn.T, rnn.B, rnn.C, atot, inverse=True)
             hip.chunk_rows(value_t.data_ptr(), value_out.data_ptr(), rnn.T, rnn.B, rnn.C, sp.value_dim, inverse=True)
@@ -1342,7 +1342,9 @@ class HipNet:
             raise hip.HipError("backward() without a preceding forward(keep_tape=True)")
         sp = self.spec
         self._gmax_next = -1
-        n, a_feat, a_act, a_tape, c_feat, c_act, c_tape = self._tape
+        # (row order and time structure of the TAPED pass: a forward without a tape in between -- an inference call on the same
+        # executor -- must not change what this backward pass assumes)
+        n, a_feat, a_act, a_tape, c_feat, c_act, c_tape, self._cm, self._rnn = self._tape
         atot = sum(sp.act_dims)
         dl = Buf(d_logits.data_ptr(), atot, n, atot)
         dv = Buf(d_value.data_ptr(), sp.value_dim, n, sp.value_dim)
