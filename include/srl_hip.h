@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 16
+#define SRL_HIP_ABI_VERSION 17
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -582,6 +582,17 @@ int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d);
  * per workgroup, NC a multiple of 256), for a training chunk: fewer operand bytes staged per multiply-add, the k-ranges restore
  * the workgroup count.  NC a multiple of 128. */
 int srl_h2_gemm_splitk(void* stream, const srl_h2_gemm_desc* d, int32_t ksplits, int32_t wide);
+/* Weight gradient of a dense layer over h2p rows (csrc/h2tn.h; ABI 17): gw[NA][NB] (+)= sum_m a[m, :]^T b[m, :] with a = the
+ * gradient with respect to the layer's output as h2p rows [M][NA] (srl_h2_pack_rows) and b = the layer's input as h2p rows
+ * [M][NB] (what srl_h2_conv kind 1 / srl_h2_gemm write), *sa, *sb their scales; row pitches in bytes (>= 4 NA, 4 NB; multiples of
+ * 16).  Both operands reach LDS by DMA and the matrix cores by transposing reads (ds_read_b64_tr_b16); every workgroup writes a
+ * float32 slab of its row range into `workspace` (srl_h2_wgrad_dense_workspace floats) and a second launch adds the slabs in a
+ * fixed order (no atomics: bit-reproducible).  accumulate 0: gw = sum; 1: gw += sum.  NA, NB multiples of 32.  Replaces the
+ * weight-gradient product of nn.Linear's backward (modules/utils.py:154-161, modules/cnn.py:128-133: the encoder's
+ * 3136 -> 512 layer, football_rnn.py:34-55: the dense tower). */
+int64_t srl_h2_wgrad_dense_workspace(int64_t M, int32_t NA, int32_t NB);
+int srl_h2_wgrad_dense(void* stream, const void* a, const void* b, const float* sa, const float* sb, int64_t M, int32_t NA, int32_t NB,
+                       int64_t a_row_bytes, int64_t b_row_bytes, float* workspace, float* gw, int32_t accumulate);
 /* srl_conv2d_obs_fwd with the output as the h2p rows kind 0 above reads (ent_order 2) instead of float32: byte kernels
  * only (uint8 channels-last frames, Cout 32), y_mask / y_absmax / workspace required; *y_scale = the scale used. */
 int srl_conv2d_obs_fwd_h2(void* stream, const srl_conv_desc* d, const void* obs, const float* mean, const float* rstd,

@@ -257,15 +257,24 @@ class H2Cnn:
                            wst.data_ptr(), channels_last=True, row_index=row_index, phase=phase,
                            dz_absmax_ptr=dz_absmax_ptr)
 
+    # The Linear's weight gradient on the pre-split operands both products of the data-gradient chain read anyway (dyh, a3) through
+    # csrc/h2tn.h (round 6: DMA in, transposing reads out); SRL_FC_WGRAD_TN=0: round 3's kernel on the float32 dy (A/B).
+    FC_WGRAD_TN = os.environ.get("SRL_FC_WGRAD_TN", "1") != "0"
+
     def _fc_wgrad(self, n, dy, dyh, a3, tag):
         net, g = self.net, self.net._g
         H = self.H
+        side = net._side_stream is not None and torch.cuda.current_stream() == net._side_stream
+        gb = g(f"{self.fc.prefix}.bias")
+        if self.FC_WGRAD_TN:
+            wsp = net.ws.get("h2tn_side" if side else "h2tn", hip.h2_wgrad_dense_workspace(n, H, 3136)).data_ptr()
+            hip.h2_wgrad_dense(dyh, a3, self._slot(S_DY, tag), self._slot(S_A3, tag), n, H, 3136, wsp, g(f"{self.fc.prefix}.weight"))
+            hip.colsum(dy.ptr, dy.ld, n, H, gb, accumulate=True)
+            return
         tiles = ((H + 127) // 128) * ((3136 + 127) // 128)
         from srl_amd.algorithm.hipnet import _split_for
         split = _split_for(n, tiles)
-        side = net._side_stream is not None and torch.cuda.current_stream() == net._side_stream
         wsp = net.ws.get("splitk_side" if side else "splitk", split * H * 3136).data_ptr() if split > 1 else None
-        gb = g(f"{self.fc.prefix}.bias")
         fused = hip.gemm_colsum_ok(H, 3136, n, dy.ptr, dy.ld, a3, 3136, 1)
         hip.gemm(H, 3136, n, dy.ptr, dy.ld, 1, a3, 3136, 1, g(f"{self.fc.prefix}.weight"), 3136, accumulate=True, split_k=split,
                  workspace=wsp, a_colsum=gb if fused else None, a_absmax=self._slot(M_DY, tag), b_h2_scale=self._slot(S_A3, tag))

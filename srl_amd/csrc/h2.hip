@@ -2,6 +2,8 @@
 // weight gradients).  See include/srl_hip.h for the contracts.
 #include "../../include/srl_hip.h"
 #include "h2conv.h"
+#include "h2tn.h"
+#include "gemm_core.h"
 #include "srl_common.h"
 
 using namespace srlh2;
@@ -230,6 +232,34 @@ extern "C" int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d) {
   else if (d->NC >= 128) rc = h2gemm_launch<4, H2X_DENSE, 3>((hipStream_t)stream, a);
   else rc = h2gemm_launch<2, H2X_DENSE, 3>((hipStream_t)stream, a);
   SRL_CHECK_ARG(rc == 0, "grid too large");
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
+// The dense weight gradient over h2p rows (h2tn.h): slabs of the row ranges, then their sum.
+extern "C" int64_t srl_h2_wgrad_dense_workspace(int64_t M, int32_t NA, int32_t NB) {
+  if (M <= 0 || NA <= 0 || NB <= 0) return 0;
+  int splits; int64_t rows;
+  h2tn_plan(M, ((NA + 255) / 256) * ((NB + 255) / 256), &splits, &rows);
+  return (int64_t)splits * NA * NB;
+}
+
+extern "C" int srl_h2_wgrad_dense(void* stream, const void* a, const void* b, const float* sa, const float* sb, int64_t M, int32_t NA,
+                                  int32_t NB, int64_t a_row_bytes, int64_t b_row_bytes, float* workspace, float* gw, int32_t accumulate) {
+  SRL_CHECK_ARG(a && b && sa && sb && workspace && gw && M >= 0 && NA > 0 && NB > 0 && NA % 32 == 0 && NB % 32 == 0,
+                "null tensor / NA, NB not multiples of 32");
+  SRL_CHECK_ARG(a_row_bytes >= (int64_t)NA * 4 && b_row_bytes >= (int64_t)NB * 4 && a_row_bytes % 16 == 0 && b_row_bytes % 16 == 0,
+                "row pitches: at least 4 bytes per channel, multiples of 16");
+  SRL_CHECK_ARG(16 * a_row_bytes < 0x7fffffffL && 16 * b_row_bytes < 0x7fffffffL, "rows of 128 MiB and more");
+  if (M == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  H2TnArgs g{};
+  g.a = a; g.b = b; g.sa = sa; g.sb = sb; g.M = M; g.NA = NA; g.NB = NB; g.a_row_bytes = a_row_bytes; g.b_row_bytes = b_row_bytes;
+  h2tn_plan(M, ((NA + 255) / 256) * ((NB + 255) / 256), &g.splits, &g.rows_per_split);
+  g.slabs = g.splits == 1 && !accumulate ? gw : workspace;   // (one range, nothing to add to: the slab IS the result)
+  srl_count_dispatch(SRL_DISP_H2, 4, 8, H2TN_NSLOT);
+  SRL_CHECK_ARG(h2tn_launch<0>(st, g) == 0, "grid too large");
+  if (g.slabs != gw) srlgemm::reduce_slabs(st, workspace, g.splits, 1L, (long)NA, (long)NB, gw, (long)NB, 0L, accumulate ? 1 : 0);
   SRL_LAUNCH_CHECK();
   return 0;
 }

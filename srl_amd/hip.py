@@ -25,7 +25,7 @@ _lib = None
 # (bench.py does, before its imports) -- INTEGRATION.md lists it with the other switches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -211,6 +211,9 @@ _SIGNATURES = {
     "srl_h2_conv": (c_int, [c_void_p, c_int32, POINTER(H2ConvArgs)]),
     "srl_h2_wgrad_workspace": (c_int64, [c_int32]),
     "srl_h2_wgrad": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "srl_h2_wgrad_dense_workspace": (c_int64, [c_int64, c_int32, c_int32]),
+    "srl_h2_wgrad_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int64, c_int64, c_void_p, c_void_p,
+                                   c_int32]),
     "srl_h2_gemm": (c_int, [c_void_p, POINTER(H2GemmDesc)]),
     "srl_h2_gemm_splitk": (c_int, [c_void_p, POINTER(H2GemmDesc), c_int32, c_int32]),
     "srl_conv2d_obs_fwd_h2": (c_int, [c_void_p, POINTER(ConvDesc)] + [c_void_p] * 13 + [c_int, c_int]),
@@ -375,7 +378,7 @@ def dispatch_counts(reset: bool = False) -> dict:
 
 def dispatch_tiles(reset: bool = False) -> dict:
     """Launches per kernel INSTANTIATION since the last reset (``srl_dispatch_tiles``), keyed ``family:p0xp1:k<p2>[:flags]`` --
-    e.g. ``gemm2h:64x256:k8:f7`` (tile, split-K factor, operand modes), ``h2:conv:0:s3`` (kind, ring depth), ``h2:gemm:4:s3``."""
+    e.g. ``gemm2h:64x256:k8:f7`` (tile, split-K factor, operand modes), ``h2:conv:0:s3`` (kind, ring depth), ``h2:gemm:4:s3``, ``h2:tn:8:s4`` (the dense weight gradient)."""
     keys, counts = (ctypes.c_uint64 * 256)(), (c_int64 * 256)()
     n = lib().srl_dispatch_tiles(keys, counts, 256, int(bool(reset)))
     if n < 0:
@@ -386,7 +389,7 @@ def dispatch_tiles(reset: bool = False) -> dict:
         fam, p0, p1, p2, fl = k >> 56, (k >> 40) & 0xffff, (k >> 24) & 0xffff, (k >> 8) & 0xffff, k & 0xff
         name = DISPATCH_FAMILIES[fam] if fam < len(DISPATCH_FAMILIES) else f"family{fam}"
         if name == "h2":
-            label = f"h2:{ {1: 'conv', 2: 'wgrad', 3: 'gemm'}.get(p0, p0)}:{p1}:s{p2}"
+            label = f"h2:{ {1: 'conv', 2: 'wgrad', 3: 'gemm', 4: 'tn', 5: 'gemmp'}.get(p0, p0)}:{p1}:s{p2}"
         elif name.startswith("obs_"):
             label = f"{name}:k{p0}:{('f32', 'h2', 'h2blk')[min(p1, 2)]}:split{p2}"  # h2blk: obs_h2.h, p2 = its persistent workgroups
         else:
@@ -1161,6 +1164,18 @@ def h2_wgrad(kind, x, dz, sx, sz, n, workspace, gw, gb=None):
     with _scope("conv_wgrad", flops, "2h"):
         _check(lib().srl_h2_wgrad(_stream(), int(kind), _vp(x), _vp(dz), _vp(sx), _vp(sz), int(n), _vp(workspace), _vp(gw), _vp(gb)),
                "srl_h2_wgrad")
+
+
+def h2_wgrad_dense_workspace(M, NA, NB) -> int:
+    return int(lib().srl_h2_wgrad_dense_workspace(int(M), int(NA), int(NB)))
+
+
+def h2_wgrad_dense(a, b, sa, sb, M, NA, NB, workspace, gw, accumulate=True, a_row_bytes=None, b_row_bytes=None):
+    """gw[NA][NB] (+)= a^T b over h2p rows: a [M][NA] (the output gradient), b [M][NB] (the layer's input)."""
+    with _scope("gemm", 2.0 * int(M) * int(NA) * int(NB), "2h"):
+        _check(lib().srl_h2_wgrad_dense(_stream(), _vp(a), _vp(b), _vp(sa), _vp(sb), int(M), int(NA), int(NB),
+                                        int(a_row_bytes or 4 * NA), int(b_row_bytes or 4 * NB), _vp(workspace), _vp(gw), int(bool(accumulate))),
+               "srl_h2_wgrad_dense")
 
 
 def h2_gemm(x, w, sx, sw, M, NC, K, out, bias=None, act=0, out_h2=False, out_scale=None, bound_in=None, bound_w=None, bound_b=None,

@@ -349,6 +349,37 @@ def test_linear_weight_gradient_reads_h2p_rows(M):
         _close(gb, dy.double().sum(0), tol=4e-6)
 
 
+@pytest.mark.parametrize("M,N,K", [(1111, 512, 3136), (BENCH_N, 512, 3136), (37, 256, 256), (1000, 96, 160), (2085, 320, 1056)])
+def test_dense_weight_gradient_on_presplit_operands(M, N, K):
+    """dW = dy^T x with BOTH operands as h2p rows (csrc/h2tn.h, round 6: LDS-DMA in, transposing reads out, slabs per row range added
+    in a fixed order): what `H2Cnn._fc_wgrad` launches for the benchmarked chunk (16 384 rows: 26 tiles x 9 row ranges), ragged row
+    counts (a last k-step of fewer than 16 rows, a last range shorter than the others), channel counts that are not multiples of the
+    256-channel tile, accumulate on / off, and bit-reproducibility."""
+    hip = _hip()
+    x = _f(M, K, seed=17, relu=True, amp=2.0)
+    dy = _f(M, N, seed=18, amp=1e-3)
+    xbuf, sx, ax = torch.empty_like(x), _slot(0.0), _absmax(hip, x)
+    hip.h2_pack_rows(x.data_ptr(), K, M, K, xbuf.data_ptr(), absmax=ax.data_ptr(), scale_out=sx.data_ptr())
+    dbuf, sd, ad = torch.empty_like(dy), _slot(0.0), _absmax(hip, dy)
+    hip.h2_pack_rows(dy.data_ptr(), N, M, N, dbuf.data_ptr(), absmax=ad.data_ptr(), scale_out=sd.data_ptr())
+    ws = torch.full((max(hip.h2_wgrad_dense_workspace(M, N, K), 4),), float("nan"), device=DEV)
+    ref = dy.double().t() @ x.double()
+    tol = 2e-6 if M < 2048 else 4e-6
+    g0 = torch.full((N, K), float("nan"), device=DEV)
+    hip.dispatch_tiles(reset=True)
+    hip.h2_wgrad_dense(dbuf.data_ptr(), xbuf.data_ptr(), sd.data_ptr(), sx.data_ptr(), M, N, K, ws.data_ptr(), g0.data_ptr(), accumulate=False)
+    assert list(hip.dispatch_tiles(reset=True)) == ["h2:tn:8:s4"]
+    _close(g0, ref, tol=tol)
+    base = _f(N, K, seed=19, amp=float(ref.abs().max()))
+    g1 = base.clone()
+    hip.h2_wgrad_dense(dbuf.data_ptr(), xbuf.data_ptr(), sd.data_ptr(), sx.data_ptr(), M, N, K, ws.data_ptr(), g1.data_ptr(), accumulate=True)
+    _close(g1, ref + base.double(), tol=tol)
+    g2 = torch.zeros(N, K, device=DEV)
+    ws.fill_(float("nan"))
+    hip.h2_wgrad_dense(dbuf.data_ptr(), xbuf.data_ptr(), sd.data_ptr(), sx.data_ptr(), M, N, K, ws.data_ptr(), g2.data_ptr(), accumulate=False)
+    assert torch.equal(g0, g2)
+
+
 # ------------------------------------------------------------------------------------------------ benchmark-size launches
 def test_benchmark_size_chunk_on_sampled_images():
     """One 16 384-image chunk -- the launches bench.py times -- through conv2 forward, its weight gradient and conv2's data
