@@ -477,6 +477,10 @@ int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, in
 /* *out = max(*out, max_i |x[i]|) (atomic: several calls may fold into one slot; the caller zeroes it): the range of a
  * weight tensor for the two-plane f16 products, once per parameter update. */
 int srl_absmax(void* stream, const float* x, int64_t n, float* out);
+/* Sign words of a ReLU output (ABI 17): bit e & 31 of mask[e >> 5] = (x[e] > 0), n a multiple of 32 -- what the convolution
+ * entry points write as y_mask when their channel count allows it, for an activation whose producer wrote none (a convolution with
+ * 4 or 8 channels in front of a wide Linear whose data gradient reads the derivative from bits, srl_h2_gemm's mask_in). */
+int srl_relu_mask(void* stream, const float* x, int64_t n, uint32_t* mask);
 /* Space-to-depth of a planar observation for a strided first convolution (stride s | KH, KW, H, W):
  * out[n, H/s, W/s, (c, ph, pw)] = obs[n, c, a*s + ph, b*s + pw], same element type, plus the whole-observation
  * LayerNorm statistics in the same pass.  A KxK stride-s convolution on obs becomes a (K/s)x(K/s) stride-1

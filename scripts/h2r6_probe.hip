@@ -10,7 +10,7 @@
 #include <vector>
 #include "../srl_amd/csrc/h2tn.h"
 #ifdef HAVE_G16
-#include "../srl_amd/csrc/h2g16.h"
+#include "../srl_amd/csrc/h2gemmp.h"
 #endif
 using namespace srlh2;
 

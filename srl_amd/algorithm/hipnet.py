@@ -426,9 +426,105 @@ class HipNet:
         t = self.ws.get(name, rows * cols)
         return Buf(t.data_ptr(), cols, rows, cols)
 
+    # ------------------------------------------------------------------ wide dense layers on pre-split operands (round 6)
+    # A Linear with thousands of inputs over thousands of rows (the football preset's tower, football_rnn.py:34-55 /
+    # cnn.py:96-135: 22528 -> 11264 -> 5632 -> 2816 -> 1408 -> 704) on the kernels the Atari encoder's Linear runs on: the input
+    # rows and the output gradient are split into two f16 pieces ONCE per pass (srl_h2_pack_rows: the same 4 bytes per element),
+    # the weights once per update in both orientations, and the three products -- srl_h2_gemm forward and data gradient,
+    # srl_h2_wgrad_dense -- move bytes by LDS-DMA and multiply three piece products.  Before, only the FIRST Linear behind the
+    # convolutions knew its input's range; the others ran the six-product bf16 kernels with register staging (gemm_bf16x3.h:
+    # 94 / 128 / 194 ms per launch of the 22528 -> 11264 layer at 51 200 rows, ~130-280 TFLOP/s).  SRL_H2_DENSE=0: off (A/B).
+    H2_DENSE = os.environ.get("SRL_H2_DENSE", "1") != "0"
+    H2D_MIN_ROWS = int(os.environ.get("SRL_H2_DENSE_MIN_ROWS", "4096"))
+    (H2D_MX, H2D_SX, H2D_MY, H2D_MDZ, H2D_SDZ, H2D_NP) = range(6)   # device floats of one pass through one layer
+    (H2D_SW, H2D_RW, H2D_SWT, H2D_RWT, H2D_NW) = range(5)           # ... of one layer's weights (per parameter version)
+
+    def _h2d_ok(self, L, x: Buf) -> bool:
+        return (self.H2_DENSE and self.on_gpu and x.rows >= self.H2D_MIN_ROWS and L.in_features >= 1024 and L.out_features >= 128
+                and L.in_features % 32 == 0 and L.out_features % 32 == 0 and L.act in (0, hip.ACT_RELU)
+                and x.ld == x.cols == L.in_features)
+
+    def _h2d_weights(self, L, transposed: bool):
+        """(h2p copy of the layer's weight in the orientation asked for, pointer of its slot array): once per parameter version."""
+        K, N = L.in_features, L.out_features
+        slots = self.ws.get(f"{L.prefix}.h2d.wslots", self.H2D_NW)
+        name = f"{L.prefix}.h2d.wt" if transposed else f"{L.prefix}.h2d.w"
+        buf = self.ws.get(name, N * K).data_ptr()
+        if not self._derived_fresh(name, buf):
+            amax = self._weight_range(L.prefix, N * K)
+            sp = slots.data_ptr()
+            if transposed:   # rows = input features: the data gradient's channels operand
+                hip.h2_weights(self._p(f"{L.prefix}.weight"), K, N, 1, amax, sp + 4 * self.H2D_SWT, sp + 4 * self.H2D_RWT, buf)
+            else:
+                hip.h2_weights(self._p(f"{L.prefix}.weight"), N, K, 0, amax, sp + 4 * self.H2D_SW, sp + 4 * self.H2D_RW, buf)
+        return buf, slots.data_ptr()
+
+    @staticmethod
+    def _h2d_pieces(n: int, width: int):
+        """Row ranges whose operands stay below srl_h2_gemm's 4 GiB (32-bit byte offsets)."""
+        step = max(256, ((0xfff00000 // (4 * width)) // 256) * 256)
+        return [(r0, min(n, r0 + step)) for r0 in range(0, n, step)]
+
+    def _linear_fwd_h2d(self, L, x: Buf, tag: str, x_range) -> Buf:
+        n, K, N = x.rows, L.in_features, L.out_features
+        sl = self.ws.get(f"{tag}{L.prefix}.h2d.slots", self.H2D_NP)
+        sl.zero_()
+        sp = sl.data_ptr()
+        wh, wsp = self._h2d_weights(L, False)
+        if x_range is None:
+            x_range = sp + 4 * self.H2D_MX
+            hip.absmax(x.ptr, n * K, x_range)
+        xh = self.ws.get(f"{tag}{L.prefix}.h2d.xh", n * K).data_ptr()
+        hip.h2_pack_rows(x.ptr, x.ld, n, K, xh, absmax=x_range, scale_out=sp + 4 * self.H2D_SX)
+        y = self._buf(f"{tag}{L.prefix}.y", n, N)
+        mask = self.ws.get(f"{tag}{L.prefix}.mask", n * N // 32, torch.int32).data_ptr() if L.act == hip.ACT_RELU else None
+        for r0, r1 in self._h2d_pieces(n, max(K, N)):
+            hip.h2_gemm(xh + 4 * r0 * K, wh, sp + 4 * self.H2D_SX, wsp + 4 * self.H2D_SW, r1 - r0, N, K, y.ptr + 4 * r0 * N,
+                        bias=self._p(f"{L.prefix}.bias"), act=1 if L.act == hip.ACT_RELU else 0,
+                        mask_out=(mask + 4 * (r0 * N // 32)) if mask else None, out_absmax=sp + 4 * self.H2D_MY)
+        self._y_range = sp + 4 * self.H2D_MY
+        return y._replace(mask=mask) if mask else y
+
+    def _linear_bwd_h2d(self, L, x: Buf, dz: Buf, in_act: int, need_dx: bool, tag: str, dz_range, dx_range) -> Optional[Buf]:
+        n, K, N = x.rows, L.in_features, L.out_features
+        sp = self.ws.get(f"{tag}{L.prefix}.h2d.slots", self.H2D_NP).data_ptr()   # (the forward pass's: S_X is read again)
+        if dz_range is None:
+            dz_range = sp + 4 * self.H2D_MDZ
+            hip.absmax(dz.ptr, n * N, dz_range)
+        dzh = self.ws.get(f"{tag}{L.prefix}.h2d.dzh", n * N).data_ptr()
+        hip.h2_pack_rows(dz.ptr, dz.ld, n, N, dzh, absmax=dz_range, scale_out=sp + 4 * self.H2D_SDZ)
+        xh = self.ws.get(f"{tag}{L.prefix}.h2d.xh", n * K).data_ptr()   # the forward pass's split input
+
+        def wg():
+            side = self._side_stream is not None and torch.cuda.current_stream() == self._side_stream
+            wsp = self.ws.get("h2tn_side" if side else "h2tn", hip.h2_wgrad_dense_workspace(n, N, K)).data_ptr()
+            hip.h2_wgrad_dense(dzh, xh, sp + 4 * self.H2D_SDZ, sp + 4 * self.H2D_SX, n, N, K, wsp, self._g(f"{L.prefix}.weight"))
+            hip.colsum(dz.ptr, dz.ld, n, N, self._g(f"{L.prefix}.bias"), accumulate=True)
+
+        if need_dx:
+            self._on_side(wg)
+        else:
+            wg()
+        if not need_dx:
+            return None
+        wth, wsp = self._h2d_weights(L, True)
+        dx = self._buf(f"{tag}{L.prefix}.dx", n, K)
+        x_mask = x.mask if in_act == hip.ACT_RELU else None
+        if in_act == hip.ACT_RELU and x_mask is None:
+            # the producer wrote no sign words (a convolution with 4 or 8 channels: its y_mask needs 32-channel blocks)
+            x_mask = self.ws.get(f"{tag}{L.prefix}.h2d.xmask", n * K // 32, torch.int32).data_ptr()
+            hip.relu_mask(x.ptr, n * K, x_mask)
+        for r0, r1 in self._h2d_pieces(n, max(K, N)):
+            hip.h2_gemm(dzh + 4 * r0 * N, wth, sp + 4 * self.H2D_SDZ, wsp + 4 * self.H2D_SWT, r1 - r0, K, N, dx.ptr + 4 * r0 * K,
+                        mask_in=(x_mask + 4 * (r0 * K // 32)) if x_mask else None, mask_in_h2order=False, out_absmax=dx_range)
+        return dx
+
     def _linear_fwd(self, L: ns.LinearSpec, x: Buf, tag: str, x_range: Optional[int] = None) -> Buf:
         """``x_range``: device float bounding max |x| when the producer tracked it (a convolution's output): with the
         weight's range the product runs on two f16 pieces per operand (srl_gemm_desc::a_absmax)."""
+        self._y_range = None
+        if self._h2d_ok(L, x):
+            return self._linear_fwd_h2d(L, x, tag, x_range)
         y = self._buf(f"{tag}{L.prefix}.y", x.rows, L.out_features)
         w_range = self._weight_range(L.prefix, L.out_features * L.in_features) if x_range is not None else None
         w, pre = self._p(f"{L.prefix}.weight"), None
@@ -459,6 +555,9 @@ class HipNet:
                     dx_into: Optional[Buf] = None, dx_accumulate=False, x_range=None, dz_range=None, dx_range=None) -> Optional[Buf]:
         """``x_range`` (the forward pass's range of this layer's input), ``dz_range``: both known -> the two products run on
         two f16 pieces per operand; ``dx_range``: device float the data gradient's range is folded into."""
+        if (dx_into is None and not dx_accumulate and self._h2d_ok(L, x) and dz.ld == dz.cols == L.out_features
+                and in_act in (0, hip.ACT_RELU)):
+            return self._linear_bwd_h2d(L, x, dz, in_act, need_dx, tag, dz_range, dx_range)
         wg = lambda: self._wgrad(L.out_features, L.in_features, x.rows, dz, x.ptr, x.ld, self._g(f"{L.prefix}.weight"),
                                  self._g(f"{L.prefix}.bias"), dz_range, x_range)
         if x_range is not None and need_dx and not dx_accumulate:
@@ -714,7 +813,7 @@ class HipNet:
                     cur = Buf(cur.ptr, L.in_features, n, L.in_features, cur.mask)
                 y = self._linear_fwd(L, cur, tag, cur_range)
                 tape.append(("linear", L, cur, cur_range, cur_act))
-                cur, cur_act, cur_range = y, L.act, None
+                cur, cur_act, cur_range = y, L.act, self._y_range   # (the wide-layer path measures its output's range)
             elif isinstance(L, ns.ObsLayerNormSpec):
                 pending_obs_ln = L
                 if isinstance(obs, torch.Tensor) and (obs.dim() < 2 or obs.shape[0] != n or

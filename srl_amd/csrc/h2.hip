@@ -3,6 +3,7 @@
 #include "../../include/srl_hip.h"
 #include "h2conv.h"
 #include "h2tn.h"
+#include "h2gemmp.h"
 #include "gemm_core.h"
 #include "srl_common.h"
 
@@ -216,10 +217,10 @@ extern "C" int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d) {
   static const bool wide_on = [] { const char* e = getenv("SRL_H2GEMM_WIDE"); return !(e && e[0] == '0'); }();
   const bool wide = wide_on && d->NC >= 1024 && d->K <= 1024;
   static const bool half_cnt = [] { const char* e = getenv("SRL_H2GEMM_HALF"); return e && e[0] == '1'; }();
-  srl_count_dispatch(SRL_DISP_H2, 3, wide ? 8 : (d->NC >= 128 ? 4 : 2), wide && !half_cnt ? 2 : 3);
   static const int dbg = [] { const char* e = getenv("SRL_H2G_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
   int rc;
+  const auto count_old = [&] { srl_count_dispatch(SRL_DISP_H2, 3, wide ? 8 : (d->NC >= 128 ? 4 : 2), wide && !half_cnt ? 2 : 3); };
   // (two 4-wavefront workgroups of 128 x 256 per CU on half k-steps instead of one 8-wavefront workgroup of 256 x 256: h2gemm.h HALF)
   // Alone 209.5 -> 192.3 us per 16 384 rows of the Linear's data gradient (same box; its leave-outs then overlap: no DMA 138, no
   // MFMAs 149, no stores 143) -- but inside the update, beside the three other row-chunk pipelines, the update gets SLOWER (91.1 /
@@ -227,6 +228,18 @@ extern "C" int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d) {
   // bytes per multiply-add (613 against 452 MB of counted traffic per launch) and that is what the neighbours compete for.  Opt-in
   // (SRL_H2GEMM_HALF=1) for the record.
   static const bool half_on = [] { const char* e = getenv("SRL_H2GEMM_HALF"); return e && e[0] == '1'; }();
+  // round 6: the wide product as a PERSISTENT kernel (h2gemmp.h: one workgroup per CU walks its tiles, the ring never drains, a
+  // tile's stores are not waited for) -- same operands, same piece products in the same order: bit-identical output.  207 -> 191 us
+  // per 16 384 rows of the Linear's data gradient on one box.  SRL_H2GEMM_P=0: the one-tile-per-workgroup launch (A/B).
+  static const bool pers_on = [] { const char* e = getenv("SRL_H2GEMM_P"); return !(e && e[0] == '0'); }();
+  if (wide && pers_on && !half_on && !dbg) {
+    srl_count_dispatch(SRL_DISP_H2, 5, 8, H2P_NSLOT);
+    rc = h2gemmp_launch<0>((hipStream_t)stream, a);
+    SRL_CHECK_ARG(rc == 0, "grid too large / rows of 8 MiB and more");
+    SRL_LAUNCH_CHECK();
+    return 0;
+  }
+  count_old();
   if (wide && half_on) rc = h2gemm_launch<8, H2X_DENSE, 3, false, true>((hipStream_t)stream, a);
   else if (wide) rc = h2gemm_launch<8, H2X_DENSE, 2, false>((hipStream_t)stream, a);
   else if (d->NC >= 128) rc = h2gemm_launch<4, H2X_DENSE, 3>((hipStream_t)stream, a);

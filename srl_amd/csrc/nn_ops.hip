@@ -825,6 +825,32 @@ extern "C" int srl_absmax(void* stream, const float* x, int64_t n, float* out) {
   return 0;
 }
 
+namespace {
+// one thread per word: 32 floats as eight 16-byte loads
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float4* __restrict__ x, long nwords, uint32_t* __restrict__ mask) {
+  for (long w = (long)blockIdx.x * 256 + threadIdx.x; w < nwords; w += (long)gridDim.x * 256) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 v = x[w * 8 + q];
+      bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (4 * q);
+    }
+    mask[w] = bits;
+  }
+}
+}  // namespace
+
+extern "C" int srl_relu_mask(void* stream, const float* x, int64_t n, uint32_t* mask) {
+  SRL_CHECK_ARG(x && mask && n >= 0 && n % 32 == 0 && ((uintptr_t)x & 15) == 0, "null / unaligned tensor, or a length that is not a multiple of 32");
+  if (n == 0) return 0;
+  const long nwords = n / 32;
+  long blocks = srl_ceil_div(nwords, 256L);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x), nwords, mask);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int srl_u8_to_f32(void* stream, const uint8_t* src, float* dst, int64_t n) {
   SRL_CHECK_ARG(src && dst, "null tensor");
   if (n == 0) return 0;

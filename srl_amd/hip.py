@@ -86,6 +86,7 @@ _SIGNATURES = {
     "srl_conv2d_nhwc_fwd": (c_int, [c_void_p, _CD] + [c_void_p] * 8 + [c_int]),
     "srl_presplit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "srl_absmax": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "srl_relu_mask": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_dispatch_tiles": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "srl_mlp_tape_floats": (c_int64, [POINTER(MlpLayer), c_int]),
     "srl_mlp_tape_floats_at": (c_int64, [POINTER(MlpLayer), c_int, c_int64]),
@@ -978,6 +979,11 @@ def mlp_bwd_dx(arr, x_ptr, ldx, rows, dy_ptr, lddy, dx_ptr, lddx):
 def absmax(x_ptr, n, out_ptr):
     """*out = max(*out, max |x|) over n float32 (``srl_absmax``)."""
     _check(lib().srl_absmax(_stream(), x_ptr, int(n), out_ptr), "srl_absmax")
+
+
+def relu_mask(x_ptr, n, mask_ptr):
+    """Sign words of n float32 (``srl_relu_mask``): bit e & 31 of mask[e >> 5] = x[e] > 0."""
+    _check(lib().srl_relu_mask(_stream(), x_ptr, int(n), mask_ptr), "srl_relu_mask")
 
 
 def conv2d_wgrad_workspace(d: ConvDesc) -> int:

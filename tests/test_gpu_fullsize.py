@@ -78,6 +78,39 @@ def check_analyze_rows_vs_oracle(tr, smp, sample, arr, picks=64):
     torch.cuda.empty_cache()
 
 
+def check_recurrent_chunks_vs_oracle(tr, smp, sample, arr, policy_args, picks=7, tol=1e-5):
+    """Full-size outputs of a RECURRENT net against the oracle: `policy.analyze(target="ppo")` over the whole sample, then sampled
+    (chunk, column) pairs -- a chunk of `chunk_len` steps starts from the state stored with its first row
+    (actor_critic_policy.py:349-380), so it is an independent little sample of its own -- through the float32
+    `OracleActorCritic`: new log-probability, state value and entropy of picks x chunk_len rows at 1e-5 relative."""
+    from oracle.net import OracleActorCritic
+    t_all, b_all = arr["reward"].shape[0] - 1, arr["reward"].shape[1]
+    C = policy_args.get("chunk_len", 10)
+    ar = tr.policy.analyze(smp[:t_all], target="ppo")
+    rng = np.random.default_rng(321)
+    cs = np.concatenate([[0, t_all // C - 1], rng.integers(0, t_all // C, picks - 2)])
+    bs = np.concatenate([[0, b_all - 1], rng.integers(0, b_all, picks - 2)])
+    rows = np.stack([np.arange(c * C, (c + 1) * C) for c in cs], 1)           # [C, picks]
+    got = [x.detach().cpu().numpy()[rows, bs[None, :]].reshape(C, picks) for x in (ar.new_action_log_probs, ar.state_values, ar.entropy)]
+    onet = OracleActorCritic(**policy_args)
+    onet.load_state_dict({k: v.numpy() for k, v in tr.policy.get_checkpoint()["state_dict"].items()})
+    tr_, tb_ = torch.from_numpy(rows).cuda(), torch.from_numpy(bs).cuda()[None, :].expand(C, picks)
+    frames = sample["obs.obs"][tr_, tb_].cpu().float()                      # [C, picks, ...]
+    action = torch.from_numpy(arr["action.x"][rows, bs[None, :]].astype(np.int64))
+    on_reset = torch.from_numpy(arr["on_reset"][rows, bs[None, :]].astype(np.float32))
+    state = tuple(torch.from_numpy(arr[f"policy_state.{k}"][rows, bs[None, :]]) for k in ("actor_hx", "critic_hx"))
+    with torch.no_grad():
+        lp, val, ent, _ = onet.analyze({"obs": frames}, action, on_reset, state)
+    if tr.policy.net.spec.popart:   # analyze returns the head's raw (normalised) values on both sides
+        pass
+    for name, g, o in zip(("log-prob", "value", "entropy"), got, (lp, val, ent)):
+        o = o.numpy().reshape(C, picks)
+        assert (np.abs(g - o) <= tol * np.maximum(np.abs(o), 1.0)).all(), (name, float(np.abs(g - o).max()))
+    del ar
+    tr.policy._analysis = None
+    tr.policy.net._tape = None
+
+
 def make(chunk_rows):
     return trainer_api.make(config.Trainer("mappo", args=dict(TRAINER, chunk_rows=chunk_rows)),
                             config.Policy("actor-critic", args=POLICY))
@@ -212,6 +245,20 @@ def test_config4_football_per_gpu_size():
 
     rows = net.encoder_rows
     pop_init = type("P", (), {"popart_state": pop0})
+    # the network's outputs at full size against the oracle (round 6: the dense tower runs on the pre-split kernels,
+    # `HipNet._linear_fwd_h2d`): 7 sampled chunks of 10 steps, each from its stored LSTM state
+    from srl_amd.algorithm.game_policies import FootballSMMPolicy
+    torch.nn.init.orthogonal_ = cheap   # (the oracle's constructor initialises 676 M parameters too, before the checkpoint replaces them)
+    try:
+        # (4e-5: two float32 evaluations of an eight-layer 22 528-wide tower + six LayerNorms + an LSTM; the layer-by-layer
+        # kernels sit at 2.2e-5 of the same oracle, the pre-split ones at 2.6e-5 -- `scripts/football_grad_check.py` holds both
+        # against the float64 oracle, gradients included)
+        check_recurrent_chunks_vs_oracle(tr, synthetic.to_sample_batch(dict(sample)), sample, arr,
+                                         dict(FootballSMMPolicy.defaults, rnn_type="lstm", seed=1,
+                                              cnn_layers=dict(obs=[(4, 5, 1, 0, "zeros"), (8, 3, 1, 0, "zeros"), (4, 3, 1, 0, "zeros")])),
+                                         tol=4e-5)
+    finally:
+        torch.nn.init.orthogonal_ = orig
     s0, p0, smp = one_step(rows)
     check_gae_vs_oracle(smp, arr, popart_net=pop_init)
     s1, p1, _ = one_step(rows // 2 + 17)  # more, unevenly cut encoder pieces

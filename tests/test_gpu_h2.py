@@ -274,7 +274,7 @@ def test_linear_forward_and_data_gradient_vs_float64(M):
                               mask_in=mask.data_ptr(), mask_in_h2order=True)
     hip.dispatch_tiles(reset=True)
     run()
-    assert hip.dispatch_tiles(reset=True) == {"h2:gemm:8:s2": 1}   # wide output, short reduction: 256 channels per workgroup
+    assert hip.dispatch_tiles(reset=True) == {"h2:gemmp:8:s4": 1}   # wide output, short reduction: the persistent kernel (h2gemmp.h)
     first = dx.clone()
     got = torch.empty(M, K, device=DEV)
     hip.h2_unpack_rows(dx.data_ptr(), M, K, osc.data_ptr(), got.data_ptr(), K)
@@ -378,6 +378,52 @@ def test_dense_weight_gradient_on_presplit_operands(M, N, K):
     ws.fill_(float("nan"))
     hip.h2_wgrad_dense(dbuf.data_ptr(), xbuf.data_ptr(), sd.data_ptr(), sx.data_ptr(), M, N, K, ws.data_ptr(), g2.data_ptr(), accumulate=False)
     assert torch.equal(g0, g2)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 1024, 64), (1111, 1056, 512), (2000, 3136, 32), (4133, 1280, 1024)])
+def test_persistent_wide_product_every_epilogue(M, N, K):
+    """csrc/h2gemmp.h (round 6: persistent workgroups, a flat ring across tiles, stores not waited for) through `srl_h2_gemm`'s wide
+    case, every epilogue it carries: float32 output with bias + ReLU + sign words out; h2p output with bias + ReLU (the bound's
+    bias term); the data-gradient form with the ReLU derivative in natural order; ragged rows, a narrow last channel tile, one
+    pair of k-steps per tile (K = 32: a tile boundary at every barrier), tiles with more than one visit per workgroup."""
+    hip = _hip()
+    x = _f(M, K, seed=41, relu=True, amp=2.0)
+    w = _f(N, K, seed=42, amp=0.03)
+    b = _f(N, seed=43, amp=0.1)
+    xbuf, sx, ax = torch.empty_like(x), _slot(0.0), _absmax(hip, x)
+    hip.h2_pack_rows(x.data_ptr(), K, M, K, xbuf.data_ptr(), absmax=ax.data_ptr(), scale_out=sx.data_ptr())
+    wp, sw, rw = _weights(hip, w, N, K, 0)
+    ref = F.relu(x.double() @ w.double().t() + b.double())
+    # float32 out, bias, ReLU, sign words
+    y = torch.full((M, N), float("nan"), device=DEV)
+    mo = torch.zeros(M * N // 32, dtype=torch.int32, device=DEV)
+    oam = _slot(0.0)
+    hip.dispatch_tiles(reset=True)
+    hip.h2_gemm(xbuf.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(), M, N, K, y.data_ptr(), bias=b.data_ptr(), act=1,
+                mask_out=mo.data_ptr(), out_absmax=oam.data_ptr())
+    assert hip.dispatch_tiles(reset=True) == {"h2:gemmp:8:s4": 1}
+    _close(y, ref)
+    assert int((mo != _mask_natural(y.view(M, 1, 1, N))).sum()) == 0
+    assert abs(float(oam) - float(y.abs().max())) <= 1e-6 * float(y.abs().max())
+    # h2p out with the bias in the bound
+    yh = torch.zeros(M * N, device=DEV)
+    osc, bb = _slot(0.0), _absmax(hip, b)
+    hip.h2_gemm(xbuf.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(), M, N, K, yh.data_ptr(), bias=b.data_ptr(), act=1, out_h2=True,
+                out_scale=osc.data_ptr(), bound_in=ax.data_ptr(), bound_w=rw.data_ptr(), bound_b=bb.data_ptr())
+    got = torch.empty(M, N, device=DEV)
+    hip.h2_unpack_rows(yh.data_ptr(), M, N, osc.data_ptr(), got.data_ptr(), N)
+    _close(got, ref, tol=4e-6)
+    # data-gradient form, derivative bits in natural order
+    act = _f(M, N, seed=44, relu=True)
+    mi = _mask_natural(act.view(M, 1, 1, N))
+    dx = torch.zeros(M * N, device=DEV)
+    oam2 = _slot(0.0)
+    hip.h2_gemm(xbuf.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(), M, N, K, dx.data_ptr(), out_h2=True, out_scale=osc.data_ptr(),
+                bound_in=ax.data_ptr(), bound_w=rw.data_ptr(), out_absmax=oam2.data_ptr(), mask_in=mi.data_ptr(), mask_in_h2order=False)
+    hip.h2_unpack_rows(dx.data_ptr(), M, N, osc.data_ptr(), got.data_ptr(), N)
+    ref2 = (x.double() @ w.double().t()) * (act > 0)
+    _close(got, ref2)
+    assert abs(float(oam2) - float(got.abs().max())) <= 2e-6 * float(got.abs().max())
 
 
 # ------------------------------------------------------------------------------------------------ benchmark-size launches

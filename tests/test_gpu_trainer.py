@@ -275,6 +275,68 @@ def test_step_vs_oracle_larger(T, B, chunk):
         assert np.abs(sd[k].numpy() - osd[k].numpy()).max() <= 3e-5, k
 
 
+@pytest.mark.parametrize("kind", ["vector", "image"])
+def test_wide_dense_layers_on_presplit_operands_vs_oracle(kind, monkeypatch):
+    """`HipNet._linear_fwd_h2d / _linear_bwd_h2d` (round 6): a Linear with >= 1024 inputs over >= 4096 rows runs its three
+    products on the pre-split kernels (srl_h2_pack_rows + srl_h2_gemm / srl_h2_wgrad_dense) -- the football preset's dense tower.
+    `vector`: LayerNorm -> Linear 1056 -> 256 (no ReLU mask below it); `image`: the reference's default convolution stack
+    (cnn.py:96-98: 4 / 8 / 4 channels -- no sign words from the convolutions, `srl_relu_mask` makes them) in front of
+    Linear 1024 -> 512 + the rest of the halving tower.  One step against the CPU oracle (returns, loss terms, gradient norm, every
+    tensor's gradient to 2 % of its rms), and both this step's and the layer-by-layer kernels' (SRL_H2_DENSE=0) gradients against the
+    float64 oracle: every tensor's error at most 3 x the layer-by-layer kernels' (+ 2e-6 of the tensor's largest element)."""
+    from srl_amd import hip
+    from srl_amd.algorithm.hipnet import HipNet
+    if kind == "vector":
+        pargs = dict(obs_dim=1056, action_dim=5, hidden_dim=256, num_dense_layers=1, num_rnn_layers=0, popart=False, layernorm=True,
+                     shared_backbone=False, chunk_len=8, seed=31)
+        spec, T, B = {"obs": ((1056,), "f32")}, 64, 80
+    else:
+        pargs = dict(obs_dim={"obs": (4, 24, 24)}, action_dim=5, hidden_dim=64, num_dense_layers=0, num_rnn_layers=0, popart=False,
+                     layernorm=True, shared_backbone=True, chunk_len=8, seed=32,
+                     cnn_layers=dict(obs=[(4, 5, 1, 0, 'zeros'), (8, 3, 1, 0, 'zeros'), (4, 3, 1, 0, 'zeros')]))
+        spec, T, B = {"obs": ((4, 24, 24), "u8")}, 64, 72
+    targs = dict(ATARI_TRAINER, chunk_rows=1 << 20)
+    arrays = synthetic.make_sample_arrays(seed=3, T=T, B=B, obs_spec=spec, action_dims=5, p_done=0.02)
+    grads, stats = {}, {}
+    for dense in (True, False):
+        monkeypatch.setattr(HipNet, "H2_DENSE", dense)
+        trainer = make_trainer(pargs, targs)
+        net = trainer.policy.net
+        if dense:
+            onet = OracleActorCritic(**pargs)
+            onet.load_state_dict({k: v.numpy() for k, v in trainer.policy.get_checkpoint()["state_dict"].items()})
+            oracle = OracleMappo(onet, **{k: v for k, v in targs.items() if k != "chunk_rows"})
+        sample = synthetic.to_sample_batch(arrays)
+        hip.dispatch_tiles(reset=True)
+        res = trainer.step(sample)
+        tiles = hip.dispatch_tiles(reset=True)
+        assert (any(k.startswith("h2:tn") for k in tiles) and any(k.startswith("h2:gemm") for k in tiles)) == dense, tiles
+        grads[dense] = {k: v.clone() for k, v in net.flat_to_reference(net.grad.detach().cpu()).items()}
+        stats[dense] = res.stats
+        if dense:
+            ostats, oout = oracle.step(arrays)
+            assert close(sample.analyzed_result.ret, oout["ret"], 1e-5)
+            for k in ("policy_loss", "value_loss", "entropy", "grad_norm"):
+                assert abs(res.stats[k] - ostats[k]) <= 2e-5 * max(abs(ostats[k]), 1e-2), (k, res.stats[k], ostats[k])
+            for k, p in onet.params.items():
+                g_ref = p.grad.double().numpy()
+                rms = np.sqrt((g_ref**2).mean())
+                err = np.sqrt(((grads[True][k].double().numpy() - g_ref)**2).mean())
+                assert err <= 2e-2 * rms, (k, float(err / max(rms, 1e-30)))
+    # the two kernel families against the float64 restatement of the same step: the pre-split kernels' gradients are as close to it
+    # as the layer-by-layer kernels' (a LayerNorm weight's gradient is a sum over rows that cancels to 1e-2 of its terms: the two
+    # float32 paths differ there by 2e-4 of the tensor's largest element, both 1e-4 from float64)
+    onet64 = OracleActorCritic(**pargs, dtype=torch.float64)
+    onet64.load_state_dict({k: v.numpy() for k, v in make_trainer(pargs, targs).policy.get_checkpoint()["state_dict"].items()})
+    OracleMappo(onet64, **{k: v for k, v in targs.items() if k != "chunk_rows"}).step(arrays)
+    for k, p in onet64.params.items():
+        g64 = p.grad.double()
+        e1 = float((grads[True][k].double() - g64).abs().max())
+        e0 = float((grads[False][k].double() - g64).abs().max())
+        scale = float(g64.abs().max())
+        assert e1 <= 3.0 * e0 + 2e-6 * scale, (k, e1, e0, scale)
+
+
 def test_cnn_step_vs_oracle_chunked():
     """NatureCNN with more samples than one row-chunk, uint8 frames resident on the device."""
     targs = dict(ATARI_TRAINER, chunk_rows=40)
