@@ -477,6 +477,19 @@ int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, in
 /* *out = max(*out, max_i |x[i]|) (atomic: several calls may fold into one slot; the caller zeroes it): the range of a
  * weight tensor for the two-plane f16 products, once per parameter update. */
 int srl_absmax(void* stream, const float* x, int64_t n, float* out);
+/* Direct convolutions for layers with 4 or 8 channels on both sides (csrc/conv_small.hip; ABI 17): NHWC float32, 3 x 3, stride 1, no
+ * padding, (Cin, Cout) in {(4, 4), (4, 8), (8, 4)} -- the reference's default convolution stack behind its first layer
+ * (modules/cnn.py:96-98) as vector-unit kernels (a thread per pixel, weights as scalar operands; the weight gradient with all
+ * 9 Cin Cout sums of a pixel column in registers, slabs per wavefront + a second launch: no atomics).  w: [Cout, 3, 3, Cin].
+ * fwd: y = act(conv(x, w) + bias) (bias may be NULL).  dgrad: dx = (dz conv^T w) * act'(x_act) with x_act = the layer's INPUT
+ * activation (the output of the activation `dact`: 0 none / x_act NULL, 1 relu, 2 tanh).  wgrad: gw += dz^T patches(x), gb +=
+ * column sums of dz (gb may be NULL); workspace: srl_conv2d_small_wgrad_workspace floats.  Replace nn.Conv2d forward / backward
+ * (modules/cnn.py:57-72) for these geometries. */
+int srl_conv2d_small_supported(const srl_conv_desc* d);
+int srl_conv2d_small_fwd(void* stream, const srl_conv_desc* d, const float* x, const float* w, const float* bias, float* y);
+int srl_conv2d_small_dgrad(void* stream, const srl_conv_desc* d, const float* dz, const float* w, const float* x_act, int32_t dact, float* dx);
+int64_t srl_conv2d_small_wgrad_workspace(const srl_conv_desc* d);
+int srl_conv2d_small_wgrad(void* stream, const srl_conv_desc* d, const float* x, const float* dz, float* workspace, float* gw, float* gb);
 /* Sign words of a ReLU output (ABI 17): bit e & 31 of mask[e >> 5] = (x[e] > 0), n a multiple of 32 -- what the convolution
  * entry points write as y_mask when their channel count allows it, for an activation whose producer wrote none (a convolution with
  * 4 or 8 channels in front of a wide Linear whose data gradient reads the derivative from bits, srl_h2_gemm's mask_in). */

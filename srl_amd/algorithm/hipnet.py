@@ -483,17 +483,19 @@ class HipNet:
                         bias=self._p(f"{L.prefix}.bias"), act=1 if L.act == hip.ACT_RELU else 0,
                         mask_out=(mask + 4 * (r0 * N // 32)) if mask else None, out_absmax=sp + 4 * self.H2D_MY)
         self._y_range = sp + 4 * self.H2D_MY
+        # what the backward pass reads again, found by the tape record's input (the backward pass of an encoder cut into pieces
+        # walks every piece under ONE tag: names would find another piece's buffers)
+        self.__dict__.setdefault("_h2d_saved", {})[(L.prefix, x.ptr)] = (xh, sp)
         return y._replace(mask=mask) if mask else y
 
     def _linear_bwd_h2d(self, L, x: Buf, dz: Buf, in_act: int, need_dx: bool, tag: str, dz_range, dx_range) -> Optional[Buf]:
         n, K, N = x.rows, L.in_features, L.out_features
-        sp = self.ws.get(f"{tag}{L.prefix}.h2d.slots", self.H2D_NP).data_ptr()   # (the forward pass's: S_X is read again)
+        xh, sp = self._h2d_saved[(L.prefix, x.ptr)]   # the forward pass's split input and its slots (S_X is read again)
         if dz_range is None:
             dz_range = sp + 4 * self.H2D_MDZ
             hip.absmax(dz.ptr, n * N, dz_range)
         dzh = self.ws.get(f"{tag}{L.prefix}.h2d.dzh", n * N).data_ptr()
         hip.h2_pack_rows(dz.ptr, dz.ld, n, N, dzh, absmax=dz_range, scale_out=sp + 4 * self.H2D_SDZ)
-        xh = self.ws.get(f"{tag}{L.prefix}.h2d.xh", n * K).data_ptr()   # the forward pass's split input
 
         def wg():
             side = self._side_stream is not None and torch.cuda.current_stream() == self._side_stream
@@ -518,6 +520,14 @@ class HipNet:
             hip.h2_gemm(dzh + 4 * r0 * N, wth, sp + 4 * self.H2D_SDZ, wsp + 4 * self.H2D_SWT, r1 - r0, K, N, dx.ptr + 4 * r0 * K,
                         mask_in=(x_mask + 4 * (r0 * K // 32)) if x_mask else None, mask_in_h2order=False, out_absmax=dx_range)
         return dx
+
+    CONV_SMALL = os.environ.get("SRL_CONV_SMALL", "1") != "0"
+
+    def _conv_small(self, L, desc) -> bool:
+        """A convolution behind the first layer with 4 or 8 channels on both sides, 3 x 3, stride 1, no padding: the direct
+        vector-unit kernels (csrc/conv_small.hip).  SRL_CONV_SMALL=0: the implicit GEMMs (A/B)."""
+        return (self.CONV_SMALL and self.on_gpu and not L.first and not L.pad and L.stride == 1 and L.k == 3
+                and hip.conv2d_small_supported(desc))
 
     def _linear_fwd(self, L: ns.LinearSpec, x: Buf, tag: str, x_range: Optional[int] = None) -> Buf:
         """``x_range``: device float bounding max |x| when the producer tracked it (a convolution's output): with the
@@ -556,7 +566,7 @@ class HipNet:
         """``x_range`` (the forward pass's range of this layer's input), ``dz_range``: both known -> the two products run on
         two f16 pieces per operand; ``dx_range``: device float the data gradient's range is folded into."""
         if (dx_into is None and not dx_accumulate and self._h2d_ok(L, x) and dz.ld == dz.cols == L.out_features
-                and in_act in (0, hip.ACT_RELU)):
+                and in_act in (0, hip.ACT_RELU) and (L.prefix, x.ptr) in self.__dict__.get("_h2d_saved", {})):
             return self._linear_bwd_h2d(L, x, dz, in_act, need_dx, tag, dz_range, dx_range)
         wg = lambda: self._wgrad(L.out_features, L.in_features, x.rows, dz, x.ptr, x.ld, self._g(f"{L.prefix}.weight"),
                                  self._g(f"{L.prefix}.bias"), dz_range, x_range)
@@ -944,8 +954,12 @@ class HipNet:
                     saved = (src, is_u8, mean, rstd, pending_obs_ln, bool(L.s2d), row_index)
                 else:
                     assert cur.ld == L.cin and cur.rows == n * h * w
-                    y_range = self._act_range() if implicit else None
-                    if implicit:
+                    small = implicit and self._conv_small(L, desc)
+                    y_range = self._act_range() if implicit and not small else None
+                    if small:
+                        # 4 / 8 channels on both sides: a direct vector-unit kernel (csrc/conv_small.hip), not a matrix-core tile
+                        hip.conv2d_small_fwd(desc, cur.ptr, self._p(f"{L.prefix}.weight"), self._p(f"{L.prefix}.bias"), y.ptr)
+                    elif implicit:
                         w_range = self._weight_range(L.prefix, L.cout * kdim) if cur_range is not None and not L.pad else None
                         xr = cur_range if w_range is not None else None
                         w, pre = self._p(f"{L.prefix}.weight"), None
@@ -1073,6 +1087,13 @@ class HipNet:
                                                gw, gb, self._g(f"{lnspec.prefix}.weight"), self._g(f"{lnspec.prefix}.bias"),
                                                self.ws.get("conv_obs_bwd", wsz).data_ptr(), channels_last=chlast, row_index=row_index)
                         g = None
+                    elif self._conv_small(L, desc):
+                        wws = self.ws.get("conv_small_wgrad", hip.conv2d_small_wgrad_workspace(desc)).data_ptr()
+                        self._on_side(lambda d=desc, xp=x.ptr, gp=g.ptr: hip.conv2d_small_wgrad(d, xp, gp, wws, gw, gb))
+                        h, w = L.in_hw
+                        dx = self._buf(f"{tag}{L.prefix}.dx", n * h * w, L.cin)
+                        hip.conv2d_small_dgrad(desc, g.ptr, wp, x.ptr if in_act else None, in_act, dx.ptr)
+                        g, g_range = dx, None
                     else:
                         wsz = hip.conv2d_wgrad_workspace(desc)
                         if g_range is None and not L.pad and g.ld == g.cols:

@@ -232,7 +232,13 @@ extern "C" int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d) {
   // tile's stores are not waited for) -- same operands, same piece products in the same order: bit-identical output.  207 -> 191 us
   // per 16 384 rows of the Linear's data gradient on one box.  SRL_H2GEMM_P=0: the one-tile-per-workgroup launch (A/B).
   static const bool pers_on = [] { const char* e = getenv("SRL_H2GEMM_P"); return !(e && e[0] == '0'); }();
-  if (wide && pers_on && !half_on && !dbg) {
+  // ... and every product large enough that a 256 x 256 tile still fills the chip several times over (the football tower's layers:
+  // 51 200 rows x 704 ... 22 528 channels): a third fewer operand bytes staged per multiply-add than the 256 x 128 tiles, 4-13 %
+  // faster at those shapes (scripts/h2r6_probe.hip)
+  // (chosen from the layer's widths and a row floor only: the pieces an encoder's rows are cut into must not change kernels --
+  // `test_config4_football_per_gpu_size` holds an update to its own result under another cut)
+  const bool big = d->M >= 4096 && d->NC >= 2048 && d->K >= 1024;
+  if ((wide || big) && pers_on && !half_on && !dbg) {
     srl_count_dispatch(SRL_DISP_H2, 5, 8, H2P_NSLOT);
     rc = h2gemmp_launch<0>((hipStream_t)stream, a);
     SRL_CHECK_ARG(rc == 0, "grid too large / rows of 8 MiB and more");

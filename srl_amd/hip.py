@@ -87,6 +87,11 @@ _SIGNATURES = {
     "srl_presplit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "srl_absmax": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "srl_relu_mask": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "srl_conv2d_small_supported": (c_int, [POINTER(ConvDesc)]),
+    "srl_conv2d_small_fwd": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srl_conv2d_small_dgrad": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "srl_conv2d_small_wgrad_workspace": (c_int64, [POINTER(ConvDesc)]),
+    "srl_conv2d_small_wgrad": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_dispatch_tiles": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "srl_mlp_tape_floats": (c_int64, [POINTER(MlpLayer), c_int]),
     "srl_mlp_tape_floats_at": (c_int64, [POINTER(MlpLayer), c_int, c_int64]),
@@ -916,6 +921,30 @@ def _conv_flops(d: ConvDesc):
 def conv2d_supported(d: ConvDesc, first_layer) -> bool:
     """first_layer: 0 / False = NHWC activation layer, 1 / True = planar observation, 2 = channels-last observation."""
     return bool(lib().srl_conv2d_supported(ctypes.byref(d), int(first_layer)))
+
+
+def conv2d_small_supported(d: ConvDesc) -> bool:
+    """Whether the direct vector-unit kernels take this layer (3 x 3, stride 1, 4 / 8 channels: csrc/conv_small.hip)."""
+    return bool(lib().srl_conv2d_small_supported(ctypes.byref(d)))
+
+
+def conv2d_small_fwd(d: ConvDesc, x_ptr, w_ptr, bias_ptr, y_ptr):
+    with _scope("conv_fwd", _conv_flops(d), "f32"):
+        _check(lib().srl_conv2d_small_fwd(_stream(), ctypes.byref(d), x_ptr, w_ptr, bias_ptr, y_ptr), "srl_conv2d_small_fwd")
+
+
+def conv2d_small_dgrad(d: ConvDesc, dz_ptr, w_ptr, x_act_ptr, dact, dx_ptr):
+    with _scope("conv_dgrad", _conv_flops(d), "f32"):
+        _check(lib().srl_conv2d_small_dgrad(_stream(), ctypes.byref(d), dz_ptr, w_ptr, x_act_ptr, int(dact), dx_ptr), "srl_conv2d_small_dgrad")
+
+
+def conv2d_small_wgrad_workspace(d: ConvDesc) -> int:
+    return int(lib().srl_conv2d_small_wgrad_workspace(ctypes.byref(d)))
+
+
+def conv2d_small_wgrad(d: ConvDesc, x_ptr, dz_ptr, ws_ptr, gw_ptr, gb_ptr=None):
+    with _scope("conv_wgrad", _conv_flops(d), "f32"):
+        _check(lib().srl_conv2d_small_wgrad(_stream(), ctypes.byref(d), x_ptr, dz_ptr, ws_ptr, gw_ptr, gb_ptr), "srl_conv2d_small_wgrad")
 
 
 def conv2d_fwd_two_piece(d: ConvDesc, x_absmax, w_absmax) -> bool:

@@ -1580,3 +1580,47 @@ def test_mlp_chain_backward_with_input_gradient(rows, chain):
     assert rel_close(dxo.cpu().numpy(), x64.grad.numpy(), 2e-5, scale=float(x64.grad.abs().max()))
     for k, (g, p_) in enumerate(zip(dev_g, p64)):
         assert rel_close(g.cpu().numpy(), p_.grad.numpy(), 2e-5, scale=float(p_.grad.abs().max()) + 1e-6), k
+
+
+@pytest.mark.parametrize("cin,cout", [(4, 8), (8, 4), (4, 4)])
+@pytest.mark.parametrize("n,H,W", [(3, 7, 9), (5, 36, 70), (64, 20, 35)])
+def test_small_channel_direct_convolutions_vs_torch(cin, cout, n, H, W):
+    """csrc/conv_small.hip (round 6): 3 x 3 stride-1 convolutions with 4 / 8 channels as vector-unit kernels -- forward (bias,
+    ReLU), data gradient (with the ReLU derivative of the layer's input) and weight / bias gradient (accumulating; slabs per
+    wavefront) against float64 torch convolutions: widths that are not multiples of the 32-pixel column blocks, an odd image count
+    (the weight gradient pairs images), heights that are not multiples of the three-row window."""
+    from srl_amd import hip
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(7 + cin * 10 + cout)
+    x = torch.rand(n, H, W, cin, device="cuda", generator=g) * 2 - 1
+    x = torch.relu(x)                                      # the input is a ReLU output (its derivative gates dx)
+    w = (torch.rand(cout, 3, 3, cin, device="cuda", generator=g) * 2 - 1) * 0.3
+    b = (torch.rand(cout, device="cuda", generator=g) * 2 - 1) * 0.1
+    d = hip.conv_desc(n, H, W, cin, 3, 3, 1, cout, hip.ACT_RELU)
+    assert hip.conv2d_small_supported(d)
+    y = torch.full((n, H - 2, W - 2, cout), float("nan"), device="cuda")
+    hip.conv2d_small_fwd(d, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr())
+    xr, wr = x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2)
+    ref = torch.relu(F.conv2d(xr, wr, b.double())).permute(0, 2, 3, 1)
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    dz = (torch.rand(n, H - 2, W - 2, cout, device="cuda", generator=g) * 2 - 1) * 1e-2
+    dx = torch.full((n, H, W, cin), float("nan"), device="cuda")
+    hip.conv2d_small_dgrad(d, dz.data_ptr(), w.data_ptr(), x.data_ptr(), hip.ACT_RELU, dx.data_ptr())
+    refd = F.conv_transpose2d(dz.double().permute(0, 3, 1, 2), wr).permute(0, 2, 3, 1) * (x > 0)
+    assert float((dx.double() - refd).abs().max()) <= 2e-6 * float(refd.abs().max())
+    dx0 = torch.full((n, H, W, cin), float("nan"), device="cuda")
+    hip.conv2d_small_dgrad(d, dz.data_ptr(), w.data_ptr(), None, 0, dx0.data_ptr())
+    refd0 = F.conv_transpose2d(dz.double().permute(0, 3, 1, 2), wr).permute(0, 2, 3, 1)
+    assert float((dx0.double() - refd0).abs().max()) <= 2e-6 * float(refd0.abs().max())
+    gw0, gb0 = torch.rand(cout, 3, 3, cin, device="cuda", generator=g), torch.rand(cout, device="cuda", generator=g)
+    gw, gb = gw0.clone(), gb0.clone()
+    ws = torch.full((hip.conv2d_small_wgrad_workspace(d),), float("nan"), device="cuda")
+    hip.conv2d_small_wgrad(d, x.data_ptr(), dz.data_ptr(), ws.data_ptr(), gw.data_ptr(), gb.data_ptr())
+    refw = torch.nn.grad.conv2d_weight(xr, wr.shape, dz.double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1) + gw0.double()
+    refb = dz.double().sum((0, 1, 2)) + gb0.double()
+    assert float((gw.double() - refw).abs().max()) <= 4e-6 * float(refw.abs().max())
+    assert float((gb.double() - refb).abs().max()) <= 4e-6 * float(refb.abs().max())
+    gw2, gb2 = gw0.clone(), gb0.clone()
+    hip.conv2d_small_wgrad(d, x.data_ptr(), dz.data_ptr(), ws.data_ptr(), gw2.data_ptr(), gb2.data_ptr())
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    assert not hip.conv2d_small_supported(hip.conv_desc(n, H, W, 8, 3, 3, 1, 8)) and not hip.conv2d_small_supported(hip.conv_desc(n, H, W, 4, 5, 5, 1, 4))
