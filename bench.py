@@ -248,10 +248,21 @@ def football_config_leg(device, steps=3):
         tr.step(sample)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
+    # algorithmic float32 flops of the two encoders' contractions, forward + both gradients (3 x 2 x 2 flops per multiply-add):
+    # three convolutions + the halving Linear tower (football_rnn.py:34-55, cnn.py:96-135); the LSTM, heads and LayerNorms are < 1 %
+    macs = (92 * 68 * 4 * 100 + 90 * 66 * 8 * 36 + 88 * 64 * 4 * 72 + 22528 * 11264 + 11264 * 5632 + 5632 * 2816 + 2816 * 1408 +
+            1408 * 704 + 704 * 128)
+    tflop = 6 * 2 * macs * T * B * 1e-12
     return dict(workload="BASELINE configs[4] per-GPU share: Google Football 11v11, 256 of 2048 envs x 200 steps, CNN + LSTM-128 "
                          "(football-smm-separate, 676 M parameters, PopArt); sample resident in HBM",
                 ms_per_update=round(ms, 2), env_steps_per_s=round(T * B / (ms * 1e-3)), steps=steps,
-                parameters=int(tr.policy.net.spec.total_params))
+                parameters=int(tr.policy.net.spec.total_params),
+                roofline=dict(bound="mfma", achieved=round(tflop / (ms * 1e-3), 1), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
+                              frac=round(tflop / (ms * 1e-3) / PEAK_BF16_MFMA_TFLOPS, 4), tflop_per_update=round(tflop, 1),
+                              note="algorithmic float32 TFLOP/s of the encoders' contractions over the WHOLE update's wall time, against "
+                                   "the dense 16-bit matrix peak; the dense tower runs as three f16 piece products per multiply-add "
+                                   "(csrc/h2gemm.h, h2gemmp.h, h2tn.h), the 4 / 8-channel convolutions on the vector units "
+                                   "(csrc/conv_small.hip)"))
 
 
 def shard_config_leg(extra=()):
