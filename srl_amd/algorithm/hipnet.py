@@ -1462,8 +1462,9 @@ class HipNet:
             raise hip.HipError("backward() without a preceding forward(keep_tape=True)")
         sp = self.spec
         self._gmax_next = -1
-        # (row order and time structure of the TAPED pass: a forward without a tape in between -- an inference call on the same
-        # executor -- must not change what this backward pass assumes)
+        # (row order and time structure travel with the tape.  They do NOT make an interleaved pass safe: a forward(keep_tape=False)
+        # between a taped forward and this call drops the tape -- the branch above raises -- and would have overwritten the shared
+        # workspace buffers the tape points at (logits, value, a_feat, mlp.y); inference beside training uses an executor of its own)
         n, a_feat, a_act, a_tape, c_feat, c_act, c_tape, self._cm, self._rnn = self._tape
         atot = sum(sp.act_dims)
         dl = Buf(d_logits.data_ptr(), atot, n, atot)

@@ -175,7 +175,34 @@ def test_mappg_step_flow_cache_and_checkpoint():
     assert not torch.equal(c["auxiliary_value_head.weight"], aux_head0)   # only the auxiliary phase trains that head
     ck = ppg.get_checkpoint()
     st = ck["aux_optimizer_state_dict"]
-    assert st["step"] == 4 and float(st["exp_avg_sq"]["auxiliary_value_head.weight"].abs().sum()) > 0
+    # torch's Adam layout (phasic_policy_gradient.py:120-128 stores `ppg_aux_optimizer.state_dict()`), parameters in the reference's order
+    names = ppg.policy.net.ref_names()
+    ia = names.index("auxiliary_value_head.weight")
+    assert set(st) == {"state", "param_groups"} and float(st["state"][ia]["step"]) == 4
+    assert float(st["state"][ia]["exp_avg_sq"].abs().sum()) > 0 and st["param_groups"][0]["lr"] == 5e-4
     fresh = trainer_api.make(config.Trainer("mappg", args=targs), config.Policy("actor-critic-auxiliary", args=pargs))
     fresh.load_checkpoint(ck)
     assert fresh._aux_steps == 4 and torch.equal(fresh._aux_m, ppg._aux_m) and torch.equal(fresh._aux_v, ppg._aux_v)
+    # ... and a state dict GENERATED BY torch.optim.Adam over parameters of the reference's shapes loads (what a reference PPG
+    # checkpoint carries), and ours loads into torch's
+    sd = ppg.policy.get_checkpoint()["state_dict"]
+    tparams = [torch.nn.Parameter(sd[n].clone().float()) for n in names] + [torch.nn.Parameter(torch.zeros(1), requires_grad=False)
+                                                                              for _ in range(3)]
+    topt = torch.optim.Adam(tparams, lr=2.5e-4, betas=(0.8, 0.95), eps=1e-6)
+    gen = torch.Generator().manual_seed(3)
+    for _ in range(3):
+        for p_ in tparams[:len(names)]:
+            p_.grad = torch.randn(p_.shape, generator=gen)
+        topt.step()
+    ck2 = dict(ck, aux_optimizer_state_dict=topt.state_dict())
+    fresh.load_checkpoint(ck2)
+    assert fresh._aux_steps == 3 and fresh._aux_lr == 2.5e-4 and fresh._aux_betas == (0.8, 0.95) and fresh._aux_eps == 1e-6
+    m_ref = fresh.policy.net.reference_to_flat({n: topt.state[p_]["exp_avg"] for n, p_ in zip(names, tparams)})
+    assert torch.equal(fresh._aux_m.cpu(), m_ref.cpu())
+    torch.optim.Adam(tparams, lr=1e-3).load_state_dict(ck["aux_optimizer_state_dict"])   # torch accepts ours
+    # episode-info averages keep their names, only the PPO step's statistics get the `ppo_` prefix (:242-253)
+    assert "ppo_policy_loss" in r2.stats and "ppo_grad_norm" in r2.stats and "frames" in r2.stats
+    assert not any(k.startswith("ppo_episode") for k in r2.stats)
+    with pytest.raises(ValueError):
+        trainer_api.make(config.Trainer("mappg", args=dict(targs, recompute_adv_among_epochs=True)),
+                         config.Policy("actor-critic-auxiliary", args=pargs))
