@@ -537,6 +537,12 @@ int srl_conv2d_obs_bwd(void* stream, const srl_conv_desc* d, const void* obs, in
  * written to *scale_out. */
 int srl_h2_pack_rows(void* stream, const float* src, int64_t ld, int64_t rows, int32_t C, const float* absmax,
                      const float* scale_in, float* scale_out, void* dst);
+/* srl_h2_pack_rows with the column sums of src beside it (ABI 17): colsum[C] (+)= sum over the rows of src -- the bias gradient of
+ * the layer whose output gradient is being packed, from the pass that reads it anyway (slabs per workgroup in `workspace`,
+ * srl_h2_pack_rows_colsum_workspace floats, added in a fixed order: no atomics).  C <= 2048, ld a multiple of 4, src 16-byte aligned. */
+int64_t srl_h2_pack_rows_colsum_workspace(int64_t rows, int32_t C);
+int srl_h2_pack_rows_colsum(void* stream, const float* src, int64_t ld, int64_t rows, int32_t C, const float* absmax, const float* scale_in,
+                            float* scale_out, void* dst, float* workspace, float* colsum, int32_t accumulate);
 int srl_h2_unpack_rows(void* stream, const void* src, int64_t rows, int32_t C, const float* scale, float* dst, int64_t ld);
 /* float32 NHWC images <-> h2 images.  layout 0: planar, raster pixel order; 1: h2p rows [n][H*W][C], raster order; 2: h2p
  * rows with the pixels of an image in parity-class-major order ((y & 1, x & 1), then y >> 1, x >> 1: what a stride-2

@@ -200,7 +200,12 @@ class H2Cnn:
             # dy -> h2p rows (its range from one pass: the producer is a float32 kernel that did not track it)
             hip.absmax(dy.ptr, n * self.H, P(M_DY))
         dyh = self._bytes(f"{t}dy", n * self.H * 4)
-        hip.h2_pack_rows(dy.ptr, self.H, n, self.H, dyh, absmax=P(M_DY), scale_out=P(S_DY))
+        if self.FC_WGRAD_TN and self.H <= 2048:
+            # the Linear's bias gradient = the column sums of dy, from the pass that splits it (a pass of its own: 32 us per chunk)
+            pws = ws.get("h2pack_colsum", hip.h2_pack_rows_colsum_workspace(n, self.H)).data_ptr()
+            hip.h2_pack_rows_colsum(dy.ptr, self.H, n, self.H, dyh, pws, g(f"{self.fc.prefix}.bias"), absmax=P(M_DY), scale_out=P(S_DY))
+        else:
+            hip.h2_pack_rows(dy.ptr, self.H, n, self.H, dyh, absmax=P(M_DY), scale_out=P(S_DY))
         # Linear: weight gradient beside the data-gradient chain
         net._on_side(lambda: self._fc_wgrad(n, dy, dyh, saved["a3"], tag))
         # Linear data gradient -> dz3 (h2p rows [n, 49, 64]), ReLU derivative of a3 from its sign bytes
@@ -269,7 +274,8 @@ class H2Cnn:
         if self.FC_WGRAD_TN:
             wsp = net.ws.get("h2tn_side" if side else "h2tn", hip.h2_wgrad_dense_workspace(n, H, 3136)).data_ptr()
             hip.h2_wgrad_dense(dyh, a3, self._slot(S_DY, tag), self._slot(S_A3, tag), n, H, 3136, wsp, g(f"{self.fc.prefix}.weight"))
-            hip.colsum(dy.ptr, dy.ld, n, H, gb, accumulate=True)
+            if H > 2048:   # (else: summed by the pack launch, `backward`)
+                hip.colsum(dy.ptr, dy.ld, n, H, gb, accumulate=True)
             return
         tiles = ((H + 127) // 128) * ((3136 + 127) // 128)
         from srl_amd.algorithm.hipnet import _split_for

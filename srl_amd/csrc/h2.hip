@@ -65,6 +65,28 @@ extern "C" int srl_h2_pack_rows(void* stream, const float* src, int64_t ld, int6
   return 0;
 }
 
+// srl_h2_pack_rows with the column sums of src added into colsum [C] (accumulate != 0) or written there: slabs per workgroup in
+// `workspace` (srl_h2_pack_rows_colsum_workspace floats), summed in a fixed order.  C <= 2048.
+static int h2_pack_colsum_blocks(int64_t rows) {
+  int64_t b = srl_ceil_div(rows, 32L);
+  return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+extern "C" int64_t srl_h2_pack_rows_colsum_workspace(int64_t rows, int32_t C) { return rows > 0 && C > 0 ? (int64_t)h2_pack_colsum_blocks(rows) * C : 0; }
+extern "C" int srl_h2_pack_rows_colsum(void* stream, const float* src, int64_t ld, int64_t rows, int32_t C, const float* absmax,
+                                       const float* scale_in, float* scale_out, void* dst, float* workspace, float* colsum, int32_t accumulate) {
+  SRL_CHECK_ARG(src && dst && workspace && colsum && (absmax || scale_in) && rows >= 0 && C > 0 && C % 32 == 0 && C <= 2048 && ld >= C && ld % 4 == 0 &&
+                    ((uintptr_t)src & 15) == 0,
+                "null tensor / C not a multiple of 32 or above 2048 / unaligned rows");
+  if (rows == 0) return 0;
+  const int nb = h2_pack_colsum_blocks(rows), lanes = 256 / (C / 8);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(h2_pack_colsum_kernel, dim3((unsigned)nb), dim3(256), (size_t)lanes * C * sizeof(float), st, src, (int64_t)ld, rows, (int)C, absmax,
+                     scale_in, scale_out, static_cast<uint8_t*>(dst), workspace);
+  hipLaunchKernelGGL(h2_colsum_finish_kernel, dim3((unsigned)srl_ceil_div(C, 256)), dim3(256), 0, st, workspace, nb, (int)C, colsum, (int)accumulate);
+  SRL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int srl_h2_unpack_rows(void* stream, const void* src, int64_t rows, int32_t C, const float* scale, float* dst, int64_t ld) {
   SRL_CHECK_ARG(src && dst && scale && rows >= 0 && C > 0 && C % 32 == 0 && ld >= C, "null tensor / C not a multiple of 32");
   if (rows == 0) return 0;

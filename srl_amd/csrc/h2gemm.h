@@ -174,6 +174,62 @@ static __global__ void h2_pack_kernel(const float* __restrict__ src, int64_t ld,
   }
 }
 
+// ... with the column sums of src beside it (round 6: the bias gradient of the layer whose output gradient is being packed -- a
+// pass of its own over the 33 MB of dy took 32 us per 16 384 rows, with float atomics).  A workgroup takes a contiguous range of
+// rows: thread t = (row lane t / (C / 8), group of 8 elements t % (C / 8)) keeps the 8 sums of its columns in registers, the row
+// lanes meet in LDS, the workgroup writes slab[blockIdx][C]; h2_colsum_finish_kernel adds the slabs in a fixed order.
+// C / 8 <= 256 threads (C <= 2048), blockDim = 256.
+static __global__ __launch_bounds__(256) void h2_pack_colsum_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int C,
+                                                                    const float* absmax, const float* scale_in, float* scale_out,
+                                                                    uint8_t* __restrict__ dst, float* __restrict__ slabs) {
+  extern __shared__ float h2pc_part[];   // [row lanes][C]
+  const float scale = scale_in ? *scale_in : h2_scale_for(*absmax);
+  if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+  const int ng = C / 8, lanes = 256 / ng;            // groups per row; row lanes of this workgroup
+  const int gi = threadIdx.x % ng, rl = threadIdx.x / ng;
+  const int blk = gi >> 2, g = gi & 3;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rl < lanes) {
+    for (int64_t row = r0 + rl; row < r1; row += lanes) {
+      const float* s = src + row * ld + blk * 32 + 4 * (g >> 1) + 16 * (g & 1);
+      const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 8);   // h2p_elem(g, 0..3), (g, 4..7)
+      cs[0] += a.x; cs[1] += a.y; cs[2] += a.z; cs[3] += a.w; cs[4] += b.x; cs[5] += b.y; cs[6] += b.z; cs[7] += b.w;
+      uint4 h0, h1;
+      h2_split_pair(a.x, a.y, scale, h0.x, h1.x);
+      h2_split_pair(a.z, a.w, scale, h0.y, h1.y);
+      h2_split_pair(b.x, b.y, scale, h0.z, h1.z);
+      h2_split_pair(b.z, b.w, scale, h0.w, h1.w);
+      uint4* d = reinterpret_cast<uint4*>(dst + (row * C + blk * 32) * 4 + g * 32);
+      d[0] = h0;
+      d[1] = h1;
+    }
+    float* p = h2pc_part + rl * C + blk * 32 + 4 * (g >> 1) + 16 * (g & 1);
+    p[0] = cs[0]; p[1] = cs[1]; p[2] = cs[2]; p[3] = cs[3]; p[8] = cs[4]; p[9] = cs[5]; p[10] = cs[6]; p[11] = cs[7];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += h2pc_part[l * C + c];
+    slabs[(int64_t)blockIdx.x * C + c] = t;
+  }
+}
+// out[c] (+)= sum over the slabs, in slab order
+static __global__ __launch_bounds__(256) void h2_colsum_finish_kernel(const float* __restrict__ slabs, int nslab, int C, float* __restrict__ out,
+                                                                      int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  int k = 0;
+  for (; k + 3 < nslab; k += 4) {
+    t0 += slabs[(int64_t)k * C + c]; t1 += slabs[(int64_t)(k + 1) * C + c]; t2 += slabs[(int64_t)(k + 2) * C + c]; t3 += slabs[(int64_t)(k + 3) * C + c];
+  }
+  for (; k < nslab; ++k) t0 += slabs[(int64_t)k * C + c];
+  const float t = (t0 + t1) + (t2 + t3);
+  out[c] = accumulate ? out[c] + t : t;
+}
+
 // h2p rows -> float32 (tests, fallbacks)
 static __global__ void h2_unpack_kernel(const uint8_t* __restrict__ src, int64_t rows, int C, const float* scale, float* __restrict__ dst,
                                  int64_t ld) {

@@ -210,6 +210,8 @@ _SIGNATURES = {
     "srl_step_plan_run": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_int, POINTER(c_void_p), c_int, c_int]),
     "srl_step_plan_destroy": (c_int, [c_void_p]),
     "srl_h2_pack_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "srl_h2_pack_rows_colsum_workspace": (c_int64, [c_int64, c_int32]),
+    "srl_h2_pack_rows_colsum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32]),
     "srl_h2_unpack_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64]),
     "srl_h2_pack_image": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "srl_h2_unpack_image": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
@@ -1158,6 +1160,16 @@ def _vp(v):
 def h2_pack_rows(src_ptr, ld, rows, C, dst_ptr, absmax=None, scale_in=None, scale_out=None):
     _check(lib().srl_h2_pack_rows(_stream(), _vp(src_ptr), int(ld), int(rows), int(C), _vp(absmax), _vp(scale_in), _vp(scale_out),
                                   _vp(dst_ptr)), "srl_h2_pack_rows")
+
+
+def h2_pack_rows_colsum_workspace(rows, C) -> int:
+    return int(lib().srl_h2_pack_rows_colsum_workspace(int(rows), int(C)))
+
+
+def h2_pack_rows_colsum(src, ld, rows, C, dst, workspace, colsum, absmax=None, scale_in=None, scale_out=None, accumulate=True):
+    """``h2_pack_rows`` + colsum[C] (+)= column sums of src (the bias gradient of the layer whose output gradient is packed)."""
+    _check(lib().srl_h2_pack_rows_colsum(_stream(), _vp(src), int(ld), int(rows), int(C), _vp(absmax), _vp(scale_in), _vp(scale_out), _vp(dst),
+                                         _vp(workspace), _vp(colsum), int(bool(accumulate))), "srl_h2_pack_rows_colsum")
 
 
 def h2_unpack_rows(src_ptr, rows, C, scale, dst_ptr, ld):

@@ -426,6 +426,30 @@ def test_persistent_wide_product_every_epilogue(M, N, K):
     assert abs(float(oam2) - float(got.abs().max())) <= 2e-6 * float(got.abs().max())
 
 
+@pytest.mark.parametrize("rows,C", [(1, 32), (37, 96), (1111, 512), (BENCH_N, 512), (300, 2048)])
+def test_pack_rows_with_column_sums(rows, C):
+    """srl_h2_pack_rows_colsum (round 6): the same pieces as srl_h2_pack_rows, bit for bit, and the column sums of the source added
+    into / written to the bias gradient (slabs per workgroup added in a fixed order: bit-reproducible)."""
+    hip = _hip()
+    x = _f(rows, C, seed=51, amp=1e-3)
+    ax = _absmax(hip, x)
+    a, b, sa, sb = torch.zeros_like(x), torch.zeros_like(x), _slot(0.0), _slot(0.0)
+    hip.h2_pack_rows(x.data_ptr(), C, rows, C, a.data_ptr(), absmax=ax.data_ptr(), scale_out=sa.data_ptr())
+    ws = torch.full((max(hip.h2_pack_rows_colsum_workspace(rows, C), 4),), float("nan"), device=DEV)
+    base = _f(C, seed=52)
+    cs = base.clone()
+    hip.h2_pack_rows_colsum(x.data_ptr(), C, rows, C, b.data_ptr(), ws.data_ptr(), cs.data_ptr(), absmax=ax.data_ptr(), scale_out=sb.data_ptr())
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and float(sa) == float(sb)
+    ref = x.double().sum(0) + base.double()
+    assert float((cs.double() - ref).abs().max()) <= 2e-6 * max(float(ref.abs().max()), 1e-30)
+    cs2 = torch.full((C,), float("nan"), device=DEV)
+    hip.h2_pack_rows_colsum(x.data_ptr(), C, rows, C, b.data_ptr(), ws.data_ptr(), cs2.data_ptr(), absmax=ax.data_ptr(), scale_out=sb.data_ptr(),
+                            accumulate=False)
+    cs3 = torch.zeros(C, device=DEV)
+    hip.h2_pack_rows_colsum(x.data_ptr(), C, rows, C, b.data_ptr(), ws.data_ptr(), cs3.data_ptr(), absmax=ax.data_ptr(), scale_out=sb.data_ptr())
+    assert torch.equal(cs2, cs3)
+
+
 # ------------------------------------------------------------------------------------------------ benchmark-size launches
 def test_benchmark_size_chunk_on_sampled_images():
     """One 16 384-image chunk -- the launches bench.py times -- through conv2 forward, its weight gradient and conv2's data
