@@ -252,15 +252,20 @@ extern "C" int srl_h2_gemm(void* stream, const srl_h2_gemm_desc* d) {
   static const bool half_on = [] { const char* e = getenv("SRL_H2GEMM_HALF"); return e && e[0] == '1'; }();
   // round 6: the wide product as a PERSISTENT kernel (h2gemmp.h: one workgroup per CU walks its tiles, the ring never drains, a
   // tile's stores are not waited for) -- same operands, same piece products in the same order: bit-identical output.  207 -> 191 us
-  // per 16 384 rows of the Linear's data gradient on one box.  SRL_H2GEMM_P=0: the one-tile-per-workgroup launch (A/B).
-  static const bool pers_on = [] { const char* e = getenv("SRL_H2GEMM_P"); return !(e && e[0] == '0'); }();
+  // per 16 384 rows of the Linear's data gradient on one box, launched alone.
+  // Default: the LARGE products only.  For the Atari data gradient the persistent kernel wins alone (one pipeline) and not in the
+  // update: four row-chunk pipelines share the chip there and fill each other's idle CUs -- alternating runs on two boxes 86.6 / 86.4
+  // (one tile per workgroup) against 89.1 / 86.4, and 85.1 / 84.9 / 85.1 against 84.9 / 88.3 / 84.6 ms per update: no gain, and two of
+  // five ring-fed runs 3.5 ms slower (a kernel that holds every CU's whole LDS for the length of the launch lets nobody else's
+  // small kernels in).  SRL_H2GEMM_P=1: also there (the per-kernel table of DESIGN section 4 names both); SRL_H2GEMM_P=0: nowhere.
+  static const int pers_mode = [] { const char* e = getenv("SRL_H2GEMM_P"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : 2; }();
   // ... and every product large enough that a 256 x 256 tile still fills the chip several times over (the football tower's layers:
   // 51 200 rows x 704 ... 22 528 channels): a third fewer operand bytes staged per multiply-add than the 256 x 128 tiles, 4-13 %
   // faster at those shapes (scripts/h2r6_probe.hip)
   // (chosen from the layer's widths and a row floor only: the pieces an encoder's rows are cut into must not change kernels --
   // `test_config4_football_per_gpu_size` holds an update to its own result under another cut)
   const bool big = d->M >= 4096 && d->NC >= 2048 && d->K >= 1024;
-  if ((wide || big) && pers_on && !half_on && !dbg) {
+  if (((wide && pers_mode == 1) || (big && pers_mode >= 1)) && !half_on && !dbg) {
     srl_count_dispatch(SRL_DISP_H2, 5, 8, H2P_NSLOT);
     rc = h2gemmp_launch<0>((hipStream_t)stream, a);
     SRL_CHECK_ARG(rc == 0, "grid too large / rows of 8 MiB and more");

@@ -31,7 +31,7 @@ def golden():
 BENCH_CHUNK_TILES = {
     "obs_fwd_bf16:k256:h2blk:split250": 1, "obs_bwd_bf16:k256:h2blk:split5": 1,
     "h2:conv:0:s3": 1, "h2:conv:1:s3": 1, "h2:conv:2:s2": 1, "h2:conv:3:s2": 1, "h2:wgrad:0:s2": 1, "h2:wgrad:1:s3": 1,
-    "h2:gemm:4:s3": 1, "h2:gemmp:8:s4": 1, "h2:tn:8:s4": 1,
+    "h2:gemm:4:s3": 1, "h2:gemm:8:s2": 1, "h2:tn:8:s4": 1,
 }
 
 

@@ -274,7 +274,7 @@ def test_linear_forward_and_data_gradient_vs_float64(M):
                               mask_in=mask.data_ptr(), mask_in_h2order=True)
     hip.dispatch_tiles(reset=True)
     run()
-    assert hip.dispatch_tiles(reset=True) == {"h2:gemmp:8:s4": 1}   # wide output, short reduction: the persistent kernel (h2gemmp.h)
+    assert hip.dispatch_tiles(reset=True) == {"h2:gemm:8:s2": 1}   # wide output, short reduction: 256 channels per workgroup
     first = dx.clone()
     got = torch.empty(M, K, device=DEV)
     hip.h2_unpack_rows(dx.data_ptr(), M, K, osc.data_ptr(), got.data_ptr(), K)
@@ -380,8 +380,37 @@ def test_dense_weight_gradient_on_presplit_operands(M, N, K):
     assert torch.equal(g0, g2)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 1024, 64), (1111, 1056, 512), (2000, 3136, 32), (4133, 1280, 1024)])
-def test_persistent_wide_product_every_epilogue(M, N, K):
+def test_persistent_wide_product_every_epilogue():
+    """The cases below in a child process with SRL_H2GEMM_P=1 (the library reads the switch once: by default the persistent kernel
+    takes only the large products, `srl_h2_gemm`'s `big`; the wide data gradient of the Atari Linear stays on one tile per
+    workgroup -- see h2.hip)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); import test_gpu_h2 as t\n"
+            "for c in [(300, 1024, 64), (1111, 1056, 512), (2000, 3136, 32), (4133, 1280, 1024)]: t._persistent_wide_case(*c)\nprint('ok')") % (root, root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRL_H2GEMM_P="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_persistent_kernel_takes_the_large_products_by_default():
+    """Default dispatch: M >= 4096, NC >= 2048, K >= 1024 (the football tower's layers) -> csrc/h2gemmp.h; checked against float64 on
+    sampled rows."""
+    hip = _hip()
+    M, N, K = 4200, 2080, 1056
+    x = _f(M, K, seed=61, relu=True, amp=2.0)
+    w = _f(N, K, seed=62, amp=0.03)
+    b = _f(N, seed=63, amp=0.1)
+    xbuf, sx, ax = torch.empty_like(x), _slot(0.0), _absmax(hip, x)
+    hip.h2_pack_rows(x.data_ptr(), K, M, K, xbuf.data_ptr(), absmax=ax.data_ptr(), scale_out=sx.data_ptr())
+    wp, sw, rw = _weights(hip, w, N, K, 0)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    hip.dispatch_tiles(reset=True)
+    hip.h2_gemm(xbuf.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(), M, N, K, y.data_ptr(), bias=b.data_ptr(), act=1)
+    assert hip.dispatch_tiles(reset=True) == {"h2:gemmp:8:s4": 1}
+    _close(y, F.relu(x.double() @ w.double().t() + b.double()))
+
+
+def _persistent_wide_case(M, N, K):
     """csrc/h2gemmp.h (round 6: persistent workgroups, a flat ring across tiles, stores not waited for) through `srl_h2_gemm`'s wide
     case, every epilogue it carries: float32 output with bias + ReLU + sign words out; h2p output with bias + ReLU (the bound's
     bias term); the data-gradient form with the ReLU derivative in natural order; ragged rows, a narrow last channel tile, one
@@ -401,7 +430,7 @@ def test_persistent_wide_product_every_epilogue(M, N, K):
     hip.dispatch_tiles(reset=True)
     hip.h2_gemm(xbuf.data_ptr(), wp.data_ptr(), sx.data_ptr(), sw.data_ptr(), M, N, K, y.data_ptr(), bias=b.data_ptr(), act=1,
                 mask_out=mo.data_ptr(), out_absmax=oam.data_ptr())
-    assert hip.dispatch_tiles(reset=True) == {"h2:gemmp:8:s4": 1}
+    assert hip.dispatch_tiles(reset=True) == {"h2:gemmp:8:s4": 1}   # (SRL_H2GEMM_P=1, set below: the persistent kernel for wide products too)
     _close(y, ref)
     assert int((mo != _mask_natural(y.view(M, 1, 1, N))).sum()) == 0
     assert abs(float(oam) - float(y.abs().max())) <= 1e-6 * float(y.abs().max())
