@@ -87,3 +87,29 @@ class OraclePPGAux:
         if gn is not None:
             out["grad_norm"] = float(gn)
         return out
+
+
+    # ---- data parallel (MultiAgentPPG inherits MultiAgentPPO.distributed, :108; the policy is DistributedDataParallel): every rank
+    # keeps the distributions of ITS entry, an epoch's loss is the rank's own masked means, the gradients are averaged over ranks
+    def enter_dp(self, entries):
+        self._ranks = []
+        for e in entries:
+            self.enter(e)
+            self._ranks.append((self.old, self.target, self.done))
+
+    def epoch_dp(self, entries):
+        params = [p for p in self.net.parameters() if p.requires_grad]
+        total, outs = [torch.zeros_like(p) for p in params], []
+        for e, (old, target, done) in zip(entries, self._ranks):
+            dists, aux, pred = self._analyze(e)
+            loss, terms = aux_loss(old, dists, aux, pred, target, done, self.beta, self.vhw)
+            for t, g in zip(total, torch.autograd.grad(loss, params, allow_unused=True)):
+                if g is not None:
+                    t += g
+            outs.append({k: float(v.detach()) for k, v in terms.items()})
+        self.optimizer.zero_grad()
+        for p, t in zip(params, total):
+            p.grad = t / len(entries)
+        gn = torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm) if self.max_grad_norm is not None else None
+        self.optimizer.step()
+        return outs, (None if gn is None else float(gn))

@@ -105,6 +105,95 @@ def test_two_rank_trainer_matches_ddp_semantics(unequal, pipelines, chunk_rows):
         assert np.abs(v - osd[k].numpy()).max() <= 3e-5, (k, np.abs(v - osd[k].numpy()).max())
 
 
+PPG_POLICY = dict(obs_dim=4, action_dim=[3, 2], hidden_dim=32, num_dense_layers=1, num_rnn_layers=0, popart=False, layernorm=True,
+                  chunk_len=8, seed=81)
+PPG_TRAINER = dict(popart=False, ppg_epochs=3, max_grad_norm=5.0, beta_clone=1.0, aux_value_head_weight=0.5,
+                   ppg_optimizer_config=dict(lr=1e-3), grad_bucket_bytes=2048, chunk_rows=40)
+
+
+def _ppg_entry(rank):
+    from srl_amd.runtime import synthetic
+    T, Bq = 16, 6
+    arr = synthetic.make_sample_arrays(seed=400 + rank, T=T, B=Bq, obs_spec=synthetic.CARTPOLE_OBS, action_dims=[3, 2],
+                                       p_done=0.1 if rank == 0 else 0.3)
+    rng = np.random.default_rng(500 + rank)
+    e = {k: v[:T] for k, v in arr.items() if k.startswith("obs.") or k == "on_reset"}
+    e["value"] = rng.standard_normal((T, Bq, 1)).astype(np.float32)
+    e["info_mask"] = (rng.random((T, Bq, 1)) < 0.2).astype(np.uint8)
+    return e
+
+
+def _ppg_perturbation(state):
+    rng = np.random.default_rng(77)
+    return {k: (np.asarray(v) + 0.05 * rng.standard_normal(np.asarray(v).shape).astype(np.float32)) for k, v in state.items()}
+
+
+def _ppg_worker(rank, world, port, out):
+    import srl_amd
+    from srl_amd.algorithm.mappg import _CacheEntry
+    from srl_amd.api import config, trainer as trainer_api
+    srl_amd.register_all()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        trainer = trainer_api.make(config.Trainer("mappg", args=PPG_TRAINER),
+                                   config.Policy("actor-critic-auxiliary", args=dict(PPG_POLICY, seed=81 + rank)))
+        trainer.distributed(rank=rank, world_size=world, init_method=None)
+        pol = trainer.policy
+        init = {k: v.numpy() for k, v in pol.get_checkpoint()["state_dict"].items()}
+        e = _ppg_entry(rank)
+        entry = _CacheEntry({k[4:]: v for k, v in e.items() if k.startswith("obs.")}, None, e["info_mask"], e["on_reset"], e["value"])
+        trainer.enter_aux_phase(entry)
+        # (the first epoch would otherwise start at KL = 0: rounding-noise gradients that Adam turns into full-size steps)
+        pol.load_checkpoint(dict(steps=pol.version, state_dict={k: torch.from_numpy(v) for k, v in _ppg_perturbation(init).items()}))
+        terms = []
+        for _ in range(PPG_TRAINER["ppg_epochs"]):
+            m = trainer.aux_epoch(entry)
+            terms.append((m.auxiliary_value_loss, m.value_head_loss, m.policy_distance, trainer.last_aux_grad_norm))
+        final = {k: v.numpy() for k, v in pol.get_checkpoint()["state_dict"].items()}
+        out[rank] = dict(init=init, final=final, terms=terms, reducer=dict(trainer._reducer.stats), buckets=len(trainer._reducer.buckets))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_ppg_auxiliary_phase_matches_ddp_semantics():
+    """`mappg` under data parallelism (phasic_policy_gradient.py:108: MultiAgentPPG inherits MultiAgentPPO.distributed; the policy is
+    DDP in the auxiliary phase too): two ranks, each with the cache entry of ITS sample (different mask counts), three auxiliary
+    epochs in chunks of 40 rows.  Against `OraclePPGAux.epoch_dp`: every rank's loss terms are masked means over its LOCAL rows, the
+    gradients are averaged over ranks before the clip and the auxiliary optimiser's step; both ranks end with identical
+    parameters, the oracle's to 2e-5; every bucket left from inside the backward pass of the last chunk."""
+    from oracle.net import OracleActorCritic
+    from oracle.ppg import OraclePPGAux
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_ppg_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = {r: out[r] for r in range(world)}
+    for k in res[0]["init"]:
+        assert np.array_equal(res[0]["init"][k], res[1]["init"][k]), k       # rank 0's parameters everywhere
+        assert np.array_equal(res[0]["final"][k], res[1]["final"][k]), k
+    for r in range(world):
+        red, nb = res[r]["reducer"], res[r]["buckets"]
+        assert nb >= 2 and red["launched_in_backward"] == nb * PPG_TRAINER["ppg_epochs"] and red["launched_in_finish"] == 0, red
+    onet = OracleActorCritic(**PPG_POLICY, auxiliary_head=True)
+    onet.load_state_dict(res[0]["init"])
+    oracle = OraclePPGAux(onet, beta_clone=1.0, aux_value_head_weight=0.5, max_grad_norm=5.0, popart=False,
+                          ppg_optimizer_config=dict(lr=1e-3))
+    entries = [_ppg_entry(r) for r in range(world)]
+    oracle.enter_dp(entries)
+    for k, v in _ppg_perturbation(res[0]["init"]).items():   # in place: the oracle's optimiser holds these tensors
+        onet.params[k].data.copy_(torch.from_numpy(v).to(onet.params[k].dtype))
+    for ep in range(PPG_TRAINER["ppg_epochs"]):
+        outs, gn = oracle.epoch_dp(entries)
+        for r in range(world):
+            got = res[r]["terms"][ep]
+            for i, k in enumerate(("auxiliary_value_loss", "value_head_loss", "policy_distance")):
+                assert abs(got[i] - outs[r][k]) <= 1e-5 * max(abs(outs[r][k]), 1e-2), (ep, r, k, got[i], outs[r][k])
+            assert abs(got[3] - gn) <= 2e-5 * max(gn, 1e-2), (ep, r, got[3], gn)
+    osd = onet.state_dict()
+    for k, v in res[0]["final"].items():
+        assert np.abs(v - osd[k].numpy()).max() <= 2e-5, (k, np.abs(v - osd[k].numpy()).max())
+
+
 def test_bench_script_with_two_ranks():
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), except that
     the two ranks share this box's GPU over gloo: every rank must reach the same collectives in the same order (warm-up,
