@@ -477,10 +477,10 @@ int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const void* obs, in
 /* *out = max(*out, max_i |x[i]|) (atomic: several calls may fold into one slot; the caller zeroes it): the range of a
  * weight tensor for the two-plane f16 products, once per parameter update. */
 int srl_absmax(void* stream, const float* x, int64_t n, float* out);
-/* Direct convolutions for layers with 4 or 8 channels on both sides (csrc/conv_small.hip; ABI 17): NHWC float32, 3 x 3, stride 1, no
- * padding, (Cin, Cout) in {(4, 4), (4, 8), (8, 4)} -- the reference's default convolution stack behind its first layer
- * (modules/cnn.py:96-98) as vector-unit kernels (a thread per pixel, weights as scalar operands; the weight gradient with all
- * 9 Cin Cout sums of a pixel column in registers, slabs per wavefront + a second launch: no atomics).  w: [Cout, 3, 3, Cin].
+/* Direct convolutions for layers with 4 or 8 channels on both sides (csrc/conv_small.hip; ABI 17): NHWC float32, 3 x 3 or 5 x 5,
+ * stride 1, no padding, Cin and Cout in {4, 8} (5 x 5: Cin 4) -- the reference's default convolution stack (modules/cnn.py:96-98: C -> C (5 x 5),
+ * C -> 2C, 2C -> C (3 x 3)) as vector-unit kernels (a thread per pixel, weights as scalar operands; the weight gradient with up to
+ * 288 sums of a pixel column in registers, slabs per wavefront + a second launch: no atomics).  w: [Cout, K, K, Cin].
  * fwd: y = act(conv(x, w) + bias) (bias may be NULL).  dgrad: dx = (dz conv^T w) * act'(x_act) with x_act = the layer's INPUT
  * activation (the output of the activation `dact`: 0 none / x_act NULL, 1 relu, 2 tanh).  wgrad: gw += dz^T patches(x), gb +=
  * column sums of dz (gb may be NULL); workspace: srl_conv2d_small_wgrad_workspace floats.  Replace nn.Conv2d forward / backward

@@ -524,9 +524,9 @@ class HipNet:
     CONV_SMALL = os.environ.get("SRL_CONV_SMALL", "1") != "0"
 
     def _conv_small(self, L, desc) -> bool:
-        """A convolution behind the first layer with 4 or 8 channels on both sides, 3 x 3, stride 1, no padding: the direct
+        """A convolution on a plain NHWC activation with 4 or 8 channels on both sides, 3 x 3 or 5 x 5, stride 1, no padding: the direct
         vector-unit kernels (csrc/conv_small.hip).  SRL_CONV_SMALL=0: the implicit GEMMs (A/B)."""
-        return (self.CONV_SMALL and self.on_gpu and not L.first and not L.pad and L.stride == 1 and L.k == 3
+        return (self.CONV_SMALL and self.on_gpu and not L.first and not L.pad and L.stride == 1 and L.k in (3, 5)
                 and hip.conv2d_small_supported(desc))
 
     def _linear_fwd(self, L: ns.LinearSpec, x: Buf, tag: str, x_range: Optional[int] = None) -> Buf:

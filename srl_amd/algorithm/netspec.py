@@ -304,6 +304,11 @@ def _pad_mode(padding, padding_mode, extents) -> int:
     return PAD_MODES[padding_mode] if padding else 0
 
 
+def _small_first_on() -> bool:
+    import os
+    return os.environ.get("SRL_CONV_SMALL", "1") != "0" and os.environ.get("SRL_CONV_SMALL_FIRST", "1") != "0"
+
+
 def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, act_name: str, cnn_layers: Dict,
                     use_maxpool: Optional[Dict] = None):
     encs = []
@@ -337,6 +342,13 @@ def _build_encoders(b: _Builder, root: str, dims: Dict, hidden: int, act: int, a
         # padding or pooling: the general path -- LayerNorm written out channels-last, every convolution (the first
         # included) an NHWC implicit GEMM over a padded / pooled activation
         generic = pool or any(layer[3] != 0 for layer in cfg)
+        # a first layer with 4 or 8 channels on both sides, 3 x 3 / 5 x 5 (4 input channels), stride 1 -- the default stack on a
+        # 4- or 8-plane observation (the football preset) -- runs as a direct vector-unit convolution on the written-out LayerNorm
+        # (csrc/conv_small.hip, round 6; mirrors srl_conv2d_small_supported): the fused first-layer kernels put its 4 output
+        # channels on 256 x 32 matrix-core tiles (59 + 122 ms per football-sized update against ~25 GB of activations)
+        if (not generic and _small_first_on() and s0 == 1 and k0 in (3, 5) and c in (4, 8) and cfg[0][0] in (4, 8)
+                and not (k0 == 5 and c == 8)):
+            generic = True
         s2d = s0 if (not generic and _allow_s2d() and s0 >= 1 and k0 % s0 == 0 and h % s0 == 0 and w % s0 == 0 and
                      (c * s0 * s0) % 4 == 0) else 0
         b.layernorm(f"{base}.0", shape, s2d=s2d)

@@ -1582,10 +1582,10 @@ def test_mlp_chain_backward_with_input_gradient(rows, chain):
         assert rel_close(g.cpu().numpy(), p_.grad.numpy(), 2e-5, scale=float(p_.grad.abs().max()) + 1e-6), k
 
 
-@pytest.mark.parametrize("cin,cout", [(4, 8), (8, 4), (4, 4)])
+@pytest.mark.parametrize("cin,cout,k", [(4, 8, 3), (8, 4, 3), (4, 4, 3), (8, 8, 3), (4, 4, 5), (4, 8, 5)])
 @pytest.mark.parametrize("n,H,W", [(3, 7, 9), (5, 36, 70), (64, 20, 35)])
-def test_small_channel_direct_convolutions_vs_torch(cin, cout, n, H, W):
-    """csrc/conv_small.hip (round 6): 3 x 3 stride-1 convolutions with 4 / 8 channels as vector-unit kernels -- forward (bias,
+def test_small_channel_direct_convolutions_vs_torch(cin, cout, k, n, H, W):
+    """csrc/conv_small.hip (round 6): 3 x 3 and 5 x 5 stride-1 convolutions with 4 / 8 channels as vector-unit kernels -- forward (bias,
     ReLU), data gradient (with the ReLU derivative of the layer's input) and weight / bias gradient (accumulating; slabs per
     wavefront) against float64 torch convolutions: widths that are not multiples of the 32-pixel column blocks, an odd image count
     (the weight gradient pairs images), heights that are not multiples of the three-row window."""
@@ -1594,16 +1594,16 @@ def test_small_channel_direct_convolutions_vs_torch(cin, cout, n, H, W):
     g = torch.Generator(device="cuda").manual_seed(7 + cin * 10 + cout)
     x = torch.rand(n, H, W, cin, device="cuda", generator=g) * 2 - 1
     x = torch.relu(x)                                      # the input is a ReLU output (its derivative gates dx)
-    w = (torch.rand(cout, 3, 3, cin, device="cuda", generator=g) * 2 - 1) * 0.3
+    w = (torch.rand(cout, k, k, cin, device="cuda", generator=g) * 2 - 1) * 0.3
     b = (torch.rand(cout, device="cuda", generator=g) * 2 - 1) * 0.1
-    d = hip.conv_desc(n, H, W, cin, 3, 3, 1, cout, hip.ACT_RELU)
+    d = hip.conv_desc(n, H, W, cin, k, k, 1, cout, hip.ACT_RELU)
     assert hip.conv2d_small_supported(d)
-    y = torch.full((n, H - 2, W - 2, cout), float("nan"), device="cuda")
+    y = torch.full((n, H - k + 1, W - k + 1, cout), float("nan"), device="cuda")
     hip.conv2d_small_fwd(d, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr())
     xr, wr = x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2)
     ref = torch.relu(F.conv2d(xr, wr, b.double())).permute(0, 2, 3, 1)
     assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
-    dz = (torch.rand(n, H - 2, W - 2, cout, device="cuda", generator=g) * 2 - 1) * 1e-2
+    dz = (torch.rand(n, H - k + 1, W - k + 1, cout, device="cuda", generator=g) * 2 - 1) * 1e-2
     dx = torch.full((n, H, W, cin), float("nan"), device="cuda")
     hip.conv2d_small_dgrad(d, dz.data_ptr(), w.data_ptr(), x.data_ptr(), hip.ACT_RELU, dx.data_ptr())
     refd = F.conv_transpose2d(dz.double().permute(0, 3, 1, 2), wr).permute(0, 2, 3, 1) * (x > 0)
@@ -1612,7 +1612,7 @@ def test_small_channel_direct_convolutions_vs_torch(cin, cout, n, H, W):
     hip.conv2d_small_dgrad(d, dz.data_ptr(), w.data_ptr(), None, 0, dx0.data_ptr())
     refd0 = F.conv_transpose2d(dz.double().permute(0, 3, 1, 2), wr).permute(0, 2, 3, 1)
     assert float((dx0.double() - refd0).abs().max()) <= 2e-6 * float(refd0.abs().max())
-    gw0, gb0 = torch.rand(cout, 3, 3, cin, device="cuda", generator=g), torch.rand(cout, device="cuda", generator=g)
+    gw0, gb0 = torch.rand(cout, k, k, cin, device="cuda", generator=g), torch.rand(cout, device="cuda", generator=g)
     gw, gb = gw0.clone(), gb0.clone()
     ws = torch.full((hip.conv2d_small_wgrad_workspace(d),), float("nan"), device="cuda")
     hip.conv2d_small_wgrad(d, x.data_ptr(), dz.data_ptr(), ws.data_ptr(), gw.data_ptr(), gb.data_ptr())
@@ -1623,4 +1623,5 @@ def test_small_channel_direct_convolutions_vs_torch(cin, cout, n, H, W):
     gw2, gb2 = gw0.clone(), gb0.clone()
     hip.conv2d_small_wgrad(d, x.data_ptr(), dz.data_ptr(), ws.data_ptr(), gw2.data_ptr(), gb2.data_ptr())
     assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
-    assert not hip.conv2d_small_supported(hip.conv_desc(n, H, W, 8, 3, 3, 1, 8)) and not hip.conv2d_small_supported(hip.conv_desc(n, H, W, 4, 5, 5, 1, 4))
+    assert not hip.conv2d_small_supported(hip.conv_desc(n, H, W, 8, 5, 5, 1, 8)) and not hip.conv2d_small_supported(hip.conv_desc(n, H, W, 4, 3, 3, 2, 4))
+    assert not hip.conv2d_small_supported(hip.conv_desc(n, H, W, 16, 3, 3, 1, 4))
