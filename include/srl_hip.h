@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRL_HIP_ABI_VERSION 17
+#define SRL_HIP_ABI_VERSION 18
 
 int srl_abi_version(void);
 const char* srl_last_error(void);
@@ -622,6 +622,12 @@ int srl_conv2d_obs_fwd_h2(void* stream, const srl_conv_desc* d, const void* obs,
                           const float* gamma, const float* beta, const float* w, const float* bias, void* y_h2, float* y_scale,
                           float* workspace, const int32_t* row_index, float* y_absmax, uint32_t* y_mask, int reuse_folded,
                           int ent_order);
+/* Only the folded weights that srl_conv2d_obs_fwd_h2 keeps in `workspace` (what reuse_folded = 1 then reads): they depend on
+ * the parameters alone (the LayerNorm affine of modules/cnn.py:100 folded into the first convolution's weights, :108), so the
+ * trainer enqueues them once per parameter version ahead of the update's first chunk.  Returns 0: written; 1: d is not the
+ * geometry of the kernel that keeps folded weights in this format (nothing written; the forward call folds for itself). */
+int srl_conv2d_obs_fold_h2(void* stream, const srl_conv_desc* d, const float* gamma, const float* beta, const float* w,
+                           const float* bias, float* workspace);
 
 /* Row gather behind the HBM observation ring: dst[i, :] = src[index[i], :], rows of row_bytes (a multiple of 4;
  * 16-byte pieces when row_bytes % 16 == 0 and both bases are 16-byte aligned).  The frames `rollout` uploaded

@@ -27,3 +27,17 @@ for a, b in list(zip(ends[:-1], ends[1:])):
     print(f"update: span {(t1 - t0) / 1e6:.2f} ms, busy {busy / 1e6:.2f} ms, idle {(t1 - t0 - busy) / 1e6:.2f} ms in {len(gaps)} gaps")
     for g in sorted(gaps, reverse=True)[:8]:
         print(f"   gap {g[0] / 1e3:8.1f} us at +{g[3]:6.2f} ms   after {g[1]}   before {g[2]}")
+if len(sys.argv) > 2:   # per-kernel totals of the LAST update (any second argument)
+    from collections import defaultdict
+    tot, cnt = defaultdict(int), defaultdict(int)
+    for s, e, n in rows[ends[-2] + 1:ends[-1] + 1]:
+        k = n.split("(")[0][:60]
+        tot[k] += e - s
+        cnt[k] += 1
+    print(f"last update: {sum(cnt.values())} launches, sum of durations {sum(tot.values()) / 1e6:.2f} ms")
+    for k in sorted(tot, key=tot.get, reverse=True)[:40]:
+        print(f"   {tot[k] / 1e3:9.1f} us  x{cnt[k]:<4d} {k}")
+if len(sys.argv) > 3:   # the first launches of the last update, in order (any third argument = how many)
+    seg = rows[ends[-2] + 1:ends[-1] + 1]
+    for s, e, n in seg[:int(sys.argv[3])] + seg[-12:]:
+        print(f"   +{(s - seg[0][0]) / 1e3:8.1f} us  {(e - s) / 1e3:7.1f} us  {n[:110]}")

@@ -74,7 +74,9 @@ class H2Cnn:
     # ------------------------------------------------------------------ helpers
     def _slots(self, tag=None):
         """tag None: the per-weights array; else the array of the pass `tag`."""
-        return self.net.ws.get(f"{self.pfx}wslots" if tag is None else f"{tag}{self.pfx}slots", N_SLOTS)
+        if tag is None:   # weight-only data: one copy for an executor and its twins (hipnet.py `wws`)
+            return self.net.wws.get(f"{self.pfx}wslots", N_SLOTS)
+        return self.net.ws.get(f"{tag}{self.pfx}slots", N_SLOTS)
 
     def _slot(self, i, tag=None):
         assert (i < N_PASS_SLOTS) == (tag is not None), i
@@ -84,14 +86,14 @@ class H2Cnn:
         return self.net.ws.get(name, (nbytes + 3) // 4).data_ptr()
 
     def _wbytes(self, name, nbytes):
-        return self._bytes(self.pfx + name, nbytes)
+        return self.net.wws.get(self.pfx + name, (nbytes + 3) // 4).data_ptr()
 
     def _prepare_weights(self):
         """Once per parameter version and block: h2p copies of the weights in the orientations the kernels read, their
         scales and the row norms that bound the outputs."""
         net = self.net
         key = self.pfx + "weights"
-        marker = self._bytes(key, 16)
+        marker = self._wbytes("weights", 16)
         if net._derived_fresh(key, marker):
             return
         p = net._p
@@ -110,6 +112,28 @@ class H2Cnn:
         amax = net._weight_range(self.fc.prefix, self.H * 3136)
         hip.h2_weights(p(f"{self.fc.prefix}.weight"), self.H, 3136, 0, amax, W(S_WF), W(R_WF), self._wbytes("wf", self.H * 3136 * 4))
         hip.h2_weights(p(f"{self.fc.prefix}.weight"), 3136, self.H, 1, amax, W(S_WFT), W(R_WFT), self._wbytes("wft", self.H * 3136 * 4))
+        net._derived_done(marker)
+
+    def _folded(self):
+        """(descriptor of one image, buffer of the first layer's folded weights).  Its own buffer: the per-position kernels of the
+        layer-by-layer path keep another format under "<prefix>.folded"."""
+        desc1 = hip.conv_desc(1, 21, 21, 64, 2, 2, 1, 32, hip.ACT_RELU)
+        return desc1, self.net.wws.get(f"{self.c1.prefix}.folded.h2", hip.conv2d_obs_fwd_workspace(desc1)).data_ptr()
+
+    def prepare(self):
+        """Everything of this block that depends on the parameters alone, enqueued now: the trainer calls it at the top of an
+        update, where the GPU otherwise idles behind the host (leaf copies, the GAE scan and a dozen fills take the host
+        ~0.4 ms to issue and the GPU ~0.05 ms to run) -- 0.25 ms of small launches that used to sit between the first chunk's
+        staging and its first convolution."""
+        net = self.net
+        self._prepare_weights()
+        desc1, fws = self._folded()
+        if not net._derived_fresh(f"{self.c1.prefix}.folded:h2", fws):
+            if hip.conv2d_obs_fold_h2(desc1, net._p(f"{self.ln.prefix}.weight"), net._p(f"{self.ln.prefix}.bias"),
+                                      net._p(f"{self.c1.prefix}.weight"), net._p(f"{self.c1.prefix}.bias"), fws):
+                net._derived_done(fws)
+            else:
+                net._derived.pop(fws, None)
 
     # ------------------------------------------------------------------ forward
     # Inference batches: the Linear's 3136-long reduction split over FC_SPLITK workgroups per tile -- the rows alone leave most CUs
@@ -148,11 +172,13 @@ class H2Cnn:
         m3 = self._bytes(f"{t}m3", n * 49 * 8)
         # first layer: frames -> a1
         desc1 = hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, hip.ACT_RELU)
-        fws = ws.get(f"{self.c1.prefix}.folded", hip.conv2d_obs_fwd_workspace(desc1)).data_ptr()
+        fws = self._folded()[1]
         reuse = net._derived_fresh(f"{self.c1.prefix}.folded:h2", fws)
         hip.conv2d_obs_fwd_h2(desc1, src.data_ptr(), mean.data_ptr(), rstd.data_ptr(), net._p(f"{self.ln.prefix}.weight"),
                               net._p(f"{self.ln.prefix}.bias"), net._p(f"{self.c1.prefix}.weight"), net._p(f"{self.c1.prefix}.bias"),
                               a1, P(S_A1), fws, row_index, P(M_A1), m1, reuse_folded=reuse, ent_order=2)
+        if not reuse:
+            net._derived_done(fws)
         # conv2, conv3
         hip.h2_conv(hip.H2_CONV2_FWD, a1, self._wbytes("w2", 0), P(S_A1), W(S_W2), n, a2, P(M_A2),
                     bias=net._p(f"{self.c2.prefix}.bias"), act=1, out_scale=P(S_A2), bound_in=P(M_A1),

@@ -136,6 +136,7 @@ class HipNet:
         self._cm = False
         self._mlp_cache = {}
         self._pver = [0]    # parameter version, shared with the twins (a list: one object)
+        self._has_twins = [False]
         self._in_update = [False]
         # > 0 while the policy serves rollout requests (ActorCriticPolicy.rollout): like the chunks of one update, consecutive
         # requests see the same parameters unless somebody said otherwise (``params_changed``), so what an executor derived from
@@ -146,7 +147,18 @@ class HipNet:
         self.last_chunk = None
         self._derived_on = os.environ.get("SRL_DERIVED_CACHE", "1") != "0"  # 0: recompute for every chunk (A/B)
         self._presplit_on = self._derived_on and os.environ.get("SRL_PRESPLIT", "1") != "0"  # weights split once per update
-        self._derived = {}  # per executor: what its workspace holds that was derived from which parameter version
+        # what a workspace buffer holds that was derived from which parameter version.  Keyed by the buffer; one dict for the
+        # executor and its twins (their buffers differ) -- since round 6 the weight-only data of the two-piece encoder block
+        # lives in ONE set of buffers, `wws`, which every twin reads: whoever meets a stale buffer first recomputes it on ITS
+        # stream and leaves an event (`_derived_done`); the others wait for that event once (`_dsynced`, per executor).  Before,
+        # each of the four executors of an update made its own copies: 4 x 225 us of small launches, which the 512-environment
+        # shard of a data-parallel rank (12.3 ms per update) does not amortise.  SRL_SHARED_DERIVED=0: per executor again (A/B)
+        self._derived = {}
+        self._devent = {}
+        self._dsynced = {}
+        self._shared_derived = os.environ.get("SRL_SHARED_DERIVED", "1") != "0"
+        self._early_derived = os.environ.get("SRL_EARLY_DERIVED", "1") != "0"
+        self.wws = self.ws
         self._side_stream = None
         self._side_used = False
         # SRL_EXPLICIT_CONV=1 forces the im2col + GEMM + col2im fallback (kept for geometries the implicit
@@ -267,9 +279,24 @@ class HipNet:
         # and in the per-position kernel's format, chosen by the row count of a call) -- fresh is what was written there last
         key, val = ptr, (what, self._pver[0], self.flat.data_ptr())
         if self._derived.get(key) == val:
+            ev = self._devent.get(ptr)
+            if ev is not None and self._dsynced.get(ptr) is not ev:   # written by another executor, maybe on another stream
+                cur = torch.cuda.current_stream()
+                if cur != ev[1]:
+                    cur.wait_event(ev[0])
+                self._dsynced[ptr] = ev
             return True
         self._derived[key] = val
+        self._devent.pop(ptr, None)
         return False
+
+    def _derived_done(self, ptr: int):
+        """The launches that fill the SHARED buffer ``ptr`` (`wws`) are enqueued: the twins order themselves behind them."""
+        if not self.on_gpu or self.wws is self.ws and not self._has_twins[0] or torch.cuda.is_current_stream_capturing():
+            return
+        ev = (torch.cuda.Event(), torch.cuda.current_stream())
+        ev[0].record(ev[1])
+        self._devent[ptr] = self._dsynced[ptr] = ev
 
     def _presplit(self, key: str, src_ptr: int, numel: int, range_ptr: int) -> Optional[int]:
         """The weight tensor at ``src_ptr`` as the two f16 pieces the two-piece kernels would otherwise make of it in every tile
@@ -289,6 +316,18 @@ class HipNet:
         if not on:
             self.last_chunk = None
 
+    def prepare_derived(self):
+        """Top of a trainer update (the parameters are final until the optimiser step): enqueue what the two-piece encoder
+        blocks derive from them -- h2p weight copies in three orientations, scales, bounds, the first layer's folded weights --
+        before the host starts on the update's head.  Opens the window `chunks_of_one_update` describes (the chunk loop closes
+        it).  Nothing to do before the first forward pass has built the blocks.  SRL_EARLY_DERIVED=0: off (A/B)."""
+        blocks = [b for b in self.__dict__.get("_h2_blocks", {}).values() if b is not None]
+        if not (self.on_gpu and self._derived_on and self._early_derived and blocks):
+            return
+        self._in_update[0] = True
+        for blk in blocks:
+            blk.prepare()
+
     def refresh_weight_ranges(self):
         """Recompute every stale weight range now, on the current stream (before two row-chunk pipelines that share the
         slots start side by side)."""
@@ -307,8 +346,11 @@ class HipNet:
         t.grad_ready_hook = None
         t._amax_next = t._gmax_next = -1
         t._side_stream, t._side_used = None, False
-        t._derived = {}
+        t._dsynced = {}
         t._h2_blocks = {}
+        self._has_twins[0] = True
+        if not self._shared_derived:
+            t.wws, t._derived, t._devent = t.ws, {}, {}
         return t
 
     def _weight_range(self, prefix: str, numel: int) -> int:

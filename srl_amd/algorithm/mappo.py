@@ -617,6 +617,9 @@ class MultiAgentPPO(PytorchTrainer):
         block = block.view(self.ppo_epochs, stride)
 
         for epoch in range(self.ppo_epochs):
+            # what the encoder blocks derive from the parameters alone goes first: it runs while the host issues the head below
+            if dscal is None:
+                net.prepare_derived()
             # ---- advantages / value targets ------------------------------------------------------------------
             if adv_d is None:
                 if have_adv:

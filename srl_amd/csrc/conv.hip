@@ -618,6 +618,29 @@ extern "C" int srl_conv2d_obs_row_index_supported(const srl_conv_desc* d, int is
   return obs_bf16_ok(d, is_u8, channels_last, nullptr) && ((long)OH * OW * d->Cout) % 4 == 0 ? 1 : 0;
 }
 
+// The first layer's block kernel (obs_h2.h) and its per-position folded weights: the geometry it serves, and the fold on its own
+// (the weights depend on the parameters only: srl_conv2d_obs_fold_h2 lets the trainer enqueue it before the update's first chunk).
+static bool obs_h2_block_geometry(const srl_conv_desc* d) {
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride);
+  return d->Cin == 64 && d->KH == 2 && d->KW == 2 && d->stride == 1 && d->Cout == 32 && OH % srlobs::kBlkH == 0 &&
+         OW % srlobs::kBlkW == 0 && OH % 2 == 0 && OW % 2 == 0;
+}
+
+static void obs_h2_fold(hipStream_t st, const srl_conv_desc* d, const float* gamma, const float* beta, const float* w,
+                        const float* bias, float* workspace) {
+  const int OH = conv_out(d->H, d->KH, d->stride), OW = conv_out(d->W, d->KW, d->stride), P = OH * OW;
+  const long Kp = (long)d->Cin * d->KH * d->KW;
+  uint16_t* wq = reinterpret_cast<uint16_t*>(workspace);
+  float* S = workspace + ((long)P * 3 * d->Cout * Kp) / 2;
+  float* b2 = S + (long)P * d->Cout;
+  float* bound = b2 + (long)P * d->Cout;
+  float* winv = workspace + (long)P * d->Cout * Kp;
+  const ObsIndex ix{d->Cin, d->H, d->W, d->KH, d->KW, d->stride, OW, 1};
+  (void)hipMemsetAsync(bound, 0, sizeof(float), st);
+  hipLaunchKernelGGL(srlobs::obs_fold_h2_kernel<ObsIndex>, dim3((unsigned)(P * d->Cout)), dim3(256), 0, st, w, bias, gamma, beta, P, ix,
+                     wq, winv, S, b2, bound, sqrtf((float)((long)d->H * d->W * d->Cin)));
+}
+
 static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* obs, int is_u8, int channels_last,
                               const float* mean, const float* rstd, const float* gamma, const float* beta,
                               const float* w, const float* bias, float* y, float* workspace, const int32_t* row_index,
@@ -654,15 +677,10 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
     float* bound = b2 + (long)P * d->Cout;  // one of the workspace's 64 spare floats: upper bound of |y| from the folded weights
     // h2 output on the Atari geometry: blocks of 2 x 4 positions per workgroup, two f16 weight pieces in registers (obs_h2.h)
     static const bool blocks_on = [] { const char* e = getenv("SRL_OBS_H2BLOCK"); return !(e && e[0] == '0'); }();
-    if (y_h2 && blocks_on && ent_order == 2 && d->Cin == 64 && d->KH == 2 && d->KW == 2 && d->stride == 1 && d->Cout == 32 &&
-        OH % srlobs::kBlkH == 0 && OW % srlobs::kBlkW == 0 && OH % 2 == 0 && OW % 2 == 0 && d->n * (long)P * 128 < 0x7fffffffL &&
+    if (y_h2 && blocks_on && ent_order == 2 && obs_h2_block_geometry(d) && d->n * (long)P * 128 < 0x7fffffffL &&
         4 * (d->n + 32) + (long)P * d->Cout <= (long)P * d->Cout * Kp / 2) {  // (the records fit behind the two planes)
       float* winv = workspace + (long)P * d->Cout * Kp;  // behind the two f16 planes, inside the room of the three bf16 ones
-      if (!reuse_folded) {
-        (void)hipMemsetAsync(bound, 0, sizeof(float), st);
-        hipLaunchKernelGGL(srlobs::obs_fold_h2_kernel<ObsIndex>, dim3((unsigned)(P * d->Cout)), dim3(256), 0, st, w, bias, gamma, beta,
-                           P, ix, wq, winv, S, b2, bound, sqrtf((float)((long)d->H * d->W * d->Cin)));
-      }
+      if (!reuse_folded) obs_h2_fold(st, d, gamma, beta, w, bias, workspace);
       srlobs::FwdH2Args h{};
       const long n_pad = srl_ceil_div(d->n, (long)srlobs::kTile) * srlobs::kTile;
       uint4* meta = reinterpret_cast<uint4*>(winv + (long)P * d->Cout);  // per-sample records of this launch, behind winv
@@ -791,6 +809,16 @@ extern "C" int srl_conv2d_obs_fwd(void* stream, const srl_conv_desc* d, const vo
                                       reuse_folded || i0 > 0);
     if (rc != 0) return rc;
   }
+  return 0;
+}
+
+extern "C" int srl_conv2d_obs_fold_h2(void* stream, const srl_conv_desc* d, const float* gamma, const float* beta, const float* w,
+                                      const float* bias, float* workspace) {
+  static const bool blocks_on = [] { const char* e = getenv("SRL_OBS_H2BLOCK"); return !(e && e[0] == '0'); }();
+  if (check_desc(d) != 0 || !blocks_on || !obs_h2_block_geometry(d)) return 1;  // not the block kernel's layer: nothing written
+  SRL_CHECK_ARG(gamma && beta && w && workspace && aligned16(workspace) && aligned16(gamma) && aligned16(beta), "null / unaligned tensor");
+  obs_h2_fold((hipStream_t)stream, d, gamma, beta, w, bias, workspace);
+  SRL_LAUNCH_CHECK();
   return 0;
 }
 

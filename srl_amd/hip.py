@@ -25,7 +25,7 @@ _lib = None
 # (bench.py does, before its imports) -- INTEGRATION.md lists it with the other switches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # loss-term slots (srl_hip.h: SRL_LT_*)
 LT_POLICY, LT_VALUE, LT_ENTROPY, LT_CLIP, LT_RATIO, LT_ADV, LT_RET, LT_MASK, LT_DONE, LT_TRUNC, LT_COUNT = range(11)
@@ -225,6 +225,7 @@ _SIGNATURES = {
     "srl_h2_gemm": (c_int, [c_void_p, POINTER(H2GemmDesc)]),
     "srl_h2_gemm_splitk": (c_int, [c_void_p, POINTER(H2GemmDesc), c_int32, c_int32]),
     "srl_conv2d_obs_fwd_h2": (c_int, [c_void_p, POINTER(ConvDesc)] + [c_void_p] * 13 + [c_int, c_int]),
+    "srl_conv2d_obs_fold_h2": (c_int, [c_void_p, POINTER(ConvDesc)] + [c_void_p] * 5),
     "srl_comm_available": (c_int, []),
     "srl_comm_unique_id": (c_int, [c_void_p]),
     "srl_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
@@ -1240,6 +1241,15 @@ def h2_gemm_splitk(x, w, sx, sw, M, NC, K, out, ksplits, wide=False):
     d = H2GemmDesc(_vp(x), _vp(w), _vp(sx), _vp(sw), int(M), int(NC), int(K), None, 0, 0, _vp(out), None, None, None, None, None, None, None, 0)
     with _scope("gemm", 2.0 * int(M) * int(NC) * int(K), "2h"):
         _check(lib().srl_h2_gemm_splitk(_stream(), ctypes.byref(d), int(ksplits), int(bool(wide))), "srl_h2_gemm_splitk")
+
+
+def conv2d_obs_fold_h2(desc, gamma, beta, w, bias, ws_ptr) -> bool:
+    """Only the folded first-layer weights ``conv2d_obs_fwd_h2(..., reuse_folded=True)`` reads.  False: not that kernel's layer."""
+    rc = lib().srl_conv2d_obs_fold_h2(_stream(), ctypes.byref(desc), _vp(gamma), _vp(beta), _vp(w), _vp(bias), _vp(ws_ptr))
+    if rc == 1:
+        return False
+    _check(rc, "srl_conv2d_obs_fold_h2")
+    return True
 
 
 def conv2d_obs_fwd_h2(desc, obs_ptr, mean, rstd, gamma, beta, w, bias, y_h2, y_scale, ws_ptr, row_index, y_absmax, y_mask,

@@ -257,7 +257,8 @@ def test_synthetic_sample_obeys_reference_invariants():
 def test_executor_host_logic_of_round_3():
     """Host-side decisions of the executor that need no GPU: split-K factors of weight gradients, and the validity window of
     what an executor derives from the weights (only inside the trainer's chunk loop, only for the current parameter version,
-    only for the same buffer; twins keep their own record but share the version)."""
+    only for the same buffer; the record is keyed by the buffer and shared with the twins, whose own buffers are other
+    pointers, while the weight-only data of the two-piece block lives in the first executor's workspace for all of them)."""
     from srl_amd.algorithm import hipnet
     assert hipnet._split_for(256, 1) == 1            # CartPole-sized: one piece (srl_gemm's small-product path)
     assert hipnet._split_for(16384, 1) == 32         # >= 512 rows per slice
@@ -272,12 +273,15 @@ def test_executor_host_logic_of_round_3():
     assert net._derived_fresh("w", 1000)             # ... the following ones reuse
     assert not net._derived_fresh("w", 2000)         # another buffer (outgrown workspace): recompute
     twin = net.twin()
-    assert not twin._derived_fresh("w", 1000)        # a twin's workspace holds nothing yet
-    assert twin._derived_fresh("w", 1000)
+    assert twin.wws is net.ws and twin.ws is not net.ws   # one set of derived weights, a workspace of its own for the rest
+    assert twin._derived_fresh("w", 2000)            # a SHARED buffer the first executor filled: fresh for the twin
+    assert not twin._derived_fresh("w", 3000)        # a buffer of the twin's own workspace holds nothing yet
+    assert twin._derived_fresh("w", 3000)
     net.params_changed()                             # optimiser step: everything derived is stale, for the twin too
-    assert not net._derived_fresh("w", 2000) and not twin._derived_fresh("w", 1000)
+    assert not net._derived_fresh("w", 2000) and not twin._derived_fresh("w", 3000)
+    assert twin._derived_fresh("w", 2000)            # ... and recomputed by one of them for both
     net.chunks_of_one_update(False)
-    assert not net._derived_fresh("w", 2000) and not twin._derived_fresh("w", 1000)
+    assert not net._derived_fresh("w", 2000) and not twin._derived_fresh("w", 3000)
 
 
 def test_host_side_queries_of_the_fused_kernels():
