@@ -55,13 +55,20 @@ class _BucketReducer:
     gradient buffer on its own stream, so a bucket is final when the LAST chunk of EACH pipeline has announced its
     parameters.  Each announcement leaves an event on its pipeline's stream; when the last pipeline completes a bucket, a
     reduction stream waits for those events, folds the other pipelines' slices into the first buffer (srl_accumulate on
-    just that slice) and launches the slice's all-reduce from there -- none of the pipelines waits."""
+    just that slice) and launches the slice's all-reduce from there -- none of the pipelines waits.
+
+    The LAST bucket to become final (the first layers' parameters, at the very end of the backward pass) has nothing left to
+    overlap with: the clip and the optimiser step need it.  `finish` closes it ON the compute stream -- wait for the pipelines'
+    tails, fold, all-reduce, all in stream order -- instead of through the reduction stream and the communicator's side stream
+    and back (three cross-stream dependencies in a row at the one place of an update where the GPU has nothing else to run;
+    SRL_LAST_BUCKET_INLINE=0: as before, A/B)."""
+    LAST_INLINE = os.environ.get("SRL_LAST_BUCKET_INLINE", "1") != "0"
 
     def __init__(self, net, bucket_bytes, comm=None):
         self.net = net
         self.comm = comm  # srl_amd.comm.NativeComm (RCCL through the C ABI on a side stream) or None (torch.distributed)
         self.buckets = []  # [lo, hi, frozenset of the parameter prefixes inside]
-        self.stats = dict(epochs=0, launched_in_backward=0, launched_in_finish=0, slices_folded=0)
+        self.stats = dict(epochs=0, launched_in_backward=0, launched_in_finish=0, slices_folded=0, closed_inline=0)
         self._fold_stream = None
         lo, pending, size = None, set(), 0
         for name, info in net.spec.params.items():
@@ -134,6 +141,8 @@ class _BucketReducer:
                     if many:
                         self.events[pipe][i] = self._mark()
                     if all(not other[i] for other in self.pending):
+                        if self.LAST_INLINE and sum(self.launched) == len(self.buckets) - 1:
+                            continue   # the last one: `finish`, on the compute stream
                         self._launch(i)
 
     @staticmethod
@@ -149,6 +158,23 @@ class _BucketReducer:
         """Launch what the backward passes did not release (``streams``: the pipelines' streams, all of their work enqueued),
         then make the current stream wait for every bucket."""
         self._finishing = True
+        rest = [i for i in range(len(self.buckets)) if not self.launched[i]]
+        if self.LAST_INLINE and len(rest) == 1 and all(not pend[rest[0]] for pend in self.pending):
+            # released by every pipeline and held back by `ready`
+            i = rest[0]
+            lo, hi, _ = self.buckets[i]
+            cur = torch.cuda.current_stream()
+            for st in streams:
+                cur.wait_stream(st)
+            if len(self.grads) > 1:
+                hip.accumulate_n(self.grads[0][lo:hi], [g[lo:hi] for g in self.grads[1:]])
+                self.stats["slices_folded"] += len(self.grads) - 1
+            if self.comm is not None:
+                self.comm.all_reduce_f32_inline(self.grads[0][lo:hi])
+            else:   # (the process group's stream picks up behind the current one, and the current one waits for it)
+                dist.all_reduce(self.grads[0][lo:hi])
+            self.launched[i] = True
+            self.stats["closed_inline"] += 1
         if len(self.grads) > 1 and not all(self.launched):
             if self._fold_stream is None:
                 self._fold_stream = torch.cuda.Stream(device=self.grads[0].device)

@@ -116,6 +116,13 @@ class NativeComm:
         assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
         hip._check(hip.lib().srl_allreduce_grads(self._enter(), self._h, t.data_ptr(), t.numel()), "srl_allreduce_grads")
 
+    def all_reduce_f32_inline(self, t: torch.Tensor):
+        """The same all-reduce enqueued on the CURRENT stream, in its order (RCCL orders the collectives of one communicator by
+        their enqueue order whatever streams they are on): for a reduction whose result the very next kernel needs."""
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        hip._check(hip.lib().srl_allreduce_grads(torch.cuda.current_stream(self.device).cuda_stream, self._h, t.data_ptr(), t.numel()),
+                   "srl_allreduce_grads")
+
     def broadcast_async(self, t: torch.Tensor, root: int = 0):
         assert t.is_contiguous() and t.is_cuda
         hip._check(hip.lib().srl_broadcast_params(self._enter(), self._h, t.data_ptr(), t.numel() * t.element_size(), root),

@@ -97,6 +97,14 @@ def test_bucket_reducer_cuts_and_readiness():
     r.ready([f"{cm}.4"]); r.ready([f"{cm}.2"])
     assert sorted(fired) == [1, 2]
     r.ready([f"{cm}.0", "obs_modules_dict.obs.0"])
+    # the bucket that becomes final LAST has nothing left to overlap with: `ready` holds it back for `finish`, which closes it in
+    # stream order on the compute stream (round 6)
+    assert sorted(fired) == [1, 2] and not r.launched[0] and not any(r.pending[0][0])
+    r.LAST_INLINE = False   # the A/B switch: as before, launched from the last release
+    r.begin()
+    fired.clear()
+    for pre in (["actor_head"], ["critic_head"], [f"{cm}.7.2"], [f"{cm}.7.0"], [f"{cm}.4"], [f"{cm}.2"], [f"{cm}.0", "obs_modules_dict.obs.0"]):
+        r.ready(pre)
     assert sorted(fired) == [0, 1, 2] and fired[-1] == 0
 
 
@@ -126,8 +134,9 @@ def test_bucket_reducer_with_two_pipelines_waits_for_both():
     r.hook(1)(every)  # pipeline 1 releases everything: only what both have released goes
     assert fired == both and len(marks) == len(both) + len(r.buckets)
     r.hook(0)(every)
-    assert sorted(fired) == list(range(len(r.buckets))) and len(marks) == 2 * len(r.buckets)
+    held = [i for i in range(len(r.buckets)) if not r.launched[i]]   # the one completed last waits for `finish` (stream order)
+    assert len(held) == 1 and sorted(fired + held) == list(range(len(r.buckets))) and len(marks) == 2 * len(r.buckets)
     assert all(ev is not None for pipe in r.events for ev in pipe)
     r.begin()  # one pipeline again: no markers
     r.ready(every)
-    assert len(marks) == 2 * len(r.buckets) and all(r.launched)
+    assert len(marks) == 2 * len(r.buckets) and sum(r.launched) == len(r.buckets) - 1

@@ -85,7 +85,10 @@ def test_two_rank_trainer_matches_ddp_semantics(unequal, pipelines, chunk_rows):
     for r in range(world):  # the overlap ran: every bucket of every epoch left from inside a backward pass
         red, nb = res[r]["reducer"], res[r]["buckets"]
         epochs = STEPS * TRAINER["ppo_epochs"]
-        assert nb >= 3 and red["launched_in_backward"] == nb * epochs and red["launched_in_finish"] == 0, red
+        # (every bucket but the one that becomes final last: that one has nothing left to overlap with and is closed in stream
+        # order behind the chunk loop, `_BucketReducer.finish`)
+        assert nb >= 3 and red["launched_in_backward"] == (nb - 1) * epochs and red["launched_in_finish"] == 0, red
+        assert red["closed_inline"] == epochs, red
         assert res[r]["pipes"] == pipelines, res[r]["pipes"]
         assert red["slices_folded"] == nb * epochs * (pipelines - 1), red
     for k in res[0]["init"]:  # both ranks start from rank 0's parameters and stay identical
@@ -173,7 +176,8 @@ def test_two_rank_ppg_auxiliary_phase_matches_ddp_semantics():
         assert np.array_equal(res[0]["final"][k], res[1]["final"][k]), k
     for r in range(world):
         red, nb = res[r]["reducer"], res[r]["buckets"]
-        assert nb >= 2 and red["launched_in_backward"] == nb * PPG_TRAINER["ppg_epochs"] and red["launched_in_finish"] == 0, red
+        assert nb >= 2 and red["launched_in_backward"] == (nb - 1) * PPG_TRAINER["ppg_epochs"] and red["launched_in_finish"] == 0, red
+        assert red["closed_inline"] == PPG_TRAINER["ppg_epochs"], red
     onet = OracleActorCritic(**PPG_POLICY, auxiliary_head=True)
     onet.load_state_dict(res[0]["init"])
     oracle = OraclePPGAux(onet, beta_clone=1.0, aux_value_head_weight=0.5, max_grad_norm=5.0, popart=False,
@@ -220,8 +224,8 @@ def test_bench_script_with_two_ranks():
     # the NatureCNN's buckets leave from inside the backward passes of the two pipelines' last chunks, layer by layer
     gb = line["config"]["grad_buckets"]
     assert line["config"]["pipelines"] >= 2 and gb["buckets"] >= 2 and gb["launched_in_finish"] == 0, gb
-    assert gb["launched_in_backward"] == gb["buckets"] * gb["epochs"], gb
-    assert 0.8 * gb["launched_in_backward"] <= gb["slices_folded"] <= gb["launched_in_backward"], gb  # (one-chunk legs: no fold)
+    assert gb["launched_in_backward"] == (gb["buckets"] - 1) * gb["epochs"] and gb["closed_inline"] == gb["epochs"], gb
+    assert 0.8 * gb["buckets"] * gb["epochs"] <= gb["slices_folded"] <= gb["buckets"] * gb["epochs"], gb  # (one-chunk legs: no fold)
 
 
 def test_bench_script_one_rank_over_rccl():
