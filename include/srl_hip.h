@@ -617,11 +617,14 @@ int64_t srl_h2_wgrad_dense_workspace(int64_t M, int32_t NA, int32_t NB);
 int srl_h2_wgrad_dense(void* stream, const void* a, const void* b, const float* sa, const float* sb, int64_t M, int32_t NA, int32_t NB,
                        int64_t a_row_bytes, int64_t b_row_bytes, float* workspace, float* gw, int32_t accumulate);
 /* srl_conv2d_obs_fwd with the output as the h2p rows kind 0 above reads (ent_order 2) instead of float32: byte kernels
- * only (uint8 channels-last frames, Cout 32), y_mask / y_absmax / workspace required; *y_scale = the scale used. */
+ * only (uint8 channels-last frames, Cout 32), y_mask / y_absmax / workspace required; *y_scale = the scale used.
+ * records: NULL, or room for 16 (n + 32) bytes of per-sample records of THIS launch (16-byte aligned).  NULL keeps them inside
+ * `workspace` behind the folded weights -- which then serves one stream at a time; with a room of its own per caller, several
+ * streams may run this entry point on one set of folded weights (reuse_folded = 1) side by side. */
 int srl_conv2d_obs_fwd_h2(void* stream, const srl_conv_desc* d, const void* obs, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, const float* w, const float* bias, void* y_h2, float* y_scale,
                           float* workspace, const int32_t* row_index, float* y_absmax, uint32_t* y_mask, int reuse_folded,
-                          int ent_order);
+                          int ent_order, void* records);
 /* Only the folded weights that srl_conv2d_obs_fwd_h2 keeps in `workspace` (what reuse_folded = 1 then reads): they depend on
  * the parameters alone (the LayerNorm affine of modules/cnn.py:100 folded into the first convolution's weights, :108), so the
  * trainer enqueues them once per parameter version ahead of the update's first chunk.  Returns 0: written; 1: d is not the

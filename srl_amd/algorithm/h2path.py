@@ -176,7 +176,8 @@ class H2Cnn:
         reuse = net._derived_fresh(f"{self.c1.prefix}.folded:h2", fws)
         hip.conv2d_obs_fwd_h2(desc1, src.data_ptr(), mean.data_ptr(), rstd.data_ptr(), net._p(f"{self.ln.prefix}.weight"),
                               net._p(f"{self.ln.prefix}.bias"), net._p(f"{self.c1.prefix}.weight"), net._p(f"{self.c1.prefix}.bias"),
-                              a1, P(S_A1), fws, row_index, P(M_A1), m1, reuse_folded=reuse, ent_order=2)
+                              a1, P(S_A1), fws, row_index, P(M_A1), m1, reuse_folded=reuse, ent_order=2,
+                              records=self._bytes(f"{t}records", 16 * (n + 32)))   # (the folded weights are shared: `wws`)
         if not reuse:
             net._derived_done(fws)
         # conv2, conv3

@@ -121,6 +121,13 @@ class HipNet:
         # fill each other's stalls: 156.3 -> 151.8 ms per update, same box); joined at the end of backward().
         # SRL_WGRAD_STREAM=0: everything on the compute stream (A/B)
         self._wgrad_side = os.environ.get("SRL_WGRAD_STREAM", "1") != "0"
+        # ... but not while the trainer runs several row-chunk pipelines side by side (`_multi`, a list shared with the twins): the
+        # other pipelines fill those stalls already, and since round 6 every large kernel of the Atari update takes the whole
+        # chip -- same box, alternating: 85.61 / 85.38 ms per update with the second stream, 85.10 / 85.22 without; the 512-env
+        # shard 11.44 / 11.47 against 11.31 / 11.43 -- and four streams fewer compete for the hardware queues.
+        # SRL_WGRAD_STREAM=2: second stream in every case (A/B)
+        self._wgrad_side_always = os.environ.get("SRL_WGRAD_STREAM", "1") == "2"
+        self._multi = [False]
         # ReLU derivatives from sign-bit masks written by the producing convolution (SRL_RELU_MASK=0: from its floats)
         self._relu_masks = os.environ.get("SRL_RELU_MASK", "1") != "0"
         # small MLP chains (every layer LayerNorm / Linear, no wider than 128) in one launch per direction (csrc/mlp_small.hip);
@@ -407,7 +414,7 @@ class HipNet:
         compute stream; without the switch, inline.  (While gradient buckets are being released, too: ``_release`` records a
         bucket's event behind BOTH streams -- until round 5 such passes ran everything inline, which cost the last chunk of every
         pipeline, i.e. EVERY chunk of an 8-GPU shard, the overlap.)"""
-        if not self._wgrad_side:
+        if not self._wgrad_side or (self._multi[0] and not self._wgrad_side_always):
             fn()
             return
         if self._side_stream is None:

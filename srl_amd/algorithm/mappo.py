@@ -753,6 +753,7 @@ class MultiAgentPPO(PytorchTrainer):
             if reducer is not None:
                 reducer.begin([x.grad for x in nets])
             net.chunks_of_one_update(True)
+            net._multi[0] = len(nets) > 1
             for x in nets:
                 x.reset_open_accumulations()  # (an accumulation a failed update left open is not continued)
             for ci in range(nchunks):
@@ -790,6 +791,7 @@ class MultiAgentPPO(PytorchTrainer):
                     for pst in streams[1:]:
                         pst.wait_stream(streams[0])
             net.chunks_of_one_update(False)
+            net._multi[0] = False
             for x in nets:
                 x.last_chunk = None
             if two and reducer is None:

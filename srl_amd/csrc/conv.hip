@@ -645,7 +645,7 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
                               const float* mean, const float* rstd, const float* gamma, const float* beta,
                               const float* w, const float* bias, float* y, float* workspace, const int32_t* row_index,
                               float* y_absmax, uint32_t* y_mask, int reuse_folded, uint8_t* y_h2 = nullptr, float* y_scale = nullptr,
-                              int ent_order = 0) {
+                              int ent_order = 0, uint4* records = nullptr) {
   SRL_CHECK_ARG(!y_h2 || (y_scale && y_mask && y_absmax && workspace && obs_bf16_ok(d, is_u8, channels_last, obs)),
                 "h2 output: byte kernels only, with y_scale, y_mask, y_absmax and the folded-weights workspace");
   SRL_CHECK_ARG(!y_mask || (d->act == 1 && d->Cout % 32 == 0), "y_mask: ReLU layers with Cout a multiple of 32");
@@ -678,12 +678,13 @@ static int conv2d_obs_fwd_run(void* stream, const srl_conv_desc* d, const void* 
     // h2 output on the Atari geometry: blocks of 2 x 4 positions per workgroup, two f16 weight pieces in registers (obs_h2.h)
     static const bool blocks_on = [] { const char* e = getenv("SRL_OBS_H2BLOCK"); return !(e && e[0] == '0'); }();
     if (y_h2 && blocks_on && ent_order == 2 && obs_h2_block_geometry(d) && d->n * (long)P * 128 < 0x7fffffffL &&
-        4 * (d->n + 32) + (long)P * d->Cout <= (long)P * d->Cout * Kp / 2) {  // (the records fit behind the two planes)
+        (records || 4 * (d->n + 32) + (long)P * d->Cout <= (long)P * d->Cout * Kp / 2)) {  // (the records fit behind the two planes)
       float* winv = workspace + (long)P * d->Cout * Kp;  // behind the two f16 planes, inside the room of the three bf16 ones
       if (!reuse_folded) obs_h2_fold(st, d, gamma, beta, w, bias, workspace);
       srlobs::FwdH2Args h{};
       const long n_pad = srl_ceil_div(d->n, (long)srlobs::kTile) * srlobs::kTile;
-      uint4* meta = reinterpret_cast<uint4*>(winv + (long)P * d->Cout);  // per-sample records of this launch, behind winv
+      // per-sample records of this launch: behind winv, or in the caller's own room when several streams share the folded weights
+      uint4* meta = records ? records : reinterpret_cast<uint4*>(winv + (long)P * d->Cout);
       hipLaunchKernelGGL(srlobs::obs_meta_kernel, dim3((unsigned)srl_ceil_div(n_pad, 256L)), dim3(256), 0, st, row_index, mean, rstd,
                          (long)d->n, n_pad, meta);
       h.frames = static_cast<const uint8_t*>(obs); h.img_stride = (long)d->H * d->W * d->Cin; h.meta = meta;
@@ -825,8 +826,9 @@ extern "C" int srl_conv2d_obs_fold_h2(void* stream, const srl_conv_desc* d, cons
 extern "C" int srl_conv2d_obs_fwd_h2(void* stream, const srl_conv_desc* d, const void* obs, const float* mean, const float* rstd,
                                      const float* gamma, const float* beta, const float* w, const float* bias, void* y_h2,
                                      float* y_scale, float* workspace, const int32_t* row_index, float* y_absmax, uint32_t* y_mask,
-                                     int reuse_folded, int ent_order) {
+                                     int reuse_folded, int ent_order, void* records) {
   SRL_CHECK_ARG(srl_conv2d_supported(d, 2), "unsupported geometry");
+  SRL_CHECK_ARG(!records || aligned16(records), "records: 16-byte aligned");
   SRL_CHECK_ARG(ent_order == 0 || (ent_order == 2 && conv_out(d->H, d->KH, d->stride) % 2 == 0 && conv_out(d->W, d->KW, d->stride) % 2 == 0),
                 "ent_order: 0 (raster) or 2 (parity-class major: even output extents)");
   const long run = images_per_launch(d, 1);
@@ -839,7 +841,7 @@ extern "C" int srl_conv2d_obs_fwd_h2(void* stream, const srl_conv_desc* d, const
     const int rc = conv2d_obs_fwd_run(stream, &s, static_cast<const uint8_t*>(obs) + adv * in_b, 1, 1, mean + adv, rstd + adv, gamma,
                                       beta, w, bias, nullptr, workspace, row_index ? row_index + i0 : nullptr, y_absmax,
                                       y_mask ? y_mask + i0 * out_e / 32 : nullptr, reuse_folded || i0 > 0,
-                                      static_cast<uint8_t*>(y_h2) + i0 * out_e * 4, y_scale, ent_order);
+                                      static_cast<uint8_t*>(y_h2) + i0 * out_e * 4, y_scale, ent_order, static_cast<uint4*>(records));
     if (rc != 0) return rc;
   }
   return 0;

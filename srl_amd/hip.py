@@ -224,7 +224,7 @@ _SIGNATURES = {
                                    c_int32]),
     "srl_h2_gemm": (c_int, [c_void_p, POINTER(H2GemmDesc)]),
     "srl_h2_gemm_splitk": (c_int, [c_void_p, POINTER(H2GemmDesc), c_int32, c_int32]),
-    "srl_conv2d_obs_fwd_h2": (c_int, [c_void_p, POINTER(ConvDesc)] + [c_void_p] * 13 + [c_int, c_int]),
+    "srl_conv2d_obs_fwd_h2": (c_int, [c_void_p, POINTER(ConvDesc)] + [c_void_p] * 13 + [c_int, c_int, c_void_p]),
     "srl_conv2d_obs_fold_h2": (c_int, [c_void_p, POINTER(ConvDesc)] + [c_void_p] * 5),
     "srl_comm_available": (c_int, []),
     "srl_comm_unique_id": (c_int, [c_void_p]),
@@ -1253,9 +1253,9 @@ def conv2d_obs_fold_h2(desc, gamma, beta, w, bias, ws_ptr) -> bool:
 
 
 def conv2d_obs_fwd_h2(desc, obs_ptr, mean, rstd, gamma, beta, w, bias, y_h2, y_scale, ws_ptr, row_index, y_absmax, y_mask,
-                      reuse_folded=False, ent_order=2):
+                      reuse_folded=False, ent_order=2, records=None):
     ri = _ptr(row_index, torch.int32, "row_index") if isinstance(row_index, torch.Tensor) else row_index
     with _scope("conv_obs_fwd", _conv_flops(desc), "obs2"):
         _check(lib().srl_conv2d_obs_fwd_h2(_stream(), ctypes.byref(desc), _vp(obs_ptr), _vp(mean), _vp(rstd), _vp(gamma), _vp(beta), _vp(w),
                                            _vp(bias), _vp(y_h2), _vp(y_scale), _vp(ws_ptr), _vp(ri), _vp(y_absmax), _vp(y_mask),
-                                           int(bool(reuse_folded)), int(ent_order)), "srl_conv2d_obs_fwd_h2")
+                                           int(bool(reuse_folded)), int(ent_order), _vp(records)), "srl_conv2d_obs_fwd_h2")

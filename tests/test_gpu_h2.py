@@ -562,6 +562,60 @@ def test_first_layer_h2_output_equals_its_float32_output():
     assert float(y.abs().max()) * float(hs.item()) < 2**15   # the a-priori bound holds
 
 
+def test_first_layer_two_streams_on_one_set_of_folded_weights():
+    """The executors of one update share the folded first-layer weights (srl_conv2d_obs_fold_h2 writes them once per parameter
+    version) and run srl_conv2d_obs_fwd_h2 side by side on their own streams: each call then needs its own room for the per-sample
+    records (`records`) -- inside the shared workspace the launches overwrite each other's (frame slot, mean, rstd).  Ten rounds of
+    two concurrent launches over different frames against the same launches one after the other: bit for bit; and (what does not
+    depend on how the GPU happens to schedule the two) a launch with its own records leaves the shared workspace untouched."""
+    hip = _hip()
+    n, slots = 8192, 2 * 8192 + 64
+    g = torch.Generator(device=DEV).manual_seed(41)
+    frames = torch.randint(0, 256, (slots, 4, 84, 84), dtype=torch.uint8, device=DEV, generator=g)
+    frames[::3] //= 8
+    s2d, mean, rstd = torch.empty(slots, 21, 21, 64, dtype=torch.uint8, device=DEV), torch.empty(slots, device=DEV), torch.empty(slots, device=DEV)
+    hip.obs_space_to_depth(frames.data_ptr(), True, slots, 4, 84, 84, 4, s2d.data_ptr(), mean.data_ptr(), rstd.data_ptr())
+    del frames
+    perm = torch.randperm(slots, device=DEV, generator=g).to(torch.int32)
+    rows = [perm[:n].contiguous(), perm[n:2 * n].contiguous()]
+    desc = hip.conv_desc(n, 21, 21, 64, 2, 2, 1, 32, 1)
+    gamma, beta = 1 + _f(21, 21, 64, seed=42, amp=0.2), _f(21, 21, 64, seed=43, amp=0.2)
+    w, b = _f(32, 2, 2, 64, seed=44, amp=0.06), _f(32, seed=45, amp=0.1)
+    ws = torch.empty(hip.conv2d_obs_fwd_workspace(desc), device=DEV)
+    assert hip.conv2d_obs_fold_h2(hip.conv_desc(1, 21, 21, 64, 2, 2, 1, 32, 1), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                  ws.data_ptr())
+    assert not hip.conv2d_obs_fold_h2(hip.conv_desc(1, 20, 20, 64, 4, 4, 2, 32, 1), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(),
+                                      b.data_ptr(), ws.data_ptr())   # not the block kernel's layer: nothing written
+    out = [[torch.zeros(n * 400 * 32, device=DEV), torch.zeros(n * 400, dtype=torch.int32, device=DEV), _slot(0.0), _slot(0.0),
+            torch.empty(4 * (n + 32), device=DEV)] for _ in range(2)]
+
+    def launch(e):
+        yh, hm, ham, hs, rec = out[e]
+        ham.zero_()
+        hip.conv2d_obs_fwd_h2(desc, s2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(),
+                              b.data_ptr(), yh.data_ptr(), hs.data_ptr(), ws.data_ptr(), rows[e], ham.data_ptr(), hm.data_ptr(),
+                              reuse_folded=True, ent_order=2, records=rec.data_ptr())
+
+    folded = ws.clone()
+    for e in range(2):   # one after the other
+        launch(e)
+    torch.cuda.synchronize()
+    assert torch.equal(ws.view(torch.int32), folded.view(torch.int32))   # nothing of a launch is kept in the shared workspace
+    want = [(o[0].clone(), o[1].clone(), float(o[2].item()), float(o[3].item())) for o in out]
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    for _ in range(10):
+        for o in out:
+            o[0].zero_(); o[1].zero_()
+        torch.cuda.synchronize()
+        for e in range(2):
+            with torch.cuda.stream(streams[e]):
+                launch(e)
+        torch.cuda.synchronize()
+        for e in range(2):
+            assert torch.equal(out[e][0], want[e][0]) and torch.equal(out[e][1], want[e][1]), e
+            assert float(out[e][2].item()) == want[e][2] and float(out[e][3].item()) == want[e][3]
+
+
 def test_first_layer_at_benchmark_size():
     """Both first-layer kernels on one 16 384-frame chunk exactly as `H2Cnn` calls them: frames read in place from a slot buffer
     through `row_index` (the HBM observation ring), forward with the h2p output in parity-class order + sign words + measured range,
