@@ -301,6 +301,7 @@ int fill(Args& a, const srl_mlp_layer* layers, int n) {
 
 #include "mlp_mfma.h"
 #include "mlp_sig.h"
+#include "mlp_sigh.h"
 
 // rows from which the matrix-core chain (mlp_mfma.h) takes over from the FMA chain; SRL_MLP_MFMA=0 switches it off (A/B)
 static long mfma_min_rows() {
@@ -354,7 +355,7 @@ extern "C" int srl_mlp_fwd(void* stream, const srl_mlp_layer* layers, int n, con
   a.x = x; a.ldx = ldx; a.rows = rows; a.tape = tape; a.tld = tape_ld; a.y = y; a.ldy = ldy;
   MArgs m;
   if (mfma_takes(a, rows, m)) {
-    if (sx_fwd(a, (hipStream_t)stream)) {   // a shape with a kernel of its own (mlp_sig.h)
+    if (hx_fwd(a, (hipStream_t)stream) || sx_fwd(a, (hipStream_t)stream)) {   // a shape with a kernel of its own (mlp_sigh.h / mlp_sig.h)
       SRL_LAUNCH_CHECK();
       return 0;
     }
@@ -415,7 +416,7 @@ static int mlp_bwd_impl(void* stream, const srl_mlp_layer* layers, int n, const 
   if (mfma_takes(a, rows, m)) {
     static const int dbg = [] { const char* e = getenv("SRL_MLP_DBG"); return e ? atoi(e) : 0; }();
     m.dbg = dbg;
-    if (sx_bwd(a, dbg, (hipStream_t)stream)) {
+    if (hx_bwd(a, dbg, (hipStream_t)stream) || sx_bwd(a, dbg, (hipStream_t)stream)) {
       SRL_LAUNCH_CHECK();
       return 0;
     }
