@@ -174,14 +174,21 @@ def mlp_roofline(device, T=128, B=4096, steps=10, trainer_args=None):
     disp = hip.dispatch_counts(reset=True)
     flops = 102.5e3 * T * B
     ach = flops / (ms * 1e-3) / 1e12
+    f16 = os.environ.get("SRL_MLP_F16", "1") != "0"   # round 6: the towers' products as three f16 piece products (csrc/mlp_sigh.h)
+    peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if f16 else PEAK_FP32_MFMA_TFLOPS
     return dict(kernel="actor / critic 2 x 64 MLPs (CartPole-shaped nets of BASELINE configs[0]) at 4096 envs x 128 steps, whole update",
-                bound="mfma", achieved=round(ach, 3), unit="TFLOP/s", peak=PEAK_FP32_MFMA_TFLOPS, frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 5),
+                bound="mfma", achieved=round(ach, 3), unit="TFLOP/s", peak=round(peak, 1), frac=round(ach / peak, 5),
+                peak_basis=("16-bit MFMA peak / 3: a float32 multiply-add as three f16 piece products (the pipe the towers run on since "
+                            "round 6)" if f16 else "float32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                achieved_over_fp32_mfma_peak=round(ach / PEAK_FP32_MFMA_TFLOPS, 5),
                 ms_per_step=round(ms, 3), env_steps_per_s=round(T * B / (ms * 1e-3)), flops_per_step=flops, traffic=None,
                 kernel_family_launches={k: v // steps for k, v in disp.items()} if isinstance(disp, dict) else disp,
-                note="each tower is ONE launch per direction (csrc/mlp_sig.h: the chain's shape is a template argument; no tape -- the "
-                     "backward pass walks the chain forward again from the 16-byte observation rows): 168 float32 MFMAs per 32 rows "
-                     "forward, 496 backward; `frac` counts the ALGORITHMIC 102.5 kFLOP per env-step over the whole update (GAE scan, "
-                     "loss, optimiser included) against the float32-MFMA peak (SURVEY 8d)")
+                note="each tower is ONE launch per direction (csrc/mlp_sigh.h: the chain's shape is a template argument, every Linear "
+                     "layer three products of f16 pieces; no tape -- the backward pass walks the chain forward again from the 16-byte "
+                     "observation rows): 66 MFMAs (32x32x16 f16) per 32 rows forward, ~190 backward (round 5, float32 MFMAs: 168 / "
+                     "496; SRL_MLP_F16=0).  `frac` counts the ALGORITHMIC 102.5 kFLOP per env-step over the whole update (GAE scan, loss, "
+                     "optimiser included) against the roof of the pipe the products run on; `achieved_over_fp32_mfma_peak` is last "
+                     "round's denominator (SURVEY 8d)")
 
 
 def smac_config_leg(device, steps=10):
@@ -653,9 +660,9 @@ def main():
                  work=sum(v["work"] for v in mm.values()), executed=sum(v["executed"] for v in mm.values()))
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12
         exe = g["executed"] / (g["ms"] * 1e-3) / 1e12
-        roofline = dict(kernel="h2conv_kernel / h2wgrad_kernel / h2gemm_kernel / gemm3_kernel (Linear weight gradient) / obs_fwd_h2_kernel / "
+        roofline = dict(kernel="h2conv_kernel / h2wgrad_kernel / h2gemm_kernel / h2tn_kernel (Linear weight gradient) / obs_fwd_h2_kernel / "
                                "obs_bwd_h2_kernel: every contraction of one step (image-stationary convolutions on pre-split f16 "
-                               "activations, the Linear's products, the first layer on bytes): float32 operands and results "
+                               "activations, the Linear's three products, the first layer on bytes): float32 operands and results "
                                "through 16-bit piece products on the f16 / bf16 matrix cores",
                         bound="mfma", achieved=round(ach, 2), unit="TFLOP/s", peak=PEAK_BF16_MFMA_TFLOPS,
                         executed=round(exe, 1), frac=round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
