@@ -2,7 +2,7 @@
 python scripts/design_table.py [round, default 05] [version, default 1]"""
 import csv, os, sys
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "06"
 v = sys.argv[2] if len(sys.argv) > 2 else "1"
 
 
@@ -24,7 +24,8 @@ ROWS = [  # label, kernel substring, flops (G), piece products, bytes (MB)
     ("conv3 weight gradient (`h2wgrad_kernel<1,3>`)", "h2wgrad_kernel<1, 3>", 59.2, 3, 545),
     ("Linear forward (`h2gemm_kernel<4,0,3>`)", "h2gemm_kernel<4, 0, 3, true", 52.6, 3, 245),
     ("Linear data gradient (`h2gemm_kernel<8,0,2,false>`)", "h2gemm_kernel<8, 0, 2, false", 52.6, 3, 245),
-    ("Linear weight gradient (`gemm3_kernel<128,128,…,2>`, split-K 5)", "gemm3_kernel<128, 128", 52.6, 3, 245),
+    ("Linear weight gradient (`h2tn_kernel`, 4 row ranges + slab sum)" if rnd >= "06" else
+     "Linear weight gradient (`gemm3_kernel<128,128,…,2>`, split-K 5)", "h2tn_kernel" if rnd >= "06" else "gemm3_kernel<128, 128", 52.6, 3, 245),
 ]
 print("| launch (kernel) | flops | MFMA floor | bytes | HBM floor | measured | × larger floor | traffic | MFMA busy | vector busy |")
 print("|---|---|---|---|---|---|---|---|---|---|")

@@ -82,7 +82,7 @@ extern "C" int srl_h2_pack_rows_colsum(void* stream, const float* src, int64_t l
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(h2_pack_colsum_kernel, dim3((unsigned)nb), dim3(256), (size_t)lanes * C * sizeof(float), st, src, (int64_t)ld, rows, (int)C, absmax,
                      scale_in, scale_out, static_cast<uint8_t*>(dst), workspace);
-  hipLaunchKernelGGL(h2_colsum_finish_kernel, dim3((unsigned)srl_ceil_div(C, 256)), dim3(256), 0, st, workspace, nb, (int)C, colsum, (int)accumulate);
+  hipLaunchKernelGGL(h2_colsum_finish_kernel, dim3((unsigned)srl_ceil_div(C, 32)), dim3(256), 0, st, workspace, nb, (int)C, colsum, (int)accumulate);
   SRL_LAUNCH_CHECK();
   return 0;
 }

@@ -215,19 +215,31 @@ static __global__ __launch_bounds__(256) void h2_pack_colsum_kernel(const float*
     slabs[(int64_t)blockIdx.x * C + c] = t;
   }
 }
-// out[c] (+)= sum over the slabs, in slab order
+// out[c] (+)= sum over the slabs, in a fixed order: a workgroup takes 32 columns, its 8 slab lanes every eighth slab each (four
+// independent sums per lane), and the lanes meet in LDS.  (First version: one thread per column walked all 512 slabs, two
+// workgroups per launch -- 35 us of dependent loads for 1 MB, in front of the layer's weight-gradient launch.)
 static __global__ __launch_bounds__(256) void h2_colsum_finish_kernel(const float* __restrict__ slabs, int nslab, int C, float* __restrict__ out,
                                                                       int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float part[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-  int k = 0;
-  for (; k + 3 < nslab; k += 4) {
-    t0 += slabs[(int64_t)k * C + c]; t1 += slabs[(int64_t)(k + 1) * C + c]; t2 += slabs[(int64_t)(k + 2) * C + c]; t3 += slabs[(int64_t)(k + 3) * C + c];
+  if (c < C) {
+    int k = sl;
+    for (; k + 24 < nslab; k += 32) {
+      t0 += slabs[(int64_t)k * C + c]; t1 += slabs[(int64_t)(k + 8) * C + c];
+      t2 += slabs[(int64_t)(k + 16) * C + c]; t3 += slabs[(int64_t)(k + 24) * C + c];
+    }
+    for (; k < nslab; k += 8) t0 += slabs[(int64_t)k * C + c];
   }
-  for (; k < nslab; ++k) t0 += slabs[(int64_t)k * C + c];
-  const float t = (t0 + t1) + (t2 + t3);
-  out[c] = accumulate ? out[c] + t : t;
+  part[sl][cl] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += part[j][cl];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // h2p rows -> float32 (tests, fallbacks)
