@@ -10,8 +10,7 @@
 //     a fragment with one conflict-free ds_read_b128; the data gradient reads the SAME copy transposed (ds_read_b64_tr_b16: four
 //     rows x 64 bytes per 32 lanes at a 64-byte pitch is every bank once), so one copy serves both directions as before;
 //   * a layer's input rows are split in registers, under a power-of-two scale PER ROW (its largest |value| -> [2^13, 2^14): the
-//     contraction runs over channels, so a row's scale leaves with the epilogue): ideally two mixed-precision instructions per
-//     element (v_fma_mixlo / mixhi); the compiler mostly emits three (packed multiply, packed convert, convert back, packed subtract);
+//     contraction runs over channels, so a row's scale leaves with the epilogue): two mixed-precision instructions per element;
 //   * bias is added in the epilogue (the accumulator is in scaled units): y = acc / (scale_w scale_row) + b, one fused multiply-add.
 // Error of a product against float32: the dropped h1 h1' term and the pieces' rounding, <= 2^-21 of |w| |x| per term (the same
 // arithmetic as the Atari encoder's h2 kernels); parity tests as for mlp_sig.h.  SRL_MLP_F16=0: the float32 kernels (A/B).
